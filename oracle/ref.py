@@ -1,0 +1,106 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes view of ``oracle/_ref/libsmcpp_ref.so`` (the real reference sources
+compiled where they lie under /root/reference by ``oracle/Makefile``; see ``ref_harness.cpp``).
+
+Never imported by the product (``smcpp_amd/``).  Used (a) to pin the C restatement ``hmm_oracle.c``, (b) to emit
+the golden vectors under ``tests/golden/`` and (c) as the ``cpu_baseline`` of ``bench.py`` (kind "reference").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_ref", "libsmcpp_ref.so")
+_lib = None
+
+
+def available() -> bool:
+    return os.path.exists(_LIB_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        # libgmpxx lives only under /opt/conda/lib; load it by absolute path (no rpath: conda's libstdc++ is older
+        # than the system one this process already uses)
+        for dep in ("/opt/conda/lib/libgmpxx.so.4",):
+            if os.path.exists(dep):
+                C.CDLL(dep, mode=C.RTLD_GLOBAL)
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.ref_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def estep(pi, T, keys, E, obs, save_gamma=False, want_alpha=False, eig_key=-1):
+    """Reference ``HMM::Estep`` on one contig with raw parameters. Returns a dict."""
+    L_ = lib()
+    pi = np.ascontiguousarray(pi, dtype=np.float64)
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    keys = np.ascontiguousarray(keys, dtype=np.int32)
+    E = np.ascontiguousarray(E, dtype=np.float64)
+    obs = np.ascontiguousarray(obs, dtype=np.int32)
+    M = pi.shape[0]
+    K, keylen = keys.shape
+    L = obs.shape[0]
+    assert obs.shape[1] == 1 + keylen and E.shape == (K, M) and T.shape == (M, M)
+    loglik = np.zeros(1)
+    xisum = np.zeros((M, M))
+    gamma = np.zeros((M, L + 1 if save_gamma else 1))
+    gs_n = np.zeros(1, dtype=np.int32)
+    gs_keys = np.zeros((K, keylen), dtype=np.int32)
+    gs_vals = np.zeros((K, M))
+    alpha = np.zeros((L + 1, M), dtype=np.float32) if want_alpha else None
+    log_c = np.zeros(L + 1) if want_alpha else None
+    q = np.zeros(4)
+    eP = np.zeros((M, M)) if eig_key >= 0 else None
+    ePi = np.zeros((M, M)) if eig_key >= 0 else None
+    ed = np.zeros(M) if eig_key >= 0 else None
+    esc = np.zeros(1) if eig_key >= 0 else None
+    eim = np.zeros(1) if eig_key >= 0 else None
+    rc = L_.ref_estep(M, K, keylen, _p(keys, C.c_int), _p(E, C.c_double), _p(pi, C.c_double), _p(T, C.c_double),
+                      L, _p(obs, C.c_int), int(save_gamma), _p(loglik, C.c_double), _p(xisum, C.c_double),
+                      _p(gamma, C.c_double), _p(gs_n, C.c_int), _p(gs_keys, C.c_int), _p(gs_vals, C.c_double),
+                      _p(alpha, C.c_float), _p(log_c, C.c_double), _p(q, C.c_double),
+                      int(eig_key), _p(eP, C.c_double), _p(ePi, C.c_double), _p(ed, C.c_double),
+                      _p(esc, C.c_double), _p(eim, C.c_double))
+    if rc != 0:
+        raise RuntimeError(L_.ref_last_error().decode())
+    n = int(gs_n[0])
+    out = dict(loglik=float(loglik[0]), xisum=xisum, gamma=gamma, q=q,
+               gamma_sums={tuple(int(x) for x in gs_keys[i]): gs_vals[i].copy() for i in range(n)})
+    if want_alpha:
+        out["alpha_hat"] = alpha
+        out["log_c"] = log_c
+    if eig_key >= 0:
+        out["eig"] = dict(P=eP, Pinv=ePi, d=ed, scale=float(esc[0]), max_imag=float(eim[0]))
+    return out
+
+
+def prep(a, s, hs, rho, theta, n=-1, raw=False):
+    """Reference pi / transition / average coalescence times / conditioned SFS (after ``incorporate_theta``)."""
+    L_ = lib()
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    hs = np.ascontiguousarray(hs, dtype=np.float64)
+    M = len(hs) - 1
+    pi = np.zeros(M)
+    T = np.zeros((M, M))
+    ct = np.zeros(M)
+    csfs = np.zeros((M, 3, n + 1)) if n >= 0 else None
+    rawc = np.zeros((M, 3, n + 1)) if (n >= 0 and raw) else None
+    rc = L_.ref_prep(len(a), _p(a, C.c_double), _p(s, C.c_double), M, _p(hs, C.c_double),
+                     C.c_double(rho), C.c_double(theta), int(n),
+                     _p(pi, C.c_double), _p(T, C.c_double), _p(ct, C.c_double), _p(csfs, C.c_double),
+                     _p(rawc, C.c_double))
+    if rc != 0:
+        raise RuntimeError(L_.ref_last_error().decode())
+    out = dict(pi=pi, T=T, avg_ct=ct, csfs=csfs)
+    if raw:
+        out["raw_csfs"] = rawc
+    return out

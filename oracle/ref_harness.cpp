@@ -1,0 +1,229 @@
+// TEST INFRASTRUCTURE ONLY — never linked into the product (smcpp_amd/).
+//
+// C-ABI harness around the REAL reference sources, compiled where they lie
+// under /root/reference (see oracle/Makefile; outputs go to oracle/_ref/).
+// It drives the reference's own
+//   HMM::HMM / HMM::Estep / HMM::Q           (src/hmm.cpp:8-193)
+//   TransitionBundle::update                 (src/transition_bundle.cpp:3-61)
+//   compute_transition                       (src/transition.cpp:256-262)
+//   PiecewiseConstantRateFunction::R / average_coal_times
+//                                            (src/piecewise_constant_rate_function.cpp:372-420)
+//   OnePopConditionedSFS::compute, incorporate_theta
+//                                            (src/conditioned_sfs.cpp:86-148)
+// directly, bypassing InferenceManager (whose translation unit needs GSL, which
+// this image does not have — so inference_manager.cpp / jcsfs.cpp are NOT built
+// and nothing is stubbed).  The only thing this file adds is glue: building
+// the InferenceBundle the reference's InferenceManager ctor would build
+// (inference_manager.cpp:21-54,232-254) and copying private HMM state out.
+//
+// `#define private public` is confined to the include of hmm.h in this TU so the harness can read
+// HMM::alpha_hat / log_c / xisum / gamma / gamma_sums (hmm.h:29-37).
+
+#include <vector>
+#include <map>
+#include <set>
+#include <cstring>
+#include <string>
+#include <stdexcept>
+
+#include "common.h"
+#include "block_key.h"
+#include "transition_bundle.h"
+#include "inference_bundle.h"
+// every header hmm.h pulls in is already included above, so the macro only touches class HMM
+#define private public
+#include "hmm.h"
+#undef private
+#include "piecewise_constant_rate_function.h"
+#include "transition.h"
+#include "conditioned_sfs.h"
+
+static thread_local std::string g_err;
+
+static block_key make_key(const int *p, int keylen)
+{
+    Vector<int> v(keylen);
+    for (int i = 0; i < keylen; ++i) v(i) = p[i];
+    return block_key(v);
+}
+
+extern "C" const char *ref_last_error() { return g_err.c_str(); }
+
+// One contig, raw parameters in, every E-step product out.
+//   keys  [K x keylen] int, E [K x M] double (emission vector per key)
+//   pi [M], T [M x M] row-major
+//   obs [L x (1+keylen)] int32 row-major (reference layout, inference_manager.cpp:180-188)
+// Outputs (any pointer may be NULL):
+//   loglik[1]; xisum [M x M] row-major; gamma [M x (L+1)] row-major if save_gamma else [M];
+//   gs_nkeys[1], gs_keys [<=K x keylen], gs_vals [<=K x M]   (std::map order)
+//   alpha_hat [(L+1) x M] float (column ell of the reference matrix = row ell here)
+//   log_c [L+1]; q [4] (values of HMM::Q, hmm.cpp:155-193)
+//   eig_* : eigensystem of key index eig_key (if >= 0): P_r, Pinv_r [M x M row-major], d_r [M], scale[1], max |imag|[1]
+extern "C" int ref_estep(int M, int K, int keylen, const int *keys, const double *E,
+                         const double *pi_in, const double *T_in,
+                         int L, const int *obs_in, int save_gamma,
+                         double *loglik, double *xisum, double *gamma,
+                         int *gs_nkeys, int *gs_keys, double *gs_vals,
+                         float *alpha_hat, double *log_c, double *q,
+                         int eig_key, double *eig_P, double *eig_Pinv, double *eig_d,
+                         double *eig_scale, double *eig_maximag)
+{
+    try
+    {
+        Vector<adouble> pi(M);
+        for (int m = 0; m < M; ++m) pi(m) = adouble(pi_in[m]);
+        Matrix<adouble> T(M, M);
+        for (int i = 0; i < M; ++i)
+            for (int j = 0; j < M; ++j)
+                T(i, j) = adouble(T_in[i * M + j]);
+        std::map<block_key, Vector<adouble> > emission_probs;
+        for (int k = 0; k < K; ++k)
+        {
+            Vector<adouble> e(M);
+            for (int m = 0; m < M; ++m) e(m) = adouble(E[k * M + m]);
+            emission_probs.emplace(make_key(keys + k * keylen, keylen), e);
+        }
+        const int ncol = 1 + keylen;
+        // obs is declared non-const in the reference's Map type; it is never written.
+        Eigen::Map<Eigen::Matrix<int, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> > obs(
+            const_cast<int *>(obs_in), L, ncol);
+        // InferenceManager::fill_targets (inference_manager.cpp:232-254)
+        spp::sparse_hash_set<std::pair<int, block_key> > targets;
+        for (int i = 0; i < L; ++i)
+        {
+            if (obs(i, 0) <= 0) throw std::runtime_error("data are malformed: span <= 0");
+            if (obs(i, 0) > 1) targets.insert({obs(i, 0), make_key(obs_in + i * ncol + 1, keylen)});
+        }
+        TransitionBundle tb(targets, &emission_probs);
+        bool sg = save_gamma != 0;
+        InferenceBundle ib{&pi, &tb, &emission_probs, &sg};
+        HMM hmm(0, obs, &ib);
+        tb.update(T, true);   // InferenceManager::Estep (inference_manager.cpp:108-114)
+        hmm.Estep(false);
+        if (loglik) *loglik = hmm.loglik();
+        if (xisum)
+            for (int i = 0; i < M; ++i)
+                for (int j = 0; j < M; ++j) xisum[i * M + j] = hmm.xisum(i, j);
+        if (gamma)
+        {
+            const int nc = hmm.gamma.cols();
+            for (int i = 0; i < M; ++i)
+                for (int j = 0; j < nc; ++j) gamma[(size_t)i * nc + j] = hmm.gamma(i, j);
+        }
+        if (gs_nkeys)
+        {
+            int n = 0;
+            for (auto &p : hmm.gamma_sums)
+            {
+                if (gs_keys) for (int i = 0; i < keylen; ++i) gs_keys[n * keylen + i] = p.first(i);
+                if (gs_vals) for (int m = 0; m < M; ++m) gs_vals[n * M + m] = p.second(m);
+                ++n;
+            }
+            *gs_nkeys = n;
+        }
+        if (alpha_hat)
+            for (int l = 0; l <= L; ++l)
+                for (int m = 0; m < M; ++m) alpha_hat[(size_t)l * M + m] = hmm.alpha_hat(m, l);
+        if (log_c)
+            for (int l = 0; l <= L; ++l) log_c[l] = hmm.log_c(l);
+        if (q)
+        {
+            Vector<adouble> qq = hmm.Q();
+            for (int i = 0; i < 4; ++i) q[i] = qq(i).value();
+        }
+        if (eig_key >= 0)
+        {
+            block_key bk = make_key(keys + eig_key * keylen, keylen);
+            auto it = tb.eigensystems.find(bk);
+            if (it == tb.eigensystems.end()) throw std::runtime_error("no eigensystem for requested key");
+            const eigensystem &es = it->second;
+            for (int i = 0; i < M; ++i)
+                for (int j = 0; j < M; ++j)
+                {
+                    if (eig_P) eig_P[i * M + j] = es.P_r(i, j);
+                    if (eig_Pinv) eig_Pinv[i * M + j] = es.Pinv_r(i, j);
+                }
+            if (eig_d) for (int i = 0; i < M; ++i) eig_d[i] = es.d_r(i);
+            if (eig_scale) *eig_scale = es.scale;
+            if (eig_maximag) *eig_maximag = es.d.imag().cwiseAbs().maxCoeff();
+        }
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_err = e.what();
+        return 1;
+    }
+}
+
+static ParameterVector make_params(int K, const double *a, const double *s)
+{
+    // mirrors _smcpp.pyx:66-83 make_params with an empty derivative list
+    std::vector<adouble> av, sv;
+    for (int k = 0; k < K; ++k) { av.push_back(adouble(a[k])); sv.push_back(adouble(s[k])); }
+    return {av, sv};
+}
+
+// Parameter preparation with the reference's own code.
+//   a[Kp], s[Kp]: piecewise-constant size history; hs[M+1] hidden-state boundaries.
+// Outputs: pi [M] (inference_manager.cpp:56-69 restated around the reference's eta->R),
+//          T [M x M] row-major (transition.cpp:256), avg_ct [M],
+//          csfs [M x 3 x (n+1)] after incorporate_theta (conditioned_sfs.cpp:100-148) when n >= 0.
+extern "C" int ref_prep(int Kp, const double *a, const double *s, int M, const double *hs,
+                        double rho, double theta, int n,
+                        double *pi_out, double *T_out, double *avg_ct_out, double *csfs_out,
+                        double *raw_csfs_out)
+{
+    try
+    {
+        ParameterVector params = make_params(Kp, a, s);
+        std::vector<double> hidden_states(hs, hs + M + 1);
+        PiecewiseConstantRateFunction<adouble> eta(params, hidden_states);
+        if (pi_out)
+        {
+            Vector<adouble> pi(M);
+            for (int m = 0; m < M - 1; ++m)
+                pi(m) = exp(-(eta.R(hidden_states.at(m)))) - exp(-(eta.R(hidden_states.at(m + 1))));
+            pi(M - 1) = exp(-(eta.R(hidden_states.at(M - 1))));
+            adouble small = eta.zero() + 1e-20;
+            pi = pi.unaryExpr([small](const adouble &x) { if (x < 1e-20) return small; return x; });
+            pi /= pi.sum();
+            for (int m = 0; m < M; ++m) pi_out[m] = pi(m).value();
+        }
+        if (T_out)
+        {
+            Matrix<adouble> T = compute_transition(eta, rho);
+            for (int i = 0; i < M; ++i)
+                for (int j = 0; j < M; ++j) T_out[i * M + j] = T(i, j).value();
+        }
+        if (avg_ct_out)
+        {
+            std::vector<adouble> v = eta.average_coal_times();
+            for (int m = 0; m < M; ++m) avg_ct_out[m] = v.at(m).value();
+        }
+        if ((csfs_out || raw_csfs_out) && n >= 0)
+        {
+            OnePopConditionedSFS<adouble> csfs(n);
+            std::vector<Matrix<adouble> > raw = csfs.compute(eta);
+            if (raw_csfs_out)
+                for (int m = 0; m < M; ++m)
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j <= n; ++j)
+                            raw_csfs_out[(m * 3 + i) * (n + 1) + j] = raw.at(m)(i, j).value();
+            if (csfs_out)
+            {
+                std::vector<Matrix<adouble> > v = incorporate_theta(raw, theta);
+                for (int m = 0; m < M; ++m)
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j <= n; ++j)
+                            csfs_out[(m * 3 + i) * (n + 1) + j] = v.at(m)(i, j).value();
+            }
+        }
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_err = e.what();
+        return 1;
+    }
+}

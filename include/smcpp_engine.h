@@ -1,0 +1,138 @@
+/* smcpp_engine.h — C ABI of the MI355X-native SMC++ E-step engine (libsmcpp_engine.so).
+ *
+ * This is the drop-in boundary for the reference's Cython binding (smcpp/_smcpp.pyx + _smcpp.pxd): every entry
+ * point below replaces one member of the C++ classes that `_smcpp.pxd:41-70` declares to Cython.  Opaque handle,
+ * plain pointers and sizes, int status (0 = ok, nonzero = error with smcpp_last_error() holding the what()-string
+ * the reference would have thrown as std::runtime_error -> Python RuntimeError, `_smcpp.pxd:43-52`).
+ *
+ * Matrix arguments are C-contiguous row-major doubles unless stated otherwise (the layout `store_matrix`,
+ * src/common.cpp:8-11, hands to numpy).  Observation arrays are int32 [L x (1+3P)] rows (span, (a,b,nb) x P),
+ * exactly what `InferenceManager::map_obs` (src/inference_manager.cpp:180-188) maps; they are copied to the
+ * device at construction and need not outlive the call.
+ *
+ * Thread safety: an instance is used from one host thread at a time (as in the reference);
+ * different instances are independent.  Every call may be made with the Python GIL released.
+ */
+#ifndef SMCPP_ENGINE_H
+#define SMCPP_ENGINE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smcpp_im smcpp_im;
+
+/* Thread-local message of the last failing call on this thread. */
+const char *smcpp_last_error(void);
+
+/* ---- construction / destruction -------------------------------------------------------------------------- */
+
+/* OnePopInferenceManager(n, obs_lengths, observations, hidden_states, polarization_error)
+ * include/inference_manager.h:130-139, src/inference_manager.cpp:506-516; bound at _smcpp.pyx:312-320.
+ * hs has n_hs = M+1 ascending entries (last may be +inf).  device < 0 selects the current HIP device. */
+int smcpp_create_onepop(int n, int n_contigs, const int *Ls, const int *const *obs,
+                        int n_hs, const double *hs, double polarization_error, int device, smcpp_im **out);
+
+/* TwoPopInferenceManager(n1, n2, a1, a2, ...)  include/inference_manager.h:141-157,
+ * src/inference_manager.cpp:518-540; bound at _smcpp.pyx:338-351.  Requires a1 + a2 == 2 and (a1,a2) != (0,2). */
+int smcpp_create_twopop(int n1, int n2, int a1, int a2, int n_contigs, const int *Ls, const int *const *obs,
+                        int n_hs, const double *hs, double polarization_error, int device, smcpp_im **out);
+
+/* delete im  (_smcpp.pyx:154-155) */
+void smcpp_destroy(smcpp_im *im);
+
+/* ---- parameters ----------------------------------------------------------------------------------------- */
+
+/* InferenceManager::setTheta / setRho / setAlpha  (src/inference_manager.cpp:71-87): mark dirty only. */
+int smcpp_set_theta(smcpp_im *im, double theta);
+int smcpp_set_rho(smcpp_im *im, double rho);
+int smcpp_set_alpha(smcpp_im *im, double alpha);
+
+/* InferenceManager::setParams(ParameterVector)  (src/inference_manager.cpp:256-260, _smcpp.pyx:66-83,327-332).
+ * a[K] piece sizes, s[K] piece lengths; da[K x nder] forward-mode derivative seeds of a (may be NULL, nder = 0). */
+int smcpp_set_params(smcpp_im *im, int K, const double *a, const double *da, int nder, const double *s);
+
+/* Raw-parameter entry (extension, SURVEY.md §7 design note): hand the engine the products of the cold host
+ * preparation directly — pi[M], T[M x M], and one emission vector per key (keys [K x 3P] int32, E [K x M]).
+ * Every key that occurs in the observations must be present.  Replaces, for one E-step, what
+ * do_dirty_work() (src/inference_manager.cpp:213-229) would have recomputed. */
+int smcpp_set_raw(smcpp_im *im, const double *pi, const double *T, int K, const int *keys, const double *E);
+
+/* ---- the hot path --------------------------------------------------------------------------------------- */
+
+/* InferenceManager::Estep(bool)  (src/inference_manager.cpp:108-114 -> HMM::Estep, src/hmm.cpp:45-153). */
+int smcpp_estep(smcpp_im *im, int forward_backward_only);
+
+/* InferenceManager::loglik()  (src/inference_manager.cpp:174-177): one value per contig. */
+int smcpp_loglik(smcpp_im *im, double *out);
+
+/* InferenceManager::Q()  (src/inference_manager.cpp:116-126 -> HMM::Q, src/hmm.cpp:155-193): the four terms
+ * summed over contigs; jac [4 x nder] may be NULL. */
+int smcpp_q(smcpp_im *im, double val[4], double *jac);
+
+/* ---- state / getters (all copy out) -------------------------------------------------------------------------- */
+
+int smcpp_set_save_gamma(smcpp_im *im, int on);          /* InferenceManager::saveGamma, _smcpp.pyx:201-205 */
+int smcpp_get_save_gamma(smcpp_im *im);
+int smcpp_num_states(smcpp_im *im);                      /* M = n_hs - 1 */
+int smcpp_num_contigs(smcpp_im *im);
+int smcpp_num_keys(smcpp_im *im);                        /* distinct block_keys over all contigs */
+int smcpp_key_len(smcpp_im *im);                         /* 3P */
+int smcpp_get_hidden_states(smcpp_im *im, double *hs);   /* _smcpp.pyx:207-213 */
+int smcpp_set_hidden_states(smcpp_im *im, int n_hs, const double *hs);
+int smcpp_get_keys(smcpp_im *im, int *keys);             /* [K x 3P], lexicographic (block_key.h:47-56) */
+
+int smcpp_get_xisum(smcpp_im *im, int contig, double *out);        /* getXisums(): [M x M]   */
+/* getGammas(): [M x (L+1)] row-major if save_gamma was set for the last E-step, else [M x 1] */
+int smcpp_get_gamma(smcpp_im *im, int contig, double *out);
+/* getGammaSums(): vals [K x M]; present[K] = 1 where the reference's std::map would hold the key */
+int smcpp_get_gamma_sums(smcpp_im *im, int contig, double *vals, unsigned char *present);
+int smcpp_get_pi(smcpp_im *im, double *out);                       /* getPi(): [M]           */
+int smcpp_get_transition(smcpp_im *im, double *out);               /* getTransition(): [M x M] */
+int smcpp_get_emission_probs(smcpp_im *im, double *out);           /* getEmissionProbs(): [K x M] */
+/* posterior decoding indices: argmax_m gamma[m, ell] for ell = 0..L (needs save_gamma) */
+int smcpp_get_gamma_argmax(smcpp_im *im, int contig, int *out);
+
+/* ---- multi-GPU ----------------------------------------------------------------------- */
+
+/* Key dictionary shared by every rank (union of the ranks' smcpp_get_keys lists, lexicographic): fixes the layout
+ * of the gamma_sums block of the packed buffer. */
+int smcpp_set_global_keys(smcpp_im *im, int Kg, const int *gkeys);
+
+/* Packed sufficient statistics of this rank's contigs, ready for one all-reduce(sum, fp64):
+ * [ sum loglik | gamma0 (M) | xisum (M*M) | gamma_sums dense (K*M) ].  Returns the length via n_out when
+ * buf == NULL.  dev != 0: buf is a device pointer (filled on the engine's stream) else a host pointer. */
+int smcpp_pack_stats(smcpp_im *im, double *buf, long *n_out, int dev);
+/* Hand the all-reduced buffer back; Q() then evaluates on the global statistics. */
+int smcpp_unpack_stats(smcpp_im *im, const double *buf, long n, int dev);
+
+/* ---- engine controls (no reference counterpart) ---------------------------------------------------------- */
+
+/* Rows per chunk of the chunk-parallel chains (0 = automatic) and the chunk-boundary convergence tolerances. */
+int smcpp_set_chunking(smcpp_im *im, int rows_per_chunk, double eps_alpha, double eps_beta);
+/* Kernel-time breakdown of the last E-step in milliseconds:
+ * [host_prep, upload, forward, backward, stats, finalize, total_device, fwd_passes, bwd_passes] */
+int smcpp_last_timing(smcpp_im *im, double out[9]);
+/* The HIP stream the engine launches on (a hipStream_t), for event timing by the caller. */
+void *smcpp_stream(smcpp_im *im);
+
+/* openmp.omp_set_num_threads (_smcpp.pyx:61-64): threads of the host-side preparation. */
+void smcpp_set_num_threads(int k);
+
+/* ---- host-only helpers (no device needed; used by the CPU test-suite) ------------------------------------ */
+
+/* eigensystem(EigenSolver(A)) as TransitionBundle::update uses it (src/transition_bundle.cpp:22,
+ * include/transition_bundle.h:9-30): P_r, Pinv_r [n x n], d_r [n], scale = max |d|, max |imag d|. */
+int smcpp_host_eigensystem(int n, const double *A, double *P, double *Pinv, double *d, double *scale,
+                           double *max_imag);
+
+/* One-population cold preparation without an engine instance:
+ * model pieces (a, s)[Kp] + hidden states -> pi [M], T [M x M], E [K x M] for the given keys [K x 3]. */
+int smcpp_host_prep_onepop(int n, int n_hs, const double *hs, double polarization_error, int Kp, const double *a,
+                           const double *s, double theta, double rho, double alpha, int K, const int *keys,
+                           double *pi, double *T, double *E);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,90 @@
+"""ctypes binding of the C ABI declared in ``include/smcpp_engine.h`` (``libsmcpp_engine.so``).
+
+This is the binding a maintainer of the reference would write in ``_smcpp.pyx`` against the C ABI (see
+INTEGRATION.md); here it is plain ctypes so the package needs no Cython build step."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def lib():
+    """Load the engine library.  Fails loudly if it has not been built (there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+            "The SMC++ MI355X engine has no CPU fallback.")
+    L = C.CDLL(path)
+    L.smcpp_last_error.restype = C.c_char_p
+    L.smcpp_stream.restype = C.c_void_p
+    L.smcpp_stream.argtypes = [C.c_void_p]
+    L.smcpp_destroy.argtypes = [C.c_void_p]
+    L.smcpp_destroy.restype = None
+    for name in ("smcpp_set_theta", "smcpp_set_rho", "smcpp_set_alpha"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_double]
+    L.smcpp_set_chunking.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+    L.smcpp_host_prep_onepop.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_int, _dp, _dp, C.c_double,
+                                         C.c_double, C.c_double, C.c_int, _ip, _dp, _dp, _dp]
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    "smcpp_last_error", "smcpp_create_onepop", "smcpp_create_twopop", "smcpp_destroy", "smcpp_set_theta",
+    "smcpp_set_rho", "smcpp_set_alpha", "smcpp_set_params", "smcpp_set_raw", "smcpp_estep", "smcpp_loglik",
+    "smcpp_q", "smcpp_set_save_gamma", "smcpp_get_save_gamma", "smcpp_num_states", "smcpp_num_contigs",
+    "smcpp_num_keys", "smcpp_key_len", "smcpp_get_hidden_states", "smcpp_set_hidden_states", "smcpp_get_keys",
+    "smcpp_get_xisum", "smcpp_get_gamma", "smcpp_get_gamma_sums", "smcpp_get_pi", "smcpp_get_transition",
+    "smcpp_get_emission_probs", "smcpp_get_gamma_argmax", "smcpp_set_global_keys", "smcpp_pack_stats",
+    "smcpp_unpack_stats", "smcpp_set_chunking", "smcpp_last_timing", "smcpp_stream", "smcpp_set_num_threads",
+    "smcpp_host_eigensystem", "smcpp_host_prep_onepop",
+]
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError(lib().smcpp_last_error().decode())
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def host_eigensystem(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = A.shape[0]
+    P = np.zeros((n, n)); Pinv = np.zeros((n, n)); d = np.zeros(n)
+    sc = C.c_double(0); mi = C.c_double(0)
+    check(lib().smcpp_host_eigensystem(n, dptr(A), dptr(P), dptr(Pinv), dptr(d), C.byref(sc), C.byref(mi)))
+    return P, Pinv, d, sc.value, mi.value
+
+
+def host_prep_onepop(n, hs, polarization_error, a, s, theta, rho, alpha, keys):
+    hs = np.ascontiguousarray(hs, dtype=np.float64)
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    keys = np.ascontiguousarray(keys, dtype=np.int32)
+    M = len(hs) - 1
+    K = len(keys)
+    pi = np.zeros(M); T = np.zeros((M, M)); E = np.zeros((K, M))
+    check(lib().smcpp_host_prep_onepop(int(n), len(hs), dptr(hs), float(polarization_error), len(a), dptr(a), dptr(s),
+                                       float(theta), float(rho), float(alpha), K, iptr(keys), dptr(pi), dptr(T),
+                                       dptr(E)))
+    return pi, T, E

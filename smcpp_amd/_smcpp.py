@@ -1,0 +1,290 @@
+"""Host-side mirror of the reference's ``smcpp._smcpp`` module surface for the E-step path.
+
+Same class names, constructor signatures, properties and error behaviour as ``smcpp/_smcpp.pyx``
+(``_PyInferenceManager`` 122-308, ``PyOnePopInferenceManager`` 310-332, ``PyTwoPopInferenceManager`` 334-368),
+implemented over the C ABI of ``include/smcpp_engine.h``.  The compute runs in HIP kernels on the MI355X;
+nothing here falls back to a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _engine as E
+
+aca = np.ascontiguousarray
+
+
+def set_num_threads(k):
+    """``_smcpp.pyx:61-64``."""
+    E.lib().smcpp_set_num_threads(int(k))
+
+
+class _PyInferenceManager:
+    def _my_init(self, observations, hidden_states, im_id=None):
+        self._im = None
+        self._im_id = im_id
+        self.seed = 1
+        if len(observations) == 0:
+            raise RuntimeError("Observations list is empty")
+        hidden_states = np.asarray(hidden_states, dtype=np.float64)
+        if not np.all(np.sort(hidden_states) == hidden_states):
+            raise RuntimeError("Hidden states must be in ascending order")
+        self._observations = [aca(ob, dtype=np.int32) for ob in observations]
+        self._Ls = np.array([ob.shape[0] for ob in self._observations], dtype=np.int32)
+        self._hs = aca(hidden_states)
+        self._num_hmms = len(observations)
+        self._model = None
+        self._theta = self._rho = self._alpha = None
+
+    def _ptrs(self):
+        arr = (C.POINTER(C.c_int) * self._num_hmms)()
+        for i, ob in enumerate(self._observations):
+            arr[i] = ob.ctypes.data_as(C.POINTER(C.c_int))
+        return arr
+
+    def __del__(self):
+        im = getattr(self, "_im", None)
+        if im:
+            E.lib().smcpp_destroy(im)
+            self._im = None
+
+    # ---- properties mirrored from _smcpp.pyx:157-183 ----
+    @property
+    def observations(self):
+        return self._observations
+
+    @property
+    def theta(self):
+        return self._theta
+
+    @theta.setter
+    def theta(self, v):
+        self._theta = v
+        E.check(E.lib().smcpp_set_theta(self._im, float(v)))
+
+    @property
+    def rho(self):
+        return self._rho
+
+    @rho.setter
+    def rho(self, v):
+        self._rho = v
+        E.check(E.lib().smcpp_set_rho(self._im, float(v)))
+
+    @property
+    def alpha(self):
+        return self._alpha
+
+    @alpha.setter
+    def alpha(self, v):
+        self._alpha = v
+        E.check(E.lib().smcpp_set_alpha(self._im, float(v)))
+
+    def E_step(self, forward_backward_only=False):
+        """``_smcpp.pyx:185-191``."""
+        if None in (self.theta, self.rho, self.alpha):
+            raise RuntimeError("theta / rho / alpha must be set")
+        E.check(E.lib().smcpp_estep(self._im, int(bool(forward_backward_only))))
+
+    @property
+    def model(self):
+        return self._model
+
+    @model.setter
+    def model(self, m):
+        self._model = m
+        if hasattr(m, "register"):
+            m.register(self)
+        self.update("model update")
+
+    @property
+    def save_gamma(self):
+        return bool(E.lib().smcpp_get_save_gamma(self._im))
+
+    @save_gamma.setter
+    def save_gamma(self, sg):
+        E.check(E.lib().smcpp_set_save_gamma(self._im, int(bool(sg))))
+
+    @property
+    def hidden_states(self):
+        hs = np.zeros(len(self._hs))
+        E.check(E.lib().smcpp_get_hidden_states(self._im, E.dptr(hs)))
+        return list(hs)
+
+    @hidden_states.setter
+    def hidden_states(self, hs):
+        hs = aca(hs, dtype=np.float64)
+        if len(hs) != len(self._hs):
+            raise RuntimeError("hidden states must be same size")
+        E.check(E.lib().smcpp_set_hidden_states(self._im, len(hs), E.dptr(hs)))
+
+    @property
+    def M(self):
+        return len(self._hs) - 1
+
+    @property
+    def keys(self):
+        K = E.lib().smcpp_num_keys(self._im)
+        kl = E.lib().smcpp_key_len(self._im)
+        k = np.zeros((K, kl), dtype=np.int32)
+        E.check(E.lib().smcpp_get_keys(self._im, E.iptr(k)))
+        return k
+
+    @property
+    def emission_probs(self):
+        keys = self.keys
+        out = np.zeros((len(keys), self.M))
+        E.check(E.lib().smcpp_get_emission_probs(self._im, E.dptr(out)))
+        return {tuple(int(x) for x in k): out[i].copy() for i, k in enumerate(keys)}
+
+    @property
+    def gamma_sums(self):
+        keys = self.keys
+        ret = []
+        for c in range(self._num_hmms):
+            vals = np.zeros((len(keys), self.M))
+            present = np.zeros(len(keys), dtype=np.uint8)
+            E.check(E.lib().smcpp_get_gamma_sums(self._im, c, E.dptr(vals),
+                                                 present.ctypes.data_as(C.POINTER(C.c_ubyte))))
+            ret.append({tuple(int(x) for x in keys[k]): vals[k].copy() for k in range(len(keys)) if present[k]})
+        return ret
+
+    @property
+    def gammas(self):
+        ret = []
+        for c in range(self._num_hmms):
+            ncol = int(self._Ls[c]) + 1 if self.save_gamma else 1
+            g = np.zeros((self.M, ncol))
+            E.check(E.lib().smcpp_get_gamma(self._im, c, E.dptr(g)))
+            ret.append(g)
+        return ret
+
+    def gamma_argmax(self, c=0):
+        out = np.zeros(int(self._Ls[c]) + 1, dtype=np.int32)
+        E.check(E.lib().smcpp_get_gamma_argmax(self._im, c, E.iptr(out)))
+        return out
+
+    @property
+    def xisums(self):
+        ret = []
+        for c in range(self._num_hmms):
+            x = np.zeros((self.M, self.M))
+            E.check(E.lib().smcpp_get_xisum(self._im, c, E.dptr(x)))
+            ret.append(x)
+        return ret
+
+    @property
+    def pi(self):
+        out = np.zeros(self.M)
+        E.check(E.lib().smcpp_get_pi(self._im, E.dptr(out)))
+        return out
+
+    @property
+    def transition(self):
+        out = np.zeros((self.M, self.M))
+        E.check(E.lib().smcpp_get_transition(self._im, E.dptr(out)))
+        return out
+
+    def Q(self, separate=False):
+        """``_smcpp.pyx:277-301`` (values; derivative seeds are the M-step path, not built yet)."""
+        q = np.zeros(4)
+        E.check(E.lib().smcpp_q(self._im, E.dptr(q), None))
+        if separate:
+            return list(q)
+        return float(q.sum())
+
+    def loglik(self):
+        """``_smcpp.pyx:303-308``: sum over contigs."""
+        return float(sum(self.logliks()))
+
+    def logliks(self):
+        out = np.zeros(self._num_hmms)
+        E.check(E.lib().smcpp_loglik(self._im, E.dptr(out)))
+        return out
+
+    # ---- engine extensions ----
+    def set_raw(self, pi, T, keys, Etab):
+        pi = aca(pi, dtype=np.float64); T = aca(T, dtype=np.float64)
+        keys = aca(keys, dtype=np.int32); Etab = aca(Etab, dtype=np.float64)
+        E.check(E.lib().smcpp_set_raw(self._im, E.dptr(pi), E.dptr(T), len(keys), E.iptr(keys), E.dptr(Etab)))
+
+    def set_chunking(self, rows_per_chunk=0, eps_alpha=0.0, eps_beta=0.0):
+        E.check(E.lib().smcpp_set_chunking(self._im, int(rows_per_chunk), float(eps_alpha), float(eps_beta)))
+
+    def last_timing(self):
+        t = np.zeros(9)
+        E.check(E.lib().smcpp_last_timing(self._im, E.dptr(t)))
+        return dict(zip(["host_prep_ms", "upload_ms", "forward_ms", "backward_ms", "stats_ms", "finalize_ms",
+                         "device_total_ms", "fwd_passes", "bwd_passes"], t))
+
+    def stream(self):
+        return E.lib().smcpp_stream(self._im)
+
+    def set_global_keys(self, gkeys):
+        gkeys = aca(gkeys, dtype=np.int32)
+        E.check(E.lib().smcpp_set_global_keys(self._im, len(gkeys), E.iptr(gkeys)))
+
+    def pack_stats(self):
+        n = C.c_long(0)
+        E.check(E.lib().smcpp_pack_stats(self._im, None, C.byref(n), 0))
+        buf = np.zeros(n.value)
+        E.check(E.lib().smcpp_pack_stats(self._im, E.dptr(buf), C.byref(n), 0))
+        return buf
+
+    def unpack_stats(self, buf):
+        buf = aca(buf, dtype=np.float64)
+        E.check(E.lib().smcpp_unpack_stats(self._im, E.dptr(buf), len(buf), 0))
+
+
+class PyOnePopInferenceManager(_PyInferenceManager):
+    """``PyOnePopInferenceManager(n, observations, hidden_states, im_id, polarization_error)`` (_smcpp.pyx:310-332)."""
+
+    def __init__(self, n, observations, hidden_states, im_id, polarization_error, device=-1):
+        self._my_init(observations, hidden_states, im_id)
+        im = C.c_void_p()
+        E.check(E.lib().smcpp_create_onepop(int(n), self._num_hmms, E.iptr(self._Ls), self._ptrs(), len(self._hs),
+                                            E.dptr(self._hs), C.c_double(polarization_error), int(device),
+                                            C.byref(im)))
+        self._im = im
+        self._n = int(n)
+        # sensible defaults (_smcpp.pyx:318-320)
+        self.alpha = 1
+        self.theta = 1e-4
+        self.rho = 1e-4
+
+    @property
+    def pid(self):
+        assert len(self._im_id) == 1
+        return self._im_id[0]
+
+    def update(self, message, *args, **kwargs):
+        m = self._model.for_pop(self.pid) if hasattr(self._model, "for_pop") else self._model
+        a = aca(np.asarray(m.stepwise_values(), dtype=np.float64))
+        s = aca(np.asarray(m.s, dtype=np.float64))
+        assert np.all(a > 0) and len(a) > 0
+        E.check(E.lib().smcpp_set_params(self._im, len(a), E.dptr(a), None, 0, E.dptr(s)))
+
+
+class PyTwoPopInferenceManager(_PyInferenceManager):
+    """``PyTwoPopInferenceManager(n1, n2, a1, a2, observations, hidden_states, im_id, polarization_error)``
+    (_smcpp.pyx:334-368).  Parameters enter through ``set_raw`` until the JointCSFS preparation is built."""
+
+    def __init__(self, n1, n2, a1, a2, observations, hidden_states, im_id, polarization_error, device=-1):
+        assert a1 + a2 == 2
+        assert a1 in [1, 2]
+        assert a2 in [0, 1]
+        self._a1 = a1
+        self._my_init(observations, hidden_states, im_id)
+        im = C.c_void_p()
+        E.check(E.lib().smcpp_create_twopop(int(n1), int(n2), int(a1), int(a2), self._num_hmms, E.iptr(self._Ls),
+                                            self._ptrs(), len(self._hs), E.dptr(self._hs),
+                                            C.c_double(polarization_error), int(device), C.byref(im)))
+        self._im = im
+        self.alpha = 1
+        self.theta = 1e-4
+        self.rho = 1e-4
+
+    def update(self, message, *args, **kwargs):
+        raise RuntimeError("two-population parameter preparation (JointCSFS) is not built yet; use set_raw")

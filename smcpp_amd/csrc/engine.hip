@@ -1,0 +1,1125 @@
+// Host orchestration + C ABI of the MI355X-native SMC++ E-step engine.
+//
+// Mirrors the reference's InferenceManager (include/inference_manager.h, src/inference_manager.cpp):
+//   ctor / map_obs / fill_targets / populate_emission_probs  -> Engine::Engine   (21-54, 180-211, 232-254)
+//   Estep                                                    -> Engine::estep    (108-114)
+//   TransitionBundle::update(T, true)                        -> Engine::host_prep (src/transition_bundle.cpp:3-61)
+//   loglik / Q / getters                                     -> smcpp_loglik / smcpp_q / smcpp_get_*  (116-177)
+// The hot path (HMM::Estep, src/hmm.cpp:45-153) runs in the HIP kernels of kernels.hpp.  There is no CPU fallback:
+// every compute entry point fails with an error if no HIP device is usable.
+#include <hip/hip_runtime.h>
+#include <omp.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/smcpp_engine.h"
+#include "kernels.hpp"
+#include "nonsym_eig.hpp"
+#include "prep.hpp"
+
+using namespace smcpp_dev;
+
+static thread_local std::string g_err;
+
+#define HIPCHK(x)                                                                                              \
+    do {                                                                                                       \
+        hipError_t e_ = (x);                                                                                   \
+        if (e_ != hipSuccess)                                                                                  \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " + __FILE__ +  \
+                                     ":" + std::to_string(__LINE__));                                          \
+    } while (0)
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        if (count <= n && p) return;
+        free();
+        n = count;
+        if (count) HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
+    }
+    void free() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void upload(const std::vector<T> &h, hipStream_t s) {
+        alloc(h.size());
+        if (!h.empty()) HIPCHK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void zero(hipStream_t s) {
+        if (n) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s));
+    }
+    ~DevBuf() { free(); }
+};
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+struct Group { int span, kid, eig; };
+
+}  // namespace
+
+struct smcpp_im {
+    // ---- static problem description -------------------------------------------------------------------------
+    int npop = 1, keylen = 3, M = 0, Mp = 0, NPL = 1, NT = 1, n_contigs = 0, K = 0, G = 0, Ke = 0;
+    int n[2] = {0, 0}, na[2] = {2, 0};
+    double polarization_error = 0.5;
+    std::vector<double> hs;
+    std::vector<int> keys;                 // [K][keylen], lexicographic
+    std::vector<int> Ls;
+    std::vector<long long> contig_base;    // row index of ell = 0 of each contig
+    long long total_rows = 0;              // sum (L+1)
+    std::vector<RowInfo> rowinfo;          // host copy
+    std::vector<Group> groups;             // sorted by (eig/kid, span)
+    std::vector<int> eig_kid;              // [Ke]
+    std::vector<int> eig_of_key;           // [K]
+    std::vector<unsigned char> present;    // [n_contigs][K] key occurs in contig
+    std::vector<unsigned char> key_nbpos;  // [K] key.nb() > 0
+    std::vector<Chunk> chunks;
+    int max_chunks_per_contig = 1;
+    int user_rows_per_chunk = 0;
+    // sorted permutations and slabs
+    std::vector<int> perm1, perme;
+    std::vector<Slab> slabs_sc, slabs_rk, slabs_eg;   // span-1 scalar slabs, span-1 rank slabs, eigen slabs
+    std::vector<int> gk_slab_off, s1_slab_off, eb_slab_off, eb_gid, ce_bucket_off, erow_slab;
+    long long n_e_rows = 0, n_1_rows = 0;
+    // ---- parameters -------------------------------------------------------------------------------------------
+    double theta = NAN, rho = NAN, alpha = 1.0;
+    bool have_raw = false, dirty = true;
+    std::vector<double> pi, T, E;          // [M], [M*M], [K*M]
+    smcpp_host::ModelParams model;         // a, s (for set_params)
+    bool have_model = false;
+    bool save_gamma = false, gamma_valid = false;
+    // ---- device -----------------------------------------------------------------------------------------------
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8];
+    DevBuf<RowInfo> d_rowinfo;
+    DevBuf<Chunk> d_chunks;
+    DevBuf<Slab> d_slabs_sc, d_slabs_rk, d_slabs_eg;
+    DevBuf<int> d_perm1, d_perme, d_gk_slab_off, d_s1_slab_off, d_eb_slab_off, d_eb_gid, d_ce_bucket_off,
+        d_erow_slab, d_g_span, d_g_eig, d_e_kid, d_contig_L, d_changed_f, d_changed_b, d_argmax;
+    DevBuf<long long> d_contig_base;
+    DevBuf<float> d_pi_f, d_Tf, d_alpha, d_ends_f, d_used_f;
+    DevBuf<double> d_E, d_dpow, d_PinvT, d_PT, d_TdT, d_Td, d_Prm, d_Pinvrm, d_dsc, d_dun, d_g_scale,
+        d_g_logscale, d_beta, d_cnorm, d_logc, d_ends_b, d_used_b, d_llpart, d_loglik, d_w1, d_gpart, d_Xs, d_Ys,
+        d_part_e, d_part_1, d_Z, d_Y, d_xisum, d_gsum, d_gamma0, d_gamma_rows, d_Sq;
+    int llblk = 64;
+    int max_pass = 0;
+    int last_fwd_passes = 0, last_bwd_passes = 0;
+    float eps_f = 2.4e-7f;
+    double eps_b = 1e-9;
+    // ---- results (host) ---------------------------------------------------------------------------------------
+    std::vector<double> loglik, h_xisum, h_gsum, h_gamma0;
+    bool stats_on_host = false;
+    double timing[9] = {0};
+    // multi-GPU
+    std::vector<int> gkeys;                // global key list [Kg][keylen]
+    std::vector<int> local_to_global;
+    bool have_global = false;
+    std::vector<double> g_stats;           // reduced [1 + M + M*M + Kg*M]
+    bool have_reduced = false;
+
+    ~smcpp_im() {
+        if (stream) {
+            for (auto &e : ev) (void)hipEventDestroy(e);
+            (void)hipStreamDestroy(stream);
+        }
+    }
+
+    void build(int npop_, const int *nn, const int *nna, int n_contigs_, const int *Ls_, const int *const *obs,
+               int n_hs, const double *hs_, double pol, int dev);
+    void make_chunks();
+    void make_slabs();
+    void alloc_device();
+    void host_prep_and_upload();
+    void run_chains();
+    void run_stats();
+    void estep();
+    void fetch_stats();
+    void prepare_params();
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// construction
+// ---------------------------------------------------------------------------------------------------------------
+void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, const int *Ls_,
+                     const int *const *obs, int n_hs, const double *hs_, double pol, int dev) {
+    npop = npop_;
+    keylen = 3 * npop;
+    for (int p = 0; p < npop; ++p) { n[p] = nn[p]; na[p] = nna[p]; }
+    polarization_error = pol;
+    if (n_contigs_ <= 0) throw std::runtime_error("Observations list is empty");
+    if (n_hs < 2) throw std::runtime_error("need at least two hidden state boundaries");
+    hs.assign(hs_, hs_ + n_hs);
+    for (int i = 1; i < n_hs; ++i)
+        if (!(hs[i] >= hs[i - 1])) throw std::runtime_error("Hidden states must be in ascending order");
+    M = n_hs - 1;
+    Mp = (M + 15) / 16 * 16;
+    NPL = (M + 63) / 64;
+    NT = Mp / 16;
+    if (M > 256) throw std::runtime_error("M > 256 hidden states is not supported by this build");
+    n_contigs = n_contigs_;
+    Ls.assign(Ls_, Ls_ + n_contigs);
+    contig_base.resize(n_contigs);
+    total_rows = 0;
+    for (int c = 0; c < n_contigs; ++c) {
+        if (Ls[c] <= 0) throw std::runtime_error("empty contig");
+        contig_base[c] = total_rows;
+        total_rows += (long long)Ls[c] + 1;
+    }
+    const int ncol = 1 + keylen;
+    // key dictionary (populate_emission_probs, inference_manager.cpp:190-211): distinct keys, lexicographic
+    std::map<std::vector<int>, int> kmap;
+    for (int c = 0; c < n_contigs; ++c) {
+        const int *ob = obs[c];
+        std::vector<int> prev;
+        for (int i = 0; i < Ls[c]; ++i) {
+            const int *r = ob + (size_t)i * ncol;
+            if (r[0] <= 0) throw std::runtime_error("data are malformed: span <= 0");
+            if (!prev.empty() && std::equal(prev.begin(), prev.end(), r + 1)) continue;
+            prev.assign(r + 1, r + ncol);
+            kmap.emplace(prev, 0);
+        }
+    }
+    K = (int)kmap.size();
+    keys.clear();
+    {
+        int id = 0;
+        for (auto &kv : kmap) { kv.second = id++; keys.insert(keys.end(), kv.first.begin(), kv.first.end()); }
+    }
+    key_nbpos.assign(K, 0);
+    for (int k = 0; k < K; ++k) {
+        int nb = 0;
+        for (int p = 0; p < npop; ++p) nb += keys[(size_t)k * keylen + 3 * p + 2];
+        key_nbpos[k] = nb > 0;
+    }
+    // rows -> (kid, span); fill_targets (inference_manager.cpp:232-254): distinct (span > 1, key) pairs
+    rowinfo.assign((size_t)total_rows, RowInfo{0, -1});
+    std::vector<int> span_of((size_t)total_rows, 1);
+    present.assign((size_t)n_contigs * K, 0);
+    std::map<std::pair<int, int>, int> gmap;   // (kid, span) -> gid
+#pragma omp parallel for schedule(dynamic)
+    for (int c = 0; c < n_contigs; ++c) {
+        const int *ob = obs[c];
+        std::vector<int> prev;
+        int prev_id = -1;
+        for (int i = 0; i < Ls[c]; ++i) {
+            const int *r = ob + (size_t)i * ncol;
+            int id;
+            if (!prev.empty() && std::equal(prev.begin(), prev.end(), r + 1)) id = prev_id;
+            else {
+                prev.assign(r + 1, r + ncol);
+                id = kmap.find(prev)->second;
+                prev_id = id;
+            }
+            const size_t g = (size_t)contig_base[c] + i + 1;
+            rowinfo[g].kid = id;
+            span_of[g] = r[0];
+            present[(size_t)c * K + id] = 1;
+        }
+    }
+    for (int c = 0; c < n_contigs; ++c)
+        for (int i = 1; i <= Ls[c]; ++i) {
+            const size_t g = (size_t)contig_base[c] + i;
+            if (span_of[g] > 1) gmap.emplace(std::make_pair(rowinfo[g].kid, span_of[g]), 0);
+        }
+    G = (int)gmap.size();
+    groups.clear();
+    eig_kid.clear();
+    eig_of_key.assign(K, -1);
+    {
+        int id = 0;
+        for (auto &kv : gmap) {
+            kv.second = id++;
+            const int kid = kv.first.first;
+            if (eig_of_key[kid] < 0) { eig_of_key[kid] = (int)eig_kid.size(); eig_kid.push_back(kid); }
+            groups.push_back(Group{kv.first.second, kid, eig_of_key[kid]});
+        }
+    }
+    Ke = (int)eig_kid.size();
+    for (int c = 0; c < n_contigs; ++c)
+        for (int i = 1; i <= Ls[c]; ++i) {
+            const size_t g = (size_t)contig_base[c] + i;
+            if (span_of[g] > 1) rowinfo[g].gid = gmap[std::make_pair(rowinfo[g].kid, span_of[g])];
+        }
+    // device
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        throw std::runtime_error("no HIP device available: the SMC++ MI355X engine has no CPU fallback");
+    if (dev >= 0) HIPCHK(hipSetDevice(dev));
+    HIPCHK(hipGetDevice(&device));
+    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    make_chunks();
+    make_slabs();
+    alloc_device();
+    // defaults after construction (_smcpp.pyx:318-320)
+    alpha = 1.0; theta = 1e-4; rho = 1e-4;
+    loglik.assign(n_contigs, 0.0);
+}
+
+void smcpp_im::make_chunks() {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    const long long slots = (long long)prop.multiProcessorCount * 4;     // one wavefront per SIMD
+    long long rows = total_rows - n_contigs;
+    int lc = user_rows_per_chunk;
+    if (lc <= 0) {
+        const char *envv = getenv("SMCPP_ROWS_PER_CHUNK");
+        if (envv) lc = atoi(envv);
+    }
+    if (lc <= 0) lc = (int)std::max<long long>(64, (rows + slots - 1) / slots);
+    chunks.clear();
+    max_chunks_per_contig = 1;
+    for (int c = 0; c < n_contigs; ++c) {
+        const int L = Ls[c];
+        const int nc = std::max(1, ceil_div(L, lc));
+        max_chunks_per_contig = std::max(max_chunks_per_contig, nc);
+        for (int j = 0; j < nc; ++j) {
+            Chunk ch;
+            ch.base = contig_base[c];
+            ch.r0 = (int)((long long)L * j / nc);
+            ch.r1 = (int)((long long)L * (j + 1) / nc);
+            ch.contig = c;
+            ch.first = (j == 0);
+            ch.last = (j == nc - 1);
+            ch.pad = 0;
+            chunks.push_back(ch);
+        }
+    }
+    max_pass = max_chunks_per_contig + 2;
+}
+
+void smcpp_im::make_slabs() {
+    // counting sorts of rows per contig
+    perm1.clear(); perme.clear();
+    slabs_sc.clear(); slabs_rk.clear(); slabs_eg.clear();
+    gk_slab_off.assign((size_t)n_contigs * K + 1, 0);
+    s1_slab_off.assign(n_contigs + 1, 0);
+    ce_bucket_off.assign((size_t)n_contigs * Ke + 1, 0);
+    eb_slab_off.clear(); eb_gid.clear(); erow_slab.clear();
+    long long n1 = 0, ne = 0;
+    for (long long r = 0; r < total_rows; ++r) {
+        // rows with ell = 0 have kid = 0, gid = -1 but are skipped below
+    }
+    for (int c = 0; c < n_contigs; ++c)
+        for (int i = 1; i <= Ls[c]; ++i) (rowinfo[(size_t)contig_base[c] + i].gid < 0 ? n1 : ne)++;
+    n_1_rows = n1; n_e_rows = ne;
+    const long long part_bytes = (long long)Mp * Mp * 8;
+    const long long target = std::max<long long>(256, std::min<long long>(2048, (64ll << 20) / part_bytes));
+    int S_RK = (int)std::max<long long>(64, (n1 + target - 1) / target);
+    S_RK = (S_RK + 3) / 4 * 4;
+    int S_EG = (int)std::max<long long>(64, (ne + target - 1) / target);
+    S_EG = (S_EG + 15) / 16 * 16;
+    const int S_SC = 512;
+    for (int c = 0; c < n_contigs; ++c) {
+        const long long base = contig_base[c];
+        // ---- span-1 rows sorted by key ----
+        std::vector<std::vector<int>> by_key(K);
+        std::vector<std::vector<int>> by_grp(G);
+        for (int i = 1; i <= Ls[c]; ++i) {
+            const RowInfo &ri = rowinfo[(size_t)base + i];
+            if (ri.gid < 0) by_key[ri.kid].push_back(i);
+            else by_grp[ri.gid].push_back(i);
+        }
+        const int seg_start = (int)perm1.size();
+        for (int k = 0; k < K; ++k) {
+            gk_slab_off[(size_t)c * K + k] = (int)slabs_sc.size();
+            const int s0 = (int)perm1.size();
+            perm1.insert(perm1.end(), by_key[k].begin(), by_key[k].end());
+            const int s1 = (int)perm1.size();
+            for (int s = s0; s < s1; s += S_SC)
+                slabs_sc.push_back(Slab{s, std::min(s + S_SC, s1), c * K + k, k, base});
+        }
+        const int seg_end = (int)perm1.size();
+        s1_slab_off[c] = (int)slabs_rk.size();
+        for (int s = seg_start; s < seg_end; s += S_RK)
+            slabs_rk.push_back(Slab{s, std::min(s + S_RK, seg_end), c, -1, base});
+        // ---- eigen rows sorted by (eigen key, group) ----
+        for (int e = 0; e < Ke; ++e) {
+            ce_bucket_off[(size_t)c * Ke + e] = (int)eb_gid.size();
+            for (int g = 0; g < G; ++g) {
+                if (groups[g].eig != e || by_grp[g].empty()) continue;
+                eb_slab_off.push_back((int)slabs_eg.size());
+                eb_gid.push_back(g);
+                const int s0 = (int)perme.size();
+                perme.insert(perme.end(), by_grp[g].begin(), by_grp[g].end());
+                const int s1 = (int)perme.size();
+                for (int s = s0; s < s1; s += S_EG) {
+                    const int se = std::min(s + S_EG, s1);
+                    for (int r = s; r < se; ++r) erow_slab.push_back((int)slabs_eg.size());
+                    slabs_eg.push_back(Slab{s, se, (int)eb_gid.size() - 1, g, base});
+                }
+            }
+        }
+    }
+    gk_slab_off[(size_t)n_contigs * K] = (int)slabs_sc.size();
+    s1_slab_off[n_contigs] = (int)slabs_rk.size();
+    ce_bucket_off[(size_t)n_contigs * Ke] = (int)eb_gid.size();
+    eb_slab_off.push_back((int)slabs_eg.size());
+}
+
+void smcpp_im::alloc_device() {
+    hipStream_t s = stream;
+    d_rowinfo.upload(rowinfo, s);
+    d_chunks.upload(chunks, s);
+    d_slabs_sc.upload(slabs_sc, s);
+    d_slabs_rk.upload(slabs_rk, s);
+    d_slabs_eg.upload(slabs_eg, s);
+    d_perm1.upload(perm1, s);
+    d_perme.upload(perme, s);
+    d_gk_slab_off.upload(gk_slab_off, s);
+    d_s1_slab_off.upload(s1_slab_off, s);
+    d_eb_slab_off.upload(eb_slab_off, s);
+    d_eb_gid.upload(eb_gid, s);
+    d_ce_bucket_off.upload(ce_bucket_off, s);
+    d_erow_slab.upload(erow_slab, s);
+    d_contig_base.upload(contig_base, s);
+    d_contig_L.upload(Ls, s);
+    std::vector<int> gs(G), ge(G);
+    for (int g = 0; g < G; ++g) { gs[g] = groups[g].span; ge[g] = groups[g].eig; }
+    d_g_span.upload(gs, s);
+    d_g_eig.upload(ge, s);
+    d_e_kid.upload(eig_kid, s);
+    const size_t nch = chunks.size();
+    d_alpha.alloc((size_t)total_rows * Mp);
+    d_beta.alloc((size_t)total_rows * Mp);
+    d_cnorm.alloc((size_t)total_rows);
+    d_logc.alloc((size_t)total_rows);
+    d_w1.alloc((size_t)total_rows);
+    d_ends_f.alloc(2 * nch * Mp);
+    d_used_f.alloc(nch * Mp);
+    d_ends_b.alloc(2 * nch * Mp);
+    d_used_b.alloc(nch * Mp);
+    d_changed_f.alloc(max_pass + 1);
+    d_changed_b.alloc(max_pass + 1);
+    d_llpart.alloc((size_t)n_contigs * llblk);
+    d_loglik.alloc(n_contigs);
+    d_gpart.alloc(std::max<size_t>(1, slabs_sc.size()) * Mp);
+    d_Xs.alloc(std::max<size_t>(1, (size_t)n_e_rows) * Mp);
+    d_Ys.alloc(std::max<size_t>(1, (size_t)n_e_rows) * Mp);
+    d_part_e.alloc(std::max<size_t>(1, slabs_eg.size()) * Mp * Mp);
+    d_part_1.alloc(std::max<size_t>(1, slabs_rk.size()) * Mp * Mp);
+    d_Z.alloc(std::max<size_t>(1, (size_t)n_contigs * Ke) * Mp * Mp);
+    d_Y.alloc(std::max<size_t>(1, (size_t)n_contigs * Ke) * Mp * Mp);
+    d_xisum.alloc((size_t)n_contigs * Mp * Mp);
+    d_gsum.alloc((size_t)n_contigs * K * Mp);
+    d_gamma0.alloc((size_t)n_contigs * Mp);
+    d_E.alloc((size_t)K * Mp);
+    d_dpow.alloc(std::max<size_t>(1, (size_t)G) * Mp);
+    d_g_scale.alloc(std::max(1, G));
+    d_g_logscale.alloc(std::max(1, G));
+    d_pi_f.alloc(Mp);
+    d_Tf.alloc((size_t)Mp * Mp);
+    d_TdT.alloc((size_t)Mp * Mp);
+    d_Td.alloc((size_t)Mp * Mp);
+    const size_t em = std::max<size_t>(1, (size_t)Ke) * Mp * Mp;
+    d_PinvT.alloc(em); d_PT.alloc(em); d_Prm.alloc(em); d_Pinvrm.alloc(em);
+    d_dsc.alloc(std::max<size_t>(1, (size_t)Ke) * Mp);
+    d_dun.alloc(std::max<size_t>(1, (size_t)Ke) * Mp);
+    // zero the row state once so padded lanes / unused rows hold finite values
+    d_alpha.zero(s); d_beta.zero(s); d_cnorm.zero(s); d_logc.zero(s); d_w1.zero(s);
+    HIPCHK(hipStreamSynchronize(s));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// parameters
+// ---------------------------------------------------------------------------------------------------------------
+void smcpp_im::prepare_params() {
+    // do_dirty_work (inference_manager.cpp:213-229) for the model-parameter path; the raw path already has pi/T/E.
+    if (have_raw) return;
+    if (!have_model) throw std::runtime_error("no model parameters: call set_params or set_raw before E_step");
+    if (npop != 1) throw std::runtime_error("two-population parameter preparation (JointCSFS) is not built yet; "
+                                            "use set_raw");
+    if (std::isnan(theta) || std::isnan(rho)) throw std::runtime_error("theta / rho / alpha must be set");
+    smcpp_host::OnePopPrep prep(n[0], hs, polarization_error);
+    prep.compute(model, theta, rho, alpha, keys, K, pi, T, E);
+}
+
+void smcpp_im::host_prep_and_upload() {
+    hipStream_t s = stream;
+    const size_t MM = (size_t)Mp * Mp;
+    // ---- TransitionBundle::update: eigensystems of diag(b_k) Td^T per eigen key (transition_bundle.cpp:15-25)
+    std::vector<smcpp_host::EigenSystem> es(Ke);
+    std::string err;
+#pragma omp parallel for schedule(dynamic)
+    for (int e = 0; e < Ke; ++e) {
+        try {
+            const double *b = &E[(size_t)eig_kid[e] * M];
+            std::vector<double> A((size_t)M * M);
+            for (int i = 0; i < M; ++i)
+                for (int j = 0; j < M; ++j) A[(size_t)i * M + j] = b[i] * T[(size_t)j * M + i];
+            es[e] = smcpp_host::eigensystem(M, A);
+        } catch (const std::exception &ex) {
+#pragma omp critical
+            err = ex.what();
+        }
+    }
+    if (!err.empty()) throw std::runtime_error(err);
+    std::vector<float> pi_f(Mp, 0.f), Tf(MM, 0.f);
+    std::vector<double> TdT(MM, 0.0), Td(MM, 0.0), Ep((size_t)K * Mp, 0.0);
+    for (int i = 0; i < M; ++i) {
+        pi_f[i] = (float)pi[i];
+        for (int j = 0; j < M; ++j) {
+            Tf[(size_t)i * Mp + j] = (float)T[(size_t)i * M + j];
+            Td[(size_t)i * Mp + j] = T[(size_t)i * M + j];
+            TdT[(size_t)j * Mp + i] = T[(size_t)i * M + j];
+        }
+    }
+    for (int k = 0; k < K; ++k)
+        for (int i = 0; i < M; ++i) Ep[(size_t)k * Mp + i] = E[(size_t)k * M + i];
+    const size_t em = std::max<size_t>(1, (size_t)Ke) * MM;
+    std::vector<double> PinvT(em, 0.0), PT(em, 0.0), Prm(em, 0.0), Pinvrm(em, 0.0);
+    std::vector<double> dsc(std::max<size_t>(1, (size_t)Ke) * Mp, 0.0), dun(std::max<size_t>(1, (size_t)Ke) * Mp, 0.0);
+    for (int e = 0; e < Ke; ++e) {
+        const auto &s_ = es[e];
+        for (int i = 0; i < M; ++i) {
+            dun[(size_t)e * Mp + i] = s_.d[i];
+            dsc[(size_t)e * Mp + i] = s_.d[i] / s_.scale;
+            for (int j = 0; j < M; ++j) {
+                const double p = s_.P[(size_t)i * M + j], pi_ = s_.Pinv[(size_t)i * M + j];
+                Prm[e * MM + (size_t)i * Mp + j] = p;
+                PT[e * MM + (size_t)j * Mp + i] = p;
+                Pinvrm[e * MM + (size_t)i * Mp + j] = pi_;
+                PinvT[e * MM + (size_t)j * Mp + i] = pi_;
+            }
+        }
+    }
+    std::vector<double> dpow(std::max<size_t>(1, (size_t)G) * Mp, 0.0), gsc(std::max(1, G), 1.0), gls(std::max(1, G), 0.0);
+    for (int g = 0; g < G; ++g) {
+        const int e = groups[g].eig, sp = groups[g].span;
+        gsc[g] = es[e].scale;
+        gls[g] = sp * std::log(es[e].scale);
+        for (int i = 0; i < M; ++i) dpow[(size_t)g * Mp + i] = std::pow(dsc[(size_t)e * Mp + i], sp);
+    }
+    d_pi_f.upload(pi_f, s); d_Tf.upload(Tf, s); d_TdT.upload(TdT, s); d_Td.upload(Td, s); d_E.upload(Ep, s);
+    d_PinvT.upload(PinvT, s); d_PT.upload(PT, s); d_Prm.upload(Prm, s); d_Pinvrm.upload(Pinvrm, s);
+    d_dsc.upload(dsc, s); d_dun.upload(dun, s); d_dpow.upload(dpow, s);
+    d_g_scale.upload(gsc, s); d_g_logscale.upload(gls, s);
+    HIPCHK(hipStreamSynchronize(s));   // the staging vectors above are pageable and die with this scope
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel launches
+// ---------------------------------------------------------------------------------------------------------------
+template <int NPL_>
+static void launch_fwd(const ChainArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_fwd_pass<NPL_>, dim3(a.nchunks), dim3(64), 0, s, a);
+}
+template <int NPL_>
+static void launch_bwd(const ChainArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_bwd_pass<NPL_>, dim3(a.nchunks), dim3(64), 0, s, a);
+}
+static void launch_chain(bool fwd, int npl, const ChainArgs &a, hipStream_t s) {
+    switch (npl) {
+        case 1: fwd ? launch_fwd<1>(a, s) : launch_bwd<1>(a, s); break;
+        case 2: fwd ? launch_fwd<2>(a, s) : launch_bwd<2>(a, s); break;
+        case 3: fwd ? launch_fwd<3>(a, s) : launch_bwd<3>(a, s); break;
+        case 4: fwd ? launch_fwd<4>(a, s) : launch_bwd<4>(a, s); break;
+        default: throw std::runtime_error("unsupported number of hidden states");
+    }
+}
+
+template <int NT_>
+static void launch_uw_t(const UWArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_eig_uw<NT_>, dim3(a.nslabs), dim3(64), 0, s, a);
+}
+static void launch_uw(int nt, const UWArgs &a, hipStream_t s) {
+    switch (nt) {
+#define C_(x) case x: launch_uw_t<x>(a, s); break;
+        C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10) C_(11) C_(12) C_(13) C_(14) C_(15) C_(16)
+#undef C_
+        default: throw std::runtime_error("unsupported number of hidden states");
+    }
+}
+template <int NPL_>
+static void launch_s1_t(const S1Args &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_s1_scalars<NPL_>, dim3(a.nslabs), dim3(64), 0, s, a);
+}
+static void launch_s1(int npl, const S1Args &a, hipStream_t s) {
+    switch (npl) {
+        case 1: launch_s1_t<1>(a, s); break;
+        case 2: launch_s1_t<2>(a, s); break;
+        case 3: launch_s1_t<3>(a, s); break;
+        case 4: launch_s1_t<4>(a, s); break;
+        default: throw std::runtime_error("unsupported number of hidden states");
+    }
+}
+
+void smcpp_im::run_chains() {
+    hipStream_t s = stream;
+    ChainArgs a;
+    a.M = M; a.Mp = Mp; a.nchunks = (int)chunks.size(); a.pass = 0;
+    a.chunks = d_chunks.p; a.rowinfo = d_rowinfo.p; a.E = d_E.p; a.dpow = d_dpow.p; a.g_eig = d_g_eig.p;
+    a.pi_f = d_pi_f.p; a.Tf = d_Tf.p; a.PinvT = d_PinvT.p; a.PT = d_PT.p;
+    a.TdT = d_TdT.p; a.Prm = d_Prm.p; a.Pinvrm = d_Pinvrm.p;
+    a.alpha = d_alpha.p; a.beta = d_beta.p; a.cnorm = d_cnorm.p;
+    a.ends_f = d_ends_f.p; a.used_f = d_used_f.p; a.ends_b = d_ends_b.p; a.used_b = d_used_b.p;
+    a.eps_f = eps_f; a.eps_b = eps_b;
+    d_changed_f.zero(s);
+    d_changed_b.zero(s);
+    std::vector<int> chf(max_pass + 1), chb(max_pass + 1);
+    auto first_quiet = [](const std::vector<int> &ch, int upto) {
+        for (int j = 0; j < upto; ++j)
+            if (ch[j] == 0) return j;
+        return -1;
+    };
+    int launched_f = 0, launched_b = 0;
+    int want_f = std::min(max_pass, last_fwd_passes > 0 ? last_fwd_passes + 1 : std::min(max_pass, 8));
+    int want_b = std::min(max_pass, last_bwd_passes > 0 ? last_bwd_passes + 1 : std::min(max_pass, 8));
+    HIPCHK(hipEventRecord(ev[1], s));
+    bool fdone = false, bdone = false;
+    int fq = -1, bq = -1;
+    while (true) {
+        if (!fdone) {
+            a.changed = d_changed_f.p;
+            for (; launched_f < want_f; ++launched_f) { a.pass = launched_f; launch_chain(true, NPL, a, s); }
+        }
+        if (launched_b == 0) HIPCHK(hipEventRecord(ev[2], s));
+        if (!bdone) {
+            a.changed = d_changed_b.p;
+            for (; launched_b < want_b; ++launched_b) { a.pass = launched_b; launch_chain(false, NPL, a, s); }
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(chf.data(), d_changed_f.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(chb.data(), d_changed_b.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(ev[3], s));
+        HIPCHK(hipStreamSynchronize(s));
+        fq = first_quiet(chf, launched_f);
+        bq = first_quiet(chb, launched_b);
+        fdone = fq >= 0 || launched_f >= max_pass;
+        bdone = bq >= 0 || launched_b >= max_pass;
+        if (fdone && bdone) break;
+        if (!fdone) want_f = std::min(max_pass, launched_f + 4);
+        if (!bdone) want_b = std::min(max_pass, launched_b + 4);
+    }
+    if (fq < 0 || bq < 0) throw std::runtime_error("chunk-boundary iteration did not converge");
+    last_fwd_passes = fq;
+    last_bwd_passes = bq;
+}
+
+void smcpp_im::run_stats() {
+    hipStream_t s = stream;
+    // log-likelihood (also materialises log_c per row)
+    LoglikArgs la;
+    la.cnorm = d_cnorm.p; la.rowinfo = d_rowinfo.p; la.g_logscale = d_g_logscale.p;
+    la.contig_base = d_contig_base.p; la.contig_L = d_contig_L.p; la.partial = d_llpart.p; la.loglik = d_loglik.p;
+    la.logc = d_logc.p; la.nblk = llblk;
+    hipLaunchKernelGGL(k_loglik_partial, dim3(llblk, n_contigs), dim3(256), 0, s, la);
+    hipLaunchKernelGGL(k_loglik_final, dim3(n_contigs), dim3(256), 0, s, la);
+    if (save_gamma) {
+        d_gamma_rows.alloc((size_t)total_rows * Mp);
+        d_gamma_rows.zero(s);
+    }
+    if (!slabs_sc.empty()) {
+        S1Args sa;
+        sa.M = M; sa.Mp = Mp; sa.nslabs = (int)slabs_sc.size(); sa.slabs = d_slabs_sc.p; sa.perm = d_perm1.p;
+        sa.alpha = d_alpha.p; sa.beta = d_beta.p; sa.logc = d_logc.p; sa.w1 = d_w1.p; sa.gpart = d_gpart.p;
+        sa.gamma_rows = save_gamma ? d_gamma_rows.p : nullptr;
+        launch_s1(NPL, sa, s);
+    }
+    AccArgs aa;
+    aa.M = M; aa.Mp = Mp; aa.NB = (Mp + 63) / 64; aa.rowinfo = d_rowinfo.p; aa.alpha = d_alpha.p; aa.beta = d_beta.p;
+    aa.w1 = d_w1.p; aa.E = d_E.p; aa.Xs = d_Xs.p; aa.Ys = d_Ys.p;
+    if (!slabs_rk.empty()) {
+        aa.nslabs = (int)slabs_rk.size(); aa.slabs = d_slabs_rk.p; aa.perm = d_perm1.p; aa.part = d_part_1.p;
+        hipLaunchKernelGGL(k_rank_acc<0>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, s, aa);
+    }
+    if (!slabs_eg.empty()) {
+        UWArgs ua;
+        ua.M = M; ua.Mp = Mp; ua.nslabs = (int)slabs_eg.size(); ua.slabs = d_slabs_eg.p; ua.perm = d_perme.p;
+        ua.alpha = d_alpha.p; ua.beta = d_beta.p; ua.g_eig = d_g_eig.p; ua.g_scale = d_g_scale.p;
+        ua.dpow = d_dpow.p; ua.PinvT = d_PinvT.p; ua.Prm = d_Prm.p; ua.Xs = d_Xs.p; ua.Ys = d_Ys.p;
+        launch_uw(NT, ua, s);
+        aa.nslabs = (int)slabs_eg.size(); aa.slabs = d_slabs_eg.p; aa.perm = d_perme.p; aa.part = d_part_e.p;
+        hipLaunchKernelGGL(k_rank_acc<1>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, s, aa);
+    }
+    HIPCHK(hipEventRecord(ev[4], s));
+    FinArgs fa;
+    fa.M = M; fa.Mp = Mp; fa.K = K; fa.G = G; fa.Ke = Ke; fa.n_contigs = n_contigs;
+    fa.eb_slab_off = d_eb_slab_off.p; fa.eb_gid = d_eb_gid.p; fa.ce_bucket_off = d_ce_bucket_off.p;
+    fa.s1_slab_off = d_s1_slab_off.p; fa.gk_slab_off = d_gk_slab_off.p; fa.g_span = d_g_span.p;
+    fa.e_kid = d_e_kid.p; fa.dsc = d_dsc.p; fa.dun = d_dun.p; fa.Prm = d_Prm.p; fa.Pinvrm = d_Pinvrm.p;
+    fa.E = d_E.p; fa.Td = d_Td.p; fa.part_e = d_part_e.p; fa.part_1 = d_part_1.p; fa.gpart = d_gpart.p;
+    fa.alpha = d_alpha.p; fa.beta = d_beta.p; fa.contig_base = d_contig_base.p;
+    fa.Z = d_Z.p; fa.Y = d_Y.p; fa.xisum = d_xisum.p; fa.gsum = d_gsum.p; fa.gamma0 = d_gamma0.p;
+    const int nb2 = ceil_div((long long)Mp * Mp, 256);
+    if (Ke > 0) {
+        hipLaunchKernelGGL(k_fin_Z, dim3(nb2, n_contigs * Ke), dim3(256), 0, s, fa);
+        hipLaunchKernelGGL(k_fin_Y, dim3(nb2, n_contigs * Ke), dim3(256), 0, s, fa);
+    }
+    hipLaunchKernelGGL(k_fin_xisum, dim3(nb2, n_contigs), dim3(256), 0, s, fa);
+    hipLaunchKernelGGL(k_fin_gamma, dim3(ceil_div((long long)(K + 1) * Mp, 256), n_contigs), dim3(256), 0, s, fa);
+    if (save_gamma && n_e_rows > 0) {
+        d_Sq.alloc((size_t)G * Mp * Mp);
+        hipLaunchKernelGGL(k_span_q, dim3(nb2, G), dim3(256), 0, s, M, Mp, G, (const int *)d_g_span.p,
+                           (const int *)d_g_eig.p, (const double *)d_dsc.p, d_Sq.p);
+        GammaRowArgs ga;
+        ga.M = M; ga.Mp = Mp; ga.nrows = (int)n_e_rows; ga.perm = d_perme.p; ga.row_slab = d_erow_slab.p;
+        ga.slabs = d_slabs_eg.p; ga.g_eig = d_g_eig.p; ga.g_span = d_g_span.p; ga.dun = d_dun.p;
+        ga.Prm = d_Prm.p; ga.Pinvrm = d_Pinvrm.p; ga.PinvT = d_PinvT.p; ga.Sq = d_Sq.p;
+        ga.alpha = d_alpha.p; ga.beta = d_beta.p; ga.gamma_rows = d_gamma_rows.p;
+        const size_t shm = (size_t)(3 * Mp + 256) * sizeof(double);
+        hipLaunchKernelGGL(k_gamma_rows_eig, dim3((unsigned)n_e_rows), dim3(256), shm, s, ga);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(loglik.data(), d_loglik.p, sizeof(double) * n_contigs, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(ev[5], s));
+    HIPCHK(hipStreamSynchronize(s));
+}
+
+void smcpp_im::estep() {
+    if (std::isnan(theta) || std::isnan(rho) || std::isnan(alpha))
+        throw std::runtime_error("theta / rho / alpha must be set");
+    HIPCHK(hipSetDevice(device));
+    auto t0 = std::chrono::steady_clock::now();
+    prepare_params();
+    if ((int)pi.size() != M || (int)T.size() != M * M || (int)E.size() != K * M)
+        throw std::runtime_error("parameters are not set");
+    HIPCHK(hipEventRecord(ev[0], stream));
+    host_prep_and_upload();   // the reference rebuilds the eigensystems on every E-step (inference_manager.cpp:112)
+    auto t1 = std::chrono::steady_clock::now();
+    run_chains();
+    run_stats();
+    auto t2 = std::chrono::steady_clock::now();
+    float f_ms = 0, b_ms = 0, s_ms = 0, fin_ms = 0;
+    (void)hipEventElapsedTime(&f_ms, ev[1], ev[2]);
+    (void)hipEventElapsedTime(&b_ms, ev[2], ev[3]);
+    (void)hipEventElapsedTime(&s_ms, ev[3], ev[4]);
+    (void)hipEventElapsedTime(&fin_ms, ev[4], ev[5]);
+    timing[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    timing[1] = 0.0;
+    timing[2] = f_ms; timing[3] = b_ms; timing[4] = s_ms; timing[5] = fin_ms;
+    timing[6] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    timing[7] = last_fwd_passes; timing[8] = last_bwd_passes;
+    stats_on_host = false;
+    have_reduced = false;
+    gamma_valid = save_gamma;
+    dirty = false;
+}
+
+void smcpp_im::fetch_stats() {
+    if (stats_on_host) return;
+    HIPCHK(hipSetDevice(device));
+    std::vector<double> x((size_t)n_contigs * Mp * Mp), g((size_t)n_contigs * K * Mp), g0((size_t)n_contigs * Mp);
+    HIPCHK(hipMemcpy(x.data(), d_xisum.p, x.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(g.data(), d_gsum.p, g.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(g0.data(), d_gamma0.p, g0.size() * sizeof(double), hipMemcpyDeviceToHost));
+    h_xisum.assign((size_t)n_contigs * M * M, 0.0);
+    h_gsum.assign((size_t)n_contigs * K * M, 0.0);
+    h_gamma0.assign((size_t)n_contigs * M, 0.0);
+    for (int c = 0; c < n_contigs; ++c) {
+        for (int i = 0; i < M; ++i) {
+            h_gamma0[(size_t)c * M + i] = g0[(size_t)c * Mp + i];
+            for (int j = 0; j < M; ++j)
+                h_xisum[((size_t)c * M + i) * M + j] = x[((size_t)c * Mp + i) * Mp + j];
+        }
+        for (int k = 0; k < K; ++k)
+            for (int i = 0; i < M; ++i)
+                h_gsum[((size_t)c * K + k) * M + i] = g[((size_t)c * K + k) * Mp + i];
+    }
+    stats_on_host = true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+#define API_BEGIN try {
+#define API_END                                                                    \
+    return 0;                                                                      \
+    }                                                                              \
+    catch (const std::exception &e) { g_err = e.what(); return 1; }               \
+    catch (...) { g_err = "unknown error"; return 1; }
+
+extern "C" {
+
+const char *smcpp_last_error(void) { return g_err.c_str(); }
+
+int smcpp_create_onepop(int n, int n_contigs, const int *Ls, const int *const *obs, int n_hs, const double *hs,
+                        double polarization_error, int device, smcpp_im **out) {
+    API_BEGIN
+    std::unique_ptr<smcpp_im> im(new smcpp_im());
+    const int nn[1] = {n}, nna[1] = {2};
+    im->build(1, nn, nna, n_contigs, Ls, obs, n_hs, hs, polarization_error, device);
+    *out = im.release();
+    API_END
+}
+
+int smcpp_create_twopop(int n1, int n2, int a1, int a2, int n_contigs, const int *Ls, const int *const *obs,
+                        int n_hs, const double *hs, double polarization_error, int device, smcpp_im **out) {
+    API_BEGIN
+    if (a1 == 0 && a2 == 2) throw std::runtime_error("(0,2) not supported");
+    if (a1 + a2 != 2) throw std::runtime_error("configuration not supported");
+    std::unique_ptr<smcpp_im> im(new smcpp_im());
+    const int nn[2] = {n1, n2}, nna[2] = {a1, a2};
+    im->build(2, nn, nna, n_contigs, Ls, obs, n_hs, hs, polarization_error, device);
+    *out = im.release();
+    API_END
+}
+
+void smcpp_destroy(smcpp_im *im) { delete im; }
+
+int smcpp_set_theta(smcpp_im *im, double v) { API_BEGIN im->theta = v; im->dirty = true; if (im->have_model) im->have_raw = false; API_END }
+int smcpp_set_rho(smcpp_im *im, double v) { API_BEGIN im->rho = v; im->dirty = true; if (im->have_model) im->have_raw = false; API_END }
+int smcpp_set_alpha(smcpp_im *im, double v) { API_BEGIN im->alpha = v; im->dirty = true; if (im->have_model) im->have_raw = false; API_END }
+
+int smcpp_set_params(smcpp_im *im, int K, const double *a, const double *da, int nder, const double *s) {
+    API_BEGIN
+    if (K <= 0) throw std::runtime_error("empty parameter vector");
+    for (int k = 0; k < K; ++k)
+        if (!(a[k] > 0)) throw std::runtime_error("model pieces must be positive");
+    (void)da; (void)nder;   // derivatives ride on the M-step path, not built yet
+    im->model.a.assign(a, a + K);
+    im->model.s.assign(s, s + K);
+    im->have_model = true;
+    im->have_raw = false;
+    im->dirty = true;
+    API_END
+}
+
+int smcpp_set_raw(smcpp_im *im, const double *pi, const double *T, int K, const int *keys, const double *E) {
+    API_BEGIN
+    const int M = im->M, kl = im->keylen;
+    std::map<std::vector<int>, int> given;
+    for (int k = 0; k < K; ++k) given[std::vector<int>(keys + (size_t)k * kl, keys + (size_t)(k + 1) * kl)] = k;
+    std::vector<double> Enew((size_t)im->K * M);
+    for (int k = 0; k < im->K; ++k) {
+        std::vector<int> key(im->keys.begin() + (size_t)k * kl, im->keys.begin() + (size_t)(k + 1) * kl);
+        auto it = given.find(key);
+        if (it == given.end()) throw std::runtime_error("set_raw: an observed key has no emission vector");
+        std::memcpy(&Enew[(size_t)k * M], E + (size_t)it->second * M, sizeof(double) * M);
+    }
+    im->pi.assign(pi, pi + M);
+    im->T.assign(T, T + (size_t)M * M);
+    im->E.swap(Enew);
+    im->have_raw = true;
+    im->dirty = true;
+    API_END
+}
+
+int smcpp_estep(smcpp_im *im, int fb_only) {
+    API_BEGIN
+    (void)fb_only;   // accepted and ignored, as in the reference (hmm.cpp:45)
+    im->estep();
+    API_END
+}
+
+int smcpp_loglik(smcpp_im *im, double *out) {
+    API_BEGIN
+    std::memcpy(out, im->loglik.data(), sizeof(double) * im->n_contigs);
+    API_END
+}
+
+static double dcs(const std::vector<double> &x) {   // doubly_compensated_summation, common.h:27-46
+    if (x.empty()) return 0.0;
+    double s = x[0], c = 0.0;
+    for (size_t i = 1; i < x.size(); ++i) {
+        const double y = c + x[i];
+        const double u = x[i] - (y - c);
+        const double t = y + s;
+        const double v = y - (t - s);
+        const double z = u + v;
+        s = t + z;
+        c = z - (s - t);
+    }
+    return s;
+}
+
+int smcpp_q(smcpp_im *im, double val[4], double *jac) {
+    API_BEGIN
+    (void)jac;
+    const int M = im->M, K = im->K;
+    if ((int)im->pi.size() != M) throw std::runtime_error("parameters are not set");
+    if (im->dirty && !im->have_raw) im->prepare_params();   // Q() does do_dirty_work() first (inference_manager.cpp:119)
+    for (int i = 0; i < 4; ++i) val[i] = 0.0;
+    std::vector<double> logpi(M), logT((size_t)M * M), logE((size_t)K * M);
+    for (int i = 0; i < M; ++i) logpi[i] = std::log(im->pi[i]);
+    for (size_t i = 0; i < logT.size(); ++i) logT[i] = std::log(im->T[i]);
+    std::vector<unsigned char> bad(K, 0);
+    for (int k = 0; k < K; ++k)
+        for (int i = 0; i < M; ++i) {
+            if (im->E[(size_t)k * M + i] <= 0.0) bad[k] = 1;
+            logE[(size_t)k * M + i] = std::log(im->E[(size_t)k * M + i]);
+        }
+    if (im->have_reduced) {
+        // statistics already summed over every rank's contigs
+        const double *g0 = &im->g_stats[1], *xs = g0 + M, *gs = xs + (size_t)M * M;
+        const int Kg = (int)(im->gkeys.size() / im->keylen);
+        for (int i = 0; i < M; ++i) val[0] += logpi[i] * g0[i];
+        std::vector<double> b0, b1;
+        for (int kg = 0; kg < Kg; ++kg) {
+            int kl = -1;
+            for (int k = 0; k < K; ++k) if (im->local_to_global[k] == kg) { kl = k; break; }
+            if (kl < 0) continue;   // a key no contig of this rank holds still needs its emission vector
+            auto &b = im->key_nbpos[kl] ? b1 : b0;
+            for (int i = 0; i < M; ++i) b.push_back(logE[(size_t)kl * M + i] * gs[(size_t)kg * M + i]);
+        }
+        val[1] = dcs(b0); val[2] = dcs(b1);
+        std::vector<double> es((size_t)M * M);
+        for (int j = 0; j < M; ++j)
+            for (int i = 0; i < M; ++i) es[(size_t)j * M + i] = logT[(size_t)i * M + j] * xs[(size_t)i * M + j];
+        val[3] = dcs(es);
+        return 0;
+    }
+    im->fetch_stats();
+    for (int c = 0; c < im->n_contigs; ++c) {
+        double q0 = 0.0;
+        for (int i = 0; i < M; ++i) q0 += logpi[i] * im->h_gamma0[(size_t)c * M + i];
+        val[0] += q0;
+        std::vector<double> b0, b1;
+        bool inf0 = false, inf1 = false;
+        for (int k = 0; k < K; ++k) {
+            if (!im->present[(size_t)c * K + k]) continue;
+            if (bad[k]) { (im->key_nbpos[k] ? inf1 : inf0) = true; continue; }
+            auto &b = im->key_nbpos[k] ? b1 : b0;
+            for (int i = 0; i < M; ++i)
+                b.push_back(logE[(size_t)k * M + i] * im->h_gsum[((size_t)c * K + k) * M + i]);
+        }
+        val[1] += inf0 ? -INFINITY : dcs(b0);
+        val[2] += inf1 ? -INFINITY : dcs(b1);
+        std::vector<double> es((size_t)M * M);
+        const double *xs = &im->h_xisum[(size_t)c * M * M];
+        for (int j = 0; j < M; ++j)
+            for (int i = 0; i < M; ++i) es[(size_t)j * M + i] = logT[(size_t)i * M + j] * xs[(size_t)i * M + j];
+        val[3] += dcs(es);
+    }
+    API_END
+}
+
+int smcpp_set_save_gamma(smcpp_im *im, int on) { API_BEGIN im->save_gamma = on != 0; API_END }
+int smcpp_get_save_gamma(smcpp_im *im) { return im->save_gamma ? 1 : 0; }
+int smcpp_num_states(smcpp_im *im) { return im->M; }
+int smcpp_num_contigs(smcpp_im *im) { return im->n_contigs; }
+int smcpp_num_keys(smcpp_im *im) { return im->K; }
+int smcpp_key_len(smcpp_im *im) { return im->keylen; }
+
+int smcpp_get_hidden_states(smcpp_im *im, double *hs) {
+    API_BEGIN std::memcpy(hs, im->hs.data(), sizeof(double) * im->hs.size()); API_END
+}
+int smcpp_set_hidden_states(smcpp_im *im, int n_hs, const double *hs) {
+    API_BEGIN
+    if (n_hs != (int)im->hs.size()) throw std::runtime_error("hidden states must be same size");
+    im->hs.assign(hs, hs + n_hs);
+    im->dirty = true;
+    if (im->have_model) im->have_raw = false;
+    API_END
+}
+int smcpp_get_keys(smcpp_im *im, int *keys) {
+    API_BEGIN std::memcpy(keys, im->keys.data(), sizeof(int) * im->keys.size()); API_END
+}
+
+int smcpp_get_xisum(smcpp_im *im, int c, double *out) {
+    API_BEGIN
+    if (c < 0 || c >= im->n_contigs) throw std::runtime_error("contig index out of range");
+    im->fetch_stats();
+    std::memcpy(out, &im->h_xisum[(size_t)c * im->M * im->M], sizeof(double) * im->M * im->M);
+    API_END
+}
+
+int smcpp_get_gamma(smcpp_im *im, int c, double *out) {
+    API_BEGIN
+    if (c < 0 || c >= im->n_contigs) throw std::runtime_error("contig index out of range");
+    const int M = im->M, Mp = im->Mp;
+    im->fetch_stats();
+    if (!im->gamma_valid) {
+        std::memcpy(out, &im->h_gamma0[(size_t)c * M], sizeof(double) * M);   // gamma is M x 1 (hmm.cpp:12-14)
+        return 0;
+    }
+    HIPCHK(hipSetDevice(im->device));
+    const int L = im->Ls[c];
+    std::vector<double> rows((size_t)(L + 1) * Mp);
+    HIPCHK(hipMemcpy(rows.data(), im->d_gamma_rows.p + (size_t)im->contig_base[c] * Mp, rows.size() * sizeof(double),
+                     hipMemcpyDeviceToHost));
+    for (int i = 0; i < M; ++i) {
+        out[(size_t)i * (L + 1)] = im->h_gamma0[(size_t)c * M + i];
+        for (int l = 1; l <= L; ++l) out[(size_t)i * (L + 1) + l] = rows[(size_t)l * Mp + i];
+    }
+    API_END
+}
+
+int smcpp_get_gamma_argmax(smcpp_im *im, int c, int *out) {
+    API_BEGIN
+    if (c < 0 || c >= im->n_contigs) throw std::runtime_error("contig index out of range");
+    if (!im->gamma_valid) throw std::runtime_error("save_gamma was not set for the last E-step");
+    HIPCHK(hipSetDevice(im->device));
+    const int L = im->Ls[c];
+    im->fetch_stats();
+    im->d_argmax.alloc((size_t)im->total_rows);
+    hipLaunchKernelGGL(k_gamma_argmax, dim3(ceil_div(L + 1, 256)), dim3(256), 0, im->stream, im->M, im->Mp,
+                       (long long)(L + 1), (const double *)(im->d_gamma_rows.p + (size_t)im->contig_base[c] * im->Mp),
+                       im->d_argmax.p);
+    HIPCHK(hipMemcpyAsync(out, im->d_argmax.p, sizeof(int) * (L + 1), hipMemcpyDeviceToHost, im->stream));
+    HIPCHK(hipStreamSynchronize(im->stream));
+    // column 0 is alpha_0 o beta_0 (hmm.cpp:150), which lives in gamma0
+    int best = 0;
+    for (int i = 1; i < im->M; ++i)
+        if (im->h_gamma0[(size_t)c * im->M + i] > im->h_gamma0[(size_t)c * im->M + best]) best = i;
+    out[0] = best;
+    API_END
+}
+
+int smcpp_get_gamma_sums(smcpp_im *im, int c, double *vals, unsigned char *present) {
+    API_BEGIN
+    if (c < 0 || c >= im->n_contigs) throw std::runtime_error("contig index out of range");
+    im->fetch_stats();
+    std::memcpy(vals, &im->h_gsum[(size_t)c * im->K * im->M], sizeof(double) * im->K * im->M);
+    std::memcpy(present, &im->present[(size_t)c * im->K], im->K);
+    API_END
+}
+
+int smcpp_get_pi(smcpp_im *im, double *out) {
+    API_BEGIN
+    if (im->pi.empty()) throw std::runtime_error("parameters are not set");
+    std::memcpy(out, im->pi.data(), sizeof(double) * im->M);
+    API_END
+}
+int smcpp_get_transition(smcpp_im *im, double *out) {
+    API_BEGIN
+    if (im->T.empty()) throw std::runtime_error("parameters are not set");
+    std::memcpy(out, im->T.data(), sizeof(double) * im->M * im->M);
+    API_END
+}
+int smcpp_get_emission_probs(smcpp_im *im, double *out) {
+    API_BEGIN
+    if (im->E.empty()) throw std::runtime_error("parameters are not set");
+    std::memcpy(out, im->E.data(), sizeof(double) * im->K * im->M);
+    API_END
+}
+
+int smcpp_set_global_keys(smcpp_im *im, int Kg, const int *gkeys) {
+    API_BEGIN
+    const int kl = im->keylen;
+    std::map<std::vector<int>, int> gm;
+    for (int k = 0; k < Kg; ++k) gm[std::vector<int>(gkeys + (size_t)k * kl, gkeys + (size_t)(k + 1) * kl)] = k;
+    im->local_to_global.assign(im->K, -1);
+    for (int k = 0; k < im->K; ++k) {
+        auto it = gm.find(std::vector<int>(im->keys.begin() + (size_t)k * kl, im->keys.begin() + (size_t)(k + 1) * kl));
+        if (it == gm.end()) throw std::runtime_error("global key list misses a local key");
+        im->local_to_global[k] = it->second;
+    }
+    im->gkeys.assign(gkeys, gkeys + (size_t)Kg * kl);
+    im->have_global = true;
+    API_END
+}
+
+int smcpp_pack_stats(smcpp_im *im, double *buf, long *n_out, int dev) {
+    API_BEGIN
+    const int M = im->M, K = im->K;
+    const int Kg = im->have_global ? (int)(im->gkeys.size() / im->keylen) : K;
+    const long n = 1 + M + (long)M * M + (long)Kg * M;
+    if (n_out) *n_out = n;
+    if (!buf) return 0;
+    im->fetch_stats();
+    std::vector<double> h(n, 0.0);
+    for (int c = 0; c < im->n_contigs; ++c) {
+        h[0] += im->loglik[c];
+        for (int i = 0; i < M; ++i) h[1 + i] += im->h_gamma0[(size_t)c * M + i];
+        for (size_t i = 0; i < (size_t)M * M; ++i) h[1 + M + i] += im->h_xisum[(size_t)c * M * M + i];
+        for (int k = 0; k < K; ++k) {
+            if (!im->present[(size_t)c * K + k]) continue;
+            const int kg = im->have_global ? im->local_to_global[k] : k;
+            for (int i = 0; i < M; ++i) h[1 + M + (size_t)M * M + (size_t)kg * M + i] += im->h_gsum[((size_t)c * K + k) * M + i];
+        }
+    }
+    if (dev) {
+        HIPCHK(hipSetDevice(im->device));
+        HIPCHK(hipMemcpy(buf, h.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    } else std::memcpy(buf, h.data(), sizeof(double) * n);
+    API_END
+}
+
+int smcpp_unpack_stats(smcpp_im *im, const double *buf, long n, int dev) {
+    API_BEGIN
+    const int M = im->M;
+    const int Kg = im->have_global ? (int)(im->gkeys.size() / im->keylen) : im->K;
+    if (n != 1 + M + (long)M * M + (long)Kg * M) throw std::runtime_error("unpack_stats: wrong buffer length");
+    if (!im->have_global) {
+        im->local_to_global.resize(im->K);
+        for (int k = 0; k < im->K; ++k) im->local_to_global[k] = k;
+        im->gkeys = im->keys;
+    }
+    im->g_stats.resize(n);
+    if (dev) {
+        HIPCHK(hipSetDevice(im->device));
+        HIPCHK(hipMemcpy(im->g_stats.data(), buf, sizeof(double) * n, hipMemcpyDeviceToHost));
+    } else std::memcpy(im->g_stats.data(), buf, sizeof(double) * n);
+    im->have_reduced = true;
+    API_END
+}
+
+int smcpp_set_chunking(smcpp_im *im, int rows_per_chunk, double eps_alpha, double eps_beta) {
+    API_BEGIN
+    HIPCHK(hipSetDevice(im->device));
+    if (eps_alpha > 0) im->eps_f = (float)eps_alpha;
+    if (eps_beta > 0) im->eps_b = eps_beta;
+    if (rows_per_chunk != im->user_rows_per_chunk) {
+        im->user_rows_per_chunk = rows_per_chunk;
+        im->make_chunks();
+        const size_t nch = im->chunks.size();
+        im->d_chunks.upload(im->chunks, im->stream);
+        im->d_ends_f.alloc(2 * nch * im->Mp); im->d_used_f.alloc(nch * im->Mp);
+        im->d_ends_b.alloc(2 * nch * im->Mp); im->d_used_b.alloc(nch * im->Mp);
+        im->d_changed_f.alloc(im->max_pass + 1); im->d_changed_b.alloc(im->max_pass + 1);
+        HIPCHK(hipStreamSynchronize(im->stream));
+        im->last_fwd_passes = im->last_bwd_passes = 0;
+    }
+    API_END
+}
+
+int smcpp_last_timing(smcpp_im *im, double out[9]) {
+    API_BEGIN std::memcpy(out, im->timing, sizeof(double) * 9); API_END
+}
+
+void *smcpp_stream(smcpp_im *im) { return (void *)im->stream; }
+
+void smcpp_set_num_threads(int k) { if (k > 0) omp_set_num_threads(k); }
+
+// ---- host-only helpers exported for the CPU test-suite (no device needed) --------------------------------------
+
+// eigensystem(EigenSolver(A)) as used by TransitionBundle::update: P_r, Pinv_r [n x n], d_r [n], scale, max|imag|
+int smcpp_host_eigensystem(int n, const double *A, double *P, double *Pinv, double *d, double *scale, double *max_imag) {
+    API_BEGIN
+    std::vector<double> a(A, A + (size_t)n * n);
+    smcpp_host::EigenSystem es = smcpp_host::eigensystem(n, a);
+    std::memcpy(P, es.P.data(), sizeof(double) * n * n);
+    std::memcpy(Pinv, es.Pinv.data(), sizeof(double) * n * n);
+    std::memcpy(d, es.d.data(), sizeof(double) * n);
+    *scale = es.scale;
+    *max_imag = es.max_imag;
+    API_END
+}
+
+// one-population parameter preparation on the host without an engine instance
+int smcpp_host_prep_onepop(int n, int n_hs, const double *hs, double polarization_error, int Kp, const double *a,
+                           const double *s, double theta, double rho, double alpha, int K, const int *keys,
+                           double *pi, double *T, double *E) {
+    API_BEGIN
+    std::vector<double> hsv(hs, hs + n_hs);
+    smcpp_host::OnePopPrep prep(n, hsv, polarization_error);
+    smcpp_host::ModelParams mp;
+    mp.a.assign(a, a + Kp);
+    mp.s.assign(s, s + Kp);
+    std::vector<int> kv(keys, keys + (size_t)K * 3);
+    std::vector<double> piv, Tv, Ev;
+    prep.compute(mp, theta, rho, alpha, kv, K, piv, Tv, Ev);
+    const int M = n_hs - 1;
+    if (pi) std::memcpy(pi, piv.data(), sizeof(double) * M);
+    if (T) std::memcpy(T, Tv.data(), sizeof(double) * M * M);
+    if (E) std::memcpy(E, Ev.data(), sizeof(double) * (size_t)K * M);
+    API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,981 @@
+// HIP kernels of the SMC++ E-step engine for gfx950 (MI355X, CDNA4; 64-wide wavefronts).
+//
+// Reference semantics reproduced here: HMM::Estep, src/hmm.cpp:45-153.
+// The restructuring (why these kernels do not look like hmm.cpp) is described in DESIGN.md:
+//   * K1 `k_fwd_pass` / K2 `k_bwd_pass`: the two dependent chains, chunk-parallel.  One wavefront owns one chunk
+//     of consecutive rows; chunk-boundary vectors are iterated to a fixed point over passes (the chains forget
+//     their start vector geometrically), so after convergence every chunk has been run from the vector its left
+//     (right) neighbour ended on.  Lane i owns hidden state i (+64q for M > 64).
+//   * K3 `k_s1_scalars`, K4 `k_rank_acc`, K5 `k_eig_uw`: sufficient statistics, embarrassingly parallel over rows,
+//     fp64 MFMA (v_mfma_f64_16x16x4_f64) rank-k updates into per-bucket M x M accumulators.
+//   * K6 finalisation kernels: span-Q Hadamard, P * Z * Pinv * B, gamma diagonals, xisum o Td with the 1e-20 floor.
+//   * K7 `k_loglik_partial` / `k_loglik_final`: log-normaliser reduction (deterministic two-stage tree).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace smcpp_dev {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+struct Chunk {
+    long long base;   // index of the contig's row 0 in the global (all contigs) row arrays
+    int r0, r1;       // the chunk owns rows ell = r0+1 .. r1 (contig relative, 1-based like hmm.cpp)
+    int contig;
+    int first;        // r0 == 0
+    int last;         // r1 == L
+    int pad;
+};
+
+struct RowInfo {      // per global row index (entry for ell = 0 of each contig is unused)
+    int kid;          // key id
+    int gid;          // (span,key) group id for span > 1 rows, -1 for span == 1
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// wavefront reductions (all 64 lanes receive the result)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// sum over the 16 lanes of a DPP row (lanes with equal lane>>4); every lane of the row gets the result
+__device__ __forceinline__ double row16_sum(double v) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1: forward chain pass  (hmm.cpp:57-96)
+// ---------------------------------------------------------------------------------------------------------------
+struct ChainArgs {
+    int M, Mp, nchunks, pass;
+    const Chunk *chunks;
+    const RowInfo *rowinfo;
+    const double *E;        // [K][Mp] emission vectors
+    const double *dpow;     // [G][Mp] (d_r/scale)^span per group
+    const int *g_eig;       // [G] eigensystem index of the group
+    // forward operands
+    const float *pi_f;      // [Mp] float(pi)
+    const float *Tf;        // [Mp][Mp] Tf[k][i] = float(T[k][i])
+    const double *PinvT;    // [Ke][Mp][Mp] PinvT[j][i] = Pinv_r[i][j]
+    const double *PT;       // [Ke][Mp][Mp] PT[j][i]    = P_r[i][j]
+    // backward operands
+    const double *TdT;      // [Mp][Mp] TdT[j][i] = T[i][j]
+    const double *Prm;      // [Ke][Mp][Mp] P_r row-major
+    const double *Pinvrm;   // [Ke][Mp][Mp] Pinv_r row-major
+    // state
+    float *alpha;           // [rows][Mp]
+    double *beta;           // [rows][Mp]
+    double *cnorm;          // [rows] forward normaliser c (log_c = log c + span*log scale is taken later)
+    float *ends_f;          // [2][nchunks][Mp]
+    float *used_f;          // [nchunks][Mp]
+    double *ends_b;         // [2][nchunks][Mp]
+    double *used_b;         // [nchunks][Mp]
+    int *changed;           // [max passes]
+    float eps_f;
+    double eps_b;
+};
+
+template <int NPL>
+__global__ __launch_bounds__(64) void k_fwd_pass(ChainArgs a) {
+    __shared__ double xs[NPL * 64];
+    __shared__ float xf[NPL * 64];
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x;
+    const int M = a.M, Mp = a.Mp, pass = a.pass;
+    if (pass > 0 && a.changed[pass - 1] == 0) return;     // the previous pass re-ran nothing: converged
+    const Chunk ch = a.chunks[c];
+    float *end_cur = a.ends_f + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
+    const float *end_prev = a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
+    float al[NPL];
+    if (pass > 0 && ch.first) {                            // exact since pass 0
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) end_cur[i] = end_prev[i]; }
+        return;
+    }
+    {
+        const float *src = (ch.first || pass == 0)
+                               ? a.pi_f
+                               : a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + (c - 1)) * Mp;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; al[q] = (i < M) ? src[i] : 0.f; }
+    }
+    if (pass > 0) {
+        bool diff = false;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = lane + 64 * q;
+            if (i < M) {
+                const float u = a.used_f[(size_t)c * Mp + i];
+                if (!(fabsf(al[q] - u) <= a.eps_f * fabsf(u))) diff = true;
+            }
+        }
+        if (!__any(diff)) {
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) end_cur[i] = end_prev[i]; }
+            return;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) a.used_f[(size_t)c * Mp + i] = al[q]; }
+    if (lane == 0) a.changed[pass] = 1;
+    if (ch.first) {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = lane + 64 * q;
+            if (i < Mp) a.alpha[(size_t)ch.base * Mp + i] = al[q];
+        }
+        if (lane == 0) a.cnorm[ch.base] = 1.0;
+    }
+    RowInfo ri = a.rowinfo[ch.base + ch.r0 + 1];
+    for (int ell = ch.r0 + 1; ell <= ch.r1; ++ell) {
+        const int nxt = (ell < ch.r1) ? ell + 1 : ell;
+        const RowInfo rn = a.rowinfo[ch.base + nxt];        // prefetch next row's descriptor
+        ri.kid = __builtin_amdgcn_readfirstlane(ri.kid);    // wave-uniform: scalar branch below
+        ri.gid = __builtin_amdgcn_readfirstlane(ri.gid);
+        const double *e = a.E + (size_t)ri.kid * Mp;
+        double ev[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; ev[q] = (i < M) ? e[i] : 0.0; }
+        double cval;
+        if (ri.gid < 0) {
+            // span == 1 (hmm.cpp:82-90): alpha' = float(diag(b) T^T) alpha in float
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) xf[lane + 64 * q] = al[q];
+            __syncthreads();
+            float acc[NPL][4];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
+            const float *Tf = a.Tf;
+            int k = 0;
+            for (; k + 4 <= M; k += 4) {
+                const float x0 = xf[k], x1 = xf[k + 1], x2 = xf[k + 2], x3 = xf[k + 3];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < Mp) {
+                        acc[q][0] = fmaf(Tf[(size_t)k * Mp + i], x0, acc[q][0]);
+                        acc[q][1] = fmaf(Tf[(size_t)(k + 1) * Mp + i], x1, acc[q][1]);
+                        acc[q][2] = fmaf(Tf[(size_t)(k + 2) * Mp + i], x2, acc[q][2]);
+                        acc[q][3] = fmaf(Tf[(size_t)(k + 3) * Mp + i], x3, acc[q][3]);
+                    }
+                }
+            }
+            for (; k < M; ++k) {
+                const float x0 = xf[k];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < Mp) acc[q][0] = fmaf(Tf[(size_t)k * Mp + i], x0, acc[q][0]);
+                }
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const float y = (acc[q][0] + acc[q][1]) + (acc[q][2] + acc[q][3]);
+                al[q] = (float)((double)y * ev[q]);
+                part += al[q];
+            }
+            const float s = wave_sum(part);
+            cval = (double)s;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) al[q] = al[q] / s;
+            __syncthreads();
+        } else {
+            // span > 1 (hmm.cpp:72-81): a = P (d~^span o (Pinv alpha)) in double
+            const int es = a.g_eig[ri.gid];
+            const double *PinvT = a.PinvT + (size_t)es * Mp * Mp;
+            const double *PT = a.PT + (size_t)es * Mp * Mp;
+            const double *dp = a.dpow + (size_t)ri.gid * Mp;
+            double dpv[NPL];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; dpv[q] = (i < M) ? dp[i] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = (double)al[q];
+            __syncthreads();
+            double acc[NPL][2];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = 0.0;
+            int k = 0;
+            for (; k + 2 <= M; k += 2) {
+                const double x0 = xs[k], x1 = xs[k + 1];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < Mp) {
+                        acc[q][0] = fma(PinvT[(size_t)k * Mp + i], x0, acc[q][0]);
+                        acc[q][1] = fma(PinvT[(size_t)(k + 1) * Mp + i], x1, acc[q][1]);
+                    }
+                }
+            }
+            for (; k < M; ++k) {
+                const double x0 = xs[k];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < Mp) acc[q][0] = fma(PinvT[(size_t)k * Mp + i], x0, acc[q][0]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = (acc[q][0] + acc[q][1]) * dpv[q];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = 0.0;
+            k = 0;
+            for (; k + 2 <= M; k += 2) {
+                const double x0 = xs[k], x1 = xs[k + 1];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < Mp) {
+                        acc[q][0] = fma(PT[(size_t)k * Mp + i], x0, acc[q][0]);
+                        acc[q][1] = fma(PT[(size_t)(k + 1) * Mp + i], x1, acc[q][1]);
+                    }
+                }
+            }
+            for (; k < M; ++k) {
+                const double x0 = xs[k];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < Mp) acc[q][0] = fma(PT[(size_t)k * Mp + i], x0, acc[q][0]);
+                }
+            }
+            double part = 0.0;
+            double av[NPL];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const int i = lane + 64 * q;
+                av[q] = (i < M) ? (acc[q][0] + acc[q][1]) : 0.0;
+                part += av[q];
+            }
+            const double s = wave_sum(part);
+            cval = s;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) al[q] = (float)(av[q] / s);
+            __syncthreads();
+        }
+        // clamp without renormalising (hmm.cpp:92-94)
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = lane + 64 * q;
+            if (i < M) { if (al[q] < 1e-10f) al[q] = 1e-10f; } else al[q] = 0.f;
+            if (i < Mp) a.alpha[(size_t)(ch.base + ell) * Mp + i] = al[q];
+        }
+        if (lane == 0) a.cnorm[ch.base + ell] = cval;
+        ri = rn;
+    }
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) end_cur[i] = al[q]; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2: backward chain pass  (hmm.cpp:97-149, beta lines 123-127,139,142)
+// beta[ell] = the vector the reference holds when it processes row ell; beta[0] = the final one.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NPL>
+__global__ __launch_bounds__(64) void k_bwd_pass(ChainArgs a) {
+    __shared__ double xs[NPL * 64];
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x;
+    const int M = a.M, Mp = a.Mp, pass = a.pass;
+    if (pass > 0 && a.changed[pass - 1] == 0) return;
+    const Chunk ch = a.chunks[c];
+    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
+    const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
+    double b[NPL];
+    if (pass > 0 && ch.last) {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) end_cur[i] = end_prev[i]; }
+        return;
+    }
+    {
+        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (c + 1)) * Mp;
+        const bool fresh = (ch.last || pass == 0);
+        const double u0 = 1.0 / (double)M;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = lane + 64 * q;
+            b[q] = (i < M) ? (fresh ? u0 : src[i]) : 0.0;
+        }
+    }
+    if (pass > 0) {
+        bool diff = false;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = lane + 64 * q;
+            if (i < M) {
+                const double u = a.used_b[(size_t)c * Mp + i];
+                if (!(fabs(b[q] - u) <= a.eps_b * fabs(u))) diff = true;
+            }
+        }
+        if (!__any(diff)) {
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) end_cur[i] = end_prev[i]; }
+            return;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) a.used_b[(size_t)c * Mp + i] = b[q]; }
+    if (lane == 0) a.changed[pass] = 1;
+    RowInfo ri = a.rowinfo[ch.base + ch.r1];
+    for (int ell = ch.r1; ell > ch.r0; --ell) {
+        const int nxt = (ell - 1 > ch.r0) ? ell - 1 : ell;
+        const RowInfo rn = a.rowinfo[ch.base + nxt];
+        ri.kid = __builtin_amdgcn_readfirstlane(ri.kid);
+        ri.gid = __builtin_amdgcn_readfirstlane(ri.gid);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = lane + 64 * q;
+            if (i < Mp) a.beta[(size_t)(ch.base + ell) * Mp + i] = b[q];
+        }
+        double bn[NPL];
+        if (ri.gid < 0) {
+            // beta <- T (B beta)   (hmm.cpp:139)
+            const double *e = a.E + (size_t)ri.kid * Mp;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const int i = lane + 64 * q;
+                xs[i] = (i < M) ? e[i] * b[q] : 0.0;
+            }
+            __syncthreads();
+            const double *TdT = a.TdT;
+            double acc[NPL][2];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = 0.0;
+            int k = 0;
+            for (; k + 2 <= M; k += 2) {
+                const double x0 = xs[k], x1 = xs[k + 1];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < Mp) {
+                        acc[q][0] = fma(TdT[(size_t)k * Mp + i], x0, acc[q][0]);
+                        acc[q][1] = fma(TdT[(size_t)(k + 1) * Mp + i], x1, acc[q][1]);
+                    }
+                }
+            }
+            for (; k < M; ++k) {
+                const double x0 = xs[k];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < Mp) acc[q][0] = fma(TdT[(size_t)k * Mp + i], x0, acc[q][0]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) bn[q] = acc[q][0] + acc[q][1];
+            __syncthreads();
+        } else {
+            // beta <- Pinv^T (d~^span o (P^T beta))   (hmm.cpp:123-127; the log/exp there only rescales)
+            const int es = a.g_eig[ri.gid];
+            const double *Prm = a.Prm + (size_t)es * Mp * Mp;
+            const double *Pinvrm = a.Pinvrm + (size_t)es * Mp * Mp;
+            const double *dp = a.dpow + (size_t)ri.gid * Mp;
+            double dpv[NPL];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; dpv[q] = (i < M) ? dp[i] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = b[q];
+            __syncthreads();
+            double acc[NPL][2];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = 0.0;
+            int k = 0;
+            for (; k + 2 <= M; k += 2) {
+                const double x0 = xs[k], x1 = xs[k + 1];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < Mp) {
+                        acc[q][0] = fma(Prm[(size_t)k * Mp + i], x0, acc[q][0]);
+                        acc[q][1] = fma(Prm[(size_t)(k + 1) * Mp + i], x1, acc[q][1]);
+                    }
+                }
+            }
+            for (; k < M; ++k) {
+                const double x0 = xs[k];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < Mp) acc[q][0] = fma(Prm[(size_t)k * Mp + i], x0, acc[q][0]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = (acc[q][0] + acc[q][1]) * dpv[q];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = 0.0;
+            k = 0;
+            for (; k + 2 <= M; k += 2) {
+                const double x0 = xs[k], x1 = xs[k + 1];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < Mp) {
+                        acc[q][0] = fma(Pinvrm[(size_t)k * Mp + i], x0, acc[q][0]);
+                        acc[q][1] = fma(Pinvrm[(size_t)(k + 1) * Mp + i], x1, acc[q][1]);
+                    }
+                }
+            }
+            for (; k < M; ++k) {
+                const double x0 = xs[k];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < Mp) acc[q][0] = fma(Pinvrm[(size_t)k * Mp + i], x0, acc[q][0]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) bn[q] = acc[q][0] + acc[q][1];
+            __syncthreads();
+        }
+        double part = 0.0;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = lane + 64 * q;
+            if (!(i < M)) bn[q] = 0.0;
+            part += bn[q];
+        }
+        const double s = wave_sum(part);                   // beta /= beta.sum()  (hmm.cpp:142)
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) b[q] = bn[q] / s;
+        ri = rn;
+    }
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int i = lane + 64 * q;
+        if (i < Mp) {
+            end_cur[i] = b[q];
+            if (ch.first) a.beta[(size_t)ch.base * Mp + i] = b[q];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K7: log-likelihood  ll = sum_ell log c_ell + span_ell log scale   (hmm.cpp:79,88,95)
+// ---------------------------------------------------------------------------------------------------------------
+struct LoglikArgs {
+    const double *cnorm;
+    const RowInfo *rowinfo;
+    const double *g_logscale;     // [G] span * log(scale)
+    const long long *contig_base; // [n_contigs]
+    const int *contig_L;          // [n_contigs]
+    double *partial;              // [n_contigs][nblk]
+    double *loglik;               // [n_contigs]
+    double *logc;                 // optional [rows]: log_c per row (needed by the span-1 weights)
+    int nblk;
+};
+
+__global__ __launch_bounds__(256) void k_loglik_partial(LoglikArgs a) {
+    __shared__ double red[256];
+    const int ct = blockIdx.y;
+    const long long base = a.contig_base[ct];
+    const int L = a.contig_L[ct];
+    const int per = (L + a.nblk - 1) / a.nblk;
+    const int lo = 1 + blockIdx.x * per;
+    const int hi = min(L, lo + per - 1);
+    double s = 0.0;
+    for (int ell = lo + threadIdx.x; ell <= hi; ell += 256) {
+        const RowInfo ri = a.rowinfo[base + ell];
+        double lc = log(a.cnorm[base + ell]);
+        if (ri.gid >= 0) lc += a.g_logscale[ri.gid];
+        a.logc[base + ell] = lc;
+        s += lc;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.partial[(size_t)ct * a.nblk + blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void k_loglik_final(LoglikArgs a) {
+    __shared__ double red[256];
+    const int ct = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < a.nblk; i += 256) s += a.partial[(size_t)ct * a.nblk + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.loglik[ct] = red[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K3: span-1 rows — per-row scalars and gamma sums  (hmm.cpp:134-138,146-148)
+//   v = alpha_ell o beta_ell / p,  p = sum(alpha_ell o beta_ell);  w1 = 1 / (exp(log_c) p)
+// One wavefront walks a slab of rows of one (contig, key) segment and keeps the running sum of v in registers.
+// ---------------------------------------------------------------------------------------------------------------
+struct Slab {
+    int start, end;    // range in the sorted row permutation
+    int bucket;        // accumulator the slab contributes to
+    int aux;           // span-1: kid; eigen: gid
+    long long base;    // contig base row
+};
+
+struct S1Args {
+    int M, Mp, nslabs;
+    const Slab *slabs;
+    const int *perm;          // sorted span-1 rows (contig-relative ell)
+    const float *alpha;
+    const double *beta;
+    const double *logc;
+    double *w1;               // [rows] per-row weight
+    double *gpart;            // [nslabs][Mp] partial gamma sums
+    double *gamma_rows;       // optional [rows][Mp] (save_gamma)
+};
+
+template <int NPL>
+__global__ __launch_bounds__(64) void k_s1_scalars(S1Args a) {
+    const int lane = threadIdx.x;
+    const Slab sl = a.slabs[blockIdx.x];
+    const int M = a.M, Mp = a.Mp;
+    double gs[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) gs[q] = 0.0;
+    for (int r = sl.start; r < sl.end; ++r) {
+        const int ell = a.perm[r];
+        const size_t row = (size_t)(sl.base + ell);
+        double v[NPL];
+        double part = 0.0;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = lane + 64 * q;
+            v[q] = (i < M) ? (double)a.alpha[row * Mp + i] * a.beta[row * Mp + i] : 0.0;
+            part += v[q];
+        }
+        const double p = wave_sum(part);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            v[q] /= p;
+            gs[q] += v[q];
+            const int i = lane + 64 * q;
+            if (a.gamma_rows && i < Mp) a.gamma_rows[row * Mp + i] = v[q];
+        }
+        if (lane == 0) a.w1[row] = 1.0 / (exp(a.logc[row]) * p);
+    }
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int i = lane + 64 * q;
+        if (i < Mp) a.gpart[(size_t)blockIdx.x * Mp + i] = gs[q];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K5: eigen rows — U = Pinv alpha_{ell-1}, W = P^T beta_ell, omega = 1 / (scale * sum_j d~_j^span U_j W_j)
+// (the exact normaliser of hmm.cpp:116-122) with fp64 MFMA; writes omega*U and W, 16 rows per
+// wavefront iteration.  MFMA f64 16x16x4 operand map: A[m = l&15][k = l>>4], B[k = l>>4][n = l&15],
+// D[row = (l>>4) + 4*reg][col = l&15].
+// ---------------------------------------------------------------------------------------------------------------
+struct UWArgs {
+    int M, Mp, nslabs;
+    const Slab *slabs;
+    const int *perm;          // sorted eigen rows (contig-relative ell)
+    const float *alpha;
+    const double *beta;
+    const int *g_eig;
+    const double *g_scale;    // [G] eigen scale of the group's key
+    const double *dpow;       // [G][Mp]
+    const double *PinvT;      // [Ke][Mp][Mp]
+    const double *Prm;        // [Ke][Mp][Mp]
+    double *Xs;               // [n eigen rows][Mp]  omega * U   (indexed by position in perm)
+    double *Ys;               // [n eigen rows][Mp]  W
+};
+
+template <int NT>   // NT = Mp / 16 state tiles
+__global__ __launch_bounds__(64) void k_eig_uw(UWArgs a) {
+    const int lane = threadIdx.x;
+    const int m = lane & 15, qd = lane >> 4;
+    const Slab sl = a.slabs[blockIdx.x];
+    const int Mp = a.Mp;
+    const int es = a.g_eig[sl.aux];
+    const double *PinvT = a.PinvT + (size_t)es * Mp * Mp;
+    const double *Prm = a.Prm + (size_t)es * Mp * Mp;
+    const double *dp = a.dpow + (size_t)sl.aux * Mp;
+    const double scale = a.g_scale[sl.aux];
+    for (int r0 = sl.start; r0 < sl.end; r0 += 16) {
+        // A operands: data rows.  lane (m, qd) feeds row r0+m, state 4*kk+qd.
+        const int ra = r0 + m;
+        const bool va = ra < sl.end;
+        const int ell_a = va ? a.perm[ra] : 1;
+        const float *arow = a.alpha + (size_t)(sl.base + ell_a - 1) * Mp;   // alpha_{ell-1}
+        const double *brow = a.beta + (size_t)(sl.base + ell_a) * Mp;       // beta_ell
+        f64x4 U[NT], W[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { U[t] = (f64x4){0, 0, 0, 0}; W[t] = (f64x4){0, 0, 0, 0}; }
+        for (int kk = 0; kk < Mp / 4; ++kk) {
+            const int st = 4 * kk + qd;
+            const double av = va ? (double)arow[st] : 0.0;
+            const double bv = va ? brow[st] : 0.0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const double pinv = PinvT[(size_t)st * Mp + 16 * t + m];   // B[k=st][n=16t+m] = Pinv[16t+m][st]
+                const double pp = Prm[(size_t)st * Mp + 16 * t + m];       // B[k=st][n=16t+m] = P[st][16t+m]
+                U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pinv, U[t], 0, 0, 0);
+                W[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, pp, W[t], 0, 0, 0);
+            }
+        }
+        // D layout: lane (m, qd), reg r holds [data row r0 + qd + 4r][state 16t + m]
+        double om[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double part = 0.0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) part += dp[16 * t + m] * U[t][r] * W[t][r];
+            const double s = row16_sum(part);
+            om[r] = 1.0 / (scale * s);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = r0 + qd + 4 * r;
+            if (rr < sl.end) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    a.Xs[(size_t)rr * Mp + 16 * t + m] = om[r] * U[t][r];
+                    a.Ys[(size_t)rr * Mp + 16 * t + m] = W[t][r];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K4: rank-k accumulation  C_slab[j][k] = sum_rows X_row[j] * Y_row[k]   (fp64 MFMA, 64x64 output block per wave)
+//   MODE 0 (span-1 rows, hmm.cpp:137-138):  X = w1 * alpha_{ell-1},  Y = beta_ell o e_key
+//   MODE 1 (eigen rows):                    X = Xs[pos] (= omega U), Y = Ys[pos] (= W)
+// grid = (nslabs, NB*NB) with NB = ceil(Mp/64); blockIdx.y selects the 64x64 block of the M x M output.
+// ---------------------------------------------------------------------------------------------------------------
+struct AccArgs {
+    int M, Mp, nslabs, NB;
+    const Slab *slabs;
+    const int *perm;
+    const RowInfo *rowinfo;
+    const float *alpha;
+    const double *beta;
+    const double *w1;
+    const double *E;
+    const double *Xs, *Ys;
+    double *part;             // [nslabs][Mp][Mp]
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
+    const int lane = threadIdx.x;
+    const int m = lane & 15, qd = lane >> 4;
+    const Slab sl = a.slabs[blockIdx.x];
+    const int Mp = a.Mp;
+    const int jb = (blockIdx.y / a.NB) * 64, kb = (blockIdx.y % a.NB) * 64;
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
+    for (int r0 = sl.start; r0 < sl.end; r0 += 4) {
+        const int r = r0 + qd;                 // this lane's data row (the MFMA k index)
+        const bool valid = r < sl.end;
+        double xa[4], yb[4];
+        if (MODE == 0) {
+            const int ell = valid ? a.perm[r] : 1;
+            const size_t row = (size_t)(sl.base + ell);
+            const double w = valid ? a.w1[row] : 0.0;
+            const int kid = a.rowinfo[row].kid;
+            const float *ap = a.alpha + (row - 1) * Mp;
+            const double *bp = a.beta + row * Mp;
+            const double *ep = a.E + (size_t)kid * Mp;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = jb + 16 * t + m, k = kb + 16 * t + m;
+                xa[t] = (valid && j < Mp) ? w * (double)ap[j] : 0.0;
+                yb[t] = (valid && k < Mp) ? bp[k] * ep[k] : 0.0;
+            }
+        } else {
+            const size_t row = (size_t)(valid ? r : sl.start);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = jb + 16 * t + m, k = kb + 16 * t + m;
+                xa[t] = (valid && j < Mp) ? a.Xs[row * Mp + j] : 0.0;
+                yb[t] = (valid && k < Mp) ? a.Ys[row * Mp + k] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], yb[j], acc[i][j], 0, 0, 0);
+    }
+    double *out = a.part + (size_t)blockIdx.x * Mp * Mp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row = jb + 16 * i + qd + 4 * rg;   // D row
+                const int col = kb + 16 * j + m;             // D col
+                if (row < Mp && col < Mp) out[(size_t)row * Mp + col] = acc[i][j][rg];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K6: finalisation
+// ---------------------------------------------------------------------------------------------------------------
+struct FinArgs {
+    int M, Mp, K, G, Ke, n_contigs;
+    // bucket bookkeeping
+    const int *eb_slab_off;   // [n_ebuckets+1] slabs of eigen bucket b are eb_slab_off[b] .. eb_slab_off[b+1]
+    const int *eb_gid;        // [n_ebuckets]
+    const int *ce_bucket_off; // [n_contigs*Ke + 1] eigen buckets of (contig, eigen key)
+    const int *s1_slab_off;   // [n_contigs + 1] span-1 rank slabs per contig (for X1)
+    const int *gk_slab_off;   // [n_contigs*K + 1] span-1 scalar slabs per (contig, key) (for gamma sums)
+    const int *g_span;        // [G]
+    const int *e_kid;         // [Ke] key id of eigen system
+    const double *dsc;        // [Ke][Mp] scaled eigenvalues
+    const double *dun;        // [Ke][Mp] unscaled eigenvalues
+    const double *Prm, *Pinvrm;   // [Ke][Mp][Mp]
+    const double *E;          // [K][Mp]
+    const double *Td;         // [Mp][Mp] row-major
+    const double *part_e;     // [n eigen slabs][Mp][Mp]
+    const double *part_1;     // [n span-1 rank slabs][Mp][Mp]
+    const double *gpart;      // [n span-1 scalar slabs][Mp]
+    const float *alpha;
+    const double *beta;
+    const long long *contig_base;
+    double *Z;                // [n_contigs*Ke][Mp][Mp]
+    double *Y;                // [n_contigs*Ke][Mp][Mp]
+    double *xisum;            // [n_contigs][Mp][Mp]
+    double *gsum;             // [n_contigs][K][Mp]
+    double *gamma0;           // [n_contigs][Mp]
+};
+
+// span_Qs entry (transition_bundle.cpp:29-59) evaluated on the fly
+__device__ __forceinline__ double span_q_elem(const double *dsc, int a, int b, int span) {
+    double d1 = dsc[a];
+    if (a == b) return pow(d1, span - 1) * (double)span;
+    double d2 = dsc[b];
+    if (fabs(d1) < fabs(d2)) { const double t = d1; d1 = d2; d2 = t; }
+    if (d1 == d2) return pow(d1, span - 1) * (double)span;   // limit; the reference formula is 0/0 here
+    const double q = exp((double)span * log(d1) + log1p(-pow(d2 / d1, span)));
+    return q / (d1 - d2);
+}
+
+// Z[(contig,e)][j][k] = sum over groups g of key e:  S_g[j][k] * Acc[contig][g][j][k]
+__global__ __launch_bounds__(256) void k_fin_Z(FinArgs a) {
+    const int ce = blockIdx.y;                    // contig * Ke + e
+    const int e = ce % a.Ke;
+    const int Mp = a.Mp, M = a.M;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Mp * Mp) return;
+    const int j = idx / Mp, k = idx % Mp;
+    double z = 0.0;
+    if (j < M && k < M) {
+        const double *dsc = a.dsc + (size_t)e * Mp;
+        for (int b = a.ce_bucket_off[ce]; b < a.ce_bucket_off[ce + 1]; ++b) {
+            double acc = 0.0;
+            for (int s = a.eb_slab_off[b]; s < a.eb_slab_off[b + 1]; ++s) acc += a.part_e[(size_t)s * Mp * Mp + idx];
+            z += span_q_elem(dsc, j, k, a.g_span[a.eb_gid[b]]) * acc;
+        }
+    }
+    a.Z[(size_t)ce * Mp * Mp + idx] = z;
+}
+
+// Y = Z * Pinv
+__global__ __launch_bounds__(256) void k_fin_Y(FinArgs a) {
+    const int ce = blockIdx.y;
+    const int e = ce % a.Ke;
+    const int Mp = a.Mp;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Mp * Mp) return;
+    const int j = idx / Mp, i = idx % Mp;
+    const double *Z = a.Z + (size_t)ce * Mp * Mp + (size_t)j * Mp;
+    const double *Pinv = a.Pinvrm + (size_t)e * Mp * Mp;
+    double s = 0.0;
+    for (int k = 0; k < a.M; ++k) s = fma(Z[k], Pinv[(size_t)k * Mp + i], s);
+    a.Y[(size_t)ce * Mp * Mp + idx] = s;
+}
+
+// xisum[contig] = max( (X1 + sum_e P_e Y_e diag(b_e)) o Td , 1e-20 )   (hmm.cpp:122,141,151-152)
+__global__ __launch_bounds__(256) void k_fin_xisum(FinArgs a) {
+    const int ct = blockIdx.y;
+    const int Mp = a.Mp, M = a.M;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Mp * Mp) return;
+    const int i = idx / Mp, k = idx % Mp;
+    double x = 0.0;
+    if (i < M && k < M) {
+        for (int s = a.s1_slab_off[ct]; s < a.s1_slab_off[ct + 1]; ++s) x += a.part_1[(size_t)s * Mp * Mp + idx];
+        for (int e = 0; e < a.Ke; ++e) {
+            const int ce = ct * a.Ke + e;
+            if (a.ce_bucket_off[ce] == a.ce_bucket_off[ce + 1]) continue;
+            const double *P = a.Prm + (size_t)e * Mp * Mp + (size_t)i * Mp;
+            const double *Y = a.Y + (size_t)ce * Mp * Mp;
+            double s = 0.0;
+            for (int j = 0; j < M; ++j) s = fma(P[j], Y[(size_t)j * Mp + k], s);
+            x += s * a.E[(size_t)a.e_kid[e] * Mp + k];
+        }
+        x *= a.Td[(size_t)i * Mp + k];
+        if (x < 1e-20) x = 1e-20;
+    }
+    a.xisum[(size_t)ct * Mp * Mp + idx] = x;
+}
+
+// gamma_sums[contig][key] and gamma0[contig]   (hmm.cpp:116-121,146,150)
+__global__ __launch_bounds__(256) void k_fin_gamma(FinArgs a) {
+    const int ct = blockIdx.y;
+    const int Mp = a.Mp, M = a.M;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (a.K + 1) * Mp) return;
+    const int k = idx / Mp, i = idx % Mp;
+    if (k == a.K) {                               // gamma.col(0) = alpha_0 o beta_0 (not normalised)
+        const size_t row = (size_t)a.contig_base[ct];
+        a.gamma0[(size_t)ct * Mp + i] = (i < M) ? (double)a.alpha[row * Mp + i] * a.beta[row * Mp + i] : 0.0;
+        return;
+    }
+    double g = 0.0;
+    if (i < M) {
+        const int ck = ct * a.K + k;
+        for (int s = a.gk_slab_off[ck]; s < a.gk_slab_off[ck + 1]; ++s) g += a.gpart[(size_t)s * Mp + i];
+        for (int e = 0; e < a.Ke; ++e) {
+            if (a.e_kid[e] != k) continue;
+            const int ce = ct * a.Ke + e;
+            if (a.ce_bucket_off[ce] == a.ce_bucket_off[ce + 1]) continue;
+            const double *P = a.Prm + (size_t)e * Mp * Mp + (size_t)i * Mp;
+            const double *Y = a.Y + (size_t)ce * Mp * Mp;
+            const double *d = a.dun + (size_t)e * Mp;
+            double s = 0.0;
+            for (int j = 0; j < M; ++j) s = fma(P[j] * d[j], Y[(size_t)j * Mp + i], s);
+            g += s;
+        }
+    }
+    a.gsum[((size_t)ct * a.K + k) * Mp + i] = g;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K8: per-row gamma of eigen rows for save_gamma  (hmm.cpp:113-121,147-148)
+//   g_i = sum_j P_ij d_j u_j (sum_k S_jk w_k Pinv_ki);  gamma_row = span * |g| / sum |g|
+// One workgroup (256 threads) per row; S is evaluated once per group into a table by k_span_q.
+// ---------------------------------------------------------------------------------------------------------------
+struct GammaRowArgs {
+    int M, Mp, nrows;
+    const int *perm;          // eigen rows (position p -> contig-relative ell), sorted by bucket
+    const int *row_slab;      // [nrows] slab index of each position (to find base / gid)
+    const Slab *slabs;
+    const int *g_eig;
+    const int *g_span;
+    const double *dun;        // [Ke][Mp]
+    const double *Prm, *Pinvrm, *PinvT;
+    const double *Sq;         // [G][Mp][Mp] span-Q tables
+    const float *alpha;
+    const double *beta;
+    double *gamma_rows;       // [rows][Mp]
+};
+
+__global__ __launch_bounds__(256) void k_span_q(int M, int Mp, int G, const int *g_span, const int *g_eig,
+                                                const double *dsc, double *Sq) {
+    const int g = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Mp * Mp) return;
+    const int j = idx / Mp, k = idx % Mp;
+    double v = 0.0;
+    if (j < M && k < M) v = span_q_elem(dsc + (size_t)g_eig[g] * Mp, j, k, g_span[g]);
+    Sq[(size_t)g * Mp * Mp + idx] = v;
+}
+
+__global__ __launch_bounds__(256) void k_gamma_rows_eig(GammaRowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int Mp = a.Mp, M = a.M;
+    double *u = sm, *w = sm + Mp, *g = sm + 2 * Mp, *red = sm + 3 * Mp;   // red[256]
+    const int p = blockIdx.x;
+    const Slab sl = a.slabs[a.row_slab[p]];
+    const int gid = sl.aux;
+    const int es = a.g_eig[gid];
+    const int span = a.g_span[gid];
+    const int ell = a.perm[p];
+    const size_t row = (size_t)(sl.base + ell);
+    const double *Prm = a.Prm + (size_t)es * Mp * Mp;
+    const double *Pinvrm = a.Pinvrm + (size_t)es * Mp * Mp;
+    const double *PinvT = a.PinvT + (size_t)es * Mp * Mp;
+    const double *S = a.Sq + (size_t)gid * Mp * Mp;      // symmetric
+    const double *d = a.dun + (size_t)es * Mp;
+    const int tid = threadIdx.x;
+    // u_j <- d_j * (Pinv alpha_{ell-1})_j ; w = P^T beta_ell
+    for (int i = tid; i < Mp; i += 256) {
+        double su = 0.0, sw = 0.0;
+        if (i < M) {
+            const float *ap = a.alpha + (row - 1) * Mp;
+            const double *bp = a.beta + row * Mp;
+            for (int j = 0; j < M; ++j) {
+                su = fma(PinvT[(size_t)j * Mp + i], (double)ap[j], su);
+                sw = fma(Prm[(size_t)j * Mp + i], bp[j], sw);
+            }
+            su *= d[i];
+        }
+        u[i] = su; w[i] = sw;
+    }
+    __syncthreads();
+    // g_i = sum_k w_k Pinv_ki H_ik,  H_ik = sum_j (P_ij d_j u_j) S_jk.  Threads = TI states x KP slices of k.
+    int TI = 1;
+    while (TI < Mp && TI < 256) TI <<= 1;
+    const int KP = 256 / TI;
+    const int il = tid % TI, kp = tid / TI;
+    double tot = 0.0;
+    for (int i0 = 0; i0 < Mp; i0 += TI) {
+        const int i = i0 + il;
+        double gi = 0.0;
+        if (i < M) {
+            const double *Pi = Prm + (size_t)i * Mp;
+            for (int k = kp; k < M; k += KP) {
+                const double *Sk = S + (size_t)k * Mp;
+                double h = 0.0;
+                for (int j = 0; j < M; ++j) h = fma(Pi[j] * u[j], Sk[j], h);
+                gi = fma(w[k] * Pinvrm[(size_t)k * Mp + i], h, gi);
+            }
+        }
+        red[tid] = gi;
+        __syncthreads();
+        if (kp == 0 && i < Mp) {
+            double sacc = 0.0;
+            for (int t = 0; t < KP; ++t) sacc += red[t * TI + il];
+            g[i] = (i < M) ? fabs(sacc) : 0.0;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < M; i += 256) tot += g[i];
+    red[tid] = tot;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    const double sum = red[0];
+    for (int i = tid; i < Mp; i += 256)
+        a.gamma_rows[row * Mp + i] = (i < M) ? (double)span * g[i] / sum : 0.0;
+}
+
+// argmax over states per row (posterior decoding indices)
+__global__ __launch_bounds__(256) void k_gamma_argmax(int M, int Mp, long long nrows, const double *gamma_rows, int *out) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrows) return;
+    const double *g = gamma_rows + (size_t)r * Mp;
+    int best = 0;
+    double bv = g[0];
+    for (int i = 1; i < M; ++i)
+        if (g[i] > bv) { bv = g[i]; best = i; }
+    out[r] = best;
+}
+
+}  // namespace smcpp_dev

@@ -1,0 +1,131 @@
+"""Parity of the HIP E-step (through the C ABI) with the golden vectors emitted by the compiled reference and with
+the C restatement (oracle/) on the same inputs.
+
+Tolerances (BASELINE.json north_star):
+  * log-likelihood: 1e-6 relative (observed ~1e-9: alpha_hat is float in the reference and here);
+  * posterior decoding indices argmax_m gamma[m, ell]: identical on every column whose reference top-1/top-2
+    relative margin exceeds 1e-5 (columns below it are reported);
+  * xisum / gamma_sums / Q: 5e-6 relative — the float-alpha noise floor of the reference itself.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+LL_TOL = 1e-6
+STAT_TOL = 5e-6
+
+
+def make_im(g, **kw):
+    from smcpp_amd import _smcpp
+    obs = np.ascontiguousarray(g["obs"], dtype=np.int32)
+    if obs.shape[1] == 4:
+        im = _smcpp.PyOnePopInferenceManager(int(g["n"]), [obs], g["hs"], ("pop1",), float(g["pol"]))
+    else:
+        im = _smcpp.PyTwoPopInferenceManager(10, 10, 2, 0, [obs], g["hs"], ("pop1", "pop2"), float(g["pol"]))
+    im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = float(g["alpha"])
+    im.set_raw(g["pi"], g["T"], g["keys"], g["E"])
+    return im
+
+
+def check_against(g, im, save_gamma):
+    ll = im.loglik()
+    assert abs(ll - float(g["loglik"])) <= LL_TOL * abs(float(g["loglik"])), (ll, float(g["loglik"]))
+    xs = im.xisums[0]
+    assert rel_err(xs, g["xisum"]) <= STAT_TOL
+    gs = im.gamma_sums[0]
+    ref_keys = [tuple(int(x) for x in k) for k in g["gs_keys"]]
+    assert sorted(gs.keys()) == sorted(ref_keys)
+    for k, v in zip(ref_keys, g["gs_vals"]):
+        scale = max(np.abs(v).max(), 1e-300)
+        assert np.max(np.abs(gs[k] - v)) <= STAT_TOL * scale, k
+    q = np.array(im.Q(separate=True))
+    assert np.all(np.abs(q - g["q"]) <= STAT_TOL * np.maximum(np.abs(g["q"]), 1e-12)), (q, g["q"])
+    gam = im.gammas[0]
+    if not save_gamma:
+        assert gam.shape == (len(g["pi"]), 1)
+        assert rel_err(gam[:, 0], g["gamma0"]) <= STAT_TOL
+        return
+    L = len(g["obs"])
+    assert gam.shape == (len(g["pi"]), L + 1)
+    st = int(g["gamma_stride"])
+    sub = gam[:, ::st]
+    assert np.max(np.abs(sub - g["gamma_sub"])) <= 2e-5 * max(1.0, float(np.abs(g["gamma_sub"]).max()))
+    arg = gam.argmax(axis=0)
+    strong = g["gamma_margin"] > 1e-5
+    mism = np.nonzero(arg != g["gamma_argmax"])[0]
+    assert not np.any(strong[mism]), f"posterior argmax differs on columns {mism[strong[mism]][:10]}"
+    arg_dev = im.gamma_argmax(0)
+    assert np.array_equal(arg_dev, arg.astype(np.int32))
+
+
+def test_golden_stats(golden):
+    im = make_im(golden)
+    im.E_step()
+    check_against(golden, im, save_gamma=False)
+
+
+def test_golden_posterior(golden):
+    im = make_im(golden)
+    im.save_gamma = True
+    im.E_step()
+    check_against(golden, im, save_gamma=True)
+
+
+@pytest.mark.parametrize("rows_per_chunk", [37, 100, 1000000])
+def test_chunking_invariance(rows_per_chunk):
+    """The chunk-parallel chains must reproduce the single-chunk (purely sequential) run."""
+    g = load_golden("G4_M64_n20_2Mbp")
+    im = make_im(g)
+    im.set_chunking(rows_per_chunk)
+    im.E_step()
+    check_against(g, im, save_gamma=False)
+    t = im.last_timing()
+    if rows_per_chunk >= 1000000:
+        assert t["fwd_passes"] == 1 and t["bwd_passes"] == 1
+
+
+def test_vs_oracle_random_small():
+    """Seeded random inputs at a size the C restatement finishes in a second, several contigs of ragged length."""
+    from oracle import oracle
+    from smcpp_amd import _smcpp, synth
+    g = load_golden("G3_M32_n10_2Mbp")
+    contigs = [synth.synth_contig(10 + i, L, 10) for i, L in enumerate([300_000, 100, 70_000, 1_000_000])]
+    contigs[1] = contigs[1][:1]                      # a one-row contig
+    im = _smcpp.PyOnePopInferenceManager(10, contigs, g["hs"], ("pop1",), 0.5)
+    im.theta = float(g["theta"]); im.rho = float(g["rho"])
+    im.set_raw(g["pi"], g["T"], g["keys"], g["E"])
+    im.E_step()
+    lls = im.logliks()
+    xs = im.xisums
+    gss = im.gamma_sums
+    qtot = np.zeros(4)
+    for c, ob in enumerate(contigs):
+        o = oracle.estep(g["pi"], g["T"], g["keys"], g["E"], ob)
+        assert abs(lls[c] - o["loglik"]) <= LL_TOL * abs(o["loglik"])
+        assert rel_err(xs[c], o["xisum"]) <= STAT_TOL
+        assert sorted(gss[c].keys()) == sorted(o["gamma_sums"].keys())
+        for k, v in o["gamma_sums"].items():
+            assert np.max(np.abs(gss[c][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300)
+        qtot += o["q"]
+    q = np.array(im.Q(separate=True))
+    assert np.all(np.abs(q - qtot) <= STAT_TOL * np.abs(qtot))
+
+
+def test_errors():
+    from smcpp_amd import _smcpp
+    g = load_golden("G1_M16_n4")
+    with pytest.raises(RuntimeError, match="empty"):
+        _smcpp.PyOnePopInferenceManager(4, [], g["hs"], ("p",), 0.5)
+    with pytest.raises(RuntimeError, match="ascending"):
+        _smcpp.PyOnePopInferenceManager(4, [g["obs"]], g["hs"][::-1].copy(), ("p",), 0.5)
+    bad = g["obs"].copy(); bad[5, 0] = 0
+    with pytest.raises(RuntimeError, match="span <= 0"):
+        _smcpp.PyOnePopInferenceManager(4, [bad], g["hs"], ("p",), 0.5)
+    im = _smcpp.PyOnePopInferenceManager(4, [g["obs"]], g["hs"], ("p",), 0.5)
+    with pytest.raises(RuntimeError):
+        im.E_step()                                   # no parameters yet
+    with pytest.raises(RuntimeError, match="same size"):
+        im.hidden_states = [0.0, 1.0]

@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py — E-step loglik-evals/sec of the MI355X-native SMC++ engine (BASELINE.json metric).
+
+One "step" = one eval of SURVEY.md §8(d): parameters marked dirty -> E-step (host eigensystem prep + upload +
+forward/backward chains + sufficient statistics on the GPU) -> loglik, over this rank's contig(s), with the
+observation arrays already resident in HBM (they are uploaded when the inference manager is constructed).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c5] [--no-cpu] [--chunk ROWS]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank owns one synthetic 100 Mbp contig (weak
+scaling, contigs are independent HMMs) and the ranks exchange ONE all-reduce(sum, fp64) of the packed
+[loglik | gamma0 | xisum | gamma_sums] statistics per step over RCCL.
+
+Prints one JSON line with the contract fields plus "roofline" (dominant kernel, timed live with HIP events on the
+engine's own stream) and "cpu_baseline" (the compiled reference `oracle/_ref` — or the C restatement `oracle/` if
+that is absent — timed on this box's host cores on a bounded prefix of the same contig).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (M, n, params fixture, description)
+    "headline": (64, 20, "params_M64_n20.npz", "1 synthetic 100 Mbp contig per GPU, M=64, n=20 (BASELINE.json metric shape)"),
+    "c2": (32, 10, "params_M32_n10.npz", "1 synthetic 100 Mbp contig per GPU, M=32, n=10 (configs[1])"),
+    "c5": (256, 50, "params_M256_n50.npz", "1 synthetic 100 Mbp contig per GPU, M=256, n=50 (configs[4])"),
+}
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector = matrix peak (AMD spec)
+
+
+def algorithmic_work(obs, M):
+    """Algorithmic flops / bytes of ONE pass of the dominant (forward chain) kernel, DESIGN.md §Kernels:
+    span-1 row: 2 M^2 (one mat-vec); span>1 row: 4 M^2 (two mat-vecs).  Bytes: alpha write 4M + row descriptor 8 +
+    normaliser 8 + emission row read 8M."""
+    R1 = int((obs[:, 0] == 1).sum())
+    Re = len(obs) - R1
+    flops = 2.0 * M * M * R1 + 4.0 * M * M * Re
+    nbytes = len(obs) * (4.0 * M + 8.0 * M + 16.0)
+    return flops, nbytes, R1, Re
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    ap.add_argument("--length-mbp", type=float, default=100.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--eps-alpha", type=float, default=0.0)
+    ap.add_argument("--eps-beta", type=float, default=0.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from smcpp_amd import _smcpp, synth
+    M, n, fixture, desc = WORKLOADS[args.workload]
+    par = np.load(os.path.join(ROOT, "tests", "golden", fixture))
+    length_bp = int(args.length_mbp * 1e6)
+    obs = synth.synth_contig(rank, length_bp, n)         # contig index = rank: independent contigs, weak scaling
+    im = _smcpp.PyOnePopInferenceManager(n, [obs], par["hs"], ("pop1",), float(par["pol"]), device=local_rank)
+    im.theta = float(par["theta"]); im.rho = float(par["rho"]); im.alpha = float(par["alpha"])
+    if args.chunk or args.eps_alpha or args.eps_beta:
+        im.set_chunking(args.chunk, args.eps_alpha, args.eps_beta)
+    if world > 1:
+        # global key dictionary so the packed gamma_sums blocks line up across ranks
+        mine = [tuple(int(x) for x in k) for k in im.keys]
+        allk = [None] * world
+        dist.all_gather_object(allk, mine)
+        gkeys = sorted(set(k for ks in allk for k in ks))
+        im.set_global_keys(np.array(gkeys, dtype=np.int32))
+    pi, T, keys, E = par["pi"], par["T"], par["keys"], par["E"]
+
+    stats_buf = None
+
+    def one_eval():
+        nonlocal stats_buf
+        im.set_raw(pi, T, keys, E)          # parameters dirty: eigensystems, uploads, everything is redone
+        im.E_step()
+        if world > 1:
+            h = im.pack_stats()
+            if stats_buf is None:
+                stats_buf = torch.empty(len(h), dtype=torch.float64, device=dev)
+            stats_buf.copy_(torch.from_numpy(h))
+            dist.all_reduce(stats_buf, op=dist.ReduceOp.SUM)       # the single collective of the E-step
+            im.unpack_stats(stats_buf.cpu().numpy())
+            return float(stats_buf[0].item())
+        return im.loglik()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_eval()
+    barrier()
+    timings = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ll = one_eval()
+        timings.append(im.last_timing())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.steps / elapsed                 # contig-E-step evals per second, whole job
+
+    # ---- roofline of the dominant kernel (forward chain pass), timed live with HIP events ----
+    # smcpp_last_timing brackets the forward / backward pass launches with hipEvents recorded on the engine's stream.
+    fwd_ms = float(np.median([t["forward_ms"] for t in timings]))
+    bwd_ms = float(np.median([t["backward_ms"] for t in timings]))
+    fpasses = float(np.median([t["fwd_passes"] for t in timings]))
+    bpasses = float(np.median([t["bwd_passes"] for t in timings]))
+    flops, nbytes, R1, Re = algorithmic_work(obs, M)
+    launches = max(fpasses, 1.0)
+    per_launch_s = 1e-3 * fwd_ms / launches
+    ach_tflops = flops / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
+    ach_gbs = nbytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+    if ach_gbs / HBM_PEAK_GBS >= ach_tflops / FP64_PEAK_TFLOPS:
+        roof = dict(bound="hbm", achieved=ach_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach_gbs / HBM_PEAK_GBS)
+    else:
+        roof = dict(bound="mfma", achieved=ach_tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=ach_tflops / FP64_PEAK_TFLOPS)
+    roof.update(traffic=None, kernel="k_fwd_pass", launches_per_step=launches, avg_launch_ms=1e3 * per_launch_s,
+                algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=nbytes)
+
+    out = None
+    if rank == 0:
+        med = {k: float(np.median([t[k] for t in timings])) for k in timings[0]}
+        out = {
+            "metric": "E-step loglik-evals/sec (100 Mbp, M=64, n=20)" if args.workload == "headline"
+            else f"E-step loglik-evals/sec ({args.length_mbp:g} Mbp, M={M}, n={n})",
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "M": M, "n": n, "rows_per_contig": int(len(obs)),
+                       "span1_rows": R1, "eigen_rows": Re, "contigs_per_gpu": 1, "length_mbp": args.length_mbp,
+                       "loglik": ll, "parallelism": f"contig-sharded x{world}, 1 all-reduce/E-step" if world > 1 else "single GPU"},
+            "split_ms": med,
+            "roofline": roof,
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(par, obs, args.cpu_seconds, M)
+            if out["cpu_baseline"] and out["cpu_baseline"].get("value"):
+                out["speedup_vs_cpu_1core"] = (value / world) / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(par, obs, budget_s, M):
+    """The reference's own C++ E-step (oracle/_ref, compiled from /root/reference/src in the build container) on
+    one host core, on a prefix of the same contig sized to ~budget_s seconds; evals/s are scaled by row count
+    (the reference's cost is linear in rows: one thread per contig, inference_manager.cpp:89-94)."""
+    try:
+        from oracle import ref
+        kind = "reference" if ref.available() else "port"
+        if kind == "port":
+            from oracle import oracle as orc
+        pi, T, keys, E = par["pi"], par["T"], par["keys"], par["E"]
+        probe = min(len(obs), 2000)
+        t = time.perf_counter()
+        (ref.estep if kind == "reference" else orc.estep)(pi, T, keys, E, obs[:probe])
+        per_row = (time.perf_counter() - t) / probe
+        rows = int(min(len(obs), max(probe, budget_s / per_row)))
+        t = time.perf_counter()
+        r = (ref.estep if kind == "reference" else orc.estep)(pi, T, keys, E, obs[:rows])
+        dt = time.perf_counter() - t
+        full = dt * len(obs) / rows
+        return {"value": 1.0 / full, "unit": "evals/s", "cores": 1, "kind": kind,
+                "sample": f"first {rows} of {len(obs)} rows of the same contig in {dt:.1f} s, scaled by row count "
+                          f"(1 thread = 1 contig, as the reference parallelises); host has {os.cpu_count()} cores",
+                "us_per_row": 1e6 * dt / rows, "loglik_prefix": r["loglik"]}
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "error": repr(e)}
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,15 @@ using namespace smcpp_dev;
 
 static thread_local std::string g_err;
 
+// libomp keeps its workers spinning for 200 ms after a parallel region by default; that steals the cores the HIP
+// runtime's own threads need between the short host-side parallel loops of an E-step.
+extern "C" void kmp_set_blocktime(int) __attribute__((weak));
+namespace {
+struct OmpInit {
+    OmpInit() { if (kmp_set_blocktime) kmp_set_blocktime(0); }
+} g_omp_init;
+}
+
 #define HIPCHK(x)                                                                                              \
     do {                                                                                                       \
         hipError_t e_ = (x);                                                                                   \
@@ -107,6 +116,11 @@ struct smcpp_im {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8];
     DevBuf<RowInfo> d_rowinfo;
+    DevBuf<int2> d_rowdesc;
+    DevBuf<float> d_T4;
+    DevBuf<double> d_fA2, d_fB2, d_bA2, d_bB2, d_bC2;
+    int wpb = 4;
+    int hot_eig = -1;
     DevBuf<Chunk> d_chunks;
     DevBuf<Slab> d_slabs_sc, d_slabs_rk, d_slabs_eg;
     DevBuf<int> d_perm1, d_perme, d_gk_slab_off, d_s1_slab_off, d_eb_slab_off, d_eb_gid, d_ce_bucket_off,
@@ -119,7 +133,7 @@ struct smcpp_im {
     int llblk = 64;
     int max_pass = 0;
     int last_fwd_passes = 0, last_bwd_passes = 0;
-    float eps_f = 2.4e-7f;
+    float eps_f = 2e-6f;
     double eps_b = 1e-9;
     // ---- results (host) ---------------------------------------------------------------------------------------
     std::vector<double> loglik, h_xisum, h_gsum, h_gamma0;
@@ -237,6 +251,7 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
             if (span_of[g] > 1) gmap.emplace(std::make_pair(rowinfo[g].kid, span_of[g]), 0);
         }
     G = (int)gmap.size();
+    if (G >= (1 << 20)) throw std::runtime_error("too many distinct (span, key) pairs");
     groups.clear();
     eig_kid.clear();
     eig_of_key.assign(K, -1);
@@ -375,6 +390,22 @@ void smcpp_im::make_slabs() {
 void smcpp_im::alloc_device() {
     hipStream_t s = stream;
     d_rowinfo.upload(rowinfo, s);
+    {
+        // packed descriptors of the chain kernels and the "hot" eigen key (most span>1 rows) they keep in registers
+        std::vector<int2> rd((size_t)total_rows);
+        std::vector<long long> cnt(std::max(1, Ke), 0);
+        for (size_t r = 0; r < rd.size(); ++r) {
+            const RowInfo &ri = rowinfo[r];
+            rd[r].x = ri.kid;
+            rd[r].y = ri.gid < 0 ? -1 : (ri.gid | (groups[ri.gid].eig << 20));
+            if (ri.gid >= 0) cnt[groups[ri.gid].eig]++;
+        }
+        hot_eig = -1;
+        for (int e = 0; e < Ke; ++e)
+            if (hot_eig < 0 || cnt[e] > cnt[hot_eig]) hot_eig = e;
+        d_rowdesc.upload(rd, s);
+        HIPCHK(hipStreamSynchronize(s));
+    }
     d_chunks.upload(chunks, s);
     d_slabs_sc.upload(slabs_sc, s);
     d_slabs_rk.upload(slabs_rk, s);
@@ -455,7 +486,7 @@ void smcpp_im::host_prep_and_upload() {
     // ---- TransitionBundle::update: eigensystems of diag(b_k) Td^T per eigen key (transition_bundle.cpp:15-25)
     std::vector<smcpp_host::EigenSystem> es(Ke);
     std::string err;
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(std::max(1, std::min(Ke, omp_get_max_threads())))
     for (int e = 0; e < Ke; ++e) {
         try {
             const double *b = &E[(size_t)eig_kid[e] * M];
@@ -509,6 +540,29 @@ void smcpp_im::host_prep_and_upload() {
     d_PinvT.upload(PinvT, s); d_PT.upload(PT, s); d_Prm.upload(Prm, s); d_Pinvrm.upload(Pinvrm, s);
     d_dsc.upload(dsc, s); d_dun.upload(dun, s); d_dpow.upload(dpow, s);
     d_g_scale.upload(gsc, s); d_g_logscale.upload(gls, s);
+    std::vector<float> T4;
+    std::vector<double> fA2, fB2, bA2, bB2, bC2;
+    if (Mp <= 64) {
+        // k-blocked copies for the LDS-resident chain kernels: [k/4][i][4] floats, [k/2][i][2] doubles
+        const int h = hot_eig;
+        T4.assign(MM, 0.f); fA2.assign(MM, 0.0); fB2.assign(MM, 0.0); bA2.assign(MM, 0.0); bB2.assign(MM, 0.0);
+        bC2.assign(MM, 0.0);
+        for (int k = 0; k < Mp; ++k)
+            for (int i = 0; i < Mp; ++i) {
+                const size_t i4 = ((size_t)(k / 4) * Mp + i) * 4 + (k % 4);
+                const size_t i2 = ((size_t)(k / 2) * Mp + i) * 2 + (k % 2);
+                T4[i4] = Tf[(size_t)k * Mp + i];
+                bA2[i2] = TdT[(size_t)k * Mp + i];
+                if (h >= 0) {
+                    fA2[i2] = PinvT[h * MM + (size_t)k * Mp + i];
+                    fB2[i2] = PT[h * MM + (size_t)k * Mp + i];
+                    bB2[i2] = Prm[h * MM + (size_t)k * Mp + i];
+                    bC2[i2] = Pinvrm[h * MM + (size_t)k * Mp + i];
+                }
+            }
+        d_T4.upload(T4, s); d_fA2.upload(fA2, s); d_fB2.upload(fB2, s);
+        d_bA2.upload(bA2, s); d_bB2.upload(bB2, s); d_bC2.upload(bC2, s);
+    }
     HIPCHK(hipStreamSynchronize(s));   // the staging vectors above are pageable and die with this scope
 }
 
@@ -516,19 +570,44 @@ void smcpp_im::host_prep_and_upload() {
 // kernel launches
 // ---------------------------------------------------------------------------------------------------------------
 template <int NPL_>
-static void launch_fwd(const ChainArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(k_fwd_pass<NPL_>, dim3(a.nchunks), dim3(64), 0, s, a);
+static void launch_chain_generic(bool fwd, const ChainArgs &a, hipStream_t s) {
+    if (fwd) hipLaunchKernelGGL((k_fwd_pass<NPL_>), dim3(a.nchunks), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_bwd_pass<NPL_>), dim3(a.nchunks), dim3(64), 0, s, a);
 }
-template <int NPL_>
-static void launch_bwd(const ChainArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(k_bwd_pass<NPL_>, dim3(a.nchunks), dim3(64), 0, s, a);
+template <int MT_, bool TAB_>
+static void launch_chain_lds_t(bool fwd, const ChainArgs &a, const LdsArgs &la, int wpb, size_t shm, hipStream_t s) {
+    const int nblk = (a.nchunks + wpb - 1) / wpb;
+    if (fwd) {
+        static bool once = false;
+        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_fwd_lds<MT_, TAB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+        hipLaunchKernelGGL((k_fwd_lds<MT_, TAB_>), dim3(nblk), dim3(64 * wpb), shm, s, a, la);
+    } else {
+        static bool once = false;
+        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_bwd_lds<MT_, TAB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+        hipLaunchKernelGGL((k_bwd_lds<MT_, TAB_>), dim3(nblk), dim3(64 * wpb), shm, s, a, la);
+    }
 }
-static void launch_chain(bool fwd, int npl, const ChainArgs &a, hipStream_t s) {
+template <int MT_>
+static void launch_chain_lds(bool fwd, const ChainArgs &a, const LdsArgs &la, int tab, int wpb, size_t shm, hipStream_t s) {
+    if (tab) launch_chain_lds_t<MT_, true>(fwd, a, la, wpb, shm, s);
+    else launch_chain_lds_t<MT_, false>(fwd, a, la, wpb, shm, s);
+}
+static void launch_chain(bool fwd, int npl, int Mp, bool generic, const ChainArgs &a, const LdsArgs &la, int tab,
+                         int wpb, size_t shm, hipStream_t s) {
+    if (npl == 1 && !generic) {
+        switch (Mp) {
+            case 16: launch_chain_lds<16>(fwd, a, la, tab, wpb, shm, s); return;
+            case 32: launch_chain_lds<32>(fwd, a, la, tab, wpb, shm, s); return;
+            case 48: launch_chain_lds<48>(fwd, a, la, tab, wpb, shm, s); return;
+            case 64: launch_chain_lds<64>(fwd, a, la, tab, wpb, shm, s); return;
+            default: break;
+        }
+    }
     switch (npl) {
-        case 1: fwd ? launch_fwd<1>(a, s) : launch_bwd<1>(a, s); break;
-        case 2: fwd ? launch_fwd<2>(a, s) : launch_bwd<2>(a, s); break;
-        case 3: fwd ? launch_fwd<3>(a, s) : launch_bwd<3>(a, s); break;
-        case 4: fwd ? launch_fwd<4>(a, s) : launch_bwd<4>(a, s); break;
+        case 1: launch_chain_generic<1>(fwd, a, s); break;
+        case 2: launch_chain_generic<2>(fwd, a, s); break;
+        case 3: launch_chain_generic<3>(fwd, a, s); break;
+        case 4: launch_chain_generic<4>(fwd, a, s); break;
         default: throw std::runtime_error("unsupported number of hidden states");
     }
 }
@@ -563,7 +642,29 @@ void smcpp_im::run_chains() {
     hipStream_t s = stream;
     ChainArgs a;
     a.M = M; a.Mp = Mp; a.nchunks = (int)chunks.size(); a.pass = 0;
-    a.chunks = d_chunks.p; a.rowinfo = d_rowinfo.p; a.E = d_E.p; a.dpow = d_dpow.p; a.g_eig = d_g_eig.p;
+    a.hot = hot_eig;
+    a.chunks = d_chunks.p; a.rowdesc = d_rowdesc.p; a.E = d_E.p; a.dpow = d_dpow.p;
+    const bool generic = getenv("SMCPP_GENERIC_CHAINS") != nullptr;
+    // LDS budget of the resident kernels: matrices + (emission, eigenvalue-power) tables + per-wavefront scratch
+    LdsArgs lf, lb;
+    size_t shm_f = 0, shm_b = 0;
+    int tab_lds = 0;
+    {
+        const size_t mm = (size_t)Mp * Mp;
+        const int wave_bytes = 512 + Mp * 8 + Mp * 4;
+        const size_t tabs = (size_t)(K + G) * Mp * 8;
+        const size_t base_f = mm * 4 + 2 * mm * 8 + (size_t)wpb * wave_bytes;
+        const size_t base_b = 3 * mm * 8 + (size_t)wpb * wave_bytes;
+        const size_t cap = 160 * 1024;
+        const int tab = (std::max(base_f, base_b) + tabs <= cap) ? 1 : 0;
+        tab_lds = tab;
+        lf.K = K; lf.G = G; lf.wave_bytes = wave_bytes;
+        lf.T4 = d_T4.p; lf.A2 = d_fA2.p; lf.B2 = d_fB2.p; lf.C2 = nullptr;
+        lb = lf;
+        lb.T4 = nullptr; lb.A2 = d_bA2.p; lb.B2 = d_bB2.p; lb.C2 = d_bC2.p;
+        shm_f = base_f + (tab ? tabs : 0);
+        shm_b = base_b + (tab ? tabs : 0);
+    }
     a.pi_f = d_pi_f.p; a.Tf = d_Tf.p; a.PinvT = d_PinvT.p; a.PT = d_PT.p;
     a.TdT = d_TdT.p; a.Prm = d_Prm.p; a.Pinvrm = d_Pinvrm.p;
     a.alpha = d_alpha.p; a.beta = d_beta.p; a.cnorm = d_cnorm.p;
@@ -586,12 +687,12 @@ void smcpp_im::run_chains() {
     while (true) {
         if (!fdone) {
             a.changed = d_changed_f.p;
-            for (; launched_f < want_f; ++launched_f) { a.pass = launched_f; launch_chain(true, NPL, a, s); }
+            for (; launched_f < want_f; ++launched_f) { a.pass = launched_f; launch_chain(true, NPL, Mp, generic, a, lf, tab_lds, wpb, shm_f, s); }
         }
         if (launched_b == 0) HIPCHK(hipEventRecord(ev[2], s));
         if (!bdone) {
             a.changed = d_changed_b.p;
-            for (; launched_b < want_b; ++launched_b) { a.pass = launched_b; launch_chain(false, NPL, a, s); }
+            for (; launched_b < want_b; ++launched_b) { a.pass = launched_b; launch_chain(false, NPL, Mp, generic, a, lb, tab_lds, wpb, shm_b, s); }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(chf.data(), d_changed_f.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, s));

@@ -31,6 +31,51 @@ struct RowInfo {      // per global row index (entry for ell = 0 of each contig 
     int kid;          // key id
     int gid;          // (span,key) group id for span > 1 rows, -1 for span == 1
 };
+// the chain kernels read a packed descriptor: gid | (eigen index << 20), or -1 for span-1 rows
+#define SMCPP_GID(ge) ((ge) & 0xFFFFF)
+#define SMCPP_ES(ge) ((ge) >> 20)
+
+// Orders this wavefront's LDS traffic without touching the vector-memory counters (a __syncthreads() would also
+// drain the outstanding alpha/beta stores and prefetches, which is what made the first version latency-bound).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const long long x = __builtin_bit_cast(long long, v);
+    int lo = (int)(x & 0xffffffffll), hi = (int)(x >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float lane_get(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double lane_get(double v, int l) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(x & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(x >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// butterfly inside each 16-lane DPP row (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), then the
+// four row totals are combined through SGPRs; every lane receives the same bits
+template <typename T>
+__device__ __forceinline__ T wave_sum_dpp(T v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    const T r0 = lane_get(v, 0), r1 = lane_get(v, 16), r2 = lane_get(v, 32), r3 = lane_get(v, 48);
+    return (r0 + r1) + (r2 + r3);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // wavefront reductions (all 64 lanes receive the result)
@@ -53,15 +98,14 @@ __device__ __forceinline__ double row16_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K1: forward chain pass  (hmm.cpp:57-96)
+// K1 / K2: the forward (hmm.cpp:57-96) and backward (hmm.cpp:97-149) chains
 // ---------------------------------------------------------------------------------------------------------------
 struct ChainArgs {
-    int M, Mp, nchunks, pass;
+    int M, Mp, nchunks, pass, hot;   // hot = eigen index whose matrices the *_hot kernels keep in registers (-1: none)
     const Chunk *chunks;
-    const RowInfo *rowinfo;
+    const int2 *rowdesc;    // [rows] {kid, gid | es << 20} (-1 for span-1 rows)
     const double *E;        // [K][Mp] emission vectors
     const double *dpow;     // [G][Mp] (d_r/scale)^span per group
-    const int *g_eig;       // [G] eigensystem index of the group
     // forward operands
     const float *pi_f;      // [Mp] float(pi)
     const float *Tf;        // [Mp][Mp] Tf[k][i] = float(T[k][i])
@@ -84,10 +128,48 @@ struct ChainArgs {
     double eps_b;
 };
 
+// y_i = sum_k Mt[k][i] x_k with Mt streamed from global memory (L2) and x broadcast from LDS.
+template <int NPL, typename TM, typename TX>
+__device__ __forceinline__ void matvec_global(const TM *__restrict__ Mt, const TX *xs, int M, int Mp, int lane,
+                                              TX (&y)[NPL]) {
+    TX acc[NPL][4];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = (TX)0;
+    int k = 0;
+    for (; k + 8 <= M; k += 8) {
+        TM m[NPL][8];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = lane + 64 * q;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m[q][u] = (i < Mp) ? Mt[(size_t)(k + u) * Mp + i] : (TM)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const TX x = xs[k + u];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) acc[q][u & 3] = fma((TX)m[q][u], x, acc[q][u & 3]);
+        }
+    }
+    for (; k < M; ++k) {
+        const TX x = xs[k];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = lane + 64 * q;
+            if (i < Mp) acc[q][0] = fma((TX)Mt[(size_t)k * Mp + i], x, acc[q][0]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) y[q] = (acc[q][0] + acc[q][1]) + (acc[q][2] + acc[q][3]);
+}
+
+// ---- forward ----------------------------------------------------------------------------------------------------
+// Generic variant (any M <= 64*NPL): every matrix is streamed from L2.  Used for M > 64 and as the reference
+// implementation the LDS-resident kernels below are tested against.
 template <int NPL>
 __global__ __launch_bounds__(64) void k_fwd_pass(ChainArgs a) {
-    __shared__ double xs[NPL * 64];
-    __shared__ float xf[NPL * 64];
+    __shared__ __attribute__((aligned(16))) double xs[NPL * 64];
+    __shared__ __attribute__((aligned(16))) float xf[NPL * 64];
     const int lane = threadIdx.x;
     const int c = blockIdx.x;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -135,134 +217,73 @@ __global__ __launch_bounds__(64) void k_fwd_pass(ChainArgs a) {
         }
         if (lane == 0) a.cnorm[ch.base] = 1.0;
     }
-    RowInfo ri = a.rowinfo[ch.base + ch.r0 + 1];
-    for (int ell = ch.r0 + 1; ell <= ch.r1; ++ell) {
-        const int nxt = (ell < ch.r1) ? ell + 1 : ell;
-        const RowInfo rn = a.rowinfo[ch.base + nxt];        // prefetch next row's descriptor
-        ri.kid = __builtin_amdgcn_readfirstlane(ri.kid);    // wave-uniform: scalar branch below
-        ri.gid = __builtin_amdgcn_readfirstlane(ri.gid);
-        const double *e = a.E + (size_t)ri.kid * Mp;
-        double ev[NPL];
+    // software pipeline: descriptor two rows ahead, emission / eigenvalue-power vectors one row ahead
+    const int2 *rd = a.rowdesc + ch.base;
+    int2 r_cur = rd[ch.r0 + 1];
+    int2 r_nxt = rd[min(ch.r0 + 2, ch.r1)];
+    double e_cur[NPL], dp_cur[NPL];
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; ev[q] = (i < M) ? e[i] : 0.0; }
+    for (int q = 0; q < NPL; ++q) {
+        const int i = lane + 64 * q;
+        e_cur[q] = (i < M) ? a.E[(size_t)r_cur.x * Mp + i] : 0.0;
+        dp_cur[q] = (i < M && r_cur.y >= 0) ? a.dpow[(size_t)SMCPP_GID(r_cur.y) * Mp + i] : 0.0;
+    }
+    for (int ell = ch.r0 + 1; ell <= ch.r1; ++ell) {
+        const int2 r_nn = rd[min(ell + 2, ch.r1)];
+        const int kid_n = __builtin_amdgcn_readfirstlane(r_nxt.x);
+        const int ge_n = __builtin_amdgcn_readfirstlane(r_nxt.y);
+        double e_nxt[NPL], dp_nxt[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = lane + 64 * q;
+            e_nxt[q] = (i < M) ? a.E[(size_t)kid_n * Mp + i] : 0.0;
+            dp_nxt[q] = (i < M && ge_n >= 0) ? a.dpow[(size_t)SMCPP_GID(ge_n) * Mp + i] : 0.0;
+        }
+        const int ge = __builtin_amdgcn_readfirstlane(r_cur.y);
         double cval;
-        if (ri.gid < 0) {
-            // span == 1 (hmm.cpp:82-90): alpha' = float(diag(b) T^T) alpha in float
+        if (ge < 0) {
+            // span == 1 (hmm.cpp:82-90): alpha' = float(diag(b) T^T) alpha, float arithmetic
 #pragma unroll
             for (int q = 0; q < NPL; ++q) xf[lane + 64 * q] = al[q];
-            __syncthreads();
-            float acc[NPL][4];
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
-            const float *Tf = a.Tf;
-            int k = 0;
-            for (; k + 4 <= M; k += 4) {
-                const float x0 = xf[k], x1 = xf[k + 1], x2 = xf[k + 2], x3 = xf[k + 3];
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int i = lane + 64 * q;
-                    if (i < Mp) {
-                        acc[q][0] = fmaf(Tf[(size_t)k * Mp + i], x0, acc[q][0]);
-                        acc[q][1] = fmaf(Tf[(size_t)(k + 1) * Mp + i], x1, acc[q][1]);
-                        acc[q][2] = fmaf(Tf[(size_t)(k + 2) * Mp + i], x2, acc[q][2]);
-                        acc[q][3] = fmaf(Tf[(size_t)(k + 3) * Mp + i], x3, acc[q][3]);
-                    }
-                }
-            }
-            for (; k < M; ++k) {
-                const float x0 = xf[k];
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int i = lane + 64 * q;
-                    if (i < Mp) acc[q][0] = fmaf(Tf[(size_t)k * Mp + i], x0, acc[q][0]);
-                }
-            }
+            wave_lds_fence();
+            float y[NPL];
+            matvec_global<NPL, float, float>(a.Tf, xf, M, Mp, lane, y);
             float part = 0.f;
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
-                const float y = (acc[q][0] + acc[q][1]) + (acc[q][2] + acc[q][3]);
-                al[q] = (float)((double)y * ev[q]);
+                al[q] = (float)((double)y[q] * e_cur[q]);
                 part += al[q];
             }
-            const float s = wave_sum(part);
+            const float s = wave_sum_dpp(part);
             cval = (double)s;
 #pragma unroll
             for (int q = 0; q < NPL; ++q) al[q] = al[q] / s;
-            __syncthreads();
         } else {
-            // span > 1 (hmm.cpp:72-81): a = P (d~^span o (Pinv alpha)) in double
-            const int es = a.g_eig[ri.gid];
-            const double *PinvT = a.PinvT + (size_t)es * Mp * Mp;
-            const double *PT = a.PT + (size_t)es * Mp * Mp;
-            const double *dp = a.dpow + (size_t)ri.gid * Mp;
-            double dpv[NPL];
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; dpv[q] = (i < M) ? dp[i] : 0.0; }
+            // span > 1 (hmm.cpp:72-81): a = P (d~^span o (Pinv alpha)), double arithmetic
+            const int es = SMCPP_ES(ge);
 #pragma unroll
             for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = (double)al[q];
-            __syncthreads();
-            double acc[NPL][2];
+            wave_lds_fence();
+            double u[NPL], av[NPL];
+            {
+                matvec_global<NPL, double, double>(a.PinvT + (size_t)es * Mp * Mp, xs, M, Mp, lane, u);
+                wave_lds_fence();
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = 0.0;
-            int k = 0;
-            for (; k + 2 <= M; k += 2) {
-                const double x0 = xs[k], x1 = xs[k + 1];
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int i = lane + 64 * q;
-                    if (i < Mp) {
-                        acc[q][0] = fma(PinvT[(size_t)k * Mp + i], x0, acc[q][0]);
-                        acc[q][1] = fma(PinvT[(size_t)(k + 1) * Mp + i], x1, acc[q][1]);
-                    }
-                }
-            }
-            for (; k < M; ++k) {
-                const double x0 = xs[k];
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int i = lane + 64 * q;
-                    if (i < Mp) acc[q][0] = fma(PinvT[(size_t)k * Mp + i], x0, acc[q][0]);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = (acc[q][0] + acc[q][1]) * dpv[q];
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = 0.0;
-            k = 0;
-            for (; k + 2 <= M; k += 2) {
-                const double x0 = xs[k], x1 = xs[k + 1];
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int i = lane + 64 * q;
-                    if (i < Mp) {
-                        acc[q][0] = fma(PT[(size_t)k * Mp + i], x0, acc[q][0]);
-                        acc[q][1] = fma(PT[(size_t)(k + 1) * Mp + i], x1, acc[q][1]);
-                    }
-                }
-            }
-            for (; k < M; ++k) {
-                const double x0 = xs[k];
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int i = lane + 64 * q;
-                    if (i < Mp) acc[q][0] = fma(PT[(size_t)k * Mp + i], x0, acc[q][0]);
-                }
+                for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = u[q] * dp_cur[q];
+                wave_lds_fence();
+                matvec_global<NPL, double, double>(a.PT + (size_t)es * Mp * Mp, xs, M, Mp, lane, av);
             }
             double part = 0.0;
-            double av[NPL];
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
                 const int i = lane + 64 * q;
-                av[q] = (i < M) ? (acc[q][0] + acc[q][1]) : 0.0;
+                if (!(i < M)) av[q] = 0.0;
                 part += av[q];
             }
-            const double s = wave_sum(part);
+            const double s = wave_sum_dpp(part);
             cval = s;
 #pragma unroll
             for (int q = 0; q < NPL; ++q) al[q] = (float)(av[q] / s);
-            __syncthreads();
         }
         // clamp without renormalising (hmm.cpp:92-94)
 #pragma unroll
@@ -272,19 +293,20 @@ __global__ __launch_bounds__(64) void k_fwd_pass(ChainArgs a) {
             if (i < Mp) a.alpha[(size_t)(ch.base + ell) * Mp + i] = al[q];
         }
         if (lane == 0) a.cnorm[ch.base + ell] = cval;
-        ri = rn;
+        wave_lds_fence();
+        r_cur = r_nxt; r_nxt = r_nn;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) { e_cur[q] = e_nxt[q]; dp_cur[q] = dp_nxt[q]; }
     }
 #pragma unroll
     for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) end_cur[i] = al[q]; }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// K2: backward chain pass  (hmm.cpp:97-149, beta lines 123-127,139,142)
+// ---- backward ---------------------------------------------------------------------------------------------------
 // beta[ell] = the vector the reference holds when it processes row ell; beta[0] = the final one.
-// ---------------------------------------------------------------------------------------------------------------
 template <int NPL>
 __global__ __launch_bounds__(64) void k_bwd_pass(ChainArgs a) {
-    __shared__ double xs[NPL * 64];
+    __shared__ __attribute__((aligned(16))) double xs[NPL * 64];
     const int lane = threadIdx.x;
     const int c = blockIdx.x;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -327,118 +349,55 @@ __global__ __launch_bounds__(64) void k_bwd_pass(ChainArgs a) {
 #pragma unroll
     for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) a.used_b[(size_t)c * Mp + i] = b[q]; }
     if (lane == 0) a.changed[pass] = 1;
-    RowInfo ri = a.rowinfo[ch.base + ch.r1];
+    const int2 *rd = a.rowdesc + ch.base;
+    int2 r_cur = rd[ch.r1];
+    int2 r_nxt = rd[max(ch.r1 - 1, ch.r0 + 1)];
+    double e_cur[NPL], dp_cur[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int i = lane + 64 * q;
+        e_cur[q] = (i < M) ? a.E[(size_t)r_cur.x * Mp + i] : 0.0;
+        dp_cur[q] = (i < M && r_cur.y >= 0) ? a.dpow[(size_t)SMCPP_GID(r_cur.y) * Mp + i] : 0.0;
+    }
     for (int ell = ch.r1; ell > ch.r0; --ell) {
-        const int nxt = (ell - 1 > ch.r0) ? ell - 1 : ell;
-        const RowInfo rn = a.rowinfo[ch.base + nxt];
-        ri.kid = __builtin_amdgcn_readfirstlane(ri.kid);
-        ri.gid = __builtin_amdgcn_readfirstlane(ri.gid);
+        const int2 r_nn = rd[max(ell - 2, ch.r0 + 1)];
+        const int kid_n = __builtin_amdgcn_readfirstlane(r_nxt.x);
+        const int ge_n = __builtin_amdgcn_readfirstlane(r_nxt.y);
+        double e_nxt[NPL], dp_nxt[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = lane + 64 * q;
+            e_nxt[q] = (i < M) ? a.E[(size_t)kid_n * Mp + i] : 0.0;
+            dp_nxt[q] = (i < M && ge_n >= 0) ? a.dpow[(size_t)SMCPP_GID(ge_n) * Mp + i] : 0.0;
+        }
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
             const int i = lane + 64 * q;
             if (i < Mp) a.beta[(size_t)(ch.base + ell) * Mp + i] = b[q];
         }
+        const int ge = __builtin_amdgcn_readfirstlane(r_cur.y);
         double bn[NPL];
-        if (ri.gid < 0) {
+        if (ge < 0) {
             // beta <- T (B beta)   (hmm.cpp:139)
-            const double *e = a.E + (size_t)ri.kid * Mp;
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) {
-                const int i = lane + 64 * q;
-                xs[i] = (i < M) ? e[i] * b[q] : 0.0;
-            }
-            __syncthreads();
-            const double *TdT = a.TdT;
-            double acc[NPL][2];
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = 0.0;
-            int k = 0;
-            for (; k + 2 <= M; k += 2) {
-                const double x0 = xs[k], x1 = xs[k + 1];
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int i = lane + 64 * q;
-                    if (i < Mp) {
-                        acc[q][0] = fma(TdT[(size_t)k * Mp + i], x0, acc[q][0]);
-                        acc[q][1] = fma(TdT[(size_t)(k + 1) * Mp + i], x1, acc[q][1]);
-                    }
-                }
-            }
-            for (; k < M; ++k) {
-                const double x0 = xs[k];
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int i = lane + 64 * q;
-                    if (i < Mp) acc[q][0] = fma(TdT[(size_t)k * Mp + i], x0, acc[q][0]);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) bn[q] = acc[q][0] + acc[q][1];
-            __syncthreads();
+            for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = e_cur[q] * b[q];
+            wave_lds_fence();
+            matvec_global<NPL, double, double>(a.TdT, xs, M, Mp, lane, bn);
         } else {
             // beta <- Pinv^T (d~^span o (P^T beta))   (hmm.cpp:123-127; the log/exp there only rescales)
-            const int es = a.g_eig[ri.gid];
-            const double *Prm = a.Prm + (size_t)es * Mp * Mp;
-            const double *Pinvrm = a.Pinvrm + (size_t)es * Mp * Mp;
-            const double *dp = a.dpow + (size_t)ri.gid * Mp;
-            double dpv[NPL];
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; dpv[q] = (i < M) ? dp[i] : 0.0; }
+            const int es = SMCPP_ES(ge);
 #pragma unroll
             for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = b[q];
-            __syncthreads();
-            double acc[NPL][2];
+            wave_lds_fence();
+            double w[NPL];
+            {
+                matvec_global<NPL, double, double>(a.Prm + (size_t)es * Mp * Mp, xs, M, Mp, lane, w);
+                wave_lds_fence();
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = 0.0;
-            int k = 0;
-            for (; k + 2 <= M; k += 2) {
-                const double x0 = xs[k], x1 = xs[k + 1];
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int i = lane + 64 * q;
-                    if (i < Mp) {
-                        acc[q][0] = fma(Prm[(size_t)k * Mp + i], x0, acc[q][0]);
-                        acc[q][1] = fma(Prm[(size_t)(k + 1) * Mp + i], x1, acc[q][1]);
-                    }
-                }
+                for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = w[q] * dp_cur[q];
+                wave_lds_fence();
+                matvec_global<NPL, double, double>(a.Pinvrm + (size_t)es * Mp * Mp, xs, M, Mp, lane, bn);
             }
-            for (; k < M; ++k) {
-                const double x0 = xs[k];
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int i = lane + 64 * q;
-                    if (i < Mp) acc[q][0] = fma(Prm[(size_t)k * Mp + i], x0, acc[q][0]);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = (acc[q][0] + acc[q][1]) * dpv[q];
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = 0.0;
-            k = 0;
-            for (; k + 2 <= M; k += 2) {
-                const double x0 = xs[k], x1 = xs[k + 1];
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int i = lane + 64 * q;
-                    if (i < Mp) {
-                        acc[q][0] = fma(Pinvrm[(size_t)k * Mp + i], x0, acc[q][0]);
-                        acc[q][1] = fma(Pinvrm[(size_t)(k + 1) * Mp + i], x1, acc[q][1]);
-                    }
-                }
-            }
-            for (; k < M; ++k) {
-                const double x0 = xs[k];
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    const int i = lane + 64 * q;
-                    if (i < Mp) acc[q][0] = fma(Pinvrm[(size_t)k * Mp + i], x0, acc[q][0]);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) bn[q] = acc[q][0] + acc[q][1];
-            __syncthreads();
         }
         double part = 0.0;
 #pragma unroll
@@ -447,10 +406,13 @@ __global__ __launch_bounds__(64) void k_bwd_pass(ChainArgs a) {
             if (!(i < M)) bn[q] = 0.0;
             part += bn[q];
         }
-        const double s = wave_sum(part);                   // beta /= beta.sum()  (hmm.cpp:142)
+        const double s = wave_sum_dpp(part);               // beta /= beta.sum()  (hmm.cpp:142)
 #pragma unroll
         for (int q = 0; q < NPL; ++q) b[q] = bn[q] / s;
-        ri = rn;
+        wave_lds_fence();
+        r_cur = r_nxt; r_nxt = r_nn;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) { e_cur[q] = e_nxt[q]; dp_cur[q] = dp_nxt[q]; }
     }
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
@@ -459,6 +421,348 @@ __global__ __launch_bounds__(64) void k_bwd_pass(ChainArgs a) {
             end_cur[i] = b[q];
             if (ch.first) a.beta[(size_t)ch.base * Mp + i] = b[q];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1' / K2': LDS-resident chains for M <= 64 (Mp == MT in {16,32,48,64}).
+// One workgroup = WPB wavefronts = WPB chunks.  The float transition matrix, the hot eigen key's two fp64 matrices,
+// the emission table and the eigenvalue-power table are staged once per workgroup into LDS (160 KiB per CU on
+// gfx950) in a k-blocked layout so that every matrix read is a conflict-free ds_read_b128 and every x_k read a
+// broadcast ds_read_b128; the row loop touches global memory only to store alpha/beta/c (never waited on) and to
+// fetch 64 row descriptors at a time.  No workgroup barrier after the staging barrier: wavefronts are independent.
+// ---------------------------------------------------------------------------------------------------------------
+struct LdsArgs {
+    int K, G;                 // table sizes; the TAB=true kernels keep the emission / power tables in LDS
+    int wave_bytes;           // per-wavefront scratch: 64 descriptors + xs[MT] + xf[MT]
+    const float *T4;          // fwd: Tf packed  [MT/4][MT][4];   bwd: unused
+    const double *A2;         // fwd: PinvT of the hot key packed [MT/2][MT][2];  bwd: TdT packed
+    const double *B2;         // fwd: PT of the hot key packed;                   bwd: P (row-major) of the hot key packed
+    const double *C2;         // bwd: Pinv (row-major) of the hot key packed
+};
+
+// y_li = sum_k M[k][li] x_k from the k-blocked LDS layout.  Operands are fetched in batches of 8 + 8 ds_read_b128 so
+// that 16 LDS reads are in flight per wavefront before the first FMA needs one.
+template <int MT>
+__device__ __forceinline__ float mv_lds(const float *sM, const float *x, int li) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    constexpr int NB = MT / 4;            // float4 blocks
+    constexpr int BT = (NB % 8 == 0) ? 8 : 4;
+#pragma unroll
+    for (int b0 = 0; b0 < NB; b0 += BT) {
+        float4 m[BT], v[BT];
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+            m[u] = reinterpret_cast<const float4 *>(sM)[(b0 + u) * MT + li];
+            v[u] = reinterpret_cast<const float4 *>(x)[b0 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+            a0 = fmaf(m[u].x, v[u].x, a0);
+            a1 = fmaf(m[u].y, v[u].y, a1);
+            a2 = fmaf(m[u].z, v[u].z, a2);
+            a3 = fmaf(m[u].w, v[u].w, a3);
+        }
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+template <int MT>
+__device__ __forceinline__ double mv_lds(const double *sM, const double *x, int li) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    constexpr int NB = MT / 2;            // double2 blocks (MT % 4 == 0 -> NB even)
+    constexpr int BT = 8;
+#pragma unroll
+    for (int b0 = 0; b0 < NB; b0 += BT) {
+        double2 m[BT], v[BT];
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+            m[u] = reinterpret_cast<const double2 *>(sM)[(b0 + u) * MT + li];
+            v[u] = reinterpret_cast<const double2 *>(x)[b0 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < BT; u += 2) {
+            a0 = fma(m[u].x, v[u].x, a0);
+            a1 = fma(m[u].y, v[u].y, a1);
+            a2 = fma(m[u + 1].x, v[u + 1].x, a2);
+            a3 = fma(m[u + 1].y, v[u + 1].y, a3);
+        }
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+__device__ __forceinline__ void lds_stage(void *dst, const void *src, int nbytes, int tid, int nthreads) {
+    uint4 *d = reinterpret_cast<uint4 *>(dst);
+    const uint4 *s = reinterpret_cast<const uint4 *>(src);
+    for (int i = tid; i < nbytes / 16; i += nthreads) d[i] = s[i];
+}
+
+template <int MT, bool TAB>
+__global__ __launch_bounds__(256) void k_fwd_lds(ChainArgs a, LdsArgs la) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+    const int M = a.M, pass = a.pass;
+    constexpr int Mp = MT;
+    if (pass > 0 && a.changed[pass - 1] == 0) return;
+    float *sT = reinterpret_cast<float *>(smem);
+    double *sA = reinterpret_cast<double *>(smem + (size_t)MT * MT * 4);
+    double *sB = sA + MT * MT;
+    double *sE = sB + MT * MT;
+    double *sD = sE + (TAB ? la.K * MT : 0);
+    unsigned char *wb = reinterpret_cast<unsigned char *>(sD + (TAB ? la.G * MT : 0)) + (size_t)wave * la.wave_bytes;
+    int2 *sdesc = reinterpret_cast<int2 *>(wb);
+    double *xs = reinterpret_cast<double *>(wb + 512);
+    float *xf = reinterpret_cast<float *>(wb + 512 + MT * 8);
+    lds_stage(sT, la.T4, MT * MT * 4, tid, nthreads);
+    if (a.hot >= 0) {
+        lds_stage(sA, la.A2, MT * MT * 8, tid, nthreads);
+        lds_stage(sB, la.B2, MT * MT * 8, tid, nthreads);
+    }
+    if (TAB) {
+        lds_stage(sE, a.E, la.K * MT * 8, tid, nthreads);
+        if (la.G > 0) lds_stage(sD, a.dpow, la.G * MT * 8, tid, nthreads);
+    }
+    __syncthreads();
+    const int c = blockIdx.x * (nthreads >> 6) + wave;
+    if (c >= a.nchunks) return;
+    const Chunk ch = a.chunks[c];
+    float *end_cur = a.ends_f + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
+    const float *end_prev = a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
+    const bool act = lane < MT;
+    const int li = act ? lane : MT - 1;
+    if (pass > 0 && ch.first) {
+        if (act) end_cur[lane] = end_prev[lane];
+        return;
+    }
+    float al;
+    {
+        const float *src = (ch.first || pass == 0)
+                               ? a.pi_f
+                               : a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + (c - 1)) * Mp;
+        al = (lane < M) ? src[lane] : 0.f;
+    }
+    if (pass > 0) {
+        bool diff = false;
+        if (lane < M) {
+            const float u = a.used_f[(size_t)c * Mp + lane];
+            if (!(fabsf(al - u) <= a.eps_f * fabsf(u))) diff = true;
+        }
+        if (!__any(diff)) {
+            if (act) end_cur[lane] = end_prev[lane];
+            return;
+        }
+    }
+    if (act) a.used_f[(size_t)c * Mp + lane] = al;
+    if (lane == 0) a.changed[pass] = 1;
+    if (ch.first) {
+        if (act) a.alpha[(size_t)ch.base * Mp + lane] = al;
+        if (lane == 0) a.cnorm[ch.base] = 1.0;
+    }
+    const int2 *rd = a.rowdesc + ch.base;
+    const int nrows = ch.r1 - ch.r0;
+    // descriptor batches of 64 rows: batch b sits in LDS while batch b+1 is already in flight in a register
+    int2 dnext;
+    {
+        const int r = ch.r0 + 1 + lane;
+        int2 d0 = (lane < nrows) ? rd[r] : make_int2(0, -1);
+        sdesc[lane] = d0;
+        const int r2 = r + 64;
+        dnext = (lane + 64 < nrows) ? rd[r2] : make_int2(0, -1);
+    }
+    wave_lds_fence();
+    // one-row-ahead pipeline of (descriptor, emission value, eigenvalue power)
+    int2 r_cur = sdesc[0];
+    int kid = __builtin_amdgcn_readfirstlane(r_cur.x), ge = __builtin_amdgcn_readfirstlane(r_cur.y);
+    double e_cur = TAB ? sE[kid * MT + li] : a.E[(size_t)kid * Mp + li];
+    double dp_cur = (ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + li] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + li]) : 0.0;
+    for (int j = 0; j < nrows; ++j) {
+        const int ell = ch.r0 + 1 + j;
+        const int jb = j & 63;
+        // fetch the next row's descriptor / vectors (next batch is swapped in when this batch is exhausted)
+        int kid_n = 0, ge_n = -1;
+        double e_nxt = 0.0, dp_nxt = 0.0;
+        if (jb == 63) {
+            wave_lds_fence();
+            sdesc[lane] = dnext;
+            const int r2 = ch.r0 + 1 + (j + 1) + 64 + lane;
+            dnext = (j + 1 + 64 + lane < nrows) ? rd[r2] : make_int2(0, -1);
+            wave_lds_fence();
+        }
+        if (j + 1 < nrows) {
+            const int2 rn = sdesc[(jb + 1) & 63];
+            kid_n = __builtin_amdgcn_readfirstlane(rn.x);
+            ge_n = __builtin_amdgcn_readfirstlane(rn.y);
+            e_nxt = TAB ? sE[kid_n * MT + li] : a.E[(size_t)kid_n * Mp + li];
+            if (ge_n >= 0) dp_nxt = TAB ? sD[SMCPP_GID(ge_n) * MT + li] : a.dpow[(size_t)SMCPP_GID(ge_n) * Mp + li];
+        }
+        double cval;
+        if (ge < 0) {
+            // span == 1 (hmm.cpp:82-90)
+            if (act) xf[lane] = al;
+            wave_lds_fence();
+            const float y = mv_lds<MT>(sT, xf, li);
+            al = (lane < M) ? (float)((double)y * e_cur) : 0.f;
+            const float s = wave_sum_dpp(al);
+            cval = (double)s;
+            al = al / s;
+        } else {
+            // span > 1 (hmm.cpp:72-81)
+            const int es = SMCPP_ES(ge);
+            if (act) xs[lane] = (double)al;
+            wave_lds_fence();
+            double av;
+            if (es == a.hot) {
+                const double u = mv_lds<MT>(sA, xs, li) * dp_cur;
+                wave_lds_fence();
+                if (act) xs[lane] = u;
+                wave_lds_fence();
+                av = mv_lds<MT>(sB, xs, li);
+            } else {
+                double u1[1], a1[1];
+                matvec_global<1, double, double>(a.PinvT + (size_t)es * Mp * Mp, xs, M, Mp, lane, u1);
+                wave_lds_fence();
+                if (act) xs[lane] = u1[0] * dp_cur;
+                wave_lds_fence();
+                matvec_global<1, double, double>(a.PT + (size_t)es * Mp * Mp, xs, M, Mp, lane, a1);
+                av = a1[0];
+            }
+            if (!(lane < M)) av = 0.0;
+            const double s = wave_sum_dpp(av);
+            cval = s;
+            al = (float)(av / s);
+        }
+        if (lane < M) { if (al < 1e-10f) al = 1e-10f; } else al = 0.f;      // clamp, hmm.cpp:92-94
+        if (act) a.alpha[(size_t)(ch.base + ell) * Mp + lane] = al;
+        if (lane == 0) a.cnorm[ch.base + ell] = cval;
+        wave_lds_fence();
+        kid = kid_n; ge = ge_n; e_cur = e_nxt; dp_cur = dp_nxt;
+    }
+    if (act) end_cur[lane] = al;
+}
+
+template <int MT, bool TAB>
+__global__ __launch_bounds__(256) void k_bwd_lds(ChainArgs a, LdsArgs la) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+    const int M = a.M, pass = a.pass;
+    constexpr int Mp = MT;
+    if (pass > 0 && a.changed[pass - 1] == 0) return;
+    double *sA = reinterpret_cast<double *>(smem);     // TdT
+    double *sB = sA + MT * MT;                         // P   (row-major)
+    double *sC = sB + MT * MT;                         // Pinv (row-major)
+    double *sE = sC + MT * MT;
+    double *sD = sE + (TAB ? la.K * MT : 0);
+    unsigned char *wb = reinterpret_cast<unsigned char *>(sD + (TAB ? la.G * MT : 0)) + (size_t)wave * la.wave_bytes;
+    int2 *sdesc = reinterpret_cast<int2 *>(wb);
+    double *xs = reinterpret_cast<double *>(wb + 512);
+    lds_stage(sA, la.A2, MT * MT * 8, tid, nthreads);
+    if (a.hot >= 0) {
+        lds_stage(sB, la.B2, MT * MT * 8, tid, nthreads);
+        lds_stage(sC, la.C2, MT * MT * 8, tid, nthreads);
+    }
+    if (TAB) {
+        lds_stage(sE, a.E, la.K * MT * 8, tid, nthreads);
+        if (la.G > 0) lds_stage(sD, a.dpow, la.G * MT * 8, tid, nthreads);
+    }
+    __syncthreads();
+    const int c = blockIdx.x * (nthreads >> 6) + wave;
+    if (c >= a.nchunks) return;
+    const Chunk ch = a.chunks[c];
+    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
+    const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
+    const bool act = lane < MT;
+    const int li = act ? lane : MT - 1;
+    if (pass > 0 && ch.last) {
+        if (act) end_cur[lane] = end_prev[lane];
+        return;
+    }
+    double b;
+    {
+        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (c + 1)) * Mp;
+        const bool fresh = (ch.last || pass == 0);
+        b = (lane < M) ? (fresh ? 1.0 / (double)M : src[lane]) : 0.0;
+    }
+    if (pass > 0) {
+        bool diff = false;
+        if (lane < M) {
+            const double u = a.used_b[(size_t)c * Mp + lane];
+            if (!(fabs(b - u) <= a.eps_b * fabs(u))) diff = true;
+        }
+        if (!__any(diff)) {
+            if (act) end_cur[lane] = end_prev[lane];
+            return;
+        }
+    }
+    if (act) a.used_b[(size_t)c * Mp + lane] = b;
+    if (lane == 0) a.changed[pass] = 1;
+    const int2 *rd = a.rowdesc + ch.base;
+    const int nrows = ch.r1 - ch.r0;
+    // rows are visited ell = r1, r1-1, ...; position j <-> ell = r1 - j
+    int2 dnext;
+    {
+        int2 d0 = (lane < nrows) ? rd[ch.r1 - lane] : make_int2(0, -1);
+        sdesc[lane] = d0;
+        dnext = (lane + 64 < nrows) ? rd[ch.r1 - lane - 64] : make_int2(0, -1);
+    }
+    wave_lds_fence();
+    int2 r_cur = sdesc[0];
+    int kid = __builtin_amdgcn_readfirstlane(r_cur.x), ge = __builtin_amdgcn_readfirstlane(r_cur.y);
+    double e_cur = TAB ? sE[kid * MT + li] : a.E[(size_t)kid * Mp + li];
+    double dp_cur = (ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + li] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + li]) : 0.0;
+    for (int j = 0; j < nrows; ++j) {
+        const int ell = ch.r1 - j;
+        const int jb = j & 63;
+        int kid_n = 0, ge_n = -1;
+        double e_nxt = 0.0, dp_nxt = 0.0;
+        if (jb == 63) {
+            wave_lds_fence();
+            sdesc[lane] = dnext;
+            dnext = (j + 1 + 64 + lane < nrows) ? rd[ch.r1 - (j + 1) - 64 - lane] : make_int2(0, -1);
+            wave_lds_fence();
+        }
+        if (j + 1 < nrows) {
+            const int2 rn = sdesc[(jb + 1) & 63];
+            kid_n = __builtin_amdgcn_readfirstlane(rn.x);
+            ge_n = __builtin_amdgcn_readfirstlane(rn.y);
+            e_nxt = TAB ? sE[kid_n * MT + li] : a.E[(size_t)kid_n * Mp + li];
+            if (ge_n >= 0) dp_nxt = TAB ? sD[SMCPP_GID(ge_n) * MT + li] : a.dpow[(size_t)SMCPP_GID(ge_n) * Mp + li];
+        }
+        if (act) a.beta[(size_t)(ch.base + ell) * Mp + lane] = b;
+        double bn;
+        if (ge < 0) {
+            // beta <- T (B beta)   (hmm.cpp:139)
+            if (act) xs[lane] = (lane < M) ? e_cur * b : 0.0;
+            wave_lds_fence();
+            bn = mv_lds<MT>(sA, xs, li);
+        } else {
+            // beta <- Pinv^T (d~^span o (P^T beta))   (hmm.cpp:123-127)
+            const int es = SMCPP_ES(ge);
+            if (act) xs[lane] = b;
+            wave_lds_fence();
+            if (es == a.hot) {
+                const double w = mv_lds<MT>(sB, xs, li) * dp_cur;
+                wave_lds_fence();
+                if (act) xs[lane] = w;
+                wave_lds_fence();
+                bn = mv_lds<MT>(sC, xs, li);
+            } else {
+                double w1[1], b1[1];
+                matvec_global<1, double, double>(a.Prm + (size_t)es * Mp * Mp, xs, M, Mp, lane, w1);
+                wave_lds_fence();
+                if (act) xs[lane] = w1[0] * dp_cur;
+                wave_lds_fence();
+                matvec_global<1, double, double>(a.Pinvrm + (size_t)es * Mp * Mp, xs, M, Mp, lane, b1);
+                bn = b1[0];
+            }
+        }
+        if (!(lane < M)) bn = 0.0;
+        const double s = wave_sum_dpp(bn);                 // beta /= beta.sum()  (hmm.cpp:142)
+        b = bn / s;
+        wave_lds_fence();
+        kid = kid_n; ge = ge_n; e_cur = e_nxt; dp_cur = dp_nxt;
+    }
+    if (act) {
+        end_cur[lane] = b;
+        if (ch.first) a.beta[(size_t)ch.base * Mp + lane] = b;
     }
 }
 

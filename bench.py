@@ -89,11 +89,8 @@ def main():
         im.set_chunking(args.chunk, args.eps_alpha, args.eps_beta)
     if world > 1:
         # global key dictionary so the packed gamma_sums blocks line up across ranks
-        mine = [tuple(int(x) for x in k) for k in im.keys]
-        allk = [None] * world
-        dist.all_gather_object(allk, mine)
-        gkeys = sorted(set(k for ks in allk for k in ks))
-        im.set_global_keys(np.array(gkeys, dtype=np.int32))
+        from smcpp_amd import dist as sd
+        im.set_global_keys(sd.union_keys(im.keys))
     pi, T, keys, E = par["pi"], par["T"], par["keys"], par["E"]
 
     stats_buf = None

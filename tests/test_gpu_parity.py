@@ -129,3 +129,23 @@ def test_errors():
         im.E_step()                                   # no parameters yet
     with pytest.raises(RuntimeError, match="same size"):
         im.hidden_states = [0.0, 1.0]
+
+
+def test_pack_stats_matches_python_layout():
+    """smcpp_pack_stats (the buffer that is all-reduced over RCCL) equals smcpp_amd.dist.pack_host on the getters."""
+    from smcpp_amd import _smcpp, dist as sd, synth
+    g = load_golden("G3_M32_n10_2Mbp")
+    contigs = [synth.synth_contig(30 + i, L, 10) for i, L in enumerate([120_000, 50_000])]
+    im = _smcpp.PyOnePopInferenceManager(10, contigs, g["hs"], ("pop1",), 0.5)
+    im.theta = float(g["theta"]); im.rho = float(g["rho"])
+    im.set_raw(g["pi"], g["T"], g["keys"], g["E"])
+    im.E_step()
+    gkeys = np.array(sorted(set(tuple(int(x) for x in k) for k in im.keys) | {(2, 9, 10)}), dtype=np.int32)
+    im.set_global_keys(gkeys)
+    buf = im.pack_stats()
+    py = sd.pack_host(list(im.logliks()), [x[:, 0] for x in im.gammas], im.xisums, im.gamma_sums, gkeys)
+    np.testing.assert_allclose(buf, py, rtol=1e-14, atol=0)
+    q_local = np.array(im.Q(separate=True))
+    im.unpack_stats(buf)                       # "reduced" over a world of one
+    q_red = np.array(im.Q(separate=True))
+    np.testing.assert_allclose(q_red, q_local, rtol=1e-12)

@@ -129,8 +129,9 @@ struct smcpp_im {
     DevBuf<float> d_pi_f, d_Tf, d_alpha, d_ends_f, d_used_f;
     DevBuf<double> d_E, d_dpow, d_PinvT, d_PT, d_TdT, d_Td, d_Prm, d_Pinvrm, d_dsc, d_dun, d_g_scale,
         d_g_logscale, d_beta, d_cnorm, d_logc, d_ends_b, d_used_b, d_llpart, d_loglik, d_w1, d_gpart, d_Xs, d_Ys,
-        d_part_e, d_part_1, d_Z, d_Y, d_xisum, d_gsum, d_gamma0, d_gamma_rows, d_Sq;
+        d_part_e, d_part_1, d_red_e, d_red_1, d_red_g, d_Z, d_Y, d_xisum, d_gsum, d_gamma0, d_gamma_rows, d_Sq;
     int llblk = 64;
+    int ZS = 8;
     int max_pass = 0;
     int last_fwd_passes = 0, last_bwd_passes = 0;
     float eps_f = 2e-6f;
@@ -289,7 +290,11 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
 void smcpp_im::make_chunks() {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
-    const long long slots = (long long)prop.multiProcessorCount * 4;     // one wavefront per SIMD
+    {
+        const char *w = getenv("SMCPP_WPB");
+        wpb = (w && atoi(w) == 8) ? 8 : 4;
+    }
+    const long long slots = (long long)prop.multiProcessorCount * wpb;   // wavefronts resident per CU
     long long rows = total_rows - n_contigs;
     int lc = user_rows_per_chunk;
     if (lc <= 0) {
@@ -339,7 +344,7 @@ void smcpp_im::make_slabs() {
     S_RK = (S_RK + 3) / 4 * 4;
     int S_EG = (int)std::max<long long>(64, (ne + target - 1) / target);
     S_EG = (S_EG + 15) / 16 * 16;
-    const int S_SC = 512;
+    const int S_SC = 256;
     for (int c = 0; c < n_contigs; ++c) {
         const long long base = contig_base[c];
         // ---- span-1 rows sorted by key ----
@@ -444,6 +449,9 @@ void smcpp_im::alloc_device() {
     d_Ys.alloc(std::max<size_t>(1, (size_t)n_e_rows) * Mp);
     d_part_e.alloc(std::max<size_t>(1, slabs_eg.size()) * Mp * Mp);
     d_part_1.alloc(std::max<size_t>(1, slabs_rk.size()) * Mp * Mp);
+    d_red_e.alloc(std::max<size_t>(1, eb_gid.size()) * ZS * Mp * Mp);
+    d_red_1.alloc((size_t)n_contigs * ZS * Mp * Mp);
+    d_red_g.alloc((size_t)n_contigs * K * Mp);
     d_Z.alloc(std::max<size_t>(1, (size_t)n_contigs * Ke) * Mp * Mp);
     d_Y.alloc(std::max<size_t>(1, (size_t)n_contigs * Ke) * Mp * Mp);
     d_xisum.alloc((size_t)n_contigs * Mp * Mp);
@@ -574,23 +582,28 @@ static void launch_chain_generic(bool fwd, const ChainArgs &a, hipStream_t s) {
     if (fwd) hipLaunchKernelGGL((k_fwd_pass<NPL_>), dim3(a.nchunks), dim3(64), 0, s, a);
     else hipLaunchKernelGGL((k_bwd_pass<NPL_>), dim3(a.nchunks), dim3(64), 0, s, a);
 }
-template <int MT_, bool TAB_>
-static void launch_chain_lds_t(bool fwd, const ChainArgs &a, const LdsArgs &la, int wpb, size_t shm, hipStream_t s) {
-    const int nblk = (a.nchunks + wpb - 1) / wpb;
+template <int MT_, bool TAB_, int WPB_>
+static void launch_chain_lds_t(bool fwd, const ChainArgs &a, const LdsArgs &la, size_t shm, hipStream_t s) {
+    const int nblk = (a.nchunks + WPB_ - 1) / WPB_;
     if (fwd) {
         static bool once = false;
-        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_fwd_lds<MT_, TAB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
-        hipLaunchKernelGGL((k_fwd_lds<MT_, TAB_>), dim3(nblk), dim3(64 * wpb), shm, s, a, la);
+        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_fwd_lds<MT_, TAB_, WPB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+        hipLaunchKernelGGL((k_fwd_lds<MT_, TAB_, WPB_>), dim3(nblk), dim3(64 * WPB_), shm, s, a, la);
     } else {
         static bool once = false;
-        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_bwd_lds<MT_, TAB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
-        hipLaunchKernelGGL((k_bwd_lds<MT_, TAB_>), dim3(nblk), dim3(64 * wpb), shm, s, a, la);
+        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_bwd_lds<MT_, TAB_, WPB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+        hipLaunchKernelGGL((k_bwd_lds<MT_, TAB_, WPB_>), dim3(nblk), dim3(64 * WPB_), shm, s, a, la);
     }
 }
 template <int MT_>
 static void launch_chain_lds(bool fwd, const ChainArgs &a, const LdsArgs &la, int tab, int wpb, size_t shm, hipStream_t s) {
-    if (tab) launch_chain_lds_t<MT_, true>(fwd, a, la, wpb, shm, s);
-    else launch_chain_lds_t<MT_, false>(fwd, a, la, wpb, shm, s);
+    if (wpb == 8) {
+        if (tab) launch_chain_lds_t<MT_, true, 8>(fwd, a, la, shm, s);
+        else launch_chain_lds_t<MT_, false, 8>(fwd, a, la, shm, s);
+    } else {
+        if (tab) launch_chain_lds_t<MT_, true, 4>(fwd, a, la, shm, s);
+        else launch_chain_lds_t<MT_, false, 4>(fwd, a, la, shm, s);
+    }
 }
 static void launch_chain(bool fwd, int npl, int Mp, bool generic, const ChainArgs &a, const LdsArgs &la, int tab,
                          int wpb, size_t shm, hipStream_t s) {
@@ -626,7 +639,7 @@ static void launch_uw(int nt, const UWArgs &a, hipStream_t s) {
 }
 template <int NPL_>
 static void launch_s1_t(const S1Args &a, hipStream_t s) {
-    hipLaunchKernelGGL(k_s1_scalars<NPL_>, dim3(a.nslabs), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_s1_scalars<NPL_>, dim3(a.nslabs), dim3(256), 0, s, a);
 }
 static void launch_s1(int npl, const S1Args &a, hipStream_t s) {
     switch (npl) {
@@ -754,7 +767,17 @@ void smcpp_im::run_stats() {
     fa.eb_slab_off = d_eb_slab_off.p; fa.eb_gid = d_eb_gid.p; fa.ce_bucket_off = d_ce_bucket_off.p;
     fa.s1_slab_off = d_s1_slab_off.p; fa.gk_slab_off = d_gk_slab_off.p; fa.g_span = d_g_span.p;
     fa.e_kid = d_e_kid.p; fa.dsc = d_dsc.p; fa.dun = d_dun.p; fa.Prm = d_Prm.p; fa.Pinvrm = d_Pinvrm.p;
-    fa.E = d_E.p; fa.Td = d_Td.p; fa.part_e = d_part_e.p; fa.part_1 = d_part_1.p; fa.gpart = d_gpart.p;
+    fa.E = d_E.p; fa.Td = d_Td.p; fa.ZS = ZS; fa.red_e = d_red_e.p; fa.red_1 = d_red_1.p; fa.red_g = d_red_g.p;
+    {
+        const int MM = Mp * Mp;
+        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 32), n_contigs * K, 1), dim3(256), 0, s,
+                           (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
+        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MM, 32), n_contigs, ZS), dim3(256), 0, s,
+                           (const double *)d_part_1.p, (const int *)d_s1_slab_off.p, d_red_1.p, MM, ZS);
+        if (!eb_gid.empty())
+            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MM, 32), (unsigned)eb_gid.size(), ZS), dim3(256), 0, s,
+                               (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MM, ZS);
+    }
     fa.alpha = d_alpha.p; fa.beta = d_beta.p; fa.contig_base = d_contig_base.p;
     fa.Z = d_Z.p; fa.Y = d_Y.p; fa.xisum = d_xisum.p; fa.gsum = d_gsum.p; fa.gamma0 = d_gamma0.p;
     const int nb2 = ceil_div((long long)Mp * Mp, 256);

@@ -441,50 +441,68 @@ struct LdsArgs {
     const double *C2;         // bwd: Pinv (row-major) of the hot key packed
 };
 
-// y_li = sum_k M[k][li] x_k from the k-blocked LDS layout.  Operands are fetched in batches of 8 + 8 ds_read_b128 so
-// that 16 LDS reads are in flight per wavefront before the first FMA needs one.
-template <int MT>
+// y_li = sum_k M[k][li] x_k from the k-blocked LDS layout.  Operands are fetched in double-buffered batches of
+// BT + BT ds_read_b128: the reads of batch b+1 are issued before the FMAs of batch b, so up to 4*BT LDS reads are
+// in flight per wavefront.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct f32x4p { f32x2 lo, hi; };   // 16 bytes: (x, y), (z, w)
+
+template <int MT, int BT>
 __device__ __forceinline__ float mv_lds(const float *sM, const float *x, int li) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    constexpr int NB = MT / 4;            // float4 blocks
-    constexpr int BT = (NB % 8 == 0) ? 8 : 4;
+    f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};        // packed accumulators: one v_pk_fma_f32 each
+    constexpr int NB = MT / 4;                        // float4 blocks
+    constexpr int B = (NB % BT == 0) ? BT : 4;        // MT = 48: 12 blocks
+    f32x4p m[2][B], v[2][B];
 #pragma unroll
-    for (int b0 = 0; b0 < NB; b0 += BT) {
-        float4 m[BT], v[BT];
+    for (int u = 0; u < B; ++u) {
+        m[0][u] = reinterpret_cast<const f32x4p *>(sM)[u * MT + li];
+        v[0][u] = reinterpret_cast<const f32x4p *>(x)[u];
+    }
 #pragma unroll
-        for (int u = 0; u < BT; ++u) {
-            m[u] = reinterpret_cast<const float4 *>(sM)[(b0 + u) * MT + li];
-            v[u] = reinterpret_cast<const float4 *>(x)[b0 + u];
+    for (int b0 = 0; b0 < NB; b0 += B) {
+        const int cur = (b0 / B) & 1, nxt = cur ^ 1;
+        if (b0 + B < NB) {
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                m[nxt][u] = reinterpret_cast<const f32x4p *>(sM)[(b0 + B + u) * MT + li];
+                v[nxt][u] = reinterpret_cast<const f32x4p *>(x)[b0 + B + u];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < BT; ++u) {
-            a0 = fmaf(m[u].x, v[u].x, a0);
-            a1 = fmaf(m[u].y, v[u].y, a1);
-            a2 = fmaf(m[u].z, v[u].z, a2);
-            a3 = fmaf(m[u].w, v[u].w, a3);
+        for (int u = 0; u < B; ++u) {
+            a01 = __builtin_elementwise_fma(m[cur][u].lo, v[cur][u].lo, a01);
+            a23 = __builtin_elementwise_fma(m[cur][u].hi, v[cur][u].hi, a23);
         }
     }
-    return (a0 + a1) + (a2 + a3);
+    return (a01.x + a01.y) + (a23.x + a23.y);
 }
-template <int MT>
+template <int MT, int BT>
 __device__ __forceinline__ double mv_lds(const double *sM, const double *x, int li) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    constexpr int NB = MT / 2;            // double2 blocks (MT % 4 == 0 -> NB even)
-    constexpr int BT = 8;
+    constexpr int NB = MT / 2;                        // double2 blocks: 8, 16, 24, 32
+    constexpr int B = (NB % BT == 0) ? BT : 4;
+    double2 m[2][B], v[2][B];
 #pragma unroll
-    for (int b0 = 0; b0 < NB; b0 += BT) {
-        double2 m[BT], v[BT];
+    for (int u = 0; u < B; ++u) {
+        m[0][u] = reinterpret_cast<const double2 *>(sM)[u * MT + li];
+        v[0][u] = reinterpret_cast<const double2 *>(x)[u];
+    }
 #pragma unroll
-        for (int u = 0; u < BT; ++u) {
-            m[u] = reinterpret_cast<const double2 *>(sM)[(b0 + u) * MT + li];
-            v[u] = reinterpret_cast<const double2 *>(x)[b0 + u];
+    for (int b0 = 0; b0 < NB; b0 += B) {
+        const int cur = (b0 / B) & 1, nxt = cur ^ 1;
+        if (b0 + B < NB) {
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                m[nxt][u] = reinterpret_cast<const double2 *>(sM)[(b0 + B + u) * MT + li];
+                v[nxt][u] = reinterpret_cast<const double2 *>(x)[b0 + B + u];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < BT; u += 2) {
-            a0 = fma(m[u].x, v[u].x, a0);
-            a1 = fma(m[u].y, v[u].y, a1);
-            a2 = fma(m[u + 1].x, v[u + 1].x, a2);
-            a3 = fma(m[u + 1].y, v[u + 1].y, a3);
+        for (int u = 0; u < B; u += 2) {
+            a0 = fma(m[cur][u].x, v[cur][u].x, a0);
+            a1 = fma(m[cur][u].y, v[cur][u].y, a1);
+            a2 = fma(m[cur][u + 1].x, v[cur][u + 1].x, a2);
+            a3 = fma(m[cur][u + 1].y, v[cur][u + 1].y, a3);
         }
     }
     return (a0 + a1) + (a2 + a3);
@@ -496,8 +514,9 @@ __device__ __forceinline__ void lds_stage(void *dst, const void *src, int nbytes
     for (int i = tid; i < nbytes / 16; i += nthreads) d[i] = s[i];
 }
 
-template <int MT, bool TAB>
-__global__ __launch_bounds__(256) void k_fwd_lds(ChainArgs a, LdsArgs la) {
+template <int MT, bool TAB, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_fwd_lds(ChainArgs a, LdsArgs la) {
+    constexpr int BT = WPB <= 4 ? 8 : 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
     const int M = a.M, pass = a.pass;
@@ -599,7 +618,7 @@ __global__ __launch_bounds__(256) void k_fwd_lds(ChainArgs a, LdsArgs la) {
             // span == 1 (hmm.cpp:82-90)
             if (act) xf[lane] = al;
             wave_lds_fence();
-            const float y = mv_lds<MT>(sT, xf, li);
+            const float y = mv_lds<MT, BT>(sT, xf, li);
             al = (lane < M) ? (float)((double)y * e_cur) : 0.f;
             const float s = wave_sum_dpp(al);
             cval = (double)s;
@@ -611,11 +630,11 @@ __global__ __launch_bounds__(256) void k_fwd_lds(ChainArgs a, LdsArgs la) {
             wave_lds_fence();
             double av;
             if (es == a.hot) {
-                const double u = mv_lds<MT>(sA, xs, li) * dp_cur;
+                const double u = mv_lds<MT, BT>(sA, xs, li) * dp_cur;
                 wave_lds_fence();
                 if (act) xs[lane] = u;
                 wave_lds_fence();
-                av = mv_lds<MT>(sB, xs, li);
+                av = mv_lds<MT, BT>(sB, xs, li);
             } else {
                 double u1[1], a1[1];
                 matvec_global<1, double, double>(a.PinvT + (size_t)es * Mp * Mp, xs, M, Mp, lane, u1);
@@ -639,8 +658,9 @@ __global__ __launch_bounds__(256) void k_fwd_lds(ChainArgs a, LdsArgs la) {
     if (act) end_cur[lane] = al;
 }
 
-template <int MT, bool TAB>
-__global__ __launch_bounds__(256) void k_bwd_lds(ChainArgs a, LdsArgs la) {
+template <int MT, bool TAB, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_bwd_lds(ChainArgs a, LdsArgs la) {
+    constexpr int BT = WPB <= 4 ? 8 : 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
     const int M = a.M, pass = a.pass;
@@ -732,18 +752,18 @@ __global__ __launch_bounds__(256) void k_bwd_lds(ChainArgs a, LdsArgs la) {
             // beta <- T (B beta)   (hmm.cpp:139)
             if (act) xs[lane] = (lane < M) ? e_cur * b : 0.0;
             wave_lds_fence();
-            bn = mv_lds<MT>(sA, xs, li);
+            bn = mv_lds<MT, BT>(sA, xs, li);
         } else {
             // beta <- Pinv^T (d~^span o (P^T beta))   (hmm.cpp:123-127)
             const int es = SMCPP_ES(ge);
             if (act) xs[lane] = b;
             wave_lds_fence();
             if (es == a.hot) {
-                const double w = mv_lds<MT>(sB, xs, li) * dp_cur;
+                const double w = mv_lds<MT, BT>(sB, xs, li) * dp_cur;
                 wave_lds_fence();
                 if (act) xs[lane] = w;
                 wave_lds_fence();
-                bn = mv_lds<MT>(sC, xs, li);
+                bn = mv_lds<MT, BT>(sC, xs, li);
             } else {
                 double w1[1], b1[1];
                 matvec_global<1, double, double>(a.Prm + (size_t)es * Mp * Mp, xs, M, Mp, lane, w1);
@@ -845,38 +865,82 @@ struct S1Args {
 };
 
 template <int NPL>
-__global__ __launch_bounds__(64) void k_s1_scalars(S1Args a) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_s1_scalars(S1Args a) {
+    __shared__ double comb[4][NPL * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Slab sl = a.slabs[blockIdx.x];
     const int M = a.M, Mp = a.Mp;
     double gs[NPL];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) gs[q] = 0.0;
-    for (int r = sl.start; r < sl.end; ++r) {
-        const int ell = a.perm[r];
-        const size_t row = (size_t)(sl.base + ell);
-        double v[NPL];
-        double part = 0.0;
+    // wavefront w takes rows start + 4*(4*it + u) + w: four independent rows in flight per iteration
+    for (int r0 = sl.start + wave; r0 < sl.end; r0 += 16) {
+        double v[4][NPL];
+        size_t row[4];
+        bool ok[4];
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = lane + 64 * q;
-            v[q] = (i < M) ? (double)a.alpha[row * Mp + i] * a.beta[row * Mp + i] : 0.0;
-            part += v[q];
-        }
-        const double p = wave_sum(part);
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 4 * u;
+            ok[u] = r < sl.end;
+            const int ell = ok[u] ? a.perm[r] : 1;
+            row[u] = (size_t)(sl.base + ell);
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            v[q] /= p;
-            gs[q] += v[q];
-            const int i = lane + 64 * q;
-            if (a.gamma_rows && i < Mp) a.gamma_rows[row * Mp + i] = v[q];
+            for (int q = 0; q < NPL; ++q) {
+                const int i = lane + 64 * q;
+                v[u][q] = (ok[u] && i < M) ? (double)a.alpha[row[u] * Mp + i] * a.beta[row[u] * Mp + i] : 0.0;
+            }
         }
-        if (lane == 0) a.w1[row] = 1.0 / (exp(a.logc[row]) * p);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;                                   // wave-uniform
+            double part = 0.0;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) part += v[u][q];
+            const double p = wave_sum_dpp(part);
+            const double ip = 1.0 / p;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const double g = v[u][q] / p;
+                gs[q] += g;
+                const int i = lane + 64 * q;
+                if (a.gamma_rows && i < Mp) a.gamma_rows[row[u] * Mp + i] = g;
+            }
+            if (lane == 0) a.w1[row[u]] = ip / exp(a.logc[row[u]]);
+        }
     }
 #pragma unroll
-    for (int q = 0; q < NPL; ++q) {
-        const int i = lane + 64 * q;
-        if (i < Mp) a.gpart[(size_t)blockIdx.x * Mp + i] = gs[q];
+    for (int q = 0; q < NPL; ++q) comb[wave][lane + 64 * q] = gs[q];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int i = lane + 64 * q;
+            if (i < Mp) a.gpart[(size_t)blockIdx.x * Mp + i] = ((comb[0][i] + comb[1][i]) + comb[2][i]) + comb[3][i];
+        }
+    }
+}
+
+// Deterministic reduction of per-slab partials: out[(b*ZS + z)][len] = sum over the z-th share of bucket b's slabs.
+// block = 32 consecutive elements x 8 slab lanes; grid = (ceil(len/32), buckets, ZS).
+__global__ __launch_bounds__(256) void k_sum_parts(const double *__restrict__ part, const int *__restrict__ off,
+                                                   double *__restrict__ out, int len, int ZS) {
+    __shared__ double red[8][32];
+    const int il = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + il;
+    const int b = blockIdx.y, z = blockIdx.z;
+    const int s0 = off[b], s1 = off[b + 1];
+    const int per = (s1 - s0 + ZS - 1) / ZS;
+    const int lo = s0 + z * per, hi = min(s1, lo + per);
+    double acc = 0.0;
+    if (idx < len)
+        for (int s = lo + sl; s < hi; s += 8) acc += part[(size_t)s * len + idx];
+    red[sl][il] = acc;
+    __syncthreads();
+    if (sl == 0 && idx < len) {
+        double t = red[0][il];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][il];
+        out[((size_t)b * ZS + z) * len + idx] = t;
     }
 }
 
@@ -1053,9 +1117,10 @@ struct FinArgs {
     const double *Prm, *Pinvrm;   // [Ke][Mp][Mp]
     const double *E;          // [K][Mp]
     const double *Td;         // [Mp][Mp] row-major
-    const double *part_e;     // [n eigen slabs][Mp][Mp]
-    const double *part_1;     // [n span-1 rank slabs][Mp][Mp]
-    const double *gpart;      // [n span-1 scalar slabs][Mp]
+    int ZS;                   // shares per bucket of the reduced partials
+    const double *red_e;      // [n eigen buckets][ZS][Mp][Mp]   (k_sum_parts of the eigen rank partials)
+    const double *red_1;      // [n_contigs][ZS][Mp][Mp]         (span-1 rank partials)
+    const double *red_g;      // [n_contigs*K][1][Mp]            (span-1 gamma partials)
     const float *alpha;
     const double *beta;
     const long long *contig_base;
@@ -1090,7 +1155,7 @@ __global__ __launch_bounds__(256) void k_fin_Z(FinArgs a) {
         const double *dsc = a.dsc + (size_t)e * Mp;
         for (int b = a.ce_bucket_off[ce]; b < a.ce_bucket_off[ce + 1]; ++b) {
             double acc = 0.0;
-            for (int s = a.eb_slab_off[b]; s < a.eb_slab_off[b + 1]; ++s) acc += a.part_e[(size_t)s * Mp * Mp + idx];
+            for (int z = 0; z < a.ZS; ++z) acc += a.red_e[((size_t)b * a.ZS + z) * Mp * Mp + idx];
             z += span_q_elem(dsc, j, k, a.g_span[a.eb_gid[b]]) * acc;
         }
     }
@@ -1121,7 +1186,7 @@ __global__ __launch_bounds__(256) void k_fin_xisum(FinArgs a) {
     const int i = idx / Mp, k = idx % Mp;
     double x = 0.0;
     if (i < M && k < M) {
-        for (int s = a.s1_slab_off[ct]; s < a.s1_slab_off[ct + 1]; ++s) x += a.part_1[(size_t)s * Mp * Mp + idx];
+        for (int z = 0; z < a.ZS; ++z) x += a.red_1[((size_t)ct * a.ZS + z) * Mp * Mp + idx];
         for (int e = 0; e < a.Ke; ++e) {
             const int ce = ct * a.Ke + e;
             if (a.ce_bucket_off[ce] == a.ce_bucket_off[ce + 1]) continue;
@@ -1152,7 +1217,7 @@ __global__ __launch_bounds__(256) void k_fin_gamma(FinArgs a) {
     double g = 0.0;
     if (i < M) {
         const int ck = ct * a.K + k;
-        for (int s = a.gk_slab_off[ck]; s < a.gk_slab_off[ck + 1]; ++s) g += a.gpart[(size_t)s * Mp + i];
+        g = a.red_g[(size_t)ck * Mp + i];
         for (int e = 0; e < a.Ke; ++e) {
             if (a.e_kid[e] != k) continue;
             const int ce = ct * a.Ke + e;

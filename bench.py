@@ -42,11 +42,11 @@ FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector = matrix peak (AMD spec; SURVEY.
 def algorithmic_work(obs, M):
     """Algorithmic flops / bytes of ONE pass of the dominant (forward chain) kernel, DESIGN.md §Kernels:
     span-1 row: 2 M^2 (one mat-vec); span>1 row: 4 M^2 (two mat-vecs).  Bytes: alpha write 4M + row descriptor 8 +
-    normaliser 8 + emission row read 8M."""
+    normaliser 8 (emission / eigenvalue-power vectors come from LDS-resident tables)."""
     R1 = int((obs[:, 0] == 1).sum())
     Re = len(obs) - R1
     flops = 2.0 * M * M * R1 + 4.0 * M * M * Re
-    nbytes = len(obs) * (4.0 * M + 8.0 * M + 16.0)
+    nbytes = len(obs) * (4.0 * M + 16.0)          # alpha row (float) + normaliser + descriptor
     return flops, nbytes, R1, Re
 
 
@@ -147,8 +147,20 @@ def main():
     else:
         roof = dict(bound="mfma", achieved=ach_tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=ach_tflops / FP64_PEAK_TFLOPS)
-    roof.update(traffic=None, kernel="k_fwd_pass", launches_per_step=launches, avg_launch_ms=1e3 * per_launch_s,
-                algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=nbytes)
+    # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md).  Only valid for the workload
+    # the profile was taken on.
+    traffic = None
+    try:
+        if args.workload == "headline" and args.length_mbp == 100.0:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_b_hbm_traffic_pmc.json")))["kernels"]
+            k = [v for name, v in prof.items() if "k_fwd_lds" in name][0]
+            traffic = 1024.0 * (2.0 * k["FETCH_SIZE_KB_median"] + k["WRITE_SIZE_KB_median"])
+    except Exception:  # noqa: BLE001
+        traffic = None
+    roof.update(traffic=traffic, kernel="k_fwd_lds (forward chain pass)", launches_per_step=launches,
+                avg_launch_ms=1e3 * per_launch_s, algorithmic_flops_per_launch=flops,
+                algorithmic_bytes_per_launch=nbytes)
 
     out = None
     if rank == 0:

@@ -21,13 +21,37 @@ def _stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
+def _gmp():
+    """GMP's C API backs the exact-rational tables of the conditioned SFS (csrc/prep.hpp).  The image ships the runtime
+    library system-wide and the header with conda; a private include directory keeps the rest of conda's headers
+    off the include path."""
+    inc = os.path.join(CSRC, "_gmp")
+    hdr = os.path.join(inc, "gmp.h")
+    if not os.path.exists(hdr):
+        for cand in ("/usr/include/gmp.h", "/usr/include/x86_64-linux-gnu/gmp.h", "/opt/conda/include/gmp.h"):
+            if os.path.exists(cand):
+                os.makedirs(inc, exist_ok=True)
+                if os.path.lexists(hdr):
+                    os.remove(hdr)
+                os.symlink(cand, hdr)
+                break
+        else:
+            raise RuntimeError("gmp.h not found")
+    for cand in ("/usr/lib/x86_64-linux-gnu/libgmp.so", "/usr/lib/x86_64-linux-gnu/libgmp.so.10",
+                 "/opt/conda/lib/libgmp.so"):
+        if os.path.exists(cand):
+            return inc, cand
+    raise RuntimeError("libgmp not found")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    gmp_inc, gmp_lib = _gmp()
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fopenmp", "-fPIC", "-shared",
-           "-Wl,-rpath,/opt/rocm/lib/llvm/lib", "-Wl,-rpath,/opt/rocm/lib",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-I" + gmp_inc, "-Wl,-rpath,/opt/rocm/lib/llvm/lib", "-Wl,-rpath,/opt/rocm/lib",
+           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-Wl," + gmp_lib]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -133,7 +133,7 @@ def main():
 
     # ---- roofline of the dominant kernel (forward chain pass), timed live with HIP events ----
     # smcpp_last_timing brackets the forward / backward pass launches with hipEvents recorded on the engine's stream.
-    fwd_ms = float(np.median([t["forward_ms"] for t in timings]))
+    fwd_ms = float(np.median([t["forward_ms"] for t in timings]))   # (overlaps the backward passes on a 2nd stream)
     bwd_ms = float(np.median([t["backward_ms"] for t in timings]))
     fpasses = float(np.median([t["fwd_passes"] for t in timings]))
     bpasses = float(np.median([t["bwd_passes"] for t in timings]))
@@ -154,11 +154,11 @@ def main():
     try:
         if args.workload == "headline" and args.length_mbp == 100.0:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r01_b_hbm_traffic_pmc.json")))["kernels"]
-            k = [v for name, v in prof.items() if "k_fwd_lds" in name][0]
+            k = [v for name, v in prof.items() if "k_fwd_" in name][0]
             traffic = 1024.0 * (2.0 * k["FETCH_SIZE_KB_median"] + k["WRITE_SIZE_KB_median"])
     except Exception:  # noqa: BLE001
         traffic = None
-    roof.update(traffic=traffic, kernel="k_fwd_lds (forward chain pass)", launches_per_step=launches,
+    roof.update(traffic=traffic, kernel="k_fwd_coop (forward chain pass; runs concurrently with k_bwd_coop)", launches_per_step=launches,
                 avg_launch_ms=1e3 * per_launch_s, algorithmic_flops_per_launch=flops,
                 algorithmic_bytes_per_launch=nbytes)
 

@@ -111,7 +111,8 @@ int smcpp_unpack_stats(smcpp_im *im, const double *buf, long n, int dev);
 /* Rows per chunk of the chunk-parallel chains (0 = automatic) and the chunk-boundary convergence tolerances. */
 int smcpp_set_chunking(smcpp_im *im, int rows_per_chunk, double eps_alpha, double eps_beta);
 /* Kernel-time breakdown of the last E-step in milliseconds:
- * [host_prep, upload, forward, backward, stats, finalize, total_device, fwd_passes, bwd_passes] */
+ * [host_prep, chains_wall, forward, backward, stats, finalize, total_device, fwd_passes, bwd_passes]
+ * (forward and backward overlap when the two chains run on separate streams; chains_wall is their union) */
 int smcpp_last_timing(smcpp_im *im, double out[9]);
 /* The HIP stream the engine launches on (a hipStream_t), for event timing by the caller. */
 void *smcpp_stream(smcpp_im *im);

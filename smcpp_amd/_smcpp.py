@@ -216,7 +216,7 @@ class _PyInferenceManager:
     def last_timing(self):
         t = np.zeros(9)
         E.check(E.lib().smcpp_last_timing(self._im, E.dptr(t)))
-        return dict(zip(["host_prep_ms", "upload_ms", "forward_ms", "backward_ms", "stats_ms", "finalize_ms",
+        return dict(zip(["host_prep_ms", "chains_wall_ms", "forward_ms", "backward_ms", "stats_ms", "finalize_ms",
                          "device_total_ms", "fwd_passes", "bwd_passes"], t))
 
     def stream(self):

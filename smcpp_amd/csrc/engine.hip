@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -113,13 +114,18 @@ struct smcpp_im {
     bool save_gamma = false, gamma_valid = false;
     // ---- device -----------------------------------------------------------------------------------------------
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: backward chain when it may overlap the forward one
     hipEvent_t ev[8];
+    int dual_stream = 1;
+    bool chains_dual = false;
     DevBuf<RowInfo> d_rowinfo;
     DevBuf<int2> d_rowdesc;
+    DevBuf<long long> d_dbg;
     DevBuf<float> d_T4;
     DevBuf<double> d_fA2, d_fB2, d_bA2, d_bB2, d_bC2;
     int wpb = 4;
+    int chain_mode = 2;   // 0 generic, 1 LDS-resident (one wavefront per chunk), 2 CU-cooperative (one workgroup per chunk)
+    int coop_bpc = 1;     // cooperative workgroups resident per CU the automatic chunking aims at
     int hot_eig = -1;
     DevBuf<Chunk> d_chunks;
     DevBuf<Slab> d_slabs_sc, d_slabs_rk, d_slabs_eg;
@@ -151,6 +157,7 @@ struct smcpp_im {
         if (stream) {
             for (auto &e : ev) (void)hipEventDestroy(e);
             (void)hipStreamDestroy(stream);
+            if (stream2) (void)hipStreamDestroy(stream2);
         }
     }
 
@@ -278,6 +285,8 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
     if (dev >= 0) HIPCHK(hipSetDevice(dev));
     HIPCHK(hipGetDevice(&device));
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    if (const char *d = getenv("SMCPP_DUAL_STREAM")) dual_stream = atoi(d);
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     make_chunks();
     make_slabs();
@@ -293,8 +302,15 @@ void smcpp_im::make_chunks() {
     {
         const char *w = getenv("SMCPP_WPB");
         wpb = (w && atoi(w) == 8) ? 8 : 4;
+        const char *m = getenv("SMCPP_CHAIN");
+        if (m) chain_mode = !strcmp(m, "generic") ? 0 : !strcmp(m, "lds") ? 1 : 2;
+        if (getenv("SMCPP_GENERIC_CHAINS")) chain_mode = 0;
+        if (Mp > 64) chain_mode = 0;
+        const char *b = getenv("SMCPP_COOP_BPC");
+        if (b && atoi(b) > 0) coop_bpc = atoi(b);
     }
-    const long long slots = (long long)prop.multiProcessorCount * wpb;   // wavefronts resident per CU
+    // chunks in flight: one per SIMD for the per-wavefront kernels, coop_bpc per CU for the cooperative ones
+    const long long slots = (long long)prop.multiProcessorCount * (chain_mode == 2 ? coop_bpc : wpb);
     long long rows = total_rows - n_contigs;
     int lc = user_rows_per_chunk;
     if (lc <= 0) {
@@ -605,6 +621,27 @@ static void launch_chain_lds(bool fwd, const ChainArgs &a, const LdsArgs &la, in
         else launch_chain_lds_t<MT_, false, 4>(fwd, a, la, shm, s);
     }
 }
+template <int MT_, bool TAB_>
+static void launch_chain_coop_t(bool fwd, const ChainArgs &a, const CoopArgs &ca, size_t shm, hipStream_t s) {
+    if (fwd) {
+        static bool once = false;
+        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_fwd_coop<MT_, TAB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+        hipLaunchKernelGGL((k_fwd_coop<MT_, TAB_>), dim3(a.nchunks), dim3(MT_ * 4), shm, s, a, ca);
+    } else {
+        static bool once = false;
+        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_bwd_coop<MT_, TAB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+        hipLaunchKernelGGL((k_bwd_coop<MT_, TAB_>), dim3(a.nchunks), dim3(MT_ * 4), shm, s, a, ca);
+    }
+}
+static bool launch_chain_coop(bool fwd, int Mp, const ChainArgs &a, const CoopArgs &ca, int tab, size_t shm, hipStream_t s) {
+    switch (Mp) {
+#define C_(x) case x: if (tab) launch_chain_coop_t<x, true>(fwd, a, ca, shm, s); else launch_chain_coop_t<x, false>(fwd, a, ca, shm, s); return true;
+        C_(16) C_(32) C_(48) C_(64)
+#undef C_
+        default: return false;
+    }
+}
+
 static void launch_chain(bool fwd, int npl, int Mp, bool generic, const ChainArgs &a, const LdsArgs &la, int tab,
                          int wpb, size_t shm, hipStream_t s) {
     if (npl == 1 && !generic) {
@@ -657,7 +694,18 @@ void smcpp_im::run_chains() {
     a.M = M; a.Mp = Mp; a.nchunks = (int)chunks.size(); a.pass = 0;
     a.hot = hot_eig;
     a.chunks = d_chunks.p; a.rowdesc = d_rowdesc.p; a.E = d_E.p; a.dpow = d_dpow.p;
-    const bool generic = getenv("SMCPP_GENERIC_CHAINS") != nullptr;
+    const bool generic = chain_mode == 0;
+    CoopArgs cargs;
+    cargs.K = K; cargs.G = G;
+    size_t shm_c = 0;
+    int tab_c = 0;
+    {
+        const int KQ = Mp / 4, UP = KQ + 2;
+        const size_t base_c = (size_t)(4 * UP + 8 * UP) * 8 + 2 * Mp * 4 + 1024 + 64;
+        const size_t tabs = ((size_t)K * 4 * UP + (size_t)G * Mp) * 8;      // backward layout is the larger one
+        tab_c = (base_c + tabs <= 64 * 1024) ? 1 : 0;
+        shm_c = base_c + (tab_c ? tabs : 0);
+    }
     // LDS budget of the resident kernels: matrices + (emission, eigenvalue-power) tables + per-wavefront scratch
     LdsArgs lf, lb;
     size_t shm_f = 0, shm_b = 0;
@@ -683,6 +731,8 @@ void smcpp_im::run_chains() {
     a.alpha = d_alpha.p; a.beta = d_beta.p; a.cnorm = d_cnorm.p;
     a.ends_f = d_ends_f.p; a.used_f = d_used_f.p; a.ends_b = d_ends_b.p; a.used_b = d_used_b.p;
     a.eps_f = eps_f; a.eps_b = eps_b;
+    a.dbg = nullptr;
+    if (getenv("SMCPP_DEBUG_CYCLES")) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }
     d_changed_f.zero(s);
     d_changed_b.zero(s);
     std::vector<int> chf(max_pass + 1), chb(max_pass + 1);
@@ -694,24 +744,48 @@ void smcpp_im::run_chains() {
     int launched_f = 0, launched_b = 0;
     int want_f = std::min(max_pass, last_fwd_passes > 0 ? last_fwd_passes + 1 : std::min(max_pass, 8));
     int want_b = std::min(max_pass, last_bwd_passes > 0 ? last_bwd_passes + 1 : std::min(max_pass, 8));
+    // The two chains are independent (beta does not depend on alpha).  The cooperative kernels leave most of a CU's
+    // LDS and issue slots idle, so the backward passes run on a second stream and share the CUs with the forward ones.
+    const bool dual = dual_stream && chain_mode == 2 && Mp <= 64;
+    hipStream_t sb = dual ? stream2 : s;
+    if (dual) {
+        HIPCHK(hipEventRecord(ev[6], s));              // parameters / zeroed flags are ready on the main stream
+        HIPCHK(hipStreamWaitEvent(sb, ev[6], 0));
+    }
     HIPCHK(hipEventRecord(ev[1], s));
     bool fdone = false, bdone = false;
     int fq = -1, bq = -1;
+    bool first_round = true;
     while (true) {
         if (!fdone) {
             a.changed = d_changed_f.p;
-            for (; launched_f < want_f; ++launched_f) { a.pass = launched_f; launch_chain(true, NPL, Mp, generic, a, lf, tab_lds, wpb, shm_f, s); }
+            for (; launched_f < want_f; ++launched_f) {
+                a.pass = launched_f;
+                if (!(chain_mode == 2 && launch_chain_coop(true, Mp, a, cargs, tab_c, shm_c, s)))
+                    launch_chain(true, NPL, Mp, generic, a, lf, tab_lds, wpb, shm_f, s);
+            }
         }
-        if (launched_b == 0) HIPCHK(hipEventRecord(ev[2], s));
+        if (first_round) HIPCHK(hipEventRecord(ev[2], dual ? sb : s));
         if (!bdone) {
             a.changed = d_changed_b.p;
-            for (; launched_b < want_b; ++launched_b) { a.pass = launched_b; launch_chain(false, NPL, Mp, generic, a, lb, tab_lds, wpb, shm_b, s); }
+            for (; launched_b < want_b; ++launched_b) {
+                a.pass = launched_b;
+                if (!(chain_mode == 2 && launch_chain_coop(false, Mp, a, cargs, tab_c, shm_c, sb)))
+                    launch_chain(false, NPL, Mp, generic, a, lb, tab_lds, wpb, shm_b, sb);
+            }
         }
         HIPCHK(hipGetLastError());
+        if (first_round && dual) HIPCHK(hipEventRecord(ev[7], s));      // end of the first batch of forward passes
         HIPCHK(hipMemcpyAsync(chf.data(), d_changed_f.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(chb.data(), d_changed_b.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(chb.data(), d_changed_b.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, sb));
+        if (dual) {
+            HIPCHK(hipEventRecord(ev[6], sb));
+            HIPCHK(hipStreamWaitEvent(s, ev[6], 0));   // the statistics (main stream) need both chains
+        }
         HIPCHK(hipEventRecord(ev[3], s));
         HIPCHK(hipStreamSynchronize(s));
+        if (dual) HIPCHK(hipStreamSynchronize(sb));
+        first_round = false;
         fq = first_quiet(chf, launched_f);
         bq = first_quiet(chb, launched_b);
         fdone = fq >= 0 || launched_f >= max_pass;
@@ -719,6 +793,13 @@ void smcpp_im::run_chains() {
         if (fdone && bdone) break;
         if (!fdone) want_f = std::min(max_pass, launched_f + 4);
         if (!bdone) want_b = std::min(max_pass, launched_b + 4);
+    }
+    chains_dual = dual;
+    if (a.dbg) {
+        long long h[16];
+        HIPCHK(hipMemcpy(h, d_dbg.p, sizeof(h), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 4; ++w)
+            fprintf(stderr, "[cycles] fwd wg1 wave%d: loop %lld, end-barrier %lld, mid-barrier %lld, rows %lld\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
     }
     if (fq < 0 || bq < 0) throw std::runtime_error("chunk-boundary iteration did not converge");
     last_fwd_passes = fq;
@@ -820,12 +901,19 @@ void smcpp_im::estep() {
     run_stats();
     auto t2 = std::chrono::steady_clock::now();
     float f_ms = 0, b_ms = 0, s_ms = 0, fin_ms = 0;
-    (void)hipEventElapsedTime(&f_ms, ev[1], ev[2]);
-    (void)hipEventElapsedTime(&b_ms, ev[2], ev[3]);
+    if (chains_dual) {
+        (void)hipEventElapsedTime(&f_ms, ev[1], ev[7]);   // forward passes (main stream)
+        (void)hipEventElapsedTime(&b_ms, ev[2], ev[3]);   // backward passes (second stream), overlapping the forward ones
+    } else {
+        (void)hipEventElapsedTime(&f_ms, ev[1], ev[2]);
+        (void)hipEventElapsedTime(&b_ms, ev[2], ev[3]);
+    }
+    float chains_ms = 0;
+    (void)hipEventElapsedTime(&chains_ms, ev[1], ev[3]);
     (void)hipEventElapsedTime(&s_ms, ev[3], ev[4]);
     (void)hipEventElapsedTime(&fin_ms, ev[4], ev[5]);
     timing[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    timing[1] = 0.0;
+    timing[1] = chains_ms;   // wall time of both chains (they overlap in dual-stream mode)
     timing[2] = f_ms; timing[3] = b_ms; timing[4] = s_ms; timing[5] = fin_ms;
     timing[6] = std::chrono::duration<double, std::milli>(t2 - t1).count();
     timing[7] = last_fwd_passes; timing[8] = last_bwd_passes;

@@ -126,6 +126,7 @@ struct ChainArgs {
     int *changed;           // [max passes]
     float eps_f;
     double eps_b;
+    long long *dbg;         // optional [8]: cycle counters of workgroup 0 (SMCPP_DEBUG_CYCLES)
 };
 
 // y_i = sum_k Mt[k][i] x_k with Mt streamed from global memory (L2) and x broadcast from LDS.
@@ -783,6 +784,471 @@ __global__ __launch_bounds__(64 * WPB) void k_bwd_lds(ChainArgs a, LdsArgs la) {
     if (act) {
         end_cur[lane] = b;
         if (ch.first) a.beta[(size_t)ch.base * Mp + lane] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1'' / K2'': CU-cooperative chains for M <= 64 (Mp == MT in {16,32,48,64}).
+// One workgroup of NW = MT/16 wavefronts advances ONE chunk.  Lane = 4*il + kq: wavefront w owns the 16 outputs
+// i = 16w + il, and the four lanes of a quad split the inner dimension into quarters k in [kq*KQ, (kq+1)*KQ),
+// KQ = MT/4, keeping their KQ elements of every operand matrix in registers (80 VGPRs at MT = 64, no LDS matrix
+// traffic).  A mat-vec is KQ FMAs + a 2-step DPP quad reduction; vectors travel between wavefronts through a
+// double-buffered LDS array and ONE s_barrier per mat-vec.  The chain state is carried unnormalised: a producer
+// writes v (and its wavefront's partial sum), the consumer scales its *result* by 1/sum and clamps its inputs at
+// 1e-10*sum, which is the reference's normalise-then-clamp (hmm.cpp:87-94) up to where the float rounding lands.
+// Because a row costs a few hundred cycles instead of a few thousand, chunks can be 4x longer (one per CU instead
+// of one per SIMD) and the boundary fixed point needs 2-3 passes instead of 5-8.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double quad_sum_d(double v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    return v;
+}
+__device__ __forceinline__ float quad_sum_f(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    return v;
+}
+
+struct CoopArgs {
+    int K, G;
+};
+
+// Makes the compiler wait for a loaded value HERE (an empty asm that reads and writes the register).  Without it the
+// one-time operand loads issued before the row loop are waited for lazily inside the loop with small vmcnt counts,
+// and since stores share that counter on gfx9 every row would then also wait for the previous row's alpha store.
+template <typename T>
+__device__ __forceinline__ void pin_reg(T &x) {
+    asm volatile("" : "+v"(x));
+}
+
+// Workgroup barrier that waits for this wavefront's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. the
+// alpha/beta stores of the row just finished (a full HBM write latency per row on the critical path).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ double rcp_f64(double s) {
+    // v_rcp_f64 + two Newton steps: 1/s to ~1 ulp without the div_scale / div_fmas / div_fixup sequence
+    double r = __builtin_amdgcn_rcp(s);
+    r = fma(fma(-s, r, 1.0), r, r);
+    r = fma(fma(-s, r, 1.0), r, r);
+    return r;
+}
+
+// The producer of a row writes its unnormalised output vector only; every consumer lane re-derives the normaliser from
+// the quarter of the vector it reads anyway (KQ adds + the quad reduction it needs for the mat-vec), so the chain
+// needs ONE barrier per mat-vec and no cross-wavefront sum exchange.
+template <int MT, bool TAB>
+__global__ __launch_bounds__(MT * 4) void k_fwd_coop(ChainArgs a, CoopArgs ca) {
+    constexpr int NW = MT / 16, KQ = MT / 4, Mp = MT, UP = KQ + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int il = lane >> 2, kq = lane & 3, i = 16 * w + il;
+    const bool owner = kq == 0;
+    const int M = a.M, pass = a.pass, c = blockIdx.x;
+    if (pass > 0 && a.changed[pass - 1] == 0) return;
+    // ---- LDS carve-up ----
+    double *sE = reinterpret_cast<double *>(smem);
+    double *sD = sE + (TAB ? ca.K * MT : 0);
+    double *ub = sD + (TAB ? ca.G * MT : 0);                 // [4][UP]   u exchange of eigen rows
+    float *xf = reinterpret_cast<float *>(ub + 4 * UP);       // [2][MT]   unnormalised chain state (float)
+    int2 *sdesc = reinterpret_cast<int2 *>(xf + 2 * MT);      // [2][64]   row descriptors
+    int *sflag = reinterpret_cast<int *>(sdesc + 128);        // [1]
+    if (TAB) {
+        lds_stage(sE, a.E, ca.K * MT * 8, tid, NW * 64);
+        if (ca.G > 0) lds_stage(sD, a.dpow, ca.G * MT * 8, tid, NW * 64);
+    }
+    const Chunk ch = a.chunks[c];
+    float *end_cur = a.ends_f + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
+    const float *end_prev = a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
+    if (pass > 0 && ch.first) {
+        if (owner) end_cur[i] = end_prev[i];
+        return;
+    }
+    // ---- start vector (owner lanes hold state i) and the skip test ----
+    float al = 0.f;
+    {
+        const float *src = (ch.first || pass == 0)
+                               ? a.pi_f
+                               : a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + (c - 1)) * Mp;
+        if (i < M) al = src[i];
+    }
+    if (tid == 0) *sflag = 0;
+    __syncthreads();
+    if (pass > 0) {
+        bool diff = false;
+        if (owner && i < M) {
+            const float u = a.used_f[(size_t)c * Mp + i];
+            if (!(fabsf(al - u) <= a.eps_f * fabsf(u))) diff = true;
+        }
+        if (__any(diff) && lane == 0) *sflag = 1;
+        __syncthreads();
+        if (*sflag == 0) {
+            if (owner) end_cur[i] = end_prev[i];
+            return;
+        }
+    }
+    if (owner) a.used_f[(size_t)c * Mp + i] = al;
+    if (tid == 0) a.changed[pass] = 1;
+    if (ch.first) {
+        if (owner) a.alpha[(size_t)ch.base * Mp + i] = al;
+        if (tid == 0) a.cnorm[ch.base] = 1.0;
+    }
+    // ---- operand quarters in registers ----
+    float tf[KQ];
+    double pinv[KQ], pt[KQ];
+    {
+        const size_t ho = (size_t)(a.hot < 0 ? 0 : a.hot) * Mp * Mp;
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) {
+            const int k = kq * KQ + t;
+            tf[t] = a.Tf[(size_t)k * Mp + i];
+            pinv[t] = (a.hot >= 0) ? a.PinvT[ho + (size_t)k * Mp + i] : 0.0;
+            pt[t] = (a.hot >= 0) ? a.PT[ho + (size_t)k * Mp + i] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) { pin_reg(tf[t]); pin_reg(pinv[t]); pin_reg(pt[t]); }
+    }
+    const int2 *rd = a.rowdesc + ch.base;
+    const int nrows = ch.r1 - ch.r0;
+    // descriptor batches: batch b lives in sdesc[b&1]; wavefront 0 fetches batch b+1 while batch b is consumed
+    int2 dnext = make_int2(0, -1);
+    if (w == 0) {
+        sdesc[lane] = (lane < nrows) ? rd[ch.r0 + 1 + lane] : make_int2(0, -1);
+        dnext = (lane + 64 < nrows) ? rd[ch.r0 + 1 + 64 + lane] : make_int2(0, -1);
+    }
+    if (owner) xf[i] = al;                     // the start vector enters as a state whose sum counts as exactly 1
+    __syncthreads();
+    // three-stage descriptor pipeline: d2 = raw descriptor of row j+2, (kid1, ge1, e1, dp1) of row j+1, *_cur of row j
+    auto desc_at = [&](int jj) { return sdesc[((jj >> 6) & 1) * 64 + (jj & 63)]; };
+    int2 d0 = desc_at(0);
+    int ge = __builtin_amdgcn_readfirstlane(d0.y);
+    {
+        const int kid0 = __builtin_amdgcn_readfirstlane(d0.x);
+        d0.x = kid0;
+    }
+    double e_cur = TAB ? sE[d0.x * MT + i] : a.E[(size_t)d0.x * Mp + i];
+    double dp_cur = (ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + i]) : 0.0;
+    int2 d1 = (nrows > 1) ? desc_at(1) : make_int2(0, -1);
+    float v_prev = al;      // owner: unnormalised output of the previous row (normalised, clamped and stored one row later)
+#ifdef SMCPP_PROFILE_CYCLES
+    long long t_loop0 = __builtin_readcyclecounter(), t_bar = 0, t_bar2 = 0;
+#endif
+    for (int j = 0; j < nrows; ++j) {
+        const int ell = ch.r0 + 1 + j;
+        const int jb = j & 63, bsel = (j >> 6) & 1, cur = j & 1, nxt = cur ^ 1;
+        if (w == 0 && jb == 32) {
+            sdesc[(bsel ^ 1) * 64 + lane] = dnext;
+            dnext = (j - 32 + 128 + lane < nrows) ? rd[ch.r0 + 1 + (j - 32) + 128 + lane] : make_int2(0, -1);
+        }
+        // stage 1 -> operands of row j+1 (descriptor fetched one iteration ago), stage 2 -> raw descriptor of row j+2
+        const int kid_n = __builtin_amdgcn_readfirstlane(d1.x);
+        const int ge_n = (j + 1 < nrows) ? __builtin_amdgcn_readfirstlane(d1.y) : -1;
+        const double e_nxt = TAB ? sE[kid_n * MT + i] : a.E[(size_t)kid_n * Mp + i];
+        const double dp_nxt = (ge_n >= 0) ? (TAB ? sD[SMCPP_GID(ge_n) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge_n) * Mp + i]) : 0.0;
+        const int2 d2 = (j + 2 < nrows) ? desc_at(j + 2) : make_int2(0, -1);
+        // ---- incoming state: quarter of x, its sum (= normaliser of the previous row), clamp threshold ----
+        const float *xin = xf + cur * MT + kq * KQ;
+        f32x2 xl[KQ / 4], xh[KQ / 4];
+        f32x2 s01 = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KQ / 4; ++t) {
+            const f32x4p x = *reinterpret_cast<const f32x4p *>(xin + 4 * t);
+            xl[t] = x.lo; xh[t] = x.hi;
+            s01 += x.lo; s01 += x.hi;
+        }
+        float sprev = quad_sum_f(s01.x + s01.y);
+        if (j == 0) sprev = 1.0f;
+        const float inv = __builtin_amdgcn_rcpf(sprev);
+        const float thr = 1e-10f * sprev;
+        // the previous row can be finished now that its normaliser is known: alpha = clamp(v / s)   (hmm.cpp:89-94)
+        if (j > 0) {
+            if (owner) {
+                float an = v_prev * inv;
+                an = (i < M) ? fmaxf(an, 1e-10f) : 0.f;
+                a.alpha[(size_t)(ch.base + ell - 1) * Mp + i] = an;
+            }
+            if (tid == 0) a.cnorm[ch.base + ell - 1] = (double)sprev;
+        }
+        float vout;
+        if (ge < 0) {
+            // span == 1: y = Tf^T max(x, thr) / s ; v = float(y e)
+            f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < KQ / 4; ++t) {
+                f32x2 l = xl[t], h = xh[t];
+                l.x = fmaxf(l.x, thr); l.y = fmaxf(l.y, thr); h.x = fmaxf(h.x, thr); h.y = fmaxf(h.y, thr);
+                const f32x2 m01 = {tf[4 * t], tf[4 * t + 1]}, m23 = {tf[4 * t + 2], tf[4 * t + 3]};
+                acc01 = __builtin_elementwise_fma(m01, l, acc01);
+                acc23 = __builtin_elementwise_fma(m23, h, acc23);
+            }
+            const float y = quad_sum_f((acc01.x + acc01.y) + (acc23.x + acc23.y)) * inv;
+            vout = (i < M) ? (float)((double)y * e_cur) : 0.f;
+        } else {
+            const int es = SMCPP_ES(ge);
+            double u;
+            if (es == a.hot) {
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int t = 0; t < KQ / 4; ++t) {
+                    a0 = fma(pinv[4 * t], (double)fmaxf(xl[t].x, thr), a0);
+                    a1 = fma(pinv[4 * t + 1], (double)fmaxf(xl[t].y, thr), a1);
+                    a0 = fma(pinv[4 * t + 2], (double)fmaxf(xh[t].x, thr), a0);
+                    a1 = fma(pinv[4 * t + 3], (double)fmaxf(xh[t].y, thr), a1);
+                }
+                u = quad_sum_d(a0 + a1);
+            } else {
+                const double *Pm = a.PinvT + (size_t)es * Mp * Mp;
+                double a0 = 0.0;
+                for (int t = 0; t < KQ; ++t) a0 = fma(Pm[(size_t)(kq * KQ + t) * Mp + i], (double)fmaxf(xin[t], thr), a0);
+                u = quad_sum_d(a0);
+            }
+            u = u * dp_cur * (double)inv;
+            if (owner) ub[(i / KQ) * UP + (i % KQ)] = (i < M) ? u : 0.0;
+#ifdef SMCPP_PROFILE_CYCLES
+            { const long long tb = __builtin_readcyclecounter(); lds_barrier(); t_bar2 += __builtin_readcyclecounter() - tb; }
+#else
+            lds_barrier();
+#endif
+            const double *uin = ub + kq * UP;
+            double av;
+            if (es == a.hot) {
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int t = 0; t < KQ; t += 2) {
+                    const double2 x = *reinterpret_cast<const double2 *>(uin + t);
+                    a0 = fma(pt[t], x.x, a0);
+                    a1 = fma(pt[t + 1], x.y, a1);
+                }
+                av = quad_sum_d(a0 + a1);
+            } else {
+                const double *Pm = a.PT + (size_t)es * Mp * Mp;
+                double a0 = 0.0;
+                for (int t = 0; t < KQ; ++t) a0 = fma(Pm[(size_t)(kq * KQ + t) * Mp + i], uin[t], a0);
+                av = quad_sum_d(a0);
+            }
+            vout = (i < M) ? (float)av : 0.f;      // the state is rounded to float as alpha_hat is (hmm.cpp:80)
+        }
+        if (owner) xf[nxt * MT + i] = vout;
+        v_prev = vout;
+        ge = ge_n; e_cur = e_nxt; dp_cur = dp_nxt; d1 = d2;
+#ifdef SMCPP_PROFILE_CYCLES
+        { const long long tb = __builtin_readcyclecounter(); lds_barrier(); t_bar += __builtin_readcyclecounter() - tb; }
+#else
+        lds_barrier();
+#endif
+    }
+#ifdef SMCPP_PROFILE_CYCLES
+    if (a.dbg && c == 1 && lane == 0) {
+        a.dbg[4 * w + 0] = __builtin_readcyclecounter() - t_loop0;
+        a.dbg[4 * w + 1] = t_bar;
+        a.dbg[4 * w + 2] = t_bar2;
+        a.dbg[4 * w + 3] = nrows;
+    }
+#endif
+    // ---- last row: normalise, clamp, store, publish the end vector ----
+    {
+        const float *xin = xf + (nrows & 1) * MT + kq * KQ;
+        float sl = 0.f;
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) sl += xin[t];
+        const float sprev = quad_sum_f(sl);
+        const float inv = __builtin_amdgcn_rcpf(sprev);
+        if (owner) {
+            float an = v_prev * inv;
+            an = (i < M) ? fmaxf(an, 1e-10f) : 0.f;
+            a.alpha[(size_t)(ch.base + ch.r1) * Mp + i] = an;
+            end_cur[i] = an;
+        }
+        if (tid == 0) a.cnorm[ch.base + ch.r1] = (double)sprev;
+    }
+}
+
+template <int MT, bool TAB>
+__global__ __launch_bounds__(MT * 4) void k_bwd_coop(ChainArgs a, CoopArgs ca) {
+    constexpr int NW = MT / 16, KQ = MT / 4, Mp = MT, UP = KQ + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int il = lane >> 2, kq = lane & 3, i = 16 * w + il;
+    const bool owner = kq == 0;
+    const int M = a.M, pass = a.pass, c = blockIdx.x;
+    if (pass > 0 && a.changed[pass - 1] == 0) return;
+    double *sE = reinterpret_cast<double *>(smem);            // [K][4][UP]: quarter-padded so that both the owner
+    double *sD = sE + (TAB ? ca.K * 4 * UP : 0);               // read e[i] and the quarter read e[kq*KQ..] are conflict-free
+    double *ub = sD + (TAB ? ca.G * MT : 0);                 // [4][UP]     w exchange of eigen rows
+    double *xb = ub + 4 * UP;                                  // [2][4][UP]  unnormalised beta
+    int2 *sdesc = reinterpret_cast<int2 *>(xb + 8 * UP);      // [2][64]
+    int *sflag = reinterpret_cast<int *>(sdesc + 128);
+    if (TAB) {
+        for (int idx = tid; idx < ca.K * MT; idx += NW * 64) {
+            const int k = idx / MT, st = idx % MT;
+            sE[(size_t)k * 4 * UP + (st / KQ) * UP + (st % KQ)] = a.E[(size_t)k * Mp + st];
+        }
+        if (ca.G > 0) lds_stage(sD, a.dpow, ca.G * MT * 8, tid, NW * 64);
+    }
+    const Chunk ch = a.chunks[c];
+    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
+    const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
+    if (pass > 0 && ch.last) {
+        if (owner) end_cur[i] = end_prev[i];
+        return;
+    }
+    double b = 0.0;
+    {
+        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (c + 1)) * Mp;
+        const bool fresh = (ch.last || pass == 0);
+        if (i < M) b = fresh ? 1.0 / (double)M : src[i];
+    }
+    if (tid == 0) *sflag = 0;
+    __syncthreads();
+    if (pass > 0) {
+        bool diff = false;
+        if (owner && i < M) {
+            const double u = a.used_b[(size_t)c * Mp + i];
+            if (!(fabs(b - u) <= a.eps_b * fabs(u))) diff = true;
+        }
+        if (__any(diff) && lane == 0) *sflag = 1;
+        __syncthreads();
+        if (*sflag == 0) {
+            if (owner) end_cur[i] = end_prev[i];
+            return;
+        }
+    }
+    if (owner) a.used_b[(size_t)c * Mp + i] = b;
+    if (tid == 0) a.changed[pass] = 1;
+    double tdt[KQ], prm[KQ], pinvrm[KQ];
+    {
+        const size_t ho = (size_t)(a.hot < 0 ? 0 : a.hot) * Mp * Mp;
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) {
+            const int k = kq * KQ + t;
+            tdt[t] = a.TdT[(size_t)k * Mp + i];
+            prm[t] = (a.hot >= 0) ? a.Prm[ho + (size_t)k * Mp + i] : 0.0;
+            pinvrm[t] = (a.hot >= 0) ? a.Pinvrm[ho + (size_t)k * Mp + i] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) { pin_reg(tdt[t]); pin_reg(prm[t]); pin_reg(pinvrm[t]); }
+    }
+    const int2 *rd = a.rowdesc + ch.base;
+    const int nrows = ch.r1 - ch.r0;
+    int2 dnext = make_int2(0, -1);
+    if (w == 0) {
+        sdesc[lane] = (lane < nrows) ? rd[ch.r1 - lane] : make_int2(0, -1);
+        dnext = (lane + 64 < nrows) ? rd[ch.r1 - lane - 64] : make_int2(0, -1);
+    }
+    __syncthreads();
+    auto desc_at = [&](int jj) { return sdesc[((jj >> 6) & 1) * 64 + (jj & 63)]; };
+    int2 d0 = desc_at(0);
+    int ge = __builtin_amdgcn_readfirstlane(d0.y);
+    int kid = __builtin_amdgcn_readfirstlane(d0.x);
+    double dp_cur = (ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + i]) : 0.0;
+    int2 d1 = (nrows > 1) ? desc_at(1) : make_int2(0, -1);
+    // the state enters as beta with sum counted as exactly 1; the e factor of a span-1 row is applied by the producer
+    if (owner) xb[(i / KQ) * UP + (i % KQ)] = b;
+    __syncthreads();
+    double b_raw = b;       // owner: unnormalised beta of the row being processed
+    for (int j = 0; j < nrows; ++j) {
+        const int ell = ch.r1 - j;
+        const int jb = j & 63, bsel = (j >> 6) & 1, cur = j & 1, nxt = cur ^ 1;
+        if (w == 0 && jb == 32) {
+            sdesc[(bsel ^ 1) * 64 + lane] = dnext;
+            dnext = (j - 32 + 128 + lane < nrows) ? rd[ch.r1 - ((j - 32) + 128 + lane)] : make_int2(0, -1);
+        }
+        const int kid_n = __builtin_amdgcn_readfirstlane(d1.x);
+        const int ge_n = (j + 1 < nrows) ? __builtin_amdgcn_readfirstlane(d1.y) : -1;
+        const double dp_nxt = (ge_n >= 0) ? (TAB ? sD[SMCPP_GID(ge_n) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge_n) * Mp + i]) : 0.0;
+        const int2 d2 = (j + 2 < nrows) ? desc_at(j + 2) : make_int2(0, -1);
+        // ---- incoming state (plain beta): quarter, sum, reciprocal ----
+        const double *xin = xb + cur * 4 * UP + kq * UP;
+        double x[KQ];
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < KQ; t += 2) {
+            const double2 v = *reinterpret_cast<const double2 *>(xin + t);
+            x[t] = v.x; x[t + 1] = v.y;
+            s0 += v.x; s1 += v.y;
+        }
+        double sprev = quad_sum_d(s0 + s1);
+        if (j == 0) sprev = 1.0;
+        const double inv = rcp_f64(sprev);
+        // beta[ell] = the normalised vector this row is processed with (hmm.cpp:142)
+        if (owner) a.beta[(size_t)(ch.base + ell) * Mp + i] = (i < M) ? b_raw * inv : 0.0;
+        double bn;
+        if (ge < 0) {
+            // beta <- T (e o beta)   (hmm.cpp:139): this lane needs e on its quarter of the inner index
+            double a0 = 0.0, a1 = 0.0;
+            if (TAB) {
+                const double *eq = sE + (size_t)kid * 4 * UP + kq * UP;
+#pragma unroll
+                for (int t = 0; t < KQ; t += 2) {
+                    const double2 ev = *reinterpret_cast<const double2 *>(eq + t);
+                    a0 = fma(tdt[t] * ev.x, x[t], a0);
+                    a1 = fma(tdt[t + 1] * ev.y, x[t + 1], a1);
+                }
+            } else {
+                const double *eq = a.E + (size_t)kid * Mp + kq * KQ;
+#pragma unroll
+                for (int t = 0; t < KQ; t += 2) {
+                    a0 = fma(tdt[t] * eq[t], x[t], a0);
+                    a1 = fma(tdt[t + 1] * eq[t + 1], x[t + 1], a1);
+                }
+            }
+            bn = quad_sum_d(a0 + a1) * inv;
+        } else {
+            const int es = SMCPP_ES(ge);
+            double wv;
+            if (es == a.hot) {
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int t = 0; t < KQ; t += 2) {
+                    a0 = fma(prm[t], x[t], a0);
+                    a1 = fma(prm[t + 1], x[t + 1], a1);
+                }
+                wv = quad_sum_d(a0 + a1);
+            } else {
+                const double *Pm = a.Prm + (size_t)es * Mp * Mp;
+                double a0 = 0.0;
+                for (int t = 0; t < KQ; ++t) a0 = fma(Pm[(size_t)(kq * KQ + t) * Mp + i], xin[t], a0);
+                wv = quad_sum_d(a0);
+            }
+            wv = wv * dp_cur * inv;
+            if (owner) ub[(i / KQ) * UP + (i % KQ)] = (i < M) ? wv : 0.0;
+            lds_barrier();
+            const double *uin = ub + kq * UP;
+            if (es == a.hot) {
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int t = 0; t < KQ; t += 2) {
+                    const double2 v = *reinterpret_cast<const double2 *>(uin + t);
+                    a0 = fma(pinvrm[t], v.x, a0);
+                    a1 = fma(pinvrm[t + 1], v.y, a1);
+                }
+                bn = quad_sum_d(a0 + a1);
+            } else {
+                const double *Pm = a.Pinvrm + (size_t)es * Mp * Mp;
+                double a0 = 0.0;
+                for (int t = 0; t < KQ; ++t) a0 = fma(Pm[(size_t)(kq * KQ + t) * Mp + i], uin[t], a0);
+                bn = quad_sum_d(a0);
+            }
+        }
+        if (!(i < M)) bn = 0.0;
+        if (owner) xb[nxt * 4 * UP + (i / KQ) * UP + (i % KQ)] = bn;
+        b_raw = bn;
+        kid = kid_n; ge = ge_n; dp_cur = dp_nxt; d1 = d2;
+        lds_barrier();
+    }
+    {
+        const double *xin = xb + (nrows & 1) * 4 * UP + kq * UP;
+        double sl = 0.0;
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) sl += xin[t];
+        const double sprev = quad_sum_d(sl);
+        if (owner) {
+            const double bf = (i < M) ? b_raw / sprev : 0.0;       // beta /= beta.sum()
+            end_cur[i] = bf;
+            if (ch.first) a.beta[(size_t)ch.base * Mp + i] = bf;
+        }
     }
 }
 

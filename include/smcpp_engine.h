@@ -70,6 +70,9 @@ int smcpp_loglik(smcpp_im *im, double *out);
  * summed over contigs; jac [4 x nder] may be NULL. */
 int smcpp_q(smcpp_im *im, double val[4], double *jac);
 
+/* Number of derivative directions the current parameters carry (nder of the last smcpp_set_params; 0 after set_raw). */
+int smcpp_num_derivatives(smcpp_im *im);
+
 /* ---- state / getters (all copy out) -------------------------------------------------------------------------- */
 
 int smcpp_set_save_gamma(smcpp_im *im, int on);          /* InferenceManager::saveGamma, _smcpp.pyx:201-205 */
@@ -132,6 +135,13 @@ int smcpp_host_eigensystem(int n, const double *A, double *P, double *Pinv, doub
 int smcpp_host_prep_onepop(int n, int n_hs, const double *hs, double polarization_error, int Kp, const double *a,
                            const double *s, double theta, double rho, double alpha, int K, const int *keys,
                            double *pi, double *T, double *E);
+
+/* The same with forward-mode derivative seeds da [Kp x nder] on the piece sizes: additionally returns the Jacobians
+ * dpi [M x nder], dT [M*M x nder], dE [K*M x nder] (what the reference carries in its adouble type, common.h:22-25). */
+int smcpp_host_prep_onepop_jac(int n, int n_hs, const double *hs, double polarization_error, int Kp, const double *a,
+                               const double *da, int nder, const double *s, double theta, double rho, double alpha,
+                               int K, const int *keys, double *pi, double *T, double *E, double *dpi, double *dT,
+                               double *dE);
 
 #ifdef __cplusplus
 }

@@ -104,3 +104,26 @@ def prep(a, s, hs, rho, theta, n=-1, raw=False):
     if raw:
         out["raw_csfs"] = rawc
     return out
+
+
+def prep_jac(a, da, s, hs, rho, theta, n):
+    """Reference values AND forward-mode Jacobians (w.r.t. the seeds ``da`` [Kp x nder] on the piece sizes) of pi,
+    the transition matrix, the average coalescence times and the conditioned SFS after ``incorporate_theta``."""
+    L_ = lib()
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    da = np.ascontiguousarray(da, dtype=np.float64)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    hs = np.ascontiguousarray(hs, dtype=np.float64)
+    M = len(hs) - 1
+    nder = da.shape[1]
+    pi = np.zeros(M); dpi = np.zeros((M, nder))
+    T = np.zeros((M, M)); dT = np.zeros((M, M, nder))
+    ct = np.zeros(M); dct = np.zeros((M, nder))
+    cs = np.zeros((M, 3, n + 1)); dcs = np.zeros((M, 3, n + 1, nder))
+    rc = L_.ref_prep_jac(len(a), _p(a, C.c_double), _p(da, C.c_double), int(nder), _p(s, C.c_double), M,
+                         _p(hs, C.c_double), C.c_double(rho), C.c_double(theta), int(n),
+                         _p(pi, C.c_double), _p(dpi, C.c_double), _p(T, C.c_double), _p(dT, C.c_double),
+                         _p(ct, C.c_double), _p(dct, C.c_double), _p(cs, C.c_double), _p(dcs, C.c_double))
+    if rc != 0:
+        raise RuntimeError(L_.ref_last_error().decode())
+    return dict(pi=pi, dpi=dpi, T=T, dT=dT, avg_ct=ct, davg_ct=dct, csfs=cs, dcsfs=dcs)

@@ -227,3 +227,63 @@ extern "C" int ref_prep(int Kp, const double *a, const double *s, int M, const d
         return 1;
     }
 }
+
+// Same as ref_prep but with forward-mode derivative seeds on the piece sizes (make_params of _smcpp.pyx:66-83 with a
+// non-empty dlist): da [Kp x nder].  Jacobian outputs are [size x nder] row-major.
+extern "C" int ref_prep_jac(int Kp, const double *a, const double *da, int nder, const double *s, int M,
+                            const double *hs, double rho, double theta, int n,
+                            double *pi_out, double *dpi_out, double *T_out, double *dT_out,
+                            double *avg_ct_out, double *davg_ct_out, double *csfs_out, double *dcsfs_out)
+{
+    try
+    {
+        std::vector<adouble> av, sv;
+        for (int k = 0; k < Kp; ++k)
+        {
+            Eigen::VectorXd d(nder);
+            for (int j = 0; j < nder; ++j) d(j) = da[k * nder + j];
+            av.push_back(adouble(a[k], d));
+            sv.push_back(adouble(s[k]));
+        }
+        ParameterVector params{av, sv};
+        std::vector<double> hidden_states(hs, hs + M + 1);
+        PiecewiseConstantRateFunction<adouble> eta(params, hidden_states);
+        auto put = [nder](const adouble &x, double *v, double *j, size_t idx) {
+            if (v) v[idx] = x.value();
+            if (j) for (int d = 0; d < nder; ++d) j[idx * nder + d] = x.derivatives().size() ? x.derivatives()(d) : 0.0;
+        };
+        {
+            Vector<adouble> pi(M);
+            for (int m = 0; m < M - 1; ++m)
+                pi(m) = exp(-(eta.R(hidden_states.at(m)))) - exp(-(eta.R(hidden_states.at(m + 1))));
+            pi(M - 1) = exp(-(eta.R(hidden_states.at(M - 1))));
+            adouble small = eta.zero() + 1e-20;
+            pi = pi.unaryExpr([small](const adouble &x) { if (x < 1e-20) return small; return x; });
+            pi /= pi.sum();
+            for (int m = 0; m < M; ++m) put(pi(m), pi_out, dpi_out, m);
+        }
+        {
+            Matrix<adouble> T = compute_transition(eta, rho);
+            for (int i = 0; i < M; ++i)
+                for (int j = 0; j < M; ++j) put(T(i, j), T_out, dT_out, (size_t)i * M + j);
+        }
+        {
+            std::vector<adouble> v = eta.average_coal_times();
+            for (int m = 0; m < M; ++m) put(v.at(m), avg_ct_out, davg_ct_out, m);
+        }
+        if (n >= 0 && (csfs_out || dcsfs_out))
+        {
+            OnePopConditionedSFS<adouble> csfs(n);
+            std::vector<Matrix<adouble> > v = incorporate_theta(csfs.compute(eta), theta);
+            for (int m = 0; m < M; ++m)
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j <= n; ++j) put(v.at(m)(i, j), csfs_out, dcsfs_out, (size_t)(m * 3 + i) * (n + 1) + j);
+        }
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_err = e.what();
+        return 1;
+    }
+}

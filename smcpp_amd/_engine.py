@@ -38,6 +38,10 @@ def lib():
     L.smcpp_set_chunking.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
     L.smcpp_host_prep_onepop.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_int, _dp, _dp, C.c_double,
                                          C.c_double, C.c_double, C.c_int, _ip, _dp, _dp, _dp]
+    L.smcpp_host_prep_onepop_jac.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_int, _dp, _dp, C.c_int, _dp,
+                                             C.c_double, C.c_double, C.c_double, C.c_int, _ip, _dp, _dp, _dp, _dp, _dp,
+                                             _dp]
+    L.smcpp_set_params.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp]
     _lib = L
     return L
 
@@ -50,7 +54,7 @@ EXPORTS = [
     "smcpp_get_xisum", "smcpp_get_gamma", "smcpp_get_gamma_sums", "smcpp_get_pi", "smcpp_get_transition",
     "smcpp_get_emission_probs", "smcpp_get_gamma_argmax", "smcpp_set_global_keys", "smcpp_pack_stats",
     "smcpp_unpack_stats", "smcpp_set_chunking", "smcpp_last_timing", "smcpp_stream", "smcpp_set_num_threads",
-    "smcpp_host_eigensystem", "smcpp_host_prep_onepop",
+    "smcpp_host_eigensystem", "smcpp_host_prep_onepop", "smcpp_host_prep_onepop_jac", "smcpp_num_derivatives",
 ]
 
 
@@ -88,3 +92,20 @@ def host_prep_onepop(n, hs, polarization_error, a, s, theta, rho, alpha, keys):
                                        float(theta), float(rho), float(alpha), K, iptr(keys), dptr(pi), dptr(T),
                                        dptr(E)))
     return pi, T, E
+
+
+def host_prep_onepop_jac(n, hs, polarization_error, a, da, s, theta, rho, alpha, keys):
+    hs = np.ascontiguousarray(hs, dtype=np.float64)
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    da = np.ascontiguousarray(da, dtype=np.float64)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    keys = np.ascontiguousarray(keys, dtype=np.int32)
+    M = len(hs) - 1
+    K = len(keys)
+    nder = da.shape[1]
+    pi = np.zeros(M); T = np.zeros((M, M)); E = np.zeros((K, M))
+    dpi = np.zeros((M, nder)); dT = np.zeros((M, M, nder)); dE = np.zeros((K, M, nder))
+    check(lib().smcpp_host_prep_onepop_jac(int(n), len(hs), dptr(hs), float(polarization_error), len(a), dptr(a),
+                                           dptr(da), int(nder), dptr(s), float(theta), float(rho), float(alpha), K,
+                                           iptr(keys), dptr(pi), dptr(T), dptr(E), dptr(dpi), dptr(dT), dptr(dE)))
+    return pi, T, E, dpi, dT, dE

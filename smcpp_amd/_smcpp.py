@@ -195,6 +195,15 @@ class _PyInferenceManager:
             return list(q)
         return float(q.sum())
 
+    def Q_with_gradient(self):
+        """The four Q terms and their forward-mode Jacobian [4 x nder] with respect to the derivative seeds handed
+        to `set_params` (what `Q()` returns inside an ad number in the reference, `_smcpp.pyx:277-301`)."""
+        q = np.zeros(4)
+        nder = E.lib().smcpp_num_derivatives(self._im)
+        jac = np.zeros((4, max(nder, 1)))
+        E.check(E.lib().smcpp_q(self._im, E.dptr(q), E.dptr(jac)))
+        return q, jac[:, :nder]
+
     def loglik(self):
         """``_smcpp.pyx:303-308``: sum over contigs."""
         return float(sum(self.logliks()))
@@ -264,7 +273,12 @@ class PyOnePopInferenceManager(_PyInferenceManager):
         a = aca(np.asarray(m.stepwise_values(), dtype=np.float64))
         s = aca(np.asarray(m.s, dtype=np.float64))
         assert np.all(a > 0) and len(a) > 0
-        E.check(E.lib().smcpp_set_params(self._im, len(a), E.dptr(a), None, 0, E.dptr(s)))
+        seeds = m.derivative_seeds() if hasattr(m, "derivative_seeds") else None
+        if seeds is None:
+            E.check(E.lib().smcpp_set_params(self._im, len(a), E.dptr(a), None, 0, E.dptr(s)))
+        else:
+            da = aca(np.asarray(seeds, dtype=np.float64))
+            E.check(E.lib().smcpp_set_params(self._im, len(a), E.dptr(a), E.dptr(da), da.shape[1], E.dptr(s)))
 
 
 class PyTwoPopInferenceManager(_PyInferenceManager):

@@ -107,9 +107,12 @@ struct smcpp_im {
     long long n_e_rows = 0, n_1_rows = 0;
     // ---- parameters -------------------------------------------------------------------------------------------
     double theta = NAN, rho = NAN, alpha = 1.0;
-    bool have_raw = false, dirty = true;
+    bool have_raw = false, dirty = true, params_fresh = false;
     std::vector<double> pi, T, E;          // [M], [M*M], [K*M]
     smcpp_host::ModelParams model;         // a, s (for set_params)
+    std::vector<double> model_da;          // [Kp x nder] derivative seeds of a
+    int nder = 0;
+    std::vector<double> dpi, dT, dE;       // Jacobians [size x nder] of pi, T, E w.r.t. the seeds
     bool have_model = false;
     bool save_gamma = false, gamma_valid = false;
     // ---- device -----------------------------------------------------------------------------------------------
@@ -495,13 +498,15 @@ void smcpp_im::alloc_device() {
 // ---------------------------------------------------------------------------------------------------------------
 void smcpp_im::prepare_params() {
     // do_dirty_work (inference_manager.cpp:213-229) for the model-parameter path; the raw path already has pi/T/E.
-    if (have_raw) return;
+    if (have_raw || params_fresh) return;
     if (!have_model) throw std::runtime_error("no model parameters: call set_params or set_raw before E_step");
     if (npop != 1) throw std::runtime_error("two-population parameter preparation (JointCSFS) is not built yet; "
                                             "use set_raw");
     if (std::isnan(theta) || std::isnan(rho)) throw std::runtime_error("theta / rho / alpha must be set");
     smcpp_host::OnePopPrep prep(n[0], hs, polarization_error);
-    prep.compute(model, theta, rho, alpha, keys, K, pi, T, E);
+    if (nder > 0) prep.compute_with_jacobian(model, model_da, nder, theta, rho, alpha, keys, K, pi, T, E, dpi, dT, dE);
+    else prep.compute(model, theta, rho, alpha, keys, K, pi, T, E);
+    params_fresh = true;
 }
 
 void smcpp_im::host_prep_and_upload() {
@@ -984,18 +989,22 @@ int smcpp_create_twopop(int n1, int n2, int a1, int a2, int n_contigs, const int
 
 void smcpp_destroy(smcpp_im *im) { delete im; }
 
-int smcpp_set_theta(smcpp_im *im, double v) { API_BEGIN im->theta = v; im->dirty = true; if (im->have_model) im->have_raw = false; API_END }
-int smcpp_set_rho(smcpp_im *im, double v) { API_BEGIN im->rho = v; im->dirty = true; if (im->have_model) im->have_raw = false; API_END }
-int smcpp_set_alpha(smcpp_im *im, double v) { API_BEGIN im->alpha = v; im->dirty = true; if (im->have_model) im->have_raw = false; API_END }
+int smcpp_set_theta(smcpp_im *im, double v) { API_BEGIN im->params_fresh = false; im->theta = v; im->dirty = true; if (im->have_model) im->have_raw = false; API_END }
+int smcpp_set_rho(smcpp_im *im, double v) { API_BEGIN im->params_fresh = false; im->rho = v; im->dirty = true; if (im->have_model) im->have_raw = false; API_END }
+int smcpp_set_alpha(smcpp_im *im, double v) { API_BEGIN im->params_fresh = false; im->alpha = v; im->dirty = true; if (im->have_model) im->have_raw = false; API_END }
 
 int smcpp_set_params(smcpp_im *im, int K, const double *a, const double *da, int nder, const double *s) {
     API_BEGIN
     if (K <= 0) throw std::runtime_error("empty parameter vector");
     for (int k = 0; k < K; ++k)
         if (!(a[k] > 0)) throw std::runtime_error("model pieces must be positive");
-    (void)da; (void)nder;   // derivatives ride on the M-step path, not built yet
+    if (nder > smcpp_host::MAXD) throw std::runtime_error("too many derivative directions (max 64)");
     im->model.a.assign(a, a + K);
     im->model.s.assign(s, s + K);
+    im->nder = (da && nder > 0) ? nder : 0;
+    im->model_da.clear();
+    if (im->nder) im->model_da.assign(da, da + (size_t)K * nder);
+    im->params_fresh = false;
     im->have_model = true;
     im->have_raw = false;
     im->dirty = true;
@@ -1019,6 +1028,7 @@ int smcpp_set_raw(smcpp_im *im, const double *pi, const double *T, int K, const 
     im->E.swap(Enew);
     im->have_raw = true;
     im->dirty = true;
+    im->nder = 0;
     API_END
 }
 
@@ -1052,10 +1062,11 @@ static double dcs(const std::vector<double> &x) {   // doubly_compensated_summat
 
 int smcpp_q(smcpp_im *im, double val[4], double *jac) {
     API_BEGIN
-    (void)jac;
     const int M = im->M, K = im->K;
+    if (!im->have_raw) im->prepare_params();   // Q() does do_dirty_work() first (inference_manager.cpp:119)
     if ((int)im->pi.size() != M) throw std::runtime_error("parameters are not set");
-    if (im->dirty && !im->have_raw) im->prepare_params();   // Q() does do_dirty_work() first (inference_manager.cpp:119)
+    const int nder = im->have_raw ? 0 : im->nder;
+    if (jac) for (int i = 0; i < 4 * nder; ++i) jac[i] = 0.0;
     for (int i = 0; i < 4; ++i) val[i] = 0.0;
     std::vector<double> logpi(M), logT((size_t)M * M), logE((size_t)K * M);
     for (int i = 0; i < M; ++i) logpi[i] = std::log(im->pi[i]);
@@ -1066,11 +1077,20 @@ int smcpp_q(smcpp_im *im, double val[4], double *jac) {
             if (im->E[(size_t)k * M + i] <= 0.0) bad[k] = 1;
             logE[(size_t)k * M + i] = std::log(im->E[(size_t)k * M + i]);
         }
+    // d/d(seed) of sum w log x = sum (w / x) dx  (forward-mode derivatives of hmm.cpp:161-185)
+    auto add_jac = [&](int term, const double *w, const double *x, const double *dx, size_t cnt) {
+        if (!jac || nder == 0) return;
+        for (size_t i = 0; i < cnt; ++i) {
+            const double f = w[i] / x[i];
+            for (int d = 0; d < nder; ++d) jac[term * nder + d] += f * dx[i * nder + d];
+        }
+    };
     if (im->have_reduced) {
         // statistics already summed over every rank's contigs
         const double *g0 = &im->g_stats[1], *xs = g0 + M, *gs = xs + (size_t)M * M;
         const int Kg = (int)(im->gkeys.size() / im->keylen);
         for (int i = 0; i < M; ++i) val[0] += logpi[i] * g0[i];
+        add_jac(0, g0, im->pi.data(), im->dpi.data(), M);
         std::vector<double> b0, b1;
         for (int kg = 0; kg < Kg; ++kg) {
             int kl = -1;
@@ -1078,12 +1098,15 @@ int smcpp_q(smcpp_im *im, double val[4], double *jac) {
             if (kl < 0) continue;   // a key no contig of this rank holds still needs its emission vector
             auto &b = im->key_nbpos[kl] ? b1 : b0;
             for (int i = 0; i < M; ++i) b.push_back(logE[(size_t)kl * M + i] * gs[(size_t)kg * M + i]);
+            add_jac(im->key_nbpos[kl] ? 2 : 1, gs + (size_t)kg * M, &im->E[(size_t)kl * M],
+                    nder ? &im->dE[(size_t)kl * M * nder] : nullptr, M);
         }
         val[1] = dcs(b0); val[2] = dcs(b1);
         std::vector<double> es((size_t)M * M);
         for (int j = 0; j < M; ++j)
             for (int i = 0; i < M; ++i) es[(size_t)j * M + i] = logT[(size_t)i * M + j] * xs[(size_t)i * M + j];
         val[3] = dcs(es);
+        add_jac(3, xs, im->T.data(), im->dT.data(), (size_t)M * M);
         return 0;
     }
     im->fetch_stats();
@@ -1091,6 +1114,7 @@ int smcpp_q(smcpp_im *im, double val[4], double *jac) {
         double q0 = 0.0;
         for (int i = 0; i < M; ++i) q0 += logpi[i] * im->h_gamma0[(size_t)c * M + i];
         val[0] += q0;
+        add_jac(0, &im->h_gamma0[(size_t)c * M], im->pi.data(), im->dpi.data(), M);
         std::vector<double> b0, b1;
         bool inf0 = false, inf1 = false;
         for (int k = 0; k < K; ++k) {
@@ -1099,6 +1123,8 @@ int smcpp_q(smcpp_im *im, double val[4], double *jac) {
             auto &b = im->key_nbpos[k] ? b1 : b0;
             for (int i = 0; i < M; ++i)
                 b.push_back(logE[(size_t)k * M + i] * im->h_gsum[((size_t)c * K + k) * M + i]);
+            add_jac(im->key_nbpos[k] ? 2 : 1, &im->h_gsum[((size_t)c * K + k) * M], &im->E[(size_t)k * M],
+                    nder ? &im->dE[(size_t)k * M * nder] : nullptr, M);
         }
         val[1] += inf0 ? -INFINITY : dcs(b0);
         val[2] += inf1 ? -INFINITY : dcs(b1);
@@ -1107,6 +1133,7 @@ int smcpp_q(smcpp_im *im, double val[4], double *jac) {
         for (int j = 0; j < M; ++j)
             for (int i = 0; i < M; ++i) es[(size_t)j * M + i] = logT[(size_t)i * M + j] * xs[(size_t)i * M + j];
         val[3] += dcs(es);
+        add_jac(3, xs, im->T.data(), im->dT.data(), (size_t)M * M);
     }
     API_END
 }
@@ -1126,6 +1153,7 @@ int smcpp_set_hidden_states(smcpp_im *im, int n_hs, const double *hs) {
     if (n_hs != (int)im->hs.size()) throw std::runtime_error("hidden states must be same size");
     im->hs.assign(hs, hs + n_hs);
     im->dirty = true;
+    im->params_fresh = false;
     if (im->have_model) im->have_raw = false;
     API_END
 }
@@ -1331,6 +1359,34 @@ int smcpp_host_prep_onepop(int n, int n_hs, const double *hs, double polarizatio
     if (pi) std::memcpy(pi, piv.data(), sizeof(double) * M);
     if (T) std::memcpy(T, Tv.data(), sizeof(double) * M * M);
     if (E) std::memcpy(E, Ev.data(), sizeof(double) * (size_t)K * M);
+    API_END
+}
+
+
+int smcpp_num_derivatives(smcpp_im *im) { return im->have_raw ? 0 : im->nder; }
+
+// values and Jacobians of the one-population preparation: da [Kp x nder]; dpi [M x nder], dT [M*M x nder], dE [K*M x nder]
+int smcpp_host_prep_onepop_jac(int n, int n_hs, const double *hs, double polarization_error, int Kp, const double *a,
+                               const double *da, int nder, const double *s, double theta, double rho, double alpha,
+                               int K, const int *keys, double *pi, double *T, double *E, double *dpi, double *dT,
+                               double *dE) {
+    API_BEGIN
+    std::vector<double> hsv(hs, hs + n_hs);
+    smcpp_host::OnePopPrep prep(n, hsv, polarization_error);
+    smcpp_host::ModelParams mp;
+    mp.a.assign(a, a + Kp);
+    mp.s.assign(s, s + Kp);
+    std::vector<double> dav(da, da + (size_t)Kp * nder);
+    std::vector<int> kv(keys, keys + (size_t)K * 3);
+    std::vector<double> piv, Tv, Ev, dpiv, dTv, dEv;
+    prep.compute_with_jacobian(mp, dav, nder, theta, rho, alpha, kv, K, piv, Tv, Ev, dpiv, dTv, dEv);
+    const int M = n_hs - 1;
+    std::memcpy(pi, piv.data(), sizeof(double) * M);
+    std::memcpy(T, Tv.data(), sizeof(double) * M * M);
+    std::memcpy(E, Ev.data(), sizeof(double) * (size_t)K * M);
+    std::memcpy(dpi, dpiv.data(), sizeof(double) * (size_t)M * nder);
+    std::memcpy(dT, dTv.data(), sizeof(double) * (size_t)M * M * nder);
+    std::memcpy(dE, dEv.data(), sizeof(double) * (size_t)K * M * nder);
     API_END
 }
 

@@ -292,11 +292,85 @@ inline std::shared_ptr<const CsfsTables> csfs_tables(int n) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// forward-mode dual numbers (the role of Eigen::AutoDiffScalar `adouble`, include/common.h:22-25): value + up to MAXD
+// directional derivatives.  The active number of directions is a thread-local set by DualScope.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int MAXD = 64;
+inline int &dual_nder() { static thread_local int n = 0; return n; }
+struct DualScope {
+    int prev;
+    explicit DualScope(int n) : prev(dual_nder()) {
+        if (n > MAXD) throw std::runtime_error("too many derivative directions (max 64)");
+        dual_nder() = n;
+    }
+    ~DualScope() { dual_nder() = prev; }
+};
+
+template <typename F>
+struct Dual {
+    F v;
+    F d[MAXD];
+    Dual() : v(0) { for (int i = 0; i < dual_nder(); ++i) d[i] = 0; }
+    Dual(F x) : v(x) { for (int i = 0; i < dual_nder(); ++i) d[i] = 0; }
+    template <typename G>
+    explicit Dual(const Dual<G> &o) : v((F)o.v) { for (int i = 0; i < dual_nder(); ++i) d[i] = (F)o.d[i]; }
+};
+#define SMCPP_DUAL_LOOP for (int i_ = 0, n_ = dual_nder(); i_ < n_; ++i_)
+template <typename F> inline Dual<F> operator+(const Dual<F> &a, const Dual<F> &b) { Dual<F> r; r.v = a.v + b.v; SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] + b.d[i_]; return r; }
+template <typename F> inline Dual<F> operator-(const Dual<F> &a, const Dual<F> &b) { Dual<F> r; r.v = a.v - b.v; SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] - b.d[i_]; return r; }
+template <typename F> inline Dual<F> operator*(const Dual<F> &a, const Dual<F> &b) { Dual<F> r; r.v = a.v * b.v; SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] * b.v + a.v * b.d[i_]; return r; }
+template <typename F> inline Dual<F> operator/(const Dual<F> &a, const Dual<F> &b) { Dual<F> r; const F ib = 1 / b.v; r.v = a.v * ib; SMCPP_DUAL_LOOP r.d[i_] = (a.d[i_] - r.v * b.d[i_]) * ib; return r; }
+template <typename F> inline Dual<F> operator-(const Dual<F> &a) { Dual<F> r; r.v = -a.v; SMCPP_DUAL_LOOP r.d[i_] = -a.d[i_]; return r; }
+template <typename F, typename G> inline Dual<F> operator+(const Dual<F> &a, G b) { Dual<F> r(a); r.v += (F)b; return r; }
+template <typename F, typename G> inline Dual<F> operator+(G b, const Dual<F> &a) { return a + b; }
+template <typename F, typename G> inline Dual<F> operator-(const Dual<F> &a, G b) { Dual<F> r(a); r.v -= (F)b; return r; }
+template <typename F, typename G> inline Dual<F> operator-(G b, const Dual<F> &a) { Dual<F> r = -a; r.v += (F)b; return r; }
+template <typename F, typename G> inline Dual<F> operator*(const Dual<F> &a, G b) { Dual<F> r; r.v = a.v * (F)b; SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] * (F)b; return r; }
+template <typename F, typename G> inline Dual<F> operator*(G b, const Dual<F> &a) { return a * b; }
+template <typename F, typename G> inline Dual<F> operator/(const Dual<F> &a, G b) { return a * ((F)1 / (F)b); }
+template <typename F, typename G> inline Dual<F> operator/(G b, const Dual<F> &a) { Dual<F> r; r.v = (F)b / a.v; SMCPP_DUAL_LOOP r.d[i_] = -r.v * a.d[i_] / a.v; return r; }
+template <typename F> inline Dual<F> &operator+=(Dual<F> &a, const Dual<F> &b) { a.v += b.v; SMCPP_DUAL_LOOP a.d[i_] += b.d[i_]; return a; }
+template <typename F> inline Dual<F> &operator-=(Dual<F> &a, const Dual<F> &b) { a.v -= b.v; SMCPP_DUAL_LOOP a.d[i_] -= b.d[i_]; return a; }
+template <typename F, typename G> inline Dual<F> &operator+=(Dual<F> &a, G b) { a.v += (F)b; return a; }
+template <typename F, typename G> inline Dual<F> &operator*=(Dual<F> &a, G b) { a.v *= (F)b; SMCPP_DUAL_LOOP a.d[i_] *= (F)b; return a; }
+template <typename F> inline Dual<F> &operator*=(Dual<F> &a, const Dual<F> &b) { a = a * b; return a; }
+template <typename F> inline Dual<F> &operator/=(Dual<F> &a, const Dual<F> &b) { a = a / b; return a; }
+template <typename F, typename G> inline Dual<F> &operator/=(Dual<F> &a, G b) { a = a / b; return a; }
+inline double m_exp(double x) { return std::exp(x); }
+inline long double m_exp(long double x) { return expl(x); }
+inline double m_expm1(double x) { return std::expm1(x); }
+inline long double m_expm1(long double x) { return expm1l(x); }
+inline double m_log(double x) { return std::log(x); }
+inline long double m_log(long double x) { return logl(x); }
+inline double m_sqrt(double x) { return std::sqrt(x); }
+inline long double m_sqrt(long double x) { return sqrtl(x); }
+inline double m_sinh(double x) { return std::sinh(x); }
+inline long double m_sinh(long double x) { return sinhl(x); }
+inline double m_cosh(double x) { return std::cosh(x); }
+inline long double m_cosh(long double x) { return coshl(x); }
+template <typename F> inline Dual<F> m_exp(const Dual<F> &a) { Dual<F> r; r.v = m_exp(a.v); SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] * r.v; return r; }
+template <typename F> inline Dual<F> m_expm1(const Dual<F> &a) { Dual<F> r; r.v = m_expm1(a.v); const F e = m_exp(a.v); SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] * e; return r; }
+template <typename F> inline Dual<F> m_log(const Dual<F> &a) { Dual<F> r; r.v = m_log(a.v); SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] / a.v; return r; }
+template <typename F> inline Dual<F> m_sqrt(const Dual<F> &a) { Dual<F> r; r.v = m_sqrt(a.v); SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] / (2 * r.v); return r; }
+template <typename F> inline Dual<F> m_sinh(const Dual<F> &a) { Dual<F> r; r.v = m_sinh(a.v); const F c = m_cosh(a.v); SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] * c; return r; }
+inline double sval(double x) { return x; }
+inline long double sval(long double x) { return x; }
+template <typename F> inline F sval(const Dual<F> &x) { return x.v; }
+typedef Dual<double> dual;
+
+template <typename S>
+struct ModelParamsT {
+    std::vector<S> a;           // piece sizes (with derivative seeds when S is dual)
+    std::vector<double> s;      // piece lengths carry no derivatives (_smcpp.pyx:78-81)
+};
+
+// ---------------------------------------------------------------------------------------------------------------
 // A9: piecewise-constant rate function
 // ---------------------------------------------------------------------------------------------------------------
-class RateFunction {
+template <typename S>
+class RateFunctionT {
 public:
-    RateFunction(const ModelParams &p, const std::vector<double> &hs) : hidden_states(hs) {
+    RateFunctionT(const ModelParamsT<S> &p, const std::vector<double> &hs) : hidden_states(hs) {
         if (p.a.size() != p.s.size() || p.a.empty()) throw std::runtime_error("all params must have same size");
         K = (int)p.a.size();
         ada.resize(K);
@@ -319,28 +393,28 @@ public:
             }
         }
         K = (int)ada.size();
-        Rrng.assign(K + 1, 0.0);
+        Rrng.assign(K + 1, S(0.0));
         for (int k = 0; k < K; ++k) Rrng[k + 1] = Rrng[k] + ada[k] * (ts[k + 1] - ts[k]);
     }
 
-    double R(double t) const {
+    S R(double t) const {
         auto ti = std::upper_bound(ts.begin(), ts.end(), t) - 1;
         const int ip = (int)(ti - ts.begin());
         return Rrng[ip] + ada[ip] * (t - *ti);
     }
 
     // int_a^b exp(-(R(t) + log_denom)) dt
-    double R_integral(double a, double b, double log_denom) const {
+    S R_integral(double a, double b, const S &log_denom) const {
         const int ip_a = (int)(std::upper_bound(ts.begin(), ts.end(), a) - 1 - ts.begin());
         int ip_b = (int)(std::upper_bound(ts.begin(), ts.end(), b) - 1 - ts.begin());
         if (std::isinf(b)) ip_b = (int)ts.size() - 2;
-        double ret = 0.0;
+        S ret(0.0);
         for (int i = ip_a; i < ip_b + 1; ++i) {
             const double left = std::max(a, ts[i]), right = std::min(b, ts[i + 1]);
             const double diff = right - left;
-            double r = std::exp(-(R(left) + log_denom));
-            if (ada[i] > 0.0) {
-                if (!std::isinf(diff)) r *= -std::expm1(-diff * ada[i]);
+            S r = m_exp(-(R(left) + log_denom));
+            if (sval(ada[i]) > 0.0) {
+                if (!std::isinf(diff)) r *= -m_expm1(-diff * ada[i]);
                 r /= ada[i];
             } else r *= diff;
             ret += r;
@@ -348,90 +422,89 @@ public:
         return ret;
     }
 
-    std::vector<double> average_coal_times() const {
-        std::vector<double> ret;
+    // NaN value marks "no coalescence possible in this interval" (piecewise_constant_rate_function.cpp:380-388)
+    std::vector<S> average_coal_times() const {
+        std::vector<S> ret;
         for (size_t i = 1; i < hidden_states.size(); ++i) {
-            const double R0 = Rrng[hs_indices[i - 1]], R1 = Rrng[hs_indices[i]];
-            if (R0 == R1) { ret.push_back(std::numeric_limits<double>::quiet_NaN()); continue; }
-            double log_denom = -R0;
+            const S R0 = Rrng[hs_indices[i - 1]], R1 = Rrng[hs_indices[i]];
+            if (sval(R0) == sval(R1)) { ret.push_back(S(std::numeric_limits<double>::quiet_NaN())); continue; }
+            S log_denom = -R0;
             const bool inf = std::isinf(ts[hs_indices[i]]);
-            if (!inf) log_denom += std::log(-std::expm1(-(R1 - R0)));
-            double x = hidden_states[i - 1] * std::exp(-(R0 + log_denom)) +
-                       R_integral(ts[hs_indices[i - 1]], ts[hs_indices[i]], log_denom);
-            if (!inf) x -= hidden_states[i] * std::exp(-(R1 + log_denom));
+            if (!inf) log_denom += m_log(-m_expm1(-(R1 - R0)));
+            S x = hidden_states[i - 1] * m_exp(-(R0 + log_denom)) +
+                  R_integral(ts[hs_indices[i - 1]], ts[hs_indices[i]], log_denom);
+            if (!inf) x -= hidden_states[i] * m_exp(-(R1 + log_denom));
             ret.push_back(x);
-            if (x > hidden_states[i] || x < hidden_states[i - 1])
+            if (sval(x) > hidden_states[i] || sval(x) < hidden_states[i - 1])
                 throw std::runtime_error("erroneous average coalescence time");
         }
         return ret;
     }
 
     // ---- integrals used by the conditioned SFS (piecewise_constant_rate_function.cpp:87-138,198-334) ----
-    static double below_helper(long rate, double tsm, double tsm1, double ad, double Rr, double log_denom) {
-        if (ad == 0) return 0.0;
+    static S below_helper(long rate, double tsm, double tsm1, const S &ad, const S &Rr, const S &log_denom) {
+        if (sval(ad) == 0) return S(0.0);
         const long l1r = 1 + rate;
         const double l1rinv = 1.0 / (double)l1r;
-        const double adadiff = ad * (tsm1 - tsm);
+        const S adadiff = ad * (tsm1 - tsm);
         if (rate == 0) {
-            if (tsm1 == INFINITY) return std::exp(-Rr - log_denom) / ad;
-            return std::exp(-Rr - log_denom) * (1.0 - std::exp(-adadiff) * (1.0 + adadiff)) / ad;
+            if (tsm1 == INFINITY) return m_exp(-Rr - log_denom) / ad;
+            return m_exp(-Rr - log_denom) * (1.0 - m_exp(-adadiff) * (1.0 + adadiff)) / ad;
         }
-        if (tsm1 == INFINITY) return std::exp(-l1r * Rr - log_denom) * (1.0 - l1rinv) / (rate * ad);
-        return std::exp(-l1r * Rr - log_denom) * (std::expm1(-l1r * adadiff) * l1rinv - std::expm1(-adadiff)) / (rate * ad);
+        if (tsm1 == INFINITY) return m_exp(-(double)l1r * Rr - log_denom) * (1.0 - l1rinv) / ((double)rate * ad);
+        return m_exp(-(double)l1r * Rr - log_denom) * (m_expm1(-(double)l1r * adadiff) * l1rinv - m_expm1(-adadiff)) /
+               ((double)rate * ad);
     }
-    static double above_helper(long rate, long lam, double tsm, double tsm1, double ad, double Rr, double log_coef) {
-        if (ad == 0) return 0.0;
-        const double adadiff = ad * (tsm1 - tsm);
-        const long l1 = lam + 1;
+    static S above_helper(long rate, long lam, double tsm, double tsm1, const S &ad, const S &Rr, const S &log_coef) {
+        if (sval(ad) == 0) return S(0.0);
+        const S adadiff = ad * (tsm1 - tsm);
+        const double l1 = (double)(lam + 1), rt = (double)rate;
         if (rate == 0)
-            return std::exp(-l1 * Rr + log_coef) * (std::expm1(-l1 * adadiff) + l1 * adadiff) / l1 / l1 / ad;
-        if (l1 == rate) {
-            if (tsm1 == INFINITY) return std::exp(-rate * Rr + log_coef) / rate / rate / ad;
-            return std::exp(-rate * Rr + log_coef) * (1 - std::exp(-rate * adadiff) * (1 + rate * adadiff)) / rate / rate / ad;
+            return m_exp(-l1 * Rr + log_coef) * (m_expm1(-l1 * adadiff) + l1 * adadiff) / l1 / l1 / ad;
+        if (lam + 1 == rate) {
+            if (tsm1 == INFINITY) return m_exp(-rt * Rr + log_coef) / rt / rt / ad;
+            return m_exp(-rt * Rr + log_coef) * (1.0 - m_exp(-rt * adadiff) * (1.0 + rt * adadiff)) / rt / rt / ad;
         }
-        if (tsm1 == INFINITY) return std::exp(-l1 * Rr + log_coef) / l1 / rate / ad;
-        if (rate < l1)
-            return -std::exp(-l1 * Rr + log_coef) *
-                   (std::expm1(-l1 * adadiff) / l1 +
-                    (std::exp(-rate * adadiff) * -std::expm1(-(double)(l1 - rate) * adadiff) / (double)(l1 - rate))) /
-                   rate / ad;
-        return -std::exp(-l1 * Rr + log_coef) *
-               (std::expm1(-l1 * adadiff) / l1 +
-                (std::exp(-l1 * adadiff) * std::expm1(-(double)(rate - l1) * adadiff) / (double)(l1 - rate))) /
-               rate / ad;
+        if (tsm1 == INFINITY) return m_exp(-l1 * Rr + log_coef) / l1 / rt / ad;
+        if (rate < lam + 1)
+            return -m_exp(-l1 * Rr + log_coef) *
+                   (m_expm1(-l1 * adadiff) / l1 + (m_exp(-rt * adadiff) * -m_expm1(-(l1 - rt) * adadiff) / (l1 - rt))) / rt / ad;
+        return -m_exp(-l1 * Rr + log_coef) *
+               (m_expm1(-l1 * adadiff) / l1 + (m_exp(-l1 * adadiff) * m_expm1(-(rt - l1) * adadiff) / (l1 - rt))) / rt / ad;
     }
-    static double single_integral(long rate, double tsm, double tsm1, double ad, double Rr, double log_coef) {
-        if (rate == 0) return std::exp(log_coef) * (tsm1 - tsm);
-        double ret = std::exp(-rate * Rr + log_coef);
-        if (tsm1 < INFINITY) ret *= -std::expm1(-rate * ad * (tsm1 - tsm));
-        ret /= ad * rate;
+    static S single_integral(long rate, double tsm, double tsm1, const S &ad, const S &Rr, const S &log_coef) {
+        if (rate == 0) return m_exp(log_coef) * (tsm1 - tsm);
+        S ret = m_exp(-(double)rate * Rr + log_coef);
+        if (tsm1 < INFINITY) ret *= -m_expm1(-(double)rate * ad * (tsm1 - tsm));
+        ret /= ad * (double)rate;
         return ret;
     }
     static long nC2(long n) { return n * (n - 1) / 2; }
 
-    // row jj-2 of C[h] ((n+1) x n each), h over hidden states
-    void tjj_double_integral_above(int n, long jj, std::vector<DMat> &C) const {
+    // row jj-2 of C[h] ((n+1) x n each, row-major vectors), h over hidden states
+    void tjj_double_integral_above(int n, long jj, std::vector<std::vector<S>> &C) const {
         const long lam = nC2(jj) - 1;
         for (size_t h = 0; h + 1 < hs_indices.size(); ++h) {
-            for (int j = 0; j < n; ++j) C[h]((int)jj - 2, j) = 0.0;
-            const double Rh = Rrng[hs_indices[h]], Rh1 = Rrng[hs_indices[h + 1]];
-            double log_denom = -Rh;
-            if (Rh1 != INFINITY) log_denom += std::log(-std::expm1(-(Rh1 - Rh)));
+            for (int j = 0; j < n; ++j) C[h][(size_t)(jj - 2) * n + j] = S(0.0);
+            const S Rh = Rrng[hs_indices[h]], Rh1 = Rrng[hs_indices[h + 1]];
+            S log_denom = -Rh;
+            if (sval(Rh1) != INFINITY) log_denom += m_log(-m_expm1(-(Rh1 - Rh)));
             for (int m = hs_indices[h]; m < hs_indices[h + 1]; ++m)
                 for (int j = 2; j < n + 2; ++j) {
                     const long rate = nC2(j);
-                    double &tgt = C[h]((int)jj - 2, j - 2);
+                    S &tgt = C[h][(size_t)(jj - 2) * n + (j - 2)];
                     tgt += above_helper(rate, lam, ts[m], ts[m + 1], ada[m], Rrng[m], -log_denom);
-                    double log_coef = -log_denom, fac;
+                    S log_coef = -log_denom, fac(0.0);
                     const long rp = lam + 1 - rate;
-                    const double Rm1 = Rrng[m + 1], Rm = Rrng[m];
+                    const double rpd = (double)rp;
+                    const S Rm1 = Rrng[m + 1], Rm = Rrng[m];
                     if (rp == 0) fac = Rm1 - Rm;
                     else if (rp < 0) {
-                        if (-rp * (Rm1 - Rm) > 20) { log_coef += -rp * Rm1; fac = -1.0 / rp; }
-                        else { log_coef += -rp * Rm; fac = -std::expm1(-rp * (Rm1 - Rm)) / rp; }
+                        if (-rpd * sval(Rm1 - Rm) > 20) { log_coef += -rpd * Rm1; fac = S(-1.0 / rpd); }
+                        else { log_coef += -rpd * Rm; fac = -m_expm1(-rpd * (Rm1 - Rm)) / rpd; }
                     } else {
-                        if (-rp * (Rm - Rm1) > 20) { log_coef += -rp * Rm; fac = 1.0 / rp; }
-                        else { log_coef += -rp * Rm1; fac = std::expm1(-rp * (Rm - Rm1)) / rp; }
+                        if (-rpd * sval(Rm - Rm1) > 20) { log_coef += -rpd * Rm; fac = S(1.0 / rpd); }
+                        else { log_coef += -rpd * Rm1; fac = m_expm1(-rpd * (Rm - Rm1)) / rpd; }
                     }
                     for (int k = m + 1; k < K; ++k)
                         tgt += single_integral(rate, ts[k], ts[k + 1], ada[k], Rrng[k], log_coef) * fac;
@@ -439,27 +512,28 @@ public:
         }
     }
 
-    // row h of tgt (M x (n+1))
-    void tjj_double_integral_below(int n, int h, DMat &tgt) const {
-        const double Rh = Rrng[hs_indices[h]], Rh1 = Rrng[hs_indices[h + 1]];
-        double log_denom = -Rh;
-        if (Rh1 != INFINITY) log_denom += std::log(-std::expm1(-(Rh1 - Rh)));
+    // row h of tgt (M x (n+1), row-major vector)
+    void tjj_double_integral_below(int n, int h, std::vector<S> &tgt) const {
+        const S Rh = Rrng[hs_indices[h]], Rh1 = Rrng[hs_indices[h + 1]];
+        S log_denom = -Rh;
+        if (sval(Rh1) != INFINITY) log_denom += m_log(-m_expm1(-(Rh1 - Rh)));
         for (int m = hs_indices[h]; m < hs_indices[h + 1]; ++m) {
-            const double Rm = Rrng[m], Rm1 = Rrng[m + 1];
-            const double log_coef = -Rm;
-            double fac = 1.0;
-            if (m < K - 1) fac = -std::expm1(-(Rm1 - Rm));
+            const S Rm = Rrng[m], Rm1 = Rrng[m + 1];
+            const S log_coef = -Rm;
+            S fac(1.0);
+            if (m < K - 1) fac = -m_expm1(-(Rm1 - Rm));
             for (int j = 2; j < n + 3; ++j) {
                 const long rate = nC2(j) - 1;
-                double v = below_helper(rate, ts[m], ts[m + 1], ada[m], Rrng[m], log_denom);
+                S v = below_helper(rate, ts[m], ts[m + 1], ada[m], Rrng[m], log_denom);
                 for (int k = 0; k < m; ++k)
                     v += fac * single_integral(rate, ts[k], ts[k + 1], ada[k], Rrng[k], log_coef - log_denom);
-                tgt(h, j - 2) += v;
+                tgt[(size_t)h * (n + 1) + (j - 2)] += v;
             }
         }
     }
 
-    std::vector<double> hidden_states, ts, ada, Rrng;
+    std::vector<double> hidden_states, ts;
+    std::vector<S> ada, Rrng;
     std::vector<int> hs_indices;
     int K = 0;
 };
@@ -469,103 +543,110 @@ public:
 // ---------------------------------------------------------------------------------------------------------------
 namespace detail {
 typedef long double ld;
-struct M3 { ld m[3][3]; };
-inline M3 m3_identity() { M3 r{}; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = i == j; return r; }
-inline M3 m3_mul(const M3 &a, const M3 &b) {
-    M3 r{};
+template <typename L> struct M3T { L m[3][3]; };
+template <typename L> inline M3T<L> m3_identity() { M3T<L> r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = L((ld)(i == j)); return r; }
+template <typename L> inline M3T<L> m3_mul(const M3T<L> &a, const M3T<L> &b) {
+    M3T<L> r;
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) { ld s = 0; for (int k = 0; k < 3; ++k) s += a.m[i][k] * b.m[k][j]; r.m[i][j] = s; }
+        for (int j = 0; j < 3; ++j) { L s((ld)0); for (int k = 0; k < 3; ++k) s += a.m[i][k] * b.m[k][j]; r.m[i][j] = s; }
     return r;
 }
 // closed-form exponential of c_rho * A_rho + c_eta * A_eta (transition.cpp:113-130); the factors e * cosh and
 // e * sinh are combined so nothing overflows (the reference relies on 256-bit MPFR here)
-inline M3 matrix_exp(ld c_rho, ld c_eta) {
-    const ld sq = sqrtl(4 * c_eta * c_eta + c_rho * c_rho);
-    const ld y = c_eta + c_rho / 2, x = sq / 2;
-    ld ec, es;   // e*cosh(x), e*sinh(x)/sq
-    if (sq == 0) { ec = 1; es = 0.5L; }
-    else {
-        const ld ep = expl(x - y), em = expl(-x - y);
-        ec = 0.5L * (ep + em);
-        es = (x < 0.5L) ? expl(-y) * sinhl(x) / sq : 0.5L * (ep - em) / sq;
+template <typename L> inline M3T<L> matrix_exp(const L &c_rho, const L &c_eta) {
+    const L sq = m_sqrt(4 * c_eta * c_eta + c_rho * c_rho);
+    const L y = c_eta + c_rho / (ld)2, x = sq / (ld)2;
+    L ec((ld)1), es((ld)0.5L);   // e*cosh(x), e*sinh(x)/sq
+    if (sval(sq) != 0) {
+        const L ep = m_exp(x - y), em = m_exp(-x - y);
+        ec = (ld)0.5L * (ep + em);
+        es = (sval(x) < 0.5L) ? m_exp(-y) * m_sinh(x) / sq : (ld)0.5L * (ep - em) / sq;
     }
-    M3 Qm{};
+    M3T<L> Qm;
     Qm.m[0][0] = ec + (2 * c_eta - c_rho) * es;
     Qm.m[0][1] = 2 * c_rho * es;
-    Qm.m[0][2] = 1 - Qm.m[0][0] - Qm.m[0][1];
+    Qm.m[0][2] = (ld)1 - Qm.m[0][0] - Qm.m[0][1];
     Qm.m[1][0] = 2 * c_eta * es;
     Qm.m[1][1] = ec - (2 * c_eta - c_rho) * es;
-    Qm.m[1][2] = 1 - Qm.m[1][0] - Qm.m[1][1];
-    Qm.m[2][0] = 0; Qm.m[2][1] = 0; Qm.m[2][2] = 1;
+    Qm.m[1][2] = (ld)1 - Qm.m[1][0] - Qm.m[1][1];
+    Qm.m[2][0] = L((ld)0); Qm.m[2][1] = L((ld)0); Qm.m[2][2] = L((ld)1);
     return Qm;
 }
+template <typename S> struct WideOf;
+template <> struct WideOf<double> {
+    typedef ld type;
+    static ld up(double x) { return (ld)x; }
+    static double down(ld x) { return (double)x; }
+};
+template <> struct WideOf<dual> {
+    typedef Dual<ld> type;
+    static Dual<ld> up(const dual &x) { return Dual<ld>(x); }
+    static dual down(const Dual<ld> &x) { return dual(x); }
+};
 }  // namespace detail
 
-inline std::vector<double> compute_transition(const RateFunction &eta, double rho) {
+template <typename S>
+inline std::vector<S> compute_transition(const RateFunctionT<S> &eta, double rho) {
     using namespace detail;
-    const std::vector<double> &ts = eta.ts, &ada = eta.ada;
+    typedef typename WideOf<S>::type L;
+    typedef WideOf<S> W;
+    const std::vector<double> &ts = eta.ts;
+    const std::vector<S> &ada = eta.ada;
     const std::vector<int> &hsi = eta.hs_indices;
     const int Mh = (int)eta.hidden_states.size();   // the reference's `this->M` (breakpoints)
     const int M = Mh - 1;
-    const std::vector<double> avg = eta.average_coal_times();
+    const std::vector<S> avg = eta.average_coal_times();
     const int nts = (int)ts.size();
-    std::vector<M3> expms(nts, m3_identity()), prods(nts, m3_identity());
+    std::vector<M3T<L>> expms(nts, m3_identity<L>()), prods(nts, m3_identity<L>());
     for (int i = hsi[0] + 1; i < nts; ++i) {
         if (!std::isinf(ts[i])) {
             const double delta = ts[i] - ts[i - 1];
-            expms[i] = matrix_exp((ld)delta * (ld)rho, (ld)ada[i - 1] * (ld)delta);
+            expms[i] = matrix_exp<L>(L((ld)delta * (ld)rho), W::up(ada[i - 1]) * (ld)delta);
         }   // infinite end: the reference push_back()s instead of assigning, so expm_U[i] stays the identity
         prods[i] = m3_mul(prods[i - 1], expms[i]);
     }
+    // the reference keeps expms / expm_prods in working (double) precision after the wide computation
+    auto narrow = [](const M3T<L> &m) { M3T<S> r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = W::down(m.m[i][j]); return r; };
     std::vector<int> avc_ip(M);
     for (int j = 0; j < M; ++j)
-        avc_ip[j] = (int)(std::upper_bound(ts.begin(), ts.end(), avg[j]) - ts.begin()) - 1;
-    std::vector<double> expm_diff(std::max(0, M - 1));
+        avc_ip[j] = (int)(std::upper_bound(ts.begin(), ts.end(), (double)sval(avg[j])) - ts.begin()) - 1;
+    std::vector<S> expm_diff(std::max(0, M - 1));
     for (int k = 1; k < M; ++k)
-        expm_diff[k - 1] = (double)prods[hsi[k]].m[0][2] - (double)prods[hsi[k - 1]].m[0][2];
-    std::vector<double> Phi((size_t)M * M, 0.0);
+        expm_diff[k - 1] = W::down(prods[hsi[k]].m[0][2]) - W::down(prods[hsi[k - 1]].m[0][2]);
+    std::vector<S> Phi((size_t)M * M, S(0.0));
     for (int j = 1; j < Mh; ++j) {
-        double *row = &Phi[(size_t)(j - 1) * M];
+        S *row = &Phi[(size_t)(j - 1) * M];
         for (int k = 0; k < j - 1; ++k) row[k] = expm_diff[k];
-        const double rct = avg[j - 1];
+        const S rct = avg[j - 1];
         const int rct_ip = avc_ip[j - 1];
-        M3 A = m3_identity();
-        for (int ell = hsi[j - 1]; ell < rct_ip; ++ell) {
-            M3 e = expms[ell];
-            for (auto &r : e.m) for (auto &v : r) v = (ld)(double)v;   // `expms` are stored as double
-            A = m3_mul(A, e);
-        }
-        const double delta = rct - ts[rct_ip];
-        const double c_eta = ada[rct_ip] * delta;
-        const double c_rho = delta * rho;
-        {
-            M3 e = matrix_exp((ld)c_rho, (ld)c_eta);
-            A = m3_mul(A, e);
-        }
-        M3 Pj = prods[hsi[j - 1]];
-        for (auto &r : Pj.m) for (auto &v : r) v = (ld)(double)v;
-        const M3 B = m3_mul(Pj, A);
-        double Rj = c_eta;
+        M3T<S> A = m3_identity<S>();
+        for (int ell = hsi[j - 1]; ell < rct_ip; ++ell) A = m3_mul(A, narrow(expms[ell]));
+        const S delta = rct - ts[rct_ip];
+        const S c_eta = ada[rct_ip] * delta;
+        const S c_rho = delta * rho;
+        A = m3_mul(A, narrow(matrix_exp<L>(W::up(c_rho), W::up(c_eta))));
+        const M3T<S> B = m3_mul(narrow(prods[hsi[j - 1]]), A);
+        S Rj = c_eta;
         Rj += ada[rct_ip] * (ts[rct_ip + 1] - rct);
         for (int jj = rct_ip + 2; jj < hsi[j]; ++jj) Rj += ada[jj] * (ts[jj + 1] - ts[jj]);
-        const double p_float = (double)B.m[0][1] * std::exp(-Rj);
-        double Rjk1 = 0.0;
+        const S p_float = B.m[0][1] * m_exp(-Rj);
+        S Rjk1(0.0);
         for (int k = j + 1; k < Mh; ++k) {
-            double inc = 0.0;
+            S inc(0.0);
             for (int jj = hsi[k - 1]; jj < hsi[k]; ++jj) inc += ada[jj] * (ts[jj + 1] - ts[jj]);
-            double p_coal = std::exp(-Rjk1);
+            S p_coal = m_exp(-Rjk1);
             Rjk1 += inc;
-            if (!std::isinf(inc)) p_coal *= -std::expm1(-inc);
+            if (!std::isinf((double)sval(inc))) p_coal *= -m_expm1(-inc);
             row[k - 1] += p_float * p_coal;
         }
-        row[j - 1] = 0.0;
-        double s = 0.0;
-        for (int k = 0; k < M; ++k) s += row[k];
-        row[j - 1] = 1.0 - s;
+        row[j - 1] = S(0.0);
+        S sm(0.0);
+        for (int k = 0; k < M; ++k) sm += row[k];
+        row[j - 1] = 1.0 - sm;
     }
     const double beta = 1e-5, p2 = beta / Mh;        // uniform mix with denominator M+1 (quirk 13)
     for (auto &x : Phi) {
-        if (x < 1e-20) x = 1e-20;
+        if (sval(x) < 1e-20) x = S(1e-20);
         x = x * (1 - beta) + p2;
     }
     return Phi;
@@ -574,16 +655,17 @@ inline std::vector<double> compute_transition(const RateFunction &eta, double rh
 // ---------------------------------------------------------------------------------------------------------------
 // A10: conditioned SFS (conditioned_sfs.cpp:13-148)
 // ---------------------------------------------------------------------------------------------------------------
-inline double dcs_sorted(std::vector<double> &v) {
-    std::sort(v.begin(), v.end(), [](double x, double y) { return std::fabs(x) > std::fabs(y); });
-    if (v.empty()) return 0.0;
-    double s = v[0], c = 0.0;
+template <typename S>
+inline S dcs_sorted(std::vector<S> &v) {
+    std::sort(v.begin(), v.end(), [](const S &x, const S &y) { return std::fabs((double)sval(x)) > std::fabs((double)sval(y)); });
+    if (v.empty()) return S(0.0);
+    S s = v[0], c(0.0);
     for (size_t i = 1; i < v.size(); ++i) {
-        const double y = c + v[i];
-        const double u = v[i] - (y - c);
-        const double t = y + s;
-        const double w = y - (t - s);
-        const double z = u + w;
+        const S y = c + v[i];
+        const S u = v[i] - (y - c);
+        const S t = y + s;
+        const S w = y - (t - s);
+        const S z = u + w;
         s = t + z;
         c = z - (s - t);
     }
@@ -591,67 +673,71 @@ inline double dcs_sorted(std::vector<double> &v) {
 }
 
 // raw CSFS per hidden state: out[m] is 3 x (n+1) row-major
-inline std::vector<DMat> conditioned_sfs(const RateFunction &eta, const CsfsTables &tb) {
+template <typename S>
+inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, const CsfsTables &tb) {
     const int n = tb.n;
     const int M = (int)eta.hidden_states.size() - 1;
-    std::vector<DMat> csfs(M, DMat(3, n + 1));
+    const int nd = dual_nder();
+    std::vector<std::vector<S>> csfs(M, std::vector<S>((size_t)3 * (n + 1), S(0.0)));
     // ---- above ----
-    std::vector<DMat> C_above(M, DMat(n + 1, std::max(n, 0)));
     if (n >= 1) {
+        std::vector<std::vector<S>> C_above(M, std::vector<S>((size_t)(n + 1) * n, S(0.0)));
 #pragma omp parallel for schedule(dynamic)
-        for (int j = 2; j < n + 3; ++j) eta.tjj_double_integral_above(n, j, C_above);
+        for (int j = 2; j < n + 3; ++j) { DualScope sc(nd); eta.tjj_double_integral_above(n, j, C_above); }
 #pragma omp parallel for schedule(dynamic)
         for (int m = 0; m < M; ++m) {
-            const DMat &Ca = C_above[m];
-            std::vector<double> tmp0(n + 1), tmp2(n + 1), v(n);
+            DualScope sc(nd);
+            const std::vector<S> &Ca = C_above[m];
+            std::vector<S> tmp0(n + 1, S(0.0)), tmp2(n + 1, S(0.0)), v(n, S(0.0));
             for (int j = 0; j < n + 1; ++j) {
-                for (int i = 0; i < n; ++i) v[i] = tb.X0(i, j) * Ca(j, i);              // C0(i,j) = C(j,i)
-                std::vector<double> w(v);
+                for (int i = 0; i < n; ++i) v[i] = Ca[(size_t)j * n + i] * tb.X0(i, j);            // C0(i,j) = C(j,i)
+                std::vector<S> w(v);
                 tmp0[j] = dcs_sorted(w);
-                for (int i = 0; i < n; ++i) v[i] = tb.X2(i, j) * Ca(n - j, i);          // C2(i,j) = C(n-j,i)
+                for (int i = 0; i < n; ++i) v[i] = Ca[(size_t)(n - j) * n + i] * tb.X2(i, j);      // C2(i,j) = C(n-j,i)
                 w = v;
                 tmp2[j] = dcs_sorted(w);
             }
             for (int b = 0; b < n; ++b) {
-                double s0 = 0.0, s2 = 0.0;
+                S s0(0.0), s2(0.0);
                 for (int j = 0; j < n + 1; ++j) { s0 += tmp0[j] * tb.Uinv_mp0(j, b); s2 += tmp2[j] * tb.Uinv_mp2(j, b); }
-                csfs[m](0, 1 + b) += s0;
-                csfs[m](2, b) += s2;
+                csfs[m][0 * (n + 1) + 1 + b] += s0;
+                csfs[m][2 * (n + 1) + b] += s2;
             }
         }
     }
     // ---- below ----
-    DMat tjj_below(M, n + 1);
+    std::vector<S> tjj_below((size_t)M * (n + 1), S(0.0));
 #pragma omp parallel for schedule(dynamic)
-    for (int m = 0; m < M; ++m) eta.tjj_double_integral_below(n, m, tjj_below);
+    for (int m = 0; m < M; ++m) { DualScope sc(nd); eta.tjj_double_integral_below(n, m, tjj_below); }
     for (int m = 0; m < M; ++m) {
         for (int b = 0; b < n; ++b) {
-            double s = 0.0;
-            for (int j = 0; j < n + 1; ++j) s += tjj_below(m, j) * tb.M0(j, b);
-            csfs[m](0, 1 + b) += s;
+            S s(0.0);
+            for (int j = 0; j < n + 1; ++j) s += tjj_below[(size_t)m * (n + 1) + j] * tb.M0(j, b);
+            csfs[m][0 * (n + 1) + 1 + b] += s;
         }
         for (int b = 0; b < n + 1; ++b) {
-            double s = 0.0;
-            for (int j = 0; j < n + 1; ++j) s += tjj_below(m, j) * tb.M1(j, b);
-            csfs[m](1, b) += s;
+            S s(0.0);
+            for (int j = 0; j < n + 1; ++j) s += tjj_below[(size_t)m * (n + 1) + j] * tb.M1(j, b);
+            csfs[m][1 * (n + 1) + b] += s;
         }
     }
     return csfs;
 }
 
-inline void incorporate_theta(std::vector<DMat> &csfs, double theta) {
+template <typename S>
+inline void incorporate_theta(std::vector<std::vector<S>> &csfs, double theta) {
     if (theta <= 0) throw std::runtime_error("mutation rate theta <= 0");
     for (auto &c : csfs) {
-        double tauh = 0.0;
-        for (double x : c.d) tauh += x;
-        const double f = -std::expm1(-theta * tauh) / tauh;
-        for (double &x : c.d) x *= f;
-        double tot = 0.0;
-        for (double x : c.d) tot += x;
-        c(0, 0) = 1.0 - tot;
-        for (double &x : c.d) if (x < 1e-10) x = 1e-10;
-        for (double x : c.d)
-            if (x < 0 || x > 1 || std::isnan(x)) throw std::runtime_error("csfs is not a probability distribution");
+        S tauh(0.0);
+        for (const S &x : c) tauh += x;
+        const S f = -m_expm1(-theta * tauh) / tauh;
+        for (S &x : c) x *= f;
+        S tot(0.0);
+        for (const S &x : c) tot += x;
+        c[0] = 1.0 - tot;
+        for (S &x : c) if (sval(x) < 1e-10) x = S(1e-10);
+        for (const S &x : c)
+            if (sval(x) < 0 || sval(x) > 1 || std::isnan((double)sval(x))) throw std::runtime_error("csfs is not a probability distribution");
     }
 }
 
@@ -664,22 +750,52 @@ public:
         : n_(n), hs_(hs), pol_(polarization_error), tables_(csfs_tables(n)) {}
 
     // keys: [K][3] (a, b, nb); outputs pi [M], T [M*M] row-major, E [K*M]
-    void compute(const ModelParams &mp, double theta, double rho, double alpha, const std::vector<int> &keys, int K,
-                 std::vector<double> &pi, std::vector<double> &T, std::vector<double> &E) {
-        RateFunction eta(mp, hs_);
+    template <typename S>
+    void compute_t(const ModelParamsT<S> &mp, double theta, double rho, double alpha, const std::vector<int> &keys,
+                   int K, std::vector<S> &pi, std::vector<S> &T, std::vector<S> &E) {
+        RateFunctionT<S> eta(mp, hs_);
         const int M = (int)hs_.size() - 1;
         // pi (inference_manager.cpp:56-69)
-        pi.assign(M, 0.0);
-        for (int m = 0; m < M - 1; ++m) pi[m] = std::exp(-eta.R(hs_[m])) - std::exp(-eta.R(hs_[m + 1]));
-        pi[M - 1] = std::exp(-eta.R(hs_[M - 1]));
-        double ps = 0.0;
-        for (double &x : pi) { if (x < 1e-20) x = 1e-20; ps += x; }
-        for (double &x : pi) x /= ps;
-        T = compute_transition(eta, rho);
-        std::vector<DMat> sfs = conditioned_sfs(eta, *tables_);
-        incorporate_theta(sfs, theta);
-        const std::vector<double> avg_ct = eta.average_coal_times();
-        emission_probs(sfs, avg_ct, theta, alpha, keys, K, E);
+        pi.assign(M, S(0.0));
+        for (int m = 0; m < M - 1; ++m) pi[m] = m_exp(-eta.R(hs_[m])) - m_exp(-eta.R(hs_[m + 1]));
+        pi[M - 1] = m_exp(-eta.R(hs_[M - 1]));
+        S ps(0.0);
+        for (S &x : pi) { if (sval(x) < 1e-20) x = S(1e-20); ps += x; }
+        for (S &x : pi) x /= ps;
+        T = compute_transition<S>(eta, rho);
+        std::vector<std::vector<S>> sfs = conditioned_sfs<S>(eta, *tables_);
+        incorporate_theta<S>(sfs, theta);
+        const std::vector<S> avg_ct = eta.average_coal_times();
+        emission_probs<S>(sfs, avg_ct, theta, alpha, keys, K, E);
+    }
+
+    void compute(const ModelParams &mp, double theta, double rho, double alpha, const std::vector<int> &keys, int K,
+                 std::vector<double> &pi, std::vector<double> &T, std::vector<double> &E) {
+        ModelParamsT<double> p;
+        p.a = mp.a; p.s = mp.s;
+        compute_t<double>(p, theta, rho, alpha, keys, K, pi, T, E);
+    }
+
+    // values + Jacobians: da [Kp x nder] seeds of the piece sizes; outputs d* are [size x nder] row-major
+    void compute_with_jacobian(const ModelParams &mp, const std::vector<double> &da, int nder, double theta, double rho,
+                               double alpha, const std::vector<int> &keys, int K, std::vector<double> &pi,
+                               std::vector<double> &T, std::vector<double> &E, std::vector<double> &dpi,
+                               std::vector<double> &dT, std::vector<double> &dE) {
+        DualScope sc(nder);
+        ModelParamsT<dual> p;
+        p.s = mp.s;
+        p.a.resize(mp.a.size());
+        for (size_t k = 0; k < mp.a.size(); ++k) {
+            p.a[k] = dual(mp.a[k]);
+            for (int d = 0; d < nder; ++d) p.a[k].d[d] = da[k * nder + d];
+        }
+        std::vector<dual> pd, Td, Ed;
+        compute_t<dual>(p, theta, rho, alpha, keys, K, pd, Td, Ed);
+        auto split = [nder](const std::vector<dual> &x, std::vector<double> &v, std::vector<double> &j) {
+            v.resize(x.size()); j.resize(x.size() * (size_t)nder);
+            for (size_t i = 0; i < x.size(); ++i) { v[i] = x[i].v; for (int d = 0; d < nder; ++d) j[i * nder + d] = x[i].d[d]; }
+        };
+        split(pd, pi, dpi); split(Td, T, dT); split(Ed, E, dE);
     }
 
     // restated marginalisation machinery -----------------------------------------------------------------------
@@ -732,32 +848,33 @@ public:
         return out;
     }
 
-    void emission_probs(const std::vector<DMat> &sfs, const std::vector<double> &avg_ct, double theta, double alpha,
-                        const std::vector<int> &keys, int K, std::vector<double> &E) const {
+    template <typename S>
+    void emission_probs(const std::vector<std::vector<S>> &sfs, const std::vector<S> &avg_ct, double theta, double alpha,
+                        const std::vector<int> &keys, int K, std::vector<S> &E) const {
         const int M = (int)sfs.size();
-        std::vector<double> e2((size_t)M * 2);
+        std::vector<S> e2((size_t)M * 2, S(0.0));
         for (int m = 0; m < M; ++m) {
-            if (std::isnan(avg_ct[m])) { e2[2 * m] = 1e-20; e2[2 * m + 1] = 1e-20; }
+            if (std::isnan((double)sval(avg_ct[m]))) { e2[2 * m] = S(1e-20); e2[2 * m + 1] = S(1e-20); }
             else {
-                const double le = -2.0 * alpha * theta * avg_ct[m];
-                e2[2 * m] = std::exp(le);
-                e2[2 * m + 1] = -std::expm1(le);
+                const S le = -2.0 * alpha * theta * avg_ct[m];
+                e2[2 * m] = m_exp(le);
+                e2[2 * m + 1] = -m_expm1(le);
             }
         }
-        E.assign((size_t)K * M, 0.0);
+        E.assign((size_t)K * M, S(0.0));
         for (int k = 0; k < K; ++k) {
             const Key bk{keys[3 * k], keys[3 * k + 1], keys[3 * k + 2]};
             const bool reduced = bk[2] == 0, miss = bk[0] == -1;
-            double *e = &E[(size_t)k * M];
+            S *e = &E[(size_t)k * M];
             if (reduced && (miss || bk[0] >= 0)) {
-                for (int m = 0; m < M; ++m) e[m] = miss ? 1.0 : e2[2 * m + (bk[0] % 2)];
+                for (int m = 0; m < M; ++m) e[m] = miss ? S(1.0) : e2[2 * m + (bk[0] % 2)];
             } else {
                 const auto bins = bins_for(bk);
                 for (const auto &p : bins)
-                    for (int m = 0; m < M; ++m) e[m] += p.second * sfs[m](p.first.first, p.first.second);
+                    for (int m = 0; m < M; ++m) e[m] += p.second * sfs[m][(size_t)p.first.first * (n_ + 1) + p.first.second];
             }
-            double mx = e[0], mn = e[0];
-            for (int m = 1; m < M; ++m) { mx = std::max(mx, e[m]); mn = std::min(mn, e[m]); }
+            double mx = sval(e[0]), mn = sval(e[0]);
+            for (int m = 1; m < M; ++m) { mx = std::max(mx, (double)sval(e[m])); mn = std::min(mn, (double)sval(e[m])); }
             if (mx > 1.0 || mn <= 0.0) throw std::runtime_error("probability vector not in [0, 1]");
         }
     }

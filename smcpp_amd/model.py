@@ -39,7 +39,15 @@ class PiecewiseModel(Observable):
 
     @property
     def dlist(self):
-        return []
+        """Derivative directions (`model.dlist`, smcpp/model.py:83-91): one per piece when `differentiable`."""
+        return list(range(len(self.a))) if self.differentiable else []
+
+    differentiable = False
+
+    def derivative_seeds(self):
+        """[K x nder] seeds d a_k / d x_j handed to `smcpp_set_params` (the `.d()` parts of the reference's ad numbers,
+        `_smcpp.pyx:70-76`): identity, i.e. gradients with respect to the piece sizes themselves."""
+        return np.eye(len(self.a)) if self.differentiable else None
 
     def for_pop(self, pop):
         assert pop == self.pid

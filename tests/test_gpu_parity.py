@@ -174,3 +174,29 @@ def test_model_parameter_path(name):
     m[1] = g["a"][1]
     im.E_step()
     assert abs(im.loglik() - ll0) <= 1e-12 * abs(ll0)
+
+
+def test_q_gradient_matches_finite_differences():
+    """dQ/da_k by forward-mode duals through the host preparation equals central finite
+    differences of Q (statistics of the E-step held fixed), the check the reference's own test_inference.py:61-74 prints."""
+    from smcpp_amd import _smcpp
+    from smcpp_amd.model import PiecewiseModel
+    g = load_golden("G1_M16_n4")
+    im = _smcpp.PyOnePopInferenceManager(int(g["n"]), [np.ascontiguousarray(g["obs"])], g["hs"], ("pop1",),
+                                         float(g["pol"]))
+    m = PiecewiseModel(g["a"], g["s"], 1e4, "pop1")
+    m.differentiable = True
+    im.model = m
+    im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = float(g["alpha"])
+    im.E_step()
+    q, jac = im.Q_with_gradient()
+    np.testing.assert_allclose(q, g["q"], rtol=5e-6)
+    assert jac.shape == (4, len(g["a"]))
+    a0 = np.array(g["a"], dtype=float)
+    for k in range(len(a0)):
+        h = 1e-6 * a0[k]
+        m[k] = a0[k] + h; qp = np.array(im.Q(separate=True))
+        m[k] = a0[k] - h; qm = np.array(im.Q(separate=True))
+        m[k] = a0[k]
+        fd = (qp - qm) / (2 * h)
+        assert np.all(np.abs(fd - jac[:, k]) <= 1e-4 * np.maximum(np.abs(jac[:, k]), 1e-3)), (k, fd, jac[:, k])

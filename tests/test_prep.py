@@ -69,3 +69,30 @@ def test_known_answers_constant_size():
     np.testing.assert_allclose(T.sum(axis=1), 1 - 1e-5 / 5, rtol=1e-12)
     assert np.all(E[2] == 1.0)                                           # missing emits 1
     np.testing.assert_allclose(E[0] + E[1], 1.0, rtol=1e-13)             # reduced keys: exp(-2 a theta E[T]) and complement
+
+
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+@pytest.mark.parametrize("M,n", [(8, 3), (32, 10)])
+def test_jacobians_vs_reference_autodiff(M, n):
+    """Forward-mode duals through rows A7-A10 against the reference's AutoDiffScalar (adouble) derivatives."""
+    from smcpp_amd import _engine, synth
+    hs = synth.hidden_states(M)
+    a, s = synth.model_pieces(6)
+    da = np.eye(6)[:, :4] + 0.25                       # arbitrary non-trivial seed matrix, nder = 4
+    theta, rho, alpha, pol = 2.5e-2, 6.25e-3, 1.0, 0.5
+    r = ref.prep_jac(a, da, s, hs, rho, theta, n)
+    keys = np.array(sorted({(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, n), (1, 0, n), (1, n, n), (2, 1, n), (0, 1, n - 1)}),
+                    dtype=np.int32)
+    pi, T, E, dpi, dT, dE = _engine.host_prep_onepop_jac(n, hs, pol, a, da, s, theta, rho, alpha, keys)
+    np.testing.assert_allclose(pi, r["pi"], rtol=1e-13)
+    np.testing.assert_allclose(dpi, r["dpi"], rtol=1e-10, atol=1e-15)
+    np.testing.assert_allclose(T, r["T"], rtol=1e-11, atol=1e-17)
+    np.testing.assert_allclose(dT, r["dT"], rtol=1e-8, atol=1e-15)
+    # emission Jacobian: the assembly is linear in the CSFS and smooth in avg_ct; compare against the reference AD inputs
+    ep0 = prep_oracle.emission_probs(keys, n, r["csfs"], r["avg_ct"], theta, alpha, pol)
+    h = 1e-6
+    for d in range(da.shape[1]):
+        ep1 = prep_oracle.emission_probs(keys, n, r["csfs"] + h * r["dcsfs"][..., d], r["avg_ct"] + h * r["davg_ct"][:, d],
+                                         theta, alpha, pol)
+        dref = np.array([(ep1[tuple(k)] - ep0[tuple(k)]) / h for k in keys.tolist()])
+        assert np.abs(dE[..., d] - dref).max() <= 1e-7 * max(np.abs(dref).max(), 1e-3)

@@ -143,6 +143,11 @@ int smcpp_host_prep_onepop_jac(int n, int n_hs, const double *hs, double polariz
                                int K, const int *keys, double *pi, double *T, double *E, double *dpi, double *dT,
                                double *dE);
 
+/* PyRateFunction.R / average_coal_times (smcpp/_smcpp.pyx:370-389): cumulative hazard R at t[0..nt) for the model
+ * pieces (a, s) and, when n_hs >= 2, E[T | hs_i <= T < hs_{i+1}] for the n_hs-1 intervals. */
+int smcpp_host_rate_function(int Kp, const double *a, const double *s, int n_hs, const double *hs, int nt,
+                             const double *t, double *R_out, double *avg_ct_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,7 @@ EXPORTS = [
     "smcpp_get_emission_probs", "smcpp_get_gamma_argmax", "smcpp_set_global_keys", "smcpp_pack_stats",
     "smcpp_unpack_stats", "smcpp_set_chunking", "smcpp_last_timing", "smcpp_stream", "smcpp_set_num_threads",
     "smcpp_host_eigensystem", "smcpp_host_prep_onepop", "smcpp_host_prep_onepop_jac", "smcpp_num_derivatives",
+    "smcpp_host_rate_function",
 ]
 
 
@@ -109,3 +110,18 @@ def host_prep_onepop_jac(n, hs, polarization_error, a, da, s, theta, rho, alpha,
                                            dptr(da), int(nder), dptr(s), float(theta), float(rho), float(alpha), K,
                                            iptr(keys), dptr(pi), dptr(T), dptr(E), dptr(dpi), dptr(dT), dptr(dE)))
     return pi, T, E, dpi, dT, dE
+
+
+def host_rate_function(a, s, t, hs=None):
+    """R(t) (and average coalescence times per hidden-state interval when ``hs`` is given)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    t = np.ascontiguousarray(np.atleast_1d(t), dtype=np.float64)
+    R = np.zeros(len(t))
+    if hs is None:
+        check(lib().smcpp_host_rate_function(len(a), dptr(a), dptr(s), 0, None, len(t), dptr(t), dptr(R), None))
+        return R
+    hs = np.ascontiguousarray(hs, dtype=np.float64)
+    ct = np.zeros(len(hs) - 1)
+    check(lib().smcpp_host_rate_function(len(a), dptr(a), dptr(s), len(hs), dptr(hs), len(t), dptr(t), dptr(R), dptr(ct)))
+    return R, ct

@@ -1390,4 +1390,23 @@ int smcpp_host_prep_onepop_jac(int n, int n_hs, const double *hs, double polariz
     API_END
 }
 
+
+// PyRateFunction.R / average_coal_times (_smcpp.pyx:370-389) without an engine instance: R at nt time points and,
+// if n_hs >= 2, the average coalescence time inside each of the n_hs-1 hidden-state intervals
+int smcpp_host_rate_function(int Kp, const double *a, const double *s, int n_hs, const double *hs, int nt,
+                             const double *t, double *R_out, double *avg_ct_out) {
+    API_BEGIN
+    smcpp_host::ModelParamsT<double> mp;
+    mp.a.assign(a, a + Kp);
+    mp.s.assign(s, s + Kp);
+    std::vector<double> hsv(hs, hs + std::max(0, n_hs));
+    smcpp_host::RateFunctionT<double> eta(mp, hsv);
+    for (int i = 0; i < nt; ++i) R_out[i] = eta.R(t[i]);
+    if (n_hs >= 2 && avg_ct_out) {
+        const std::vector<double> v = eta.average_coal_times();
+        std::memcpy(avg_ct_out, v.data(), sizeof(double) * v.size());
+    }
+    API_END
+}
+
 }  // extern "C"

@@ -1,0 +1,162 @@
+"""On-disk format and pre-HMM data shaping — the producers of the row arrays the inference
+manager consumes.  Restated from the reference's Python (`smcpp/estimation_tools.py:51-60,117-167,236-267`,
+`smcpp/contig.py`); integer work on the host, not on the timed path."""
+from __future__ import annotations
+
+import gzip
+import json
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+import numpy as np
+
+
+@dataclass
+class Contig:
+    """`smcpp/contig.py:7-27`."""
+    data: np.ndarray
+    pid: Tuple[str, ...] = ("pop1",)
+    n: List[int] = field(default_factory=list)
+    a: List[int] = field(default_factory=list)
+    fn: str = ""
+
+    @property
+    def npop(self):
+        return len(self.pid)
+
+    def __len__(self):
+        return int(self.data[:, 0].sum())
+
+
+def load_smc(fn: str) -> Contig:
+    """`.smc(.gz)` reader: header `# SMC++ {json}` with `pids / dist / undist`, then space-separated int rows
+    `span a b nb [a2 b2 nb2]`.  When the distinguished pair sits in the second population (a = (0, 2)) the column blocks
+    are swapped so that it comes first (`estimation_tools.py:236-267`)."""
+    opener = gzip.open if fn.endswith(".gz") else open
+    with opener(fn, "rt") as f:
+        first = next(f).strip()
+        if not first.startswith("# SMC++"):
+            raise RuntimeError("Data file is not in SMC++ format: %s" % fn)
+        attrs = json.loads(first[7:])
+        if "pids" not in attrs:
+            raise RuntimeError("Data format is too old. Re-run VCF2SMC.")
+        rows = [[int(x) for x in line.split()] for line in f if line.strip() and not line.startswith("#")]
+    if not rows:
+        raise RuntimeError("empty dataset: %s" % fn)
+    A = np.array(rows, dtype=np.int32)
+    a = [len(x) for x in attrs["dist"]]
+    n = [len(u) for u in attrs["undist"]]
+    pid = tuple(attrs["pids"])
+    if len(a) == 2 and a[0] == 0 and a[1] == 2:
+        n, a, pid = n[::-1], a[::-1], pid[::-1]
+        A = A[:, [0, 4, 5, 6, 1, 2, 3]]
+    return Contig(pid=pid, data=np.ascontiguousarray(A, dtype=np.int32), n=n, a=a, fn=fn)
+
+
+def compress_repeated_obs(dataset: np.ndarray) -> np.ndarray:
+    """Merge consecutive rows with equal observations, adding their spans (`estimation_tools.py:51-60`)."""
+    dataset = np.asarray(dataset)
+    if len(dataset) == 0:
+        return dataset.copy()
+    change = np.ones(len(dataset), dtype=bool)
+    change[1:] = np.any(dataset[1:, 1:] != dataset[:-1, 1:], axis=1)
+    starts = np.nonzero(change)[0]
+    csum = np.concatenate(([0], np.cumsum(dataset[:, 0], dtype=np.int64)))
+    out = dataset[starts].copy()
+    out[:, 0] = csum[np.concatenate((starts[1:], [len(dataset)]))] - csum[starts]
+    return out
+
+
+def break_long_spans(contig: Contig, span_cutoff: int) -> List[Contig]:
+    """Cut a contig at missing runs of at least `span_cutoff` positions; every piece starts with one missing row
+    (`estimation_tools.py:117-167`)."""
+    obs = contig.data
+    miss = np.zeros_like(obs[0])
+    miss[0] = 1
+    miss[1::3] = -1
+    long_spans = np.where((obs[:, 0] >= span_cutoff) & np.all(obs[:, 1::3] == -1, axis=1)
+                          & np.all(obs[:, 3::3] == 0, axis=1))[0]
+    out = []
+    cob = 0
+    for x in long_spans.tolist() + [None]:
+        out.append(Contig(data=np.ascontiguousarray(np.insert(obs[cob:x], 0, miss, 0), dtype=np.int32),
+                          pid=contig.pid, fn=contig.fn, n=contig.n, a=contig.a))
+        if x is not None:
+            cob = x + 1
+    return out
+
+
+def thin_data(data: np.ndarray, thinning: int, offset: int = 0) -> np.ndarray:
+    """The thinning of `_estimation_tools.pyx:8-84`: walking along the contig with a counter `i` (start `offset`),
+    only the LAST position of every window of `thinning` positions keeps its full observation; every other position
+    keeps the distinguished counts only (`(a, 0, 0)` per population).  Rows whose distinguished counts sum to 2 are
+    recoded as non-segregating (`a = 0`), at thinned positions to an all-zero row — a quirk of the reference, whose
+    `b`/`nb` scratch views are never filled, mirrored here."""
+    data = np.asarray(data, dtype=np.int32)
+    npop = (data.shape[1] - 1) // 3
+    out = []
+    i = offset
+    for row in data:
+        span = int(row[0])
+        thin = np.zeros(3 * npop, dtype=np.int32)
+        thin[0::3] = row[1::3]
+        sa = int(row[1::3].sum())
+        if sa == 2:
+            thin[0::3] = 0
+        while span > 0:
+            if i < thinning and i + span >= thinning:
+                if thinning - i > 1:
+                    out.append(np.concatenate(([thinning - i - 1], thin)))
+                if sa == 2:
+                    out.append(np.concatenate(([1], np.zeros(3 * npop, dtype=np.int32))))
+                else:
+                    out.append(np.concatenate(([1], row[1:])))
+                span -= thinning - i
+                i = 0
+            else:
+                out.append(np.concatenate(([span], thin)))
+                i += span
+                break
+    ret = np.array(out, dtype=np.int32).reshape(-1, data.shape[1])
+    assert ret[:, 0].sum() == data[:, 0].sum()
+    return ret
+
+
+def bin_observations(data: np.ndarray, w: int, na) -> np.ndarray:
+    """Windows of `w` positions (`_estimation_tools.pyx:101-173`): each bin is represented by the row with the largest
+    observed sample size `sum_pops nb + na * (a >= 0)` (first such row; when only the distinguished pair is observed a
+    segregating row wins), emitted with span 1.  `na` = distinguished lineages per population."""
+    data = np.array(data, dtype=np.int32, copy=True)
+    K = (data.shape[1] - 1) // 3
+    na = list(na)
+
+    def process_bin(i, j):
+        max_ss, mq = -2, 0
+        for q in range(i, j + 1):
+            if data[q, 0] == 0:
+                continue
+            ss, seg = 0, 0
+            for aa in range(K):
+                ss += int(data[q, 3 * aa + 3]) + na[aa] * int(data[q, 3 * aa + 1] >= 0)
+                seg += max(0, int(data[q, 3 * aa + 1]))
+            if ss > max_ss:
+                mq, max_ss = q, ss
+            if max_ss == 2 and seg == 1:
+                mq = q
+        return np.concatenate(([1], data[mq, 1:]))
+
+    out = []
+    i = j = seen = 0
+    while j < data.shape[0]:
+        span = int(data[j, 0])
+        if seen + span > w:
+            data[j, 0] = w - seen
+            out.append(process_bin(i, j))
+            data[j, 0] = span - (w - seen)
+            seen = 0
+            i = j
+        else:
+            j += 1
+            seen += span
+    out.append(process_bin(i, j - 1))
+    return np.array(out, dtype=np.int32)

@@ -1,0 +1,65 @@
+"""The `smc++ posterior` product (reference `smcpp/commands/posterior.py:48-111` and
+`smcpp/estimation_tools.py:170-197`): balanced hidden states, posterior decoding matrix and its argmax path."""
+from __future__ import annotations
+
+import numpy as np
+import scipy.optimize
+
+from . import _engine, _smcpp
+from .model import PiecewiseModel
+
+
+def balance_hidden_states(model, M):
+    """Break points `[0, b_1, ..., b_{M-1}, inf)` (coalescent units) such that the probability of coalescing in each
+    of the M intervals is equal under the model: `exp(-R(b_m)) = (M - m) / M`, root-found with Brent's method exactly
+    as `estimation_tools.py:170-197` does (which is called with M+1 and returns generations = 2 N0 x these)."""
+    a = np.asarray(model.stepwise_values(), dtype=float)
+    s = np.asarray(model.s, dtype=float)
+    ret = [0.0]
+    for m in range(1, M):
+        def f(t):
+            return float(np.exp(-_engine.host_rate_function(a, s, t)[0]) - (M - m) / M)
+        lo = hi = ret[-1]
+        while f(lo) * f(hi) >= 0:
+            hi = 2 * (hi + 1)
+        ret.append(scipy.optimize.brentq(f, lo, hi))
+    ret.append(np.inf)
+    return np.array(ret)
+
+
+def posterior(model, contigs, M, n, theta, rho, alpha=1.0, polarization_error=0.5, hidden_states=None, device=-1):
+    """Posterior decoding of each contig.  Returns `(hidden_states, gammas, sites, paths)`:
+    `gammas[c]` is `[M, L+1]` with columns normalised to one (`posterior.py:102-106`), `sites[c]` the cumulative
+    positions of the rows, `paths[c]` the argmax state per column computed on the device.
+    A missing row is prepended to every contig as the reference does (`posterior.py:83`)."""
+    hs = balance_hidden_states(model, M) if hidden_states is None else np.asarray(hidden_states, dtype=float)
+    obs = []
+    for c in contigs:
+        d = np.asarray(c, dtype=np.int32)
+        miss = np.zeros((1, d.shape[1]), dtype=np.int32)
+        miss[0, 0] = 1
+        miss[0, 1::3] = -1
+        obs.append(np.ascontiguousarray(np.vstack([miss, d])))
+    im = _smcpp.PyOnePopInferenceManager(n, obs, hs, (getattr(model, "pid", "pop1"),), polarization_error, device=device)
+    im.model = model
+    im.theta = theta
+    im.rho = rho
+    im.alpha = alpha
+    im.save_gamma = True
+    im.E_step()
+    gammas, sites, paths = [], [], []
+    for c, g in enumerate(im.gammas):
+        g = g / g.sum(axis=0, keepdims=True)
+        gammas.append(g)
+        sites.append(np.concatenate(([0], np.cumsum(obs[c][:, 0]))))
+        paths.append(im.gamma_argmax(c))
+    return hs, gammas, sites, paths
+
+
+def save_npz(path, hs, gammas, sites, names):
+    """`.npz` layout of `smc++ posterior` (README.rst:348-372): `hidden_states`, `<file>`, `<file>_sites`."""
+    out = {"hidden_states": hs}
+    for nm, g, s in zip(names, gammas, sites):
+        out[nm] = g
+        out[nm + "_sites"] = s
+    np.savez_compressed(path, **out)

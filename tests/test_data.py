@@ -1,0 +1,68 @@
+"""f-2 / f-3 helpers: data format, data shaping identities (test/unit/test_bugs.py:35-47 intent), rate function known
+answers (test_bugs.py:18-33) and balanced hidden states."""
+import gzip
+import json
+import os
+
+import numpy as np
+
+from conftest import load_golden
+
+
+def test_rate_function_known_answers():
+    from smcpp_amd import _engine
+    # constant size: R(t) = t / a
+    R = _engine.host_rate_function([1.0], [1.0], [0.0, 0.5, 2.0])
+    np.testing.assert_allclose(R, [0.0, 0.5, 2.0], rtol=1e-14)
+    R = _engine.host_rate_function([2.0, 0.5], [1.0, 1.0], [0.5, 1.0, 3.0])
+    np.testing.assert_allclose(R, [0.25, 0.5, 0.5 + 4.0], rtol=1e-14)
+    # E[T | t1 <= T < t2] for Exp(1)
+    t1, t2 = 0.3, 1.7
+    _, ct = _engine.host_rate_function([1.0], [1.0], [0.0], hs=[0.0, t1, t2, np.inf])
+    ex = lambda lo, hi: ((lo + 1) * np.exp(-lo) - (hi + 1) * np.exp(-hi)) / (np.exp(-lo) - np.exp(-hi))
+    np.testing.assert_allclose(ct, [ex(0, t1), ex(t1, t2), t2 + 1.0], rtol=1e-12)
+
+
+def test_balance_hidden_states_constant_size():
+    from smcpp_amd.model import PiecewiseModel
+    from smcpp_amd.posterior import balance_hidden_states
+    hs = balance_hidden_states(PiecewiseModel([1.0], [1.0]), 8)
+    expect = np.r_[-np.log(1 - np.arange(8) / 8.0), np.inf]
+    np.testing.assert_allclose(hs, expect, rtol=1e-9, atol=1e-12)
+
+
+def test_compress_and_break(tmp_path):
+    from smcpp_amd import data
+    d = np.array([[3, 0, 0, 0], [2, 0, 0, 0], [1, 1, 2, 4], [1, 1, 2, 4], [500, -1, 0, 0], [4, 0, 0, 0]], dtype=np.int32)
+    c = data.compress_repeated_obs(d)
+    assert c.tolist() == [[5, 0, 0, 0], [2, 1, 2, 4], [500, -1, 0, 0], [4, 0, 0, 0]]
+    assert c[:, 0].sum() == d[:, 0].sum()
+    pieces = data.break_long_spans(data.Contig(data=c, n=[4], a=[2]), 100)
+    assert len(pieces) == 2
+    assert pieces[0].data.tolist() == [[1, -1, 0, 0], [5, 0, 0, 0], [2, 1, 2, 4]]
+    assert pieces[1].data.tolist() == [[1, -1, 0, 0], [4, 0, 0, 0]]
+    # .smc round trip incl. the column swap for a = (0, 2)
+    fn = str(tmp_path / "x.smc.gz")
+    hdr = {"pids": ["A", "B"], "dist": [[], [["s", 0], ["s", 1]]], "undist": [[["u", 0]], [["v", 0], ["v", 1]]], "version": "t"}
+    with gzip.open(fn, "wt") as f:
+        f.write("# SMC++ " + json.dumps(hdr) + "\n")
+        f.write("10 0 0 1 0 0 2\n1 0 1 1 1 0 2\n")
+    ct = data.load_smc(fn)
+    assert ct.pid == ("B", "A") and ct.a == [2, 0] and ct.n == [2, 1]
+    assert ct.data.tolist() == [[10, 0, 0, 2, 0, 0, 1], [1, 1, 0, 2, 0, 1, 1]]
+
+
+def test_thinning_and_binning():
+    from smcpp_amd import data
+    d = np.array([[7, 0, 1, 5], [3, 1, 0, 5], [10, -1, 0, 0], [2, 2, 5, 5]], dtype=np.int32)
+    t = data.thin_data(d, 4)
+    assert t[:, 0].sum() == d[:, 0].sum()                      # positions are conserved (asserted in the reference too)
+    # positions 3, 7 (0-based) close a window inside the first two rows and keep their SFS; 11, 15, 19 are missing
+    assert t.tolist()[:5] == [[3, 0, 0, 0], [1, 0, 1, 5], [3, 0, 0, 0], [1, 1, 0, 5], [2, 1, 0, 0]]
+    assert t[-1].tolist() == [2, 0, 0, 0]                      # a = 2 row recoded as non-segregating
+    b = data.bin_observations(np.array([[3, 0, 0, 0], [1, 1, 0, 0], [4, 0, 0, 0], [1, 0, 2, 5], [6, -1, 0, 0]],
+                                       dtype=np.int32), 5, [2])
+    assert b[:, 0].tolist() == [1, 1, 1]
+    assert b[0, 1:].tolist() == [1, 0, 0]                      # only the pair observed: the segregating row wins
+    assert b[1, 1:].tolist() == [0, 2, 5]                      # the row with undistinguished samples wins
+    assert b[2, 1:].tolist() == [-1, 0, 0]

@@ -200,3 +200,22 @@ def test_q_gradient_matches_finite_differences():
         m[k] = a0[k]
         fd = (qp - qm) / (2 * h)
         assert np.all(np.abs(fd - jac[:, k]) <= 1e-4 * np.abs(jac[:, k]) + 1e-5), (k, fd, jac[:, k])
+
+
+def test_posterior_product_on_reference_test_contig():
+    """`smc++ posterior` on the reference's own un-binned test contig (test/bugs/11/chr11_5subjs.smc.gz, fixture G7):
+    the decoded path must equal the reference's argmax on every column with a relative top-1/top-2 margin > 1e-5."""
+    from smcpp_amd.model import PiecewiseModel
+    from smcpp_amd.posterior import posterior
+    g = load_golden("G7_M32_n8_chr11")
+    m = PiecewiseModel(g["a"], g["s"], 1e4, "pop1")
+    hs, gammas, sites, paths = posterior(m, [g["obs"][1:]], 32, int(g["n"]), float(g["theta"]), float(g["rho"]),
+                                         float(g["alpha"]), float(g["pol"]), hidden_states=g["hs"])
+    L = len(g["obs"])
+    assert gammas[0].shape == (32, L + 1) and paths[0].shape == (L + 1,)
+    np.testing.assert_allclose(gammas[0].sum(axis=0), 1.0, rtol=1e-12)
+    assert sites[0][-1] == g["obs"][:, 0].sum()
+    strong = g["gamma_margin"] > 1e-5
+    mism = np.nonzero(paths[0] != g["gamma_argmax"])[0]
+    assert not np.any(strong[mism])
+    assert np.array_equal(paths[0], gammas[0].argmax(axis=0))

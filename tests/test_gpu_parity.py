@@ -219,3 +219,18 @@ def test_posterior_product_on_reference_test_contig():
     mism = np.nonzero(paths[0] != g["gamma_argmax"])[0]
     assert not np.any(strong[mism])
     assert np.array_equal(paths[0], gammas[0].argmax(axis=0))
+
+
+def test_em_iterations_increase_the_likelihood():
+    """End-to-end property of E-step statistics + Q + gradients: an EM step cannot decrease the log-likelihood
+    (up to the float-alpha noise of the E-step).  Data are simulated under a size history that differs from the start."""
+    from smcpp_amd import synth
+    from smcpp_amd.estimate import em
+    g = load_golden("G1_M16_n4")
+    contigs = [synth.synth_contig(40 + i, 400_000, 4) for i in range(2)]
+    a0 = np.ones(4)
+    model, ll = em(contigs, 4, g["hs"], a0, g["s"], float(g["theta"]), float(g["rho"]), iterations=3)
+    assert len(ll) == 4
+    assert np.all(np.diff(ll) >= -1e-6 * np.abs(ll[:-1])), ll
+    assert ll[-1] > ll[0] + 1e-3
+    assert np.all(model.a > 0)

@@ -144,7 +144,7 @@ struct smcpp_im {
     int max_pass = 0;
     int last_fwd_passes = 0, last_bwd_passes = 0;
     float eps_f = 2e-6f;
-    double eps_b = 1e-9;
+    double eps_b = 1e-6;   // relative; beta only enters products with the float alpha (noise floor 2e-6), see DESIGN.md §3
     // ---- results (host) ---------------------------------------------------------------------------------------
     std::vector<double> loglik, h_xisum, h_gsum, h_gamma0;
     bool stats_on_host = false;

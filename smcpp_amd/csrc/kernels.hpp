@@ -855,6 +855,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop(ChainArgs a, CoopArgs ca) {
     float *xf = reinterpret_cast<float *>(ub + 4 * UP);       // [2][MT]   unnormalised chain state (float)
     int2 *sdesc = reinterpret_cast<int2 *>(xf + 2 * MT);      // [2][64]   row descriptors
     int *sflag = reinterpret_cast<int *>(sdesc + 128);        // [1]
+    int *mflag = sflag + 4;                                    // [4] per-wavefront "not merged yet" flags
     if (TAB) {
         lds_stage(sE, a.E, ca.K * MT * 8, tid, NW * 64);
         if (ca.G > 0) lds_stage(sD, a.dpow, ca.G * MT * 8, tid, NW * 64);
@@ -875,6 +876,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop(ChainArgs a, CoopArgs ca) {
         if (i < M) al = src[i];
     }
     if (tid == 0) *sflag = 0;
+    if (lane == 0) mflag[w] = 1;
     __syncthreads();
     if (pass > 0) {
         bool diff = false;
@@ -932,12 +934,25 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop(ChainArgs a, CoopArgs ca) {
     double dp_cur = (ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + i]) : 0.0;
     int2 d1 = (nrows > 1) ? desc_at(1) : make_int2(0, -1);
     float v_prev = al;      // owner: unnormalised output of the previous row (normalised, clamped and stored one row later)
+    // Re-runs (pass > 0) stop as soon as the new trajectory has merged with the one stored by the previous pass: every
+    // 16 rows the freshly normalised alpha row is compared with the stored one before it is overwritten; once they agree
+    // within eps the remaining rows, normalisers and the end vector of the previous pass stay valid (the perturbation of
+    // a start vector decays geometrically), so late, sparse passes cost a few hundred rows instead of a whole chunk.
+    const bool rerun = pass > 0;
+    float old_pref = 0.f;
+    bool merged = false;
 #ifdef SMCPP_PROFILE_CYCLES
     long long t_loop0 = __builtin_readcyclecounter(), t_bar = 0, t_bar2 = 0;
 #endif
     for (int j = 0; j < nrows; ++j) {
         const int ell = ch.r0 + 1 + j;
         const int jb = j & 63, bsel = (j >> 6) & 1, cur = j & 1, nxt = cur ^ 1;
+        if (rerun && j > 16 && (j & 15) == 1) {
+            int nm = mflag[0];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) nm |= mflag[q];
+            if (nm == 0) { merged = true; break; }
+        }
         if (w == 0 && jb == 32) {
             sdesc[(bsel ^ 1) * 64 + lane] = dnext;
             dnext = (j - 32 + 128 + lane < nrows) ? rd[ch.r0 + 1 + (j - 32) + 128 + lane] : make_int2(0, -1);
@@ -964,13 +979,18 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop(ChainArgs a, CoopArgs ca) {
         const float thr = 1e-10f * sprev;
         // the previous row can be finished now that its normaliser is known: alpha = clamp(v / s)   (hmm.cpp:89-94)
         if (j > 0) {
-            if (owner) {
-                float an = v_prev * inv;
-                an = (i < M) ? fmaxf(an, 1e-10f) : 0.f;
-                a.alpha[(size_t)(ch.base + ell - 1) * Mp + i] = an;
+            float an = v_prev * inv;
+            an = (i < M) ? fmaxf(an, 1e-10f) : 0.f;
+            if (rerun && (j & 15) == 0) {
+                // old_pref = the stored alpha of row ell-1 (fetched one iteration ago, before this overwrite)
+                const bool bad = owner && i < M && !(fabsf(an - old_pref) <= a.eps_f * fabsf(old_pref));
+                const bool anyb = __any(bad);
+                if (lane == 0) mflag[w] = anyb ? 1 : 0;
             }
+            if (owner) a.alpha[(size_t)(ch.base + ell - 1) * Mp + i] = an;
             if (tid == 0) a.cnorm[ch.base + ell - 1] = (double)sprev;
         }
+        if (rerun && (j & 15) == 15 && owner) old_pref = a.alpha[(size_t)(ch.base + ell) * Mp + i];
         float vout;
         if (ge < 0) {
             // span == 1: y = Tf^T max(x, thr) / s ; v = float(y e)
@@ -1047,6 +1067,10 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop(ChainArgs a, CoopArgs ca) {
         a.dbg[4 * w + 3] = nrows;
     }
 #endif
+    if (merged) {
+        if (owner) end_cur[i] = end_prev[i];      // the stored tail of the chunk and its end vector are still valid
+        return;
+    }
     // ---- last row: normalise, clamp, store, publish the end vector ----
     {
         const float *xin = xf + (nrows & 1) * MT + kq * KQ;
@@ -1080,6 +1104,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop(ChainArgs a, CoopArgs ca) {
     double *xb = ub + 4 * UP;                                  // [2][4][UP]  unnormalised beta
     int2 *sdesc = reinterpret_cast<int2 *>(xb + 8 * UP);      // [2][64]
     int *sflag = reinterpret_cast<int *>(sdesc + 128);
+    int *mflag = sflag + 4;
     if (TAB) {
         for (int idx = tid; idx < ca.K * MT; idx += NW * 64) {
             const int k = idx / MT, st = idx % MT;
@@ -1101,6 +1126,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop(ChainArgs a, CoopArgs ca) {
         if (i < M) b = fresh ? 1.0 / (double)M : src[i];
     }
     if (tid == 0) *sflag = 0;
+    if (lane == 0) mflag[w] = 1;
     __syncthreads();
     if (pass > 0) {
         bool diff = false;
@@ -1148,9 +1174,18 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop(ChainArgs a, CoopArgs ca) {
     if (owner) xb[(i / KQ) * UP + (i % KQ)] = b;
     __syncthreads();
     double b_raw = b;       // owner: unnormalised beta of the row being processed
+    const bool rerun = pass > 0;   // early exit once the re-run has merged with the stored trajectory (see k_fwd_coop)
+    double old_pref = 0.0;
+    bool merged = false;
     for (int j = 0; j < nrows; ++j) {
         const int ell = ch.r1 - j;
         const int jb = j & 63, bsel = (j >> 6) & 1, cur = j & 1, nxt = cur ^ 1;
+        if (rerun && j > 16 && (j & 15) == 1) {
+            int nm = mflag[0];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) nm |= mflag[q];
+            if (nm == 0) { merged = true; break; }
+        }
         if (w == 0 && jb == 32) {
             sdesc[(bsel ^ 1) * 64 + lane] = dnext;
             dnext = (j - 32 + 128 + lane < nrows) ? rd[ch.r1 - ((j - 32) + 128 + lane)] : make_int2(0, -1);
@@ -1173,7 +1208,16 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop(ChainArgs a, CoopArgs ca) {
         if (j == 0) sprev = 1.0;
         const double inv = rcp_f64(sprev);
         // beta[ell] = the normalised vector this row is processed with (hmm.cpp:142)
-        if (owner) a.beta[(size_t)(ch.base + ell) * Mp + i] = (i < M) ? b_raw * inv : 0.0;
+        {
+            const double bnrm = (i < M) ? b_raw * inv : 0.0;
+            if (rerun && (j & 15) == 0 && j > 0) {
+                const bool bad = owner && i < M && !(fabs(bnrm - old_pref) <= a.eps_b * fabs(old_pref));
+                const bool anyb = __any(bad);
+                if (lane == 0) mflag[w] = anyb ? 1 : 0;
+            }
+            if (owner) a.beta[(size_t)(ch.base + ell) * Mp + i] = bnrm;
+        }
+        if (rerun && (j & 15) == 15 && owner && j + 1 < nrows) old_pref = a.beta[(size_t)(ch.base + ell - 1) * Mp + i];
         double bn;
         if (ge < 0) {
             // beta <- T (e o beta)   (hmm.cpp:139): this lane needs e on its quarter of the inner index
@@ -1237,6 +1281,10 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop(ChainArgs a, CoopArgs ca) {
         b_raw = bn;
         kid = kid_n; ge = ge_n; dp_cur = dp_nxt; d1 = d2;
         lds_barrier();
+    }
+    if (merged) {
+        if (owner) end_cur[i] = end_prev[i];
+        return;
     }
     {
         const double *xin = xb + (nrows & 1) * 4 * UP + kq * UP;

@@ -148,6 +148,22 @@ int smcpp_host_prep_onepop_jac(int n, int n_hs, const double *hs, double polariz
 int smcpp_host_rate_function(int Kp, const double *a, const double *s, int n_hs, const double *hs, int nt,
                              const double *t, double *R_out, double *avg_ct_out);
 
+/* The same with derivative seeds (PyRateFunction on a model with differentiable pieces): dR_out [nt x nder],
+ * davg_ct_out [(n_hs-1) x nder]. */
+int smcpp_host_rate_function_jac(int Kp, const double *a, const double *da, int nder, const double *s, int n_hs,
+                                 const double *hs, int nt, const double *t, double *R_out, double *dR_out,
+                                 double *avg_ct_out, double *davg_ct_out);
+
+/* PyRateFunction.random_coal_times (smcpp/_smcpp.pyx:391-399, piecewise_constant_rate_function.cpp:337-368): K
+ * coalescence times conditioned on [t1, t2), one std::mt19937 per draw seeded with seeds[i]; returns t and R(t). */
+int smcpp_host_random_coal_times(int Kp, const double *a, const double *s, double t1, double t2, int K,
+                                 const unsigned long long *seeds, double *t_out, double *R_out);
+
+/* raw_sfs (smcpp/_smcpp.pyx:401-412, sfs_cython inference_manager.cpp:492-504): the 3 x (n+1) conditioned SFS of the
+ * single hidden state [t1, t2) before incorporate_theta; dsfs [3*(n+1) x nder] may be NULL when nder == 0. */
+int smcpp_host_raw_sfs(int n, int Kp, const double *a, const double *da, int nder, const double *s, double t1,
+                       double t2, int below_only, double *sfs, double *dsfs);
+
 #ifdef __cplusplus
 }
 #endif

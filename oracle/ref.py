@@ -127,3 +127,21 @@ def prep_jac(a, da, s, hs, rho, theta, n):
     if rc != 0:
         raise RuntimeError(L_.ref_last_error().decode())
     return dict(pi=pi, dpi=dpi, T=T, dT=dT, avg_ct=ct, davg_ct=dct, csfs=cs, dcsfs=dcs)
+
+
+def rate(a, s, t, t1=0.0, t2=1.0, seeds=(), n=-1):
+    """Reference ``PyRateFunction.R`` at ``t``, ``random_time(t1, t2, seed)`` (+ its R) per seed and, for ``n >= 0``,
+    the ``compute_below`` part of the conditioned SFS of the state [t1, t2)."""
+    L_ = lib()
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    t = np.ascontiguousarray(np.atleast_1d(t), dtype=np.float64)
+    seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+    R = np.zeros(len(t)); rt = np.zeros(len(seeds)); rR = np.zeros(len(seeds))
+    below = np.zeros((3, n + 1)) if n >= 0 else None
+    rc = L_.ref_rate(len(a), _p(a, C.c_double), _p(s, C.c_double), len(t), _p(t, C.c_double), _p(R, C.c_double),
+                     C.c_double(t1), C.c_double(t2), len(seeds), _p(seeds, C.c_longlong), _p(rt, C.c_double),
+                     _p(rR, C.c_double), int(n), _p(below, C.c_double))
+    if rc != 0:
+        raise RuntimeError(L_.ref_last_error().decode())
+    return dict(R=R, random_t=rt, random_R=rR, below=below)

@@ -287,3 +287,41 @@ extern "C" int ref_prep_jac(int Kp, const double *a, const double *da, int nder,
         return 1;
     }
 }
+
+// PyRateFunction.R / random_coal_times and raw_sfs(below_only) of the real reference (piecewise_constant_rate_function.cpp:
+// 157-161,337-368; conditioned_sfs.cpp:13-39): R at t[0..nt), one random_time per seed (with R of it), and the
+// compute_below part of the conditioned SFS of the single state [t1, t2).
+extern "C" int ref_rate(int Kp, const double *a, const double *s, int nt, const double *t, double *R_out,
+                        double t1, double t2, int nseeds, const long long *seeds, double *rt_out, double *rR_out,
+                        int n, double *below_out)
+{
+    try
+    {
+        ParameterVector params = make_params(Kp, a, s);
+        {
+            PiecewiseConstantRateFunction<adouble> eta(params, std::vector<double>());
+            for (int i = 0; i < nt; ++i) R_out[i] = eta.R(adouble(t[i])).value();
+            for (int i = 0; i < nseeds; ++i)
+            {
+                adouble x = eta.random_time(t1, t2, seeds[i]);
+                rt_out[i] = x.value();
+                rR_out[i] = eta.R(x).value();
+            }
+        }
+        if (n >= 0 && below_out)
+        {
+            std::vector<double> hs{t1, t2};
+            PiecewiseConstantRateFunction<adouble> eta(params, hs);
+            OnePopConditionedSFS<adouble> csfs(n);
+            Matrix<adouble> m = csfs.compute_below(eta).at(0);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j <= n; ++j) below_out[i * (n + 1) + j] = m(i, j).value();
+        }
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_err = e.what();
+        return 1;
+    }
+}

@@ -55,7 +55,7 @@ EXPORTS = [
     "smcpp_get_emission_probs", "smcpp_get_gamma_argmax", "smcpp_set_global_keys", "smcpp_pack_stats",
     "smcpp_unpack_stats", "smcpp_set_chunking", "smcpp_last_timing", "smcpp_stream", "smcpp_set_num_threads",
     "smcpp_host_eigensystem", "smcpp_host_prep_onepop", "smcpp_host_prep_onepop_jac", "smcpp_num_derivatives",
-    "smcpp_host_rate_function",
+    "smcpp_host_rate_function", "smcpp_host_rate_function_jac", "smcpp_host_random_coal_times", "smcpp_host_raw_sfs",
 ]
 
 
@@ -125,3 +125,51 @@ def host_rate_function(a, s, t, hs=None):
     ct = np.zeros(len(hs) - 1)
     check(lib().smcpp_host_rate_function(len(a), dptr(a), dptr(s), len(hs), dptr(hs), len(t), dptr(t), dptr(R), dptr(ct)))
     return R, ct
+
+
+def host_rate_function_jac(a, da, s, t, hs=None):
+    """Values and Jacobians (w.r.t. the seeds ``da`` [K x nder]) of R(t) and, with ``hs``, of the average coalescence
+    times: returns (R, dR) or (R, dR, ct, dct)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    da = np.ascontiguousarray(da, dtype=np.float64).reshape(len(a), -1)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    t = np.ascontiguousarray(np.atleast_1d(t), dtype=np.float64)
+    nder = da.shape[1]
+    R = np.zeros(len(t)); dR = np.zeros((len(t), nder))
+    if hs is None or len(hs) < 2:
+        check(lib().smcpp_host_rate_function_jac(len(a), dptr(a), dptr(da), nder, dptr(s), 0, None, len(t), dptr(t),
+                                                 dptr(R), dptr(dR), None, None))
+        return R, dR
+    hs = np.ascontiguousarray(hs, dtype=np.float64)
+    ct = np.zeros(len(hs) - 1); dct = np.zeros((len(hs) - 1, nder))
+    check(lib().smcpp_host_rate_function_jac(len(a), dptr(a), dptr(da), nder, dptr(s), len(hs), dptr(hs), len(t),
+                                             dptr(t), dptr(R), dptr(dR), dptr(ct), dptr(dct)))
+    return R, dR, ct, dct
+
+
+def host_random_coal_times(a, s, t1, t2, seeds):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    t = np.zeros(len(seeds)); R = np.zeros(len(seeds))
+    check(lib().smcpp_host_random_coal_times(len(a), dptr(a), dptr(s), C.c_double(t1), C.c_double(t2), len(seeds),
+                                             seeds.ctypes.data_as(C.POINTER(C.c_ulonglong)), dptr(t), dptr(R)))
+    return t, R
+
+
+def host_raw_sfs(n, a, s, t1, t2, below_only=False, da=None):
+    """3 x (n+1) conditioned SFS of the single state [t1, t2) before ``incorporate_theta``; with ``da`` also its
+    Jacobian [3, n+1, nder]."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    out = np.zeros((3, n + 1))
+    if da is None:
+        check(lib().smcpp_host_raw_sfs(int(n), len(a), dptr(a), None, 0, dptr(s), C.c_double(t1), C.c_double(t2),
+                                       int(bool(below_only)), dptr(out), None))
+        return out
+    da = np.ascontiguousarray(da, dtype=np.float64).reshape(len(a), -1)
+    nder = da.shape[1]
+    dout = np.zeros((3, n + 1, nder))
+    check(lib().smcpp_host_raw_sfs(int(n), len(a), dptr(a), dptr(da), nder, dptr(s), C.c_double(t1), C.c_double(t2),
+                                   int(bool(below_only)), dptr(out), dptr(dout)))
+    return out, dout

@@ -302,3 +302,51 @@ class PyTwoPopInferenceManager(_PyInferenceManager):
 
     def update(self, message, *args, **kwargs):
         raise RuntimeError("two-population parameter preparation (JointCSFS) is not built yet; use set_raw")
+
+
+class PyRateFunction:
+    """Mirror of `PyRateFunction` (smcpp/_smcpp.pyx:370-399): cumulative hazard of a piecewise-constant model.
+    Values are plain floats; `R_jac` / `average_coal_times_jac` additionally return the Jacobians with respect to the
+    model's `derivative_seeds()` (the `.d()` parts of the reference's ad numbers)."""
+
+    def __init__(self, model, hs):
+        self._model = model
+        self._hs = np.asarray(list(hs), dtype=np.float64)
+        self._a = np.asarray([float(x) for x in model.stepwise_values()], dtype=np.float64)
+        self._s = np.asarray(model.s, dtype=np.float64)
+
+    def R(self, t):
+        assert np.isfinite(t)
+        return float(E.host_rate_function(self._a, self._s, [t])[0])
+
+    def average_coal_times(self):
+        if len(self._hs) < 2:
+            return []
+        return list(E.host_rate_function(self._a, self._s, [0.0], self._hs)[1])
+
+    def _seeds(self):
+        da = getattr(self._model, "derivative_seeds", lambda: None)()
+        return np.eye(len(self._a)) if da is None else da
+
+    def R_jac(self, t):
+        R, dR = E.host_rate_function_jac(self._a, self._seeds(), self._s, [t])[:2]
+        return float(R[0]), dR[0]
+
+    def average_coal_times_jac(self):
+        _, _, ct, dct = E.host_rate_function_jac(self._a, self._seeds(), self._s, [0.0], self._hs)
+        return ct, dct
+
+    def random_coal_times(self, t1, t2, K):
+        seeds = np.random.randint(0, np.iinfo(np.int64).max, size=K, dtype=np.int64).astype(np.uint64)
+        t, R = E.host_random_coal_times(self._a, self._s, t1, t2, seeds)
+        return [[float(x), float(y)] for x, y in zip(t, R)]
+
+
+def raw_sfs(model, n, t1, t2, below_only=False, jac=False):
+    """Mirror of `raw_sfs` (smcpp/_smcpp.pyx:401-412): conditioned SFS [3, n+1] of the single hidden state [t1, t2)."""
+    a = np.asarray([float(x) for x in model.stepwise_values()], dtype=np.float64)
+    s = np.asarray(model.s, dtype=np.float64)
+    if not jac:
+        return E.host_raw_sfs(n, a, s, t1, t2, below_only)
+    da = getattr(model, "derivative_seeds", lambda: None)()
+    return E.host_raw_sfs(n, a, s, t1, t2, below_only, da=np.eye(len(a)) if da is None else da)

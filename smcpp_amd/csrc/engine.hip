@@ -1409,4 +1409,71 @@ int smcpp_host_rate_function(int Kp, const double *a, const double *s, int n_hs,
     API_END
 }
 
+// seeds a dual model from (a, da); nder == 0 leaves the derivative parts empty
+static smcpp_host::ModelParamsT<smcpp_host::dual> dual_model(int Kp, const double *a, const double *da, int nder,
+                                                              const double *s) {
+    smcpp_host::ModelParamsT<smcpp_host::dual> mp;
+    mp.s.assign(s, s + Kp);
+    mp.a.resize(Kp);
+    for (int k = 0; k < Kp; ++k) {
+        mp.a[k] = smcpp_host::dual(a[k]);
+        for (int d = 0; d < nder; ++d) mp.a[k].d[d] = da[(size_t)k * nder + d];
+    }
+    return mp;
+}
+
+int smcpp_host_rate_function_jac(int Kp, const double *a, const double *da, int nder, const double *s, int n_hs,
+                                 const double *hs, int nt, const double *t, double *R_out, double *dR_out,
+                                 double *avg_ct_out, double *davg_ct_out) {
+    API_BEGIN
+    if (nder < 0 || nder > smcpp_host::MAXD) throw std::runtime_error("too many derivatives");
+    smcpp_host::DualScope sc(nder);
+    std::vector<double> hsv(hs, hs + std::max(0, n_hs));
+    smcpp_host::RateFunctionT<smcpp_host::dual> eta(dual_model(Kp, a, da, nder, s), hsv);
+    for (int i = 0; i < nt; ++i) {
+        const smcpp_host::dual r = eta.R(t[i]);
+        R_out[i] = r.v;
+        for (int d = 0; d < nder; ++d) dR_out[(size_t)i * nder + d] = r.d[d];
+    }
+    if (n_hs >= 2 && avg_ct_out) {
+        const std::vector<smcpp_host::dual> v = eta.average_coal_times();
+        for (size_t i = 0; i < v.size(); ++i) {
+            avg_ct_out[i] = v[i].v;
+            if (davg_ct_out) for (int d = 0; d < nder; ++d) davg_ct_out[i * nder + d] = v[i].d[d];
+        }
+    }
+    API_END
+}
+
+int smcpp_host_random_coal_times(int Kp, const double *a, const double *s, double t1, double t2, int K,
+                                 const unsigned long long *seeds, double *t_out, double *R_out) {
+    API_BEGIN
+    smcpp_host::ModelParamsT<double> mp;
+    mp.a.assign(a, a + Kp);
+    mp.s.assign(s, s + Kp);
+    smcpp_host::RateFunctionT<double> eta(mp, std::vector<double>());
+    for (int i = 0; i < K; ++i) {
+        t_out[i] = eta.random_time(t1, t2, seeds[i]);
+        R_out[i] = eta.R(t_out[i]);
+    }
+    API_END
+}
+
+int smcpp_host_raw_sfs(int n, int Kp, const double *a, const double *da, int nder, const double *s, double t1,
+                       double t2, int below_only, double *sfs, double *dsfs) {
+    API_BEGIN
+    if (n < 0) throw std::runtime_error("n must be >= 0");
+    if (nder < 0 || nder > smcpp_host::MAXD) throw std::runtime_error("too many derivatives");
+    smcpp_host::DualScope sc(nder);
+    const std::vector<double> hsv{t1, t2};
+    smcpp_host::RateFunctionT<smcpp_host::dual> eta(dual_model(Kp, a, da, nder, s), hsv);
+    const auto tb = smcpp_host::csfs_tables(n);
+    const auto v = smcpp_host::conditioned_sfs<smcpp_host::dual>(eta, *tb, below_only != 0);
+    for (size_t i = 0; i < v[0].size(); ++i) {
+        sfs[i] = v[0][i].v;
+        if (dsfs) for (int d = 0; d < nder; ++d) dsfs[i * nder + d] = v[0][i].d[d];
+    }
+    API_END
+}
+
 }  // extern "C"

@@ -20,6 +20,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <random>
 #include <set>
 #include <stdexcept>
 #include <vector>
@@ -342,6 +343,8 @@ inline double m_expm1(double x) { return std::expm1(x); }
 inline long double m_expm1(long double x) { return expm1l(x); }
 inline double m_log(double x) { return std::log(x); }
 inline long double m_log(long double x) { return logl(x); }
+inline double m_log1p(double x) { return std::log1p(x); }
+inline long double m_log1p(long double x) { return log1pl(x); }
 inline double m_sqrt(double x) { return std::sqrt(x); }
 inline long double m_sqrt(long double x) { return sqrtl(x); }
 inline double m_sinh(double x) { return std::sinh(x); }
@@ -351,6 +354,7 @@ inline long double m_cosh(long double x) { return coshl(x); }
 template <typename F> inline Dual<F> m_exp(const Dual<F> &a) { Dual<F> r; r.v = m_exp(a.v); SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] * r.v; return r; }
 template <typename F> inline Dual<F> m_expm1(const Dual<F> &a) { Dual<F> r; r.v = m_expm1(a.v); const F e = m_exp(a.v); SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] * e; return r; }
 template <typename F> inline Dual<F> m_log(const Dual<F> &a) { Dual<F> r; r.v = m_log(a.v); SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] / a.v; return r; }
+template <typename F> inline Dual<F> m_log1p(const Dual<F> &a) { Dual<F> r; r.v = m_log1p(a.v); SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] / (1 + a.v); return r; }
 template <typename F> inline Dual<F> m_sqrt(const Dual<F> &a) { Dual<F> r; r.v = m_sqrt(a.v); SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] / (2 * r.v); return r; }
 template <typename F> inline Dual<F> m_sinh(const Dual<F> &a) { Dual<F> r; r.v = m_sinh(a.v); const F c = m_cosh(a.v); SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] * c; return r; }
 inline double sval(double x) { return x; }
@@ -401,6 +405,25 @@ public:
         auto ti = std::upper_bound(ts.begin(), ts.end(), t) - 1;
         const int ip = (int)(ti - ts.begin());
         return Rrng[ip] + ada[ip] * (t - *ti);
+    }
+
+    // inverse of the cumulative hazard (piecewise_constant_rate_function.cpp:415-420)
+    S Rinv(const S &y) const {
+        int ip = 0;
+        while (ip + 1 < (int)Rrng.size() && !(sval(y) < sval(Rrng[ip + 1]))) ++ip;
+        if (ip >= K) ip = K - 1;
+        return (y - Rrng[ip]) / ada[ip] + ts[ip];
+    }
+
+    // coalescence time conditioned on [a, b): inverse-cdf draw from Exp(1) truncated to [R(a), R(b))
+    // (piecewise_constant_rate_function.cpp:337-368); one std::mt19937 per call, seeded by the caller
+    S random_time(double a, double b, unsigned long long seed) const {
+        std::mt19937 gen(seed);
+        const double unif = std::uniform_real_distribution<double>{0.0, 1.0}(gen);
+        const S Ra = R(a);
+        if (std::isinf(b)) return Rinv(Ra - std::log1p(-unif));
+        const S Rb = R(b);
+        return Rinv(Ra - m_log1p(m_expm1(-(Rb - Ra)) * unif));
     }
 
     // int_a^b exp(-(R(t) + log_denom)) dt
@@ -674,13 +697,13 @@ inline S dcs_sorted(std::vector<S> &v) {
 
 // raw CSFS per hidden state: out[m] is 3 x (n+1) row-major
 template <typename S>
-inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, const CsfsTables &tb) {
+inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, const CsfsTables &tb, bool below_only = false) {
     const int n = tb.n;
     const int M = (int)eta.hidden_states.size() - 1;
     const int nd = dual_nder();
     std::vector<std::vector<S>> csfs(M, std::vector<S>((size_t)3 * (n + 1), S(0.0)));
     // ---- above ----
-    if (n >= 1) {
+    if (n >= 1 && !below_only) {
         std::vector<std::vector<S>> C_above(M, std::vector<S>((size_t)(n + 1) * n, S(0.0)));
 #pragma omp parallel for schedule(dynamic)
         for (int j = 2; j < n + 3; ++j) { DualScope sc(nd); eta.tjj_double_integral_above(n, j, C_above); }

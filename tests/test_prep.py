@@ -96,3 +96,84 @@ def test_jacobians_vs_reference_autodiff(M, n):
                                          theta, alpha, pol)
         dref = np.array([(ep1[tuple(k)] - ep0[tuple(k)]) / h for k in keys.tolist()])
         assert np.abs(dE[..., d] - dref).max() <= 1e-7 * max(np.abs(dref).max(), 1e-3)
+
+
+# ---- module helpers next to the managers: PyRateFunction, raw_sfs, golden G8 ----
+def _g8():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G8_prep_only.npz"))
+
+
+@pytest.mark.parametrize("si", [0, 1, 2])
+def test_rate_function_and_raw_sfs_golden(si):
+    from smcpp_amd import _smcpp, _engine
+    from smcpp_amd.model import PiecewiseModel
+    g = _g8()
+    a, s, hs, t = g[f"S{si}_a"], g[f"S{si}_s"], g[f"S{si}_hs"], g[f"S{si}_t"]
+    m = PiecewiseModel(a, s, 1e4)
+    eta = _smcpp.PyRateFunction(m, hs)
+    np.testing.assert_allclose([eta.R(x) for x in t], g[f"S{si}_R"], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(eta.average_coal_times(), g[f"S{si}_avg_ct"], rtol=1e-13)
+    rt, rR = _engine.host_random_coal_times(a, s, 0.01, 0.5, g["seeds"].astype(np.uint64))
+    np.testing.assert_allclose(rt, g[f"S{si}_random_t"], rtol=1e-13)
+    np.testing.assert_allclose(rR, g[f"S{si}_random_R"], rtol=1e-13)
+    assert np.all((rt > 0.01) & (rt < 0.5))
+    for n in (0, 2, 10, 20):
+        for iv, (t1, t2) in enumerate(g["intervals"]):
+            want = g[f"S{si}_sfs_n{n}_i{iv}"]
+            got = _smcpp.raw_sfs(m, n, t1, t2)
+            np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-15 * np.abs(want).max())
+            wb = g[f"S{si}_below_n{n}_i{iv}"]
+            gb = _smcpp.raw_sfs(m, n, t1, t2, below_only=True)
+            np.testing.assert_allclose(gb, wb, rtol=1e-11, atol=1e-15 * max(np.abs(wb).max(), 1e-300))
+
+
+def test_reference_known_answers_rate_function_and_sfs():
+    """The reference's own known-answer tests (test/unit/test_bugs.py:8-33), restated against this module."""
+    import scipy.integrate
+    from smcpp_amd import _smcpp
+    from smcpp_amd.model import PiecewiseModel
+    model1 = PiecewiseModel([1.0], [1.0], 1e4)
+    eta = _smcpp.PyRateFunction(model1, [0.0, 1.0, 2.0, np.inf])
+    assert eta.R(2.0) == 2.0
+    n = 5
+    raw = _smcpp.raw_sfs(model1, n - 2, 0.0, np.inf)
+    undist = np.zeros(n)                                     # util.undistinguished_sfs: fold (a, b) -> a + b
+    for i in range(3):
+        for j in range(n - 1):
+            if i + j < n:
+                undist[i + j] += raw[i, j]
+    assert np.allclose(undist[1:], 2.0 / np.arange(1, n))
+    ts = [0.0, 0.5, 1.0, 2.0, np.inf]
+    for t1, t2 in zip(ts[:-1], ts[1:]):
+        ans = scipy.integrate.quad(lambda t: t * np.exp(-t), t1, t2)[0] / (np.exp(-t1) - np.exp(-t2))
+        for nn in [0, 2, 10, 20]:
+            np.testing.assert_allclose(_smcpp.raw_sfs(model1, nn, t1, t2).sum(axis=1)[1], 2.0 * ans)
+    # random coalescence times stay inside the conditioning interval (test_bugs.py:8-16)
+    s = np.diff(np.logspace(-2, 0.5, 33))
+    m2 = PiecewiseModel(np.exp(np.linspace(-2.4, 3.6, 32) % 1.7 - 1.0), s, 1e4)
+    for t, Rt in _smcpp.PyRateFunction(m2, []).random_coal_times(0.0, 0.02, 10):
+        assert 0.0 < t < 0.02
+
+
+def test_rate_function_jacobian_vs_finite_differences():
+    """Mirror of test/unit/test_rate_function.py (AD of R(t) against one-sided differences), asserted here."""
+    from smcpp_amd import _smcpp
+    from smcpp_amd.model import PiecewiseModel
+    K = 10
+    s = np.diff(np.logspace(np.log10(.01), np.log10(3.), K + 1))
+    a = np.exp(np.array([0.27, -1.05, 0.67, 0.31, -2.30, 0.26, 0.20, 0.50, 0.32, 0.50]))
+    hs = np.concatenate([[0.], np.logspace(-2, 1, 10), [np.inf]])
+    m = PiecewiseModel(a, s, 1e4)
+    m.differentiable = True
+    eta = _smcpp.PyRateFunction(m, hs)
+    Rt, dR = eta.R_jac(1.08)
+    ct, dct = eta.average_coal_times_jac()
+    sf, dsf = _smcpp.raw_sfs(m, 6, 0.05, 0.9, jac=True)
+    for k in range(K):
+        ap = a.copy(); ap[k] += 1e-7
+        mp = PiecewiseModel(ap, s, 1e4)
+        ep = _smcpp.PyRateFunction(mp, hs)
+        assert abs((ep.R(1.08) - Rt) * 1e7 - dR[k]) <= 1e-5 * max(1.0, abs(dR[k]))
+        np.testing.assert_allclose((np.array(ep.average_coal_times()) - ct) * 1e7, dct[:, k], atol=2e-6)
+        np.testing.assert_allclose((_smcpp.raw_sfs(mp, 6, 0.05, 0.9) - sf) * 1e7, dsf[:, :, k], atol=2e-6)

@@ -164,6 +164,27 @@ int smcpp_host_random_coal_times(int Kp, const double *a, const double *s, doubl
 int smcpp_host_raw_sfs(int n, int Kp, const double *a, const double *da, int nder, const double *s, double t1,
                        double t2, int below_only, double *sfs, double *dsfs);
 
+/* TwoPopInferenceManager::setParams (src/inference_manager.cpp:542-550, smcpp/_smcpp.pyx:353-368): the distinguished
+ * model (pi, transition, average coalescence times), the two per-population models and the split time for the joint
+ * CSFS.  d* are derivative seeds [K x nder] (NULL = zero) sharing one set of nder directions (`model.dlist`). */
+int smcpp_set_params_twopop(smcpp_im *im, int Kd, const double *ad, const double *sd, const double *dad, int K1,
+                            const double *a1, const double *s1, const double *da1, int K2, const double *a2,
+                            const double *s2, const double *da2, double split, int nder);
+
+/* joint_csfs (smcpp/_smcpp.pyx:416-437; JointCSFS src/jcsfs.cpp:219-420): per hidden state the tensor
+ * [(a1+1) x (n1+1) x (a2+1) x (n2+1)], out [(n_hs-1) x that], Kmc Monte-Carlo draws for the averaged Moran
+ * transition below the split (the reference's default is 10).  With nder > 0, da1 / da2 [K x nder] seed the piece
+ * sizes (NULL = zero) and dout [size x nder] receives the Jacobian. */
+int smcpp_host_joint_csfs(int n1, int n2, int a1, int a2, int n_hs, const double *hs, int K1, const double *pa1,
+                          const double *ps1, const double *da1, int K2, const double *pa2, const double *ps2,
+                          const double *da2, int nder, double split, int Kmc, double *out, double *dout);
+
+/* Whole two-population cold preparation without an engine instance: pi [M], T [M x M], E [K x M] for keys [K x 6]. */
+int smcpp_host_prep_twopop(int n1, int n2, int a1, int a2, int n_hs, const double *hs, double polarization_error,
+                           int Kd, const double *ad, const double *sd, int K1, const double *pa1, const double *ps1,
+                           int K2, const double *pa2, const double *ps2, double split, double theta, double rho,
+                           double alpha, int K, const int *keys, double *pi, double *T, double *E);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,3 +145,17 @@ def rate(a, s, t, t1=0.0, t2=1.0, seeds=(), n=-1):
     if rc != 0:
         raise RuntimeError(L_.ref_last_error().decode())
     return dict(R=R, random_t=rt, random_R=rR, below=below)
+
+
+def random_times_shared(a, s, t1, t2, K):
+    """K draws of the reference's ``random_time(1., t1, t2, gen)`` from one default-seeded ``std::mt19937`` — the
+    sequence ``JointCSFS`` uses (jcsfs.cpp:120-127).  Returns (t, R(t))."""
+    L_ = lib()
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    t = np.zeros(K); R = np.zeros(K)
+    rc = L_.ref_random_times_shared(len(a), _p(a, C.c_double), _p(s, C.c_double), C.c_double(t1), C.c_double(t2),
+                                    int(K), _p(t, C.c_double), _p(R, C.c_double))
+    if rc != 0:
+        raise RuntimeError(L_.ref_last_error().decode())
+    return t, R

@@ -325,3 +325,28 @@ extern "C" int ref_rate(int Kp, const double *a, const double *s, int nt, const 
         return 1;
     }
 }
+
+// K coalescence times drawn the way JointCSFS draws them (jcsfs.cpp:120-127): ONE default-constructed std::mt19937
+// shared by the K calls of the reference's public random_time(fac, a, b, gen); returns t and R(t).
+extern "C" int ref_random_times_shared(int Kp, const double *a, const double *s, double t1, double t2, int K,
+                                       double *t_out, double *R_out)
+{
+    try
+    {
+        ParameterVector params = make_params(Kp, a, s);
+        const PiecewiseConstantRateFunction<adouble> eta(params, std::vector<double>());
+        std::mt19937 gen;
+        for (int k = 0; k < K; ++k)
+        {
+            const adouble t = eta.random_time(1., t1, t2, gen);
+            t_out[k] = t.value();
+            R_out[k] = eta.R(t).value();
+        }
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_err = e.what();
+        return 1;
+    }
+}

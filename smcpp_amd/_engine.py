@@ -56,6 +56,7 @@ EXPORTS = [
     "smcpp_unpack_stats", "smcpp_set_chunking", "smcpp_last_timing", "smcpp_stream", "smcpp_set_num_threads",
     "smcpp_host_eigensystem", "smcpp_host_prep_onepop", "smcpp_host_prep_onepop_jac", "smcpp_num_derivatives",
     "smcpp_host_rate_function", "smcpp_host_rate_function_jac", "smcpp_host_random_coal_times", "smcpp_host_raw_sfs",
+    "smcpp_set_params_twopop", "smcpp_host_joint_csfs", "smcpp_host_prep_twopop",
 ]
 
 
@@ -173,3 +174,41 @@ def host_raw_sfs(n, a, s, t1, t2, below_only=False, da=None):
     check(lib().smcpp_host_raw_sfs(int(n), len(a), dptr(a), dptr(da), nder, dptr(s), C.c_double(t1), C.c_double(t2),
                                    int(bool(below_only)), dptr(out), dptr(dout)))
     return out, dout
+
+
+def host_joint_csfs(n1, n2, a1, a2, hs, model1, model2, split, K=10, da1=None, da2=None):
+    """Joint CSFS per hidden state: array [M, a1+1, n1+1, a2+1, n2+1]; ``model*`` = (a, s).  With derivative seeds
+    ``da1`` / ``da2`` ([K x nder], either may be None) also returns the Jacobian [..., nder]."""
+    hs = np.ascontiguousarray(hs, dtype=np.float64)
+    a1v, s1v = (np.ascontiguousarray(x, dtype=np.float64) for x in model1)
+    a2v, s2v = (np.ascontiguousarray(x, dtype=np.float64) for x in model2)
+    out = np.zeros((len(hs) - 1, a1 + 1, n1 + 1, a2 + 1, n2 + 1))
+    if da1 is None and da2 is None:
+        check(lib().smcpp_host_joint_csfs(n1, n2, a1, a2, len(hs), dptr(hs), len(a1v), dptr(a1v), dptr(s1v), None,
+                                          len(a2v), dptr(a2v), dptr(s2v), None, 0, C.c_double(split), int(K),
+                                          dptr(out), None))
+        return out
+    nder = (da1 if da1 is not None else da2).shape[1]
+    d1 = None if da1 is None else np.ascontiguousarray(da1, dtype=np.float64)
+    d2 = None if da2 is None else np.ascontiguousarray(da2, dtype=np.float64)
+    dout = np.zeros(out.shape + (nder,))
+    check(lib().smcpp_host_joint_csfs(n1, n2, a1, a2, len(hs), dptr(hs), len(a1v), dptr(a1v), dptr(s1v),
+                                      None if d1 is None else dptr(d1), len(a2v), dptr(a2v), dptr(s2v),
+                                      None if d2 is None else dptr(d2), nder, C.c_double(split), int(K), dptr(out),
+                                      dptr(dout)))
+    return out, dout
+
+
+def host_prep_twopop(n1, n2, a1, a2, hs, pol, dist, model1, model2, split, theta, rho, alpha, keys):
+    hs = np.ascontiguousarray(hs, dtype=np.float64)
+    ad, sd = (np.ascontiguousarray(x, dtype=np.float64) for x in dist)
+    a1v, s1v = (np.ascontiguousarray(x, dtype=np.float64) for x in model1)
+    a2v, s2v = (np.ascontiguousarray(x, dtype=np.float64) for x in model2)
+    keys = np.ascontiguousarray(keys, dtype=np.int32).reshape(-1, 6)
+    M = len(hs) - 1
+    pi = np.zeros(M); T = np.zeros((M, M)); E = np.zeros((len(keys), M))
+    check(lib().smcpp_host_prep_twopop(n1, n2, a1, a2, len(hs), dptr(hs), C.c_double(pol), len(ad), dptr(ad), dptr(sd),
+                                       len(a1v), dptr(a1v), dptr(s1v), len(a2v), dptr(a2v), dptr(s2v), C.c_double(split),
+                                       C.c_double(theta), C.c_double(rho), C.c_double(alpha), len(keys), iptr(keys),
+                                       dptr(pi), dptr(T), dptr(E)))
+    return pi, T, E

@@ -283,7 +283,8 @@ class PyOnePopInferenceManager(_PyInferenceManager):
 
 class PyTwoPopInferenceManager(_PyInferenceManager):
     """``PyTwoPopInferenceManager(n1, n2, a1, a2, observations, hidden_states, im_id, polarization_error)``
-    (_smcpp.pyx:334-368).  Parameters enter through ``set_raw`` until the JointCSFS preparation is built."""
+    (_smcpp.pyx:334-368).  `im.model = TwoPopulationModel(...)` feeds the distinguished model, both populations and
+    the split to the engine's JointCSFS preparation; `set_raw` remains available."""
 
     def __init__(self, n1, n2, a1, a2, observations, hidden_states, im_id, polarization_error, device=-1):
         assert a1 + a2 == 2
@@ -301,7 +302,22 @@ class PyTwoPopInferenceManager(_PyInferenceManager):
         self.rho = 1e-4
 
     def update(self, message, *args, **kwargs):
-        raise RuntimeError("two-population parameter preparation (JointCSFS) is not built yet; use set_raw")
+        m = self._model
+        pids = self._im_id
+        dist = None if self._a1 == 1 else pids[0]              # both lineages apart -> special distinguished model
+        dm = m.for_pop(dist)
+        ms = [m.for_pop(p) for p in pids]
+        arrs, seeds = [], []
+        for q in (dm, ms[0], ms[1]):
+            arrs.append((aca(np.asarray(q.stepwise_values(), dtype=np.float64)), aca(np.asarray(q.s, dtype=np.float64))))
+            sd = q.derivative_seeds() if hasattr(q, "derivative_seeds") else None
+            seeds.append(None if sd is None else aca(np.asarray(sd, dtype=np.float64)))
+        nder = max([0] + [x.shape[1] for x in seeds if x is not None])
+        ptr = lambda x: None if x is None else E.dptr(x)       # noqa: E731
+        (ad, sd_), (a1, s1), (a2, s2) = arrs
+        E.check(E.lib().smcpp_set_params_twopop(self._im, len(ad), E.dptr(ad), E.dptr(sd_), ptr(seeds[0]), len(a1),
+                                                E.dptr(a1), E.dptr(s1), ptr(seeds[1]), len(a2), E.dptr(a2),
+                                                E.dptr(s2), ptr(seeds[2]), C.c_double(float(m.split)), int(nder)))
 
 
 class PyRateFunction:
@@ -350,3 +366,13 @@ def raw_sfs(model, n, t1, t2, below_only=False, jac=False):
         return E.host_raw_sfs(n, a, s, t1, t2, below_only)
     da = getattr(model, "derivative_seeds", lambda: None)()
     return E.host_raw_sfs(n, a, s, t1, t2, below_only, da=np.eye(len(a)) if da is None else da)
+
+
+def joint_csfs(n1, n2, a1, a2, model, hidden_states, K=10):
+    """Mirror of `joint_csfs` (smcpp/_smcpp.pyx:416-437, "used for testing purposes only"): list over hidden states of
+    the joint conditioned SFS [(a1+1), (n1+1), (a2+1), (n2+1)] of a `TwoPopulationModel`."""
+    assert (a1 == 2 and a2 == 0) or (a1 == a2 == 1)
+    p1, p2 = model.for_pop(model.pids[0]), model.for_pop(model.pids[1])
+    J = E.host_joint_csfs(n1, n2, a1, a2, np.asarray(list(hidden_states), dtype=np.float64),
+                          (p1.stepwise_values(), p1.s), (p2.stepwise_values(), p2.s), float(model.split), K)
+    return [J[m] for m in range(J.shape[0])]

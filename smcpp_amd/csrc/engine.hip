@@ -26,6 +26,7 @@
 #include "kernels.hpp"
 #include "nonsym_eig.hpp"
 #include "prep.hpp"
+#include "jcsfs.hpp"
 
 using namespace smcpp_dev;
 
@@ -109,7 +110,10 @@ struct smcpp_im {
     double theta = NAN, rho = NAN, alpha = 1.0;
     bool have_raw = false, dirty = true, params_fresh = false;
     std::vector<double> pi, T, E;          // [M], [M*M], [K*M]
-    smcpp_host::ModelParams model;         // a, s (for set_params)
+    smcpp_host::ModelParams model;         // a, s (for set_params); the distinguished model of a two-population manager
+    smcpp_host::ModelParams model_p1, model_p2;          // two populations: per-population pieces (set_params_twopop)
+    std::vector<double> model_da1, model_da2;            // their derivative seeds [K x nder]
+    double split = 0.0;
     std::vector<double> model_da;          // [Kp x nder] derivative seeds of a
     int nder = 0;
     std::vector<double> dpi, dT, dE;       // Jacobians [size x nder] of pi, T, E w.r.t. the seeds
@@ -496,13 +500,53 @@ void smcpp_im::alloc_device() {
 // ---------------------------------------------------------------------------------------------------------------
 // parameters
 // ---------------------------------------------------------------------------------------------------------------
+static smcpp_host::ModelParamsT<smcpp_host::dual> make_dual_model(const smcpp_host::ModelParams &mp,
+                                                                   const std::vector<double> &da, int nder) {
+    smcpp_host::ModelParamsT<smcpp_host::dual> r;
+    r.s = mp.s;
+    r.a.resize(mp.a.size());
+    for (size_t k = 0; k < mp.a.size(); ++k) {
+        r.a[k] = smcpp_host::dual(mp.a[k]);
+        if (!da.empty()) for (int d = 0; d < nder; ++d) r.a[k].d[d] = da[k * nder + d];
+    }
+    return r;
+}
+
+static void split_duals(const std::vector<smcpp_host::dual> &x, int nder, std::vector<double> &v, std::vector<double> &j) {
+    v.resize(x.size());
+    j.resize(x.size() * (size_t)nder);
+    for (size_t i = 0; i < x.size(); ++i) {
+        v[i] = x[i].v;
+        for (int d = 0; d < nder; ++d) j[i * nder + d] = x[i].d[d];
+    }
+}
+
 void smcpp_im::prepare_params() {
     // do_dirty_work (inference_manager.cpp:213-229) for the model-parameter path; the raw path already has pi/T/E.
     if (have_raw || params_fresh) return;
     if (!have_model) throw std::runtime_error("no model parameters: call set_params or set_raw before E_step");
-    if (npop != 1) throw std::runtime_error("two-population parameter preparation (JointCSFS) is not built yet; "
-                                            "use set_raw");
     if (std::isnan(theta) || std::isnan(rho)) throw std::runtime_error("theta / rho / alpha must be set");
+    if (npop == 2) {
+        // TwoPopInferenceManager::setParams (inference_manager.cpp:542-550): pi / T from the distinguished model,
+        // emissions from the joint CSFS of (population 1, population 2, split)
+        if (model_p1.a.empty() || model_p2.a.empty())
+            throw std::runtime_error("two-population manager: call set_params_twopop (or set_raw) before E_step");
+        smcpp_host::TwoPopPrep prep(n[0], n[1], na[0], na[1], hs, polarization_error);
+        if (nder > 0) {
+            smcpp_host::DualScope sc(nder);
+            std::vector<smcpp_host::dual> pd, Td, Ed;
+            prep.compute_t<smcpp_host::dual>(make_dual_model(model, model_da, nder), make_dual_model(model_p1, model_da1, nder),
+                                             make_dual_model(model_p2, model_da2, nder), split, theta, rho, alpha, keys, K,
+                                             pd, Td, Ed);
+            split_duals(pd, nder, pi, dpi); split_duals(Td, nder, T, dT); split_duals(Ed, nder, E, dE);
+        } else {
+            smcpp_host::ModelParamsT<double> d, p1, p2;
+            d.a = model.a; d.s = model.s; p1.a = model_p1.a; p1.s = model_p1.s; p2.a = model_p2.a; p2.s = model_p2.s;
+            prep.compute_t<double>(d, p1, p2, split, theta, rho, alpha, keys, K, pi, T, E);
+        }
+        params_fresh = true;
+        return;
+    }
     smcpp_host::OnePopPrep prep(n[0], hs, polarization_error);
     if (nder > 0) prep.compute_with_jacobian(model, model_da, nder, theta, rho, alpha, keys, K, pi, T, E, dpi, dT, dE);
     else prep.compute(model, theta, rho, alpha, keys, K, pi, T, E);
@@ -1011,6 +1055,37 @@ int smcpp_set_params(smcpp_im *im, int K, const double *a, const double *da, int
     API_END
 }
 
+int smcpp_set_params_twopop(smcpp_im *im, int Kd, const double *ad, const double *sd, const double *dad, int K1,
+                            const double *a1, const double *s1, const double *da1, int K2, const double *a2,
+                            const double *s2, const double *da2, double split, int nder) {
+    API_BEGIN
+    if (im->npop != 2) throw std::runtime_error("set_params_twopop on a one-population manager");
+    if (Kd <= 0 || K1 <= 0 || K2 <= 0) throw std::runtime_error("empty parameter vector");
+    if (!(split >= 0)) throw std::runtime_error("split time must be >= 0");
+    if (nder > smcpp_host::MAXD) throw std::runtime_error("too many derivative directions (max 64)");
+    auto chk = [](int K, const double *a) {
+        for (int k = 0; k < K; ++k)
+            if (!(a[k] > 0)) throw std::runtime_error("model pieces must be positive");
+    };
+    chk(Kd, ad); chk(K1, a1); chk(K2, a2);
+    im->model.a.assign(ad, ad + Kd); im->model.s.assign(sd, sd + Kd);
+    im->model_p1.a.assign(a1, a1 + K1); im->model_p1.s.assign(s1, s1 + K1);
+    im->model_p2.a.assign(a2, a2 + K2); im->model_p2.s.assign(s2, s2 + K2);
+    im->split = split;
+    im->nder = nder > 0 ? nder : 0;
+    im->model_da.clear(); im->model_da1.clear(); im->model_da2.clear();
+    if (im->nder) {
+        if (dad) im->model_da.assign(dad, dad + (size_t)Kd * nder);
+        if (da1) im->model_da1.assign(da1, da1 + (size_t)K1 * nder);
+        if (da2) im->model_da2.assign(da2, da2 + (size_t)K2 * nder);
+    }
+    im->params_fresh = false;
+    im->have_model = true;
+    im->have_raw = false;
+    im->dirty = true;
+    API_END
+}
+
 int smcpp_set_raw(smcpp_im *im, const double *pi, const double *T, int K, const int *keys, const double *E) {
     API_BEGIN
     const int M = im->M, kl = im->keylen;
@@ -1473,6 +1548,61 @@ int smcpp_host_raw_sfs(int n, int Kp, const double *a, const double *da, int nde
         sfs[i] = v[0][i].v;
         if (dsfs) for (int d = 0; d < nder; ++d) dsfs[i * nder + d] = v[0][i].d[d];
     }
+    API_END
+}
+
+int smcpp_host_joint_csfs(int n1, int n2, int a1, int a2, int n_hs, const double *hs, int K1, const double *pa1,
+                          const double *ps1, const double *da1, int K2, const double *pa2, const double *ps2,
+                          const double *da2, int nder, double split, int Kmc, double *out, double *dout) {
+    API_BEGIN
+    if (nder < 0 || nder > smcpp_host::MAXD) throw std::runtime_error("too many derivative directions (max 64)");
+    std::vector<double> hsv(hs, hs + n_hs);
+    smcpp_host::ModelParams m1, m2;
+    m1.a.assign(pa1, pa1 + K1); m1.s.assign(ps1, ps1 + K1);
+    m2.a.assign(pa2, pa2 + K2); m2.s.assign(ps2, ps2 + K2);
+    if (nder == 0) {
+        smcpp_host::ModelParamsT<double> p1, p2;
+        p1.a = m1.a; p1.s = m1.s; p2.a = m2.a; p2.s = m2.s;
+        smcpp_host::JointCsfsT<double> j(n1, n2, a1, a2, hsv, Kmc);
+        const auto J = j.compute(p1, p2, split);
+        size_t o = 0;
+        for (const auto &m : J) { std::memcpy(out + o, m.data(), sizeof(double) * m.size()); o += m.size(); }
+    } else {
+        smcpp_host::DualScope sc(nder);
+        std::vector<double> d1, d2;
+        if (da1) d1.assign(da1, da1 + (size_t)K1 * nder);
+        if (da2) d2.assign(da2, da2 + (size_t)K2 * nder);
+        smcpp_host::JointCsfsT<smcpp_host::dual> j(n1, n2, a1, a2, hsv, Kmc);
+        const auto J = j.compute(make_dual_model(m1, d1, nder), make_dual_model(m2, d2, nder), split);
+        size_t o = 0;
+        for (const auto &m : J)
+            for (const auto &x : m) {
+                out[o] = x.v;
+                if (dout) for (int d = 0; d < nder; ++d) dout[o * nder + d] = x.d[d];
+                ++o;
+            }
+    }
+    API_END
+}
+
+int smcpp_host_prep_twopop(int n1, int n2, int a1, int a2, int n_hs, const double *hs, double polarization_error,
+                           int Kd, const double *ad, const double *sd, int K1, const double *pa1, const double *ps1,
+                           int K2, const double *pa2, const double *ps2, double split, double theta, double rho,
+                           double alpha, int K, const int *keys, double *pi, double *T, double *E) {
+    API_BEGIN
+    std::vector<double> hsv(hs, hs + n_hs);
+    smcpp_host::TwoPopPrep prep(n1, n2, a1, a2, hsv, polarization_error);
+    smcpp_host::ModelParamsT<double> d, p1, p2;
+    d.a.assign(ad, ad + Kd); d.s.assign(sd, sd + Kd);
+    p1.a.assign(pa1, pa1 + K1); p1.s.assign(ps1, ps1 + K1);
+    p2.a.assign(pa2, pa2 + K2); p2.s.assign(ps2, ps2 + K2);
+    std::vector<int> kv(keys, keys + (size_t)K * 6);
+    std::vector<double> piv, Tv, Ev;
+    prep.compute_t<double>(d, p1, p2, split, theta, rho, alpha, kv, K, piv, Tv, Ev);
+    const int M = n_hs - 1;
+    std::memcpy(pi, piv.data(), sizeof(double) * M);
+    std::memcpy(T, Tv.data(), sizeof(double) * M * M);
+    std::memcpy(E, Ev.data(), sizeof(double) * (size_t)K * M);
     API_END
 }
 

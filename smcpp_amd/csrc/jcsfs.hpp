@@ -1,0 +1,491 @@
+// Host-side preparation for two-population managers: the joint conditioned SFS and the two-population emission table.
+//
+// What it computes follows the reference's JointCSFS (src/jcsfs.cpp:83-420, include/jcsfs.h; the better documented
+// Python original is smcpp/jcsfs.py) and the generic-P emission assembly of NPopInferenceManager
+// (src/inference_manager.cpp:263-482, include/bin_key.h, include/marginalize_key.h, include/tensorslice.h).
+//
+// PARITY NOTE: the reference translation unit jcsfs.cpp includes GSL headers and GSL is not part of this image, so it
+// cannot be compiled here and the numbers of this file are NOT pinned against a reference build.  They are pinned
+// (tests/test_jcsfs.py) by the invariants the reference's own tests assert (test/unit/test_jcsfs.py: pop-1 and pop-2
+// marginals against raw_sfs), by exact identities (total branch length, symmetry of the two helper paths at the
+// split) and, for every ingredient that is shared with the one-population path (rate function, conditioned SFS,
+// shift/truncate), by the goldens of that path.
+//
+// Everything is templated on the scalar so the same code yields values (double) and forward-mode Jacobians (dual).
+#pragma once
+
+#include "nonsym_eig.hpp"
+#include "prep.hpp"
+
+namespace smcpp_host {
+
+// model seen from `shift` units back in time (common.cpp:63-78)
+template <typename S>
+inline ModelParamsT<S> shift_params(const ModelParamsT<S> &p, double shift) {
+    const int K = (int)p.s.size();
+    std::vector<double> cs(K + 1, 0.0);
+    for (int k = 0; k < K; ++k) cs[k + 1] = cs[k] + p.s[k];
+    cs[K] = INFINITY;
+    const int ip = (int)(std::upper_bound(cs.begin(), cs.end(), shift) - cs.begin()) - 1;
+    ModelParamsT<S> r;
+    r.s.assign(p.s.begin() + ip, p.s.end());
+    r.a.assign(p.a.begin() + ip, p.a.end());
+    r.s[0] = cs[ip + 1] - shift;
+    r.s.back() = 1.0;
+    return r;
+}
+
+// model cut at `tt` and crashed to size 1e-8 above it, so that nothing coalesces later (common.cpp:80-97)
+template <typename S>
+inline ModelParamsT<S> truncate_params(const ModelParamsT<S> &p, double tt) {
+    const int K = (int)p.s.size();
+    std::vector<double> cs(K + 1, 0.0);
+    for (int k = 0; k < K; ++k) cs[k + 1] = cs[k] + p.s[k];
+    cs[K] = INFINITY;
+    const int ip = (int)(std::upper_bound(cs.begin(), cs.end(), tt) - cs.begin()) - 1;
+    ModelParamsT<S> r;
+    r.s.assign(p.s.begin(), p.s.begin() + ip + 1);
+    r.a.assign(p.a.begin(), p.a.begin() + ip + 1);
+    r.s[ip] = tt - cs[ip];
+    r.s.push_back(1.0);
+    r.a.push_back(S(1e-8));
+    return r;
+}
+
+// exp(t * Q) of a (modified) Moran rate matrix through its eigensystem (jcsfs.h:38-58)
+struct MoranExp {
+    int dim = 0;
+    EigenSystem es;
+    MoranExp() {}
+    // plain Moran model on N lineages (moran_eigensystem.cpp:8-29)
+    static MoranExp plain(int N) {
+        std::vector<double> Q((size_t)(N + 1) * (N + 1), 0.0);
+        for (int i = 0; i <= N; ++i) {
+            double sm = 0.0;
+            const double b = 0.5 * i * (N - i);
+            if (i > 0) { Q[(size_t)i * (N + 1) + i - 1] = b; sm += b; }
+            if (i < N) { Q[(size_t)i * (N + 1) + i + 1] = b; sm += b; }
+            Q[(size_t)i * (N + 1) + i] = -sm;
+        }
+        return MoranExp(N + 1, Q);
+    }
+    // Moran model on N lineages next to `na` distinguished ones of which `a` are derived (moran_eigensystem.cpp:31-52)
+    static MoranExp modified(int N, int a, int na) {
+        std::vector<double> Q((size_t)(N + 1) * (N + 1), 0.0);
+        for (int i = 0; i <= N; ++i) {
+            double sm = 0.0;
+            if (i > 0) { const double b = (double)(na - a) * i + 0.5 * i * (N - i); Q[(size_t)i * (N + 1) + i - 1] = b; sm += b; }
+            if (i < N) { const double b = (double)a * (N - i) + 0.5 * i * (N - i); Q[(size_t)i * (N + 1) + i + 1] = b; sm += b; }
+            Q[(size_t)i * (N + 1) + i] = -sm;
+        }
+        return MoranExp(N + 1, Q);
+    }
+    template <typename S>
+    std::vector<S> expM(const S &t) const {
+        std::vector<S> eD(dim);
+        for (int j = 0; j < dim; ++j) eD[j] = m_exp(t * es.d[j]);
+        std::vector<S> out((size_t)dim * dim, S(0.0));
+        for (int i = 0; i < dim; ++i)
+            for (int j = 0; j < dim; ++j) {
+                const S pe = eD[j] * es.P[(size_t)i * dim + j];
+                for (int k = 0; k < dim; ++k) out[(size_t)i * dim + k] += pe * es.Pinv[(size_t)j * dim + k];
+            }
+        return out;
+    }
+
+private:
+    MoranExp(int d, const std::vector<double> &Q) : dim(d), es(eigensystem(d, Q)) {}
+};
+
+// fold a 3 x (n+1) conditioned SFS over the distinguished pair: entry k-1 = total weight of k derived among n+2
+// (jcsfs.cpp:57-69)
+template <typename S>
+inline std::vector<S> undistinguished_sfs(const std::vector<S> &csfs, int n) {
+    std::vector<S> ret(n + 1, S(0.0));
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < n + 1; ++b)
+            if (1 <= a + b && a + b < n + 2) ret[a + b - 1] += csfs[(size_t)a * (n + 1) + b];
+    return ret;
+}
+
+template <typename S>
+class JointCsfsT {
+public:
+    JointCsfsT(int n1, int n2, int a1, int a2, const std::vector<double> &hidden_states, int K = 10)
+        : n1(n1), n2(n2), a1(a1), a2(a2), hs(hidden_states), M((int)hidden_states.size() - 1), K(K) {
+        if (!((a1 == 2 && a2 == 0) || (a1 == 1 && a2 == 1))) throw std::runtime_error("unsupported jcsfs configuration");
+        d2 = n2 + 1; d1 = (a2 + 1) * d2; d0 = (n1 + 1) * d1;
+        if (a1 == 2) {
+            Mn1p1 = MoranExp::plain(n1 + 1);
+            Mn2 = MoranExp::plain(n2);
+            Mn10 = MoranExp::modified(n1, 0, 2);
+            Mn11 = MoranExp::modified(n1, 1, 2);
+            Mn12 = MoranExp::modified(n1, 2, 2);
+        } else {
+            Mn10 = MoranExp::modified(n1, 0, 1);
+            Mn11 = MoranExp::modified(n1, 1, 1);
+            Mn20 = MoranExp::modified(n2, 0, 1);
+            Mn21 = MoranExp::modified(n2, 1, 1);
+        }
+        // hypergeometric tables (jcsfs.cpp:19-55); scipy.stats.hypergeom.pmf(k, Mtot, n, N) in GSL argument order
+        hyp1.assign((size_t)(n1 + 1) * (n1 + n2 + 1), 0.0);
+        for (int nseg = 0; nseg <= n1 + n2; ++nseg)
+            for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1); ++np1)
+                hyp1[(size_t)np1 * (n1 + n2 + 1) + nseg] = OnePopPrep::hypergeom_pdf(np1, nseg, n1 + n2 - nseg, n1);
+        hyp2.assign((size_t)(n1 + 2) * (n1 + n2), 0.0);
+        for (int nseg = 1; nseg <= n1 + n2; ++nseg)
+            for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1 + 1); ++np1)
+                hyp2[(size_t)np1 * (n1 + n2) + nseg - 1] = OnePopPrep::hypergeom_pdf(np1, nseg, n1 + n2 + 1 - nseg, n1 + 1);
+    }
+
+    int tensor_size() const { return (a1 + 1) * d0; }
+
+    // per hidden state the tensor [(a1+1), (n1+1), (a2+1), (n2+1)] flattened row-major (jcsfs.h:83-87)
+    std::vector<std::vector<S>> compute(const ModelParamsT<S> &p1, const ModelParamsT<S> &p2, double split_) {
+        params1 = p1; params2 = p2; split = split_;
+        J.assign(M, std::vector<S>((size_t)tensor_size(), S(0.0)));
+        if (a1 == 1) apart();
+        else together();
+        for (int m = 0; m < M; ++m) {
+            for (S &x : J[m])
+                if (!(sval(x) > 1e-20)) x = S(1e-20);                 // floor; the derivative of a floored entry is zero
+            at(m, 0, 0, 0, 0) = S(0.0);                                // non-segregating configurations carry no mass
+            at(m, a1, n1, a2, n2) = S(0.0);
+        }
+        return J;
+    }
+
+private:
+    S &at(int m, int i, int j, int k, int l) { return J[m][(size_t)i * d0 + (size_t)j * d1 + (size_t)k * d2 + l]; }
+    std::vector<std::vector<S>> csfs_of(int n, const RateFunctionT<S> &eta, bool below_only = false) const {
+        return conditioned_sfs<S>(eta, *csfs_tables(n), below_only);
+    }
+    double h1(int np1, int nseg) const { return hyp1[(size_t)np1 * (n1 + n2 + 1) + nseg]; }
+    double h2(int np1, int nseg) const { return hyp2[(size_t)np1 * (n1 + n2) + nseg - 1]; }
+
+    // ---- both distinguished lineages in population 1 (jcsfs.cpp:371-420) ----
+    void together() {
+        eta1.reset(new RateFunctionT<S>(params1, std::vector<double>{split - 1e-6, split + 1e-6}));
+        const RateFunctionT<S> eta2(params2, std::vector<double>());
+        Rts1 = eta1->R(split);
+        Rts2 = eta2.R(split);
+        eMn1[0] = Mn10.expM(Rts1);
+        eMn1[1] = Mn11.expM(Rts1);
+        eMn1[2].assign(eMn1[0].rbegin(), eMn1[0].rend());              // rows and columns reversed
+        eMn2 = Mn2.expM(Rts2);
+        for (int m = 0; m < M; ++m) {
+            const double t1 = hs[m], t2 = hs[m + 1];
+            if (t1 < t2 && t2 <= split) tau_below_split(m, t1, t2, S(1.0));
+            else if (split <= t1 && t1 < t2) tau_above_split(m, t1, t2, S(1.0));
+            else {
+                const S e1 = m_exp(-eta1->R(t1));
+                const S e2 = std::isinf(t2) ? S(0.0) : m_exp(-eta1->R(t2));
+                const S w = (m_exp(-Rts1) - e2) / (e1 - e2);
+                tau_below_split(m, t1, split, 1.0 - w);
+                tau_above_split(m, split, t2, w);
+            }
+            // population 2 below the split: no distinguished lineage there, so its private branches are the folded
+            // truncated SFS
+            if (n2 == 1) at(m, 0, 0, 0, 1) += split;
+            if (n2 > 1) {
+                const RateFunctionT<S> eta2_trunc(truncate_params(params2, split), std::vector<double>{0.0, INFINITY});
+                const std::vector<S> r = undistinguished_sfs(csfs_of(n2 - 2, eta2_trunc)[0], n2 - 2);
+                S remain(0.0);
+                for (int i = 0; i < n2 - 1; ++i) {
+                    at(m, 0, 0, 0, i + 1) += r[i];
+                    remain += r[i] * ((double)(i + 1) / (double)n2);
+                }
+                remain -= S(split);
+                at(m, 0, 0, 0, n2) -= remain;
+            }
+        }
+    }
+
+    // distinguished pair coalesces in [t1, t2) with t2 <= split (jcsfs.cpp:83-163)
+    void tau_below_split(int m, double t1, double t2, const S &weight) {
+        const RateFunctionT<S> eta(params1, std::vector<double>());
+        const RateFunctionT<S> eta1_trunc(truncate_params(params1, split), std::vector<double>{t1, t2});
+        const std::vector<S> trunc = csfs_of(n1, eta1_trunc)[0];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j <= n1; ++j)
+                if (sval(trunc[(size_t)i * (n1 + 1) + j]) > 0) at(m, i, j, 0, 0) = weight * trunc[(size_t)i * (n1 + 1) + j];
+        const std::vector<S> tsfs = undistinguished_sfs(trunc, n1);
+        S Et(0.0);
+        for (int k = 0; k <= n1; ++k) Et += tsfs[k] * ((double)(k + 1) / (double)(n1 + 2));
+        at(m, 2, n1, 0, 0) = (split - Et) * weight;
+        // above the split: SFS of the n1 + n2 + 1 lineages there, carried down through the Moran models
+        const RateFunctionT<S> eta1_shift(shift_params(params1, split), std::vector<double>{0.0, INFINITY});
+        const std::vector<S> sfs_above = undistinguished_sfs(csfs_of(n1 + n2 - 1, eta1_shift)[0], n1 + n2 - 1);
+        const int r = n1 + 2, c = n1 + 1;
+        std::vector<S> avg0((size_t)r * c, S(0.0)), avg2((size_t)r * c, S(0.0));
+        std::mt19937 gen;                                               // default seed, re-created per call (quirk 14)
+        for (int k = 0; k < K; ++k) {
+            const S t = eta.random_time(t1, t2, gen);
+            const S Rt = eta.R_at(t);
+            const std::vector<S> A = Mn1p1.expM(Rts1 - Rt);           // r x r
+            const std::vector<S> B = Mn10.expM(Rt), C = Mn12.expM(Rt); // c x c
+            for (int i = 0; i < r; ++i)
+                for (int q = 0; q < c; ++q) {
+                    // (A diag(S0)).leftCols(c) and (A diag(S2)).rightCols(c)
+                    const S a0 = A[(size_t)i * r + q] * (1.0 - (double)q / (double)(n1 + 1));
+                    const S a2 = A[(size_t)i * r + q + 1] * ((double)(q + 1) / (double)(n1 + 1));
+                    for (int j = 0; j < c; ++j) {
+                        avg0[(size_t)i * c + j] += a0 * B[(size_t)q * c + j];
+                        avg2[(size_t)i * c + j] += a2 * C[(size_t)q * c + j];
+                    }
+                }
+        }
+        for (S &x : avg0) x /= (double)K;
+        for (S &x : avg2) x /= (double)K;
+        for (int b1 = 0; b1 <= n1; ++b1)
+            for (int b2 = 0; b2 <= n2; ++b2)
+                for (int nseg = 1; nseg <= n1 + n2; ++nseg)
+                    for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1 + 1); ++np1) {
+                        const int np2 = nseg - np1;
+                        S x = sfs_above[nseg - 1];
+                        x *= eMn2[(size_t)np2 * (n2 + 1) + b2];
+                        x *= h2(np1, nseg);
+                        x *= weight;
+                        at(m, 0, b1, 0, b2) += x * avg0[(size_t)np1 * c + b1];
+                        at(m, 2, b1, 0, b2) += x * avg2[(size_t)np1 * c + b1];
+                    }
+    }
+
+    // distinguished pair coalesces in [t1, t2) with split <= t1 (jcsfs.cpp:166-216)
+    void tau_above_split(int m, double t1, double t2, const S &weight) {
+        const RateFunctionT<S> shifted(shift_params(params1, split), std::vector<double>{t1 - split, t2 - split});
+        const std::vector<S> rsfs = csfs_of(n1 + n2, shifted)[0];      // 3 x (n1+n2+1)
+        const int w = n1 + n2 + 1;
+        for (int b1 = 0; b1 <= n1; ++b1)
+            for (int b2 = 0; b2 <= n2; ++b2)
+                for (int nseg = 0; nseg <= n1 + n2; ++nseg)
+                    for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1); ++np1) {
+                        const int np2 = nseg - np1;
+                        const double h = h1(np1, nseg);
+                        for (int i = 0; i < 3; ++i) {
+                            S x = rsfs[(size_t)i * w + nseg];
+                            x *= eMn1[i][(size_t)np1 * (n1 + 1) + b1];
+                            x *= eMn2[(size_t)np2 * (n2 + 1) + b2];
+                            x *= h;
+                            x *= weight;
+                            at(m, i, b1, 0, b2) += x;
+                        }
+                    }
+        // population 1 below the split: the below-part of a CSFS conditioned on coalescence right at the split
+        const std::vector<S> below = csfs_of(n1, *eta1, true)[0];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j <= n1; ++j)
+                if (sval(below[(size_t)i * (n1 + 1) + j]) > 0) at(m, i, j, 0, 0) += weight * below[(size_t)i * (n1 + 1) + j];
+    }
+
+    // ---- one distinguished lineage in each population (jcsfs.cpp:256-366) ----
+    void apart() {
+        std::vector<double> times{0.0};
+        for (int m = 1; m < M; ++m)
+            if (hs[m] > split) times.push_back(hs[m] - split);
+        times.push_back(INFINITY);
+        const RateFunctionT<S> shifted(shift_params(params1, split), times);
+        const std::vector<std::vector<S>> at_split = csfs_of(n1 + n2, shifted);
+        const S R1 = RateFunctionT<S>(params1, std::vector<double>()).R(split);
+        const S R2 = RateFunctionT<S>(params2, std::vector<double>()).R(split);
+        const std::vector<S> T10 = Mn10.expM(R1), T11 = Mn11.expM(R1), T20 = Mn20.expM(R2), T21 = Mn21.expM(R2);
+        const int w = n1 + n2 + 1;
+        int i = 0;
+        for (int m = 0; m < M; ++m) {
+            if (hs[m + 1] <= split) continue;       // the two lineages cannot meet below the split
+            const std::vector<S> &cs = at_split[i++];
+            for (int b1 = 0; b1 <= n1; ++b1)
+                for (int b2 = 0; b2 <= n2; ++b2)
+                    for (int nseg = 0; nseg <= n1 + n2; ++nseg)
+                        for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1); ++np1) {
+                            const int np2 = nseg - np1;
+                            const double h = h1(np1, nseg);
+                            const S &t10 = T10[(size_t)np1 * (n1 + 1) + b1], &t11 = T11[(size_t)np1 * (n1 + 1) + b1];
+                            const S &t20 = T20[(size_t)np2 * (n2 + 1) + b2], &t21 = T21[(size_t)np2 * (n2 + 1) + b2];
+                            at(m, 1, b1, 1, b2) += h * cs[(size_t)2 * w + nseg] * t11 * t21;
+                            at(m, 1, b1, 0, b2) += 0.5 * h * cs[(size_t)1 * w + nseg] * t11 * t20;
+                            at(m, 0, b1, 1, b2) += 0.5 * h * cs[(size_t)1 * w + nseg] * t10 * t21;
+                            at(m, 0, b1, 0, b2) += h * cs[(size_t)0 * w + nseg] * t10 * t20;
+                        }
+        }
+        if (split == 0.0) return;
+        // private branches of each population below the split, the same for every hidden state
+        for (int pop = 0; pop < 2; ++pop) {
+            const ModelParamsT<S> &pp = pop == 0 ? params1 : params2;
+            const int ni = pop == 0 ? n1 : n2;
+            const RateFunctionT<S> eta_trunc(truncate_params(pp, split), std::vector<double>{0.0, INFINITY});
+            std::vector<S> r;
+            if (ni > 0) r = undistinguished_sfs(csfs_of(ni - 1, eta_trunc)[0], ni - 1);
+            for (int k = 1; k <= ni; ++k) {
+                const double fac = (double)k / (double)(ni + 1);
+                const S x1 = (1.0 - fac) * r[k - 1], x2 = fac * r[k - 1];
+                for (int m = 0; m < M; ++m) {
+                    if (pop == 0) { at(m, 0, k, 0, 0) += x1; at(m, 1, k - 1, 0, 0) += x2; }
+                    else { at(m, 0, 0, 0, k) += x1; at(m, 0, 0, 1, k - 1) += x2; }
+                }
+            }
+            S remain(0.0);
+            for (int k = 1; k <= ni; ++k) remain += r[k - 1] * (double)k;
+            remain /= (double)(ni + 1);
+            remain -= S(split);
+            for (int m = 0; m < M; ++m) {
+                if (pop == 0) at(m, 1, ni, 0, 0) -= remain;
+                else at(m, 0, 0, 1, ni) -= remain;
+            }
+        }
+    }
+
+    const int n1, n2, a1, a2;
+    const std::vector<double> hs;
+    const int M, K;
+    int d0, d1, d2;
+    MoranExp Mn1p1, Mn2, Mn10, Mn11, Mn12, Mn20, Mn21;
+    std::vector<double> hyp1, hyp2;
+    // state of one compute()
+    ModelParamsT<S> params1, params2;
+    double split = 0.0;
+    std::unique_ptr<RateFunctionT<S>> eta1;
+    S Rts1, Rts2;
+    std::array<std::vector<S>, 3> eMn1;
+    std::vector<S> eMn2;
+    std::vector<std::vector<S>> J;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// two-population preparation: pi / transition from the distinguished model, emission table from the joint CSFS
+// (TwoPopInferenceManager::setParams inference_manager.cpp:542-550 + the generic-P do_dirty_work)
+// ---------------------------------------------------------------------------------------------------------------
+class TwoPopPrep {
+public:
+    TwoPopPrep(int n1, int n2, int a1, int a2, const std::vector<double> &hs, double polarization_error, int K = 10)
+        : hs_(hs), pol_(polarization_error), K_(K) {
+        if (a1 + a2 != 2) throw std::runtime_error("configuration not supported");
+        if (a1 == 0 && a2 == 2) throw std::runtime_error("(0,2) not supported");
+        n_[0] = n1; n_[1] = n2; na_[0] = a1; na_[1] = a2;
+    }
+
+    typedef std::array<int, 6> Key;
+
+    // raw joint CSFS per hidden state (what `joint_csfs` of smcpp/_smcpp.pyx:416-437 returns)
+    template <typename S>
+    std::vector<std::vector<S>> jcsfs(const ModelParamsT<S> &p1, const ModelParamsT<S> &p2, double split) const {
+        JointCsfsT<S> j(n_[0], n_[1], na_[0], na_[1], hs_, K_);
+        return j.compute(p1, p2, split);
+    }
+
+    // keys [K][6]; outputs pi [M], T [M*M], E [K*M]
+    template <typename S>
+    void compute_t(const ModelParamsT<S> &dist, const ModelParamsT<S> &p1, const ModelParamsT<S> &p2, double split,
+                   double theta, double rho, double alpha, const std::vector<int> &keys, int K, std::vector<S> &pi,
+                   std::vector<S> &T, std::vector<S> &E) const {
+        RateFunctionT<S> eta(dist, hs_);
+        const int M = (int)hs_.size() - 1;
+        pi.assign(M, S(0.0));
+        for (int m = 0; m < M - 1; ++m) pi[m] = m_exp(-eta.R(hs_[m])) - m_exp(-eta.R(hs_[m + 1]));
+        pi[M - 1] = m_exp(-eta.R(hs_[M - 1]));
+        S ps(0.0);
+        for (S &x : pi) { if (sval(x) < 1e-20) x = S(1e-20); ps += x; }
+        for (S &x : pi) x /= ps;
+        T = compute_transition<S>(eta, rho);
+        std::vector<std::vector<S>> sfs = jcsfs<S>(p1, p2, split);
+        incorporate_theta<S>(sfs, theta);
+        const std::vector<S> avg_ct = eta.average_coal_times();
+        std::vector<S> e2((size_t)M * 2, S(0.0));
+        for (int m = 0; m < M; ++m) {
+            if (std::isnan((double)sval(avg_ct[m]))) { e2[2 * m] = S(1e-20); e2[2 * m + 1] = S(1e-20); }
+            else {
+                const S le = -2.0 * alpha * theta * avg_ct[m];
+                e2[2 * m] = m_exp(le);
+                e2[2 * m + 1] = -m_expm1(le);
+            }
+        }
+        const int d2 = n_[1] + 1, d1 = (na_[1] + 1) * d2, d0 = (n_[0] + 1) * d1;
+        E.assign((size_t)K * M, S(0.0));
+        for (int k = 0; k < K; ++k) {
+            Key bk;
+            for (int q = 0; q < 6; ++q) bk[q] = keys[(size_t)6 * k + q];
+            bool reduced = true, miss = true;
+            int amin = 1 << 30, asum = 0;
+            for (int p = 0; p < 2; ++p) {
+                reduced &= bk[3 * p + 2] == 0;
+                if (na_[p] > 0) miss &= bk[3 * p] == -1;
+                amin = std::min(amin, bk[3 * p]);
+                asum += bk[3 * p];
+            }
+            S *e = &E[(size_t)k * M];
+            if (reduced && (miss || amin >= 0)) {
+                for (int m = 0; m < M; ++m) e[m] = miss ? S(1.0) : e2[2 * m + (asum % 2)];
+            } else {
+                for (const auto &p : bins_for(bk)) {
+                    const size_t idx = (size_t)p.first[0] * d0 + (size_t)p.first[1] * d1 + (size_t)p.first[2] * d2 + p.first[3];
+                    for (int m = 0; m < M; ++m) e[m] += p.second * sfs[m][idx];
+                }
+            }
+            double mx = sval(e[0]), mn = sval(e[0]);
+            for (int m = 1; m < M; ++m) { mx = std::max(mx, (double)sval(e[m])); mn = std::min(mn, (double)sval(e[m])); }
+            if (mx > 1.0 || mn <= 0.0) throw std::runtime_error("probability vector not in [0, 1]");
+        }
+    }
+
+    // construct_bins for one observed key (inference_manager.cpp:329-386 with P = 2): weights over (a1, b1, a2, b2)
+    std::map<std::array<int, 4>, double> bins_for(const Key &bk) const {
+        auto is_mono = [&](const Key &k) {
+            for (int p = 0; p < 2; ++p)
+                if (k[3 * p] != na_[p] || k[3 * p + 1] != k[3 * p + 2]) return false;
+            return true;
+        };
+        // bin_key<2> with cutoff 1.0: a == -1 expands over 0..na(p); b/nb > 1 never holds
+        std::vector<std::array<int, 3>> side[2];
+        for (int p = 0; p < 2; ++p) {
+            const int a = bk[3 * p], b = bk[3 * p + 1], nb = bk[3 * p + 2];
+            if (a == -1) for (int aa = 0; aa <= na_[p]; ++aa) side[p].push_back({aa, b, nb});
+            else side[p].push_back({a, b, nb});
+        }
+        std::map<Key, double> m;
+        for (const auto &k0 : side[0])
+            for (const auto &k1 : side[1]) {
+                // marginalize_key<2>: lift each population from nb to n observed, independent hypergeometric weights
+                std::vector<std::pair<std::array<int, 3>, double>> lift[2];
+                const std::array<int, 3> kk[2] = {k0, k1};
+                for (int p = 0; p < 2; ++p) {
+                    std::map<std::array<int, 3>, double> acc;
+                    for (int x = kk[p][1]; x <= n_[p] + kk[p][1] - kk[p][2]; ++x)
+                        acc[{kk[p][0], x, n_[p]}] += OnePopPrep::hypergeom_pdf(kk[p][1], x, n_[p] - x, kk[p][2]);
+                    lift[p].assign(acc.begin(), acc.end());
+                }
+                for (const auto &l0 : lift[0])
+                    for (const auto &l1 : lift[1]) {
+                        Key mbk{l0.first[0], l0.first[1], l0.first[2], l1.first[0], l1.first[1], l1.first[2]};
+                        const double pr = l0.second * l1.second;
+                        if (is_mono(mbk)) mbk = Key{0, 0, mbk[2], 0, 0, mbk[5]};
+                        m[mbk] += (1.0 - pol_) * pr;
+                        Key fk;
+                        for (int p = 0; p < 2; ++p) {
+                            fk[3 * p] = na_[p] - mbk[3 * p];
+                            fk[3 * p + 1] = mbk[3 * p + 2] - mbk[3 * p + 1];
+                            fk[3 * p + 2] = mbk[3 * p + 2];
+                        }
+                        m[fk] += pol_ * pr;
+                    }
+            }
+        double s = 0.0;
+        std::map<Key, double> m2;
+        for (const auto &p : m) {
+            if (p.second <= 0 || is_mono(p.first)) continue;
+            m2[p.first] = p.second;
+            s += p.second;
+        }
+        if (s <= 0) throw std::runtime_error("s<=0");
+        std::map<std::array<int, 4>, double> out;
+        for (const auto &p : m2) out[{p.first[0], p.first[1], p.first[3], p.first[4]}] += p.second / s;
+        return out;
+    }
+
+private:
+    int n_[2], na_[2];
+    std::vector<double> hs_;
+    double pol_;
+    int K_;
+};
+
+}  // namespace smcpp_host

@@ -363,6 +363,18 @@ inline EigenSystem eigensystem(int n, const std::vector<double> &A) {
         es.P = {1.0}; es.Pinv = {1.0}; es.d = {A[0]}; es.scale = std::fabs(A[0]); es.max_imag = 0.0;
         return es;
     }
+    {
+        // the zero matrix (e.g. the Moran rate matrix of a single lineage) has no direction for the back-substitution
+        // to normalise: every vector is an eigenvector, take the identity
+        double amax = 0.0;
+        for (double x : A) amax = std::max(amax, std::fabs(x));
+        if (amax == 0.0) {
+            es.P.assign((size_t)n * n, 0.0);
+            for (int i = 0; i < n; ++i) es.P[(size_t)i * n + i] = 1.0;
+            es.Pinv = es.P; es.d.assign(n, 0.0); es.scale = 0.0; es.max_imag = 0.0;
+            return es;
+        }
+    }
     detail::orthes(n, H, V);
     detail::hqr2(n, H, V, wr, wi);
     es.d = wr;

@@ -407,6 +407,13 @@ public:
         return Rrng[ip] + ada[ip] * (t - *ti);
     }
 
+    // R at a time that itself carries derivatives (jcsfs.cpp:127: R of a random coalescence time)
+    S R_at(const S &t) const {
+        auto ti = std::upper_bound(ts.begin(), ts.end(), (double)sval(t)) - 1;
+        const int ip = (int)(ti - ts.begin());
+        return Rrng[ip] + ada[ip] * (t - *ti);
+    }
+
     // inverse of the cumulative hazard (piecewise_constant_rate_function.cpp:415-420)
     S Rinv(const S &y) const {
         int ip = 0;
@@ -419,6 +426,9 @@ public:
     // (piecewise_constant_rate_function.cpp:337-368); one std::mt19937 per call, seeded by the caller
     S random_time(double a, double b, unsigned long long seed) const {
         std::mt19937 gen(seed);
+        return random_time(a, b, gen);
+    }
+    S random_time(double a, double b, std::mt19937 &gen) const {
         const double unif = std::uniform_real_distribution<double>{0.0, 1.0}(gen);
         const S Ra = R(a);
         if (std::isinf(b)) return Rinv(Ra - std::log1p(-unif));

@@ -59,3 +59,117 @@ class PiecewiseModel(Observable):
     def __setitem__(self, it, x):
         self.a[it] = x
         self.update_observers("model update")
+
+
+class _Pieces:
+    """Plain (a, s) view handed to the managers by `TwoPopulationModel.for_pop`; `seeds` are the derivative seeds of
+    its pieces in the joint direction space of the two-population model (None when nothing is differentiable)."""
+
+    def __init__(self, a, s, seeds=None):
+        self.a = np.asarray(a, dtype=np.float64)
+        self.s = np.asarray(s, dtype=np.float64)
+        self._seeds = seeds
+
+    def stepwise_values(self):
+        return self.a
+
+    def derivative_seeds(self):
+        return self._seeds
+
+
+class TwoPopulationModel(Observable):
+    """Mirror of `SMCTwoPopulationModel` (smcpp/model.py:259-333) for piecewise-constant populations: population 1's
+    history `model1`, population 2's private history `model2` below (more recent than) `split`; above the split both
+    follow `model1`.  `for_pop(pid)` returns what `PyTwoPopInferenceManager.update` (smcpp/_smcpp.pyx:353-368) needs:
+    pid of population 1 -> model1; pid of population 2 -> model2 up to the split followed by model1; `None` -> the
+    distinguished model of a manager whose two distinguished lineages sit in different populations (no coalescence
+    before the split: an infinite first piece of length `split`, then model1)."""
+    NPOP = 2
+
+    def __init__(self, model1, model2, split):
+        super().__init__()
+        self.model1, self.model2 = model1, model2
+        self._split = float(split)
+        model1.register(self)
+        model2.register(self)
+
+    @property
+    def pids(self):
+        return [self.model1.pid, self.model2.pid]
+
+    @property
+    def N0(self):
+        return self.model1.N0
+
+    @property
+    def split(self):
+        return self._split
+
+    @split.setter
+    def split(self, x):
+        self._split = float(x)
+        self.update_observers("model update")
+
+    def update(self, message, *args, **kwargs):
+        self.update_observers("model update")
+
+    @property
+    def differentiable(self):
+        return bool(self.model1.differentiable or self.model2.differentiable)
+
+    @property
+    def dlist(self):
+        return list(range(len(self.model1.a) + len(self.model2.a))) if self.differentiable else []
+
+    def _seed_rows(self, which, idx):
+        """Rows of the joint seed matrix [K1 + K2 directions] for pieces `idx` of model `which` (0 or 1)."""
+        if not self.differentiable:
+            return None
+        K1, K2 = len(self.model1.a), len(self.model2.a)
+        out = np.zeros((len(idx), K1 + K2))
+        m = (self.model1, self.model2)[which]
+        if m.differentiable:
+            for r, k in enumerate(idx):
+                out[r, k + (K1 if which else 0)] = 1.0
+        return out
+
+    @staticmethod
+    def _cut(m, split):
+        """Piece boundaries of `m` with the split inserted: (cs with a final inf, index of the split in it)."""
+        cs = np.concatenate([[0.0], np.cumsum(m.s)])
+        cs[-1] = np.inf
+        ip = int(np.searchsorted(cs, split))
+        return np.insert(cs, ip, split), ip
+
+    def for_pop(self, pid):
+        m1, m2, split = self.model1, self.model2, self._split
+        if pid is None:
+            cs, ip = self._cut(m1, split)
+            sp = np.diff(cs)
+            sp[-1] = 1.0
+            s = sp[ip - 1:].copy()
+            s[0] = split
+            idx = list(range(ip - 1, len(m1.a)))
+            a = np.insert(np.asarray(m1.a, dtype=np.float64)[ip - 1:], 0, np.inf)
+            seeds = self._seed_rows(0, idx)
+            if seeds is not None:
+                seeds = np.vstack([np.zeros((1, seeds.shape[1])), seeds])
+            return _Pieces(a, s, seeds)
+        i = self.pids.index(pid)
+        if i == 0:
+            return _Pieces(m1.a, m1.s, self._seed_rows(0, list(range(len(m1.a)))))
+        # population 2: its own pieces below the split, population 1's above it
+        parts = []
+        for which, m in ((1, m2), (0, m1)):
+            cs, ip = self._cut(m, split)
+            sp = np.diff(cs)
+            sp[-1] = 1.0
+            ap_idx = list(np.insert(np.arange(len(m.a)), ip, ip - 1))      # the piece containing the split is cut in two
+            parts.append((which, sp, ap_idx, ip))
+        (w2, sp2, idx2, ip2), (w1, sp1, idx1, ip1) = parts
+        s = np.concatenate([sp2[:ip2], sp1[ip1:]])
+        a = np.concatenate([np.asarray(m2.a, dtype=np.float64)[idx2[:ip2]], np.asarray(m1.a, dtype=np.float64)[idx1[ip1:]]])
+        seeds = None
+        if self.differentiable:
+            seeds = np.vstack([self._seed_rows(1, idx2[:ip2]), self._seed_rows(0, idx1[ip1:])])
+        return _Pieces(a, s, seeds)

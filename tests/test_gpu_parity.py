@@ -234,3 +234,52 @@ def test_em_iterations_increase_the_likelihood():
     assert np.all(np.diff(ll) >= -1e-6 * np.abs(ll[:-1])), ll
     assert ll[-1] > ll[0] + 1e-3
     assert np.all(model.a > 0)
+
+
+@pytest.mark.parametrize("a1,a2,M,split", [(2, 0, 24, 0.3), (1, 1, 24, 0.005), (1, 1, 1, 0.3)])
+def test_two_population_model_path(a1, a2, M, split):
+    """`PyTwoPopInferenceManager` driven the reference's way (im.model = two-population model; SURVEY.md config C4
+    shape): the engine prepares pi / T from the distinguished model and the emission table from its JointCSFS; the
+    E-step on those parameters must equal the C restatement of hmm.cpp fed with the same parameters (6-int keys)."""
+    from oracle import oracle
+    from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel, TwoPopulationModel
+    n1, n2 = 6, 5
+    a, s = synth.model_pieces()
+    m1 = PiecewiseModel(a, s, 1e4, pid="pop1")
+    m2 = PiecewiseModel(1.5 + 0.5 * np.cos(np.arange(8)), s[:8], 1e4, pid="pop2")
+    contigs = []
+    for ci, L in enumerate([400_000, 150_000]):
+        obs = synth.synth_contig_twopop(3 + ci, L, n1, n2).copy()
+        if a1 == 1:                               # one distinguished lineage per population: a2 in {0, 1}, missing together
+            nm = obs[:, 1] >= 0
+            obs[nm, 4] = (obs[nm, 2] + obs[nm, 6] + obs[nm, 0]) % 2
+            obs[~nm, 4] = -1
+        contigs.append(np.ascontiguousarray(obs, dtype=np.int32))
+    hs = synth.hidden_states(M)
+    im = _smcpp.PyTwoPopInferenceManager(n1, n2, a1, a2, contigs, hs, ("pop1", "pop2"), 0.5)
+    tm = TwoPopulationModel(m1, m2, split)
+    im.model = tm
+    im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0
+    im.E_step()
+    pi, T = im.pi, im.transition
+    keys = im.keys
+    ep = im.emission_probs
+    Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
+    assert np.all(np.isfinite(T)) and np.all(Etab > 0) and np.all(Etab <= 1)
+    lls = im.logliks()
+    xs, gss = im.xisums, im.gamma_sums
+    for c, ob in enumerate(contigs):
+        o = oracle.estep(pi, T, keys, Etab, ob)
+        assert abs(lls[c] - o["loglik"]) <= LL_TOL * abs(o["loglik"])
+        assert rel_err(xs[c], o["xisum"]) <= STAT_TOL
+        for k, v in o["gamma_sums"].items():
+            assert np.max(np.abs(gss[c][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300)
+    # the split is a parameter: moving it changes the likelihood, moving it back restores it bit for bit
+    ll0 = im.loglik()
+    tm.split = split * 1.5
+    im.E_step()
+    assert abs(im.loglik() - ll0) > 1e-9 * abs(ll0)
+    tm.split = split
+    im.E_step()
+    assert abs(im.loglik() - ll0) <= 1e-12 * abs(ll0)

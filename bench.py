@@ -5,7 +5,7 @@ One "step" = one eval of SURVEY.md §8(d): parameters marked dirty -> E-step (ho
 forward/backward chains + sufficient statistics on the GPU) -> loglik, over this rank's contig(s), with the
 observation arrays already resident in HBM (they are uploaded when the inference manager is constructed).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c5] [--no-cpu] [--chunk ROWS]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c4|c5] [--no-cpu] [--chunk ROWS]
 
 N > 1: launched by torch.distributed.run, one rank per GPU; every rank owns one synthetic 100 Mbp contig (weak
 scaling, contigs are independent HMMs) and the ranks exchange ONE all-reduce(sum, fp64) of the packed
@@ -34,6 +34,9 @@ WORKLOADS = {
     "headline": (64, 20, "params_M64_n20.npz", "1 synthetic 100 Mbp contig per GPU, M=64, n=20 (BASELINE.json metric shape)"),
     "c2": (32, 10, "params_M32_n10.npz", "1 synthetic 100 Mbp contig per GPU, M=32, n=10 (configs[1])"),
     "c5": (256, 50, "params_M256_n50.npz", "1 synthetic 100 Mbp contig per GPU, M=256, n=50 (configs[4])"),
+    # two populations, both distinguished lineages in population 1, split 0.5; the parameters come
+    # from the engine's own JointCSFS preparation, computed once outside the timed region like the fixtures above
+    "c4": (48, 10, None, "1 synthetic two-population 100 Mbp contig per GPU, M=48, n1=n2=10, a=(2,0), split=0.5 (configs[3])"),
 }
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector = matrix peak (AMD spec)
@@ -80,10 +83,25 @@ def main():
 
     from smcpp_amd import _smcpp, synth
     M, n, fixture, desc = WORKLOADS[args.workload]
-    par = np.load(os.path.join(ROOT, "tests", "golden", fixture))
     length_bp = int(args.length_mbp * 1e6)
-    obs = synth.synth_contig(rank, length_bp, n)         # contig index = rank: independent contigs, weak scaling
-    im = _smcpp.PyOnePopInferenceManager(n, [obs], par["hs"], ("pop1",), float(par["pol"]), device=local_rank)
+    if args.workload == "c4":
+        from smcpp_amd import _engine
+        from smcpp_amd.model import PiecewiseModel, TwoPopulationModel
+        obs = synth.synth_contig_twopop(rank, length_bp, n, n)
+        hs = synth.hidden_states(M)
+        a, s_ = synth.model_pieces()
+        tm = TwoPopulationModel(PiecewiseModel(a, s_, 1e4, pid="pop1"),
+                                PiecewiseModel(1.5 + 0.5 * np.cos(np.arange(8)), s_[:8], 1e4, pid="pop2"), 0.5)
+        keys4 = np.unique(obs[:, 1:], axis=0).astype(np.int32)
+        d, p1, p2 = tm.for_pop("pop1"), tm.for_pop("pop1"), tm.for_pop("pop2")
+        pi4, T4, E4 = _engine.host_prep_twopop(n, n, 2, 0, hs, 0.5, (d.a, d.s), (p1.a, p1.s), (p2.a, p2.s), tm.split,
+                                               synth.THETA, synth.RHO, synth.ALPHA, keys4)
+        par = dict(pi=pi4, T=T4, keys=keys4, E=E4, hs=hs, pol=0.5, theta=synth.THETA, rho=synth.RHO, alpha=synth.ALPHA)
+        im = _smcpp.PyTwoPopInferenceManager(n, n, 2, 0, [obs], hs, ("pop1", "pop2"), 0.5, device=local_rank)
+    else:
+        par = np.load(os.path.join(ROOT, "tests", "golden", fixture))
+        obs = synth.synth_contig(rank, length_bp, n)         # contig index = rank: independent contigs, weak scaling
+        im = _smcpp.PyOnePopInferenceManager(n, [obs], par["hs"], ("pop1",), float(par["pol"]), device=local_rank)
     im.theta = float(par["theta"]); im.rho = float(par["rho"]); im.alpha = float(par["alpha"])
     if args.chunk or args.eps_alpha or args.eps_beta:
         im.set_chunking(args.chunk, args.eps_alpha, args.eps_beta)

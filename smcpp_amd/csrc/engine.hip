@@ -51,6 +51,29 @@ struct OmpInit {
 
 namespace {
 
+// Pinned host staging for the per-E-step parameter upload: pageable hipMemcpyAsync is staged synchronously by the
+// runtime (~10 us per call, ~20 calls per E-step); from pinned memory the copies are plain DMA enqueues and the host
+// does not have to wait for them before launching the chains.  Reset at the start of every upload; the previous
+// E-step has synchronised its stream by then.
+struct PinnedArena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+    void reset(size_t need) {
+        off = 0;
+        if (need <= cap) return;
+        if (base) (void)hipHostFree(base);
+        cap = need + need / 4 + 4096;
+        HIPCHK(hipHostMalloc((void **)&base, cap, hipHostMallocDefault));
+    }
+    void *take(size_t bytes) {
+        const size_t o = (off + 255) & ~(size_t)255;
+        if (o + bytes > cap) throw std::runtime_error("internal: pinned staging arena too small");
+        off = o + bytes;
+        return base + o;
+    }
+    ~PinnedArena() { if (base) (void)hipHostFree(base); }
+};
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -69,6 +92,13 @@ struct DevBuf {
     void upload(const std::vector<T> &h, hipStream_t s) {
         alloc(h.size());
         if (!h.empty()) HIPCHK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void upload_staged(const std::vector<T> &h, PinnedArena &ar, hipStream_t s) {
+        alloc(h.size());
+        if (h.empty()) return;
+        void *q = ar.take(h.size() * sizeof(T));
+        std::memcpy(q, h.data(), h.size() * sizeof(T));
+        HIPCHK(hipMemcpyAsync(p, q, h.size() * sizeof(T), hipMemcpyHostToDevice, s));
     }
     void zero(hipStream_t s) {
         if (n) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s));
@@ -122,7 +152,7 @@ struct smcpp_im {
     // ---- device -----------------------------------------------------------------------------------------------
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: backward chain when it may overlap the forward one
-    hipEvent_t ev[8];
+    hipEvent_t ev[10];
     int dual_stream = 1;
     bool chains_dual = false;
     DevBuf<RowInfo> d_rowinfo;
@@ -143,6 +173,7 @@ struct smcpp_im {
     DevBuf<double> d_E, d_dpow, d_PinvT, d_PT, d_TdT, d_Td, d_Prm, d_Pinvrm, d_dsc, d_dun, d_g_scale,
         d_g_logscale, d_beta, d_cnorm, d_logc, d_ends_b, d_used_b, d_llpart, d_loglik, d_w1, d_gpart, d_Xs, d_Ys,
         d_part_e, d_part_1, d_red_e, d_red_1, d_red_g, d_Z, d_Y, d_xisum, d_gsum, d_gamma0, d_gamma_rows, d_Sq;
+    PinnedArena stage;
     int llblk = 64;
     int ZS = 8;
     int max_pass = 0;
@@ -603,16 +634,26 @@ void smcpp_im::host_prep_and_upload() {
         }
     }
     std::vector<double> dpow(std::max<size_t>(1, (size_t)G) * Mp, 0.0), gsc(std::max(1, G), 1.0), gls(std::max(1, G), 0.0);
+#pragma omp parallel for schedule(static) num_threads(std::max(1, std::min(8, omp_get_max_threads()))) if (G * M > 512)
     for (int g = 0; g < G; ++g) {
         const int e = groups[g].eig, sp = groups[g].span;
         gsc[g] = es[e].scale;
         gls[g] = sp * std::log(es[e].scale);
         for (int i = 0; i < M; ++i) dpow[(size_t)g * Mp + i] = std::pow(dsc[(size_t)e * Mp + i], sp);
     }
-    d_pi_f.upload(pi_f, s); d_Tf.upload(Tf, s); d_TdT.upload(TdT, s); d_Td.upload(Td, s); d_E.upload(Ep, s);
-    d_PinvT.upload(PinvT, s); d_PT.upload(PT, s); d_Prm.upload(Prm, s); d_Pinvrm.upload(Pinvrm, s);
-    d_dsc.upload(dsc, s); d_dun.upload(dun, s); d_dpow.upload(dpow, s);
-    d_g_scale.upload(gsc, s); d_g_logscale.upload(gls, s);
+    {
+        size_t need = 64 * 256;
+        need += (pi_f.size() + Tf.size()) * 4 + 2 * MM * 4;
+        need += (TdT.size() + Td.size() + Ep.size() + PinvT.size() + PT.size() + Prm.size() + Pinvrm.size() + dsc.size() +
+                 dun.size() + dpow.size() + gsc.size() + gls.size() + 5 * MM) * 8;
+        stage.reset(need);
+    }
+    d_pi_f.upload_staged(pi_f, stage, s); d_Tf.upload_staged(Tf, stage, s); d_TdT.upload_staged(TdT, stage, s);
+    d_Td.upload_staged(Td, stage, s); d_E.upload_staged(Ep, stage, s);
+    d_PinvT.upload_staged(PinvT, stage, s); d_PT.upload_staged(PT, stage, s); d_Prm.upload_staged(Prm, stage, s);
+    d_Pinvrm.upload_staged(Pinvrm, stage, s);
+    d_dsc.upload_staged(dsc, stage, s); d_dun.upload_staged(dun, stage, s); d_dpow.upload_staged(dpow, stage, s);
+    d_g_scale.upload_staged(gsc, stage, s); d_g_logscale.upload_staged(gls, stage, s);
     std::vector<float> T4;
     std::vector<double> fA2, fB2, bA2, bB2, bC2;
     if (Mp <= 64) {
@@ -633,10 +674,10 @@ void smcpp_im::host_prep_and_upload() {
                     bC2[i2] = Pinvrm[h * MM + (size_t)k * Mp + i];
                 }
             }
-        d_T4.upload(T4, s); d_fA2.upload(fA2, s); d_fB2.upload(fB2, s);
-        d_bA2.upload(bA2, s); d_bB2.upload(bB2, s); d_bC2.upload(bC2, s);
+        d_T4.upload_staged(T4, stage, s); d_fA2.upload_staged(fA2, stage, s); d_fB2.upload_staged(fB2, stage, s);
+        d_bA2.upload_staged(bA2, stage, s); d_bB2.upload_staged(bB2, stage, s); d_bC2.upload_staged(bC2, stage, s);
     }
-    HIPCHK(hipStreamSynchronize(s));   // the staging vectors above are pageable and die with this scope
+    // no synchronisation: the copies read the pinned arena, which lives until the next E-step resets it
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -795,7 +836,7 @@ void smcpp_im::run_chains() {
     int want_b = std::min(max_pass, last_bwd_passes > 0 ? last_bwd_passes + 1 : std::min(max_pass, 8));
     // The two chains are independent (beta does not depend on alpha).  The cooperative kernels leave most of a CU's
     // LDS and issue slots idle, so the backward passes run on a second stream and share the CUs with the forward ones.
-    const bool dual = dual_stream && chain_mode == 2 && Mp <= 64;
+    const bool dual = dual_stream && ((chain_mode == 2 && Mp <= 64) || Mp > 64);
     hipStream_t sb = dual ? stream2 : s;
     if (dual) {
         HIPCHK(hipEventRecord(ev[6], s));              // parameters / zeroed flags are ready on the main stream
@@ -868,6 +909,25 @@ void smcpp_im::run_stats() {
         d_gamma_rows.alloc((size_t)total_rows * Mp);
         d_gamma_rows.zero(s);
     }
+    // The eigen-row branch (U/W products, rank update, span-Q Hadamard, Y) does not depend on the span-1 branch
+    // (log_c, omega_1, rank update); with two streams the short launches of one fill the gaps of the other.
+    const bool split_streams = dual_stream && stream2 != nullptr && !slabs_eg.empty();
+    hipStream_t se = split_streams ? stream2 : s;
+    if (split_streams) {
+        HIPCHK(hipEventRecord(ev[8], s));
+        HIPCHK(hipStreamWaitEvent(se, ev[8], 0));
+    }
+    FinArgs fa;
+    fa.M = M; fa.Mp = Mp; fa.K = K; fa.G = G; fa.Ke = Ke; fa.n_contigs = n_contigs;
+    fa.eb_slab_off = d_eb_slab_off.p; fa.eb_gid = d_eb_gid.p; fa.ce_bucket_off = d_ce_bucket_off.p;
+    fa.s1_slab_off = d_s1_slab_off.p; fa.gk_slab_off = d_gk_slab_off.p; fa.g_span = d_g_span.p;
+    fa.e_kid = d_e_kid.p; fa.dsc = d_dsc.p; fa.dun = d_dun.p; fa.Prm = d_Prm.p; fa.Pinvrm = d_Pinvrm.p;
+    fa.E = d_E.p; fa.Td = d_Td.p; fa.ZS = ZS; fa.red_e = d_red_e.p; fa.red_1 = d_red_1.p; fa.red_g = d_red_g.p;
+    fa.alpha = d_alpha.p; fa.beta = d_beta.p; fa.contig_base = d_contig_base.p;
+    fa.Z = d_Z.p; fa.Y = d_Y.p; fa.xisum = d_xisum.p; fa.gsum = d_gsum.p; fa.gamma0 = d_gamma0.p;
+    const int MMi = Mp * Mp;
+    const int nb2 = ceil_div((long long)Mp * Mp, 256);
+    // ---- span-1 branch (main stream) ----
     if (!slabs_sc.empty()) {
         S1Args sa;
         sa.M = M; sa.Mp = Mp; sa.nslabs = (int)slabs_sc.size(); sa.slabs = d_slabs_sc.p; sa.perm = d_perm1.p;
@@ -882,38 +942,32 @@ void smcpp_im::run_stats() {
         aa.nslabs = (int)slabs_rk.size(); aa.slabs = d_slabs_rk.p; aa.perm = d_perm1.p; aa.part = d_part_1.p;
         hipLaunchKernelGGL(k_rank_acc<0>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, s, aa);
     }
+    hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 32), n_contigs * K, 1), dim3(256), 0, s,
+                       (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
+    hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 32), n_contigs, ZS), dim3(256), 0, s,
+                       (const double *)d_part_1.p, (const int *)d_s1_slab_off.p, d_red_1.p, MMi, ZS);
+    HIPCHK(hipEventRecord(ev[4], s));
+    // ---- eigen branch (second stream when available) ----
     if (!slabs_eg.empty()) {
         UWArgs ua;
         ua.M = M; ua.Mp = Mp; ua.nslabs = (int)slabs_eg.size(); ua.slabs = d_slabs_eg.p; ua.perm = d_perme.p;
         ua.alpha = d_alpha.p; ua.beta = d_beta.p; ua.g_eig = d_g_eig.p; ua.g_scale = d_g_scale.p;
         ua.dpow = d_dpow.p; ua.PinvT = d_PinvT.p; ua.Prm = d_Prm.p; ua.Xs = d_Xs.p; ua.Ys = d_Ys.p;
-        launch_uw(NT, ua, s);
-        aa.nslabs = (int)slabs_eg.size(); aa.slabs = d_slabs_eg.p; aa.perm = d_perme.p; aa.part = d_part_e.p;
-        hipLaunchKernelGGL(k_rank_acc<1>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, s, aa);
-    }
-    HIPCHK(hipEventRecord(ev[4], s));
-    FinArgs fa;
-    fa.M = M; fa.Mp = Mp; fa.K = K; fa.G = G; fa.Ke = Ke; fa.n_contigs = n_contigs;
-    fa.eb_slab_off = d_eb_slab_off.p; fa.eb_gid = d_eb_gid.p; fa.ce_bucket_off = d_ce_bucket_off.p;
-    fa.s1_slab_off = d_s1_slab_off.p; fa.gk_slab_off = d_gk_slab_off.p; fa.g_span = d_g_span.p;
-    fa.e_kid = d_e_kid.p; fa.dsc = d_dsc.p; fa.dun = d_dun.p; fa.Prm = d_Prm.p; fa.Pinvrm = d_Pinvrm.p;
-    fa.E = d_E.p; fa.Td = d_Td.p; fa.ZS = ZS; fa.red_e = d_red_e.p; fa.red_1 = d_red_1.p; fa.red_g = d_red_g.p;
-    {
-        const int MM = Mp * Mp;
-        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 32), n_contigs * K, 1), dim3(256), 0, s,
-                           (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
-        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MM, 32), n_contigs, ZS), dim3(256), 0, s,
-                           (const double *)d_part_1.p, (const int *)d_s1_slab_off.p, d_red_1.p, MM, ZS);
+        launch_uw(NT, ua, se);
+        AccArgs ae = aa;
+        ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
+        hipLaunchKernelGGL(k_rank_acc<1>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
         if (!eb_gid.empty())
-            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MM, 32), (unsigned)eb_gid.size(), ZS), dim3(256), 0, s,
-                               (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MM, ZS);
+            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 32), (unsigned)eb_gid.size(), ZS), dim3(256), 0, se,
+                               (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MMi, ZS);
     }
-    fa.alpha = d_alpha.p; fa.beta = d_beta.p; fa.contig_base = d_contig_base.p;
-    fa.Z = d_Z.p; fa.Y = d_Y.p; fa.xisum = d_xisum.p; fa.gsum = d_gsum.p; fa.gamma0 = d_gamma0.p;
-    const int nb2 = ceil_div((long long)Mp * Mp, 256);
     if (Ke > 0) {
-        hipLaunchKernelGGL(k_fin_Z, dim3(nb2, n_contigs * Ke), dim3(256), 0, s, fa);
-        hipLaunchKernelGGL(k_fin_Y, dim3(nb2, n_contigs * Ke), dim3(256), 0, s, fa);
+        hipLaunchKernelGGL(k_fin_Z, dim3(nb2, n_contigs * Ke), dim3(256), 0, se, fa);
+        hipLaunchKernelGGL(k_fin_Y, dim3(nb2, n_contigs * Ke), dim3(256), 0, se, fa);
+    }
+    if (split_streams) {
+        HIPCHK(hipEventRecord(ev[9], se));
+        HIPCHK(hipStreamWaitEvent(s, ev[9], 0));
     }
     hipLaunchKernelGGL(k_fin_xisum, dim3(nb2, n_contigs), dim3(256), 0, s, fa);
     hipLaunchKernelGGL(k_fin_gamma, dim3(ceil_div((long long)(K + 1) * Mp, 256), n_contigs), dim3(256), 0, s, fa);

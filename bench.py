@@ -5,7 +5,7 @@ One "step" = one eval of SURVEY.md §8(d): parameters marked dirty -> E-step (ho
 forward/backward chains + sufficient statistics on the GPU) -> loglik, over this rank's contig(s), with the
 observation arrays already resident in HBM (they are uploaded when the inference manager is constructed).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c4|c5] [--no-cpu] [--chunk ROWS]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c3|c4|c5] [--no-cpu] [--chunk ROWS]
 
 N > 1: launched by torch.distributed.run, one rank per GPU; every rank owns one synthetic 100 Mbp contig (weak
 scaling, contigs are independent HMMs) and the ranks exchange ONE all-reduce(sum, fp64) of the packed
@@ -34,6 +34,8 @@ WORKLOADS = {
     "headline": (64, 20, "params_M64_n20.npz", "1 synthetic 100 Mbp contig per GPU, M=64, n=20 (BASELINE.json metric shape)"),
     "c2": (32, 10, "params_M32_n10.npz", "1 synthetic 100 Mbp contig per GPU, M=32, n=10 (configs[1])"),
     "c5": (256, 50, "params_M256_n50.npz", "1 synthetic 100 Mbp contig per GPU, M=256, n=50 (configs[4])"),
+    # whole genome: the 22 autosome-like contigs (2 872 Mbp) sharded longest-first over the ranks; STRONG scaling
+    "c3": (64, 20, "params_M64_n20.npz", "22 synthetic contigs, 2872 Mbp in total, M=64, n=20, LPT-sharded over the GPUs (configs[2])"),
     # two populations, both distinguished lineages in population 1, split 0.5; the parameters come
     # from the engine's own JointCSFS preparation, computed once outside the timed region like the fixtures above
     "c4": (48, 10, None, "1 synthetic two-population 100 Mbp contig per GPU, M=48, n1=n2=10, a=(2,0), split=0.5 (configs[3])"),
@@ -75,11 +77,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # SMCPP_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 code path (key union, packed all-reduce, barrier,
+    # max over ranks) be exercised on a box with fewer GPUs than ranks (ranks share devices, the reduction runs on the
+    # host).  The measured configuration is always nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("SMCPP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from smcpp_amd import _smcpp, synth
     M, n, fixture, desc = WORKLOADS[args.workload]
@@ -98,6 +110,14 @@ def main():
                                                synth.THETA, synth.RHO, synth.ALPHA, keys4)
         par = dict(pi=pi4, T=T4, keys=keys4, E=E4, hs=hs, pol=0.5, theta=synth.THETA, rho=synth.RHO, alpha=synth.ALPHA)
         im = _smcpp.PyTwoPopInferenceManager(n, n, 2, 0, [obs], hs, ("pop1", "pop2"), 0.5, device=local_rank)
+    elif args.workload == "c3":
+        from smcpp_amd import dist as sd
+        par = np.load(os.path.join(ROOT, "tests", "golden", fixture))
+        owner = sd.lpt_shard(synth.C3_LENGTHS_MBP, world)
+        mine = [i for i in range(len(owner)) if owner[i] == rank]
+        contigs = [synth.synth_contig(i, int(synth.C3_LENGTHS_MBP[i] * 1e6), n) for i in mine]
+        obs = np.concatenate(contigs)                    # only for the algorithmic work / CPU baseline bookkeeping
+        im = _smcpp.PyOnePopInferenceManager(n, contigs, par["hs"], ("pop1",), float(par["pol"]), device=local_rank)
     else:
         par = np.load(os.path.join(ROOT, "tests", "golden", fixture))
         obs = synth.synth_contig(rank, length_bp, n)         # contig index = rank: independent contigs, weak scaling
@@ -120,7 +140,7 @@ def main():
         if world > 1:
             h = im.pack_stats()
             if stats_buf is None:
-                stats_buf = torch.empty(len(h), dtype=torch.float64, device=dev)
+                stats_buf = torch.empty(len(h), dtype=torch.float64, device=red_dev)
             stats_buf.copy_(torch.from_numpy(h))
             dist.all_reduce(stats_buf, op=dist.ReduceOp.SUM)       # the single collective of the E-step
             im.unpack_stats(stats_buf.cpu().numpy())
@@ -143,11 +163,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * args.steps / elapsed                 # contig-E-step evals per second, whole job
+    if args.workload == "c3":
+        value = args.steps / elapsed                     # whole-genome evals per second (the ranks share ONE eval)
+    else:
+        value = world * args.steps / elapsed             # contig-E-step evals per second, whole job
 
     # ---- roofline of the dominant kernel (forward chain pass), timed live with HIP events ----
     # smcpp_last_timing brackets the forward / backward pass launches with hipEvents recorded on the engine's stream.
@@ -186,12 +209,15 @@ def main():
         med = {k: float(np.median([t[k] for t in timings])) for k in timings[0]}
         out = {
             "metric": "E-step loglik-evals/sec (100 Mbp, M=64, n=20)" if args.workload == "headline"
-            else f"E-step loglik-evals/sec ({args.length_mbp:g} Mbp, M={M}, n={n})",
+            else ("whole-genome E-step loglik-evals/sec (22 contigs, 2872 Mbp, M=64, n=20)" if args.workload == "c3"
+                  else f"E-step loglik-evals/sec ({args.length_mbp:g} Mbp, M={M}, n={n})"),
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.workload == "c3" else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "M": M, "n": n, "rows_per_contig": int(len(obs)),
-                       "span1_rows": R1, "eigen_rows": Re, "contigs_per_gpu": 1, "length_mbp": args.length_mbp,
+                       "span1_rows": R1, "eigen_rows": Re,
+                       "contigs_per_gpu": len(contigs) if args.workload == "c3" else 1,
+                       "length_mbp": float(sum(synth.C3_LENGTHS_MBP)) if args.workload == "c3" else args.length_mbp,
                        "loglik": ll, "parallelism": f"contig-sharded x{world}, 1 all-reduce/E-step" if world > 1 else "single GPU"},
             "split_ms": med,
             "roofline": roof,

@@ -346,6 +346,13 @@ void smcpp_im::make_chunks() {
         if (Mp > 64) chain_mode = 0;
         const char *b = getenv("SMCPP_COOP_BPC");
         if (b && atoi(b) > 0) coop_bpc = atoi(b);
+        else {
+            // More workgroups per CU hide the per-row latency of the cooperative kernels (measured on 6.8 M rows:
+            // throughput x1.27 / x1.36 / x1.42 for 2 / 3 / 4 per CU) but shorten the chunks, and every chunk pays
+            // ~1100 rows of re-run history; the break-even points below follow from those two numbers.
+            const long long per_cu = (total_rows - n_contigs) / std::max(1, prop.multiProcessorCount);
+            coop_bpc = per_cu < 3000 ? 1 : per_cu < 9000 ? 2 : per_cu < 17000 ? 3 : 4;
+        }
     }
     // chunks in flight: one per SIMD for the per-wavefront kernels, coop_bpc per CU for the cooperative ones
     const long long slots = (long long)prop.multiProcessorCount * (chain_mode == 2 ? coop_bpc : wpb);
@@ -587,60 +594,64 @@ void smcpp_im::prepare_params() {
 void smcpp_im::host_prep_and_upload() {
     hipStream_t s = stream;
     const size_t MM = (size_t)Mp * Mp;
-    // ---- TransitionBundle::update: eigensystems of diag(b_k) Td^T per eigen key (transition_bundle.cpp:15-25)
-    std::vector<smcpp_host::EigenSystem> es(Ke);
+    const size_t em = std::max<size_t>(1, (size_t)Ke) * MM;
+    std::vector<double> PinvT(em, 0.0), PT(em, 0.0), Prm(em, 0.0), Pinvrm(em, 0.0);
+    std::vector<double> dsc(std::max<size_t>(1, (size_t)Ke) * Mp, 0.0), dun(std::max<size_t>(1, (size_t)Ke) * Mp, 0.0);
+    std::vector<double> dpow(std::max<size_t>(1, (size_t)G) * Mp, 0.0), gsc(std::max(1, G), 1.0), gls(std::max(1, G), 0.0);
+    std::vector<float> pi_f(Mp, 0.f), Tf(MM, 0.f);
+    std::vector<double> TdT(MM, 0.0), Td(MM, 0.0), Ep((size_t)K * Mp, 0.0);
+    // groups of each eigen key (so that one task finishes everything that depends on one eigensystem)
+    std::vector<std::vector<int>> groups_of(Ke);
+    for (int g = 0; g < G; ++g) groups_of[groups[g].eig].push_back(g);
+    // ---- TransitionBundle::update: eigensystems of diag(b_k) Td^T per eigen key (transition_bundle.cpp:15-25), the
+    // transposed / row-major copies the kernels read and the eigenvalue powers of every (span, key) group, ONE
+    // parallel region (task Ke packs the key-independent arrays)
     std::string err;
-#pragma omp parallel for schedule(dynamic) num_threads(std::max(1, std::min(Ke, omp_get_max_threads())))
-    for (int e = 0; e < Ke; ++e) {
+#pragma omp parallel for schedule(dynamic) num_threads(std::max(1, std::min(Ke + 1, omp_get_max_threads())))
+    for (int e = 0; e <= Ke; ++e) {
+        if (e == Ke) {
+            for (int i = 0; i < M; ++i) {
+                pi_f[i] = (float)pi[i];
+                for (int j = 0; j < M; ++j) {
+                    Tf[(size_t)i * Mp + j] = (float)T[(size_t)i * M + j];
+                    Td[(size_t)i * Mp + j] = T[(size_t)i * M + j];
+                    TdT[(size_t)j * Mp + i] = T[(size_t)i * M + j];
+                }
+            }
+            for (int k = 0; k < K; ++k)
+                for (int i = 0; i < M; ++i) Ep[(size_t)k * Mp + i] = E[(size_t)k * M + i];
+            continue;
+        }
         try {
             const double *b = &E[(size_t)eig_kid[e] * M];
             std::vector<double> A((size_t)M * M);
             for (int i = 0; i < M; ++i)
                 for (int j = 0; j < M; ++j) A[(size_t)i * M + j] = b[i] * T[(size_t)j * M + i];
-            es[e] = smcpp_host::eigensystem(M, A);
+            const smcpp_host::EigenSystem s_ = smcpp_host::eigensystem(M, A);
+            for (int i = 0; i < M; ++i) {
+                dun[(size_t)e * Mp + i] = s_.d[i];
+                dsc[(size_t)e * Mp + i] = s_.d[i] / s_.scale;
+                for (int j = 0; j < M; ++j) {
+                    const double p = s_.P[(size_t)i * M + j], pi_ = s_.Pinv[(size_t)i * M + j];
+                    Prm[e * MM + (size_t)i * Mp + j] = p;
+                    PT[e * MM + (size_t)j * Mp + i] = p;
+                    Pinvrm[e * MM + (size_t)i * Mp + j] = pi_;
+                    PinvT[e * MM + (size_t)j * Mp + i] = pi_;
+                }
+            }
+            const double ls = std::log(s_.scale);
+            for (int g : groups_of[e]) {
+                const int sp = groups[g].span;
+                gsc[g] = s_.scale;
+                gls[g] = sp * ls;
+                for (int i = 0; i < M; ++i) dpow[(size_t)g * Mp + i] = std::pow(dsc[(size_t)e * Mp + i], sp);
+            }
         } catch (const std::exception &ex) {
 #pragma omp critical
             err = ex.what();
         }
     }
     if (!err.empty()) throw std::runtime_error(err);
-    std::vector<float> pi_f(Mp, 0.f), Tf(MM, 0.f);
-    std::vector<double> TdT(MM, 0.0), Td(MM, 0.0), Ep((size_t)K * Mp, 0.0);
-    for (int i = 0; i < M; ++i) {
-        pi_f[i] = (float)pi[i];
-        for (int j = 0; j < M; ++j) {
-            Tf[(size_t)i * Mp + j] = (float)T[(size_t)i * M + j];
-            Td[(size_t)i * Mp + j] = T[(size_t)i * M + j];
-            TdT[(size_t)j * Mp + i] = T[(size_t)i * M + j];
-        }
-    }
-    for (int k = 0; k < K; ++k)
-        for (int i = 0; i < M; ++i) Ep[(size_t)k * Mp + i] = E[(size_t)k * M + i];
-    const size_t em = std::max<size_t>(1, (size_t)Ke) * MM;
-    std::vector<double> PinvT(em, 0.0), PT(em, 0.0), Prm(em, 0.0), Pinvrm(em, 0.0);
-    std::vector<double> dsc(std::max<size_t>(1, (size_t)Ke) * Mp, 0.0), dun(std::max<size_t>(1, (size_t)Ke) * Mp, 0.0);
-    for (int e = 0; e < Ke; ++e) {
-        const auto &s_ = es[e];
-        for (int i = 0; i < M; ++i) {
-            dun[(size_t)e * Mp + i] = s_.d[i];
-            dsc[(size_t)e * Mp + i] = s_.d[i] / s_.scale;
-            for (int j = 0; j < M; ++j) {
-                const double p = s_.P[(size_t)i * M + j], pi_ = s_.Pinv[(size_t)i * M + j];
-                Prm[e * MM + (size_t)i * Mp + j] = p;
-                PT[e * MM + (size_t)j * Mp + i] = p;
-                Pinvrm[e * MM + (size_t)i * Mp + j] = pi_;
-                PinvT[e * MM + (size_t)j * Mp + i] = pi_;
-            }
-        }
-    }
-    std::vector<double> dpow(std::max<size_t>(1, (size_t)G) * Mp, 0.0), gsc(std::max(1, G), 1.0), gls(std::max(1, G), 0.0);
-#pragma omp parallel for schedule(static) num_threads(std::max(1, std::min(8, omp_get_max_threads()))) if (G * M > 512)
-    for (int g = 0; g < G; ++g) {
-        const int e = groups[g].eig, sp = groups[g].span;
-        gsc[g] = es[e].scale;
-        gls[g] = sp * std::log(es[e].scale);
-        for (int i = 0; i < M; ++i) dpow[(size_t)g * Mp + i] = std::pow(dsc[(size_t)e * Mp + i], sp);
-    }
     {
         size_t need = 64 * 256;
         need += (pi_f.size() + Tf.size()) * 4 + 2 * MM * 4;

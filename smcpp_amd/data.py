@@ -160,3 +160,83 @@ def bin_observations(data: np.ndarray, w: int, na) -> np.ndarray:
             seen += span
     out.append(process_bin(i, j - 1))
     return np.array(out, dtype=np.int32)
+
+
+def watterson_theta(contigs) -> float:
+    """Watterson's estimator per base pair over a list of contigs (`smcpp/data_filter.py:300-322`): segregating span
+    over sum(span * (log n + 0.5 / n + 0.57721)) with n the number of observed haplotypes of each row."""
+    num = 0.0
+    denom = 0.0
+    for c in contigs:
+        d = c.data
+        spans = d[:, 0]
+        seg = np.any(d[:, 1::3] >= 1, axis=1) | np.any(d[:, 2::3] > 0, axis=1)
+        num += spans[seg].sum()
+        sample_sizes = d[:, 3::3].sum(axis=1) + (d[:, 1::3] >= 0).sum(axis=1)
+        nm = sample_sizes > 0
+        ss = sample_sizes[nm].astype(np.float64)
+        denom += (spans[nm] * (np.log(ss) + 0.5 / ss + 0.57721)).sum()
+    return float(num / denom)
+
+
+def recode_monomorphic(contig: Contig) -> Contig:
+    """Rows where every sampled haplotype is derived carry no information: recode them as all-ancestral
+    (`smcpp/data_filter.py:325-336`).  In place, like the reference."""
+    d = contig.data
+    w = np.all(d[:, 1::3] == np.asarray(contig.a), axis=1) & np.all(d[:, 2::3] == d[:, 3::3], axis=1)
+    d[w, 1::3] = 0
+    d[w, 2::3] = 0
+    return contig
+
+
+def recode_nonseg(contig: Contig, cutoff) -> Contig:
+    """Long runs of homozygosity (`smcpp/estimation_tools.py:88-114`): with a cutoff they become missing data; with
+    `cutoff=None` the reference only warns (threshold 50 000) and leaves the data alone."""
+    if cutoff is None:
+        return contig
+    d = contig.data
+    runs = (d[:, 0] > cutoff) & np.all(d[:, 1::3] == 0, axis=1) & np.all(d[:, 2::3] == 0, axis=1)
+    d[runs, 1::3] = -1
+    d[runs, 3::3] = 0
+    return contig
+
+
+def windowed_mutation_counts(contig: Contig, w: int) -> np.ndarray:
+    """Per window of `w` base pairs: [number of non-missing positions, number of heterozygous ones]
+    (`smcpp/_estimation_tools.pyx:212-255`; used to choose hidden states).  Returns an int32 array [2, L // w + 1]."""
+    assert w > 0
+    data = contig.data
+    L = int(data[:, 0].sum())
+    ret = np.zeros((L // w + 1, 2), dtype=np.int32)
+    npop = (data.shape[1] - 1) // 3
+    j = 0
+    seen = nmiss = mut = 0
+    i = 0
+    last = data[0].copy()
+    nrows = data.shape[0]
+    while i < nrows:
+        span = int(last[0])
+        sp = min(span, w - seen)
+        extra = seen + span - w
+        seen += sp
+        a = 0
+        for k in range(npop):
+            if last[1 + 3 * k] != -1:
+                a += int(last[1 + 3 * k])
+            else:
+                a = -1
+                break
+        if a >= 0:
+            mut += sp * (a % 2)
+            nmiss += sp
+        if extra > 0:
+            last[0] = extra
+            ret[j] = (nmiss, mut)
+            j += 1
+            nmiss = mut = seen = 0
+        else:
+            i += 1
+            if i < nrows:
+                last = data[i].copy()
+    ret[j] = (nmiss, mut)
+    return ret.T

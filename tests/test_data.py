@@ -5,6 +5,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 from conftest import load_golden
 
@@ -66,3 +67,29 @@ def test_thinning_and_binning():
     assert b[0, 1:].tolist() == [1, 0, 0]                      # only the pair observed: the segregating row wins
     assert b[1, 1:].tolist() == [0, 2, 5]                      # the row with undistinguished samples wins
     assert b[2, 1:].tolist() == [-1, 0, 0]
+
+
+def test_watterson_recode_and_windowed_counts():
+    from smcpp_amd import data as D
+    rows = np.array([[5, 0, 0, 4], [1, 1, 2, 4], [3, -1, 0, 0], [2, 0, 0, 4], [1, 2, 4, 4], [4, 1, 0, 0]], dtype=np.int32)
+    c = D.Contig(rows.copy(), ("p",), [4], [2])
+    # segregating rows: (1,2,4) span 1, (2,4,4) span 1, (1,0,0) span 4 -> 6; sample size as the reference counts
+    # it: nb + 1 per population whose distinguished genotype is not missing
+    seg = 1 + 1 + 4
+    ss = np.array([5, 5, 0, 5, 5, 1.0]); sp = np.array([5, 1, 3, 2, 1, 4.0]); nm = ss > 0
+    want = seg / (sp[nm] * (np.log(ss[nm]) + 0.5 / ss[nm] + 0.57721)).sum()
+    assert D.watterson_theta([c]) == pytest.approx(want, rel=1e-14)
+    D.recode_monomorphic(c)
+    assert c.data[4].tolist() == [1, 0, 0, 4]                 # (a, b, nb) = (2, 4, 4): everything derived
+    assert c.data[1].tolist() == [1, 1, 2, 4]
+    big = D.Contig(np.array([[60000, 0, 0, 0], [7, 0, 0, 2], [10, 1, 0, 0]], dtype=np.int32), ("p",), [2], [2])
+    D.recode_nonseg(big, None)
+    assert big.data[0].tolist() == [60000, 0, 0, 0]
+    D.recode_nonseg(big, 50000)
+    assert big.data[0].tolist() == [60000, -1, 0, 0] and big.data[1].tolist() == [7, 0, 0, 2]
+    # windows of 4 bp over 5 + 1 + 3(missing) + 2 + 1 + 4 = 16 bp; a in {1} is heterozygous
+    c2 = D.Contig(rows.copy(), ("p",), [4], [2])
+    wc = D.windowed_mutation_counts(c2, 4)
+    assert wc.shape == (2, 16 // 4 + 1)
+    # positions: 0-4 hom, 5 het, 6-8 missing, 9-10 hom, 11 (a=2, even) hom, 12-15 het
+    assert wc[0].tolist() == [4, 2, 3, 4, 0] and wc[1].tolist() == [0, 1, 0, 4, 0]

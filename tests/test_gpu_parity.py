@@ -283,3 +283,71 @@ def test_two_population_model_path(a1, a2, M, split):
     tm.split = split
     im.E_step()
     assert abs(im.loglik() - ll0) <= 1e-12 * abs(ll0)
+
+
+@pytest.mark.parametrize("M,n,length,chunk", [(2, 3, 400_000, 0), (3, 5, 300_000, 50), (15, 4, 300_000, 0),
+                                               (17, 6, 300_000, 40), (33, 8, 300_000, 0), (47, 9, 250_000, 64),
+                                               (65, 10, 200_000, 0), (100, 12, 150_000, 64), (130, 6, 120_000, 0),
+                                               (200, 8, 80_000, 48), (256, 10, 60_000, 0)])
+def test_state_count_sweep_vs_oracle(M, n, length, chunk):
+    """Every kernel family (cooperative M <= 64 at each padded width, generic 64 < M <= 256, odd widths that need
+    padding) against the C restatement, parameters from the engine's own preparation, several ragged contigs, with and
+    without forced multi-chunk iteration; posterior rows included."""
+    from oracle import oracle
+    from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel
+    hs = synth.hidden_states(M)
+    a, s = synth.model_pieces()
+    contigs = [synth.synth_contig(100 + M + i, L, n) for i, L in enumerate([length, length // 3, 20_000])]
+    im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
+    im.model = PiecewiseModel(a, s, 1e4, "pop1")
+    im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0
+    if chunk:
+        im.set_chunking(chunk)
+    im.save_gamma = True
+    im.E_step()
+    pi, T, keys = im.pi, im.transition, im.keys
+    ep = im.emission_probs
+    Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
+    lls, xs, gss, gams = im.logliks(), im.xisums, im.gamma_sums, im.gammas
+    for c, ob in enumerate(contigs):
+        o = oracle.estep(pi, T, keys, Etab, ob, save_gamma=True)
+        assert abs(lls[c] - o["loglik"]) <= LL_TOL * abs(o["loglik"])
+        assert rel_err(xs[c], o["xisum"]) <= STAT_TOL
+        for k, v in o["gamma_sums"].items():
+            assert np.max(np.abs(gss[c][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300)
+        g_ref = o["gamma"]
+        assert gams[c].shape == g_ref.shape
+        assert np.max(np.abs(gams[c] - g_ref)) <= 2e-5 * max(1.0, float(np.abs(g_ref).max()))
+        top2 = np.sort(g_ref, axis=0)[-2:] if M > 1 else None
+        if M > 1:
+            margin = (top2[1] - top2[0]) / np.maximum(top2[1], 1e-300)
+            mism = np.nonzero(gams[c].argmax(axis=0) != g_ref.argmax(axis=0))[0]
+            assert not np.any(margin[mism] > 1e-5)
+
+
+def test_many_tiny_contigs():
+    """300 contigs of 1-40 rows each (ragged, most shorter than any chunk): per-contig results against the oracle."""
+    from oracle import oracle
+    from smcpp_amd import _smcpp, synth
+    g = load_golden("G3_M32_n10_2Mbp")
+    rng = np.random.default_rng(7)
+    big = synth.synth_contig(77, 3_000_000, 10)
+    contigs = []
+    pos = 0
+    for _ in range(300):
+        L = int(rng.integers(1, 41))
+        contigs.append(np.ascontiguousarray(big[pos:pos + L]))
+        pos += L
+    im = _smcpp.PyOnePopInferenceManager(10, contigs, g["hs"], ("pop1",), 0.5)
+    im.theta = float(g["theta"]); im.rho = float(g["rho"])
+    im.set_raw(g["pi"], g["T"], g["keys"], g["E"])
+    im.E_step()
+    lls, xs, gss = im.logliks(), im.xisums, im.gamma_sums
+    tot = 0.0
+    for c in range(0, 300, 7):
+        o = oracle.estep(g["pi"], g["T"], g["keys"], g["E"], contigs[c])
+        assert abs(lls[c] - o["loglik"]) <= LL_TOL * max(1.0, abs(o["loglik"]))
+        assert rel_err(xs[c], o["xisum"]) <= STAT_TOL
+        assert sorted(gss[c].keys()) == sorted(o["gamma_sums"].keys())
+    assert np.isfinite(im.loglik())

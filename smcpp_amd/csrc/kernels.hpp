@@ -914,11 +914,13 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop(ChainArgs a, CoopArgs ca) {
     }
     const int2 *rd = a.rowdesc + ch.base;
     const int nrows = ch.r1 - ch.r0;
-    // descriptor batches: batch b lives in sdesc[b&1]; wavefront 0 fetches batch b+1 while batch b is consumed
-    int2 dnext = make_int2(0, -1);
+    // descriptor batches of 64 rows: batch b lives in sdesc[b&1]; batches 0 and 1 are staged here, batch b+1 by
+    // wavefront 0 in the middle of batch b.  The fetch is deliberately synchronous inside its branch: a load whose
+    // result is carried across iterations makes the compiler wait for vmcnt(0) - i.e. for the alpha store just
+    // issued - on EVERY row (measured: the dominant stall of the previous version of this loop).
     if (w == 0) {
         sdesc[lane] = (lane < nrows) ? rd[ch.r0 + 1 + lane] : make_int2(0, -1);
-        dnext = (lane + 64 < nrows) ? rd[ch.r0 + 1 + 64 + lane] : make_int2(0, -1);
+        sdesc[64 + lane] = (lane + 64 < nrows) ? rd[ch.r0 + 1 + 64 + lane] : make_int2(0, -1);
     }
     if (owner) xf[i] = al;                     // the start vector enters as a state whose sum counts as exactly 1
     __syncthreads();
@@ -939,7 +941,6 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop(ChainArgs a, CoopArgs ca) {
     // within eps the remaining rows, normalisers and the end vector of the previous pass stay valid (the perturbation of
     // a start vector decays geometrically), so late, sparse passes cost a few hundred rows instead of a whole chunk.
     const bool rerun = pass > 0;
-    float old_pref = 0.f;
     bool merged = false;
 #ifdef SMCPP_PROFILE_CYCLES
     long long t_loop0 = __builtin_readcyclecounter(), t_bar = 0, t_bar2 = 0;
@@ -953,9 +954,9 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop(ChainArgs a, CoopArgs ca) {
             for (int q = 1; q < NW; ++q) nm |= mflag[q];
             if (nm == 0) { merged = true; break; }
         }
-        if (w == 0 && jb == 32) {
-            sdesc[(bsel ^ 1) * 64 + lane] = dnext;
-            dnext = (j - 32 + 128 + lane < nrows) ? rd[ch.r0 + 1 + (j - 32) + 128 + lane] : make_int2(0, -1);
+        if (w == 0 && jb == 32 && j >= 64) {
+            const int2 dn = (j + 32 + lane < nrows) ? rd[ch.r0 + 1 + j + 32 + lane] : make_int2(0, -1);
+            sdesc[(bsel ^ 1) * 64 + lane] = dn;
         }
         // stage 1 -> operands of row j+1 (descriptor fetched one iteration ago), stage 2 -> raw descriptor of row j+2
         const int kid_n = __builtin_amdgcn_readfirstlane(d1.x);
@@ -982,7 +983,8 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop(ChainArgs a, CoopArgs ca) {
             float an = v_prev * inv;
             an = (i < M) ? fmaxf(an, 1e-10f) : 0.f;
             if (rerun && (j & 15) == 0) {
-                // old_pref = the stored alpha of row ell-1 (fetched one iteration ago, before this overwrite)
+                // the alpha this row had in the previous pass, read (and waited for) right before it is overwritten
+                const float old_pref = owner ? a.alpha[(size_t)(ch.base + ell - 1) * Mp + i] : 0.f;
                 const bool bad = owner && i < M && !(fabsf(an - old_pref) <= a.eps_f * fabsf(old_pref));
                 const bool anyb = __any(bad);
                 if (lane == 0) mflag[w] = anyb ? 1 : 0;
@@ -990,7 +992,6 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop(ChainArgs a, CoopArgs ca) {
             if (owner) a.alpha[(size_t)(ch.base + ell - 1) * Mp + i] = an;
             if (tid == 0) a.cnorm[ch.base + ell - 1] = (double)sprev;
         }
-        if (rerun && (j & 15) == 15 && owner) old_pref = a.alpha[(size_t)(ch.base + ell) * Mp + i];
         float vout;
         if (ge < 0) {
             // span == 1: y = Tf^T max(x, thr) / s ; v = float(y e)
@@ -1158,10 +1159,9 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop(ChainArgs a, CoopArgs ca) {
     }
     const int2 *rd = a.rowdesc + ch.base;
     const int nrows = ch.r1 - ch.r0;
-    int2 dnext = make_int2(0, -1);
-    if (w == 0) {
+    if (w == 0) {            // descriptor batches: see k_fwd_coop
         sdesc[lane] = (lane < nrows) ? rd[ch.r1 - lane] : make_int2(0, -1);
-        dnext = (lane + 64 < nrows) ? rd[ch.r1 - lane - 64] : make_int2(0, -1);
+        sdesc[64 + lane] = (lane + 64 < nrows) ? rd[ch.r1 - lane - 64] : make_int2(0, -1);
     }
     __syncthreads();
     auto desc_at = [&](int jj) { return sdesc[((jj >> 6) & 1) * 64 + (jj & 63)]; };
@@ -1175,7 +1175,6 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop(ChainArgs a, CoopArgs ca) {
     __syncthreads();
     double b_raw = b;       // owner: unnormalised beta of the row being processed
     const bool rerun = pass > 0;   // early exit once the re-run has merged with the stored trajectory (see k_fwd_coop)
-    double old_pref = 0.0;
     bool merged = false;
     for (int j = 0; j < nrows; ++j) {
         const int ell = ch.r1 - j;
@@ -1186,9 +1185,9 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop(ChainArgs a, CoopArgs ca) {
             for (int q = 1; q < NW; ++q) nm |= mflag[q];
             if (nm == 0) { merged = true; break; }
         }
-        if (w == 0 && jb == 32) {
-            sdesc[(bsel ^ 1) * 64 + lane] = dnext;
-            dnext = (j - 32 + 128 + lane < nrows) ? rd[ch.r1 - ((j - 32) + 128 + lane)] : make_int2(0, -1);
+        if (w == 0 && jb == 32 && j >= 64) {
+            const int2 dn = (j + 32 + lane < nrows) ? rd[ch.r1 - (j + 32 + lane)] : make_int2(0, -1);
+            sdesc[(bsel ^ 1) * 64 + lane] = dn;
         }
         const int kid_n = __builtin_amdgcn_readfirstlane(d1.x);
         const int ge_n = (j + 1 < nrows) ? __builtin_amdgcn_readfirstlane(d1.y) : -1;
@@ -1211,13 +1210,13 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop(ChainArgs a, CoopArgs ca) {
         {
             const double bnrm = (i < M) ? b_raw * inv : 0.0;
             if (rerun && (j & 15) == 0 && j > 0) {
+                const double old_pref = owner ? a.beta[(size_t)(ch.base + ell) * Mp + i] : 0.0;
                 const bool bad = owner && i < M && !(fabs(bnrm - old_pref) <= a.eps_b * fabs(old_pref));
                 const bool anyb = __any(bad);
                 if (lane == 0) mflag[w] = anyb ? 1 : 0;
             }
             if (owner) a.beta[(size_t)(ch.base + ell) * Mp + i] = bnrm;
         }
-        if (rerun && (j & 15) == 15 && owner && j + 1 < nrows) old_pref = a.beta[(size_t)(ch.base + ell - 1) * Mp + i];
         double bn;
         if (ge < 0) {
             // beta <- T (e o beta)   (hmm.cpp:139): this lane needs e on its quarter of the inner index

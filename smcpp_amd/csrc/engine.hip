@@ -78,16 +78,29 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool borrowed = false;      // p points into the parameter arena (see ParamArena): never freed here
     void alloc(size_t count) {
-        if (count <= n && p) return;
+        if (count <= n && p && !borrowed) return;
         free();
         n = count;
         if (count) HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
     }
     void free() {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        borrowed = false;
+    }
+    // place this buffer at byte offset `off` of the parameter arena and stage its contents at the same offset of the
+    // pinned mirror; the caller issues ONE copy for the whole arena afterwards
+    void place(const std::vector<T> &h, char *dev_base, char *host_base, size_t &off) {
+        if (p && !borrowed) (void)hipFree(p);
+        off = (off + 255) & ~(size_t)255;
+        p = reinterpret_cast<T *>(dev_base + off);
+        n = h.size();
+        borrowed = true;
+        if (!h.empty()) std::memcpy(host_base + off, h.data(), h.size() * sizeof(T));
+        off += h.size() * sizeof(T);
     }
     void upload(const std::vector<T> &h, hipStream_t s) {
         alloc(h.size());
@@ -174,6 +187,8 @@ struct smcpp_im {
         d_g_logscale, d_beta, d_cnorm, d_logc, d_ends_b, d_used_b, d_llpart, d_loglik, d_w1, d_gpart, d_Xs, d_Ys,
         d_part_e, d_part_1, d_red_e, d_red_1, d_red_g, d_Z, d_Y, d_xisum, d_gsum, d_gamma0, d_gamma_rows, d_Sq;
     PinnedArena stage;
+    char *d_param = nullptr;      // device side of the per-E-step parameter arena
+    size_t param_cap = 0;
     int llblk = 64;
     int ZS = 8;
     int max_pass = 0;
@@ -197,6 +212,7 @@ struct smcpp_im {
             (void)hipStreamDestroy(stream);
             if (stream2) (void)hipStreamDestroy(stream2);
         }
+        if (d_param) (void)hipFree(d_param);
     }
 
     void build(int npop_, const int *nn, const int *nna, int n_contigs_, const int *Ls_, const int *const *obs,
@@ -652,19 +668,6 @@ void smcpp_im::host_prep_and_upload() {
         }
     }
     if (!err.empty()) throw std::runtime_error(err);
-    {
-        size_t need = 64 * 256;
-        need += (pi_f.size() + Tf.size()) * 4 + 2 * MM * 4;
-        need += (TdT.size() + Td.size() + Ep.size() + PinvT.size() + PT.size() + Prm.size() + Pinvrm.size() + dsc.size() +
-                 dun.size() + dpow.size() + gsc.size() + gls.size() + 5 * MM) * 8;
-        stage.reset(need);
-    }
-    d_pi_f.upload_staged(pi_f, stage, s); d_Tf.upload_staged(Tf, stage, s); d_TdT.upload_staged(TdT, stage, s);
-    d_Td.upload_staged(Td, stage, s); d_E.upload_staged(Ep, stage, s);
-    d_PinvT.upload_staged(PinvT, stage, s); d_PT.upload_staged(PT, stage, s); d_Prm.upload_staged(Prm, stage, s);
-    d_Pinvrm.upload_staged(Pinvrm, stage, s);
-    d_dsc.upload_staged(dsc, stage, s); d_dun.upload_staged(dun, stage, s); d_dpow.upload_staged(dpow, stage, s);
-    d_g_scale.upload_staged(gsc, stage, s); d_g_logscale.upload_staged(gls, stage, s);
     std::vector<float> T4;
     std::vector<double> fA2, fB2, bA2, bB2, bC2;
     if (Mp <= 64) {
@@ -685,9 +688,33 @@ void smcpp_im::host_prep_and_upload() {
                     bC2[i2] = Pinvrm[h * MM + (size_t)k * Mp + i];
                 }
             }
-        d_T4.upload_staged(T4, stage, s); d_fA2.upload_staged(fA2, stage, s); d_fB2.upload_staged(fB2, stage, s);
-        d_bA2.upload_staged(bA2, stage, s); d_bB2.upload_staged(bB2, stage, s); d_bC2.upload_staged(bC2, stage, s);
     }
+    // ---- one contiguous parameter arena on the device, mirrored in pinned host memory: ONE copy per E-step ----
+    size_t need = 32 * 256;
+    need += (pi_f.size() + Tf.size() + T4.size()) * 4;
+    need += (TdT.size() + Td.size() + Ep.size() + PinvT.size() + PT.size() + Prm.size() + Pinvrm.size() + dsc.size() +
+             dun.size() + dpow.size() + gsc.size() + gls.size() + fA2.size() + fB2.size() + bA2.size() + bB2.size() +
+             bC2.size()) * 8;
+    stage.reset(need);
+    if (need > param_cap) {
+        if (d_param) (void)hipFree(d_param);
+        param_cap = need + need / 4;
+        HIPCHK(hipMalloc((void **)&d_param, param_cap));
+    }
+    size_t off = 0;
+    char *hb = stage.base;
+    d_pi_f.place(pi_f, d_param, hb, off); d_Tf.place(Tf, d_param, hb, off); d_TdT.place(TdT, d_param, hb, off);
+    d_Td.place(Td, d_param, hb, off); d_E.place(Ep, d_param, hb, off);
+    d_PinvT.place(PinvT, d_param, hb, off); d_PT.place(PT, d_param, hb, off); d_Prm.place(Prm, d_param, hb, off);
+    d_Pinvrm.place(Pinvrm, d_param, hb, off);
+    d_dsc.place(dsc, d_param, hb, off); d_dun.place(dun, d_param, hb, off); d_dpow.place(dpow, d_param, hb, off);
+    d_g_scale.place(gsc, d_param, hb, off); d_g_logscale.place(gls, d_param, hb, off);
+    if (Mp <= 64) {
+        d_T4.place(T4, d_param, hb, off); d_fA2.place(fA2, d_param, hb, off); d_fB2.place(fB2, d_param, hb, off);
+        d_bA2.place(bA2, d_param, hb, off); d_bB2.place(bB2, d_param, hb, off); d_bC2.place(bC2, d_param, hb, off);
+    }
+    if (off > need) throw std::runtime_error("internal: parameter arena overflow");
+    HIPCHK(hipMemcpyAsync(d_param, hb, off, hipMemcpyHostToDevice, s));
     // no synchronisation: the copies read the pinned arena, which lives until the next E-step resets it
 }
 

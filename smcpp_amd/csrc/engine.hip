@@ -37,7 +37,10 @@ static thread_local std::string g_err;
 extern "C" void kmp_set_blocktime(int) __attribute__((weak));
 namespace {
 struct OmpInit {
-    OmpInit() { if (kmp_set_blocktime) kmp_set_blocktime(0); }
+    OmpInit() {
+        const char *e = getenv("SMCPP_OMP_BLOCKTIME");
+        if (kmp_set_blocktime) kmp_set_blocktime(e ? atoi(e) : 0);
+    }
 } g_omp_init;
 }
 
@@ -188,6 +191,9 @@ struct smcpp_im {
         d_part_e, d_part_1, d_red_e, d_red_1, d_red_g, d_Z, d_Y, d_xisum, d_gsum, d_gamma0, d_gamma_rows, d_Sq;
     PinnedArena stage;
     char *d_param = nullptr;      // device side of the per-E-step parameter arena
+    int *h_flags = nullptr;       // pinned: per-pass "something re-ran" flags of both chains, read back every round
+    double *h_ll = nullptr;       // pinned: per-contig log-likelihoods
+    int h_flags_cap = 0, h_ll_cap = 0;
     size_t param_cap = 0;
     int llblk = 64;
     int ZS = 8;
@@ -213,6 +219,8 @@ struct smcpp_im {
             if (stream2) (void)hipStreamDestroy(stream2);
         }
         if (d_param) (void)hipFree(d_param);
+        if (h_flags) (void)hipHostFree(h_flags);
+        if (h_ll) (void)hipHostFree(h_ll);
     }
 
     void build(int npop_, const int *nn, const int *nna, int n_contigs_, const int *Ls_, const int *const *obs,
@@ -863,8 +871,13 @@ void smcpp_im::run_chains() {
     if (getenv("SMCPP_DEBUG_CYCLES")) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }
     d_changed_f.zero(s);
     d_changed_b.zero(s);
-    std::vector<int> chf(max_pass + 1), chb(max_pass + 1);
-    auto first_quiet = [](const std::vector<int> &ch, int upto) {
+    if (h_flags_cap < 2 * (max_pass + 1)) {
+        if (h_flags) (void)hipHostFree(h_flags);
+        h_flags_cap = 2 * (max_pass + 1);
+        HIPCHK(hipHostMalloc((void **)&h_flags, sizeof(int) * h_flags_cap, hipHostMallocDefault));
+    }
+    int *chf = h_flags, *chb = h_flags + (max_pass + 1);
+    auto first_quiet = [](const int *ch, int upto) {
         for (int j = 0; j < upto; ++j)
             if (ch[j] == 0) return j;
         return -1;
@@ -904,8 +917,8 @@ void smcpp_im::run_chains() {
         }
         HIPCHK(hipGetLastError());
         if (first_round && dual) HIPCHK(hipEventRecord(ev[7], s));      // end of the first batch of forward passes
-        HIPCHK(hipMemcpyAsync(chf.data(), d_changed_f.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(chb.data(), d_changed_b.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, sb));
+        HIPCHK(hipMemcpyAsync(chf, d_changed_f.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(chb, d_changed_b.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, sb));
         if (dual) {
             HIPCHK(hipEventRecord(ev[6], sb));
             HIPCHK(hipStreamWaitEvent(s, ev[6], 0));   // the statistics (main stream) need both chains
@@ -1022,9 +1035,15 @@ void smcpp_im::run_stats() {
         hipLaunchKernelGGL(k_gamma_rows_eig, dim3((unsigned)n_e_rows), dim3(256), shm, s, ga);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(loglik.data(), d_loglik.p, sizeof(double) * n_contigs, hipMemcpyDeviceToHost, s));
+    if (h_ll_cap < n_contigs) {
+        if (h_ll) (void)hipHostFree(h_ll);
+        h_ll_cap = n_contigs;
+        HIPCHK(hipHostMalloc((void **)&h_ll, sizeof(double) * h_ll_cap, hipHostMallocDefault));
+    }
+    HIPCHK(hipMemcpyAsync(h_ll, d_loglik.p, sizeof(double) * n_contigs, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(ev[5], s));
     HIPCHK(hipStreamSynchronize(s));
+    std::memcpy(loglik.data(), h_ll, sizeof(double) * n_contigs);
 }
 
 void smcpp_im::estep() {

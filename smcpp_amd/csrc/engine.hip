@@ -149,6 +149,7 @@ struct smcpp_im {
     int user_rows_per_chunk = 0;
     // sorted permutations and slabs
     std::vector<int> perm1, perme;
+    std::vector<int2> perm1k;
     std::vector<Slab> slabs_sc, slabs_rk, slabs_eg;   // span-1 scalar slabs, span-1 rank slabs, eigen slabs
     std::vector<int> gk_slab_off, s1_slab_off, eb_slab_off, eb_gid, ce_bucket_off, erow_slab;
     long long n_e_rows = 0, n_1_rows = 0;
@@ -182,6 +183,7 @@ struct smcpp_im {
     int hot_eig = -1;
     DevBuf<Chunk> d_chunks;
     DevBuf<Slab> d_slabs_sc, d_slabs_rk, d_slabs_eg;
+    DevBuf<int2> d_perm1k;                 // span-1 rows sorted by key: {ell, key id} (one load resolves both)
     DevBuf<int> d_perm1, d_perme, d_gk_slab_off, d_s1_slab_off, d_eb_slab_off, d_eb_gid, d_ce_bucket_off,
         d_erow_slab, d_g_span, d_g_eig, d_e_kid, d_contig_L, d_changed_f, d_changed_b, d_argmax;
     DevBuf<long long> d_contig_base;
@@ -410,7 +412,7 @@ void smcpp_im::make_chunks() {
 
 void smcpp_im::make_slabs() {
     // counting sorts of rows per contig
-    perm1.clear(); perme.clear();
+    perm1.clear(); perme.clear(); perm1k.clear();
     slabs_sc.clear(); slabs_rk.clear(); slabs_eg.clear();
     gk_slab_off.assign((size_t)n_contigs * K + 1, 0);
     s1_slab_off.assign(n_contigs + 1, 0);
@@ -424,7 +426,9 @@ void smcpp_im::make_slabs() {
         for (int i = 1; i <= Ls[c]; ++i) (rowinfo[(size_t)contig_base[c] + i].gid < 0 ? n1 : ne)++;
     n_1_rows = n1; n_e_rows = ne;
     const long long part_bytes = (long long)Mp * Mp * 8;
-    const long long target = std::max<long long>(256, std::min<long long>(2048, (64ll << 20) / part_bytes));
+    // slabs = independent single-wavefront work items; several thousand keep the 2048 resident wavefronts of the
+    // chip balanced on large inputs (each slab owns an Mp x Mp partial: at most 256 MB of them)
+    const long long target = std::max<long long>(256, std::min<long long>(8192, (256ll << 20) / part_bytes));
     int S_RK = (int)std::max<long long>(64, (n1 + target - 1) / target);
     S_RK = (S_RK + 3) / 4 * 4;
     int S_EG = (int)std::max<long long>(64, (ne + target - 1) / target);
@@ -445,6 +449,7 @@ void smcpp_im::make_slabs() {
             gk_slab_off[(size_t)c * K + k] = (int)slabs_sc.size();
             const int s0 = (int)perm1.size();
             perm1.insert(perm1.end(), by_key[k].begin(), by_key[k].end());
+            for (int ell : by_key[k]) perm1k.push_back(make_int2(ell, k));
             const int s1 = (int)perm1.size();
             for (int s = s0; s < s1; s += S_SC)
                 slabs_sc.push_back(Slab{s, std::min(s + S_SC, s1), c * K + k, k, base});
@@ -501,6 +506,7 @@ void smcpp_im::alloc_device() {
     d_slabs_rk.upload(slabs_rk, s);
     d_slabs_eg.upload(slabs_eg, s);
     d_perm1.upload(perm1, s);
+    d_perm1k.upload(perm1k, s);
     d_perme.upload(perme, s);
     d_gk_slab_off.upload(gk_slab_off, s);
     d_s1_slab_off.upload(s1_slab_off, s);
@@ -530,8 +536,9 @@ void smcpp_im::alloc_device() {
     d_llpart.alloc((size_t)n_contigs * llblk);
     d_loglik.alloc(n_contigs);
     d_gpart.alloc(std::max<size_t>(1, slabs_sc.size()) * Mp);
-    d_Xs.alloc(std::max<size_t>(1, (size_t)n_e_rows) * Mp);
-    d_Ys.alloc(std::max<size_t>(1, (size_t)n_e_rows) * Mp);
+    // omega*U and W of the eigen rows only go through memory when the fused kernel cannot be used (M > 64)
+    d_Xs.alloc(NT <= 4 ? 1 : std::max<size_t>(1, (size_t)n_e_rows) * Mp);
+    d_Ys.alloc(NT <= 4 ? 1 : std::max<size_t>(1, (size_t)n_e_rows) * Mp);
     d_part_e.alloc(std::max<size_t>(1, slabs_eg.size()) * Mp * Mp);
     d_part_1.alloc(std::max<size_t>(1, slabs_rk.size()) * Mp * Mp);
     d_red_e.alloc(std::max<size_t>(1, eb_gid.size()) * ZS * Mp * Mp);
@@ -990,12 +997,12 @@ void smcpp_im::run_stats() {
     aa.M = M; aa.Mp = Mp; aa.NB = (Mp + 63) / 64; aa.rowinfo = d_rowinfo.p; aa.alpha = d_alpha.p; aa.beta = d_beta.p;
     aa.w1 = d_w1.p; aa.E = d_E.p; aa.Xs = d_Xs.p; aa.Ys = d_Ys.p;
     if (!slabs_rk.empty()) {
-        aa.nslabs = (int)slabs_rk.size(); aa.slabs = d_slabs_rk.p; aa.perm = d_perm1.p; aa.part = d_part_1.p;
+        aa.nslabs = (int)slabs_rk.size(); aa.slabs = d_slabs_rk.p; aa.perm = d_perm1.p; aa.permk = d_perm1k.p; aa.part = d_part_1.p;
         hipLaunchKernelGGL(k_rank_acc<0>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, s, aa);
     }
-    hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 32), n_contigs * K, 1), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, s,
                        (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
-    hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 32), n_contigs, ZS), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), n_contigs, ZS), dim3(256), 0, s,
                        (const double *)d_part_1.p, (const int *)d_s1_slab_off.p, d_red_1.p, MMi, ZS);
     HIPCHK(hipEventRecord(ev[4], s));
     // ---- eigen branch (second stream when available) ----
@@ -1004,12 +1011,21 @@ void smcpp_im::run_stats() {
         ua.M = M; ua.Mp = Mp; ua.nslabs = (int)slabs_eg.size(); ua.slabs = d_slabs_eg.p; ua.perm = d_perme.p;
         ua.alpha = d_alpha.p; ua.beta = d_beta.p; ua.g_eig = d_g_eig.p; ua.g_scale = d_g_scale.p;
         ua.dpow = d_dpow.p; ua.PinvT = d_PinvT.p; ua.Prm = d_Prm.p; ua.Xs = d_Xs.p; ua.Ys = d_Ys.p;
-        launch_uw(NT, ua, se);
-        AccArgs ae = aa;
-        ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
-        hipLaunchKernelGGL(k_rank_acc<1>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
+        if (NT <= 4) {
+            switch (NT) {
+                case 1: hipLaunchKernelGGL(k_eig_fused<1>, dim3(ua.nslabs), dim3(64), 0, se, ua, d_part_e.p); break;
+                case 2: hipLaunchKernelGGL(k_eig_fused<2>, dim3(ua.nslabs), dim3(64), 0, se, ua, d_part_e.p); break;
+                case 3: hipLaunchKernelGGL(k_eig_fused<3>, dim3(ua.nslabs), dim3(64), 0, se, ua, d_part_e.p); break;
+                default: hipLaunchKernelGGL(k_eig_fused<4>, dim3(ua.nslabs), dim3(64), 0, se, ua, d_part_e.p); break;
+            }
+        } else {
+            launch_uw(NT, ua, se);
+            AccArgs ae = aa;
+            ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
+            hipLaunchKernelGGL(k_rank_acc<1>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
+        }
         if (!eb_gid.empty())
-            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 32), (unsigned)eb_gid.size(), ZS), dim3(256), 0, se,
+            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), (unsigned)eb_gid.size(), ZS), dim3(256), 0, se,
                                (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MMi, ZS);
     }
     if (Ke > 0) {

@@ -1434,27 +1434,26 @@ __global__ __launch_bounds__(256) void k_s1_scalars(S1Args a) {
 }
 
 // Deterministic reduction of per-slab partials: out[(b*ZS + z)][len] = sum over the z-th share of bucket b's slabs.
-// block = 32 consecutive elements x 8 slab lanes; grid = (ceil(len/32), buckets, ZS).
+// One thread per output element, four independent partial sums over the slabs of its share (fixed order, no atomics):
+// every wavefront reads 512 contiguous bytes of each slab.  grid = (ceil(len/256), buckets, ZS).
 __global__ __launch_bounds__(256) void k_sum_parts(const double *__restrict__ part, const int *__restrict__ off,
                                                    double *__restrict__ out, int len, int ZS) {
-    __shared__ double red[8][32];
-    const int il = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + il;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y, z = blockIdx.z;
     const int s0 = off[b], s1 = off[b + 1];
     const int per = (s1 - s0 + ZS - 1) / ZS;
     const int lo = s0 + z * per, hi = min(s1, lo + per);
-    double acc = 0.0;
-    if (idx < len)
-        for (int s = lo + sl; s < hi; s += 8) acc += part[(size_t)s * len + idx];
-    red[sl][il] = acc;
-    __syncthreads();
-    if (sl == 0 && idx < len) {
-        double t = red[0][il];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) t += red[k][il];
-        out[((size_t)b * ZS + z) * len + idx] = t;
+    if (idx >= len) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int s = lo;
+    for (; s + 3 < hi; s += 4) {
+        a0 += part[(size_t)s * len + idx];
+        a1 += part[(size_t)(s + 1) * len + idx];
+        a2 += part[(size_t)(s + 2) * len + idx];
+        a3 += part[(size_t)(s + 3) * len + idx];
     }
+    for (; s < hi; ++s) a0 += part[(size_t)s * len + idx];
+    out[((size_t)b * ZS + z) * len + idx] = (a0 + a1) + (a2 + a3);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1535,6 +1534,91 @@ __global__ __launch_bounds__(64) void k_eig_uw(UWArgs a) {
     }
 }
 
+// K5+K4 fused (Mp <= 64): the D registers of the U / W products ARE the A / B fragments of the rank update
+// (rows r0+4r .. r0+4r+3 sit on lanes qd = 0..3), so the slab's  sum_rows (omega U) W^T  is accumulated in the same
+// wavefront without omega*U and W ever going to memory (saves 2 x 8M bytes written and read per eigen row).
+template <int NT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_eig_fused(UWArgs a, double *part) {
+    constexpr int KQ = 4 * NT;                 // states per lane of the k dimension: lane (m, qd) owns KQ*qd .. +KQ-1
+    const int lane = threadIdx.x;
+    const int m = lane & 15, qd = lane >> 4;
+    const Slab sl = a.slabs[blockIdx.x];
+    const int Mp = a.Mp;
+    const int es = a.g_eig[sl.aux];
+    const double *PinvT = a.PinvT + (size_t)es * Mp * Mp;
+    const double *Prm = a.Prm + (size_t)es * Mp * Mp;
+    const double *dp = a.dpow + (size_t)sl.aux * Mp;
+    const double scale = a.g_scale[sl.aux];
+    f64x4 acc[NT][NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
+    for (int r0 = sl.start; r0 < sl.end; r0 += 16) {
+        const int ra = r0 + m;
+        const bool va = ra < sl.end;
+        const int ell_a = va ? a.perm[ra] : 1;
+        // The MFMA sums over k in any order, so k-step kk of lane (m, qd) is state KQ*qd + kk: every lane reads ONE
+        // contiguous 16*NT-byte (alpha) / 32*NT-byte (beta) piece of its row instead of a stride-4 gather.
+        const float4 *arow = reinterpret_cast<const float4 *>(a.alpha + (size_t)(sl.base + ell_a - 1) * Mp + KQ * qd);
+        const double2 *brow = reinterpret_cast<const double2 *>(a.beta + (size_t)(sl.base + ell_a) * Mp + KQ * qd);
+        f64x4 U[NT], W[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { U[t] = (f64x4){0, 0, 0, 0}; W[t] = (f64x4){0, 0, 0, 0}; }
+        // four k-steps per block; the next block's piece of the two rows is in flight while this one is multiplied
+        // (keeping all 16*NT bytes + every B operand live at once costs 512 registers and scratch: one wavefront per
+        // SIMD and a scratch-limited launch, measured 6x slower)
+        float4 a4 = va ? arow[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        double2 b01 = va ? brow[0] : make_double2(0.0, 0.0), b23 = va ? brow[1] : make_double2(0.0, 0.0);
+#pragma unroll 1
+        for (int t4 = 0; t4 < NT; ++t4) {
+            const float avv[4] = {a4.x, a4.y, a4.z, a4.w};
+            const double bvv[4] = {b01.x, b01.y, b23.x, b23.y};
+            if (t4 + 1 < NT) {
+                a4 = va ? arow[t4 + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                b01 = va ? brow[2 * t4 + 2] : make_double2(0.0, 0.0);
+                b23 = va ? brow[2 * t4 + 3] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int st = KQ * qd + 4 * t4 + k4;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const double pinv = PinvT[(size_t)st * Mp + 16 * t + m];   // B[k][n = 16t+m] = Pinv[16t+m][st]
+                    const double pp = Prm[(size_t)st * Mp + 16 * t + m];       // B[k][n = 16t+m] = P[st][16t+m]
+                    U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)avv[k4], pinv, U[t], 0, 0, 0);
+                    W[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(bvv[k4], pp, W[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double pr = 0.0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) pr += dp[16 * t + m] * U[t][r] * W[t][r];
+            const double sm = row16_sum(pr);
+            const bool vr = r0 + qd + 4 * r < sl.end;        // padded rows carry U = W = 0 and must stay 0
+            const double om = vr ? 1.0 / (scale * sm) : 0.0;
+            double xa[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xa[t] = om * U[t][r];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], W[j][r], acc[i][j], 0, 0, 0);
+        }
+    }
+    double *out = part + (size_t)blockIdx.x * Mp * Mp;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                out[(size_t)(16 * i + qd + 4 * rg) * Mp + 16 * j + m] = acc[i][j][rg];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // K4: rank-k accumulation  C_slab[j][k] = sum_rows X_row[j] * Y_row[k]   (fp64 MFMA, 64x64 output block per wave)
 //   MODE 0 (span-1 rows, hmm.cpp:137-138):  X = w1 * alpha_{ell-1},  Y = beta_ell o e_key
@@ -1545,6 +1629,7 @@ struct AccArgs {
     int M, Mp, nslabs, NB;
     const Slab *slabs;
     const int *perm;
+    const int2 *permk;        // MODE 0: {ell, key id} per sorted span-1 row
     const RowInfo *rowinfo;
     const float *alpha;
     const double *beta;
@@ -1566,25 +1651,54 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
-    for (int r0 = sl.start; r0 < sl.end; r0 += 4) {
-        const int r = r0 + qd;                 // this lane's data row (the MFMA k index)
-        const bool valid = r < sl.end;
-        double xa[4], yb[4];
-        if (MODE == 0) {
-            const int ell = valid ? a.perm[r] : 1;
-            const size_t row = (size_t)(sl.base + ell);
-            const double w = valid ? a.w1[row] : 0.0;
-            const int kid = a.rowinfo[row].kid;
+    if (MODE == 0) {
+        // Software pipeline over groups of 4 rows (the MFMA k dimension): the {ell, key} pair is fetched two groups
+        // ahead and the operands one group ahead, so the dependent chain  index -> row -> operands  (three memory
+        // round trips, measured 4.8 us per group against 0.43 us of MFMA) no longer serialises every group.
+        auto fetch_pk = [&](int r0) {
+            const int r = r0 + qd;
+            return (r < sl.end) ? a.permk[r] : make_int2(-1, 0);
+        };
+        struct Ops { double w; float ap[4]; double bp[4], ep[4]; };
+        auto fetch_ops = [&](const int2 pk) {
+            Ops o;
+            const bool valid = pk.x >= 0;
+            const size_t row = (size_t)(sl.base + (valid ? pk.x : 1));
+            o.w = valid ? a.w1[row] : 0.0;
             const float *ap = a.alpha + (row - 1) * Mp;
             const double *bp = a.beta + row * Mp;
-            const double *ep = a.E + (size_t)kid * Mp;
+            const double *ep = a.E + (size_t)pk.y * Mp;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int j = jb + 16 * t + m, k = kb + 16 * t + m;
-                xa[t] = (valid && j < Mp) ? w * (double)ap[j] : 0.0;
-                yb[t] = (valid && k < Mp) ? bp[k] * ep[k] : 0.0;
+                o.ap[t] = (valid && j < Mp) ? ap[j] : 0.f;
+                o.bp[t] = (valid && k < Mp) ? bp[k] : 0.0;
+                o.ep[t] = (k < Mp) ? ep[k] : 0.0;
             }
-        } else {
+            return o;
+        };
+        int2 pk1 = fetch_pk(sl.start);
+        Ops cur = fetch_ops(pk1);
+        pk1 = fetch_pk(sl.start + 4);
+        for (int r0 = sl.start; r0 < sl.end; r0 += 4) {
+            const int2 pk2 = fetch_pk(r0 + 8);
+            const Ops nxt = fetch_ops(pk1);          // operands of group r0 + 4 (all-zero past the end of the slab)
+            double xa[4], yb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { xa[t] = cur.w * (double)cur.ap[t]; yb[t] = cur.bp[t] * cur.ep[t]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], yb[j], acc[i][j], 0, 0, 0);
+            cur = nxt;
+            pk1 = pk2;
+        }
+    } else {
+        for (int r0 = sl.start; r0 < sl.end; r0 += 4) {
+            const int r = r0 + qd;                 // this lane's data row (the MFMA k index)
+            const bool valid = r < sl.end;
+            double xa[4], yb[4];
             const size_t row = (size_t)(valid ? r : sl.start);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -1592,12 +1706,12 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
                 xa[t] = (valid && j < Mp) ? a.Xs[row * Mp + j] : 0.0;
                 yb[t] = (valid && k < Mp) ? a.Ys[row * Mp + k] : 0.0;
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], yb[j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], yb[j], acc[i][j], 0, 0, 0);
     }
     double *out = a.part + (size_t)blockIdx.x * Mp * Mp;
 #pragma unroll

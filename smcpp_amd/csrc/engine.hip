@@ -455,6 +455,10 @@ void smcpp_im::make_slabs() {
                 slabs_sc.push_back(Slab{s, std::min(s + S_SC, s1), c * K + k, k, base});
         }
         const int seg_end = (int)perm1.size();
+        // the rank update does not need key-homogeneous slabs (the key only selects an L2-resident emission vector):
+        // its copy of the permutation runs in natural row order, so every slab streams through alpha / beta
+        std::sort(perm1k.begin() + seg_start, perm1k.begin() + seg_end,
+                  [](const int2 &x, const int2 &y) { return x.x < y.x; });
         s1_slab_off[c] = (int)slabs_rk.size();
         for (int s = seg_start; s < seg_end; s += S_RK)
             slabs_rk.push_back(Slab{s, std::min(s + S_RK, seg_end), c, -1, base});

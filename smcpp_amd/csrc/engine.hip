@@ -418,6 +418,7 @@ void smcpp_im::make_slabs() {
     s1_slab_off.assign(n_contigs + 1, 0);
     ce_bucket_off.assign((size_t)n_contigs * Ke + 1, 0);
     eb_slab_off.clear(); eb_gid.clear(); erow_slab.clear();
+    int last_eig_key = -1;
     long long n1 = 0, ne = 0;
     for (long long r = 0; r < total_rows; ++r) {
         // rows with ell = 0 have kid = 0, gid = -1 but are skipped below
@@ -467,6 +468,16 @@ void smcpp_im::make_slabs() {
             ce_bucket_off[(size_t)c * Ke + e] = (int)eb_gid.size();
             for (int g = 0; g < G; ++g) {
                 if (groups[g].eig != e || by_grp[g].empty()) continue;
+                // the fused eigen kernel shares one LDS copy of (Pinv, P) among the 4 slabs of a workgroup: pad with
+                // empty slabs (they add zero partials to the previous bucket) so that no workgroup mixes eigen keys
+                if (!slabs_eg.empty() && last_eig_key != e) {
+                    while (slabs_eg.size() % 4 != 0) {
+                        Slab pad = slabs_eg.back();
+                        pad.start = pad.end;
+                        slabs_eg.push_back(pad);
+                    }
+                }
+                last_eig_key = e;
                 eb_slab_off.push_back((int)slabs_eg.size());
                 eb_gid.push_back(g);
                 const int s0 = (int)perme.size();
@@ -1016,11 +1027,14 @@ void smcpp_im::run_stats() {
         ua.alpha = d_alpha.p; ua.beta = d_beta.p; ua.g_eig = d_g_eig.p; ua.g_scale = d_g_scale.p;
         ua.dpow = d_dpow.p; ua.PinvT = d_PinvT.p; ua.Prm = d_Prm.p; ua.Xs = d_Xs.p; ua.Ys = d_Ys.p;
         if (NT <= 4) {
+            const int nblk = ceil_div(ua.nslabs, 4);
+            const size_t shm = (size_t)2 * (16 * NT) * (16 * NT + 1) * sizeof(double);
             switch (NT) {
-                case 1: hipLaunchKernelGGL(k_eig_fused<1>, dim3(ua.nslabs), dim3(64), 0, se, ua, d_part_e.p); break;
-                case 2: hipLaunchKernelGGL(k_eig_fused<2>, dim3(ua.nslabs), dim3(64), 0, se, ua, d_part_e.p); break;
-                case 3: hipLaunchKernelGGL(k_eig_fused<3>, dim3(ua.nslabs), dim3(64), 0, se, ua, d_part_e.p); break;
-                default: hipLaunchKernelGGL(k_eig_fused<4>, dim3(ua.nslabs), dim3(64), 0, se, ua, d_part_e.p); break;
+#define F_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_eig_fused<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
+                        hipLaunchKernelGGL(k_eig_fused<x>, dim3(nblk), dim3(256), shm, se, ua, d_part_e.p); } break;
+                F_(1) F_(2) F_(3)
+                default: F_(4)
+#undef F_
             }
         } else {
             launch_uw(NT, ua, se);

@@ -1538,15 +1538,32 @@ __global__ __launch_bounds__(64) void k_eig_uw(UWArgs a) {
 // (rows r0+4r .. r0+4r+3 sit on lanes qd = 0..3), so the slab's  sum_rows (omega U) W^T  is accumulated in the same
 // wavefront without omega*U and W ever going to memory (saves 2 x 8M bytes written and read per eigen row).
 template <int NT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_eig_fused(UWArgs a, double *part) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_eig_fused(UWArgs a, double *part) {
     constexpr int KQ = 4 * NT;                 // states per lane of the k dimension: lane (m, qd) owns KQ*qd .. +KQ-1
-    const int lane = threadIdx.x;
+    constexpr int MT = 16 * NT;
+    constexpr int LD = MT + 1;                 // padded row: lanes qd and qd+1 of one LDS pass land 32 banks apart
+    extern __shared__ double eig_lds[];        // [2][MT][LD]: Pinv^T and P of the eigen key of this block's first slab
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m = lane & 15, qd = lane >> 4;
-    const Slab sl = a.slabs[blockIdx.x];
     const int Mp = a.Mp;
-    const int es = a.g_eig[sl.aux];
-    const double *PinvT = a.PinvT + (size_t)es * Mp * Mp;
-    const double *Prm = a.Prm + (size_t)es * Mp * Mp;
+    const int slab0 = blockIdx.x * 4;
+    const int es0 = a.g_eig[a.slabs[slab0].aux];
+    {
+        // the B operands of the U / W products are the same two matrices for every row of a key: one copy per
+        // workgroup in LDS instead of 2 x 16 x NT dependent L2 loads per 16-row tile (measured: 64 serialised round
+        // trips, 37 us per tile)
+        const double *g0 = a.PinvT + (size_t)es0 * Mp * Mp, *g1 = a.Prm + (size_t)es0 * Mp * Mp;
+        for (int idx = threadIdx.x; idx < MT * MT; idx += 256) {
+            const int r = idx / MT, c = idx % MT;
+            eig_lds[r * LD + c] = g0[(size_t)r * Mp + c];
+            eig_lds[MT * LD + r * LD + c] = g1[(size_t)r * Mp + c];
+        }
+    }
+    __syncthreads();
+    const int slab = slab0 + wv;
+    if (slab >= a.nslabs) return;
+    const Slab sl = a.slabs[slab];
+    const double *sPinvT = eig_lds, *sPrm = eig_lds + MT * LD;   // the host pads the slab list: one key per workgroup
     const double *dp = a.dpow + (size_t)sl.aux * Mp;
     const double scale = a.g_scale[sl.aux];
     f64x4 acc[NT][NT];
@@ -1555,9 +1572,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
     for (int r0 = sl.start; r0 < sl.end; r0 += 16) {
-        const int ra = r0 + m;
-        const bool va = ra < sl.end;
-        const int ell_a = va ? a.perm[ra] : 1;
+        // rows past the end of the slab re-read its last row (unconditional loads: see k_rank_acc) and get omega = 0
+        const int ra = min(r0 + m, sl.end - 1);
+        const int ell_a = a.perm[ra];
         // The MFMA sums over k in any order, so k-step kk of lane (m, qd) is state KQ*qd + kk: every lane reads ONE
         // contiguous 16*NT-byte (alpha) / 32*NT-byte (beta) piece of its row instead of a stride-4 gather.
         const float4 *arow = reinterpret_cast<const float4 *>(a.alpha + (size_t)(sl.base + ell_a - 1) * Mp + KQ * qd);
@@ -1566,26 +1583,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
 #pragma unroll
         for (int t = 0; t < NT; ++t) { U[t] = (f64x4){0, 0, 0, 0}; W[t] = (f64x4){0, 0, 0, 0}; }
         // four k-steps per block; the next block's piece of the two rows is in flight while this one is multiplied
-        // (keeping all 16*NT bytes + every B operand live at once costs 512 registers and scratch: one wavefront per
-        // SIMD and a scratch-limited launch, measured 6x slower)
-        float4 a4 = va ? arow[0] : make_float4(0.f, 0.f, 0.f, 0.f);
-        double2 b01 = va ? brow[0] : make_double2(0.0, 0.0), b23 = va ? brow[1] : make_double2(0.0, 0.0);
+        float4 a4 = arow[0];
+        double2 b01 = brow[0], b23 = brow[1];
 #pragma unroll 1
         for (int t4 = 0; t4 < NT; ++t4) {
             const float avv[4] = {a4.x, a4.y, a4.z, a4.w};
             const double bvv[4] = {b01.x, b01.y, b23.x, b23.y};
-            if (t4 + 1 < NT) {
-                a4 = va ? arow[t4 + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-                b01 = va ? brow[2 * t4 + 2] : make_double2(0.0, 0.0);
-                b23 = va ? brow[2 * t4 + 3] : make_double2(0.0, 0.0);
+            {
+                const int tn = min(t4 + 1, NT - 1);      // the last block re-reads itself instead of branching
+                a4 = arow[tn];
+                b01 = brow[2 * tn];
+                b23 = brow[2 * tn + 1];
             }
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
                 const int st = KQ * qd + 4 * t4 + k4;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const double pinv = PinvT[(size_t)st * Mp + 16 * t + m];   // B[k][n = 16t+m] = Pinv[16t+m][st]
-                    const double pp = Prm[(size_t)st * Mp + 16 * t + m];       // B[k][n = 16t+m] = P[st][16t+m]
+                    // B[k][n = 16t+m] = Pinv[16t+m][st]  and  P[st][16t+m]
+                    const double pinv = sPinvT[st * LD + 16 * t + m];
+                    const double pp = sPrm[st * LD + 16 * t + m];
                     U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)avv[k4], pinv, U[t], 0, 0, 0);
                     W[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(bvv[k4], pp, W[t], 0, 0, 0);
                 }
@@ -1597,7 +1614,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
 #pragma unroll
             for (int t = 0; t < NT; ++t) pr += dp[16 * t + m] * U[t][r] * W[t][r];
             const double sm = row16_sum(pr);
-            const bool vr = r0 + qd + 4 * r < sl.end;        // padded rows carry U = W = 0 and must stay 0
+            const bool vr = r0 + qd + 4 * r < sl.end;        // padded rows must not contribute
             const double om = vr ? 1.0 / (scale * sm) : 0.0;
             double xa[NT];
 #pragma unroll
@@ -1609,7 +1626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], W[j][r], acc[i][j], 0, 0, 0);
         }
     }
-    double *out = part + (size_t)blockIdx.x * Mp * Mp;
+    double *out = part + (size_t)slab * Mp * Mp;
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -1655,26 +1672,35 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
         // Software pipeline over groups of 4 rows (the MFMA k dimension): the {ell, key} pair is fetched two groups
         // ahead and the operands one group ahead, so the dependent chain  index -> row -> operands  (three memory
         // round trips, measured 4.8 us per group against 0.43 us of MFMA) no longer serialises every group.
+        // every load is unconditional (indices clamped into the slab / the matrix, results masked afterwards):
+        // a load under an exec-mask branch makes the compiler fall back to s_waitcnt vmcnt(0), which would drain the
+        // prefetched group as well
+        const int last = sl.end - 1;
         auto fetch_pk = [&](int r0) {
             const int r = r0 + qd;
-            return (r < sl.end) ? a.permk[r] : make_int2(-1, 0);
+            int2 pk = a.permk[min(r, last)];
+            pk.x = (r <= last) ? pk.x : -1;
+            return pk;
         };
-        struct Ops { double w; float ap[4]; double bp[4], ep[4]; };
-        auto fetch_ops = [&](const int2 pk) {
+        struct Ops { double w; float ap[4]; double bp[4], ep[4]; bool valid; };
+        int jc[4], kc[4];
+        bool jv[4], kv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = jb + 16 * t + m, k = kb + 16 * t + m;
+            jv[t] = j < Mp; kv[t] = k < Mp;
+            jc[t] = jv[t] ? j : 0; kc[t] = kv[t] ? k : 0;
+        }
+        auto fetch_ops = [&](const int2 pk) {      // raw loads only; masking happens where the values are consumed
             Ops o;
-            const bool valid = pk.x >= 0;
-            const size_t row = (size_t)(sl.base + (valid ? pk.x : 1));
-            o.w = valid ? a.w1[row] : 0.0;
+            o.valid = pk.x >= 0;
+            const size_t row = (size_t)(sl.base + (o.valid ? pk.x : 1));
+            o.w = a.w1[row];
             const float *ap = a.alpha + (row - 1) * Mp;
             const double *bp = a.beta + row * Mp;
             const double *ep = a.E + (size_t)pk.y * Mp;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int j = jb + 16 * t + m, k = kb + 16 * t + m;
-                o.ap[t] = (valid && j < Mp) ? ap[j] : 0.f;
-                o.bp[t] = (valid && k < Mp) ? bp[k] : 0.0;
-                o.ep[t] = (k < Mp) ? ep[k] : 0.0;
-            }
+            for (int t = 0; t < 4; ++t) { o.ap[t] = ap[jc[t]]; o.bp[t] = bp[kc[t]]; o.ep[t] = ep[kc[t]]; }
             return o;
         };
         int2 pk1 = fetch_pk(sl.start);
@@ -1685,7 +1711,10 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
             const Ops nxt = fetch_ops(pk1);          // operands of group r0 + 4 (all-zero past the end of the slab)
             double xa[4], yb[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { xa[t] = cur.w * (double)cur.ap[t]; yb[t] = cur.bp[t] * cur.ep[t]; }
+            for (int t = 0; t < 4; ++t) {
+                xa[t] = (cur.valid && jv[t]) ? cur.w * (double)cur.ap[t] : 0.0;
+                yb[t] = kv[t] ? cur.bp[t] * cur.ep[t] : 0.0;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--eps-alpha", type=float, default=0.0)
     ap.add_argument("--eps-beta", type=float, default=0.0)
+    ap.add_argument("--warm", action="store_true",
+                    help="additionally measure the opt-in warm start on a sequence of perturbed parameter sets "
+                         "(reported as an extra object; the headline value is always the cold E-step)")
     args = ap.parse_args()
 
     import torch
@@ -204,6 +207,38 @@ def main():
                 avg_launch_ms=1e3 * per_launch_s, algorithmic_flops_per_launch=flops,
                 algorithmic_bytes_per_launch=nbytes)
 
+    # ---- optional: warm start (smcpp_set_warm_start) on a parameter trajectory, the way an optimiser calls the path ----
+    warm_obj = None
+    if args.warm and world == 1:
+        rng = np.random.default_rng(11)
+
+        def perturbed(scale):
+            # every emission vector and the transition matrix move by a relative `scale` (rows of T renormalised)
+            Ep = np.clip(E * (1.0 + scale * rng.standard_normal(E.shape)), 1e-12, 1.0)
+            Tp = T * (1.0 + scale * rng.standard_normal(T.shape))
+            Tp *= (T.sum(axis=1) / Tp.sum(axis=1))[:, None]
+            return Tp, Ep
+
+        def sequence(warm):
+            im.set_warm_start(warm)
+            im.set_raw(pi, T, keys, E); im.E_step()            # iteration 0 (cold either way)
+            ts, lls = [], []
+            for it in range(args.steps):
+                Tp, Ep = perturbed(1e-2 / (1 + it))               # steps shrink as an EM run converges
+                t0 = time.perf_counter()
+                im.set_raw(pi, Tp, keys, Ep); im.E_step(); lls.append(im.loglik())
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts)), lls, im.last_timing()
+
+        rng = np.random.default_rng(11); t_cold, ll_cold, _ = sequence(False)
+        rng = np.random.default_rng(11); t_warm, ll_warm, tw = sequence(True)
+        im.set_warm_start(False)
+        warm_obj = {"note": "same sequence of perturbed parameter sets (relative step 1e-2/(1+it)) evaluated cold and with "
+                            "smcpp_set_warm_start; not part of `value`",
+                    "cold_ms_per_eval": 1e3 * t_cold, "warm_ms_per_eval": 1e3 * t_warm,
+                    "max_rel_loglik_diff": float(max(abs(a - b) / abs(a) for a, b in zip(ll_cold, ll_warm))),
+                    "warm_fwd_passes": tw["fwd_passes"], "warm_bwd_passes": tw["bwd_passes"]}
+
     out = None
     if rank == 0:
         med = {k: float(np.median([t[k] for t in timings])) for k in timings[0]}
@@ -222,6 +257,8 @@ def main():
             "split_ms": med,
             "roofline": roof,
         }
+        if warm_obj:
+            out["warm_start"] = warm_obj
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(par, obs, args.cpu_seconds, M)
             if out["cpu_baseline"] and out["cpu_baseline"].get("value"):

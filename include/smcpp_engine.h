@@ -113,6 +113,12 @@ int smcpp_unpack_stats(smcpp_im *im, const double *buf, long n, int dev);
 
 /* Rows per chunk of the chunk-parallel chains (0 = automatic) and the chunk-boundary convergence tolerances. */
 int smcpp_set_chunking(smcpp_im *im, int rows_per_chunk, double eps_alpha, double eps_beta);
+
+/* Extension (off by default): start the chunk-parallel chains of the next E-step from the converged chunk-boundary
+ * vectors of the previous E-step of this manager instead of pi / the uniform vector.  In an EM or optimiser loop the
+ * parameters move little between calls, so the re-run passes merge after a fraction of a chunk; the fixed-point
+ * iteration and its convergence certificate are unchanged, results agree with a cold start within eps. */
+int smcpp_set_warm_start(smcpp_im *im, int on);
 /* Kernel-time breakdown of the last E-step in milliseconds:
  * [host_prep, chains_wall, forward, backward, stats, finalize, total_device, fwd_passes, bwd_passes]
  * (forward and backward overlap when the two chains run on separate streams; chains_wall is their union) */

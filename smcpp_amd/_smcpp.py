@@ -222,6 +222,10 @@ class _PyInferenceManager:
     def set_chunking(self, rows_per_chunk=0, eps_alpha=0.0, eps_beta=0.0):
         E.check(E.lib().smcpp_set_chunking(self._im, int(rows_per_chunk), float(eps_alpha), float(eps_beta)))
 
+    def set_warm_start(self, on=True):
+        """Extension: reuse the previous E-step's converged chunk-boundary vectors as start vectors (see the header)."""
+        E.check(E.lib().smcpp_set_warm_start(self._im, int(bool(on))))
+
     def last_timing(self):
         t = np.zeros(9)
         E.check(E.lib().smcpp_last_timing(self._im, E.dptr(t)))

@@ -191,6 +191,10 @@ struct smcpp_im {
     DevBuf<double> d_E, d_dpow, d_PinvT, d_PT, d_TdT, d_Td, d_Prm, d_Pinvrm, d_dsc, d_dun, d_g_scale,
         d_g_logscale, d_beta, d_cnorm, d_logc, d_ends_b, d_used_b, d_llpart, d_loglik, d_w1, d_gpart, d_Xs, d_Ys,
         d_part_e, d_part_1, d_red_e, d_red_1, d_red_g, d_Z, d_Y, d_xisum, d_gsum, d_gamma0, d_gamma_rows, d_Sq;
+    // opt-in warm start: chunk-boundary vectors of the previous converged E-step (see smcpp_set_warm_start)
+    bool warm_start = false, warm_valid = false;
+    DevBuf<float> d_warm_f;
+    DevBuf<double> d_warm_b;
     PinnedArena stage;
     char *d_param = nullptr;      // device side of the per-E-step parameter arena
     int *h_flags = nullptr;       // pinned: per-pass "something re-ran" flags of both chains, read back every round
@@ -890,6 +894,10 @@ void smcpp_im::run_chains() {
     a.ends_f = d_ends_f.p; a.used_f = d_used_f.p; a.ends_b = d_ends_b.p; a.used_b = d_used_b.p;
     a.eps_f = eps_f; a.eps_b = eps_b;
     a.dbg = nullptr;
+    const bool warm = warm_start && warm_valid && chain_mode == 2 && Mp <= 64 &&
+                      d_warm_f.n == chunks.size() * (size_t)Mp && d_warm_b.n == chunks.size() * (size_t)Mp;
+    a.warm_f = warm ? d_warm_f.p : nullptr;
+    a.warm_b = warm ? d_warm_b.p : nullptr;
     if (getenv("SMCPP_DEBUG_CYCLES")) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }
     d_changed_f.zero(s);
     d_changed_b.zero(s);
@@ -967,6 +975,17 @@ void smcpp_im::run_chains() {
     if (fq < 0 || bq < 0) throw std::runtime_error("chunk-boundary iteration did not converge");
     last_fwd_passes = fq;
     last_bwd_passes = bq;
+    if (warm_start && chain_mode == 2 && Mp <= 64) {
+        // every pass after the first quiet one only copies the boundary vectors forward: the buffer of the last
+        // launched pass holds the converged ones
+        const size_t nel = chunks.size() * (size_t)Mp;
+        d_warm_f.alloc(nel); d_warm_b.alloc(nel);
+        HIPCHK(hipMemcpyAsync(d_warm_f.p, d_ends_f.p + (size_t)((launched_f - 1) & 1) * nel, nel * sizeof(float),
+                              hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_warm_b.p, d_ends_b.p + (size_t)((launched_b - 1) & 1) * nel, nel * sizeof(double),
+                              hipMemcpyDeviceToDevice, s));
+        warm_valid = true;
+    }
 }
 
 void smcpp_im::run_stats() {
@@ -1228,6 +1247,13 @@ int smcpp_set_params_twopop(smcpp_im *im, int Kd, const double *ad, const double
     im->have_model = true;
     im->have_raw = false;
     im->dirty = true;
+    API_END
+}
+
+int smcpp_set_warm_start(smcpp_im *im, int on) {
+    API_BEGIN
+    im->warm_start = on != 0;
+    if (!on) im->warm_valid = false;
     API_END
 }
 
@@ -1527,6 +1553,7 @@ int smcpp_set_chunking(smcpp_im *im, int rows_per_chunk, double eps_alpha, doubl
     if (eps_beta > 0) im->eps_b = eps_beta;
     if (rows_per_chunk != im->user_rows_per_chunk) {
         im->user_rows_per_chunk = rows_per_chunk;
+        im->warm_valid = false;
         im->make_chunks();
         const size_t nch = im->chunks.size();
         im->d_chunks.upload(im->chunks, im->stream);

@@ -127,6 +127,10 @@ struct ChainArgs {
     float eps_f;
     double eps_b;
     long long *dbg;         // optional [8]: cycle counters of workgroup 0 (SMCPP_DEBUG_CYCLES)
+    // optional warm start (cooperative kernels): the converged chunk-boundary vectors of the previous E-step of this
+    // manager, used instead of pi / the uniform vector as pass-0 start vectors; nullptr = cold start
+    const float *warm_f;    // [nchunks][Mp] end vectors of the forward chunks
+    const double *warm_b;   // [nchunks][Mp] end vectors of the backward chunks
 };
 
 // y_i = sum_k Mt[k][i] x_k with Mt streamed from global memory (L2) and x broadcast from LDS.
@@ -870,9 +874,9 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop(ChainArgs a, CoopArgs ca) {
     // ---- start vector (owner lanes hold state i) and the skip test ----
     float al = 0.f;
     {
-        const float *src = (ch.first || pass == 0)
-                               ? a.pi_f
-                               : a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + (c - 1)) * Mp;
+        const float *src = ch.first ? a.pi_f
+                           : pass == 0 ? (a.warm_f ? a.warm_f + (size_t)(c - 1) * Mp : a.pi_f)
+                                       : a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + (c - 1)) * Mp;
         if (i < M) al = src[i];
     }
     if (tid == 0) *sflag = 0;
@@ -1122,8 +1126,9 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop(ChainArgs a, CoopArgs ca) {
     }
     double b = 0.0;
     {
-        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (c + 1)) * Mp;
-        const bool fresh = (ch.last || pass == 0);
+        const double *src = (pass == 0) ? a.warm_b + (size_t)(c + 1) * Mp
+                                        : a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (c + 1)) * Mp;
+        const bool fresh = ch.last || (pass == 0 && a.warm_b == nullptr);
         if (i < M) b = fresh ? 1.0 / (double)M : src[i];
     }
     if (tid == 0) *sflag = 0;

@@ -351,3 +351,40 @@ def test_many_tiny_contigs():
         assert rel_err(xs[c], o["xisum"]) <= STAT_TOL
         assert sorted(gss[c].keys()) == sorted(o["gamma_sums"].keys())
     assert np.isfinite(im.loglik())
+
+
+def test_warm_start_matches_cold_start():
+    """Opt-in extension: an E-step that starts its chunk-parallel chains from the previous E-step's boundary vectors
+    must give what a cold manager gives on the same (perturbed) parameters, in fewer / shorter passes."""
+    from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel
+    g = load_golden("G4_M64_n20_2Mbp")
+    obs = synth.synth_contig(0, 30_000_000, 20)
+    a0 = np.array(g["a"], dtype=float)
+
+    def manager(warm):
+        im = _smcpp.PyOnePopInferenceManager(20, [obs], g["hs"], ("pop1",), float(g["pol"]))
+        im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = float(g["alpha"])
+        im.set_chunking(300)                       # many chunks so that the iteration matters at this size
+        if warm:
+            im.set_warm_start(True)
+        return im
+
+    warm, cold = manager(True), manager(False)
+    mw, mc = PiecewiseModel(a0, g["s"], 1e4, "pop1"), PiecewiseModel(a0, g["s"], 1e4, "pop1")
+    warm.model = mw; cold.model = mc
+    warm.E_step(); cold.E_step()
+    assert abs(warm.loglik() - cold.loglik()) <= 1e-12 * abs(cold.loglik())       # first call: nothing to reuse
+    rng = np.random.default_rng(3)
+    for it in range(3):
+        a1 = a0 * (1.0 + 0.02 * rng.standard_normal(len(a0)) / (it + 1))
+        mw[:] = a1; mc[:] = a1
+        warm.E_step(); cold.E_step()
+        lw, lc = warm.loglik(), cold.loglik()
+        assert abs(lw - lc) <= 1e-8 * abs(lc)
+        assert rel_err(warm.xisums[0], cold.xisums[0]) <= STAT_TOL
+        gw, gc = warm.gamma_sums[0], cold.gamma_sums[0]
+        for k, v in gc.items():
+            assert np.max(np.abs(gw[k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300)
+        tw, tc = warm.last_timing(), cold.last_timing()
+        assert tw["fwd_passes"] <= tc["fwd_passes"] and tw["bwd_passes"] <= tc["bwd_passes"]

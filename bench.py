@@ -141,11 +141,20 @@ def main():
         im.set_raw(pi, T, keys, E)          # parameters dirty: eigensystems, uploads, everything is redone
         im.E_step()
         if world > 1:
+            if backend == "nccl":
+                # the packed statistics are written by one kernel straight into the tensor RCCL reduces
+                if stats_buf is None:
+                    stats_buf = torch.empty(im.stats_len(), dtype=torch.float64, device=dev)
+                im.pack_stats_device(stats_buf.data_ptr())
+                dist.all_reduce(stats_buf, op=dist.ReduceOp.SUM)       # the single collective of the E-step
+                ll_sum = float(stats_buf[0].item())                   # (synchronises the reduction)
+                im.unpack_stats_device(stats_buf.data_ptr(), stats_buf.numel())
+                return ll_sum
             h = im.pack_stats()
             if stats_buf is None:
                 stats_buf = torch.empty(len(h), dtype=torch.float64, device=red_dev)
             stats_buf.copy_(torch.from_numpy(h))
-            dist.all_reduce(stats_buf, op=dist.ReduceOp.SUM)       # the single collective of the E-step
+            dist.all_reduce(stats_buf, op=dist.ReduceOp.SUM)
             im.unpack_stats(stats_buf.cpu().numpy())
             return float(stats_buf[0].item())
         return im.loglik()

@@ -246,6 +246,22 @@ class _PyInferenceManager:
         E.check(E.lib().smcpp_pack_stats(self._im, E.dptr(buf), C.byref(n), 0))
         return buf
 
+    def stats_len(self):
+        n = C.c_long(0)
+        E.check(E.lib().smcpp_pack_stats(self._im, None, C.byref(n), 0))
+        return int(n.value)
+
+    def pack_stats_device(self, device_ptr):
+        """Write the packed statistics into a device buffer of `stats_len()` doubles (e.g. `tensor.data_ptr()` of the
+        fp64 tensor that is all-reduced over RCCL); returns after the kernel has finished."""
+        n = C.c_long(0)
+        E.check(E.lib().smcpp_pack_stats(self._im, C.cast(C.c_void_p(int(device_ptr)), C.POINTER(C.c_double)),
+                                         C.byref(n), 1))
+
+    def unpack_stats_device(self, device_ptr, n):
+        E.check(E.lib().smcpp_unpack_stats(self._im, C.cast(C.c_void_p(int(device_ptr)), C.POINTER(C.c_double)),
+                                           int(n), 1))
+
     def unpack_stats(self, buf):
         buf = aca(buf, dtype=np.float64)
         E.check(E.lib().smcpp_unpack_stats(self._im, E.dptr(buf), len(buf), 0))

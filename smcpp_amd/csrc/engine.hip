@@ -195,6 +195,9 @@ struct smcpp_im {
     bool warm_start = false, warm_valid = false;
     DevBuf<float> d_warm_f;
     DevBuf<double> d_warm_b;
+    DevBuf<unsigned char> d_present;       // device copies used by k_pack_stats
+    DevBuf<int> d_g2l;
+    bool pack_tables_ready = false;
     PinnedArena stage;
     char *d_param = nullptr;      // device side of the per-E-step parameter arena
     int *h_flags = nullptr;       // pinned: per-pass "something re-ran" flags of both chains, read back every round
@@ -1498,6 +1501,7 @@ int smcpp_set_global_keys(smcpp_im *im, int Kg, const int *gkeys) {
     }
     im->gkeys.assign(gkeys, gkeys + (size_t)Kg * kl);
     im->have_global = true;
+    im->pack_tables_ready = false;
     API_END
 }
 
@@ -1508,6 +1512,27 @@ int smcpp_pack_stats(smcpp_im *im, double *buf, long *n_out, int dev) {
     const long n = 1 + M + (long)M * M + (long)Kg * M;
     if (n_out) *n_out = n;
     if (!buf) return 0;
+    if (dev) {
+        // device path: one kernel writes the packed layout into the caller's device buffer (e.g. the tensor that is
+        // all-reduced over RCCL) - no host round trip
+        HIPCHK(hipSetDevice(im->device));
+        if (!im->pack_tables_ready) {
+            std::vector<int> g2l(Kg, -1);
+            for (int k = 0; k < K; ++k) g2l[im->have_global ? im->local_to_global[k] : k] = k;
+            im->d_g2l.upload(g2l, im->stream);
+            im->d_present.upload(im->present, im->stream);
+            HIPCHK(hipStreamSynchronize(im->stream));
+            im->pack_tables_ready = true;
+        }
+        PackArgs pa;
+        pa.M = M; pa.Mp = im->Mp; pa.K = K; pa.Kg = Kg; pa.n_contigs = im->n_contigs;
+        pa.loglik = im->d_loglik.p; pa.gamma0 = im->d_gamma0.p; pa.xisum = im->d_xisum.p; pa.gsum = im->d_gsum.p;
+        pa.present = im->d_present.p; pa.g2l = im->d_g2l.p; pa.out = buf;
+        hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, im->stream, pa);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(im->stream));
+        return 0;
+    }
     im->fetch_stats();
     std::vector<double> h(n, 0.0);
     for (int c = 0; c < im->n_contigs; ++c) {
@@ -1520,10 +1545,7 @@ int smcpp_pack_stats(smcpp_im *im, double *buf, long *n_out, int dev) {
             for (int i = 0; i < M; ++i) h[1 + M + (size_t)M * M + (size_t)kg * M + i] += im->h_gsum[((size_t)c * K + k) * M + i];
         }
     }
-    if (dev) {
-        HIPCHK(hipSetDevice(im->device));
-        HIPCHK(hipMemcpy(buf, h.data(), sizeof(double) * n, hipMemcpyHostToDevice));
-    } else std::memcpy(buf, h.data(), sizeof(double) * n);
+    std::memcpy(buf, h.data(), sizeof(double) * n);
     API_END
 }
 

@@ -1760,6 +1760,45 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
             }
 }
 
+// Packed per-rank statistics for the single all-reduce of a multi-GPU E-step, written straight into the caller's device
+// buffer:  out = [ sum loglik | gamma0 (M) | xisum (M*M) | gamma-sums by GLOBAL key index (Kg*M) ],
+// each summed over this rank's contigs in contig order (deterministic).  One thread per output element.
+struct PackArgs {
+    int M, Mp, K, Kg, n_contigs;
+    const double *loglik;         // [n_contigs]
+    const double *gamma0;         // [n_contigs][Mp]
+    const double *xisum;          // [n_contigs][Mp][Mp]
+    const double *gsum;           // [n_contigs][K][Mp]
+    const unsigned char *present; // [n_contigs][K]
+    const int *g2l;               // [Kg] local key id of a global key, -1 if this rank never sees it
+    double *out;
+};
+
+__global__ __launch_bounds__(256) void k_pack_stats(PackArgs a) {
+    const long n = 1 + a.M + (long)a.M * a.M + (long)a.Kg * a.M;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    double acc = 0.0;
+    if (idx == 0) {
+        for (int c = 0; c < a.n_contigs; ++c) acc += a.loglik[c];
+    } else if (idx < 1 + a.M) {
+        const int i = (int)idx - 1;
+        for (int c = 0; c < a.n_contigs; ++c) acc += a.gamma0[(size_t)c * a.Mp + i];
+    } else if (idx < 1 + a.M + (long)a.M * a.M) {
+        const long e = idx - 1 - a.M;
+        const int i = (int)(e / a.M), j = (int)(e % a.M);
+        for (int c = 0; c < a.n_contigs; ++c) acc += a.xisum[((size_t)c * a.Mp + i) * a.Mp + j];
+    } else {
+        const long e = idx - 1 - a.M - (long)a.M * a.M;
+        const int kg = (int)(e / a.M), i = (int)(e % a.M);
+        const int k = a.g2l[kg];
+        if (k >= 0)
+            for (int c = 0; c < a.n_contigs; ++c)
+                if (a.present[(size_t)c * a.K + k]) acc += a.gsum[((size_t)c * a.K + k) * a.Mp + i];
+    }
+    a.out[idx] = acc;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // K6: finalisation
 // ---------------------------------------------------------------------------------------------------------------

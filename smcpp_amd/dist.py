@@ -87,3 +87,26 @@ def q_from_stats(buf, pi, T, gkeys, E_by_key):
         q[2 if nb > 0 else 1] += float(np.sum(np.log(e) * gs[i]))
     q[3] = float(np.sum(np.log(T) * xs))
     return q
+
+
+def allgather_logliks(local_logliks, owner, device=None, group=None):
+    """``loglik()`` keeps its per-contig vector across ranks: every rank contributes the log-likelihoods
+    of the contigs it owns; the result is ordered by global contig index.  ``owner[i]`` = rank of contig i (the
+    ``lpt_shard`` assignment); ``local_logliks`` follow the rank's own contigs in increasing global index."""
+    import torch
+    import torch.distributed as dist
+    owner = np.asarray(owner)
+    n = len(owner)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return np.asarray(local_logliks, dtype=np.float64)
+    rank = dist.get_rank(group)
+    mine = np.nonzero(owner == rank)[0]
+    assert len(mine) == len(local_logliks)
+    # a sum-all-reduce of a vector that is zero outside the owned slots is an all-gather with a fixed layout
+    v = np.zeros(n)
+    v[mine] = np.asarray(local_logliks, dtype=np.float64)
+    t = torch.from_numpy(v)
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()

@@ -39,6 +39,8 @@ def _worker(rank, world, port, out_dir):
     buf = sd.pack_host([r["loglik"] for r in res], [r["gamma"][:, 0] for r in res], [r["xisum"] for r in res],
                        [r["gamma_sums"] for r in res], gkeys)
     red = sd.allreduce_stats(buf)
+    lls = sd.allgather_logliks([r["loglik"] for r in res], owner)
+    np.save(os.path.join(out_dir, f"lls{rank}.npy"), lls)
     np.save(os.path.join(out_dir, f"red{rank}.npy"), red)
     np.save(os.path.join(out_dir, f"keys{rank}.npy"), gkeys)
     dist.barrier()
@@ -60,6 +62,10 @@ def test_two_rank_allreduce_matches_serial(tmp_path):
     serial = sd.pack_host([r["loglik"] for r in res], [r["gamma"][:, 0] for r in res], [r["xisum"] for r in res],
                           [r["gamma_sums"] for r in res], k0)
     np.testing.assert_allclose(r0, serial, rtol=1e-12, atol=1e-300)
+    # loglik() keeps its per-contig vector: gathered in global contig order on every rank
+    l0 = np.load(tmp_path / "lls0.npy"); l1 = np.load(tmp_path / "lls1.npy")
+    assert np.array_equal(l0, l1)
+    np.testing.assert_array_equal(l0, np.array([r["loglik"] for r in res]))
     E_by_key = {tuple(int(x) for x in k): e for k, e in zip(g["keys"], g["E"])}
     q = sd.q_from_stats(r0, g["pi"], g["T"], k0, E_by_key)
     np.testing.assert_allclose(q, sum(r["q"] for r in res), rtol=1e-9)

@@ -145,6 +145,14 @@ def test_pack_stats_matches_python_layout():
     buf = im.pack_stats()
     py = sd.pack_host(list(im.logliks()), [x[:, 0] for x in im.gammas], im.xisums, im.gamma_sums, gkeys)
     np.testing.assert_allclose(buf, py, rtol=1e-14, atol=0)
+    # device path (what bench.py hands to RCCL): one kernel writes the same layout into a caller-owned device tensor
+    import torch
+    tbuf = torch.full((im.stats_len(),), -1.0, dtype=torch.float64, device="cuda")
+    im.pack_stats_device(tbuf.data_ptr())
+    np.testing.assert_allclose(tbuf.cpu().numpy(), buf, rtol=1e-14, atol=0)
+    q_before = np.array(im.Q(separate=True))
+    im.unpack_stats_device(tbuf.data_ptr(), tbuf.numel())      # "reduced" over a world of one, from the device buffer
+    np.testing.assert_allclose(np.array(im.Q(separate=True)), q_before, rtol=1e-12)
     q_local = np.array(im.Q(separate=True))
     im.unpack_stats(buf)                       # "reduced" over a world of one
     q_red = np.array(im.Q(separate=True))

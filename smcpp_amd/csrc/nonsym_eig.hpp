@@ -40,7 +40,7 @@ inline void cdiv(double xr, double xi, double yr, double yi, double &cr, double 
 inline void orthes(int n, std::vector<double> &H, std::vector<double> &V) {
     auto h = [&](int i, int j) -> double & { return H[(size_t)i * n + j]; };
     auto v = [&](int i, int j) -> double & { return V[(size_t)i * n + j]; };
-    std::vector<double> ort(n, 0.0);
+    std::vector<double> ort(n, 0.0), fcol(n, 0.0);
     const int low = 0, high = n - 1;
     for (int m = low + 1; m <= high - 1; ++m) {
         double sc = 0.0;
@@ -52,11 +52,20 @@ inline void orthes(int n, std::vector<double> &H, std::vector<double> &V) {
             if (ort[m] > 0) g = -g;
             hh -= ort[m] * g;
             ort[m] -= g;
-            for (int j = m; j < n; ++j) {
-                double f = 0.0;
-                for (int i = high; i >= m; --i) f += ort[i] * h(i, j);
-                f /= hh;
-                for (int i = m; i <= high; ++i) h(i, j) -= f * ort[i];
+            // H <- (I - u u^T / hh) H on columns m..n-1.  Row sweeps with a row of partial sums: every f[j] is still
+            // accumulated over i = high .. m in that order (bit-identical to the column-at-a-time form), but the matrix
+            // is walked along its rows
+            std::fill(fcol.begin() + m, fcol.end(), 0.0);
+            for (int i = high; i >= m; --i) {
+                const double oi = ort[i];
+                const double *hr = &H[(size_t)i * n];
+                for (int j = m; j < n; ++j) fcol[j] += oi * hr[j];
+            }
+            for (int j = m; j < n; ++j) fcol[j] /= hh;
+            for (int i = m; i <= high; ++i) {
+                const double oi = ort[i];
+                double *hr = &H[(size_t)i * n];
+                for (int j = m; j < n; ++j) hr[j] -= fcol[j] * oi;
             }
             for (int i = 0; i <= high; ++i) {
                 double f = 0.0;
@@ -73,11 +82,18 @@ inline void orthes(int n, std::vector<double> &H, std::vector<double> &V) {
     for (int m = high - 1; m >= low + 1; --m) {
         if (h(m, m - 1) != 0.0) {
             for (int i = m + 1; i <= high; ++i) ort[i] = h(i, m - 1);
-            for (int j = m; j <= high; ++j) {
-                double g = 0.0;
-                for (int i = m; i <= high; ++i) g += ort[i] * v(i, j);
-                g = (g / ort[m]) / h(m, m - 1);
-                for (int i = m; i <= high; ++i) v(i, j) += g * ort[i];
+            std::fill(fcol.begin() + m, fcol.begin() + high + 1, 0.0);
+            for (int i = m; i <= high; ++i) {                     // g[j] accumulated over i = m .. high as before
+                const double oi = ort[i];
+                const double *vr = &V[(size_t)i * n];
+                for (int j = m; j <= high; ++j) fcol[j] += oi * vr[j];
+            }
+            const double om = ort[m], hm = h(m, m - 1);
+            for (int j = m; j <= high; ++j) fcol[j] = (fcol[j] / om) / hm;
+            for (int i = m; i <= high; ++i) {
+                const double oi = ort[i];
+                double *vr = &V[(size_t)i * n];
+                for (int j = m; j <= high; ++j) vr[j] += fcol[j] * oi;
             }
         }
     }
@@ -88,7 +104,12 @@ inline void orthes(int n, std::vector<double> &H, std::vector<double> &V) {
 inline void hqr2(int nn, std::vector<double> &H, std::vector<double> &V, std::vector<double> &wr,
                  std::vector<double> &wi) {
     auto h = [&](int i, int j) -> double & { return H[(size_t)i * nn + j]; };
-    auto v = [&](int i, int j) -> double & { return V[(size_t)i * nn + j]; };
+    // the accumulated transform is kept TRANSPOSED while this routine runs: every reflection of a sweep updates three
+    // columns of V for all rows - with Vt those are three contiguous, vectorisable rows instead of a stride-n walk
+    std::vector<double> Vt((size_t)nn * nn);
+    for (int i = 0; i < nn; ++i)
+        for (int j = 0; j < nn; ++j) Vt[(size_t)j * nn + i] = V[(size_t)i * nn + j];
+    auto v = [&](int i, int j) -> double & { return Vt[(size_t)j * nn + i]; };
     int n = nn - 1;
     const int low = 0, high = nn - 1;
     const double eps = std::pow(2.0, -52.0);
@@ -220,33 +241,58 @@ inline void hqr2(int nn, std::vector<double> &H, std::vector<double> &V, std::ve
                         h(i, k) -= p;
                         h(i, k + 1) -= p * q;
                     }
-                    for (int i = low; i <= high; ++i) {
-                        p = x * v(i, k) + y * v(i, k + 1);
-                        if (notlast) { p += z * v(i, k + 2); v(i, k + 2) -= p * r; }
-                        v(i, k) -= p;
-                        v(i, k + 1) -= p * q;
+                    {
+                        double *v0 = &Vt[(size_t)k * nn], *v1 = &Vt[(size_t)(k + 1) * nn];
+                        if (notlast) {
+                            double *v2 = &Vt[(size_t)(k + 2) * nn];
+                            for (int i = low; i <= high; ++i) {
+                                double pp = x * v0[i] + y * v1[i];
+                                pp += z * v2[i];
+                                v2[i] -= pp * r;
+                                v0[i] -= pp;
+                                v1[i] -= pp * q;
+                            }
+                        } else {
+                            for (int i = low; i <= high; ++i) {
+                                const double pp = x * v0[i] + y * v1[i];
+                                v0[i] -= pp;
+                                v1[i] -= pp * q;
+                            }
+                        }
                     }
                 }
             }
         }
     }
-    if (norm == 0.0) return;
+    auto put_back = [&]() {
+        for (int i = 0; i < nn; ++i)
+            for (int j = 0; j < nn; ++j) V[(size_t)i * nn + j] = Vt[(size_t)j * nn + i];
+    };
+    if (norm == 0.0) { put_back(); return; }
     // back-substitute to find the vectors of the upper (quasi-)triangular form
+    std::vector<double> xc(nn, 0.0);
     for (n = nn - 1; n >= 0; --n) {
         p = wr[n]; q = wi[n];
         if (q == 0) {                       // real vector
+            // column n of H is mirrored in the contiguous vector xc so that the dot products below walk two
+            // contiguous arrays (same operands, same order)
             int l = n;
             h(n, n) = 1.0;
+            xc[n] = 1.0;
             for (int i = n - 1; i >= 0; --i) {
                 w = h(i, i) - p;
                 r = 0.0;
-                for (int j = l; j <= n; ++j) r += h(i, j) * h(j, n);
+                {
+                    const double *hr = &H[(size_t)i * nn];
+                    for (int j = l; j <= n; ++j) r += hr[j] * xc[j];
+                }
                 if (wi[i] < 0.0) { z = w; s = r; }
                 else {
                     l = i;
                     if (wi[i] == 0.0) {
                         if (w != 0.0) h(i, n) = -r / w;
                         else h(i, n) = -r / (eps * norm);
+                        xc[i] = h(i, n);
                     } else {                // solve the 2x2 real block
                         x = h(i, i + 1); y = h(i + 1, i);
                         q = (wr[i] - p) * (wr[i] - p) + wi[i] * wi[i];
@@ -254,10 +300,11 @@ inline void hqr2(int nn, std::vector<double> &H, std::vector<double> &V, std::ve
                         h(i, n) = t;
                         if (std::fabs(x) > std::fabs(z)) h(i + 1, n) = (-r - w * t) / x;
                         else h(i + 1, n) = (-s - y * t) / z;
+                        xc[i] = h(i, n); xc[i + 1] = h(i + 1, n);
                     }
                     t = std::fabs(h(i, n));            // overflow control
                     if ((eps * t) * t > 1)
-                        for (int j = i; j <= n; ++j) h(j, n) /= t;
+                        for (int j = i; j <= n; ++j) { h(j, n) /= t; xc[j] = h(j, n); }
                 }
             }
         } else if (q < 0) {                 // complex vector, stored in columns n-1 (re) and n (im)
@@ -306,12 +353,21 @@ inline void hqr2(int nn, std::vector<double> &H, std::vector<double> &V, std::ve
         }
     }
     // multiply by the accumulated orthogonal transform
-    for (int j = nn - 1; j >= low; --j)
-        for (int i = low; i <= high; ++i) {
-            z = 0.0;
-            for (int k = low; k <= std::min(j, high); ++k) z += v(i, k) * h(k, j);
-            v(i, j) = z;
+    // V <- V * (upper triangle of H), i.e. column j of V becomes sum_{k <= j} h(k,j) * (column k of V), k ascending as
+    // in the scalar form; columns of V are rows of Vt, done from the last column down so that it can run in place
+    {
+        std::vector<double> out(nn);
+        for (int j = nn - 1; j >= low; --j) {
+            std::fill(out.begin(), out.end(), 0.0);
+            for (int k = low; k <= std::min(j, high); ++k) {
+                const double hk = h(k, j);
+                const double *vk = &Vt[(size_t)k * nn];
+                for (int i = low; i <= high; ++i) out[i] += vk[i] * hk;
+            }
+            std::copy(out.begin() + low, out.begin() + high + 1, &Vt[(size_t)j * nn + low]);
         }
+    }
+    put_back();
 }
 
 // In-place inverse by LU with partial pivoting (row-major n x n).  T is double or std::complex<double>.

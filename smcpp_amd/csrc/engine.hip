@@ -175,10 +175,12 @@ struct smcpp_im {
     DevBuf<RowInfo> d_rowinfo;
     DevBuf<int2> d_rowdesc;
     DevBuf<long long> d_dbg;
-    DevBuf<float> d_T4;
+    DevBuf<float> d_T4, d_qTf;
+    DevBuf<double> d_qTdT, d_qPinvT, d_qPT, d_qPrm, d_qPinvrm;   // quarter-interleaved operands of the big-M chains
     DevBuf<double> d_fA2, d_fB2, d_bA2, d_bB2, d_bC2;
     int wpb = 4;
-    int chain_mode = 2;   // 0 generic, 1 LDS-resident (one wavefront per chunk), 2 CU-cooperative (one workgroup per chunk)
+    int chain_mode = 2;   // 0 generic, 1 LDS-resident (one wavefront per chunk), 2 CU-cooperative (one workgroup per chunk),
+                          // 3 CU-cooperative with streamed operands (64 < M <= 256)
     int coop_bpc = 1;     // cooperative workgroups resident per CU the automatic chunking aims at
     int hot_eig = -1;
     DevBuf<Chunk> d_chunks;
@@ -376,7 +378,8 @@ void smcpp_im::make_chunks() {
         const char *m = getenv("SMCPP_CHAIN");
         if (m) chain_mode = !strcmp(m, "generic") ? 0 : !strcmp(m, "lds") ? 1 : 2;
         if (getenv("SMCPP_GENERIC_CHAINS")) chain_mode = 0;
-        if (Mp > 64) chain_mode = 0;
+        // 64 < M <= 256: the streaming cooperative kernels (k_fwd_big / k_bwd_big) unless generic is forced
+        if (Mp > 64) chain_mode = (chain_mode == 0) ? 0 : 3;
         const char *b = getenv("SMCPP_COOP_BPC");
         if (b && atoi(b) > 0) coop_bpc = atoi(b);
         else {
@@ -388,7 +391,7 @@ void smcpp_im::make_chunks() {
         }
     }
     // chunks in flight: one per SIMD for the per-wavefront kernels, coop_bpc per CU for the cooperative ones
-    const long long slots = (long long)prop.multiProcessorCount * (chain_mode == 2 ? coop_bpc : wpb);
+    const long long slots = (long long)prop.multiProcessorCount * (chain_mode >= 2 ? (chain_mode == 3 ? 1 : coop_bpc) : wpb);
     long long rows = total_rows - n_contigs;
     int lc = user_rows_per_chunk;
     if (lc <= 0) {
@@ -726,8 +729,31 @@ void smcpp_im::host_prep_and_upload() {
                 }
             }
     }
+    std::vector<float> qTf;
+    std::vector<double> qTdT, qPinvT, qPT, qPrm, qPinvrm;
+    if (Mp > 64 && chain_mode == 3) {
+        // quarter-interleaved streaming layouts  Q[t][i][kq] = Mt[(kq*KQ + t)*Mp + i]  (k_fwd_big / k_bwd_big)
+        const int KQ = Mp / 4;
+        qTf.assign(MM, 0.f); qTdT.assign(MM, 0.0);
+        qPinvT.assign(em, 0.0); qPT.assign(em, 0.0); qPrm.assign(em, 0.0); qPinvrm.assign(em, 0.0);
+#pragma omp parallel for schedule(static) num_threads(std::max(1, std::min(8, omp_get_max_threads())))
+        for (int t = 0; t < KQ; ++t)
+            for (int i = 0; i < Mp; ++i)
+                for (int q = 0; q < 4; ++q) {
+                    const size_t dst = ((size_t)t * Mp + i) * 4 + q, src = (size_t)(q * KQ + t) * Mp + i;
+                    qTf[dst] = Tf[src];
+                    qTdT[dst] = TdT[src];
+                    for (int e = 0; e < Ke; ++e) {
+                        qPinvT[e * MM + dst] = PinvT[e * MM + src];
+                        qPT[e * MM + dst] = PT[e * MM + src];
+                        qPrm[e * MM + dst] = Prm[e * MM + src];
+                        qPinvrm[e * MM + dst] = Pinvrm[e * MM + src];
+                    }
+                }
+    }
     // ---- one contiguous parameter arena on the device, mirrored in pinned host memory: ONE copy per E-step ----
     size_t need = 32 * 256;
+    need += qTf.size() * 4 + (qTdT.size() + qPinvT.size() + qPT.size() + qPrm.size() + qPinvrm.size()) * 8;
     need += (pi_f.size() + Tf.size() + T4.size()) * 4;
     need += (TdT.size() + Td.size() + Ep.size() + PinvT.size() + PT.size() + Prm.size() + Pinvrm.size() + dsc.size() +
              dun.size() + dpow.size() + gsc.size() + gls.size() + fA2.size() + fB2.size() + bA2.size() + bB2.size() +
@@ -749,6 +775,11 @@ void smcpp_im::host_prep_and_upload() {
     if (Mp <= 64) {
         d_T4.place(T4, d_param, hb, off); d_fA2.place(fA2, d_param, hb, off); d_fB2.place(fB2, d_param, hb, off);
         d_bA2.place(bA2, d_param, hb, off); d_bB2.place(bB2, d_param, hb, off); d_bC2.place(bC2, d_param, hb, off);
+    }
+    if (!qTf.empty()) {
+        d_qTf.place(qTf, d_param, hb, off); d_qTdT.place(qTdT, d_param, hb, off);
+        d_qPinvT.place(qPinvT, d_param, hb, off); d_qPT.place(qPT, d_param, hb, off);
+        d_qPrm.place(qPrm, d_param, hb, off); d_qPinvrm.place(qPinvrm, d_param, hb, off);
     }
     if (off > need) throw std::runtime_error("internal: parameter arena overflow");
     HIPCHK(hipMemcpyAsync(d_param, hb, off, hipMemcpyHostToDevice, s));
@@ -803,6 +834,20 @@ static bool launch_chain_coop(bool fwd, int Mp, const ChainArgs &a, const CoopAr
 #define C_(x) case x: if (tab) launch_chain_coop_t<x, true>(fwd, a, ca, shm, s); else launch_chain_coop_t<x, false>(fwd, a, ca, shm, s); return true;
         C_(16) C_(32) C_(48) C_(64)
 #undef C_
+        default: return false;
+    }
+}
+
+template <int MT_>
+static void launch_chain_big_t(bool fwd, const ChainArgs &a, const BigArgs &qa, hipStream_t s) {
+    if (fwd) hipLaunchKernelGGL((k_fwd_big<MT_>), dim3(a.nchunks), dim3(MT_ * 4), 0, s, a, qa);
+    else hipLaunchKernelGGL((k_bwd_big<MT_>), dim3(a.nchunks), dim3(MT_ * 4), 0, s, a, qa);
+}
+static bool launch_chain_big(bool fwd, int Mp, const ChainArgs &a, const BigArgs &qa, hipStream_t s) {
+    switch (Mp) {
+#define B_(x) case x: launch_chain_big_t<x>(fwd, a, qa, s); return true;
+        B_(80) B_(96) B_(112) B_(128) B_(144) B_(160) B_(176) B_(192) B_(208) B_(224) B_(240) B_(256)
+#undef B_
         default: return false;
     }
 }
@@ -862,6 +907,9 @@ void smcpp_im::run_chains() {
     const bool generic = chain_mode == 0;
     CoopArgs cargs;
     cargs.K = K; cargs.G = G;
+    BigArgs bargs;
+    bargs.qTf = d_qTf.p; bargs.qPinvT = d_qPinvT.p; bargs.qPT = d_qPT.p; bargs.qTdT = d_qTdT.p;
+    bargs.qPrm = d_qPrm.p; bargs.qPinvrm = d_qPinvrm.p;
     size_t shm_c = 0;
     int tab_c = 0;
     {
@@ -935,7 +983,8 @@ void smcpp_im::run_chains() {
             a.changed = d_changed_f.p;
             for (; launched_f < want_f; ++launched_f) {
                 a.pass = launched_f;
-                if (!(chain_mode == 2 && launch_chain_coop(true, Mp, a, cargs, tab_c, shm_c, s)))
+                if (!(chain_mode == 3 && launch_chain_big(true, Mp, a, bargs, s)) &&
+                    !(chain_mode == 2 && launch_chain_coop(true, Mp, a, cargs, tab_c, shm_c, s)))
                     launch_chain(true, NPL, Mp, generic, a, lf, tab_lds, wpb, shm_f, s);
             }
         }
@@ -944,7 +993,8 @@ void smcpp_im::run_chains() {
             a.changed = d_changed_b.p;
             for (; launched_b < want_b; ++launched_b) {
                 a.pass = launched_b;
-                if (!(chain_mode == 2 && launch_chain_coop(false, Mp, a, cargs, tab_c, shm_c, sb)))
+                if (!(chain_mode == 3 && launch_chain_big(false, Mp, a, bargs, sb)) &&
+                    !(chain_mode == 2 && launch_chain_coop(false, Mp, a, cargs, tab_c, shm_c, sb)))
                     launch_chain(false, NPL, Mp, generic, a, lb, tab_lds, wpb, shm_b, sb);
             }
         }

@@ -1305,6 +1305,331 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop(ChainArgs a, CoopArgs ca) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Cooperative chains for 64 < M <= 256: same workgroup-per-chunk scheme as k_fwd_coop / k_bwd_coop (lane 4*il + kq owns
+// quarter kq of the inner index of state i, state exchanged through LDS, consumer-side normaliser), but the operand
+// quarters no longer fit the register file (1024 threads leave 128 VGPRs each), so every matrix is STREAMED from L2
+// once per row in a quarter-interleaved layout  Q[t][i][kq] = Mt[(kq*KQ + t)*Mp + i]  in which the 64 lanes of a
+// wavefront read 64 consecutive elements (one fully used 256-/512-byte access per k-step).  One chunk per CU instead
+// of the four independent wavefronts of the generic kernels: a quarter of the row-steps re-read the matrices, and
+// chunks four times as long need 2-3 passes instead of 6-7.
+// ---------------------------------------------------------------------------------------------------------------
+struct BigArgs {
+    const float *qTf;        // [KQ][Mp][4]            forward span-1 operand
+    const double *qPinvT;    // [Ke][KQ][Mp][4]        forward eigen operands
+    const double *qPT;
+    const double *qTdT;      // [KQ][Mp][4]            backward span-1 operand
+    const double *qPrm;      // [Ke][KQ][Mp][4]        backward eigen operands
+    const double *qPinvrm;
+};
+
+// One streamed quarter product: acc = sum_t q[t*QS] * x(t), with B independent loads in flight per batch (the whole
+// row of the operand has to come from L2 every step; the loop is latency-bound unless many loads are outstanding).
+template <int KQ, int B, typename TM, typename F>
+__device__ __forceinline__ auto stream_dot(const TM *__restrict__ q, size_t QS, int rot, F &&xval) {
+    using TA = decltype(q[0] * xval(0));
+    TA acc[4] = {TA(0), TA(0), TA(0), TA(0)};
+    static_assert(KQ % 4 == 0, "quarter length must be a multiple of 4");
+    constexpr int BB = (KQ % B == 0) ? B : 4;
+    // `rot` (a multiple of BB, different per workgroup) rotates the order of the k-steps: all workgroups stream the
+    // same matrix at the same pace, and without it they all ask the same one or two L2 channels at the same time
+#pragma unroll 1
+    for (int n = 0; n < KQ; n += BB) {
+        int t0 = n + rot;
+        if (t0 >= KQ) t0 -= KQ;
+        TM m[BB];
+#pragma unroll
+        for (int u = 0; u < BB; ++u) m[u] = q[(size_t)(t0 + u) * QS];
+#pragma unroll
+        for (int u = 0; u < BB; ++u) acc[u & 3] += m[u] * xval(t0 + u);
+    }
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+template <int MT>
+__global__ __launch_bounds__(MT * 4) void k_fwd_big(ChainArgs a, BigArgs qa) {
+    constexpr int NW = MT / 16, KQ = MT / 4, Mp = MT, UP = KQ + 2, QS = 4 * MT;   // QS = stride of one k-step in a Q layout
+    constexpr int FB = 16, DB = (MT > 128) ? 8 : 16;   // loads in flight per lane (1024 threads leave 128 VGPRs each)
+    __shared__ __attribute__((aligned(16))) double ub[4 * UP];
+    __shared__ __attribute__((aligned(16))) float xf[2 * MT];
+    __shared__ int2 sdesc[128];
+    __shared__ int sflag;
+    __shared__ int mflag[NW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int il = lane >> 2, kq = lane & 3, i = 16 * w + il;
+    const bool owner = kq == 0;
+    const int M = a.M, pass = a.pass, c = blockIdx.x;
+    if (pass > 0 && a.changed[pass - 1] == 0) return;
+    const Chunk ch = a.chunks[c];
+    float *end_cur = a.ends_f + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
+    const float *end_prev = a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
+    if (pass > 0 && ch.first) {
+        if (owner) end_cur[i] = end_prev[i];
+        return;
+    }
+    float al = 0.f;
+    {
+        const float *src = (ch.first || pass == 0) ? a.pi_f
+                                                   : a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + (c - 1)) * Mp;
+        if (i < M) al = src[i];
+    }
+    if (tid == 0) sflag = 0;
+    if (lane == 0) mflag[w] = 1;
+    __syncthreads();
+    if (pass > 0) {
+        bool diff = false;
+        if (owner && i < M) {
+            const float u = a.used_f[(size_t)c * Mp + i];
+            if (!(fabsf(al - u) <= a.eps_f * fabsf(u))) diff = true;
+        }
+        if (__any(diff) && lane == 0) sflag = 1;
+        __syncthreads();
+        if (sflag == 0) {
+            if (owner) end_cur[i] = end_prev[i];
+            return;
+        }
+    }
+    if (owner) a.used_f[(size_t)c * Mp + i] = al;
+    if (tid == 0) a.changed[pass] = 1;
+    if (ch.first) {
+        if (owner) a.alpha[(size_t)ch.base * Mp + i] = al;
+        if (tid == 0) a.cnorm[ch.base] = 1.0;
+    }
+    const int2 *rd = a.rowdesc + ch.base;
+    const int nrows = ch.r1 - ch.r0;
+    if (w == 0) {
+        sdesc[lane] = (lane < nrows) ? rd[ch.r0 + 1 + lane] : make_int2(0, -1);
+        sdesc[64 + lane] = (lane + 64 < nrows) ? rd[ch.r0 + 1 + 64 + lane] : make_int2(0, -1);
+    }
+    if (owner) xf[i] = al;
+    __syncthreads();
+    const size_t qoff = (size_t)4 * i + kq;                 // this lane's element of every k-step of a Q layout
+    constexpr int FBB = (KQ % FB == 0) ? FB : 4, DBB = (KQ % DB == 0) ? DB : 4;
+    const int rotf = (int)((blockIdx.x * 7u) % (unsigned)(KQ / FBB)) * FBB, rotd = (int)((blockIdx.x * 7u) % (unsigned)(KQ / DBB)) * DBB;
+    float v_prev = al;
+    const bool rerun = pass > 0;
+    bool merged = false;
+    for (int j = 0; j < nrows; ++j) {
+        const int ell = ch.r0 + 1 + j;
+        const int jb = j & 63, bsel = (j >> 6) & 1, cur = j & 1, nxt = cur ^ 1;
+        if (rerun && j > 16 && (j & 15) == 1) {
+            int nm = mflag[0];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) nm |= mflag[q];
+            if (nm == 0) { merged = true; break; }
+        }
+        if (w == 0 && jb == 32 && j >= 64) {
+            const int2 dn = (j + 32 + lane < nrows) ? rd[ch.r0 + 1 + j + 32 + lane] : make_int2(0, -1);
+            sdesc[(bsel ^ 1) * 64 + lane] = dn;
+        }
+        const int2 d0 = sdesc[bsel * 64 + jb];
+        const int kid = __builtin_amdgcn_readfirstlane(d0.x);
+        const int ge = __builtin_amdgcn_readfirstlane(d0.y);
+        // ---- normaliser of the previous row from this lane's quarter of the state ----
+        const float *xin = xf + cur * MT + kq * KQ;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < KQ; t += 4) {
+            const f32x4p x = *reinterpret_cast<const f32x4p *>(xin + t);
+            s0 += x.lo.x + x.lo.y; s1 += x.hi.x + x.hi.y;
+        }
+        float sprev = quad_sum_f(s0 + s1);
+        if (j == 0) sprev = 1.0f;
+        const float inv = __builtin_amdgcn_rcpf(sprev);
+        const float thr = 1e-10f * sprev;
+        if (j > 0) {
+            float an = v_prev * inv;
+            an = (i < M) ? fmaxf(an, 1e-10f) : 0.f;
+            if (rerun && (j & 15) == 0) {
+                const float old_pref = owner ? a.alpha[(size_t)(ch.base + ell - 1) * Mp + i] : 0.f;
+                const bool bad = owner && i < M && !(fabsf(an - old_pref) <= a.eps_f * fabsf(old_pref));
+                const bool anyb = __any(bad);
+                if (lane == 0) mflag[w] = anyb ? 1 : 0;
+            }
+            if (owner) a.alpha[(size_t)(ch.base + ell - 1) * Mp + i] = an;
+            if (tid == 0) a.cnorm[ch.base + ell - 1] = (double)sprev;
+        }
+        float vout;
+        if (ge < 0) {
+            const double e_cur = a.E[(size_t)kid * Mp + i];
+            const float *q = qa.qTf + qoff;
+            const float dot = stream_dot<KQ, FB>(q, QS, rotf, [&](int t) { return fmaxf(xin[t], thr); });
+            const float y = quad_sum_f(dot) * inv;
+            vout = (i < M) ? (float)((double)y * e_cur) : 0.f;
+        } else {
+            const int es = SMCPP_ES(ge);
+            const double dp_cur = a.dpow[(size_t)SMCPP_GID(ge) * Mp + i];
+            const double *q1 = qa.qPinvT + (size_t)es * Mp * Mp + qoff;
+            double u = quad_sum_d(stream_dot<KQ, DB>(q1, QS, rotd, [&](int t) { return (double)fmaxf(xin[t], thr); }));
+            u = u * dp_cur * (double)inv;
+            if (owner) ub[(i / KQ) * UP + (i % KQ)] = (i < M) ? u : 0.0;
+            lds_barrier();
+            const double *uin = ub + kq * UP;
+            const double *q2 = qa.qPT + (size_t)es * Mp * Mp + qoff;
+            const double av = quad_sum_d(stream_dot<KQ, DB>(q2, QS, rotd, [&](int t) { return uin[t]; }));
+            vout = (i < M) ? (float)av : 0.f;
+        }
+        if (owner) xf[nxt * MT + i] = vout;
+        v_prev = vout;
+        lds_barrier();
+    }
+    if (merged) {
+        if (owner) end_cur[i] = end_prev[i];
+        return;
+    }
+    {
+        const float *xin = xf + (nrows & 1) * MT + kq * KQ;
+        float sl = 0.f;
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) sl += xin[t];
+        const float sprev = quad_sum_f(sl);
+        const float inv = __builtin_amdgcn_rcpf(sprev);
+        if (owner) {
+            float an = v_prev * inv;
+            an = (i < M) ? fmaxf(an, 1e-10f) : 0.f;
+            a.alpha[(size_t)(ch.base + ch.r1) * Mp + i] = an;
+            end_cur[i] = an;
+        }
+        if (tid == 0) a.cnorm[ch.base + ch.r1] = (double)sprev;
+    }
+}
+
+template <int MT>
+__global__ __launch_bounds__(MT * 4) void k_bwd_big(ChainArgs a, BigArgs qa) {
+    constexpr int NW = MT / 16, KQ = MT / 4, Mp = MT, UP = KQ + 2, QS = 4 * MT;
+    constexpr int DB = (MT > 128) ? 8 : 16;
+    __shared__ __attribute__((aligned(16))) double ub[4 * UP];
+    __shared__ __attribute__((aligned(16))) double xb[2 * 4 * UP];
+    __shared__ int2 sdesc[128];
+    __shared__ int sflag;
+    __shared__ int mflag[NW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int il = lane >> 2, kq = lane & 3, i = 16 * w + il;
+    const bool owner = kq == 0;
+    const int M = a.M, pass = a.pass, c = blockIdx.x;
+    if (pass > 0 && a.changed[pass - 1] == 0) return;
+    const Chunk ch = a.chunks[c];
+    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
+    const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
+    if (pass > 0 && ch.last) {
+        if (owner) end_cur[i] = end_prev[i];
+        return;
+    }
+    double b = 0.0;
+    {
+        const bool fresh = ch.last || pass == 0;
+        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (fresh ? c : c + 1)) * Mp;
+        if (i < M) b = fresh ? 1.0 / (double)M : src[i];
+    }
+    if (tid == 0) sflag = 0;
+    if (lane == 0) mflag[w] = 1;
+    __syncthreads();
+    if (pass > 0) {
+        bool diff = false;
+        if (owner && i < M) {
+            const double u = a.used_b[(size_t)c * Mp + i];
+            if (!(fabs(b - u) <= a.eps_b * fabs(u))) diff = true;
+        }
+        if (__any(diff) && lane == 0) sflag = 1;
+        __syncthreads();
+        if (sflag == 0) {
+            if (owner) end_cur[i] = end_prev[i];
+            return;
+        }
+    }
+    if (owner) a.used_b[(size_t)c * Mp + i] = b;
+    if (tid == 0) a.changed[pass] = 1;
+    const int2 *rd = a.rowdesc + ch.base;
+    const int nrows = ch.r1 - ch.r0;
+    if (w == 0) {
+        sdesc[lane] = (lane < nrows) ? rd[ch.r1 - lane] : make_int2(0, -1);
+        sdesc[64 + lane] = (lane + 64 < nrows) ? rd[ch.r1 - lane - 64] : make_int2(0, -1);
+    }
+    if (owner) xb[(i / KQ) * UP + (i % KQ)] = b;
+    __syncthreads();
+    const size_t qoff = (size_t)4 * i + kq;
+    constexpr int DBB = (KQ % DB == 0) ? DB : 4;
+    const int rotd = (int)((blockIdx.x * 7u) % (unsigned)(KQ / DBB)) * DBB;
+    double b_raw = b;
+    const bool rerun = pass > 0;
+    bool merged = false;
+    for (int j = 0; j < nrows; ++j) {
+        const int ell = ch.r1 - j;
+        const int jb = j & 63, bsel = (j >> 6) & 1, cur = j & 1, nxt = cur ^ 1;
+        if (rerun && j > 16 && (j & 15) == 1) {
+            int nm = mflag[0];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) nm |= mflag[q];
+            if (nm == 0) { merged = true; break; }
+        }
+        if (w == 0 && jb == 32 && j >= 64) {
+            const int2 dn = (j + 32 + lane < nrows) ? rd[ch.r1 - (j + 32 + lane)] : make_int2(0, -1);
+            sdesc[(bsel ^ 1) * 64 + lane] = dn;
+        }
+        const int2 d0 = sdesc[bsel * 64 + jb];
+        const int kid = __builtin_amdgcn_readfirstlane(d0.x);
+        const int ge = __builtin_amdgcn_readfirstlane(d0.y);
+        const double *xin = xb + cur * 4 * UP + kq * UP;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < KQ; t += 2) {
+            const double2 v = *reinterpret_cast<const double2 *>(xin + t);
+            s0 += v.x; s1 += v.y;
+        }
+        double sprev = quad_sum_d(s0 + s1);
+        if (j == 0) sprev = 1.0;
+        const double inv = rcp_f64(sprev);
+        {
+            const double bnrm = (i < M) ? b_raw * inv : 0.0;
+            if (rerun && (j & 15) == 0 && j > 0) {
+                const double old_pref = owner ? a.beta[(size_t)(ch.base + ell) * Mp + i] : 0.0;
+                const bool bad = owner && i < M && !(fabs(bnrm - old_pref) <= a.eps_b * fabs(old_pref));
+                const bool anyb = __any(bad);
+                if (lane == 0) mflag[w] = anyb ? 1 : 0;
+            }
+            if (owner) a.beta[(size_t)(ch.base + ell) * Mp + i] = bnrm;
+        }
+        double bn;
+        if (ge < 0) {
+            // beta <- T (e o beta): this lane needs e on its quarter of the inner index
+            const double *eq = a.E + (size_t)kid * Mp + kq * KQ;
+            const double *q = qa.qTdT + qoff;
+            bn = quad_sum_d(stream_dot<KQ, DB>(q, QS, rotd, [&](int t) { return eq[t] * xin[t]; })) * inv;
+        } else {
+            const int es = SMCPP_ES(ge);
+            const double dp_cur = a.dpow[(size_t)SMCPP_GID(ge) * Mp + i];
+            const double *q1 = qa.qPrm + (size_t)es * Mp * Mp + qoff;
+            double wv = quad_sum_d(stream_dot<KQ, DB>(q1, QS, rotd, [&](int t) { return xin[t]; }));
+            wv = wv * dp_cur * inv;
+            if (owner) ub[(i / KQ) * UP + (i % KQ)] = (i < M) ? wv : 0.0;
+            lds_barrier();
+            const double *uin = ub + kq * UP;
+            const double *q2 = qa.qPinvrm + (size_t)es * Mp * Mp + qoff;
+            bn = quad_sum_d(stream_dot<KQ, DB>(q2, QS, rotd, [&](int t) { return uin[t]; }));
+        }
+        if (!(i < M)) bn = 0.0;
+        if (owner) xb[nxt * 4 * UP + (i / KQ) * UP + (i % KQ)] = bn;
+        b_raw = bn;
+        lds_barrier();
+    }
+    if (merged) {
+        if (owner) end_cur[i] = end_prev[i];
+        return;
+    }
+    {
+        const double *xin = xb + (nrows & 1) * 4 * UP + kq * UP;
+        double sl = 0.0;
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) sl += xin[t];
+        const double sprev = quad_sum_d(sl);
+        if (owner) {
+            const double bf = (i < M) ? b_raw / sprev : 0.0;
+            end_cur[i] = bf;
+            if (ch.first) a.beta[(size_t)ch.base * Mp + i] = bf;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K7: log-likelihood  ll = sum_ell log c_ell + span_ell log scale   (hmm.cpp:79,88,95)
 // ---------------------------------------------------------------------------------------------------------------
 struct LoglikArgs {

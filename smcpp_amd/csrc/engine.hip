@@ -917,6 +917,7 @@ void smcpp_im::run_chains() {
         const size_t base_c = (size_t)(4 * UP + 8 * UP) * 8 + 2 * Mp * 4 + 1024 + 64;
         const size_t tabs = ((size_t)K * 4 * UP + (size_t)G * Mp) * 8;      // backward layout is the larger one
         tab_c = (base_c + tabs <= 64 * 1024) ? 1 : 0;
+        if (const char *tv = getenv("SMCPP_COOP_TAB")) tab_c = tab_c && atoi(tv) != 0;    // test hook: force the global-table path
         shm_c = base_c + (tab_c ? tabs : 0);
     }
     // LDS budget of the resident kernels: matrices + (emission, eigenvalue-power) tables + per-wavefront scratch

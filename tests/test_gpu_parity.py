@@ -293,7 +293,9 @@ def test_two_population_model_path(a1, a2, M, split):
     assert abs(im.loglik() - ll0) <= 1e-12 * abs(ll0)
 
 
-@pytest.mark.parametrize("M,n,length,chunk", [(2, 3, 400_000, 0), (3, 5, 300_000, 50), (15, 4, 300_000, 0),
+@pytest.mark.parametrize("M,n,length,chunk", [(64, 12, 400_000, -1),         # chunk = -1: emission / power tables from global memory
+                                               (48, 9, 300_000, -1),         # (the path taken when they do not fit the LDS)
+                                               (2, 3, 400_000, 0), (3, 5, 300_000, 50), (15, 4, 300_000, 0),
                                                (17, 6, 300_000, 40), (33, 8, 300_000, 0), (47, 9, 250_000, 64),
                                                (65, 10, 200_000, 0), (100, 12, 150_000, 64), (130, 6, 120_000, 0),
                                                (200, 8, 80_000, 48), (256, 10, 60_000, 0)])
@@ -310,10 +312,16 @@ def test_state_count_sweep_vs_oracle(M, n, length, chunk):
     im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
     im.model = PiecewiseModel(a, s, 1e4, "pop1")
     im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0
-    if chunk:
+    import os
+    if chunk > 0:
         im.set_chunking(chunk)
+    if chunk < 0:
+        os.environ["SMCPP_COOP_TAB"] = "0"
     im.save_gamma = True
-    im.E_step()
+    try:
+        im.E_step()
+    finally:
+        os.environ.pop("SMCPP_COOP_TAB", None)
     pi, T, keys = im.pi, im.transition, im.keys
     ep = im.emission_probs
     Etab = np.array([ep[tuple(k)] for k in keys.tolist()])

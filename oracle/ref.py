@@ -159,3 +159,42 @@ def random_times_shared(a, s, t1, t2, K):
     if rc != 0:
         raise RuntimeError(L_.ref_last_error().decode())
     return t, R
+
+
+def q_jac(obs, keys, n, a, da, s, hs, rho, theta, alpha, polarization_error):
+    """``HMM::Q`` values and gradients by the reference's own AD on one contig (see ``ref_q_jac`` in ref_harness.cpp).
+    ``keys`` [K x 3] sorted as the manager holds them; ``da`` [Kp x nder] seeds.  Returns (q [4], jac [4 x nder], loglik)."""
+    from . import prep_oracle
+    L_ = lib()
+    obs = np.ascontiguousarray(obs, dtype=np.int32)
+    keys = np.ascontiguousarray(keys, dtype=np.int32)
+    a = np.ascontiguousarray(a, dtype=np.float64); s = np.ascontiguousarray(s, dtype=np.float64)
+    da = np.ascontiguousarray(da, dtype=np.float64).reshape(len(a), -1)
+    hs = np.ascontiguousarray(hs, dtype=np.float64)
+    M = len(hs) - 1
+    nder = da.shape[1]
+    tk = [tuple(int(x) for x in k) for k in keys]
+    kind = np.zeros(len(tk), dtype=np.int32)
+    off = [0]; idx = []; w = []
+    need = [k for k in tk if not (k[2] == 0 and (k[0] == -1 or k[0] >= 0))]
+    bins = prep_oracle.construct_bins(need, n, polarization_error) if need else {}
+    for i, k in enumerate(tk):
+        if k[2] == 0 and k[0] == -1:
+            kind[i] = 1
+        elif k[2] == 0 and k[0] >= 0:
+            kind[i] = 2 + (k[0] % 2)
+        else:
+            for (aa, bb), p in bins[k].items():
+                idx.append(aa * (n + 1) + bb); w.append(p)
+        off.append(len(idx))
+    off = np.array(off, dtype=np.int32)
+    idx = np.array(idx if idx else [0], dtype=np.int32)
+    w = np.array(w if w else [0.0], dtype=np.float64)
+    q = np.zeros(4); jac = np.zeros((4, nder)); ll = np.zeros(1)
+    rc = L_.ref_q_jac(M, len(tk), _p(keys, C.c_int), len(obs), _p(obs, C.c_int), int(n), len(a), _p(a, C.c_double),
+                      _p(da, C.c_double), nder, _p(s, C.c_double), _p(hs, C.c_double), C.c_double(rho),
+                      C.c_double(theta), C.c_double(alpha), _p(kind, C.c_int), _p(off, C.c_int), _p(idx, C.c_int),
+                      _p(w, C.c_double), _p(q, C.c_double), _p(jac, C.c_double), _p(ll, C.c_double))
+    if rc != 0:
+        raise RuntimeError(L_.ref_last_error().decode())
+    return q, jac, float(ll[0])

@@ -350,3 +350,92 @@ extern "C" int ref_random_times_shared(int Kp, const double *a, const double *s,
         return 1;
     }
 }
+
+// Q with gradients by the reference's own forward-mode AD (Eigen::AutoDiffScalar, common.h:22-25), one-population:
+// pi, the transition matrix, the conditioned SFS (incorporate_theta) and the average coalescence times come from the
+// reference functions on adouble inputs seeded with da [Kp x nder]; the emission vector of key k is the linear
+// combination the reference's recompute_emission_probs forms (inference_manager.cpp:413-465, a translation unit that
+// cannot be built here): kind[k] = 1: all ones; 2 / 3: e2 column 0 / 1 (exp(-2 alpha theta E[T]) and its complement);
+// 0: sum of w * csfs[m](idx / (n+1), idx % (n+1)) over bin_idx/bin_w[bin_off[k] .. bin_off[k+1]) — the weights are
+// plain doubles computed by oracle/prep_oracle.py.  Then the real HMM::Estep and HMM::Q run on those adoubles.
+// Outputs: q [4], jac [4 x nder], loglik [1].
+extern "C" int ref_q_jac(int M, int K, const int *keys, int L, const int *obs_in, int n,
+                         int Kp, const double *a, const double *da, int nder, const double *s, const double *hs,
+                         double rho, double theta, double alpha,
+                         const int *kind, const int *bin_off, const int *bin_idx, const double *bin_w,
+                         double *q_out, double *jac_out, double *loglik)
+{
+    try
+    {
+        const int keylen = 3;
+        std::vector<adouble> av, sv;
+        for (int k = 0; k < Kp; ++k)
+        {
+            Eigen::VectorXd d(nder);
+            for (int j = 0; j < nder; ++j) d(j) = da[k * nder + j];
+            av.push_back(adouble(a[k], d));
+            sv.push_back(adouble(s[k]));
+        }
+        ParameterVector params{av, sv};
+        std::vector<double> hidden_states(hs, hs + M + 1);
+        PiecewiseConstantRateFunction<adouble> eta(params, hidden_states);
+        Vector<adouble> pi(M);
+        for (int m = 0; m < M - 1; ++m)
+            pi(m) = exp(-(eta.R(hidden_states.at(m)))) - exp(-(eta.R(hidden_states.at(m + 1))));
+        pi(M - 1) = exp(-(eta.R(hidden_states.at(M - 1))));
+        adouble small = eta.zero() + 1e-20;
+        pi = pi.unaryExpr([small](const adouble &x) { if (x < 1e-20) return small; return x; });
+        pi /= pi.sum();
+        Matrix<adouble> T = compute_transition(eta, rho);
+        OnePopConditionedSFS<adouble> csfs(n);
+        std::vector<Matrix<adouble> > sfs = incorporate_theta(csfs.compute(eta), theta);
+        std::vector<adouble> avg_ct = eta.average_coal_times();
+        Matrix<adouble> e2(M, 2);
+        for (int m = 0; m < M; ++m)
+        {
+            adouble log_e2m = -2. * alpha * theta * avg_ct.at(m);
+            e2(m, 0) = exp(log_e2m);
+            e2(m, 1) = -expm1(log_e2m);
+        }
+        std::map<block_key, Vector<adouble> > emission_probs;
+        for (int k = 0; k < K; ++k)
+        {
+            Vector<adouble> e(M);
+            e.fill(eta.zero());
+            if (kind[k] == 1) e.fill(eta.zero() + 1.);
+            else if (kind[k] == 2) e = e2.col(0);
+            else if (kind[k] == 3) e = e2.col(1);
+            else
+                for (int b = bin_off[k]; b < bin_off[k + 1]; ++b)
+                    for (int m = 0; m < M; ++m)
+                        e(m) += bin_w[b] * sfs.at(m)(bin_idx[b] / (n + 1), bin_idx[b] % (n + 1));
+            emission_probs.emplace(make_key(keys + k * keylen, keylen), e);
+        }
+        const int ncol = 1 + keylen;
+        Eigen::Map<Eigen::Matrix<int, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> > obs(
+            const_cast<int *>(obs_in), L, ncol);
+        spp::sparse_hash_set<std::pair<int, block_key> > targets;
+        for (int i = 0; i < L; ++i)
+            if (obs(i, 0) > 1) targets.insert({obs(i, 0), make_key(obs_in + i * ncol + 1, keylen)});
+        TransitionBundle tb(targets, &emission_probs);
+        bool sg = false;
+        InferenceBundle ib{&pi, &tb, &emission_probs, &sg};
+        HMM hmm(0, obs, &ib);
+        tb.update(T, true);
+        hmm.Estep(false);
+        if (loglik) *loglik = hmm.loglik();
+        Vector<adouble> qq = hmm.Q();
+        for (int i = 0; i < 4; ++i)
+        {
+            q_out[i] = qq(i).value();
+            for (int d = 0; d < nder; ++d)
+                jac_out[i * nder + d] = qq(i).derivatives().size() ? qq(i).derivatives()(d) : 0.0;
+        }
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_err = e.what();
+        return 1;
+    }
+}

@@ -404,3 +404,28 @@ def test_warm_start_matches_cold_start():
             assert np.max(np.abs(gw[k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300)
         tw, tc = warm.last_timing(), cold.last_timing()
         assert tw["fwd_passes"] <= tc["fwd_passes"] and tw["bwd_passes"] <= tc["bwd_passes"]
+
+
+@pytest.mark.parametrize("name", ["G1_M16_n4", "G3_M32_n10_2Mbp", "G4_M64_n20_2Mbp", "G7_M32_n8_chr11"])
+def test_q_gradient_matches_reference_autodiff(name):
+    """SURVEY.md §8(f) row f-1, golden G10: dQ/da_k from the engine (duals through the host preparation, linear in the
+    GPU E-step statistics) against the gradients the reference's own AD gives on the same contig."""
+    from smcpp_amd import _smcpp
+    from smcpp_amd.model import PiecewiseModel
+    import os
+    g = load_golden(name)
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G10_q_gradients.npz"))
+    im = _smcpp.PyOnePopInferenceManager(int(g["n"]), [np.ascontiguousarray(g["obs"])], g["hs"], ("pop1",),
+                                         float(g["pol"]))
+    m = PiecewiseModel(g["a"], g["s"], 1e4, "pop1")
+    m.differentiable = True
+    im.model = m
+    im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = float(g["alpha"])
+    im.E_step()
+    q, jac = im.Q_with_gradient()
+    qr, jr = G[name + "_q"], G[name + "_jac"]
+    assert np.all(np.abs(q - qr) <= STAT_TOL * np.maximum(np.abs(qr), 1e-12))
+    # every row of the Jacobian is linear in one family of statistics: same relative tolerance against its largest entry
+    for r in range(4):
+        scale = max(np.abs(jr[r]).max(), 1e-300)
+        assert np.max(np.abs(jac[r] - jr[r])) <= 2 * STAT_TOL * scale, (r, jac[r], jr[r])

@@ -268,7 +268,7 @@ def main():
         }
         if warm_obj:
             out["warm_start"] = warm_obj
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:          # the CPU baseline is timed at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(par, obs, args.cpu_seconds, M)
             if out["cpu_baseline"] and out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_1core"] = (value / world) / out["cpu_baseline"]["value"]

@@ -206,7 +206,7 @@ def main():
     traffic = None
     try:
         if args.workload == "headline" and args.length_mbp == 100.0:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_f_hbm_traffic_pmc.json")))["kernels"]
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_g_hbm_traffic_pmc.json")))["kernels"]
             k = [v for name, v in prof.items() if "k_fwd_coop" in name][0]
             # a pass that re-runs every chunk (the max over launches; converged check passes write nothing)
             traffic = 1024.0 * (2.0 * k["FETCH_SIZE_KB_max"] + k["WRITE_SIZE_KB_max"])

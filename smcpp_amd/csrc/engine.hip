@@ -398,7 +398,9 @@ void smcpp_im::make_chunks() {
         const char *envv = getenv("SMCPP_ROWS_PER_CHUNK");
         if (envv) lc = atoi(envv);
     }
-    if (lc <= 0) lc = (int)std::max<long long>(64, (rows + slots - 1) / slots);
+    // every chunk pays ~1000 rows of re-run history however short it is, so small inputs get few, long chunks rather
+    // than one sliver per CU (a 1 500-row contig: 3 chunks and 4 passes instead of 24 chunks and 15 passes)
+    if (lc <= 0) lc = (int)std::max<long long>(512, (rows + slots - 1) / slots);
     chunks.clear();
     max_chunks_per_contig = 1;
     for (int c = 0; c < n_contigs; ++c) {

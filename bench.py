@@ -97,6 +97,9 @@ def main():
     red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from smcpp_amd import _smcpp, synth
+    # torch.distributed.run exports OMP_NUM_THREADS=1 to every rank; the engine's host phase (one eigensystem per eigen
+    # key, in parallel) wants a handful of threads, which is what the reference's --cores / set_num_threads is for
+    _smcpp.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(1, world))))
     M, n, fixture, desc = WORKLOADS[args.workload]
     length_bp = int(args.length_mbp * 1e6)
     if args.workload == "c4":

@@ -93,3 +93,64 @@ def test_watterson_recode_and_windowed_counts():
     assert wc.shape == (2, 16 // 4 + 1)
     # positions: 0-4 hom, 5 het, 6-8 missing, 9-10 hom, 11 (a=2, even) hom, 12-15 het
     assert wc[0].tolist() == [4, 2, 3, 4, 0] and wc[1].tolist() == [0, 1, 0, 4, 0]
+
+
+def _random_rows(rng, L, n=6, npop=1):
+    rows = []
+    for _ in range(L):
+        r = [int(rng.integers(1, 40))]
+        for _p in range(npop):
+            if rng.random() < 0.1:
+                r += [-1, 0, 0]
+            else:
+                nb = int(rng.choice([0, 0, 0, n]))
+                r += [int(rng.integers(0, 3)), int(rng.integers(0, nb + 1)), nb]
+        rows.append(r)
+    return np.array(rows, dtype=np.int32)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_shaping_invariants_on_random_contigs(seed):
+    """Properties the reference's pipeline relies on (`estimation_tools.py:51-60,117-167`, `_estimation_tools.pyx:8-173`):
+    spans are conserved, compression is idempotent and never leaves equal neighbours, thinning keeps the full
+    observation exactly once per window, binning emits one span-1 row per window."""
+    from smcpp_amd import data as D
+    rng = np.random.default_rng(seed)
+    npop = 1 + seed % 2
+    raw = _random_rows(rng, 300, npop=npop)
+    total = int(raw[:, 0].sum())
+    c = D.compress_repeated_obs(raw)
+    assert int(c[:, 0].sum()) == total
+    assert np.all(np.any(c[1:, 1:] != c[:-1, 1:], axis=1))
+    np.testing.assert_array_equal(D.compress_repeated_obs(c), c)
+    # expanding both to one row per base gives the same sequence
+    np.testing.assert_array_equal(np.repeat(raw[:, 1:], raw[:, 0], axis=0), np.repeat(c[:, 1:], c[:, 0], axis=0))
+    thinning = int(rng.integers(5, 60))
+    t = D.thin_data(raw, thinning)
+    assert int(t[:, 0].sum()) == total
+    per_base_raw = np.repeat(raw[:, 1:], raw[:, 0], axis=0)
+    per_base_thin = np.repeat(t[:, 1:], t[:, 0], axis=0)
+    keep = np.arange(total) % thinning == thinning - 1          # last position of every window
+    sa2 = per_base_raw[:, 0::3].sum(axis=1) == 2
+    # kept positions carry the full observation (unless the distinguished counts sum to 2: recoded to zeros)
+    np.testing.assert_array_equal(per_base_thin[keep & ~sa2], per_base_raw[keep & ~sa2])
+    assert np.all(per_base_thin[keep & sa2] == 0)
+    # every other position keeps the distinguished counts only
+    other = ~keep
+    assert np.all(per_base_thin[other][:, 1::3] == 0) and np.all(per_base_thin[other][:, 2::3] == 0)
+    np.testing.assert_array_equal(per_base_thin[other & ~sa2][:, 0::3], per_base_raw[other & ~sa2][:, 0::3])
+    w = int(rng.integers(3, 25))
+    b = D.bin_observations(raw, w, [2] + [0] * (npop - 1))
+    assert np.all(b[:, 0] == 1)
+    assert len(b) in (total // w, total // w + 1, -(-total // w))
+    # cutting at long missing runs: the pieces put back together (minus the leading missing row of each piece and the
+    # runs that were cut out) give the original rows
+    raw2 = raw.copy()
+    miss = np.zeros(raw.shape[1], dtype=np.int32); miss[0] = 5000; miss[1::3] = -1
+    raw2 = np.insert(raw2, [50, 180], miss, axis=0)
+    pieces = D.break_long_spans(D.Contig(raw2, tuple("p%d" % i for i in range(npop)), [6] * npop, [2] + [0] * (npop - 1)), 1000)
+    assert len(pieces) == 3
+    back = np.concatenate([p.data[1:] for p in pieces])
+    np.testing.assert_array_equal(back, raw)
+    for p in pieces:
+        assert p.data[0, 0] == 1 and np.all(p.data[0, 1::3] == -1)

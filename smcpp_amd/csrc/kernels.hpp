@@ -1716,31 +1716,45 @@ __global__ __launch_bounds__(256) void k_s1_scalars(S1Args a) {
     double gs[NPL];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) gs[q] = 0.0;
-    // wavefront w takes rows start + 4*(4*it + u) + w: four independent rows in flight per iteration
+    // wavefront w takes rows start + 4*(4*it + u) + w: four independent rows in flight per iteration.  All loads are
+    // unconditional (row index clamped into the slab, padded states read the zeros the chains left there) and the row
+    // indices of the NEXT iteration are fetched while this one is reduced: one memory round trip per iteration instead
+    // of three (index -> operands -> log_c), and no exec-mask branch around a load (see k_rank_acc).
+    const int last = sl.end - 1;
+    int elln[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) elln[u] = a.perm[min(sl.start + wave + 4 * u, last)];
     for (int r0 = sl.start + wave; r0 < sl.end; r0 += 16) {
-        double v[4][NPL];
+        double v[4][NPL], lc[4];
         size_t row[4];
         bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int r = r0 + 4 * u;
-            ok[u] = r < sl.end;
-            const int ell = ok[u] ? a.perm[r] : 1;
-            row[u] = (size_t)(sl.base + ell);
+            ok[u] = r0 + 4 * u < sl.end;
+            row[u] = (size_t)(sl.base + elln[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) elln[u] = a.perm[min(r0 + 16 + 4 * u, last)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            lc[u] = a.logc[row[u]];
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
-                const int i = lane + 64 * q;
-                v[u][q] = (ok[u] && i < M) ? (double)a.alpha[row[u] * Mp + i] * a.beta[row[u] * Mp + i] : 0.0;
+                const int i = min(lane + 64 * q, Mp - 1);
+                v[u][q] = (double)a.alpha[row[u] * Mp + i] * a.beta[row[u] * Mp + i];
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (!ok[u]) continue;                                   // wave-uniform
             double part = 0.0;
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) part += v[u][q];
+            for (int q = 0; q < NPL; ++q) {
+                if (lane + 64 * q >= M) v[u][q] = 0.0;
+                part += v[u][q];
+            }
             const double p = wave_sum_dpp(part);
             const double ip = 1.0 / p;
+            if (!ok[u]) continue;                                   // wave-uniform
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
                 const double g = v[u][q] / p;
@@ -1748,7 +1762,7 @@ __global__ __launch_bounds__(256) void k_s1_scalars(S1Args a) {
                 const int i = lane + 64 * q;
                 if (a.gamma_rows && i < Mp) a.gamma_rows[row[u] * Mp + i] = g;
             }
-            if (lane == 0) a.w1[row[u]] = ip / exp(a.logc[row[u]]);
+            if (lane == 0) a.w1[row[u]] = ip / exp(lc[u]);
         }
     }
 #pragma unroll

@@ -429,3 +429,36 @@ def test_q_gradient_matches_reference_autodiff(name):
     for r in range(4):
         scale = max(np.abs(jr[r]).max(), 1e-300)
         assert np.max(np.abs(jac[r] - jr[r])) <= 2 * STAT_TOL * scale, (r, jac[r], jr[r])
+
+
+def test_config_c1_reference_example_end_to_end():
+    """Config C1 (BASELINE.json configs[0]): the reference's example VCF -> rows (smcpp_amd.vcf2smc) -> the E-step on the
+    un-binned contig with the missing row `estimate` prepends, and on the thinned / binned / compressed contig the main
+    EM loop sees; GPU against the C restatement on the same rows, parameters from the engine's own preparation."""
+    import os
+    from oracle import oracle
+    from smcpp_amd import _smcpp, data as D, synth, vcf2smc as V
+    from smcpp_amd.model import PiecewiseModel
+    vcf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example.vcf.gz")
+    c, _ = V.vcf2smc(vcf, "1", ("pop1", ["msp_0", "msp_1", "msp_2"]))
+    n = c.n[0]
+    raw = np.ascontiguousarray(np.vstack([[1, -1, 0, 0], c.data]), dtype=np.int32)
+    assert raw.shape == (1850, 4)                                  # SURVEY.md §8d: what the reference's bootstrap sees
+    thin = D.compress_repeated_obs(D.bin_observations(D.thin_data(c.data, 895), 100, [2]))
+    thin = np.ascontiguousarray(np.vstack([[1, -1, 0, 0], thin]), dtype=np.int32)
+    a, s = synth.model_pieces()
+    for rows, M in ((raw, 1), (raw, 16), (thin, 15)):
+        hs = synth.hidden_states(M)
+        im = _smcpp.PyOnePopInferenceManager(n, [rows], hs, ("pop1",), 0.5)
+        im.model = PiecewiseModel(a, s, 1e4, "pop1")
+        im.theta = 1e-3 if rows is raw else 0.1; im.rho = 2.5e-4 if rows is raw else 2.5e-2; im.alpha = 1.0
+        im.E_step()
+        ep = im.emission_probs
+        Etab = np.array([ep[tuple(k)] for k in im.keys.tolist()])
+        o = oracle.estep(im.pi, im.transition, im.keys, Etab, rows)
+        assert abs(im.loglik() - o["loglik"]) <= LL_TOL * abs(o["loglik"])
+        assert rel_err(im.xisums[0], o["xisum"]) <= STAT_TOL
+        for k, v in o["gamma_sums"].items():
+            assert np.max(np.abs(im.gamma_sums[0][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300)
+        q = np.array(im.Q(separate=True))
+        assert np.all(np.abs(q - o["q"]) <= STAT_TOL * np.maximum(np.abs(o["q"]), 1e-12))

@@ -200,3 +200,27 @@ def test_vcf2smc_on_the_reference_example(tmp_path):
     # a missing cutoff turns long gaps into missing rows
     c3, _ = V.vcf2smc(vcf, "1", ("pop1", ["msp_0", "msp_1", "msp_2"]), missing_cutoff=5000)
     assert np.any((c3.data[:, 0] > 5000) & (c3.data[:, 1] == -1)) and int(c3.data[:, 0].sum()) == 1_000_000
+
+
+def test_reference_pipeline_shape_on_the_example():
+    """The reference's `estimate` pipeline on its example contig (`analysis/base.py:48-58`, `analysis.py:59-66`:
+    Compress, BreakLongSpans(100000), Thin(500 ln(2+n)), BinObservations(100), RecodeMonomorphic, Compress).  Measured
+    with the reference end to end: the bootstrap sees 1 850 un-binned rows, the main EM loop 2 727 rows
+    with 3 distinct keys, 10 (span > 1, key) groups and a longest span of 14 — reproduced exactly."""
+    from smcpp_amd import data as D, vcf2smc as V
+    vcf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example.vcf.gz")
+    c, _ = V.vcf2smc(vcf, "1", ("pop1", ["msp_0", "msp_1", "msp_2"]))
+    c.data = D.compress_repeated_obs(c.data)
+    pieces = D.break_long_spans(c, 100000)
+    assert len(pieces) == 1 and pieces[0].data.shape == (1850, 4)
+    p = pieces[0]
+    thinning = int(500 * np.log(2 + p.n[0]))
+    assert thinning == 895
+    b = D.bin_observations(D.thin_data(p.data, thinning), 100, [2])
+    q = D.recode_monomorphic(D.Contig(b, p.pid, p.n, p.a))
+    z = D.compress_repeated_obs(q.data)
+    assert len(z) == 2727
+    assert len(np.unique(z[:, 1:], axis=0)) == 3
+    assert len(np.unique(z[z[:, 0] > 1], axis=0)) == 10
+    assert int(z[:, 0].max()) == 14
+    assert abs(D.watterson_theta(pieces) - 4.02337e-4) < 1e-8

@@ -444,14 +444,17 @@ def test_config_c1_reference_example_end_to_end():
     n = c.n[0]
     raw = np.ascontiguousarray(np.vstack([[1, -1, 0, 0], c.data]), dtype=np.int32)
     assert raw.shape == (1850, 4)                                  # what the reference's bootstrap sees
-    thin = D.compress_repeated_obs(D.bin_observations(D.thin_data(c.data, 895), 100, [2]))
-    thin = np.ascontiguousarray(np.vstack([[1, -1, 0, 0], thin]), dtype=np.int32)
+    piece = D.break_long_spans(D.Contig(D.compress_repeated_obs(c.data), c.pid, c.n, c.a), 100000)[0]
+    binned = D.recode_monomorphic(D.Contig(D.bin_observations(D.thin_data(piece.data, 895), 100, [2]), c.pid, c.n, c.a))
+    thin = np.ascontiguousarray(D.compress_repeated_obs(binned.data), dtype=np.int32)
+    assert thin.shape == (2727, 4)                                 # what the reference's main EM loop sees
     a, s = synth.model_pieces()
     for rows, M in ((raw, 1), (raw, 16), (thin, 15)):
         hs = synth.hidden_states(M)
         im = _smcpp.PyOnePopInferenceManager(n, [rows], hs, ("pop1",), 0.5)
         im.model = PiecewiseModel(a, s, 1e4, "pop1")
-        im.theta = 1e-3 if rows is raw else 0.1; im.rho = 2.5e-4 if rows is raw else 2.5e-2; im.alpha = 1.0
+        # mutation rate per row unit from Watterson's estimator of this contig (4.02e-4 per bp; bins of 100 bp)
+        im.theta = 4.02e-4 if rows is raw else 4.02e-2; im.rho = 1e-4 if rows is raw else 1e-2; im.alpha = 1.0
         im.E_step()
         ep = im.emission_probs
         Etab = np.array([ep[tuple(k)] for k in im.keys.tolist()])

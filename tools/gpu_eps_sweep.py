@@ -1,5 +1,5 @@
 """Developer tool (not collected by pytest): accuracy / time of the chunk-boundary tolerances on the headline workload.
-The single-chunk run (= the purely sequential algorithm) is the yardstick.  Usage: python tests/gpu_eps_sweep.py"""
+The single-chunk run (= the purely sequential algorithm) is the yardstick.  Usage: python tools/gpu_eps_sweep.py"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -651,6 +651,8 @@ void smcpp_im::prepare_params() {
 
 void smcpp_im::host_prep_and_upload() {
     hipStream_t s = stream;
+    const bool tm = getenv("SMCPP_HOST_TIMING") != nullptr;
+    auto tp0 = std::chrono::steady_clock::now();
     const size_t MM = (size_t)Mp * Mp;
     const size_t em = std::max<size_t>(1, (size_t)Ke) * MM;
     std::vector<double> PinvT(em, 0.0), PT(em, 0.0), Prm(em, 0.0), Pinvrm(em, 0.0);
@@ -710,6 +712,7 @@ void smcpp_im::host_prep_and_upload() {
         }
     }
     if (!err.empty()) throw std::runtime_error(err);
+    auto tp1 = std::chrono::steady_clock::now();
     std::vector<float> T4;
     std::vector<double> fA2, fB2, bA2, bB2, bC2;
     if (Mp <= 64) {
@@ -784,7 +787,14 @@ void smcpp_im::host_prep_and_upload() {
         d_qPrm.place(qPrm, d_param, hb, off); d_qPinvrm.place(qPinvrm, d_param, hb, off);
     }
     if (off > need) throw std::runtime_error("internal: parameter arena overflow");
+    auto tp2 = std::chrono::steady_clock::now();
     HIPCHK(hipMemcpyAsync(d_param, hb, off, hipMemcpyHostToDevice, s));
+    if (tm) {
+        auto tp3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[host] eigensystems+packing %.3f ms, layouts+staging %.3f ms, copy enqueue %.3f ms (%zu bytes)\n",
+                ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), off);
+    }
     // no synchronisation: the copies read the pinned arena, which lives until the next E-step resets it
 }
 

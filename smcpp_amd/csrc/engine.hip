@@ -200,6 +200,8 @@ struct smcpp_im {
     DevBuf<unsigned char> d_present;       // device copies used by k_pack_stats
     DevBuf<int> d_g2l;
     bool pack_tables_ready = false;
+    std::vector<double> hs_PinvT, hs_PT, hs_Prm, hs_Pinvrm, hs_dsc, hs_dun, hs_dpow, hs_gsc, hs_gls, hs_TdT, hs_Td, hs_Ep;
+    std::vector<float> hs_pi_f, hs_Tf;      // host staging of the per-E-step parameter arrays (see host_prep_and_upload)
     PinnedArena stage;
     char *d_param = nullptr;      // device side of the per-E-step parameter arena
     int *h_flags = nullptr;       // pinned: per-pass "something re-ran" flags of both chains, read back every round
@@ -655,11 +657,18 @@ void smcpp_im::host_prep_and_upload() {
     auto tp0 = std::chrono::steady_clock::now();
     const size_t MM = (size_t)Mp * Mp;
     const size_t em = std::max<size_t>(1, (size_t)Ke) * MM;
-    std::vector<double> PinvT(em, 0.0), PT(em, 0.0), Prm(em, 0.0), Pinvrm(em, 0.0);
-    std::vector<double> dsc(std::max<size_t>(1, (size_t)Ke) * Mp, 0.0), dun(std::max<size_t>(1, (size_t)Ke) * Mp, 0.0);
-    std::vector<double> dpow(std::max<size_t>(1, (size_t)G) * Mp, 0.0), gsc(std::max(1, G), 1.0), gls(std::max(1, G), 0.0);
-    std::vector<float> pi_f(Mp, 0.f), Tf(MM, 0.f);
-    std::vector<double> TdT(MM, 0.0), Td(MM, 0.0), Ep((size_t)K * Mp, 0.0);
+    // staging vectors live in the manager: allocated and zeroed once (only entries of real states are ever written, so
+    // the padding stays zero), not ~0.5 MB of fresh zero-filled storage per E-step
+    auto ensure = [](auto &v, size_t n, auto init) { if (v.size() != n) v.assign(n, init); };
+    ensure(hs_PinvT, em, 0.0); ensure(hs_PT, em, 0.0); ensure(hs_Prm, em, 0.0); ensure(hs_Pinvrm, em, 0.0);
+    ensure(hs_dsc, std::max<size_t>(1, (size_t)Ke) * Mp, 0.0); ensure(hs_dun, std::max<size_t>(1, (size_t)Ke) * Mp, 0.0);
+    ensure(hs_dpow, std::max<size_t>(1, (size_t)G) * Mp, 0.0); ensure(hs_gsc, (size_t)std::max(1, G), 1.0);
+    ensure(hs_gls, (size_t)std::max(1, G), 0.0);
+    ensure(hs_pi_f, (size_t)Mp, 0.f); ensure(hs_Tf, MM, 0.f);
+    ensure(hs_TdT, MM, 0.0); ensure(hs_Td, MM, 0.0); ensure(hs_Ep, (size_t)K * Mp, 0.0);
+    std::vector<double> &PinvT = hs_PinvT, &PT = hs_PT, &Prm = hs_Prm, &Pinvrm = hs_Pinvrm, &dsc = hs_dsc, &dun = hs_dun,
+                        &dpow = hs_dpow, &gsc = hs_gsc, &gls = hs_gls, &TdT = hs_TdT, &Td = hs_Td, &Ep = hs_Ep;
+    std::vector<float> &pi_f = hs_pi_f, &Tf = hs_Tf;
     // groups of each eigen key (so that one task finishes everything that depends on one eigensystem)
     std::vector<std::vector<int>> groups_of(Ke);
     for (int g = 0; g < G; ++g) groups_of[groups[g].eig].push_back(g);

@@ -292,8 +292,10 @@ def cpu_baseline(par, obs, budget_s, M):
             from oracle import oracle as orc
         pi, T, keys, E = par["pi"], par["T"], par["keys"], par["E"]
         probe = min(len(obs), 2000)
+        fn = ref.estep if kind == "reference" else orc.estep
+        fn(pi, T, keys, E, obs[:probe])                      # first call: library load, page-in
         t = time.perf_counter()
-        (ref.estep if kind == "reference" else orc.estep)(pi, T, keys, E, obs[:probe])
+        fn(pi, T, keys, E, obs[:probe])
         per_row = (time.perf_counter() - t) / probe
         rows = int(min(len(obs), max(probe, budget_s / per_row)))
         t = time.perf_counter()

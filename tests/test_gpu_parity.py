@@ -465,3 +465,25 @@ def test_config_c1_reference_example_end_to_end():
             assert np.max(np.abs(im.gamma_sums[0][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300)
         q = np.array(im.Q(separate=True))
         assert np.all(np.abs(q - o["q"]) <= STAT_TOL * np.maximum(np.abs(o["q"]), 1e-12))
+
+
+def test_em_on_the_reference_example_pipeline():
+    """VCF -> rows -> the reference's shaping pipeline -> balanced hidden states -> three EM iterations on the GPU
+    (the whole C1 flow of SURVEY.md §8d, with this repository's callers of the path): the log-likelihood must rise."""
+    import os
+    from smcpp_amd import data as D, posterior as PO, vcf2smc as V
+    from smcpp_amd.estimate import em
+    from smcpp_amd.model import PiecewiseModel
+    vcf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example.vcf.gz")
+    c, _ = V.vcf2smc(vcf, "1", ("pop1", ["msp_0", "msp_1", "msp_2"]))
+    piece = D.break_long_spans(D.Contig(D.compress_repeated_obs(c.data), c.pid, c.n, c.a), 100000)[0]
+    theta_bp = D.watterson_theta([piece])
+    binned = D.recode_monomorphic(D.Contig(D.bin_observations(D.thin_data(piece.data, 895), 100, [2]), c.pid, c.n, c.a))
+    rows = np.ascontiguousarray(D.compress_repeated_obs(binned.data), dtype=np.int32)
+    s = np.diff(np.concatenate([[0.0], np.logspace(-2, 0.7, 8)]))
+    a0 = np.ones(len(s))
+    hs = PO.balance_hidden_states(PiecewiseModel(a0, s, 1e4, "pop1"), 16)
+    assert len(hs) == 17 and hs[0] == 0 and np.isinf(hs[-1]) and np.all(np.diff(hs[:-1]) > 0)
+    model, ll = em([rows], c.n[0], hs, a0, s, 100 * theta_bp, 25 * theta_bp, iterations=3, penalty=1.0)
+    assert np.all(np.diff(ll) >= -1e-6 * np.abs(ll[:-1])), ll
+    assert ll[-1] > ll[0]

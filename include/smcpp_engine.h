@@ -131,6 +131,12 @@ void smcpp_set_num_threads(int k);
 
 /* ---- host-only helpers (no device needed; used by the CPU test-suite) ------------------------------------ */
 
+/* Test hook: 1 = evaluate the conditioned SFS term by term exactly as src/piecewise_constant_rate_function.cpp:214-334
+ * and src/conditioned_sfs.cpp:42-83 write it (O(pieces^2 n^2), reproduces the compiled reference to 1e-15 relative);
+ * 0 (default) = the factored O(pieces n^2) evaluation (same integrals through prefix / suffix sums over the pieces,
+ * within 5e-16 absolute of the literal one on the emission table).  Returns the previous setting. */
+int smcpp_host_set_csfs_direct(int on);
+
 /* eigensystem(EigenSolver(A)) as TransitionBundle::update uses it (src/transition_bundle.cpp:22,
  * include/transition_bundle.h:9-30): P_r, Pinv_r [n x n], d_r [n], scale = max |d|, max |imag d|. */
 int smcpp_host_eigensystem(int n, const double *A, double *P, double *Pinv, double *d, double *scale,

@@ -11,14 +11,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsmcpp_engine.so")
 SOURCES = ["engine.hip"]
-DEPS = ["engine.hip", "kernels.hpp", "nonsym_eig.hpp", "prep.hpp", os.path.join("..", "..", "include", "smcpp_engine.h")]
+
+
+def _deps():
+    """Every source the library is compiled from: csrc/*.hip, csrc/*.hpp and the public header."""
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))] + \
+           [os.path.join(HERE, "..", "include", "smcpp_engine.h"), os.path.abspath(__file__)]
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def _gmp():

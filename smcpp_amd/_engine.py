@@ -57,6 +57,7 @@ EXPORTS = [
     "smcpp_host_eigensystem", "smcpp_host_prep_onepop", "smcpp_host_prep_onepop_jac", "smcpp_num_derivatives",
     "smcpp_host_rate_function", "smcpp_host_rate_function_jac", "smcpp_host_random_coal_times", "smcpp_host_raw_sfs",
     "smcpp_set_params_twopop", "smcpp_host_joint_csfs", "smcpp_host_prep_twopop", "smcpp_set_warm_start",
+    "smcpp_host_set_csfs_direct",
 ]
 
 
@@ -71,6 +72,12 @@ def dptr(a):
 
 def iptr(a):
     return None if a is None else a.ctypes.data_as(_ip)
+
+
+def host_set_csfs_direct(on):
+    """Test hook: literal (reference-order) evaluation of the conditioned SFS instead of the factored one; returns the
+    previous setting."""
+    return bool(lib().smcpp_host_set_csfs_direct(int(bool(on))))
 
 
 def host_eigensystem(A):

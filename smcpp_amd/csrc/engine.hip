@@ -1668,6 +1668,12 @@ void *smcpp_stream(smcpp_im *im) { return (void *)im->stream; }
 
 void smcpp_set_num_threads(int k) { if (k > 0) omp_set_num_threads(k); }
 
+int smcpp_host_set_csfs_direct(int on) {
+    const int prev = smcpp_host::csfs_direct_flag();
+    smcpp_host::csfs_direct_flag() = on != 0;
+    return prev;
+}
+
 // ---- host-only helpers exported for the CPU test-suite (no device needed) --------------------------------------
 
 // eigensystem(EigenSolver(A)) as used by TransitionBundle::update: P_r, Pinv_r [n x n], d_r [n], scale, max|imag|

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <map>
 #include <memory>
@@ -705,9 +706,11 @@ inline S dcs_sorted(std::vector<S> &v) {
     return s;
 }
 
-// raw CSFS per hidden state: out[m] is 3 x (n+1) row-major
+// raw CSFS per hidden state: out[m] is 3 x (n+1) row-major.  Literal evaluation, term by term as the reference
+// writes it (O(pieces^2 n^2) transcendental calls); kept as the in-tree cross-check of conditioned_sfs() below
+// (tests/test_prep.py) and selected at run time by SMCPP_CSFS_DIRECT=1 / smcpp_host_set_csfs_direct(1).
 template <typename S>
-inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, const CsfsTables &tb, bool below_only = false) {
+inline std::vector<std::vector<S>> conditioned_sfs_direct(const RateFunctionT<S> &eta, const CsfsTables &tb, bool below_only = false) {
     const int n = tb.n;
     const int M = (int)eta.hidden_states.size() - 1;
     const int nd = dual_nder();
@@ -752,6 +755,232 @@ inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, 
             S s(0.0);
             for (int j = 0; j < n + 1; ++j) s += tjj_below[(size_t)m * (n + 1) + j] * tb.M1(j, b);
             csfs[m][1 * (n + 1) + b] += s;
+        }
+    }
+    return csfs;
+}
+
+// The same quantity in O(pieces n^2) transcendental calls.  The reference's inner sums over the pieces after (above)
+// or before (below) piece m,
+//     sum_k single_integral(rate, piece k, log_coef) = sum_k exp(-rate R_k + log_coef) g(rate, k),
+//     g(rate, k) = -expm1(-rate ada_k (t_{k+1} - t_k)) / (ada_k rate)        (no expm1 factor on the infinite last piece)
+// depend on (m, lam) only through the factor exp(log_coef), so they are
+//     above:  exp(-rate R_{m+1} + log_coef) * Ssuf[rate][m],   Ssuf[rate][m-1] = g(rate, m) + exp(-rate (R_{m+1} - R_m)) Ssuf[rate][m]
+//     below:  exp(log_coef)                 * Ppre[rate][m],   Ppre[rate][m+1] = Ppre[rate][m] + exp(-rate R_m) g(rate, m)
+// (all terms are non-negative: no cancellation; the leading factor is formed with the reference's own operation order
+// for its first term k = m+1).  Everything that depends on one index only (exp(-l1 R_m + log_coef), expm1(-l1 adadiff),
+// exp(-rate adadiff)) is hoisted out of the (lam, rate) double loop with its arithmetic unchanged.  One OpenMP task per
+// hidden state does the integrals, the compensated contractions with X0 / X2 and the Moran back-transformation of
+// that state.
+// 0 = factored evaluation (default), 1 = literal evaluation; initialised from SMCPP_CSFS_DIRECT, set over the C ABI by
+// smcpp_host_set_csfs_direct (test hook)
+inline int &csfs_direct_flag() {
+    static int flag = getenv("SMCPP_CSFS_DIRECT") != nullptr ? 1 : 0;
+    return flag;
+}
+
+template <typename S>
+struct CsfsPieceTables {
+    int K = 0, n = 0;
+    std::vector<S> Ssuf;     // [n][K]       rate = C(j,2),   j = 2..n+1 : suffix sums of the "above" integrals
+    std::vector<S> Ppre;     // [n+1][K+1]   rate = C(j,2)-1, j = 2..n+2 : prefix sums of the "below" integrals
+};
+
+template <typename S>
+inline CsfsPieceTables<S> csfs_piece_tables(const RateFunctionT<S> &eta, int n, bool below_only) {
+    CsfsPieceTables<S> t;
+    const int K = eta.K;
+    t.K = K; t.n = n;
+    const std::vector<double> &ts = eta.ts;
+    const int nd = dual_nder();
+    if (!below_only && n >= 1) {
+        t.Ssuf.assign((size_t)n * K, S(0.0));
+#pragma omp parallel for schedule(static)
+        for (int jr = 0; jr < n; ++jr) {
+            DualScope sc(nd);
+            const double rate = (double)RateFunctionT<S>::nC2(jr + 2);
+            S *Sj = &t.Ssuf[(size_t)jr * K];
+            Sj[K - 1] = S(0.0);
+            for (int m = K - 1; m >= 1; --m) {
+                const S &ad = eta.ada[m];
+                if (ts[m + 1] < INFINITY) {
+                    const S em = m_expm1(-rate * ad * (ts[m + 1] - ts[m]));
+                    Sj[m - 1] = -em / (ad * rate) + (1.0 + em) * Sj[m];
+                } else Sj[m - 1] = 1.0 / (ad * rate);
+            }
+        }
+    }
+    t.Ppre.assign((size_t)(n + 1) * (K + 1), S(0.0));
+#pragma omp parallel for schedule(static)
+    for (int jr = 0; jr < n + 1; ++jr) {
+        DualScope sc(nd);
+        const long ratel = RateFunctionT<S>::nC2(jr + 2) - 1;
+        const double rate = (double)ratel;
+        S *Pj = &t.Ppre[(size_t)jr * (K + 1)];
+        Pj[0] = S(0.0);
+        for (int m = 0; m < K; ++m) {
+            if (ratel == 0) { Pj[m + 1] = S(ts[m + 1]); continue; }      // sum_k (t_{k+1} - t_k) = t_{m+1}
+            const S &ad = eta.ada[m];
+            S g = m_exp(-rate * eta.Rrng[m]);
+            if (ts[m + 1] < INFINITY) g *= -m_expm1(-rate * ad * (ts[m + 1] - ts[m]));
+            g /= ad * rate;
+            Pj[m + 1] = Pj[m] + g;
+        }
+    }
+    return t;
+}
+
+// Accurate sum of v[0..cnt).  The reference sorts the terms by decreasing magnitude and applies doubly-compensated
+// summation (common.h:27-46, conditioned_sfs.cpp:63-67), whose result is within 2 ulp of the exact sum; a cascaded
+// TwoSum accumulation (error eps |sum| + cnt eps^2 sum |v|) gives that quality without the sort, which was 85 % of the
+// time of this function once the integrals were factored.  Derivative parts are plain sums (they are linear in the terms).
+inline double accurate_sum(const double *v, int cnt) {
+    double hi = 0.0, lo = 0.0;
+    for (int i = 0; i < cnt; ++i) {
+        const double x = v[i], t = hi + x, z = t - hi;
+        lo += (hi - (t - z)) + (x - z);
+        hi = t;
+    }
+    return hi + lo;
+}
+template <typename F>
+inline Dual<F> accurate_sum(const Dual<F> *v, int cnt) {
+    Dual<F> r;
+    F hi = 0, lo = 0;
+    for (int i = 0; i < cnt; ++i) {
+        const F x = v[i].v, t = hi + x, z = t - hi;
+        lo += (hi - (t - z)) + (x - z);
+        hi = t;
+        SMCPP_DUAL_LOOP r.d[i_] += v[i].d[i_];
+    }
+    r.v = hi + lo;
+    return r;
+}
+
+template <typename S>
+inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, const CsfsTables &tb, bool below_only = false) {
+    const bool direct = csfs_direct_flag() != 0;
+    bool zero_ada = false;
+    for (const S &x : eta.ada) zero_ada = zero_ada || sval(x) == 0;
+    if (direct || zero_ada) return conditioned_sfs_direct<S>(eta, tb, below_only);   // ada == 0: the factored sums divide by it
+    typedef RateFunctionT<S> RF;
+    const int n = tb.n;
+    const int M = (int)eta.hidden_states.size() - 1;
+    const int K = eta.K;
+    const int nd = dual_nder();
+    const std::vector<double> &ts = eta.ts;
+    const std::vector<S> &ada = eta.ada, &Rrng = eta.Rrng;
+    const std::vector<int> &hsi = eta.hs_indices;
+    const bool above = n >= 1 && !below_only;
+    const CsfsPieceTables<S> pt = csfs_piece_tables<S>(eta, n, below_only);
+    std::vector<std::vector<S>> csfs(M, std::vector<S>((size_t)3 * (n + 1), S(0.0)));
+#pragma omp parallel
+    {
+        DualScope sc(nd);
+        std::vector<S> Ca(above ? (size_t)(n + 1) * n : 0), A(n + 1), A1(n + 1), B(n + 1), El(n + 1), ert(n), e1(n), tmp0(n + 1), tmp2(n + 1), v(n),
+            below(n + 1);
+#pragma omp for schedule(dynamic)
+        for (int h = 0; h < M; ++h) {
+            const S Rh = Rrng[hsi[h]], Rh1 = Rrng[hsi[h + 1]];
+            S log_denom = -Rh;
+            if (sval(Rh1) != INFINITY) log_denom += m_log(-m_expm1(-(Rh1 - Rh)));
+            S *out = csfs[h].data();
+            // ---- above (tjj_double_integral_above for every jj, piecewise_constant_rate_function.cpp:214-299) ----
+            if (above) {
+                for (S &x : Ca) x = S(0.0);
+                const S log_coef0 = -log_denom;
+                for (int m = hsi[h]; m < hsi[h + 1]; ++m) {
+                    const S &ad = ada[m];
+                    const bool fin = ts[m + 1] < INFINITY;
+                    const S adadiff = ad * (ts[m + 1] - ts[m]);
+                    const S Rm = Rrng[m], Rm1 = Rrng[m + 1];
+                    const S dR = Rm1 - Rm;
+                    for (int jl = 0; jl <= n; ++jl) {
+                        const double l1 = (double)(RF::nC2(jl + 2));               // lam + 1
+                        A[jl] = m_exp(-l1 * Rm + log_coef0);
+                        if (m + 1 < K) A1[jl] = m_exp(-l1 * Rm1 + log_coef0);
+                        if (fin) { B[jl] = m_expm1(-l1 * adadiff); El[jl] = m_exp(-l1 * adadiff); }
+                    }
+                    if (fin) for (int jr = 0; jr < n; ++jr) {
+                        ert[jr] = m_exp(-(double)RF::nC2(jr + 2) * adadiff);
+                        e1[jr] = m_exp(-(double)RF::nC2(jr + 2) * dR);
+                    }
+                    for (int jl = 0; jl <= n; ++jl) {
+                        const long l1l = RF::nC2(jl + 2);
+                        const double l1 = (double)l1l;
+                        for (int jr = 0; jr < n; ++jr) {
+                            const long ratel = RF::nC2(jr + 2);
+                            const double rt = (double)ratel;
+                            S &tgt = Ca[(size_t)jl * n + jr];
+                            // _double_integral_above_helper on the piece itself (rate >= 1 here)
+                            if (l1l == ratel) {
+                                if (!fin) tgt += A[jl] / rt / rt / ad;
+                                else tgt += A[jl] * (1.0 - ert[jr] * (1.0 + rt * adadiff)) / rt / rt / ad;
+                            } else if (!fin) tgt += A[jl] / l1 / rt / ad;
+                            else if (ratel < l1l)
+                                tgt += -A[jl] * (B[jl] / l1 + (ert[jr] * -m_expm1(-(l1 - rt) * adadiff) / (l1 - rt))) / rt / ad;
+                            else
+                                tgt += -A[jl] * (B[jl] / l1 + (El[jl] * m_expm1(-(rt - l1) * adadiff) / (l1 - rt))) / rt / ad;
+                            // the later pieces k > m
+                            if (m + 1 >= K) continue;
+                            // exp(-rate R_{m+1} + log_coef) with log_coef = -log_denom - rp R_{m+1} or - rp R_m (rp = l1 - rate) is
+                            // exp(-log_denom - l1 R_{m+1}) = A1[jl]  or  exp(-log_denom - l1 R_m) exp(-rate (R_{m+1} - R_m)) =
+                            // A[jl] e1[jr]: two hoisted tables instead of one exp per (lam, rate) pair (and without the
+                            // cancellation between -rate R and -rp R inside the exponent)
+                            S coef(0.0), fac(0.0);
+                            const long rp = l1l - ratel;
+                            const double rpd = (double)rp;
+                            if (rp == 0) { fac = dR; coef = A1[jl]; }
+                            else if (rp < 0) {
+                                if (-rpd * sval(dR) > 20) { coef = A1[jl]; fac = S(-1.0 / rpd); }
+                                else { coef = A[jl] * e1[jr]; fac = -m_expm1(-rpd * dR) / rpd; }
+                            } else {
+                                if (-rpd * sval(Rm - Rm1) > 20) { coef = A[jl] * e1[jr]; fac = S(1.0 / rpd); }
+                                else { coef = A1[jl]; fac = m_expm1(-rpd * (Rm - Rm1)) / rpd; }
+                            }
+                            tgt += coef * pt.Ssuf[(size_t)jr * K + m] * fac;
+                        }
+                    }
+                }
+                // ---- contractions (conditioned_sfs.cpp:42-83) ----
+                for (int j = 0; j < n + 1; ++j) {
+                    for (int i = 0; i < n; ++i) v[i] = Ca[(size_t)j * n + i] * tb.X0(i, j);              // C0(i,j) = C(j,i)
+                    tmp0[j] = accurate_sum(v.data(), n);
+                    for (int i = 0; i < n; ++i) v[i] = Ca[(size_t)(n - j) * n + i] * tb.X2(i, j);        // C2(i,j) = C(n-j,i)
+                    tmp2[j] = accurate_sum(v.data(), n);
+                }
+                for (int b = 0; b < n; ++b) {
+                    S s0(0.0), s2(0.0);
+                    for (int j = 0; j < n + 1; ++j) { s0 += tmp0[j] * tb.Uinv_mp0(j, b); s2 += tmp2[j] * tb.Uinv_mp2(j, b); }
+                    out[0 * (n + 1) + 1 + b] += s0;
+                    out[2 * (n + 1) + b] += s2;
+                }
+            }
+            // ---- below (tjj_double_integral_below, piecewise_constant_rate_function.cpp:302-334) ----
+            for (S &x : below) x = S(0.0);
+            for (int m = hsi[h]; m < hsi[h + 1]; ++m) {
+                const S Rm = Rrng[m], Rm1 = Rrng[m + 1];
+                const S c = -Rm - log_denom;
+                S fac(1.0);
+                if (m < K - 1) fac = -m_expm1(-(Rm1 - Rm));
+                const S ec = m > 0 ? m_exp(c) : S(0.0);
+                for (int j = 2; j < n + 3; ++j) {
+                    const long rate = RF::nC2(j) - 1;
+                    S val = RF::below_helper(rate, ts[m], ts[m + 1], ada[m], Rm, log_denom);
+                    if (m > 0) val += fac * (ec * pt.Ppre[(size_t)(j - 2) * (K + 1) + m]);
+                    below[j - 2] += val;
+                }
+            }
+            for (int b = 0; b < n; ++b) {
+                S s(0.0);
+                for (int j = 0; j < n + 1; ++j) s += below[j] * tb.M0(j, b);
+                out[0 * (n + 1) + 1 + b] += s;
+            }
+            for (int b = 0; b < n + 1; ++b) {
+                S s(0.0);
+                for (int j = 0; j < n + 1; ++j) s += below[j] * tb.M1(j, b);
+                out[1 * (n + 1) + b] += s;
+            }
         }
     }
     return csfs;

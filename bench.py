@@ -1,26 +1,34 @@
 #!/usr/bin/env python
 """bench.py — E-step loglik-evals/sec of the MI355X-native SMC++ engine (BASELINE.json metric).
 
-One "step" = one eval of SURVEY.md §8(d): parameters marked dirty -> E-step (host eigensystem prep + upload +
-forward/backward chains + sufficient statistics on the GPU) -> loglik, over this rank's contig(s), with the
-observation arrays already resident in HBM (they are uploaded when the inference manager is constructed).
+One "step" = one eval exactly as SURVEY.md §8(d) defines it: `set_params(model)` (parameters dirty) -> `E_step()`
+(cold preparation A6-A10: rate function, pi, transition, conditioned SFS, emission table; eigensystems; upload;
+forward / backward chains and sufficient statistics on the GPU) -> `loglik()`, over this rank's contig(s), with the
+observation arrays already resident in HBM (they are uploaded when the inference manager is constructed).  This is
+what `InferenceManager::Estep` does after `setParams` (src/inference_manager.cpp:108-114,213-229,256-260).
+`split_ms.hmm_only_ms` additionally reports the same eval with the prepared parameters handed over by `set_raw`
+(no A6-A10), which is what round 1 timed.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c3|c4|c5] [--no-cpu] [--chunk ROWS]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c3|c4|c5|posterior] [--no-cpu]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank owns one synthetic 100 Mbp contig (weak
-scaling, contigs are independent HMMs) and the ranks exchange ONE all-reduce(sum, fp64) of the packed
-[loglik | gamma0 | xisum | gamma_sums] statistics per step over RCCL.
+`--gpus N` with N > 1 and no torchrun environment re-launches itself under `torch.distributed.run` (one rank per
+GPU, RCCL); under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  Every rank owns one synthetic 100 Mbp contig
+(weak scaling; `c3` shards the 22 contigs of a whole genome longest-first, strong scaling) and the ranks exchange ONE
+all-reduce(sum, fp64) of the packed [loglik | gamma0 | xisum | gamma_sums] statistics per step
+(`smcpp_amd.dist.ShardedInferenceManager`).  If the box has fewer GPUs than ranks the ranks share
+devices and reduce over gloo (a functional test of the N > 1 path, flagged in the output; never a measurement).
 
 Prints one JSON line with the contract fields plus "roofline" (dominant kernel, timed live with HIP events on the
-engine's own stream) and "cpu_baseline" (the compiled reference `oracle/_ref` — or the C restatement `oracle/` if
-that is absent — timed on this box's host cores on a bounded prefix of the same contig).
+stream it is launched on) and "cpu_baseline" (the compiled reference `oracle/_ref`: its own cold preparation +
+`HMM::Estep` on a bounded prefix of the same contig, one host core).
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,23 +44,68 @@ WORKLOADS = {
     "c5": (256, 50, "params_M256_n50.npz", "1 synthetic 100 Mbp contig per GPU, M=256, n=50 (configs[4])"),
     # whole genome: the 22 autosome-like contigs (2 872 Mbp) sharded longest-first over the ranks; STRONG scaling
     "c3": (64, 20, "params_M64_n20.npz", "22 synthetic contigs, 2872 Mbp in total, M=64, n=20, LPT-sharded over the GPUs (configs[2])"),
-    # two populations, both distinguished lineages in population 1, split 0.5; the parameters come
-    # from the engine's own JointCSFS preparation, computed once outside the timed region like the fixtures above
+    # two populations, both distinguished lineages in population 1, split 0.5
     "c4": (48, 10, None, "1 synthetic two-population 100 Mbp contig per GPU, M=48, n1=n2=10, a=(2,0), split=0.5 (configs[3])"),
+    # posterior decoding: un-binned rows, long spans, small rho, save_gamma
+    "posterior": (32, 8, None, "posterior decode: 1 un-binned contig, 1e6 rows, spans to 1e5, rho=6e-5, M=32, n=8, save_gamma"),
 }
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector = matrix peak (AMD spec)
 
 
-def algorithmic_work(obs, M):
-    """Algorithmic flops / bytes of ONE pass of the dominant (forward chain) kernel, DESIGN.md §Kernels:
-    span-1 row: 2 M^2 (one mat-vec); span>1 row: 4 M^2 (two mat-vecs).  Bytes: alpha write 4M + row descriptor 8 +
-    normaliser 8 (emission / eigenvalue-power vectors come from LDS-resident tables)."""
-    R1 = int((obs[:, 0] == 1).sum())
-    Re = len(obs) - R1
+def chain_pass_work(obs_list, M):
+    """Algorithmic work of ONE sequential pass of a chain over the rows (what `HMM::Estep`'s forward or backward loop
+    needs, src/hmm.cpp:61-96,102-149): span-1 row = one M x M mat-vec (2 M^2 flop), span>1 row = two (4 M^2, through
+    the eigenbasis).  Bytes of the forward pass: alpha row written (4M, float) + normaliser (8) + descriptor read (8);
+    of the backward pass: beta row written (8M) + descriptor (8)."""
+    R1 = sum(int((o[:, 0] == 1).sum()) for o in obs_list)
+    R = sum(len(o) for o in obs_list)
+    Re = R - R1
     flops = 2.0 * M * M * R1 + 4.0 * M * M * Re
-    nbytes = len(obs) * (4.0 * M + 16.0)          # alpha row (float) + normaliser + descriptor
-    return flops, nbytes, R1, Re
+    return flops, R * (4.0 * M + 16.0), R * (8.0 * M + 8.0), R1, Re
+
+
+def eval_work(obs_list, M):
+    """F_alg = 2 M^3 Re + 12 M^2 R + 4 M^3 G + 25 M^3 Ke,  B_alg = R (24 M + 32) per eval."""
+    F = B = 0.0
+    for o in obs_list:
+        R = len(o)
+        e = o[o[:, 0] > 1]
+        Re = len(e)
+        G = len(np.unique(e, axis=0)) if Re else 0
+        Ke = len(np.unique(e[:, 1:], axis=0)) if Re else 0
+        F += 2.0 * M ** 3 * Re + 12.0 * M * M * R + 4.0 * M ** 3 * G + 25.0 * M ** 3 * Ke
+        B += R * (24.0 * M + 32.0)
+    return F, B
+
+
+def synth_posterior_contig(rows, n, seed=7):
+    """Un-binned rows as `smc++ posterior` sees them (smcpp/commands/posterior.py:48-111): long monomorphic runs with
+    spans up to 1e5 separated by span-1 segregating sites, a sprinkling of missing stretches."""
+    rng = np.random.default_rng(seed)
+    ob = np.zeros((rows, 4), dtype=np.int32)
+    kind = rng.random(rows)
+    seg = kind < 0.45                                    # segregating site: span 1, full SFS observation
+    mis = (kind >= 0.45) & (kind < 0.50)                 # missing stretch
+    mono = ~(seg | mis)
+    ob[seg, 0] = 1
+    ob[seg, 1] = rng.integers(0, 2, seg.sum())
+    ob[seg, 3] = n
+    ob[seg, 2] = np.where(ob[seg, 1] == 1, rng.integers(0, n + 1, seg.sum()), rng.integers(1, n + 1, seg.sum()))
+    ob[mis, 0] = rng.integers(1, 5000, mis.sum()); ob[mis, 1] = -1
+    ob[mono, 0] = np.minimum(100000, 1 + (rng.pareto(1.2, mono.sum()) * 200).astype(np.int64))
+    ob[mono, 3] = n
+    return ob
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start N ranks of this script."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -67,10 +120,11 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--eps-alpha", type=float, default=0.0)
     ap.add_argument("--eps-beta", type=float, default=0.0)
-    ap.add_argument("--warm", action="store_true",
-                    help="additionally measure the opt-in warm start on a sequence of perturbed parameter sets "
-                         "(reported as an extra object; the headline value is always the cold E-step)")
+    ap.add_argument("--raw", action="store_true", help="time set_raw -> E_step -> loglik only (no cold preparation)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -78,14 +132,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using the launcher's world size", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    # SMCPP_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 code path (key union, packed all-reduce, barrier,
-    # max over ranks) be exercised on a box with fewer GPUs than ranks (ranks share devices, the reduction runs on the
-    # host).  The measured configuration is always nccl (= RCCL), one rank per GPU.
-    backend = os.environ.get("SMCPP_BENCH_BACKEND", "nccl")
+    # Fewer GPUs than ranks (or SMCPP_BENCH_BACKEND=gloo): the ranks share devices and reduce on the host.  That
+    # exercises the whole N > 1 path (sharding, key union, packed all-reduce, barrier, max over ranks) and is flagged
+    # in the output; the measured configuration is always nccl (= RCCL), one rank per GPU.
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("SMCPP_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
     if backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()
+        local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -97,84 +154,107 @@ def main():
     red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from smcpp_amd import _smcpp, synth
-    # torch.distributed.run exports OMP_NUM_THREADS=1 to every rank; the engine's host phase (one eigensystem per eigen
-    # key, in parallel) wants a handful of threads, which is what the reference's --cores / set_num_threads is for
-    _smcpp.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(1, world))))
+    from smcpp_amd import dist as sd
+    from smcpp_amd.model import PiecewiseModel, TwoPopulationModel
+    # torch.distributed.run exports OMP_NUM_THREADS=1 to every rank; the engine's host phase (conditioned SFS per
+    # hidden state, one eigensystem per eigen key) wants a handful of threads — the reference's --cores / set_num_threads
+    host_threads = max(1, min(8, (os.cpu_count() or 8) // max(1, world)))
+    _smcpp.set_num_threads(host_threads)
     M, n, fixture, desc = WORKLOADS[args.workload]
     length_bp = int(args.length_mbp * 1e6)
+    par = None
     if args.workload == "c4":
-        from smcpp_amd import _engine
-        from smcpp_amd.model import PiecewiseModel, TwoPopulationModel
-        obs = synth.synth_contig_twopop(rank, length_bp, n, n)
+        contigs = [synth.synth_contig_twopop(rank, length_bp, n, n)]
         hs = synth.hidden_states(M)
         a, s_ = synth.model_pieces()
-        tm = TwoPopulationModel(PiecewiseModel(a, s_, 1e4, pid="pop1"),
-                                PiecewiseModel(1.5 + 0.5 * np.cos(np.arange(8)), s_[:8], 1e4, pid="pop2"), 0.5)
-        keys4 = np.unique(obs[:, 1:], axis=0).astype(np.int32)
-        d, p1, p2 = tm.for_pop("pop1"), tm.for_pop("pop1"), tm.for_pop("pop2")
-        pi4, T4, E4 = _engine.host_prep_twopop(n, n, 2, 0, hs, 0.5, (d.a, d.s), (p1.a, p1.s), (p2.a, p2.s), tm.split,
-                                               synth.THETA, synth.RHO, synth.ALPHA, keys4)
-        par = dict(pi=pi4, T=T4, keys=keys4, E=E4, hs=hs, pol=0.5, theta=synth.THETA, rho=synth.RHO, alpha=synth.ALPHA)
-        im = _smcpp.PyTwoPopInferenceManager(n, n, 2, 0, [obs], hs, ("pop1", "pop2"), 0.5, device=local_rank)
-    elif args.workload == "c3":
-        from smcpp_amd import dist as sd
-        par = np.load(os.path.join(ROOT, "tests", "golden", fixture))
-        owner = sd.lpt_shard(synth.C3_LENGTHS_MBP, world)
-        mine = [i for i in range(len(owner)) if owner[i] == rank]
-        contigs = [synth.synth_contig(i, int(synth.C3_LENGTHS_MBP[i] * 1e6), n) for i in mine]
-        obs = np.concatenate(contigs)                    # only for the algorithmic work / CPU baseline bookkeeping
-        im = _smcpp.PyOnePopInferenceManager(n, contigs, par["hs"], ("pop1",), float(par["pol"]), device=local_rank)
+        model = TwoPopulationModel(PiecewiseModel(a, s_, 1e4, pid="pop1"),
+                                   PiecewiseModel(1.5 + 0.5 * np.cos(np.arange(8)), s_[:8], 1e4, pid="pop2"), 0.5)
+        theta, rho, alpha, pol = synth.THETA, synth.RHO, synth.ALPHA, 0.5
+        all_contigs = None
+
+        def factory(obs, d):
+            return _smcpp.PyTwoPopInferenceManager(n, n, 2, 0, obs, hs, ("pop1", "pop2"), pol, device=d)
     else:
-        par = np.load(os.path.join(ROOT, "tests", "golden", fixture))
-        obs = synth.synth_contig(rank, length_bp, n)         # contig index = rank: independent contigs, weak scaling
-        im = _smcpp.PyOnePopInferenceManager(n, [obs], par["hs"], ("pop1",), float(par["pol"]), device=local_rank)
-    im.theta = float(par["theta"]); im.rho = float(par["rho"]); im.alpha = float(par["alpha"])
+        if args.workload == "posterior":
+            hs = synth.hidden_states(M)
+            a, s_ = synth.model_pieces()
+            theta, rho, alpha, pol = 1e-4 * 2, 6e-5, 1.0, 0.5
+            contigs = [synth_posterior_contig(1_000_000, n, seed=7 + rank)]
+        else:
+            par = np.load(os.path.join(ROOT, "tests", "golden", fixture))
+            hs, a, s_ = par["hs"], par["a"], par["s"]
+            theta, rho, alpha, pol = float(par["theta"]), float(par["rho"]), float(par["alpha"]), float(par["pol"])
+            if args.workload == "c3":
+                owner = sd.lpt_shard(synth.C3_LENGTHS_MBP, world)
+                contigs = [synth.synth_contig(i, int(synth.C3_LENGTHS_MBP[i] * 1e6), n)
+                           for i in range(len(owner)) if owner[i] == rank]
+            else:
+                contigs = [synth.synth_contig(rank, length_bp, n)]   # contig index = rank: independent contigs, weak scaling
+        model = PiecewiseModel(a, s_, 1e4, pid="pop1")
+
+        def factory(obs, d):
+            return _smcpp.PyOnePopInferenceManager(n, obs, hs, ("pop1",), pol, device=d)
+
+    if world > 1:
+        # every rank generated only its own contigs; tell the sharded manager the global layout
+        if args.workload == "c3":
+            lengths = [int(x * 1e4) for x in synth.C3_LENGTHS_MBP]
+            obs_all = [None] * len(lengths)
+            owner = sd.lpt_shard(lengths, world)
+            mine = [i for i in range(len(lengths)) if owner[i] == rank]
+            for i, c in zip(mine, contigs):
+                obs_all[i] = c
+        else:
+            lengths = [1] * world                      # one contig per rank; equal weights -> contig r on rank r
+            obs_all = [None] * world
+            obs_all[rank] = contigs[0]
+        sim = sd.ShardedInferenceManager(n, obs_all, hs, ("pop1",), pol, device=local_rank, lengths=lengths,
+                                         factory=factory)
+        assert [i for i in sim.mine] == ([i for i in range(len(lengths)) if sd.lpt_shard(lengths, world)[i] == rank])
+        im = sim.im
+    else:
+        sim = None
+        im = factory(contigs, local_rank)
+    top = sim if sim is not None else im
+    top.theta = theta; top.rho = rho; top.alpha = alpha
+    if args.workload == "posterior":
+        im.save_gamma = True
     if args.chunk or args.eps_alpha or args.eps_beta:
         im.set_chunking(args.chunk, args.eps_alpha, args.eps_beta)
-    if world > 1:
-        # global key dictionary so the packed gamma_sums blocks line up across ranks
-        from smcpp_amd import dist as sd
-        im.set_global_keys(sd.union_keys(im.keys))
-    pi, T, keys, E = par["pi"], par["T"], par["keys"], par["E"]
-
-    stats_buf = None
 
     def one_eval():
-        nonlocal stats_buf
-        im.set_raw(pi, T, keys, E)          # parameters dirty: eigensystems, uploads, everything is redone
-        im.E_step()
-        if world > 1:
-            if backend == "nccl":
-                # the packed statistics are written by one kernel straight into the tensor RCCL reduces
-                if stats_buf is None:
-                    stats_buf = torch.empty(im.stats_len(), dtype=torch.float64, device=dev)
-                im.pack_stats_device(stats_buf.data_ptr())
-                dist.all_reduce(stats_buf, op=dist.ReduceOp.SUM)       # the single collective of the E-step
-                ll_sum = float(stats_buf[0].item())                   # (synchronises the reduction)
-                im.unpack_stats_device(stats_buf.data_ptr(), stats_buf.numel())
-                return ll_sum
-            h = im.pack_stats()
-            if stats_buf is None:
-                stats_buf = torch.empty(len(h), dtype=torch.float64, device=red_dev)
-            stats_buf.copy_(torch.from_numpy(h))
-            dist.all_reduce(stats_buf, op=dist.ReduceOp.SUM)
-            im.unpack_stats(stats_buf.cpu().numpy())
-            return float(stats_buf[0].item())
-        return im.loglik()
+        top.model = model            # setParams: parameters dirty, A6-A10 + eigensystems + uploads are all redone
+        top.E_step()                 # (N > 1: includes the single all-reduce of the packed statistics)
+        return top.loglik()
+
+    raw = None
+
+    def one_eval_raw():
+        top.set_raw(*raw)            # prepared parameters handed over: no cold preparation in the E-step
+        top.E_step()
+        return top.loglik()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    ll = one_eval()
+    # the prepared parameters of the same model, for the hmm-only split (global key list when sharded)
+    kk = sim.keys if sim is not None else im.keys
+    if sim is None:
+        ep = im.emission_probs
+        raw = (im.pi, im.transition, kk, np.array([ep[tuple(int(x) for x in k)] for k in kk]))
+    step = one_eval_raw if (args.raw and raw is not None) else one_eval
     for _ in range(args.warmup):
-        one_eval()
+        step()
     barrier()
-    timings = []
+    timings, host_timings = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ll = one_eval()
+        ll = step()
         timings.append(im.last_timing())
+        host_timings.append(im.last_host_timing())
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -186,111 +266,117 @@ def main():
         value = args.steps / elapsed                     # whole-genome evals per second (the ranks share ONE eval)
     else:
         value = world * args.steps / elapsed             # contig-E-step evals per second, whole job
+    med = {k: float(np.median([t[k] for t in timings])) for k in timings[0]}
+    med.update({k: float(np.median([t[k] for t in host_timings])) for k in host_timings[0]})
 
-    # ---- roofline of the dominant kernel (forward chain pass), timed live with HIP events ----
-    # smcpp_last_timing brackets the forward / backward pass launches with hipEvents recorded on the engine's stream.
-    fwd_ms = float(np.median([t["forward_ms"] for t in timings]))   # (overlaps the backward passes on a 2nd stream)
-    bwd_ms = float(np.median([t["backward_ms"] for t in timings]))
-    fpasses = float(np.median([t["fwd_passes"] for t in timings]))
-    bpasses = float(np.median([t["bwd_passes"] for t in timings]))
-    flops, nbytes, R1, Re = algorithmic_work(obs, M)
-    launches = max(fpasses, 1.0)
-    per_launch_s = 1e-3 * fwd_ms / launches
-    ach_tflops = flops / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
-    ach_gbs = nbytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
-    if ach_gbs / HBM_PEAK_GBS >= ach_tflops / FP64_PEAK_TFLOPS:
-        roof = dict(bound="hbm", achieved=ach_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach_gbs / HBM_PEAK_GBS)
-    else:
-        roof = dict(bound="mfma", achieved=ach_tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=ach_tflops / FP64_PEAK_TFLOPS)
-    # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md).  Only valid for the workload
-    # the profile was taken on.
+    # ---- hmm-only split: the same eval with set_raw (outside the timed region) ----
+    if raw is not None and not args.raw:
+        for _ in range(2):
+            one_eval_raw()
+        ts = []
+        for _ in range(max(5, args.steps // 2)):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter(); one_eval_raw(); ts.append(time.perf_counter() - t1)
+        med["hmm_only_ms"] = 1e3 * float(np.median(ts))
+
+    # ---- roofline of the dominant kernel ----
+    # The chain kernels (k_fwd_coop / k_bwd_coop, k_*_big for M > 64) dominate.  smcpp_last_timing brackets ALL pass
+    # launches of each chain of one E-step with hipEvents on the stream they are launched on, so `kernel_ms_per_step`
+    # is the kernel's time per step summed over its passes (= rocprofv3's total for the kernel / steps).  `achieved`
+    # credits ONE pass of algorithmic work: the re-run passes of the chunk-parallel fixed point are overhead, not work.
+    flops, bytes_f, bytes_b, R1, Re = chain_pass_work(contigs, M)
+    fwd_ms, bwd_ms = med["forward_ms"], med["backward_ms"]
+    dom_fwd = fwd_ms >= bwd_ms
+    k_ms = fwd_ms if dom_fwd else bwd_ms
+    k_bytes = bytes_f if dom_fwd else bytes_b
+    big = M > 64
+    kname = ("k_fwd_big" if big else "k_fwd_coop") if dom_fwd else ("k_bwd_big" if big else "k_bwd_coop")
+    ach_tflops = flops / (1e-3 * k_ms) / 1e12 if k_ms > 0 else 0.0
+    ach_gbs = k_bytes / (1e-3 * k_ms) / 1e9 if k_ms > 0 else 0.0
+    roof = dict(bound="mfma", achieved=ach_tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach_tflops / FP64_PEAK_TFLOPS)
+    # HBM bytes per step from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes); only for the profiled workload
     traffic = None
     try:
-        if args.workload == "headline" and args.length_mbp == 100.0:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_g_hbm_traffic_pmc.json")))["kernels"]
-            k = [v for name, v in prof.items() if "k_fwd_coop" in name][0]
-            # a pass that re-runs every chunk (the max over launches; converged check passes write nothing)
-            traffic = 1024.0 * (2.0 * k["FETCH_SIZE_KB_max"] + k["WRITE_SIZE_KB_max"])
+        if args.workload == "headline" and args.length_mbp == 100.0 and world == 1:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic_pmc.json")))
+            k = [v for name, v in prof["kernels"].items() if kname in name][0]
+            traffic = float(k["bytes_per_step"])
     except Exception:  # noqa: BLE001
         traffic = None
-    roof.update(traffic=traffic, kernel="k_fwd_coop (forward chain pass; runs concurrently with k_bwd_coop)", launches_per_step=launches,
-                avg_launch_ms=1e3 * per_launch_s, algorithmic_flops_per_launch=flops,
-                algorithmic_bytes_per_launch=nbytes)
-
-    # ---- optional: warm start (smcpp_set_warm_start) on a parameter trajectory, the way an optimiser calls the path ----
-    warm_obj = None
-    if args.warm and world == 1:
-        rng = np.random.default_rng(11)
-
-        def perturbed(scale):
-            # every emission vector and the transition matrix move by a relative `scale` (rows of T renormalised)
-            Ep = np.clip(E * (1.0 + scale * rng.standard_normal(E.shape)), 1e-12, 1.0)
-            Tp = T * (1.0 + scale * rng.standard_normal(T.shape))
-            Tp *= (T.sum(axis=1) / Tp.sum(axis=1))[:, None]
-            return Tp, Ep
-
-        def sequence(warm):
-            im.set_warm_start(warm)
-            im.set_raw(pi, T, keys, E); im.E_step()            # iteration 0 (cold either way)
-            ts, lls = [], []
-            for it in range(args.steps):
-                Tp, Ep = perturbed(1e-2 / (1 + it))               # steps shrink as an EM run converges
-                t0 = time.perf_counter()
-                im.set_raw(pi, Tp, keys, Ep); im.E_step(); lls.append(im.loglik())
-                ts.append(time.perf_counter() - t0)
-            return float(np.median(ts)), lls, im.last_timing()
-
-        rng = np.random.default_rng(11); t_cold, ll_cold, _ = sequence(False)
-        rng = np.random.default_rng(11); t_warm, ll_warm, tw = sequence(True)
-        im.set_warm_start(False)
-        warm_obj = {"note": "same sequence of perturbed parameter sets (relative step 1e-2/(1+it)) evaluated cold and with "
-                            "smcpp_set_warm_start; not part of `value`",
-                    "cold_ms_per_eval": 1e3 * t_cold, "warm_ms_per_eval": 1e3 * t_warm,
-                    "max_rel_loglik_diff": float(max(abs(a - b) / abs(a) for a, b in zip(ll_cold, ll_warm))),
-                    "warm_fwd_passes": tw["fwd_passes"], "warm_bwd_passes": tw["bwd_passes"]}
+    F_alg, B_alg = eval_work(contigs, M)
+    roof.update(
+        traffic=traffic, kernel=f"{kname} (all passes of one E-step; the other chain runs concurrently on a second stream)",
+        kernel_ms_per_step=k_ms, passes=med["fwd_passes"] if dom_fwd else med["bwd_passes"],
+        algorithmic_flops_one_pass=flops, algorithmic_bytes_one_pass=k_bytes,
+        hbm_gbs=ach_gbs, hbm_frac=ach_gbs / HBM_PEAK_GBS,
+        other_chain={"kernel": ("k_bwd" if dom_fwd else "k_fwd") + ("_big" if big else "_coop"),
+                     "kernel_ms_per_step": bwd_ms if dom_fwd else fwd_ms,
+                     "tflops": flops / (1e-3 * (bwd_ms if dom_fwd else fwd_ms)) / 1e12 if min(fwd_ms, bwd_ms) > 0 else 0.0},
+        # whole eval on SURVEY.md §8(d)'s F_alg / B_alg (the restructured statistics do not execute the 2 M^3 Re term,
+        # DESIGN.md §3, so this is a figure of merit against the reference's algorithm, not achieved MFMA work)
+        eval={"F_alg": F_alg, "B_alg": B_alg, "tflops_on_F_alg": F_alg / (1e-3 * ms_per_step) / 1e12,
+              "frac_on_F_alg": F_alg / (1e-3 * ms_per_step) / 1e12 / FP64_PEAK_TFLOPS,
+              "gbs_on_B_alg": B_alg / (1e-3 * ms_per_step) / 1e9},
+        note="latency-bound sequential chains: frac = one pass of algorithmic flops / kernel time per step / fp64 peak")
 
     out = None
     if rank == 0:
-        med = {k: float(np.median([t[k] for t in timings])) for k in timings[0]}
         out = {
             "metric": "E-step loglik-evals/sec (100 Mbp, M=64, n=20)" if args.workload == "headline"
             else ("whole-genome E-step loglik-evals/sec (22 contigs, 2872 Mbp, M=64, n=20)" if args.workload == "c3"
-                  else f"E-step loglik-evals/sec ({args.length_mbp:g} Mbp, M={M}, n={n})"),
+                  else f"E-step loglik-evals/sec ({desc})"),
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.workload == "c3" else "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if args.workload == "c3" else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc, "M": M, "n": n, "rows_per_contig": int(len(obs)),
-                       "span1_rows": R1, "eigen_rows": Re,
-                       "contigs_per_gpu": len(contigs) if args.workload == "c3" else 1,
+            "config": {"workload": desc, "eval": "set_raw -> E_step -> loglik (no cold preparation)" if args.raw
+                       else "set_params -> E_step -> loglik (SURVEY.md 8(d))",
+                       "M": M, "n": n, "rows": int(sum(len(c) for c in contigs)),
+                       "span1_rows": R1, "eigen_rows": Re, "contigs_per_gpu": len(contigs),
                        "length_mbp": float(sum(synth.C3_LENGTHS_MBP)) if args.workload == "c3" else args.length_mbp,
-                       "loglik": ll, "parallelism": f"contig-sharded x{world}, 1 all-reduce/E-step" if world > 1 else "single GPU"},
+                       "loglik": ll, "host_threads": host_threads,
+                       "parallelism": f"contig-sharded x{world}, 1 all-reduce/E-step" if world > 1 else "single GPU"},
             "split_ms": med,
             "roofline": roof,
         }
-        if warm_obj:
-            out["warm_start"] = warm_obj
-        if not args.no_cpu and world == 1:          # the CPU baseline is timed at N = 1 only (rank 0's host cores)
-            out["cpu_baseline"] = cpu_baseline(par, obs, args.cpu_seconds, M)
+        if world > 1:
+            out["config"]["backend"] = "nccl (RCCL)" if backend == "nccl" else \
+                f"{backend}: {world} ranks share {ndev} device(s) - functional test of the N>1 path, not a measurement"
+        if not args.no_cpu and world == 1:                          # the CPU baseline is timed at N = 1 only
+            # the reference's E-step gets the engine's prepared parameters of this model (pi, T, emission table), its
+            # cold preparation is timed on the model itself (one population only: the two-population joint CSFS is in
+            # a translation unit of the reference that needs GSL)
+            model_args = None if args.workload == "c4" else (a, s_, hs, rho, theta, n)
+            out["cpu_baseline"] = cpu_baseline(raw, model_args, np.concatenate(contigs), args.cpu_seconds, args.raw)
             if out["cpu_baseline"] and out["cpu_baseline"].get("value"):
-                out["speedup_vs_cpu_1core"] = (value / world) / out["cpu_baseline"]["value"]
+                out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(par, obs, budget_s, M):
-    """The reference's own C++ E-step (oracle/_ref, compiled from /root/reference/src in the build container) on
-    one host core, on a prefix of the same contig sized to ~budget_s seconds; evals/s are scaled by row count
-    (the reference's cost is linear in rows: one thread per contig, inference_manager.cpp:89-94)."""
+def cpu_baseline(raw, model_args, obs, budget_s, raw_only):
+    """The reference's own C++ on one host core (oracle/_ref, compiled from /root/reference/src in the build
+    container): its cold preparation (`ref_prep`: rate function, transition, conditioned SFS — what setParams +
+    do_dirty_work recompute, src/inference_manager.cpp:213-229) timed in full, plus `HMM::Estep` on a prefix of the same
+    contig sized to ~budget_s seconds and scaled by row count (the reference's E-step cost is linear in rows: one
+    thread per contig, inference_manager.cpp:89-94)."""
     try:
         from oracle import ref
         kind = "reference" if ref.available() else "port"
         if kind == "port":
             from oracle import oracle as orc
-        pi, T, keys, E = par["pi"], par["T"], par["keys"], par["E"]
+        pi, T, keys, E = raw
+        prep_s = 0.0
+        if kind == "reference" and not raw_only and model_args is not None:
+            args = model_args
+            ref.prep(*args)                                   # first call builds the n-only tables (cached, as in the reference)
+            ts = []
+            for _ in range(3):
+                t = time.perf_counter(); ref.prep(*args); ts.append(time.perf_counter() - t)
+            prep_s = float(np.median(ts))
         probe = min(len(obs), 2000)
         fn = ref.estep if kind == "reference" else orc.estep
         fn(pi, T, keys, E, obs[:probe])                      # first call: library load, page-in
@@ -299,13 +385,15 @@ def cpu_baseline(par, obs, budget_s, M):
         per_row = (time.perf_counter() - t) / probe
         rows = int(min(len(obs), max(probe, budget_s / per_row)))
         t = time.perf_counter()
-        r = (ref.estep if kind == "reference" else orc.estep)(pi, T, keys, E, obs[:rows])
+        r = fn(pi, T, keys, E, obs[:rows])
         dt = time.perf_counter() - t
         full = dt * len(obs) / rows
-        return {"value": 1.0 / full, "unit": "evals/s", "cores": 1, "kind": kind,
-                "sample": f"first {rows} of {len(obs)} rows of the same contig in {dt:.1f} s, scaled by row count "
+        return {"value": 1.0 / (full + prep_s), "unit": "evals/s", "cores": 1, "kind": kind,
+                "sample": f"reference cold preparation timed in full ({1e3 * prep_s:.1f} ms) + HMM::Estep on the first "
+                          f"{rows} of {len(obs)} rows of the same contig(s) in {dt:.1f} s, scaled by row count "
                           f"(1 thread = 1 contig, as the reference parallelises); host has {os.cpu_count()} cores",
-                "us_per_row": 1e6 * dt / rows, "loglik_prefix": r["loglik"]}
+                "prep_ms": 1e3 * prep_s, "estep_s_scaled": full, "us_per_row": 1e6 * dt / rows,
+                "loglik_prefix": r["loglik"]}
     except Exception as e:  # noqa: BLE001
         return {"value": None, "error": repr(e)}
 

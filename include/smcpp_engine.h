@@ -88,6 +88,9 @@ int smcpp_get_keys(smcpp_im *im, int *keys);             /* [K x 3P], lexicograp
 int smcpp_get_xisum(smcpp_im *im, int contig, double *out);        /* getXisums(): [M x M]   */
 /* getGammas(): [M x (L+1)] row-major if save_gamma was set for the last E-step, else [M x 1] */
 int smcpp_get_gamma(smcpp_im *im, int contig, double *out);
+/* Number of columns smcpp_get_gamma writes for this contig: L+1 if the LAST E-step ran with save_gamma, else 1
+ * (the flag may have been toggled since); -1 for a bad contig index.  Size the buffer from this. */
+int smcpp_gamma_cols(smcpp_im *im, int contig);
 /* getGammaSums(): vals [K x M]; present[K] = 1 where the reference's std::map would hold the key */
 int smcpp_get_gamma_sums(smcpp_im *im, int contig, double *vals, unsigned char *present);
 int smcpp_get_pi(smcpp_im *im, double *out);                       /* getPi(): [M]           */
@@ -123,6 +126,9 @@ int smcpp_set_warm_start(smcpp_im *im, int on);
  * [host_prep, chains_wall, forward, backward, stats, finalize, total_device, fwd_passes, bwd_passes]
  * (forward and backward overlap when the two chains run on separate streams; chains_wall is their union) */
 int smcpp_last_timing(smcpp_im *im, double out[9]);
+/* Host phase of the last E-step in milliseconds: [cold preparation A6-A10 (0 when the parameters were still fresh or
+ * came from smcpp_set_raw), eigensystems, layouts + staging + copy enqueue, whole host phase] */
+int smcpp_last_host_timing(smcpp_im *im, double out[4]);
 /* The HIP stream the engine launches on (a hipStream_t), for event timing by the caller. */
 void *smcpp_stream(smcpp_im *im);
 

@@ -28,20 +28,59 @@ def lib():
             f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
             "The SMC++ MI355X engine has no CPU fallback.")
     L = C.CDLL(path)
-    L.smcpp_last_error.restype = C.c_char_p
-    L.smcpp_stream.restype = C.c_void_p
-    L.smcpp_stream.argtypes = [C.c_void_p]
-    L.smcpp_destroy.argtypes = [C.c_void_p]
-    L.smcpp_destroy.restype = None
-    for name in ("smcpp_set_theta", "smcpp_set_rho", "smcpp_set_alpha"):
-        getattr(L, name).argtypes = [C.c_void_p, C.c_double]
-    L.smcpp_set_chunking.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
-    L.smcpp_host_prep_onepop.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_int, _dp, _dp, C.c_double,
-                                         C.c_double, C.c_double, C.c_int, _ip, _dp, _dp, _dp]
-    L.smcpp_host_prep_onepop_jac.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_int, _dp, _dp, C.c_int, _dp,
-                                             C.c_double, C.c_double, C.c_double, C.c_int, _ip, _dp, _dp, _dp, _dp, _dp,
-                                             _dp]
-    L.smcpp_set_params.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp]
+    # every export gets its prototype: ints are coerced (numpy integer scalars included), `long` stays 64-bit, and a
+    # wrong argument count is an error instead of stack garbage
+    vp, i, d, lg = C.c_void_p, C.c_int, C.c_double, C.c_long
+    ipp = C.POINTER(C.POINTER(C.c_int))
+    ubp = C.POINTER(C.c_ubyte)
+    ullp = C.POINTER(C.c_ulonglong)
+    protos = {
+        "smcpp_last_error": (C.c_char_p, []),
+        "smcpp_create_onepop": (i, [i, i, _ip, ipp, i, _dp, d, i, C.POINTER(vp)]),
+        "smcpp_create_twopop": (i, [i, i, i, i, i, _ip, ipp, i, _dp, d, i, C.POINTER(vp)]),
+        "smcpp_destroy": (None, [vp]),
+        "smcpp_set_theta": (i, [vp, d]), "smcpp_set_rho": (i, [vp, d]), "smcpp_set_alpha": (i, [vp, d]),
+        "smcpp_set_params": (i, [vp, i, _dp, _dp, i, _dp]),
+        "smcpp_set_raw": (i, [vp, _dp, _dp, i, _ip, _dp]),
+        "smcpp_estep": (i, [vp, i]),
+        "smcpp_loglik": (i, [vp, _dp]),
+        "smcpp_q": (i, [vp, _dp, _dp]),
+        "smcpp_num_derivatives": (i, [vp]),
+        "smcpp_set_save_gamma": (i, [vp, i]), "smcpp_get_save_gamma": (i, [vp]),
+        "smcpp_num_states": (i, [vp]), "smcpp_num_contigs": (i, [vp]), "smcpp_num_keys": (i, [vp]),
+        "smcpp_key_len": (i, [vp]),
+        "smcpp_get_hidden_states": (i, [vp, _dp]), "smcpp_set_hidden_states": (i, [vp, i, _dp]),
+        "smcpp_get_keys": (i, [vp, _ip]),
+        "smcpp_get_xisum": (i, [vp, i, _dp]), "smcpp_get_gamma": (i, [vp, i, _dp]), "smcpp_gamma_cols": (i, [vp, i]),
+        "smcpp_get_gamma_sums": (i, [vp, i, _dp, ubp]),
+        "smcpp_get_pi": (i, [vp, _dp]), "smcpp_get_transition": (i, [vp, _dp]),
+        "smcpp_get_emission_probs": (i, [vp, _dp]), "smcpp_get_gamma_argmax": (i, [vp, i, _ip]),
+        "smcpp_set_global_keys": (i, [vp, i, _ip]),
+        "smcpp_pack_stats": (i, [vp, _dp, C.POINTER(lg), i]), "smcpp_unpack_stats": (i, [vp, _dp, lg, i]),
+        "smcpp_set_chunking": (i, [vp, i, d, d]), "smcpp_set_warm_start": (i, [vp, i]),
+        "smcpp_last_timing": (i, [vp, _dp]), "smcpp_last_host_timing": (i, [vp, _dp]), "smcpp_stream": (vp, [vp]),
+        "smcpp_set_num_threads": (None, [i]),
+        "smcpp_host_set_csfs_direct": (i, [i]),
+        "smcpp_host_eigensystem": (i, [i, _dp, _dp, _dp, _dp, _dp, _dp]),
+        "smcpp_host_prep_onepop": (i, [i, i, _dp, d, i, _dp, _dp, d, d, d, i, _ip, _dp, _dp, _dp]),
+        "smcpp_host_prep_onepop_jac": (i, [i, i, _dp, d, i, _dp, _dp, i, _dp, d, d, d, i, _ip, _dp, _dp, _dp, _dp,
+                                           _dp, _dp]),
+        "smcpp_host_rate_function": (i, [i, _dp, _dp, i, _dp, i, _dp, _dp, _dp]),
+        "smcpp_host_rate_function_jac": (i, [i, _dp, _dp, i, _dp, i, _dp, i, _dp, _dp, _dp, _dp, _dp]),
+        "smcpp_host_random_coal_times": (i, [i, _dp, _dp, d, d, i, ullp, _dp, _dp]),
+        "smcpp_host_raw_sfs": (i, [i, i, _dp, _dp, i, _dp, d, d, i, _dp, _dp]),
+        "smcpp_set_params_twopop": (i, [vp, i, _dp, _dp, _dp, i, _dp, _dp, _dp, i, _dp, _dp, _dp, d, i]),
+        "smcpp_host_joint_csfs": (i, [i, i, i, i, i, _dp, i, _dp, _dp, _dp, i, _dp, _dp, _dp, i, d, i, _dp, _dp]),
+        "smcpp_host_prep_twopop": (i, [i, i, i, i, i, _dp, d, i, _dp, _dp, i, _dp, _dp, i, _dp, _dp, d, d, d, d, i,
+                                       _ip, _dp, _dp, _dp]),
+    }
+    missing = [n for n in EXPORTS if n not in protos]
+    if missing:
+        raise RuntimeError(f"internal: no ctypes prototype for {missing}")
+    for name, (res, args) in protos.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
     _lib = L
     return L
 
@@ -57,7 +96,7 @@ EXPORTS = [
     "smcpp_host_eigensystem", "smcpp_host_prep_onepop", "smcpp_host_prep_onepop_jac", "smcpp_num_derivatives",
     "smcpp_host_rate_function", "smcpp_host_rate_function_jac", "smcpp_host_random_coal_times", "smcpp_host_raw_sfs",
     "smcpp_set_params_twopop", "smcpp_host_joint_csfs", "smcpp_host_prep_twopop", "smcpp_set_warm_start",
-    "smcpp_host_set_csfs_direct",
+    "smcpp_host_set_csfs_direct", "smcpp_gamma_cols", "smcpp_last_host_timing",
 ]
 
 

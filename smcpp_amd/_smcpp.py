@@ -155,7 +155,8 @@ class _PyInferenceManager:
     def gammas(self):
         ret = []
         for c in range(self._num_hmms):
-            ncol = int(self._Ls[c]) + 1 if self.save_gamma else 1
+            # sized from what the LAST E-step stored (the save_gamma flag may have been toggled since)
+            ncol = int(E.lib().smcpp_gamma_cols(self._im, c))
             g = np.zeros((self.M, ncol))
             E.check(E.lib().smcpp_get_gamma(self._im, c, E.dptr(g)))
             ret.append(g)
@@ -232,6 +233,11 @@ class _PyInferenceManager:
         return dict(zip(["host_prep_ms", "chains_wall_ms", "forward_ms", "backward_ms", "stats_ms", "finalize_ms",
                          "device_total_ms", "fwd_passes", "bwd_passes"], t))
 
+    def last_host_timing(self):
+        t = np.zeros(4)
+        E.check(E.lib().smcpp_last_host_timing(self._im, E.dptr(t)))
+        return dict(zip(["cold_prep_ms", "eigensystems_ms", "staging_ms", "host_total_ms"], t))
+
     def stream(self):
         return E.lib().smcpp_stream(self._im)
 
@@ -257,6 +263,7 @@ class _PyInferenceManager:
         n = C.c_long(0)
         E.check(E.lib().smcpp_pack_stats(self._im, C.cast(C.c_void_p(int(device_ptr)), C.POINTER(C.c_double)),
                                          C.byref(n), 1))
+        return int(n.value)
 
     def unpack_stats_device(self, device_ptr, n):
         E.check(E.lib().smcpp_unpack_stats(self._im, C.cast(C.c_void_p(int(device_ptr)), C.POINTER(C.c_double)),

@@ -165,7 +165,7 @@ struct smcpp_im {
     int nder = 0;
     std::vector<double> dpi, dT, dE;       // Jacobians [size x nder] of pi, T, E w.r.t. the seeds
     bool have_model = false;
-    bool save_gamma = false, gamma_valid = false;
+    bool save_gamma = false, gamma_valid = false, estep_done = false;
     // ---- device -----------------------------------------------------------------------------------------------
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: backward chain when it may overlap the forward one
@@ -218,12 +218,19 @@ struct smcpp_im {
     std::vector<double> loglik, h_xisum, h_gsum, h_gamma0;
     bool stats_on_host = false;
     double timing[9] = {0};
+    double host_timing[4] = {0};   // [cold preparation A6-A10, eigensystems, layouts + staging, whole host phase] of the last E-step, ms
     // multi-GPU
     std::vector<int> gkeys;                // global key list [Kg][keylen]
     std::vector<int> local_to_global;
     bool have_global = false;
     std::vector<double> g_stats;           // reduced [1 + M + M*M + Kg*M]
     bool have_reduced = false;
+    // emission vectors (and Jacobians) of EVERY global key, so that Q on the all-reduced statistics also covers keys
+    // that only other ranks' contigs hold; rows of keys nobody supplied (set_raw) are NaN
+    std::vector<double> Eg, dEg;
+    std::vector<int> raw_keys;             // what the last set_raw handed over: [Kr][keylen], raw_E [Kr][M]
+    std::vector<double> raw_E;
+    void global_emissions();
 
     ~smcpp_im() {
         if (stream) {
@@ -642,13 +649,55 @@ void smcpp_im::prepare_params() {
             d.a = model.a; d.s = model.s; p1.a = model_p1.a; p1.s = model_p1.s; p2.a = model_p2.a; p2.s = model_p2.s;
             prep.compute_t<double>(d, p1, p2, split, theta, rho, alpha, keys, K, pi, T, E);
         }
+        Eg.clear(); dEg.clear();           // rebuilt from the local table on demand (global_emissions)
         params_fresh = true;
         return;
     }
     smcpp_host::OnePopPrep prep(n[0], hs, polarization_error);
-    if (nder > 0) prep.compute_with_jacobian(model, model_da, nder, theta, rho, alpha, keys, K, pi, T, E, dpi, dT, dE);
-    else prep.compute(model, theta, rho, alpha, keys, K, pi, T, E);
+    // with a global key dictionary (multi-GPU) the emission table is prepared for every global key; the local table
+    // is the sub-list of the keys this rank's contigs hold
+    const std::vector<int> &pk = have_global ? gkeys : keys;
+    const int Kp_ = (int)(pk.size() / keylen);
+    std::vector<double> Ep, dEp;
+    if (nder > 0) prep.compute_with_jacobian(model, model_da, nder, theta, rho, alpha, pk, Kp_, pi, T, Ep, dpi, dT, dEp);
+    else prep.compute(model, theta, rho, alpha, pk, Kp_, pi, T, Ep);
+    if (!have_global) { E.swap(Ep); dE.swap(dEp); }
+    else {
+        E.assign((size_t)K * M, 0.0);
+        dE.assign(nder > 0 ? (size_t)K * M * nder : 0, 0.0);
+        for (int k = 0; k < K; ++k) {
+            const int kg = local_to_global[k];
+            std::memcpy(&E[(size_t)k * M], &Ep[(size_t)kg * M], sizeof(double) * M);
+            if (nder > 0) std::memcpy(&dE[(size_t)k * M * nder], &dEp[(size_t)kg * M * nder], sizeof(double) * M * nder);
+        }
+        Eg.swap(Ep); dEg.swap(dEp);
+    }
     params_fresh = true;
+}
+
+// Emission vectors of the global keys for the reduced Q when the parameters did not come from prepare_params
+void smcpp_im::global_emissions() {
+    const int Kg = (int)(gkeys.size() / keylen);
+    if (!have_raw && (int)Eg.size() == Kg * M) return;        // prepare_params filled them
+    Eg.assign((size_t)Kg * M, NAN);
+    dEg.clear();
+    std::map<std::vector<int>, int> gm;
+    for (int k = 0; k < Kg; ++k) gm[std::vector<int>(gkeys.begin() + (size_t)k * keylen, gkeys.begin() + (size_t)(k + 1) * keylen)] = k;
+    if (have_raw) {
+        const int Kr = (int)(raw_keys.size() / keylen);
+        for (int k = 0; k < Kr; ++k) {
+            auto it = gm.find(std::vector<int>(raw_keys.begin() + (size_t)k * keylen, raw_keys.begin() + (size_t)(k + 1) * keylen));
+            if (it != gm.end()) std::memcpy(&Eg[(size_t)it->second * M], &raw_E[(size_t)k * M], sizeof(double) * M);
+        }
+    } else {
+        // two-population path: the joint-CSFS preparation works on the local key list only
+        for (int k = 0; k < K; ++k) std::memcpy(&Eg[(size_t)local_to_global[k] * M], &E[(size_t)k * M], sizeof(double) * M);
+        if (nder > 0) {
+            dEg.assign((size_t)Kg * M * nder, NAN);
+            for (int k = 0; k < K; ++k)
+                std::memcpy(&dEg[(size_t)local_to_global[k] * M * nder], &dE[(size_t)k * M * nder], sizeof(double) * M * nder);
+        }
+    }
 }
 
 void smcpp_im::host_prep_and_upload() {
@@ -798,6 +847,11 @@ void smcpp_im::host_prep_and_upload() {
     if (off > need) throw std::runtime_error("internal: parameter arena overflow");
     auto tp2 = std::chrono::steady_clock::now();
     HIPCHK(hipMemcpyAsync(d_param, hb, off, hipMemcpyHostToDevice, s));
+    {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        host_timing[1] = ms(tp0, tp1);
+        host_timing[2] = ms(tp1, std::chrono::steady_clock::now());
+    }
     if (tm) {
         auto tp3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -1180,6 +1234,7 @@ void smcpp_im::estep() {
     HIPCHK(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
     prepare_params();
+    host_timing[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if ((int)pi.size() != M || (int)T.size() != M * M || (int)E.size() != K * M)
         throw std::runtime_error("parameters are not set");
     HIPCHK(hipEventRecord(ev[0], stream));
@@ -1201,6 +1256,7 @@ void smcpp_im::estep() {
     (void)hipEventElapsedTime(&s_ms, ev[3], ev[4]);
     (void)hipEventElapsedTime(&fin_ms, ev[4], ev[5]);
     timing[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    host_timing[3] = timing[0];
     timing[1] = chains_ms;   // wall time of both chains (they overlap in dual-stream mode)
     timing[2] = f_ms; timing[3] = b_ms; timing[4] = s_ms; timing[5] = fin_ms;
     timing[6] = std::chrono::duration<double, std::milli>(t2 - t1).count();
@@ -1208,10 +1264,12 @@ void smcpp_im::estep() {
     stats_on_host = false;
     have_reduced = false;
     gamma_valid = save_gamma;
+    estep_done = true;
     dirty = false;
 }
 
 void smcpp_im::fetch_stats() {
+    if (!estep_done) throw std::runtime_error("no E-step has been run on this manager yet");
     if (stats_on_host) return;
     HIPCHK(hipSetDevice(device));
     std::vector<double> x((size_t)n_contigs * Mp * Mp), g((size_t)n_contigs * K * Mp), g0((size_t)n_contigs * Mp);
@@ -1347,6 +1405,8 @@ int smcpp_set_raw(smcpp_im *im, const double *pi, const double *T, int K, const 
     im->pi.assign(pi, pi + M);
     im->T.assign(T, T + (size_t)M * M);
     im->E.swap(Enew);
+    im->raw_keys.assign(keys, keys + (size_t)K * kl);
+    im->raw_E.assign(E, E + (size_t)K * M);
     im->have_raw = true;
     im->dirty = true;
     im->nder = 0;
@@ -1362,6 +1422,7 @@ int smcpp_estep(smcpp_im *im, int fb_only) {
 
 int smcpp_loglik(smcpp_im *im, double *out) {
     API_BEGIN
+    if (!im->estep_done) throw std::runtime_error("no E-step has been run on this manager yet");
     std::memcpy(out, im->loglik.data(), sizeof(double) * im->n_contigs);
     API_END
 }
@@ -1407,22 +1468,34 @@ int smcpp_q(smcpp_im *im, double val[4], double *jac) {
         }
     };
     if (im->have_reduced) {
-        // statistics already summed over every rank's contigs
+        // statistics already summed over every rank's contigs: every global key contributes, also those no contig of
+        // this rank holds (their emission vectors come from the same preparation, see prepare_params)
         const double *g0 = &im->g_stats[1], *xs = g0 + M, *gs = xs + (size_t)M * M;
-        const int Kg = (int)(im->gkeys.size() / im->keylen);
+        const int Kg = (int)(im->gkeys.size() / im->keylen), kl = im->keylen;
+        im->global_emissions();
         for (int i = 0; i < M; ++i) val[0] += logpi[i] * g0[i];
         add_jac(0, g0, im->pi.data(), im->dpi.data(), M);
         std::vector<double> b0, b1;
+        bool inf0 = false, inf1 = false;
         for (int kg = 0; kg < Kg; ++kg) {
-            int kl = -1;
-            for (int k = 0; k < K; ++k) if (im->local_to_global[k] == kg) { kl = k; break; }
-            if (kl < 0) continue;   // a key no contig of this rank holds still needs its emission vector
-            auto &b = im->key_nbpos[kl] ? b1 : b0;
-            for (int i = 0; i < M; ++i) b.push_back(logE[(size_t)kl * M + i] * gs[(size_t)kg * M + i]);
-            add_jac(im->key_nbpos[kl] ? 2 : 1, gs + (size_t)kg * M, &im->E[(size_t)kl * M],
-                    nder ? &im->dE[(size_t)kl * M * nder] : nullptr, M);
+            const double *e = &im->Eg[(size_t)kg * M], *g = gs + (size_t)kg * M;
+            int nb = 0;
+            for (int p = 0; p < im->npop; ++p) nb += im->gkeys[(size_t)kg * kl + 3 * p + 2];
+            bool any = false, nan = false, nonpos = false;
+            for (int i = 0; i < M; ++i) { any = any || g[i] != 0.0; nan = nan || std::isnan(e[i]); nonpos = nonpos || e[i] <= 0.0; }
+            if (!any) continue;                          // no contig anywhere holds the key (hmm.cpp:166-181 skips it too)
+            if (nan) throw std::runtime_error("Q on all-reduced statistics: no emission vector for a key that another "
+                                              "rank's contigs hold (set_raw must supply every global key)");
+            if (nonpos) { (nb > 0 ? inf1 : inf0) = true; continue; }
+            auto &b = nb > 0 ? b1 : b0;
+            for (int i = 0; i < M; ++i) b.push_back(std::log(e[i]) * g[i]);
+            if (nder) {
+                if (im->dEg.empty()) throw std::runtime_error("Q gradient on all-reduced statistics needs model parameters (set_params)");
+                add_jac(nb > 0 ? 2 : 1, g, e, &im->dEg[(size_t)kg * M * nder], M);
+            }
         }
-        val[1] = dcs(b0); val[2] = dcs(b1);
+        val[1] = inf0 ? -INFINITY : dcs(b0);
+        val[2] = inf1 ? -INFINITY : dcs(b1);
         std::vector<double> es((size_t)M * M);
         for (int j = 0; j < M; ++j)
             for (int i = 0; i < M; ++i) es[(size_t)j * M + i] = logT[(size_t)i * M + j] * xs[(size_t)i * M + j];
@@ -1511,6 +1584,11 @@ int smcpp_get_gamma(smcpp_im *im, int c, double *out) {
     API_END
 }
 
+int smcpp_gamma_cols(smcpp_im *im, int c) {
+    if (c < 0 || c >= im->n_contigs) return -1;
+    return im->gamma_valid ? im->Ls[c] + 1 : 1;
+}
+
 int smcpp_get_gamma_argmax(smcpp_im *im, int c, int *out) {
     API_BEGIN
     if (c < 0 || c >= im->n_contigs) throw std::runtime_error("contig index out of range");
@@ -1574,6 +1652,8 @@ int smcpp_set_global_keys(smcpp_im *im, int Kg, const int *gkeys) {
     im->gkeys.assign(gkeys, gkeys + (size_t)Kg * kl);
     im->have_global = true;
     im->pack_tables_ready = false;
+    im->params_fresh = false;              // the emission table is now prepared over the global key list
+    im->Eg.clear(); im->dEg.clear();
     API_END
 }
 
@@ -1584,6 +1664,7 @@ int smcpp_pack_stats(smcpp_im *im, double *buf, long *n_out, int dev) {
     const long n = 1 + M + (long)M * M + (long)Kg * M;
     if (n_out) *n_out = n;
     if (!buf) return 0;
+    if (!im->estep_done) throw std::runtime_error("no E-step has been run on this manager yet");
     if (dev) {
         // device path: one kernel writes the packed layout into the caller's device buffer (e.g. the tensor that is
         // all-reduced over RCCL) - no host round trip
@@ -1662,6 +1743,10 @@ int smcpp_set_chunking(smcpp_im *im, int rows_per_chunk, double eps_alpha, doubl
 
 int smcpp_last_timing(smcpp_im *im, double out[9]) {
     API_BEGIN std::memcpy(out, im->timing, sizeof(double) * 9); API_END
+}
+
+int smcpp_last_host_timing(smcpp_im *im, double out[4]) {
+    API_BEGIN std::memcpy(out, im->host_timing, sizeof(double) * 4); API_END
 }
 
 void *smcpp_stream(smcpp_im *im) { return (void *)im->stream; }

@@ -15,6 +15,8 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -1015,6 +1017,9 @@ public:
     template <typename S>
     void compute_t(const ModelParamsT<S> &mp, double theta, double rho, double alpha, const std::vector<int> &keys,
                    int K, std::vector<S> &pi, std::vector<S> &T, std::vector<S> &E) {
+        static const bool tm = getenv("SMCPP_HOST_TIMING") != nullptr;
+        auto clk = [] { return std::chrono::steady_clock::now(); };
+        auto t0 = clk();
         RateFunctionT<S> eta(mp, hs_);
         const int M = (int)hs_.size() - 1;
         // pi (inference_manager.cpp:56-69)
@@ -1024,11 +1029,19 @@ public:
         S ps(0.0);
         for (S &x : pi) { if (sval(x) < 1e-20) x = S(1e-20); ps += x; }
         for (S &x : pi) x /= ps;
+        auto t1 = clk();
         T = compute_transition<S>(eta, rho);
+        auto t2 = clk();
         std::vector<std::vector<S>> sfs = conditioned_sfs<S>(eta, *tables_);
+        auto t3 = clk();
         incorporate_theta<S>(sfs, theta);
         const std::vector<S> avg_ct = eta.average_coal_times();
         emission_probs<S>(sfs, avg_ct, theta, alpha, keys, K, E);
+        if (tm) {
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "[prep] rate+pi %.3f ms, transition %.3f ms, csfs %.3f ms, theta+emission %.3f ms\n", ms(t0, t1),
+                    ms(t1, t2), ms(t2, t3), ms(t3, clk()));
+        }
     }
 
     void compute(const ModelParams &mp, double theta, double rho, double alpha, const std::vector<int> &keys, int K,

@@ -110,3 +110,125 @@ def allgather_logliks(local_logliks, owner, device=None, group=None):
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.cpu().numpy()
+
+
+class ShardedInferenceManager:
+    """The inference-manager surface (`E_step / loglik / logliks / Q / Q_with_gradient`, model / theta / rho / alpha,
+    `_smcpp.pyx:122-308`) over contigs sharded across the ranks of a `torch.distributed` group, one process per GPU.
+
+    The reference treats contigs as independent HMMs (one OpenMP task each, `src/inference_manager.cpp:89-94`) and
+    only ever consumes sums over them (`InferenceManager::Q` 116-126, `loglik` 174-177 + `sum(llret)` in
+    `_smcpp.pyx:303-308`).  Here every rank builds an ordinary manager over the contigs `lpt_shard` assigns to it,
+    runs the E-step on its own GPU, and the ranks exchange ONE all-reduce(sum, fp64) of the packed statistics
+    `[sum loglik | gamma0 | xisum | gamma_sums]`; afterwards `Q()` is evaluated on the reduced statistics and is
+    identical on every rank, so an optimiser driven by it stays in lock-step without further communication.
+
+    With backend "nccl" (= RCCL) the packed buffer is written by one kernel straight into the tensor that is reduced
+    over xGMI; with "gloo" (CPU tests, or ranks sharing a device) it goes through the host.  Without an initialised
+    process group (or world size 1) it degenerates to the local manager.
+
+    observations: the list of ALL contigs, identical on every rank; entries this rank does not own may be None if
+    `lengths` gives every contig's row count (so a rank need not load the others' data).
+    factory: callable(local_observations, device) -> manager; defaults to a one-population manager.
+    """
+
+    def __init__(self, n, observations, hidden_states, im_id, polarization_error, *, device=-1, group=None,
+                 lengths=None, factory=None):
+        import torch.distributed as dist
+        self._group = group
+        self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.world = self._dist.get_world_size(group) if self._dist else 1
+        self.rank = self._dist.get_rank(group) if self._dist else 0
+        if lengths is None:
+            lengths = [len(ob) for ob in observations]
+        if self.world > len(lengths):
+            raise RuntimeError(f"{self.world} ranks but only {len(lengths)} contigs: every rank needs at least one contig")
+        self.owner = lpt_shard(lengths, self.world)
+        self.mine = [i for i in range(len(lengths)) if self.owner[i] == self.rank]
+        local = [observations[i] for i in self.mine]
+        if any(ob is None for ob in local):
+            raise RuntimeError("a contig assigned to this rank was not provided")
+        if factory is None:
+            from . import _smcpp
+
+            def factory(obs, dev):
+                return _smcpp.PyOnePopInferenceManager(n, obs, hidden_states, im_id, polarization_error, device=dev)
+        self.im = factory(local, device)
+        self._nccl = bool(self._dist) and self._dist.get_backend(group) == "nccl"
+        self._buf = None
+        self._ll_sum = None
+        self._lls = None
+        if self.world > 1:
+            # global key dictionary: fixes the layout of the gamma_sums block and makes the engine prepare the
+            # emission vectors of keys only other ranks' contigs hold (they enter Q through the reduced statistics)
+            self.im.set_global_keys(union_keys(self.im.keys, group))
+
+    # ---- parameters: passed through to the local manager (every rank sets the same values) ----
+    @property
+    def model(self):
+        return self.im.model
+
+    @model.setter
+    def model(self, m):
+        self.im.model = m
+
+    def set_raw(self, pi, T, keys, E):
+        """Raw parameters; with more than one rank `keys` must cover the union of every rank's keys."""
+        self.im.set_raw(pi, T, keys, E)
+
+    theta = property(lambda self: self.im.theta, lambda self, v: setattr(self.im, "theta", v))
+    rho = property(lambda self: self.im.rho, lambda self, v: setattr(self.im, "rho", v))
+    alpha = property(lambda self: self.im.alpha, lambda self, v: setattr(self.im, "alpha", v))
+    M = property(lambda self: self.im.M)
+
+    @property
+    def keys(self):
+        """Union of every rank's keys (lexicographic)."""
+        return union_keys(self.im.keys, self._group) if self.world > 1 else self.im.keys
+
+    def E_step(self, forward_backward_only=False):
+        """Local E-step on this rank's contigs + the single all-reduce of the packed statistics."""
+        self.im.E_step(forward_backward_only)
+        self._lls = None
+        if self.world == 1:
+            self._ll_sum = float(self.im.loglik())
+            return
+        import torch
+        if self._nccl:
+            if self._buf is None:
+                self._buf = torch.empty(self.im.stats_len(), dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+            self.im.pack_stats_device(self._buf.data_ptr())           # returns after the kernel has finished
+            self._dist.all_reduce(self._buf, op=self._dist.ReduceOp.SUM, group=self._group)
+            self._ll_sum = float(self._buf[0].item())                 # synchronises the reduction
+            self.im.unpack_stats_device(self._buf.data_ptr(), self._buf.numel())
+        else:
+            h = self.im.pack_stats()
+            t = torch.from_numpy(h)
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+            self._ll_sum = float(t[0].item())
+            self.im.unpack_stats(t.numpy())
+
+    def loglik(self):
+        """Sum over ALL contigs of every rank (`_smcpp.pyx:303-308`)."""
+        if self._ll_sum is None:
+            raise RuntimeError("no E-step has been run on this manager yet")
+        return self._ll_sum
+
+    def logliks(self):
+        """Per-contig log-likelihoods in global contig order (one small extra collective, on demand)."""
+        if self._lls is None:
+            dev = None
+            if self._nccl:
+                import torch
+                dev = torch.device("cuda", torch.cuda.current_device())
+            self._lls = allgather_logliks(self.im.logliks(), self.owner, device=dev, group=self._group)
+        return self._lls
+
+    def Q(self, separate=False):
+        return self.im.Q(separate)
+
+    def Q_with_gradient(self):
+        return self.im.Q_with_gradient()
+
+    def last_timing(self):
+        return self.im.last_timing()

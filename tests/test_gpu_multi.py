@@ -1,0 +1,212 @@
+"""The N > 1 path on the GPU engine: `smcpp_amd.dist.ShardedInferenceManager` with two ranks
+sharing the one device of the test box (gloo reduction on the host; the measured configuration reduces the same
+packed buffer over RCCL) against the single-rank manager holding every contig, plus the boundary fixes that belong
+to it (reduced Q over keys a rank does not hold, buffer sizing of the gamma getter, getters before the first E-step)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _contigs(disjoint):
+    """Five ragged contigs; with `disjoint`, contig 0 holds only rows with b == 0 and contig 1 only rows with b > 0 or
+    a == -1 (plus the reduced keys), so the two ranks' key dictionaries differ in both directions."""
+    from smcpp_amd import synth
+    cs = [synth.synth_contig(50 + i, L, 10) for i, L in enumerate([700_000, 650_000, 90_000, 300_000, 60_000])]
+    if disjoint:
+        c0, c1 = cs[0], cs[1]
+        cs[0] = np.ascontiguousarray(c0[(c0[:, 2] == 0) & (c0[:, 1] >= 0)])
+        cs[1] = np.ascontiguousarray(c1[(c1[:, 2] > 0) | (c1[:, 3] == 0)])
+        cs = cs[:2]
+    return cs
+
+
+def _setup(im, g, use_model):
+    from smcpp_amd.model import PiecewiseModel
+    im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = float(g["alpha"])
+    if use_model:
+        m = PiecewiseModel(g["a"], g["s"], 1e4, "pop1")
+        m.differentiable = True
+        im.model = m
+    else:
+        im.set_raw(g["pi"], g["T"], g["keys"], g["E"])
+
+
+def _worker(rank, world, port, out_dir, disjoint, use_model):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from smcpp_amd import dist as sd
+    g = load_golden("G3_M32_n10_2Mbp")
+    contigs = _contigs(disjoint)
+    sim = sd.ShardedInferenceManager(10, contigs, g["hs"], ("pop1",), 0.5, device=0)
+    _setup(sim, g, use_model)
+    sim.E_step()
+    res = dict(rank=rank, mine=[int(i) for i in sim.mine], loglik=sim.loglik(), logliks=list(map(float, sim.logliks())),
+               q=list(map(float, sim.Q(separate=True))), local_keys=sim.im.keys.tolist(), keys=sim.keys.tolist())
+    if use_model:
+        q, jac = sim.Q_with_gradient()
+        res["jac"] = jac.tolist()
+    with open(os.path.join(out_dir, f"r{rank}.json"), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("disjoint,use_model", [(False, False), (False, True), (True, True), (True, False)])
+def test_two_ranks_match_single_manager(tmp_path, disjoint, use_model):
+    from smcpp_amd import _smcpp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), disjoint, use_model), nprocs=world, join=True)
+    r = [json.load(open(tmp_path / f"r{i}.json")) for i in range(world)]
+    g = load_golden("G3_M32_n10_2Mbp")
+    contigs = _contigs(disjoint)
+    im = _smcpp.PyOnePopInferenceManager(10, contigs, g["hs"], ("pop1",), 0.5)
+    _setup(im, g, use_model)
+    im.E_step()
+    assert sorted(r[0]["mine"] + r[1]["mine"]) == list(range(len(contigs)))
+    if disjoint:                                     # each rank lacks keys the other holds
+        k0, k1 = set(map(tuple, r[0]["local_keys"])), set(map(tuple, r[1]["local_keys"]))
+        assert k0 - k1 and k1 - k0
+    assert r[0]["keys"] == r[1]["keys"] == im.keys.tolist()
+    for x in r:
+        assert abs(x["loglik"] - im.loglik()) <= 1e-12 * abs(im.loglik())
+        np.testing.assert_allclose(x["logliks"], im.logliks(), rtol=1e-13)
+    # every rank evaluates Q on the same reduced statistics: bitwise equal across ranks, and equal to the single
+    # manager up to the summation order over contigs (~1e-13)
+    assert r[0]["q"] == r[1]["q"]
+    np.testing.assert_allclose(r[0]["q"], im.Q(separate=True), rtol=1e-11)
+    if use_model:
+        assert r[0]["jac"] == r[1]["jac"]
+        _, jac = im.Q_with_gradient()
+        np.testing.assert_allclose(np.array(r[0]["jac"]), jac, rtol=1e-9, atol=1e-9 * np.abs(jac).max())
+
+
+def test_reduced_q_needs_every_global_key():
+    """set_raw on a rank that was not given the emission vector of a key other ranks hold: Q must fail loudly instead
+    of silently dropping the key's statistics."""
+    from smcpp_amd import _smcpp, synth
+    g = load_golden("G3_M32_n10_2Mbp")
+    c = synth.synth_contig(50, 300_000, 10)
+    sub = np.ascontiguousarray(c[(c[:, 2] == 0) & (c[:, 1] >= 0)])
+    im = _smcpp.PyOnePopInferenceManager(10, [sub], g["hs"], ("pop1",), 0.5)
+    im.theta = float(g["theta"]); im.rho = float(g["rho"])
+    loc = set(map(tuple, im.keys.tolist()))
+    sel = [i for i, k in enumerate(g["keys"].tolist()) if tuple(k) in loc]
+    im.set_raw(g["pi"], g["T"], g["keys"][sel], g["E"][sel])          # only this rank's keys
+    im.E_step()
+    im.set_global_keys(g["keys"])
+    buf = im.pack_stats()
+    M, Kg = 32, len(g["keys"])
+    other = [i for i in range(Kg) if i not in sel][0]
+    buf[1 + M + M * M + other * M: 1 + M + M * M + (other + 1) * M] = 1.0   # "another rank" saw that key
+    im.unpack_stats(buf)
+    with pytest.raises(RuntimeError, match="no emission vector"):
+        im.Q(separate=True)
+    im.set_raw(g["pi"], g["T"], g["keys"], g["E"])                     # every global key supplied: fine
+    im.E_step()
+    im.unpack_stats(buf)
+    assert np.all(np.isfinite(im.Q(separate=True)))
+
+
+def test_gamma_getter_is_sized_from_the_last_estep():
+    """Toggling save_gamma after an E-step must not change what the getter returns (heap overflow)."""
+    from smcpp_amd import _smcpp
+    g = load_golden("G1_M16_n4")
+    im = _smcpp.PyOnePopInferenceManager(4, [g["obs"]], g["hs"], ("p",), 0.5)
+    with pytest.raises(RuntimeError, match="no E-step"):
+        im.xisums
+    with pytest.raises(RuntimeError, match="no E-step"):
+        im.loglik()
+    im.theta = float(g["theta"]); im.rho = float(g["rho"])
+    im.set_raw(g["pi"], g["T"], g["keys"], g["E"])
+    im.save_gamma = True
+    im.E_step()
+    full = im.gammas[0]
+    assert full.shape == (16, len(g["obs"]) + 1)
+    im.save_gamma = False
+    again = im.gammas[0]                              # still the stored M x (L+1) matrix
+    assert again.shape == full.shape and np.array_equal(again, full)
+    im.E_step()
+    assert im.gammas[0].shape == (16, 1)
+    im.save_gamma = True
+    assert im.gammas[0].shape == (16, 1)              # flag toggled, nothing stored yet
+
+
+def test_c5_shape_m256_n50_vs_oracle():
+    """Config C5 at its real shape: M = 256, n = 50 (K ~ 100 keys), parameters from the engine's own preparation
+    (checked against the compiled reference's table in tests/test_prep.py), 250 kbp against the C restatement."""
+    from oracle import oracle
+    from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "params_M256_n50.npz")))
+    full = synth.synth_contig(0, 100_000_000, 50)               # the C5 contig (same generator, same seed)
+    head = full[:600]                                           # its first ~250 kbp ...
+    assert head[:, 0].sum() * 100 >= 200_000
+    # ... followed by one row of every key the first 40 000 rows hold, so that the emission table is exercised at the
+    # C5 key count without an oracle run over megabases (the C restatement costs ~0.1 s per eigen row at M = 256)
+    seen = {tuple(r) for r in head[:, 1:].tolist()}
+    extra = []
+    for r in full[600:40_000].tolist():
+        if tuple(r[1:]) not in seen:
+            seen.add(tuple(r[1:])); extra.append(r)
+    obs = np.ascontiguousarray(np.vstack([head, np.array(extra, dtype=np.int32).reshape(-1, 4)]), dtype=np.int32)
+    im = _smcpp.PyOnePopInferenceManager(50, [obs], g["hs"], ("pop1",), float(g["pol"]))
+    im.model = PiecewiseModel(g["a"], g["s"], 1e4, "pop1")
+    im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = float(g["alpha"])
+    im.set_chunking(200)                                       # 4 chunks: the chunk-parallel iteration is exercised
+    im.E_step()
+    keys = im.keys
+    assert len(keys) >= 80
+    ep = im.emission_probs
+    Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
+    ref_E = {tuple(int(x) for x in k): e for k, e in zip(g["keys"], g["E"])}
+    for k, e in zip(keys.tolist(), Etab):
+        np.testing.assert_allclose(e, ref_E[tuple(k)], rtol=5e-14, atol=1e-18)
+    np.testing.assert_allclose(im.transition, g["T"], rtol=1e-10, atol=1e-17)
+    o = oracle.estep(im.pi, im.transition, keys, Etab, obs)
+    assert abs(im.loglik() - o["loglik"]) <= 1e-6 * abs(o["loglik"])
+    xs = im.xisums[0]
+    assert np.max(np.abs(xs - o["xisum"]) / np.maximum(np.abs(o["xisum"]), 1e-300)) <= 5e-6
+    for k, v in o["gamma_sums"].items():
+        assert np.max(np.abs(im.gamma_sums[0][k] - v)) <= 5e-6 * max(np.abs(v).max(), 1e-300)
+    q = np.array(im.Q(separate=True))
+    assert np.all(np.abs(q - o["q"]) <= 5e-6 * np.maximum(np.abs(o["q"]), 1e-12))
+
+
+def test_bench_gpus_2_self_launches():
+    """`python bench.py --gpus 2` without a torchrun environment must start two ranks itself and report n_gpus = 2
+    (on this one-GPU box the ranks share the device and reduce over gloo, which the output flags)."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--length-mbp", "10", "--no-cpu"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "set_params" in out["config"]["eval"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                          "--length-mbp", "10", "--no-cpu"], capture_output=True, text=True, env=env, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    o1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    # rank 0 of the two-rank run holds the same contig as the single-rank run; the reduced log-likelihood adds rank 1's
+    assert out["config"]["loglik"] < o1["config"]["loglik"] < 0

@@ -24,6 +24,7 @@
 
 #include "../../include/smcpp_engine.h"
 #include "kernels.hpp"
+#include "chains2.hpp"
 #include "nonsym_eig.hpp"
 #include "prep.hpp"
 #include "jcsfs.hpp"
@@ -125,6 +126,7 @@ struct DevBuf {
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 struct Group { int span, kid, eig; };
+constexpr int ROWDESC_PAD = 256;
 
 }  // namespace
 
@@ -523,12 +525,14 @@ void smcpp_im::alloc_device() {
     d_rowinfo.upload(rowinfo, s);
     {
         // packed descriptors of the chain kernels and the "hot" eigen key (most span>1 rows) they keep in registers
-        std::vector<int2> rd((size_t)total_rows);
+        // ROWDESC_PAD span-1 descriptors of key 0 on both sides: the chain kernels prefetch descriptors up to 192 rows
+        // past either end of a chunk without bounds tests (chains2.hpp)
+        std::vector<int2> rd((size_t)total_rows + 2 * ROWDESC_PAD, make_int2(0, -1));
         std::vector<long long> cnt(std::max(1, Ke), 0);
-        for (size_t r = 0; r < rd.size(); ++r) {
+        for (size_t r = 0; r < (size_t)total_rows; ++r) {
             const RowInfo &ri = rowinfo[r];
-            rd[r].x = ri.kid;
-            rd[r].y = ri.gid < 0 ? -1 : (ri.gid | (groups[ri.gid].eig << 20));
+            rd[ROWDESC_PAD + r].x = ri.kid;
+            rd[ROWDESC_PAD + r].y = ri.gid < 0 ? -1 : (ri.gid | (groups[ri.gid].eig << 20));
             if (ri.gid >= 0) cnt[groups[ri.gid].eig]++;
         }
         hot_eig = -1;
@@ -892,8 +896,30 @@ static void launch_chain_lds(bool fwd, const ChainArgs &a, const LdsArgs &la, in
         else launch_chain_lds_t<MT_, false, 4>(fwd, a, la, shm, s);
     }
 }
+// generation 2 of the cooperative chains (chains2.hpp): pass 0 and the re-run passes are separate instantiations
+template <int MT_, bool TAB_, bool RERUN_>
+static void launch_chain_coop2_t(bool fwd, const ChainArgs &a, const CoopArgs &ca, size_t shm, hipStream_t s) {
+    if (fwd) {
+        static bool once = false;
+        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_fwd_coop2<MT_, TAB_, RERUN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+        hipLaunchKernelGGL((k_fwd_coop2<MT_, TAB_, RERUN_>), dim3(a.nchunks), dim3(MT_ * 4), shm, s, a, ca);
+    } else {
+        static bool once = false;
+        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_bwd_coop2<MT_, TAB_, RERUN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+        hipLaunchKernelGGL((k_bwd_coop2<MT_, TAB_, RERUN_>), dim3(a.nchunks), dim3(MT_ * 4), shm, s, a, ca);
+    }
+}
+static int coop_generation() {
+    static const int gen = [] { const char *e = getenv("SMCPP_COOP_GEN"); return (e && atoi(e) == 1) ? 1 : 2; }();
+    return gen;
+}
 template <int MT_, bool TAB_>
 static void launch_chain_coop_t(bool fwd, const ChainArgs &a, const CoopArgs &ca, size_t shm, hipStream_t s) {
+    if (coop_generation() == 2) {
+        if (a.pass > 0) launch_chain_coop2_t<MT_, TAB_, true>(fwd, a, ca, shm, s);
+        else launch_chain_coop2_t<MT_, TAB_, false>(fwd, a, ca, shm, s);
+        return;
+    }
     if (fwd) {
         static bool once = false;
         if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_fwd_coop<MT_, TAB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
@@ -978,7 +1004,7 @@ void smcpp_im::run_chains() {
     ChainArgs a;
     a.M = M; a.Mp = Mp; a.nchunks = (int)chunks.size(); a.pass = 0;
     a.hot = hot_eig;
-    a.chunks = d_chunks.p; a.rowdesc = d_rowdesc.p; a.E = d_E.p; a.dpow = d_dpow.p;
+    a.chunks = d_chunks.p; a.rowdesc = d_rowdesc.p + ROWDESC_PAD; a.E = d_E.p; a.dpow = d_dpow.p;
     const bool generic = chain_mode == 0;
     CoopArgs cargs;
     cargs.K = K; cargs.G = G;

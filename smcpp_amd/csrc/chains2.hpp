@@ -78,19 +78,23 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
         if (owner) a.alpha[(size_t)ch.base * Mp + i] = al;
         if (tid == 0) a.cnorm[ch.base] = 1.0;
     }
+    // operand quarters in registers: float T and the eigenvector matrices of the two eigen keys with the most span > 1
+    // rows (binned data: the monomorphic and the heterozygous reduced key); other eigen keys read theirs from L2
     float tf[KQ];
-    double pinv[KQ], pt[KQ];
+    double pinv[KQ], pt[KQ], pinv2[KQ], pt2[KQ];
     {
-        const size_t ho = (size_t)(a.hot < 0 ? 0 : a.hot) * Mp * Mp;
+        const size_t ho = (size_t)(a.hot < 0 ? 0 : a.hot) * Mp * Mp, ho2 = (size_t)(a.hot2 < 0 ? 0 : a.hot2) * Mp * Mp;
 #pragma unroll
         for (int t = 0; t < KQ; ++t) {
             const int k = kq * KQ + t;
             tf[t] = a.Tf[(size_t)k * Mp + i];
             pinv[t] = (a.hot >= 0) ? a.PinvT[ho + (size_t)k * Mp + i] : 0.0;
             pt[t] = (a.hot >= 0) ? a.PT[ho + (size_t)k * Mp + i] : 0.0;
+            pinv2[t] = (a.hot2 >= 0) ? a.PinvT[ho2 + (size_t)k * Mp + i] : 0.0;
+            pt2[t] = (a.hot2 >= 0) ? a.PT[ho2 + (size_t)k * Mp + i] : 0.0;
         }
 #pragma unroll
-        for (int t = 0; t < KQ; ++t) { pin_reg(tf[t]); pin_reg(pinv[t]); pin_reg(pt[t]); }
+        for (int t = 0; t < KQ; ++t) { pin_reg(tf[t]); pin_reg(pinv[t]); pin_reg(pt[t]); pin_reg(pinv2[t]); pin_reg(pt2[t]); }
     }
     // descriptors of the chunk's rows, staged 64 at a time (batch b in sdesc[b & 1]); the array is padded, reads past the
     // chunk return descriptors of rows this workgroup never processes
@@ -193,6 +197,16 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
                     a3 = fma(pinv[4 * t + 3], (double)xh[t].y, a3);
                 }
                 u = quad_sum_d((a0 + a1) + (a2 + a3));
+            } else if (es == a.hot2) {
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int t = 0; t < Q4; ++t) {
+                    a0 = fma(pinv2[4 * t], (double)xl[t].x, a0);
+                    a1 = fma(pinv2[4 * t + 1], (double)xl[t].y, a1);
+                    a2 = fma(pinv2[4 * t + 2], (double)xh[t].x, a2);
+                    a3 = fma(pinv2[4 * t + 3], (double)xh[t].y, a3);
+                }
+                u = quad_sum_d((a0 + a1) + (a2 + a3));
             } else {
                 const double *Pm = a.PinvT + (size_t)es * Mp * Mp;
                 double a0 = 0.0;
@@ -214,6 +228,18 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
                     a1 = fma(pt[t + 1], x0.y, a1);
                     a2 = fma(pt[t + 2], x1.x, a2);
                     a3 = fma(pt[t + 3], x1.y, a3);
+                }
+                av = quad_sum_d((a0 + a1) + (a2 + a3));
+            } else if (es == a.hot2) {
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int t = 0; t < KQ; t += 4) {
+                    const double2 x0 = *reinterpret_cast<const double2 *>(uin + t);
+                    const double2 x1 = *reinterpret_cast<const double2 *>(uin + t + 2);
+                    a0 = fma(pt2[t], x0.x, a0);
+                    a1 = fma(pt2[t + 1], x0.y, a1);
+                    a2 = fma(pt2[t + 2], x1.x, a2);
+                    a3 = fma(pt2[t + 3], x1.y, a3);
                 }
                 av = quad_sum_d((a0 + a1) + (a2 + a3));
             } else {
@@ -304,18 +330,20 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
     }
     if (owner) a.used_b[(size_t)c * Mp + i] = b;
     if (tid == 0) a.changed[pass] = 1;
-    double tdt[KQ], prm[KQ], pinvrm[KQ];
+    double tdt[KQ], prm[KQ], pinvrm[KQ], prm2[KQ], pinvrm2[KQ];
     {
-        const size_t ho = (size_t)(a.hot < 0 ? 0 : a.hot) * Mp * Mp;
+        const size_t ho = (size_t)(a.hot < 0 ? 0 : a.hot) * Mp * Mp, ho2 = (size_t)(a.hot2 < 0 ? 0 : a.hot2) * Mp * Mp;
 #pragma unroll
         for (int t = 0; t < KQ; ++t) {
             const int k = kq * KQ + t;
             tdt[t] = a.TdT[(size_t)k * Mp + i];
             prm[t] = (a.hot >= 0) ? a.Prm[ho + (size_t)k * Mp + i] : 0.0;
             pinvrm[t] = (a.hot >= 0) ? a.Pinvrm[ho + (size_t)k * Mp + i] : 0.0;
+            prm2[t] = (a.hot2 >= 0) ? a.Prm[ho2 + (size_t)k * Mp + i] : 0.0;
+            pinvrm2[t] = (a.hot2 >= 0) ? a.Pinvrm[ho2 + (size_t)k * Mp + i] : 0.0;
         }
 #pragma unroll
-        for (int t = 0; t < KQ; ++t) { pin_reg(tdt[t]); pin_reg(prm[t]); pin_reg(pinvrm[t]); }
+        for (int t = 0; t < KQ; ++t) { pin_reg(tdt[t]); pin_reg(prm[t]); pin_reg(pinvrm[t]); pin_reg(prm2[t]); pin_reg(pinvrm2[t]); }
     }
     // descriptors in processing order: iteration j handles row ell = r1 - j; the array is padded in front as well
     const int2 *rd = a.rowdesc + ch.base + ch.r1;
@@ -403,6 +431,16 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
                     a3 = fma(prm[t + 3], x[t + 3], a3);
                 }
                 wv = quad_sum_d((a0 + a1) + (a2 + a3));
+            } else if (es == a.hot2) {
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int t = 0; t < KQ; t += 4) {
+                    a0 = fma(prm2[t], x[t], a0);
+                    a1 = fma(prm2[t + 1], x[t + 1], a1);
+                    a2 = fma(prm2[t + 2], x[t + 2], a2);
+                    a3 = fma(prm2[t + 3], x[t + 3], a3);
+                }
+                wv = quad_sum_d((a0 + a1) + (a2 + a3));
             } else {
                 const double *Pm = a.Prm + (size_t)es * Mp * Mp;
                 double a0 = 0.0;
@@ -423,6 +461,18 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
                     a1 = fma(pinvrm[t + 1], v0.y, a1);
                     a2 = fma(pinvrm[t + 2], v1.x, a2);
                     a3 = fma(pinvrm[t + 3], v1.y, a3);
+                }
+                bn = quad_sum_d((a0 + a1) + (a2 + a3));
+            } else if (es == a.hot2) {
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int t = 0; t < KQ; t += 4) {
+                    const double2 v0 = *reinterpret_cast<const double2 *>(uin + t);
+                    const double2 v1 = *reinterpret_cast<const double2 *>(uin + t + 2);
+                    a0 = fma(pinvrm2[t], v0.x, a0);
+                    a1 = fma(pinvrm2[t + 1], v0.y, a1);
+                    a2 = fma(pinvrm2[t + 2], v1.x, a2);
+                    a3 = fma(pinvrm2[t + 3], v1.y, a3);
                 }
                 bn = quad_sum_d((a0 + a1) + (a2 + a3));
             } else {

@@ -184,7 +184,7 @@ struct smcpp_im {
     int chain_mode = 2;   // 0 generic, 1 LDS-resident (one wavefront per chunk), 2 CU-cooperative (one workgroup per chunk),
                           // 3 CU-cooperative with streamed operands (64 < M <= 256)
     int coop_bpc = 1;     // cooperative workgroups resident per CU the automatic chunking aims at
-    int hot_eig = -1;
+    int hot_eig = -1, hot_eig2 = -1;
     DevBuf<Chunk> d_chunks;
     DevBuf<Slab> d_slabs_sc, d_slabs_rk, d_slabs_eg;
     DevBuf<int2> d_perm1k;                 // span-1 rows sorted by key: {ell, key id} (one load resolves both)
@@ -535,9 +535,11 @@ void smcpp_im::alloc_device() {
             rd[ROWDESC_PAD + r].y = ri.gid < 0 ? -1 : (ri.gid | (groups[ri.gid].eig << 20));
             if (ri.gid >= 0) cnt[groups[ri.gid].eig]++;
         }
-        hot_eig = -1;
+        hot_eig = hot_eig2 = -1;
         for (int e = 0; e < Ke; ++e)
             if (hot_eig < 0 || cnt[e] > cnt[hot_eig]) hot_eig = e;
+        for (int e = 0; e < Ke; ++e)
+            if (e != hot_eig && (hot_eig2 < 0 || cnt[e] > cnt[hot_eig2])) hot_eig2 = e;
         d_rowdesc.upload(rd, s);
         HIPCHK(hipStreamSynchronize(s));
     }
@@ -1003,7 +1005,7 @@ void smcpp_im::run_chains() {
     hipStream_t s = stream;
     ChainArgs a;
     a.M = M; a.Mp = Mp; a.nchunks = (int)chunks.size(); a.pass = 0;
-    a.hot = hot_eig;
+    a.hot = hot_eig; a.hot2 = hot_eig2;
     a.chunks = d_chunks.p; a.rowdesc = d_rowdesc.p + ROWDESC_PAD; a.E = d_E.p; a.dpow = d_dpow.p;
     const bool generic = chain_mode == 0;
     CoopArgs cargs;

@@ -102,6 +102,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 // ---------------------------------------------------------------------------------------------------------------
 struct ChainArgs {
     int M, Mp, nchunks, pass, hot;   // hot = eigen index whose matrices the *_hot kernels keep in registers (-1: none)
+    int hot2;                        // second register-resident eigen key of the generation-2 cooperative chains (-1: none)
     const Chunk *chunks;
     const int2 *rowdesc;    // [rows] {kid, gid | es << 20} (-1 for span-1 rows)
     const double *E;        // [K][Mp] emission vectors

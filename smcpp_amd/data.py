@@ -67,6 +67,58 @@ def compress_repeated_obs(dataset: np.ndarray) -> np.ndarray:
     return out
 
 
+def decompress_polymorphic_spans(dataset: np.ndarray) -> np.ndarray:
+    """Rows with span > 1 that are neither missing nor non-segregating are expanded into `span` rows of span 1
+    (`estimation_tools.py:63-85`)."""
+    dataset = np.asarray(dataset)
+    miss = np.all(dataset[:, 1::3] == -1, axis=1) & np.all(dataset[:, 3::3] == 0, axis=1)
+    nonseg = np.all(dataset[:, 1::3] == 0, axis=1) & (np.all(dataset[:, 2::3] == dataset[:, 3::3], axis=1)
+                                                      | np.all(dataset[:, 2::3] == 0, axis=1))
+    expand = (dataset[:, 0] > 1) & ~nonseg & ~miss
+    if not expand.any():
+        return dataset
+    reps = np.where(expand, dataset[:, 0], 1)
+    out = np.repeat(dataset, reps, axis=0)
+    out[np.repeat(expand, reps), 0] = 1
+    return out
+
+
+def validate(contig: Contig) -> Contig:
+    """`Validate` (`smcpp/data_filter.py:129-165`): at sites where every sampled haplotype carries the derived allele the
+    undistinguished count b is zeroed in place (the reference's assignment to the distinguished columns hits a copy and
+    has no effect; `RecodeMonomorphic` does that job later); malformed rows raise."""
+    d = contig.data
+    a = np.asarray(contig.a)
+    n = np.asarray(contig.n)
+    nonseg = ((np.all(d[:, 1::3] == a[None, :], axis=1) | np.all(d[:, 1::3] == -1, axis=1))
+              & np.all(d[:, 2::3] == d[:, 3::3], axis=1) & np.any(d[:, 3::3] > 0, axis=1))
+    if np.any(nonseg):
+        # the reference zeroes a COPY of the distinguished columns (fancy indexing) and b in place: only b changes
+        d[nonseg, 2::3] = 0
+    # operator precedence of the reference: `span <= (0 | any(a > A))`, then `| any(b > nb) | any(nb > n)`
+    bad = (d[:, 0] <= (0 | np.any(d[:, 1::3] > a[None, :], axis=1))) | np.any(d[:, 2::3] > d[:, 3::3], axis=1) \
+        | np.any(d[:, 3::3] > n[None, :], axis=1)
+    if np.any(bad):
+        raise RuntimeError("data validation failed")
+    return contig
+
+
+def drop_small_contigs(contigs, cutoff):
+    """`DropSmallContigs` (`smcpp/data_filter.py:283-297`)."""
+    ret = [c for c in contigs if len(c) > cutoff]
+    if not ret:
+        raise RuntimeError("All contigs are <.01cM (estimated). Please double check your data.")
+    return ret
+
+
+def drop_uninformative_contigs(contigs):
+    """`DropUninformativeContigs` (`smcpp/data_filter.py:259-280`): contigs without a single variable site are dropped."""
+    ret = [c for c in contigs if ((c.data[:, 1::3].sum(axis=1) > 0) | (c.data[:, 2::3].sum(axis=1) > 0)).sum() > 0]
+    if not ret:
+        raise RuntimeError("No contigs have mutation data. Inference is impossible.")
+    return ret
+
+
 def break_long_spans(contig: Contig, span_cutoff: int) -> List[Contig]:
     """Cut a contig at missing runs of at least `span_cutoff` positions; every piece starts with one missing row
     (`estimation_tools.py:117-167`)."""

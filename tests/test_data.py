@@ -224,3 +224,60 @@ def test_reference_pipeline_shape_on_the_example():
     assert len(np.unique(z[z[:, 0] > 1], axis=0)) == 10
     assert int(z[:, 0].max()) == 14
     assert abs(D.watterson_theta(pieces) - 4.02337e-4) < 1e-8
+
+
+# ---- golden G11: the reference's own shaping code run on real data (tests/golden/make_golden_pipeline.py) ----
+def _g11():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G11_pipeline.npz"))
+
+
+def test_pipeline_rows_equal_reference_on_the_example_contig():
+    """Row-for-row equality with the reference's `estimation_tools.py` / `data_filter.py` on the contig made from the
+    reference's example VCF (which this repository's converter must also reproduce from the VCF)."""
+    from smcpp_amd import data as D, vcf2smc as V
+    g = _g11()
+    vcf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example.vcf.gz")
+    c, _ = V.vcf2smc(vcf, "1", ("pop1", ["msp_0", "msp_1", "msp_2"]))
+    assert np.array_equal(c.data, g["ex_raw"]) and list(c.n) == g["ex_n"].tolist() and list(c.a) == g["ex_a"].tolist()
+    comp = D.compress_repeated_obs(c.data)
+    assert np.array_equal(comp, g["ex_compress"])
+    assert np.array_equal(D.decompress_polymorphic_spans(comp), g["ex_decompress"])
+    for cutoff in (100000, 5000, 2000):
+        pieces = D.break_long_spans(D.Contig(comp.copy(), c.pid, c.n, c.a), cutoff)
+        assert len(pieces) == int(g[f"ex_break_{cutoff}_n"])
+        for i, p in enumerate(pieces):
+            assert np.array_equal(p.data, g[f"ex_break_{cutoff}_{i}"]), (cutoff, i)
+    for cutoff in (None, 3000):
+        r = D.recode_nonseg(D.Contig(comp.copy(), c.pid, c.n, c.a), cutoff)
+        assert np.array_equal(r.data, g[f"ex_recode_nonseg_{cutoff}"])
+    np.testing.assert_allclose(D.watterson_theta([c]), float(g["ex_watterson"]), rtol=1e-14)
+    assert np.array_equal(D.validate(D.Contig(c.data.copy(), c.pid, c.n, c.a)).data, g["ex_validate"])
+    assert np.array_equal(D.recode_monomorphic(D.Contig(c.data.copy(), c.pid, c.n, c.a)).data, g["ex_recode_mono"])
+
+
+def test_pipeline_rows_equal_reference_on_its_test_data(tmp_path):
+    """The reference's own `.smc.gz` test files (test/bugs/11): reader, compression, span breaking, long-run recoding,
+    Watterson's estimator and monomorphic recoding, row for row."""
+    from smcpp_amd import data as D
+    g = _g11()
+    for fi, name in enumerate(g["bug11_files"].tolist()):
+        fn = str(tmp_path / name)
+        with gzip.open(fn, "wt") as f:
+            f.write(str(g[f"bug11_{fi}_text"]))
+        c = D.load_smc(fn)
+        assert c.pid == tuple(g[f"bug11_{fi}_pid"].tolist())
+        assert list(c.n) == g[f"bug11_{fi}_n"].tolist() and list(c.a) == g[f"bug11_{fi}_a"].tolist()
+        d = g[f"bug11_{fi}_data"]
+        assert np.array_equal(c.data, d)
+        comp = D.compress_repeated_obs(d)
+        assert np.array_equal(comp, g[f"bug11_{fi}_compress"])
+        pieces = D.break_long_spans(D.Contig(comp.copy(), c.pid, c.n, c.a), 20000)
+        assert len(pieces) == int(g[f"bug11_{fi}_break_n"])
+        for i, p in enumerate(pieces):
+            assert np.array_equal(p.data, g[f"bug11_{fi}_break_{i}"])
+        r = D.recode_nonseg(D.Contig(comp.copy(), c.pid, c.n, c.a), 10000)
+        assert np.array_equal(r.data, g[f"bug11_{fi}_recode_nonseg"])
+        np.testing.assert_allclose(D.watterson_theta([D.Contig(d.copy(), c.pid, c.n, c.a)]), float(g[f"bug11_{fi}_watterson"]),
+                                   rtol=1e-14)
+        assert np.array_equal(D.recode_monomorphic(D.Contig(d.copy(), c.pid, c.n, c.a)).data, g[f"bug11_{fi}_recode_mono"])
+    assert np.array_equal(D.compress_repeated_obs(g["kat_compress_in"]), g["kat_compress_out"])

@@ -188,6 +188,8 @@ __global__ __launch_bounds__(256) void k_mix(const float *__restrict__ Tf, const
     double *ub = sD + G * MT;                                   // [4][UP]
     float *xf = reinterpret_cast<float *>(ub + 4 * UP);         // [2][MT]
     int2 *sdesc = reinterpret_cast<int2 *>(xf + 2 * MT);        // [2][64]
+    float *ring = reinterpret_cast<float *>(sdesc + 128);       // [8][MT] alpha rows waiting for a coalesced store
+    double *cring = reinterpret_cast<double *>(ring + 8 * MT);  // [8]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int il = lane >> 2, kq = lane & 3, i = 16 * w + il;
     const bool owner = kq == 0;
@@ -241,6 +243,18 @@ __global__ __launch_bounds__(256) void k_mix(const float *__restrict__ Tf, const
             if (MODE == 0) {
                 if (owner) arow[(size_t)j * MT + i] = an;
                 if (tid == 0) crow[j] = (double)sprev;
+            }
+            if (MODE == 2) {
+                // rows go to an LDS ring; every 4th row ONE wavefront writes the four finished rows (1 KB) with a single
+                // 16-byte store per lane (the barrier of the previous row ordered the ring writes)
+                if (owner) ring[(j & 7) * MT + i] = an;
+                if (tid == 0) cring[j & 7] = (double)sprev;
+                if ((j & 3) == 0 && j >= 4 && w == ((j >> 2) & 3)) {
+                    const int r0 = j - 4;                                   // rows r0 .. r0+3 are complete
+                    const float4 v = *reinterpret_cast<const float4 *>(ring + (r0 & 7) * MT + lane * 4);
+                    *reinterpret_cast<float4 *>(alpha + ((size_t)blockIdx.x * nrows + r0) * MT + lane * 4) = v;
+                    if (lane < 4) crow[r0 + lane] = cring[(r0 & 7) + lane];
+                }
             }
         }
 #pragma unroll
@@ -351,15 +365,17 @@ int main() {
         CHK(hipMemcpy(dPi, Pinv.data(), Pinv.size() * 8, hipMemcpyHostToDevice)); CHK(hipMemcpy(dPt, Pt.data(), Pt.size() * 8, hipMemcpyHostToDevice));
         CHK(hipMemcpy(dEt, Et.data(), Et.size() * 8, hipMemcpyHostToDevice)); CHK(hipMemcpy(dDt, Dt.data(), Dt.size() * 8, hipMemcpyHostToDevice));
         CHK(hipMemcpy(dD, desc.data(), desc.size() * 8, hipMemcpyHostToDevice));
-        const size_t shm = (size_t)(K + G) * MT * 8 + 4 * (KQ + 2) * 8 + 2 * MT * 4 + 128 * 8 + 64;
+        const size_t shm = (size_t)(K + G) * MT * 8 + 4 * (KQ + 2) * 8 + 2 * MT * 4 + 128 * 8 + 8 * MT * 4 + 64 + 64;
         CHK(hipFuncSetAttribute((const void *)k_mix<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         CHK(hipFuncSetAttribute((const void *)k_mix<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        for (int mode = 0; mode < 2; ++mode) {
+        CHK(hipFuncSetAttribute((const void *)k_mix<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int mode = 0; mode < 3; ++mode) {
             hipEvent_t e0, e1;
             CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
             auto launch = [&]() {
                 if (mode == 0) hipLaunchKernelGGL(k_mix<0>, dim3(256), dim3(256), shm, 0, dT, dPi, dPt, dEt, dDt, dD, K, G, dA, dC, nr, dcyc);
-                else hipLaunchKernelGGL(k_mix<1>, dim3(256), dim3(256), shm, 0, dT, dPi, dPt, dEt, dDt, dD, K, G, dA, dC, nr, dcyc);
+                else if (mode == 1) hipLaunchKernelGGL(k_mix<1>, dim3(256), dim3(256), shm, 0, dT, dPi, dPt, dEt, dDt, dD, K, G, dA, dC, nr, dcyc);
+                else hipLaunchKernelGGL(k_mix<2>, dim3(256), dim3(256), shm, 0, dT, dPi, dPt, dEt, dDt, dD, K, G, dA, dC, nr, dcyc);
             };
             launch(); CHK(hipDeviceSynchronize());
             CHK(hipEventRecord(e0, 0));
@@ -368,7 +384,7 @@ int main() {
             float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
             long long cyc = 0; CHK(hipMemcpy(&cyc, dcyc, 8, hipMemcpyDeviceToHost));
             printf("mixed loop (45%% eigen rows), %s: %8.1f ns/row, %.1f ticks/row, %.3f ms per 920-row pass\n",
-                   mode == 0 ? "with stores" : "no stores  ", 1e6 * ms / 10 / nr, (double)cyc / nr, ms / 10);
+                   mode == 0 ? "with stores" : mode == 1 ? "no stores  " : "LDS-staged stores", 1e6 * ms / 10 / nr, (double)cyc / nr, ms / 10);
         }
     }
     return 0;

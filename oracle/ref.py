@@ -198,3 +198,41 @@ def q_jac(obs, keys, n, a, da, s, hs, rho, theta, alpha, polarization_error):
     if rc != 0:
         raise RuntimeError(L_.ref_last_error().decode())
     return q, jac, float(ll[0])
+
+
+def shift_or_truncate(a, s, t, truncate=False):
+    """Reference ``shiftParams`` / ``truncateParams`` (src/common.cpp:63-98)."""
+    L_ = lib()
+    a = np.ascontiguousarray(a, dtype=np.float64); s = np.ascontiguousarray(s, dtype=np.float64)
+    ao = np.zeros(len(a) + 2); so = np.zeros(len(a) + 2)
+    K = C.c_int(0)
+    rc = L_.ref_shift_or_truncate(int(bool(truncate)), len(a), _p(a, C.c_double), _p(s, C.c_double), C.c_double(t),
+                                  C.byref(K), _p(ao, C.c_double), _p(so, C.c_double))
+    if rc != 0:
+        raise RuntimeError(L_.ref_last_error().decode())
+    return ao[:K.value].copy(), so[:K.value].copy()
+
+
+def modified_moran(N, a, na):
+    """Reference ``modified_moran_rate_matrix(N, a, na)`` (src/moran_eigensystem.cpp:31-52), dense."""
+    L_ = lib()
+    out = np.zeros((N + 1, N + 1))
+    if L_.ref_modified_moran(int(N), int(a), int(na), _p(out, C.c_double)) != 0:
+        raise RuntimeError(L_.ref_last_error().decode())
+    return out
+
+
+def raw_csfs(a, s, hs, n, t=()):
+    """Reference ``OnePopConditionedSFS(n).compute(eta)`` [M, 3, n+1] on hidden states ``hs`` and ``eta.R`` at ``t``."""
+    L_ = lib()
+    a = np.ascontiguousarray(a, dtype=np.float64); s = np.ascontiguousarray(s, dtype=np.float64)
+    hs = np.ascontiguousarray(hs, dtype=np.float64)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    M = len(hs) - 1
+    out = np.zeros((M, 3, n + 1)) if n >= 0 else None
+    R = np.zeros(len(t))
+    rc = L_.ref_raw_csfs(len(a), _p(a, C.c_double), _p(s, C.c_double), M, _p(hs, C.c_double), int(n),
+                         _p(out, C.c_double), len(t), _p(t, C.c_double), _p(R, C.c_double))
+    if rc != 0:
+        raise RuntimeError(L_.ref_last_error().decode())
+    return out, R

@@ -439,3 +439,64 @@ extern "C" int ref_q_jac(int M, int K, const int *keys, int L, const int *obs_in
         return 1;
     }
 }
+
+// ---- pieces of JointCSFS<T>::pre_compute_apart (src/jcsfs.cpp:258-367) that ARE compiled here --------------------------
+// jcsfs.cpp itself needs GSL and is not built; these three entry points hand the compiled building blocks it calls to
+// oracle/jcsfs_apart_oracle.py, which restates only the assembly loops around them.
+
+#include "moran_eigensystem.h"
+
+// shiftParams / truncateParams (src/common.cpp:63-98): which = 0 shift, 1 truncate.  Returns the new piece count.
+extern "C" int ref_shift_or_truncate(int which, int Kp, const double *a, const double *s, double t, int *Kout,
+                                     double *a_out, double *s_out)
+{
+    try
+    {
+        ParameterVector params = make_params(Kp, a, s);
+        ParameterVector r = which == 0 ? shiftParams(params, t) : truncateParams(params, t);
+        *Kout = (int)r[0].size();
+        for (int k = 0; k < *Kout; ++k) { a_out[k] = r[0][k].value(); s_out[k] = r[1][k].value(); }
+        return 0;
+    }
+    catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+// modified_moran_rate_matrix(N, a, na) (src/moran_eigensystem.cpp:31-52), dense row-major [(N+1) x (N+1)]
+extern "C" int ref_modified_moran(int N, int a, int na, double *out)
+{
+    try
+    {
+        Eigen::SparseMatrix<mpq_class, Eigen::RowMajor> Mq = modified_moran_rate_matrix(N, a, na);
+        for (int i = 0; i <= N; ++i)
+            for (int j = 0; j <= N; ++j) out[i * (N + 1) + j] = 0.0;
+        for (int k = 0; k < Mq.outerSize(); ++k)
+            for (Eigen::SparseMatrix<mpq_class, Eigen::RowMajor>::InnerIterator it(Mq, k); it; ++it)
+                out[it.row() * (N + 1) + it.col()] = it.value().get_d();
+        return 0;
+    }
+    catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+// OnePopConditionedSFS<adouble>(n).compute(eta) only (src/conditioned_sfs.cpp:86-97): raw CSFS [M x 3 x (n+1)] of the
+// model (a, s) on the hidden states hs[M+1], and R(t) at nt points
+extern "C" int ref_raw_csfs(int Kp, const double *a, const double *s, int M, const double *hs, int n, double *out,
+                            int nt, const double *t, double *R_out)
+{
+    try
+    {
+        ParameterVector params = make_params(Kp, a, s);
+        std::vector<double> hidden_states(hs, hs + M + 1);
+        PiecewiseConstantRateFunction<adouble> eta(params, hidden_states);
+        if (out)
+        {
+            OnePopConditionedSFS<adouble> csfs(n);
+            std::vector<Matrix<adouble> > raw = csfs.compute(eta);
+            for (int m = 0; m < M; ++m)
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j <= n; ++j) out[(m * 3 + i) * (n + 1) + j] = raw.at(m)(i, j).value();
+        }
+        for (int i = 0; i < nt; ++i) R_out[i] = eta.R(t[i]).value();
+        return 0;
+    }
+    catch (const std::exception &e) { g_err = e.what(); return 1; }
+}

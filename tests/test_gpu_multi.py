@@ -210,3 +210,37 @@ def test_bench_gpus_2_self_launches():
     o1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     # rank 0 of the two-rank run holds the same contig as the single-rank run; the reduced log-likelihood adds rank 1's
     assert out["config"]["loglik"] < o1["config"]["loglik"] < 0
+
+
+def test_c4_real_shape_two_population_model_path():
+    """Config C4 at its real shape through `im.model = TwoPopulationModel(...)`: M = 48, n1 = n2 = 10, a = (2, 0),
+    split 0.5, 6-int keys.  The emission table the engine prepares is compared with golden G13 (reference jcsfs.py +
+    compiled reference C++), and the E-step with the C restatement of hmm.cpp fed with the FIXTURE's parameters (not the
+    engine's own), on the first 12 000 rows of the C4 contig."""
+    from oracle import oracle
+    from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel, TwoPopulationModel
+    g = np.load(os.path.join(ROOT, "tests", "golden", "G13_c4_params.npz"))
+    obs = np.ascontiguousarray(synth.synth_contig_twopop(0, 100_000_000, 10, 10)[:12_000])
+    im = _smcpp.PyTwoPopInferenceManager(10, 10, 2, 0, [obs], g["hs"], ("pop1", "pop2"), float(g["pol"]))
+    im.model = TwoPopulationModel(PiecewiseModel(g["a1"], g["s1"], 1e4, pid="pop1"),
+                                  PiecewiseModel(g["a2"], g["s2"], 1e4, pid="pop2"), float(g["split"]))
+    im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = float(g["alpha"])
+    im.E_step()
+    ref_E = {tuple(int(x) for x in k): e for k, e in zip(g["keys"], g["E"])}
+    ep = im.emission_probs
+    keys = im.keys
+    assert keys.shape[1] == 6 and len(keys) >= 100
+    for k in keys.tolist():
+        np.testing.assert_allclose(ep[tuple(k)], ref_E[tuple(k)], rtol=1e-8, atol=1e-14)
+    np.testing.assert_allclose(im.pi, g["pi"], rtol=1e-13)
+    np.testing.assert_allclose(im.transition, g["T"], rtol=1e-11, atol=1e-17)
+    Etab = np.array([ref_E[tuple(k)] for k in keys.tolist()])
+    o = oracle.estep(g["pi"], g["T"], keys, Etab, obs)
+    assert abs(im.loglik() - o["loglik"]) <= 1e-6 * abs(o["loglik"])
+    xs = im.xisums[0]
+    assert np.max(np.abs(xs - o["xisum"]) / np.maximum(np.abs(o["xisum"]), 1e-300)) <= 5e-6
+    for k, v in o["gamma_sums"].items():
+        assert np.max(np.abs(im.gamma_sums[0][k] - v)) <= 5e-6 * max(np.abs(v).max(), 1e-300)
+    q = np.array(im.Q(separate=True))
+    assert np.all(np.abs(q - o["q"]) <= 5e-6 * np.maximum(np.abs(o["q"]), 1e-12))

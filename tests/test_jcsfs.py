@@ -14,7 +14,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle import prep_oracle
+from oracle import prep_oracle, ref
 from smcpp_amd import _engine as E, _smcpp
 from smcpp_amd.model import PiecewiseModel, TwoPopulationModel
 
@@ -165,3 +165,58 @@ def test_two_population_emission_table(a1, a2):
     else:
         assert np.isnan(ct[0]) and pi[0] == pytest.approx(1e-20 / (1 + 1e-20), rel=1e-6) or pi[0] < 1e-15
     assert np.all(Etab > 0) and np.all(Etab <= 1)
+
+
+# ---- a1 = a2 = 1 ("apart", src/jcsfs.cpp:258-367): golden G12 ------------------------------------------------------
+# jcsfs.cpp cannot be compiled here (GSL) and the reference's Python original only covers a1 = 2, so G12 is assembled
+# by oracle/jcsfs_apart_oracle.py from the COMPILED reference building blocks the C++ calls (shiftParams /
+# truncateParams, OnePopConditionedSFS::compute, R, modified_moran_rate_matrix); only the assembly loops, expm and the
+# hypergeometric weights are restated there (in numpy / scipy, independently of the product's C++).
+def _g12():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G12_jcsfs_apart.npz"))
+
+
+def test_apart_matches_golden_from_compiled_reference_pieces():
+    from smcpp_amd import _engine
+    g = _g12()
+    a1, a2, s = g["a1"], g["a2"], g["s"]
+    for i in range(int(g["ncases"])):
+        n1, n2 = (int(x) for x in g[f"c{i}_n"])
+        J = _engine.host_joint_csfs(n1, n2, 1, 1, g[f"c{i}_hs"], (a1, s), (a2, s), float(g[f"c{i}_split"]))
+        R = g[f"c{i}_J"]
+        # entries are times in coalescent units (up to O(1)); 5e-15 absolute = a few ulp of the largest ones
+        np.testing.assert_allclose(J, R, rtol=1e-10, atol=5e-15, err_msg=f"case {i}: n=({n1},{n2})")
+        assert np.all(J[:, 0, 0, 0, 0] == 0) and np.all(J[:, 1, n1, 1, n2] == 0)
+
+
+@pytest.mark.skipif(not ref.available(), reason="compiled reference (oracle/_ref) not built")
+def test_apart_matches_live_oracle_on_other_models():
+    from oracle import jcsfs_apart_oracle as JA
+    from smcpp_amd import _engine
+    rng = np.random.default_rng(5)
+    for n1, n2 in ((2, 7), (5, 1)):
+        a1 = np.exp(rng.normal(0, 0.7, 5)); a2 = np.exp(rng.normal(0, 0.7, 3))
+        s1 = np.exp(rng.normal(-2, 0.8, 5)); s2 = np.exp(rng.normal(-2, 0.8, 3))
+        hs = np.r_[0.0, np.sort(np.exp(rng.normal(-1.5, 1.2, 7))), np.inf]
+        for split in (0.0, float(hs[2]), 0.33):
+            J = _engine.host_joint_csfs(n1, n2, 1, 1, hs, (a1, s1), (a2, s2), split)
+            R = JA.joint_csfs_apart(n1, n2, hs, (a1, s1), (a2, s2), split)
+            np.testing.assert_allclose(J, R, rtol=1e-10, atol=5e-15)
+
+
+def test_c4_real_shape_parameters_match_reference_fixture():
+    """Config C4 at its real shape (M = 48, n1 = n2 = 10, a = (2, 0), split 0.5; golden G13 = the reference's Python
+    JointCSFS backed by the compiled C++ + ref_prep + the literal emission templates): the engine's two-population
+    cold preparation, for every key of the C4 contig."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G13_c4_params.npz"))
+    m1, m2 = (g["a1"], g["s1"]), (g["a2"], g["s2"])
+    pi, T, Etab = E.host_prep_twopop(10, 10, 2, 0, g["hs"], float(g["pol"]), m1, m1, m2, float(g["split"]),
+                                     float(g["theta"]), float(g["rho"]), float(g["alpha"]), g["keys"])
+    np.testing.assert_allclose(pi, g["pi"], rtol=1e-13)
+    np.testing.assert_allclose(T, g["T"], rtol=1e-11, atol=1e-17)
+    assert len(g["keys"]) >= 150
+    np.testing.assert_allclose(Etab, g["E"], rtol=1e-8, atol=1e-14)
+    J = E.host_joint_csfs(10, 10, 2, 0, g["hs"], m1, m2, float(g["split"]))
+    np.testing.assert_allclose(J, g["J"], rtol=1e-9, atol=2e-14)

@@ -96,6 +96,17 @@ int smcpp_get_gamma_sums(smcpp_im *im, int contig, double *vals, unsigned char *
 int smcpp_get_pi(smcpp_im *im, double *out);                       /* getPi(): [M]           */
 int smcpp_get_transition(smcpp_im *im, double *out);               /* getTransition(): [M x M] */
 int smcpp_get_emission_probs(smcpp_im *im, double *out);           /* getEmissionProbs(): [K x M] */
+/* Jacobians of the three getters above with respect to the derivative seeds of the last smcpp_set_params
+ * (`store_matrix(const Matrix<adouble>&, double*, double*)`, src/common.cpp; _smcpp.pyx:215-275): row-major
+ * [M x nder], [M*M x nder], [K*M x nder].  Nothing is written when nder == 0; an error after smcpp_set_raw. */
+int smcpp_get_pi_jac(smcpp_im *im, double *out);
+int smcpp_get_transition_jac(smcpp_im *im, double *out);
+int smcpp_get_emission_probs_jac(smcpp_im *im, double *out);
+/* getEmission() (include/inference_manager.h:72,166; src/inference_manager.cpp:392-407): the conditioned SFS after
+ * incorporate_theta per hidden state, flattened row-major: [M x cols], cols = prod_p (a_p + 1)(n_p + 1);
+ * jac [M*cols x nder] may be NULL. */
+int smcpp_num_emission_cols(smcpp_im *im);
+int smcpp_get_emission(smcpp_im *im, double *out, double *jac);
 /* posterior decoding indices: argmax_m gamma[m, ell] for ell = 0..L (needs save_gamma) */
 int smcpp_get_gamma_argmax(smcpp_im *im, int contig, int *out);
 
@@ -132,6 +143,13 @@ int smcpp_last_host_timing(smcpp_im *im, double out[4]);
 /* The HIP stream the engine launches on (a hipStream_t), for event timing by the caller. */
 void *smcpp_stream(smcpp_im *im);
 
+/* init_logger_cb (include/common.h, _smcpp.pxd:26, _smcpp.pyx:32-55): the engine's messages (level "DEBUG", "INFO",
+ * "WARNING", ...) are handed to the binding, which forwards them to Python's logging; NULL = silent (the default). */
+void smcpp_init_logger_cb(void (*cb)(const char *name, const char *level, const char *message));
+/* init_cache (include/matrix_cache.h, _smcpp.pxd:87-88, src/matrix_cache.cpp:46-110): prefix of the on-disk store of the
+ * n-only conditioned-SFS tables (exact-rational work: 0.35 s at n = 10, 0.9 s at n = 50 when computed); one file
+ * `<path>.n<N>` per sample size, written atomically.  Empty / NULL = no store (tables live in the process only). */
+int smcpp_init_cache(const char *path);
 /* openmp.omp_set_num_threads (_smcpp.pyx:61-64): threads of the host-side preparation. */
 void smcpp_set_num_threads(int k);
 

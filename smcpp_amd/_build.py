@@ -63,5 +63,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+CY_SRC = os.path.join(HERE, "_smcpp_cy.pyx")
+
+
+def cython_module_path():
+    import sysconfig
+    return os.path.join(HERE, "_smcpp_cy" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_cython(force: bool = False) -> str:
+    """Compile the Cython binding `_smcpp_cy.pyx` (the drop-in for the reference's `_smcpp.pyx`) against the C ABI,
+    in-tree next to libsmcpp_engine.so (found at run time through an $ORIGIN rpath)."""
+    import sysconfig
+    import numpy
+    out = cython_module_path()
+    if not force and os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(CY_SRC),
+                                                                         os.path.getmtime(os.path.join(HERE, "..", "include", "smcpp_engine.h"))):
+        return out
+    build(force=False)
+    cpp = os.path.join(HERE, "_smcpp_cy.cpp")
+    subprocess.check_call([os.environ.get("PYTHON", "python3"), "-m", "cython", "-3", "--cplus", CY_SRC, "-o", cpp])
+    inc = [sysconfig.get_paths()["include"], numpy.get_include(), os.path.join(HERE, "..", "include")]
+    cmd = ["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-deprecated-declarations", "-DNPY_NO_DEPRECATED_API=NPY_1_7_API_VERSION"]
+    cmd += ["-I" + i for i in inc] + [cpp, "-o", out, "-L" + HERE, "-l:libsmcpp_engine.so", "-Wl,-rpath,$ORIGIN"]
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -55,6 +55,10 @@ def lib():
         "smcpp_get_gamma_sums": (i, [vp, i, _dp, ubp]),
         "smcpp_get_pi": (i, [vp, _dp]), "smcpp_get_transition": (i, [vp, _dp]),
         "smcpp_get_emission_probs": (i, [vp, _dp]), "smcpp_get_gamma_argmax": (i, [vp, i, _ip]),
+        "smcpp_get_pi_jac": (i, [vp, _dp]), "smcpp_get_transition_jac": (i, [vp, _dp]),
+        "smcpp_get_emission_probs_jac": (i, [vp, _dp]), "smcpp_num_emission_cols": (i, [vp]),
+        "smcpp_get_emission": (i, [vp, _dp, _dp]),
+        "smcpp_init_logger_cb": (None, [C.c_void_p]), "smcpp_init_cache": (i, [C.c_char_p]),
         "smcpp_set_global_keys": (i, [vp, i, _ip]),
         "smcpp_pack_stats": (i, [vp, _dp, C.POINTER(lg), i]), "smcpp_unpack_stats": (i, [vp, _dp, lg, i]),
         "smcpp_set_chunking": (i, [vp, i, d, d]), "smcpp_set_warm_start": (i, [vp, i]),
@@ -96,7 +100,9 @@ EXPORTS = [
     "smcpp_host_eigensystem", "smcpp_host_prep_onepop", "smcpp_host_prep_onepop_jac", "smcpp_num_derivatives",
     "smcpp_host_rate_function", "smcpp_host_rate_function_jac", "smcpp_host_random_coal_times", "smcpp_host_raw_sfs",
     "smcpp_set_params_twopop", "smcpp_host_joint_csfs", "smcpp_host_prep_twopop", "smcpp_set_warm_start",
-    "smcpp_host_set_csfs_direct", "smcpp_gamma_cols", "smcpp_last_host_timing",
+    "smcpp_host_set_csfs_direct", "smcpp_gamma_cols", "smcpp_last_host_timing", "smcpp_get_pi_jac",
+    "smcpp_get_transition_jac", "smcpp_get_emission_probs_jac", "smcpp_num_emission_cols", "smcpp_get_emission",
+    "smcpp_init_logger_cb", "smcpp_init_cache",
 ]
 
 

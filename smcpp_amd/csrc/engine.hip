@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -32,6 +33,20 @@
 using namespace smcpp_dev;
 
 static thread_local std::string g_err;
+
+// Logger::logger_cb (src/common.cpp:35-40, _smcpp.pxd:26): messages of the engine go to the binding's callback
+typedef void (*smcpp_logger_cb_t)(const char *name, const char *level, const char *message);
+static smcpp_logger_cb_t g_logger_cb = nullptr;
+static void log_msg(const char *level, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+static void log_msg(const char *level, const char *fmt, ...) {
+    if (!g_logger_cb) return;
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_logger_cb("engine", level, buf);
+}
 
 // libomp keeps its workers spinning for 200 ms after a parallel region by default; that steals the cores the HIP
 // runtime's own threads need between the short host-side parallel loops of an E-step.
@@ -166,6 +181,7 @@ struct smcpp_im {
     std::vector<double> model_da;          // [Kp x nder] derivative seeds of a
     int nder = 0;
     std::vector<double> dpi, dT, dE;       // Jacobians [size x nder] of pi, T, E w.r.t. the seeds
+    std::vector<double> emission, demission;   // InferenceManager::emission [M x cols] (+ Jacobian), model path only
     bool have_model = false;
     bool save_gamma = false, gamma_valid = false, estep_done = false;
     // ---- device -----------------------------------------------------------------------------------------------
@@ -645,15 +661,17 @@ void smcpp_im::prepare_params() {
         smcpp_host::TwoPopPrep prep(n[0], n[1], na[0], na[1], hs, polarization_error);
         if (nder > 0) {
             smcpp_host::DualScope sc(nder);
-            std::vector<smcpp_host::dual> pd, Td, Ed;
+            std::vector<smcpp_host::dual> pd, Td, Ed, emd;
             prep.compute_t<smcpp_host::dual>(make_dual_model(model, model_da, nder), make_dual_model(model_p1, model_da1, nder),
                                              make_dual_model(model_p2, model_da2, nder), split, theta, rho, alpha, keys, K,
-                                             pd, Td, Ed);
+                                             pd, Td, Ed, &emd);
             split_duals(pd, nder, pi, dpi); split_duals(Td, nder, T, dT); split_duals(Ed, nder, E, dE);
+            split_duals(emd, nder, emission, demission);
         } else {
             smcpp_host::ModelParamsT<double> d, p1, p2;
             d.a = model.a; d.s = model.s; p1.a = model_p1.a; p1.s = model_p1.s; p2.a = model_p2.a; p2.s = model_p2.s;
-            prep.compute_t<double>(d, p1, p2, split, theta, rho, alpha, keys, K, pi, T, E);
+            prep.compute_t<double>(d, p1, p2, split, theta, rho, alpha, keys, K, pi, T, E, &emission);
+            demission.clear();
         }
         Eg.clear(); dEg.clear();           // rebuilt from the local table on demand (global_emissions)
         params_fresh = true;
@@ -665,8 +683,9 @@ void smcpp_im::prepare_params() {
     const std::vector<int> &pk = have_global ? gkeys : keys;
     const int Kp_ = (int)(pk.size() / keylen);
     std::vector<double> Ep, dEp;
-    if (nder > 0) prep.compute_with_jacobian(model, model_da, nder, theta, rho, alpha, pk, Kp_, pi, T, Ep, dpi, dT, dEp);
-    else prep.compute(model, theta, rho, alpha, pk, Kp_, pi, T, Ep);
+    if (nder > 0) prep.compute_with_jacobian(model, model_da, nder, theta, rho, alpha, pk, Kp_, pi, T, Ep, dpi, dT, dEp,
+                                             &emission, &demission);
+    else { prep.compute(model, theta, rho, alpha, pk, Kp_, pi, T, Ep, &emission); demission.clear(); }
     if (!have_global) { E.swap(Ep); dE.swap(dEp); }
     else {
         E.assign((size_t)K * M, 0.0);
@@ -1289,6 +1308,9 @@ void smcpp_im::estep() {
     timing[2] = f_ms; timing[3] = b_ms; timing[4] = s_ms; timing[5] = fin_ms;
     timing[6] = std::chrono::duration<double, std::milli>(t2 - t1).count();
     timing[7] = last_fwd_passes; timing[8] = last_bwd_passes;
+    log_msg("DEBUG", "E-step: %d contig(s), %lld rows, M = %d, K = %d keys; host %.3f ms, chains %.3f ms (%d forward / %d "
+            "backward passes), statistics %.3f ms; loglik[0] = %.10g", n_contigs, total_rows - n_contigs, M, K, timing[0],
+            (double)chains_ms, last_fwd_passes, last_bwd_passes, (double)(s_ms + fin_ms), loglik.empty() ? 0.0 : loglik[0]);
     stats_on_host = false;
     have_reduced = false;
     gamma_valid = save_gamma;
@@ -1663,6 +1685,51 @@ int smcpp_get_emission_probs(smcpp_im *im, double *out) {
     API_BEGIN
     if (im->E.empty()) throw std::runtime_error("parameters are not set");
     std::memcpy(out, im->E.data(), sizeof(double) * im->K * im->M);
+    API_END
+}
+
+// ---- derivative-carrying getters (what the binding wraps into ad numbers, _smcpp.pyx:103-120,215-275) ----
+static void need_model_params(smcpp_im *im) {
+    if (im->have_raw) throw std::runtime_error("parameters were set with set_raw: no model, no derivatives");
+    im->prepare_params();
+}
+int smcpp_get_pi_jac(smcpp_im *im, double *out) {
+    API_BEGIN
+    need_model_params(im);
+    if (im->nder > 0) std::memcpy(out, im->dpi.data(), sizeof(double) * im->dpi.size());
+    API_END
+}
+int smcpp_get_transition_jac(smcpp_im *im, double *out) {
+    API_BEGIN
+    need_model_params(im);
+    if (im->nder > 0) std::memcpy(out, im->dT.data(), sizeof(double) * im->dT.size());
+    API_END
+}
+int smcpp_get_emission_probs_jac(smcpp_im *im, double *out) {
+    API_BEGIN
+    need_model_params(im);
+    if (im->nder > 0) std::memcpy(out, im->dE.data(), sizeof(double) * im->dE.size());
+    API_END
+}
+int smcpp_num_emission_cols(smcpp_im *im) {
+    int cols = 1;
+    for (int p = 0; p < im->npop; ++p) cols *= (im->na[p] + 1) * (im->n[p] + 1);
+    return cols;
+}
+int smcpp_get_emission(smcpp_im *im, double *out, double *jac) {
+    API_BEGIN
+    need_model_params(im);
+    if (im->emission.size() != (size_t)im->M * smcpp_num_emission_cols(im)) throw std::runtime_error("emission matrix is not available");
+    std::memcpy(out, im->emission.data(), sizeof(double) * im->emission.size());
+    if (jac && im->nder > 0) std::memcpy(jac, im->demission.data(), sizeof(double) * im->demission.size());
+    API_END
+}
+
+void smcpp_init_logger_cb(void (*cb)(const char *, const char *, const char *)) { g_logger_cb = cb; }
+
+int smcpp_init_cache(const char *path) {
+    API_BEGIN
+    smcpp_host::csfs_cache_prefix() = path ? path : "";
     API_END
 }
 

@@ -377,7 +377,7 @@ public:
     template <typename S>
     void compute_t(const ModelParamsT<S> &dist, const ModelParamsT<S> &p1, const ModelParamsT<S> &p2, double split,
                    double theta, double rho, double alpha, const std::vector<int> &keys, int K, std::vector<S> &pi,
-                   std::vector<S> &T, std::vector<S> &E) const {
+                   std::vector<S> &T, std::vector<S> &E, std::vector<S> *emission_out = nullptr) const {
         RateFunctionT<S> eta(dist, hs_);
         const int M = (int)hs_.size() - 1;
         pi.assign(M, S(0.0));
@@ -389,6 +389,10 @@ public:
         T = compute_transition<S>(eta, rho);
         std::vector<std::vector<S>> sfs = jcsfs<S>(p1, p2, split);
         incorporate_theta<S>(sfs, theta);
+        if (emission_out) {
+            emission_out->clear();
+            for (const auto &c : sfs) emission_out->insert(emission_out->end(), c.begin(), c.end());
+        }
         const std::vector<S> avg_ct = eta.average_coal_times();
         std::vector<S> e2((size_t)M * 2, S(0.0));
         for (int m = 0; m < M; ++m) {

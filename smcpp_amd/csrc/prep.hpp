@@ -19,6 +19,9 @@
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unistd.h>
 #include <limits>
 #include <map>
 #include <memory>
@@ -244,6 +247,46 @@ inline QMat below_coeffs(int n) {
 
 }  // namespace detail
 
+// On-disk store of the n-only tables (the role of MatrixCache's cereal archive, src/matrix_cache.cpp:46-110): one
+// little-endian file `<prefix>.n<N>` per sample size: magic, n, then the six matrices as (rows, cols, doubles).  Written
+// to a temporary name and renamed, so concurrent processes never read a partial file.  Empty prefix = no store.
+inline std::string &csfs_cache_prefix() { static std::string p; return p; }
+
+namespace detail {
+inline bool load_tables(const std::string &fn, int n, CsfsTables &t) {
+    FILE *f = fopen(fn.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    char magic[8];
+    int nn = -1;
+    if (fread(magic, 1, 8, f) == 8 && !memcmp(magic, "SMCPPT01", 8) && fread(&nn, sizeof(int), 1, f) == 1 && nn == n) {
+        ok = true;
+        for (DMat *m : {&t.X0, &t.X2, &t.M0, &t.M1, &t.Uinv_mp0, &t.Uinv_mp2}) {
+            int rc[2];
+            if (fread(rc, sizeof(int), 2, f) != 2 || rc[0] < 0 || rc[1] < 0 || (long long)rc[0] * rc[1] > (1ll << 26)) { ok = false; break; }
+            *m = DMat(rc[0], rc[1]);
+            if (fread(m->d.data(), sizeof(double), m->d.size(), f) != m->d.size()) { ok = false; break; }
+        }
+        ok = ok && t.X0.r == n && t.X0.c == n + 1 && t.M1.r == n + 1 && t.M1.c == n + 1;
+    }
+    fclose(f);
+    t.n = n;
+    return ok;
+}
+inline void store_tables(const std::string &fn, const CsfsTables &t) {
+    const std::string tmp = fn + ".tmp" + std::to_string((long long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;                                   // an unwritable cache directory is not an error (as in the reference)
+    bool ok = fwrite("SMCPPT01", 1, 8, f) == 8 && fwrite(&t.n, sizeof(int), 1, f) == 1;
+    for (const DMat *m : {&t.X0, &t.X2, &t.M0, &t.M1, &t.Uinv_mp0, &t.Uinv_mp2}) {
+        const int rc[2] = {m->r, m->c};
+        ok = ok && fwrite(rc, sizeof(int), 2, f) == 2 && fwrite(m->d.data(), sizeof(double), m->d.size(), f) == m->d.size();
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), fn.c_str()) != 0) remove(tmp.c_str());
+}
+}  // namespace detail
+
 inline std::shared_ptr<const CsfsTables> csfs_tables(int n) {
     static std::mutex mu;
     static std::map<int, std::shared_ptr<const CsfsTables>> memo;
@@ -252,6 +295,11 @@ inline std::shared_ptr<const CsfsTables> csfs_tables(int n) {
     if (it != memo.end()) return it->second;
     auto t = std::make_shared<CsfsTables>();
     t->n = n;
+    const std::string cache_fn = csfs_cache_prefix().empty() ? std::string() : csfs_cache_prefix() + ".n" + std::to_string(n);
+    if (!cache_fn.empty() && detail::load_tables(cache_fn, n, *t)) {
+        memo.emplace(n, t);
+        return t;
+    }
     const detail::Moran me = detail::moran_eigensystem(n);
     const int N1 = n + 1;
     // Uinv_mp0 = Uinv.rightCols(n); Uinv_mp2 = Uinv.reverse().leftCols(n)   (conditioned_sfs.cpp:8-9)
@@ -291,6 +339,7 @@ inline std::shared_ptr<const CsfsTables> csfs_tables(int n) {
     t->X2 = to_double(qmul(WnbjT, Dab, Urevtop));
     t->M0 = to_double(qmul(bc, w0, P_undist));
     t->M1 = to_double(qmul(bc, w1, P_dist));
+    if (!cache_fn.empty()) detail::store_tables(cache_fn, *t);
     memo.emplace(n, t);
     return t;
 }
@@ -1016,7 +1065,7 @@ public:
     // keys: [K][3] (a, b, nb); outputs pi [M], T [M*M] row-major, E [K*M]
     template <typename S>
     void compute_t(const ModelParamsT<S> &mp, double theta, double rho, double alpha, const std::vector<int> &keys,
-                   int K, std::vector<S> &pi, std::vector<S> &T, std::vector<S> &E) {
+                   int K, std::vector<S> &pi, std::vector<S> &T, std::vector<S> &E, std::vector<S> *emission_out = nullptr) {
         static const bool tm = getenv("SMCPP_HOST_TIMING") != nullptr;
         auto clk = [] { return std::chrono::steady_clock::now(); };
         auto t0 = clk();
@@ -1035,6 +1084,10 @@ public:
         std::vector<std::vector<S>> sfs = conditioned_sfs<S>(eta, *tables_);
         auto t3 = clk();
         incorporate_theta<S>(sfs, theta);
+        if (emission_out) {                      // InferenceManager::emission: the table per state, flattened row-major
+            emission_out->clear();
+            for (const auto &c : sfs) emission_out->insert(emission_out->end(), c.begin(), c.end());
+        }
         const std::vector<S> avg_ct = eta.average_coal_times();
         emission_probs<S>(sfs, avg_ct, theta, alpha, keys, K, E);
         if (tm) {
@@ -1045,17 +1098,19 @@ public:
     }
 
     void compute(const ModelParams &mp, double theta, double rho, double alpha, const std::vector<int> &keys, int K,
-                 std::vector<double> &pi, std::vector<double> &T, std::vector<double> &E) {
+                 std::vector<double> &pi, std::vector<double> &T, std::vector<double> &E,
+                 std::vector<double> *emission = nullptr) {
         ModelParamsT<double> p;
         p.a = mp.a; p.s = mp.s;
-        compute_t<double>(p, theta, rho, alpha, keys, K, pi, T, E);
+        compute_t<double>(p, theta, rho, alpha, keys, K, pi, T, E, emission);
     }
 
     // values + Jacobians: da [Kp x nder] seeds of the piece sizes; outputs d* are [size x nder] row-major
     void compute_with_jacobian(const ModelParams &mp, const std::vector<double> &da, int nder, double theta, double rho,
                                double alpha, const std::vector<int> &keys, int K, std::vector<double> &pi,
                                std::vector<double> &T, std::vector<double> &E, std::vector<double> &dpi,
-                               std::vector<double> &dT, std::vector<double> &dE) {
+                               std::vector<double> &dT, std::vector<double> &dE, std::vector<double> *emission = nullptr,
+                               std::vector<double> *demission = nullptr) {
         DualScope sc(nder);
         ModelParamsT<dual> p;
         p.s = mp.s;
@@ -1064,13 +1119,14 @@ public:
             p.a[k] = dual(mp.a[k]);
             for (int d = 0; d < nder; ++d) p.a[k].d[d] = da[k * nder + d];
         }
-        std::vector<dual> pd, Td, Ed;
-        compute_t<dual>(p, theta, rho, alpha, keys, K, pd, Td, Ed);
+        std::vector<dual> pd, Td, Ed, emd;
+        compute_t<dual>(p, theta, rho, alpha, keys, K, pd, Td, Ed, emission ? &emd : nullptr);
         auto split = [nder](const std::vector<dual> &x, std::vector<double> &v, std::vector<double> &j) {
             v.resize(x.size()); j.resize(x.size() * (size_t)nder);
             for (size_t i = 0; i < x.size(); ++i) { v[i] = x[i].v; for (int d = 0; d < nder; ++d) j[i * nder + d] = x[i].d[d]; }
         };
         split(pd, pi, dpi); split(Td, T, dT); split(Ed, E, dE);
+        if (emission) { std::vector<double> tmp; split(emd, *emission, demission ? *demission : tmp); }
     }
 
     // restated marginalisation machinery -----------------------------------------------------------------------

@@ -61,6 +61,41 @@ class PiecewiseModel(Observable):
         self.update_observers("model update")
 
 
+class AdPiecewiseModel(Observable):
+    """Piecewise-constant model whose piece sizes are ad VARIABLES, the way the reference's models hand parameters to
+    `_smcpp.pyx` (`make_params`, 66-83): `stepwise_values()` returns ad numbers, `dlist` the variables derivatives are
+    taken with respect to (`smcpp/model.py:83-91`).  Used with the Cython binding `smcpp_amd._smcpp_cy`."""
+
+    def __init__(self, a, s, N0=1e4, pid=None, differentiable=None):
+        super().__init__()
+        from .ad import adnumber
+        assert len(a) == len(s)
+        self._vars = [adnumber(float(x), tag=("a", k)) for k, x in enumerate(a)]
+        self.s = np.array(s, dtype=np.float64)
+        self.N0 = N0
+        self.pid = pid
+        self._diff = list(range(len(a))) if differentiable is None else list(differentiable)
+
+    def stepwise_values(self):
+        return list(self._vars)
+
+    @property
+    def dlist(self):
+        return [self._vars[k] for k in self._diff]
+
+    def for_pop(self, pop):
+        assert pop == self.pid
+        return self
+
+    def __getitem__(self, it):
+        return self._vars[it]
+
+    def __setitem__(self, it, x):
+        from .ad import adnumber
+        self._vars[it] = adnumber(float(x), tag=("a", it))
+        self.update_observers("model update")
+
+
 class _Pieces:
     """Plain (a, s) view handed to the managers by `TwoPopulationModel.for_pop`; `seeds` are the derivative seeds of
     its pieces in the joint direction space of the two-population model (None when nothing is differentiable)."""

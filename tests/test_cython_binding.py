@@ -1,0 +1,137 @@
+"""The compiled Cython binding `smcpp_amd/_smcpp_cy.pyx` (the drop-in for the reference's `smcpp/_smcpp.pyx`,
+INTEGRATION.md): builds in the CPU container, links against the C ABI, and returns ad numbers where the reference does."""
+import logging
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+@pytest.fixture(scope="module")
+def cy():
+    from smcpp_amd import _build
+    _build.build_cython()
+    from smcpp_amd import _smcpp_cy
+    return _smcpp_cy
+
+
+def test_module_surface(cy):
+    for name in ("PyOnePopInferenceManager", "PyTwoPopInferenceManager", "PyRateFunction", "raw_sfs", "set_num_threads",
+                 "_check_abort", "_init_cache"):
+        assert hasattr(cy, name), name
+    assert cy.abort is False
+    cy.set_num_threads(2)
+
+
+def test_rate_function_and_raw_sfs_return_ad_numbers(cy):
+    from smcpp_amd import _engine
+    from smcpp_amd.model import AdPiecewiseModel
+    a = np.array([1.0, 2.0, 0.5, 1.5]); s = np.array([0.05, 0.2, 0.5, 1.0])
+    m = AdPiecewiseModel(a, s, differentiable=[0, 2, 3])
+    dl = m.dlist
+    eta = cy.PyRateFunction(m, [0.0, 0.3, 1.0, np.inf])
+    R = eta.R(0.6)
+    Rv, dR, ct, dct = _engine.host_rate_function_jac(a, np.eye(4)[:, [0, 2, 3]], s, [0.6], hs=[0.0, 0.3, 1.0, np.inf])
+    assert abs(R.x - Rv[0]) <= 1e-15 and [R.d(v) for v in dl] == list(dR[0])
+    act = eta.average_coal_times()
+    assert len(act) == 3
+    np.testing.assert_allclose([z.x for z in act], ct, rtol=1e-15)
+    np.testing.assert_allclose([[z.d(v) for v in dl] for z in act], dct, rtol=1e-14)
+    assert act[0].d(m[1]) == 0.0                                   # not in dlist
+    sfs = cy.raw_sfs(m, 5, 0.1, 0.9)
+    v, dv = _engine.host_raw_sfs(5, a, s, 0.1, 0.9, da=np.eye(4)[:, [0, 2, 3]])
+    assert sfs.shape == (3, 6)
+    np.testing.assert_allclose(np.vectorize(lambda z: z.x)(sfs), v, rtol=1e-15)
+    np.testing.assert_allclose(np.array([[[z.d(x) for x in dl] for z in row] for row in sfs]), dv, rtol=1e-14, atol=1e-300)
+    t = eta.random_coal_times(0.1, 0.5, 4)
+    assert len(t) == 4 and all(0.1 < x[0] < 0.5 for x in t)
+    # without derivative variables plain floats come back, as in the reference (_smcpp.pyx:104-105)
+    m0 = AdPiecewiseModel(a, s, differentiable=[])
+    assert isinstance(cy.PyRateFunction(m0, []).R(0.2), float)
+
+
+def test_init_cache_stores_the_tables_on_disk(tmp_path):
+    """`_init_cache` (smcpp/_smcpp.pyx:24-30 -> init_cache, src/matrix_cache.cpp:46-110): a second process finds the
+    n-only tables on disk and produces identical numbers."""
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from smcpp_amd import _smcpp_cy as cy\n"
+            "from smcpp_amd.model import AdPiecewiseModel\n"
+            "cy._init_cache()\n"
+            "m = AdPiecewiseModel([1.0, 2.0], [0.1, 1.0], differentiable=[])\n"
+            "print(repr(cy.raw_sfs(m, 7, 0.0, 1.0).astype(float).tolist()))\n") % ROOT
+    env = dict(os.environ, XDG_CACHE_HOME=str(tmp_path))
+    out1 = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, check=True).stdout
+    files = sorted(os.listdir(tmp_path / "smcpp_amd"))
+    assert files == ["matrices.dat.n7"], files
+    stamp = os.path.getmtime(tmp_path / "smcpp_amd" / files[0])
+    out2 = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, check=True).stdout
+    assert out1 == out2 and os.path.getmtime(tmp_path / "smcpp_amd" / files[0]) == stamp     # read, not rewritten
+    with open(tmp_path / "smcpp_amd" / files[0], "r+b") as f:                                 # a damaged file is ignored
+        f.seek(20); f.write(b"\xff" * 8); f.truncate(200)
+    out3 = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, check=True).stdout
+    assert out3 == out1
+
+
+@pytest.mark.gpu
+def test_managers_through_the_compiled_binding(cy, caplog):
+    """The reference's calling sequence on the compiled module: im.model = m (ad variables), theta / rho / alpha,
+    E_step, loglik, Q() as ad numbers, derivative-carrying pi / transition / emission / emission_probs; compared with
+    the ctypes binding on the same inputs and with golden G4 / G10."""
+    from smcpp_amd import _smcpp
+    from smcpp_amd.model import AdPiecewiseModel, PiecewiseModel
+    g = load_golden("G4_M64_n20_2Mbp")
+    G = np.load(os.path.join(ROOT, "tests", "golden", "G10_q_gradients.npz"))
+    obs = np.ascontiguousarray(g["obs"], dtype=np.int32)
+    im = cy.PyOnePopInferenceManager(int(g["n"]), [obs], g["hs"], ("pop1",), float(g["pol"]))
+    m = AdPiecewiseModel(g["a"], g["s"], 1e4, "pop1")
+    dl = m.dlist
+    with caplog.at_level(logging.DEBUG):
+        im.model = m
+        im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = float(g["alpha"])
+        im.E_step()
+    assert any("E-step" in r.getMessage() and r.name.startswith("smcpp._smcpp:") for r in caplog.records)   # logger_cb
+    assert abs(im.loglik() - float(g["loglik"])) <= 1e-6 * abs(float(g["loglik"]))
+    qq = im.Q(separate=True)
+    qr, jr = G["G4_M64_n20_2Mbp_q"], G["G4_M64_n20_2Mbp_jac"]
+    for r in range(4):
+        assert abs(qq[r].x - qr[r]) <= 5e-6 * max(abs(qr[r]), 1e-12)
+        jac = np.array([qq[r].d(v) for v in dl])
+        assert np.max(np.abs(jac - jr[r])) <= 1e-5 * max(np.abs(jr[r]).max(), 1e-300)
+    q = im.Q()
+    assert abs(q.x - sum(z.x for z in qq)) <= 1e-9 * abs(q.x)
+    np.testing.assert_allclose([q.d(v) for v in dl], np.sum([[z.d(v) for v in dl] for z in qq], axis=0), rtol=1e-12)
+    # the ctypes binding on the same inputs
+    im2 = _smcpp.PyOnePopInferenceManager(int(g["n"]), [obs], g["hs"], ("pop1",), float(g["pol"]))
+    m2 = PiecewiseModel(g["a"], g["s"], 1e4, "pop1"); m2.differentiable = True
+    im2.model = m2
+    im2.theta = float(g["theta"]); im2.rho = float(g["rho"]); im2.alpha = float(g["alpha"])
+    im2.E_step()
+    assert im.loglik() == im2.loglik()
+    pi = im.pi
+    assert pi.shape == (64, 1) and abs(sum(z.x for z in pi[:, 0]) - 1) < 1e-12
+    T = im.transition
+    np.testing.assert_array_equal(np.vectorize(lambda z: z.x)(T), im2.transition)
+    em = im.emission
+    assert em.shape == (64, 3 * 21) and all(0 < z.x <= 1 for z in em.reshape(-1))
+    ep = im.emission_probs
+    ep2 = im2.emission_probs
+    assert sorted(ep) == sorted(ep2)
+    for k in ep:
+        np.testing.assert_array_equal(np.array([z.x if hasattr(z, "x") else z for z in ep[k]]), ep2[k])
+    # a derivative actually flows: d pi / d a_0 by finite differences of the ctypes binding's pi
+    h = 1e-6
+    # (the getters return the members as of the last do_dirty_work, like the reference's: Q() refreshes them)
+    m2[0] = g["a"][0] * (1 + h); im2.Q(); p1 = im2.pi.copy()
+    m2[0] = g["a"][0] * (1 - h); im2.Q(); p0 = im2.pi.copy()
+    fd = (p1 - p0) / (2 * h * g["a"][0])
+    an = np.array([z.d(dl[0]) for z in pi[:, 0]])
+    assert np.max(np.abs(fd - an)) <= 1e-5 * np.abs(an).max()
+    np.testing.assert_allclose(im.xisums[0], im2.xisums[0], rtol=1e-12)
+    assert sorted(im.gamma_sums[0]) == sorted(im2.gamma_sums[0])
+    assert im.gammas[0].shape == (64, 1)
+    with pytest.raises(RuntimeError, match="same size"):
+        im.hidden_states = [0.0, 1.0]

@@ -320,6 +320,15 @@ def main():
               "gbs_on_B_alg": B_alg / (1e-3 * ms_per_step) / 1e9},
         note="latency-bound sequential chains: frac = one pass of algorithmic flops / kernel time per step / fp64 peak")
 
+    if args.workload == "posterior":
+        # the product of this workload is the M x (L+1) posterior matrix: 8 M L bytes written by the statistics phase
+        # (span-1 rows by k_s1_scalars, eigen rows by k_gamma_rows_mfma: 2 M^3 flops per eigen row on the matrix cores)
+        gbytes = 8.0 * M * sum(len(c) + 1 for c in contigs)
+        t_stat = 1e-3 * (med["stats_ms"] + med["finalize_ms"])
+        roof["posterior"] = {"gamma_bytes": gbytes, "statistics_ms": 1e3 * t_stat, "gamma_write_gbs": gbytes / t_stat / 1e9,
+                             "gamma_write_frac_of_hbm": gbytes / t_stat / 1e9 / HBM_PEAK_GBS,
+                             "eigen_row_tflops": 2.0 * M ** 3 * Re / t_stat / 1e12,
+                             "fwd_passes": med["fwd_passes"], "bwd_passes": med["bwd_passes"]}
     out = None
     if rank == 0:
         out = {

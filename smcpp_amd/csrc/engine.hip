@@ -169,6 +169,7 @@ struct smcpp_im {
     std::vector<int2> perm1k;
     std::vector<Slab> slabs_sc, slabs_rk, slabs_eg;   // span-1 scalar slabs, span-1 rank slabs, eigen slabs
     std::vector<int> gk_slab_off, s1_slab_off, eb_slab_off, eb_gid, ce_bucket_off, erow_slab;
+    std::vector<int> ce_row_off;           // [n_contigs*Ke + 1] first position in perme of every (contig, eigen key)
     long long n_e_rows = 0, n_1_rows = 0;
     // ---- parameters -------------------------------------------------------------------------------------------
     double theta = NAN, rho = NAN, alpha = 1.0;
@@ -210,7 +211,7 @@ struct smcpp_im {
     DevBuf<float> d_pi_f, d_Tf, d_alpha, d_ends_f, d_used_f;
     DevBuf<double> d_E, d_dpow, d_PinvT, d_PT, d_TdT, d_Td, d_Prm, d_Pinvrm, d_dsc, d_dun, d_g_scale,
         d_g_logscale, d_beta, d_cnorm, d_logc, d_ends_b, d_used_b, d_llpart, d_loglik, d_w1, d_gpart, d_Xs, d_Ys,
-        d_part_e, d_part_1, d_red_e, d_red_1, d_red_g, d_Z, d_Y, d_xisum, d_gsum, d_gamma0, d_gamma_rows, d_Sq;
+        d_part_e, d_part_1, d_red_e, d_red_1, d_red_g, d_Z, d_Zpart, d_Y, d_xisum, d_gsum, d_gamma0, d_gamma_rows, d_Sq;
     // opt-in warm start: chunk-boundary vectors of the previous converged E-step (see smcpp_set_warm_start)
     bool warm_start = false, warm_valid = false;
     DevBuf<float> d_warm_f;
@@ -456,6 +457,7 @@ void smcpp_im::make_slabs() {
     gk_slab_off.assign((size_t)n_contigs * K + 1, 0);
     s1_slab_off.assign(n_contigs + 1, 0);
     ce_bucket_off.assign((size_t)n_contigs * Ke + 1, 0);
+    ce_row_off.assign((size_t)n_contigs * Ke + 1, 0);
     eb_slab_off.clear(); eb_gid.clear(); erow_slab.clear();
     int last_eig_key = -1;
     long long n1 = 0, ne = 0;
@@ -505,6 +507,7 @@ void smcpp_im::make_slabs() {
         // ---- eigen rows sorted by (eigen key, group) ----
         for (int e = 0; e < Ke; ++e) {
             ce_bucket_off[(size_t)c * Ke + e] = (int)eb_gid.size();
+            ce_row_off[(size_t)c * Ke + e] = (int)perme.size();
             for (int g = 0; g < G; ++g) {
                 if (groups[g].eig != e || by_grp[g].empty()) continue;
                 // the fused eigen kernel shares one LDS copy of (Pinv, P) among the 4 slabs of a workgroup: pad with
@@ -533,6 +536,7 @@ void smcpp_im::make_slabs() {
     gk_slab_off[(size_t)n_contigs * K] = (int)slabs_sc.size();
     s1_slab_off[n_contigs] = (int)slabs_rk.size();
     ce_bucket_off[(size_t)n_contigs * Ke] = (int)eb_gid.size();
+    ce_row_off[(size_t)n_contigs * Ke] = (int)perme.size();
     eb_slab_off.push_back((int)slabs_eg.size());
 }
 
@@ -1242,7 +1246,14 @@ void smcpp_im::run_stats() {
                                (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MMi, ZS);
     }
     if (Ke > 0) {
-        hipLaunchKernelGGL(k_fin_Z, dim3(nb2, n_contigs * Ke), dim3(256), 0, se, fa);
+        // slices of the groups of one (contig, key): enough blocks to fill the chip when there are many groups
+        int max_b = 0;
+        for (size_t ce = 0; ce + 1 < ce_bucket_off.size(); ++ce) max_b = std::max(max_b, ce_bucket_off[ce + 1] - ce_bucket_off[ce]);
+        const int nsl = std::max(1, std::min(std::min(256, max_b / 16), 4096 / std::max(1, nb2 * n_contigs * Ke)));
+        if (nsl > 1) { d_Zpart.alloc((size_t)nsl * n_contigs * Ke * Mp * Mp); fa.Zpart = d_Zpart.p; }
+        else fa.Zpart = nullptr;
+        hipLaunchKernelGGL(k_fin_Z, dim3(nb2, n_contigs * Ke, nsl), dim3(256), 0, se, fa);
+        if (nsl > 1) hipLaunchKernelGGL(k_fin_Zsum, dim3(nb2, n_contigs * Ke), dim3(256), 0, se, fa, nsl, n_contigs * Ke);
         hipLaunchKernelGGL(k_fin_Y, dim3(nb2, n_contigs * Ke), dim3(256), 0, se, fa);
     }
     if (split_streams) {
@@ -1260,8 +1271,27 @@ void smcpp_im::run_stats() {
         ga.slabs = d_slabs_eg.p; ga.g_eig = d_g_eig.p; ga.g_span = d_g_span.p; ga.dun = d_dun.p;
         ga.Prm = d_Prm.p; ga.Pinvrm = d_Pinvrm.p; ga.PinvT = d_PinvT.p; ga.Sq = d_Sq.p;
         ga.alpha = d_alpha.p; ga.beta = d_beta.p; ga.gamma_rows = d_gamma_rows.p;
-        const size_t shm = (size_t)(3 * Mp + 256) * sizeof(double);
-        hipLaunchKernelGGL(k_gamma_rows_eig, dim3((unsigned)n_e_rows), dim3(256), shm, s, ga);
+        static const bool scalar_rows = getenv("SMCPP_GAMMA_ROWS_SCALAR") != nullptr;
+        if (NT <= 4 && !scalar_rows) {
+            // matrix-core version: one launch per (contig, eigen key) so that a workgroup shares one LDS copy of P, Pinv
+            const size_t shm2 = (size_t)(2 * Mp * (Mp + 1) + 16 * Mp) * sizeof(double);
+            for (int ce = 0; ce < n_contigs * Ke; ++ce) {
+                const int q0 = ce_row_off[ce], q1 = ce_row_off[ce + 1];
+                if (q1 <= q0) continue;
+                const int rpw = std::max(1, std::min(16, (q1 - q0 + 4095) / 4096));      // rows per wavefront
+                const int nblk = ceil_div(q1 - q0, 4 * rpw);
+                switch (NT) {
+#define G_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_gamma_rows_mfma<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
+                        hipLaunchKernelGGL(k_gamma_rows_mfma<x>, dim3(nblk), dim3(256), shm2, s, ga, q0, q1, ce % Ke, rpw); } break;
+                    G_(1) G_(2) G_(3)
+                    default: G_(4)
+#undef G_
+                }
+            }
+        } else {
+            const size_t shm = (size_t)(3 * Mp + 256) * sizeof(double);
+            hipLaunchKernelGGL(k_gamma_rows_eig, dim3((unsigned)n_e_rows), dim3(256), shm, s, ga);
+        }
     }
     HIPCHK(hipGetLastError());
     if (h_ll_cap < n_contigs) {

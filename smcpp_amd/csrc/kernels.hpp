@@ -2165,6 +2165,7 @@ struct FinArgs {
     const double *beta;
     const long long *contig_base;
     double *Z;                // [n_contigs*Ke][Mp][Mp]
+    double *Zpart;            // [slices][n_contigs*Ke][Mp][Mp] partial sums of k_fin_Z over slices of the groups
     double *Y;                // [n_contigs*Ke][Mp][Mp]
     double *xisum;            // [n_contigs][Mp][Mp]
     double *gsum;             // [n_contigs][K][Mp]
@@ -2183,6 +2184,9 @@ __device__ __forceinline__ double span_q_elem(const double *dsc, int a, int b, i
 }
 
 // Z[(contig,e)][j][k] = sum over groups g of key e:  S_g[j][k] * Acc[contig][g][j][k]
+// blockIdx.z = slice of the (contig, key)'s groups: binned data have a few dozen groups (one slice), un-binned data
+// (posterior decoding) tens of thousands - one thread per matrix element looping over all of them serially left the
+// chip idle for 60 ms.  Slices are contiguous ranges summed in order (k_fin_Zsum), so the result is deterministic.
 __global__ __launch_bounds__(256) void k_fin_Z(FinArgs a) {
     const int ce = blockIdx.y;                    // contig * Ke + e
     const int e = ce % a.Ke;
@@ -2190,16 +2194,30 @@ __global__ __launch_bounds__(256) void k_fin_Z(FinArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= Mp * Mp) return;
     const int j = idx / Mp, k = idx % Mp;
+    const int nsl = gridDim.z, sl = blockIdx.z;
     double z = 0.0;
     if (j < M && k < M) {
         const double *dsc = a.dsc + (size_t)e * Mp;
-        for (int b = a.ce_bucket_off[ce]; b < a.ce_bucket_off[ce + 1]; ++b) {
+        const int b0 = a.ce_bucket_off[ce], b1 = a.ce_bucket_off[ce + 1];
+        const int per = (b1 - b0 + nsl - 1) / nsl;
+        const int lo = b0 + sl * per, hi = min(b1, lo + per);
+        for (int b = lo; b < hi; ++b) {
             double acc = 0.0;
-            for (int z = 0; z < a.ZS; ++z) acc += a.red_e[((size_t)b * a.ZS + z) * Mp * Mp + idx];
+            for (int zz = 0; zz < a.ZS; ++zz) acc += a.red_e[((size_t)b * a.ZS + zz) * Mp * Mp + idx];
             z += span_q_elem(dsc, j, k, a.g_span[a.eb_gid[b]]) * acc;
         }
     }
-    a.Z[(size_t)ce * Mp * Mp + idx] = z;
+    double *out = nsl == 1 ? a.Z : a.Zpart;
+    out[((size_t)sl * gridDim.y + ce) * Mp * Mp + idx] = z;
+}
+__global__ __launch_bounds__(256) void k_fin_Zsum(FinArgs a, int nsl, int nce) {
+    const int ce = blockIdx.y;
+    const int MM = a.Mp * a.Mp;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= MM) return;
+    double z = 0.0;
+    for (int sl = 0; sl < nsl; ++sl) z += a.Zpart[((size_t)sl * nce + ce) * MM + idx];
+    a.Z[(size_t)ce * MM + idx] = z;
 }
 
 // Y = Z * Pinv
@@ -2373,6 +2391,111 @@ __global__ __launch_bounds__(256) void k_gamma_rows_eig(GammaRowArgs a) {
     const double sum = red[0];
     for (int i = tid; i < Mp; i += 256)
         a.gamma_rows[row * Mp + i] = (i < M) ? (double)span * g[i] / sum : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gamma rows of eigen rows on the matrix cores (M <= 64).  Per row the reference evaluates (hmm.cpp:113-121)
+//     g = diag( P D (u w^T o S) P^-1 ),   gamma_row = span |g| / sum |g|,     u = P^-1 alpha_{l-1}, w = P^T beta_l,
+// i.e. 2 M^3 flops: G = P Z with Z[a][b] = (d_a u_a) S_ab w_b, then g_i = sum_b G_ib Pinv_bi.  k_gamma_rows_eig did this
+// with one workgroup of scalar FMAs per row (0.35 TFLOP/s); here one WAVEFRONT owns a row and the M x M x M product runs
+// as v_mfma_f64_16x16x4_f64 tiles: A = P from an LDS copy shared by the 4 wavefronts of the workgroup (one launch per
+// (contig, eigen key), so a workgroup never mixes keys), B = Z built on the fly from the group's span-Q table (read
+// once per row, coalesced 128-byte pieces) and the row's u, w; the D tiles are folded into g against Pinv (LDS) and
+// reduced over the 16 lanes of a DPP row.  A wavefront walks over ROWS rows so the LDS staging is amortised.
+// MFMA operand map (guide §3): A[m = l&15][k = l>>4], B[k = l>>4][n = l&15], D[row = (l>>4) + 4 reg][col = l&15].
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_gamma_rows_mfma(GammaRowArgs a, int p0, int p1, int es, int rows_per_wave) {
+    constexpr int MT = 16 * NT, LD = MT + 1;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *sP = sm;                         // [MT][LD]  P row-major
+    double *sPinv = sm + MT * LD;            // [MT][LD]  Pinv row-major
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *su = sPinv + MT * LD + wv * 4 * MT;   // per wavefront: u [MT], w [MT], g [MT], x [MT] (alpha / beta staging)
+    double *sw = su + MT, *sg = sw + MT, *sx = sg + MT;
+    const int Mp = a.Mp, M = a.M;
+    {
+        const double *Prm = a.Prm + (size_t)es * Mp * Mp, *Pinvrm = a.Pinvrm + (size_t)es * Mp * Mp;
+        for (int idx = tid; idx < MT * MT; idx += 256) {
+            const int r = idx / MT, c = idx % MT;
+            sP[r * LD + c] = Prm[(size_t)r * Mp + c];
+            sPinv[r * LD + c] = Pinvrm[(size_t)r * Mp + c];
+        }
+    }
+    __syncthreads();
+    const double *dun = a.dun + (size_t)es * Mp;
+    const int kq = lane >> 4, n = lane & 15;
+    const int pbeg = p0 + (blockIdx.x * 4 + wv) * rows_per_wave;
+    const int pend = min(p1, pbeg + rows_per_wave);
+    for (int p = pbeg; p < pend; ++p) {
+        const Slab sl = a.slabs[a.row_slab[p]];
+        const int gid = sl.aux;
+        const int span = a.g_span[gid];
+        const size_t row = (size_t)(sl.base + a.perm[p]);
+        const double *S = a.Sq + (size_t)gid * Mp * Mp;
+        // ---- u = d o (Pinv alpha_{l-1}),  w = P^T beta_l  (lane j = state j) ----
+        if (lane < MT) sx[lane] = (lane < M) ? (double)a.alpha[(row - 1) * Mp + lane] : 0.0;
+        wave_lds_fence();
+        double uu = 0.0;
+        if (lane < MT) {
+#pragma unroll 8
+            for (int k = 0; k < MT; ++k) uu = fma(sPinv[lane * LD + k], sx[k], uu);
+            uu *= (lane < M) ? dun[lane] : 0.0;
+        }
+        wave_lds_fence();
+        if (lane < MT) { su[lane] = uu; sx[lane] = (lane < M) ? a.beta[row * Mp + lane] : 0.0; }
+        wave_lds_fence();
+        double ww = 0.0;
+        if (lane < MT) {
+#pragma unroll 8
+            for (int k = 0; k < MT; ++k) ww = fma(sP[k * LD + lane], sx[k], ww);
+            sw[lane] = ww;
+        }
+        wave_lds_fence();
+        // ---- G = P Z tile by tile, folded into g ----
+        double gacc[NT][4];
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gacc[it][r] = 0.0;
+#pragma unroll 1
+        for (int bt = 0; bt < NT; ++bt) {
+            const int bb = bt * 16 + n;
+            const double wb = sw[bb];
+            f64x4 D[NT];
+#pragma unroll
+            for (int it = 0; it < NT; ++it) D[it] = (f64x4){0, 0, 0, 0};
+            // B[k][n] = u[a0+k] S[a0+k][bb] w[bb]; the next k-step's S element is loaded while this one is multiplied
+            double s_nxt = S[(size_t)kq * Mp + bb];
+#pragma unroll 4
+            for (int a0 = 0; a0 < MT; a0 += 4) {
+                const int aa = a0 + kq;
+                const double s_cur = s_nxt;
+                s_nxt = S[(size_t)min(aa + 4, MT - 1) * Mp + bb];
+                const double bf = su[aa] * s_cur * wb;
+#pragma unroll
+                for (int it = 0; it < NT; ++it)
+                    D[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(sP[(it * 16 + n) * LD + aa], bf, D[it], 0, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gacc[it][r] = fma(D[it][r], sPinv[bb * LD + it * 16 + kq + 4 * r], gacc[it][r]);
+        }
+        // g_i = sum over the 16 columns (lanes of one DPP row): i = 16 it + kq + 4 r
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double gi = row16_sum(gacc[it][r]);
+                if (n == 0) sg[it * 16 + kq + 4 * r] = fabs(gi);
+            }
+        wave_lds_fence();
+        const double mine = (lane < M) ? sg[lane] : 0.0;
+        const double tot = wave_sum(mine);
+        if (lane < Mp) a.gamma_rows[row * Mp + lane] = (lane < M) ? (double)span * mine / tot : 0.0;
+        wave_lds_fence();
+    }
 }
 
 // argmax over states per row (posterior decoding indices)

@@ -29,8 +29,10 @@ def balance_hidden_states(model, M):
 
 def posterior(model, contigs, M, n, theta, rho, alpha=1.0, polarization_error=0.5, hidden_states=None, device=-1):
     """Posterior decoding of each contig.  Returns `(hidden_states, gammas, sites, paths)`:
-    `gammas[c]` is `[M, L+1]` with columns normalised to one (`posterior.py:102-106`), `sites[c]` the cumulative
-    positions of the rows, `paths[c]` the argmax state per column computed on the device.
+    `gammas[c]` is `[M, L+1]` with columns normalised to one (`posterior.py:102-106`), `sites[c]` the span column of the
+    rows handed to the manager (missing row included) exactly as the reference stores it under `<file>_sites`
+    (`posterior.py:109`: `obs[:, 0]`, one entry per row; cumulative positions are `np.cumsum` of it), `paths[c]` the
+    argmax state per column computed on the device.
     A missing row is prepended to every contig as the reference does (`posterior.py:83`)."""
     hs = balance_hidden_states(model, M) if hidden_states is None else np.asarray(hidden_states, dtype=float)
     obs = []
@@ -51,7 +53,7 @@ def posterior(model, contigs, M, n, theta, rho, alpha=1.0, polarization_error=0.
     for c, g in enumerate(im.gammas):
         g = g / g.sum(axis=0, keepdims=True)
         gammas.append(g)
-        sites.append(np.concatenate(([0], np.cumsum(obs[c][:, 0]))))
+        sites.append(obs[c][:, 0].copy())
         paths.append(im.gamma_argmax(c))
     return hs, gammas, sites, paths
 

@@ -8,6 +8,7 @@
 //   * clamps are integer maxima (the operands are non-negative floats or tiny negative rounding residues, for which
 //     the signed-integer order gives the same result): fmaxf costs a v_max canonicalisation per operand in IEEE mode;
 //   * quarter sums are trees, the fp64 dot products run on four accumulators;
+//   * the two most frequent eigen keys are register-resident (HOT2 instantiations exist only when there is a second key);
 //   * backward chain: the emission factor of a span-1 row is applied by the PRODUCER of the exchanged vector (one
 //     multiply on 16 lanes instead of 16 multiplies and 8 LDS reads on every lane), and the running scale is the sum
 //     of the vector exchanged ONE ROW EARLIER - beta enters every statistic only through scale-free ratios
@@ -22,7 +23,7 @@ __device__ __forceinline__ float imax_f(float a, float b) {
     return __builtin_bit_cast(float, max(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b)));
 }
 
-template <int MT, bool TAB, bool RERUN>
+template <int MT, bool TAB, bool RERUN, bool HOT2>
 __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) {
     constexpr int NW = MT / 16, KQ = MT / 4, Mp = MT, UP = KQ + 2, Q4 = KQ / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
     // operand quarters in registers: float T and the eigenvector matrices of the two eigen keys with the most span > 1
     // rows (binned data: the monomorphic and the heterozygous reduced key); other eigen keys read theirs from L2
     float tf[KQ];
-    double pinv[KQ], pt[KQ], pinv2[KQ], pt2[KQ];
+    double pinv[KQ], pt[KQ], pinv2[HOT2 ? KQ : 1], pt2[HOT2 ? KQ : 1];
     {
         const size_t ho = (size_t)(a.hot < 0 ? 0 : a.hot) * Mp * Mp, ho2 = (size_t)(a.hot2 < 0 ? 0 : a.hot2) * Mp * Mp;
 #pragma unroll
@@ -90,11 +91,13 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
             tf[t] = a.Tf[(size_t)k * Mp + i];
             pinv[t] = (a.hot >= 0) ? a.PinvT[ho + (size_t)k * Mp + i] : 0.0;
             pt[t] = (a.hot >= 0) ? a.PT[ho + (size_t)k * Mp + i] : 0.0;
-            pinv2[t] = (a.hot2 >= 0) ? a.PinvT[ho2 + (size_t)k * Mp + i] : 0.0;
-            pt2[t] = (a.hot2 >= 0) ? a.PT[ho2 + (size_t)k * Mp + i] : 0.0;
+            if (HOT2) {
+                pinv2[HOT2 ? t : 0] = (a.hot2 >= 0) ? a.PinvT[ho2 + (size_t)k * Mp + i] : 0.0;
+                pt2[HOT2 ? t : 0] = (a.hot2 >= 0) ? a.PT[ho2 + (size_t)k * Mp + i] : 0.0;
+            }
         }
 #pragma unroll
-        for (int t = 0; t < KQ; ++t) { pin_reg(tf[t]); pin_reg(pinv[t]); pin_reg(pt[t]); pin_reg(pinv2[t]); pin_reg(pt2[t]); }
+        for (int t = 0; t < KQ; ++t) { pin_reg(tf[t]); pin_reg(pinv[t]); pin_reg(pt[t]); if (HOT2) { pin_reg(pinv2[HOT2 ? t : 0]); pin_reg(pt2[HOT2 ? t : 0]); } }
     }
     // descriptors of the chunk's rows, staged 64 at a time (batch b in sdesc[b & 1]); the array is padded, reads past the
     // chunk return descriptors of rows this workgroup never processes
@@ -197,14 +200,14 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
                     a3 = fma(pinv[4 * t + 3], (double)xh[t].y, a3);
                 }
                 u = quad_sum_d((a0 + a1) + (a2 + a3));
-            } else if (es == a.hot2) {
+            } else if (HOT2 && es == a.hot2) {
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
                 for (int t = 0; t < Q4; ++t) {
-                    a0 = fma(pinv2[4 * t], (double)xl[t].x, a0);
-                    a1 = fma(pinv2[4 * t + 1], (double)xl[t].y, a1);
-                    a2 = fma(pinv2[4 * t + 2], (double)xh[t].x, a2);
-                    a3 = fma(pinv2[4 * t + 3], (double)xh[t].y, a3);
+                    a0 = fma(pinv2[HOT2 ? (4 * t) : 0], (double)xl[t].x, a0);
+                    a1 = fma(pinv2[HOT2 ? (4 * t + 1) : 0], (double)xl[t].y, a1);
+                    a2 = fma(pinv2[HOT2 ? (4 * t + 2) : 0], (double)xh[t].x, a2);
+                    a3 = fma(pinv2[HOT2 ? (4 * t + 3) : 0], (double)xh[t].y, a3);
                 }
                 u = quad_sum_d((a0 + a1) + (a2 + a3));
             } else {
@@ -230,16 +233,16 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
                     a3 = fma(pt[t + 3], x1.y, a3);
                 }
                 av = quad_sum_d((a0 + a1) + (a2 + a3));
-            } else if (es == a.hot2) {
+            } else if (HOT2 && es == a.hot2) {
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
                 for (int t = 0; t < KQ; t += 4) {
                     const double2 x0 = *reinterpret_cast<const double2 *>(uin + t);
                     const double2 x1 = *reinterpret_cast<const double2 *>(uin + t + 2);
-                    a0 = fma(pt2[t], x0.x, a0);
-                    a1 = fma(pt2[t + 1], x0.y, a1);
-                    a2 = fma(pt2[t + 2], x1.x, a2);
-                    a3 = fma(pt2[t + 3], x1.y, a3);
+                    a0 = fma(pt2[HOT2 ? t : 0], x0.x, a0);
+                    a1 = fma(pt2[HOT2 ? (t + 1) : 0], x0.y, a1);
+                    a2 = fma(pt2[HOT2 ? (t + 2) : 0], x1.x, a2);
+                    a3 = fma(pt2[HOT2 ? (t + 3) : 0], x1.y, a3);
                 }
                 av = quad_sum_d((a0 + a1) + (a2 + a3));
             } else {
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
     }
 }
 
-template <int MT, bool TAB, bool RERUN>
+template <int MT, bool TAB, bool RERUN, bool HOT2>
 __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) {
     constexpr int NW = MT / 16, KQ = MT / 4, Mp = MT, UP = KQ + 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
     }
     if (owner) a.used_b[(size_t)c * Mp + i] = b;
     if (tid == 0) a.changed[pass] = 1;
-    double tdt[KQ], prm[KQ], pinvrm[KQ], prm2[KQ], pinvrm2[KQ];
+    double tdt[KQ], prm[KQ], pinvrm[KQ], prm2[HOT2 ? KQ : 1], pinvrm2[HOT2 ? KQ : 1];
     {
         const size_t ho = (size_t)(a.hot < 0 ? 0 : a.hot) * Mp * Mp, ho2 = (size_t)(a.hot2 < 0 ? 0 : a.hot2) * Mp * Mp;
 #pragma unroll
@@ -339,11 +342,13 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
             tdt[t] = a.TdT[(size_t)k * Mp + i];
             prm[t] = (a.hot >= 0) ? a.Prm[ho + (size_t)k * Mp + i] : 0.0;
             pinvrm[t] = (a.hot >= 0) ? a.Pinvrm[ho + (size_t)k * Mp + i] : 0.0;
-            prm2[t] = (a.hot2 >= 0) ? a.Prm[ho2 + (size_t)k * Mp + i] : 0.0;
-            pinvrm2[t] = (a.hot2 >= 0) ? a.Pinvrm[ho2 + (size_t)k * Mp + i] : 0.0;
+            if (HOT2) {
+                prm2[HOT2 ? t : 0] = (a.hot2 >= 0) ? a.Prm[ho2 + (size_t)k * Mp + i] : 0.0;
+                pinvrm2[HOT2 ? t : 0] = (a.hot2 >= 0) ? a.Pinvrm[ho2 + (size_t)k * Mp + i] : 0.0;
+            }
         }
 #pragma unroll
-        for (int t = 0; t < KQ; ++t) { pin_reg(tdt[t]); pin_reg(prm[t]); pin_reg(pinvrm[t]); pin_reg(prm2[t]); pin_reg(pinvrm2[t]); }
+        for (int t = 0; t < KQ; ++t) { pin_reg(tdt[t]); pin_reg(prm[t]); pin_reg(pinvrm[t]); if (HOT2) { pin_reg(prm2[HOT2 ? t : 0]); pin_reg(pinvrm2[HOT2 ? t : 0]); } }
     }
     // descriptors in processing order: iteration j handles row ell = r1 - j; the array is padded in front as well
     const int2 *rd = a.rowdesc + ch.base + ch.r1;
@@ -431,14 +436,14 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
                     a3 = fma(prm[t + 3], x[t + 3], a3);
                 }
                 wv = quad_sum_d((a0 + a1) + (a2 + a3));
-            } else if (es == a.hot2) {
+            } else if (HOT2 && es == a.hot2) {
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
                 for (int t = 0; t < KQ; t += 4) {
-                    a0 = fma(prm2[t], x[t], a0);
-                    a1 = fma(prm2[t + 1], x[t + 1], a1);
-                    a2 = fma(prm2[t + 2], x[t + 2], a2);
-                    a3 = fma(prm2[t + 3], x[t + 3], a3);
+                    a0 = fma(prm2[HOT2 ? t : 0], x[t], a0);
+                    a1 = fma(prm2[HOT2 ? (t + 1) : 0], x[t + 1], a1);
+                    a2 = fma(prm2[HOT2 ? (t + 2) : 0], x[t + 2], a2);
+                    a3 = fma(prm2[HOT2 ? (t + 3) : 0], x[t + 3], a3);
                 }
                 wv = quad_sum_d((a0 + a1) + (a2 + a3));
             } else {
@@ -463,16 +468,16 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
                     a3 = fma(pinvrm[t + 3], v1.y, a3);
                 }
                 bn = quad_sum_d((a0 + a1) + (a2 + a3));
-            } else if (es == a.hot2) {
+            } else if (HOT2 && es == a.hot2) {
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
                 for (int t = 0; t < KQ; t += 4) {
                     const double2 v0 = *reinterpret_cast<const double2 *>(uin + t);
                     const double2 v1 = *reinterpret_cast<const double2 *>(uin + t + 2);
-                    a0 = fma(pinvrm2[t], v0.x, a0);
-                    a1 = fma(pinvrm2[t + 1], v0.y, a1);
-                    a2 = fma(pinvrm2[t + 2], v1.x, a2);
-                    a3 = fma(pinvrm2[t + 3], v1.y, a3);
+                    a0 = fma(pinvrm2[HOT2 ? t : 0], v0.x, a0);
+                    a1 = fma(pinvrm2[HOT2 ? (t + 1) : 0], v0.y, a1);
+                    a2 = fma(pinvrm2[HOT2 ? (t + 2) : 0], v1.x, a2);
+                    a3 = fma(pinvrm2[HOT2 ? (t + 3) : 0], v1.y, a3);
                 }
                 bn = quad_sum_d((a0 + a1) + (a2 + a3));
             } else {

@@ -922,17 +922,24 @@ static void launch_chain_lds(bool fwd, const ChainArgs &a, const LdsArgs &la, in
     }
 }
 // generation 2 of the cooperative chains (chains2.hpp): pass 0 and the re-run passes are separate instantiations
-template <int MT_, bool TAB_, bool RERUN_>
-static void launch_chain_coop2_t(bool fwd, const ChainArgs &a, const CoopArgs &ca, size_t shm, hipStream_t s) {
+template <int MT_, bool TAB_, bool RERUN_, bool HOT2_>
+static void launch_chain_coop2_tt(bool fwd, const ChainArgs &a, const CoopArgs &ca, size_t shm, hipStream_t s) {
     if (fwd) {
         static bool once = false;
-        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_fwd_coop2<MT_, TAB_, RERUN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
-        hipLaunchKernelGGL((k_fwd_coop2<MT_, TAB_, RERUN_>), dim3(a.nchunks), dim3(MT_ * 4), shm, s, a, ca);
+        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_fwd_coop2<MT_, TAB_, RERUN_, HOT2_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+        hipLaunchKernelGGL((k_fwd_coop2<MT_, TAB_, RERUN_, HOT2_>), dim3(a.nchunks), dim3(MT_ * 4), shm, s, a, ca);
     } else {
         static bool once = false;
-        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_bwd_coop2<MT_, TAB_, RERUN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
-        hipLaunchKernelGGL((k_bwd_coop2<MT_, TAB_, RERUN_>), dim3(a.nchunks), dim3(MT_ * 4), shm, s, a, ca);
+        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_bwd_coop2<MT_, TAB_, RERUN_, HOT2_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+        hipLaunchKernelGGL((k_bwd_coop2<MT_, TAB_, RERUN_, HOT2_>), dim3(a.nchunks), dim3(MT_ * 4), shm, s, a, ca);
     }
+}
+template <int MT_, bool TAB_, bool RERUN_>
+static void launch_chain_coop2_t(bool fwd, const ChainArgs &a, const CoopArgs &ca, size_t shm, hipStream_t s) {
+    // without a second eigen key the 64 VGPRs of its operands are not allocated (measured on the whole genome: keeping
+    // it beats the extra occupancy, 33.2 vs 36.6 ms - the L2 path of a non-resident key costs more than a lost wavefront)
+    if (a.hot2 >= 0) launch_chain_coop2_tt<MT_, TAB_, RERUN_, true>(fwd, a, ca, shm, s);
+    else launch_chain_coop2_tt<MT_, TAB_, RERUN_, false>(fwd, a, ca, shm, s);
 }
 static int coop_generation() {
     static const int gen = [] { const char *e = getenv("SMCPP_COOP_GEN"); return (e && atoi(e) == 1) ? 1 : 2; }();
@@ -1249,7 +1256,7 @@ void smcpp_im::run_stats() {
         // slices of the groups of one (contig, key): enough blocks to fill the chip when there are many groups
         int max_b = 0;
         for (size_t ce = 0; ce + 1 < ce_bucket_off.size(); ++ce) max_b = std::max(max_b, ce_bucket_off[ce + 1] - ce_bucket_off[ce]);
-        const int nsl = std::max(1, std::min(std::min(256, max_b / 16), 4096 / std::max(1, nb2 * n_contigs * Ke)));
+        const int nsl = std::max(1, std::min(std::min(256, max_b), 2048 / std::max(1, nb2 * n_contigs * Ke)));
         if (nsl > 1) { d_Zpart.alloc((size_t)nsl * n_contigs * Ke * Mp * Mp); fa.Zpart = d_Zpart.p; }
         else fa.Zpart = nullptr;
         hipLaunchKernelGGL(k_fin_Z, dim3(nb2, n_contigs * Ke, nsl), dim3(256), 0, se, fa);

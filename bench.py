@@ -158,7 +158,7 @@ def main():
     from smcpp_amd.model import PiecewiseModel, TwoPopulationModel
     # torch.distributed.run exports OMP_NUM_THREADS=1 to every rank; the engine's host phase (conditioned SFS per
     # hidden state, one eigensystem per eigen key) wants a handful of threads — the reference's --cores / set_num_threads
-    host_threads = max(1, min(8, (os.cpu_count() or 8) // max(1, world)))
+    host_threads = max(1, min(int(os.environ.get("SMCPP_BENCH_THREADS", "8")), (os.cpu_count() or 8) // max(1, world)))
     _smcpp.set_num_threads(host_threads)
     M, n, fixture, desc = WORKLOADS[args.workload]
     length_bp = int(args.length_mbp * 1e6)
@@ -299,9 +299,11 @@ def main():
     traffic = None
     try:
         if args.workload == "headline" and args.length_mbp == 100.0 and world == 1:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic_pmc.json")))
-            k = [v for name, v in prof["kernels"].items() if kname in name][0]
-            traffic = float(k["bytes_per_step"])
+            import glob
+            pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_hbm_traffic_pmc.json")))[-1]
+            prof = json.load(open(pf))
+            # pass 0 and the re-run passes are separate instantiations of the kernel: per-step bytes of all of them
+            traffic = float(sum(v["bytes_per_step"] for name, v in prof["kernels"].items() if kname in name))
     except Exception:  # noqa: BLE001
         traffic = None
     F_alg, B_alg = eval_work(contigs, M)

@@ -160,6 +160,8 @@ struct smcpp_im {
     std::vector<int> eig_kid;              // [Ke]
     std::vector<int> eig_of_key;           // [K]
     std::vector<unsigned char> present;    // [n_contigs][K] key occurs in contig
+    std::vector<double> span_sum;          // [n_contigs][K] positions covered by the key in the contig
+    std::vector<double> pi_default;        // [M] initial distribution of the constant-size default model (defaultEta)
     std::vector<unsigned char> key_nbpos;  // [K] key.nb() > 0
     std::vector<Chunk> chunks;
     int max_chunks_per_contig = 1;
@@ -333,6 +335,7 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
     rowinfo.assign((size_t)total_rows, RowInfo{0, -1});
     std::vector<int> span_of((size_t)total_rows, 1);
     present.assign((size_t)n_contigs * K, 0);
+    span_sum.assign((size_t)n_contigs * K, 0.0);
     std::map<std::pair<int, int>, int> gmap;   // (kid, span) -> gid
 #pragma omp parallel for schedule(dynamic)
     for (int c = 0; c < n_contigs; ++c) {
@@ -352,6 +355,7 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
             rowinfo[g].kid = id;
             span_of[g] = r[0];
             present[(size_t)c * K + id] = 1;
+            span_sum[(size_t)c * K + id] += (double)r[0];
         }
     }
     for (int c = 0; c < n_contigs; ++c)
@@ -392,6 +396,18 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
     make_chunks();
     make_slabs();
     alloc_device();
+    // pi of defaultEta (a = s = {1}: R(t) = t), inference_manager.cpp:12-19,43,56-69: what a fresh HMM's statistics hold
+    pi_default.assign(M, 0.0);
+    {
+        double sm = 0.0;
+        for (int m = 0; m < M; ++m) {
+            double v = std::exp(-hs[m]) - ((m + 1 < M) ? std::exp(-hs[m + 1]) : 0.0);
+            if (v < 1e-20) v = 1e-20;
+            pi_default[m] = v;
+            sm += v;
+        }
+        for (double &v : pi_default) v /= sm;
+    }
     // defaults after construction (_smcpp.pyx:318-320)
     alpha = 1.0; theta = 1e-4; rho = 1e-4;
     loglik.assign(n_contigs, 0.0);
@@ -1356,8 +1372,21 @@ void smcpp_im::estep() {
 }
 
 void smcpp_im::fetch_stats() {
-    if (!estep_done) throw std::runtime_error("no E-step has been run on this manager yet");
     if (stats_on_host) return;
+    if (!estep_done) {
+        // the statistics of a freshly constructed HMM (hmm.cpp:8-29): xisum = 0, gamma = 0 and per key the positions it
+        // covers weighted by the default model's initial distribution - what Q() sees before the first E-step (the
+        // reference derives its regularisation weight from exactly that value, smcpp/analysis/analysis.py:120-125)
+        h_xisum.assign((size_t)n_contigs * M * M, 0.0);
+        h_gamma0.assign((size_t)n_contigs * M, 0.0);
+        h_gsum.assign((size_t)n_contigs * K * M, 0.0);
+        for (int c = 0; c < n_contigs; ++c)
+            for (int k = 0; k < K; ++k)
+                for (int i = 0; i < M; ++i)
+                    h_gsum[((size_t)c * K + k) * M + i] = span_sum[(size_t)c * K + k] * pi_default[i];
+        stats_on_host = true;
+        return;
+    }
     HIPCHK(hipSetDevice(device));
     std::vector<double> x((size_t)n_contigs * Mp * Mp), g((size_t)n_contigs * K * Mp), g0((size_t)n_contigs * Mp);
     HIPCHK(hipMemcpy(x.data(), d_xisum.p, x.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1509,8 +1538,7 @@ int smcpp_estep(smcpp_im *im, int fb_only) {
 
 int smcpp_loglik(smcpp_im *im, double *out) {
     API_BEGIN
-    if (!im->estep_done) throw std::runtime_error("no E-step has been run on this manager yet");
-    std::memcpy(out, im->loglik.data(), sizeof(double) * im->n_contigs);
+    std::memcpy(out, im->loglik.data(), sizeof(double) * im->n_contigs);    // 0 before the first E-step (hmm.cpp:11: ll(0.))
     API_END
 }
 
@@ -1633,6 +1661,7 @@ int smcpp_set_hidden_states(smcpp_im *im, int n_hs, const double *hs) {
     API_BEGIN
     if (n_hs != (int)im->hs.size()) throw std::runtime_error("hidden states must be same size");
     im->hs.assign(hs, hs + n_hs);
+    if (!im->estep_done) im->stats_on_host = false;
     im->dirty = true;
     im->params_fresh = false;
     if (im->have_model) im->have_raw = false;
@@ -1796,7 +1825,7 @@ int smcpp_pack_stats(smcpp_im *im, double *buf, long *n_out, int dev) {
     const long n = 1 + M + (long)M * M + (long)Kg * M;
     if (n_out) *n_out = n;
     if (!buf) return 0;
-    if (!im->estep_done) throw std::runtime_error("no E-step has been run on this manager yet");
+    if (dev && !im->estep_done) throw std::runtime_error("no E-step has been run on this manager yet");
     if (dev) {
         // device path: one kernel writes the packed layout into the caller's device buffer (e.g. the tensor that is
         // all-reduced over RCCL) - no host round trip

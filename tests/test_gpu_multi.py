@@ -131,12 +131,20 @@ def test_gamma_getter_is_sized_from_the_last_estep():
     from smcpp_amd import _smcpp
     g = load_golden("G1_M16_n4")
     im = _smcpp.PyOnePopInferenceManager(4, [g["obs"]], g["hs"], ("p",), 0.5)
-    with pytest.raises(RuntimeError, match="no E-step"):
-        im.xisums
-    with pytest.raises(RuntimeError, match="no E-step"):
-        im.loglik()
+    # before the first E-step the getters return what a freshly constructed reference HMM holds (hmm.cpp:8-29): zeros,
+    # and per key the positions it covers weighted by the constant-size default model's initial distribution
+    assert np.all(im.xisums[0] == 0) and im.loglik() == 0.0 and np.all(im.gammas[0] == 0) and im.gammas[0].shape == (16, 1)
+    hs = g["hs"]
+    pi0 = np.exp(-hs[:-1]) - np.r_[np.exp(-hs[1:-1]), 0.0]
+    pi0 /= pi0.sum()
+    gs = im.gamma_sums[0]
+    for k, v in gs.items():
+        span = g["obs"][np.all(g["obs"][:, 1:] == np.array(k), axis=1), 0].sum()
+        np.testing.assert_allclose(v, span * pi0, rtol=1e-13)
     im.theta = float(g["theta"]); im.rho = float(g["rho"])
     im.set_raw(g["pi"], g["T"], g["keys"], g["E"])
+    q0 = np.array(im.Q(separate=True))
+    assert q0[0] == 0 and q0[3] == 0 and q0[1] < 0 and q0[2] < 0
     im.save_gamma = True
     im.E_step()
     full = im.gammas[0]

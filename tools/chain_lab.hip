@@ -322,7 +322,9 @@ static void run(const char *name, K kernel, int threads, const float *dT, const 
     printf("%-58s %8.1f ns/row  %8.1f counter ticks/row\n", name, 1e6 * ms / 5 / nrows, (double)cyc / nrows);
 }
 
-int main() {
+int lab_mfma();
+int main(int argc, char **argv) {
+    if (argc > 1 && argv[1][0] == 'm') return lab_mfma();
     const int nrows = 4000, blocks = 512;
     std::vector<float> T(MT * MT);
     std::vector<double> E(MT);
@@ -386,6 +388,144 @@ int main() {
             printf("mixed loop (45%% eigen rows), %s: %8.1f ns/row, %.1f ticks/row, %.3f ms per 920-row pass\n",
                    mode == 0 ? "with stores" : mode == 1 ? "no stores  " : "LDS-staged stores", 1e6 * ms / 10 / nr, (double)cyc / nr, ms / 10);
         }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MFMA lock-step probe (north_star's kernel form): 16 chains per workgroup advance together, the state is a 64 x 16
+// matrix X (one column per chain) and a row-step is  Y = T^T X  (span-1 chains),  U = Pinv X, V = P (d^s o U)  (eigen
+// chains) as v_mfma_f64_16x16x4_f64 tiles: wavefront w owns state tile w (the D layout of its 16 x 16 tile is also the B
+// layout the next step needs, but the other three tiles live in other wavefronts, so X goes through LDS once per
+// product).  All three products are computed for all 16 chains (the row types of neighbouring chains differ) and the
+// result is selected per chain.  Operand quarters (A fragments of T^T, Pinv, P: 16 k-steps each) stay in registers.
+// ---------------------------------------------------------------------------------------------------------------
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+
+template <int MODE>   // 0: all three products; 1: T product only (lower bound for an all-span-1 input)
+__global__ __launch_bounds__(256) void k_mfma_lock(const double *__restrict__ Tt, const double *__restrict__ Pinv,
+                                                    const double *__restrict__ Pt, const double *__restrict__ Etab,
+                                                    const double *__restrict__ Dtab, const int2 *__restrict__ desc, int K, int G,
+                                                    float *alpha, double *cnorm, int nrows, long long *cycles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *sE = reinterpret_cast<double *>(smem);          // [K][64]
+    double *sD = sE + K * MT;                                // [G][64]
+    double *Xs = sD + G * MT;                                // [2][64][16]
+    double *Us = Xs + 2 * MT * 16;                           // [64][16]
+    int2 *sdesc = reinterpret_cast<int2 *>(Us + MT * 16);    // [16 chains][64 rows]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = lane & 15, kk = lane >> 4;                 // chain (column), k within a 4-step / row group of the D tile
+    for (int x = tid; x < K * MT; x += 256) sE[x] = Etab[x];
+    for (int x = tid; x < G * MT; x += 256) sD[x] = Dtab[x];
+    // A fragments: A[m = lane & 15][k = lane >> 4] of the three operators restricted to output tile w
+    double at[16], ap[16], aq[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int k = 4 * t + kk, i = 16 * w + n;
+        at[t] = Tt[(size_t)k * MT + i];                      // (T^T)[i][k] = T[k][i]
+        ap[t] = Pinv[(size_t)i * MT + k];                    // Pinv[i][k]
+        aq[t] = Pt[(size_t)k * MT + i];                      // P[i][k] stored transposed
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { asm volatile("" : "+v"(at[t])); asm volatile("" : "+v"(ap[t])); asm volatile("" : "+v"(aq[t])); }
+    const int chain0 = blockIdx.x * 16;
+    // descriptors of 64 rows of each of the 16 chains
+    for (int x = tid; x < 16 * 64; x += 256) sdesc[x] = desc[(size_t)(chain0 + x / 64) * (nrows + 192) + (x % 64)];
+    for (int x = tid; x < MT * 16; x += 256) Xs[x] = 1.0 / MT;
+    __syncthreads();
+    const long long t0 = __builtin_readcyclecounter();
+    for (int j = 0; j < nrows; ++j) {
+        const int cur = j & 1, nxt = cur ^ 1;
+        if ((j & 63) == 0 && j > 0) {                                    // refill the descriptor window (synchronously)
+            __syncthreads();
+            for (int x = tid; x < 16 * 64; x += 256) sdesc[x] = desc[(size_t)(chain0 + x / 64) * (nrows + 192) + j + (x % 64)];
+            __syncthreads();
+        }
+        const int2 d = sdesc[n * 64 + (j & 63)];                         // this lane's chain
+        const bool eig = d.y >= 0;
+        // ---- B fragments of X (all 64 rows of column n over the 16 k-steps), column sum, clamp ----
+        const double *xin = Xs + cur * MT * 16;
+        double b[16];
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { b[t] = xin[(4 * t + kk) * 16 + n]; s += b[t]; }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const double inv = 1.0 / s, thr = 1e-10 * s;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) b[t] = fmax(b[t], thr);
+        f64x4_t Y = {0, 0, 0, 0}, U = {0, 0, 0, 0}, V = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            Y = __builtin_amdgcn_mfma_f64_16x16x4f64(at[t], b[t], Y, 0, 0, 0);
+            if (MODE == 0) U = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[t], b[t], U, 0, 0, 0);
+        }
+        // D layout: row = kk + 4 r of tile w, column n
+        double out[4];
+        if (MODE == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * w + kk + 4 * r;
+                Us[i * 16 + n] = U[r] * sD[(eig ? d.y : 0) * MT + i] * inv;
+            }
+            lds_barrier();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) V = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[t], Us[(4 * t + kk) * 16 + n], V, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * w + kk + 4 * r;
+            const double y1 = Y[r] * inv * sE[d.x * MT + i];
+            out[r] = (MODE == 0 && eig) ? V[r] : y1;
+            out[r] = (double)(float)out[r];
+            Xs[nxt * MT * 16 + i * 16 + n] = out[r];
+            alpha[((size_t)(chain0 + n) * nrows + j) * MT + i] = (float)(out[r] * inv);
+        }
+        if (w == 0 && kk == 0) cnorm[(size_t)(chain0 + n) * nrows + j] = s;
+        lds_barrier();
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    if (tid == 0 && blockIdx.x == 0) cycles[0] = t1 - t0;
+}
+
+int lab_mfma() {
+    const int K = 43, G = 54, nr = 1650, blocks = 256;            // 4096 chains of 1650 rows = the whole-genome workload
+    std::vector<double> Tt(MT * MT), Pinv(MT * MT), Pt(MT * MT), Et((size_t)K * MT), Dt((size_t)G * MT);
+    for (int k = 0; k < MT; ++k) for (int i = 0; i < MT; ++i) { Tt[k * MT + i] = (k == i ? 0.9 : 0.1 / 63); Pinv[k * MT + i] = (k == i ? 1.0 : 0.001); Pt[k * MT + i] = (k == i ? 1.0 : -0.001); }
+    for (auto &x : Et) x = 0.7; for (auto &x : Dt) x = 0.9;
+    std::vector<int2> desc((size_t)blocks * 16 * (nr + 192));
+    unsigned rs = 777;
+    for (size_t r = 0; r < desc.size(); ++r) {
+        rs = rs * 1664525u + 1013904223u;
+        const bool eig = (rs >> 8) % 100 < 45;
+        desc[r] = make_int2((int)((rs >> 16) % K), eig ? (int)((rs >> 20) % G) : -1);
+    }
+    double *dT, *dPi, *dPt, *dEt, *dDt, *dC; int2 *dD; float *dA; long long *dcyc;
+    CHK(hipMalloc(&dT, Tt.size() * 8)); CHK(hipMalloc(&dPi, Pinv.size() * 8)); CHK(hipMalloc(&dPt, Pt.size() * 8));
+    CHK(hipMalloc(&dEt, Et.size() * 8)); CHK(hipMalloc(&dDt, Dt.size() * 8)); CHK(hipMalloc(&dD, desc.size() * 8));
+    CHK(hipMalloc(&dA, (size_t)blocks * 16 * nr * MT * 4)); CHK(hipMalloc(&dC, (size_t)blocks * 16 * nr * 8)); CHK(hipMalloc(&dcyc, 8));
+    CHK(hipMemcpy(dT, Tt.data(), Tt.size() * 8, hipMemcpyHostToDevice)); CHK(hipMemcpy(dPi, Pinv.data(), Pinv.size() * 8, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(dPt, Pt.data(), Pt.size() * 8, hipMemcpyHostToDevice)); CHK(hipMemcpy(dEt, Et.data(), Et.size() * 8, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(dDt, Dt.data(), Dt.size() * 8, hipMemcpyHostToDevice)); CHK(hipMemcpy(dD, desc.data(), desc.size() * 8, hipMemcpyHostToDevice));
+    const size_t shm = (size_t)(K + G) * MT * 8 + 3 * MT * 16 * 8 + 16 * 64 * 8 + 64;
+    CHK(hipFuncSetAttribute((const void *)k_mfma_lock<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CHK(hipFuncSetAttribute((const void *)k_mfma_lock<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (int mode = 0; mode < 2; ++mode) {
+        hipEvent_t e0, e1;
+        CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+        auto launch = [&]() {
+            if (mode == 0) hipLaunchKernelGGL(k_mfma_lock<0>, dim3(blocks), dim3(256), shm, 0, dT, dPi, dPt, dEt, dDt, dD, K, G, dA, dC, nr, dcyc);
+            else hipLaunchKernelGGL(k_mfma_lock<1>, dim3(blocks), dim3(256), shm, 0, dT, dPi, dPt, dEt, dDt, dD, K, G, dA, dC, nr, dcyc);
+        };
+        launch(); CHK(hipDeviceSynchronize());
+        CHK(hipEventRecord(e0, 0));
+        for (int r = 0; r < 3; ++r) launch();
+        CHK(hipEventRecord(e1, 0)); CHK(hipDeviceSynchronize());
+        float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
+        long long cyc = 0; CHK(hipMemcpy(&cyc, dcyc, 8, hipMemcpyDeviceToHost));
+        printf("MFMA lock-step, 16 chains / workgroup, %s: %8.1f ns per step = %6.1f ns per chain-row, %.1f ticks/step; one pass over "
+               "%d chains x %d rows: %.3f ms\n", mode == 0 ? "T + Pinv + P products" : "T product only     ", 1e6 * ms / 3 / nr,
+               1e6 * ms / 3 / nr / 16, (double)cyc / nr, blocks * 16, nr, ms / 3);
     }
     return 0;
 }

@@ -23,7 +23,7 @@ __device__ __forceinline__ float imax_f(float a, float b) {
     return __builtin_bit_cast(float, max(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b)));
 }
 
-template <int MT, bool TAB, bool RERUN, bool HOT2>
+template <int MT, bool TAB, bool RERUN, bool HOT2, bool POWER = false>
 __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) {
     constexpr int NW = MT / 16, KQ = MT / 4, Mp = MT, UP = KQ + 2, Q4 = KQ / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
     int *mflag = sflag + 4;                                    // [4] per-wavefront "not merged yet" flags
     if (TAB) {
         lds_stage(sE, a.E, ca.K * MT * 8, tid, NW * 64);
-        if (ca.G > 0) lds_stage(sD, a.dpow, ca.G * MT * 8, tid, NW * 64);
+        if (!POWER && ca.G > 0) lds_stage(sD, a.dpow, ca.G * MT * 8, tid, NW * 64);
     }
     const Chunk ch = a.chunks[c];
     float *end_cur = a.ends_f + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
@@ -89,9 +89,9 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
         for (int t = 0; t < KQ; ++t) {
             const int k = kq * KQ + t;
             tf[t] = a.Tf[(size_t)k * Mp + i];
-            pinv[t] = (a.hot >= 0) ? a.PinvT[ho + (size_t)k * Mp + i] : 0.0;
-            pt[t] = (a.hot >= 0) ? a.PT[ho + (size_t)k * Mp + i] : 0.0;
-            if (HOT2) {
+            pinv[t] = (!POWER && a.hot >= 0) ? a.PinvT[ho + (size_t)k * Mp + i] : 0.0;
+            pt[t] = (!POWER && a.hot >= 0) ? a.PT[ho + (size_t)k * Mp + i] : 0.0;
+            if (HOT2 && !POWER) {
                 pinv2[HOT2 ? t : 0] = (a.hot2 >= 0) ? a.PinvT[ho2 + (size_t)k * Mp + i] : 0.0;
                 pt2[HOT2 ? t : 0] = (a.hot2 >= 0) ? a.PT[ho2 + (size_t)k * Mp + i] : 0.0;
             }
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
     int ge = __builtin_amdgcn_readfirstlane(d0.y);
     const int kid0 = __builtin_amdgcn_readfirstlane(d0.x);
     double e_cur = TAB ? sE[kid0 * MT + i] : a.E[(size_t)kid0 * Mp + i];
-    double dp_cur = (ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + i]) : 0.0;
+    double dp_cur = (!POWER && ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + i]) : 0.0;
     int2 d1 = sdesc[1];
     float v_prev = al;
     float *arow = a.alpha + (size_t)(ch.base + ch.r0) * Mp + i;        // row ell-1 of iteration j is arow + j * Mp
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
         const int ge_n = __builtin_amdgcn_readfirstlane(d1.y);
         const int gid_n = ge_n < 0 ? 0 : SMCPP_GID(ge_n);
         const double e_nxt = TAB ? sE[kid_n * MT + i] : a.E[(size_t)kid_n * Mp + i];
-        const double dp_nxt = TAB ? sD[gid_n * MT + i] : ((ge_n >= 0) ? a.dpow[(size_t)gid_n * Mp + i] : 0.0);
+        const double dp_nxt = POWER ? 0.0 : (TAB ? sD[gid_n * MT + i] : ((ge_n >= 0) ? a.dpow[(size_t)gid_n * Mp + i] : 0.0));
         const int2 d2 = sdesc[(((j + 2) >> 6) & 1) * 64 + ((j + 2) & 63)];
         // ---- incoming state: quarter of x, its sum (= normaliser of the previous row), clamp threshold ----
         const float *xin = xf + cur * MT + kq * KQ;
@@ -187,6 +187,22 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
             }
             const float y = quad_sum_f((acc01.x + acc01.y) + (acc23.x + acc23.y)) * inv;
             vout = (float)((double)y * e_cur);
+        } else if (POWER) {
+            // eigen-free pre-pass: alpha <- A_g alpha with A_g = (diag(e) T^T)^span built by k_group_powers
+            // (synchronous loads on purpose: a quarter prefetched one row ahead is a loop-carried load, for which the
+            // compiler waits with vmcnt(0) - i.e. for the alpha store of every row; measured 8 % slower)
+            const double *Aq = a.Ag + (size_t)SMCPP_GID(ge) * MT * MT + (size_t)i * MT + kq * KQ;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int t = 0; t < Q4; ++t) {
+                const double2 m01 = *reinterpret_cast<const double2 *>(Aq + 4 * t);
+                const double2 m23 = *reinterpret_cast<const double2 *>(Aq + 4 * t + 2);
+                a0 = fma(m01.x, (double)xl[t].x, a0);
+                a1 = fma(m01.y, (double)xl[t].y, a1);
+                a2 = fma(m23.x, (double)xh[t].x, a2);
+                a3 = fma(m23.y, (double)xh[t].y, a3);
+            }
+            vout = (float)(quad_sum_d((a0 + a1) + (a2 + a3)) * (double)inv);
         } else {
             const int es = SMCPP_ES(ge);
             double u;
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
     }
 }
 
-template <int MT, bool TAB, bool RERUN, bool HOT2>
+template <int MT, bool TAB, bool RERUN, bool HOT2, bool POWER = false>
 __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) {
     constexpr int NW = MT / 16, KQ = MT / 4, Mp = MT, UP = KQ + 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -299,7 +315,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
     int *mflag = sflag + 4;
     if (TAB) {
         lds_stage(sE, a.E, ca.K * MT * 8, tid, NW * 64);
-        if (ca.G > 0) lds_stage(sD, a.dpow, ca.G * MT * 8, tid, NW * 64);
+        if (!POWER && ca.G > 0) lds_stage(sD, a.dpow, ca.G * MT * 8, tid, NW * 64);
     }
     const Chunk ch = a.chunks[c];
     double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
@@ -340,9 +356,9 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
         for (int t = 0; t < KQ; ++t) {
             const int k = kq * KQ + t;
             tdt[t] = a.TdT[(size_t)k * Mp + i];
-            prm[t] = (a.hot >= 0) ? a.Prm[ho + (size_t)k * Mp + i] : 0.0;
-            pinvrm[t] = (a.hot >= 0) ? a.Pinvrm[ho + (size_t)k * Mp + i] : 0.0;
-            if (HOT2) {
+            prm[t] = (!POWER && a.hot >= 0) ? a.Prm[ho + (size_t)k * Mp + i] : 0.0;
+            pinvrm[t] = (!POWER && a.hot >= 0) ? a.Pinvrm[ho + (size_t)k * Mp + i] : 0.0;
+            if (HOT2 && !POWER) {
                 prm2[HOT2 ? t : 0] = (a.hot2 >= 0) ? a.Prm[ho2 + (size_t)k * Mp + i] : 0.0;
                 pinvrm2[HOT2 ? t : 0] = (a.hot2 >= 0) ? a.Pinvrm[ho2 + (size_t)k * Mp + i] : 0.0;
             }
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
     int2 d0 = sdesc[0];
     int ge = __builtin_amdgcn_readfirstlane(d0.y);
     const int kid0 = __builtin_amdgcn_readfirstlane(d0.x);
-    double dp_cur = (ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + i]) : 0.0;
+    double dp_cur = (!POWER && ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + i]) : 0.0;
     int2 d1 = sdesc[1];
     // the exchanged vector z: beta itself before an eigen row, e o beta before a span-1 row (hmm.cpp:139)
     {
@@ -389,7 +405,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
         const int ge_n = __builtin_amdgcn_readfirstlane(d1.y);
         const int gid_n = ge_n < 0 ? 0 : SMCPP_GID(ge_n);
         const double e_nxt = TAB ? sE[kid_n * MT + i] : a.E[(size_t)kid_n * Mp + i];
-        const double dp_nxt = TAB ? sD[gid_n * MT + i] : ((ge_n >= 0) ? a.dpow[(size_t)gid_n * Mp + i] : 0.0);
+        const double dp_nxt = POWER ? 0.0 : (TAB ? sD[gid_n * MT + i] : ((ge_n >= 0) ? a.dpow[(size_t)gid_n * Mp + i] : 0.0));
         const int2 d2 = sdesc[(((j + 2) >> 6) & 1) * 64 + ((j + 2) & 63)];
         // ---- incoming exchanged vector: this lane's quarter ----
         const double *xin = xb + cur * 4 * UP + kq * UP;
@@ -421,6 +437,20 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
                 a1 = fma(tdt[t + 1], x[t + 1], a1);
                 a2 = fma(tdt[t + 2], x[t + 2], a2);
                 a3 = fma(tdt[t + 3], x[t + 3], a3);
+            }
+            bn = quad_sum_d((a0 + a1) + (a2 + a3)) * inv_cur;
+        } else if (POWER) {
+            // eigen-free pre-pass: beta <- A_g^T beta
+            const double *Aq = a.AgT + (size_t)SMCPP_GID(ge) * MT * MT + (size_t)i * MT + kq * KQ;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int t = 0; t < KQ; t += 4) {
+                const double2 m01 = *reinterpret_cast<const double2 *>(Aq + t);
+                const double2 m23 = *reinterpret_cast<const double2 *>(Aq + t + 2);
+                a0 = fma(m01.x, x[t], a0);
+                a1 = fma(m01.y, x[t + 1], a1);
+                a2 = fma(m23.x, x[t + 2], a2);
+                a3 = fma(m23.y, x[t + 3], a3);
             }
             bn = quad_sum_d((a0 + a1) + (a2 + a3)) * inv_cur;
         } else {
@@ -517,6 +547,65 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
             end_cur[i] = bf;
             if (ch.first) a.beta[(size_t)ch.base * Mp + i] = bf;
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Operands of the eigen-free pre-pass.  A_e = diag(e_key) T^T is the one-position forward operator of eigen key e
+// (the matrix whose eigensystem TransitionBundle::update takes, transition_bundle.cpp:15-25); a span-s row applies
+// A_e^s (forward) or its transpose (backward).  One workgroup per eigen key walks s = 2 .. max span with one
+// M x M x M product per step (A in LDS, the running power double-buffered in LDS) and stores the powers the key's
+// groups need, row-major and transposed.  span_gid[e][s] = group of (key e, span s) or -1.  Used only when the spans
+// are short and few (binned data); tens of microseconds, against 0.6 ms of host eigensolves it takes off the critical
+// path (engine.hip: estep).
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void k_group_powers(int M, int max_span, const int *__restrict__ e_kid,
+                                                       const int *__restrict__ span_gid, const double *__restrict__ E,
+                                                       const double *__restrict__ Td, double *__restrict__ Ag,
+                                                       double *__restrict__ AgT) {
+    constexpr int LD = MT + 1, CW = MT / 4;
+    extern __shared__ __attribute__((aligned(16))) double smp[];
+    double *sA = smp;                       // [MT][MT]   A[k][c]   (read as rows of 16 contiguous columns: broadcast)
+    double *sP = smp + MT * MT;             // [2][MT][LD] running power, rows padded (lanes read different rows)
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const double *em = E + (size_t)e_kid[e] * MT;
+    for (int idx = tid; idx < MT * MT; idx += 256) {
+        const int i = idx / MT, k = idx % MT;
+        const double v = (i < M && k < M) ? em[i] * Td[(size_t)k * MT + i] : 0.0;       // A[i][k] = e_i T[k][i]
+        sA[i * MT + k] = v;
+        sP[i * LD + k] = v;
+    }
+    __syncthreads();
+    const int i = tid >> 2, cb = (tid & 3) * CW;
+    const int *sg = span_gid + (size_t)e * (max_span + 1);
+    for (int sp = 2; sp <= max_span; ++sp) {
+        const double *Pc = sP + ((sp & 1) ? MT * LD : 0);        // power sp-1 lives in buffer (sp-1)&1... see below
+        double *Pn = sP + ((sp & 1) ? 0 : MT * LD);
+        double acc[CW];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) acc[c] = 0.0;
+        if (i < MT) {
+            for (int k = 0; k < MT; ++k) {
+                const double pv = Pc[i * LD + k];
+                const double *ar = sA + k * MT + cb;
+#pragma unroll
+                for (int c = 0; c < CW; ++c) acc[c] = fma(pv, ar[c], acc[c]);
+            }
+        }
+        const int g = sg[sp];
+        if (i < MT) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                Pn[i * LD + cb + c] = acc[c];
+                if (g >= 0) {
+                    Ag[(size_t)g * MT * MT + (size_t)i * MT + cb + c] = acc[c];
+                    AgT[(size_t)g * MT * MT + (size_t)(cb + c) * MT + i] = acc[c];
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 

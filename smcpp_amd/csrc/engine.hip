@@ -145,6 +145,8 @@ constexpr int ROWDESC_PAD = 256;
 
 }  // namespace
 
+static int coop_generation();
+
 struct smcpp_im {
     // ---- static problem description -------------------------------------------------------------------------
     int npop = 1, keylen = 3, M = 0, Mp = 0, NPL = 1, NT = 1, n_contigs = 0, K = 0, G = 0, Ke = 0;
@@ -190,7 +192,7 @@ struct smcpp_im {
     // ---- device -----------------------------------------------------------------------------------------------
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: backward chain when it may overlap the forward one
-    hipEvent_t ev[10];
+    hipEvent_t ev[14];                                  // 10..13: forward / backward interval of the eigen-free pre-pass
     int dual_stream = 1;
     bool chains_dual = false;
     DevBuf<RowInfo> d_rowinfo;
@@ -204,6 +206,18 @@ struct smcpp_im {
                           // 3 CU-cooperative with streamed operands (64 < M <= 256)
     int coop_bpc = 1;     // cooperative workgroups resident per CU the automatic chunking aims at
     int hot_eig = -1, hot_eig2 = -1;
+    // eigen-free pre-pass (chains2.hpp: k_group_powers, POWER instantiations): pass 0 runs on group powers while the host
+    // solves the eigenproblems; only for short, few spans (binned data) and chunks short enough that pass 1 re-runs them whole
+    bool power_ok = false, prepass_launched = false;
+    int max_span_pw = 0;
+    std::vector<int> span_gid;             // [Ke][max_span_pw + 1] group of (eigen key, span) or -1
+    DevBuf<int> d_span_gid;
+    PinnedArena pre_stage;                 // static operands of the pre-pass (pi, T, emission table): own pinned mirror
+    char *d_pre = nullptr;
+    size_t pre_cap = 0;
+    bool static_packed = false;
+    float pre_f_ms = 0.f, pre_b_ms = 0.f;
+    DevBuf<double> d_Ag, d_AgT;            // [G][Mp][Mp]
     DevBuf<Chunk> d_chunks;
     DevBuf<Slab> d_slabs_sc, d_slabs_rk, d_slabs_eg;
     DevBuf<int2> d_perm1k;                 // span-1 rows sorted by key: {ell, key id} (one load resolves both)
@@ -260,6 +274,7 @@ struct smcpp_im {
             if (stream2) (void)hipStreamDestroy(stream2);
         }
         if (d_param) (void)hipFree(d_param);
+        if (d_pre) (void)hipFree(d_pre);
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_ll) (void)hipHostFree(h_ll);
     }
@@ -270,6 +285,9 @@ struct smcpp_im {
     void make_slabs();
     void alloc_device();
     void host_prep_and_upload();
+    void stage_static_and_prepass();
+    void setup_power();
+    ChainArgs chain_args();
     void run_chains();
     void run_stats();
     void estep();
@@ -463,7 +481,7 @@ void smcpp_im::make_chunks() {
             chunks.push_back(ch);
         }
     }
-    max_pass = max_chunks_per_contig + 2;
+    max_pass = max_chunks_per_contig + 3;   // (+1: the full pass that follows an eigen-free pre-pass)
 }
 
 void smcpp_im::make_slabs() {
@@ -556,6 +574,26 @@ void smcpp_im::make_slabs() {
     eb_slab_off.push_back((int)slabs_eg.size());
 }
 
+void smcpp_im::setup_power() {
+    int mx = 0;
+    for (int g = 0; g < G; ++g) mx = std::max(mx, groups[g].span);
+    int longest = 0;
+    for (const Chunk &ch : chunks) longest = std::max(longest, ch.r1 - ch.r0);
+    const char *pe = getenv("SMCPP_POWER_PREPASS");
+    // short, few spans (binned data) so that the powers are cheap; chunks short enough that pass 1 re-runs them whole
+    // anyway (the rows of the pre-pass are all overwritten: its normalisers carry no eigenvalue scale)
+    power_ok = chain_mode == 2 && coop_generation() == 2 && Mp <= 64 && Ke >= 1 && G >= 1 && G <= 512 && mx <= 64 &&
+               longest <= 2000 && !(pe && atoi(pe) == 0);
+    max_span_pw = mx;
+    if (!power_ok) return;
+    span_gid.assign((size_t)Ke * (mx + 1), -1);
+    for (int g = 0; g < G; ++g) span_gid[(size_t)groups[g].eig * (mx + 1) + groups[g].span] = g;
+    d_span_gid.upload(span_gid, stream);
+    d_Ag.alloc((size_t)G * Mp * Mp);
+    d_AgT.alloc((size_t)G * Mp * Mp);
+    HIPCHK(hipStreamSynchronize(stream));
+}
+
 void smcpp_im::alloc_device() {
     hipStream_t s = stream;
     d_rowinfo.upload(rowinfo, s);
@@ -599,6 +637,7 @@ void smcpp_im::alloc_device() {
     d_g_span.upload(gs, s);
     d_g_eig.upload(ge, s);
     d_e_kid.upload(eig_kid, s);
+    setup_power();
     const size_t nch = chunks.size();
     d_alpha.alloc((size_t)total_rows * Mp);
     d_beta.alloc((size_t)total_rows * Mp);
@@ -773,6 +812,7 @@ void smcpp_im::host_prep_and_upload() {
 #pragma omp parallel for schedule(dynamic) num_threads(std::max(1, std::min(Ke + 1, omp_get_max_threads())))
     for (int e = 0; e <= Ke; ++e) {
         if (e == Ke) {
+            if (static_packed) continue;
             for (int i = 0; i < M; ++i) {
                 pi_f[i] = (float)pi[i];
                 for (int j = 0; j < M; ++j) {
@@ -818,7 +858,7 @@ void smcpp_im::host_prep_and_upload() {
     auto tp1 = std::chrono::steady_clock::now();
     std::vector<float> T4;
     std::vector<double> fA2, fB2, bA2, bB2, bC2;
-    if (Mp <= 64) {
+    if (Mp <= 64 && chain_mode == 1) {
         // k-blocked copies for the LDS-resident chain kernels: [k/4][i][4] floats, [k/2][i][2] doubles
         const int h = hot_eig;
         T4.assign(MM, 0.f); fA2.assign(MM, 0.0); fB2.assign(MM, 0.0); bA2.assign(MM, 0.0); bB2.assign(MM, 0.0);
@@ -880,7 +920,7 @@ void smcpp_im::host_prep_and_upload() {
     d_Pinvrm.place(Pinvrm, d_param, hb, off);
     d_dsc.place(dsc, d_param, hb, off); d_dun.place(dun, d_param, hb, off); d_dpow.place(dpow, d_param, hb, off);
     d_g_scale.place(gsc, d_param, hb, off); d_g_logscale.place(gls, d_param, hb, off);
-    if (Mp <= 64) {
+    if (Mp <= 64 && chain_mode == 1) {
         d_T4.place(T4, d_param, hb, off); d_fA2.place(fA2, d_param, hb, off); d_fB2.place(fB2, d_param, hb, off);
         d_bA2.place(bA2, d_param, hb, off); d_bB2.place(bB2, d_param, hb, off); d_bC2.place(bC2, d_param, hb, off);
     }
@@ -950,6 +990,18 @@ static void launch_chain_coop2_tt(bool fwd, const ChainArgs &a, const CoopArgs &
         hipLaunchKernelGGL((k_bwd_coop2<MT_, TAB_, RERUN_, HOT2_>), dim3(a.nchunks), dim3(MT_ * 4), shm, s, a, ca);
     }
 }
+template <int MT_, bool TAB_>
+static void launch_chain_power_t(bool fwd, const ChainArgs &a, const CoopArgs &ca, size_t shm, hipStream_t s) {
+    if (fwd) {
+        static bool once = false;
+        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_fwd_coop2<MT_, TAB_, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+        hipLaunchKernelGGL((k_fwd_coop2<MT_, TAB_, false, false, true>), dim3(a.nchunks), dim3(MT_ * 4), shm, s, a, ca);
+    } else {
+        static bool once = false;
+        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_bwd_coop2<MT_, TAB_, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+        hipLaunchKernelGGL((k_bwd_coop2<MT_, TAB_, false, false, true>), dim3(a.nchunks), dim3(MT_ * 4), shm, s, a, ca);
+    }
+}
 template <int MT_, bool TAB_, bool RERUN_>
 static void launch_chain_coop2_t(bool fwd, const ChainArgs &a, const CoopArgs &ca, size_t shm, hipStream_t s) {
     // without a second eigen key the 64 VGPRs of its operands are not allocated (measured on the whole genome: keeping
@@ -964,7 +1016,8 @@ static int coop_generation() {
 template <int MT_, bool TAB_>
 static void launch_chain_coop_t(bool fwd, const ChainArgs &a, const CoopArgs &ca, size_t shm, hipStream_t s) {
     if (coop_generation() == 2) {
-        if (a.pass > 0) launch_chain_coop2_t<MT_, TAB_, true>(fwd, a, ca, shm, s);
+        if (a.variant == 1) launch_chain_power_t<MT_, TAB_>(fwd, a, ca, shm, s);
+        else if (a.pass > 0 && a.variant != 2) launch_chain_coop2_t<MT_, TAB_, true>(fwd, a, ca, shm, s);
         else launch_chain_coop2_t<MT_, TAB_, false>(fwd, a, ca, shm, s);
         return;
     }
@@ -1047,12 +1100,118 @@ static void launch_s1(int npl, const S1Args &a, hipStream_t s) {
     }
 }
 
-void smcpp_im::run_chains() {
-    hipStream_t s = stream;
+ChainArgs smcpp_im::chain_args() {
     ChainArgs a;
     a.M = M; a.Mp = Mp; a.nchunks = (int)chunks.size(); a.pass = 0;
-    a.hot = hot_eig; a.hot2 = hot_eig2;
+    a.hot = hot_eig; a.hot2 = hot_eig2; a.variant = 0;
     a.chunks = d_chunks.p; a.rowdesc = d_rowdesc.p + ROWDESC_PAD; a.E = d_E.p; a.dpow = d_dpow.p;
+    a.pi_f = d_pi_f.p; a.Tf = d_Tf.p; a.PinvT = d_PinvT.p; a.PT = d_PT.p;
+    a.TdT = d_TdT.p; a.Prm = d_Prm.p; a.Pinvrm = d_Pinvrm.p;
+    a.alpha = d_alpha.p; a.beta = d_beta.p; a.cnorm = d_cnorm.p;
+    a.ends_f = d_ends_f.p; a.used_f = d_used_f.p; a.ends_b = d_ends_b.p; a.used_b = d_used_b.p;
+    a.eps_f = eps_f; a.eps_b = eps_b;
+    a.dbg = nullptr;
+    a.warm_f = nullptr; a.warm_b = nullptr;
+    a.Ag = d_Ag.p; a.AgT = d_AgT.p;
+    a.changed = nullptr;
+    return a;
+}
+
+// LDS budget of the cooperative kernels: exchange buffers + descriptors (+ the emission / eigenvalue-power tables when
+// they fit: TAB)
+static void coop_lds(int Mp, int K, int G, int &tab_c, size_t &shm_c) {
+    const int KQ = Mp / 4, UP = KQ + 2;
+    const size_t base_c = (size_t)(4 * UP + 8 * UP) * 8 + 2 * Mp * 4 + 1024 + 64;
+    const size_t tabs = ((size_t)K * 4 * UP + (size_t)G * Mp) * 8;      // backward layout of generation 1 is the larger one
+    tab_c = (base_c + tabs <= 64 * 1024) ? 1 : 0;
+    if (const char *tv = getenv("SMCPP_COOP_TAB")) tab_c = tab_c && atoi(tv) != 0;    // test hook: force the global-table path
+    shm_c = base_c + (tab_c ? tabs : 0);
+}
+
+// Eigen-free pre-pass: upload pi / T / emission table, build the group powers on the device and launch pass 0 of both
+// chains on them; the host then solves the eigenproblems while the GPU runs (estep()).
+void smcpp_im::stage_static_and_prepass() {
+    prepass_launched = false;
+    static_packed = false;
+    if (!power_ok || (warm_start && warm_valid)) return;
+    hipStream_t s = stream, sb = dual_stream ? stream2 : stream;
+    const size_t MM = (size_t)Mp * Mp;
+    auto ensure = [](auto &v, size_t n, auto init) { if (v.size() != n) v.assign(n, init); };
+    ensure(hs_pi_f, (size_t)Mp, 0.f); ensure(hs_Tf, MM, 0.f);
+    ensure(hs_TdT, MM, 0.0); ensure(hs_Td, MM, 0.0); ensure(hs_Ep, (size_t)K * Mp, 0.0);
+    for (int i = 0; i < M; ++i) {
+        hs_pi_f[i] = (float)pi[i];
+        for (int j = 0; j < M; ++j) {
+            hs_Tf[(size_t)i * Mp + j] = (float)T[(size_t)i * M + j];
+            hs_Td[(size_t)i * Mp + j] = T[(size_t)i * M + j];
+            hs_TdT[(size_t)j * Mp + i] = T[(size_t)i * M + j];
+        }
+    }
+    for (int k = 0; k < K; ++k)
+        for (int i = 0; i < M; ++i) hs_Ep[(size_t)k * Mp + i] = E[(size_t)k * M + i];
+    static_packed = true;
+    // own small arena (the main one is filled and copied after the eigensolve)
+    const size_t need = 8 * 256 + (hs_pi_f.size() + hs_Tf.size()) * 4 + (hs_TdT.size() + hs_Td.size() + hs_Ep.size()) * 8;
+    pre_stage.reset(need);
+    if (need > pre_cap) {
+        if (d_pre) (void)hipFree(d_pre);
+        pre_cap = need + need / 4;
+        HIPCHK(hipMalloc((void **)&d_pre, pre_cap));
+    }
+    size_t off = 0;
+    auto put = [&](const void *src, size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        std::memcpy(pre_stage.base + off, src, bytes);
+        char *dp = d_pre + off;
+        off += bytes;
+        return dp;
+    };
+    ChainArgs a = chain_args();
+    a.pi_f = reinterpret_cast<const float *>(put(hs_pi_f.data(), hs_pi_f.size() * 4));
+    a.Tf = reinterpret_cast<const float *>(put(hs_Tf.data(), hs_Tf.size() * 4));
+    a.TdT = reinterpret_cast<const double *>(put(hs_TdT.data(), hs_TdT.size() * 8));
+    const double *pre_Td = reinterpret_cast<const double *>(put(hs_Td.data(), hs_Td.size() * 8));
+    a.E = reinterpret_cast<const double *>(put(hs_Ep.data(), hs_Ep.size() * 8));
+    HIPCHK(hipMemcpyAsync(d_pre, pre_stage.base, off, hipMemcpyHostToDevice, s));
+    d_changed_f.zero(s);
+    d_changed_b.zero(s);
+    {
+        const size_t shm = (size_t)(Mp * Mp + 2 * Mp * (Mp + 1)) * sizeof(double);
+        switch (Mp) {
+#define P_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_group_powers<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
+                    hipLaunchKernelGGL(k_group_powers<x>, dim3(Ke), dim3(256), shm, s, M, max_span_pw, (const int *)d_e_kid.p, (const int *)d_span_gid.p, a.E, pre_Td, d_Ag.p, d_AgT.p); } break;
+            P_(16) P_(32) P_(48) P_(64)
+#undef P_
+            default: throw std::runtime_error("internal: power pre-pass with an unsupported state count");
+        }
+    }
+    static const int dbg_level = getenv("SMCPP_POWER_DEBUG") ? atoi(getenv("SMCPP_POWER_DEBUG")) : 0;
+    if (dbg_level == 1) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[power] powers ok\n"); static_packed = false; return; }
+    int tab_c; size_t shm_c;
+    coop_lds(Mp, K, G, tab_c, shm_c);
+    CoopArgs cargs;
+    cargs.K = K; cargs.G = G;
+    a.variant = 1; a.pass = 0;
+    if (sb != s) {
+        HIPCHK(hipEventRecord(ev[6], s));
+        HIPCHK(hipStreamWaitEvent(sb, ev[6], 0));
+    }
+    HIPCHK(hipEventRecord(ev[10], s));
+    a.changed = d_changed_f.p;
+    launch_chain_coop(true, Mp, a, cargs, tab_c, shm_c, s);
+    HIPCHK(hipEventRecord(ev[11], s));
+    HIPCHK(hipEventRecord(ev[12], sb));
+    a.changed = d_changed_b.p;
+    launch_chain_coop(false, Mp, a, cargs, tab_c, shm_c, sb);
+    HIPCHK(hipEventRecord(ev[13], sb));
+    HIPCHK(hipGetLastError());
+    if (dbg_level == 2) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipStreamSynchronize(sb)); fprintf(stderr, "[power] pre-pass ok\n"); }
+    prepass_launched = true;
+}
+
+void smcpp_im::run_chains() {
+    hipStream_t s = stream;
+    ChainArgs a = chain_args();
     const bool generic = chain_mode == 0;
     CoopArgs cargs;
     cargs.K = K; cargs.G = G;
@@ -1061,14 +1220,7 @@ void smcpp_im::run_chains() {
     bargs.qPrm = d_qPrm.p; bargs.qPinvrm = d_qPinvrm.p;
     size_t shm_c = 0;
     int tab_c = 0;
-    {
-        const int KQ = Mp / 4, UP = KQ + 2;
-        const size_t base_c = (size_t)(4 * UP + 8 * UP) * 8 + 2 * Mp * 4 + 1024 + 64;
-        const size_t tabs = ((size_t)K * 4 * UP + (size_t)G * Mp) * 8;      // backward layout is the larger one
-        tab_c = (base_c + tabs <= 64 * 1024) ? 1 : 0;
-        if (const char *tv = getenv("SMCPP_COOP_TAB")) tab_c = tab_c && atoi(tv) != 0;    // test hook: force the global-table path
-        shm_c = base_c + (tab_c ? tabs : 0);
-    }
+    coop_lds(Mp, K, G, tab_c, shm_c);
     // LDS budget of the resident kernels: matrices + (emission, eigenvalue-power) tables + per-wavefront scratch
     LdsArgs lf, lb;
     size_t shm_f = 0, shm_b = 0;
@@ -1089,19 +1241,16 @@ void smcpp_im::run_chains() {
         shm_f = base_f + (tab ? tabs : 0);
         shm_b = base_b + (tab ? tabs : 0);
     }
-    a.pi_f = d_pi_f.p; a.Tf = d_Tf.p; a.PinvT = d_PinvT.p; a.PT = d_PT.p;
-    a.TdT = d_TdT.p; a.Prm = d_Prm.p; a.Pinvrm = d_Pinvrm.p;
-    a.alpha = d_alpha.p; a.beta = d_beta.p; a.cnorm = d_cnorm.p;
-    a.ends_f = d_ends_f.p; a.used_f = d_used_f.p; a.ends_b = d_ends_b.p; a.used_b = d_used_b.p;
-    a.eps_f = eps_f; a.eps_b = eps_b;
-    a.dbg = nullptr;
     const bool warm = warm_start && warm_valid && chain_mode == 2 && Mp <= 64 &&
                       d_warm_f.n == chunks.size() * (size_t)Mp && d_warm_b.n == chunks.size() * (size_t)Mp;
     a.warm_f = warm ? d_warm_f.p : nullptr;
     a.warm_b = warm ? d_warm_b.p : nullptr;
     if (getenv("SMCPP_DEBUG_CYCLES")) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }
-    d_changed_f.zero(s);
-    d_changed_b.zero(s);
+    const bool pre = prepass_launched;      // pass 0 of both chains already runs (eigen-free pre-pass, flags zeroed there)
+    if (!pre) {
+        d_changed_f.zero(s);
+        d_changed_b.zero(s);
+    }
     if (h_flags_cap < 2 * (max_pass + 1)) {
         if (h_flags) (void)hipHostFree(h_flags);
         h_flags_cap = 2 * (max_pass + 1);
@@ -1113,9 +1262,17 @@ void smcpp_im::run_chains() {
             if (ch[j] == 0) return j;
         return -1;
     };
-    int launched_f = 0, launched_b = 0;
+    int launched_f = pre ? 1 : 0, launched_b = pre ? 1 : 0;
     int want_f = std::min(max_pass, last_fwd_passes > 0 ? last_fwd_passes + 1 : std::min(max_pass, 8));
     int want_b = std::min(max_pass, last_bwd_passes > 0 ? last_bwd_passes + 1 : std::min(max_pass, 8));
+    const size_t nel_ends = chunks.size() * (size_t)Mp;
+    // after a pre-pass, pass 1 is a FULL pass from the pre-pass's end vectors (no skip test, no merge exit): every stored
+    // row then comes from the exact kernels
+    auto set_variant = [&](int pass) {
+        a.pass = pass;
+        if (pre && pass == 1) { a.variant = 2; a.warm_f = d_ends_f.p; a.warm_b = d_ends_b.p; (void)nel_ends; }
+        else { a.variant = 0; a.warm_f = warm ? d_warm_f.p : nullptr; a.warm_b = warm ? d_warm_b.p : nullptr; }
+    };
     // The two chains are independent (beta does not depend on alpha).  The cooperative kernels leave most of a CU's
     // LDS and issue slots idle, so the backward passes run on a second stream and share the CUs with the forward ones.
     const bool dual = dual_stream && ((chain_mode == 2 && Mp <= 64) || Mp > 64);
@@ -1132,7 +1289,7 @@ void smcpp_im::run_chains() {
         if (!fdone) {
             a.changed = d_changed_f.p;
             for (; launched_f < want_f; ++launched_f) {
-                a.pass = launched_f;
+                set_variant(launched_f);
                 if (!(chain_mode == 3 && launch_chain_big(true, Mp, a, bargs, s)) &&
                     !(chain_mode == 2 && launch_chain_coop(true, Mp, a, cargs, tab_c, shm_c, s)))
                     launch_chain(true, NPL, Mp, generic, a, lf, tab_lds, wpb, shm_f, s);
@@ -1142,7 +1299,7 @@ void smcpp_im::run_chains() {
         if (!bdone) {
             a.changed = d_changed_b.p;
             for (; launched_b < want_b; ++launched_b) {
-                a.pass = launched_b;
+                set_variant(launched_b);
                 if (!(chain_mode == 3 && launch_chain_big(false, Mp, a, bargs, sb)) &&
                     !(chain_mode == 2 && launch_chain_coop(false, Mp, a, cargs, tab_c, shm_c, sb)))
                     launch_chain(false, NPL, Mp, generic, a, lb, tab_lds, wpb, shm_b, sb);
@@ -1338,6 +1495,7 @@ void smcpp_im::estep() {
     if ((int)pi.size() != M || (int)T.size() != M * M || (int)E.size() != K * M)
         throw std::runtime_error("parameters are not set");
     HIPCHK(hipEventRecord(ev[0], stream));
+    stage_static_and_prepass();   // (when eligible) pass 0 of both chains starts now, on eigen-free operands
     host_prep_and_upload();   // the reference rebuilds the eigensystems on every E-step (inference_manager.cpp:112)
     auto t1 = std::chrono::steady_clock::now();
     run_chains();
@@ -1353,6 +1511,13 @@ void smcpp_im::estep() {
     }
     float chains_ms = 0;
     (void)hipEventElapsedTime(&chains_ms, ev[1], ev[3]);
+    if (prepass_launched) {
+        // pass 0 ran before ev[1] (concurrently with the host eigensolve): add its kernel intervals
+        (void)hipEventElapsedTime(&pre_f_ms, ev[10], ev[11]);
+        (void)hipEventElapsedTime(&pre_b_ms, ev[12], ev[13]);
+        f_ms += pre_f_ms; b_ms += pre_b_ms;
+        chains_ms += std::max(pre_f_ms, pre_b_ms);
+    }
     (void)hipEventElapsedTime(&s_ms, ev[3], ev[4]);
     (void)hipEventElapsedTime(&fin_ms, ev[4], ev[5]);
     timing[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -1897,6 +2062,7 @@ int smcpp_set_chunking(smcpp_im *im, int rows_per_chunk, double eps_alpha, doubl
         im->d_ends_b.alloc(2 * nch * im->Mp); im->d_used_b.alloc(nch * im->Mp);
         im->d_changed_f.alloc(im->max_pass + 1); im->d_changed_b.alloc(im->max_pass + 1);
         HIPCHK(hipStreamSynchronize(im->stream));
+        im->setup_power();
         im->last_fwd_passes = im->last_bwd_passes = 0;
     }
     API_END

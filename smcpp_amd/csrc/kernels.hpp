@@ -103,6 +103,8 @@ __device__ __forceinline__ double row16_sum(double v) {
 struct ChainArgs {
     int M, Mp, nchunks, pass, hot;   // hot = eigen index whose matrices the *_hot kernels keep in registers (-1: none)
     int hot2;                        // second register-resident eigen key of the generation-2 cooperative chains (-1: none)
+    int variant;                     // host-side dispatch: 0 = by pass number, 1 = eigen-free pre-pass (pass 0 on group powers),
+                                     // 2 = full pass from the previous pass's end vectors (no skip test, no merge exit)
     const Chunk *chunks;
     const int2 *rowdesc;    // [rows] {kid, gid | es << 20} (-1 for span-1 rows)
     const double *E;        // [K][Mp] emission vectors
@@ -130,6 +132,7 @@ struct ChainArgs {
     long long *dbg;         // optional [8]: cycle counters of workgroup 0 (SMCPP_DEBUG_CYCLES)
     // optional warm start (cooperative kernels): the converged chunk-boundary vectors of the previous E-step of this
     // manager, used instead of pi / the uniform vector as pass-0 start vectors; nullptr = cold start
+    const double *Ag, *AgT; // [G][Mp][Mp] group powers (diag(e) T^T)^span and their transposes (eigen-free pre-pass only)
     const float *warm_f;    // [nchunks][Mp] end vectors of the forward chunks
     const double *warm_b;   // [nchunks][Mp] end vectors of the backward chunks
 };

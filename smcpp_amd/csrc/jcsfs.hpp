@@ -13,6 +13,7 @@
 //
 // Everything is templated on the scalar so the same code yields values (double) and forward-mode Jacobians (dual).
 #pragma once
+#include <string>
 
 #include "nonsym_eig.hpp"
 #include "prep.hpp"
@@ -173,32 +174,54 @@ private:
         eMn1[1] = Mn11.expM(Rts1);
         eMn1[2].assign(eMn1[0].rbegin(), eMn1[0].rend());              // rows and columns reversed
         eMn2 = Mn2.expM(Rts2);
+        // pieces that do not depend on the hidden state, computed once (the reference recomputes them per state):
+        // the folded truncated SFS of population 2 below the split and the SFS above the split that tau_below_split uses
+        std::vector<S> r2;
+        if (n2 > 1) {
+            const RateFunctionT<S> eta2_trunc(truncate_params(params2, split), std::vector<double>{0.0, INFINITY});
+            r2 = undistinguished_sfs(csfs_of(n2 - 2, eta2_trunc)[0], n2 - 2);
+        }
+        bool any_below = false;
+        for (int m = 0; m < M; ++m) any_below = any_below || hs[m] < split;
+        if (any_below) {
+            const RateFunctionT<S> eta1_shift(shift_params(params1, split), std::vector<double>{0.0, INFINITY});
+            sfs_above_split = undistinguished_sfs(csfs_of(n1 + n2 - 1, eta1_shift)[0], n1 + n2 - 1);
+        }
+        // hidden states are independent: one task each
+        const int nd = dual_nder();
+        std::string err;
+#pragma omp parallel for schedule(dynamic)
         for (int m = 0; m < M; ++m) {
-            const double t1 = hs[m], t2 = hs[m + 1];
-            if (t1 < t2 && t2 <= split) tau_below_split(m, t1, t2, S(1.0));
-            else if (split <= t1 && t1 < t2) tau_above_split(m, t1, t2, S(1.0));
-            else {
-                const S e1 = m_exp(-eta1->R(t1));
-                const S e2 = std::isinf(t2) ? S(0.0) : m_exp(-eta1->R(t2));
-                const S w = (m_exp(-Rts1) - e2) / (e1 - e2);
-                tau_below_split(m, t1, split, 1.0 - w);
-                tau_above_split(m, split, t2, w);
-            }
-            // population 2 below the split: no distinguished lineage there, so its private branches are the folded
-            // truncated SFS
-            if (n2 == 1) at(m, 0, 0, 0, 1) += split;
-            if (n2 > 1) {
-                const RateFunctionT<S> eta2_trunc(truncate_params(params2, split), std::vector<double>{0.0, INFINITY});
-                const std::vector<S> r = undistinguished_sfs(csfs_of(n2 - 2, eta2_trunc)[0], n2 - 2);
-                S remain(0.0);
-                for (int i = 0; i < n2 - 1; ++i) {
-                    at(m, 0, 0, 0, i + 1) += r[i];
-                    remain += r[i] * ((double)(i + 1) / (double)n2);
+            DualScope sc(nd);
+            try {
+                const double t1 = hs[m], t2 = hs[m + 1];
+                if (t1 < t2 && t2 <= split) tau_below_split(m, t1, t2, S(1.0));
+                else if (split <= t1 && t1 < t2) tau_above_split(m, t1, t2, S(1.0));
+                else {
+                    const S e1 = m_exp(-eta1->R(t1));
+                    const S e2 = std::isinf(t2) ? S(0.0) : m_exp(-eta1->R(t2));
+                    const S w = (m_exp(-Rts1) - e2) / (e1 - e2);
+                    tau_below_split(m, t1, split, 1.0 - w);
+                    tau_above_split(m, split, t2, w);
                 }
-                remain -= S(split);
-                at(m, 0, 0, 0, n2) -= remain;
+                // population 2 below the split: no distinguished lineage there, so its private branches are the folded
+                // truncated SFS
+                if (n2 == 1) at(m, 0, 0, 0, 1) += split;
+                if (n2 > 1) {
+                    S remain(0.0);
+                    for (int i = 0; i < n2 - 1; ++i) {
+                        at(m, 0, 0, 0, i + 1) += r2[i];
+                        remain += r2[i] * ((double)(i + 1) / (double)n2);
+                    }
+                    remain -= S(split);
+                    at(m, 0, 0, 0, n2) -= remain;
+                }
+            } catch (const std::exception &ex) {
+#pragma omp critical
+                err = ex.what();
             }
         }
+        if (!err.empty()) throw std::runtime_error(err);
     }
 
     // distinguished pair coalesces in [t1, t2) with t2 <= split (jcsfs.cpp:83-163)
@@ -213,9 +236,8 @@ private:
         S Et(0.0);
         for (int k = 0; k <= n1; ++k) Et += tsfs[k] * ((double)(k + 1) / (double)(n1 + 2));
         at(m, 2, n1, 0, 0) = (split - Et) * weight;
-        // above the split: SFS of the n1 + n2 + 1 lineages there, carried down through the Moran models
-        const RateFunctionT<S> eta1_shift(shift_params(params1, split), std::vector<double>{0.0, INFINITY});
-        const std::vector<S> sfs_above = undistinguished_sfs(csfs_of(n1 + n2 - 1, eta1_shift)[0], n1 + n2 - 1);
+        // above the split: SFS of the n1 + n2 + 1 lineages there (together()), carried down through the Moran models
+        const std::vector<S> &sfs_above = sfs_above_split;
         const int r = n1 + 2, c = n1 + 1;
         std::vector<S> avg0((size_t)r * c, S(0.0)), avg2((size_t)r * c, S(0.0));
         std::mt19937 gen;                                               // default seed, re-created per call (quirk 14)
@@ -347,7 +369,7 @@ private:
     std::unique_ptr<RateFunctionT<S>> eta1;
     S Rts1, Rts2;
     std::array<std::vector<S>, 3> eMn1;
-    std::vector<S> eMn2;
+    std::vector<S> eMn2, sfs_above_split;
     std::vector<std::vector<S>> J;
 };
 

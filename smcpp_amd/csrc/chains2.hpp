@@ -39,6 +39,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
     int2 *sdesc = reinterpret_cast<int2 *>(xf + 2 * MT);      // [2][64]   row descriptors
     int *sflag = reinterpret_cast<int *>(sdesc + 128);        // [1]
     int *mflag = sflag + 4;                                    // [4] per-wavefront "not merged yet" flags
+    float *ptmp = reinterpret_cast<float *>(smem + ca.power_off);   // [2][MT] POWER: vector between two power applications
     if (TAB) {
         lds_stage(sE, a.E, ca.K * MT * 8, tid, NW * 64);
         if (!POWER && ca.G > 0) lds_stage(sD, a.dpow, ca.G * MT * 8, tid, NW * 64);
@@ -98,6 +99,19 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
         }
 #pragma unroll
         for (int t = 0; t < KQ; ++t) { pin_reg(tf[t]); pin_reg(pinv[t]); pin_reg(pt[t]); if (HOT2) { pin_reg(pinv2[HOT2 ? t : 0]); pin_reg(pt2[HOT2 ? t : 0]); } }
+    }
+    // eigen-free pre-pass: quarters of A^2, A^4, A^8, A^16 of the hot eigen key, A = diag(e) T^T (k_binary_powers)
+    float pw[POWER ? 4 : 1][POWER ? KQ : 1];
+    if (POWER) {
+        const float *B0 = a.Bf + (size_t)(a.hot < 0 ? 0 : a.hot) * 4 * MT * MT + (size_t)i * MT + kq * KQ;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int t = 0; t < KQ; ++t) pw[POWER ? b : 0][POWER ? t : 0] = B0[(size_t)b * MT * MT + t];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int t = 0; t < KQ; ++t) pin_reg(pw[POWER ? b : 0][POWER ? t : 0]);
     }
     // descriptors of the chunk's rows, staged 64 at a time (batch b in sdesc[b & 1]); the array is padded, reads past the
     // chunk return descriptors of rows this workgroup never processes
@@ -188,21 +202,56 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
             const float y = quad_sum_f((acc01.x + acc01.y) + (acc23.x + acc23.y)) * inv;
             vout = (float)((double)y * e_cur);
         } else if (POWER) {
-            // eigen-free pre-pass: alpha <- A_g alpha with A_g = (diag(e) T^T)^span built by k_group_powers
-            // (synchronous loads on purpose: a quarter prefetched one row ahead is a loop-carried load, for which the
-            // compiler waits with vmcnt(0) - i.e. for the alpha store of every row; measured 8 % slower)
-            const double *Aq = a.Ag + (size_t)SMCPP_GID(ge) * MT * MT + (size_t)i * MT + kq * KQ;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            // eigen-free pre-pass: alpha <- A^span alpha, one application of A^(2^b) per set bit b of the span (float: this
+            // pass only produces chunk-boundary vectors that the exact passes correct), the vector going through LDS
+            // between two applications
+            const int sp = a.g_span[SMCPP_GID(ge)];
+            const bool hotk = SMCPP_ES(ge) == a.hot;
+            const float *Bq = a.Bf + (size_t)SMCPP_ES(ge) * 4 * MT * MT + (size_t)i * MT + kq * KQ;
+            float vq[KQ];
 #pragma unroll
-            for (int t = 0; t < Q4; ++t) {
-                const double2 m01 = *reinterpret_cast<const double2 *>(Aq + 4 * t);
-                const double2 m23 = *reinterpret_cast<const double2 *>(Aq + 4 * t + 2);
-                a0 = fma(m01.x, (double)xl[t].x, a0);
-                a1 = fma(m01.y, (double)xl[t].y, a1);
-                a2 = fma(m23.x, (double)xh[t].x, a2);
-                a3 = fma(m23.y, (double)xh[t].y, a3);
+            for (int t = 0; t < Q4; ++t) { vq[4 * t] = xl[t].x; vq[4 * t + 1] = xl[t].y; vq[4 * t + 2] = xh[t].x; vq[4 * t + 3] = xh[t].y; }
+            float outv = 0.f;
+            int napp = 0;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                if (!((sp >> b) & 1)) continue;
+                if (napp > 0) {
+                    float *tb = ptmp + (napp & 1) * MT;
+                    if (owner) tb[i] = outv;
+                    lds_barrier();
+#pragma unroll
+                    for (int t = 0; t < KQ; ++t) vq[t] = tb[kq * KQ + t];
+                }
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                if (b == 0) {
+#pragma unroll
+                    for (int t = 0; t < KQ; t += 4) {
+                        a0 = fmaf(tf[t], vq[t], a0); a1 = fmaf(tf[t + 1], vq[t + 1], a1);
+                        a2 = fmaf(tf[t + 2], vq[t + 2], a2); a3 = fmaf(tf[t + 3], vq[t + 3], a3);
+                    }
+                } else if (hotk) {
+#pragma unroll
+                    for (int t = 0; t < KQ; t += 4) {
+                        a0 = fmaf(pw[POWER ? b - 1 : 0][POWER ? t : 0], vq[t], a0);
+                        a1 = fmaf(pw[POWER ? b - 1 : 0][POWER ? t + 1 : 0], vq[t + 1], a1);
+                        a2 = fmaf(pw[POWER ? b - 1 : 0][POWER ? t + 2 : 0], vq[t + 2], a2);
+                        a3 = fmaf(pw[POWER ? b - 1 : 0][POWER ? t + 3 : 0], vq[t + 3], a3);
+                    }
+                } else {
+                    const float *Bb_ = Bq + (size_t)(b - 1) * MT * MT;      // another eigen key: its powers come from L2
+#pragma unroll
+                    for (int t = 0; t < KQ; t += 4) {
+                        const float4 m = *reinterpret_cast<const float4 *>(Bb_ + t);
+                        a0 = fmaf(m.x, vq[t], a0); a1 = fmaf(m.y, vq[t + 1], a1);
+                        a2 = fmaf(m.z, vq[t + 2], a2); a3 = fmaf(m.w, vq[t + 3], a3);
+                    }
+                }
+                outv = quad_sum_f((a0 + a1) + (a2 + a3));
+                if (b == 0) outv *= (float)e_cur;
+                ++napp;
             }
-            vout = (float)(quad_sum_d((a0 + a1) + (a2 + a3)) * (double)inv);
+            vout = outv * inv;
         } else {
             const int es = SMCPP_ES(ge);
             double u;
@@ -313,6 +362,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
     int2 *sdesc = reinterpret_cast<int2 *>(xb + 8 * UP);      // [2][64]
     int *sflag = reinterpret_cast<int *>(sdesc + 128);
     int *mflag = sflag + 4;
+    double *ptmp = reinterpret_cast<double *>(smem + ca.power_off);   // [2][4][UP] POWER: vector between two power applications
     if (TAB) {
         lds_stage(sE, a.E, ca.K * MT * 8, tid, NW * 64);
         if (!POWER && ca.G > 0) lds_stage(sD, a.dpow, ca.G * MT * 8, tid, NW * 64);
@@ -366,6 +416,19 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
 #pragma unroll
         for (int t = 0; t < KQ; ++t) { pin_reg(tdt[t]); pin_reg(prm[t]); pin_reg(pinvrm[t]); if (HOT2) { pin_reg(prm2[HOT2 ? t : 0]); pin_reg(pinvrm2[HOT2 ? t : 0]); } }
     }
+    // eigen-free pre-pass: quarters of the TRANSPOSED powers (A^2)^T .. (A^16)^T of the hot eigen key
+    double pw[POWER ? 4 : 1][POWER ? KQ : 1];
+    if (POWER) {
+        const double *B0 = a.Bb + (size_t)(a.hot < 0 ? 0 : a.hot) * 4 * MT * MT + (size_t)i * MT + kq * KQ;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int t = 0; t < KQ; ++t) pw[POWER ? b : 0][POWER ? t : 0] = B0[(size_t)b * MT * MT + t];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int t = 0; t < KQ; ++t) pin_reg(pw[POWER ? b : 0][POWER ? t : 0]);
+    }
     // descriptors in processing order: iteration j handles row ell = r1 - j; the array is padded in front as well
     const int2 *rd = a.rowdesc + ch.base + ch.r1;
     const int nrows = ch.r1 - ch.r0;
@@ -377,6 +440,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
     int2 d0 = sdesc[0];
     int ge = __builtin_amdgcn_readfirstlane(d0.y);
     const int kid0 = __builtin_amdgcn_readfirstlane(d0.x);
+    int kid_cur = kid0;
     double dp_cur = (!POWER && ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + i]) : 0.0;
     int2 d1 = sdesc[1];
     // the exchanged vector z: beta itself before an eigen row, e o beta before a span-1 row (hmm.cpp:139)
@@ -427,6 +491,14 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
             }
             if (owner) brow[-(ptrdiff_t)j * Mp] = bnrm;
         }
+        // running scale for the NEXT row from the sum of the vector this row consumes (off the critical path)
+        double inv_next;
+        {
+            double s0 = (x[0] + x[1]) + (x[2] + x[3]);
+#pragma unroll
+            for (int t = 4; t < KQ; t += 4) s0 += (x[t] + x[t + 1]) + (x[t + 2] + x[t + 3]);
+            inv_next = rcp_f64(quad_sum_d(s0));
+        }
         double bn;
         if (ge < 0) {
             // beta <- T (e o beta): e was applied by the producer of x
@@ -440,19 +512,52 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
             }
             bn = quad_sum_d((a0 + a1) + (a2 + a3)) * inv_cur;
         } else if (POWER) {
-            // eigen-free pre-pass: beta <- A_g^T beta
-            const double *Aq = a.AgT + (size_t)SMCPP_GID(ge) * MT * MT + (size_t)i * MT + kq * KQ;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            // eigen-free pre-pass: beta <- (A^T)^span beta, A^T = T diag(e); one application per set bit of the span
+            const int sp = a.g_span[SMCPP_GID(ge)];
+            const bool hotk = SMCPP_ES(ge) == a.hot;
+            const double *Bq = a.Bb + (size_t)SMCPP_ES(ge) * 4 * MT * MT + (size_t)i * MT + kq * KQ;
+            double outv = 0.0;
+            int napp = 0;
 #pragma unroll
-            for (int t = 0; t < KQ; t += 4) {
-                const double2 m01 = *reinterpret_cast<const double2 *>(Aq + t);
-                const double2 m23 = *reinterpret_cast<const double2 *>(Aq + t + 2);
-                a0 = fma(m01.x, x[t], a0);
-                a1 = fma(m01.y, x[t + 1], a1);
-                a2 = fma(m23.x, x[t + 2], a2);
-                a3 = fma(m23.y, x[t + 3], a3);
+            for (int b = 0; b < 5; ++b) {
+                if (!((sp >> b) & 1)) continue;
+                if (napp > 0) {
+                    double *tb = ptmp + (napp & 1) * 4 * UP;
+                    if (owner) tb[(i / KQ) * UP + (i % KQ)] = outv;
+                    lds_barrier();
+#pragma unroll
+                    for (int t = 0; t < KQ; ++t) x[t] = tb[kq * UP + t];
+                }
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                if (b == 0) {
+                    const double *eq = TAB ? sE + (size_t)kid_cur * MT + kq * KQ : a.E + (size_t)kid_cur * Mp + kq * KQ;
+#pragma unroll
+                    for (int t = 0; t < KQ; t += 4) {
+                        a0 = fma(tdt[t] * eq[t], x[t], a0); a1 = fma(tdt[t + 1] * eq[t + 1], x[t + 1], a1);
+                        a2 = fma(tdt[t + 2] * eq[t + 2], x[t + 2], a2); a3 = fma(tdt[t + 3] * eq[t + 3], x[t + 3], a3);
+                    }
+                } else if (hotk) {
+#pragma unroll
+                    for (int t = 0; t < KQ; t += 4) {
+                        a0 = fma(pw[POWER ? b - 1 : 0][POWER ? t : 0], x[t], a0);
+                        a1 = fma(pw[POWER ? b - 1 : 0][POWER ? t + 1 : 0], x[t + 1], a1);
+                        a2 = fma(pw[POWER ? b - 1 : 0][POWER ? t + 2 : 0], x[t + 2], a2);
+                        a3 = fma(pw[POWER ? b - 1 : 0][POWER ? t + 3 : 0], x[t + 3], a3);
+                    }
+                } else {
+                    const double *Bb_ = Bq + (size_t)(b - 1) * MT * MT;
+#pragma unroll
+                    for (int t = 0; t < KQ; t += 4) {
+                        const double2 m01 = *reinterpret_cast<const double2 *>(Bb_ + t);
+                        const double2 m23 = *reinterpret_cast<const double2 *>(Bb_ + t + 2);
+                        a0 = fma(m01.x, x[t], a0); a1 = fma(m01.y, x[t + 1], a1);
+                        a2 = fma(m23.x, x[t + 2], a2); a3 = fma(m23.y, x[t + 3], a3);
+                    }
+                }
+                outv = quad_sum_d((a0 + a1) + (a2 + a3));
+                ++napp;
             }
-            bn = quad_sum_d((a0 + a1) + (a2 + a3)) * inv_cur;
+            bn = outv * inv_cur;
         } else {
             const int es = SMCPP_ES(ge);
             double wv;
@@ -518,17 +623,12 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
             }
         }
         bn = (i < M) ? bn : 0.0;
-        // running scale for the NEXT row from the sum of the vector this row consumed (off the critical path)
-        {
-            double s0 = (x[0] + x[1]) + (x[2] + x[3]);
-#pragma unroll
-            for (int t = 4; t < KQ; t += 4) s0 += (x[t] + x[t + 1]) + (x[t + 2] + x[t + 3]);
-            inv_cur = rcp_f64(quad_sum_d(s0));
-        }
+        inv_cur = inv_next;
         // exchanged vector for the next row; the last row of the chunk hands over plain beta (exact normalisation below)
         const bool e_next = ge_n < 0 && j + 1 < nrows;
         if (owner) xb[nxt * 4 * UP + (i / KQ) * UP + (i % KQ)] = e_next ? bn * e_nxt : bn;
         b_raw = bn;
+        kid_cur = kid_n;
         ge = ge_n; dp_cur = dp_nxt; d1 = d2;
         lds_barrier();
     }
@@ -554,55 +654,44 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
 // ---------------------------------------------------------------------------------------------------------------
 // Operands of the eigen-free pre-pass.  A_e = diag(e_key) T^T is the one-position forward operator of eigen key e
 // (the matrix whose eigensystem TransitionBundle::update takes, transition_bundle.cpp:15-25); a span-s row applies
-// A_e^s (forward) or its transpose (backward).  One workgroup per eigen key walks s = 2 .. max span with one
-// M x M x M product per step (A in LDS, the running power double-buffered in LDS) and stores the powers the key's
-// groups need, row-major and transposed.  span_gid[e][s] = group of (key e, span s) or -1.  Used only when the spans
-// are short and few (binned data); tens of microseconds, against 0.6 ms of host eigensolves it takes off the critical
-// path (engine.hip: estep).
+// A_e^s (forward) or its transpose (backward) as the product of the binary powers A^(2^b) of the set bits of s.
+// One workgroup per eigen key squares A four times (A^2, A^4, A^8, A^16: spans up to 31) in LDS and stores them as
+// float row-major (forward operand Bf[e][b-1][i][k]) and double transposed (backward operand Bb[e][b-1][i][k] =
+// A^(2^b)[k][i]).  Tens of microseconds, against 0.6 ms of host eigensolves taken off the critical path (engine.hip: estep).
 // ---------------------------------------------------------------------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(256) void k_group_powers(int M, int max_span, const int *__restrict__ e_kid,
-                                                       const int *__restrict__ span_gid, const double *__restrict__ E,
-                                                       const double *__restrict__ Td, double *__restrict__ Ag,
-                                                       double *__restrict__ AgT) {
+__global__ __launch_bounds__(256) void k_binary_powers(int M, const int *__restrict__ e_kid, const double *__restrict__ E,
+                                                        const double *__restrict__ Td, float *__restrict__ Bf,
+                                                        double *__restrict__ Bb) {
     constexpr int LD = MT + 1, CW = MT / 4;
     extern __shared__ __attribute__((aligned(16))) double smp[];
-    double *sA = smp;                       // [MT][MT]   A[k][c]   (read as rows of 16 contiguous columns: broadcast)
-    double *sP = smp + MT * MT;             // [2][MT][LD] running power, rows padded (lanes read different rows)
+    double *sP = smp;                       // [2][MT][LD] running power, rows padded
     const int e = blockIdx.x, tid = threadIdx.x;
     const double *em = E + (size_t)e_kid[e] * MT;
     for (int idx = tid; idx < MT * MT; idx += 256) {
         const int i = idx / MT, k = idx % MT;
-        const double v = (i < M && k < M) ? em[i] * Td[(size_t)k * MT + i] : 0.0;       // A[i][k] = e_i T[k][i]
-        sA[i * MT + k] = v;
-        sP[i * LD + k] = v;
+        sP[i * LD + k] = (i < M && k < M) ? em[i] * Td[(size_t)k * MT + i] : 0.0;       // A[i][k] = e_i T[k][i]
     }
     __syncthreads();
     const int i = tid >> 2, cb = (tid & 3) * CW;
-    const int *sg = span_gid + (size_t)e * (max_span + 1);
-    for (int sp = 2; sp <= max_span; ++sp) {
-        const double *Pc = sP + ((sp & 1) ? MT * LD : 0);        // power sp-1 lives in buffer (sp-1)&1... see below
-        double *Pn = sP + ((sp & 1) ? 0 : MT * LD);
+    for (int b = 0; b < 4; ++b) {
+        const double *Pc = sP + (b & 1) * MT * LD;
+        double *Pn = sP + ((b & 1) ^ 1) * MT * LD;
         double acc[CW];
 #pragma unroll
         for (int c = 0; c < CW; ++c) acc[c] = 0.0;
         if (i < MT) {
             for (int k = 0; k < MT; ++k) {
                 const double pv = Pc[i * LD + k];
-                const double *ar = sA + k * MT + cb;
+                const double *ar = Pc + k * LD + cb;
 #pragma unroll
                 for (int c = 0; c < CW; ++c) acc[c] = fma(pv, ar[c], acc[c]);
             }
-        }
-        const int g = sg[sp];
-        if (i < MT) {
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 Pn[i * LD + cb + c] = acc[c];
-                if (g >= 0) {
-                    Ag[(size_t)g * MT * MT + (size_t)i * MT + cb + c] = acc[c];
-                    AgT[(size_t)g * MT * MT + (size_t)(cb + c) * MT + i] = acc[c];
-                }
+                Bf[((size_t)e * 4 + b) * MT * MT + (size_t)i * MT + cb + c] = (float)acc[c];
+                Bb[((size_t)e * 4 + b) * MT * MT + (size_t)(cb + c) * MT + i] = acc[c];
             }
         }
         __syncthreads();

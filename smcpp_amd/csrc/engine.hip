@@ -210,14 +210,13 @@ struct smcpp_im {
     // solves the eigenproblems; only for short, few spans (binned data) and chunks short enough that pass 1 re-runs them whole
     bool power_ok = false, prepass_launched = false;
     int max_span_pw = 0;
-    std::vector<int> span_gid;             // [Ke][max_span_pw + 1] group of (eigen key, span) or -1
-    DevBuf<int> d_span_gid;
     PinnedArena pre_stage;                 // static operands of the pre-pass (pi, T, emission table): own pinned mirror
     char *d_pre = nullptr;
     size_t pre_cap = 0;
     bool static_packed = false;
     float pre_f_ms = 0.f, pre_b_ms = 0.f;
-    DevBuf<double> d_Ag, d_AgT;            // [G][Mp][Mp]
+    DevBuf<float> d_Bf;                    // [Ke][4][Mp][Mp] binary powers A^2..A^16 per eigen key (forward operand)
+    DevBuf<double> d_Bb;                   // [Ke][4][Mp][Mp] their transposes (backward operand)
     DevBuf<Chunk> d_chunks;
     DevBuf<Slab> d_slabs_sc, d_slabs_rk, d_slabs_eg;
     DevBuf<int2> d_perm1k;                 // span-1 rows sorted by key: {ell, key id} (one load resolves both)
@@ -580,18 +579,14 @@ void smcpp_im::setup_power() {
     int longest = 0;
     for (const Chunk &ch : chunks) longest = std::max(longest, ch.r1 - ch.r0);
     const char *pe = getenv("SMCPP_POWER_PREPASS");
-    // short, few spans (binned data) so that the powers are cheap; chunks short enough that pass 1 re-runs them whole
-    // anyway (the rows of the pre-pass are all overwritten: its normalisers carry no eigenvalue scale)
-    power_ok = chain_mode == 2 && coop_generation() == 2 && Mp <= 64 && Ke >= 1 && G >= 1 && G <= 512 && mx <= 64 &&
-               longest <= 2000 && !(pe && atoi(pe) == 0);
+    // spans below 32 (binned data: four squarings give every power); chunks short enough that pass 1 re-runs them whole
+    // anyway (the rows of the pre-pass are all overwritten: it runs in float and its normalisers carry no eigenvalue scale)
+    power_ok = chain_mode == 2 && coop_generation() == 2 && Mp <= 64 && Ke >= 1 && G >= 1 && mx <= 31 && longest <= 2000 &&
+               !(pe && atoi(pe) == 0);
     max_span_pw = mx;
     if (!power_ok) return;
-    span_gid.assign((size_t)Ke * (mx + 1), -1);
-    for (int g = 0; g < G; ++g) span_gid[(size_t)groups[g].eig * (mx + 1) + groups[g].span] = g;
-    d_span_gid.upload(span_gid, stream);
-    d_Ag.alloc((size_t)G * Mp * Mp);
-    d_AgT.alloc((size_t)G * Mp * Mp);
-    HIPCHK(hipStreamSynchronize(stream));
+    d_Bf.alloc((size_t)Ke * 4 * Mp * Mp);
+    d_Bb.alloc((size_t)Ke * 4 * Mp * Mp);
 }
 
 void smcpp_im::alloc_device() {
@@ -1112,7 +1107,7 @@ ChainArgs smcpp_im::chain_args() {
     a.eps_f = eps_f; a.eps_b = eps_b;
     a.dbg = nullptr;
     a.warm_f = nullptr; a.warm_b = nullptr;
-    a.Ag = d_Ag.p; a.AgT = d_AgT.p;
+    a.Bf = d_Bf.p; a.Bb = d_Bb.p; a.g_span = d_g_span.p;
     a.changed = nullptr;
     return a;
 }
@@ -1176,10 +1171,10 @@ void smcpp_im::stage_static_and_prepass() {
     d_changed_f.zero(s);
     d_changed_b.zero(s);
     {
-        const size_t shm = (size_t)(Mp * Mp + 2 * Mp * (Mp + 1)) * sizeof(double);
+        const size_t shm = (size_t)(2 * Mp * (Mp + 1)) * sizeof(double);
         switch (Mp) {
-#define P_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_group_powers<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
-                    hipLaunchKernelGGL(k_group_powers<x>, dim3(Ke), dim3(256), shm, s, M, max_span_pw, (const int *)d_e_kid.p, (const int *)d_span_gid.p, a.E, pre_Td, d_Ag.p, d_AgT.p); } break;
+#define P_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_binary_powers<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
+                    hipLaunchKernelGGL(k_binary_powers<x>, dim3(Ke), dim3(256), shm, s, M, (const int *)d_e_kid.p, a.E, pre_Td, d_Bf.p, d_Bb.p); } break;
             P_(16) P_(32) P_(48) P_(64)
 #undef P_
             default: throw std::runtime_error("internal: power pre-pass with an unsupported state count");
@@ -1191,6 +1186,8 @@ void smcpp_im::stage_static_and_prepass() {
     coop_lds(Mp, K, G, tab_c, shm_c);
     CoopArgs cargs;
     cargs.K = K; cargs.G = G;
+    cargs.power_off = (int)shm_c;          // two scratch vectors behind the regular carve-up
+    shm_c += 2048;
     a.variant = 1; a.pass = 0;
     if (sb != s) {
         HIPCHK(hipEventRecord(ev[6], s));
@@ -1214,7 +1211,7 @@ void smcpp_im::run_chains() {
     ChainArgs a = chain_args();
     const bool generic = chain_mode == 0;
     CoopArgs cargs;
-    cargs.K = K; cargs.G = G;
+    cargs.K = K; cargs.G = G; cargs.power_off = 0;
     BigArgs bargs;
     bargs.qTf = d_qTf.p; bargs.qPinvT = d_qPinvT.p; bargs.qPT = d_qPT.p; bargs.qTdT = d_qTdT.p;
     bargs.qPrm = d_qPrm.p; bargs.qPinvrm = d_qPinvrm.p;

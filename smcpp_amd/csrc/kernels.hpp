@@ -132,7 +132,11 @@ struct ChainArgs {
     long long *dbg;         // optional [8]: cycle counters of workgroup 0 (SMCPP_DEBUG_CYCLES)
     // optional warm start (cooperative kernels): the converged chunk-boundary vectors of the previous E-step of this
     // manager, used instead of pi / the uniform vector as pass-0 start vectors; nullptr = cold start
-    const double *Ag, *AgT; // [G][Mp][Mp] group powers (diag(e) T^T)^span and their transposes (eigen-free pre-pass only)
+    // eigen-free pre-pass only: binary powers A^2, A^4, A^8, A^16 of A = diag(e) T^T per eigen key, float row-major for
+    // the forward chain, double transposed for the backward chain; span of every group
+    const float *Bf;        // [Ke][4][Mp][Mp]
+    const double *Bb;       // [Ke][4][Mp][Mp]
+    const int *g_span;      // [G]
     const float *warm_f;    // [nchunks][Mp] end vectors of the forward chunks
     const double *warm_b;   // [nchunks][Mp] end vectors of the backward chunks
 };
@@ -820,6 +824,7 @@ __device__ __forceinline__ float quad_sum_f(float v) {
 
 struct CoopArgs {
     int K, G;
+    int power_off;   // byte offset of the scratch vectors of the eigen-free pre-pass in the dynamic LDS
 };
 
 // Makes the compiler wait for a loaded value HERE (an empty asm that reads and writes the register).  Without it the

@@ -342,6 +342,46 @@ def test_state_count_sweep_vs_oracle(M, n, length, chunk):
             assert not np.any(margin[mism] > 1e-5)
 
 
+@pytest.mark.parametrize("M,n", [(64, 20), (32, 10), (48, 7), (16, 4)])
+def test_eigen_free_prepass_on_and_off_vs_oracle(M, n):
+    """The two ways the cooperative chains run on binned data (spans < 32): eigensystem kernels only
+    (SMCPP_POWER_PREPASS=0) and eigen-free pre-pass + a full eigensystem pass (the default).  Each against the C
+    restatement at the stated tolerances, and against each other far below them (every stored row comes from the
+    eigensystem kernels either way; the pre-pass only changes the start vectors of the chunks)."""
+    import os
+    from oracle import oracle
+    from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel
+    hs = synth.hidden_states(M)
+    a, s = synth.model_pieces()
+    contigs = [synth.synth_contig(300 + M, 3_000_000, n), synth.synth_contig(301 + M, 150_000, n)]
+    res = {}
+    for mode in (0, 1):
+        os.environ["SMCPP_POWER_PREPASS"] = str(mode)
+        try:
+            im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
+            im.model = PiecewiseModel(a, s, 1e4, "pop1")
+            im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0
+            for _ in range(2):            # the second E-step pre-queues as many passes as the first one needed
+                im.E_step()
+            res[mode] = (np.array(im.logliks()), im.xisums, im.gamma_sums, np.array(im.Q(separate=True)))
+        finally:
+            os.environ.pop("SMCPP_POWER_PREPASS", None)
+    pi, T, keys = im.pi, im.transition, im.keys
+    ep = im.emission_probs
+    Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
+    for c, ob in enumerate(contigs):
+        o = oracle.estep(pi, T, keys, Etab, ob)
+        for mode, (lls, xs, gss, q) in res.items():
+            assert abs(lls[c] - o["loglik"]) <= LL_TOL * abs(o["loglik"]), mode
+            assert rel_err(xs[c], o["xisum"]) <= STAT_TOL, mode
+            for k, v in o["gamma_sums"].items():
+                assert np.max(np.abs(gss[c][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300), (mode, k)
+    for mode in (1,):
+        assert np.all(np.abs(res[mode][0] - res[0][0]) <= 1e-8 * np.abs(res[0][0])), mode
+        assert np.all(np.abs(res[mode][3] - res[0][3]) <= 1e-6 * np.maximum(np.abs(res[0][3]), 1e-12)), mode
+
+
 def test_many_tiny_contigs():
     """300 contigs of 1-40 rows each (ragged, most shorter than any chunk): per-contig results against the oracle."""
     from oracle import oracle

@@ -12,6 +12,8 @@
 // Pinned by tests/test_prep.py against the compiled reference (oracle/_ref: ref_prep) and the golden parameter files.
 #pragma once
 #include <gmp.h>
+#include <functional>
+#include <exception>
 
 #include <algorithm>
 #include <array>
@@ -837,18 +839,15 @@ struct CsfsPieceTables {
     std::vector<S> Ppre;     // [n+1][K+1]   rate = C(j,2)-1, j = 2..n+2 : prefix sums of the "below" integrals
 };
 
+// Fills t (sized by the caller) with orphaned work-sharing loops: call from every thread of a parallel region (each with
+// its DualScope set); returns after the barrier that ends the second loop.
 template <typename S>
-inline CsfsPieceTables<S> csfs_piece_tables(const RateFunctionT<S> &eta, int n, bool below_only) {
-    CsfsPieceTables<S> t;
+inline void csfs_piece_tables_ws(const RateFunctionT<S> &eta, int n, bool above, CsfsPieceTables<S> &t) {
     const int K = eta.K;
-    t.K = K; t.n = n;
     const std::vector<double> &ts = eta.ts;
-    const int nd = dual_nder();
-    if (!below_only && n >= 1) {
-        t.Ssuf.assign((size_t)n * K, S(0.0));
-#pragma omp parallel for schedule(static)
+    if (above) {
+#pragma omp for schedule(static) nowait
         for (int jr = 0; jr < n; ++jr) {
-            DualScope sc(nd);
             const double rate = (double)RateFunctionT<S>::nC2(jr + 2);
             S *Sj = &t.Ssuf[(size_t)jr * K];
             Sj[K - 1] = S(0.0);
@@ -861,10 +860,8 @@ inline CsfsPieceTables<S> csfs_piece_tables(const RateFunctionT<S> &eta, int n, 
             }
         }
     }
-    t.Ppre.assign((size_t)(n + 1) * (K + 1), S(0.0));
-#pragma omp parallel for schedule(static)
+#pragma omp for schedule(static)
     for (int jr = 0; jr < n + 1; ++jr) {
-        DualScope sc(nd);
         const long ratel = RateFunctionT<S>::nC2(jr + 2) - 1;
         const double rate = (double)ratel;
         S *Pj = &t.Ppre[(size_t)jr * (K + 1)];
@@ -878,7 +875,6 @@ inline CsfsPieceTables<S> csfs_piece_tables(const RateFunctionT<S> &eta, int n, 
             Pj[m + 1] = Pj[m] + g;
         }
     }
-    return t;
 }
 
 // Accurate sum of v[0..cnt).  The reference sorts the terms by decreasing magnitude and applies doubly-compensated
@@ -908,12 +904,18 @@ inline Dual<F> accurate_sum(const Dual<F> *v, int cnt) {
     return r;
 }
 
+// `side` (optional): an independent serial job of the caller (the transition matrix, 0.06 ms) that one thread of this
+// function's parallel region runs while the others already work on hidden states.
 template <typename S>
-inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, const CsfsTables &tb, bool below_only = false) {
+inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, const CsfsTables &tb, bool below_only = false,
+                                                   const std::function<void()> *side = nullptr) {
     const bool direct = csfs_direct_flag() != 0;
     bool zero_ada = false;
     for (const S &x : eta.ada) zero_ada = zero_ada || sval(x) == 0;
-    if (direct || zero_ada) return conditioned_sfs_direct<S>(eta, tb, below_only);   // ada == 0: the factored sums divide by it
+    if (direct || zero_ada) {                                                        // ada == 0: the factored sums divide by it
+        if (side) (*side)();
+        return conditioned_sfs_direct<S>(eta, tb, below_only);
+    }
     typedef RateFunctionT<S> RF;
     const int n = tb.n;
     const int M = (int)eta.hidden_states.size() - 1;
@@ -923,11 +925,32 @@ inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, 
     const std::vector<S> &ada = eta.ada, &Rrng = eta.Rrng;
     const std::vector<int> &hsi = eta.hs_indices;
     const bool above = n >= 1 && !below_only;
-    const CsfsPieceTables<S> pt = csfs_piece_tables<S>(eta, n, below_only);
+    // one parallel region for everything: the piece tables (a few microseconds, static), then - without a barrier in
+    // between - the caller's side job on whichever thread gets there first and the hidden states on all of them
+    CsfsPieceTables<S> pt;
+    pt.K = K; pt.n = n;
+    if (above) pt.Ssuf.assign((size_t)n * K, S(0.0));
+    pt.Ppre.assign((size_t)(n + 1) * (K + 1), S(0.0));
     std::vector<std::vector<S>> csfs(M, std::vector<S>((size_t)3 * (n + 1), S(0.0)));
+    std::exception_ptr side_err;
+    static const bool tm = getenv("SMCPP_HOST_TIMING") != nullptr;
+    double tmark[64][4] = {};
+    const auto tbase = std::chrono::steady_clock::now();
+    auto now_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tbase).count(); };
 #pragma omp parallel
     {
         DualScope sc(nd);
+        const int tid_ = omp_get_thread_num();
+        if (tm && tid_ < 64) tmark[tid_][0] = now_us();
+        csfs_piece_tables_ws<S>(eta, n, above, pt);       // orphaned work-sharing loops, barrier at the end
+        if (tm && tid_ < 64) tmark[tid_][1] = now_us();
+#pragma omp single nowait
+        {
+            if (side) {
+                try { (*side)(); } catch (...) { side_err = std::current_exception(); }
+            }
+        }
+        if (tm && tid_ < 64) tmark[tid_][2] = now_us();
         std::vector<S> Ca(above ? (size_t)(n + 1) * n : 0), A(n + 1), A1(n + 1), B(n + 1), El(n + 1), ert(n), e1(n), tmp0(n + 1), tmp2(n + 1), v(n),
             below(n + 1);
 #pragma omp for schedule(dynamic)
@@ -1032,8 +1055,17 @@ inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, 
                 for (int j = 0; j < n + 1; ++j) s += below[j] * tb.M1(j, b);
                 out[1 * (n + 1) + b] += s;
             }
+            if (tm && tid_ < 64) tmark[tid_][3] = now_us();      // nowait loop below: last state finished by this thread
         }
     }
+    if (tm) {
+        const double tend = now_us();
+        fprintf(stderr, "[csfs] region %.1f us; per thread (enter, tables done, side done, last state):", tend);
+        for (int t = 0; t < std::min(64, omp_get_max_threads()); ++t)
+            fprintf(stderr, " [%.0f %.0f %.0f %.0f]", tmark[t][0], tmark[t][1], tmark[t][2], tmark[t][3]);
+        fprintf(stderr, "\n");
+    }
+    if (side_err) std::rethrow_exception(side_err);
     return csfs;
 }
 
@@ -1079,9 +1111,10 @@ public:
         for (S &x : pi) { if (sval(x) < 1e-20) x = S(1e-20); ps += x; }
         for (S &x : pi) x /= ps;
         auto t1 = clk();
-        T = compute_transition<S>(eta, rho);
-        auto t2 = clk();
-        std::vector<std::vector<S>> sfs = conditioned_sfs<S>(eta, *tables_);
+        auto t2 = t1;
+        // the transition matrix (serial, long double) rides along in the conditioned SFS's parallel region
+        const std::function<void()> side = [&] { T = compute_transition<S>(eta, rho); };
+        std::vector<std::vector<S>> sfs = conditioned_sfs<S>(eta, *tables_, false, &side);
         auto t3 = clk();
         incorporate_theta<S>(sfs, theta);
         if (emission_out) {                      // InferenceManager::emission: the table per state, flattened row-major
@@ -1092,7 +1125,7 @@ public:
         emission_probs<S>(sfs, avg_ct, theta, alpha, keys, K, E);
         if (tm) {
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            fprintf(stderr, "[prep] rate+pi %.3f ms, transition %.3f ms, csfs %.3f ms, theta+emission %.3f ms\n", ms(t0, t1),
+            fprintf(stderr, "[prep] rate+pi %.3f ms, (transition inside csfs: %.3f) csfs+transition %.3f ms, theta+emission %.3f ms\n", ms(t0, t1),
                     ms(t1, t2), ms(t2, t3), ms(t3, clk()));
         }
     }

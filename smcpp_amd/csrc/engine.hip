@@ -217,6 +217,10 @@ struct smcpp_im {
     float pre_f_ms = 0.f, pre_b_ms = 0.f;
     DevBuf<float> d_Bf;                    // [Ke][4][Mp][Mp] binary powers A^2..A^16 per eigen key (forward operand)
     DevBuf<double> d_Bb;                   // [Ke][4][Mp][Mp] their transposes (backward operand)
+    // pre-pass of the streamed-operand chains (64 < M <= 256): device-built layouts of T and of the powers A .. A^16
+    DevBuf<double> d_W, d_pre_qTdT;        // [Ke][5][Mp][Mp] row-major powers (fp64) / [KQ][Mp][4]
+    DevBuf<float> d_qBf, d_qBb, d_pre_qTf; // [Ke][5][KQ][Mp][4] float streaming layouts / [KQ][Mp][4]
+    BigArgs pre_bargs;
     DevBuf<Chunk> d_chunks;
     DevBuf<Slab> d_slabs_sc, d_slabs_rk, d_slabs_eg;
     DevBuf<int2> d_perm1k;                 // span-1 rows sorted by key: {ell, key id} (one load resolves both)
@@ -581,10 +585,20 @@ void smcpp_im::setup_power() {
     const char *pe = getenv("SMCPP_POWER_PREPASS");
     // spans below 32 (binned data: four squarings give every power); chunks short enough that pass 1 re-runs them whole
     // anyway (the rows of the pre-pass are all overwritten: it runs in float and its normalisers carry no eigenvalue scale)
-    power_ok = chain_mode == 2 && coop_generation() == 2 && Mp <= 64 && Ke >= 1 && G >= 1 && mx <= 31 && longest <= 2000 &&
-               !(pe && atoi(pe) == 0);
+    const bool coop_pre = chain_mode == 2 && coop_generation() == 2 && Mp <= 64;
+    const bool big_pre = chain_mode == 3 && Mp > 64 && Mp <= 256;
+    power_ok = (coop_pre || big_pre) && Ke >= 1 && G >= 1 && mx <= 31 && longest <= 2000 && !(pe && atoi(pe) == 0);
     max_span_pw = mx;
     if (!power_ok) return;
+    if (big_pre) {
+        const size_t MM = (size_t)Mp * Mp;
+        d_W.alloc((size_t)Ke * 5 * MM);
+        d_qBf.alloc((size_t)Ke * 5 * MM);
+        d_qBb.alloc((size_t)Ke * 5 * MM);
+        d_pre_qTf.alloc(MM);
+        d_pre_qTdT.alloc(MM);
+        return;
+    }
     d_Bf.alloc((size_t)Ke * 4 * Mp * Mp);
     d_Bb.alloc((size_t)Ke * 4 * Mp * Mp);
 }
@@ -1037,6 +1051,11 @@ static bool launch_chain_coop(bool fwd, int Mp, const ChainArgs &a, const CoopAr
 
 template <int MT_>
 static void launch_chain_big_t(bool fwd, const ChainArgs &a, const BigArgs &qa, hipStream_t s) {
+    if (a.variant == 1) {          // eigen-free pre-pass
+        if (fwd) hipLaunchKernelGGL((k_fwd_big<MT_, true>), dim3(a.nchunks), dim3(MT_ * 4), 0, s, a, qa);
+        else hipLaunchKernelGGL((k_bwd_big<MT_, true>), dim3(a.nchunks), dim3(MT_ * 4), 0, s, a, qa);
+        return;
+    }
     if (fwd) hipLaunchKernelGGL((k_fwd_big<MT_>), dim3(a.nchunks), dim3(MT_ * 4), 0, s, a, qa);
     else hipLaunchKernelGGL((k_bwd_big<MT_>), dim3(a.nchunks), dim3(MT_ * 4), 0, s, a, qa);
 }
@@ -1162,6 +1181,42 @@ void smcpp_im::stage_static_and_prepass() {
         return dp;
     };
     ChainArgs a = chain_args();
+    if (chain_mode == 3) {
+        // streamed-operand chains: pi, T (row-major) and the emission table go up, everything else is built on the device
+        a.pi_f = reinterpret_cast<const float *>(put(hs_pi_f.data(), hs_pi_f.size() * 4));
+        const double *pre_Td = reinterpret_cast<const double *>(put(hs_Td.data(), hs_Td.size() * 8));
+        a.E = reinterpret_cast<const double *>(put(hs_Ep.data(), hs_Ep.size() * 8));
+        HIPCHK(hipMemcpyAsync(d_pre, pre_stage.base, off, hipMemcpyHostToDevice, s));
+        d_changed_f.zero(s);
+        d_changed_b.zero(s);
+        const int nb = ceil_div((long long)MM, 256);
+        hipLaunchKernelGGL(k_big_tq, dim3(nb), dim3(256), 0, s, Mp, pre_Td, d_pre_qTf.p, d_pre_qTdT.p);
+        hipLaunchKernelGGL(k_pow_init, dim3(nb, Ke), dim3(256), 0, s, M, Mp, (const int *)d_e_kid.p, a.E, pre_Td, d_W.p);
+        for (int b = 0; b < 4; ++b)
+            hipLaunchKernelGGL(k_sq_f64, dim3(Mp / 16, Mp / 16, Ke), dim3(64), 0, s, Mp, (const double *)(d_W.p + (size_t)b * MM),
+                               d_W.p + (size_t)(b + 1) * MM, (size_t)5 * MM);
+        hipLaunchKernelGGL(k_pow_layout, dim3(nb, Ke * 5), dim3(256), 0, s, Mp, (const double *)d_W.p, d_qBf.p, d_qBb.p);
+        pre_bargs = BigArgs();
+        pre_bargs.qTf = d_pre_qTf.p; pre_bargs.qTdT = d_pre_qTdT.p;
+        pre_bargs.qPinvT = pre_bargs.qPT = pre_bargs.qPrm = pre_bargs.qPinvrm = nullptr;
+        pre_bargs.qBf = d_qBf.p; pre_bargs.qBb = d_qBb.p;
+        a.variant = 1; a.pass = 0;
+        if (sb != s) {
+            HIPCHK(hipEventRecord(ev[6], s));
+            HIPCHK(hipStreamWaitEvent(sb, ev[6], 0));
+        }
+        HIPCHK(hipEventRecord(ev[10], s));
+        a.changed = d_changed_f.p;
+        launch_chain_big(true, Mp, a, pre_bargs, s);
+        HIPCHK(hipEventRecord(ev[11], s));
+        HIPCHK(hipEventRecord(ev[12], sb));
+        a.changed = d_changed_b.p;
+        launch_chain_big(false, Mp, a, pre_bargs, sb);
+        HIPCHK(hipEventRecord(ev[13], sb));
+        HIPCHK(hipGetLastError());
+        prepass_launched = true;
+        return;
+    }
     a.pi_f = reinterpret_cast<const float *>(put(hs_pi_f.data(), hs_pi_f.size() * 4));
     a.Tf = reinterpret_cast<const float *>(put(hs_Tf.data(), hs_Tf.size() * 4));
     a.TdT = reinterpret_cast<const double *>(put(hs_TdT.data(), hs_TdT.size() * 8));
@@ -1214,7 +1269,7 @@ void smcpp_im::run_chains() {
     cargs.K = K; cargs.G = G; cargs.power_off = 0;
     BigArgs bargs;
     bargs.qTf = d_qTf.p; bargs.qPinvT = d_qPinvT.p; bargs.qPT = d_qPT.p; bargs.qTdT = d_qTdT.p;
-    bargs.qPrm = d_qPrm.p; bargs.qPinvrm = d_qPinvrm.p;
+    bargs.qPrm = d_qPrm.p; bargs.qPinvrm = d_qPinvrm.p; bargs.qBf = nullptr; bargs.qBb = nullptr;
     size_t shm_c = 0;
     int tab_c = 0;
     coop_lds(Mp, K, G, tab_c, shm_c);

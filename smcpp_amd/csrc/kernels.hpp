@@ -1329,6 +1329,10 @@ struct BigArgs {
     const double *qTdT;      // [KQ][Mp][4]            backward span-1 operand
     const double *qPrm;      // [Ke][KQ][Mp][4]        backward eigen operands
     const double *qPinvrm;
+    // eigen-free pre-pass (PRE instantiations): float binary powers A^(2^b), b = 0..4, of A = diag(e) T^T per eigen key,
+    // qBf: Q[t][i][kq] = A^p[i][kq*KQ + t] (forward), qBb: Q[t][i][kq] = A^p[kq*KQ + t][i] (backward)   (k_pow_layout)
+    const float *qBf;        // [Ke][5][KQ][Mp][4]
+    const float *qBb;        // [Ke][5][KQ][Mp][4]
 };
 
 // One streamed quarter product: acc = sum_t q[t*QS] * x(t), with B independent loads in flight per batch (the whole
@@ -1354,12 +1358,17 @@ __device__ __forceinline__ auto stream_dot(const TM *__restrict__ q, size_t QS, 
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-template <int MT>
+// PRE = eigen-free pre-pass (engine.hip: stage_static_and_prepass): eigen rows apply the float binary powers of
+// A = diag(e) T^T, one per set bit of the span, nothing is stored but the chunk's end vector - it only has to hand pass 1
+// (a.variant == 2: a full pass from those end vectors, no skip test, no merge exit) a start vector while the host is
+// still solving the eigenproblems.
+template <int MT, bool PRE = false>
 __global__ __launch_bounds__(MT * 4) void k_fwd_big(ChainArgs a, BigArgs qa) {
     constexpr int NW = MT / 16, KQ = MT / 4, Mp = MT, UP = KQ + 2, QS = 4 * MT;   // QS = stride of one k-step in a Q layout
     constexpr int FB = 16, DB = (MT > 128) ? 8 : 16;   // loads in flight per lane (1024 threads leave 128 VGPRs each)
     __shared__ __attribute__((aligned(16))) double ub[4 * UP];
     __shared__ __attribute__((aligned(16))) float xf[2 * MT];
+    __shared__ __attribute__((aligned(16))) float tbf[PRE ? 2 * MT : 4];
     __shared__ int2 sdesc[128];
     __shared__ int sflag;
     __shared__ int mflag[NW];
@@ -1367,11 +1376,12 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_big(ChainArgs a, BigArgs qa) {
     const int il = lane >> 2, kq = lane & 3, i = 16 * w + il;
     const bool owner = kq == 0;
     const int M = a.M, pass = a.pass, c = blockIdx.x;
+    const bool full = a.variant == 2;
     if (pass > 0 && a.changed[pass - 1] == 0) return;
     const Chunk ch = a.chunks[c];
     float *end_cur = a.ends_f + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
     const float *end_prev = a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
-    if (pass > 0 && ch.first) {
+    if (pass > 0 && !full && ch.first) {
         if (owner) end_cur[i] = end_prev[i];
         return;
     }
@@ -1384,7 +1394,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_big(ChainArgs a, BigArgs qa) {
     if (tid == 0) sflag = 0;
     if (lane == 0) mflag[w] = 1;
     __syncthreads();
-    if (pass > 0) {
+    if (pass > 0 && !full) {
         bool diff = false;
         if (owner && i < M) {
             const float u = a.used_f[(size_t)c * Mp + i];
@@ -1399,7 +1409,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_big(ChainArgs a, BigArgs qa) {
     }
     if (owner) a.used_f[(size_t)c * Mp + i] = al;
     if (tid == 0) a.changed[pass] = 1;
-    if (ch.first) {
+    if (ch.first && !PRE) {
         if (owner) a.alpha[(size_t)ch.base * Mp + i] = al;
         if (tid == 0) a.cnorm[ch.base] = 1.0;
     }
@@ -1415,7 +1425,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_big(ChainArgs a, BigArgs qa) {
     constexpr int FBB = (KQ % FB == 0) ? FB : 4, DBB = (KQ % DB == 0) ? DB : 4;
     const int rotf = (int)((blockIdx.x * 7u) % (unsigned)(KQ / FBB)) * FBB, rotd = (int)((blockIdx.x * 7u) % (unsigned)(KQ / DBB)) * DBB;
     float v_prev = al;
-    const bool rerun = pass > 0;
+    const bool rerun = pass > 0 && !full;
     bool merged = false;
     for (int j = 0; j < nrows; ++j) {
         const int ell = ch.r0 + 1 + j;
@@ -1454,8 +1464,8 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_big(ChainArgs a, BigArgs qa) {
                 const bool anyb = __any(bad);
                 if (lane == 0) mflag[w] = anyb ? 1 : 0;
             }
-            if (owner) a.alpha[(size_t)(ch.base + ell - 1) * Mp + i] = an;
-            if (tid == 0) a.cnorm[ch.base + ell - 1] = (double)sprev;
+            if (owner && !PRE) a.alpha[(size_t)(ch.base + ell - 1) * Mp + i] = an;
+            if (tid == 0 && !PRE) a.cnorm[ch.base + ell - 1] = (double)sprev;
         }
         float vout;
         if (ge < 0) {
@@ -1464,6 +1474,27 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_big(ChainArgs a, BigArgs qa) {
             const float dot = stream_dot<KQ, FB>(q, QS, rotf, [&](int t) { return fmaxf(xin[t], thr); });
             const float y = quad_sum_f(dot) * inv;
             vout = (i < M) ? (float)((double)y * e_cur) : 0.f;
+        } else if (PRE) {
+            const int es = SMCPP_ES(ge);
+            const int sp = a.g_span[SMCPP_GID(ge)];
+            float outv = 0.f;
+            int napp = 0;
+            for (int b = 0; b < 5; ++b) {
+                if (!((sp >> b) & 1)) continue;
+                const float *q = qa.qBf + ((size_t)es * 5 + b) * Mp * Mp + qoff;
+                float dot;
+                if (napp == 0) dot = stream_dot<KQ, FB>(q, QS, rotf, [&](int t) { return fmaxf(xin[t], thr); });
+                else {
+                    float *tb = tbf + (napp & 1) * MT;
+                    if (owner) tb[i] = outv;
+                    lds_barrier();
+                    const float *tin = tb + kq * KQ;
+                    dot = stream_dot<KQ, FB>(q, QS, rotf, [&](int t) { return tin[t]; });
+                }
+                outv = quad_sum_f(dot);
+                ++napp;
+            }
+            vout = (i < M) ? outv * inv : 0.f;
         } else {
             const int es = SMCPP_ES(ge);
             const double dp_cur = a.dpow[(size_t)SMCPP_GID(ge) * Mp + i];
@@ -1495,19 +1526,20 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_big(ChainArgs a, BigArgs qa) {
         if (owner) {
             float an = v_prev * inv;
             an = (i < M) ? fmaxf(an, 1e-10f) : 0.f;
-            a.alpha[(size_t)(ch.base + ch.r1) * Mp + i] = an;
+            if (!PRE) a.alpha[(size_t)(ch.base + ch.r1) * Mp + i] = an;
             end_cur[i] = an;
         }
-        if (tid == 0) a.cnorm[ch.base + ch.r1] = (double)sprev;
+        if (tid == 0 && !PRE) a.cnorm[ch.base + ch.r1] = (double)sprev;
     }
 }
 
-template <int MT>
+template <int MT, bool PRE = false>
 __global__ __launch_bounds__(MT * 4) void k_bwd_big(ChainArgs a, BigArgs qa) {
     constexpr int NW = MT / 16, KQ = MT / 4, Mp = MT, UP = KQ + 2, QS = 4 * MT;
     constexpr int DB = (MT > 128) ? 8 : 16;
     __shared__ __attribute__((aligned(16))) double ub[4 * UP];
     __shared__ __attribute__((aligned(16))) double xb[2 * 4 * UP];
+    __shared__ __attribute__((aligned(16))) double tbd[PRE ? 2 * 4 * UP : 2];
     __shared__ int2 sdesc[128];
     __shared__ int sflag;
     __shared__ int mflag[NW];
@@ -1515,11 +1547,12 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_big(ChainArgs a, BigArgs qa) {
     const int il = lane >> 2, kq = lane & 3, i = 16 * w + il;
     const bool owner = kq == 0;
     const int M = a.M, pass = a.pass, c = blockIdx.x;
+    const bool full = a.variant == 2;
     if (pass > 0 && a.changed[pass - 1] == 0) return;
     const Chunk ch = a.chunks[c];
     double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
     const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
-    if (pass > 0 && ch.last) {
+    if (pass > 0 && !full && ch.last) {
         if (owner) end_cur[i] = end_prev[i];
         return;
     }
@@ -1532,7 +1565,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_big(ChainArgs a, BigArgs qa) {
     if (tid == 0) sflag = 0;
     if (lane == 0) mflag[w] = 1;
     __syncthreads();
-    if (pass > 0) {
+    if (pass > 0 && !full) {
         bool diff = false;
         if (owner && i < M) {
             const double u = a.used_b[(size_t)c * Mp + i];
@@ -1559,7 +1592,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_big(ChainArgs a, BigArgs qa) {
     constexpr int DBB = (KQ % DB == 0) ? DB : 4;
     const int rotd = (int)((blockIdx.x * 7u) % (unsigned)(KQ / DBB)) * DBB;
     double b_raw = b;
-    const bool rerun = pass > 0;
+    const bool rerun = pass > 0 && !full;
     bool merged = false;
     for (int j = 0; j < nrows; ++j) {
         const int ell = ch.r1 - j;
@@ -1595,7 +1628,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_big(ChainArgs a, BigArgs qa) {
                 const bool anyb = __any(bad);
                 if (lane == 0) mflag[w] = anyb ? 1 : 0;
             }
-            if (owner) a.beta[(size_t)(ch.base + ell) * Mp + i] = bnrm;
+            if (owner && !PRE) a.beta[(size_t)(ch.base + ell) * Mp + i] = bnrm;
         }
         double bn;
         if (ge < 0) {
@@ -1603,6 +1636,27 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_big(ChainArgs a, BigArgs qa) {
             const double *eq = a.E + (size_t)kid * Mp + kq * KQ;
             const double *q = qa.qTdT + qoff;
             bn = quad_sum_d(stream_dot<KQ, DB>(q, QS, rotd, [&](int t) { return eq[t] * xin[t]; })) * inv;
+        } else if (PRE) {
+            const int es = SMCPP_ES(ge);
+            const int sp = a.g_span[SMCPP_GID(ge)];
+            double outv = 0.0;
+            int napp = 0;
+            for (int b = 0; b < 5; ++b) {
+                if (!((sp >> b) & 1)) continue;
+                const float *q = qa.qBb + ((size_t)es * 5 + b) * Mp * Mp + qoff;
+                double dot;
+                if (napp == 0) dot = stream_dot<KQ, DB>(q, QS, rotd, [&](int t) { return xin[t]; });
+                else {
+                    double *tb = tbd + (napp & 1) * 4 * UP;
+                    if (owner) tb[(i / KQ) * UP + (i % KQ)] = outv;
+                    lds_barrier();
+                    const double *tin = tb + kq * UP;
+                    dot = stream_dot<KQ, DB>(q, QS, rotd, [&](int t) { return tin[t]; });
+                }
+                outv = quad_sum_d(dot);
+                ++napp;
+            }
+            bn = outv * inv;
         } else {
             const int es = SMCPP_ES(ge);
             const double dp_cur = a.dpow[(size_t)SMCPP_GID(ge) * Mp + i];
@@ -1633,9 +1687,61 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_big(ChainArgs a, BigArgs qa) {
         if (owner) {
             const double bf = (i < M) ? b_raw / sprev : 0.0;
             end_cur[i] = bf;
-            if (ch.first) a.beta[(size_t)ch.base * Mp + i] = bf;
+            if (ch.first && !PRE) a.beta[(size_t)ch.base * Mp + i] = bf;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Operands of the eigen-free pre-pass for 64 < M <= 256, built on the device from the row-major transition matrix and
+// the emission table right after they are uploaded (the host is busy with the eigenproblems): the two streaming layouts
+// of T, A_e = diag(e) T^T per eigen key, its squares A^2 .. A^16 (fp64 MFMA, one 16 x 16 tile per wavefront) and the
+// float streaming layouts of all five powers.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_big_tq(int Mp, const double *__restrict__ Td, float *__restrict__ qTf,
+                                                 double *__restrict__ qTdT) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= Mp * Mp) return;
+    const int KQ = Mp / 4, q = d & 3, i = (d >> 2) % Mp, t = (d >> 2) / Mp, k = q * KQ + t;
+    qTf[d] = (float)Td[(size_t)k * Mp + i];          // Tf[k][i]
+    qTdT[d] = Td[(size_t)i * Mp + k];                 // TdT[k][i] = T[i][k]
+}
+
+__global__ __launch_bounds__(256) void k_pow_init(int M, int Mp, const int *__restrict__ e_kid, const double *__restrict__ E,
+                                                   const double *__restrict__ Td, double *__restrict__ W) {
+    const int idx = blockIdx.x * 256 + threadIdx.x, e = blockIdx.y;
+    if (idx >= Mp * Mp) return;
+    const int i = idx / Mp, k = idx % Mp;
+    const double ev = E[(size_t)e_kid[e] * Mp + i];
+    W[(size_t)e * 5 * Mp * Mp + idx] = (i < M && k < M) ? ev * Td[(size_t)k * Mp + i] : 0.0;     // A[i][k] = e_i T[k][i]
+}
+
+// dst = src * src, row-major [Mp][Mp]; grid (Mp/16, Mp/16, Ke), one wavefront per 16 x 16 tile; `stride` = doubles between
+// the matrices of consecutive eigen keys
+__global__ __launch_bounds__(64) void k_sq_f64(int Mp, const double *__restrict__ src, double *__restrict__ dst, size_t stride) {
+    const int lane = threadIdx.x, m = lane & 15, qd = lane >> 4;
+    const double *S = src + blockIdx.z * stride;
+    double *D = dst + blockIdx.z * stride;
+    const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+    f64x4 acc = {0, 0, 0, 0};
+#pragma unroll 8
+    for (int kk = 0; kk < Mp / 4; ++kk) {
+        const double av = S[(size_t)(r0 + m) * Mp + 4 * kk + qd];      // A[m][k]
+        const double bv = S[(size_t)(4 * kk + qd) * Mp + c0 + m];      // B[k][n]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) D[(size_t)(r0 + qd + 4 * r) * Mp + c0 + m] = acc[r];     // D[row = qd + 4r][col = m]
+}
+
+__global__ __launch_bounds__(256) void k_pow_layout(int Mp, const double *__restrict__ W, float *__restrict__ qBf,
+                                                     float *__restrict__ qBb) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= Mp * Mp) return;
+    const size_t mo = (size_t)blockIdx.y * Mp * Mp;          // blockIdx.y = e * 5 + b
+    const int KQ = Mp / 4, q = d & 3, i = (d >> 2) % Mp, t = (d >> 2) / Mp, k = q * KQ + t;
+    qBf[mo + d] = (float)W[mo + (size_t)i * Mp + k];
+    qBb[mo + d] = (float)W[mo + (size_t)k * Mp + i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -165,6 +165,10 @@ int smcpp_host_set_csfs_direct(int on);
  * include/transition_bundle.h:9-30): P_r, Pinv_r [n x n], d_r [n], scale = max |d|, max |imag d|. */
 int smcpp_host_eigensystem(int n, const double *A, double *P, double *Pinv, double *d, double *scale,
                            double *max_imag);
+/* the same, computed by `threads` cooperating threads (smcpp_amd/csrc/nonsym_eig_team.hpp: bit-identical results); what the
+ * engine uses for M >= 128 */
+int smcpp_host_eigensystem_team(int n, const double *A, int threads, double *P, double *Pinv, double *d, double *scale,
+                                double *max_imag);
 
 /* One-population cold preparation without an engine instance:
  * model pieces (a, s)[Kp] + hidden states -> pi [M], T [M x M], E [K x M] for the given keys [K x 3]. */

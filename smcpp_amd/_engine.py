@@ -66,6 +66,7 @@ def lib():
         "smcpp_set_num_threads": (None, [i]),
         "smcpp_host_set_csfs_direct": (i, [i]),
         "smcpp_host_eigensystem": (i, [i, _dp, _dp, _dp, _dp, _dp, _dp]),
+        "smcpp_host_eigensystem_team": (i, [i, _dp, i, _dp, _dp, _dp, _dp, _dp]),
         "smcpp_host_prep_onepop": (i, [i, i, _dp, d, i, _dp, _dp, d, d, d, i, _ip, _dp, _dp, _dp]),
         "smcpp_host_prep_onepop_jac": (i, [i, i, _dp, d, i, _dp, _dp, i, _dp, d, d, d, i, _ip, _dp, _dp, _dp, _dp,
                                            _dp, _dp]),
@@ -97,7 +98,7 @@ EXPORTS = [
     "smcpp_get_xisum", "smcpp_get_gamma", "smcpp_get_gamma_sums", "smcpp_get_pi", "smcpp_get_transition",
     "smcpp_get_emission_probs", "smcpp_get_gamma_argmax", "smcpp_set_global_keys", "smcpp_pack_stats",
     "smcpp_unpack_stats", "smcpp_set_chunking", "smcpp_last_timing", "smcpp_stream", "smcpp_set_num_threads",
-    "smcpp_host_eigensystem", "smcpp_host_prep_onepop", "smcpp_host_prep_onepop_jac", "smcpp_num_derivatives",
+    "smcpp_host_eigensystem", "smcpp_host_eigensystem_team", "smcpp_host_prep_onepop", "smcpp_host_prep_onepop_jac", "smcpp_num_derivatives",
     "smcpp_host_rate_function", "smcpp_host_rate_function_jac", "smcpp_host_random_coal_times", "smcpp_host_raw_sfs",
     "smcpp_set_params_twopop", "smcpp_host_joint_csfs", "smcpp_host_prep_twopop", "smcpp_set_warm_start",
     "smcpp_host_set_csfs_direct", "smcpp_gamma_cols", "smcpp_last_host_timing", "smcpp_get_pi_jac",
@@ -131,6 +132,16 @@ def host_eigensystem(A):
     P = np.zeros((n, n)); Pinv = np.zeros((n, n)); d = np.zeros(n)
     sc = C.c_double(0); mi = C.c_double(0)
     check(lib().smcpp_host_eigensystem(n, dptr(A), dptr(P), dptr(Pinv), dptr(d), C.byref(sc), C.byref(mi)))
+    return P, Pinv, d, sc.value, mi.value
+
+
+def host_eigensystem_team(A, threads):
+    """`host_eigensystem` computed by `threads` cooperating threads (what the engine does for M >= 128)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = A.shape[0]
+    P = np.zeros((n, n)); Pinv = np.zeros((n, n)); d = np.zeros(n)
+    sc = C.c_double(0); mi = C.c_double(0)
+    check(lib().smcpp_host_eigensystem_team(n, dptr(A), int(threads), dptr(P), dptr(Pinv), dptr(d), C.byref(sc), C.byref(mi)))
     return P, Pinv, d, sc.value, mi.value
 
 

@@ -27,6 +27,7 @@
 #include "kernels.hpp"
 #include "chains2.hpp"
 #include "nonsym_eig.hpp"
+#include "nonsym_eig_team.hpp"
 #include "prep.hpp"
 #include "jcsfs.hpp"
 
@@ -221,6 +222,7 @@ struct smcpp_im {
     DevBuf<double> d_W, d_pre_qTdT;        // [Ke][5][Mp][Mp] row-major powers (fp64) / [KQ][Mp][4]
     DevBuf<float> d_qBf, d_qBb, d_pre_qTf; // [Ke][5][KQ][Mp][4] float streaming layouts / [KQ][Mp][4]
     BigArgs pre_bargs;
+    std::vector<std::unique_ptr<smcpp_host::EigTeam>> eig_teams;    // team-parallel eigensolver (M >= 128), one team per eigen key
     DevBuf<Chunk> d_chunks;
     DevBuf<Slab> d_slabs_sc, d_slabs_rk, d_slabs_eg;
     DevBuf<int2> d_perm1k;                 // span-1 rows sorted by key: {ell, key id} (one load resolves both)
@@ -818,49 +820,108 @@ void smcpp_im::host_prep_and_upload() {
     // transposed / row-major copies the kernels read and the eigenvalue powers of every (span, key) group, ONE
     // parallel region (task Ke packs the key-independent arrays)
     std::string err;
-#pragma omp parallel for schedule(dynamic) num_threads(std::max(1, std::min(Ke + 1, omp_get_max_threads())))
-    for (int e = 0; e <= Ke; ++e) {
-        if (e == Ke) {
-            if (static_packed) continue;
-            for (int i = 0; i < M; ++i) {
-                pi_f[i] = (float)pi[i];
-                for (int j = 0; j < M; ++j) {
-                    Tf[(size_t)i * Mp + j] = (float)T[(size_t)i * M + j];
-                    Td[(size_t)i * Mp + j] = T[(size_t)i * M + j];
-                    TdT[(size_t)j * Mp + i] = T[(size_t)i * M + j];
-                }
+    auto pack_static = [&]() {
+        if (static_packed) return;
+        for (int i = 0; i < M; ++i) {
+            pi_f[i] = (float)pi[i];
+            for (int j = 0; j < M; ++j) {
+                Tf[(size_t)i * Mp + j] = (float)T[(size_t)i * M + j];
+                Td[(size_t)i * Mp + j] = T[(size_t)i * M + j];
+                TdT[(size_t)j * Mp + i] = T[(size_t)i * M + j];
             }
-            for (int k = 0; k < K; ++k)
-                for (int i = 0; i < M; ++i) Ep[(size_t)k * Mp + i] = E[(size_t)k * M + i];
-            continue;
         }
-        try {
-            const double *b = &E[(size_t)eig_kid[e] * M];
-            std::vector<double> A((size_t)M * M);
-            for (int i = 0; i < M; ++i)
-                for (int j = 0; j < M; ++j) A[(size_t)i * M + j] = b[i] * T[(size_t)j * M + i];
-            const smcpp_host::EigenSystem s_ = smcpp_host::eigensystem(M, A);
-            for (int i = 0; i < M; ++i) {
-                dun[(size_t)e * Mp + i] = s_.d[i];
-                dsc[(size_t)e * Mp + i] = s_.d[i] / s_.scale;
-                for (int j = 0; j < M; ++j) {
-                    const double p = s_.P[(size_t)i * M + j], pi_ = s_.Pinv[(size_t)i * M + j];
-                    Prm[e * MM + (size_t)i * Mp + j] = p;
-                    PT[e * MM + (size_t)j * Mp + i] = p;
-                    Pinvrm[e * MM + (size_t)i * Mp + j] = pi_;
-                    PinvT[e * MM + (size_t)j * Mp + i] = pi_;
-                }
+        for (int k = 0; k < K; ++k)
+            for (int i = 0; i < M; ++i) Ep[(size_t)k * Mp + i] = E[(size_t)k * M + i];
+    };
+    auto make_A = [&](int e, std::vector<double> &A) {
+        const double *b = &E[(size_t)eig_kid[e] * M];
+        A.resize((size_t)M * M);
+        for (int i = 0; i < M; ++i)
+            for (int j = 0; j < M; ++j) A[(size_t)i * M + j] = b[i] * T[(size_t)j * M + i];
+    };
+    // rows i = r0, r0 + step, ... of the device layouts of eigen key e; the eigenvalue powers of its groups with r0 == 0
+    auto unpack = [&](int e, const smcpp_host::EigenSystem &s_, int r0, int step) {
+        for (int i = r0; i < M; i += step) {
+            dun[(size_t)e * Mp + i] = s_.d[i];
+            dsc[(size_t)e * Mp + i] = s_.d[i] / s_.scale;
+            for (int j = 0; j < M; ++j) {
+                const double p = s_.P[(size_t)i * M + j], pi_ = s_.Pinv[(size_t)i * M + j];
+                Prm[e * MM + (size_t)i * Mp + j] = p;
+                PT[e * MM + (size_t)j * Mp + i] = p;
+                Pinvrm[e * MM + (size_t)i * Mp + j] = pi_;
+                PinvT[e * MM + (size_t)j * Mp + i] = pi_;
             }
-            const double ls = std::log(s_.scale);
-            for (int g : groups_of[e]) {
-                const int sp = groups[g].span;
-                gsc[g] = s_.scale;
-                gls[g] = sp * ls;
-                for (int i = 0; i < M; ++i) dpow[(size_t)g * Mp + i] = std::pow(dsc[(size_t)e * Mp + i], sp);
+        }
+        if (r0 != 0) return;
+        const double ls = std::log(s_.scale);
+        for (int g : groups_of[e]) {
+            const int sp = groups[g].span;
+            gsc[g] = s_.scale;
+            gls[g] = sp * ls;
+            for (int i = 0; i < M; ++i) dpow[(size_t)g * Mp + i] = std::pow(s_.d[i] / s_.scale, sp);
+        }
+    };
+    // M >= 128: a team of threads per eigen key (nonsym_eig_team.hpp: bit-identical to the serial routine); the size follows
+    // the thread count the caller allows (smcpp_set_num_threads), SMCPP_EIG_TEAM overrides it (1 = serial routine)
+    // Every team is confined to one L3 domain for the duration of the region (see nonsym_eig_team.hpp: unpinned on a
+    // two-socket host the element hand-overs make it slower than the serial routine); without sysfs topology, or with
+    // SMCPP_EIG_TEAM=1, the serial routine runs.
+    static const std::vector<std::vector<int>> l3 = smcpp_host::cpu_l3_groups();
+    int team = (M >= 128 && Ke >= 1 && (int)l3.size() >= Ke) ? std::min(8, omp_get_max_threads() / Ke) : 1;
+    if (const char *te = getenv("SMCPP_EIG_TEAM")) team = std::max(1, std::min(16, atoi(te)));
+    if (M < 32 || (int)l3.size() < Ke) team = 1;
+    bool team_done = false;
+    if (team >= 2) {
+        pack_static();
+        if ((int)eig_teams.size() != Ke || eig_teams[0]->size != team) {
+            eig_teams.clear();
+            for (int e = 0; e < Ke; ++e) eig_teams.emplace_back(new smcpp_host::EigTeam(team));
+        }
+        std::vector<std::vector<double>> As(Ke);
+        std::vector<smcpp_host::EigenSystem> ess(Ke);
+        for (int e = 0; e < Ke; ++e) make_A(e, As[e]);
+        bool ok = true;
+        // L3 domains next to the one the calling thread runs in (same socket first: sysfs lists them in CPU order)
+        int g0 = 0;
+        {
+            const int here = sched_getcpu();
+            for (size_t g = 0; g < l3.size(); ++g)
+                for (int c : l3[g]) if (c == here) g0 = (int)g;
+        }
+        static const bool pin = !(getenv("SMCPP_EIG_PIN") && atoi(getenv("SMCPP_EIG_PIN")) == 0);
+#pragma omp parallel num_threads(Ke * team)
+        {
+            if (omp_get_num_threads() != Ke * team) {
+#pragma omp single
+                ok = false;
+            } else {
+                const int tid = omp_get_thread_num(), e = tid / team, rank = tid % team;
+                smcpp_host::ScopedAffinity aff(pin ? &l3[(size_t)(g0 + e) % l3.size()] : nullptr);
+                smcpp_host::EigTeam &tm = *eig_teams[e];
+                int gen = tm.generation.load(std::memory_order_acquire);
+                smcpp_host::eigensystem_team(M, As[e], ess[e], tm, rank, gen);
+                if (!tm.failed.load()) unpack(e, ess[e], rank, team);
             }
-        } catch (const std::exception &ex) {
+        }
+        if (ok) {
+            for (int e = 0; e < Ke; ++e)
+                if (eig_teams[e]->failed.load()) err = eig_teams[e]->error.empty() ? "eigensolver failed" : eig_teams[e]->error;
+            team_done = true;
+        }
+    }
+    if (!team_done) {
+#pragma omp parallel for schedule(dynamic) num_threads(std::max(1, std::min(Ke + 1, omp_get_max_threads())))
+        for (int e = 0; e <= Ke; ++e) {
+            if (e == Ke) { pack_static(); continue; }
+            try {
+                std::vector<double> A;
+                make_A(e, A);
+                const smcpp_host::EigenSystem s_ = smcpp_host::eigensystem(M, A);
+                unpack(e, s_, 0, 1);
+            } catch (const std::exception &ex) {
 #pragma omp critical
-            err = ex.what();
+                err = ex.what();
+            }
         }
     }
     if (!err.empty()) throw std::runtime_error(err);
@@ -2141,6 +2202,37 @@ int smcpp_host_set_csfs_direct(int on) {
 // ---- host-only helpers exported for the CPU test-suite (no device needed) --------------------------------------
 
 // eigensystem(EigenSolver(A)) as used by TransitionBundle::update: P_r, Pinv_r [n x n], d_r [n], scale, max|imag|
+// the same through the team-parallel routine (nonsym_eig_team.hpp) with `threads` cooperating threads
+int smcpp_host_eigensystem_team(int n, const double *A, int threads, double *P, double *Pinv, double *d, double *scale,
+                                double *max_imag) {
+    API_BEGIN
+    if (n < 1 || threads < 1 || threads > 64) throw std::runtime_error("bad arguments");
+    std::vector<double> a(A, A + (size_t)n * n);
+    smcpp_host::EigTeam tm(threads);
+    smcpp_host::EigenSystem es;
+    bool ok = true;
+    if (n == 1) es = smcpp_host::eigensystem(n, a);
+    else {
+#pragma omp parallel num_threads(threads)
+        {
+            if (omp_get_num_threads() != threads) {
+#pragma omp single
+                ok = false;
+            } else {
+                int gen = 0;
+                smcpp_host::eigensystem_team(n, a, es, tm, omp_get_thread_num(), gen);
+            }
+        }
+    }
+    if (!ok) throw std::runtime_error("the OpenMP runtime did not provide the requested team");
+    if (tm.failed.load()) throw std::runtime_error(tm.error.empty() ? "eigensolver failed" : tm.error);
+    std::copy(es.P.begin(), es.P.end(), P);
+    std::copy(es.Pinv.begin(), es.Pinv.end(), Pinv);
+    std::copy(es.d.begin(), es.d.end(), d);
+    *scale = es.scale; *max_imag = es.max_imag;
+    API_END
+}
+
 int smcpp_host_eigensystem(int n, const double *A, double *P, double *Pinv, double *d, double *scale, double *max_imag) {
     API_BEGIN
     std::vector<double> a(A, A + (size_t)n * n);

@@ -47,6 +47,27 @@ def test_host_eigensystem_real(name):
     assert np.allclose(np.linalg.norm(P, axis=0), 1.0)         # unit-norm columns like EigenSolver
 
 
+@pytest.mark.parametrize("n,threads", [(256, 8), (256, 3), (130, 5), (64, 2), (17, 3), (2, 2)])
+def test_team_eigensystem_is_bit_identical_to_the_serial_one(n, threads):
+    """nonsym_eig_team.hpp splits the EISPACK pipeline over a team of threads without changing the order of any
+    floating-point operation on any matrix element: P, Pinv, d must be EQUAL to the serial routine's, for a real spectrum
+    (the team path proper) and for a complex one (fallback to the serial routine on rank 0)."""
+    from smcpp_amd import _engine
+    rng = np.random.RandomState(n + threads)
+    S = np.exp(-0.3 * np.abs(np.subtract.outer(np.arange(n), np.arange(n)))) * (0.5 + rng.rand(n, n)) + 1e-6
+    S = np.triu(S) + np.triu(S, 1).T + 5 * np.eye(n)
+    T = S / S.sum(axis=1, keepdims=True)                  # reversible chain: diag(e) T^T has a real spectrum
+    A_real = (0.9 + 0.1 * rng.rand(n))[:, None] * T.T
+    A_cplx = rng.rand(n, n) - 0.3
+    for A, real in ((A_real, True), (A_cplx, False)):
+        ref = _engine.host_eigensystem(A)
+        got = _engine.host_eigensystem_team(A, threads)
+        if real:
+            assert ref[4] == 0.0
+        for x, y in zip(ref, got):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
 def test_host_eigensystem_complex_pairs():
     from smcpp_amd import _engine
     rng = np.random.RandomState(3)

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
     }
     if (owner) a.used_f[(size_t)c * Mp + i] = al;
     if (tid == 0) a.changed[pass] = 1;
-    if (ch.first) {
+    // POWER = pre-pass: pass 1 (a full pass) rewrites every row, only the chunk's end vector is kept
+    if (ch.first && !POWER) {
         if (owner) a.alpha[(size_t)ch.base * Mp + i] = al;
         if (tid == 0) a.cnorm[ch.base] = 1.0;
     }
@@ -181,8 +182,8 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
                 const bool anyb = __any(bad);
                 if (lane == 0) mflag[w] = anyb ? 1 : 0;
             }
-            if (owner) arow[(size_t)j * Mp] = an;
-            if (tid == 0) crow[j] = (double)sprev;
+            if (owner && !POWER) arow[(size_t)j * Mp] = an;
+            if (tid == 0 && !POWER) crow[j] = (double)sprev;
         }
 #pragma unroll
         for (int t = 0; t < Q4; ++t) {
@@ -339,10 +340,10 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
         if (owner) {
             float an = v_prev * inv;
             an = (i < M) ? fmaxf(an, 1e-10f) : 0.f;
-            a.alpha[(size_t)(ch.base + ch.r1) * Mp + i] = an;
+            if (!POWER) a.alpha[(size_t)(ch.base + ch.r1) * Mp + i] = an;
             end_cur[i] = an;
         }
-        if (tid == 0) a.cnorm[ch.base + ch.r1] = (double)sprev;
+        if (tid == 0 && !POWER) a.cnorm[ch.base + ch.r1] = (double)sprev;
     }
 }
 
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
                 const bool anyb = __any(bad);
                 if (lane == 0) mflag[w] = anyb ? 1 : 0;
             }
-            if (owner) brow[-(ptrdiff_t)j * Mp] = bnrm;
+            if (owner && !POWER) brow[-(ptrdiff_t)j * Mp] = bnrm;
         }
         // running scale for the NEXT row from the sum of the vector this row consumes (off the critical path)
         double inv_next;
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
         if (owner) {
             const double bf = (i < M) ? b_raw / sprev : 0.0;       // beta /= beta.sum()
             end_cur[i] = bf;
-            if (ch.first) a.beta[(size_t)ch.base * Mp + i] = bf;
+            if (ch.first && !POWER) a.beta[(size_t)ch.base * Mp + i] = bf;
         }
     }
 }
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
 // Operands of the eigen-free pre-pass.  A_e = diag(e_key) T^T is the one-position forward operator of eigen key e
 // (the matrix whose eigensystem TransitionBundle::update takes, transition_bundle.cpp:15-25); a span-s row applies
 // A_e^s (forward) or its transpose (backward) as the product of the binary powers A^(2^b) of the set bits of s.
-// One workgroup per eigen key squares A four times (A^2, A^4, A^8, A^16: spans up to 31) in LDS and stores them as
+// One workgroup per eigen key squares A four times (A^2, A^4, A^8, A^16: spans up to 31) in LDS on the matrix cores and stores them as
 // float row-major (forward operand Bf[e][b-1][i][k]) and double transposed (backward operand Bb[e][b-1][i][k] =
 // A^(2^b)[k][i]).  Tens of microseconds, against 0.6 ms of host eigensolves taken off the critical path (engine.hip: estep).
 // ---------------------------------------------------------------------------------------------------------------
@@ -663,38 +664,62 @@ template <int MT>
 __global__ __launch_bounds__(256) void k_binary_powers(int M, const int *__restrict__ e_kid, const double *__restrict__ E,
                                                         const double *__restrict__ Td, float *__restrict__ Bf,
                                                         double *__restrict__ Bb) {
-    constexpr int LD = MT + 1, CW = MT / 4;
+    constexpr int LD = MT + 1, NT = MT / 16, NE = (MT * MT + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) double smp[];
     double *sP = smp;                       // [2][MT][LD] running power, rows padded
-    const int e = blockIdx.x, tid = threadIdx.x;
+    const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m = lane & 15, qd = lane >> 4;
     const double *em = E + (size_t)e_kid[e] * MT;
-    for (int idx = tid; idx < MT * MT; idx += 256) {
-        const int i = idx / MT, k = idx % MT;
-        sP[i * LD + k] = (i < M && k < M) ? em[i] * Td[(size_t)k * MT + i] : 0.0;       // A[i][k] = e_i T[k][i]
+    {
+        // A[i][k] = e_i T[k][i]: coalesced reads of T's rows, every load issued before the first LDS store
+        double v[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int idx = tid + 256 * u, k = idx / MT, i = idx % MT;
+            v[u] = (idx < MT * MT && i < M && k < M) ? em[i] * Td[(size_t)k * MT + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int idx = tid + 256 * u, k = idx / MT, i = idx % MT;
+            if (idx < MT * MT) sP[i * LD + k] = v[u];
+        }
     }
     __syncthreads();
-    const int i = tid >> 2, cb = (tid & 3) * CW;
     for (int b = 0; b < 4; ++b) {
         const double *Pc = sP + (b & 1) * MT * LD;
         double *Pn = sP + ((b & 1) ^ 1) * MT * LD;
-        double acc[CW];
+        // square on the matrix cores: wavefront w owns rows 16w .. 16w+15 (v_mfma_f64_16x16x4: A[m][k = qd], B[k = qd][n = m],
+        // D[row = qd + 4r][col = m])
+        if (w < NT) {
+            f64x4 acc[NT];
 #pragma unroll
-        for (int c = 0; c < CW; ++c) acc[c] = 0.0;
-        if (i < MT) {
-            for (int k = 0; k < MT; ++k) {
-                const double pv = Pc[i * LD + k];
-                const double *ar = Pc + k * LD + cb;
+            for (int t = 0; t < NT; ++t) acc[t] = (f64x4){0, 0, 0, 0};
+#pragma unroll 4
+            for (int kk = 0; kk < MT / 4; ++kk) {
+                const double av = Pc[(16 * w + m) * LD + 4 * kk + qd];
 #pragma unroll
-                for (int c = 0; c < CW; ++c) acc[c] = fma(pv, ar[c], acc[c]);
+                for (int t = 0; t < NT; ++t) {
+                    const double bv = Pc[(4 * kk + qd) * LD + 16 * t + m];
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int c = 0; c < CW; ++c) {
-                Pn[i * LD + cb + c] = acc[c];
-                Bf[((size_t)e * 4 + b) * MT * MT + (size_t)i * MT + cb + c] = (float)acc[c];
-                Bb[((size_t)e * 4 + b) * MT * MT + (size_t)(cb + c) * MT + i] = acc[c];
-            }
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Pn[(16 * w + qd + 4 * r) * LD + 16 * t + m] = acc[t][r];
         }
         __syncthreads();
+        // copy the new power out, both layouts coalesced (row-major float: lanes along k; transposed double: lanes along i)
+        float *of = Bf + ((size_t)e * 4 + b) * MT * MT;
+        double *ob = Bb + ((size_t)e * 4 + b) * MT * MT;
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int idx = tid + 256 * u, r = idx / MT, c = idx % MT;
+            if (idx < MT * MT) {
+                of[idx] = (float)Pn[r * LD + c];
+                ob[idx] = Pn[c * LD + r];
+            }
+        }
     }
 }
 

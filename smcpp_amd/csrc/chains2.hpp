@@ -356,6 +356,11 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
     const bool owner = kq == 0;
     const int M = a.M, pass = a.pass, c = blockIdx.x;
     if (RERUN && a.changed[pass - 1] == 0) return;
+    // the backward chain (fp64 throughout) is the longer of the two that share a CU: its wavefronts win the issue arbitration
+    // against the forward kernel's (the engine passes SMCPP_BWD_PRIO through ChainArgs::prio; 0 = hardware default)
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     double *sE = reinterpret_cast<double *>(smem);            // [K][MT]
     double *sD = sE + (TAB ? ca.K * MT : 0);                   // [G][MT]
     double *ub = sD + (TAB ? ca.G * MT : 0);                   // [4][UP]     w exchange of eigen rows

@@ -1188,6 +1188,7 @@ ChainArgs smcpp_im::chain_args() {
     a.dbg = nullptr;
     a.warm_f = nullptr; a.warm_b = nullptr;
     a.Bf = d_Bf.p; a.Bb = d_Bb.p; a.g_span = d_g_span.p;
+    { static const int pr = getenv("SMCPP_BWD_PRIO") ? std::max(0, std::min(3, atoi(getenv("SMCPP_BWD_PRIO")))) : 1; a.prio = pr; }
     a.changed = nullptr;
     return a;
 }
@@ -1468,8 +1469,6 @@ void smcpp_im::run_stats() {
     la.cnorm = d_cnorm.p; la.rowinfo = d_rowinfo.p; la.g_logscale = d_g_logscale.p;
     la.contig_base = d_contig_base.p; la.contig_L = d_contig_L.p; la.partial = d_llpart.p; la.loglik = d_loglik.p;
     la.logc = d_logc.p; la.nblk = llblk;
-    hipLaunchKernelGGL(k_loglik_partial, dim3(llblk, n_contigs), dim3(256), 0, s, la);
-    hipLaunchKernelGGL(k_loglik_final, dim3(n_contigs), dim3(256), 0, s, la);
     if (save_gamma) {
         d_gamma_rows.alloc((size_t)total_rows * Mp);
         d_gamma_rows.zero(s);
@@ -1482,6 +1481,10 @@ void smcpp_im::run_stats() {
         HIPCHK(hipEventRecord(ev[8], s));
         HIPCHK(hipStreamWaitEvent(se, ev[8], 0));
     }
+    // nothing in the statistics reads log_c any more (the span-1 weights take c itself): the two log-likelihood kernels
+    // ride on the eigen stream instead of heading the critical path of the main one
+    hipLaunchKernelGGL(k_loglik_partial, dim3(llblk, n_contigs), dim3(256), 0, se, la);
+    hipLaunchKernelGGL(k_loglik_final, dim3(n_contigs), dim3(256), 0, se, la);
     FinArgs fa;
     fa.M = M; fa.Mp = Mp; fa.K = K; fa.G = G; fa.Ke = Ke; fa.n_contigs = n_contigs;
     fa.eb_slab_off = d_eb_slab_off.p; fa.eb_gid = d_eb_gid.p; fa.ce_bucket_off = d_ce_bucket_off.p;
@@ -1496,7 +1499,7 @@ void smcpp_im::run_stats() {
     if (!slabs_sc.empty()) {
         S1Args sa;
         sa.M = M; sa.Mp = Mp; sa.nslabs = (int)slabs_sc.size(); sa.slabs = d_slabs_sc.p; sa.perm = d_perm1.p;
-        sa.alpha = d_alpha.p; sa.beta = d_beta.p; sa.logc = d_logc.p; sa.w1 = d_w1.p; sa.gpart = d_gpart.p;
+        sa.alpha = d_alpha.p; sa.beta = d_beta.p; sa.cnorm = d_cnorm.p; sa.w1 = d_w1.p; sa.gpart = d_gpart.p;
         sa.gamma_rows = save_gamma ? d_gamma_rows.p : nullptr;
         launch_s1(NPL, sa, s);
     }

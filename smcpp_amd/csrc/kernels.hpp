@@ -137,6 +137,7 @@ struct ChainArgs {
     const float *Bf;        // [Ke][4][Mp][Mp]
     const double *Bb;       // [Ke][4][Mp][Mp]
     const int *g_span;      // [G]
+    int prio;               // wave priority (s_setprio) of the backward cooperative kernels, 0..3
     const float *warm_f;    // [nchunks][Mp] end vectors of the forward chunks
     const double *warm_b;   // [nchunks][Mp] end vectors of the backward chunks
 };
@@ -1800,7 +1801,7 @@ __global__ __launch_bounds__(256) void k_loglik_final(LoglikArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // K3: span-1 rows — per-row scalars and gamma sums  (hmm.cpp:134-138,146-148)
-//   v = alpha_ell o beta_ell / p,  p = sum(alpha_ell o beta_ell);  w1 = 1 / (exp(log_c) p)
+//   v = alpha_ell o beta_ell / p,  p = sum(alpha_ell o beta_ell);  w1 = 1 / (c_ell p)
 // One wavefront walks a slab of rows of one (contig, key) segment and keeps the running sum of v in registers.
 // ---------------------------------------------------------------------------------------------------------------
 struct Slab {
@@ -1816,7 +1817,7 @@ struct S1Args {
     const int *perm;          // sorted span-1 rows (contig-relative ell)
     const float *alpha;
     const double *beta;
-    const double *logc;
+    const double *cnorm;      // [rows] forward normaliser c_ell of every row (span-1 rows carry no eigenvalue scale)
     double *w1;               // [rows] per-row weight
     double *gpart;            // [nslabs][Mp] partial gamma sums
     double *gamma_rows;       // optional [rows][Mp] (save_gamma)
@@ -1852,7 +1853,7 @@ __global__ __launch_bounds__(256) void k_s1_scalars(S1Args a) {
         for (int u = 0; u < 4; ++u) elln[u] = a.perm[min(r0 + 16 + 4 * u, last)];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            lc[u] = a.logc[row[u]];
+            lc[u] = a.cnorm[row[u]];
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
                 const int i = min(lane + 64 * q, Mp - 1);
@@ -1877,7 +1878,7 @@ __global__ __launch_bounds__(256) void k_s1_scalars(S1Args a) {
                 const int i = lane + 64 * q;
                 if (a.gamma_rows && i < Mp) a.gamma_rows[row[u] * Mp + i] = g;
             }
-            if (lane == 0) a.w1[row[u]] = ip / exp(lc[u]);
+            if (lane == 0) a.w1[row[u]] = ip / lc[u];
         }
     }
 #pragma unroll
@@ -2344,9 +2345,18 @@ __global__ __launch_bounds__(256) void k_fin_Y(FinArgs a) {
     const int j = idx / Mp, i = idx % Mp;
     const double *Z = a.Z + (size_t)ce * Mp * Mp + (size_t)j * Mp;
     const double *Pinv = a.Pinvrm + (size_t)e * Mp * Mp;
-    double s = 0.0;
-    for (int k = 0; k < a.M; ++k) s = fma(Z[k], Pinv[(size_t)k * Mp + i], s);
-    a.Y[(size_t)ce * Mp * Mp + idx] = s;
+    // four independent partial sums: the loop is bound by the latency of its loads, not by the M multiply-adds
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+#pragma unroll 2
+    for (; k + 3 < a.M; k += 4) {
+        s0 = fma(Z[k], Pinv[(size_t)k * Mp + i], s0);
+        s1 = fma(Z[k + 1], Pinv[(size_t)(k + 1) * Mp + i], s1);
+        s2 = fma(Z[k + 2], Pinv[(size_t)(k + 2) * Mp + i], s2);
+        s3 = fma(Z[k + 3], Pinv[(size_t)(k + 3) * Mp + i], s3);
+    }
+    for (; k < a.M; ++k) s0 = fma(Z[k], Pinv[(size_t)k * Mp + i], s0);
+    a.Y[(size_t)ce * Mp * Mp + idx] = (s0 + s1) + (s2 + s3);
 }
 
 // xisum[contig] = max( (X1 + sum_e P_e Y_e diag(b_e)) o Td , 1e-20 )   (hmm.cpp:122,141,151-152)
@@ -2364,9 +2374,17 @@ __global__ __launch_bounds__(256) void k_fin_xisum(FinArgs a) {
             if (a.ce_bucket_off[ce] == a.ce_bucket_off[ce + 1]) continue;
             const double *P = a.Prm + (size_t)e * Mp * Mp + (size_t)i * Mp;
             const double *Y = a.Y + (size_t)ce * Mp * Mp;
-            double s = 0.0;
-            for (int j = 0; j < M; ++j) s = fma(P[j], Y[(size_t)j * Mp + k], s);
-            x += s * a.E[(size_t)a.e_kid[e] * Mp + k];
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int j = 0;
+#pragma unroll 2
+            for (; j + 3 < M; j += 4) {
+                s0 = fma(P[j], Y[(size_t)j * Mp + k], s0);
+                s1 = fma(P[j + 1], Y[(size_t)(j + 1) * Mp + k], s1);
+                s2 = fma(P[j + 2], Y[(size_t)(j + 2) * Mp + k], s2);
+                s3 = fma(P[j + 3], Y[(size_t)(j + 3) * Mp + k], s3);
+            }
+            for (; j < M; ++j) s0 = fma(P[j], Y[(size_t)j * Mp + k], s0);
+            x += ((s0 + s1) + (s2 + s3)) * a.E[(size_t)a.e_kid[e] * Mp + k];
         }
         x *= a.Td[(size_t)i * Mp + k];
         if (x < 1e-20) x = 1e-20;

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
     // eigen-free pre-pass: quarters of A^2, A^4, A^8, A^16 of the hot eigen key, A = diag(e) T^T (k_binary_powers)
     float pw[POWER ? 4 : 1][POWER ? KQ : 1];
     if (POWER) {
-        const float *B0 = a.Bf + (size_t)(a.hot < 0 ? 0 : a.hot) * 4 * MT * MT + (size_t)i * MT + kq * KQ;
+        const float *B0 = a.Bf + (size_t)(a.hot < 0 ? 0 : a.hot) * a.npow * MT * MT + (size_t)i * MT + kq * KQ;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
             // between two applications
             const int sp = a.g_span[SMCPP_GID(ge)];
             const bool hotk = SMCPP_ES(ge) == a.hot;
-            const float *Bq = a.Bf + (size_t)SMCPP_ES(ge) * 4 * MT * MT + (size_t)i * MT + kq * KQ;
+            const float *Bq = a.Bf + (size_t)SMCPP_ES(ge) * a.npow * MT * MT + (size_t)i * MT + kq * KQ;
             float vq[KQ];
 #pragma unroll
             for (int t = 0; t < Q4; ++t) { vq[4 * t] = xl[t].x; vq[4 * t + 1] = xl[t].y; vq[4 * t + 2] = xh[t].x; vq[4 * t + 3] = xh[t].y; }
@@ -250,6 +250,27 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
                 }
                 outv = quad_sum_f((a0 + a1) + (a2 + a3));
                 if (b == 0) outv *= (float)e_cur;
+                ++napp;
+            }
+            // spans of 32 and more (un-thinned or sparsely polymorphic data): the higher powers of every key come from L2
+            for (int b = 5; b < a.nbits; ++b) {
+                if (!((sp >> b) & 1)) continue;
+                if (napp > 0) {
+                    float *tb = ptmp + (napp & 1) * MT;
+                    if (owner) tb[i] = outv;
+                    lds_barrier();
+#pragma unroll
+                    for (int t = 0; t < KQ; ++t) vq[t] = tb[kq * KQ + t];
+                }
+                const float *Bb_ = Bq + (size_t)(b - 1) * MT * MT;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int t = 0; t < KQ; t += 4) {
+                    const float4 m = *reinterpret_cast<const float4 *>(Bb_ + t);
+                    a0 = fmaf(m.x, vq[t], a0); a1 = fmaf(m.y, vq[t + 1], a1);
+                    a2 = fmaf(m.z, vq[t + 2], a2); a3 = fmaf(m.w, vq[t + 3], a3);
+                }
+                outv = quad_sum_f((a0 + a1) + (a2 + a3));
                 ++napp;
             }
             vout = outv * inv;
@@ -425,7 +446,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
     // eigen-free pre-pass: quarters of the TRANSPOSED powers (A^2)^T .. (A^16)^T of the hot eigen key
     double pw[POWER ? 4 : 1][POWER ? KQ : 1];
     if (POWER) {
-        const double *B0 = a.Bb + (size_t)(a.hot < 0 ? 0 : a.hot) * 4 * MT * MT + (size_t)i * MT + kq * KQ;
+        const double *B0 = a.Bb + (size_t)(a.hot < 0 ? 0 : a.hot) * a.npow * MT * MT + (size_t)i * MT + kq * KQ;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -521,7 +542,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
             // eigen-free pre-pass: beta <- (A^T)^span beta, A^T = T diag(e); one application per set bit of the span
             const int sp = a.g_span[SMCPP_GID(ge)];
             const bool hotk = SMCPP_ES(ge) == a.hot;
-            const double *Bq = a.Bb + (size_t)SMCPP_ES(ge) * 4 * MT * MT + (size_t)i * MT + kq * KQ;
+            const double *Bq = a.Bb + (size_t)SMCPP_ES(ge) * a.npow * MT * MT + (size_t)i * MT + kq * KQ;
             double outv = 0.0;
             int napp = 0;
 #pragma unroll
@@ -559,6 +580,27 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
                         a0 = fma(m01.x, x[t], a0); a1 = fma(m01.y, x[t + 1], a1);
                         a2 = fma(m23.x, x[t + 2], a2); a3 = fma(m23.y, x[t + 3], a3);
                     }
+                }
+                outv = quad_sum_d((a0 + a1) + (a2 + a3));
+                ++napp;
+            }
+            for (int b = 5; b < a.nbits; ++b) {          // long spans: higher powers from L2 (see k_fwd_coop2)
+                if (!((sp >> b) & 1)) continue;
+                if (napp > 0) {
+                    double *tb = ptmp + (napp & 1) * 4 * UP;
+                    if (owner) tb[(i / KQ) * UP + (i % KQ)] = outv;
+                    lds_barrier();
+#pragma unroll
+                    for (int t = 0; t < KQ; ++t) x[t] = tb[kq * UP + t];
+                }
+                const double *Bb_ = Bq + (size_t)(b - 1) * MT * MT;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int t = 0; t < KQ; t += 4) {
+                    const double2 m01 = *reinterpret_cast<const double2 *>(Bb_ + t);
+                    const double2 m23 = *reinterpret_cast<const double2 *>(Bb_ + t + 2);
+                    a0 = fma(m01.x, x[t], a0); a1 = fma(m01.y, x[t + 1], a1);
+                    a2 = fma(m23.x, x[t + 2], a2); a3 = fma(m23.y, x[t + 3], a3);
                 }
                 outv = quad_sum_d((a0 + a1) + (a2 + a3));
                 ++napp;
@@ -661,14 +703,15 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
 // Operands of the eigen-free pre-pass.  A_e = diag(e_key) T^T is the one-position forward operator of eigen key e
 // (the matrix whose eigensystem TransitionBundle::update takes, transition_bundle.cpp:15-25); a span-s row applies
 // A_e^s (forward) or its transpose (backward) as the product of the binary powers A^(2^b) of the set bits of s.
-// One workgroup per eigen key squares A four times (A^2, A^4, A^8, A^16: spans up to 31) in LDS on the matrix cores and stores them as
+// One workgroup per eigen key squares A nsq times (A^2 .. A^(2^nsq); nsq = 4 covers spans up to 31, 11 spans up to 4095)
+// in LDS on the matrix cores and stores them as
 // float row-major (forward operand Bf[e][b-1][i][k]) and double transposed (backward operand Bb[e][b-1][i][k] =
 // A^(2^b)[k][i]).  Tens of microseconds, against 0.6 ms of host eigensolves taken off the critical path (engine.hip: estep).
 // ---------------------------------------------------------------------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(256) void k_binary_powers(int M, const int *__restrict__ e_kid, const double *__restrict__ E,
-                                                        const double *__restrict__ Td, float *__restrict__ Bf,
-                                                        double *__restrict__ Bb) {
+__global__ __launch_bounds__(256) void k_binary_powers(int M, int nsq, const int *__restrict__ e_kid,
+                                                        const double *__restrict__ E, const double *__restrict__ Td,
+                                                        float *__restrict__ Bf, double *__restrict__ Bb) {
     constexpr int LD = MT + 1, NT = MT / 16, NE = (MT * MT + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) double smp[];
     double *sP = smp;                       // [2][MT][LD] running power, rows padded
@@ -689,8 +732,9 @@ __global__ __launch_bounds__(256) void k_binary_powers(int M, const int *__restr
             if (idx < MT * MT) sP[i * LD + k] = v[u];
         }
     }
+    double *smax = sP + 2 * MT * LD;        // [4] per-wavefront maxima (behind the two matrices, see the launch)
     __syncthreads();
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < nsq; ++b) {
         const double *Pc = sP + (b & 1) * MT * LD;
         double *Pn = sP + ((b & 1) ^ 1) * MT * LD;
         // square on the matrix cores: wavefront w owns rows 16w .. 16w+15 (v_mfma_f64_16x16x4: A[m][k = qd], B[k = qd][n = m],
@@ -714,9 +758,31 @@ __global__ __launch_bounds__(256) void k_binary_powers(int M, const int *__restr
                 for (int r = 0; r < 4; ++r) Pn[(16 * w + qd + 4 * r) * LD + 16 * t + m] = acc[t][r];
         }
         __syncthreads();
+        // Powers beyond A^16 (spans of 32 and more) would leave the float range (|lambda| < 1): every power is rescaled to
+        // max |entry| = 1.  The pre-pass only needs directions - both chains renormalise their vector on every row.
+        if (b >= 4) {
+            double mx = 0.0;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int idx = tid + 256 * u, r = idx / MT, c = idx % MT;
+                if (idx < MT * MT) mx = fmax(mx, fabs(Pn[r * LD + c]));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+            if (lane == 0) smax[w] = mx;
+            __syncthreads();
+            mx = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+            const double sc = mx > 0.0 ? 1.0 / mx : 1.0;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int idx = tid + 256 * u, r = idx / MT, c = idx % MT;
+                if (idx < MT * MT) Pn[r * LD + c] *= sc;
+            }
+            __syncthreads();
+        }
         // copy the new power out, both layouts coalesced (row-major float: lanes along k; transposed double: lanes along i)
-        float *of = Bf + ((size_t)e * 4 + b) * MT * MT;
-        double *ob = Bb + ((size_t)e * 4 + b) * MT * MT;
+        float *of = Bf + ((size_t)e * nsq + b) * MT * MT;
+        double *ob = Bb + ((size_t)e * nsq + b) * MT * MT;
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
             const int idx = tid + 256 * u, r = idx / MT, c = idx % MT;

@@ -210,7 +210,7 @@ struct smcpp_im {
     // eigen-free pre-pass (chains2.hpp: k_group_powers, POWER instantiations): pass 0 runs on group powers while the host
     // solves the eigenproblems; only for short, few spans (binned data) and chunks short enough that pass 1 re-runs them whole
     bool power_ok = false, prepass_launched = false;
-    int max_span_pw = 0;
+    int max_span_pw = 0, pw_nbits = 5, pw_npow = 4;
     PinnedArena pre_stage;                 // static operands of the pre-pass (pi, T, emission table): own pinned mirror
     char *d_pre = nullptr;
     size_t pre_cap = 0;
@@ -589,8 +589,13 @@ void smcpp_im::setup_power() {
     // anyway (the rows of the pre-pass are all overwritten: it runs in float and its normalisers carry no eigenvalue scale)
     const bool coop_pre = chain_mode == 2 && coop_generation() == 2 && Mp <= 64;
     const bool big_pre = chain_mode == 3 && Mp > 64 && Mp <= 256;
-    power_ok = (coop_pre || big_pre) && Ke >= 1 && G >= 1 && mx <= 31 && longest <= 2000 && !(pe && atoi(pe) == 0);
+    // spans: five bits with the streamed-operand chains; twelve (4095 positions) with the cooperative ones, whose powers
+    // beyond A^16 are read from L2 by the few rows that need them
+    power_ok = ((coop_pre && mx <= 4095) || (big_pre && mx <= 31)) && Ke >= 1 && G >= 1 && longest <= 2000 && !(pe && atoi(pe) == 0);
     max_span_pw = mx;
+    pw_nbits = 5;
+    while ((1 << pw_nbits) <= mx) ++pw_nbits;
+    pw_npow = pw_nbits - 1;
     if (!power_ok) return;
     if (big_pre) {
         const size_t MM = (size_t)Mp * Mp;
@@ -601,8 +606,8 @@ void smcpp_im::setup_power() {
         d_pre_qTdT.alloc(MM);
         return;
     }
-    d_Bf.alloc((size_t)Ke * 4 * Mp * Mp);
-    d_Bb.alloc((size_t)Ke * 4 * Mp * Mp);
+    d_Bf.alloc((size_t)Ke * pw_npow * Mp * Mp);
+    d_Bb.alloc((size_t)Ke * pw_npow * Mp * Mp);
 }
 
 void smcpp_im::alloc_device() {
@@ -806,12 +811,12 @@ void smcpp_im::host_prep_and_upload() {
     auto ensure = [](auto &v, size_t n, auto init) { if (v.size() != n) v.assign(n, init); };
     ensure(hs_PinvT, em, 0.0); ensure(hs_PT, em, 0.0); ensure(hs_Prm, em, 0.0); ensure(hs_Pinvrm, em, 0.0);
     ensure(hs_dsc, std::max<size_t>(1, (size_t)Ke) * Mp, 0.0); ensure(hs_dun, std::max<size_t>(1, (size_t)Ke) * Mp, 0.0);
-    ensure(hs_dpow, std::max<size_t>(1, (size_t)G) * Mp, 0.0); ensure(hs_gsc, (size_t)std::max(1, G), 1.0);
+    ensure(hs_gsc, (size_t)std::max(1, G), 1.0);
     ensure(hs_gls, (size_t)std::max(1, G), 0.0);
     ensure(hs_pi_f, (size_t)Mp, 0.f); ensure(hs_Tf, MM, 0.f);
     ensure(hs_TdT, MM, 0.0); ensure(hs_Td, MM, 0.0); ensure(hs_Ep, (size_t)K * Mp, 0.0);
     std::vector<double> &PinvT = hs_PinvT, &PT = hs_PT, &Prm = hs_Prm, &Pinvrm = hs_Pinvrm, &dsc = hs_dsc, &dun = hs_dun,
-                        &dpow = hs_dpow, &gsc = hs_gsc, &gls = hs_gls, &TdT = hs_TdT, &Td = hs_Td, &Ep = hs_Ep;
+                        &gsc = hs_gsc, &gls = hs_gls, &TdT = hs_TdT, &Td = hs_Td, &Ep = hs_Ep;
     std::vector<float> &pi_f = hs_pi_f, &Tf = hs_Tf;
     // groups of each eigen key (so that one task finishes everything that depends on one eigensystem)
     std::vector<std::vector<int>> groups_of(Ke);
@@ -857,8 +862,7 @@ void smcpp_im::host_prep_and_upload() {
         for (int g : groups_of[e]) {
             const int sp = groups[g].span;
             gsc[g] = s_.scale;
-            gls[g] = sp * ls;
-            for (int i = 0; i < M; ++i) dpow[(size_t)g * Mp + i] = std::pow(s_.d[i] / s_.scale, sp);
+            gls[g] = sp * ls;                  // the eigenvalue powers (d_r / scale)^span of the group: k_group_dpow, on the device
         }
     };
     // M >= 128: a team of threads per eigen key (nonsym_eig_team.hpp: bit-identical to the serial routine); the size follows
@@ -974,7 +978,7 @@ void smcpp_im::host_prep_and_upload() {
     need += qTf.size() * 4 + (qTdT.size() + qPinvT.size() + qPT.size() + qPrm.size() + qPinvrm.size()) * 8;
     need += (pi_f.size() + Tf.size() + T4.size()) * 4;
     need += (TdT.size() + Td.size() + Ep.size() + PinvT.size() + PT.size() + Prm.size() + Pinvrm.size() + dsc.size() +
-             dun.size() + dpow.size() + gsc.size() + gls.size() + fA2.size() + fB2.size() + bA2.size() + bB2.size() +
+             dun.size() + gsc.size() + gls.size() + fA2.size() + fB2.size() + bA2.size() + bB2.size() +
              bC2.size()) * 8;
     stage.reset(need);
     if (need > param_cap) {
@@ -988,7 +992,7 @@ void smcpp_im::host_prep_and_upload() {
     d_Td.place(Td, d_param, hb, off); d_E.place(Ep, d_param, hb, off);
     d_PinvT.place(PinvT, d_param, hb, off); d_PT.place(PT, d_param, hb, off); d_Prm.place(Prm, d_param, hb, off);
     d_Pinvrm.place(Pinvrm, d_param, hb, off);
-    d_dsc.place(dsc, d_param, hb, off); d_dun.place(dun, d_param, hb, off); d_dpow.place(dpow, d_param, hb, off);
+    d_dsc.place(dsc, d_param, hb, off); d_dun.place(dun, d_param, hb, off);
     d_g_scale.place(gsc, d_param, hb, off); d_g_logscale.place(gls, d_param, hb, off);
     if (Mp <= 64 && chain_mode == 1) {
         d_T4.place(T4, d_param, hb, off); d_fA2.place(fA2, d_param, hb, off); d_fB2.place(fB2, d_param, hb, off);
@@ -1002,6 +1006,11 @@ void smcpp_im::host_prep_and_upload() {
     if (off > need) throw std::runtime_error("internal: parameter arena overflow");
     auto tp2 = std::chrono::steady_clock::now();
     HIPCHK(hipMemcpyAsync(d_param, hb, off, hipMemcpyHostToDevice, s));
+    // (d_r / scale)^span for every (span, eigen key) group: G x M calls of pow() - 2 ms of host time on data with a few
+    // thousand distinct spans, microseconds here
+    if (G > 0)
+        hipLaunchKernelGGL(k_group_dpow, dim3(ceil_div((long long)G * Mp, 256)), dim3(256), 0, s, G, M, Mp, (const int *)d_g_span.p,
+                           (const int *)d_g_eig.p, (const double *)d_dsc.p, d_dpow.p);
     {
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         host_timing[1] = ms(tp0, tp1);
@@ -1187,7 +1196,7 @@ ChainArgs smcpp_im::chain_args() {
     a.eps_f = eps_f; a.eps_b = eps_b;
     a.dbg = nullptr;
     a.warm_f = nullptr; a.warm_b = nullptr;
-    a.Bf = d_Bf.p; a.Bb = d_Bb.p; a.g_span = d_g_span.p;
+    a.Bf = d_Bf.p; a.Bb = d_Bb.p; a.g_span = d_g_span.p; a.nbits = pw_nbits; a.npow = pw_npow;
     { static const int pr = getenv("SMCPP_BWD_PRIO") ? std::max(0, std::min(3, atoi(getenv("SMCPP_BWD_PRIO")))) : 1; a.prio = pr; }
     a.changed = nullptr;
     return a;
@@ -1288,10 +1297,10 @@ void smcpp_im::stage_static_and_prepass() {
     d_changed_f.zero(s);
     d_changed_b.zero(s);
     {
-        const size_t shm = (size_t)(2 * Mp * (Mp + 1)) * sizeof(double);
+        const size_t shm = (size_t)(2 * Mp * (Mp + 1) + 8) * sizeof(double);
         switch (Mp) {
 #define P_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_binary_powers<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
-                    hipLaunchKernelGGL(k_binary_powers<x>, dim3(Ke), dim3(256), shm, s, M, (const int *)d_e_kid.p, a.E, pre_Td, d_Bf.p, d_Bb.p); } break;
+                    hipLaunchKernelGGL(k_binary_powers<x>, dim3(Ke), dim3(256), shm, s, M, pw_npow, (const int *)d_e_kid.p, a.E, pre_Td, d_Bf.p, d_Bb.p); } break;
             P_(16) P_(32) P_(48) P_(64)
 #undef P_
             default: throw std::runtime_error("internal: power pre-pass with an unsupported state count");

@@ -137,6 +137,7 @@ struct ChainArgs {
     const float *Bf;        // [Ke][4][Mp][Mp]
     const double *Bb;       // [Ke][4][Mp][Mp]
     const int *g_span;      // [G]
+    int nbits, npow;        // eigen-free pre-pass: bits of the longest span, powers stored per key (= max(4, nbits - 1))
     int prio;               // wave priority (s_setprio) of the backward cooperative kernels, 0..3
     const float *warm_f;    // [nchunks][Mp] end vectors of the forward chunks
     const double *warm_b;   // [nchunks][Mp] end vectors of the backward chunks
@@ -1743,6 +1744,17 @@ __global__ __launch_bounds__(256) void k_pow_layout(int Mp, const double *__rest
     const int KQ = Mp / 4, q = d & 3, i = (d >> 2) % Mp, t = (d >> 2) / Mp, k = q * KQ + t;
     qBf[mo + d] = (float)W[mo + (size_t)i * Mp + k];
     qBb[mo + d] = (float)W[mo + (size_t)k * Mp + i];
+}
+
+// Eigenvalue powers of every (span, eigen key) group: dpow[g][i] = (d_r[i] / scale)^span   (transition_bundle.h:9-30 keeps
+// d_scaled; hmm.cpp:72,112 raise it to the span of the row)
+__global__ __launch_bounds__(256) void k_group_dpow(int G, int M, int Mp, const int *__restrict__ g_span,
+                                                     const int *__restrict__ g_eig, const double *__restrict__ dsc,
+                                                     double *__restrict__ dpow) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)G * Mp) return;
+    const int g = (int)(idx / Mp), i = (int)(idx % Mp);
+    dpow[idx] = (i < M) ? pow(dsc[(size_t)g_eig[g] * Mp + i], (double)g_span[g]) : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

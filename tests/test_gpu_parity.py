@@ -382,6 +382,49 @@ def test_eigen_free_prepass_on_and_off_vs_oracle(M, n):
         assert np.all(np.abs(res[mode][3] - res[0][3]) <= 1e-6 * np.maximum(np.abs(res[0][3]), 1e-12)), mode
 
 
+@pytest.mark.parametrize("M,n,max_span", [(64, 20, 4000), (32, 6, 700), (48, 9, 100)])
+def test_eigen_free_prepass_with_long_spans_vs_oracle(M, n, max_span):
+    """Spans of 32 .. 4095 positions: the pre-pass applies rescaled powers A^32 .. A^2048 from L2 on the rows that need them;
+    every stored row still comes from the eigensystem kernels.  Pre-pass on / off against the C restatement."""
+    import os
+    from oracle import oracle
+    from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel
+    hs = synth.hidden_states(M)
+    a, s = synth.model_pieces()
+    rng = np.random.RandomState(M + n)
+    contigs = []
+    for ci, L in enumerate([2_000_000, 200_000]):
+        c = synth.synth_contig(500 + M + ci, L, n).copy()
+        long_rows = np.nonzero(c[:, 0] > 1)[0]
+        pick = rng.choice(long_rows, size=len(long_rows) // 12, replace=False)
+        c[pick, 0] = rng.randint(32, max_span + 1, size=len(pick))         # a twelfth of the runs becomes long
+        c[pick[0], 0] = max_span
+        contigs.append(np.ascontiguousarray(c))
+    res = {}
+    for mode in (0, 1):
+        os.environ["SMCPP_POWER_PREPASS"] = str(mode)
+        try:
+            im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
+            im.model = PiecewiseModel(a, s, 1e4, "pop1")
+            im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0
+            im.E_step(); im.E_step()
+            res[mode] = (np.array(im.logliks()), im.xisums, im.gamma_sums)
+        finally:
+            os.environ.pop("SMCPP_POWER_PREPASS", None)
+    pi, T, keys = im.pi, im.transition, im.keys
+    ep = im.emission_probs
+    Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
+    for c, ob in enumerate(contigs):
+        o = oracle.estep(pi, T, keys, Etab, ob)
+        for mode, (lls, xs, gss) in res.items():
+            assert abs(lls[c] - o["loglik"]) <= LL_TOL * abs(o["loglik"]), mode
+            assert rel_err(xs[c], o["xisum"]) <= STAT_TOL, mode
+            for k, v in o["gamma_sums"].items():
+                assert np.max(np.abs(gss[c][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300), (mode, k)
+    assert np.all(np.abs(res[1][0] - res[0][0]) <= 1e-8 * np.abs(res[0][0]))
+
+
 def test_many_tiny_contigs():
     """300 contigs of 1-40 rows each (ragged, most shorter than any chunk): per-contig results against the oracle."""
     from oracle import oracle

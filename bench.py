@@ -159,7 +159,7 @@ def main():
     # torch.distributed.run exports OMP_NUM_THREADS=1 to every rank; the engine's host phase (conditioned SFS per
     # hidden state, one eigensystem per eigen key) wants a handful of threads — the reference's --cores / set_num_threads
     # (M >= 128: the 256 x 256 eigenproblems run on teams of 8 threads per eigen key, nonsym_eig_team.hpp)
-    default_threads = "8" if WORKLOADS[args.workload][0] < 128 else "15"
+    default_threads = "12" if WORKLOADS[args.workload][0] < 128 else "15"
     host_threads = max(1, min(int(os.environ.get("SMCPP_BENCH_THREADS", default_threads)), (os.cpu_count() or 8) // max(1, world)))
     _smcpp.set_num_threads(host_threads)
     M, n, fixture, desc = WORKLOADS[args.workload]

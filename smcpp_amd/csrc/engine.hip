@@ -9,6 +9,7 @@
 // every compute entry point fails with an error if no HIP device is usable.
 #include <hip/hip_runtime.h>
 #include <omp.h>
+#include <mutex>
 
 #include <algorithm>
 #include <chrono>
@@ -870,10 +871,15 @@ void smcpp_im::host_prep_and_upload() {
     // Every team is confined to one L3 domain for the duration of the region (see nonsym_eig_team.hpp: unpinned on a
     // two-socket host the element hand-overs make it slower than the serial routine); without sysfs topology, or with
     // SMCPP_EIG_TEAM=1, the serial routine runs.
-    static const std::vector<std::vector<int>> l3 = smcpp_host::cpu_l3_groups();
-    int team = (M >= 128 && Ke >= 1 && (int)l3.size() >= Ke) ? std::min(8, omp_get_max_threads() / Ke) : 1;
+    static std::vector<std::vector<int>> l3;
+    static std::once_flag l3_once;
+    int team = (M >= 128 && Ke >= 1) ? std::min(8, omp_get_max_threads() / Ke) : 1;
     if (const char *te = getenv("SMCPP_EIG_TEAM")) team = std::max(1, std::min(16, atoi(te)));
-    if (M < 32 || (int)l3.size() < Ke) team = 1;
+    if (M < 32) team = 1;
+    if (team >= 2) {
+        std::call_once(l3_once, [] { l3 = smcpp_host::cpu_l3_groups(); });     // a few hundred sysfs reads, once per process
+        if ((int)l3.size() < Ke) team = 1;
+    }
     bool team_done = false;
     if (team >= 2) {
         pack_static();

@@ -295,7 +295,10 @@ struct smcpp_im {
     void setup_power();
     ChainArgs chain_args();
     void run_chains();
-    void run_stats();
+    void run_stats();            // = enqueue_stats() unless run_chains() already queued them, + finish_stats()
+    void enqueue_stats();
+    void finish_stats();
+    bool stats_enqueued = false;
     void estep();
     void fetch_stats();
     void prepare_params();
@@ -1443,6 +1446,11 @@ void smcpp_im::run_chains() {
             HIPCHK(hipStreamWaitEvent(s, ev[6], 0));   // the statistics (main stream) need both chains
         }
         HIPCHK(hipEventRecord(ev[3], s));
+        // Optimistic: the first batch normally contains the quiet pass (it is sized from the previous E-step), so the
+        // statistics are queued behind it BEFORE the host waits for the flags - the read-back round trip and their launch
+        // latency disappear behind GPU work.  If the flags say otherwise the statistics are simply queued again later.
+        if (first_round && !save_gamma) enqueue_stats();
+        else stats_enqueued = false;
         HIPCHK(hipStreamSynchronize(s));
         if (dual) HIPCHK(hipStreamSynchronize(sb));
         first_round = false;
@@ -1451,6 +1459,7 @@ void smcpp_im::run_chains() {
         fdone = fq >= 0 || launched_f >= max_pass;
         bdone = bq >= 0 || launched_b >= max_pass;
         if (fdone && bdone) break;
+        stats_enqueued = false;             // more passes follow: whatever was queued is stale
         if (!fdone) want_f = std::min(max_pass, launched_f + 4);
         if (!bdone) want_b = std::min(max_pass, launched_b + 4);
     }
@@ -1461,7 +1470,7 @@ void smcpp_im::run_chains() {
         for (int w = 0; w < 4; ++w)
             fprintf(stderr, "[cycles] fwd wg1 wave%d: loop %lld, end-barrier %lld, mid-barrier %lld, rows %lld\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
     }
-    if (fq < 0 || bq < 0) throw std::runtime_error("chunk-boundary iteration did not converge");
+    if (fq < 0 || bq < 0) { stats_enqueued = false; throw std::runtime_error("chunk-boundary iteration did not converge"); }
     last_fwd_passes = fq;
     last_bwd_passes = bq;
     if (warm_start && chain_mode == 2 && Mp <= 64) {
@@ -1478,6 +1487,17 @@ void smcpp_im::run_chains() {
 }
 
 void smcpp_im::run_stats() {
+    if (!stats_enqueued) enqueue_stats();
+    finish_stats();
+}
+
+void smcpp_im::finish_stats() {
+    HIPCHK(hipStreamSynchronize(stream));
+    std::memcpy(loglik.data(), h_ll, sizeof(double) * n_contigs);
+    stats_enqueued = false;
+}
+
+void smcpp_im::enqueue_stats() {
     hipStream_t s = stream;
     // log-likelihood (also materialises log_c per row)
     LoglikArgs la;
@@ -1612,8 +1632,7 @@ void smcpp_im::run_stats() {
     }
     HIPCHK(hipMemcpyAsync(h_ll, d_loglik.p, sizeof(double) * n_contigs, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(ev[5], s));
-    HIPCHK(hipStreamSynchronize(s));
-    std::memcpy(loglik.data(), h_ll, sizeof(double) * n_contigs);
+    stats_enqueued = true;
 }
 
 void smcpp_im::estep() {

@@ -342,11 +342,11 @@ def test_state_count_sweep_vs_oracle(M, n, length, chunk):
             assert not np.any(margin[mism] > 1e-5)
 
 
-@pytest.mark.parametrize("M,n", [(64, 20), (32, 10), (48, 7), (16, 4)])
+@pytest.mark.parametrize("M,n", [(64, 20), (32, 10), (48, 7), (16, 4), (130, 6), (256, 8)])
 def test_eigen_free_prepass_on_and_off_vs_oracle(M, n):
     """The two ways the cooperative chains run on binned data (spans < 32): eigensystem kernels only
-    (SMCPP_POWER_PREPASS=0) and eigen-free pre-pass + a full eigensystem pass (the default).  Each against the C
-    restatement at the stated tolerances, and against each other far below them (every stored row comes from the
+    (SMCPP_POWER_PREPASS=0) and eigen-free pre-pass + a full eigensystem pass (the default; cooperative kernels for
+    M <= 64, streamed-operand kernels with device-built powers above).  Each against the C restatement at the stated tolerances, and against each other far below them (every stored row comes from the
     eigensystem kernels either way; the pre-pass only changes the start vectors of the chunks)."""
     import os
     from oracle import oracle
@@ -354,7 +354,7 @@ def test_eigen_free_prepass_on_and_off_vs_oracle(M, n):
     from smcpp_amd.model import PiecewiseModel
     hs = synth.hidden_states(M)
     a, s = synth.model_pieces()
-    contigs = [synth.synth_contig(300 + M, 3_000_000, n), synth.synth_contig(301 + M, 150_000, n)]
+    contigs = [synth.synth_contig(300 + M, 3_000_000 if M <= 64 else 1_200_000, n), synth.synth_contig(301 + M, 150_000, n)]
     res = {}
     for mode in (0, 1):
         os.environ["SMCPP_POWER_PREPASS"] = str(mode)

@@ -160,7 +160,17 @@ def main():
     # hidden state, one eigensystem per eigen key) wants a handful of threads — the reference's --cores / set_num_threads
     # (M >= 128: the 256 x 256 eigenproblems run on teams of 8 threads per eigen key, nonsym_eig_team.hpp)
     default_threads = "12" if WORKLOADS[args.workload][0] < 128 else "15"
-    host_threads = max(1, min(int(os.environ.get("SMCPP_BENCH_THREADS", default_threads)), (os.cpu_count() or 8) // max(1, world)))
+    # never more than this rank's share of the CPUs the container may actually use (cgroup quota, not os.cpu_count():
+    # the 1-GPU box shows 256 CPUs and allows 16; OpenMP workers spin between regions and eat the quota of their neighbours)
+    avail = os.cpu_count() or 8
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            avail = max(1, min(avail, int(int(q) / int(per))))
+    except Exception:  # noqa: BLE001
+        pass
+    share = max(1, avail // max(1, world) - (1 if avail // max(1, world) > 2 else 0))
+    host_threads = max(1, min(int(os.environ.get("SMCPP_BENCH_THREADS", default_threads)), share))
     _smcpp.set_num_threads(host_threads)
     M, n, fixture, desc = WORKLOADS[args.workload]
     length_bp = int(args.length_mbp * 1e6)

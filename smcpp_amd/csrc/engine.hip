@@ -27,6 +27,7 @@
 #include "../../include/smcpp_engine.h"
 #include "kernels.hpp"
 #include "chains2.hpp"
+#include "chains_lock.hpp"
 #include "nonsym_eig.hpp"
 #include "nonsym_eig_team.hpp"
 #include "prep.hpp"
@@ -205,7 +206,7 @@ struct smcpp_im {
     DevBuf<double> d_fA2, d_fB2, d_bA2, d_bB2, d_bC2;
     int wpb = 4;
     int chain_mode = 2;   // 0 generic, 1 LDS-resident (one wavefront per chunk), 2 CU-cooperative (one workgroup per chunk),
-                          // 3 CU-cooperative with streamed operands (64 < M <= 256)
+                          // 3 CU-cooperative with streamed operands (64 < M <= 256), 4 lock-step on the matrix cores (16 chunks per workgroup)
     int coop_bpc = 1;     // cooperative workgroups resident per CU the automatic chunking aims at
     int hot_eig = -1, hot_eig2 = -1;
     // eigen-free pre-pass (chains2.hpp: k_group_powers, POWER instantiations): pass 0 runs on group powers while the host
@@ -440,6 +441,11 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
     loglik.assign(n_contigs, 0.0);
 }
 
+static long long lock_min_rows() {
+    static const long long v = getenv("SMCPP_LOCK_MIN_ROWS") ? atoll(getenv("SMCPP_LOCK_MIN_ROWS")) : 1200;
+    return v;
+}
+
 void smcpp_im::make_chunks() {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -447,8 +453,12 @@ void smcpp_im::make_chunks() {
         const char *w = getenv("SMCPP_WPB");
         wpb = (w && atoi(w) == 8) ? 8 : 4;
         const char *m = getenv("SMCPP_CHAIN");
-        if (m) chain_mode = !strcmp(m, "generic") ? 0 : !strcmp(m, "lds") ? 1 : 2;
+        if (m) chain_mode = !strcmp(m, "generic") ? 0 : !strcmp(m, "lds") ? 1 : (!strcmp(m, "lock") && Mp == 64) ? 4 : 2;
         if (getenv("SMCPP_GENERIC_CHAINS")) chain_mode = 0;
+        // lock-step chains on the matrix cores (chains_lock.hpp): 16 chunks per workgroup, so 16 x more and 16 x shorter
+        // chunks - they pay off when those are still long against the ~900 rows of history every chunk re-runs
+        if (!m && Mp == 64 && (total_rows - n_contigs) / ((long long)prop.multiProcessorCount * LOCK_NC) >= lock_min_rows())
+            chain_mode = 4;
         // 64 < M <= 256: the streaming cooperative kernels (k_fwd_big / k_bwd_big) unless generic is forced
         if (Mp > 64) chain_mode = (chain_mode == 0) ? 0 : 3;
         const char *b = getenv("SMCPP_COOP_BPC");
@@ -462,7 +472,8 @@ void smcpp_im::make_chunks() {
         }
     }
     // chunks in flight: one per SIMD for the per-wavefront kernels, coop_bpc per CU for the cooperative ones
-    const long long slots = (long long)prop.multiProcessorCount * (chain_mode >= 2 ? (chain_mode == 3 ? 1 : coop_bpc) : wpb);
+    const long long slots = (long long)prop.multiProcessorCount *
+                            (chain_mode == 4 ? LOCK_NC : chain_mode >= 2 ? (chain_mode == 3 ? 1 : coop_bpc) : wpb);
     long long rows = total_rows - n_contigs;
     int lc = user_rows_per_chunk;
     if (lc <= 0) {
@@ -1138,6 +1149,18 @@ static void launch_chain_big_t(bool fwd, const ChainArgs &a, const BigArgs &qa, 
     if (fwd) hipLaunchKernelGGL((k_fwd_big<MT_>), dim3(a.nchunks), dim3(MT_ * 4), 0, s, a, qa);
     else hipLaunchKernelGGL((k_bwd_big<MT_>), dim3(a.nchunks), dim3(MT_ * 4), 0, s, a, qa);
 }
+static bool launch_chain_lock(bool fwd, int Mp, const ChainArgs &a, hipStream_t s) {
+    if (Mp != 64) return false;
+    const dim3 grid((unsigned)((a.nchunks + LOCK_NC - 1) / LOCK_NC)), block(256);
+    if (fwd) {
+        if (a.pass > 0) hipLaunchKernelGGL((k_fwd_lock<64, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_fwd_lock<64, false>), grid, block, 0, s, a);
+    } else {
+        if (a.pass > 0) hipLaunchKernelGGL((k_bwd_lock<64, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_bwd_lock<64, false>), grid, block, 0, s, a);
+    }
+    return true;
+}
 static bool launch_chain_big(bool fwd, int Mp, const ChainArgs &a, const BigArgs &qa, hipStream_t s) {
     switch (Mp) {
 #define B_(x) case x: launch_chain_big_t<x>(fwd, a, qa, s); return true;
@@ -1407,7 +1430,7 @@ void smcpp_im::run_chains() {
     };
     // The two chains are independent (beta does not depend on alpha).  The cooperative kernels leave most of a CU's
     // LDS and issue slots idle, so the backward passes run on a second stream and share the CUs with the forward ones.
-    const bool dual = dual_stream && ((chain_mode == 2 && Mp <= 64) || Mp > 64);
+    const bool dual = dual_stream && ((chain_mode == 2 && Mp <= 64) || chain_mode == 4 || Mp > 64);
     hipStream_t sb = dual ? stream2 : s;
     if (dual) {
         HIPCHK(hipEventRecord(ev[6], s));              // parameters / zeroed flags are ready on the main stream
@@ -1422,7 +1445,8 @@ void smcpp_im::run_chains() {
             a.changed = d_changed_f.p;
             for (; launched_f < want_f; ++launched_f) {
                 set_variant(launched_f);
-                if (!(chain_mode == 3 && launch_chain_big(true, Mp, a, bargs, s)) &&
+                if (!(chain_mode == 4 && launch_chain_lock(true, Mp, a, s)) &&
+                    !(chain_mode == 3 && launch_chain_big(true, Mp, a, bargs, s)) &&
                     !(chain_mode == 2 && launch_chain_coop(true, Mp, a, cargs, tab_c, shm_c, s)))
                     launch_chain(true, NPL, Mp, generic, a, lf, tab_lds, wpb, shm_f, s);
             }
@@ -1432,7 +1456,8 @@ void smcpp_im::run_chains() {
             a.changed = d_changed_b.p;
             for (; launched_b < want_b; ++launched_b) {
                 set_variant(launched_b);
-                if (!(chain_mode == 3 && launch_chain_big(false, Mp, a, bargs, sb)) &&
+                if (!(chain_mode == 4 && launch_chain_lock(false, Mp, a, sb)) &&
+                    !(chain_mode == 3 && launch_chain_big(false, Mp, a, bargs, sb)) &&
                     !(chain_mode == 2 && launch_chain_coop(false, Mp, a, cargs, tab_c, shm_c, sb)))
                     launch_chain(false, NPL, Mp, generic, a, lb, tab_lds, wpb, shm_b, sb);
             }

@@ -425,6 +425,53 @@ def test_eigen_free_prepass_with_long_spans_vs_oracle(M, n, max_span):
     assert np.all(np.abs(res[1][0] - res[0][0]) <= 1e-8 * np.abs(res[0][0]))
 
 
+@pytest.mark.parametrize("M,n,chunk", [(64, 20, 0), (64, 12, 37), (50, 6, 150), (64, 8, 400)])
+def test_lock_step_chains_vs_oracle(M, n, chunk):
+    """The lock-step chains (16 chunks per workgroup on the matrix cores, chains_lock.hpp) forced on small inputs: ragged
+    contigs (so the 16 columns of a workgroup have different lengths and some do not exist), chunks far shorter than the
+    chains' memory (many passes, per-column merge exits and skip tests), three eigen keys (one register-resident), against the
+    C restatement and against the cooperative kernels."""
+    import os
+    from oracle import oracle
+    from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel
+    hs = synth.hidden_states(M)
+    a, s = synth.model_pieces()
+    contigs = [synth.synth_contig(700 + M + i, L, n) for i, L in enumerate([1_500_000, 40_000, 600_000, 900, 250_000])]
+    res = {}
+    for mode in ("coop", "lock"):
+        os.environ["SMCPP_CHAIN"] = mode
+        try:
+            im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
+            im.model = PiecewiseModel(a, s, 1e4, "pop1")
+            im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0
+            if chunk > 0:
+                im.set_chunking(chunk)
+            im.save_gamma = True
+            im.E_step(); im.E_step()
+            res[mode] = (np.array(im.logliks()), im.xisums, im.gamma_sums, im.gammas)
+        finally:
+            os.environ.pop("SMCPP_CHAIN", None)
+    pi, T, keys = im.pi, im.transition, im.keys
+    ep = im.emission_probs
+    Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
+    for c, ob in enumerate(contigs):
+        o = oracle.estep(pi, T, keys, Etab, ob, save_gamma=True)
+        for mode, (lls, xs, gss, gams) in res.items():
+            assert abs(lls[c] - o["loglik"]) <= LL_TOL * abs(o["loglik"]), mode
+            assert rel_err(xs[c], o["xisum"]) <= STAT_TOL, mode
+            for k, v in o["gamma_sums"].items():
+                assert np.max(np.abs(gss[c][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300), (mode, k)
+            g_ref = o["gamma"]
+            assert np.max(np.abs(gams[c] - g_ref)) <= 2e-5 * max(1.0, float(np.abs(g_ref).max())), mode
+            top2 = np.sort(g_ref, axis=0)[-2:]
+            margin = (top2[1] - top2[0]) / np.maximum(top2[1], 1e-300)
+            mism = np.nonzero(gams[c].argmax(axis=0) != g_ref.argmax(axis=0))[0]
+            assert not np.any(margin[mism] > 1e-5), mode
+    # (the span-1 product is rounded differently - fp64 MFMA then float vs float FMAs - so the two agree at float noise level)
+    assert np.all(np.abs(res["lock"][0] - res["coop"][0]) <= 2 * LL_TOL * np.abs(res["coop"][0]))
+
+
 def test_many_tiny_contigs():
     """300 contigs of 1-40 rows each (ragged, most shorter than any chunk): per-contig results against the oracle."""
     from oracle import oracle

@@ -9,15 +9,17 @@
 //
 // Semantics are those of hmm.cpp:57-149 exactly as k_fwd_coop2 / k_bwd_coop2 (chains2.hpp) implement them: float alpha with
 // the 1e-10 floor applied relative to the running sum, double beta, chunk-parallel fixed point with per-chunk skip test,
-// merge exit and certificate (here per COLUMN; a workgroup stops when all of its columns have).  The span-1 product is done in
-// fp64 and rounded to float afterwards (the reference multiplies in float): the same operator, different rounding, inside the
-// float noise the reference itself carries.
+// merge exit and certificate (here per COLUMN; a workgroup stops when all of its columns have).  The forward span-1 product is a
+// float product as in the reference (v_mfma_f32_16x16x4, other summation order than Eigen's: the float noise the reference
+// itself carries).
 // tools/chain_lab.hip `m` measured the structure first: 2.35 us per lock-step row with three products = 147 ns per chain-row
 // against 630 ns of the cooperative kernels - but 16 x more chunks, hence 16 x shorter ones, and every chunk pays ~900 rows of
 // re-run history: it only wins above ~3.7 M rows per GPU.
 #pragma once
 
 namespace smcpp_dev {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int LOCK_NC = 16;      // chunks (columns) per workgroup
 constexpr int LOCK_W = 64;       // descriptor window (rows per refill)
@@ -123,8 +125,17 @@ __global__ __launch_bounds__(256) void k_fwd_lock(ChainArgs a) {
         if (ch.first && w == 0 && kk == 0) a.cnorm[ch.base] = 1.0;
     }
     // ---- operators: T^T and the hot eigen key in registers ----
-    double at[16], ap[16], aq[16];
-    lock_frags_rm<MT>(a.TdT, w, lane, at);                                    // (T^T)[i][k] = TdT[i][k]
+    // T^T in FLOAT (the reference's span-1 product is a float product, hmm.cpp:83): v_mfma_f32_16x16x4 is half the cycles of
+    // the f64 form.  Its D layout is row = 4 (lane >> 4) + reg where the f64 form has (lane >> 4) + 4 reg, so the rows of the
+    // A operand are permuted (tile row m stands for state (m >> 2) + 4 (m & 3)): both products then hold the same four states
+    // in the same four registers of a lane
+    float at[16];
+    double ap[16], aq[16];
+    {
+        const int m = lane & 15, sig = (m >> 2) + 4 * (m & 3);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) at[t] = (float)a.TdT[(size_t)(16 * w + sig) * MT + 4 * t + kk];       // (T^T)[i][k] = TdT[i][k]
+    }
     const size_t ho = (size_t)(a.hot < 0 ? 0 : a.hot) * Mp * Mp;
     lock_frags_rm<MT>(a.Pinvrm + ho, w, lane, ap);                            // Pinv[i][k]
     lock_frags_rm<MT>(a.Prm + ho, w, lane, aq);                               // P[i][k]
@@ -216,7 +227,9 @@ __global__ __launch_bounds__(256) void k_fwd_lock(ChainArgs a) {
         for (int t = 0; t < 16; ++t) b[t] = fmax(b[t], thr);
         const bool eig = compute && d_cur.y >= 0;
         const int es = eig ? SMCPP_ES(d_cur.y) : -1;
-        const f64x4 Y = lock_prod(at, b);
+        f32x4v Y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 16; ++t) Y = __builtin_amdgcn_mfma_f32_16x16x4f32(at[t], (float)b[t], Y, 0, 0, 0);
         f64x4 U = {0, 0, 0, 0};
         const bool any_eig = __any(eig);
         bool other = eig && es != a.hot;
@@ -261,7 +274,7 @@ __global__ __launch_bounds__(256) void k_fwd_lock(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 16 * w + kk + 4 * r;
-            const float y = (float)Y[r] * inv;
+            const float y = Y[r] * inv;
             float v = eig ? (float)V[r] : (float)((double)y * e_cur[r]);
             v = (i < M && compute) ? v : 0.f;
             vprev[r] = v;

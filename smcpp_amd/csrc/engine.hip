@@ -442,7 +442,7 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
 }
 
 static long long lock_min_rows() {
-    static const long long v = getenv("SMCPP_LOCK_MIN_ROWS") ? atoll(getenv("SMCPP_LOCK_MIN_ROWS")) : 1200;
+    static const long long v = getenv("SMCPP_LOCK_MIN_ROWS") ? atoll(getenv("SMCPP_LOCK_MIN_ROWS")) : 450;
     return v;
 }
 

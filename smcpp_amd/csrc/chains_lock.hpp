@@ -1,7 +1,7 @@
-// Lock-step chains on the matrix cores (M <= 64 padded to MT = 64, inputs with at least 16 chunks per CU: a whole genome on
-// one GPU).  SIXTEEN chunks advance together in one workgroup: the state is the MT x 16 matrix X (one column per chunk) and a
+// Lock-step chains on the matrix cores (M <= 64, MT = padded width; inputs with long chunks even at 16 chunks per CU: a whole
+// genome on one GPU).  SIXTEEN chunks advance together in one workgroup: the state is the MT x 16 matrix X (one column per chunk) and a
 // row-step is  Y = T^T X  (chunks on a span-1 row),  U = Pinv X, V = P (d^s o U)  (chunks on an eigen row) as
-// v_mfma_f64_16x16x4_f64 tiles - wavefront w owns state tile w, the A fragments (operator quarters: 16 k-steps each) of T and
+// v_mfma_f64_16x16x4_f64 tiles - wavefront w owns state tile w (MT / 16 wavefronts), the A fragments (MT / 4 k-steps each) of T and
 // of the hot eigen key stay in registers, X goes through LDS once per product.  All products are computed for all 16 columns
 // (neighbouring chunks sit on rows of different type) and the result is selected per column.  Emission and eigenvalue-power
 // vectors of the NEXT row are fetched from L2 one step ahead (the descriptors are known), so no table lives in LDS and a
@@ -37,32 +37,33 @@ struct LockShared {
 };
 
 // one operator applied to X: acc = A X with A fragments `af` (16 k-steps) and B fragments `b`
-__device__ __forceinline__ f64x4 lock_prod(const double (&af)[16], const double (&b)[16]) {
+template <int KS>
+__device__ __forceinline__ f64x4 lock_prod(const double (&af)[KS], const double (&b)[KS]) {
     f64x4 acc = {0, 0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t], b[t], acc, 0, 0, 0);
+    for (int t = 0; t < KS; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t], b[t], acc, 0, 0, 0);
     return acc;
 }
 
 // A fragments of a row-major [MT][MT] matrix restricted to output tile w: A[m = lane & 15][k = 4 t + (lane >> 4)] = Mx[(16 w + m) MT + k]
 template <int MT>
-__device__ __forceinline__ void lock_frags_rm(const double *__restrict__ Mx, int w, int lane, double (&af)[16]) {
+__device__ __forceinline__ void lock_frags_rm(const double *__restrict__ Mx, int w, int lane, double (&af)[MT / 4]) {
     const int m = lane & 15, kk = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) af[t] = (4 * t + kk < MT) ? Mx[(size_t)(16 * w + m) * MT + 4 * t + kk] : 0.0;
+    for (int t = 0; t < MT / 4; ++t) af[t] = Mx[(size_t)(16 * w + m) * MT + 4 * t + kk];
 }
 // ... of the TRANSPOSE of a row-major matrix: A[m][k] = Mx[k MT + 16 w + m]
 template <int MT>
-__device__ __forceinline__ void lock_frags_tr(const double *__restrict__ Mx, int w, int lane, double (&af)[16]) {
+__device__ __forceinline__ void lock_frags_tr(const double *__restrict__ Mx, int w, int lane, double (&af)[MT / 4]) {
     const int m = lane & 15, kk = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) af[t] = (4 * t + kk < MT) ? Mx[(size_t)(4 * t + kk) * MT + 16 * w + m] : 0.0;
+    for (int t = 0; t < MT / 4; ++t) af[t] = Mx[(size_t)(4 * t + kk) * MT + 16 * w + m];
 }
 
 template <int MT, bool RERUN>
-__global__ __launch_bounds__(256) void k_fwd_lock(ChainArgs a) {
-    static_assert(MT == 64, "lock-step chains: 64 padded states (four state tiles, four wavefronts)");
-    constexpr int Mp = MT;
+__global__ __launch_bounds__(MT * 4) void k_fwd_lock(ChainArgs a) {
+    static_assert(MT % 16 == 0 && MT >= 16 && MT <= 64, "lock-step chains: one wavefront per tile of 16 padded states");
+    constexpr int Mp = MT, KS = MT / 4, NTH = MT * 4;
     __shared__ __attribute__((aligned(16))) LockShared<MT> sh;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n = lane & 15, kk = lane >> 4;                 // column (chunk), k within a 4-step / row group of the D tile
@@ -129,18 +130,18 @@ __global__ __launch_bounds__(256) void k_fwd_lock(ChainArgs a) {
     // the f64 form.  Its D layout is row = 4 (lane >> 4) + reg where the f64 form has (lane >> 4) + 4 reg, so the rows of the
     // A operand are permuted (tile row m stands for state (m >> 2) + 4 (m & 3)): both products then hold the same four states
     // in the same four registers of a lane
-    float at[16];
-    double ap[16], aq[16];
+    float at[KS];
+    double ap[KS], aq[KS];
     {
         const int m = lane & 15, sig = (m >> 2) + 4 * (m & 3);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) at[t] = (float)a.TdT[(size_t)(16 * w + sig) * MT + 4 * t + kk];       // (T^T)[i][k] = TdT[i][k]
+        for (int t = 0; t < KS; ++t) at[t] = (float)a.TdT[(size_t)(16 * w + sig) * MT + 4 * t + kk];       // (T^T)[i][k] = TdT[i][k]
     }
     const size_t ho = (size_t)(a.hot < 0 ? 0 : a.hot) * Mp * Mp;
     lock_frags_rm<MT>(a.Pinvrm + ho, w, lane, ap);                            // Pinv[i][k]
     lock_frags_rm<MT>(a.Prm + ho, w, lane, aq);                               // P[i][k]
 #pragma unroll
-    for (int t = 0; t < 16; ++t) { pin_reg(at[t]); pin_reg(ap[t]); pin_reg(aq[t]); }
+    for (int t = 0; t < KS; ++t) { pin_reg(at[t]); pin_reg(ap[t]); pin_reg(aq[t]); }
     // ---- per-column bookkeeping in LDS, first descriptor window, start state ----
     if (w == 0 && kk == 0) {
         sh.base[n] = ch.base + ch.r0 + 1;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void k_fwd_lock(ChainArgs a) {
     int maxrows = 0;
     for (int q = 0; q < LOCK_NC; ++q) maxrows = max(maxrows, sh.nrows[q]);
     auto fill_window = [&](int j0) {
-        for (int x = tid; x < LOCK_NC * LOCK_W; x += 256) {
+        for (int x = tid; x < LOCK_NC * LOCK_W; x += NTH) {
             const int q = x / LOCK_W, o = x % LOCK_W;
             const int nr = sh.nrows[q];
             sh.desc[q][o] = a.rowdesc[sh.base[q] + (nr > 0 ? min(j0 + o, nr - 1) : 0)];
@@ -181,10 +182,10 @@ __global__ __launch_bounds__(256) void k_fwd_lock(ChainArgs a) {
     for (int j = 0; j <= maxrows; ++j) {
         const int cur = j & 1, nxt = cur ^ 1;
         // ---- B fragments of X, column sum (= normaliser of the previous row), relative floor ----
-        double b[16];
+        double b[KS];
         double s = 0.0;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) { b[t] = sh.Xs[cur][4 * t + kk][n]; s += b[t]; }
+        for (int t = 0; t < KS; ++t) { b[t] = sh.Xs[cur][4 * t + kk][n]; s += b[t]; }
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
         const float sprev = (j == 0) ? 1.0f : (float)s;
@@ -224,25 +225,25 @@ __global__ __launch_bounds__(256) void k_fwd_lock(ChainArgs a) {
         const bool compute = running && j < nrows;
         // ---- products ----
 #pragma unroll
-        for (int t = 0; t < 16; ++t) b[t] = fmax(b[t], thr);
+        for (int t = 0; t < KS; ++t) b[t] = fmax(b[t], thr);
         const bool eig = compute && d_cur.y >= 0;
         const int es = eig ? SMCPP_ES(d_cur.y) : -1;
         f32x4v Y = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 16; ++t) Y = __builtin_amdgcn_mfma_f32_16x16x4f32(at[t], (float)b[t], Y, 0, 0, 0);
+        for (int t = 0; t < KS; ++t) Y = __builtin_amdgcn_mfma_f32_16x16x4f32(at[t], (float)b[t], Y, 0, 0, 0);
         f64x4 U = {0, 0, 0, 0};
         const bool any_eig = __any(eig);
         bool other = eig && es != a.hot;
         if (any_eig) {
-            if (__any(eig && es == a.hot)) U = lock_prod(ap, b);
+            if (__any(eig && es == a.hot)) U = lock_prod<KS>(ap, b);
             // eigen keys that are not register-resident: one at a time, fragments from L2
             unsigned long long rest = __ballot(other);
             while (rest) {
                 const int src = __ffsll((long long)rest) - 1;
                 const int e2 = __shfl(es, src, 64);
-                double af[16];
+                double af[KS];
                 lock_frags_rm<MT>(a.Pinvrm + (size_t)e2 * Mp * Mp, w, lane, af);
-                const f64x4 U2 = lock_prod(af, b);
+                const f64x4 U2 = lock_prod<KS>(af, b);
                 if (es == e2) U = U2;
                 rest &= ~__ballot(es == e2);
             }
@@ -255,17 +256,17 @@ __global__ __launch_bounds__(256) void k_fwd_lock(ChainArgs a) {
         lds_barrier();                       // Us complete (every wave takes the same branches: it sees all 16 descriptors)
         f64x4 V = {0, 0, 0, 0};
         if (any_eig) {
-            double ub[16];
+            double ub[KS];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) ub[t] = sh.Us[4 * t + kk][n];
-            if (__any(eig && es == a.hot)) V = lock_prod(aq, ub);
+            for (int t = 0; t < KS; ++t) ub[t] = sh.Us[4 * t + kk][n];
+            if (__any(eig && es == a.hot)) V = lock_prod<KS>(aq, ub);
             unsigned long long rest = __ballot(other);
             while (rest) {
                 const int src = __ffsll((long long)rest) - 1;
                 const int e2 = __shfl(es, src, 64);
-                double af[16];
+                double af[KS];
                 lock_frags_rm<MT>(a.Prm + (size_t)e2 * Mp * Mp, w, lane, af);
-                const f64x4 V2 = lock_prod(af, ub);
+                const f64x4 V2 = lock_prod<KS>(af, ub);
                 if (es == e2) V = V2;
                 rest &= ~__ballot(es == e2);
             }
@@ -300,9 +301,9 @@ __global__ __launch_bounds__(256) void k_fwd_lock(ChainArgs a) {
 // D rows, with the emission vector of the next row fetched one step ahead); beta is stored in the running scale - every
 // consumer of beta is invariant to a per-row scale - and the chunk's end vector is normalised exactly.
 template <int MT, bool RERUN>
-__global__ __launch_bounds__(256) void k_bwd_lock(ChainArgs a) {
-    static_assert(MT == 64, "lock-step chains: 64 padded states (four state tiles, four wavefronts)");
-    constexpr int Mp = MT;
+__global__ __launch_bounds__(MT * 4) void k_bwd_lock(ChainArgs a) {
+    static_assert(MT % 16 == 0 && MT >= 16 && MT <= 64, "lock-step chains: one wavefront per tile of 16 padded states");
+    constexpr int Mp = MT, KS = MT / 4, NTH = MT * 4;
     __shared__ __attribute__((aligned(16))) LockShared<MT> sh;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n = lane & 15, kk = lane >> 4;
@@ -359,13 +360,13 @@ __global__ __launch_bounds__(256) void k_bwd_lock(ChainArgs a) {
         for (int r = 0; r < 4; ++r) a.used_b[(size_t)c * Mp + 16 * w + kk + 4 * r] = bs[r];
     }
     // ---- operators: T, P^T, Pinv^T of the hot key (A[m][k] of the transposes of the row-major / stored forms) ----
-    double at[16], ap[16], aq[16];
+    double at[KS], ap[KS], aq[KS];
     lock_frags_tr<MT>(a.TdT, w, lane, at);                                    // T[i][k] = TdT[k][i]
     const size_t ho = (size_t)(a.hot < 0 ? 0 : a.hot) * Mp * Mp;
     lock_frags_tr<MT>(a.Prm + ho, w, lane, ap);                               // (P^T)[i][k] = P[k][i]
     lock_frags_tr<MT>(a.Pinvrm + ho, w, lane, aq);                            // (Pinv^T)[i][k] = Pinv[k][i]
 #pragma unroll
-    for (int t = 0; t < 16; ++t) { pin_reg(at[t]); pin_reg(ap[t]); pin_reg(aq[t]); }
+    for (int t = 0; t < KS; ++t) { pin_reg(at[t]); pin_reg(ap[t]); pin_reg(aq[t]); }
     if (w == 0 && kk == 0) {
         sh.base[n] = ch.base + ch.r1;              // iteration j reads the descriptor of row r1 - j
         sh.nrows[n] = active ? nrows : 0;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void k_bwd_lock(ChainArgs a) {
     int maxrows = 0;
     for (int q = 0; q < LOCK_NC; ++q) maxrows = max(maxrows, sh.nrows[q]);
     auto fill_window = [&](int j0) {
-        for (int x = tid; x < LOCK_NC * LOCK_W; x += 256) {
+        for (int x = tid; x < LOCK_NC * LOCK_W; x += NTH) {
             const int q = x / LOCK_W, o = x % LOCK_W;
             const int nr = sh.nrows[q];
             sh.desc[q][o] = a.rowdesc[sh.base[q] - (nr > 0 ? min(j0 + o, nr - 1) : 0)];
@@ -405,10 +406,10 @@ __global__ __launch_bounds__(256) void k_bwd_lock(ChainArgs a) {
     bool running = active, merged = false;
     for (int j = 0; j <= maxrows; ++j) {
         const int cur = j & 1, nxt = cur ^ 1;
-        double b[16];
+        double b[KS];
         double s = 0.0;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) { b[t] = sh.Xs[cur][4 * t + kk][n]; s += b[t]; }
+        for (int t = 0; t < KS; ++t) { b[t] = sh.Xs[cur][4 * t + kk][n]; s += b[t]; }
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
         // descriptor of the NEXT row and, if it is a span-1 row, its emission vector on this lane's D rows: in flight during
@@ -456,19 +457,19 @@ __global__ __launch_bounds__(256) void k_bwd_lock(ChainArgs a) {
         const double inv = rcp_f64(s);
         const bool eig = compute && d_cur.y >= 0;
         const int es = eig ? SMCPP_ES(d_cur.y) : -1;
-        const f64x4 Z = lock_prod(at, b);
+        const f64x4 Z = lock_prod<KS>(at, b);
         f64x4 Wv = {0, 0, 0, 0};
         const bool any_eig = __any(eig);
         const bool other = eig && es != a.hot;
         if (any_eig) {
-            if (__any(eig && es == a.hot)) Wv = lock_prod(ap, b);
+            if (__any(eig && es == a.hot)) Wv = lock_prod<KS>(ap, b);
             unsigned long long rest = __ballot(other);
             while (rest) {
                 const int src = __ffsll((long long)rest) - 1;
                 const int e2 = __shfl(es, src, 64);
-                double af[16];
+                double af[KS];
                 lock_frags_tr<MT>(a.Prm + (size_t)e2 * Mp * Mp, w, lane, af);
-                const f64x4 W2 = lock_prod(af, b);
+                const f64x4 W2 = lock_prod<KS>(af, b);
                 if (es == e2) Wv = W2;
                 rest &= ~__ballot(es == e2);
             }
@@ -478,17 +479,17 @@ __global__ __launch_bounds__(256) void k_bwd_lock(ChainArgs a) {
         lds_barrier();
         f64x4 O = {0, 0, 0, 0};
         if (any_eig) {
-            double ub[16];
+            double ub[KS];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) ub[t] = sh.Us[4 * t + kk][n];
-            if (__any(eig && es == a.hot)) O = lock_prod(aq, ub);
+            for (int t = 0; t < KS; ++t) ub[t] = sh.Us[4 * t + kk][n];
+            if (__any(eig && es == a.hot)) O = lock_prod<KS>(aq, ub);
             unsigned long long rest = __ballot(other);
             while (rest) {
                 const int src = __ffsll((long long)rest) - 1;
                 const int e2 = __shfl(es, src, 64);
-                double af[16];
+                double af[KS];
                 lock_frags_tr<MT>(a.Pinvrm + (size_t)e2 * Mp * Mp, w, lane, af);
-                const f64x4 O2 = lock_prod(af, ub);
+                const f64x4 O2 = lock_prod<KS>(af, ub);
                 if (es == e2) O = O2;
                 rest &= ~__ballot(es == e2);
             }

@@ -453,11 +453,11 @@ void smcpp_im::make_chunks() {
         const char *w = getenv("SMCPP_WPB");
         wpb = (w && atoi(w) == 8) ? 8 : 4;
         const char *m = getenv("SMCPP_CHAIN");
-        if (m) chain_mode = !strcmp(m, "generic") ? 0 : !strcmp(m, "lds") ? 1 : (!strcmp(m, "lock") && Mp == 64) ? 4 : 2;
+        if (m) chain_mode = !strcmp(m, "generic") ? 0 : !strcmp(m, "lds") ? 1 : (!strcmp(m, "lock") && Mp <= 64) ? 4 : 2;
         if (getenv("SMCPP_GENERIC_CHAINS")) chain_mode = 0;
         // lock-step chains on the matrix cores (chains_lock.hpp): 16 chunks per workgroup, so 16 x more and 16 x shorter
         // chunks - they pay off when those are still long against the ~900 rows of history every chunk re-runs
-        if (!m && Mp == 64 && (total_rows - n_contigs) / ((long long)prop.multiProcessorCount * LOCK_NC) >= lock_min_rows())
+        if (!m && Mp <= 64 && (total_rows - n_contigs) / ((long long)prop.multiProcessorCount * LOCK_NC) >= lock_min_rows())
             chain_mode = 4;
         // 64 < M <= 256: the streaming cooperative kernels (k_fwd_big / k_bwd_big) unless generic is forced
         if (Mp > 64) chain_mode = (chain_mode == 0) ? 0 : 3;
@@ -1149,17 +1149,25 @@ static void launch_chain_big_t(bool fwd, const ChainArgs &a, const BigArgs &qa, 
     if (fwd) hipLaunchKernelGGL((k_fwd_big<MT_>), dim3(a.nchunks), dim3(MT_ * 4), 0, s, a, qa);
     else hipLaunchKernelGGL((k_bwd_big<MT_>), dim3(a.nchunks), dim3(MT_ * 4), 0, s, a, qa);
 }
-static bool launch_chain_lock(bool fwd, int Mp, const ChainArgs &a, hipStream_t s) {
-    if (Mp != 64) return false;
-    const dim3 grid((unsigned)((a.nchunks + LOCK_NC - 1) / LOCK_NC)), block(256);
+template <int MT_>
+static void launch_chain_lock_t(bool fwd, const ChainArgs &a, hipStream_t s) {
+    const dim3 grid((unsigned)((a.nchunks + LOCK_NC - 1) / LOCK_NC)), block(MT_ * 4);
     if (fwd) {
-        if (a.pass > 0) hipLaunchKernelGGL((k_fwd_lock<64, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_fwd_lock<64, false>), grid, block, 0, s, a);
+        if (a.pass > 0) hipLaunchKernelGGL((k_fwd_lock<MT_, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_fwd_lock<MT_, false>), grid, block, 0, s, a);
     } else {
-        if (a.pass > 0) hipLaunchKernelGGL((k_bwd_lock<64, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_bwd_lock<64, false>), grid, block, 0, s, a);
+        if (a.pass > 0) hipLaunchKernelGGL((k_bwd_lock<MT_, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_bwd_lock<MT_, false>), grid, block, 0, s, a);
     }
-    return true;
+}
+static bool launch_chain_lock(bool fwd, int Mp, const ChainArgs &a, hipStream_t s) {
+    switch (Mp) {
+        case 16: launch_chain_lock_t<16>(fwd, a, s); return true;
+        case 32: launch_chain_lock_t<32>(fwd, a, s); return true;
+        case 48: launch_chain_lock_t<48>(fwd, a, s); return true;
+        case 64: launch_chain_lock_t<64>(fwd, a, s); return true;
+        default: return false;
+    }
 }
 static bool launch_chain_big(bool fwd, int Mp, const ChainArgs &a, const BigArgs &qa, hipStream_t s) {
     switch (Mp) {

@@ -425,7 +425,8 @@ def test_eigen_free_prepass_with_long_spans_vs_oracle(M, n, max_span):
     assert np.all(np.abs(res[1][0] - res[0][0]) <= 1e-8 * np.abs(res[0][0]))
 
 
-@pytest.mark.parametrize("M,n,chunk", [(64, 20, 0), (64, 12, 37), (50, 6, 150), (64, 8, 400)])
+@pytest.mark.parametrize("M,n,chunk", [(64, 20, 0), (64, 12, 37), (50, 6, 150), (64, 8, 400), (32, 10, 0), (33, 5, 90), (16, 4, 60),
+                                       (7, 3, 0)])
 def test_lock_step_chains_vs_oracle(M, n, chunk):
     """The lock-step chains (16 chunks per workgroup on the matrix cores, chains_lock.hpp) forced on small inputs: ragged
     contigs (so the 16 columns of a workgroup have different lengths and some do not exist), chunks far shorter than the

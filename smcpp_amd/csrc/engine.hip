@@ -441,9 +441,12 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
     loglik.assign(n_contigs, 0.0);
 }
 
-static long long lock_min_rows() {
-    static const long long v = getenv("SMCPP_LOCK_MIN_ROWS") ? atoll(getenv("SMCPP_LOCK_MIN_ROWS")) : 450;
-    return v;
+// rows per (CU x 16) from which the lock-step chains win (tools/lock_crossover.py on the whole-genome generator: M = 64 and 48
+// from ~400, M = 32 from ~700; at M = 16 the cooperative kernels are never slower)
+static long long lock_min_rows(int Mp) {
+    static const long long v = getenv("SMCPP_LOCK_MIN_ROWS") ? atoll(getenv("SMCPP_LOCK_MIN_ROWS")) : -1;
+    if (v >= 0) return v;
+    return Mp >= 48 ? 450 : Mp >= 32 ? 800 : (1ll << 40);
 }
 
 void smcpp_im::make_chunks() {
@@ -457,7 +460,7 @@ void smcpp_im::make_chunks() {
         if (getenv("SMCPP_GENERIC_CHAINS")) chain_mode = 0;
         // lock-step chains on the matrix cores (chains_lock.hpp): 16 chunks per workgroup, so 16 x more and 16 x shorter
         // chunks - they pay off when those are still long against the ~900 rows of history every chunk re-runs
-        if (!m && Mp <= 64 && (total_rows - n_contigs) / ((long long)prop.multiProcessorCount * LOCK_NC) >= lock_min_rows())
+        if (!m && Mp <= 64 && (total_rows - n_contigs) / ((long long)prop.multiProcessorCount * LOCK_NC) >= lock_min_rows(Mp))
             chain_mode = 4;
         // 64 < M <= 256: the streaming cooperative kernels (k_fwd_big / k_bwd_big) unless generic is forced
         if (Mp > 64) chain_mode = (chain_mode == 0) ? 0 : 3;

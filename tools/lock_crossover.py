@@ -3,7 +3,7 @@ import os, sys, time, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from smcpp_amd import _smcpp, synth
 from smcpp_amd.model import PiecewiseModel
-M, n = 64, 20
+M, n = int(os.environ.get("LOCK_M", 64)), int(os.environ.get("LOCK_N", 20))
 hs = synth.hidden_states(M); a, s = synth.model_pieces()
 L = [248, 242, 198, 190, 181, 171, 159, 145, 138, 133, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51]
 allc = [synth.synth_contig(i, l * 1_000_000, n) for i, l in enumerate(L)]

@@ -302,7 +302,9 @@ def main():
     k_ms = fwd_ms if dom_fwd else bwd_ms
     k_bytes = bytes_f if dom_fwd else bytes_b
     big = M > 64
-    kname = ("k_fwd_big" if big else "k_fwd_coop") if dom_fwd else ("k_bwd_big" if big else "k_bwd_coop")
+    lock = hasattr(im, "chain_mode") and im.chain_mode() == 4
+    fam = "_lock" if lock else "_big" if big else "_coop"
+    kname = ("k_fwd" if dom_fwd else "k_bwd") + fam
     ach_tflops = flops / (1e-3 * k_ms) / 1e12 if k_ms > 0 else 0.0
     ach_gbs = k_bytes / (1e-3 * k_ms) / 1e9 if k_ms > 0 else 0.0
     roof = dict(bound="mfma", achieved=ach_tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach_tflops / FP64_PEAK_TFLOPS)
@@ -324,7 +326,7 @@ def main():
         kernel_ms_per_step=k_ms, passes=med["fwd_passes"] if dom_fwd else med["bwd_passes"],
         algorithmic_flops_one_pass=flops, algorithmic_bytes_one_pass=k_bytes,
         hbm_gbs=ach_gbs, hbm_frac=ach_gbs / HBM_PEAK_GBS,
-        other_chain={"kernel": ("k_bwd" if dom_fwd else "k_fwd") + ("_big" if big else "_coop"),
+        other_chain={"kernel": ("k_bwd" if dom_fwd else "k_fwd") + fam,
                      "kernel_ms_per_step": bwd_ms if dom_fwd else fwd_ms,
                      "tflops": flops / (1e-3 * (bwd_ms if dom_fwd else fwd_ms)) / 1e12 if min(fwd_ms, bwd_ms) > 0 else 0.0},
         # whole eval on SURVEY.md §8(d)'s F_alg / B_alg (the restructured statistics do not execute the 2 M^3 Re term,

@@ -137,6 +137,9 @@ int smcpp_set_warm_start(smcpp_im *im, int on);
  * [host_prep, chains_wall, forward, backward, stats, finalize, total_device, fwd_passes, bwd_passes]
  * (forward and backward overlap when the two chains run on separate streams; chains_wall is their union) */
 int smcpp_last_timing(smcpp_im *im, double out[9]);
+/* diagnostics: the chain kernel family in use (0 generic, 1 LDS-resident, 2 cooperative, 3 cooperative with streamed
+ * operands, 4 lock-step on the matrix cores) */
+int smcpp_chain_mode(smcpp_im *im);
 /* Host phase of the last E-step in milliseconds: [cold preparation A6-A10 (0 when the parameters were still fresh or
  * came from smcpp_set_raw), eigensystems, layouts + staging + copy enqueue, whole host phase] */
 int smcpp_last_host_timing(smcpp_im *im, double out[4]);

@@ -62,7 +62,7 @@ def lib():
         "smcpp_set_global_keys": (i, [vp, i, _ip]),
         "smcpp_pack_stats": (i, [vp, _dp, C.POINTER(lg), i]), "smcpp_unpack_stats": (i, [vp, _dp, lg, i]),
         "smcpp_set_chunking": (i, [vp, i, d, d]), "smcpp_set_warm_start": (i, [vp, i]),
-        "smcpp_last_timing": (i, [vp, _dp]), "smcpp_last_host_timing": (i, [vp, _dp]), "smcpp_stream": (vp, [vp]),
+        "smcpp_last_timing": (i, [vp, _dp]), "smcpp_last_host_timing": (i, [vp, _dp]), "smcpp_stream": (vp, [vp]), "smcpp_chain_mode": (i, [vp]),
         "smcpp_set_num_threads": (None, [i]),
         "smcpp_host_set_csfs_direct": (i, [i]),
         "smcpp_host_eigensystem": (i, [i, _dp, _dp, _dp, _dp, _dp, _dp]),
@@ -97,7 +97,7 @@ EXPORTS = [
     "smcpp_num_keys", "smcpp_key_len", "smcpp_get_hidden_states", "smcpp_set_hidden_states", "smcpp_get_keys",
     "smcpp_get_xisum", "smcpp_get_gamma", "smcpp_get_gamma_sums", "smcpp_get_pi", "smcpp_get_transition",
     "smcpp_get_emission_probs", "smcpp_get_gamma_argmax", "smcpp_set_global_keys", "smcpp_pack_stats",
-    "smcpp_unpack_stats", "smcpp_set_chunking", "smcpp_last_timing", "smcpp_stream", "smcpp_set_num_threads",
+    "smcpp_unpack_stats", "smcpp_set_chunking", "smcpp_last_timing", "smcpp_stream", "smcpp_chain_mode", "smcpp_set_num_threads",
     "smcpp_host_eigensystem", "smcpp_host_eigensystem_team", "smcpp_host_prep_onepop", "smcpp_host_prep_onepop_jac", "smcpp_num_derivatives",
     "smcpp_host_rate_function", "smcpp_host_rate_function_jac", "smcpp_host_random_coal_times", "smcpp_host_raw_sfs",
     "smcpp_set_params_twopop", "smcpp_host_joint_csfs", "smcpp_host_prep_twopop", "smcpp_set_warm_start",

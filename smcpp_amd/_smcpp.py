@@ -227,6 +227,10 @@ class _PyInferenceManager:
         """Extension: reuse the previous E-step's converged chunk-boundary vectors as start vectors (see the header)."""
         E.check(E.lib().smcpp_set_warm_start(self._im, int(bool(on))))
 
+    def chain_mode(self):
+        """Chain kernel family in use: 0 generic, 1 LDS-resident, 2 cooperative, 3 streamed operands, 4 lock-step (MFMA)."""
+        return int(E.lib().smcpp_chain_mode(self._im))
+
     def last_timing(self):
         t = np.zeros(9)
         E.check(E.lib().smcpp_last_timing(self._im, E.dptr(t)))

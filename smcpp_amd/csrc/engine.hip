@@ -2264,6 +2264,10 @@ int smcpp_last_host_timing(smcpp_im *im, double out[4]) {
 
 void *smcpp_stream(smcpp_im *im) { return (void *)im->stream; }
 
+// which chain kernels this manager runs: 0 generic, 1 LDS-resident, 2 cooperative, 3 cooperative with streamed operands,
+// 4 lock-step on the matrix cores (chosen at construction / smcpp_set_chunking from the state count and the input size)
+int smcpp_chain_mode(smcpp_im *im) { return im ? im->chain_mode : -1; }
+
 void smcpp_set_num_threads(int k) { if (k > 0) omp_set_num_threads(k); }
 
 int smcpp_host_set_csfs_direct(int on) {

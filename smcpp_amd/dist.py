@@ -232,3 +232,6 @@ class ShardedInferenceManager:
 
     def last_timing(self):
         return self.im.last_timing()
+
+    def chain_mode(self):
+        return self.im.chain_mode()

@@ -111,8 +111,8 @@ def self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--length-mbp", type=float, default=100.0)
     ap.add_argument("--no-cpu", action="store_true")

@@ -61,13 +61,24 @@ def check_against(g, im, save_gamma):
     assert np.array_equal(arg_dev, arg.astype(np.int32))
 
 
-def test_golden_stats(golden):
+@pytest.fixture(params=["default", "lock"])
+def chain_family(request, monkeypatch):
+    """Every golden vector is checked with the chain kernels the engine picks by itself (cooperative / streamed operands at
+    these sizes) and with the lock-step kernels on the matrix cores forced (they take over on whole genomes, M <= 64)."""
+    if request.param == "lock":
+        monkeypatch.setenv("SMCPP_CHAIN", "lock")
+    return request.param
+
+
+def test_golden_stats(golden, chain_family):
     im = make_im(golden)
+    if chain_family == "lock" and len(golden["pi"]) <= 64:
+        assert im.chain_mode() == 4
     im.E_step()
     check_against(golden, im, save_gamma=False)
 
 
-def test_golden_posterior(golden):
+def test_golden_posterior(golden, chain_family):
     im = make_im(golden)
     im.save_gamma = True
     im.E_step()

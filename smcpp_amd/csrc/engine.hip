@@ -195,7 +195,7 @@ struct smcpp_im {
     // ---- device -----------------------------------------------------------------------------------------------
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: backward chain when it may overlap the forward one
-    hipEvent_t ev[14];                                  // 10..13: forward / backward interval of the eigen-free pre-pass
+    hipEvent_t ev[15];                                  // 10..13: forward / backward interval of the eigen-free pre-pass; 14: span-1 scalars done
     int dual_stream = 1;
     bool chains_dual = false;
     DevBuf<RowInfo> d_rowinfo;
@@ -1573,6 +1573,7 @@ void smcpp_im::enqueue_stats() {
         sa.alpha = d_alpha.p; sa.beta = d_beta.p; sa.cnorm = d_cnorm.p; sa.w1 = d_w1.p; sa.gpart = d_gpart.p;
         sa.gamma_rows = save_gamma ? d_gamma_rows.p : nullptr;
         launch_s1(NPL, sa, s);
+        if (split_streams) HIPCHK(hipEventRecord(ev[14], s));
     }
     AccArgs aa;
     aa.M = M; aa.Mp = Mp; aa.NB = (Mp + 63) / 64; aa.rowinfo = d_rowinfo.p; aa.alpha = d_alpha.p; aa.beta = d_beta.p;
@@ -1581,8 +1582,12 @@ void smcpp_im::enqueue_stats() {
         aa.nslabs = (int)slabs_rk.size(); aa.slabs = d_slabs_rk.p; aa.perm = d_perm1.p; aa.permk = d_perm1k.p; aa.part = d_part_1.p;
         hipLaunchKernelGGL(k_rank_acc<0>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, s, aa);
     }
-    hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, s,
-                       (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
+    // the per-key gamma sums only need the span-1 scalars: with two streams their reduction runs at the tail of the eigen
+    // stream (which finishes earlier) instead of between the two rank-update kernels of the main one
+    const bool gsum_on_se = split_streams && !slabs_sc.empty();
+    if (!gsum_on_se)
+        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, s,
+                           (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
     hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), n_contigs, ZS), dim3(256), 0, s,
                        (const double *)d_part_1.p, (const int *)d_s1_slab_off.p, d_red_1.p, MMi, ZS);
     HIPCHK(hipEventRecord(ev[4], s));
@@ -1622,6 +1627,11 @@ void smcpp_im::enqueue_stats() {
         hipLaunchKernelGGL(k_fin_Z, dim3(nb2, n_contigs * Ke, nsl), dim3(256), 0, se, fa);
         if (nsl > 1) hipLaunchKernelGGL(k_fin_Zsum, dim3(nb2, n_contigs * Ke), dim3(256), 0, se, fa, nsl, n_contigs * Ke);
         hipLaunchKernelGGL(k_fin_Y, dim3(nb2, n_contigs * Ke), dim3(256), 0, se, fa);
+    }
+    if (gsum_on_se) {
+        HIPCHK(hipStreamWaitEvent(se, ev[14], 0));
+        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, se,
+                           (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
     }
     if (split_streams) {
         HIPCHK(hipEventRecord(ev[9], se));

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_lab(const float *__restrict__ Tf, const
             xl[t] = x.lo; xh[t] = x.hi;
         }
         float sprev = 1.f, inv = 1.f, thr = 0.f;
-        if (VAR <= 3 || VAR == 6 || VAR == 7) {
+        if (VAR <= 3 || VAR == 6 || VAR == 7 || VAR == 9) {
             float sq;
             if (VAR == 0 || VAR == 1 || VAR == 3) {
                 f32x2 s01 = {0.f, 0.f};
@@ -81,7 +81,15 @@ __global__ __launch_bounds__(256) void k_lab(const float *__restrict__ Tf, const
             if (VAR == 6) { const float s_now = sprev; sprev = s_old; s_old = s_now; }
             inv = __builtin_amdgcn_rcpf(sprev);
             thr = 1e-10f * sprev;
-            if (j > 0) {
+            if (j > 0 && VAR == 9) {
+                // rotating store: wavefront (j & 3) writes the WHOLE previous row (256 contiguous bytes) from the exchanged
+                // vector in LDS, the other three skip the store and everything that only feeds it
+                if (w == (j & 3)) {
+                    const float xv = xf[cur * MT + lane];
+                    arow[(size_t)(j - 1) * MT + lane] = imax(xv * inv, 1e-10f);
+                    if (lane == 0) cnorm[(size_t)blockIdx.x * nrows + j - 1] = (double)sprev;
+                }
+            } else if (j > 0) {
                 float an = v_prev * inv;
                 an = VAR == 0 ? fmaxf(an, 1e-10f) : imax(an, 1e-10f);
                 if (VAR != 7 && owner) arow[(size_t)(j - 1) * MT + i] = an;
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(256) void k_lab(const float *__restrict__ Tf, const
         for (int t = 0; t < 4; ++t) {
             f32x2 l = xl[t], h = xh[t];
             if (VAR == 0) { l.x = fmaxf(l.x, thr); l.y = fmaxf(l.y, thr); h.x = fmaxf(h.x, thr); h.y = fmaxf(h.y, thr); }
-            if (VAR == 1 || VAR == 2 || VAR == 6 || VAR == 7) { l.x = imax(l.x, thr); l.y = imax(l.y, thr); h.x = imax(h.x, thr); h.y = imax(h.y, thr); }
+            if (VAR == 1 || VAR == 2 || VAR == 6 || VAR == 7 || VAR == 9) { l.x = imax(l.x, thr); l.y = imax(l.y, thr); h.x = imax(h.x, thr); h.y = imax(h.y, thr); }
             const f32x2 m01 = {tf[4 * t], tf[4 * t + 1]}, m23 = {tf[4 * t + 2], tf[4 * t + 3]};
             acc01 = __builtin_elementwise_fma(m01, l, acc01);
             acc23 = __builtin_elementwise_fma(m23, h, acc23);
@@ -347,6 +355,7 @@ int main(int argc, char **argv) {
         run("6 as 2, normaliser one row late", k_lab<6>, 256, dT, dE, dA, dC, dcyc, nrows, b);
         run("7 as 2, no global stores", k_lab<7>, 256, dT, dE, dA, dC, dcyc, nrows, b);
         run("8 one wavefront per chunk, lane = state", k_lab1<0>, 64, dT, dE, dA, dC, dcyc, nrows, b);
+        run("9 as 2, whole-row store by wavefront (j & 3)", k_lab<9>, 256, dT, dE, dA, dC, dcyc, nrows, b);
     }
     // ---- mixed loop ----
     {

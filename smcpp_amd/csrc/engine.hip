@@ -460,8 +460,16 @@ void smcpp_im::make_chunks() {
         if (getenv("SMCPP_GENERIC_CHAINS")) chain_mode = 0;
         // lock-step chains on the matrix cores (chains_lock.hpp): 16 chunks per workgroup, so 16 x more and 16 x shorter
         // chunks - they pay off when those are still long against the ~900 rows of history every chunk re-runs
-        if (!m && Mp <= 64 && (total_rows - n_contigs) / ((long long)prop.multiProcessorCount * LOCK_NC) >= lock_min_rows(Mp))
-            chain_mode = 4;
+        if (!m && Mp <= 64 && (total_rows - n_contigs) / ((long long)prop.multiProcessorCount * LOCK_NC) >= lock_min_rows(Mp)) {
+            // ... and when one eigen key dominates the span > 1 rows (binned data: the monomorphic key): only its operators are
+            // register-resident there, every other key present in a step costs two L2 round trips for the whole workgroup
+            std::vector<long long> cnt(std::max(1, Ke), 0);
+            long long ne = 0;
+            for (const RowInfo &ri : rowinfo)
+                if (ri.gid >= 0) { ++cnt[groups[ri.gid].eig]; ++ne; }
+            const long long top = *std::max_element(cnt.begin(), cnt.end());
+            if (ne == 0 || 10 * top >= 9 * ne) chain_mode = 4;
+        }
         // 64 < M <= 256: the streaming cooperative kernels (k_fwd_big / k_bwd_big) unless generic is forced
         if (Mp > 64) chain_mode = (chain_mode == 0) ? 0 : 3;
         const char *b = getenv("SMCPP_COOP_BPC");

@@ -156,6 +156,7 @@ struct smcpp_im {
     int n[2] = {0, 0}, na[2] = {2, 0};
     double polarization_error = 0.5;
     std::vector<double> hs;
+    std::unique_ptr<smcpp_host::TwoPopPrep> twopop_prep;     // two-population preparation (key -> tensor-bin tables cached inside)
     std::vector<int> keys;                 // [K][keylen], lexicographic
     std::vector<int> Ls;
     std::vector<long long> contig_base;    // row index of ell = 0 of each contig
@@ -759,7 +760,8 @@ void smcpp_im::prepare_params() {
         // emissions from the joint CSFS of (population 1, population 2, split)
         if (model_p1.a.empty() || model_p2.a.empty())
             throw std::runtime_error("two-population manager: call set_params_twopop (or set_raw) before E_step");
-        smcpp_host::TwoPopPrep prep(n[0], n[1], na[0], na[1], hs, polarization_error);
+        if (!twopop_prep) twopop_prep.reset(new smcpp_host::TwoPopPrep(n[0], n[1], na[0], na[1], hs, polarization_error));
+        smcpp_host::TwoPopPrep &prep = *twopop_prep;
         if (nder > 0) {
             smcpp_host::DualScope sc(nder);
             std::vector<smcpp_host::dual> pd, Td, Ed, emd;
@@ -2030,6 +2032,7 @@ int smcpp_set_hidden_states(smcpp_im *im, int n_hs, const double *hs) {
     API_BEGIN
     if (n_hs != (int)im->hs.size()) throw std::runtime_error("hidden states must be same size");
     im->hs.assign(hs, hs + n_hs);
+    im->twopop_prep.reset();
     if (!im->estep_done) im->stats_on_host = false;
     im->dirty = true;
     im->params_fresh = false;

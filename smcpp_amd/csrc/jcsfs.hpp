@@ -187,6 +187,34 @@ private:
             const RateFunctionT<S> eta1_shift(shift_params(params1, split), std::vector<double>{0.0, INFINITY});
             sfs_above_split = undistinguished_sfs(csfs_of(n1 + n2 - 1, eta1_shift)[0], n1 + n2 - 1);
         }
+        // The two quadruple loops of the reference (jcsfs.cpp:141-160 and 181-200) sum, per hidden state, products in which only
+        // ONE factor depends on the state (the Moran averages below the split, the shifted SFS above it).  The state-independent
+        // contractions are formed once:
+        //   Cb[np1][b2]         = sum_nseg sfs_above[nseg-1] h2(np1, nseg) eMn2[nseg-np1][b2]
+        //   Da[i][nseg][b1][b2] = sum_np1  eMn1[i][np1][b1] eMn2[nseg-np1][b2] h1(np1, nseg)
+        // and every state contracts them with its own factor (all terms are non-negative: only the order of the sums changes).
+        const int c1 = n1 + 1, c2 = n2 + 1;
+        Cb_.assign((size_t)(n1 + 2) * c2, S(0.0));
+        if (any_below)
+            for (int nseg = 1; nseg <= n1 + n2; ++nseg)
+                for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1 + 1); ++np1) {
+                    const S f = sfs_above_split[nseg - 1] * h2(np1, nseg);
+                    for (int b2 = 0; b2 <= n2; ++b2) Cb_[(size_t)np1 * c2 + b2] += f * eMn2[(size_t)(nseg - np1) * c2 + b2];
+                }
+        bool any_above = false;
+        for (int m = 0; m < M; ++m) any_above = any_above || hs[m + 1] > split;
+        Da_.assign((size_t)3 * (n1 + n2 + 1) * c1 * c2, S(0.0));
+        if (any_above)
+            for (int i = 0; i < 3; ++i)
+                for (int nseg = 0; nseg <= n1 + n2; ++nseg)
+                    for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1); ++np1) {
+                        const double h = h1(np1, nseg);
+                        S *dst = &Da_[((size_t)i * (n1 + n2 + 1) + nseg) * c1 * c2];
+                        for (int b1 = 0; b1 <= n1; ++b1) {
+                            const S f = eMn1[i][(size_t)np1 * c1 + b1] * h;
+                            for (int b2 = 0; b2 <= n2; ++b2) dst[(size_t)b1 * c2 + b2] += f * eMn2[(size_t)(nseg - np1) * c2 + b2];
+                        }
+                    }
         // hidden states are independent: one task each
         const int nd = dual_nder();
         std::string err;
@@ -259,18 +287,18 @@ private:
         }
         for (S &x : avg0) x /= (double)K;
         for (S &x : avg2) x /= (double)K;
+        (void)sfs_above;
         for (int b1 = 0; b1 <= n1; ++b1)
-            for (int b2 = 0; b2 <= n2; ++b2)
-                for (int nseg = 1; nseg <= n1 + n2; ++nseg)
-                    for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1 + 1); ++np1) {
-                        const int np2 = nseg - np1;
-                        S x = sfs_above[nseg - 1];
-                        x *= eMn2[(size_t)np2 * (n2 + 1) + b2];
-                        x *= h2(np1, nseg);
-                        x *= weight;
-                        at(m, 0, b1, 0, b2) += x * avg0[(size_t)np1 * c + b1];
-                        at(m, 2, b1, 0, b2) += x * avg2[(size_t)np1 * c + b1];
-                    }
+            for (int b2 = 0; b2 <= n2; ++b2) {
+                S s0(0.0), s2(0.0);
+                for (int np1 = 0; np1 <= n1 + 1; ++np1) {
+                    const S &cb = Cb_[(size_t)np1 * (n2 + 1) + b2];
+                    s0 += cb * avg0[(size_t)np1 * c + b1];
+                    s2 += cb * avg2[(size_t)np1 * c + b1];
+                }
+                at(m, 0, b1, 0, b2) += weight * s0;
+                at(m, 2, b1, 0, b2) += weight * s2;
+            }
     }
 
     // distinguished pair coalesces in [t1, t2) with split <= t1 (jcsfs.cpp:166-216)
@@ -278,21 +306,16 @@ private:
         const RateFunctionT<S> shifted(shift_params(params1, split), std::vector<double>{t1 - split, t2 - split});
         const std::vector<S> rsfs = csfs_of(n1 + n2, shifted)[0];      // 3 x (n1+n2+1)
         const int w = n1 + n2 + 1;
-        for (int b1 = 0; b1 <= n1; ++b1)
-            for (int b2 = 0; b2 <= n2; ++b2)
-                for (int nseg = 0; nseg <= n1 + n2; ++nseg)
-                    for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1); ++np1) {
-                        const int np2 = nseg - np1;
-                        const double h = h1(np1, nseg);
-                        for (int i = 0; i < 3; ++i) {
-                            S x = rsfs[(size_t)i * w + nseg];
-                            x *= eMn1[i][(size_t)np1 * (n1 + 1) + b1];
-                            x *= eMn2[(size_t)np2 * (n2 + 1) + b2];
-                            x *= h;
-                            x *= weight;
-                            at(m, i, b1, 0, b2) += x;
-                        }
-                    }
+        {
+            const int c1 = n1 + 1, c2 = n2 + 1;
+            for (int i = 0; i < 3; ++i)
+                for (int nseg = 0; nseg <= n1 + n2; ++nseg) {
+                    const S f = rsfs[(size_t)i * w + nseg] * weight;
+                    const S *src = &Da_[((size_t)i * w + nseg) * c1 * c2];
+                    for (int b1 = 0; b1 <= n1; ++b1)
+                        for (int b2 = 0; b2 <= n2; ++b2) at(m, i, b1, 0, b2) += f * src[(size_t)b1 * c2 + b2];
+                }
+        }
         // population 1 below the split: the below-part of a CSFS conditioned on coalescence right at the split
         const std::vector<S> below = csfs_of(n1, *eta1, true)[0];
         for (int i = 0; i < 3; ++i)
@@ -370,6 +393,8 @@ private:
     S Rts1, Rts2;
     std::array<std::vector<S>, 3> eMn1;
     std::vector<S> eMn2, sfs_above_split;
+    std::vector<S> Cb_;      // [(n1+2)][(n2+1)]  state-independent contraction of tau_below_split (see together())
+    std::vector<S> Da_;      // [3][(n1+n2+1)][(n1+1)][(n2+1)]  ... of tau_above_split
     std::vector<std::vector<S>> J;
 };
 
@@ -408,8 +433,12 @@ public:
         S ps(0.0);
         for (S &x : pi) { if (sval(x) < 1e-20) x = S(1e-20); ps += x; }
         for (S &x : pi) x /= ps;
+        static const bool tm = getenv("SMCPP_HOST_TIMING") != nullptr;
+        const auto tc0 = std::chrono::steady_clock::now();
         T = compute_transition<S>(eta, rho);
+        const auto tc1 = std::chrono::steady_clock::now();
         std::vector<std::vector<S>> sfs = jcsfs<S>(p1, p2, split);
+        const auto tc2 = std::chrono::steady_clock::now();
         incorporate_theta<S>(sfs, theta);
         if (emission_out) {
             emission_out->clear();
@@ -427,6 +456,18 @@ public:
         }
         const int d2 = n_[1] + 1, d1 = (na_[1] + 1) * d2, d0 = (n_[0] + 1) * d1;
         E.assign((size_t)K * M, S(0.0));
+        // the bins of a key (tensor index, weight) depend on the key only: built once per key dictionary, not per E-step
+        if (bins_keys_.size() != (size_t)6 * K || !std::equal(bins_keys_.begin(), bins_keys_.end(), keys.begin())) {
+            bins_keys_.assign(keys.begin(), keys.begin() + (size_t)6 * K);
+            bins_cache_.assign(K, {});
+            for (int k = 0; k < K; ++k) {
+                Key bk;
+                for (int q = 0; q < 6; ++q) bk[q] = keys[(size_t)6 * k + q];
+                for (const auto &p : bins_for(bk))
+                    bins_cache_[k].emplace_back((size_t)p.first[0] * d0 + (size_t)p.first[1] * d1 + (size_t)p.first[2] * d2 + p.first[3],
+                                                p.second);
+            }
+        }
         for (int k = 0; k < K; ++k) {
             Key bk;
             for (int q = 0; q < 6; ++q) bk[q] = keys[(size_t)6 * k + q];
@@ -442,18 +483,24 @@ public:
             if (reduced && (miss || amin >= 0)) {
                 for (int m = 0; m < M; ++m) e[m] = miss ? S(1.0) : e2[2 * m + (asum % 2)];
             } else {
-                for (const auto &p : bins_for(bk)) {
-                    const size_t idx = (size_t)p.first[0] * d0 + (size_t)p.first[1] * d1 + (size_t)p.first[2] * d2 + p.first[3];
-                    for (int m = 0; m < M; ++m) e[m] += p.second * sfs[m][idx];
-                }
+                for (const auto &p : bins_cache_[k])
+                    for (int m = 0; m < M; ++m) e[m] += p.second * sfs[m][p.first];
             }
             double mx = sval(e[0]), mn = sval(e[0]);
             for (int m = 1; m < M; ++m) { mx = std::max(mx, (double)sval(e[m])); mn = std::min(mn, (double)sval(e[m])); }
             if (mx > 1.0 || mn <= 0.0) throw std::runtime_error("probability vector not in [0, 1]");
         }
+        if (tm) {
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "[prep2] transition %.3f ms, joint csfs %.3f ms, theta + emission assembly (%d keys) %.3f ms\n", ms(tc0, tc1),
+                    ms(tc1, tc2), K, ms(tc2, std::chrono::steady_clock::now()));
+        }
     }
 
     // construct_bins for one observed key (inference_manager.cpp:329-386 with P = 2): weights over (a1, b1, a2, b2)
+    mutable std::vector<int> bins_keys_;                                         // key dictionary the cache below belongs to
+    mutable std::vector<std::vector<std::pair<size_t, double>>> bins_cache_;     // per key: (flattened tensor index, weight)
+
     std::map<std::array<int, 4>, double> bins_for(const Key &bk) const {
         auto is_mono = [&](const Key &k) {
             for (int p = 0; p < 2; ++p)

@@ -937,7 +937,8 @@ inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, 
     double tmark[64][4] = {};
     const auto tbase = std::chrono::steady_clock::now();
     auto now_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tbase).count(); };
-#pragma omp parallel
+    // (called per hidden state from inside the joint CSFS's own parallel loop: no nested team there)
+#pragma omp parallel if (!omp_in_parallel())
     {
         DualScope sc(nd);
         const int tid_ = omp_get_thread_num();
@@ -1058,7 +1059,7 @@ inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, 
             if (tm && tid_ < 64) tmark[tid_][3] = now_us();      // nowait loop below: last state finished by this thread
         }
     }
-    if (tm) {
+    if (tm && !omp_in_parallel()) {
         const double tend = now_us();
         fprintf(stderr, "[csfs] region %.1f us; per thread (enter, tables done, side done, last state):", tend);
         for (int t = 0; t < std::min(64, omp_get_max_threads()); ++t)

@@ -1368,6 +1368,7 @@ void smcpp_im::stage_static_and_prepass() {
     cargs.power_off = (int)shm_c;          // two scratch vectors behind the regular carve-up
     shm_c += 2048;
     a.variant = 1; a.pass = 0;
+    { static const int pm = getenv("SMCPP_BWD_PRIO_MASK") ? atoi(getenv("SMCPP_BWD_PRIO_MASK")) : 7; if (!(pm & 1)) a.prio = 0; }
     if (sb != s) {
         HIPCHK(hipEventRecord(ev[6], s));
         HIPCHK(hipStreamWaitEvent(sb, ev[6], 0));
@@ -1444,10 +1445,14 @@ void smcpp_im::run_chains() {
     const size_t nel_ends = chunks.size() * (size_t)Mp;
     // after a pre-pass, pass 1 is a FULL pass from the pre-pass's end vectors (no skip test, no merge exit): every stored
     // row then comes from the exact kernels
+    // issue priority of the backward wavefronts per pass (SMCPP_BWD_PRIO_MASK: bit 0 pre-pass, bit 1 the full pass after
+    // it, bit 2 every other pass)
+    static const int prio_mask = getenv("SMCPP_BWD_PRIO_MASK") ? atoi(getenv("SMCPP_BWD_PRIO_MASK")) : 7;
+    const int prio0 = a.prio;
     auto set_variant = [&](int pass) {
         a.pass = pass;
-        if (pre && pass == 1) { a.variant = 2; a.warm_f = d_ends_f.p; a.warm_b = d_ends_b.p; (void)nel_ends; }
-        else { a.variant = 0; a.warm_f = warm ? d_warm_f.p : nullptr; a.warm_b = warm ? d_warm_b.p : nullptr; }
+        if (pre && pass == 1) { a.variant = 2; a.warm_f = d_ends_f.p; a.warm_b = d_ends_b.p; (void)nel_ends; a.prio = (prio_mask & 2) ? prio0 : 0; }
+        else { a.variant = 0; a.warm_f = warm ? d_warm_f.p : nullptr; a.warm_b = warm ? d_warm_b.p : nullptr; a.prio = (prio_mask & 4) ? prio0 : 0; }
     };
     // The two chains are independent (beta does not depend on alpha).  The cooperative kernels leave most of a CU's
     // LDS and issue slots idle, so the backward passes run on a second stream and share the CUs with the forward ones.

@@ -185,10 +185,14 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_coop2(ChainArgs a, CoopArgs ca) 
             if (owner && !POWER) arow[(size_t)j * Mp] = an;
             if (tid == 0 && !POWER) crow[j] = (double)sprev;
         }
+        // (the pre-pass only has to deliver a start vector: the 1e-10 floor moves its end vector by less than the tolerance
+        // of the skip test, and sixteen integer maxima per lane and row are 8 % of a span-1 row)
+        if (!POWER) {
 #pragma unroll
-        for (int t = 0; t < Q4; ++t) {
-            xl[t].x = imax_f(xl[t].x, thr); xl[t].y = imax_f(xl[t].y, thr);
-            xh[t].x = imax_f(xh[t].x, thr); xh[t].y = imax_f(xh[t].y, thr);
+            for (int t = 0; t < Q4; ++t) {
+                xl[t].x = imax_f(xl[t].x, thr); xl[t].y = imax_f(xl[t].y, thr);
+                xh[t].x = imax_f(xh[t].x, thr); xh[t].y = imax_f(xh[t].y, thr);
+            }
         }
         float vout;
         if (ge < 0) {

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
-bash tools/profile_round.sh r02_g > /dev/null 2>&1
-O=gpurun_out/r02_g
+bash tools/profile_round.sh r02_h > /dev/null 2>&1
+O=gpurun_out/r02_h
 for w in c2 c3 c4 c5 posterior; do python bench.py --workload $w > $O/bench_$w.log 2>&1; tail -1 $O/bench_$w.log | cut -c1-200; done
 python bench.py --gpus 2 > $O/bench_gpus2.log 2>&1; tail -1 $O/bench_gpus2.log | cut -c1-200
 python bench.py --gpus 2 --workload c3 > $O/bench_c3_gpus2.log 2>&1; tail -1 $O/bench_c3_gpus2.log | cut -c1-200

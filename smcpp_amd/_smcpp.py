@@ -46,8 +46,11 @@ class _PyInferenceManager:
 
     def __del__(self):
         im = getattr(self, "_im", None)
-        if im:
-            E.lib().smcpp_destroy(im)
+        if im and E is not None:         # (at interpreter shutdown the module globals may already be gone)
+            try:
+                E.lib().smcpp_destroy(im)
+            except Exception:  # noqa: BLE001
+                pass
             self._im = None
 
     # ---- properties mirrored from _smcpp.pyx:157-183 ----

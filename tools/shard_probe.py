@@ -24,5 +24,5 @@ for rank in range(min(world, int(os.environ.get("SHARD_RANKS", 2)))):
             im.model = m; im.E_step(); ll = im.loglik()
         ms = (time.perf_counter() - t) / 20 * 1e3
         tm = im.last_timing()
-        print(f"world {world} rank {rank}: contigs {idx} rows {rows} {mode}: {ms:.2f} ms per eval (chains {tm['chains_wall_ms']:.2f}, passes {tm['fwd_passes']:.0f}/{tm['bwd_passes']:.0f})")
+        print(f"world {world} rank {rank}: contigs {idx} rows {rows} {mode}: {ms:.2f} ms per eval", {k: round(float(v), 2) for k, v in tm.items()})
         del im

@@ -1726,7 +1726,6 @@ __global__ __launch_bounds__(64) void k_sq_f64(int Mp, const double *__restrict_
     double *D = dst + blockIdx.z * stride;
     const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
     f64x4 acc = {0, 0, 0, 0};
-#pragma unroll 8
     for (int kk = 0; kk < Mp / 4; ++kk) {
         const double av = S[(size_t)(r0 + m) * Mp + 4 * kk + qd];      // A[m][k]
         const double bv = S[(size_t)(4 * kk + qd) * Mp + c0 + m];      // B[k][n]

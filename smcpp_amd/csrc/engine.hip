@@ -222,8 +222,8 @@ struct smcpp_im {
     DevBuf<float> d_Bf;                    // [Ke][4][Mp][Mp] binary powers A^2..A^16 per eigen key (forward operand)
     DevBuf<double> d_Bb;                   // [Ke][4][Mp][Mp] their transposes (backward operand)
     // pre-pass of the streamed-operand chains (64 < M <= 256): device-built layouts of T and of the powers A .. A^16
-    DevBuf<double> d_W, d_pre_qTdT;        // [Ke][5][Mp][Mp] row-major powers (fp64) / [KQ][Mp][4]
-    DevBuf<float> d_qBf, d_qBb, d_pre_qTf; // [Ke][5][KQ][Mp][4] float streaming layouts / [KQ][Mp][4]
+    DevBuf<double> d_W, d_pre_qTdT;        // [Ke][nbits][Mp][Mp] row-major powers (fp64) / [KQ][Mp][4]
+    DevBuf<float> d_qBf, d_qBb, d_pre_qTf; // [Ke][nbits][KQ][Mp][4] float streaming layouts / [KQ][Mp][4]
     BigArgs pre_bargs;
     std::vector<std::unique_ptr<smcpp_host::EigTeam>> eig_teams;    // team-parallel eigensolver (M >= 128), one team per eigen key
     DevBuf<Chunk> d_chunks;
@@ -616,9 +616,9 @@ void smcpp_im::setup_power() {
     // anyway (the rows of the pre-pass are all overwritten: it runs in float and its normalisers carry no eigenvalue scale)
     const bool coop_pre = chain_mode == 2 && coop_generation() == 2 && Mp <= 64;
     const bool big_pre = chain_mode == 3 && Mp > 64 && Mp <= 256;
-    // spans: five bits with the streamed-operand chains; twelve (4095 positions) with the cooperative ones, whose powers
-    // beyond A^16 are read from L2 by the few rows that need them
-    power_ok = ((coop_pre && mx <= 4095) || (big_pre && mx <= 31)) && Ke >= 1 && G >= 1 && longest <= 2000 && !(pe && atoi(pe) == 0);
+    // spans up to twelve bits (4095 positions); the cooperative chains read the powers beyond A^16 from L2 on the few rows
+    // that need them, the streamed-operand ones stream every power anyway
+    power_ok = (coop_pre || big_pre) && mx <= 4095 && Ke >= 1 && G >= 1 && longest <= 2000 && !(pe && atoi(pe) == 0);
     max_span_pw = mx;
     pw_nbits = 5;
     while ((1 << pw_nbits) <= mx) ++pw_nbits;
@@ -626,9 +626,9 @@ void smcpp_im::setup_power() {
     if (!power_ok) return;
     if (big_pre) {
         const size_t MM = (size_t)Mp * Mp;
-        d_W.alloc((size_t)Ke * 5 * MM);
-        d_qBf.alloc((size_t)Ke * 5 * MM);
-        d_qBb.alloc((size_t)Ke * 5 * MM);
+        d_W.alloc((size_t)Ke * pw_nbits * MM);
+        d_qBf.alloc((size_t)Ke * pw_nbits * MM);
+        d_qBb.alloc((size_t)Ke * pw_nbits * MM);
         d_pre_qTf.alloc(MM);
         d_pre_qTdT.alloc(MM);
         return;
@@ -1315,11 +1315,14 @@ void smcpp_im::stage_static_and_prepass() {
         d_changed_b.zero(s);
         const int nb = ceil_div((long long)MM, 256);
         hipLaunchKernelGGL(k_big_tq, dim3(nb), dim3(256), 0, s, Mp, pre_Td, d_pre_qTf.p, d_pre_qTdT.p);
-        hipLaunchKernelGGL(k_pow_init, dim3(nb, Ke), dim3(256), 0, s, M, Mp, (const int *)d_e_kid.p, a.E, pre_Td, d_W.p);
-        for (int b = 0; b < 4; ++b)
+        hipLaunchKernelGGL(k_pow_init, dim3(nb, Ke), dim3(256), 0, s, M, Mp, pw_nbits, (const int *)d_e_kid.p, a.E, pre_Td, d_W.p);
+        for (int b = 0; b + 1 < pw_nbits; ++b) {
             hipLaunchKernelGGL(k_sq_f64, dim3(Mp / 16, Mp / 16, Ke), dim3(64), 0, s, Mp, (const double *)(d_W.p + (size_t)b * MM),
-                               d_W.p + (size_t)(b + 1) * MM, (size_t)5 * MM);
-        hipLaunchKernelGGL(k_pow_layout, dim3(nb, Ke * 5), dim3(256), 0, s, Mp, (const double *)d_W.p, d_qBf.p, d_qBb.p);
+                               d_W.p + (size_t)(b + 1) * MM, (size_t)pw_nbits * MM);
+            if (b + 1 >= 5)
+                hipLaunchKernelGGL(k_pow_rescale, dim3(Ke), dim3(256), 0, s, Mp, d_W.p + (size_t)(b + 1) * MM, (size_t)pw_nbits * MM);
+        }
+        hipLaunchKernelGGL(k_pow_layout, dim3(nb, Ke * pw_nbits), dim3(256), 0, s, Mp, (const double *)d_W.p, d_qBf.p, d_qBb.p);
         pre_bargs = BigArgs();
         pre_bargs.qTf = d_pre_qTf.p; pre_bargs.qTdT = d_pre_qTdT.p;
         pre_bargs.qPinvT = pre_bargs.qPT = pre_bargs.qPrm = pre_bargs.qPinvrm = nullptr;

@@ -1331,10 +1331,10 @@ struct BigArgs {
     const double *qTdT;      // [KQ][Mp][4]            backward span-1 operand
     const double *qPrm;      // [Ke][KQ][Mp][4]        backward eigen operands
     const double *qPinvrm;
-    // eigen-free pre-pass (PRE instantiations): float binary powers A^(2^b), b = 0..4, of A = diag(e) T^T per eigen key,
+    // eigen-free pre-pass (PRE instantiations): float binary powers A^(2^b), b = 0..nbits-1 (rescaled from A^32 on), of A = diag(e) T^T per eigen key,
     // qBf: Q[t][i][kq] = A^p[i][kq*KQ + t] (forward), qBb: Q[t][i][kq] = A^p[kq*KQ + t][i] (backward)   (k_pow_layout)
-    const float *qBf;        // [Ke][5][KQ][Mp][4]
-    const float *qBb;        // [Ke][5][KQ][Mp][4]
+    const float *qBf;        // [Ke][nbits][KQ][Mp][4]
+    const float *qBb;        // [Ke][nbits][KQ][Mp][4]
 };
 
 // One streamed quarter product: acc = sum_t q[t*QS] * x(t), with B independent loads in flight per batch (the whole
@@ -1481,9 +1481,9 @@ __global__ __launch_bounds__(MT * 4) void k_fwd_big(ChainArgs a, BigArgs qa) {
             const int sp = a.g_span[SMCPP_GID(ge)];
             float outv = 0.f;
             int napp = 0;
-            for (int b = 0; b < 5; ++b) {
+            for (int b = 0; b < a.nbits; ++b) {
                 if (!((sp >> b) & 1)) continue;
-                const float *q = qa.qBf + ((size_t)es * 5 + b) * Mp * Mp + qoff;
+                const float *q = qa.qBf + ((size_t)es * a.nbits + b) * Mp * Mp + qoff;
                 float dot;
                 if (napp == 0) dot = stream_dot<KQ, FB>(q, QS, rotf, [&](int t) { return fmaxf(xin[t], thr); });
                 else {
@@ -1643,9 +1643,9 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_big(ChainArgs a, BigArgs qa) {
             const int sp = a.g_span[SMCPP_GID(ge)];
             double outv = 0.0;
             int napp = 0;
-            for (int b = 0; b < 5; ++b) {
+            for (int b = 0; b < a.nbits; ++b) {
                 if (!((sp >> b) & 1)) continue;
-                const float *q = qa.qBb + ((size_t)es * 5 + b) * Mp * Mp + qoff;
+                const float *q = qa.qBb + ((size_t)es * a.nbits + b) * Mp * Mp + qoff;
                 double dot;
                 if (napp == 0) dot = stream_dot<KQ, DB>(q, QS, rotd, [&](int t) { return xin[t]; });
                 else {
@@ -1709,13 +1709,31 @@ __global__ __launch_bounds__(256) void k_big_tq(int Mp, const double *__restrict
     qTdT[d] = Td[(size_t)i * Mp + k];                 // TdT[k][i] = T[i][k]
 }
 
-__global__ __launch_bounds__(256) void k_pow_init(int M, int Mp, const int *__restrict__ e_kid, const double *__restrict__ E,
-                                                   const double *__restrict__ Td, double *__restrict__ W) {
+__global__ __launch_bounds__(256) void k_pow_init(int M, int Mp, int npw, const int *__restrict__ e_kid,
+                                                   const double *__restrict__ E, const double *__restrict__ Td,
+                                                   double *__restrict__ W) {
     const int idx = blockIdx.x * 256 + threadIdx.x, e = blockIdx.y;
     if (idx >= Mp * Mp) return;
     const int i = idx / Mp, k = idx % Mp;
     const double ev = E[(size_t)e_kid[e] * Mp + i];
-    W[(size_t)e * 5 * Mp * Mp + idx] = (i < M && k < M) ? ev * Td[(size_t)k * Mp + i] : 0.0;     // A[i][k] = e_i T[k][i]
+    W[(size_t)e * npw * Mp * Mp + idx] = (i < M && k < M) ? ev * Td[(size_t)k * Mp + i] : 0.0;     // A[i][k] = e_i T[k][i]
+}
+
+// Powers from A^32 on (spans of 32 and more) are rescaled to max |entry| = 1 before they are squared again: with |lambda| < 1
+// they would leave the float range of the streaming layouts, and the pre-pass only needs directions.  One workgroup per matrix.
+__global__ __launch_bounds__(256) void k_pow_rescale(int Mp, double *__restrict__ Wb, size_t stride) {
+    __shared__ double smax[4];
+    double *P = Wb + blockIdx.x * stride;
+    const int tid = threadIdx.x;
+    double mx = 0.0;
+    for (int idx = tid; idx < Mp * Mp; idx += 256) mx = fmax(mx, fabs(P[idx]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) smax[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    const double sc = mx > 0.0 ? 1.0 / mx : 1.0;
+    for (int idx = tid; idx < Mp * Mp; idx += 256) P[idx] *= sc;
 }
 
 // dst = src * src, row-major [Mp][Mp]; grid (Mp/16, Mp/16, Ke), one wavefront per 16 x 16 tile; `stride` = doubles between
@@ -1739,7 +1757,7 @@ __global__ __launch_bounds__(256) void k_pow_layout(int Mp, const double *__rest
                                                      float *__restrict__ qBb) {
     const int d = blockIdx.x * 256 + threadIdx.x;
     if (d >= Mp * Mp) return;
-    const size_t mo = (size_t)blockIdx.y * Mp * Mp;          // blockIdx.y = e * 5 + b
+    const size_t mo = (size_t)blockIdx.y * Mp * Mp;          // blockIdx.y = e * (powers per key) + b
     const int KQ = Mp / 4, q = d & 3, i = (d >> 2) % Mp, t = (d >> 2) / Mp, k = q * KQ + t;
     qBf[mo + d] = (float)W[mo + (size_t)i * Mp + k];
     qBb[mo + d] = (float)W[mo + (size_t)k * Mp + i];

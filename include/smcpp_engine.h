@@ -138,8 +138,13 @@ int smcpp_set_warm_start(smcpp_im *im, int on);
  * (forward and backward overlap when the two chains run on separate streams; chains_wall is their union) */
 int smcpp_last_timing(smcpp_im *im, double out[9]);
 /* diagnostics: the chain kernel family in use (0 generic, 1 LDS-resident, 2 cooperative, 3 cooperative with streamed
- * operands, 4 lock-step on the matrix cores) */
+ * operands, 4 lock-step on the matrix cores, 5 scans over the semiseparable structure of the transition matrix -
+ * src/transition.cpp:176-254 - one position per step, no eigensystem; an E-step whose T lacks that structure runs the
+ * dense kernels instead) */
 int smcpp_chain_mode(smcpp_im *im);
+/* Test hook of family 5: one position of both scan chains on nvec vectors: out_f = e o (T^T x), out_b = T (e o x); T is
+ * [M][M] row-major, x / e / out_* are [nvec][M].  Returns 2 when T has no semiseparable structure (nothing is written). */
+int smcpp_debug_ss_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b);
 /* Host phase of the last E-step in milliseconds: [cold preparation A6-A10 (0 when the parameters were still fresh or
  * came from smcpp_set_raw), eigensystems, layouts + staging + copy enqueue, whole host phase] */
 int smcpp_last_host_timing(smcpp_im *im, double out[4]);

@@ -1,0 +1,500 @@
+// Chains on the SEMISEPARABLE structure of the SMC++ transition matrix: O(M) per position instead of O(M^2) per row.
+//
+// The reference builds T in HJTransition (src/transition.cpp:176-254): below the diagonal T(i,j) depends on the column only,
+// above it it is  p_float(i) * exp(R_i) * exp(-R_{j-1}) (1 - exp(-inc_j)), i.e. rank one, and the final mixing
+// Phi*(1-beta) + beta/(M+1) adds one constant.  So with generators  d (diagonal), g (lower), c0 (the constant) and the
+// recurrence  Phi'(i,j+1) = a_j Phi'(i,j),  Phi'(i,i+1) = b_i  for the upper part,
+//   (T^T x)_j = d_j x_j + g_j sum_{i>j} x_i + c0 sum_{i<j} x_i + Z_j,            Z_{j+1} = a_j Z_j + b_j x_j,
+//   (T w)_i   = d_i w_i + sum_{j<i} g_j w_j + c0 sum_{j>i} w_j + b_i V_i,        V_i = w_{i+1} + a_{i+1} V_{i+1},
+// which are prefix sums over the state index.  One WAVEFRONT owns one chunk, lane l owns NPL consecutive states (M <= 64 NPL),
+// the prefix sums are Kogge-Stone scans over the lanes with DPP moves (row_shr 1/2/4/8, row_bcast 15/31), the weighted
+// ones with per-lane level multipliers - no LDS exchange, no barrier, no operand matrix at all.  A row of span s is s such
+// steps of its key's operator diag(e) T^T (forward) or T diag(e) (backward): exactly the operator whose eigensystem the
+// reference takes (transition_bundle.cpp:15-25), so NO eigensystem is needed by the chains; the engine extracts the
+// generators from T on every E-step, verifies the reconstruction entry by entry and falls back to the dense kernels
+// when it fails (smcpp_set_raw with an arbitrary matrix).
+//
+// Semantics (hmm.cpp:57-149) as in chains2.hpp: stored alpha is float(normalised vector) floored at 1e-10f, stored beta is the
+// vector in a running scale (every consumer is scale free), only the normaliser c of a row is stored; the chain itself runs
+// in fp64 without the per-row float rounding (the reference's own float noise is what the 5e-6 tolerance of the statistics
+// is made of; tests/golden parity: <= 1e-6 observed).  The reference multiplies a span-1 row by float(e_j T_ij): the rounding
+// of the diagonal entry (0.99..) is a systematic factor per state, it is reproduced (`dF`), the off-diagonal one is noise.
+// The backward lanes hold the states in REVERSED order so that its sums over j > i are prefix scans as well.
+// Chunk-parallel fixed point, skip test, merge exit and certificate: as chains2.hpp, per wavefront.
+#pragma once
+
+namespace smcpp_dev {
+
+struct SsArgs {
+    int M, Mp, nchunks, pass, K, nlds;   // nlds: emission vectors of key slots < nlds live in LDS, the rest comes from L2
+    const Chunk *chunks;
+    const int2 *rowdesc;        // [rows, padded] {key slot, span}
+    const double *E;            // [K][MS] emission vectors by key slot, state order, zero padded (MS = 64 NPL)
+    const float *pi_f;          // [Mp]
+    // generators by POSITION (MS doubles each); forward position p = state p, backward position p = state MS-1-p
+    const double *f_dc, *f_g, *f_cg, *f_b, *f_a, *f_d;
+    const double *b_dc, *b_g, *b_b, *b_a;
+    double c0;
+    float *alpha;
+    double *beta, *cnorm;
+    float *ends_f, *used_f;
+    double *ends_b, *used_b;
+    int *changed_f, *changed_b;
+    float eps_f;
+    double eps_b;
+    int full;                   // 1: every chunk runs whole from the previous pass's end vectors (no skip test, no merge exit)
+};
+
+template <int CTRL>
+__device__ __forceinline__ double dpp0(double v) {      // shifted copy, 0.0 where the source lane does not exist
+    const long long x = __builtin_bit_cast(long long, v);
+    int lo = (int)(x & 0xffffffffll), hi = (int)(x >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+constexpr int DPP_SHR1 = 0x111, DPP_SHR2 = 0x112, DPP_SHR4 = 0x114, DPP_SHR8 = 0x118, DPP_BC15 = 0x142, DPP_BC31 = 0x143,
+              DPP_WSHR1 = 0x138;
+
+// inclusive prefix sum over the 64 lanes; c15 / c31 = 1.0 on the lanes the two broadcast levels feed (rows 1,3 / rows 2,3)
+template <typename T>
+__device__ __forceinline__ T ss_scan(T v, T c15, T c31) {
+    v += dpp0<DPP_SHR1>(v);
+    v += dpp0<DPP_SHR2>(v);
+    v += dpp0<DPP_SHR4>(v);
+    v += dpp0<DPP_SHR8>(v);
+    v = __builtin_fma(c15, dpp0<DPP_BC15>(v), v);
+    v = __builtin_fma(c31, dpp0<DPP_BC31>(v), v);
+    return v;
+}
+__device__ __forceinline__ float ss_scan_f(float v, float c15, float c31) {
+    v += dpp0<DPP_SHR1>(v);
+    v += dpp0<DPP_SHR2>(v);
+    v += dpp0<DPP_SHR4>(v);
+    v += dpp0<DPP_SHR8>(v);
+    v = __builtin_fmaf(c15, dpp0<DPP_BC15>(v), v);
+    v = __builtin_fmaf(c31, dpp0<DPP_BC31>(v), v);
+    return v;
+}
+// inclusive scan of the recurrence  z_l = A_l z_{l-1} + y_l  with the level multipliers lv[] of ss_levels()
+__device__ __forceinline__ double ss_scan_w(double v, const double (&lv)[6]) {
+    v = __builtin_fma(lv[0], dpp0<DPP_SHR1>(v), v);
+    v = __builtin_fma(lv[1], dpp0<DPP_SHR2>(v), v);
+    v = __builtin_fma(lv[2], dpp0<DPP_SHR4>(v), v);
+    v = __builtin_fma(lv[3], dpp0<DPP_SHR8>(v), v);
+    v = __builtin_fma(lv[4], dpp0<DPP_BC15>(v), v);
+    v = __builtin_fma(lv[5], dpp0<DPP_BC31>(v), v);
+    return v;
+}
+// level multipliers of the lane recurrence with per-lane factor A: before level D, m_l = prod of A over the window the lane
+// has absorbed so far (lanes l-D+1 .. l, cut at the start of its 16-lane row; after the row levels, the whole row / pair)
+__device__ __forceinline__ void ss_levels(double A, int lane, double (&lv)[6]) {
+    const int r = lane & 15, row = lane >> 4;
+    double m = A, t;
+    lv[0] = m; t = dpp0<DPP_SHR1>(m); m = (r >= 1) ? m * t : m;
+    lv[1] = m; t = dpp0<DPP_SHR2>(m); m = (r >= 2) ? m * t : m;
+    lv[2] = m; t = dpp0<DPP_SHR4>(m); m = (r >= 4) ? m * t : m;
+    lv[3] = m; t = dpp0<DPP_SHR8>(m); m = (r >= 8) ? m * t : m;
+    lv[4] = (row & 1) ? m : 0.0; t = dpp0<DPP_BC15>(m); m = (row & 1) ? m * t : m;
+    lv[5] = (row >= 2) ? m : 0.0;
+}
+
+template <int NPL>
+struct SsFwdC { double dc[NPL], g[NPL], cg[NPL], b[NPL], a[NPL], d[NPL], cumA[NPL], lv[6], c15, c31; };
+template <int NPL>
+struct SsBwdC { double dc[NPL], g[NPL], b[NPL], a[NPL], cumA[NPL], lv[6], c15, c31, c0; float c15f, c31f; };
+
+template <int NPL>
+__device__ __forceinline__ void ss_load_fwd(const SsArgs &a, int lane, SsFwdC<NPL> &c) {
+    double cum = 1.0;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int p = lane * NPL + k;
+        c.dc[k] = a.f_dc[p]; c.g[k] = a.f_g[p]; c.cg[k] = a.f_cg[p]; c.b[k] = a.f_b[p]; c.a[k] = a.f_a[p]; c.d[k] = a.f_d[p];
+        cum *= c.a[k];
+        c.cumA[k] = cum;
+    }
+    ss_levels(cum, lane, c.lv);
+    const int row = lane >> 4;
+    c.c15 = (row & 1) ? 1.0 : 0.0;
+    c.c31 = (row >= 2) ? 1.0 : 0.0;
+}
+template <int NPL>
+__device__ __forceinline__ void ss_load_bwd(const SsArgs &a, int lane, SsBwdC<NPL> &c) {
+    double cum = 1.0;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int p = lane * NPL + k;
+        c.dc[k] = a.b_dc[p]; c.g[k] = a.b_g[p]; c.b[k] = a.b_b[p]; c.a[k] = a.b_a[p];
+        cum *= c.a[k];
+        c.cumA[k] = cum;
+    }
+    ss_levels(cum, lane, c.lv);
+    const int row = lane >> 4;
+    c.c15 = (row & 1) ? 1.0 : 0.0;
+    c.c31 = (row >= 2) ? 1.0 : 0.0;
+    c.c15f = (float)c.c15; c.c31f = (float)c.c31;
+    c.c0 = a.c0;
+}
+
+// one position of the forward chain:  out = e o (T^T x)  [+ dfix o x];  S = sum x
+template <int NPL>
+__device__ __forceinline__ void ss_fwd_step(const SsFwdC<NPL> &c, const double (&x)[NPL], const double (&e)[NPL],
+                                            double (&out)[NPL], double &S) {
+    double lp[NPL], w[NPL];
+    lp[0] = x[0];
+    w[0] = c.b[0] * x[0];
+#pragma unroll
+    for (int k = 1; k < NPL; ++k) {
+        lp[k] = lp[k - 1] + x[k];
+        w[k] = __builtin_fma(c.a[k], w[k - 1], c.b[k] * x[k]);
+    }
+    const double li = ss_scan(lp[NPL - 1], c.c15, c.c31);
+    const double LI = ss_scan_w(w[NPL - 1], c.lv);
+    S = lane_get(li, 63);
+    const double lex = li - lp[NPL - 1];
+    const double LIp = dpp0<DPP_WSHR1>(LI);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const double incl = lex + lp[k];
+        const double Z = (k == 0) ? LIp : __builtin_fma(c.cumA[k - 1 < 0 ? 0 : k - 1], LIp, w[k - 1 < 0 ? 0 : k - 1]);
+        const double t = __builtin_fma(c.dc[k], x[k], __builtin_fma(c.g[k], S, __builtin_fma(c.cg[k], incl, Z)));
+        out[k] = e[k] * t;
+    }
+}
+
+// one position of the backward chain (position p = state MS-1-p):  out = T (e o b);  Sw = sum (e o b) (float accuracy)
+template <int NPL>
+__device__ __forceinline__ void ss_bwd_step(const SsBwdC<NPL> &c, const double (&bv)[NPL], const double (&e)[NPL],
+                                            double (&out)[NPL], float &Sw) {
+    double w[NPL], lg[NPL], u[NPL];
+    float lf[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) w[k] = e[k] * bv[k];
+    lg[0] = c.g[0] * w[0];
+    u[0] = w[0];
+    lf[0] = (float)w[0];
+#pragma unroll
+    for (int k = 1; k < NPL; ++k) {
+        lg[k] = __builtin_fma(c.g[k], w[k], lg[k - 1]);
+        u[k] = __builtin_fma(c.a[k], u[k - 1], w[k]);
+        lf[k] = lf[k - 1] + (float)w[k];
+    }
+    const double lig = ss_scan(lg[NPL - 1], c.c15, c.c31);
+    const double LI = ss_scan_w(u[NPL - 1], c.lv);
+    const float lif = ss_scan_f(lf[NPL - 1], c.c15f, c.c31f);
+    const double Gtot = lane_get(lig, 63);
+    Sw = lane_get(lif, 63);
+    const double lexg = lig - lg[NPL - 1];
+    const float lexf = lif - lf[NPL - 1];
+    const double LIp = dpp0<DPP_WSHR1>(LI);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const double inclG = lexg + lg[k];
+        const double inclW = (double)(lexf + lf[k]);
+        const double V = (k == 0) ? LIp : __builtin_fma(c.cumA[k - 1 < 0 ? 0 : k - 1], LIp, u[k - 1 < 0 ? 0 : k - 1]);
+        out[k] = __builtin_fma(c.dc[k], w[k], (Gtot - inclG) + __builtin_fma(c.c0, inclW, c.b[k] * V));
+    }
+}
+
+// emission vector of key slot `slot` at this lane's positions (forward: states lane NPL + k; backward: MS-1-(lane NPL + k))
+template <int NPL, bool BWD>
+__device__ __forceinline__ void ss_emission(const SsArgs &a, const double *sE, int slot, int lane, double (&e)[NPL]) {
+    constexpr int MS = 64 * NPL;
+    // `slot` is wavefront-uniform: two separate address spaces, not a flat pointer
+    if (slot < a.nlds) {
+        const double *src = sE + (size_t)slot * MS;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) e[k] = src[BWD ? MS - 1 - (lane * NPL + k) : lane * NPL + k];
+    } else {
+        const double *src = a.E + (size_t)slot * MS;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) e[k] = src[BWD ? MS - 1 - (lane * NPL + k) : lane * NPL + k];
+    }
+}
+
+template <int NPL, bool RERUN>
+__device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *sE, int c, int lane) {
+    constexpr int MS = 64 * NPL;
+    const int M = a.M, Mp = a.Mp, pass = a.pass;
+    const Chunk ch = a.chunks[c];
+    float *end_cur = a.ends_f + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
+    const float *end_prev = a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
+    int st[NPL];
+    bool live[NPL], stor[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { st[k] = lane * NPL + k; live[k] = st[k] < M; stor[k] = st[k] < Mp; }
+    if (RERUN && ch.first) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = end_prev[st[k]];
+        return;
+    }
+    double x[NPL];
+    {
+        const float *src = (ch.first || !RERUN) ? a.pi_f : a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + (c - 1)) * Mp;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) x[k] = live[k] ? (double)src[st[k]] : 0.0;
+    }
+    if (RERUN && !a.full) {
+        bool diff = false;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k)
+            if (live[k]) {
+                const float u = a.used_f[(size_t)c * Mp + st[k]];
+                if (!(fabsf((float)x[k] - u) <= a.eps_f * fabsf(u))) diff = true;
+            }
+        if (!__any(diff)) {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = end_prev[st[k]];
+            return;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) if (stor[k]) a.used_f[(size_t)c * Mp + st[k]] = (float)x[k];
+    if (lane == 0) a.changed_f[pass] = 1;
+    if (ch.first) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) if (stor[k]) a.alpha[(size_t)ch.base * Mp + st[k]] = (float)x[k];
+        if (lane == 0) a.cnorm[ch.base] = 1.0;
+    }
+    SsFwdC<NPL> cst;
+    ss_load_fwd<NPL>(a, lane, cst);
+    const int2 *rd = a.rowdesc + ch.base + ch.r0 + 1;          // descriptor of iteration j (row ell = r0 + 1 + j)
+    const int nrows = ch.r1 - ch.r0;
+    int2 dcur = rd[lane], dnxt = rd[64 + lane];
+    float *arow = a.alpha + (size_t)(ch.base + ch.r0) * Mp;    // row ell - 1 of iteration j is arow + j Mp
+    double *crow = a.cnorm + ch.base + ch.r0;
+    double e[NPL];
+    ss_emission<NPL, false>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0), lane, e);
+    bool merged = false;
+    for (int j = 0; j < nrows; ++j) {
+        const int jl = j & 63;
+        const int span = __builtin_amdgcn_readlane(dcur.y, jl);
+        // descriptor / emission vector of the next row
+        if (jl == 63) { dcur = dnxt; dnxt = rd[j + 65 + lane]; }
+        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63);
+        double en[NPL];
+        ss_emission<NPL, false>(a, sE, slot_n, lane, en);
+        // first position of the row: the sum of the incoming vector finishes the PREVIOUS row
+        double y[NPL], S;
+        ss_fwd_step<NPL>(cst, x, e, y, S);
+        const double inv = rcp_f64(S);
+        if (j > 0) {
+            float an[NPL];
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) an[k] = live[k] ? fmaxf((float)(x[k] * inv), 1e-10f) : 0.f;
+            if (RERUN && !a.full && (j & 15) == 0 && j >= 16) {
+                bool bad = false;
+#pragma unroll
+                for (int k = 0; k < NPL; ++k)
+                    if (live[k]) {
+                        const float old = arow[(size_t)j * Mp + st[k]];
+                        if (!(fabsf(an[k] - old) <= a.eps_f * fabsf(old))) bad = true;
+                    }
+                if (!__any(bad)) { merged = true; break; }
+            }
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) if (stor[k]) arow[(size_t)j * Mp + st[k]] = an[k];
+            if (lane == 0) crow[j] = S;
+        }
+        if (span == 1) {
+            // hmm.cpp:85-86 multiplies by float(e_j T_ij): the rounding of the diagonal entry is systematic per state
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const double ed = e[k] * cst.d[k];
+                y[k] = __builtin_fma((double)(float)ed - ed, x[k], y[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) x[k] = y[k] * inv;
+        for (int t = 1; t < span; ++t) {
+            double S2;
+            ss_fwd_step<NPL>(cst, x, e, y, S2);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) x[k] = y[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) e[k] = en[k];
+    }
+    if (merged) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = end_prev[st[k]];
+        return;
+    }
+    {
+        double part = 0.0;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) part += x[k];
+        const double S = wave_sum_dpp(part);
+        const double inv = 1.0 / S;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const float an = live[k] ? fmaxf((float)(x[k] * inv), 1e-10f) : 0.f;
+            if (stor[k]) { a.alpha[(size_t)(ch.base + ch.r1) * Mp + st[k]] = an; end_cur[st[k]] = an; }
+        }
+        if (lane == 0) a.cnorm[ch.base + ch.r1] = S;
+    }
+}
+
+template <int NPL, bool RERUN>
+__device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *sE, int c, int lane) {
+    constexpr int MS = 64 * NPL;
+    const int M = a.M, Mp = a.Mp, pass = a.pass;
+    const Chunk ch = a.chunks[c];
+    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
+    const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
+    int st[NPL];
+    bool live[NPL], stor[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { st[k] = MS - 1 - (lane * NPL + k); live[k] = st[k] < M; stor[k] = st[k] < Mp; }
+    if (RERUN && ch.last) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = end_prev[st[k]];
+        return;
+    }
+    double b[NPL];
+    {
+        const bool fresh = ch.last || !RERUN;
+        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (fresh ? c : c + 1)) * Mp;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) b[k] = live[k] ? (fresh ? 1.0 / (double)M : src[st[k]]) : 0.0;
+    }
+    if (RERUN && !a.full) {
+        bool diff = false;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k)
+            if (live[k]) {
+                const double u = a.used_b[(size_t)c * Mp + st[k]];
+                if (!(fabs(b[k] - u) <= a.eps_b * fabs(u))) diff = true;
+            }
+        if (!__any(diff)) {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = end_prev[st[k]];
+            return;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) if (stor[k]) a.used_b[(size_t)c * Mp + st[k]] = b[k];
+    if (lane == 0) a.changed_b[pass] = 1;
+    SsBwdC<NPL> cst;
+    ss_load_bwd<NPL>(a, lane, cst);
+    const int2 *rd = a.rowdesc + ch.base + ch.r1;               // descriptor of iteration j (row ell = r1 - j) is rd[-j]
+    const int nrows = ch.r1 - ch.r0;
+    int2 dcur = rd[-lane], dnxt = rd[-64 - lane];
+    double *brow = a.beta + (size_t)(ch.base + ch.r1) * Mp;     // row ell of iteration j is brow - j Mp
+    double e[NPL];
+    ss_emission<NPL, true>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0), lane, e);
+    bool merged = false;
+    for (int j = 0; j < nrows; ++j) {
+        const int jl = j & 63;
+        const int span = __builtin_amdgcn_readlane(dcur.y, jl);
+        if (jl == 63) { dcur = dnxt; dnxt = rd[-(j + 65) - lane]; }
+        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63);
+        double en[NPL];
+        ss_emission<NPL, true>(a, sE, slot_n, lane, en);
+        // beta[ell] in the running scale (hmm.cpp:142 renormalises; every consumer is invariant to a per-row scale)
+        if (RERUN && !a.full && (j & 15) == 0 && j >= 16) {
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k)
+                if (live[k]) {
+                    const double old = brow[-(ptrdiff_t)j * Mp + st[k]];
+                    if (!(fabs(b[k] - old) <= a.eps_b * fabs(old))) bad = true;
+                }
+            if (!__any(bad)) { merged = true; break; }
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) if (stor[k]) brow[-(ptrdiff_t)j * Mp + st[k]] = b[k];
+        double y[NPL];
+        float Sw;
+        ss_bwd_step<NPL>(cst, b, e, y, Sw);
+        const double inv = (double)__builtin_amdgcn_rcpf(Sw);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) b[k] = y[k] * inv;
+        for (int t = 1; t < span; ++t) {
+            float S2;
+            ss_bwd_step<NPL>(cst, b, e, y, S2);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) b[k] = y[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) e[k] = en[k];
+    }
+    if (merged) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = end_prev[st[k]];
+        return;
+    }
+    {
+        // (padded positions hold the lower-triangle total, not zero: their emission entry is zero, so they never feed a scan)
+        double part = 0.0;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) part += live[k] ? b[k] : 0.0;
+        const double S = wave_sum_dpp(part);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const double bf = live[k] ? b[k] / S : 0.0;          // beta /= beta.sum()  (seeds gamma[:,0], hmm.cpp:150)
+            if (stor[k]) { end_cur[st[k]] = bf; if (ch.first) a.beta[(size_t)ch.base * Mp + st[k]] = bf; }
+        }
+    }
+}
+
+// One workgroup = 4 wavefronts = chunks 2 blk, 2 blk + 1 forward (wavefronts 0, 1) and backward (wavefronts 2, 3); they share
+// one LDS copy of the emission vectors of the `nlds` most frequent keys.
+template <int NPL, bool RERUN>
+__global__ __launch_bounds__(256) void k_chain_ss(SsArgs a) {
+    constexpr int MS = 64 * NPL;
+    extern __shared__ __attribute__((aligned(16))) double ss_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool fwd = w < 2;
+    if (RERUN && a.changed_f[a.pass - 1] == 0 && a.changed_b[a.pass - 1] == 0) return;
+    for (int idx = tid; idx < a.nlds * MS; idx += 256) ss_lds[idx] = a.E[idx];
+    __syncthreads();
+    const int c = 2 * blockIdx.x + (w & 1);
+    if (c >= a.nchunks) return;
+    if (fwd) {
+        if (RERUN && a.changed_f[a.pass - 1] == 0) return;
+        ss_forward_wave<NPL, RERUN>(a, ss_lds, c, lane);
+    } else {
+        if (RERUN && a.changed_b[a.pass - 1] == 0) return;
+        __builtin_amdgcn_s_setprio(1);
+        ss_backward_wave<NPL, RERUN>(a, ss_lds, c, lane);
+    }
+}
+
+// Unit-test entry (tests/test_gpu_ss.py through smcpp_debug_ss_apply): out_f = e o (T^T x), out_b = T (e o x) by the scans,
+// one wavefront per vector.
+template <int NPL>
+__global__ __launch_bounds__(64) void k_ss_apply(SsArgs a, const double *__restrict__ x, const double *__restrict__ e,
+                                                 double *__restrict__ out_f, double *__restrict__ out_b, int nvec) {
+    constexpr int MS = 64 * NPL;
+    const int lane = threadIdx.x, v = blockIdx.x;
+    if (v >= nvec) return;
+    SsFwdC<NPL> cf;
+    SsBwdC<NPL> cb;
+    ss_load_fwd<NPL>(a, lane, cf);
+    ss_load_bwd<NPL>(a, lane, cb);
+    double xf[NPL], ef[NPL], xb[NPL], eb[NPL], yf[NPL], yb[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int p = lane * NPL + k, q = MS - 1 - p;
+        xf[k] = x[(size_t)v * MS + p]; ef[k] = e[(size_t)v * MS + p];
+        xb[k] = x[(size_t)v * MS + q]; eb[k] = e[(size_t)v * MS + q];
+    }
+    double S; float Sw;
+    ss_fwd_step<NPL>(cf, xf, ef, yf, S);
+    ss_bwd_step<NPL>(cb, xb, eb, yb, Sw);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int p = lane * NPL + k, q = MS - 1 - p;
+        out_f[(size_t)v * MS + p] = yf[k];
+        out_b[(size_t)v * MS + q] = yb[k];
+    }
+}
+
+}  // namespace smcpp_dev

@@ -28,6 +28,7 @@
 #include "kernels.hpp"
 #include "chains2.hpp"
 #include "chains_lock.hpp"
+#include "chains_ss.hpp"
 #include "nonsym_eig.hpp"
 #include "nonsym_eig_team.hpp"
 #include "prep.hpp"
@@ -209,6 +210,21 @@ struct smcpp_im {
     int chain_mode = 2;   // 0 generic, 1 LDS-resident (one wavefront per chunk), 2 CU-cooperative (one workgroup per chunk),
                           // 3 CU-cooperative with streamed operands (64 < M <= 256), 4 lock-step on the matrix cores (16 chunks per workgroup)
     int coop_bpc = 1;     // cooperative workgroups resident per CU the automatic chunking aims at
+    // ---- chains on the semiseparable structure of T (chains_ss.hpp; chain_mode 5) ------------------------------------------
+    bool ss_static = false;                // the input qualifies (short spans); whether T does is decided on every E-step
+    bool ss_active = false;                // this E-step's chains run on the scan kernels
+    int ss_max_span = 0;
+    int ss_nlds = 0;                       // key slots whose emission vectors live in LDS
+    int ss_launched = 0, last_ss_passes = 0;
+    std::vector<int> ss_slot_of_key;       // frequency rank of every key (slot 0 = most rows)
+    DevBuf<int2> d_rowdesc_ss;             // [rows, padded] {key slot, span}
+    SsArgs ss_args;
+    bool ss_extract_generators();          // generators of T (verified entry by entry) into ss_gen; false: T has no such structure
+    std::vector<double> ss_gen;            // [10][MS]: f_dc f_g f_cg f_b f_a f_d b_dc b_g b_b b_a
+    double ss_c0 = 0.0;
+    void ss_launch_initial();
+    void ss_launch_passes(int upto);
+    void run_chains_ss();
     int hot_eig = -1, hot_eig2 = -1;
     // eigen-free pre-pass (chains2.hpp: k_group_powers, POWER instantiations): pass 0 runs on group powers while the host
     // solves the eigenproblems; only for short, few spans (binned data) and chunks short enough that pass 1 re-runs them whole
@@ -473,6 +489,16 @@ void smcpp_im::make_chunks() {
         }
         // 64 < M <= 256: the streaming cooperative kernels (k_fwd_big / k_bwd_big) unless generic is forced
         if (Mp > 64) chain_mode = (chain_mode == 0) ? 0 : 3;
+        // Chains on the semiseparable structure of T (chains_ss.hpp): one position per step, so the input qualifies when
+        // its spans are short (binned data; un-binned posterior data with spans of 10^4 .. 10^5 keep the eigen kernels).
+        // chain_mode then names the DENSE kernels an E-step falls back to when its T has no such structure.
+        ss_max_span = 1;
+        for (const Group &g : groups) ss_max_span = std::max(ss_max_span, g.span);
+        {
+            const char *se = getenv("SMCPP_SS");
+            ss_static = !(se && atoi(se) == 0) && (!m || !strcmp(m, "ss")) && ss_max_span <= 512 && Mp <= 256;
+            if (ss_static) chain_mode = Mp > 64 ? 3 : 2;
+        }
         const char *b = getenv("SMCPP_COOP_BPC");
         if (b && atoi(b) > 0) coop_bpc = atoi(b);
         else {
@@ -484,8 +510,53 @@ void smcpp_im::make_chunks() {
         }
     }
     // chunks in flight: one per SIMD for the per-wavefront kernels, coop_bpc per CU for the cooperative ones
-    const long long slots = (long long)prop.multiProcessorCount *
-                            (chain_mode == 4 ? LOCK_NC : chain_mode >= 2 ? (chain_mode == 3 ? 1 : coop_bpc) : wpb);
+    long long slots = (long long)prop.multiProcessorCount *
+                      (chain_mode == 4 ? LOCK_NC : chain_mode >= 2 ? (chain_mode == 3 ? 1 : coop_bpc) : wpb);
+    if (ss_static && user_rows_per_chunk <= 0 && !getenv("SMCPP_ROWS_PER_CHUNK")) {
+        // scan chains: one wavefront per chunk and direction, a workgroup = 2 forward + 2 backward chunks = one wavefront per
+        // SIMD; chunks are cut by POSITIONS (sum of spans), the unit of work of these kernels.  Every chunk pays the same
+        // ~3000 positions of re-run history however short it is (the chains forget with an e-fold of ~240 positions).
+        static const int wpc = getenv("SMCPP_SS_WPC") ? std::max(1, atoi(getenv("SMCPP_SS_WPC"))) : 1;
+        slots = (long long)prop.multiProcessorCount * 2 * wpc;
+        std::vector<long long> cum;
+        long long total_bins = 0;
+        for (int c = 0; c < n_contigs; ++c)
+            for (int i = 1; i <= Ls[c]; ++i) {
+                const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
+                total_bins += ri.gid < 0 ? 1 : groups[ri.gid].span;
+            }
+        const long long bpc = std::max<long long>(2048, (total_bins + slots - 1) / slots);
+        chunks.clear();
+        max_chunks_per_contig = 1;
+        for (int c = 0; c < n_contigs; ++c) {
+            const int L = Ls[c];
+            cum.assign((size_t)L + 1, 0);
+            for (int i = 1; i <= L; ++i) {
+                const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
+                cum[i] = cum[i - 1] + (ri.gid < 0 ? 1 : groups[ri.gid].span);
+            }
+            const int nc = (int)std::max<long long>(1, std::min<long long>(L, (cum[L] + bpc - 1) / bpc));
+            max_chunks_per_contig = std::max(max_chunks_per_contig, nc);
+            int prev = 0;
+            for (int j = 0; j < nc; ++j) {
+                int r1;
+                if (j == nc - 1) r1 = L;
+                else {
+                    const long long target = cum[L] * (j + 1) / nc;
+                    r1 = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+                    r1 = std::max(prev + 1, std::min(r1, L - (nc - 1 - j)));
+                }
+                Chunk ch;
+                ch.base = contig_base[c];
+                ch.r0 = prev; ch.r1 = r1; ch.contig = c;
+                ch.first = (j == 0); ch.last = (j == nc - 1); ch.pad = 0;
+                chunks.push_back(ch);
+                prev = r1;
+            }
+        }
+        max_pass = max_chunks_per_contig + 3;
+        return;
+    }
     long long rows = total_rows - n_contigs;
     int lc = user_rows_per_chunk;
     if (lc <= 0) {
@@ -618,7 +689,7 @@ void smcpp_im::setup_power() {
     const bool big_pre = chain_mode == 3 && Mp > 64 && Mp <= 256;
     // spans up to twelve bits (4095 positions); the cooperative chains read the powers beyond A^16 from L2 on the few rows
     // that need them, the streamed-operand ones stream every power anyway
-    power_ok = (coop_pre || big_pre) && mx <= 4095 && Ke >= 1 && G >= 1 && longest <= 2000 && !(pe && atoi(pe) == 0);
+    power_ok = (coop_pre || big_pre) && mx <= 4095 && Ke >= 1 && G >= 1 && longest <= 2000 && !(pe && atoi(pe) == 0) && !ss_static;
     max_span_pw = mx;
     pw_nbits = 5;
     while ((1 << pw_nbits) <= mx) ++pw_nbits;
@@ -659,6 +730,29 @@ void smcpp_im::alloc_device() {
             if (e != hot_eig && (hot_eig2 < 0 || cnt[e] > cnt[hot_eig2])) hot_eig2 = e;
         d_rowdesc.upload(rd, s);
         HIPCHK(hipStreamSynchronize(s));
+    }
+    {
+        // scan chains: descriptors {key slot, span}; slot = frequency rank of the key (the emission vectors of the first
+        // ss_nlds slots live in LDS); same padding as above with span-1 rows of slot 0
+        std::vector<long long> kc(K, 0);
+        for (int c = 0; c < n_contigs; ++c)
+            for (int i = 1; i <= Ls[c]; ++i) kc[rowinfo[(size_t)contig_base[c] + i].kid]++;
+        std::vector<int> order(K);
+        for (int k = 0; k < K; ++k) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return kc[x] > kc[y]; });
+        ss_slot_of_key.assign(K, 0);
+        for (int r = 0; r < K; ++r) ss_slot_of_key[order[r]] = r;
+        const int MS = 64 * NPL;
+        ss_nlds = (int)std::min<long long>(K, (64 * 1024) / ((long long)MS * 8));
+        if (ss_static) {
+            std::vector<int2> rd((size_t)total_rows + 2 * ROWDESC_PAD, make_int2(0, 1));
+            for (size_t r = 0; r < (size_t)total_rows; ++r) {
+                const RowInfo &ri = rowinfo[r];
+                rd[ROWDESC_PAD + r] = make_int2(ss_slot_of_key[ri.kid], ri.gid < 0 ? 1 : groups[ri.gid].span);
+            }
+            d_rowdesc_ss.upload(rd, s);
+            HIPCHK(hipStreamSynchronize(s));
+        }
     }
     d_chunks.upload(chunks, s);
     d_slabs_sc.upload(slabs_sc, s);
@@ -890,7 +984,8 @@ void smcpp_im::host_prep_and_upload() {
         for (int g : groups_of[e]) {
             const int sp = groups[g].span;
             gsc[g] = s_.scale;
-            gls[g] = sp * ls;                  // the eigenvalue powers (d_r / scale)^span of the group: k_group_dpow, on the device
+            // (the eigenvalue powers (d_r / scale)^span of the group: k_group_dpow, on the device)
+            gls[g] = ss_active ? 0.0 : sp * ls;   // the scan chains apply the operator itself: their normalisers carry no eigenvalue scale
         }
     };
     // M >= 128: a team of threads per eigen key (nonsym_eig_team.hpp: bit-identical to the serial routine); the size follows
@@ -1540,6 +1635,185 @@ void smcpp_im::run_chains() {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// chains on the semiseparable structure of T (chains_ss.hpp)
+// ---------------------------------------------------------------------------------------------------------------
+// Generators of T = diag(d) + [below: g_j] + [above: c0 + Phi'(i,j)], Phi'(i,i+1) = b_i, Phi'(i,j+1) = a_j Phi'(i,j)
+// (transition.cpp:176-254; c0 = 1e-5 / (M + 1) is the mixing constant of lines 249-254).  The dense T is what the reference's
+// getters hand out and what the statistics use, so the generators are taken FROM it and the reconstruction is checked entry by
+// entry: a T without this structure (smcpp_set_raw with an arbitrary matrix) sends the E-step to the dense kernels.
+static bool ss_generators(int M, int NPL, const double *Tm, std::vector<double> &gen, double &c0_out) {
+    const int MS = 64 * NPL;
+    const double c0 = 1e-5 / (double)(M + 1);
+    const double tol = 1e-11;
+    std::vector<double> d(M), g(M, 0.0), a(M, 0.0), b(M, 0.0);
+    for (int j = 0; j < M; ++j) d[j] = Tm[(size_t)j * M + j];
+    for (int j = 0; j + 1 < M; ++j) {
+        g[j] = Tm[(size_t)(M - 1) * M + j];
+        b[j] = Tm[(size_t)j * M + j + 1] - c0;
+        for (int i = j + 1; i < M; ++i)
+            if (!(std::fabs(Tm[(size_t)i * M + j] - g[j]) <= tol * std::fabs(g[j]))) return false;
+    }
+    for (int j = 1; j + 1 < M; ++j) {
+        int ib = 0;
+        for (int i = 1; i < j; ++i)
+            if (Tm[(size_t)i * M + j] > Tm[(size_t)ib * M + j]) ib = i;
+        const double den = Tm[(size_t)ib * M + j] - c0;
+        a[j] = den > 0.0 ? (Tm[(size_t)ib * M + j + 1] - c0) / den : 0.0;
+    }
+    for (int i = 0; i + 1 < M; ++i) {
+        double v = b[i];
+        for (int j = i + 1; j < M; ++j) {
+            const double t = Tm[(size_t)i * M + j];
+            if (!(std::fabs(c0 + v - t) <= tol * std::fabs(t)) || !(t > 0.0)) return false;
+            v *= a[j];
+        }
+    }
+    for (int j = 0; j < M; ++j)
+        if (!(d[j] > 0.0) || !std::isfinite(a[j]) || !std::isfinite(b[j])) return false;
+    c0_out = c0;
+    gen.assign((size_t)10 * MS, 0.0);
+    double *f_dc = &gen[0], *f_g = f_dc + MS, *f_cg = f_g + MS, *f_b = f_cg + MS, *f_a = f_b + MS, *f_d = f_a + MS,
+           *b_dc = f_d + MS, *b_g = b_dc + MS, *b_b = b_g + MS, *b_a = b_b + MS;
+    for (int j = 0; j < M; ++j) {
+        f_dc[j] = d[j] - c0; f_g[j] = g[j]; f_cg[j] = c0 - g[j]; f_b[j] = b[j]; f_a[j] = a[j]; f_d[j] = d[j];
+        const int p = MS - 1 - j;
+        b_dc[p] = d[j] - c0; b_g[p] = g[j]; b_b[p] = b[j]; b_a[p] = a[j];
+    }
+    return true;
+}
+
+bool smcpp_im::ss_extract_generators() {
+    if (!ss_generators(M, NPL, T.data(), ss_gen, ss_c0)) return false;
+    // a row of span s applies its operator s times without rescaling: keep clear of underflow
+    for (const Group &gr : groups) {
+        double mn = 1.0;
+        for (int i = 0; i < M; ++i) mn = std::min(mn, E[(size_t)gr.kid * M + i]);
+        if (!(mn > 0.0) || (double)gr.span * std::log(mn) < -450.0) return false;
+    }
+    return true;
+}
+
+template <int NPL_>
+static void launch_chain_ss_t(const SsArgs &a, size_t shm, hipStream_t s) {
+    static bool once = false;
+    if (!once) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss<NPL_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss<NPL_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once = true;
+    }
+    const int nblk = (a.nchunks + 1) / 2;
+    if (a.pass == 0) hipLaunchKernelGGL((k_chain_ss<NPL_, false>), dim3(nblk), dim3(256), shm, s, a);
+    else hipLaunchKernelGGL((k_chain_ss<NPL_, true>), dim3(nblk), dim3(256), shm, s, a);
+}
+static void launch_chain_ss(int npl, const SsArgs &a, size_t shm, hipStream_t s) {
+    switch (npl) {
+        case 1: launch_chain_ss_t<1>(a, shm, s); break;
+        case 2: launch_chain_ss_t<2>(a, shm, s); break;
+        case 3: launch_chain_ss_t<3>(a, shm, s); break;
+        case 4: launch_chain_ss_t<4>(a, shm, s); break;
+        default: throw std::runtime_error("unsupported number of hidden states");
+    }
+}
+
+void smcpp_im::ss_launch_passes(int upto) {
+    const size_t shm = (size_t)ss_nlds * 64 * NPL * sizeof(double);
+    for (; ss_launched < upto; ++ss_launched) {
+        ss_args.pass = ss_launched;
+        launch_chain_ss(NPL, ss_args, shm, stream);
+    }
+    HIPCHK(hipGetLastError());
+}
+
+// Upload pi, the generators and the emission vectors (by key slot) and start the passes: nothing here needs an eigensystem,
+// so the host solves the eigenproblems of the statistics while the chains run.
+void smcpp_im::ss_launch_initial() {
+    hipStream_t s = stream;
+    const int MS = 64 * NPL;
+    std::vector<float> &pi_f = hs_pi_f;
+    if (pi_f.size() != (size_t)Mp) pi_f.assign(Mp, 0.f);
+    for (int i = 0; i < M; ++i) pi_f[i] = (float)pi[i];
+    const size_t need = 8 * 256 + pi_f.size() * 4 + ss_gen.size() * 8 + (size_t)K * MS * 8;
+    pre_stage.reset(need);
+    if (need > pre_cap) {
+        if (d_pre) (void)hipFree(d_pre);
+        pre_cap = need + need / 4;
+        HIPCHK(hipMalloc((void **)&d_pre, pre_cap));
+    }
+    size_t off = 0;
+    auto put = [&](const void *src, size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        if (src) std::memcpy(pre_stage.base + off, src, bytes);
+        char *dp = d_pre + off;
+        off += bytes;
+        return dp;
+    };
+    SsArgs &a = ss_args;
+    a = SsArgs();
+    a.M = M; a.Mp = Mp; a.nchunks = (int)chunks.size(); a.pass = 0; a.K = K; a.nlds = ss_nlds;
+    a.chunks = d_chunks.p; a.rowdesc = d_rowdesc_ss.p + ROWDESC_PAD;
+    a.pi_f = reinterpret_cast<const float *>(put(pi_f.data(), pi_f.size() * 4));
+    const double *gd = reinterpret_cast<const double *>(put(ss_gen.data(), ss_gen.size() * 8));
+    a.f_dc = gd; a.f_g = gd + MS; a.f_cg = gd + 2 * MS; a.f_b = gd + 3 * MS; a.f_a = gd + 4 * MS; a.f_d = gd + 5 * MS;
+    a.b_dc = gd + 6 * MS; a.b_g = gd + 7 * MS; a.b_b = gd + 8 * MS; a.b_a = gd + 9 * MS;
+    a.c0 = ss_c0;
+    {
+        const size_t eoff = (off + 255) & ~(size_t)255;
+        double *he = reinterpret_cast<double *>(pre_stage.base + eoff);
+        std::memset(he, 0, (size_t)K * MS * 8);
+        for (int k = 0; k < K; ++k)
+            std::memcpy(he + (size_t)ss_slot_of_key[k] * MS, &E[(size_t)k * M], sizeof(double) * M);
+        a.E = reinterpret_cast<const double *>(put(nullptr, (size_t)K * MS * 8));
+    }
+    a.alpha = d_alpha.p; a.beta = d_beta.p; a.cnorm = d_cnorm.p;
+    a.ends_f = d_ends_f.p; a.used_f = d_used_f.p; a.ends_b = d_ends_b.p; a.used_b = d_used_b.p;
+    a.changed_f = d_changed_f.p; a.changed_b = d_changed_b.p;
+    a.eps_f = eps_f; a.eps_b = eps_b; a.full = 0;
+    HIPCHK(hipMemcpyAsync(d_pre, pre_stage.base, off, hipMemcpyHostToDevice, s));
+    d_changed_f.zero(s);
+    d_changed_b.zero(s);
+    HIPCHK(hipEventRecord(ev[10], s));
+    ss_launched = 0;
+    const int want = std::min(max_pass, last_ss_passes > 0 ? last_ss_passes + 1 : std::min(max_pass, 6));
+    ss_launch_passes(want);
+    HIPCHK(hipEventRecord(ev[11], s));
+}
+
+void smcpp_im::run_chains_ss() {
+    hipStream_t s = stream;
+    if (h_flags_cap < 2 * (max_pass + 1)) {
+        if (h_flags) (void)hipHostFree(h_flags);
+        h_flags_cap = 2 * (max_pass + 1);
+        HIPCHK(hipHostMalloc((void **)&h_flags, sizeof(int) * h_flags_cap, hipHostMallocDefault));
+    }
+    int *chf = h_flags, *chb = h_flags + (max_pass + 1);
+    auto first_quiet = [](const int *cf, const int *cb, int upto) {
+        for (int j = 0; j < upto; ++j)
+            if (cf[j] == 0 && cb[j] == 0) return j;
+        return -1;
+    };
+    HIPCHK(hipEventRecord(ev[1], s));
+    bool first_round = true;
+    int q = -1;
+    while (true) {
+        HIPCHK(hipMemcpyAsync(chf, d_changed_f.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(chb, d_changed_b.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(ev[3], s));
+        if (first_round && !save_gamma) enqueue_stats();       // optimistic, as run_chains()
+        else stats_enqueued = false;
+        HIPCHK(hipStreamSynchronize(s));
+        first_round = false;
+        q = first_quiet(chf, chb, ss_launched);
+        if (q >= 0 || ss_launched >= max_pass) break;
+        stats_enqueued = false;
+        ss_launch_passes(std::min(max_pass, ss_launched + 3));
+    }
+    chains_dual = false;
+    if (q < 0) { stats_enqueued = false; throw std::runtime_error("chunk-boundary iteration did not converge"); }
+    last_ss_passes = q;
+    last_fwd_passes = last_bwd_passes = q;
+}
+
 void smcpp_im::run_stats() {
     if (!stats_enqueued) enqueue_stats();
     finish_stats();
@@ -1709,14 +1983,18 @@ void smcpp_im::estep() {
     if ((int)pi.size() != M || (int)T.size() != M * M || (int)E.size() != K * M)
         throw std::runtime_error("parameters are not set");
     HIPCHK(hipEventRecord(ev[0], stream));
-    stage_static_and_prepass();   // (when eligible) pass 0 of both chains starts now, on eigen-free operands
+    ss_active = ss_static && ss_extract_generators();
+    if (ss_active) { prepass_launched = false; static_packed = false; ss_launch_initial(); }   // the chains need no eigensystem: they start now
+    else stage_static_and_prepass();   // (when eligible) pass 0 of both chains starts now, on eigen-free operands
     host_prep_and_upload();   // the reference rebuilds the eigensystems on every E-step (inference_manager.cpp:112)
     auto t1 = std::chrono::steady_clock::now();
-    run_chains();
+    if (ss_active) run_chains_ss(); else run_chains();
     run_stats();
     auto t2 = std::chrono::steady_clock::now();
     float f_ms = 0, b_ms = 0, s_ms = 0, fin_ms = 0;
-    if (chains_dual) {
+    if (ss_active) {
+        // one launch per pass for both directions, timed below
+    } else if (chains_dual) {
         (void)hipEventElapsedTime(&f_ms, ev[1], ev[7]);   // forward passes (main stream)
         (void)hipEventElapsedTime(&b_ms, ev[2], ev[3]);   // backward passes (second stream), overlapping the forward ones
     } else {
@@ -1725,6 +2003,13 @@ void smcpp_im::estep() {
     }
     float chains_ms = 0;
     (void)hipEventElapsedTime(&chains_ms, ev[1], ev[3]);
+    if (ss_active) {
+        // the first batch of passes ran before ev[1] (concurrently with the host phase); both directions share the launches
+        float first_ms = 0;
+        (void)hipEventElapsedTime(&first_ms, ev[10], ev[11]);
+        chains_ms += first_ms;
+        f_ms = b_ms = chains_ms;
+    }
     if (prepass_launched) {
         // pass 0 ran before ev[1] (concurrently with the host eigensolve): add its kernel intervals
         (void)hipEventElapsedTime(&pre_f_ms, ev[10], ev[11]);
@@ -1734,6 +2019,7 @@ void smcpp_im::estep() {
     }
     (void)hipEventElapsedTime(&s_ms, ev[3], ev[4]);
     (void)hipEventElapsedTime(&fin_ms, ev[4], ev[5]);
+    (void)hipGetLastError();      // an interval over an event this E-step never recorded must not surface in the next launch check
     timing[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
     host_timing[3] = timing[0];
     timing[1] = chains_ms;   // wall time of both chains (they overlap in dual-stream mode)
@@ -2295,7 +2581,50 @@ void *smcpp_stream(smcpp_im *im) { return (void *)im->stream; }
 
 // which chain kernels this manager runs: 0 generic, 1 LDS-resident, 2 cooperative, 3 cooperative with streamed operands,
 // 4 lock-step on the matrix cores (chosen at construction / smcpp_set_chunking from the state count and the input size)
-int smcpp_chain_mode(smcpp_im *im) { return im ? im->chain_mode : -1; }
+// 5 = scans over the semiseparable structure of T (chains_ss.hpp; the dense kernels named by the other values remain the
+// fallback of an E-step whose T has no such structure)
+int smcpp_chain_mode(smcpp_im *im) { return im ? (im->ss_static ? 5 : im->chain_mode) : -1; }
+
+// Test hook (tests/test_gpu_ss.py): one position of both scan chains on nvec vectors, out_f = e o (T^T x), out_b = T (e o x);
+// x, e and the outputs are [nvec][M].  Returns 2 when T has no semiseparable structure.
+int smcpp_debug_ss_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b) {
+    API_BEGIN
+    const int NPL = (M + 63) / 64, MS = 64 * NPL;
+    if (NPL > 4) throw std::runtime_error("unsupported number of hidden states");
+    std::vector<double> gen;
+    double c0 = 0.0;
+    if (!ss_generators(M, NPL, T, gen, c0)) return 2;
+    std::vector<double> hx((size_t)nvec * MS, 0.0), he((size_t)nvec * MS, 0.0);
+    for (int v = 0; v < nvec; ++v) {
+        std::memcpy(&hx[(size_t)v * MS], x + (size_t)v * M, sizeof(double) * M);
+        std::memcpy(&he[(size_t)v * MS], e + (size_t)v * M, sizeof(double) * M);
+    }
+    DevBuf<double> dg, dx, de, df, db;
+    hipStream_t s = nullptr;
+    dg.upload(gen, s); dx.upload(hx, s); de.upload(he, s);
+    df.alloc(hx.size()); db.alloc(hx.size());
+    SsArgs a = SsArgs();
+    a.M = M;
+    const double *gd = dg.p;
+    a.f_dc = gd; a.f_g = gd + MS; a.f_cg = gd + 2 * MS; a.f_b = gd + 3 * MS; a.f_a = gd + 4 * MS; a.f_d = gd + 5 * MS;
+    a.b_dc = gd + 6 * MS; a.b_g = gd + 7 * MS; a.b_b = gd + 8 * MS; a.b_a = gd + 9 * MS;
+    a.c0 = c0;
+    switch (NPL) {
+        case 1: hipLaunchKernelGGL(k_ss_apply<1>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
+        case 2: hipLaunchKernelGGL(k_ss_apply<2>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
+        case 3: hipLaunchKernelGGL(k_ss_apply<3>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
+        default: hipLaunchKernelGGL(k_ss_apply<4>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<double> hf(hx.size()), hb(hx.size());
+    HIPCHK(hipMemcpy(hf.data(), df.p, hf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hb.data(), db.p, hb.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int v = 0; v < nvec; ++v) {
+        std::memcpy(out_f + (size_t)v * M, &hf[(size_t)v * MS], sizeof(double) * M);
+        std::memcpy(out_b + (size_t)v * M, &hb[(size_t)v * MS], sizeof(double) * M);
+    }
+    API_END
+}
 
 void smcpp_set_num_threads(int k) { if (k > 0) omp_set_num_threads(k); }
 

@@ -61,12 +61,15 @@ def check_against(g, im, save_gamma):
     assert np.array_equal(arg_dev, arg.astype(np.int32))
 
 
-@pytest.fixture(params=["default", "lock"])
+@pytest.fixture(params=["default", "dense", "lock"])
 def chain_family(request, monkeypatch):
-    """Every golden vector is checked with the chain kernels the engine picks by itself (cooperative / streamed operands at
-    these sizes) and with the lock-step kernels on the matrix cores forced (they take over on whole genomes, M <= 64)."""
+    """Every golden vector is checked with the chain kernels the engine picks by itself (the scans over the semiseparable
+    structure of T when the spans are short, else cooperative / streamed operands), with the scans switched off (the dense
+    kernels every manager falls back to) and with the lock-step kernels on the matrix cores forced (M <= 64)."""
     if request.param == "lock":
         monkeypatch.setenv("SMCPP_CHAIN", "lock")
+    if request.param == "dense":
+        monkeypatch.setenv("SMCPP_SS", "0")
     return request.param
 
 
@@ -74,6 +77,10 @@ def test_golden_stats(golden, chain_family):
     im = make_im(golden)
     if chain_family == "lock" and len(golden["pi"]) <= 64:
         assert im.chain_mode() == 4
+    if chain_family == "default" and int(np.max(golden["obs"][:, 0])) <= 512:
+        assert im.chain_mode() == 5
+    if chain_family == "dense":
+        assert im.chain_mode() != 5
     im.E_step()
     check_against(golden, im, save_gamma=False)
 

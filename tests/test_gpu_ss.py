@@ -1,0 +1,123 @@
+"""Scan chains on the semiseparable structure of the transition matrix (smcpp_amd/csrc/chains_ss.hpp).
+
+The reference builds T in HJTransition (src/transition.cpp:176-254): constant columns below the diagonal, a rank-one part plus
+one constant above it.  These tests check, on the GPU,
+  * one position of both chains (the Kogge-Stone scans over the lanes) against the dense products with the golden T's of the
+    compiled reference, for 1 .. 4 states per lane (M = 16 .. 256);
+  * that a matrix without that structure is refused (the engine then runs the dense kernels);
+  * the whole E-step on the scan kernels against the goldens is covered by tests/test_gpu_parity.py (chain family "default").
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def ss_apply(T, x, e):
+    from smcpp_amd import _engine
+    L = _engine.lib()
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    e = np.ascontiguousarray(e, dtype=np.float64)
+    of = np.empty_like(x)
+    ob = np.empty_like(x)
+    rc = L.smcpp_debug_ss_apply(T.shape[0], _engine.dptr(T), x.shape[0], _engine.dptr(x), _engine.dptr(e),
+                                _engine.dptr(of), _engine.dptr(ob))
+    if rc == 1:
+        raise RuntimeError(L.smcpp_last_error().decode())
+    return rc, of, ob
+
+
+def check_products(of, ob, ref_f, ref_b):
+    """Sums over "the other side" of a state are total - prefix: an entry 1e-12 below the largest of its vector carries
+    that cancellation (1e-16 of the TOTAL), far below the 1e-10 floor the reference puts under alpha; so the bound is
+    1e-14 of the vector's largest entry and, per entry, 1e-7."""
+    for o, r in ((of, ref_f), (ob, ref_b)):
+        err = np.abs(o - r)
+        assert np.all(np.isfinite(o))
+        assert np.max(err / np.max(np.abs(r), axis=1, keepdims=True)) < 1e-14
+        assert np.max(err / np.abs(r)) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["G1_M16_n4", "G3_M32_n10_2Mbp", "G5_M48_twopop_layout", "G4_M64_n20_2Mbp",
+                                  "params_M256_n50"])
+def test_one_position_matches_dense_products(name):
+    g = load_golden(name)
+    T = np.asarray(g["T"], dtype=np.float64)
+    M = T.shape[0]
+    rng = np.random.default_rng(7)
+    nvec = 37
+    # vectors with the dynamic range of real alpha / beta rows (entries down to 1e-12 of the largest)
+    x = rng.random((nvec, M)) ** 8 + 1e-12
+    x[0] = 1.0
+    x[1] = 0.0; x[1, M - 1] = 1.0
+    x[2] = 0.0; x[2, 0] = 1.0
+    e = 0.2 + 0.8 * rng.random((nvec, M))
+    rc, of, ob = ss_apply(T, x, e)
+    assert rc == 0
+    ref_f = e * (x @ T)               # e o (T^T x)
+    ref_b = (e * x) @ T.T             # T (e o x)
+    check_products(of, ob, ref_f, ref_b)
+
+
+@pytest.mark.parametrize("M", [70, 100, 130, 200])
+def test_one_position_other_state_counts(M):
+    """State counts that do not fill the lanes (2 .. 4 states per lane, padded): a T of the reference's form from generators."""
+    rng = np.random.default_rng(M)
+    c0 = 1e-5 / (M + 1)
+    g = 1e-4 * rng.random(M)
+    u = 1e-3 * rng.random(M)
+    r = np.cumsum(0.05 + 0.1 * rng.random(M))
+    T = np.zeros((M, M))
+    for i in range(M):
+        T[i, :i] = g[:i] + c0
+        for j in range(i + 1, M):
+            T[i, j] = c0 + u[i] * np.exp(-(r[j] - r[i]))
+        T[i, i] = 1.0 - T[i].sum()
+    x = rng.random((5, M)) ** 6 + 1e-10
+    e = 0.1 + rng.random((5, M))
+    rc, of, ob = ss_apply(T, x, e)
+    assert rc == 0
+    ref_f = e * (x @ T)
+    ref_b = (e * x) @ T.T
+    check_products(of, ob, ref_f, ref_b)
+
+
+def test_unstructured_matrix_is_refused():
+    rng = np.random.default_rng(3)
+    M = 24
+    T = rng.random((M, M)) + 0.01
+    T /= T.sum(axis=1, keepdims=True)
+    rc, _, _ = ss_apply(T, np.ones((1, M)), np.ones((1, M)))
+    assert rc == 2
+
+
+def test_engine_falls_back_to_dense_kernels_on_unstructured_T():
+    """set_raw with a matrix of no structure: same manager, dense chain kernels, results against the C restatement."""
+    from oracle import oracle
+    from smcpp_amd import _smcpp
+    g = load_golden("G1_M16_n4")
+    M = len(g["pi"])
+    rng = np.random.default_rng(11)
+    S = rng.random((M, M)); S = S + S.T + 20.0 * np.eye(M)      # reversible chain: real spectrum (the oracle takes LAPACK's eig)
+    T = S / S.sum(axis=1, keepdims=True)
+    obs = np.ascontiguousarray(g["obs"][:800], dtype=np.int32)
+    obs[:, 0] = np.minimum(obs[:, 0], 40)
+    im = _smcpp.PyOnePopInferenceManager(int(g["n"]), [obs], g["hs"], ("pop1",), float(g["pol"]))
+    assert im.chain_mode() == 5
+    im.theta = float(g["theta"]); im.rho = float(g["rho"])
+    im.set_raw(g["pi"], T, g["keys"], g["E"])
+    im.E_step()
+    o = oracle.estep(g["pi"], T, g["keys"], g["E"], obs)
+    assert abs(im.loglik() - o["loglik"]) <= 1e-6 * abs(o["loglik"])
+    assert np.max(np.abs(im.xisums[0] - o["xisum"]) / np.abs(o["xisum"])) <= 5e-6
+    # ... and the structured T of the golden on the same manager afterwards (scan kernels)
+    im.set_raw(g["pi"], g["T"], g["keys"], g["E"])
+    im.E_step()
+    o = oracle.estep(g["pi"], g["T"], g["keys"], g["E"], obs)
+    assert abs(im.loglik() - o["loglik"]) <= 1e-6 * abs(o["loglik"])
+    assert np.max(np.abs(im.xisums[0] - o["xisum"]) / np.abs(o["xisum"])) <= 5e-6

@@ -15,10 +15,11 @@
 // when it fails (smcpp_set_raw with an arbitrary matrix).
 //
 // Semantics (hmm.cpp:57-149) as in chains2.hpp: stored alpha is float(normalised vector) floored at 1e-10f, stored beta is the
-// vector in a running scale (every consumer is scale free), only the normaliser c of a row is stored; the chain itself runs
-// in fp64 without the per-row float rounding (the reference's own float noise is what the 5e-6 tolerance of the statistics
-// is made of; tests/golden parity: <= 1e-6 observed).  The reference multiplies a span-1 row by float(e_j T_ij): the rounding
-// of the diagonal entry (0.99..) is a systematic factor per state, it is reproduced (`dF`), the off-diagonal one is noise.
+// vector in a running scale (every consumer is scale free), only the normaliser c of a row is stored.  The chain itself runs
+// in fp64; what the reference feeds back into it row by row - the float rounding and the 1e-10 floor of the stored vector,
+// and for a span-1 row the float rounding of the operator's diagonal float(e_j T_jj) - is reproduced through the diagonal of
+// the (linear) operator; the off-diagonal remainder is 1e-2 x 6e-8 (tests: xisum / gamma sums <= 1e-6 against the compiled
+// reference and the C restatement, where the dense kernels reach 3e-6).
 // The backward lanes hold the states in REVERSED order so that its sums over j > i are prefix scans as well.
 // Chunk-parallel fixed point, skip test, merge exit and certificate: as chains2.hpp, per wavefront.
 #pragma once
@@ -42,7 +43,11 @@ struct SsArgs {
     int *changed_f, *changed_b;
     float eps_f;
     double eps_b;
-    int full;                   // 1: every chunk runs whole from the previous pass's end vectors (no skip test, no merge exit)
+    int full_f, full_b;         // 1: every chunk of the direction runs whole from the previous pass's end vectors (no skip
+                                // test, no merge exit, the contig's first / last chunk included): the fp64 pass after light passes
+    int mode_f, mode_b;         // per direction: 0 = first pass (from pi / uniform, stores), 1 = re-run pass, 2 = light pass (float,
+                                // store-free: only the chunk's end vector is produced - history for the passes that follow)
+    long long *dbg;             // optional [8] (SMCPP_DEBUG_CYCLES): shader-clock / 100 MHz ticks / positions of chunk 1, pass 0
 };
 
 template <int CTRL>
@@ -142,7 +147,9 @@ __device__ __forceinline__ void ss_load_bwd(const SsArgs &a, int lane, SsBwdC<NP
     c.c0 = a.c0;
 }
 
-// one position of the forward chain:  out = e o (T^T x)  [+ dfix o x];  S = sum x
+// The scans of one position are written level by level across the independent chains: a DPP move may only read a register two
+// instructions after it was written, so one chain alone pays a wait state per level, two or three interleaved pay none.
+// one position of the forward chain:  out = e o (T^T x);  S = sum x
 template <int NPL>
 __device__ __forceinline__ void ss_fwd_step(const SsFwdC<NPL> &c, const double (&x)[NPL], const double (&e)[NPL],
                                             double (&out)[NPL], double &S) {
@@ -154,11 +161,24 @@ __device__ __forceinline__ void ss_fwd_step(const SsFwdC<NPL> &c, const double (
         lp[k] = lp[k - 1] + x[k];
         w[k] = __builtin_fma(c.a[k], w[k - 1], c.b[k] * x[k]);
     }
-    const double li = ss_scan(lp[NPL - 1], c.c15, c.c31);
-    const double LI = ss_scan_w(w[NPL - 1], c.lv);
+    double p_ = lp[NPL - 1], z_ = w[NPL - 1];
+    {
+        double tp, tz;
+        tp = dpp0<DPP_SHR1>(p_); tz = dpp0<DPP_SHR1>(z_); p_ += tp; z_ = __builtin_fma(c.lv[0], tz, z_);
+        tp = dpp0<DPP_SHR2>(p_); tz = dpp0<DPP_SHR2>(z_); p_ += tp; z_ = __builtin_fma(c.lv[1], tz, z_);
+        tp = dpp0<DPP_SHR4>(p_); tz = dpp0<DPP_SHR4>(z_); p_ += tp; z_ = __builtin_fma(c.lv[2], tz, z_);
+        tp = dpp0<DPP_SHR8>(p_); tz = dpp0<DPP_SHR8>(z_); p_ += tp; z_ = __builtin_fma(c.lv[3], tz, z_);
+        tp = dpp0<DPP_BC15>(p_); tz = dpp0<DPP_BC15>(z_); p_ = __builtin_fma(c.c15, tp, p_); z_ = __builtin_fma(c.lv[4], tz, z_);
+        tp = dpp0<DPP_BC31>(p_); tz = dpp0<DPP_BC31>(z_); p_ = __builtin_fma(c.c31, tp, p_); z_ = __builtin_fma(c.lv[5], tz, z_);
+    }
+    const double li = p_, LI = z_;
     S = lane_get(li, 63);
-    const double lex = li - lp[NPL - 1];
     const double LIp = dpp0<DPP_WSHR1>(LI);
+    if (NPL == 1) {
+        out[0] = e[0] * __builtin_fma(c.dc[0], x[0], __builtin_fma(c.g[0], S, __builtin_fma(c.cg[0], li, LIp)));
+        return;
+    }
+    const double lex = li - lp[NPL - 1];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         const double incl = lex + lp[k];
@@ -185,14 +205,31 @@ __device__ __forceinline__ void ss_bwd_step(const SsBwdC<NPL> &c, const double (
         u[k] = __builtin_fma(c.a[k], u[k - 1], w[k]);
         lf[k] = lf[k - 1] + (float)w[k];
     }
-    const double lig = ss_scan(lg[NPL - 1], c.c15, c.c31);
-    const double LI = ss_scan_w(u[NPL - 1], c.lv);
-    const float lif = ss_scan_f(lf[NPL - 1], c.c15f, c.c31f);
+    double p_ = lg[NPL - 1], z_ = u[NPL - 1];
+    float f_ = lf[NPL - 1];
+    {
+        double tp, tz;
+        float tf;
+        tp = dpp0<DPP_SHR1>(p_); tz = dpp0<DPP_SHR1>(z_); tf = dpp0<DPP_SHR1>(f_); p_ += tp; z_ = __builtin_fma(c.lv[0], tz, z_); f_ += tf;
+        tp = dpp0<DPP_SHR2>(p_); tz = dpp0<DPP_SHR2>(z_); tf = dpp0<DPP_SHR2>(f_); p_ += tp; z_ = __builtin_fma(c.lv[1], tz, z_); f_ += tf;
+        tp = dpp0<DPP_SHR4>(p_); tz = dpp0<DPP_SHR4>(z_); tf = dpp0<DPP_SHR4>(f_); p_ += tp; z_ = __builtin_fma(c.lv[2], tz, z_); f_ += tf;
+        tp = dpp0<DPP_SHR8>(p_); tz = dpp0<DPP_SHR8>(z_); tf = dpp0<DPP_SHR8>(f_); p_ += tp; z_ = __builtin_fma(c.lv[3], tz, z_); f_ += tf;
+        tp = dpp0<DPP_BC15>(p_); tz = dpp0<DPP_BC15>(z_); tf = dpp0<DPP_BC15>(f_);
+        p_ = __builtin_fma(c.c15, tp, p_); z_ = __builtin_fma(c.lv[4], tz, z_); f_ = __builtin_fmaf(c.c15f, tf, f_);
+        tp = dpp0<DPP_BC31>(p_); tz = dpp0<DPP_BC31>(z_); tf = dpp0<DPP_BC31>(f_);
+        p_ = __builtin_fma(c.c31, tp, p_); z_ = __builtin_fma(c.lv[5], tz, z_); f_ = __builtin_fmaf(c.c31f, tf, f_);
+    }
+    const double lig = p_, LI = z_;
+    const float lif = f_;
     const double Gtot = lane_get(lig, 63);
     Sw = lane_get(lif, 63);
+    const double LIp = dpp0<DPP_WSHR1>(LI);
+    if (NPL == 1) {
+        out[0] = __builtin_fma(c.dc[0], w[0], (Gtot - lig) + __builtin_fma(c.c0, (double)lif, c.b[0] * LIp));
+        return;
+    }
     const double lexg = lig - lg[NPL - 1];
     const float lexf = lif - lf[NPL - 1];
-    const double LIp = dpp0<DPP_WSHR1>(LI);
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         const double inclG = lexg + lg[k];
@@ -229,7 +266,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     bool live[NPL], stor[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) { st[k] = lane * NPL + k; live[k] = st[k] < M; stor[k] = st[k] < Mp; }
-    if (RERUN && ch.first) {
+    if (RERUN && ch.first && !a.full_f) {
 #pragma unroll
         for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = end_prev[st[k]];
         return;
@@ -240,7 +277,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
 #pragma unroll
         for (int k = 0; k < NPL; ++k) x[k] = live[k] ? (double)src[st[k]] : 0.0;
     }
-    if (RERUN && !a.full) {
+    if (RERUN && !a.full_f) {
         bool diff = false;
 #pragma unroll
         for (int k = 0; k < NPL; ++k)
@@ -272,9 +309,12 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     double e[NPL];
     ss_emission<NPL, false>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0), lane, e);
     bool merged = false;
+    const long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
+    long long npos = 0;
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
+        npos += span;
         // descriptor / emission vector of the next row
         if (jl == 63) { dcur = dnxt; dnxt = rd[j + 65 + lane]; }
         const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63);
@@ -284,11 +324,23 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
         double y[NPL], S;
         ss_fwd_step<NPL>(cst, x, e, y, S);
         const double inv = rcp_f64(S);
+        // The reference continues from the STORED vector: normalised, rounded to float, floored at 1e-10 (hmm.cpp:80-94).  That
+        // feedback is not noise for small entries (a state whose alpha falls under the floor after a heterozygous row re-enters
+        // the next row with 1e-10 instead: 1e-5 on the statistics of the most recent states), so it is reproduced: the operator
+        // is linear, and of the perturbation  fb = stored - exact  only the diagonal part e d fb matters (the rest is
+        // fb times the off-diagonal mass of T, <= 1e-2 x 6e-8).
+        double fb[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) fb[k] = 0.0;
         if (j > 0) {
             float an[NPL];
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) an[k] = live[k] ? fmaxf((float)(x[k] * inv), 1e-10f) : 0.f;
-            if (RERUN && !a.full && (j & 15) == 0 && j >= 16) {
+            for (int k = 0; k < NPL; ++k) {
+                const double xs = x[k] * inv;
+                an[k] = live[k] ? fmaxf((float)xs, 1e-10f) : 0.f;
+                fb[k] = (double)an[k] - xs;
+            }
+            if (RERUN && !a.full_f && (j & 15) == 0 && j >= 16) {
                 bool bad = false;
 #pragma unroll
                 for (int k = 0; k < NPL; ++k)
@@ -302,16 +354,13 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
             for (int k = 0; k < NPL; ++k) if (stor[k]) arow[(size_t)j * Mp + st[k]] = an[k];
             if (lane == 0) crow[j] = S;
         }
-        if (span == 1) {
-            // hmm.cpp:85-86 multiplies by float(e_j T_ij): the rounding of the diagonal entry is systematic per state
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) {
-                const double ed = e[k] * cst.d[k];
-                y[k] = __builtin_fma((double)(float)ed - ed, x[k], y[k]);
-            }
+        for (int k = 0; k < NPL; ++k) {
+            double ed = e[k] * cst.d[k];
+            // hmm.cpp:85-86 multiplies a span-1 row by float(e_j T_ij): the rounding of the diagonal entry is systematic per state
+            if (span == 1) { const double edf = (double)(float)ed; y[k] = __builtin_fma(edf - ed, x[k], y[k]); ed = edf; }
+            x[k] = __builtin_fma(ed, fb[k], y[k] * inv);
         }
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) x[k] = y[k] * inv;
         for (int t = 1; t < span; ++t) {
             double S2;
             ss_fwd_step<NPL>(cst, x, e, y, S2);
@@ -320,6 +369,10 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) e[k] = en[k];
+    }
+    if (a.dbg && !RERUN && c == 1 && lane == 0) {
+        a.dbg[0] = __builtin_readcyclecounter() - t0c; a.dbg[1] = __builtin_amdgcn_s_memrealtime() - t0r;
+        a.dbg[2] = npos; a.dbg[3] = nrows;
     }
     if (merged) {
 #pragma unroll
@@ -352,7 +405,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
     bool live[NPL], stor[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) { st[k] = MS - 1 - (lane * NPL + k); live[k] = st[k] < M; stor[k] = st[k] < Mp; }
-    if (RERUN && ch.last) {
+    if (RERUN && ch.last && !a.full_b) {
 #pragma unroll
         for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = end_prev[st[k]];
         return;
@@ -364,7 +417,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
 #pragma unroll
         for (int k = 0; k < NPL; ++k) b[k] = live[k] ? (fresh ? 1.0 / (double)M : src[st[k]]) : 0.0;
     }
-    if (RERUN && !a.full) {
+    if (RERUN && !a.full_b) {
         bool diff = false;
 #pragma unroll
         for (int k = 0; k < NPL; ++k)
@@ -390,15 +443,18 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
     double e[NPL];
     ss_emission<NPL, true>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0), lane, e);
     bool merged = false;
+    const long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
+    long long npos = 0;
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
+        npos += span;
         if (jl == 63) { dcur = dnxt; dnxt = rd[-(j + 65) - lane]; }
         const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63);
         double en[NPL];
         ss_emission<NPL, true>(a, sE, slot_n, lane, en);
         // beta[ell] in the running scale (hmm.cpp:142 renormalises; every consumer is invariant to a per-row scale)
-        if (RERUN && !a.full && (j & 15) == 0 && j >= 16) {
+        if (RERUN && !a.full_b && (j & 15) == 0 && j >= 16) {
             bool bad = false;
 #pragma unroll
             for (int k = 0; k < NPL; ++k)
@@ -425,6 +481,10 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
 #pragma unroll
         for (int k = 0; k < NPL; ++k) e[k] = en[k];
     }
+    if (a.dbg && !RERUN && c == 1 && lane == 0) {
+        a.dbg[4] = __builtin_readcyclecounter() - t0c; a.dbg[5] = __builtin_amdgcn_s_memrealtime() - t0r;
+        a.dbg[6] = npos; a.dbg[7] = nrows;
+    }
     if (merged) {
 #pragma unroll
         for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = end_prev[st[k]];
@@ -444,26 +504,244 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Light passes.  A chunk needs ~13 e-folds of history before its rows are exact (the chains forget with an e-fold of
+// 240 / 340 positions), i.e. on one 100 Mbp contig cut into 512 chunks MORE positions of history than positions of its own.
+// Whatever a pass computes from a start vector that is still off is recomputed later, so those passes neither store rows
+// nor need fp64: they run the same scans in float (fused v_add_f32_dpp: one instruction per level instead of three) and
+// hand on the chunk's end vector only.  The pass that follows them is a full fp64 pass from their end vectors, then the
+// usual re-run passes with skip test, merge exit and certificate - so a light pass can only change HOW FAST the fixed
+// point is reached, never the result.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NPL>
+struct SsLightC { float dc[NPL], g[NPL], cg[NPL], b[NPL], a[NPL], cumA[NPL], lv[6], c15, c31, c0; };
+
+template <int NPL, bool BWD>
+__device__ __forceinline__ void ss_load_light(const SsArgs &a, int lane, SsLightC<NPL> &c) {
+    double cum = 1.0;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int p = lane * NPL + k;
+        c.dc[k] = (float)(BWD ? a.b_dc[p] : a.f_dc[p]);
+        c.g[k] = (float)(BWD ? a.b_g[p] : a.f_g[p]);
+        c.cg[k] = BWD ? 0.f : (float)a.f_cg[p];
+        c.b[k] = (float)(BWD ? a.b_b[p] : a.f_b[p]);
+        const double av = BWD ? a.b_a[p] : a.f_a[p];
+        c.a[k] = (float)av;
+        cum *= av;
+        c.cumA[k] = (float)cum;
+    }
+    double lv[6];
+    ss_levels(cum, lane, lv);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) c.lv[q] = (float)lv[q];
+    const int row = lane >> 4;
+    c.c15 = (row & 1) ? 1.f : 0.f;
+    c.c31 = (row >= 2) ? 1.f : 0.f;
+    c.c0 = (float)a.c0;
+}
+
+template <int NPL>
+__device__ __forceinline__ void ss_fwd_step_f(const SsLightC<NPL> &c, const float (&x)[NPL], const float (&e)[NPL],
+                                              float (&out)[NPL], float &S) {
+    float lp[NPL], w[NPL];
+    lp[0] = x[0];
+    w[0] = c.b[0] * x[0];
+#pragma unroll
+    for (int k = 1; k < NPL; ++k) {
+        lp[k] = lp[k - 1] + x[k];
+        w[k] = __builtin_fmaf(c.a[k], w[k - 1], c.b[k] * x[k]);
+    }
+    float p_ = lp[NPL - 1], z_ = w[NPL - 1];
+    p_ += dpp0<DPP_SHR1>(p_); z_ = __builtin_fmaf(c.lv[0], dpp0<DPP_SHR1>(z_), z_);
+    p_ += dpp0<DPP_SHR2>(p_); z_ = __builtin_fmaf(c.lv[1], dpp0<DPP_SHR2>(z_), z_);
+    p_ += dpp0<DPP_SHR4>(p_); z_ = __builtin_fmaf(c.lv[2], dpp0<DPP_SHR4>(z_), z_);
+    p_ += dpp0<DPP_SHR8>(p_); z_ = __builtin_fmaf(c.lv[3], dpp0<DPP_SHR8>(z_), z_);
+    p_ = __builtin_fmaf(c.c15, dpp0<DPP_BC15>(p_), p_); z_ = __builtin_fmaf(c.lv[4], dpp0<DPP_BC15>(z_), z_);
+    p_ = __builtin_fmaf(c.c31, dpp0<DPP_BC31>(p_), p_); z_ = __builtin_fmaf(c.lv[5], dpp0<DPP_BC31>(z_), z_);
+    S = lane_get(p_, 63);
+    const float LIp = dpp0<DPP_WSHR1>(z_);
+    const float lex = p_ - lp[NPL - 1];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const float incl = lex + lp[k];
+        const float Z = (k == 0) ? LIp : __builtin_fmaf(c.cumA[k - 1 < 0 ? 0 : k - 1], LIp, w[k - 1 < 0 ? 0 : k - 1]);
+        out[k] = e[k] * __builtin_fmaf(c.dc[k], x[k], __builtin_fmaf(c.g[k], S, __builtin_fmaf(c.cg[k], incl, Z)));
+    }
+}
+
+template <int NPL>
+__device__ __forceinline__ void ss_bwd_step_f(const SsLightC<NPL> &c, const float (&bv)[NPL], const float (&e)[NPL],
+                                              float (&out)[NPL], float &Sw) {
+    float w[NPL], lg[NPL], u[NPL], lf[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) w[k] = e[k] * bv[k];
+    lg[0] = c.g[0] * w[0];
+    u[0] = w[0];
+    lf[0] = w[0];
+#pragma unroll
+    for (int k = 1; k < NPL; ++k) {
+        lg[k] = __builtin_fmaf(c.g[k], w[k], lg[k - 1]);
+        u[k] = __builtin_fmaf(c.a[k], u[k - 1], w[k]);
+        lf[k] = lf[k - 1] + w[k];
+    }
+    float p_ = lg[NPL - 1], z_ = u[NPL - 1], f_ = lf[NPL - 1];
+    p_ += dpp0<DPP_SHR1>(p_); z_ = __builtin_fmaf(c.lv[0], dpp0<DPP_SHR1>(z_), z_); f_ += dpp0<DPP_SHR1>(f_);
+    p_ += dpp0<DPP_SHR2>(p_); z_ = __builtin_fmaf(c.lv[1], dpp0<DPP_SHR2>(z_), z_); f_ += dpp0<DPP_SHR2>(f_);
+    p_ += dpp0<DPP_SHR4>(p_); z_ = __builtin_fmaf(c.lv[2], dpp0<DPP_SHR4>(z_), z_); f_ += dpp0<DPP_SHR4>(f_);
+    p_ += dpp0<DPP_SHR8>(p_); z_ = __builtin_fmaf(c.lv[3], dpp0<DPP_SHR8>(z_), z_); f_ += dpp0<DPP_SHR8>(f_);
+    p_ = __builtin_fmaf(c.c15, dpp0<DPP_BC15>(p_), p_); z_ = __builtin_fmaf(c.lv[4], dpp0<DPP_BC15>(z_), z_);
+    f_ = __builtin_fmaf(c.c15, dpp0<DPP_BC15>(f_), f_);
+    p_ = __builtin_fmaf(c.c31, dpp0<DPP_BC31>(p_), p_); z_ = __builtin_fmaf(c.lv[5], dpp0<DPP_BC31>(z_), z_);
+    f_ = __builtin_fmaf(c.c31, dpp0<DPP_BC31>(f_), f_);
+    const float Gtot = lane_get(p_, 63);
+    Sw = lane_get(f_, 63);
+    const float LIp = dpp0<DPP_WSHR1>(z_);
+    const float lexg = p_ - lg[NPL - 1], lexf = f_ - lf[NPL - 1];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const float inclG = lexg + lg[k], inclW = lexf + lf[k];
+        const float V = (k == 0) ? LIp : __builtin_fmaf(c.cumA[k - 1 < 0 ? 0 : k - 1], LIp, u[k - 1 < 0 ? 0 : k - 1]);
+        out[k] = __builtin_fmaf(c.dc[k], w[k], (Gtot - inclG) + __builtin_fmaf(c.c0, inclW, c.b[k] * V));
+    }
+}
+
+template <int NPL, bool BWD>
+__device__ __forceinline__ void ss_emission_f(const SsArgs &a, const double *sE, int slot, int lane, float (&e)[NPL]) {
+    double ed[NPL];
+    ss_emission<NPL, BWD>(a, sE, slot, lane, ed);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) e[k] = (float)ed[k];
+}
+
+template <int NPL>
+__device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *sE, int c, int lane) {
+    const int M = a.M, Mp = a.Mp, pass = a.pass;
+    const Chunk ch = a.chunks[c];
+    float *end_cur = a.ends_f + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
+    int st[NPL];
+    bool live[NPL], stor[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { st[k] = lane * NPL + k; live[k] = st[k] < M; stor[k] = st[k] < Mp; }
+    float x[NPL];
+    {
+        const float *src = (ch.first || pass == 0) ? a.pi_f : a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + (c - 1)) * Mp;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) x[k] = live[k] ? src[st[k]] : 0.f;
+    }
+    if (lane == 0) a.changed_f[pass] = 1;
+    SsLightC<NPL> cst;
+    ss_load_light<NPL, false>(a, lane, cst);
+    const int2 *rd = a.rowdesc + ch.base + ch.r0 + 1;
+    const int nrows = ch.r1 - ch.r0;
+    int2 dcur = rd[lane], dnxt = rd[64 + lane];
+    float e[NPL];
+    ss_emission_f<NPL, false>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0), lane, e);
+    for (int j = 0; j < nrows; ++j) {
+        const int jl = j & 63;
+        const int span = __builtin_amdgcn_readlane(dcur.y, jl);
+        if (jl == 63) { dcur = dnxt; dnxt = rd[j + 65 + lane]; }
+        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63);
+        float en[NPL], y[NPL], S;
+        ss_emission_f<NPL, false>(a, sE, slot_n, lane, en);
+        ss_fwd_step_f<NPL>(cst, x, e, y, S);
+        const float inv = __builtin_amdgcn_rcpf(S);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) x[k] = y[k] * inv;
+        for (int t = 1; t < span; ++t) {
+            float S2;
+            ss_fwd_step_f<NPL>(cst, x, e, y, S2);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) x[k] = y[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) e[k] = en[k];
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) part += x[k];
+    const float inv = 1.f / wave_sum_dpp(part);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = live[k] ? fmaxf(x[k] * inv, 1e-10f) : 0.f;
+}
+
+template <int NPL>
+__device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double *sE, int c, int lane) {
+    constexpr int MS = 64 * NPL;
+    const int M = a.M, Mp = a.Mp, pass = a.pass;
+    const Chunk ch = a.chunks[c];
+    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
+    int st[NPL];
+    bool live[NPL], stor[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { st[k] = MS - 1 - (lane * NPL + k); live[k] = st[k] < M; stor[k] = st[k] < Mp; }
+    float b[NPL];
+    {
+        const bool fresh = ch.last || pass == 0;
+        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (fresh ? c : c + 1)) * Mp;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) b[k] = live[k] ? (fresh ? 1.f / (float)M : (float)src[st[k]]) : 0.f;
+    }
+    if (lane == 0) a.changed_b[pass] = 1;
+    SsLightC<NPL> cst;
+    ss_load_light<NPL, true>(a, lane, cst);
+    const int2 *rd = a.rowdesc + ch.base + ch.r1;
+    const int nrows = ch.r1 - ch.r0;
+    int2 dcur = rd[-lane], dnxt = rd[-64 - lane];
+    float e[NPL];
+    ss_emission_f<NPL, true>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0), lane, e);
+    for (int j = 0; j < nrows; ++j) {
+        const int jl = j & 63;
+        const int span = __builtin_amdgcn_readlane(dcur.y, jl);
+        if (jl == 63) { dcur = dnxt; dnxt = rd[-(j + 65) - lane]; }
+        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63);
+        float en[NPL], y[NPL], Sw;
+        ss_emission_f<NPL, true>(a, sE, slot_n, lane, en);
+        ss_bwd_step_f<NPL>(cst, b, e, y, Sw);
+        const float inv = __builtin_amdgcn_rcpf(Sw);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) b[k] = y[k] * inv;
+        for (int t = 1; t < span; ++t) {
+            float S2;
+            ss_bwd_step_f<NPL>(cst, b, e, y, S2);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) b[k] = y[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) e[k] = en[k];
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) part += live[k] ? b[k] : 0.f;
+    const float inv = 1.f / wave_sum_dpp(part);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = live[k] ? (double)(b[k] * inv) : 0.0;
+}
+
 // One workgroup = 4 wavefronts = chunks 2 blk, 2 blk + 1 forward (wavefronts 0, 1) and backward (wavefronts 2, 3); they share
 // one LDS copy of the emission vectors of the `nlds` most frequent keys.
-template <int NPL, bool RERUN>
+template <int NPL>
 __global__ __launch_bounds__(256) void k_chain_ss(SsArgs a) {
     constexpr int MS = 64 * NPL;
     extern __shared__ __attribute__((aligned(16))) double ss_lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool fwd = w < 2;
-    if (RERUN && a.changed_f[a.pass - 1] == 0 && a.changed_b[a.pass - 1] == 0) return;
+    const bool idle_f = a.mode_f == 1 && a.changed_f[a.pass - 1] == 0, idle_b = a.mode_b == 1 && a.changed_b[a.pass - 1] == 0;
+    if (idle_f && idle_b) return;
     for (int idx = tid; idx < a.nlds * MS; idx += 256) ss_lds[idx] = a.E[idx];
     __syncthreads();
     const int c = 2 * blockIdx.x + (w & 1);
     if (c >= a.nchunks) return;
     if (fwd) {
-        if (RERUN && a.changed_f[a.pass - 1] == 0) return;
-        ss_forward_wave<NPL, RERUN>(a, ss_lds, c, lane);
+        if (idle_f) return;
+        if (a.mode_f == 0) ss_forward_wave<NPL, false>(a, ss_lds, c, lane);
+        else if (a.mode_f == 1) ss_forward_wave<NPL, true>(a, ss_lds, c, lane);
+        else ss_forward_light<NPL>(a, ss_lds, c, lane);
     } else {
-        if (RERUN && a.changed_b[a.pass - 1] == 0) return;
-        __builtin_amdgcn_s_setprio(1);
-        ss_backward_wave<NPL, RERUN>(a, ss_lds, c, lane);
+        if (idle_b) return;
+        if (a.mode_b == 0) ss_backward_wave<NPL, false>(a, ss_lds, c, lane);
+        else if (a.mode_b == 1) ss_backward_wave<NPL, true>(a, ss_lds, c, lane);
+        else ss_backward_light<NPL>(a, ss_lds, c, lane);
     }
 }
 

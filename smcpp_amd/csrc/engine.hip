@@ -216,6 +216,8 @@ struct smcpp_im {
     int ss_max_span = 0;
     int ss_nlds = 0;                       // key slots whose emission vectors live in LDS
     int ss_launched = 0, last_ss_passes = 0;
+    long long ss_positions = 0;            // sum of spans
+    int ss_light_f = 0, ss_light_b = 0;    // light (float, store-free) passes per direction before the full fp64 pass
     std::vector<int> ss_slot_of_key;       // frequency rank of every key (slot 0 = most rows)
     DevBuf<int2> d_rowdesc_ss;             // [rows, padded] {key slot, span}
     SsArgs ss_args;
@@ -554,7 +556,7 @@ void smcpp_im::make_chunks() {
                 prev = r1;
             }
         }
-        max_pass = max_chunks_per_contig + 3;
+        max_pass = max_chunks_per_contig + 3 + 4;      // (+4: light passes)
         return;
     }
     long long rows = total_rows - n_contigs;
@@ -585,6 +587,7 @@ void smcpp_im::make_chunks() {
         }
     }
     max_pass = max_chunks_per_contig + 3;   // (+1: the full pass that follows an eigen-free pre-pass)
+    if (ss_static) max_pass += 4;           // light passes of the scan chains
 }
 
 void smcpp_im::make_slabs() {
@@ -744,6 +747,12 @@ void smcpp_im::alloc_device() {
         for (int r = 0; r < K; ++r) ss_slot_of_key[order[r]] = r;
         const int MS = 64 * NPL;
         ss_nlds = (int)std::min<long long>(K, (64 * 1024) / ((long long)MS * 8));
+        ss_positions = 0;
+        for (int c = 0; c < n_contigs; ++c)
+            for (int i = 1; i <= Ls[c]; ++i) {
+                const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
+                ss_positions += ri.gid < 0 ? 1 : groups[ri.gid].span;
+            }
         if (ss_static) {
             std::vector<int2> rd((size_t)total_rows + 2 * ROWDESC_PAD, make_int2(0, 1));
             for (size_t r = 0; r < (size_t)total_rows; ++r) {
@@ -1698,13 +1707,10 @@ template <int NPL_>
 static void launch_chain_ss_t(const SsArgs &a, size_t shm, hipStream_t s) {
     static bool once = false;
     if (!once) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss<NPL_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss<NPL_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss<NPL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;
     }
-    const int nblk = (a.nchunks + 1) / 2;
-    if (a.pass == 0) hipLaunchKernelGGL((k_chain_ss<NPL_, false>), dim3(nblk), dim3(256), shm, s, a);
-    else hipLaunchKernelGGL((k_chain_ss<NPL_, true>), dim3(nblk), dim3(256), shm, s, a);
+    hipLaunchKernelGGL((k_chain_ss<NPL_>), dim3((a.nchunks + 1) / 2), dim3(256), shm, s, a);
 }
 static void launch_chain_ss(int npl, const SsArgs &a, size_t shm, hipStream_t s) {
     switch (npl) {
@@ -1719,8 +1725,16 @@ static void launch_chain_ss(int npl, const SsArgs &a, size_t shm, hipStream_t s)
 void smcpp_im::ss_launch_passes(int upto) {
     const size_t shm = (size_t)ss_nlds * 64 * NPL * sizeof(double);
     for (; ss_launched < upto; ++ss_launched) {
-        ss_args.pass = ss_launched;
-        launch_chain_ss(NPL, ss_args, shm, stream);
+        // per direction: `light` store-free float passes (history), then one full fp64 pass from their end vectors, then re-run
+        // passes; without light passes the first pass is the full one (from pi / the uniform vector)
+        const int p = ss_launched;
+        ss_args.pass = p;
+        ss_args.mode_f = p < ss_light_f ? 2 : p == 0 ? 0 : 1;
+        ss_args.mode_b = p < ss_light_b ? 2 : p == 0 ? 0 : 1;
+        ss_args.full_f = (p > 0 && p == ss_light_f) ? 1 : 0;
+        ss_args.full_b = (p > 0 && p == ss_light_b) ? 1 : 0;
+        const SsArgs &a = ss_args;
+        launch_chain_ss(NPL, a, shm, stream);
     }
     HIPCHK(hipGetLastError());
 }
@@ -1768,7 +1782,21 @@ void smcpp_im::ss_launch_initial() {
     a.alpha = d_alpha.p; a.beta = d_beta.p; a.cnorm = d_cnorm.p;
     a.ends_f = d_ends_f.p; a.used_f = d_used_f.p; a.ends_b = d_ends_b.p; a.used_b = d_used_b.p;
     a.changed_f = d_changed_f.p; a.changed_b = d_changed_b.p;
-    a.eps_f = eps_f; a.eps_b = eps_b; a.full = 0;
+    a.eps_f = eps_f; a.eps_b = eps_b; a.full_f = a.full_b = 0;
+    {
+        // light passes: enough of them that the full pass starts ~11 e-folds of history in (the chains forget with an e-fold of
+        // ~240 positions forward, ~340 backward on the benchmark model); none when the chunks are long against that
+        long long pos = 0;
+        const int ef = getenv("SMCPP_SS_LIGHT_F") ? atoi(getenv("SMCPP_SS_LIGHT_F")) : -1;
+        const int eb = getenv("SMCPP_SS_LIGHT_B") ? atoi(getenv("SMCPP_SS_LIGHT_B")) : -1;
+        pos = ss_positions / std::max<size_t>(1, chunks.size());
+        auto pick = [&](double hist) { return pos <= 0 || (double)pos > 1.5 * hist ? 0 : std::min(4, (int)std::ceil(hist / (double)pos)); };
+        ss_light_f = ef >= 0 ? ef : pick(2800.0);
+        ss_light_b = eb >= 0 ? eb : pick(3900.0);
+        if (chunks.size() <= (size_t)n_contigs) ss_light_f = ss_light_b = 0;      // one chunk per contig: nothing to iterate
+    }
+    a.dbg = nullptr;
+    if (getenv("SMCPP_DEBUG_CYCLES")) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }
     HIPCHK(hipMemcpyAsync(d_pre, pre_stage.base, off, hipMemcpyHostToDevice, s));
     d_changed_f.zero(s);
     d_changed_b.zero(s);
@@ -1809,6 +1837,12 @@ void smcpp_im::run_chains_ss() {
         ss_launch_passes(std::min(max_pass, ss_launched + 3));
     }
     chains_dual = false;
+    if (ss_args.dbg) {
+        long long h[8];
+        HIPCHK(hipMemcpy(h, d_dbg.p, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[cycles] ss pass 0, chunk 1: forward %lld shader clocks, %lld x 10 ns, %lld positions, %lld rows; backward %lld "
+                "clocks, %lld x 10 ns, %lld positions, %lld rows\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    }
     if (q < 0) { stats_enqueued = false; throw std::runtime_error("chunk-boundary iteration did not converge"); }
     last_ss_passes = q;
     last_fwd_passes = last_bwd_passes = q;

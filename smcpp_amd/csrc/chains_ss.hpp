@@ -48,6 +48,13 @@ struct SsArgs {
     int mode_f, mode_b;         // per direction: 0 = first pass (from pi / uniform, stores), 1 = re-run pass, 2 = light pass (float,
                                 // store-free: only the chunk's end vector is produced - history for the passes that follow)
     long long *dbg;             // optional [8] (SMCPP_DEBUG_CYCLES): shader-clock / 100 MHz ticks / positions of chunk 1, pass 0
+    // light passes on COARSE chunks handing over to the four-chains-per-wavefront kernels (chains_ss4.hpp): a coarse chunk is
+    // Chunk::pad & 0xFFFFFF .. + (Chunk::pad >> 24) - 1 of the fine list; a direction's LAST light pass also writes the vector
+    // at every fine boundary into the fine end-vector arrays (parity of the pass)
+    const Chunk *fine;
+    int nfine, hand_f, hand_b;
+    float *fine_ends_f;
+    double *fine_ends_b;
 };
 
 template <int CTRL>
@@ -361,11 +368,23 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
             if (span == 1) { const double edf = (double)(float)ed; y[k] = __builtin_fma(edf - ed, x[k], y[k]); ed = edf; }
             x[k] = __builtin_fma(ed, fb[k], y[k] * inv);
         }
-        for (int t = 1; t < span; ++t) {
+        {
+            // two positions per trip (the DPP moves are convergent operations: the compiler will not unroll this loop itself)
             double S2;
-            ss_fwd_step<NPL>(cst, x, e, y, S2);
+            int t = 1;
+            for (; t + 1 < span; t += 2) {
+                ss_fwd_step<NPL>(cst, x, e, y, S2);
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) x[k] = y[k];
+                for (int k = 0; k < NPL; ++k) x[k] = y[k];
+                ss_fwd_step<NPL>(cst, x, e, y, S2);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) x[k] = y[k];
+            }
+            if (t < span) {
+                ss_fwd_step<NPL>(cst, x, e, y, S2);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) x[k] = y[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) e[k] = en[k];
@@ -472,11 +491,23 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
         const double inv = (double)__builtin_amdgcn_rcpf(Sw);
 #pragma unroll
         for (int k = 0; k < NPL; ++k) b[k] = y[k] * inv;
-        for (int t = 1; t < span; ++t) {
+        {
+            // two positions per trip (the DPP moves are convergent operations: the compiler will not unroll this loop itself)
             float S2;
-            ss_bwd_step<NPL>(cst, b, e, y, S2);
+            int t = 1;
+            for (; t + 1 < span; t += 2) {
+                ss_bwd_step<NPL>(cst, b, e, y, S2);
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) b[k] = y[k];
+                for (int k = 0; k < NPL; ++k) b[k] = y[k];
+                ss_bwd_step<NPL>(cst, b, e, y, S2);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) b[k] = y[k];
+            }
+            if (t < span) {
+                ss_bwd_step<NPL>(cst, b, e, y, S2);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) b[k] = y[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) e[k] = en[k];
@@ -637,6 +668,9 @@ __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *
     int2 dcur = rd[lane], dnxt = rd[64 + lane];
     float e[NPL];
     ss_emission_f<NPL, false>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0), lane, e);
+    int fcur = ch.pad & 0xFFFFFF;
+    const int fend = fcur + (ch.pad >> 24);
+    int nextb = (a.hand_f && fcur < fend) ? a.fine[fcur].r1 - ch.r0 : -1;
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
@@ -648,14 +682,38 @@ __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *
         const float inv = __builtin_amdgcn_rcpf(S);
 #pragma unroll
         for (int k = 0; k < NPL; ++k) x[k] = y[k] * inv;
-        for (int t = 1; t < span; ++t) {
+        {
+            // two positions per trip (the DPP moves are convergent operations: the compiler will not unroll this loop itself)
             float S2;
-            ss_fwd_step_f<NPL>(cst, x, e, y, S2);
+            int t = 1;
+            for (; t + 1 < span; t += 2) {
+                ss_fwd_step_f<NPL>(cst, x, e, y, S2);
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) x[k] = y[k];
+                for (int k = 0; k < NPL; ++k) x[k] = y[k];
+                ss_fwd_step_f<NPL>(cst, x, e, y, S2);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) x[k] = y[k];
+            }
+            if (t < span) {
+                ss_fwd_step_f<NPL>(cst, x, e, y, S2);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) x[k] = y[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) e[k] = en[k];
+        if (j + 1 == nextb) {
+            // end of a fine chunk: hand its (normalised, floored) end vector to the four-chains kernels
+            float pt = 0.f;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) pt += x[k];
+            const float iv = 1.f / wave_sum_dpp(pt);
+            float *dst = a.fine_ends_f + ((size_t)(pass & 1) * a.nfine + fcur) * Mp;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) if (stor[k]) dst[st[k]] = live[k] ? fmaxf(x[k] * iv, 1e-10f) : 0.f;
+            ++fcur;
+            nextb = fcur < fend ? a.fine[fcur].r1 - ch.r0 : -1;
+        }
     }
     float part = 0.f;
 #pragma unroll
@@ -690,6 +748,9 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
     int2 dcur = rd[-lane], dnxt = rd[-64 - lane];
     float e[NPL];
     ss_emission_f<NPL, true>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0), lane, e);
+    const int fbeg = ch.pad & 0xFFFFFF;
+    int fcur = fbeg + (ch.pad >> 24) - 1;
+    int nextb = (a.hand_b && fcur >= fbeg) ? ch.r1 - a.fine[fcur].r0 : -1;
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
@@ -701,14 +762,37 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
         const float inv = __builtin_amdgcn_rcpf(Sw);
 #pragma unroll
         for (int k = 0; k < NPL; ++k) b[k] = y[k] * inv;
-        for (int t = 1; t < span; ++t) {
+        {
+            // two positions per trip (the DPP moves are convergent operations: the compiler will not unroll this loop itself)
             float S2;
-            ss_bwd_step_f<NPL>(cst, b, e, y, S2);
+            int t = 1;
+            for (; t + 1 < span; t += 2) {
+                ss_bwd_step_f<NPL>(cst, b, e, y, S2);
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) b[k] = y[k];
+                for (int k = 0; k < NPL; ++k) b[k] = y[k];
+                ss_bwd_step_f<NPL>(cst, b, e, y, S2);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) b[k] = y[k];
+            }
+            if (t < span) {
+                ss_bwd_step_f<NPL>(cst, b, e, y, S2);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) b[k] = y[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) e[k] = en[k];
+        if (j + 1 == nextb) {
+            float pt = 0.f;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) pt += live[k] ? b[k] : 0.f;
+            const float iv = 1.f / wave_sum_dpp(pt);
+            double *dst = a.fine_ends_b + ((size_t)(pass & 1) * a.nfine + fcur) * Mp;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) if (stor[k]) dst[st[k]] = live[k] ? (double)(b[k] * iv) : 0.0;
+            --fcur;
+            nextb = fcur >= fbeg ? ch.r1 - a.fine[fcur].r0 : -1;
+        }
     }
     float part = 0.f;
 #pragma unroll
@@ -726,7 +810,9 @@ __global__ __launch_bounds__(256) void k_chain_ss(SsArgs a) {
     extern __shared__ __attribute__((aligned(16))) double ss_lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool fwd = w < 2;
-    const bool idle_f = a.mode_f == 1 && a.changed_f[a.pass - 1] == 0, idle_b = a.mode_b == 1 && a.changed_b[a.pass - 1] == 0;
+    // mode 3: the direction takes no part in this launch (its pass runs in the other layout's kernel)
+    const bool idle_f = a.mode_f == 3 || (a.mode_f == 1 && a.changed_f[a.pass - 1] == 0);
+    const bool idle_b = a.mode_b == 3 || (a.mode_b == 1 && a.changed_b[a.pass - 1] == 0);
     if (idle_f && idle_b) return;
     for (int idx = tid; idx < a.nlds * MS; idx += 256) ss_lds[idx] = a.E[idx];
     __syncthreads();

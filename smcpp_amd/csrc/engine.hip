@@ -29,6 +29,7 @@
 #include "chains2.hpp"
 #include "chains_lock.hpp"
 #include "chains_ss.hpp"
+#include "chains_ss4.hpp"
 #include "nonsym_eig.hpp"
 #include "nonsym_eig_team.hpp"
 #include "prep.hpp"
@@ -213,6 +214,7 @@ struct smcpp_im {
     // ---- chains on the semiseparable structure of T (chains_ss.hpp; chain_mode 5) ------------------------------------------
     bool ss_static = false;                // the input qualifies (short spans); whether T does is decided on every E-step
     bool ss_active = false;                // this E-step's chains run on the scan kernels
+    bool eigfree = false;                  // ... and its statistics need no eigensystem either (k_span_fold): no eigensolve at all
     int ss_max_span = 0;
     int ss_nlds = 0;                       // key slots whose emission vectors live in LDS
     int ss_launched = 0, last_ss_passes = 0;
@@ -220,7 +222,20 @@ struct smcpp_im {
     int ss_light_f = 0, ss_light_b = 0;    // light (float, store-free) passes per direction before the full fp64 pass
     std::vector<int> ss_slot_of_key;       // frequency rank of every key (slot 0 = most rows)
     DevBuf<int2> d_rowdesc_ss;             // [rows, padded] {key slot, span}
+    DevBuf<double> d_Fall;                 // [n_contigs Ke][smax][Mp][Mp] scratch of the span fold (k_span_F -> k_span_H)
     SsArgs ss_args;
+    // four chains per wavefront (chains_ss4.hpp, M <= 64): the fp64 passes run on `chunks` (fine), the light passes on groups of
+    // four of them (`chunks1`, coarse) and hand over the fine boundary vectors
+    bool ss4 = false;
+    int SPL = 1;
+    std::vector<Chunk> chunks1;
+    DevBuf<Chunk> d_chunks1;
+    DevBuf<float> d_ends1_f;
+    DevBuf<double> d_ends1_b;
+    std::vector<double> ss_gen4;
+    SsArgs ss4_args;
+    void build_coarse_chunks();
+    void upload_chunk_state();
     bool ss_extract_generators();          // generators of T (verified entry by entry) into ss_gen; false: T has no such structure
     std::vector<double> ss_gen;            // [10][MS]: f_dc f_g f_cg f_b f_a f_d b_dc b_g b_b b_a
     double ss_c0 = 0.0;
@@ -500,6 +515,12 @@ void smcpp_im::make_chunks() {
             const char *se = getenv("SMCPP_SS");
             ss_static = !(se && atoi(se) == 0) && (!m || !strcmp(m, "ss")) && ss_max_span <= 512 && Mp <= 256;
             if (ss_static) chain_mode = Mp > 64 ? 3 : 2;
+            SPL = (M + 15) / 16;
+            // (opt-in: on one 100 Mbp contig the fine chunks are shorter than the history a re-run has to cover, so the re-run passes
+            // cascade over several launches - measured 1.9 ms of chains against 1.0 ms with one chain per wavefront; the layout pays
+            // when the chunks are long, i.e. on whole genomes, and is kept for that: DESIGN.md)
+            const char *s4 = getenv("SMCPP_SS4");
+            ss4 = ss_static && Mp <= 64 && (s4 && atoi(s4) != 0) && (long long)K * 16 * SPL * 8 <= 100 * 1024;
         }
         const char *b = getenv("SMCPP_COOP_BPC");
         if (b && atoi(b) > 0) coop_bpc = atoi(b);
@@ -519,7 +540,7 @@ void smcpp_im::make_chunks() {
         // SIMD; chunks are cut by POSITIONS (sum of spans), the unit of work of these kernels.  Every chunk pays the same
         // ~3000 positions of re-run history however short it is (the chains forget with an e-fold of ~240 positions).
         static const int wpc = getenv("SMCPP_SS_WPC") ? std::max(1, atoi(getenv("SMCPP_SS_WPC"))) : 1;
-        slots = (long long)prop.multiProcessorCount * 2 * wpc;
+        slots = (long long)prop.multiProcessorCount * 2 * wpc * (ss4 ? 4 : 1);
         std::vector<long long> cum;
         long long total_bins = 0;
         for (int c = 0; c < n_contigs; ++c)
@@ -527,7 +548,7 @@ void smcpp_im::make_chunks() {
                 const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
                 total_bins += ri.gid < 0 ? 1 : groups[ri.gid].span;
             }
-        const long long bpc = std::max<long long>(2048, (total_bins + slots - 1) / slots);
+        const long long bpc = std::max<long long>(ss4 ? 512 : 2048, (total_bins + slots - 1) / slots);
         chunks.clear();
         max_chunks_per_contig = 1;
         for (int c = 0; c < n_contigs; ++c) {
@@ -557,6 +578,7 @@ void smcpp_im::make_chunks() {
             }
         }
         max_pass = max_chunks_per_contig + 3 + 4;      // (+4: light passes)
+        build_coarse_chunks();
         return;
     }
     long long rows = total_rows - n_contigs;
@@ -588,6 +610,38 @@ void smcpp_im::make_chunks() {
     }
     max_pass = max_chunks_per_contig + 3;   // (+1: the full pass that follows an eigen-free pre-pass)
     if (ss_static) max_pass += 4;           // light passes of the scan chains
+    build_coarse_chunks();
+}
+
+// coarse chunks of the light passes: groups of four consecutive fine chunks of a contig (Chunk::pad = first fine | count << 24)
+void smcpp_im::build_coarse_chunks() {
+    chunks1.clear();
+    if (!ss4) return;
+    size_t i = 0;
+    while (i < chunks.size()) {
+        size_t j = i + 1;
+        while (j < chunks.size() && j - i < 4 && chunks[j].contig == chunks[i].contig) ++j;
+        Chunk c = chunks[i];
+        c.r1 = chunks[j - 1].r1;
+        c.last = chunks[j - 1].last;
+        c.pad = (int)i | ((int)(j - i) << 24);
+        chunks1.push_back(c);
+        i = j;
+    }
+}
+
+void smcpp_im::upload_chunk_state() {
+    const size_t nch = chunks.size();
+    d_chunks.upload(chunks, stream);
+    d_ends_f.alloc(2 * nch * Mp); d_used_f.alloc(nch * Mp);
+    d_ends_b.alloc(2 * nch * Mp); d_used_b.alloc(nch * Mp);
+    d_changed_f.alloc(max_pass + 1); d_changed_b.alloc(max_pass + 1);
+    if (ss4) {
+        d_chunks1.upload(chunks1, stream);
+        d_ends1_f.alloc(2 * chunks1.size() * Mp);
+        d_ends1_b.alloc(2 * chunks1.size() * Mp);
+    }
+    HIPCHK(hipStreamSynchronize(stream));
 }
 
 void smcpp_im::make_slabs() {
@@ -763,7 +817,7 @@ void smcpp_im::alloc_device() {
             HIPCHK(hipStreamSynchronize(s));
         }
     }
-    d_chunks.upload(chunks, s);
+    upload_chunk_state();
     d_slabs_sc.upload(slabs_sc, s);
     d_slabs_rk.upload(slabs_rk, s);
     d_slabs_eg.upload(slabs_eg, s);
@@ -784,18 +838,11 @@ void smcpp_im::alloc_device() {
     d_g_eig.upload(ge, s);
     d_e_kid.upload(eig_kid, s);
     setup_power();
-    const size_t nch = chunks.size();
     d_alpha.alloc((size_t)total_rows * Mp);
     d_beta.alloc((size_t)total_rows * Mp);
     d_cnorm.alloc((size_t)total_rows);
     d_logc.alloc((size_t)total_rows);
     d_w1.alloc((size_t)total_rows);
-    d_ends_f.alloc(2 * nch * Mp);
-    d_used_f.alloc(nch * Mp);
-    d_ends_b.alloc(2 * nch * Mp);
-    d_used_b.alloc(nch * Mp);
-    d_changed_f.alloc(max_pass + 1);
-    d_changed_b.alloc(max_pass + 1);
     d_llpart.alloc((size_t)n_contigs * llblk);
     d_loglik.alloc(n_contigs);
     d_gpart.alloc(std::max<size_t>(1, slabs_sc.size()) * Mp);
@@ -1012,6 +1059,13 @@ void smcpp_im::host_prep_and_upload() {
         if ((int)l3.size() < Ke) team = 1;
     }
     bool team_done = false;
+    if (eigfree) {
+        // no eigensystem is needed anywhere in this E-step: only the key-independent arrays are packed
+        pack_static();
+        for (int g = 0; g < G; ++g) { gsc[g] = 1.0; gls[g] = 0.0; }
+        team = 1;
+        team_done = true;
+    }
     if (team >= 2) {
         pack_static();
         if ((int)eig_teams.size() != Ke || eig_teams[0]->size != team) {
@@ -1145,7 +1199,7 @@ void smcpp_im::host_prep_and_upload() {
     HIPCHK(hipMemcpyAsync(d_param, hb, off, hipMemcpyHostToDevice, s));
     // (d_r / scale)^span for every (span, eigen key) group: G x M calls of pow() - 2 ms of host time on data with a few
     // thousand distinct spans, microseconds here
-    if (G > 0)
+    if (G > 0 && !eigfree)
         hipLaunchKernelGGL(k_group_dpow, dim3(ceil_div((long long)G * Mp, 256)), dim3(256), 0, s, G, M, Mp, (const int *)d_g_span.p,
                            (const int *)d_g_eig.p, (const double *)d_dsc.p, d_dpow.p);
     {
@@ -1651,8 +1705,7 @@ void smcpp_im::run_chains() {
 // (transition.cpp:176-254; c0 = 1e-5 / (M + 1) is the mixing constant of lines 249-254).  The dense T is what the reference's
 // getters hand out and what the statistics use, so the generators are taken FROM it and the reconstruction is checked entry by
 // entry: a T without this structure (smcpp_set_raw with an arbitrary matrix) sends the E-step to the dense kernels.
-static bool ss_generators(int M, int NPL, const double *Tm, std::vector<double> &gen, double &c0_out) {
-    const int MS = 64 * NPL;
+static bool ss_generators(int M, int MS, const double *Tm, std::vector<double> &gen, double &c0_out) {
     const double c0 = 1e-5 / (double)(M + 1);
     const double tol = 1e-11;
     std::vector<double> d(M), g(M, 0.0), a(M, 0.0), b(M, 0.0);
@@ -1693,7 +1746,8 @@ static bool ss_generators(int M, int NPL, const double *Tm, std::vector<double> 
 }
 
 bool smcpp_im::ss_extract_generators() {
-    if (!ss_generators(M, NPL, T.data(), ss_gen, ss_c0)) return false;
+    if (!ss_generators(M, 64 * NPL, T.data(), ss_gen, ss_c0)) return false;
+    if (ss4 && !ss_generators(M, 16 * SPL, T.data(), ss_gen4, ss_c0)) return false;
     // a row of span s applies its operator s times without rescaling: keep clear of underflow
     for (const Group &gr : groups) {
         double mn = 1.0;
@@ -1722,19 +1776,60 @@ static void launch_chain_ss(int npl, const SsArgs &a, size_t shm, hipStream_t s)
     }
 }
 
+template <int SPL_>
+static void launch_chain_ss4_t(const SsArgs &a, size_t shm, hipStream_t s) {
+    static bool once = false;
+    if (!once) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss4<SPL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once = true;
+    }
+    hipLaunchKernelGGL((k_chain_ss4<SPL_>), dim3((a.nchunks + 7) / 8), dim3(256), shm, s, a);
+}
+static void launch_chain_ss4(int spl, const SsArgs &a, size_t shm, hipStream_t s) {
+    switch (spl) {
+        case 1: launch_chain_ss4_t<1>(a, shm, s); break;
+        case 2: launch_chain_ss4_t<2>(a, shm, s); break;
+        case 3: launch_chain_ss4_t<3>(a, shm, s); break;
+        case 4: launch_chain_ss4_t<4>(a, shm, s); break;
+        default: throw std::runtime_error("unsupported number of hidden states");
+    }
+}
+
 void smcpp_im::ss_launch_passes(int upto) {
     const size_t shm = (size_t)ss_nlds * 64 * NPL * sizeof(double);
+    const size_t shm4 = (size_t)K * 16 * SPL * sizeof(double);
     for (; ss_launched < upto; ++ss_launched) {
         // per direction: `light` store-free float passes (history), then one full fp64 pass from their end vectors, then re-run
         // passes; without light passes the first pass is the full one (from pi / the uniform vector)
         const int p = ss_launched;
-        ss_args.pass = p;
-        ss_args.mode_f = p < ss_light_f ? 2 : p == 0 ? 0 : 1;
-        ss_args.mode_b = p < ss_light_b ? 2 : p == 0 ? 0 : 1;
-        ss_args.full_f = (p > 0 && p == ss_light_f) ? 1 : 0;
-        ss_args.full_b = (p > 0 && p == ss_light_b) ? 1 : 0;
-        const SsArgs &a = ss_args;
-        launch_chain_ss(NPL, a, shm, stream);
+        const bool lf = p < ss_light_f, lb = p < ss_light_b;
+        if (!ss4) {
+            ss_args.pass = p;
+            ss_args.mode_f = lf ? 2 : p == 0 ? 0 : 1;
+            ss_args.mode_b = lb ? 2 : p == 0 ? 0 : 1;
+            ss_args.full_f = (p > 0 && p == ss_light_f) ? 1 : 0;
+            ss_args.full_b = (p > 0 && p == ss_light_b) ? 1 : 0;
+            launch_chain_ss(NPL, ss_args, shm, stream);
+            continue;
+        }
+        // M <= 64: the light passes run on the coarse chunks (one chain per wavefront), the fp64 passes on the fine ones (four
+        // chains per wavefront); a direction's last light pass hands over the fine boundary vectors
+        if (lf || lb) {
+            ss_args.pass = p;
+            ss_args.mode_f = lf ? 2 : 3;
+            ss_args.mode_b = lb ? 2 : 3;
+            ss_args.hand_f = p == ss_light_f - 1;
+            ss_args.hand_b = p == ss_light_b - 1;
+            launch_chain_ss(NPL, ss_args, shm, stream);
+        }
+        if (!lf || !lb) {
+            ss4_args.pass = p;
+            ss4_args.mode_f = lf ? 3 : p == 0 ? 0 : 1;
+            ss4_args.mode_b = lb ? 3 : p == 0 ? 0 : 1;
+            ss4_args.full_f = (p > 0 && p == ss_light_f) ? 1 : 0;
+            ss4_args.full_b = (p > 0 && p == ss_light_b) ? 1 : 0;
+            launch_chain_ss4(SPL, ss4_args, shm4, stream);
+        }
     }
     HIPCHK(hipGetLastError());
 }
@@ -1747,7 +1842,9 @@ void smcpp_im::ss_launch_initial() {
     std::vector<float> &pi_f = hs_pi_f;
     if (pi_f.size() != (size_t)Mp) pi_f.assign(Mp, 0.f);
     for (int i = 0; i < M; ++i) pi_f[i] = (float)pi[i];
-    const size_t need = 8 * 256 + pi_f.size() * 4 + ss_gen.size() * 8 + (size_t)K * MS * 8;
+    const int MS4 = 16 * SPL;
+    const size_t need = 12 * 256 + pi_f.size() * 4 + ss_gen.size() * 8 + (size_t)K * MS * 8 +
+                        (ss4 ? ss_gen4.size() * 8 + (size_t)K * MS4 * 8 : 0);
     pre_stage.reset(need);
     if (need > pre_cap) {
         if (d_pre) (void)hipFree(d_pre);
@@ -1783,17 +1880,37 @@ void smcpp_im::ss_launch_initial() {
     a.ends_f = d_ends_f.p; a.used_f = d_used_f.p; a.ends_b = d_ends_b.p; a.used_b = d_used_b.p;
     a.changed_f = d_changed_f.p; a.changed_b = d_changed_b.p;
     a.eps_f = eps_f; a.eps_b = eps_b; a.full_f = a.full_b = 0;
+    a.fine = nullptr; a.nfine = 0; a.hand_f = a.hand_b = 0; a.fine_ends_f = nullptr; a.fine_ends_b = nullptr;
+    if (ss4) {
+        SsArgs &b4 = ss4_args;
+        b4 = a;                                  // fine chunks, fine end vectors, row state: as above
+        const double *g4 = reinterpret_cast<const double *>(put(ss_gen4.data(), ss_gen4.size() * 8));
+        b4.f_dc = g4; b4.f_g = g4 + MS4; b4.f_cg = g4 + 2 * MS4; b4.f_b = g4 + 3 * MS4; b4.f_a = g4 + 4 * MS4; b4.f_d = g4 + 5 * MS4;
+        b4.b_dc = g4 + 6 * MS4; b4.b_g = g4 + 7 * MS4; b4.b_b = g4 + 8 * MS4; b4.b_a = g4 + 9 * MS4;
+        {
+            const size_t eoff = (off + 255) & ~(size_t)255;
+            double *he = reinterpret_cast<double *>(pre_stage.base + eoff);
+            std::memset(he, 0, (size_t)K * MS4 * 8);
+            for (int k = 0; k < K; ++k)
+                std::memcpy(he + (size_t)ss_slot_of_key[k] * MS4, &E[(size_t)k * M], sizeof(double) * M);
+            b4.E = reinterpret_cast<const double *>(put(nullptr, (size_t)K * MS4 * 8));
+        }
+        // the light passes of the one-chain-per-wavefront kernels: coarse chunks, their own end vectors
+        a.chunks = d_chunks1.p; a.nchunks = (int)chunks1.size();
+        a.ends_f = d_ends1_f.p; a.ends_b = d_ends1_b.p; a.used_f = nullptr; a.used_b = nullptr;
+        a.fine = d_chunks.p; a.nfine = (int)chunks.size(); a.fine_ends_f = d_ends_f.p; a.fine_ends_b = d_ends_b.p;
+    }
     {
         // light passes: enough of them that the full pass starts ~11 e-folds of history in (the chains forget with an e-fold of
         // ~240 positions forward, ~340 backward on the benchmark model); none when the chunks are long against that
         long long pos = 0;
         const int ef = getenv("SMCPP_SS_LIGHT_F") ? atoi(getenv("SMCPP_SS_LIGHT_F")) : -1;
         const int eb = getenv("SMCPP_SS_LIGHT_B") ? atoi(getenv("SMCPP_SS_LIGHT_B")) : -1;
-        pos = ss_positions / std::max<size_t>(1, chunks.size());
+        pos = ss_positions / std::max<size_t>(1, ss4 ? chunks1.size() : chunks.size());
         auto pick = [&](double hist) { return pos <= 0 || (double)pos > 1.5 * hist ? 0 : std::min(4, (int)std::ceil(hist / (double)pos)); };
         ss_light_f = ef >= 0 ? ef : pick(2800.0);
         ss_light_b = eb >= 0 ? eb : pick(3900.0);
-        if (chunks.size() <= (size_t)n_contigs) ss_light_f = ss_light_b = 0;      // one chunk per contig: nothing to iterate
+        if ((ss4 ? chunks1.size() : chunks.size()) <= (size_t)n_contigs) ss_light_f = ss_light_b = 0;   // one chunk per contig: nothing to iterate
     }
     a.dbg = nullptr;
     if (getenv("SMCPP_DEBUG_CYCLES")) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }
@@ -1898,6 +2015,7 @@ void smcpp_im::enqueue_stats() {
         sa.M = M; sa.Mp = Mp; sa.nslabs = (int)slabs_sc.size(); sa.slabs = d_slabs_sc.p; sa.perm = d_perm1.p;
         sa.alpha = d_alpha.p; sa.beta = d_beta.p; sa.cnorm = d_cnorm.p; sa.w1 = d_w1.p; sa.gpart = d_gpart.p;
         sa.gamma_rows = save_gamma ? d_gamma_rows.p : nullptr;
+        sa.only_w1 = 0;
         launch_s1(NPL, sa, s);
         if (split_streams) HIPCHK(hipEventRecord(ev[14], s));
     }
@@ -1918,7 +2036,32 @@ void smcpp_im::enqueue_stats() {
                        (const double *)d_part_1.p, (const int *)d_s1_slab_off.p, d_red_1.p, MMi, ZS);
     HIPCHK(hipEventRecord(ev[4], s));
     // ---- eigen branch (second stream when available) ----
-    if (!slabs_eg.empty()) {
+    fa.eigfree = eigfree ? 1 : 0;
+    if (!slabs_eg.empty() && eigfree) {
+        // weights of the span > 1 rows (as those of the span-1 rows), rank accumulation per (span, key) group, deterministic
+        // reduction of the slab partials, then the span fold per (contig, key)
+        S1Args se_a;
+        se_a.M = M; se_a.Mp = Mp; se_a.nslabs = (int)slabs_eg.size(); se_a.slabs = d_slabs_eg.p; se_a.perm = d_perme.p;
+        se_a.alpha = d_alpha.p; se_a.beta = d_beta.p; se_a.cnorm = d_cnorm.p; se_a.w1 = d_w1.p; se_a.gpart = d_gpart.p;
+        se_a.gamma_rows = nullptr; se_a.only_w1 = 1;
+        launch_s1(NPL, se_a, se);
+        AccArgs ae = aa;
+        ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
+        hipLaunchKernelGGL(k_rank_acc<2>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
+        if (!eb_gid.empty())
+            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), (unsigned)eb_gid.size(), ZS), dim3(256), 0, se,
+                               (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MMi, ZS);
+        if (ZS != 8) throw std::runtime_error("internal: k_span_F expects 8 shares per bucket");
+        d_Fall.alloc((size_t)n_contigs * Ke * ss_max_span * Mp * Mp);
+        switch (NT) {
+#define S_(x) case x: hipLaunchKernelGGL(k_span_F<x>, dim3(n_contigs * Ke, x), dim3(64), 0, se, fa, ss_max_span, d_Fall.p); \
+                    hipLaunchKernelGGL(k_span_H<x>, dim3(n_contigs * Ke, x), dim3(64), 0, se, fa, ss_max_span, (const double *)d_Fall.p); break;
+            S_(1) S_(2) S_(3)
+            default: S_(4)
+#undef S_
+        }
+    }
+    if (!slabs_eg.empty() && !eigfree) {
         UWArgs ua;
         ua.M = M; ua.Mp = Mp; ua.nslabs = (int)slabs_eg.size(); ua.slabs = d_slabs_eg.p; ua.perm = d_perme.p;
         ua.alpha = d_alpha.p; ua.beta = d_beta.p; ua.g_eig = d_g_eig.p; ua.g_scale = d_g_scale.p;
@@ -1943,7 +2086,7 @@ void smcpp_im::enqueue_stats() {
             hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), (unsigned)eb_gid.size(), ZS), dim3(256), 0, se,
                                (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MMi, ZS);
     }
-    if (Ke > 0) {
+    if (Ke > 0 && !eigfree) {
         // slices of the groups of one (contig, key): enough blocks to fill the chip when there are many groups
         int max_b = 0;
         for (size_t ce = 0; ce + 1 < ce_bucket_off.size(); ++ce) max_b = std::max(max_b, ce_bucket_off[ce + 1] - ce_bucket_off[ce]);
@@ -2018,6 +2161,11 @@ void smcpp_im::estep() {
         throw std::runtime_error("parameters are not set");
     HIPCHK(hipEventRecord(ev[0], stream));
     ss_active = ss_static && ss_extract_generators();
+    {
+        // span > 1 rows without an eigensystem (kernels.hpp: k_span_fold): the span is expanded by smax steps of two M x M products
+        static const bool off = getenv("SMCPP_EIGFREE") && atoi(getenv("SMCPP_EIGFREE")) == 0;
+        eigfree = ss_active && !off && Mp <= 64 && ss_max_span <= 64 && !save_gamma;
+    }
     if (ss_active) { prepass_launched = false; static_packed = false; ss_launch_initial(); }   // the chains need no eigensystem: they start now
     else stage_static_and_prepass();   // (when eligible) pass 0 of both chains starts now, on eigen-free operands
     host_prep_and_upload();   // the reference rebuilds the eigensystems on every E-step (inference_manager.cpp:112)
@@ -2591,12 +2739,7 @@ int smcpp_set_chunking(smcpp_im *im, int rows_per_chunk, double eps_alpha, doubl
         im->user_rows_per_chunk = rows_per_chunk;
         im->warm_valid = false;
         im->make_chunks();
-        const size_t nch = im->chunks.size();
-        im->d_chunks.upload(im->chunks, im->stream);
-        im->d_ends_f.alloc(2 * nch * im->Mp); im->d_used_f.alloc(nch * im->Mp);
-        im->d_ends_b.alloc(2 * nch * im->Mp); im->d_used_b.alloc(nch * im->Mp);
-        im->d_changed_f.alloc(im->max_pass + 1); im->d_changed_b.alloc(im->max_pass + 1);
-        HIPCHK(hipStreamSynchronize(im->stream));
+        im->upload_chunk_state();
         im->setup_power();
         im->last_fwd_passes = im->last_bwd_passes = 0;
     }
@@ -2627,7 +2770,7 @@ int smcpp_debug_ss_apply(int M, const double *T, int nvec, const double *x, cons
     if (NPL > 4) throw std::runtime_error("unsupported number of hidden states");
     std::vector<double> gen;
     double c0 = 0.0;
-    if (!ss_generators(M, NPL, T, gen, c0)) return 2;
+    if (!ss_generators(M, MS, T, gen, c0)) return 2;
     std::vector<double> hx((size_t)nvec * MS, 0.0), he((size_t)nvec * MS, 0.0);
     for (int v = 0; v < nvec; ++v) {
         std::memcpy(&hx[(size_t)v * MS], x + (size_t)v * M, sizeof(double) * M);
@@ -2648,6 +2791,47 @@ int smcpp_debug_ss_apply(int M, const double *T, int nvec, const double *x, cons
         case 2: hipLaunchKernelGGL(k_ss_apply<2>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
         case 3: hipLaunchKernelGGL(k_ss_apply<3>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
         default: hipLaunchKernelGGL(k_ss_apply<4>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<double> hf(hx.size()), hb(hx.size());
+    HIPCHK(hipMemcpy(hf.data(), df.p, hf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hb.data(), db.p, hb.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int v = 0; v < nvec; ++v) {
+        std::memcpy(out_f + (size_t)v * M, &hf[(size_t)v * MS], sizeof(double) * M);
+        std::memcpy(out_b + (size_t)v * M, &hb[(size_t)v * MS], sizeof(double) * M);
+    }
+    API_END
+}
+
+// ... and of the four-chains-per-wavefront layout (M <= 64): same contract.
+int smcpp_debug_ss4_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b) {
+    API_BEGIN
+    if (M > 64) throw std::runtime_error("four chains per wavefront: M <= 64");
+    const int SPL = (M + 15) / 16, MS = 16 * SPL;
+    std::vector<double> gen;
+    double c0 = 0.0;
+    if (!ss_generators(M, MS, T, gen, c0)) return 2;
+    std::vector<double> hx((size_t)nvec * MS, 0.0), he((size_t)nvec * MS, 0.0);
+    for (int v = 0; v < nvec; ++v) {
+        std::memcpy(&hx[(size_t)v * MS], x + (size_t)v * M, sizeof(double) * M);
+        std::memcpy(&he[(size_t)v * MS], e + (size_t)v * M, sizeof(double) * M);
+    }
+    DevBuf<double> dg, dx, de, df, db;
+    hipStream_t s = nullptr;
+    dg.upload(gen, s); dx.upload(hx, s); de.upload(he, s);
+    df.alloc(hx.size()); db.alloc(hx.size());
+    SsArgs a = SsArgs();
+    a.M = M;
+    const double *gd = dg.p;
+    a.f_dc = gd; a.f_g = gd + MS; a.f_cg = gd + 2 * MS; a.f_b = gd + 3 * MS; a.f_a = gd + 4 * MS; a.f_d = gd + 5 * MS;
+    a.b_dc = gd + 6 * MS; a.b_g = gd + 7 * MS; a.b_b = gd + 8 * MS; a.b_a = gd + 9 * MS;
+    a.c0 = c0;
+    const int nb = (nvec + 3) / 4;
+    switch (SPL) {
+        case 1: hipLaunchKernelGGL(k_ss4_apply<1>, dim3(nb), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
+        case 2: hipLaunchKernelGGL(k_ss4_apply<2>, dim3(nb), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
+        case 3: hipLaunchKernelGGL(k_ss4_apply<3>, dim3(nb), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
+        default: hipLaunchKernelGGL(k_ss4_apply<4>, dim3(nb), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
     }
     HIPCHK(hipGetLastError());
     std::vector<double> hf(hx.size()), hb(hx.size());

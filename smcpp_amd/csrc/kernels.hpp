@@ -1850,6 +1850,7 @@ struct S1Args {
     double *w1;               // [rows] per-row weight
     double *gpart;            // [nslabs][Mp] partial gamma sums
     double *gamma_rows;       // optional [rows][Mp] (save_gamma)
+    int only_w1;              // 1: weights only (the eigen-free statistics of span > 1 rows take their gamma from the span fold)
 };
 
 template <int NPL>
@@ -1910,6 +1911,7 @@ __global__ __launch_bounds__(256) void k_s1_scalars(S1Args a) {
             if (lane == 0) a.w1[row[u]] = ip / lc[u];
         }
     }
+    if (a.only_w1) return;
 #pragma unroll
     for (int q = 0; q < NPL; ++q) comb[wave][lane + 64 * q] = gs[q];
     __syncthreads();
@@ -2129,6 +2131,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 // K4: rank-k accumulation  C_slab[j][k] = sum_rows X_row[j] * Y_row[k]   (fp64 MFMA, 64x64 output block per wave)
 //   MODE 0 (span-1 rows, hmm.cpp:137-138):  X = w1 * alpha_{ell-1},  Y = beta_ell o e_key
 //   MODE 1 (eigen rows):                    X = Xs[pos] (= omega U), Y = Ys[pos] (= W)
+//   MODE 2 (span > 1 rows, eigen-free):     X = w1 * alpha_{ell-1},  Y = beta_ell   (k_span_fold expands the span afterwards)
 // grid = (nslabs, NB*NB) with NB = ceil(Mp/64); blockIdx.y selects the 64x64 block of the M x M output.
 // ---------------------------------------------------------------------------------------------------------------
 struct AccArgs {
@@ -2157,7 +2160,7 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 2) {
         // Software pipeline over groups of 4 rows (the MFMA k dimension): the {ell, key} pair is fetched two groups
         // ahead and the operands one group ahead, so the dependent chain  index -> row -> operands  (three memory
         // round trips, measured 4.8 us per group against 0.43 us of MFMA) no longer serialises every group.
@@ -2167,7 +2170,9 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
         const int last = sl.end - 1;
         auto fetch_pk = [&](int r0) {
             const int r = r0 + qd;
-            int2 pk = a.permk[min(r, last)];
+            int2 pk;
+            if (MODE == 0) pk = a.permk[min(r, last)];
+            else { pk.x = a.perm[min(r, last)]; pk.y = 0; }
             pk.x = (r <= last) ? pk.x : -1;
             return pk;
         };
@@ -2189,7 +2194,7 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
             const double *bp = a.beta + row * Mp;
             const double *ep = a.E + (size_t)pk.y * Mp;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { o.ap[t] = ap[jc[t]]; o.bp[t] = bp[kc[t]]; o.ep[t] = ep[kc[t]]; }
+            for (int t = 0; t < 4; ++t) { o.ap[t] = ap[jc[t]]; o.bp[t] = bp[kc[t]]; o.ep[t] = MODE == 0 ? ep[kc[t]] : 1.0; }
             return o;
         };
         int2 pk1 = fetch_pk(sl.start);
@@ -2314,6 +2319,7 @@ struct FinArgs {
     double *xisum;            // [n_contigs][Mp][Mp]
     double *gsum;             // [n_contigs][K][Mp]
     double *gamma0;           // [n_contigs][Mp]
+    int eigfree;              // 1: Y holds W of k_span_fold, the first Mp entries of Z its diag(A W) (no eigensystem anywhere)
 };
 
 // span_Qs entry (transition_bundle.cpp:29-59) evaluated on the fly
@@ -2388,6 +2394,154 @@ __global__ __launch_bounds__(256) void k_fin_Y(FinArgs a) {
     a.Y[(size_t)ce * Mp * Mp + idx] = (s0 + s1) + (s2 + s3);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Eigen-free statistics of the span > 1 rows (binned data: spans of a few dozen positions at most).
+// A row of span s applies A = diag(e) T^T s times; the reference evaluates the sum over the s positions of the row through
+// the eigensystem of A and the span-Q matrix (hmm.cpp:113-122, transition_bundle.cpp:29-59: Q(a,b) = sum_t d_a^t d_b^(s-1-t)).
+// Written without the eigensystem the same quantity is
+//     xis_row = [ sum_{t=0}^{s-1} A^t (alpha_{ell-1} beta_ell^T) A^(s-1-t) ] diag(e),   v_row = diag( A [ ... ] ),
+// both linear in the rank-one matrix, so with Acc_s = sum over the rows of span s of omega alpha beta^T (k_rank_acc<2>)
+//     W = sum_s sum_{t<s} A^t Acc_s A^(s-1-t)  =  H_0,    F_t = Acc_{t+1} + F_{t+1} A,   H_t = F_t + A H_{t+1}
+// (two M x M products per step, smax steps) and  xisum += W diag(e),  gamma_sums[key] += diag(A W).
+// Rows of F do not mix and columns of H do not mix, so both recurrences split into independent 16-wide strips, one wavefront
+// each, and written as LEFT products (F^T_t = Acc^T + A^T F^T_{t+1}) the D fragments of one v_mfma_f64_16x16x4 step are the B
+// fragments of the next (row 4 kk + qd of the operand sits on lane group qd, register kk % 4): no LDS, no barrier.
+// k_span_F writes F_t (all t) to scratch, k_span_H consumes it.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(64) void k_span_F(FinArgs a, int smax, double *__restrict__ Fall) {
+    constexpr int MT = 16 * NT, ZSC = 8;
+    const int ce = blockIdx.x, e = ce % a.Ke, sp = blockIdx.y;       // strip: rows 16 sp .. of F
+    const int b0 = a.ce_bucket_off[ce], b1 = a.ce_bucket_off[ce + 1];
+    if (b0 == b1) return;
+    const int lane = threadIdx.x, m = lane & 15, qd = lane >> 4;
+    const int Mp = a.Mp, M = a.M;
+    const double *ek = a.E + (size_t)a.e_kid[e] * Mp;
+    // A operand of A^T, output row tile tt:  A^T[16 tt + m][4 kk + qd] = A[4 kk + qd][16 tt + m] = e_k T[16 tt + m][k]
+    double at[NT][MT / 4];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int kk = 0; kk < MT / 4; ++kk) {
+            const int k = 4 * kk + qd, i = 16 * tt + m;
+            at[tt][kk] = (k < M && i < M) ? ek[k] * a.Td[(size_t)i * Mp + k] : 0.0;
+        }
+    f64x4 X[NT];                                                      // F^T strip: rows 16 tt + qd + 4 r (columns of F), column 16 sp + m (row of F)
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) X[tt] = (f64x4){0, 0, 0, 0};
+    int bcur = b1 - 1;                                                // buckets of a (contig, key) are sorted by span
+    double *Fce = Fall + (size_t)ce * smax * Mp * Mp;
+    for (int t = smax - 1; t >= 0; --t) {
+        const bool has = bcur >= b0 && a.g_span[a.eb_gid[bcur]] == t + 1;
+        double av[NT][4][ZSC];
+        if (has) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t idx = (size_t)(16 * sp + m) * Mp + 16 * tt + qd + 4 * r;      // Acc[row of F][column of F]
+#pragma unroll
+                    for (int zz = 0; zz < ZSC; ++zz) av[tt][r][zz] = a.red_e[((size_t)bcur * ZSC + zz) * Mp * Mp + idx];
+                }
+        }
+        f64x4 Xn[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) Xn[tt] = (f64x4){0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < MT / 4; ++kk) {
+            const double bv = X[kk / 4][kk % 4];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) Xn[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[tt][kk], bv, Xn[tt], 0, 0, 0);
+        }
+        if (has) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int zz = 0; zz < ZSC; ++zz) acc += av[tt][r][zz];
+                    Xn[tt][r] += acc;
+                }
+            --bcur;
+        }
+        double *Ft = Fce + (size_t)t * Mp * Mp;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            X[tt] = Xn[tt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = 16 * tt + qd + 4 * r, row = 16 * sp + m;
+                if (row < Mp && col < Mp) Ft[(size_t)row * Mp + col] = Xn[tt][r];
+            }
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(64) void k_span_H(FinArgs a, int smax, const double *__restrict__ Fall) {
+    constexpr int MT = 16 * NT;
+    const int ce = blockIdx.x, e = ce % a.Ke, sp = blockIdx.y;       // strip: columns 16 sp .. of H
+    const int b0 = a.ce_bucket_off[ce], b1 = a.ce_bucket_off[ce + 1];
+    if (b0 == b1) return;
+    const int lane = threadIdx.x, m = lane & 15, qd = lane >> 4;
+    const int Mp = a.Mp, M = a.M;
+    const double *ek = a.E + (size_t)a.e_kid[e] * Mp;
+    // A operand of A, output row tile tt:  A[16 tt + m][4 kk + qd] = e_i T[k][i]
+    double af[NT][MT / 4];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int kk = 0; kk < MT / 4; ++kk) {
+            const int k = 4 * kk + qd, i = 16 * tt + m;
+            af[tt][kk] = (k < M && i < M) ? ek[i] * a.Td[(size_t)k * Mp + i] : 0.0;
+        }
+    f64x4 H[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) H[tt] = (f64x4){0, 0, 0, 0};
+    const double *Fce = Fall + (size_t)ce * smax * Mp * Mp;
+    for (int t = smax - 1; t >= 0; --t) {
+        const double *Ft = Fce + (size_t)t * Mp * Mp;
+        f64x4 Hn[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * tt + qd + 4 * r, col = 16 * sp + m;
+                Hn[tt][r] = (row < Mp && col < Mp) ? Ft[(size_t)row * Mp + col] : 0.0;
+            }
+#pragma unroll
+        for (int kk = 0; kk < MT / 4; ++kk) {
+            const double bv = H[kk / 4][kk % 4];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) Hn[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[tt][kk], bv, Hn[tt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) H[tt] = Hn[tt];
+    }
+    // W = H_0 (row-major [Mp][Mp], in the eigen path's Y buffer) and diag(A W) (first Mp entries of its Z buffer)
+    double *Wout = a.Y + (size_t)ce * Mp * Mp;
+    double *gout = a.Z + (size_t)ce * Mp * Mp;
+    f64x4 G = {0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < MT / 4; ++kk) {
+        double afd = 0.0;                                             // row tile sp of A
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) afd = (tt == sp) ? af[tt][kk] : afd;
+        G = __builtin_amdgcn_mfma_f64_16x16x4f64(afd, H[kk / 4][kk % 4], G, 0, 0, 0);
+    }
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * tt + qd + 4 * r, col = 16 * sp + m;
+            if (row < Mp && col < Mp) Wout[(size_t)row * Mp + col] = H[tt][r];
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (qd + 4 * r == m && 16 * sp + m < Mp) gout[16 * sp + m] = G[r];
+}
+
 // xisum[contig] = max( (X1 + sum_e P_e Y_e diag(b_e)) o Td , 1e-20 )   (hmm.cpp:122,141,151-152)
 __global__ __launch_bounds__(256) void k_fin_xisum(FinArgs a) {
     const int ct = blockIdx.y;
@@ -2403,6 +2557,7 @@ __global__ __launch_bounds__(256) void k_fin_xisum(FinArgs a) {
             if (a.ce_bucket_off[ce] == a.ce_bucket_off[ce + 1]) continue;
             const double *P = a.Prm + (size_t)e * Mp * Mp + (size_t)i * Mp;
             const double *Y = a.Y + (size_t)ce * Mp * Mp;
+            if (a.eigfree) { x += Y[(size_t)i * Mp + k] * a.E[(size_t)a.e_kid[e] * Mp + k]; continue; }
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             int j = 0;
 #pragma unroll 2
@@ -2441,6 +2596,7 @@ __global__ __launch_bounds__(256) void k_fin_gamma(FinArgs a) {
             if (a.e_kid[e] != k) continue;
             const int ce = ct * a.Ke + e;
             if (a.ce_bucket_off[ce] == a.ce_bucket_off[ce + 1]) continue;
+            if (a.eigfree) { g += a.Z[(size_t)ce * Mp * Mp + i]; continue; }
             const double *P = a.Prm + (size_t)e * Mp * Mp + (size_t)i * Mp;
             const double *Y = a.Y + (size_t)ce * Mp * Mp;
             const double *d = a.dun + (size_t)e * Mp;

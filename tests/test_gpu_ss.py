@@ -17,7 +17,7 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-def ss_apply(T, x, e):
+def ss_apply(T, x, e, four=False):
     from smcpp_amd import _engine
     L = _engine.lib()
     T = np.ascontiguousarray(T, dtype=np.float64)
@@ -25,8 +25,8 @@ def ss_apply(T, x, e):
     e = np.ascontiguousarray(e, dtype=np.float64)
     of = np.empty_like(x)
     ob = np.empty_like(x)
-    rc = L.smcpp_debug_ss_apply(T.shape[0], _engine.dptr(T), x.shape[0], _engine.dptr(x), _engine.dptr(e),
-                                _engine.dptr(of), _engine.dptr(ob))
+    fn = L.smcpp_debug_ss4_apply if four else L.smcpp_debug_ss_apply
+    rc = fn(T.shape[0], _engine.dptr(T), x.shape[0], _engine.dptr(x), _engine.dptr(e), _engine.dptr(of), _engine.dptr(ob))
     if rc == 1:
         raise RuntimeError(L.smcpp_last_error().decode())
     return rc, of, ob
@@ -57,11 +57,12 @@ def test_one_position_matches_dense_products(name):
     x[1] = 0.0; x[1, M - 1] = 1.0
     x[2] = 0.0; x[2, 0] = 1.0
     e = 0.2 + 0.8 * rng.random((nvec, M))
-    rc, of, ob = ss_apply(T, x, e)
-    assert rc == 0
     ref_f = e * (x @ T)               # e o (T^T x)
     ref_b = (e * x) @ T.T             # T (e o x)
-    check_products(of, ob, ref_f, ref_b)
+    for four in ([False, True] if M <= 64 else [False]):      # one chain / four chains per wavefront
+        rc, of, ob = ss_apply(T, x, e, four)
+        assert rc == 0
+        check_products(of, ob, ref_f, ref_b)
 
 
 @pytest.mark.parametrize("M", [70, 100, 130, 200])

@@ -222,7 +222,6 @@ struct smcpp_im {
     int ss_light_f = 0, ss_light_b = 0;    // light (float, store-free) passes per direction before the full fp64 pass
     std::vector<int> ss_slot_of_key;       // frequency rank of every key (slot 0 = most rows)
     DevBuf<int2> d_rowdesc_ss;             // [rows, padded] {key slot, span}
-    DevBuf<double> d_Fall;                 // [n_contigs Ke][smax][Mp][Mp] scratch of the span fold (k_span_F -> k_span_H)
     SsArgs ss_args;
     // four chains per wavefront (chains_ss4.hpp, M <= 64): the fp64 passes run on `chunks` (fine), the light passes on groups of
     // four of them (`chunks1`, coarse) and hand over the fine boundary vectors
@@ -665,9 +664,11 @@ void smcpp_im::make_slabs() {
     // slabs = independent single-wavefront work items; several thousand keep the 2048 resident wavefronts of the
     // chip balanced on large inputs (each slab owns an Mp x Mp partial: at most 256 MB of them)
     const long long target = std::max<long long>(256, std::min<long long>(8192, (256ll << 20) / part_bytes));
-    int S_RK = (int)std::max<long long>(64, (n1 + target - 1) / target);
+    // (at least 192 rows per slab: every slab costs an Mp x Mp partial written and read back, 128 MB of traffic per headline
+    // E-step with 64-row slabs)
+    int S_RK = (int)std::max<long long>(192, (n1 + target - 1) / target);
     S_RK = (S_RK + 3) / 4 * 4;
-    int S_EG = (int)std::max<long long>(64, (ne + target - 1) / target);
+    int S_EG = (int)std::max<long long>(192, (ne + target - 1) / target);
     S_EG = (S_EG + 15) / 16 * 16;
     const int S_SC = 256;
     for (int c = 0; c < n_contigs; ++c) {
@@ -1997,8 +1998,9 @@ void smcpp_im::enqueue_stats() {
     }
     // nothing in the statistics reads log_c any more (the span-1 weights take c itself): the two log-likelihood kernels
     // ride on the eigen stream instead of heading the critical path of the main one
-    hipLaunchKernelGGL(k_loglik_partial, dim3(llblk, n_contigs), dim3(256), 0, se, la);
-    hipLaunchKernelGGL(k_loglik_final, dim3(n_contigs), dim3(256), 0, se, la);
+    hipStream_t sl = eigfree ? s : se;          // (the eigen-free branch of the second stream is the longer one)
+    hipLaunchKernelGGL(k_loglik_partial, dim3(llblk, n_contigs), dim3(256), 0, sl, la);
+    hipLaunchKernelGGL(k_loglik_final, dim3(n_contigs), dim3(256), 0, sl, la);
     FinArgs fa;
     fa.M = M; fa.Mp = Mp; fa.K = K; fa.G = G; fa.Ke = Ke; fa.n_contigs = n_contigs;
     fa.eb_slab_off = d_eb_slab_off.p; fa.eb_gid = d_eb_gid.p; fa.ce_bucket_off = d_ce_bucket_off.p;
@@ -2021,7 +2023,7 @@ void smcpp_im::enqueue_stats() {
     }
     AccArgs aa;
     aa.M = M; aa.Mp = Mp; aa.NB = (Mp + 63) / 64; aa.rowinfo = d_rowinfo.p; aa.alpha = d_alpha.p; aa.beta = d_beta.p;
-    aa.w1 = d_w1.p; aa.E = d_E.p; aa.Xs = d_Xs.p; aa.Ys = d_Ys.p;
+    aa.w1 = d_w1.p; aa.cnorm = d_cnorm.p; aa.E = d_E.p; aa.Xs = d_Xs.p; aa.Ys = d_Ys.p;
     if (!slabs_rk.empty()) {
         aa.nslabs = (int)slabs_rk.size(); aa.slabs = d_slabs_rk.p; aa.perm = d_perm1.p; aa.permk = d_perm1k.p; aa.part = d_part_1.p;
         hipLaunchKernelGGL(k_rank_acc<0>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, s, aa);
@@ -2044,18 +2046,17 @@ void smcpp_im::enqueue_stats() {
         se_a.M = M; se_a.Mp = Mp; se_a.nslabs = (int)slabs_eg.size(); se_a.slabs = d_slabs_eg.p; se_a.perm = d_perme.p;
         se_a.alpha = d_alpha.p; se_a.beta = d_beta.p; se_a.cnorm = d_cnorm.p; se_a.w1 = d_w1.p; se_a.gpart = d_gpart.p;
         se_a.gamma_rows = nullptr; se_a.only_w1 = 1;
-        launch_s1(NPL, se_a, se);
+        if (aa.NB != 1) launch_s1(NPL, se_a, se);              // M <= 64: k_rank_acc<2> forms the weights itself
         AccArgs ae = aa;
         ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
         hipLaunchKernelGGL(k_rank_acc<2>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
-        if (!eb_gid.empty())
-            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), (unsigned)eb_gid.size(), ZS), dim3(256), 0, se,
-                               (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MMi, ZS);
-        if (ZS != 8) throw std::runtime_error("internal: k_span_F expects 8 shares per bucket");
-        d_Fall.alloc((size_t)n_contigs * Ke * ss_max_span * Mp * Mp);
+        if (!eb_gid.empty())                                     // ONE share per bucket: k_span_F reads it on its serial path
+            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), (unsigned)eb_gid.size(), 1), dim3(256), 0, se,
+                               (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MMi, 1);
+        const size_t shm = (size_t)2 * Mp * (Mp + 1) * sizeof(double);
         switch (NT) {
-#define S_(x) case x: hipLaunchKernelGGL(k_span_F<x>, dim3(n_contigs * Ke, x), dim3(64), 0, se, fa, ss_max_span, d_Fall.p); \
-                    hipLaunchKernelGGL(k_span_H<x>, dim3(n_contigs * Ke, x), dim3(64), 0, se, fa, ss_max_span, (const double *)d_Fall.p); break;
+#define S_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_span_FH<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
+                    hipLaunchKernelGGL(k_span_FH<x>, dim3(n_contigs * Ke), dim3(128 * x), shm, se, fa, ss_max_span); } break;
             S_(1) S_(2) S_(3)
             default: S_(4)
 #undef S_

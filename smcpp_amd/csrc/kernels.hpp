@@ -2143,6 +2143,7 @@ struct AccArgs {
     const float *alpha;
     const double *beta;
     const double *w1;
+    const double *cnorm;      // MODE 2, M <= 64: the weight is formed in the kernel
     const double *E;
     const double *Xs, *Ys;
     double *part;             // [nslabs][Mp][Mp]
@@ -2176,7 +2177,7 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
             pk.x = (r <= last) ? pk.x : -1;
             return pk;
         };
-        struct Ops { double w; float ap[4]; double bp[4], ep[4]; bool valid; };
+        struct Ops { double w; float ap[4], an[4]; double bp[4], ep[4]; bool valid; };
         int jc[4], kc[4];
         bool jv[4], kv[4];
 #pragma unroll
@@ -2189,12 +2190,18 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
             Ops o;
             o.valid = pk.x >= 0;
             const size_t row = (size_t)(sl.base + (o.valid ? pk.x : 1));
-            o.w = a.w1[row];
+            // MODE 2 with the whole state vector in this block (M <= 64): the weight 1 / (c_ell sum alpha_ell beta_ell) is formed here
+            // from the row's own alpha (one more 4 M bytes per row instead of a separate pass over alpha and beta)
+            const bool inl = MODE == 2 && a.NB == 1;
+            o.w = inl ? a.cnorm[row] : a.w1[row];
             const float *ap = a.alpha + (row - 1) * Mp;
             const double *bp = a.beta + row * Mp;
             const double *ep = a.E + (size_t)pk.y * Mp;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { o.ap[t] = ap[jc[t]]; o.bp[t] = bp[kc[t]]; o.ep[t] = MODE == 0 ? ep[kc[t]] : 1.0; }
+            for (int t = 0; t < 4; ++t) {
+                o.ap[t] = ap[jc[t]]; o.bp[t] = bp[kc[t]]; o.ep[t] = MODE == 0 ? ep[kc[t]] : 1.0;
+                o.an[t] = inl ? ap[Mp + kc[t]] : 0.f;
+            }
             return o;
         };
         int2 pk1 = fetch_pk(sl.start);
@@ -2204,9 +2211,16 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
             const int2 pk2 = fetch_pk(r0 + 8);
             const Ops nxt = fetch_ops(pk1);          // operands of group r0 + 4 (all-zero past the end of the slab)
             double xa[4], yb[4];
+            double wgt = cur.w;
+            if (MODE == 2 && a.NB == 1) {
+                double pp = 0.0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pp += kv[t] ? (double)cur.an[t] * cur.bp[t] : 0.0;
+                wgt = 1.0 / (cur.w * row16_sum(pp));
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                xa[t] = (cur.valid && jv[t]) ? cur.w * (double)cur.ap[t] : 0.0;
+                xa[t] = (cur.valid && jv[t]) ? wgt * (double)cur.ap[t] : 0.0;
                 yb[t] = kv[t] ? cur.bp[t] * cur.ep[t] : 0.0;
             }
 #pragma unroll
@@ -2406,119 +2420,89 @@ __global__ __launch_bounds__(256) void k_fin_Y(FinArgs a) {
 // Rows of F do not mix and columns of H do not mix, so both recurrences split into independent 16-wide strips, one wavefront
 // each, and written as LEFT products (F^T_t = Acc^T + A^T F^T_{t+1}) the D fragments of one v_mfma_f64_16x16x4 step are the B
 // fragments of the next (row 4 kk + qd of the operand sits on lane group qd, register kk % 4): no LDS, no barrier.
-// k_span_F writes F_t (all t) to scratch, k_span_H consumes it.
 // ---------------------------------------------------------------------------------------------------------------
+// One workgroup per (contig, key), 2 NT wavefronts: wavefronts 0 .. NT-1 run the F strips one step AHEAD of wavefronts
+// NT .. 2 NT - 1, which run the H strips; F_t goes from one group to the other through a double-buffered LDS copy, one barrier
+// per step.
 template <int NT>
-__global__ __launch_bounds__(64) void k_span_F(FinArgs a, int smax, double *__restrict__ Fall) {
-    constexpr int MT = 16 * NT, ZSC = 8;
-    const int ce = blockIdx.x, e = ce % a.Ke, sp = blockIdx.y;       // strip: rows 16 sp .. of F
+__global__ __launch_bounds__(128 * NT) void k_span_FH(FinArgs a, int smax) {
+    constexpr int MT = 16 * NT, LD = MT + 1;
+    extern __shared__ __attribute__((aligned(16))) double sfh_lds[];       // [2][MT][LD]: F_t, row-major
+    const int ce = blockIdx.x, e = ce % a.Ke;
     const int b0 = a.ce_bucket_off[ce], b1 = a.ce_bucket_off[ce + 1];
     if (b0 == b1) return;
-    const int lane = threadIdx.x, m = lane & 15, qd = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool isF = wv < NT;
+    const int sp = isF ? wv : wv - NT;
+    const int m = lane & 15, qd = lane >> 4;
     const int Mp = a.Mp, M = a.M;
     const double *ek = a.E + (size_t)a.e_kid[e] * Mp;
-    // A operand of A^T, output row tile tt:  A^T[16 tt + m][4 kk + qd] = A[4 kk + qd][16 tt + m] = e_k T[16 tt + m][k]
-    double at[NT][MT / 4];
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-        for (int kk = 0; kk < MT / 4; ++kk) {
-            const int k = 4 * kk + qd, i = 16 * tt + m;
-            at[tt][kk] = (k < M && i < M) ? ek[k] * a.Td[(size_t)i * Mp + k] : 0.0;
-        }
-    f64x4 X[NT];                                                      // F^T strip: rows 16 tt + qd + 4 r (columns of F), column 16 sp + m (row of F)
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) X[tt] = (f64x4){0, 0, 0, 0};
-    int bcur = b1 - 1;                                                // buckets of a (contig, key) are sorted by span
-    double *Fce = Fall + (size_t)ce * smax * Mp * Mp;
-    for (int t = smax - 1; t >= 0; --t) {
-        const bool has = bcur >= b0 && a.g_span[a.eb_gid[bcur]] == t + 1;
-        double av[NT][4][ZSC];
-        if (has) {
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const size_t idx = (size_t)(16 * sp + m) * Mp + 16 * tt + qd + 4 * r;      // Acc[row of F][column of F]
-#pragma unroll
-                    for (int zz = 0; zz < ZSC; ++zz) av[tt][r][zz] = a.red_e[((size_t)bcur * ZSC + zz) * Mp * Mp + idx];
-                }
-        }
-        f64x4 Xn[NT];
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) Xn[tt] = (f64x4){0, 0, 0, 0};
-#pragma unroll
-        for (int kk = 0; kk < MT / 4; ++kk) {
-            const double bv = X[kk / 4][kk % 4];
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) Xn[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[tt][kk], bv, Xn[tt], 0, 0, 0);
-        }
-        if (has) {
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int zz = 0; zz < ZSC; ++zz) acc += av[tt][r][zz];
-                    Xn[tt][r] += acc;
-                }
-            --bcur;
-        }
-        double *Ft = Fce + (size_t)t * Mp * Mp;
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            X[tt] = Xn[tt];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int col = 16 * tt + qd + 4 * r, row = 16 * sp + m;
-                if (row < Mp && col < Mp) Ft[(size_t)row * Mp + col] = Xn[tt][r];
-            }
-        }
-    }
-}
-
-template <int NT>
-__global__ __launch_bounds__(64) void k_span_H(FinArgs a, int smax, const double *__restrict__ Fall) {
-    constexpr int MT = 16 * NT;
-    const int ce = blockIdx.x, e = ce % a.Ke, sp = blockIdx.y;       // strip: columns 16 sp .. of H
-    const int b0 = a.ce_bucket_off[ce], b1 = a.ce_bucket_off[ce + 1];
-    if (b0 == b1) return;
-    const int lane = threadIdx.x, m = lane & 15, qd = lane >> 4;
-    const int Mp = a.Mp, M = a.M;
-    const double *ek = a.E + (size_t)a.e_kid[e] * Mp;
-    // A operand of A, output row tile tt:  A[16 tt + m][4 kk + qd] = e_i T[k][i]
+    // A operands (output row tile tt, k = 4 kk + qd):  F group: A^T[16 tt + m][k] = e_k T[16 tt + m][k];  H group: A[16 tt + m][k] = e_i T[k][i]
     double af[NT][MT / 4];
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
         for (int kk = 0; kk < MT / 4; ++kk) {
             const int k = 4 * kk + qd, i = 16 * tt + m;
-            af[tt][kk] = (k < M && i < M) ? ek[i] * a.Td[(size_t)k * Mp + i] : 0.0;
+            const double v = isF ? ek[min(k, Mp - 1)] * a.Td[(size_t)min(i, Mp - 1) * Mp + min(k, Mp - 1)]
+                                 : ek[min(i, Mp - 1)] * a.Td[(size_t)min(k, Mp - 1) * Mp + min(i, Mp - 1)];
+            af[tt][kk] = (k < M && i < M) ? v : 0.0;
         }
-    f64x4 H[NT];
+    f64x4 X[NT];         // F group: F^T strip (rows = columns of F, column 16 sp + m = row of F);  H group: H strip (column 16 sp + m)
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt) H[tt] = (f64x4){0, 0, 0, 0};
-    const double *Fce = Fall + (size_t)ce * smax * Mp * Mp;
-    for (int t = smax - 1; t >= 0; --t) {
-        const double *Ft = Fce + (size_t)t * Mp * Mp;
-        f64x4 Hn[NT];
+    for (int tt = 0; tt < NT; ++tt) X[tt] = (f64x4){0, 0, 0, 0};
+    int bcur = b1 - 1;   // buckets of a (contig, key) are sorted by span
+    // iteration it: the F group computes F_t for t = smax - 1 - it, the H group H_t for t = smax - it (from the F_t of the last iteration)
+    for (int it = 0; it <= smax; ++it) {
+        const int tF = smax - 1 - it, tH = smax - it;
+        double *sFw = sfh_lds + (size_t)(it & 1) * MT * LD;
+        const double *sFr = sfh_lds + (size_t)((it + 1) & 1) * MT * LD;
+        const bool work = isF ? tF >= 0 : tH < smax;
+        f64x4 Xn[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) Xn[tt] = (f64x4){0, 0, 0, 0};
+        double av[NT][4];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * tt + qd + 4 * r, col = 16 * sp + m;
-                Hn[tt][r] = (row < Mp && col < Mp) ? Ft[(size_t)row * Mp + col] : 0.0;
+            for (int r = 0; r < 4; ++r) av[tt][r] = 0.0;
+        if (work) {
+            if (isF) {
+                const bool has = bcur >= b0 && a.g_span[a.eb_gid[bcur]] == tF + 1;
+                if (has) {
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)             // Acc[row of F][column of F], ONE share per bucket
+                            av[tt][r] = a.red_e[(size_t)bcur * Mp * Mp + (size_t)min(16 * sp + m, Mp - 1) * Mp + min(16 * tt + qd + 4 * r, Mp - 1)];
+                    --bcur;
+                }
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) av[tt][r] = sFr[(16 * tt + qd + 4 * r) * LD + 16 * sp + m];     // F_t[row][column of the strip]
             }
 #pragma unroll
-        for (int kk = 0; kk < MT / 4; ++kk) {
-            const double bv = H[kk / 4][kk % 4];
+            for (int kk = 0; kk < MT / 4; ++kk) {
+                const double bv = X[kk / 4][kk % 4];
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt) Hn[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[tt][kk], bv, Hn[tt], 0, 0, 0);
+                for (int tt = 0; tt < NT; ++tt) Xn[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[tt][kk], bv, Xn[tt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[tt][r] = Xn[tt][r] + av[tt][r];
+            if (isF) {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sFw[(16 * sp + m) * LD + 16 * tt + qd + 4 * r] = X[tt][r];         // F_t[row 16 sp + m][column]
+            }
         }
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) H[tt] = Hn[tt];
+        __syncthreads();
     }
+    if (isF) return;
     // W = H_0 (row-major [Mp][Mp], in the eigen path's Y buffer) and diag(A W) (first Mp entries of its Z buffer)
     double *Wout = a.Y + (size_t)ce * Mp * Mp;
     double *gout = a.Z + (size_t)ce * Mp * Mp;
@@ -2528,14 +2512,14 @@ __global__ __launch_bounds__(64) void k_span_H(FinArgs a, int smax, const double
         double afd = 0.0;                                             // row tile sp of A
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) afd = (tt == sp) ? af[tt][kk] : afd;
-        G = __builtin_amdgcn_mfma_f64_16x16x4f64(afd, H[kk / 4][kk % 4], G, 0, 0, 0);
+        G = __builtin_amdgcn_mfma_f64_16x16x4f64(afd, X[kk / 4][kk % 4], G, 0, 0, 0);
     }
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * tt + qd + 4 * r, col = 16 * sp + m;
-            if (row < Mp && col < Mp) Wout[(size_t)row * Mp + col] = H[tt][r];
+            if (row < Mp && col < Mp) Wout[(size_t)row * Mp + col] = X[tt][r];
         }
 #pragma unroll
     for (int r = 0; r < 4; ++r)

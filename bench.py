@@ -298,43 +298,68 @@ def main():
     # credits ONE pass of algorithmic work: the re-run passes of the chunk-parallel fixed point are overhead, not work.
     flops, bytes_f, bytes_b, R1, Re = chain_pass_work(contigs, M)
     fwd_ms, bwd_ms = med["forward_ms"], med["backward_ms"]
-    dom_fwd = fwd_ms >= bwd_ms
-    k_ms = fwd_ms if dom_fwd else bwd_ms
-    k_bytes = bytes_f if dom_fwd else bytes_b
-    big = M > 64
-    lock = hasattr(im, "chain_mode") and im.chain_mode() == 4
-    fam = "_lock" if lock else "_big" if big else "_coop"
-    kname = ("k_fwd" if dom_fwd else "k_bwd") + fam
-    ach_tflops = flops / (1e-3 * k_ms) / 1e12 if k_ms > 0 else 0.0
-    ach_gbs = k_bytes / (1e-3 * k_ms) / 1e9 if k_ms > 0 else 0.0
-    roof = dict(bound="mfma", achieved=ach_tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach_tflops / FP64_PEAK_TFLOPS)
+    mode = im.chain_mode() if hasattr(im, "chain_mode") else -1
+    F_alg, B_alg = eval_work(contigs, M)
+    if mode == 5:
+        # Scan chains (chains_ss.hpp): ONE kernel runs both directions (forward and backward wavefronts share a workgroup), so
+        # the dominant kernel is k_chain_ss and `achieved` credits ONE pass of the algorithmic work of BOTH chains
+        # (2 M^2 R1 + 4 M^2 Re flops per chain) against the time of ALL its launches of one E-step (light
+        # passes, full pass, re-run passes).  The kernel executes O(M) per position, not those flops: it is bound by VALU
+        # issue (tools/dpp_lab.hip: 2.3 ns per instruction and wavefront, one wavefront per SIMD), the figure is the
+        # reference's algorithm priced on this kernel's clock.
+        kname = "k_chain_ss"
+        k_ms = med["chains_wall_ms"]
+        k_flops, k_bytes = 2.0 * flops, bytes_f + bytes_b
+        ach_tflops = k_flops / (1e-3 * k_ms) / 1e12 if k_ms > 0 else 0.0
+        ach_gbs = k_bytes / (1e-3 * k_ms) / 1e9 if k_ms > 0 else 0.0
+        roof = dict(bound="mfma", achieved=ach_tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach_tflops / FP64_PEAK_TFLOPS)
+        positions = float(sum(int(c[:, 0].sum()) for c in contigs))
+        other = {"bound_detail": "VALU issue: O(M) scans per position over the semiseparable structure of T, no matrix product "
+                                 "executes (achieved = algorithmic flops of the reference's dense formulation / kernel time)",
+                 "positions": positions, "positions_per_us": positions / (1e3 * k_ms) if k_ms > 0 else 0.0,
+                 "per_chain_tflops": ach_tflops / 2.0}
+        note = "both chains in one kernel; frac = one pass of algorithmic flops of both chains / kernel time per step / fp64 peak"
+    else:
+        # The chain kernels (k_fwd_coop / k_bwd_coop, k_*_big for M > 64) dominate.  smcpp_last_timing brackets ALL pass
+        # launches of each chain of one E-step with hipEvents on the stream they are launched on, so `kernel_ms_per_step`
+        # is the kernel's time per step summed over its passes (= rocprofv3's total for the kernel / steps).  `achieved`
+        # credits ONE pass of algorithmic work: the re-run passes of the chunk-parallel fixed point are overhead, not work.
+        dom_fwd = fwd_ms >= bwd_ms
+        k_ms = fwd_ms if dom_fwd else bwd_ms
+        k_flops, k_bytes = flops, (bytes_f if dom_fwd else bytes_b)
+        fam = "_lock" if mode == 4 else "_big" if M > 64 else "_coop"
+        kname = ("k_fwd" if dom_fwd else "k_bwd") + fam
+        ach_tflops = flops / (1e-3 * k_ms) / 1e12 if k_ms > 0 else 0.0
+        ach_gbs = k_bytes / (1e-3 * k_ms) / 1e9 if k_ms > 0 else 0.0
+        roof = dict(bound="mfma", achieved=ach_tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach_tflops / FP64_PEAK_TFLOPS)
+        other = {"bound_detail": "latency of the dependent mat-vecs (VALU / L2 streaming; lock-step family: fp64 MFMA)",
+                 "other_chain": {"kernel": ("k_bwd" if dom_fwd else "k_fwd") + fam,
+                                 "kernel_ms_per_step": bwd_ms if dom_fwd else fwd_ms,
+                                 "tflops": flops / (1e-3 * (bwd_ms if dom_fwd else fwd_ms)) / 1e12 if min(fwd_ms, bwd_ms) > 0 else 0.0}}
+        note = "latency-bound sequential chains: frac = one pass of algorithmic flops / kernel time per step / fp64 peak"
     # HBM bytes per step from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes); only for the profiled workload
     traffic = None
     try:
         if args.workload == "headline" and args.length_mbp == 100.0 and world == 1:
             import glob
-            pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_hbm_traffic_pmc.json")))[-1]
+            pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[0-9]*_hbm_traffic_pmc.json")))[-1]
             prof = json.load(open(pf))
-            # pass 0 and the re-run passes are separate instantiations of the kernel: per-step bytes of all of them
-            traffic = float(sum(v["bytes_per_step"] for name, v in prof["kernels"].items() if kname in name))
+            # every launch of the kernel (pass 0 / light / full / re-run): per-step bytes of all of them
+            tr = [v["bytes_per_step"] for name, v in prof["kernels"].items() if kname in name]
+            traffic = float(sum(tr)) if tr else None
     except Exception:  # noqa: BLE001
         traffic = None
-    F_alg, B_alg = eval_work(contigs, M)
     roof.update(
-        traffic=traffic, kernel=f"{kname} (all passes of one E-step; the other chain runs concurrently on a second stream)",
-        kernel_ms_per_step=k_ms, passes=med["fwd_passes"] if dom_fwd else med["bwd_passes"],
-        algorithmic_flops_one_pass=flops, algorithmic_bytes_one_pass=k_bytes,
-        hbm_gbs=ach_gbs, hbm_frac=ach_gbs / HBM_PEAK_GBS,
-        other_chain={"kernel": ("k_bwd" if dom_fwd else "k_fwd") + fam,
-                     "kernel_ms_per_step": bwd_ms if dom_fwd else fwd_ms,
-                     "tflops": flops / (1e-3 * (bwd_ms if dom_fwd else fwd_ms)) / 1e12 if min(fwd_ms, bwd_ms) > 0 else 0.0},
-        # whole eval on SURVEY.md §8(d)'s F_alg / B_alg (the restructured statistics do not execute the 2 M^3 Re term,
-        # DESIGN.md §3, so this is a figure of merit against the reference's algorithm, not achieved MFMA work)
-        eval={"F_alg": F_alg, "B_alg": B_alg, "tflops_on_F_alg": F_alg / (1e-3 * ms_per_step) / 1e12,
-              "frac_on_F_alg": F_alg / (1e-3 * ms_per_step) / 1e12 / FP64_PEAK_TFLOPS,
+        traffic=traffic, kernel=f"{kname} (all launches of one E-step)",
+        kernel_ms_per_step=k_ms, passes=med["fwd_passes"],
+        algorithmic_flops_one_pass=k_flops, algorithmic_bytes_one_pass=k_bytes,
+        hbm_gbs=ach_gbs, hbm_frac=ach_gbs / HBM_PEAK_GBS, **other,
+        # whole eval on SURVEY.md §8(d)'s F_alg / B_alg: a figure of merit against the REFERENCE's algorithm (its 2 M^3 Re term is
+        # not executed by the restructured statistics), not a fraction of anything this engine executes
+        eval={"F_alg": F_alg, "B_alg": B_alg, "reference_algorithm_tflops_equivalent": F_alg / (1e-3 * ms_per_step) / 1e12,
               "gbs_on_B_alg": B_alg / (1e-3 * ms_per_step) / 1e9},
-        note="latency-bound sequential chains: frac = one pass of algorithmic flops / kernel time per step / fp64 peak")
+        note=note)
 
     if args.workload == "posterior":
         # the product of this workload is the M x (L+1) posterior matrix: 8 M L bytes written by the statistics phase

@@ -123,6 +123,10 @@ int smcpp_pack_stats(smcpp_im *im, double *buf, long *n_out, int dev);
 /* Hand the all-reduced buffer back; Q() then evaluates on the global statistics. */
 int smcpp_unpack_stats(smcpp_im *im, const double *buf, long n, int dev);
 
+/* InferenceManager::debug (_smcpp.pxd:53): a public flag the reference declares to Cython; nothing in its C++ reads it. */
+int smcpp_set_debug(smcpp_im *im, int on);
+int smcpp_get_debug(smcpp_im *im);
+
 /* ---- engine controls (no reference counterpart) ---------------------------------------------------------- */
 
 /* Rows per chunk of the chunk-parallel chains (0 = automatic) and the chunk-boundary convergence tolerances. */
@@ -152,6 +156,8 @@ int smcpp_debug_ss4_apply(int M, const double *T, int nvec, const double *x, con
 int smcpp_last_host_timing(smcpp_im *im, double out[4]);
 /* The HIP stream the engine launches on (a hipStream_t), for event timing by the caller. */
 void *smcpp_stream(smcpp_im *im);
+/* The HIP device the manager lives on (buffers handed to smcpp_pack_stats / smcpp_unpack_stats must live there). */
+int smcpp_device(smcpp_im *im);
 
 /* init_logger_cb (include/common.h, _smcpp.pxd:26, _smcpp.pyx:32-55): the engine's messages (level "DEBUG", "INFO",
  * "WARNING", ...) are handed to the binding, which forwards them to Python's logging; NULL = silent (the default). */

@@ -64,6 +64,7 @@ def lib():
         "smcpp_set_chunking": (i, [vp, i, d, d]), "smcpp_set_warm_start": (i, [vp, i]),
         "smcpp_last_timing": (i, [vp, _dp]), "smcpp_last_host_timing": (i, [vp, _dp]), "smcpp_stream": (vp, [vp]), "smcpp_chain_mode": (i, [vp]),
         "smcpp_set_num_threads": (None, [i]),
+        "smcpp_set_debug": (i, [vp, i]), "smcpp_get_debug": (i, [vp]), "smcpp_device": (i, [vp]),
         "smcpp_debug_ss_apply": (i, [i, _dp, i, _dp, _dp, _dp, _dp]),
         "smcpp_debug_ss4_apply": (i, [i, _dp, i, _dp, _dp, _dp, _dp]),
         "smcpp_host_set_csfs_direct": (i, [i]),
@@ -105,7 +106,7 @@ EXPORTS = [
     "smcpp_set_params_twopop", "smcpp_host_joint_csfs", "smcpp_host_prep_twopop", "smcpp_set_warm_start",
     "smcpp_host_set_csfs_direct", "smcpp_gamma_cols", "smcpp_last_host_timing", "smcpp_get_pi_jac",
     "smcpp_get_transition_jac", "smcpp_get_emission_probs_jac", "smcpp_num_emission_cols", "smcpp_get_emission",
-    "smcpp_init_logger_cb", "smcpp_init_cache", "smcpp_debug_ss_apply", "smcpp_debug_ss4_apply",
+    "smcpp_init_logger_cb", "smcpp_init_cache", "smcpp_debug_ss_apply", "smcpp_debug_ss4_apply", "smcpp_set_debug", "smcpp_get_debug", "smcpp_device",
 ]
 
 

@@ -230,8 +230,22 @@ class _PyInferenceManager:
         """Extension: reuse the previous E-step's converged chunk-boundary vectors as start vectors (see the header)."""
         E.check(E.lib().smcpp_set_warm_start(self._im, int(bool(on))))
 
+    def device_index(self):
+        """The HIP device this manager lives on."""
+        return int(E.lib().smcpp_device(self._im))
+
+    @property
+    def debug(self):
+        """`InferenceManager::debug` (`_smcpp.pxd:53`): declared by the reference, read by nothing in its C++."""
+        return bool(E.lib().smcpp_get_debug(self._im))
+
+    @debug.setter
+    def debug(self, on):
+        E.check(E.lib().smcpp_set_debug(self._im, int(bool(on))))
+
     def chain_mode(self):
-        """Chain kernel family in use: 0 generic, 1 LDS-resident, 2 cooperative, 3 streamed operands, 4 lock-step (MFMA)."""
+        """Chain kernel family in use: 0 generic, 1 LDS-resident, 2 cooperative, 3 streamed operands, 4 lock-step (MFMA),
+        5 scans over the semiseparable structure of the transition matrix (the other families are its fallback)."""
         return int(E.lib().smcpp_chain_mode(self._im))
 
     def last_timing(self):

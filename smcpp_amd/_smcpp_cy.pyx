@@ -45,6 +45,8 @@ cdef extern from "smcpp_engine.h":
     int smcpp_num_derivatives(smcpp_im *im)
     int smcpp_set_save_gamma(smcpp_im *im, int on)
     int smcpp_get_save_gamma(smcpp_im *im)
+    int smcpp_set_debug(smcpp_im *im, int on)
+    int smcpp_get_debug(smcpp_im *im)
     int smcpp_num_keys(smcpp_im *im)
     int smcpp_key_len(smcpp_im *im)
     int smcpp_get_hidden_states(smcpp_im *im, double *hs)
@@ -250,6 +252,14 @@ cdef class _PyInferenceManager:
 
         def __set__(self, bint sg):
             _check(smcpp_set_save_gamma(self._im, sg))
+
+    property debug:
+        # InferenceManager::debug (_smcpp.pxd:53)
+        def __get__(self):
+            return bool(smcpp_get_debug(self._im))
+
+        def __set__(self, bint on):
+            _check(smcpp_set_debug(self._im, on))
 
     property hidden_states:
         def __get__(self):

@@ -572,6 +572,35 @@ __device__ __forceinline__ void ss_load_light(const SsArgs &a, int lane, SsLight
     c.c0 = (float)a.c0;
 }
 
+// The lane-level float scans of the light passes as ONE instruction per level and chain: v_add_f32 / v_fmac_f32 take the DPP
+// move as an operand modifier (the compiler fuses the add but not the multiply-add).  A DPP read of a register needs two wait
+// states after the VALU write: three interleaved chains provide them, two chains take one s_nop per level.
+// tools/dpp_lab.hip: every one of these instructions issues in 5.3 clocks, as a plain v_add_f32 does.
+#define SS_DPP_ "row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+__device__ __forceinline__ void ss_light_scan2(float &p, float &z, const float (&lv)[6], float c15, float c31) {
+    asm volatile("s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:1 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %2 row_shr:1 " SS_DPP_ "s_nop 0\n"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:2 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %3 row_shr:2 " SS_DPP_ "s_nop 0\n"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:4 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %4 row_shr:4 " SS_DPP_ "s_nop 0\n"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:8 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %5 row_shr:8 " SS_DPP_ "s_nop 0\n"
+                 "v_fmac_f32_dpp %0, %0, %8 row_bcast:15 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %6 row_bcast:15 " SS_DPP_ "s_nop 0\n"
+                 "v_fmac_f32_dpp %0, %0, %9 row_bcast:31 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %7 row_bcast:31 " SS_DPP_ "s_nop 1\n"
+                 : "+v"(p), "+v"(z)
+                 : "v"(lv[0]), "v"(lv[1]), "v"(lv[2]), "v"(lv[3]), "v"(lv[4]), "v"(lv[5]), "v"(c15), "v"(c31));
+}
+__device__ __forceinline__ void ss_light_scan3(float &p, float &z, float &f, const float (&lv)[6], float c15, float c31) {
+    asm volatile("s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:1 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %3 row_shr:1 " SS_DPP_ "v_add_f32_dpp %2, %2, %2 row_shr:1 " SS_DPP_
+                 "v_add_f32_dpp %0, %0, %0 row_shr:2 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %4 row_shr:2 " SS_DPP_ "v_add_f32_dpp %2, %2, %2 row_shr:2 " SS_DPP_
+                 "v_add_f32_dpp %0, %0, %0 row_shr:4 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %5 row_shr:4 " SS_DPP_ "v_add_f32_dpp %2, %2, %2 row_shr:4 " SS_DPP_
+                 "v_add_f32_dpp %0, %0, %0 row_shr:8 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %6 row_shr:8 " SS_DPP_ "v_add_f32_dpp %2, %2, %2 row_shr:8 " SS_DPP_
+                 "v_fmac_f32_dpp %0, %0, %9 row_bcast:15 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %7 row_bcast:15 " SS_DPP_ "v_fmac_f32_dpp %2, %2, %9 row_bcast:15 " SS_DPP_
+                 "v_fmac_f32_dpp %0, %0, %10 row_bcast:31 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %8 row_bcast:31 " SS_DPP_ "v_fmac_f32_dpp %2, %2, %10 row_bcast:31 " SS_DPP_ "s_nop 1\n"
+                 : "+v"(p), "+v"(z), "+v"(f)
+                 : "v"(lv[0]), "v"(lv[1]), "v"(lv[2]), "v"(lv[3]), "v"(lv[4]), "v"(lv[5]), "v"(c15), "v"(c31));
+}
+#undef SS_DPP_
+
 template <int NPL>
 __device__ __forceinline__ void ss_fwd_step_f(const SsLightC<NPL> &c, const float (&x)[NPL], const float (&e)[NPL],
                                               float (&out)[NPL], float &S) {
@@ -584,12 +613,7 @@ __device__ __forceinline__ void ss_fwd_step_f(const SsLightC<NPL> &c, const floa
         w[k] = __builtin_fmaf(c.a[k], w[k - 1], c.b[k] * x[k]);
     }
     float p_ = lp[NPL - 1], z_ = w[NPL - 1];
-    p_ += dpp0<DPP_SHR1>(p_); z_ = __builtin_fmaf(c.lv[0], dpp0<DPP_SHR1>(z_), z_);
-    p_ += dpp0<DPP_SHR2>(p_); z_ = __builtin_fmaf(c.lv[1], dpp0<DPP_SHR2>(z_), z_);
-    p_ += dpp0<DPP_SHR4>(p_); z_ = __builtin_fmaf(c.lv[2], dpp0<DPP_SHR4>(z_), z_);
-    p_ += dpp0<DPP_SHR8>(p_); z_ = __builtin_fmaf(c.lv[3], dpp0<DPP_SHR8>(z_), z_);
-    p_ = __builtin_fmaf(c.c15, dpp0<DPP_BC15>(p_), p_); z_ = __builtin_fmaf(c.lv[4], dpp0<DPP_BC15>(z_), z_);
-    p_ = __builtin_fmaf(c.c31, dpp0<DPP_BC31>(p_), p_); z_ = __builtin_fmaf(c.lv[5], dpp0<DPP_BC31>(z_), z_);
+    ss_light_scan2(p_, z_, c.lv, c.c15, c.c31);
     S = lane_get(p_, 63);
     const float LIp = dpp0<DPP_WSHR1>(z_);
     const float lex = p_ - lp[NPL - 1];
@@ -617,14 +641,7 @@ __device__ __forceinline__ void ss_bwd_step_f(const SsLightC<NPL> &c, const floa
         lf[k] = lf[k - 1] + w[k];
     }
     float p_ = lg[NPL - 1], z_ = u[NPL - 1], f_ = lf[NPL - 1];
-    p_ += dpp0<DPP_SHR1>(p_); z_ = __builtin_fmaf(c.lv[0], dpp0<DPP_SHR1>(z_), z_); f_ += dpp0<DPP_SHR1>(f_);
-    p_ += dpp0<DPP_SHR2>(p_); z_ = __builtin_fmaf(c.lv[1], dpp0<DPP_SHR2>(z_), z_); f_ += dpp0<DPP_SHR2>(f_);
-    p_ += dpp0<DPP_SHR4>(p_); z_ = __builtin_fmaf(c.lv[2], dpp0<DPP_SHR4>(z_), z_); f_ += dpp0<DPP_SHR4>(f_);
-    p_ += dpp0<DPP_SHR8>(p_); z_ = __builtin_fmaf(c.lv[3], dpp0<DPP_SHR8>(z_), z_); f_ += dpp0<DPP_SHR8>(f_);
-    p_ = __builtin_fmaf(c.c15, dpp0<DPP_BC15>(p_), p_); z_ = __builtin_fmaf(c.lv[4], dpp0<DPP_BC15>(z_), z_);
-    f_ = __builtin_fmaf(c.c15, dpp0<DPP_BC15>(f_), f_);
-    p_ = __builtin_fmaf(c.c31, dpp0<DPP_BC31>(p_), p_); z_ = __builtin_fmaf(c.lv[5], dpp0<DPP_BC31>(z_), z_);
-    f_ = __builtin_fmaf(c.c31, dpp0<DPP_BC31>(f_), f_);
+    ss_light_scan3(p_, z_, f_, c.lv, c.c15, c.c31);
     const float Gtot = lane_get(p_, 63);
     Sw = lane_get(f_, 63);
     const float LIp = dpp0<DPP_WSHR1>(z_);

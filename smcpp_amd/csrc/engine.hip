@@ -234,6 +234,8 @@ struct smcpp_im {
     std::vector<double> ss_gen4;
     SsArgs ss4_args;
     void build_coarse_chunks();
+    void update_pi_default();
+    bool debug = false;                    // InferenceManager::debug (_smcpp.pxd:53): declared by the reference, read by nothing
     void upload_chunk_state();
     bool ss_extract_generators();          // generators of T (verified entry by entry) into ss_gen; false: T has no such structure
     std::vector<double> ss_gen;            // [10][MS]: f_dc f_g f_cg f_b f_a f_d b_dc b_g b_b b_a
@@ -457,18 +459,7 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
     make_chunks();
     make_slabs();
     alloc_device();
-    // pi of defaultEta (a = s = {1}: R(t) = t), inference_manager.cpp:12-19,43,56-69: what a fresh HMM's statistics hold
-    pi_default.assign(M, 0.0);
-    {
-        double sm = 0.0;
-        for (int m = 0; m < M; ++m) {
-            double v = std::exp(-hs[m]) - ((m + 1 < M) ? std::exp(-hs[m + 1]) : 0.0);
-            if (v < 1e-20) v = 1e-20;
-            pi_default[m] = v;
-            sm += v;
-        }
-        for (double &v : pi_default) v /= sm;
-    }
+    update_pi_default();
     // defaults after construction (_smcpp.pyx:318-320)
     alpha = 1.0; theta = 1e-4; rho = 1e-4;
     loglik.assign(n_contigs, 0.0);
@@ -547,7 +538,7 @@ void smcpp_im::make_chunks() {
                 const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
                 total_bins += ri.gid < 0 ? 1 : groups[ri.gid].span;
             }
-        const long long bpc = std::max<long long>(ss4 ? 512 : 2048, (total_bins + slots - 1) / slots);
+        const long long bpc = std::max<long long>(ss4 ? 512 : 1024, (total_bins + slots - 1) / slots);
         chunks.clear();
         max_chunks_per_contig = 1;
         for (int c = 0; c < n_contigs; ++c) {
@@ -641,6 +632,20 @@ void smcpp_im::upload_chunk_state() {
         d_ends1_b.alloc(2 * chunks1.size() * Mp);
     }
     HIPCHK(hipStreamSynchronize(stream));
+}
+
+// pi of defaultEta (a = s = {1}: R(t) = t), inference_manager.cpp:12-19,43,56-69: what a fresh HMM's statistics hold; follows
+// the hidden states (smcpp_set_hidden_states before the first E-step)
+void smcpp_im::update_pi_default() {
+    pi_default.assign(M, 0.0);
+    double sm = 0.0;
+    for (int m = 0; m < M; ++m) {
+        double v = std::exp(-hs[m]) - ((m + 1 < M) ? std::exp(-hs[m + 1]) : 0.0);
+        if (v < 1e-20) v = 1e-20;
+        pi_default[m] = v;
+        sm += v;
+    }
+    for (double &v : pi_default) v /= sm;
 }
 
 void smcpp_im::make_slabs() {
@@ -2509,6 +2514,7 @@ int smcpp_set_hidden_states(smcpp_im *im, int n_hs, const double *hs) {
     API_BEGIN
     if (n_hs != (int)im->hs.size()) throw std::runtime_error("hidden states must be same size");
     im->hs.assign(hs, hs + n_hs);
+    im->update_pi_default();
     im->twopop_prep.reset();
     if (!im->estep_done) im->stats_on_host = false;
     im->dirty = true;
@@ -2844,6 +2850,10 @@ int smcpp_debug_ss4_apply(int M, const double *T, int nvec, const double *x, con
     }
     API_END
 }
+
+int smcpp_device(smcpp_im *im) { return im ? im->device : -1; }
+int smcpp_set_debug(smcpp_im *im, int on) { API_BEGIN im->debug = on != 0; API_END }
+int smcpp_get_debug(smcpp_im *im) { return im && im->debug ? 1 : 0; }
 
 void smcpp_set_num_threads(int k) { if (k > 0) omp_set_num_threads(k); }
 

@@ -269,7 +269,10 @@ inline bool load_tables(const std::string &fn, int n, CsfsTables &t) {
             *m = DMat(rc[0], rc[1]);
             if (fread(m->d.data(), sizeof(double), m->d.size(), f) != m->d.size()) { ok = false; break; }
         }
-        ok = ok && t.X0.r == n && t.X0.c == n + 1 && t.M1.r == n + 1 && t.M1.c == n + 1;
+        // every table at the shape csfs_tables() builds (a truncated or foreign file must not be indexed out of bounds)
+        ok = ok && t.X0.r == n && t.X0.c == n + 1 && t.X2.r == t.X0.r && t.X2.c == t.X0.c &&
+             t.M1.r == n + 1 && t.M1.c == n + 1 && t.M0.r == n + 1 && t.M0.c == n &&
+             t.Uinv_mp0.r == n + 1 && t.Uinv_mp0.c == n && t.Uinv_mp2.r == n + 1 && t.Uinv_mp2.c == n;
     }
     fclose(f);
     t.n = n;

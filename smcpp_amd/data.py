@@ -95,9 +95,10 @@ def validate(contig: Contig) -> Contig:
     if np.any(nonseg):
         # the reference zeroes a COPY of the distinguished columns (fancy indexing) and b in place: only b changes
         d[nonseg, 2::3] = 0
-    # operator precedence of the reference: `span <= (0 | any(a > A))`, then `| any(b > nb) | any(nb > n)`
-    bad = (d[:, 0] <= (0 | np.any(d[:, 1::3] > a[None, :], axis=1))) | np.any(d[:, 2::3] > d[:, 3::3], axis=1) \
-        | np.any(d[:, 3::3] > n[None, :], axis=1)
+    # operator precedence of the reference (data_filter.py:146-150): `|` binds tighter than `<=`, so the test is
+    # `span <= (0 | any(a > A) | any(b > nb) | any(nb > n))`: a row with span > 1 passes whatever its counts are
+    bad = d[:, 0] <= (0 | np.any(d[:, 1::3] > a[None, :], axis=1) | np.any(d[:, 2::3] > d[:, 3::3], axis=1)
+                      | np.any(d[:, 3::3] > n[None, :], axis=1))
     if np.any(bad):
         raise RuntimeError("data validation failed")
     return contig

@@ -133,7 +133,7 @@ class ShardedInferenceManager:
     """
 
     def __init__(self, n, observations, hidden_states, im_id, polarization_error, *, device=-1, group=None,
-                 lengths=None, factory=None):
+                 lengths=None, factory=None, always_reduce=False):
         import torch.distributed as dist
         self._group = group
         self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
@@ -154,11 +154,15 @@ class ShardedInferenceManager:
             def factory(obs, dev):
                 return _smcpp.PyOnePopInferenceManager(n, obs, hidden_states, im_id, polarization_error, device=dev)
         self.im = factory(local, device)
+        self._device = self.im.device_index() if hasattr(self.im, "device_index") else 0
+        # always_reduce: run the pack -> all-reduce -> unpack path even in a group of ONE rank (test hook: the device-buffer
+        # branch of the RCCL backend on a single GPU)
+        self._reduce = bool(self._dist) and (self.world > 1 or always_reduce)
         self._nccl = bool(self._dist) and self._dist.get_backend(group) == "nccl"
         self._buf = None
         self._ll_sum = None
         self._lls = None
-        if self.world > 1:
+        if self._reduce:
             # global key dictionary: fixes the layout of the gamma_sums block and makes the engine prepare the
             # emission vectors of keys only other ranks' contigs hold (they enter Q through the reduced statistics)
             self.im.set_global_keys(union_keys(self.im.keys, group))
@@ -184,19 +188,20 @@ class ShardedInferenceManager:
     @property
     def keys(self):
         """Union of every rank's keys (lexicographic)."""
-        return union_keys(self.im.keys, self._group) if self.world > 1 else self.im.keys
+        return union_keys(self.im.keys, self._group) if self._reduce else self.im.keys
 
     def E_step(self, forward_backward_only=False):
         """Local E-step on this rank's contigs + the single all-reduce of the packed statistics."""
         self.im.E_step(forward_backward_only)
         self._lls = None
-        if self.world == 1:
+        if not self._reduce:
             self._ll_sum = float(self.im.loglik())
             return
         import torch
         if self._nccl:
             if self._buf is None:
-                self._buf = torch.empty(self.im.stats_len(), dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+                # on the device the ENGINE lives on (the pack / unpack kernels dereference the pointer there)
+                self._buf = torch.empty(self.im.stats_len(), dtype=torch.float64, device=torch.device("cuda", self._device))
             self.im.pack_stats_device(self._buf.data_ptr())           # returns after the kernel has finished
             self._dist.all_reduce(self._buf, op=self._dist.ReduceOp.SUM, group=self._group)
             self._ll_sum = float(self._buf[0].item())                 # synchronises the reduction
@@ -220,7 +225,7 @@ class ShardedInferenceManager:
             dev = None
             if self._nccl:
                 import torch
-                dev = torch.device("cuda", torch.cuda.current_device())
+                dev = torch.device("cuda", self._device)
             self._lls = allgather_logliks(self.im.logliks(), self.owner, device=dev, group=self._group)
         return self._lls
 

@@ -125,6 +125,21 @@ def main():
         out[f"bug11_{fi}_watterson"] = np.array(w.theta_hat)
         out[f"bug11_{fi}_recode_mono"] = DF.RecodeMonomorphic().run(
             [Contig(pid=contig.pid, data=d.copy(), n=contig.n, a=contig.a, fn=f)])[0].data
+    # ---- (c) Validate on malformed rows: `span <= 0 | A | B | C` parses as `span <= (0 | A | B | C)` (data_filter.py:146-150),
+    # so a row with span > 1 passes whatever its counts are; which of these one-violation contigs the reference refuses ----
+    cases = np.array([[1, 3, 0, 0], [5, 3, 0, 0], [1, 0, 3, 2], [7, 0, 3, 2], [1, 0, 0, 9], [2, 0, 0, 9], [0, 0, 0, 0], [4, 1, 2, 4]],
+                     dtype=np.int32)
+    raised = []
+    for row in cases:
+        d = np.array([[3, 0, 0, 0], row, [2, 1, 1, 4]], dtype=np.int32)
+        try:
+            DF.Validate().run(Contig(pid=("pop1",), data=np.ascontiguousarray(d), n=np.array([4]), a=np.array([2]), fn="case"))
+            raised.append(False)
+        except RuntimeError:
+            raised.append(True)
+    out["validate_cases"] = cases
+    out["validate_raised"] = np.array(raised)
+
     # known answers of the reference's own unit tests for the Cython functions it cannot run here (test_bugs.py:35-47)
     out["kat_compress_in"] = np.array([[1, 0, 0, 0], [2, 0, 0, 0]], dtype=np.int32)
     out["kat_compress_out"] = ET.compress_repeated_obs(np.array([[1, 0, 0, 0], [2, 0, 0, 0]]))

@@ -252,6 +252,16 @@ def test_pipeline_rows_equal_reference_on_the_example_contig():
         assert np.array_equal(r.data, g[f"ex_recode_nonseg_{cutoff}"])
     np.testing.assert_allclose(D.watterson_theta([c]), float(g["ex_watterson"]), rtol=1e-14)
     assert np.array_equal(D.validate(D.Contig(c.data.copy(), c.pid, c.n, c.a)).data, g["ex_validate"])
+    # malformed rows: the reference's test is `span <= (0 | a > A | b > nb | nb > n)` (operator precedence), i.e. a violating row of
+    # span > 1 passes; G11 records which of these one-violation contigs the reference's Validate refused
+    for row, raised in zip(g["validate_cases"], g["validate_raised"]):
+        d = np.array([[3, 0, 0, 0], row, [2, 1, 1, 4]], dtype=np.int32)
+        cc = D.Contig(np.ascontiguousarray(d), ("pop1",), np.array([4]), np.array([2]))
+        if raised:
+            with pytest.raises(RuntimeError, match="data validation failed"):
+                D.validate(cc)
+        else:
+            D.validate(cc)
     assert np.array_equal(D.recode_monomorphic(D.Contig(c.data.copy(), c.pid, c.n, c.a)).data, g["ex_recode_mono"])
 
 

@@ -99,6 +99,54 @@ def test_two_ranks_match_single_manager(tmp_path, disjoint, use_model):
         np.testing.assert_allclose(np.array(r[0]["jac"]), jac, rtol=1e-9, atol=1e-9 * np.abs(jac).max())
 
 
+def _nccl_worker(rank, port, out_dir):
+    """ONE rank, backend nccl (= RCCL): the device-buffer branch of ShardedInferenceManager.E_step (k_pack_stats writes into
+    the reduced tensor, all_reduce on the device, k_unpack) that a gloo group never takes."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from smcpp_amd.dist import ShardedInferenceManager
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=1)
+    g = load_golden("G3_M32_n10_2Mbp")
+    contigs = _contigs(True)
+    sim = ShardedInferenceManager(10, contigs, g["hs"], ("pop1",), 0.5, always_reduce=True)
+    assert sim._nccl and sim._reduce
+    _setup(sim, g, True)
+    sim.E_step()
+    q, jac = sim.Q_with_gradient()
+    res = dict(loglik=sim.loglik(), logliks=list(map(float, sim.logliks())), q=list(map(float, sim.Q(separate=True))),
+               jac=jac.tolist(), buf_device=str(sim._buf.device), keys=sim.keys.tolist())
+    with open(os.path.join(out_dir, "nccl.json"), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_nccl_device_buffer_branch_world_of_one(tmp_path):
+    """The RCCL path of the sharded manager (pack on the device -> all_reduce -> unpack on the device) executed for real: a
+    process group of ONE rank with backend nccl and `always_reduce`.  Against the plain manager on the same contigs: the
+    reduced statistics are the manager's own, summed over its contigs by k_pack_stats (1e-12: summation order)."""
+    from smcpp_amd import _smcpp
+    mp.spawn(_nccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = json.load(open(tmp_path / "nccl.json"))
+    g = load_golden("G3_M32_n10_2Mbp")
+    contigs = _contigs(True)
+    im = _smcpp.PyOnePopInferenceManager(10, contigs, g["hs"], ("pop1",), 0.5)
+    _setup(im, g, True)
+    im.E_step()
+    assert r["buf_device"].startswith("cuda")
+    assert r["keys"] == im.keys.tolist()
+    assert abs(r["loglik"] - im.loglik()) <= 1e-12 * abs(im.loglik())
+    np.testing.assert_allclose(r["logliks"], im.logliks(), rtol=1e-13)
+    np.testing.assert_allclose(r["q"], im.Q(separate=True), rtol=1e-11)
+    _, jac = im.Q_with_gradient()
+    np.testing.assert_allclose(np.array(r["jac"]), jac, rtol=1e-9, atol=1e-9 * np.abs(jac).max())
+
+
 def test_reduced_q_needs_every_global_key():
     """set_raw on a rank that was not given the emission vector of a key other ranks hold: Q must fail loudly instead
     of silently dropping the key's statistics."""

@@ -165,7 +165,8 @@ class EMTerminationException(Exception):
 
 
 class EMOptimizer:
-    """E-step / M-step loop of smcpp/optimize/optimizers.py:163-197 with the result-changing plugins built in."""
+    """E-step / M-step loop of smcpp/optimize/optimizers.py:163-197 with the result-changing plugins built in: the log-likelihood
+    monitor (termination), ScaleOptimizer (common shift before every M-step), ParameterOptimizer("rho"), AnalysisSaver."""
 
     def __init__(self, analysis, algorithm, xtol, ftol, single, learn_rho, outdir=None, base="model"):
         self._analysis, self._algorithm, self._xtol, self._ftol, self._single = analysis, algorithm, xtol, ftol, single
@@ -190,8 +191,9 @@ class EMOptimizer:
     def _minimize(self, x0, coords, bounds):
         if len(coords) > 1:
             return scipy.optimize.minimize(self._f, x0, jac=True, args=(coords,), bounds=bounds, method=self._algorithm)
-        res = scipy.optimize.minimize_scalar(lambda x: self._f(np.array([x]), coords)[0], bounds=bounds[0],
-                                             options={"xatol": self._xtol}, method="bounded")
+        # (the reference hands {'xtol', 'ftol'} to scipy's bounded scalar solver, optimizers.py:132-138: names that solver does
+        # not know, so it runs at its default xatol = 1e-5; reproduced, a coarser stop would end the search 0.1 log-units early)
+        res = scipy.optimize.minimize_scalar(lambda x: self._f(np.array([x]), coords)[0], bounds=bounds[0], method="bounded")
         res.x = np.array([res.x])
         return res
 
@@ -213,6 +215,20 @@ class EMOptimizer:
                 raise EMTerminationException()
         self._old_loglik = ll
 
+    def _scale_step(self):
+        """`ScaleOptimizer` (smcpp/optimize/plugins/scale_optimizer.py: enabled, registered by SMCPPOptimizer for every run incl.
+        the bootstrap): before each M-step one bounded search over a common shift of all the model's coordinates."""
+        an = self._analysis
+        an.model.differentiate([])
+        x0 = np.array(an.model[:], dtype=float)
+
+        def f(alpha):
+            an.model[:] = x0 + alpha
+            return -float(an.Q())
+
+        res = scipy.optimize.minimize_scalar(f, method="bounded", bounds=(-1, 1))
+        an.model[:] = x0 + res.x
+
     def _update_rho(self):
         an = self._analysis
         lo, hi = an._theta / 100, 100 * an._theta
@@ -231,6 +247,8 @@ class EMOptimizer:
             for i in range(niter):
                 an.E_step()
                 self._post_estep(i)
+                # "pre M-step" observers (the reference keeps them in a WeakSet: their order is not defined there either)
+                self._scale_step()
                 if self._learn_rho:
                     self._update_rho()
                 for coords in self._coordinates():
@@ -428,3 +446,49 @@ class Analysis:
              "hidden_states": {self.populations[0]: [float(x) for x in self.hidden_states]}}
         with open(filename + ".json", "wt") as f:
             json.dump(d, f, sort_keys=True, indent=4)
+
+
+# ---- a minimal EM driver on raw piece sizes (no hidden-state selection, no plugins): what the monotonicity tests drive ----
+def em(contigs, n, hidden_states, a0, s, theta, rho, alpha=1.0, polarization_error=0.5, iterations=5,
+       penalty=0.0, bounds=(1e-2, 1e2), device=-1, callback=None):
+    """Returns `(model, logliks)`: `logliks[i]` is the log-likelihood at the parameters entering EM iteration i."""
+    from .model import PiecewiseModel
+    model = PiecewiseModel(np.array(a0, dtype=float), np.array(s, dtype=float), 1e4, "pop1")
+    model.differentiable = True
+    im = _smcpp.PyOnePopInferenceManager(n, contigs, hidden_states, ("pop1",), polarization_error, device=device)
+    im.model = model
+    im.theta = theta
+    im.rho = rho
+    im.alpha = alpha
+    K = len(model.a)
+    logliks = []
+
+    def neg_q(x):
+        model.a[:] = np.exp(x)
+        model.update_observers("model update")
+        q, jac = im.Q_with_gradient()
+        f = -q.sum()
+        g = -(jac.sum(axis=0)) * np.exp(x)          # chain rule for a = exp(x)
+        if penalty > 0:
+            d = np.diff(x)
+            f += penalty * np.sum(d * d)
+            gp = np.zeros(K)
+            gp[:-1] -= 2 * penalty * d
+            gp[1:] += 2 * penalty * d
+            g = g + gp
+        return f, g
+
+    for it in range(iterations):
+        im.E_step()
+        logliks.append(im.loglik())
+        if callback:
+            callback(it, logliks[-1], model.a.copy())
+        x0 = np.log(model.a)
+        res = scipy.optimize.minimize(neg_q, x0, jac=True, method="L-BFGS-B",
+                                      bounds=[(np.log(bounds[0]), np.log(bounds[1]))] * K,
+                                      options={"maxiter": 50})
+        model.a[:] = np.exp(res.x)
+        model.update_observers("model update")
+    im.E_step()
+    logliks.append(im.loglik())
+    return model, np.array(logliks)

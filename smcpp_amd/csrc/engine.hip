@@ -222,6 +222,7 @@ struct smcpp_im {
     int ss_light_f = 0, ss_light_b = 0;    // light (float, store-free) passes per direction before the full fp64 pass
     std::vector<int> ss_slot_of_key;       // frequency rank of every key (slot 0 = most rows)
     DevBuf<int2> d_rowdesc_ss;             // [rows, padded] {key slot, span}
+    DevBuf<double> d_Fall;                 // [n_contigs Ke][smax][Mp][Mp] scratch of the span fold for M > 64 (k_span_big)
     SsArgs ss_args;
     // four chains per wavefront (chains_ss4.hpp, M <= 64): the fp64 passes run on `chunks` (fine), the light passes on groups of
     // four of them (`chunks1`, coarse) and hand over the fine boundary vectors
@@ -2059,6 +2060,21 @@ void smcpp_im::enqueue_stats() {
             hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), (unsigned)eb_gid.size(), 1), dim3(256), 0, se,
                                (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MMi, 1);
         const size_t shm = (size_t)2 * Mp * (Mp + 1) * sizeof(double);
+        if (NT > 4) {
+            // 64 < M <= 256: strips of 16 rows (F) / columns (H), one workgroup each, F_t through scratch
+            d_Fall.alloc((size_t)n_contigs * Ke * ss_max_span * Mp * Mp);
+            const int nstrip = NT, nwg = n_contigs * Ke * nstrip;
+            if (NT <= 8) {
+                hipLaunchKernelGGL((k_span_big<8, 0>), dim3(nwg), dim3(512), 0, se, fa, ss_max_span, d_Fall.p);
+                hipLaunchKernelGGL((k_span_big<8, 1>), dim3(nwg), dim3(512), 0, se, fa, ss_max_span, d_Fall.p);
+            } else if (NT <= 12) {
+                hipLaunchKernelGGL((k_span_big<12, 0>), dim3(nwg), dim3(768), 0, se, fa, ss_max_span, d_Fall.p);
+                hipLaunchKernelGGL((k_span_big<12, 1>), dim3(nwg), dim3(768), 0, se, fa, ss_max_span, d_Fall.p);
+            } else {
+                hipLaunchKernelGGL((k_span_big<16, 0>), dim3(nwg), dim3(1024), 0, se, fa, ss_max_span, d_Fall.p);
+                hipLaunchKernelGGL((k_span_big<16, 1>), dim3(nwg), dim3(1024), 0, se, fa, ss_max_span, d_Fall.p);
+            }
+        } else
         switch (NT) {
 #define S_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_span_FH<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
                     hipLaunchKernelGGL(k_span_FH<x>, dim3(n_contigs * Ke), dim3(128 * x), shm, se, fa, ss_max_span); } break;
@@ -2170,7 +2186,7 @@ void smcpp_im::estep() {
     {
         // span > 1 rows without an eigensystem (kernels.hpp: k_span_fold): the span is expanded by smax steps of two M x M products
         static const bool off = getenv("SMCPP_EIGFREE") && atoi(getenv("SMCPP_EIGFREE")) == 0;
-        eigfree = ss_active && !off && Mp <= 64 && ss_max_span <= 64 && !save_gamma;
+        eigfree = ss_active && !off && Mp <= 256 && ss_max_span <= 64 && !save_gamma;
     }
     if (ss_active) { prepass_launched = false; static_packed = false; ss_launch_initial(); }   // the chains need no eigensystem: they start now
     else stage_static_and_prepass();   // (when eligible) pass 0 of both chains starts now, on eigen-free operands

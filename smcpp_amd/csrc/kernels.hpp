@@ -2526,6 +2526,99 @@ __global__ __launch_bounds__(128 * NT) void k_span_FH(FinArgs a, int smax) {
         if (qd + 4 * r == m && 16 * sp + m < Mp) gout[16 * sp + m] = G[r];
 }
 
+// The same fold for 64 < M <= 256 (NTP = padded tile count 8 / 12 / 16): one workgroup of NTP wavefronts per 16-wide strip,
+// wavefront tt owns output tile tt of the strip and keeps ITS A fragments (MT/4 doubles per lane) in registers for all steps;
+// the strip (MT x 16) is exchanged through a double-buffered LDS copy, one barrier per step.  PHASE 0: F^T strips (rows of F),
+// F_t written to scratch;  PHASE 1: H strips (columns of H), W = H_0 and diag(A W) written at the end.
+template <int NTP, int PHASE>
+__global__ __launch_bounds__(64 * NTP) void k_span_big(FinArgs a, int smax, double *__restrict__ Fall) {
+    constexpr int MT = 16 * NTP, LDX = 17;
+    __shared__ double sX[2][MT * LDX];
+    const int ns = (a.Mp + 15) / 16;                                  // strips that exist
+    const int ce = blockIdx.x / ns, sp = blockIdx.x % ns, e = ce % a.Ke;
+    const int b0 = a.ce_bucket_off[ce], b1 = a.ce_bucket_off[ce + 1];
+    if (b0 == b1) return;
+    const int tid = threadIdx.x, lane = tid & 63, tt = tid >> 6;
+    const int m = lane & 15, qd = lane >> 4;
+    const int Mp = a.Mp, M = a.M;
+    const double *ek = a.E + (size_t)a.e_kid[e] * Mp;
+    // A operand of this wavefront's output tile, k = 4 kk + qd:  PHASE 0: A^T[16 tt + m][k] = e_k T[16 tt + m][k];  PHASE 1: A[16 tt + m][k] = e_i T[k][i]
+    double af[MT / 4];
+#pragma unroll
+    for (int kk = 0; kk < MT / 4; ++kk) {
+        const int k = 4 * kk + qd, i = 16 * tt + m;
+        const int kc = min(k, Mp - 1), ic = min(i, Mp - 1);
+        const double v = PHASE == 0 ? ek[kc] * a.Td[(size_t)ic * Mp + kc] : ek[ic] * a.Td[(size_t)kc * Mp + ic];
+        af[kk] = (k < M && i < M) ? v : 0.0;
+    }
+    // the strip starts at zero
+    for (int idx = tid; idx < MT * LDX; idx += 64 * NTP) { sX[0][idx] = 0.0; sX[1][idx] = 0.0; }
+    __syncthreads();
+    int bcur = b1 - 1;
+    double *Fce = Fall + (size_t)ce * smax * Mp * Mp;
+    f64x4 X = {0, 0, 0, 0};
+    for (int t = smax - 1; t >= 0; --t) {
+        const int cur = (smax - 1 - t) & 1;
+        const double *sr = sX[cur];
+        double *sw = sX[cur ^ 1];
+        double av[4] = {0.0, 0.0, 0.0, 0.0};
+        double *Ft = Fce + (size_t)t * Mp * Mp;
+        if (PHASE == 0) {
+            const bool has = bcur >= b0 && a.g_span[a.eb_gid[bcur]] == t + 1;
+            if (has) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                         // Acc[row of F = 16 sp + m][column of F = 16 tt + qd + 4 r]
+                    const int row = 16 * sp + m, col = 16 * tt + qd + 4 * r;
+                    av[r] = (row < Mp && col < Mp) ? a.red_e[(size_t)bcur * Mp * Mp + (size_t)row * Mp + col] : 0.0;
+                }
+                --bcur;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                             // F_t[row 16 tt + qd + 4 r][column 16 sp + m]
+                const int row = 16 * tt + qd + 4 * r, col = 16 * sp + m;
+                av[r] = (row < Mp && col < Mp) ? Ft[(size_t)row * Mp + col] : 0.0;
+            }
+        }
+        f64x4 Xn = {0, 0, 0, 0};
+#pragma unroll 8
+        for (int kk = 0; kk < MT / 4; ++kk)
+            Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], sr[(4 * kk + qd) * LDX + m], Xn, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            X[r] = Xn[r] + av[r];
+            sw[(16 * tt + qd + 4 * r) * LDX + m] = X[r];
+        }
+        if (PHASE == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                             // F_t[row 16 sp + m][column 16 tt + qd + 4 r]
+                const int row = 16 * sp + m, col = 16 * tt + qd + 4 * r;
+                if (row < Mp && col < Mp) Ft[(size_t)row * Mp + col] = X[r];
+            }
+        }
+        __syncthreads();
+    }
+    if (PHASE == 0) return;
+    // W = H_0 strip; diag(A W): tile sp of A W, computed by wavefront sp from the final strip
+    double *Wout = a.Y + (size_t)ce * Mp * Mp;
+    double *gout = a.Z + (size_t)ce * Mp * Mp;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tt + qd + 4 * r, col = 16 * sp + m;
+        if (row < Mp && col < Mp) Wout[(size_t)row * Mp + col] = X[r];
+    }
+    if (tt == sp) {
+        const double *sr = sX[smax & 1];
+        f64x4 G = {0, 0, 0, 0};
+#pragma unroll 8
+        for (int kk = 0; kk < MT / 4; ++kk)
+            G = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], sr[(4 * kk + qd) * LDX + m], G, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (qd + 4 * r == m && 16 * sp + m < Mp) gout[16 * sp + m] = G[r];
+    }
+}
+
 // xisum[contig] = max( (X1 + sum_e P_e Y_e diag(b_e)) o Td , 1e-20 )   (hmm.cpp:122,141,151-152)
 __global__ __launch_bounds__(256) void k_fin_xisum(FinArgs a) {
     const int ct = blockIdx.y;

@@ -48,6 +48,46 @@ def test_smcmodel_pieces_seeds_and_dict():
     np.testing.assert_array_equal(m2.stepwise_values(), m.stepwise_values())
 
 
+def test_model_classes_match_the_reference_python_classes():
+    """Golden G15 (tests/golden/make_golden_model.py): the reference's OWN smcpp/model.py + smcpp/spline/piecewise.py and the knot
+    placement / regularisation scaling of its Analysis (analysis.py:104-126), imported where they lie and run on fixed inputs:
+    `s`, `stepwise_values` (with the clipping to [1e-3, 1e3]), `__call__`, `regularizer`, `to_dict` / `from_dict`, `randomize`
+    under a fixed seed, `_init_knots`, `_init_regularization`."""
+    import types
+    from conftest import load_golden
+    from smcpp_amd.analysis import Analysis, SMCModel
+    g = load_golden("G15_model")
+    for ci in range(int(g["n_cases"])):
+        m = SMCModel(g[f"c{ci}_knots"], 1e4, "pop1")
+        m[:] = g[f"c{ci}_y"]
+        np.testing.assert_allclose(m.s, g[f"c{ci}_s"], rtol=1e-14)
+        np.testing.assert_allclose(m.stepwise_values(), g[f"c{ci}_stepwise"], rtol=1e-14)
+        np.testing.assert_allclose(m(g[f"c{ci}_points"]), g[f"c{ci}_values"], rtol=1e-14)
+        assert abs(m.regularizer() - float(g[f"c{ci}_regularizer"])) <= 1e-12 * max(1.0, abs(float(g[f"c{ci}_regularizer"])))
+        ref_d = json.loads(str(g[f"c{ci}_dict"]))
+        d = m.to_dict()
+        assert sorted(d) == sorted(ref_d)
+        for k in ("class", "spline_class", "pid", "N0"):
+            assert d[k] == ref_d[k]
+        np.testing.assert_allclose(d["knots"], ref_d["knots"], rtol=0)
+        np.testing.assert_allclose(d["y"], ref_d["y"], rtol=0)
+        m2 = SMCModel.from_dict(ref_d)                       # a file the reference wrote is read back
+        np.testing.assert_array_equal(m2.stepwise_values(), m.stepwise_values())
+        np.random.seed(3)
+        m.randomize()
+        np.testing.assert_allclose(m[:], g[f"c{ci}_randomized"], rtol=1e-15)
+    for k in range(int(g["n_knot_cases"])):
+        t1, tK = [None if np.isnan(x) else float(x) for x in g[f"k{k}_t"]]
+        ns = types.SimpleNamespace()
+        Analysis._init_knots(ns, g[f"k{k}_hs"], t1, tK)
+        np.testing.assert_allclose(ns._knots, g[f"k{k}_knots"], rtol=1e-15)
+    for q, rp, lam, pen in g["penalty_cases"]:
+        ns = types.SimpleNamespace(_args=types.SimpleNamespace(lambda_=None if np.isnan(lam) else float(lam),
+                                                               regularization_penalty=float(rp)), Q=lambda q=q: float(q))
+        Analysis._init_regularization(ns)
+        assert abs(ns._penalty - pen) <= 1e-14 * abs(pen)
+
+
 def _example_contig():
     from smcpp_amd import vcf2smc as V
     c, _ = V.vcf2smc(os.path.join(ROOT, "tests", "golden", "example.vcf.gz"), "1", ("pop1", ["msp_0", "msp_1", "msp_2"]))
@@ -73,11 +113,30 @@ def test_analysis_replays_the_reference_run_on_the_example(tmp_path):
     an.run()
     ll = an._optimizer.logliks
     assert len(ll) == 1
-    # the main model starts from the bootstrap M-step's optimum: four log-sizes fitted to 1 Mbp by L-BFGS-B inside +-3
-    # log-unit bounds, some of them barely identified, so where the optimiser stops depends on its path (this
-    # repository's gradients come from the engine, the reference's from its ad numbers).  Observed: -1351.2254 against
-    # the reference's -1350.7839 (3.3e-4 relative) - the replay pins the flow, not the last digits
-    assert abs(ll[0] - (-1350.7839372364251)) <= 1e-3 * 1350.8, ll
+    # the main model starts from the bootstrap M-step's optimum: four log-sizes fitted to 1 Mbp (ScaleOptimizer's common shift,
+    # then L-BFGS-B inside +-3 log-unit bounds), some of them barely identified, so where the optimiser stops depends on its
+    # path (this repository's gradients come from the engine, the reference's from its ad numbers).  Observed: -1351.0197
+    # against the reference's -1350.7839 (1.7e-4 relative; 3.3e-4 before the scale step was reproduced) - the replay pins
+    # the flow; the numbers of this data set at a FIXED parameter point are pinned below against the C restatement
+    assert abs(ll[0] - (-1350.7839372364251)) <= 4e-4 * 1350.8, ll
+    # ---- the engine on the main-stage data (2 727 thinned / binned rows, 15 balanced states) at a parameter point no
+    # optimiser has touched: constant size at Watterson's estimate; against oracle/ (hmm.cpp restated) on the same inputs ----
+    from oracle import oracle
+    from smcpp_amd import _smcpp
+    from smcpp_amd.analysis import SMCModel
+    fixed = SMCModel(an.model.knots, an.model.N0, "pop1")
+    fixed[:] = np.log(an._watterson / (2.0 * args.mu * an._N0))
+    obs = [np.ascontiguousarray(c.data, dtype=np.int32) for c in an.contigs]
+    im = _smcpp.PyOnePopInferenceManager(an.contigs[0].n[0], obs, an.hidden_states, ("pop1",), 0.0)
+    im.theta = an._theta; im.rho = an._rho; im.alpha = args.w
+    im.model = fixed
+    im.E_step()
+    ep = im.emission_probs
+    keys = im.keys
+    o = oracle.estep(im.pi, im.transition, keys, np.array([ep[tuple(k)] for k in keys.tolist()]), obs[0])
+    assert abs(im.loglik() - o["loglik"]) <= 1e-6 * abs(o["loglik"])
+    assert np.max(np.abs(im.xisums[0] - o["xisum"]) / np.abs(o["xisum"])) <= 5e-6
+    assert np.all(np.abs(np.array(im.Q(separate=True)) - o["q"]) <= 5e-6 * np.maximum(np.abs(o["q"]), 1e-12))
     j = json.load(open(tmp_path / "model.final.json"))
     assert sorted(j) == ["alpha", "hidden_states", "model", "rho", "theta"]
     assert j["theta"] == 1e-4 and j["alpha"] == 100 and j["model"]["class"] == "SMCModel"

@@ -254,7 +254,7 @@ def test_em_iterations_increase_the_likelihood():
     """End-to-end property of E-step statistics + Q + gradients: an EM step cannot decrease the log-likelihood
     (up to the float-alpha noise of the E-step).  Data are simulated under a size history that differs from the start."""
     from smcpp_amd import synth
-    from smcpp_amd.estimate import em
+    from smcpp_amd.analysis import em
     g = load_golden("G1_M16_n4")
     contigs = [synth.synth_contig(40 + i, 400_000, 4) for i in range(2)]
     a0 = np.ones(4)
@@ -624,7 +624,7 @@ def test_em_on_the_reference_example_pipeline():
     (the whole C1 flow of SURVEY.md §8d, with this repository's callers of the path): the log-likelihood must rise."""
     import os
     from smcpp_amd import data as D, posterior as PO, vcf2smc as V
-    from smcpp_amd.estimate import em
+    from smcpp_amd.analysis import em
     from smcpp_amd.model import PiecewiseModel
     vcf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example.vcf.gz")
     c, _ = V.vcf2smc(vcf, "1", ("pop1", ["msp_0", "msp_1", "msp_2"]))

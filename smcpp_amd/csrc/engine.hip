@@ -197,8 +197,9 @@ struct smcpp_im {
     bool save_gamma = false, gamma_valid = false, estep_done = false;
     // ---- device -----------------------------------------------------------------------------------------------
     int device = 0;
+    hipStream_t stream3 = nullptr;         // third branch of the statistics (per-key gamma sums)
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: backward chain when it may overlap the forward one
-    hipEvent_t ev[15];                                  // 10..13: forward / backward interval of the eigen-free pre-pass; 14: span-1 scalars done
+    hipEvent_t ev[18];                                  // 10..13: forward / backward interval of the eigen-free pre-pass; 14: span-1 scalars done
     int dual_stream = 1;
     bool chains_dual = false;
     DevBuf<RowInfo> d_rowinfo;
@@ -315,6 +316,7 @@ struct smcpp_im {
             for (auto &e : ev) (void)hipEventDestroy(e);
             (void)hipStreamDestroy(stream);
             if (stream2) (void)hipStreamDestroy(stream2);
+            if (stream3) (void)hipStreamDestroy(stream3);
         }
         if (d_param) (void)hipFree(d_param);
         if (d_pre) (void)hipFree(d_pre);
@@ -455,6 +457,7 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
     HIPCHK(hipGetDevice(&device));
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking));
     if (const char *d = getenv("SMCPP_DUAL_STREAM")) dual_stream = atoi(d);
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     make_chunks();
@@ -670,11 +673,13 @@ void smcpp_im::make_slabs() {
     // slabs = independent single-wavefront work items; several thousand keep the 2048 resident wavefronts of the
     // chip balanced on large inputs (each slab owns an Mp x Mp partial: at most 256 MB of them)
     const long long target = std::max<long long>(256, std::min<long long>(8192, (256ll << 20) / part_bytes));
-    // (at least 192 rows per slab: every slab costs an Mp x Mp partial written and read back, 128 MB of traffic per headline
-    // E-step with 64-row slabs)
-    int S_RK = (int)std::max<long long>(192, (n1 + target - 1) / target);
+    // (at least SMCPP_SLAB_ROWS rows per slab, default 128: every slab costs an Mp x Mp partial written and read back - 128 MB of
+    // traffic per headline E-step with 64-row slabs -, but a slab is walked by ONE wavefront, and below ~1000 slabs the rank
+    // kernels leave SIMDs idle: 64 .. 192 rows measured: 633 / 641 / 666 / 665 headline evals per second)
+    static const int slab_rows = getenv("SMCPP_SLAB_ROWS") ? std::max(16, atoi(getenv("SMCPP_SLAB_ROWS"))) : 128;
+    int S_RK = (int)std::max<long long>(slab_rows, (n1 + target - 1) / target);
     S_RK = (S_RK + 3) / 4 * 4;
-    int S_EG = (int)std::max<long long>(192, (ne + target - 1) / target);
+    int S_EG = (int)std::max<long long>(slab_rows, (ne + target - 1) / target);
     S_EG = (S_EG + 15) / 16 * 16;
     const int S_SC = 256;
     for (int c = 0; c < n_contigs; ++c) {
@@ -1948,11 +1953,13 @@ void smcpp_im::run_chains_ss() {
     bool first_round = true;
     int q = -1;
     while (true) {
+        HIPCHK(hipEventRecord(ev[3], s));
+        // optimistic, as run_chains(): the statistics are queued right behind the passes, the flag read-back behind them (the host
+        // only looks at the flags after the synchronisation; in the rare round that needs more passes the statistics are redone)
+        if (first_round && !save_gamma) enqueue_stats();
+        else stats_enqueued = false;
         HIPCHK(hipMemcpyAsync(chf, d_changed_f.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(chb, d_changed_b.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipEventRecord(ev[3], s));
-        if (first_round && !save_gamma) enqueue_stats();       // optimistic, as run_chains()
-        else stats_enqueued = false;
         HIPCHK(hipStreamSynchronize(s));
         first_round = false;
         q = first_quiet(chf, chb, ss_launched);
@@ -2017,27 +2024,57 @@ void smcpp_im::enqueue_stats() {
     fa.Z = d_Z.p; fa.Y = d_Y.p; fa.xisum = d_xisum.p; fa.gsum = d_gsum.p; fa.gamma0 = d_gamma0.p;
     const int MMi = Mp * Mp;
     const int nb2 = ceil_div((long long)Mp * Mp, 256);
+    AccArgs aa;
+    aa.M = M; aa.Mp = Mp; aa.NB = (Mp + 63) / 64; aa.rowinfo = d_rowinfo.p; aa.alpha = d_alpha.p; aa.beta = d_beta.p;
+    aa.w1 = d_w1.p; aa.cnorm = d_cnorm.p; aa.E = d_E.p; aa.Xs = d_Xs.p; aa.Ys = d_Ys.p;
+    // Eigen-free statistics: the span fold (k_span_FH: ~20 serial steps on a few CUs) ends the longest dependency chain of the
+    // phase, so what it waits for - the rank accumulation of the span > 1 rows - goes FIRST and alone; the span-1 branches start
+    // behind it and run while the fold does
+    const bool rank2_early = eigfree && split_streams && !slabs_eg.empty();
+    if (rank2_early) {
+        if (aa.NB != 1) {
+            S1Args se_a;
+            se_a.M = M; se_a.Mp = Mp; se_a.nslabs = (int)slabs_eg.size(); se_a.slabs = d_slabs_eg.p; se_a.perm = d_perme.p;
+            se_a.alpha = d_alpha.p; se_a.beta = d_beta.p; se_a.cnorm = d_cnorm.p; se_a.w1 = d_w1.p; se_a.gpart = d_gpart.p;
+            se_a.gamma_rows = nullptr; se_a.only_w1 = 1;
+            launch_s1(NPL, se_a, se);
+        }
+        AccArgs ae = aa;
+        ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
+        hipLaunchKernelGGL(k_rank_acc<2>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
+        HIPCHK(hipEventRecord(ev[17], se));
+        HIPCHK(hipStreamWaitEvent(s, ev[17], 0));
+    }
     // ---- span-1 branch (main stream) ----
+    // M <= 64: k_rank_acc forms the weights itself, so the per-key gamma sums (k_s1_scalars + their reduction) are a third
+    // independent branch: own stream, joined before the finalisation
+    const bool s1_own = dual_stream && stream3 != nullptr && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_sc.empty();
+    hipStream_t s1s = s1_own ? stream3 : s;
+    if (s1_own) {
+        HIPCHK(hipEventRecord(ev[15], s));
+        HIPCHK(hipStreamWaitEvent(s1s, ev[15], 0));
+    }
     if (!slabs_sc.empty()) {
         S1Args sa;
         sa.M = M; sa.Mp = Mp; sa.nslabs = (int)slabs_sc.size(); sa.slabs = d_slabs_sc.p; sa.perm = d_perm1.p;
         sa.alpha = d_alpha.p; sa.beta = d_beta.p; sa.cnorm = d_cnorm.p; sa.w1 = d_w1.p; sa.gpart = d_gpart.p;
         sa.gamma_rows = save_gamma ? d_gamma_rows.p : nullptr;
         sa.only_w1 = 0;
-        launch_s1(NPL, sa, s);
-        if (split_streams) HIPCHK(hipEventRecord(ev[14], s));
+        launch_s1(NPL, sa, s1s);
+        if (s1_own) {
+            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, s1s,
+                               (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
+            HIPCHK(hipEventRecord(ev[16], s1s));
+        } else if (split_streams) HIPCHK(hipEventRecord(ev[14], s));
     }
-    AccArgs aa;
-    aa.M = M; aa.Mp = Mp; aa.NB = (Mp + 63) / 64; aa.rowinfo = d_rowinfo.p; aa.alpha = d_alpha.p; aa.beta = d_beta.p;
-    aa.w1 = d_w1.p; aa.cnorm = d_cnorm.p; aa.E = d_E.p; aa.Xs = d_Xs.p; aa.Ys = d_Ys.p;
     if (!slabs_rk.empty()) {
         aa.nslabs = (int)slabs_rk.size(); aa.slabs = d_slabs_rk.p; aa.perm = d_perm1.p; aa.permk = d_perm1k.p; aa.part = d_part_1.p;
         hipLaunchKernelGGL(k_rank_acc<0>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, s, aa);
     }
     // the per-key gamma sums only need the span-1 scalars: with two streams their reduction runs at the tail of the eigen
     // stream (which finishes earlier) instead of between the two rank-update kernels of the main one
-    const bool gsum_on_se = split_streams && !slabs_sc.empty();
-    if (!gsum_on_se)
+    const bool gsum_on_se = split_streams && !slabs_sc.empty() && !s1_own;
+    if (!gsum_on_se && !s1_own)
         hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, s,
                            (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
     hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), n_contigs, ZS), dim3(256), 0, s,
@@ -2052,10 +2089,12 @@ void smcpp_im::enqueue_stats() {
         se_a.M = M; se_a.Mp = Mp; se_a.nslabs = (int)slabs_eg.size(); se_a.slabs = d_slabs_eg.p; se_a.perm = d_perme.p;
         se_a.alpha = d_alpha.p; se_a.beta = d_beta.p; se_a.cnorm = d_cnorm.p; se_a.w1 = d_w1.p; se_a.gpart = d_gpart.p;
         se_a.gamma_rows = nullptr; se_a.only_w1 = 1;
-        if (aa.NB != 1) launch_s1(NPL, se_a, se);              // M <= 64: k_rank_acc<2> forms the weights itself
-        AccArgs ae = aa;
-        ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
-        hipLaunchKernelGGL(k_rank_acc<2>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
+        if (!rank2_early) {
+            if (aa.NB != 1) launch_s1(NPL, se_a, se);          // M <= 64: k_rank_acc<2> forms the weights itself
+            AccArgs ae = aa;
+            ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
+            hipLaunchKernelGGL(k_rank_acc<2>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
+        }
         if (!eb_gid.empty())                                     // ONE share per bucket: k_span_F reads it on its serial path
             hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), (unsigned)eb_gid.size(), 1), dim3(256), 0, se,
                                (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MMi, 1);
@@ -2128,6 +2167,7 @@ void smcpp_im::enqueue_stats() {
         HIPCHK(hipEventRecord(ev[9], se));
         HIPCHK(hipStreamWaitEvent(s, ev[9], 0));
     }
+    if (s1_own) HIPCHK(hipStreamWaitEvent(s, ev[16], 0));
     hipLaunchKernelGGL(k_fin_xisum, dim3(nb2, n_contigs), dim3(256), 0, s, fa);
     hipLaunchKernelGGL(k_fin_gamma, dim3(ceil_div((long long)(K + 1) * Mp, 256), n_contigs), dim3(256), 0, s, fa);
     if (save_gamma && n_e_rows > 0) {

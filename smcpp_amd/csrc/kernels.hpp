@@ -2190,9 +2190,9 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
             Ops o;
             o.valid = pk.x >= 0;
             const size_t row = (size_t)(sl.base + (o.valid ? pk.x : 1));
-            // MODE 2 with the whole state vector in this block (M <= 64): the weight 1 / (c_ell sum alpha_ell beta_ell) is formed here
-            // from the row's own alpha (one more 4 M bytes per row instead of a separate pass over alpha and beta)
-            const bool inl = MODE == 2 && a.NB == 1;
+            // the whole state vector in this block (M <= 64): the weight 1 / (c_ell sum alpha_ell beta_ell) is formed here from the
+            // row's own alpha (4 M bytes more per row; no pass over alpha and beta has to run first)
+            const bool inl = a.NB == 1;
             o.w = inl ? a.cnorm[row] : a.w1[row];
             const float *ap = a.alpha + (row - 1) * Mp;
             const double *bp = a.beta + row * Mp;
@@ -2212,7 +2212,7 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
             const Ops nxt = fetch_ops(pk1);          // operands of group r0 + 4 (all-zero past the end of the slab)
             double xa[4], yb[4];
             double wgt = cur.w;
-            if (MODE == 2 && a.NB == 1) {
+            if (a.NB == 1) {
                 double pp = 0.0;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) pp += kv[t] ? (double)cur.an[t] * cur.bp[t] : 0.0;

@@ -86,17 +86,19 @@ def test_two_ranks_match_single_manager(tmp_path, disjoint, use_model):
         k0, k1 = set(map(tuple, r[0]["local_keys"])), set(map(tuple, r[1]["local_keys"]))
         assert k0 - k1 and k1 - k0
     assert r[0]["keys"] == r[1]["keys"] == im.keys.tolist()
+    # a contig's chunk layout (hence where the chunk-parallel fixed point stops, within its tolerance: rows near a chunk start
+    # carry up to eps = 2e-6 / 1e-6 of relative error in alpha / beta) depends on what else its manager holds: the sharded run and
+    # the single manager agree to that tolerance, not bitwise (observed 2e-10 on the log-likelihood)
     for x in r:
-        assert abs(x["loglik"] - im.loglik()) <= 1e-12 * abs(im.loglik())
-        np.testing.assert_allclose(x["logliks"], im.logliks(), rtol=1e-13)
-    # every rank evaluates Q on the same reduced statistics: bitwise equal across ranks, and equal to the single
-    # manager up to the summation order over contigs (~1e-13)
+        assert abs(x["loglik"] - im.loglik()) <= 1e-9 * abs(im.loglik())
+        np.testing.assert_allclose(x["logliks"], im.logliks(), rtol=1e-9)
+    # every rank evaluates Q on the same reduced statistics: bitwise equal across ranks
     assert r[0]["q"] == r[1]["q"]
-    np.testing.assert_allclose(r[0]["q"], im.Q(separate=True), rtol=1e-11)
+    np.testing.assert_allclose(r[0]["q"], im.Q(separate=True), rtol=1e-7)
     if use_model:
         assert r[0]["jac"] == r[1]["jac"]
         _, jac = im.Q_with_gradient()
-        np.testing.assert_allclose(np.array(r[0]["jac"]), jac, rtol=1e-9, atol=1e-9 * np.abs(jac).max())
+        np.testing.assert_allclose(np.array(r[0]["jac"]), jac, rtol=1e-6, atol=1e-7 * np.abs(jac).max())
 
 
 def _nccl_worker(rank, port, out_dir):

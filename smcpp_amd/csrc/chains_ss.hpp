@@ -28,7 +28,13 @@ namespace smcpp_dev {
 
 struct SsArgs {
     int M, Mp, nchunks, pass, K, nlds;   // nlds: emission vectors of key slots < nlds live in LDS, the rest comes from L2
-    const Chunk *chunks;
+    const Chunk *chunks;        // chunks of the forward chain
+    // The backward chain costs more per position (three scans against two) and forgets more slowly, so it gets MORE, SHORTER
+    // chunks than the forward chain: own chunk list; `tasks` assigns (direction << 30 | chunk) to every wavefront of the launch,
+    // -1 = none (one-chain-per-wavefront kernels only; the four-chains kernels use the same list for both directions)
+    const Chunk *chunks_b;
+    int nchunks_b;
+    const int *tasks;
     const int2 *rowdesc;        // [rows, padded] {key slot, span}
     const double *E;            // [K][MS] emission vectors by key slot, state order, zero padded (MS = 64 NPL)
     const float *pi_f;          // [Mp]
@@ -417,9 +423,9 @@ template <int NPL, bool RERUN>
 __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
-    const Chunk ch = a.chunks[c];
-    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
-    const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
+    const Chunk ch = a.chunks_b[c];
+    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks_b + c) * Mp;
+    const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks_b + c) * Mp;
     int st[NPL];
     bool live[NPL], stor[NPL];
 #pragma unroll
@@ -432,7 +438,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
     double b[NPL];
     {
         const bool fresh = ch.last || !RERUN;
-        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (fresh ? c : c + 1)) * Mp;
+        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks_b + (fresh ? c : c + 1)) * Mp;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) b[k] = live[k] ? (fresh ? 1.0 / (double)M : src[st[k]]) : 0.0;
     }
@@ -744,8 +750,8 @@ template <int NPL>
 __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
-    const Chunk ch = a.chunks[c];
-    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
+    const Chunk ch = a.chunks_b[c];
+    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks_b + c) * Mp;
     int st[NPL];
     bool live[NPL], stor[NPL];
 #pragma unroll
@@ -753,7 +759,7 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
     float b[NPL];
     {
         const bool fresh = ch.last || pass == 0;
-        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (fresh ? c : c + 1)) * Mp;
+        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks_b + (fresh ? c : c + 1)) * Mp;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) b[k] = live[k] ? (fresh ? 1.f / (float)M : (float)src[st[k]]) : 0.f;
     }
@@ -826,15 +832,16 @@ __global__ __launch_bounds__(256) void k_chain_ss(SsArgs a) {
     constexpr int MS = 64 * NPL;
     extern __shared__ __attribute__((aligned(16))) double ss_lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const bool fwd = w < 2;
     // mode 3: the direction takes no part in this launch (its pass runs in the other layout's kernel)
     const bool idle_f = a.mode_f == 3 || (a.mode_f == 1 && a.changed_f[a.pass - 1] == 0);
     const bool idle_b = a.mode_b == 3 || (a.mode_b == 1 && a.changed_b[a.pass - 1] == 0);
     if (idle_f && idle_b) return;
     for (int idx = tid; idx < a.nlds * MS; idx += 256) ss_lds[idx] = a.E[idx];
     __syncthreads();
-    const int c = 2 * blockIdx.x + (w & 1);
-    if (c >= a.nchunks) return;
+    const int task = a.tasks[4 * blockIdx.x + w];
+    if (task < 0) return;
+    const bool fwd = !(task >> 30);
+    const int c = task & 0x3FFFFFFF;
     if (fwd) {
         if (idle_f) return;
         if (a.mode_f == 0) ss_forward_wave<NPL, false>(a, ss_lds, c, lane);

@@ -303,10 +303,10 @@ __device__ __forceinline__ void ss4_backward_wave(const SsArgs &a, const double 
     const int M = a.M, Mp = a.Mp, pass = a.pass;
     const int r = lane >> 4, q = lane & 15;
     const int c = cbase + r;
-    const bool exists = c < a.nchunks;
-    const Chunk ch = a.chunks[exists ? c : a.nchunks - 1];
-    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + (exists ? c : 0)) * Mp;
-    const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (exists ? c : 0)) * Mp;
+    const bool exists = c < a.nchunks_b;
+    const Chunk ch = a.chunks_b[exists ? c : a.nchunks_b - 1];
+    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks_b + (exists ? c : 0)) * Mp;
+    const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks_b + (exists ? c : 0)) * Mp;
     int st[SPL];
     bool live[SPL], stor[SPL];
 #pragma unroll
@@ -317,7 +317,7 @@ __device__ __forceinline__ void ss4_backward_wave(const SsArgs &a, const double 
     double b[SPL];
     {
         const bool fresh = ch.last || !RERUN;
-        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + ((fresh || !exists) ? (exists ? c : 0) : c + 1)) * Mp;
+        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks_b + ((fresh || !exists) ? (exists ? c : 0) : c + 1)) * Mp;
 #pragma unroll
         for (int k = 0; k < SPL; ++k) b[k] = (exists && live[k]) ? (fresh ? 1.0 / (double)M : src[st[k]]) : 0.0;
     }

@@ -225,6 +225,10 @@ struct smcpp_im {
     DevBuf<int2> d_rowdesc_ss;             // [rows, padded] {key slot, span}
     DevBuf<double> d_Fall;                 // [n_contigs Ke][smax][Mp][Mp] scratch of the span fold for M > 64 (k_span_big)
     SsArgs ss_args;
+    std::vector<Chunk> chunks_b;           // backward chunks of the scan chains (more and shorter than the forward ones)
+    std::vector<int> ss_tasks;             // (direction << 30 | chunk) per wavefront of a k_chain_ss launch
+    DevBuf<Chunk> d_chunks_b;
+    DevBuf<int> d_tasks;
     // four chains per wavefront (chains_ss4.hpp, M <= 64): the fp64 passes run on `chunks` (fine), the light passes on groups of
     // four of them (`chunks1`, coarse) and hand over the fine boundary vectors
     bool ss4 = false;
@@ -534,7 +538,7 @@ void smcpp_im::make_chunks() {
         // SIMD; chunks are cut by POSITIONS (sum of spans), the unit of work of these kernels.  Every chunk pays the same
         // ~3000 positions of re-run history however short it is (the chains forget with an e-fold of ~240 positions).
         static const int wpc = getenv("SMCPP_SS_WPC") ? std::max(1, atoi(getenv("SMCPP_SS_WPC"))) : 1;
-        slots = (long long)prop.multiProcessorCount * 2 * wpc * (ss4 ? 4 : 1);
+        const long long waves = (long long)prop.multiProcessorCount * 4 * wpc;      // one wavefront per SIMD (x wpc)
         std::vector<long long> cum;
         long long total_bins = 0;
         for (int c = 0; c < n_contigs; ++c)
@@ -542,34 +546,49 @@ void smcpp_im::make_chunks() {
                 const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
                 total_bins += ri.gid < 0 ? 1 : groups[ri.gid].span;
             }
-        const long long bpc = std::max<long long>(ss4 ? 512 : 1024, (total_bins + slots - 1) / slots);
-        chunks.clear();
         max_chunks_per_contig = 1;
-        for (int c = 0; c < n_contigs; ++c) {
-            const int L = Ls[c];
-            cum.assign((size_t)L + 1, 0);
-            for (int i = 1; i <= L; ++i) {
-                const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
-                cum[i] = cum[i - 1] + (ri.gid < 0 ? 1 : groups[ri.gid].span);
-            }
-            const int nc = (int)std::max<long long>(1, std::min<long long>(L, (cum[L] + bpc - 1) / bpc));
-            max_chunks_per_contig = std::max(max_chunks_per_contig, nc);
-            int prev = 0;
-            for (int j = 0; j < nc; ++j) {
-                int r1;
-                if (j == nc - 1) r1 = L;
-                else {
-                    const long long target = cum[L] * (j + 1) / nc;
-                    r1 = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
-                    r1 = std::max(prev + 1, std::min(r1, L - (nc - 1 - j)));
+        auto cut = [&](long long nslots, long long floor_bins, std::vector<Chunk> &out) {
+            const long long bpc = std::max<long long>(floor_bins, (total_bins + nslots - 1) / nslots);
+            out.clear();
+            for (int c = 0; c < n_contigs; ++c) {
+                const int L = Ls[c];
+                cum.assign((size_t)L + 1, 0);
+                for (int i = 1; i <= L; ++i) {
+                    const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
+                    cum[i] = cum[i - 1] + (ri.gid < 0 ? 1 : groups[ri.gid].span);
                 }
-                Chunk ch;
-                ch.base = contig_base[c];
-                ch.r0 = prev; ch.r1 = r1; ch.contig = c;
-                ch.first = (j == 0); ch.last = (j == nc - 1); ch.pad = 0;
-                chunks.push_back(ch);
-                prev = r1;
+                const int nc = (int)std::max<long long>(1, std::min<long long>(L, (cum[L] + bpc - 1) / bpc));
+                max_chunks_per_contig = std::max(max_chunks_per_contig, nc);
+                int prev = 0;
+                for (int j = 0; j < nc; ++j) {
+                    int r1;
+                    if (j == nc - 1) r1 = L;
+                    else {
+                        const long long target = cum[L] * (j + 1) / nc;
+                        r1 = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+                        r1 = std::max(prev + 1, std::min(r1, L - (nc - 1 - j)));
+                    }
+                    Chunk ch;
+                    ch.base = contig_base[c];
+                    ch.r0 = prev; ch.r1 = r1; ch.contig = c;
+                    ch.first = (j == 0); ch.last = (j == nc - 1); ch.pad = 0;
+                    out.push_back(ch);
+                    prev = r1;
+                }
             }
+        };
+        if (ss4) {
+            cut(waves * 2, 512, chunks);          // fine chunks: four chains per wavefront, half the wavefronts per direction
+            chunks_b = chunks;
+        } else {
+            // the forward chain gets SMCPP_SS_FWD_SHARE of the wavefronts.  Default one half: the backward chain's light position
+            // costs 38 instructions against 25, but the fp64 passes of the two directions take the same time (forward: stores, the
+            // reciprocal and the feedback of the stored vector per row), and measured on the headline 0.45 / 0.42 / 0.38 / 0.34 lose
+            // 6 / 12 / 28 / 37 % of chain time against 0.5
+            static const double share = getenv("SMCPP_SS_FWD_SHARE") ? atof(getenv("SMCPP_SS_FWD_SHARE")) : 0.5;
+            const long long nf = std::max<long long>(1, (long long)(share * (double)waves + 0.5));
+            cut(nf, 1024, chunks);
+            cut(std::max<long long>(1, waves - nf), 1024, chunks_b);
         }
         max_pass = max_chunks_per_contig + 3 + 4;      // (+4: light passes)
         build_coarse_chunks();
@@ -604,6 +623,7 @@ void smcpp_im::make_chunks() {
     }
     max_pass = max_chunks_per_contig + 3;   // (+1: the full pass that follows an eigen-free pre-pass)
     if (ss_static) max_pass += 4;           // light passes of the scan chains
+    chunks_b = chunks;
     build_coarse_chunks();
 }
 
@@ -625,8 +645,25 @@ void smcpp_im::build_coarse_chunks() {
 }
 
 void smcpp_im::upload_chunk_state() {
-    const size_t nch = chunks.size();
+    const size_t nch = std::max(chunks.size(), chunks_b.size());
     d_chunks.upload(chunks, stream);
+    d_chunks_b.upload(chunks_b, stream);
+    {
+        // wavefront -> (direction, chunk) of the one-chain-per-wavefront launches: the two directions interleaved in proportion, so
+        // that every workgroup (4 wavefronts = the 4 SIMDs of a CU) holds its share of both; with the four-chains kernels in
+        // use these launches run the COARSE chunks (light passes)
+        const size_t nf = ss4 ? chunks1.size() : chunks.size(), nb = ss4 ? chunks1.size() : chunks_b.size();
+        ss_tasks.clear();
+        size_t i = 0, j = 0;
+        while (i < nf || j < nb) {
+            // next task: the direction that is behind its proportional share
+            const bool take_f = j >= nb || (i < nf && (double)i * (double)nb <= (double)j * (double)nf);
+            if (take_f) ss_tasks.push_back((int)i++);
+            else ss_tasks.push_back((1 << 30) | (int)j++);
+        }
+        while (ss_tasks.size() % 4) ss_tasks.push_back(-1);
+        d_tasks.upload(ss_tasks, stream);
+    }
     d_ends_f.alloc(2 * nch * Mp); d_used_f.alloc(nch * Mp);
     d_ends_b.alloc(2 * nch * Mp); d_used_b.alloc(nch * Mp);
     d_changed_f.alloc(max_pass + 1); d_changed_b.alloc(max_pass + 1);
@@ -1770,20 +1807,20 @@ bool smcpp_im::ss_extract_generators() {
 }
 
 template <int NPL_>
-static void launch_chain_ss_t(const SsArgs &a, size_t shm, hipStream_t s) {
+static void launch_chain_ss_t(const SsArgs &a, int ntasks, size_t shm, hipStream_t s) {
     static bool once = false;
     if (!once) {
         HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss<NPL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;
     }
-    hipLaunchKernelGGL((k_chain_ss<NPL_>), dim3((a.nchunks + 1) / 2), dim3(256), shm, s, a);
+    hipLaunchKernelGGL((k_chain_ss<NPL_>), dim3(ntasks / 4), dim3(256), shm, s, a);
 }
-static void launch_chain_ss(int npl, const SsArgs &a, size_t shm, hipStream_t s) {
+static void launch_chain_ss(int npl, const SsArgs &a, int ntasks, size_t shm, hipStream_t s) {
     switch (npl) {
-        case 1: launch_chain_ss_t<1>(a, shm, s); break;
-        case 2: launch_chain_ss_t<2>(a, shm, s); break;
-        case 3: launch_chain_ss_t<3>(a, shm, s); break;
-        case 4: launch_chain_ss_t<4>(a, shm, s); break;
+        case 1: launch_chain_ss_t<1>(a, ntasks, shm, s); break;
+        case 2: launch_chain_ss_t<2>(a, ntasks, shm, s); break;
+        case 3: launch_chain_ss_t<3>(a, ntasks, shm, s); break;
+        case 4: launch_chain_ss_t<4>(a, ntasks, shm, s); break;
         default: throw std::runtime_error("unsupported number of hidden states");
     }
 }
@@ -1821,7 +1858,7 @@ void smcpp_im::ss_launch_passes(int upto) {
             ss_args.mode_b = lb ? 2 : p == 0 ? 0 : 1;
             ss_args.full_f = (p > 0 && p == ss_light_f) ? 1 : 0;
             ss_args.full_b = (p > 0 && p == ss_light_b) ? 1 : 0;
-            launch_chain_ss(NPL, ss_args, shm, stream);
+            launch_chain_ss(NPL, ss_args, (int)ss_tasks.size(), shm, stream);
             continue;
         }
         // M <= 64: the light passes run on the coarse chunks (one chain per wavefront), the fp64 passes on the fine ones (four
@@ -1832,7 +1869,7 @@ void smcpp_im::ss_launch_passes(int upto) {
             ss_args.mode_b = lb ? 2 : 3;
             ss_args.hand_f = p == ss_light_f - 1;
             ss_args.hand_b = p == ss_light_b - 1;
-            launch_chain_ss(NPL, ss_args, shm, stream);
+            launch_chain_ss(NPL, ss_args, (int)ss_tasks.size(), shm, stream);
         }
         if (!lf || !lb) {
             ss4_args.pass = p;
@@ -1875,6 +1912,7 @@ void smcpp_im::ss_launch_initial() {
     a = SsArgs();
     a.M = M; a.Mp = Mp; a.nchunks = (int)chunks.size(); a.pass = 0; a.K = K; a.nlds = ss_nlds;
     a.chunks = d_chunks.p; a.rowdesc = d_rowdesc_ss.p + ROWDESC_PAD;
+    a.chunks_b = d_chunks_b.p; a.nchunks_b = (int)chunks_b.size(); a.tasks = d_tasks.p;
     a.pi_f = reinterpret_cast<const float *>(put(pi_f.data(), pi_f.size() * 4));
     const double *gd = reinterpret_cast<const double *>(put(ss_gen.data(), ss_gen.size() * 8));
     a.f_dc = gd; a.f_g = gd + MS; a.f_cg = gd + 2 * MS; a.f_b = gd + 3 * MS; a.f_a = gd + 4 * MS; a.f_d = gd + 5 * MS;
@@ -1909,6 +1947,7 @@ void smcpp_im::ss_launch_initial() {
         }
         // the light passes of the one-chain-per-wavefront kernels: coarse chunks, their own end vectors
         a.chunks = d_chunks1.p; a.nchunks = (int)chunks1.size();
+        a.chunks_b = d_chunks1.p; a.nchunks_b = (int)chunks1.size();
         a.ends_f = d_ends1_f.p; a.ends_b = d_ends1_b.p; a.used_f = nullptr; a.used_b = nullptr;
         a.fine = d_chunks.p; a.nfine = (int)chunks.size(); a.fine_ends_f = d_ends_f.p; a.fine_ends_b = d_ends_b.p;
     }
@@ -1919,10 +1958,12 @@ void smcpp_im::ss_launch_initial() {
         const int ef = getenv("SMCPP_SS_LIGHT_F") ? atoi(getenv("SMCPP_SS_LIGHT_F")) : -1;
         const int eb = getenv("SMCPP_SS_LIGHT_B") ? atoi(getenv("SMCPP_SS_LIGHT_B")) : -1;
         pos = ss_positions / std::max<size_t>(1, ss4 ? chunks1.size() : chunks.size());
-        auto pick = [&](double hist) { return pos <= 0 || (double)pos > 1.5 * hist ? 0 : std::min(4, (int)std::ceil(hist / (double)pos)); };
-        ss_light_f = ef >= 0 ? ef : pick(2800.0);
-        ss_light_b = eb >= 0 ? eb : pick(3900.0);
-        if ((ss4 ? chunks1.size() : chunks.size()) <= (size_t)n_contigs) ss_light_f = ss_light_b = 0;   // one chunk per contig: nothing to iterate
+        const long long pos_b = ss_positions / std::max<size_t>(1, ss4 ? chunks1.size() : chunks_b.size());
+        auto pick = [&](double hist, long long p_) { return p_ <= 0 || (double)p_ > 1.5 * hist ? 0 : std::min(4, (int)std::ceil(hist / (double)p_)); };
+        ss_light_f = ef >= 0 ? ef : pick(2800.0, pos);
+        ss_light_b = eb >= 0 ? eb : pick(3900.0, pos_b);
+        if ((ss4 ? chunks1.size() : chunks.size()) <= (size_t)n_contigs) ss_light_f = 0;      // one chunk per contig: nothing to iterate
+        if ((ss4 ? chunks1.size() : chunks_b.size()) <= (size_t)n_contigs) ss_light_b = 0;
     }
     a.dbg = nullptr;
     if (getenv("SMCPP_DEBUG_CYCLES")) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }

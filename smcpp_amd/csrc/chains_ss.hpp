@@ -622,6 +622,10 @@ __device__ __forceinline__ void ss_fwd_step_f(const SsLightC<NPL> &c, const floa
     ss_light_scan2(p_, z_, c.lv, c.c15, c.c31);
     S = lane_get(p_, 63);
     const float LIp = dpp0<DPP_WSHR1>(z_);
+    if (NPL == 1) {
+        out[0] = e[0] * __builtin_fmaf(c.dc[0], x[0], __builtin_fmaf(c.g[0], S, __builtin_fmaf(c.cg[0], p_, LIp)));
+        return;
+    }
     const float lex = p_ - lp[NPL - 1];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
@@ -651,6 +655,10 @@ __device__ __forceinline__ void ss_bwd_step_f(const SsLightC<NPL> &c, const floa
     const float Gtot = lane_get(p_, 63);
     Sw = lane_get(f_, 63);
     const float LIp = dpp0<DPP_WSHR1>(z_);
+    if (NPL == 1) {
+        out[0] = __builtin_fmaf(c.dc[0], w[0], (Gtot - p_) + __builtin_fmaf(c.c0, f_, c.b[0] * LIp));
+        return;
+    }
     const float lexg = p_ - lg[NPL - 1], lexf = f_ - lf[NPL - 1];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {

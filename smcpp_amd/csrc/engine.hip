@@ -223,6 +223,7 @@ struct smcpp_im {
     int ss_light_f = 0, ss_light_b = 0;    // light (float, store-free) passes per direction before the full fp64 pass
     std::vector<int> ss_slot_of_key;       // frequency rank of every key (slot 0 = most rows)
     DevBuf<int2> d_rowdesc_ss;             // [rows, padded] {key slot, span}
+    DevBuf<double> d_gpart2;               // [span-1 rank slabs][K][Mp] gamma partials of k_rank_acc_g
     DevBuf<double> d_Fall;                 // [n_contigs Ke][smax][Mp][Mp] scratch of the span fold for M > 64 (k_span_big)
     SsArgs ss_args;
     std::vector<Chunk> chunks_b;           // backward chunks of the scan chains (more and shorter than the forward ones)
@@ -2089,13 +2090,19 @@ void smcpp_im::enqueue_stats() {
     // ---- span-1 branch (main stream) ----
     // M <= 64: k_rank_acc forms the weights itself, so the per-key gamma sums (k_s1_scalars + their reduction) are a third
     // independent branch: own stream, joined before the finalisation
-    const bool s1_own = dual_stream && stream3 != nullptr && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_sc.empty();
+    // SMCPP_GAMMA_FUSE=1 (M <= 64 and K <= 64): the gamma sums ride on the span-1 rank update (k_rank_acc_g) and k_s1_scalars does
+    // not run at all: 110 MB less traffic per headline E-step, but 12 more fp64 MFMAs per group of four rows on the critical
+    // stream (v_mfma_f64_16x16x4 is a 16-pass instruction on gfx950): 0.285 ms of statistics against 0.235 ms with the gamma sums
+    // as a third concurrent branch - measured, so the fusion is opt-in
+    const bool gfuse_on = getenv("SMCPP_GAMMA_FUSE") && atoi(getenv("SMCPP_GAMMA_FUSE")) != 0;
+    const bool gfuse = gfuse_on && (Mp + 63) / 64 == 1 && K <= 64 && !save_gamma && !slabs_rk.empty();
+    const bool s1_own = !gfuse && dual_stream && stream3 != nullptr && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_sc.empty();
     hipStream_t s1s = s1_own ? stream3 : s;
     if (s1_own) {
         HIPCHK(hipEventRecord(ev[15], s));
         HIPCHK(hipStreamWaitEvent(s1s, ev[15], 0));
     }
-    if (!slabs_sc.empty()) {
+    if (!slabs_sc.empty() && !gfuse) {
         S1Args sa;
         sa.M = M; sa.Mp = Mp; sa.nslabs = (int)slabs_sc.size(); sa.slabs = d_slabs_sc.p; sa.perm = d_perm1.p;
         sa.alpha = d_alpha.p; sa.beta = d_beta.p; sa.cnorm = d_cnorm.p; sa.w1 = d_w1.p; sa.gpart = d_gpart.p;
@@ -2110,12 +2117,24 @@ void smcpp_im::enqueue_stats() {
     }
     if (!slabs_rk.empty()) {
         aa.nslabs = (int)slabs_rk.size(); aa.slabs = d_slabs_rk.p; aa.perm = d_perm1.p; aa.permk = d_perm1k.p; aa.part = d_part_1.p;
+        if (gfuse) {
+            d_gpart2.alloc((size_t)slabs_rk.size() * K * Mp);
+            switch ((K + 15) / 16) {
+                case 1: hipLaunchKernelGGL(k_rank_acc_g<1>, dim3(aa.nslabs), dim3(64), 0, s, aa, K, d_gpart2.p); break;
+                case 2: hipLaunchKernelGGL(k_rank_acc_g<2>, dim3(aa.nslabs), dim3(64), 0, s, aa, K, d_gpart2.p); break;
+                case 3: hipLaunchKernelGGL(k_rank_acc_g<3>, dim3(aa.nslabs), dim3(64), 0, s, aa, K, d_gpart2.p); break;
+                default: hipLaunchKernelGGL(k_rank_acc_g<4>, dim3(aa.nslabs), dim3(64), 0, s, aa, K, d_gpart2.p); break;
+            }
+            // gamma sums per contig: the slabs of a contig are contiguous (s1_slab_off), red_g is [contig][K][Mp]
+            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(K * Mp, 256), n_contigs, 1), dim3(256), 0, s,
+                               (const double *)d_gpart2.p, (const int *)d_s1_slab_off.p, d_red_g.p, K * Mp, 1);
+        } else
         hipLaunchKernelGGL(k_rank_acc<0>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, s, aa);
     }
     // the per-key gamma sums only need the span-1 scalars: with two streams their reduction runs at the tail of the eigen
     // stream (which finishes earlier) instead of between the two rank-update kernels of the main one
-    const bool gsum_on_se = split_streams && !slabs_sc.empty() && !s1_own;
-    if (!gsum_on_se && !s1_own)
+    const bool gsum_on_se = split_streams && !slabs_sc.empty() && !s1_own && !gfuse;
+    if (!gsum_on_se && !s1_own && !gfuse)
         hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, s,
                            (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
     hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), n_contigs, ZS), dim3(256), 0, s,

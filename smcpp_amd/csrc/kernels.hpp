@@ -2263,6 +2263,112 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K4g: the span-1 rank update WITH the per-key gamma sums (M <= 64, K <= 64): what k_s1_scalars + k_rank_acc<0> do in two
+// passes over alpha and beta, in one.  The gamma sums of a slab are a second rank update with a ONE-HOT left operand:
+//     Gs[key][state] = sum_rows [key_row == key] * (alpha_ell o beta_ell / p)[state]
+// A[m = key in tile][k = row of the group] is 0 / 1, B[k][n] = gamma_row: KT * NT more MFMAs per group of 4 rows, no second
+// read of the rows, no per-key row permutation.  Writes part[slab][Mp][Mp] and gpart[slab][K][Mp].
+// ---------------------------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(64) void k_rank_acc_g(AccArgs a, int K, double *__restrict__ gpart) {
+    const int lane = threadIdx.x;
+    const int m = lane & 15, qd = lane >> 4;
+    const Slab sl = a.slabs[blockIdx.x];
+    const int Mp = a.Mp, M = a.M;
+    f64x4 acc[4][4], gac[KT][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < KT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gac[i][j] = (f64x4){0, 0, 0, 0};
+    const int last = sl.end - 1;
+    auto fetch_pk = [&](int r0) {
+        const int r = r0 + qd;
+        int2 pk = a.permk[min(r, last)];
+        pk.x = (r <= last) ? pk.x : -1;
+        return pk;
+    };
+    struct Ops { double c; float ap[4], an[4]; double bp[4], ep[4]; int key; bool valid; };
+    int sc[4];
+    bool sv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int j = 16 * t + m; sv[t] = j < Mp; sc[t] = sv[t] ? j : 0; }
+    auto fetch_ops = [&](const int2 pk) {          // raw, unconditional loads (see k_rank_acc)
+        Ops o;
+        o.valid = pk.x >= 0;
+        o.key = pk.y;
+        const size_t row = (size_t)(sl.base + (o.valid ? pk.x : 1));
+        o.c = a.cnorm[row];
+        const float *ap = a.alpha + (row - 1) * Mp;
+        const double *bp = a.beta + row * Mp;
+        const double *ep = a.E + (size_t)pk.y * Mp;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { o.ap[t] = ap[sc[t]]; o.an[t] = ap[Mp + sc[t]]; o.bp[t] = bp[sc[t]]; o.ep[t] = ep[sc[t]]; }
+        return o;
+    };
+    int2 pk1 = fetch_pk(sl.start);
+    Ops cur = fetch_ops(pk1);
+    pk1 = fetch_pk(sl.start + 4);
+    for (int r0 = sl.start; r0 < sl.end; r0 += 4) {
+        const int2 pk2 = fetch_pk(r0 + 8);
+        const Ops nxt = fetch_ops(pk1);
+        double pp = 0.0, v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            v[t] = (sv[t] && 16 * t + m < M) ? (double)cur.an[t] * cur.bp[t] : 0.0;      // alpha_ell o beta_ell
+            pp += v[t];
+        }
+        const double p = row16_sum(pp);
+        const double ip = cur.valid ? 1.0 / p : 0.0;
+        const double wgt = ip / cur.c;                                       // 1 / (c_ell p), hmm.cpp:137-138
+        double xa[4], yb[4], gb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            xa[t] = sv[t] ? wgt * (double)cur.ap[t] : 0.0;
+            yb[t] = sv[t] ? cur.bp[t] * cur.ep[t] : 0.0;
+            gb[t] = v[t] * ip;                                               // gamma row (hmm.cpp:134-136)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], yb[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const double oh = (cur.valid && cur.key == 16 * kt + m) ? 1.0 : 0.0;     // A[m = key][k = qd]
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                gac[kt][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(oh, gb[j], gac[kt][j], 0, 0, 0);
+        }
+        cur = nxt;
+        pk1 = pk2;
+    }
+    double *out = a.part + (size_t)blockIdx.x * Mp * Mp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row = 16 * i + qd + 4 * rg, col = 16 * j + m;
+                if (row < Mp && col < Mp) out[(size_t)row * Mp + col] = acc[i][j][rg];
+            }
+    double *go = gpart + (size_t)blockIdx.x * K * Mp;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int key = 16 * kt + qd + 4 * rg, col = 16 * j + m;
+                if (key < K && col < Mp) go[(size_t)key * Mp + col] = gac[kt][j][rg];
+            }
+}
+
 // Packed per-rank statistics for the single all-reduce of a multi-GPU E-step, written straight into the caller's device
 // buffer:  out = [ sum loglik | gamma0 (M) | xisum (M*M) | gamma-sums by GLOBAL key index (Kg*M) ],
 // each summed over this rank's contigs in contig order (deterministic).  One thread per output element.

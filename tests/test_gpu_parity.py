@@ -752,3 +752,20 @@ def test_full_size_whole_genome_scan_vs_lockstep(monkeypatch):
         for k, v in gl[c].items():
             assert np.max(np.abs(g_scan[c][k] - v)) <= 2 * STAT_TOL * max(np.abs(v).max(), 1e-300), (c, k)
     np.testing.assert_allclose(q_scan, lock.Q(separate=True), rtol=2 * STAT_TOL)
+
+
+def test_gamma_sums_fused_into_the_rank_update(monkeypatch):
+    """SMCPP_GAMMA_FUSE=1: the per-key gamma sums as a one-hot rank update inside the span-1 rank kernel (k_rank_acc_g) instead of
+    k_s1_scalars; same goldens, same tolerances, and against the default path far below them."""
+    res = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("SMCPP_GAMMA_FUSE", fuse)
+        for name in ("G4_M64_n20_2Mbp", "G1_M16_n4", "G5_M48_twopop_layout"):
+            g = load_golden(name)
+            im = make_im(g)
+            im.E_step()
+            check_against(g, im, save_gamma=False)
+            res[(fuse, name)] = im.gamma_sums[0]
+    for name in ("G4_M64_n20_2Mbp", "G1_M16_n4", "G5_M48_twopop_layout"):
+        for k, v in res[("0", name)].items():
+            np.testing.assert_allclose(res[("1", name)][k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())

@@ -11,5 +11,5 @@ python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tai
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_c5 -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload c5 --steps 5 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_c3 -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload c3 --steps 5 > /dev/null 2>&1
-tools/dpp_lab > $GRAFT_REPO_ROOT/$O/dpp_lab.log 2>&1
+$GRAFT_REPO_ROOT/tools/dpp_lab > $GRAFT_REPO_ROOT/$O/dpp_lab.log 2>&1
 tail -1 $GRAFT_REPO_ROOT/$O/bench_default.log | cut -c1-300

@@ -179,6 +179,12 @@ struct smcpp_im {
     std::vector<int2> perm1k;
     std::vector<Slab> slabs_sc, slabs_rk, slabs_eg;   // span-1 scalar slabs, span-1 rank slabs, eigen slabs
     std::vector<int> gk_slab_off, s1_slab_off, eb_slab_off, eb_gid, ce_bucket_off, erow_slab;
+    // generation-2 eigen statistics (M <= 64): slabs over the sorted eigen rows of a (contig, eigen key) that MIX span groups
+    std::vector<Slab> slabs_ek;
+    std::vector<int> ek_slab_off, epos_gid;
+    DevBuf<Slab> d_slabs_ek;
+    DevBuf<int> d_ek_slab_off, d_epos_gid;
+    DevBuf<double> d_part_ek, d_red_ek;
     std::vector<int> ce_row_off;           // [n_contigs*Ke + 1] first position in perme of every (contig, eigen key)
     long long n_e_rows = 0, n_1_rows = 0;
     // ---- parameters -------------------------------------------------------------------------------------------
@@ -199,8 +205,9 @@ struct smcpp_im {
     int device = 0;
     hipStream_t stream3 = nullptr;         // third branch of the statistics (per-key gamma sums)
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: backward chain when it may overlap the forward one
-    hipEvent_t ev[18];                                  // 10..13: forward / backward interval of the eigen-free pre-pass; 14: span-1 scalars done
+    hipEvent_t ev[22];                                  // 10..13: forward / backward interval of the eigen-free pre-pass; 14: span-1 scalars done
     int dual_stream = 1;
+    hipStream_t stream_hi = nullptr;
     bool chains_dual = false;
     DevBuf<RowInfo> d_rowinfo;
     DevBuf<int2> d_rowdesc;
@@ -221,6 +228,11 @@ struct smcpp_im {
     int ss_launched = 0, last_ss_passes = 0;
     long long ss_positions = 0;            // sum of spans
     int ss_light_f = 0, ss_light_b = 0;    // light (float, store-free) passes per direction before the full fp64 pass
+    // opt-in warm start of the scan chains (smcpp_set_warm_start): the first pass of an E-step starts every chunk from the boundary
+    // vector the PREVIOUS converged E-step left (parity ss_warm_parity of the end-vector arrays) instead of pi / the uniform
+    // vector, and one light pass fewer runs; pass indices then start at ss_pass0 (1 or 2: the parity the first pass reads)
+    bool ss_warm_valid = false;
+    int ss_warm_parity = 0, ss_pass0 = 0;
     std::vector<int> ss_slot_of_key;       // frequency rank of every key (slot 0 = most rows)
     DevBuf<int2> d_rowdesc_ss;             // [rows, padded] {key slot, span}
     DevBuf<double> d_gpart2;               // [span-1 rank slabs][K][Mp] gamma partials of k_rank_acc_g
@@ -322,6 +334,7 @@ struct smcpp_im {
             (void)hipStreamDestroy(stream);
             if (stream2) (void)hipStreamDestroy(stream2);
             if (stream3) (void)hipStreamDestroy(stream3);
+            if (stream_hi) (void)hipStreamDestroy(stream_hi);
         }
         if (d_param) (void)hipFree(d_param);
         if (d_pre) (void)hipFree(d_pre);
@@ -463,6 +476,13 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking));
+    {
+        // the eigen-free statistics end in a serial fold on a few CUs: its branch gets a stream of the highest priority so that its
+        // workgroups are placed ahead of the chip-filling rank updates they run beside
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&stream_hi, hipStreamNonBlocking, greatest));
+    }
     if (const char *d = getenv("SMCPP_DUAL_STREAM")) dual_stream = atoi(d);
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     make_chunks();
@@ -591,7 +611,7 @@ void smcpp_im::make_chunks() {
             cut(nf, 1024, chunks);
             cut(std::max<long long>(1, waves - nf), 1024, chunks_b);
         }
-        max_pass = max_chunks_per_contig + 3 + 4;      // (+4: light passes)
+        max_pass = max_chunks_per_contig + 3 + 4 + 2;  // (+4: light passes, +2: a warm start numbers its passes from 1 or 2)
         build_coarse_chunks();
         return;
     }
@@ -646,6 +666,7 @@ void smcpp_im::build_coarse_chunks() {
 }
 
 void smcpp_im::upload_chunk_state() {
+    ss_warm_valid = false;
     const size_t nch = std::max(chunks.size(), chunks_b.size());
     d_chunks.upload(chunks, stream);
     d_chunks_b.upload(chunks_b, stream);
@@ -782,6 +803,23 @@ void smcpp_im::make_slabs() {
     ce_bucket_off[(size_t)n_contigs * Ke] = (int)eb_gid.size();
     ce_row_off[(size_t)n_contigs * Ke] = (int)perme.size();
     eb_slab_off.push_back((int)slabs_eg.size());
+    // generation-2 eigen slabs: the sorted eigen rows of every (contig, eigen key) cut into S_EG-row pieces regardless of the span
+    // groups; padded like slabs_eg so that a workgroup of four never mixes keys
+    slabs_ek.clear(); epos_gid.clear();
+    ek_slab_off.assign((size_t)n_contigs * Ke + 1, 0);
+    epos_gid.reserve(perme.size());
+    for (size_t q = 0; q < erow_slab.size(); ++q) epos_gid.push_back(slabs_eg[erow_slab[q]].aux);
+    for (int c = 0; c < n_contigs; ++c)
+        for (int e = 0; e < Ke; ++e) {
+            const size_t ce = (size_t)c * Ke + e;
+            const int q0 = ce_row_off[ce], q1 = ce_row_off[ce + 1];
+            if (q1 > q0) while (slabs_ek.size() % 4 != 0) { Slab pad = slabs_ek.back(); pad.start = pad.end; slabs_ek.push_back(pad); }
+            ek_slab_off[ce] = (int)slabs_ek.size();
+            for (int q = q0; q < q1; q += S_EG) slabs_ek.push_back(Slab{q, std::min(q + S_EG, q1), (int)ce, e, contig_base[c]});
+        }
+    // (a padding slab sits in front of the first slab of the next key: it belongs to the PREVIOUS (contig, key)'s range only if
+    // that range is recorded after it, so ranges are closed here, over the padded list)
+    ek_slab_off[(size_t)n_contigs * Ke] = (int)slabs_ek.size();
 }
 
 void smcpp_im::setup_power() {
@@ -880,6 +918,9 @@ void smcpp_im::alloc_device() {
     d_eb_gid.upload(eb_gid, s);
     d_ce_bucket_off.upload(ce_bucket_off, s);
     d_erow_slab.upload(erow_slab, s);
+    d_slabs_ek.upload(slabs_ek, s);
+    d_ek_slab_off.upload(ek_slab_off, s);
+    d_epos_gid.upload(epos_gid, s);
     d_contig_base.upload(contig_base, s);
     d_contig_L.upload(Ls, s);
     std::vector<int> gs(G), ge(G);
@@ -893,15 +934,21 @@ void smcpp_im::alloc_device() {
     d_cnorm.alloc((size_t)total_rows);
     d_logc.alloc((size_t)total_rows);
     d_w1.alloc((size_t)total_rows);
+    {
+        // blocks per contig of the log-likelihood reduction: ~2 000 rows each (64 blocks took 0.13 ms on a contig of a million rows)
+        int maxL = 0;
+        for (int c = 0; c < n_contigs; ++c) maxL = std::max(maxL, Ls[c]);
+        llblk = std::max(64, std::min(1024, (maxL + 2047) / 2048));
+    }
     d_llpart.alloc((size_t)n_contigs * llblk);
     d_loglik.alloc(n_contigs);
     d_gpart.alloc(std::max<size_t>(1, slabs_sc.size()) * Mp);
     // omega*U and W of the eigen rows only go through memory when the fused kernel cannot be used (M > 64)
     d_Xs.alloc(NT <= 4 ? 1 : std::max<size_t>(1, (size_t)n_e_rows) * Mp);
     d_Ys.alloc(NT <= 4 ? 1 : std::max<size_t>(1, (size_t)n_e_rows) * Mp);
-    d_part_e.alloc(std::max<size_t>(1, slabs_eg.size()) * Mp * Mp);
+    // (d_part_e / d_red_e - one M x M partial per span GROUP slab / bucket - are allocated where they are used: un-binned data have
+    // 10^5 groups and never take those paths when M <= 64)
     d_part_1.alloc(std::max<size_t>(1, slabs_rk.size()) * Mp * Mp);
-    d_red_e.alloc(std::max<size_t>(1, eb_gid.size()) * ZS * Mp * Mp);
     d_red_1.alloc((size_t)n_contigs * ZS * Mp * Mp);
     d_red_g.alloc((size_t)n_contigs * K * Mp);
     d_Z.alloc(std::max<size_t>(1, (size_t)n_contigs * Ke) * Mp * Mp);
@@ -1966,14 +2013,23 @@ void smcpp_im::ss_launch_initial() {
         if ((ss4 ? chunks1.size() : chunks.size()) <= (size_t)n_contigs) ss_light_f = 0;      // one chunk per contig: nothing to iterate
         if ((ss4 ? chunks1.size() : chunks_b.size()) <= (size_t)n_contigs) ss_light_b = 0;
     }
+    ss_pass0 = 0;
+    if (warm_start && ss_warm_valid && !ss4 && chunks.size() > (size_t)n_contigs && chunks_b.size() > (size_t)n_contigs) {
+        // the boundary vectors of the previous E-step are exact for ITS parameters, i.e. off by the parameter step instead of by
+        // O(1): they replace one light pass; every stored row still comes from the full fp64 pass on the new parameters
+        ss_pass0 = ss_warm_parity == 0 ? 1 : 2;
+        ss_light_f = ss_pass0 + std::max(0, ss_light_f - 1);
+        ss_light_b = ss_pass0 + std::max(0, ss_light_b - 1);
+    }
+    ss_warm_valid = false;                     // (set again when this E-step's chains have converged)
     a.dbg = nullptr;
     if (getenv("SMCPP_DEBUG_CYCLES")) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }
     HIPCHK(hipMemcpyAsync(d_pre, pre_stage.base, off, hipMemcpyHostToDevice, s));
     d_changed_f.zero(s);
     d_changed_b.zero(s);
     HIPCHK(hipEventRecord(ev[10], s));
-    ss_launched = 0;
-    const int want = std::min(max_pass, last_ss_passes > 0 ? last_ss_passes + 1 : std::min(max_pass, 6));
+    ss_launched = ss_pass0;
+    const int want = std::min(max_pass, ss_pass0 + (last_ss_passes > 0 ? last_ss_passes + 1 : 6));
     ss_launch_passes(want);
     HIPCHK(hipEventRecord(ev[11], s));
 }
@@ -1986,11 +2042,13 @@ void smcpp_im::run_chains_ss() {
         HIPCHK(hipHostMalloc((void **)&h_flags, sizeof(int) * h_flags_cap, hipHostMallocDefault));
     }
     int *chf = h_flags, *chb = h_flags + (max_pass + 1);
-    auto first_quiet = [](const int *cf, const int *cb, int upto) {
-        for (int j = 0; j < upto; ++j)
+    const int p0 = ss_pass0;
+    auto first_quiet = [p0](const int *cf, const int *cb, int upto) {
+        for (int j = p0; j < upto; ++j)
             if (cf[j] == 0 && cb[j] == 0) return j;
         return -1;
     };
+    ss_warm_valid = false;
     HIPCHK(hipEventRecord(ev[1], s));
     bool first_round = true;
     int q = -1;
@@ -2017,8 +2075,11 @@ void smcpp_im::run_chains_ss() {
                 "clocks, %lld x 10 ns, %lld positions, %lld rows\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     }
     if (q < 0) { stats_enqueued = false; throw std::runtime_error("chunk-boundary iteration did not converge"); }
-    last_ss_passes = q;
-    last_fwd_passes = last_bwd_passes = q;
+    last_ss_passes = q - p0;
+    last_fwd_passes = last_bwd_passes = q - p0;
+    // every launched pass carried the end vectors forward (a skipped chunk copies them): they sit at the last pass's parity
+    ss_warm_parity = (ss_launched - 1) & 1;
+    ss_warm_valid = !ss4;
 }
 
 void smcpp_im::run_stats() {
@@ -2046,24 +2107,31 @@ void smcpp_im::enqueue_stats() {
     // The eigen-row branch (U/W products, rank update, span-Q Hadamard, Y) does not depend on the span-1 branch
     // (log_c, omega_1, rank update); with two streams the short launches of one fill the gaps of the other.
     const bool split_streams = dual_stream && stream2 != nullptr && !slabs_eg.empty();
-    hipStream_t se = split_streams ? stream2 : s;
+    const int stats_variant = getenv("SMCPP_STATS_VARIANT") ? atoi(getenv("SMCPP_STATS_VARIANT")) : 0;
+    hipStream_t se = split_streams ? ((eigfree && (stats_variant & 1)) ? stream_hi : stream2) : s;
     if (split_streams) {
         HIPCHK(hipEventRecord(ev[8], s));
         HIPCHK(hipStreamWaitEvent(se, ev[8], 0));
     }
     // nothing in the statistics reads log_c any more (the span-1 weights take c itself): the two log-likelihood kernels
     // ride on the eigen stream instead of heading the critical path of the main one
-    hipStream_t sl = eigfree ? s : se;          // (the eigen-free branch of the second stream is the longer one)
+    // ... and on a third stream when there is one: on un-binned data (a million rows per contig) they take 0.1 ms
+    const bool ll_own = split_streams && stream3 != nullptr && !eigfree;     // (eigen-free: free at the head of the main stream, which waits there)
+    hipStream_t sl = ll_own ? stream3 : (eigfree ? s : se);          // (the eigen-free branch of the second stream is the longer one)
+    if (ll_own) HIPCHK(hipStreamWaitEvent(sl, ev[8], 0));
     hipLaunchKernelGGL(k_loglik_partial, dim3(llblk, n_contigs), dim3(256), 0, sl, la);
     hipLaunchKernelGGL(k_loglik_final, dim3(n_contigs), dim3(256), 0, sl, la);
+    if (ll_own) HIPCHK(hipEventRecord(ev[19], sl));
     FinArgs fa;
     fa.M = M; fa.Mp = Mp; fa.K = K; fa.G = G; fa.Ke = Ke; fa.n_contigs = n_contigs;
     fa.eb_slab_off = d_eb_slab_off.p; fa.eb_gid = d_eb_gid.p; fa.ce_bucket_off = d_ce_bucket_off.p;
     fa.s1_slab_off = d_s1_slab_off.p; fa.gk_slab_off = d_gk_slab_off.p; fa.g_span = d_g_span.p;
     fa.e_kid = d_e_kid.p; fa.dsc = d_dsc.p; fa.dun = d_dun.p; fa.Prm = d_Prm.p; fa.Pinvrm = d_Pinvrm.p;
-    fa.E = d_E.p; fa.Td = d_Td.p; fa.ZS = ZS; fa.red_e = d_red_e.p; fa.red_1 = d_red_1.p; fa.red_g = d_red_g.p;
+    fa.E = d_E.p; fa.Td = d_Td.p; fa.ZS = ZS; fa.red_e = nullptr; fa.red_1 = d_red_1.p; fa.red_g = d_red_g.p;
     fa.alpha = d_alpha.p; fa.beta = d_beta.p; fa.contig_base = d_contig_base.p;
     fa.Z = d_Z.p; fa.Y = d_Y.p; fa.xisum = d_xisum.p; fa.gsum = d_gsum.p; fa.gamma0 = d_gamma0.p;
+    fa.dpow = d_dpow.p;
+    fa.part_e = nullptr;
     const int MMi = Mp * Mp;
     const int nb2 = ceil_div((long long)Mp * Mp, 256);
     AccArgs aa;
@@ -2072,7 +2140,13 @@ void smcpp_im::enqueue_stats() {
     // Eigen-free statistics: the span fold (k_span_FH: ~20 serial steps on a few CUs) ends the longest dependency chain of the
     // phase, so what it waits for - the rank accumulation of the span > 1 rows - goes FIRST and alone; the span-1 branches start
     // behind it and run while the fold does
-    const bool rank2_early = eigfree && split_streams && !slabs_eg.empty();
+    const bool rank2_early = eigfree && split_streams && !slabs_eg.empty() && !(stats_variant & 2);
+    const bool eig_gen2 = !eigfree && NT <= 4 && !slabs_eg.empty() && !(getenv("SMCPP_EIG_GEN") && atoi(getenv("SMCPP_EIG_GEN")) == 1);
+    if (!slabs_eg.empty() && !eig_gen2) {
+        d_part_e.alloc(std::max<size_t>(1, slabs_eg.size()) * Mp * Mp);
+        fa.part_e = d_part_e.p;
+        if (eigfree) { d_red_e.alloc(std::max<size_t>(1, eb_gid.size()) * Mp * Mp); fa.red_e = d_red_e.p; }
+    }
     if (rank2_early) {
         if (aa.NB != 1) {
             S1Args se_a;
@@ -2159,20 +2233,17 @@ void smcpp_im::enqueue_stats() {
             hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), (unsigned)eb_gid.size(), 1), dim3(256), 0, se,
                                (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MMi, 1);
         const size_t shm = (size_t)2 * Mp * (Mp + 1) * sizeof(double);
-        if (NT > 4) {
-            // 64 < M <= 256: strips of 16 rows (F) / columns (H), one workgroup each, F_t through scratch
+        // SMCPP_SPAN_FH=1: the one-workgroup-per-(contig, key) fold (M <= 64) instead of the strip kernels
+        const bool use_fh = NT <= 4 && getenv("SMCPP_SPAN_FH") && atoi(getenv("SMCPP_SPAN_FH")) != 0;
+        if (!use_fh) {
+            // strips of 16 rows (F) / columns (H), one workgroup each, F_t through scratch
             d_Fall.alloc((size_t)n_contigs * Ke * ss_max_span * Mp * Mp);
             const int nstrip = NT, nwg = n_contigs * Ke * nstrip;
-            if (NT <= 8) {
-                hipLaunchKernelGGL((k_span_big<8, 0>), dim3(nwg), dim3(512), 0, se, fa, ss_max_span, d_Fall.p);
-                hipLaunchKernelGGL((k_span_big<8, 1>), dim3(nwg), dim3(512), 0, se, fa, ss_max_span, d_Fall.p);
-            } else if (NT <= 12) {
-                hipLaunchKernelGGL((k_span_big<12, 0>), dim3(nwg), dim3(768), 0, se, fa, ss_max_span, d_Fall.p);
-                hipLaunchKernelGGL((k_span_big<12, 1>), dim3(nwg), dim3(768), 0, se, fa, ss_max_span, d_Fall.p);
-            } else {
-                hipLaunchKernelGGL((k_span_big<16, 0>), dim3(nwg), dim3(1024), 0, se, fa, ss_max_span, d_Fall.p);
-                hipLaunchKernelGGL((k_span_big<16, 1>), dim3(nwg), dim3(1024), 0, se, fa, ss_max_span, d_Fall.p);
-            }
+#define B_(x) { hipLaunchKernelGGL((k_span_big<x, 0>), dim3(nwg), dim3(64 * x), 0, se, fa, ss_max_span, d_Fall.p); \
+                hipLaunchKernelGGL((k_span_big<x, 1>), dim3(nwg), dim3(64 * x), 0, se, fa, ss_max_span, d_Fall.p); }
+            if (NT == 1) B_(1) else if (NT == 2) B_(2) else if (NT == 3) B_(3) else if (NT == 4) B_(4)
+            else if (NT <= 8) B_(8) else if (NT <= 12) B_(12) else B_(16)
+#undef B_
         } else
         switch (NT) {
 #define S_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_span_FH<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
@@ -2182,11 +2253,40 @@ void smcpp_im::enqueue_stats() {
 #undef S_
         }
     }
-    if (!slabs_eg.empty() && !eigfree) {
+    if (eig_gen2) {
+        // generation 2 (M <= 64): slabs that mix span groups, the span-Q weighting inside the accumulation (k_eig_fused2)
+        UWArgs ua;
+        ua.M = M; ua.Mp = Mp; ua.nslabs = (int)slabs_ek.size(); ua.slabs = d_slabs_ek.p; ua.perm = d_perme.p;
+        ua.alpha = d_alpha.p; ua.beta = d_beta.p; ua.g_eig = d_g_eig.p; ua.g_scale = d_g_scale.p;
+        ua.dpow = d_dpow.p; ua.PinvT = d_PinvT.p; ua.Prm = d_Prm.p; ua.Xs = nullptr; ua.Ys = nullptr;
+        ua.pos_gid = d_epos_gid.p; ua.g_span = d_g_span.p;
+        const int nce = n_contigs * Ke;
+        const int LEN = MMi + Mp;                       // per slab: the M x M accumulator and the M diagonal sums
+        d_part_ek.alloc(std::max<size_t>(1, slabs_ek.size()) * LEN);
+        // shares of the cross-slab reduction: ~32 slabs each (un-binned data: thousands of slabs on a handful of (contig, key) pairs)
+        int max_sl = 1;
+        for (int ce = 0; ce < nce; ++ce) max_sl = std::max(max_sl, ek_slab_off[ce + 1] - ek_slab_off[ce]);
+        const int nsh = std::max(1, std::min(128, (max_sl + 31) / 32));
+        d_red_ek.alloc((size_t)nce * nsh * LEN);
+        const int nblk = ceil_div(ua.nslabs, 4);
+        const size_t shm = (size_t)2 * (16 * NT) * (16 * NT + 1) * sizeof(double);
+        switch (NT) {
+#define F_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_eig_fused2<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
+                    hipLaunchKernelGGL(k_eig_fused2<x>, dim3(nblk), dim3(256), shm, se, ua, d_part_ek.p); } break;
+            F_(1) F_(2) F_(3)
+            default: F_(4)
+#undef F_
+        }
+        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(LEN, 256), (unsigned)nce, nsh), dim3(256), 0, se,
+                           (const double *)d_part_ek.p, (const int *)d_ek_slab_off.p, d_red_ek.p, LEN, nsh);
+        hipLaunchKernelGGL(k_fin_Z2, dim3(nb2, nce), dim3(256), 0, se, fa, (const double *)d_red_ek.p, nsh);
+        hipLaunchKernelGGL(k_fin_Y, dim3(nb2, nce), dim3(256), 0, se, fa);
+    }
+    if (!slabs_eg.empty() && !eigfree && !eig_gen2) {
         UWArgs ua;
         ua.M = M; ua.Mp = Mp; ua.nslabs = (int)slabs_eg.size(); ua.slabs = d_slabs_eg.p; ua.perm = d_perme.p;
         ua.alpha = d_alpha.p; ua.beta = d_beta.p; ua.g_eig = d_g_eig.p; ua.g_scale = d_g_scale.p;
-        ua.dpow = d_dpow.p; ua.PinvT = d_PinvT.p; ua.Prm = d_Prm.p; ua.Xs = d_Xs.p; ua.Ys = d_Ys.p;
+        ua.dpow = d_dpow.p; ua.PinvT = d_PinvT.p; ua.Prm = d_Prm.p; ua.Xs = d_Xs.p; ua.Ys = d_Ys.p; ua.pos_gid = nullptr; ua.g_span = nullptr;
         if (NT <= 4) {
             const int nblk = ceil_div(ua.nslabs, 4);
             const size_t shm = (size_t)2 * (16 * NT) * (16 * NT + 1) * sizeof(double);
@@ -2203,11 +2303,9 @@ void smcpp_im::enqueue_stats() {
             ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
             hipLaunchKernelGGL(k_rank_acc<1>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
         }
-        if (!eb_gid.empty())
-            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), (unsigned)eb_gid.size(), ZS), dim3(256), 0, se,
-                               (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MMi, ZS);
+        // (no reduction pass over the slab partials: k_fin_Z sums the slabs of a bucket itself)
     }
-    if (Ke > 0 && !eigfree) {
+    if (Ke > 0 && !eigfree && !eig_gen2) {
         // slices of the groups of one (contig, key): enough blocks to fill the chip when there are many groups
         int max_b = 0;
         for (size_t ce = 0; ce + 1 < ce_bucket_off.size(); ++ce) max_b = std::max(max_b, ce_bucket_off[ce + 1] - ce_bucket_off[ce]);
@@ -2231,17 +2329,40 @@ void smcpp_im::enqueue_stats() {
     hipLaunchKernelGGL(k_fin_xisum, dim3(nb2, n_contigs), dim3(256), 0, s, fa);
     hipLaunchKernelGGL(k_fin_gamma, dim3(ceil_div((long long)(K + 1) * Mp, 256), n_contigs), dim3(256), 0, s, fa);
     if (save_gamma && n_e_rows > 0) {
-        d_Sq.alloc((size_t)G * Mp * Mp);
-        hipLaunchKernelGGL(k_span_q, dim3(nb2, G), dim3(256), 0, s, M, Mp, G, (const int *)d_g_span.p,
-                           (const int *)d_g_eig.p, (const double *)d_dsc.p, d_Sq.p);
         GammaRowArgs ga;
         ga.M = M; ga.Mp = Mp; ga.nrows = (int)n_e_rows; ga.perm = d_perme.p; ga.row_slab = d_erow_slab.p;
-        ga.slabs = d_slabs_eg.p; ga.g_eig = d_g_eig.p; ga.g_span = d_g_span.p; ga.dun = d_dun.p;
-        ga.Prm = d_Prm.p; ga.Pinvrm = d_Pinvrm.p; ga.PinvT = d_PinvT.p; ga.Sq = d_Sq.p;
+        ga.slabs = d_slabs_eg.p; ga.g_eig = d_g_eig.p; ga.g_span = d_g_span.p; ga.dun = d_dun.p; ga.dsc = d_dsc.p; ga.dpow = d_dpow.p;
+        ga.Prm = d_Prm.p; ga.Pinvrm = d_Pinvrm.p; ga.PinvT = d_PinvT.p; ga.Sq = nullptr;
         ga.alpha = d_alpha.p; ga.beta = d_beta.p; ga.gamma_rows = d_gamma_rows.p;
         static const bool scalar_rows = getenv("SMCPP_GAMMA_ROWS_SCALAR") != nullptr;
-        if (NT <= 4 && !scalar_rows) {
-            // matrix-core version: one launch per (contig, eigen key) so that a workgroup shares one LDS copy of P, Pinv
+        // SMCPP_GAMMA_ROWS_GEN=1: generation 1 of the matrix-core kernel (span-Q table in memory, scalar u / w)
+        static const int rows_gen = getenv("SMCPP_GAMMA_ROWS_GEN") ? atoi(getenv("SMCPP_GAMMA_ROWS_GEN")) : 2;
+        const bool mfma_rows = NT <= 4 && !scalar_rows;
+        if (!mfma_rows || rows_gen == 1) {
+            d_Sq.alloc((size_t)G * Mp * Mp);
+            hipLaunchKernelGGL(k_span_q, dim3(nb2, G), dim3(256), 0, s, M, Mp, G, (const int *)d_g_span.p,
+                               (const int *)d_g_eig.p, (const double *)d_dsc.p, (const double *)d_dpow.p, d_Sq.p);
+            ga.Sq = d_Sq.p;
+        }
+        if (mfma_rows && rows_gen != 1) {
+            // one launch per (contig, eigen key): a workgroup shares one LDS copy of P, Pinv and the reciprocal eigenvalue differences
+            const int NW = NT <= 2 ? 4 : 2;
+            const size_t shm2 = (size_t)(3 * Mp * (Mp + 1) + NW * (2 * 16 * (Mp + 1) + Mp * 17)) * sizeof(double);
+            for (int ce = 0; ce < n_contigs * Ke; ++ce) {
+                const int q0 = ce_row_off[ce], q1 = ce_row_off[ce + 1];
+                if (q1 <= q0) continue;
+                const int nbatch = std::max(1, std::min(4, (q1 - q0 + 16 * NW * 2048 - 1) / (16 * NW * 2048)));   // batches of 16 rows per wavefront
+                const int nblk = ceil_div(q1 - q0, 16 * NW * nbatch);
+                switch (NT) {
+#define G_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_gamma_rows_b<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
+                        hipLaunchKernelGGL(k_gamma_rows_b<x>, dim3(nblk), dim3(64 * (x <= 2 ? 4 : 2)), shm2, s, ga, q0, q1, ce % Ke, nbatch); } break;
+                    G_(1) G_(2) G_(3)
+                    default: G_(4)
+#undef G_
+                }
+            }
+        } else if (mfma_rows) {
+            // generation 1: one launch per (contig, eigen key) so that a workgroup shares one LDS copy of P, Pinv
             const size_t shm2 = (size_t)(2 * Mp * (Mp + 1) + 16 * Mp) * sizeof(double);
             for (int ce = 0; ce < n_contigs * Ke; ++ce) {
                 const int q0 = ce_row_off[ce], q1 = ce_row_off[ce + 1];
@@ -2267,6 +2388,7 @@ void smcpp_im::enqueue_stats() {
         h_ll_cap = n_contigs;
         HIPCHK(hipHostMalloc((void **)&h_ll, sizeof(double) * h_ll_cap, hipHostMallocDefault));
     }
+    if (ll_own) HIPCHK(hipStreamWaitEvent(s, ev[19], 0));
     HIPCHK(hipMemcpyAsync(h_ll, d_loglik.p, sizeof(double) * n_contigs, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(ev[5], s));
     stats_enqueued = true;
@@ -2283,6 +2405,7 @@ void smcpp_im::estep() {
         throw std::runtime_error("parameters are not set");
     HIPCHK(hipEventRecord(ev[0], stream));
     ss_active = ss_static && ss_extract_generators();
+    if (!ss_active) ss_warm_valid = false;
     {
         // span > 1 rows without an eigensystem (kernels.hpp: k_span_fold): the span is expanded by smax steps of two M x M products
         static const bool off = getenv("SMCPP_EIGFREE") && atoi(getenv("SMCPP_EIGFREE")) == 0;

@@ -1966,6 +1966,8 @@ struct UWArgs {
     const double *Prm;        // [Ke][Mp][Mp]
     double *Xs;               // [n eigen rows][Mp]  omega * U   (indexed by position in perm)
     double *Ys;               // [n eigen rows][Mp]  W
+    const int *pos_gid;       // [n eigen rows] group of every sorted position (k_eig_fused2: slabs that mix groups)
+    const int *g_span;        // [G]
 };
 
 template <int NT>   // NT = Mp / 16 state tiles
@@ -2125,6 +2127,137 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg)
                 out[(size_t)(16 * i + qd + 4 * rg) * Mp + 16 * j + m] = acc[i][j][rg];
+}
+
+// K5+K4 fused, generation 2 (round 3): slabs that MIX span groups.  The span-Q weighting that follows the accumulation,
+// Z = sum_g S_g o Acc_g with S_g[j][k] = (p_j - p_k) / (d_j - d_k), p = (d / scale)^span of the group, is linear in the group's
+// powers, so it moves inside the sum over rows:
+//     Z[j][k] = 1 / (d_j - d_k) * sum_rows [ (p_j omega u_j) w_k - (omega u_j) (p_k w_k) ]        (j != k)
+//     Z[j][j] = 1 / d_j * sum_rows span p_j omega u_j w_j
+// - two rank updates into ONE accumulator and one vector, whatever the spans of the rows are.  Un-binned data (posterior
+// decoding) have 10^5 groups of a handful of rows each: generation 1 wrote and re-read one M x M partial per GROUP (800 MB
+// each way on the posterior workload, and a [groups][8][M][M] reduction buffer), this one writes one per 128-row slab.
+// aux of a slab = its eigen key; the host pads the slab list so that a workgroup never mixes keys.
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_eig_fused2(UWArgs a, double *part) {
+    constexpr int KQ = 4 * NT;                 // states per lane of the k dimension: lane (m, qd) owns KQ*qd .. +KQ-1
+    constexpr int MT = 16 * NT;
+    constexpr int LD = MT + 1;
+    extern __shared__ double eig_lds[];        // [2][MT][LD]: Pinv^T and P of the eigen key of this block's first slab
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m = lane & 15, qd = lane >> 4;
+    const int Mp = a.Mp;
+    const int slab0 = blockIdx.x * 4;
+    const int es0 = a.slabs[slab0].aux;
+    {
+        const double *g0 = a.PinvT + (size_t)es0 * Mp * Mp, *g1 = a.Prm + (size_t)es0 * Mp * Mp;
+        for (int idx = threadIdx.x; idx < MT * MT; idx += 256) {
+            const int r = idx / MT, c = idx % MT;
+            eig_lds[r * LD + c] = g0[(size_t)r * Mp + c];
+            eig_lds[MT * LD + r * LD + c] = g1[(size_t)r * Mp + c];
+        }
+    }
+    __syncthreads();
+    const int slab = slab0 + wv;
+    if (slab >= a.nslabs) return;
+    const Slab sl = a.slabs[slab];
+    const double *sPinvT = eig_lds, *sPrm = eig_lds + MT * LD;
+    f64x4 acc[NT][NT];
+    double dgacc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        dgacc[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
+    }
+    double scale = 1.0;
+    if (sl.start < sl.end) scale = a.g_scale[a.pos_gid[sl.start]];          // the eigen scale belongs to the key
+    for (int r0 = sl.start; r0 < sl.end; r0 += 16) {
+        const int ra = min(r0 + m, sl.end - 1);
+        const int ell_a = a.perm[ra];
+        // D layout below: lane (m, qd), register r holds data row r0 + qd + 4 r: its group, span and powers
+        int gr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gr[r] = a.pos_gid[min(r0 + qd + 4 * r, sl.end - 1)];
+        const float4 *arow = reinterpret_cast<const float4 *>(a.alpha + (size_t)(sl.base + ell_a - 1) * Mp + KQ * qd);
+        const double2 *brow = reinterpret_cast<const double2 *>(a.beta + (size_t)(sl.base + ell_a) * Mp + KQ * qd);
+        double dp[4][NT], spn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            spn[r] = (double)a.g_span[gr[r]];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) dp[r][t] = a.dpow[(size_t)gr[r] * Mp + 16 * t + m];
+        }
+        f64x4 U[NT], W[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { U[t] = (f64x4){0, 0, 0, 0}; W[t] = (f64x4){0, 0, 0, 0}; }
+        float4 a4 = arow[0];
+        double2 b01 = brow[0], b23 = brow[1];
+#pragma unroll 1
+        for (int t4 = 0; t4 < NT; ++t4) {
+            const float avv[4] = {a4.x, a4.y, a4.z, a4.w};
+            const double bvv[4] = {b01.x, b01.y, b23.x, b23.y};
+            {
+                const int tn = min(t4 + 1, NT - 1);
+                a4 = arow[tn];
+                b01 = brow[2 * tn];
+                b23 = brow[2 * tn + 1];
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int st = KQ * qd + 4 * t4 + k4;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const double pinv = sPinvT[st * LD + 16 * t + m];
+                    const double pp = sPrm[st * LD + 16 * t + m];
+                    U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)avv[k4], pinv, U[t], 0, 0, 0);
+                    W[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(bvv[k4], pp, W[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double pr = 0.0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) pr += dp[r][t] * U[t][r] * W[t][r];
+            const double sm = row16_sum(pr);
+            const bool vr = r0 + qd + 4 * r < sl.end;        // padded rows must not contribute
+            const double om = vr ? 1.0 / (scale * sm) : 0.0;
+            double xa[NT], xp[NT], yp[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                xa[t] = om * U[t][r];
+                xp[t] = xa[t] * dp[r][t];
+                yp[t] = W[t][r] * dp[r][t];
+                dgacc[t] = fma(spn[r] * xp[t], W[t][r], dgacc[t]);
+                xa[t] = -xa[t];
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xp[i], W[j][r], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], yp[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    // partial of the slab: [Mp][Mp] accumulator followed by the [Mp] diagonal sums (ONE reduction pass takes both)
+    double *out = part + (size_t)slab * ((size_t)Mp * Mp + Mp);
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                out[(size_t)(16 * i + qd + 4 * rg) * Mp + 16 * j + m] = acc[i][j][rg];
+    // the diagonal sums: over the four lane groups (data rows qd + 4 r of every tile)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        double v = dgacc[t];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (qd == 0) out[(size_t)Mp * Mp + 16 * t + m] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2440,6 +2573,8 @@ struct FinArgs {
     double *gsum;             // [n_contigs][K][Mp]
     double *gamma0;           // [n_contigs][Mp]
     int eigfree;              // 1: Y holds W of k_span_fold, the first Mp entries of Z its diag(A W) (no eigensystem anywhere)
+    const double *dpow;       // [G][Mp] (d_r / scale)^span per group
+    const double *part_e;     // [eigen slabs][Mp][Mp] rank partials of the eigen rows (k_fin_Z sums a bucket's slabs itself)
 };
 
 // span_Qs entry (transition_bundle.cpp:29-59) evaluated on the fly
@@ -2451,6 +2586,19 @@ __device__ __forceinline__ double span_q_elem(const double *dsc, int a, int b, i
     if (d1 == d2) return pow(d1, span - 1) * (double)span;   // limit; the reference formula is 0/0 here
     const double q = exp((double)span * log(d1) + log1p(-pow(d2 / d1, span)));
     return q / (d1 - d2);
+}
+
+// The same entry from the group's eigenvalue powers pw[i] = dsc[i]^span (k_group_dpow): Q(a,b) = (d_a^s - d_b^s) / (d_a - d_b),
+// Q(a,a) = s d_a^(s-1) - one division instead of pow + exp + log + log1p per entry (un-binned data have 10^4 - 10^5 groups of
+// M^2 entries each: the transcendental form was 0.9 ms per posterior E-step).  Same conditioning as the reference's expression
+// (both take the difference of two nearly equal numbers when d_a is close to d_b); equal eigenvalues give the limit.
+__device__ __forceinline__ double span_q_pow(const double *dsc, const double *pw, int a, int b, int span) {
+    const double d1 = dsc[a], p1 = pw[a];
+    const double dg = d1 != 0.0 ? (double)span * p1 / d1 : 0.0;
+    if (a == b) return dg;
+    const double d2 = dsc[b];
+    if (d1 == d2) return dg;
+    return (p1 - pw[b]) / (d1 - d2);
 }
 
 // Z[(contig,e)][j][k] = sum over groups g of key e:  S_g[j][k] * Acc[contig][g][j][k]
@@ -2465,29 +2613,92 @@ __global__ __launch_bounds__(256) void k_fin_Z(FinArgs a) {
     if (idx >= Mp * Mp) return;
     const int j = idx / Mp, k = idx % Mp;
     const int nsl = gridDim.z, sl = blockIdx.z;
+    const size_t MM = (size_t)Mp * Mp;
     double z = 0.0;
     if (j < M && k < M) {
         const double *dsc = a.dsc + (size_t)e * Mp;
+        const double d1 = dsc[j], d2 = dsc[k];
+        const double id1 = d1 != 0.0 ? 1.0 / d1 : 0.0;
+        const bool same = j == k || d1 == d2;
+        const double idd = same ? 0.0 : 1.0 / (d1 - d2);
         const int b0 = a.ce_bucket_off[ce], b1 = a.ce_bucket_off[ce + 1];
         const int per = (b1 - b0 + nsl - 1) / nsl;
         const int lo = b0 + sl * per, hi = min(b1, lo + per);
-        for (int b = lo; b < hi; ++b) {
-            double acc = 0.0;
-            for (int zz = 0; zz < a.ZS; ++zz) acc += a.red_e[((size_t)b * a.ZS + zz) * Mp * Mp + idx];
-            z += span_q_elem(dsc, j, k, a.g_span[a.eb_gid[b]]) * acc;
+        // The slab partials of a bucket are summed HERE (un-binned data: one slab per group - a separate reduction pass only copied
+        // 245 MB), four buckets in flight: the chain  bucket -> group -> (span, powers, partial)  is two round trips per batch
+        // instead of two per bucket.
+        for (int b = lo; b < hi; b += 4) {
+            int gid[4], s0[4], s1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bu = min(b + u, hi - 1);
+                gid[u] = a.eb_gid[bu]; s0[u] = a.eb_slab_off[bu]; s1[u] = a.eb_slab_off[bu + 1];
+            }
+            double pa[4], pb[4], ac[4];
+            int spn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                spn[u] = a.g_span[gid[u]];
+                pa[u] = a.dpow[(size_t)gid[u] * Mp + j];
+                pb[u] = a.dpow[(size_t)gid[u] * Mp + k];
+                ac[u] = s1[u] > s0[u] ? a.part_e[(size_t)s0[u] * MM + idx] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                for (int q = s0[u] + 1; q < s1[u]; ++q) ac[u] += a.part_e[(size_t)q * MM + idx];
+                // span-Q entry from the powers (span_q_pow): (p_a - p_b) / (d_a - d_b), span d^(span-1) on the diagonal
+                const double qv = same ? (double)spn[u] * pa[u] * id1 : (pa[u] - pb[u]) * idd;
+                if (b + u < hi) z += qv * ac[u];
+            }
         }
     }
     double *out = nsl == 1 ? a.Z : a.Zpart;
-    out[((size_t)sl * gridDim.y + ce) * Mp * Mp + idx] = z;
+    out[((size_t)sl * gridDim.y + ce) * MM + idx] = z;
 }
+// Z of the key from the reduced generation-2 partials:  red [ce][nsh][Mp*Mp + Mp] (k_sum_parts in nsh shares)
+__global__ __launch_bounds__(256) void k_fin_Z2(FinArgs a, const double *red, int nsh) {
+    const int ce = blockIdx.y;
+    const int e = ce % a.Ke;
+    const int Mp = a.Mp, M = a.M;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Mp * Mp) return;
+    const int j = idx / Mp, k = idx % Mp;
+    const size_t MM = (size_t)Mp * Mp, LEN = MM + Mp;
+    double z = 0.0;
+    if (j < M && k < M) {
+        const double *dsc = a.dsc + (size_t)e * Mp;
+        const double d1 = dsc[j], d2 = dsc[k];
+        const bool diag = j == k;
+        if ((diag && d1 != 0.0) || (!diag && d1 != d2)) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            const double *rp = red + (size_t)ce * nsh * LEN + (diag ? MM + j : (size_t)idx);
+            int zz = 0;
+            for (; zz + 3 < nsh; zz += 4) {
+                s0 += rp[(size_t)zz * LEN]; s1 += rp[(size_t)(zz + 1) * LEN];
+                s2 += rp[(size_t)(zz + 2) * LEN]; s3 += rp[(size_t)(zz + 3) * LEN];
+            }
+            for (; zz < nsh; ++zz) s0 += rp[(size_t)zz * LEN];
+            z = ((s0 + s1) + (s2 + s3)) / (diag ? d1 : d1 - d2);
+        }
+    }
+    a.Z[(size_t)ce * MM + idx] = z;
+}
+
 __global__ __launch_bounds__(256) void k_fin_Zsum(FinArgs a, int nsl, int nce) {
     const int ce = blockIdx.y;
     const int MM = a.Mp * a.Mp;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= MM) return;
-    double z = 0.0;
-    for (int sl = 0; sl < nsl; ++sl) z += a.Zpart[((size_t)sl * nce + ce) * MM + idx];
-    a.Z[(size_t)ce * MM + idx] = z;
+    double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+    int sl = 0;
+    for (; sl + 3 < nsl; sl += 4) {
+        z0 += a.Zpart[((size_t)sl * nce + ce) * MM + idx];
+        z1 += a.Zpart[((size_t)(sl + 1) * nce + ce) * MM + idx];
+        z2 += a.Zpart[((size_t)(sl + 2) * nce + ce) * MM + idx];
+        z3 += a.Zpart[((size_t)(sl + 3) * nce + ce) * MM + idx];
+    }
+    for (; sl < nsl; ++sl) z0 += a.Zpart[((size_t)sl * nce + ce) * MM + idx];
+    a.Z[(size_t)ce * MM + idx] = (z0 + z1) + (z2 + z3);
 }
 
 // Y = Z * Pinv
@@ -2632,14 +2843,21 @@ __global__ __launch_bounds__(128 * NT) void k_span_FH(FinArgs a, int smax) {
         if (qd + 4 * r == m && 16 * sp + m < Mp) gout[16 * sp + m] = G[r];
 }
 
-// The same fold for 64 < M <= 256 (NTP = padded tile count 8 / 12 / 16): one workgroup of NTP wavefronts per 16-wide strip,
-// wavefront tt owns output tile tt of the strip and keeps ITS A fragments (MT/4 doubles per lane) in registers for all steps;
-// the strip (MT x 16) is exchanged through a double-buffered LDS copy, one barrier per step.  PHASE 0: F^T strips (rows of F),
-// F_t written to scratch;  PHASE 1: H strips (columns of H), W = H_0 and diag(A W) written at the end.
+// The same fold with one workgroup per 16-wide STRIP (NTP = padded tile count: 1 .. 4 for M <= 64, 8 / 12 / 16 up to 256): a
+// workgroup of NTP wavefronts, wavefront tt owns output tile tt of the strip and keeps ITS A fragments (MT/4 doubles per lane) in
+// registers for all steps; the strip (MT x 16) is exchanged through a double-buffered LDS copy, one barrier per step.
+// PHASE 0: F^T strips (rows of F), F_t written to scratch;  PHASE 1: H strips (columns of H), W = H_0 and diag(A W) written at
+// the end.  k_span_FH above keeps a (contig, key) on ONE CU, whose four matrix pipes then bound a step (2 x 16 tiles x 16 k-steps
+// x 64 cycles / 4 = 3.4 us); here a step is 16 MFMAs per wavefront.  What a step adds to the product (the Acc bucket of its span,
+// or F_t from the scratch) is fetched FOUR STEPS AHEAD with unconditional, index-clamped loads - on the serial path the three
+// dependent round trips bucket -> span -> matrix cost more than the product itself; the bucket of every step comes from a
+// small LDS table built once.
 template <int NTP, int PHASE>
 __global__ __launch_bounds__(64 * NTP) void k_span_big(FinArgs a, int smax, double *__restrict__ Fall) {
     constexpr int MT = 16 * NTP, LDX = 17;
     __shared__ double sX[2][MT * LDX];
+    __shared__ int sbk[64];                                           // bucket holding span t + 1, or -1 (smax <= 64)
+    __builtin_amdgcn_s_setprio(3);                                    // a serial chain of small products beside chip-filling kernels
     const int ns = (a.Mp + 15) / 16;                                  // strips that exist
     const int ce = blockIdx.x / ns, sp = blockIdx.x % ns, e = ce % a.Ke;
     const int b0 = a.ce_bucket_off[ce], b1 = a.ce_bucket_off[ce + 1];
@@ -2648,6 +2866,14 @@ __global__ __launch_bounds__(64 * NTP) void k_span_big(FinArgs a, int smax, doub
     const int m = lane & 15, qd = lane >> 4;
     const int Mp = a.Mp, M = a.M;
     const double *ek = a.E + (size_t)a.e_kid[e] * Mp;
+    if (PHASE == 0) {
+        for (int idx = tid; idx < 64; idx += 64 * NTP) sbk[idx] = -1;
+        __syncthreads();
+        for (int b = b0 + tid; b < b1; b += 64 * NTP) {
+            const int sp_ = a.g_span[a.eb_gid[b]];
+            if (sp_ >= 1 && sp_ <= 64) sbk[sp_ - 1] = b;
+        }
+    }
     // A operand of this wavefront's output tile, k = 4 kk + qd:  PHASE 0: A^T[16 tt + m][k] = e_k T[16 tt + m][k];  PHASE 1: A[16 tt + m][k] = e_i T[k][i]
     double af[MT / 4];
 #pragma unroll
@@ -2660,59 +2886,70 @@ __global__ __launch_bounds__(64 * NTP) void k_span_big(FinArgs a, int smax, doub
     // the strip starts at zero
     for (int idx = tid; idx < MT * LDX; idx += 64 * NTP) { sX[0][idx] = 0.0; sX[1][idx] = 0.0; }
     __syncthreads();
-    int bcur = b1 - 1;
     double *Fce = Fall + (size_t)ce * smax * Mp * Mp;
+    // element (row, column) this lane adds in register r:  PHASE 0: Acc[row of F = 16 sp + m][column of F = 16 tt + qd + 4 r];
+    // PHASE 1: F_t[row 16 tt + qd + 4 r][column 16 sp + m]
+    int eoff[4];
+    bool eok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = PHASE == 0 ? 16 * sp + m : 16 * tt + qd + 4 * r;
+        const int col = PHASE == 0 ? 16 * tt + qd + 4 * r : 16 * sp + m;
+        eok[r] = row < Mp && col < Mp;
+        eoff[r] = min(row, Mp - 1) * Mp + min(col, Mp - 1);
+    }
+    auto fetch = [&](int t, double (&v)[4]) {                          // raw loads; masked where they are consumed
+        const int tc = max(t, 0);
+        const double *src;
+        if (PHASE == 0) src = a.red_e + (size_t)max(sbk[tc], b0) * Mp * Mp;
+        else src = Fce + (size_t)tc * Mp * Mp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = src[eoff[r]];
+    };
+    // ring of PF steps in flight: beside the chip-filling rank updates a round trip to L2 / HBM takes several steps' worth of time
+    constexpr int PF = 4;
+    double q[PF][4];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) fetch(smax - 1 - d, q[d]);
     f64x4 X = {0, 0, 0, 0};
-    for (int t = smax - 1; t >= 0; --t) {
-        const int cur = (smax - 1 - t) & 1;
-        const double *sr = sX[cur];
-        double *sw = sX[cur ^ 1];
-        double av[4] = {0.0, 0.0, 0.0, 0.0};
-        double *Ft = Fce + (size_t)t * Mp * Mp;
-        if (PHASE == 0) {
-            const bool has = bcur >= b0 && a.g_span[a.eb_gid[bcur]] == t + 1;
-            if (has) {
+    for (int t0 = smax - 1; t0 >= 0; t0 -= PF) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {                         // Acc[row of F = 16 sp + m][column of F = 16 tt + qd + 4 r]
-                    const int row = 16 * sp + m, col = 16 * tt + qd + 4 * r;
-                    av[r] = (row < Mp && col < Mp) ? a.red_e[(size_t)bcur * Mp * Mp + (size_t)row * Mp + col] : 0.0;
-                }
-                --bcur;
-            }
-        } else {
+        for (int d = 0; d < PF; ++d) {
+            const int t = t0 - d;
+            if (t < 0) break;
+            const int cur = (smax - 1 - t) & 1;
+            const double *sr = sX[cur];
+            double *sw = sX[cur ^ 1];
+            const bool has = PHASE == 1 || sbk[t] >= 0;
+            double av[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {                             // F_t[row 16 tt + qd + 4 r][column 16 sp + m]
-                const int row = 16 * tt + qd + 4 * r, col = 16 * sp + m;
-                av[r] = (row < Mp && col < Mp) ? Ft[(size_t)row * Mp + col] : 0.0;
-            }
-        }
-        f64x4 Xn = {0, 0, 0, 0};
+            for (int r = 0; r < 4; ++r) av[r] = (has && eok[r]) ? q[d][r] : 0.0;
+            fetch(t - PF, q[d]);
+            f64x4 Xn = {0, 0, 0, 0};
 #pragma unroll 8
-        for (int kk = 0; kk < MT / 4; ++kk)
-            Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], sr[(4 * kk + qd) * LDX + m], Xn, 0, 0, 0);
+            for (int kk = 0; kk < MT / 4; ++kk)
+                Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], sr[(4 * kk + qd) * LDX + m], Xn, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            X[r] = Xn[r] + av[r];
-            sw[(16 * tt + qd + 4 * r) * LDX + m] = X[r];
-        }
-        if (PHASE == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {                             // F_t[row 16 sp + m][column 16 tt + qd + 4 r]
-                const int row = 16 * sp + m, col = 16 * tt + qd + 4 * r;
-                if (row < Mp && col < Mp) Ft[(size_t)row * Mp + col] = X[r];
+            for (int r = 0; r < 4; ++r) {
+                X[r] = Xn[r] + av[r];
+                sw[(16 * tt + qd + 4 * r) * LDX + m] = X[r];
             }
+            if (PHASE == 0) {
+                double *Ft = Fce + (size_t)t * Mp * Mp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)                           // F_t[row 16 sp + m][column 16 tt + qd + 4 r]
+                    if (eok[r]) Ft[eoff[r]] = X[r];
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (PHASE == 0) return;
     // W = H_0 strip; diag(A W): tile sp of A W, computed by wavefront sp from the final strip
     double *Wout = a.Y + (size_t)ce * Mp * Mp;
     double *gout = a.Z + (size_t)ce * Mp * Mp;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 16 * tt + qd + 4 * r, col = 16 * sp + m;
-        if (row < Mp && col < Mp) Wout[(size_t)row * Mp + col] = X[r];
-    }
+    for (int r = 0; r < 4; ++r)
+        if (eok[r]) Wout[eoff[r]] = X[r];
     if (tt == sp) {
         const double *sr = sX[smax & 1];
         f64x4 G = {0, 0, 0, 0};
@@ -2804,21 +3041,23 @@ struct GammaRowArgs {
     const int *g_eig;
     const int *g_span;
     const double *dun;        // [Ke][Mp]
+    const double *dsc;        // [Ke][Mp] scaled eigenvalues (what the span-Q entries are built from)
+    const double *dpow;       // [G][Mp] dsc^span per group
     const double *Prm, *Pinvrm, *PinvT;
-    const double *Sq;         // [G][Mp][Mp] span-Q tables
+    const double *Sq;         // [G][Mp][Mp] span-Q tables (k_gamma_rows_eig only)
     const float *alpha;
     const double *beta;
     double *gamma_rows;       // [rows][Mp]
 };
 
 __global__ __launch_bounds__(256) void k_span_q(int M, int Mp, int G, const int *g_span, const int *g_eig,
-                                                const double *dsc, double *Sq) {
+                                                const double *dsc, const double *dpow, double *Sq) {
     const int g = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= Mp * Mp) return;
     const int j = idx / Mp, k = idx % Mp;
     double v = 0.0;
-    if (j < M && k < M) v = span_q_elem(dsc + (size_t)g_eig[g] * Mp, j, k, g_span[g]);
+    if (j < M && k < M) v = span_q_pow(dsc + (size_t)g_eig[g] * Mp, dpow + (size_t)g * Mp, j, k, g_span[g]);
     Sq[(size_t)g * Mp * Mp + idx] = v;
 }
 
@@ -2995,6 +3234,185 @@ __global__ __launch_bounds__(256) void k_gamma_rows_mfma(GammaRowArgs a, int p0,
         const double tot = wave_sum(mine);
         if (lane < Mp) a.gamma_rows[row * Mp + lane] = (lane < M) ? (double)span * mine / tot : 0.0;
         wave_lds_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Generation 2 of the kernel above (round 3).  Same mathematics, same operand map; what changed:
+//   * u = d o (Pinv alpha), w = P^T beta of SIXTEEN rows at a time as two MFMA products (the rows of a launch share the key, so
+//     Pinv / P are common; the scalar dot products of generation 1 cost as many cycles as the M^3 product itself);
+//   * the span-Q entries are formed on the fly from the group's eigenvalue powers, S_ab = (p_a - p_b) * 1/(d_a - d_b) with the
+//     reciprocal differences in an LDS table per key: no [G][M][M] table in memory (245 MB on the posterior workload), no 8 KB
+//     of it through L2 per row, no k_span_q launch;
+//   * the fold's reduction over the 16 columns goes through a padded LDS tile (one write per value, 16 reads per state)
+//     instead of a DPP tree per value.
+// A wavefront walks `nbatch` batches of 16 consecutive rows (sorted by group: the powers are re-read only when the group changes).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT <= 2 ? 256 : 128) void k_gamma_rows_b(GammaRowArgs a, int p0, int p1, int es, int nbatch) {
+    constexpr int MT = 16 * NT, LD = MT + 1, NW = NT <= 2 ? 4 : 2, KS = MT / 4;
+    constexpr bool REG = NT <= 2;            // M <= 32: the lane's fragments of P, Pinv and the reciprocal differences live in registers
+    constexpr int NR = REG ? NT * KS : 1, NF = REG ? NT * NT * 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *sP = sm;                         // [MT][LD]  P row-major
+    double *sPinv = sP + MT * LD;            // [MT][LD]  Pinv row-major
+    double *sInvD = sPinv + MT * LD;         // [MT][LD]  1 / (d_a - d_b), 0 where the eigenvalues are equal
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *sU = sInvD + MT * LD + (size_t)wv * (2 * 16 * LD + MT * 17);   // per wavefront: x = d o u [16 rows][LD], w [16][LD], fold tile [MT][17]
+    double *sW = sU + 16 * LD, *sG = sW + 16 * LD;
+    const int Mp = a.Mp, M = a.M;
+    const double *dsc = a.dsc + (size_t)es * Mp, *dun = a.dun + (size_t)es * Mp;
+    {
+        const double *Prm = a.Prm + (size_t)es * Mp * Mp, *Pinvrm = a.Pinvrm + (size_t)es * Mp * Mp;
+        for (int idx = tid; idx < MT * MT; idx += 64 * NW) {
+            const int r = idx / MT, c = idx % MT;
+            sP[r * LD + c] = Prm[(size_t)r * Mp + c];
+            sPinv[r * LD + c] = Pinvrm[(size_t)r * Mp + c];
+            const double dd = dsc[r] - dsc[c];
+            sInvD[r * LD + c] = (dd != 0.0 && r < M && c < M) ? 1.0 / dd : 0.0;
+        }
+    }
+    __syncthreads();
+    const int kq = lane >> 4, n = lane & 15;
+    double invda[KS], dux[NT][4];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const int aa = 4 * kk + kq;
+        const double d = dsc[aa];
+        invda[kk] = (aa < M && d != 0.0) ? 1.0 / d : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = it * 16 + kq + 4 * r;
+            dux[it][r] = i < M ? dun[i] : 0.0;
+        }
+    double rP[NR], rID[NR], rF[NF];          // A fragments of P [it][kk], 1/(d_aa - d_bb) [bt][kk], Pinv[bb][i] of the fold [bt][it][r]
+    if (REG) {
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                rP[it * KS + kk] = sP[(it * 16 + n) * LD + 4 * kk + kq];
+                rID[it * KS + kk] = sInvD[(4 * kk + kq) * LD + it * 16 + n];
+            }
+#pragma unroll
+        for (int bt = 0; bt < NT; ++bt)
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rF[(bt * NT + it) * 4 + r] = sPinv[(bt * 16 + n) * LD + it * 16 + kq + 4 * r];
+    }
+    const int pw0 = p0 + (blockIdx.x * NW + wv) * nbatch * 16;
+    const int pw1 = min(p1, pw0 + nbatch * 16);
+    int gid_prev = -1, span = 1;
+    double pa[KS], sd[KS], pb[NT];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) { pa[kk] = 0.0; sd[kk] = 0.0; }
+#pragma unroll
+    for (int bt = 0; bt < NT; ++bt) pb[bt] = 0.0;
+    for (int pbat = pw0; pbat < pw1; pbat += 16) {
+        const int nb = min(16, pw1 - pbat);
+        // lane n describes row pbat + n: the row loop below reads group, span and row index with v_readlane (no dependent
+        // global loads on the per-row path)
+        const int pn = min(pbat + n, pw1 - 1);
+        const Slab sln = a.slabs[a.row_slab[pn]];
+        const int gid_n = sln.aux;
+        const long long rown = sln.base + a.perm[pn];
+        const int span_n = a.g_span[gid_n];
+        // ---- x = d o (Pinv alpha_{l-1}),  w = P^T beta_l for the 16 rows of the batch (column n of the products = row pbat + n) ----
+        {
+            const float *ap = a.alpha + (size_t)(rown - 1) * Mp;
+            const double *bp = a.beta + (size_t)rown * Mp;
+            f64x4 DU[NT], DW[NT];
+#pragma unroll
+            for (int it = 0; it < NT; ++it) { DU[it] = (f64x4){0, 0, 0, 0}; DW[it] = (f64x4){0, 0, 0, 0}; }
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int st = 4 * kk + kq;
+                const double av = (double)ap[st], bv = bp[st];
+#pragma unroll
+                for (int it = 0; it < NT; ++it) {
+                    DU[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(sPinv[(it * 16 + n) * LD + st], av, DU[it], 0, 0, 0);
+                    DW[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(sP[st * LD + it * 16 + n], bv, DW[it], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = it * 16 + kq + 4 * r;
+                    sU[n * LD + i] = DU[it][r] * dux[it][r];
+                    sW[n * LD + i] = DW[it][r];
+                }
+        }
+        wave_lds_fence();
+        for (int q = 0; q < nb; ++q) {
+            const int gid = __builtin_amdgcn_readlane(gid_n, q);
+            const size_t row = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)(rown >> 32), q) << 32) |
+                               (unsigned)__builtin_amdgcn_readlane((int)(rown & 0xffffffffll), q);
+            if (gid != gid_prev) {                                   // wave-uniform
+                gid_prev = gid;
+                span = __builtin_amdgcn_readlane(span_n, q);
+                const double *pw = a.dpow + (size_t)gid * Mp;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    pa[kk] = pw[4 * kk + kq];
+                    sd[kk] = (double)span * pa[kk] * invda[kk];      // span d^(span-1)
+                }
+#pragma unroll
+                for (int bt = 0; bt < NT; ++bt) pb[bt] = pw[16 * bt + n];
+            }
+            double xs[KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) xs[kk] = sU[q * LD + 4 * kk + kq];
+            double gacc[NT][4];
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gacc[it][r] = 0.0;
+#pragma unroll
+            for (int bt = 0; bt < NT; ++bt) {
+                const int bb = bt * 16 + n;
+                const double wb = sW[q * LD + bb];
+                f64x4 D[NT];
+#pragma unroll
+                for (int it = 0; it < NT; ++it) D[it] = (f64x4){0, 0, 0, 0};
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    const int aa = 4 * kk + kq;
+                    const double idf = REG ? rID[bt * KS + kk] : sInvD[aa * LD + bb];
+                    const double sq = (aa == bb) ? sd[kk] : (pa[kk] - pb[bt]) * idf;
+                    const double bf = xs[kk] * wb * sq;             // B[k = aa][n = bb] = (d u)_aa S_ab w_bb
+#pragma unroll
+                    for (int it = 0; it < NT; ++it)
+                        D[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(REG ? rP[it * KS + kk] : sP[(it * 16 + n) * LD + aa], bf, D[it], 0, 0, 0);
+                }
+#pragma unroll
+                for (int it = 0; it < NT; ++it)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        gacc[it][r] = fma(D[it][r], REG ? rF[(bt * NT + it) * 4 + r] : sPinv[bb * LD + it * 16 + kq + 4 * r], gacc[it][r]);
+            }
+            // g_i = sum over the columns: tile [i][n] through LDS, lane i sums its row
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sG[(it * 16 + kq + 4 * r) * 17 + n] = gacc[it][r];
+            wave_lds_fence();
+            double mine = 0.0;
+            if (lane < MT) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; c += 2) { s0 += sG[lane * 17 + c]; s1 += sG[lane * 17 + c + 1]; }
+                mine = lane < M ? fabs(s0 + s1) : 0.0;
+            }
+            const double tot = wave_sum(mine);
+            if (lane < Mp) a.gamma_rows[row * Mp + lane] = (double)span * mine / tot;
+            wave_lds_fence();
+        }
     }
 }
 

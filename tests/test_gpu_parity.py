@@ -556,6 +556,12 @@ def test_warm_start_matches_cold_start():
             assert np.max(np.abs(gw[k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300)
         tw, tc = warm.last_timing(), cold.last_timing()
         assert tw["fwd_passes"] <= tc["fwd_passes"] and tw["bwd_passes"] <= tc["bwd_passes"]
+    # a JUMP in parameter space: the stale boundary vectors are then no better than pi, the iteration has to absorb it
+    a2 = a0[::-1] * 2.5
+    mw[:] = a2; mc[:] = a2
+    warm.E_step(); cold.E_step()
+    assert abs(warm.loglik() - cold.loglik()) <= 1e-8 * abs(cold.loglik())
+    assert rel_err(warm.xisums[0], cold.xisums[0]) <= STAT_TOL
 
 
 @pytest.mark.parametrize("name", ["G1_M16_n4", "G3_M32_n10_2Mbp", "G4_M64_n20_2Mbp", "G7_M32_n8_chr11"])

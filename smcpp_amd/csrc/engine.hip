@@ -179,6 +179,13 @@ struct smcpp_im {
     std::vector<int2> perm1k;
     std::vector<Slab> slabs_sc, slabs_rk, slabs_eg;   // span-1 scalar slabs, span-1 rank slabs, eigen slabs
     std::vector<int> gk_slab_off, s1_slab_off, eb_slab_off, eb_gid, ce_bucket_off, erow_slab;
+    // fused span-1 statistics (M <= 64): single-key slabs over the key-sorted span-1 rows (perm1), with their ranges per contig
+    // (rank partials) and per (contig, key) (gamma partials)
+    std::vector<Slab> slabs_fk;
+    std::vector<int> fk_c_off, fk_gk_off;
+    DevBuf<Slab> d_slabs_fk;
+    DevBuf<int> d_fk_c_off, d_fk_gk_off;
+    DevBuf<double> d_gpart_fk;
     // generation-2 eigen statistics (M <= 64): slabs over the sorted eigen rows of a (contig, eigen key) that MIX span groups
     std::vector<Slab> slabs_ek;
     std::vector<int> ek_slab_off, epos_gid;
@@ -803,6 +810,22 @@ void smcpp_im::make_slabs() {
     ce_bucket_off[(size_t)n_contigs * Ke] = (int)eb_gid.size();
     ce_row_off[(size_t)n_contigs * Ke] = (int)perme.size();
     eb_slab_off.push_back((int)slabs_eg.size());
+    // single-key span-1 slabs in key-sorted order (k_rank_acc<3>)
+    slabs_fk.clear();
+    fk_c_off.assign(n_contigs + 1, 0);
+    fk_gk_off.assign((size_t)n_contigs * K + 1, 0);
+    for (int c = 0; c < n_contigs; ++c) {
+        fk_c_off[c] = (int)slabs_fk.size();
+        for (int k = 0; k < K; ++k) {
+            fk_gk_off[(size_t)c * K + k] = (int)slabs_fk.size();
+            const int g0 = gk_slab_off[(size_t)c * K + k], g1 = gk_slab_off[(size_t)c * K + k + 1];
+            if (g1 <= g0) continue;
+            const int q0 = slabs_sc[g0].start, q1 = slabs_sc[g1 - 1].end;       // the (contig, key) segment of perm1
+            for (int q = q0; q < q1; q += S_RK) slabs_fk.push_back(Slab{q, std::min(q + S_RK, q1), c, k, contig_base[c]});
+        }
+    }
+    fk_c_off[n_contigs] = (int)slabs_fk.size();
+    fk_gk_off[(size_t)n_contigs * K] = (int)slabs_fk.size();
     // generation-2 eigen slabs: the sorted eigen rows of every (contig, eigen key) cut into S_EG-row pieces regardless of the span
     // groups; padded like slabs_eg so that a workgroup of four never mixes keys
     slabs_ek.clear(); epos_gid.clear();
@@ -919,6 +942,9 @@ void smcpp_im::alloc_device() {
     d_ce_bucket_off.upload(ce_bucket_off, s);
     d_erow_slab.upload(erow_slab, s);
     d_slabs_ek.upload(slabs_ek, s);
+    d_slabs_fk.upload(slabs_fk, s);
+    d_fk_c_off.upload(fk_c_off, s);
+    d_fk_gk_off.upload(fk_gk_off, s);
     d_ek_slab_off.upload(ek_slab_off, s);
     d_epos_gid.upload(epos_gid, s);
     d_contig_base.upload(contig_base, s);
@@ -2137,6 +2163,7 @@ void smcpp_im::enqueue_stats() {
     AccArgs aa;
     aa.M = M; aa.Mp = Mp; aa.NB = (Mp + 63) / 64; aa.rowinfo = d_rowinfo.p; aa.alpha = d_alpha.p; aa.beta = d_beta.p;
     aa.w1 = d_w1.p; aa.cnorm = d_cnorm.p; aa.E = d_E.p; aa.Xs = d_Xs.p; aa.Ys = d_Ys.p;
+    aa.gpart = nullptr;
     // Eigen-free statistics: the span fold (k_span_FH: ~20 serial steps on a few CUs) ends the longest dependency chain of the
     // phase, so what it waits for - the rank accumulation of the span > 1 rows - goes FIRST and alone; the span-1 branches start
     // behind it and run while the fold does
@@ -2170,13 +2197,21 @@ void smcpp_im::enqueue_stats() {
     // as a third concurrent branch - measured, so the fusion is opt-in
     const bool gfuse_on = getenv("SMCPP_GAMMA_FUSE") && atoi(getenv("SMCPP_GAMMA_FUSE")) != 0;
     const bool gfuse = gfuse_on && (Mp + 63) / 64 == 1 && K <= 64 && !save_gamma && !slabs_rk.empty();
-    const bool s1_own = !gfuse && dual_stream && stream3 != nullptr && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_sc.empty();
+    // M <= 64, from half a million span-1 rows on: ONE pass over the span-1 rows in key-sorted order, single-key slabs - the rank
+    // update and the key's gamma sums from the same operands (k_rank_acc<3>); k_s1_scalars and its second read of alpha / beta do
+    // not run.  Measured: whole genome (3.6 M span-1 rows, bandwidth-bound) 3.77 -> 3.15 ms of statistics; one 100 Mbp contig
+    // (129 k rows, one wavefront per SIMD, latency-bound) 0.208 -> 0.225 ms - there the gamma sums stay a third concurrent
+    // branch.  SMCPP_S1_FUSE=0 / 1 forces either form.
+    const char *kf_env = getenv("SMCPP_S1_FUSE");
+    const bool kfuse = !gfuse && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_fk.empty() &&
+                       (kf_env ? atoi(kf_env) != 0 : n_1_rows >= 500000);
+    const bool s1_own = !gfuse && !kfuse && dual_stream && stream3 != nullptr && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_sc.empty();
     hipStream_t s1s = s1_own ? stream3 : s;
     if (s1_own) {
         HIPCHK(hipEventRecord(ev[15], s));
         HIPCHK(hipStreamWaitEvent(s1s, ev[15], 0));
     }
-    if (!slabs_sc.empty() && !gfuse) {
+    if (!slabs_sc.empty() && !gfuse && !kfuse) {
         S1Args sa;
         sa.M = M; sa.Mp = Mp; sa.nslabs = (int)slabs_sc.size(); sa.slabs = d_slabs_sc.p; sa.perm = d_perm1.p;
         sa.alpha = d_alpha.p; sa.beta = d_beta.p; sa.cnorm = d_cnorm.p; sa.w1 = d_w1.p; sa.gpart = d_gpart.p;
@@ -2189,6 +2224,17 @@ void smcpp_im::enqueue_stats() {
             HIPCHK(hipEventRecord(ev[16], s1s));
         } else if (split_streams) HIPCHK(hipEventRecord(ev[14], s));
     }
+    if (kfuse) {
+        d_part_1.alloc(std::max<size_t>(1, slabs_fk.size()) * Mp * Mp);
+        d_gpart_fk.alloc(slabs_fk.size() * Mp);
+        aa.nslabs = (int)slabs_fk.size(); aa.slabs = d_slabs_fk.p; aa.perm = d_perm1.p; aa.permk = nullptr; aa.part = d_part_1.p;
+        aa.gpart = d_gpart_fk.p;
+        hipLaunchKernelGGL(k_rank_acc<3>, dim3(aa.nslabs, 1), dim3(64), 0, s, aa);
+        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, s,
+                           (const double *)d_gpart_fk.p, (const int *)d_fk_gk_off.p, d_red_g.p, Mp, 1);
+        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), n_contigs, ZS), dim3(256), 0, s,
+                           (const double *)d_part_1.p, (const int *)d_fk_c_off.p, d_red_1.p, MMi, ZS);
+    } else
     if (!slabs_rk.empty()) {
         aa.nslabs = (int)slabs_rk.size(); aa.slabs = d_slabs_rk.p; aa.perm = d_perm1.p; aa.permk = d_perm1k.p; aa.part = d_part_1.p;
         if (gfuse) {
@@ -2207,10 +2253,11 @@ void smcpp_im::enqueue_stats() {
     }
     // the per-key gamma sums only need the span-1 scalars: with two streams their reduction runs at the tail of the eigen
     // stream (which finishes earlier) instead of between the two rank-update kernels of the main one
-    const bool gsum_on_se = split_streams && !slabs_sc.empty() && !s1_own && !gfuse;
-    if (!gsum_on_se && !s1_own && !gfuse)
+    const bool gsum_on_se = split_streams && !slabs_sc.empty() && !s1_own && !gfuse && !kfuse;
+    if (!gsum_on_se && !s1_own && !gfuse && !kfuse)
         hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, s,
                            (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
+    if (!kfuse)
     hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), n_contigs, ZS), dim3(256), 0, s,
                        (const double *)d_part_1.p, (const int *)d_s1_slab_off.p, d_red_1.p, MMi, ZS);
     HIPCHK(hipEventRecord(ev[4], s));

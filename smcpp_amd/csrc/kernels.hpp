@@ -2265,6 +2265,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 //   MODE 0 (span-1 rows, hmm.cpp:137-138):  X = w1 * alpha_{ell-1},  Y = beta_ell o e_key
 //   MODE 1 (eigen rows):                    X = Xs[pos] (= omega U), Y = Ys[pos] (= W)
 //   MODE 2 (span > 1 rows, eigen-free):     X = w1 * alpha_{ell-1},  Y = beta_ell   (k_span_fold expands the span afterwards)
+//   MODE 3 (span-1 rows, M <= 64, slabs of ONE key in key-sorted order): MODE 0 plus the key's gamma sums
+//           sum_rows alpha_ell o beta_ell / p_ell (hmm.cpp:134-136,146-148) from the operands the weight is formed from anyway -
+//           k_s1_scalars (a second pass over alpha and beta of every span-1 row) does not run
 // grid = (nslabs, NB*NB) with NB = ceil(Mp/64); blockIdx.y selects the 64x64 block of the M x M output.
 // ---------------------------------------------------------------------------------------------------------------
 struct AccArgs {
@@ -2280,6 +2283,7 @@ struct AccArgs {
     const double *E;
     const double *Xs, *Ys;
     double *part;             // [nslabs][Mp][Mp]
+    double *gpart;            // MODE 3: [nslabs][Mp] gamma sums of the slab's key
 };
 
 template <int MODE>
@@ -2294,7 +2298,7 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
-    if (MODE == 0 || MODE == 2) {
+    if (MODE == 0 || MODE == 2 || MODE == 3) {
         // Software pipeline over groups of 4 rows (the MFMA k dimension): the {ell, key} pair is fetched two groups
         // ahead and the operands one group ahead, so the dependent chain  index -> row -> operands  (three memory
         // round trips, measured 4.8 us per group against 0.43 us of MFMA) no longer serialises every group.
@@ -2306,7 +2310,7 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
             const int r = r0 + qd;
             int2 pk;
             if (MODE == 0) pk = a.permk[min(r, last)];
-            else { pk.x = a.perm[min(r, last)]; pk.y = 0; }
+            else { pk.x = a.perm[min(r, last)]; pk.y = MODE == 3 ? sl.aux : 0; }
             pk.x = (r <= last) ? pk.x : -1;
             return pk;
         };
@@ -2318,6 +2322,11 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
             const int j = jb + 16 * t + m, k = kb + 16 * t + m;
             jv[t] = j < Mp; kv[t] = k < Mp;
             jc[t] = jv[t] ? j : 0; kc[t] = kv[t] ? k : 0;
+        }
+        double ekc[4] = {1.0, 1.0, 1.0, 1.0}, gsum[4] = {0.0, 0.0, 0.0, 0.0};
+        if (MODE == 3) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ekc[t] = a.E[(size_t)sl.aux * Mp + kc[t]];
         }
         auto fetch_ops = [&](const int2 pk) {      // raw loads only; masking happens where the values are consumed
             Ops o;
@@ -2332,7 +2341,7 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
             const double *ep = a.E + (size_t)pk.y * Mp;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                o.ap[t] = ap[jc[t]]; o.bp[t] = bp[kc[t]]; o.ep[t] = MODE == 0 ? ep[kc[t]] : 1.0;
+                o.ap[t] = ap[jc[t]]; o.bp[t] = bp[kc[t]]; o.ep[t] = MODE == 0 ? ep[kc[t]] : MODE == 3 ? ekc[t] : 1.0;
                 o.an[t] = inl ? ap[Mp + kc[t]] : 0.f;
             }
             return o;
@@ -2349,7 +2358,14 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
                 double pp = 0.0;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) pp += kv[t] ? (double)cur.an[t] * cur.bp[t] : 0.0;
-                wgt = 1.0 / (cur.w * row16_sum(pp));
+                const double psum = row16_sum(pp);
+                wgt = 1.0 / (cur.w * psum);
+                if (MODE == 3) {
+                    const double ip = 1.0 / psum;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        gsum[t] += (cur.valid && kv[t]) ? (double)cur.an[t] * cur.bp[t] * ip : 0.0;
+                }
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -2363,6 +2379,16 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], yb[j], acc[i][j], 0, 0, 0);
             cur = nxt;
             pk1 = pk2;
+        }
+        if (MODE == 3) {
+            // lane (m, qd) summed the rows qd, qd + 4, ... of the slab at states kb + 16 t + m: fold the four lane groups
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                double v = gsum[t];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (qd == 0 && kb + 16 * t + m < Mp) a.gpart[(size_t)blockIdx.x * Mp + kb + 16 * t + m] = v;
+            }
         }
     } else {
         for (int r0 = sl.start; r0 < sl.end; r0 += 4) {

@@ -775,3 +775,25 @@ def test_gamma_sums_fused_into_the_rank_update(monkeypatch):
     for name in ("G4_M64_n20_2Mbp", "G1_M16_n4", "G5_M48_twopop_layout"):
         for k, v in res[("0", name)].items():
             np.testing.assert_allclose(res[("1", name)][k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
+
+
+def test_span1_statistics_one_pass_in_key_order(monkeypatch):
+    """SMCPP_S1_FUSE: the span-1 rank update and the per-key gamma sums in ONE pass over key-sorted single-key slabs (k_rank_acc<3>,
+    the default from half a million span-1 rows on) against the two-kernel form (k_s1_scalars + k_rank_acc<0>): same goldens, same
+    tolerances, and against each other far below them."""
+    res = {}
+    names = ("G4_M64_n20_2Mbp", "G3_M32_n10_2Mbp", "G1_M16_n4", "G5_M48_twopop_layout")
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("SMCPP_S1_FUSE", fuse)
+        for name in names:
+            g = load_golden(name)
+            im = make_im(g)
+            im.E_step()
+            check_against(g, im, save_gamma=False)
+            res[(fuse, name)] = (im.gamma_sums[0], im.xisums[0])
+    for name in names:
+        g0, x0 = res[("0", name)]
+        g1, x1 = res[("1", name)]
+        assert rel_err(x1, x0) <= 1e-11
+        for k, v in g0.items():
+            np.testing.assert_allclose(g1[k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())

@@ -239,6 +239,11 @@ struct smcpp_im {
     // vector the PREVIOUS converged E-step left (parity ss_warm_parity of the end-vector arrays) instead of pi / the uniform
     // vector, and one light pass fewer runs; pass indices then start at ss_pass0 (1 or 2: the parity the first pass reads)
     bool ss_warm_valid = false;
+    // the per-pass 'changed' flags of the scan chains are cleared right after they were read (on stream3, event ev[21]) instead of at
+    // the head of the next E-step's critical path
+    bool ss_flags_clean = false;
+    // lean E-steps copy the (small) parameter arena on stream2 while the chains run; the statistics wait for ev[20]
+    bool arena_side = false;
     int ss_warm_parity = 0, ss_pass0 = 0;
     std::vector<int> ss_slot_of_key;       // frequency rank of every key (slot 0 = most rows)
     DevBuf<int2> d_rowdesc_ss;             // [rows, padded] {key slot, span}
@@ -674,6 +679,7 @@ void smcpp_im::build_coarse_chunks() {
 
 void smcpp_im::upload_chunk_state() {
     ss_warm_valid = false;
+    if (ss_flags_clean) { HIPCHK(hipStreamSynchronize(stream3)); ss_flags_clean = false; }
     const size_t nch = std::max(chunks.size(), chunks_b.size());
     d_chunks.upload(chunks, stream);
     d_chunks_b.upload(chunks_b, stream);
@@ -1126,10 +1132,17 @@ void smcpp_im::host_prep_and_upload() {
     // transposed / row-major copies the kernels read and the eigenvalue powers of every (span, key) group, ONE
     // parallel region (task Ke packs the key-independent arrays)
     std::string err;
+    // scan chains + eigen-free statistics: nothing on the device reads the float / transposed copies of T or any eigenvector
+    // matrix - they are neither packed nor staged nor copied (M = 256: 7.5 MB through the pinned arena, 1 ms of host time)
+    const bool lean = eigfree && ss_active;
     auto pack_static = [&]() {
         if (static_packed) return;
         for (int i = 0; i < M; ++i) {
             pi_f[i] = (float)pi[i];
+            if (lean) {
+                for (int j = 0; j < M; ++j) Td[(size_t)i * Mp + j] = T[(size_t)i * M + j];
+                continue;
+            }
             for (int j = 0; j < M; ++j) {
                 Tf[(size_t)i * Mp + j] = (float)T[(size_t)i * M + j];
                 Td[(size_t)i * Mp + j] = T[(size_t)i * M + j];
@@ -1288,10 +1301,15 @@ void smcpp_im::host_prep_and_upload() {
                 }
     }
     // ---- one contiguous parameter arena on the device, mirrored in pinned host memory: ONE copy per E-step ----
+    static const std::vector<double> none_d;
+    static const std::vector<float> none_f;
+    const std::vector<float> &uTf = lean ? none_f : Tf;
+    const std::vector<double> &uTdT = lean ? none_d : TdT, &uPinvT = lean ? none_d : PinvT, &uPT = lean ? none_d : PT,
+                              &uPrm = lean ? none_d : Prm, &uPinvrm = lean ? none_d : Pinvrm;
     size_t need = 32 * 256;
     need += qTf.size() * 4 + (qTdT.size() + qPinvT.size() + qPT.size() + qPrm.size() + qPinvrm.size()) * 8;
-    need += (pi_f.size() + Tf.size() + T4.size()) * 4;
-    need += (TdT.size() + Td.size() + Ep.size() + PinvT.size() + PT.size() + Prm.size() + Pinvrm.size() + dsc.size() +
+    need += (pi_f.size() + uTf.size() + T4.size()) * 4;
+    need += (uTdT.size() + Td.size() + Ep.size() + uPinvT.size() + uPT.size() + uPrm.size() + uPinvrm.size() + dsc.size() +
              dun.size() + gsc.size() + gls.size() + fA2.size() + fB2.size() + bA2.size() + bB2.size() +
              bC2.size()) * 8;
     stage.reset(need);
@@ -1302,10 +1320,10 @@ void smcpp_im::host_prep_and_upload() {
     }
     size_t off = 0;
     char *hb = stage.base;
-    d_pi_f.place(pi_f, d_param, hb, off); d_Tf.place(Tf, d_param, hb, off); d_TdT.place(TdT, d_param, hb, off);
+    d_pi_f.place(pi_f, d_param, hb, off); d_Tf.place(uTf, d_param, hb, off); d_TdT.place(uTdT, d_param, hb, off);
     d_Td.place(Td, d_param, hb, off); d_E.place(Ep, d_param, hb, off);
-    d_PinvT.place(PinvT, d_param, hb, off); d_PT.place(PT, d_param, hb, off); d_Prm.place(Prm, d_param, hb, off);
-    d_Pinvrm.place(Pinvrm, d_param, hb, off);
+    d_PinvT.place(uPinvT, d_param, hb, off); d_PT.place(uPT, d_param, hb, off); d_Prm.place(uPrm, d_param, hb, off);
+    d_Pinvrm.place(uPinvrm, d_param, hb, off);
     d_dsc.place(dsc, d_param, hb, off); d_dun.place(dun, d_param, hb, off);
     d_g_scale.place(gsc, d_param, hb, off); d_g_logscale.place(gls, d_param, hb, off);
     if (Mp <= 64 && chain_mode == 1) {
@@ -1319,6 +1337,12 @@ void smcpp_im::host_prep_and_upload() {
     }
     if (off > need) throw std::runtime_error("internal: parameter arena overflow");
     auto tp2 = std::chrono::steady_clock::now();
+    arena_side = lean && stream2 != nullptr && dual_stream;
+    if (arena_side) {
+        // nothing the chains read lives in this arena: the copy runs beside them, the statistics wait for it
+        HIPCHK(hipMemcpyAsync(d_param, hb, off, hipMemcpyHostToDevice, stream2));
+        HIPCHK(hipEventRecord(ev[20], stream2));
+    } else
     HIPCHK(hipMemcpyAsync(d_param, hb, off, hipMemcpyHostToDevice, s));
     // (d_r / scale)^span for every (span, eigen key) group: G x M calls of pow() - 2 ms of host time on data with a few
     // thousand distinct spans, microseconds here
@@ -2051,8 +2075,9 @@ void smcpp_im::ss_launch_initial() {
     a.dbg = nullptr;
     if (getenv("SMCPP_DEBUG_CYCLES")) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }
     HIPCHK(hipMemcpyAsync(d_pre, pre_stage.base, off, hipMemcpyHostToDevice, s));
-    d_changed_f.zero(s);
-    d_changed_b.zero(s);
+    if (ss_flags_clean) HIPCHK(hipStreamWaitEvent(s, ev[21], 0));
+    else { d_changed_f.zero(s); d_changed_b.zero(s); }
+    ss_flags_clean = false;
     HIPCHK(hipEventRecord(ev[10], s));
     ss_launched = ss_pass0;
     const int want = std::min(max_pass, ss_pass0 + (last_ss_passes > 0 ? last_ss_passes + 1 : 6));
@@ -2094,6 +2119,13 @@ void smcpp_im::run_chains_ss() {
         ss_launch_passes(std::min(max_pass, ss_launched + 3));
     }
     chains_dual = false;
+    if (stream3 != nullptr && q >= 0) {
+        // the flags have been read: clear them for the next E-step off the critical path
+        d_changed_f.zero(stream3);
+        d_changed_b.zero(stream3);
+        HIPCHK(hipEventRecord(ev[21], stream3));
+        ss_flags_clean = true;
+    }
     if (ss_args.dbg) {
         long long h[8];
         HIPCHK(hipMemcpy(h, d_dbg.p, sizeof(h), hipMemcpyDeviceToHost));
@@ -2121,6 +2153,7 @@ void smcpp_im::finish_stats() {
 
 void smcpp_im::enqueue_stats() {
     hipStream_t s = stream;
+    if (arena_side) HIPCHK(hipStreamWaitEvent(s, ev[20], 0));
     // log-likelihood (also materialises log_c per row)
     LoglikArgs la;
     la.cnorm = d_cnorm.p; la.rowinfo = d_rowinfo.p; la.g_logscale = d_g_logscale.p;
@@ -2453,6 +2486,7 @@ void smcpp_im::estep() {
     HIPCHK(hipEventRecord(ev[0], stream));
     ss_active = ss_static && ss_extract_generators();
     if (!ss_active) ss_warm_valid = false;
+    if (!ss_active && ss_flags_clean) { HIPCHK(hipStreamWaitEvent(stream, ev[21], 0)); ss_flags_clean = false; }
     {
         // span > 1 rows without an eigensystem (kernels.hpp: k_span_fold): the span is expanded by smax steps of two M x M products
         static const bool off = getenv("SMCPP_EIGFREE") && atoi(getenv("SMCPP_EIGFREE")) == 0;

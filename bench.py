@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--eps-alpha", type=float, default=0.0)
     ap.add_argument("--eps-beta", type=float, default=0.0)
     ap.add_argument("--raw", action="store_true", help="time set_raw -> E_step -> loglik only (no cold preparation)")
+    ap.add_argument("--warm", action="store_true", help="additionally report the opt-in warm start (smcpp_set_warm_start) on a "
+                    "trajectory of perturbed parameters; never part of `value`")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -298,7 +300,7 @@ def main():
     # pass fewer).  An optimiser never evaluates the same point twice, so the models alternate between +-2 % perturbations of the
     # population sizes: every eval sees parameters ~4 % away from the previous eval's.
     warm = None
-    if args.workload in ("headline", "c2") and world == 1 and hasattr(im, "set_warm_start") and not args.raw:
+    if args.warm and args.workload in ("headline", "c2") and world == 1 and hasattr(im, "set_warm_start") and not args.raw:
         try:
             rng = np.random.default_rng(7)
             traj = [PiecewiseModel(np.asarray(a) * np.exp(0.02 * sgn * rng.standard_normal(len(a))), s_, 1e4, pid="pop1")

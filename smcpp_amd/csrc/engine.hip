@@ -232,6 +232,7 @@ struct smcpp_im {
     bool eigfree = false;                  // ... and its statistics need no eigensystem either (k_span_fold): no eigensolve at all
     int ss_max_span = 0;
     int ss_nlds = 0;                       // key slots whose emission vectors live in LDS
+    int ss_wpc = 1;                        // scan chains: wavefronts per SIMD (workgroups per CU) the chunk list is cut for
     int ss_launched = 0, last_ss_passes = 0;
     long long ss_positions = 0;            // sum of spans
     int ss_light_f = 0, ss_light_b = 0;    // light (float, store-free) passes per direction before the full fp64 pass
@@ -570,8 +571,6 @@ void smcpp_im::make_chunks() {
         // scan chains: one wavefront per chunk and direction, a workgroup = 2 forward + 2 backward chunks = one wavefront per
         // SIMD; chunks are cut by POSITIONS (sum of spans), the unit of work of these kernels.  Every chunk pays the same
         // ~3000 positions of re-run history however short it is (the chains forget with an e-fold of ~240 positions).
-        static const int wpc = getenv("SMCPP_SS_WPC") ? std::max(1, atoi(getenv("SMCPP_SS_WPC"))) : 1;
-        const long long waves = (long long)prop.multiProcessorCount * 4 * wpc;      // one wavefront per SIMD (x wpc)
         std::vector<long long> cum;
         long long total_bins = 0;
         for (int c = 0; c < n_contigs; ++c)
@@ -579,9 +578,49 @@ void smcpp_im::make_chunks() {
                 const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
                 total_bins += ri.gid < 0 ? 1 : groups[ri.gid].span;
             }
+        // Wavefronts per SIMD: one wavefront leaves a quarter of the issue slots empty (an instruction occupies the SIMD for 4 of
+        // the ~5.3 clocks between two issues of one wavefront), a second and third fill them - but every chunk pays ~3 000 positions
+        // of re-run history, so only inputs whose chunks stay long (>= 9 000 positions) take them.  Whole genome (28.7 M
+        // positions): 9.3 / 8.2 / 7.9 ms of chains with 1 / 2 / 3; a 3.4 M-position shard: 1.83 / 1.95 ms with 1 / 2.
+        const long long simds = (long long)prop.multiProcessorCount * 4;
+        ss_wpc = getenv("SMCPP_SS_WPC") ? std::max(1, std::min(4, atoi(getenv("SMCPP_SS_WPC"))))
+                                        : (int)std::max<long long>(1, std::min<long long>(3, total_bins / (simds * 9000)));
+        const long long waves = simds * ss_wpc;
         max_chunks_per_contig = 1;
+        // positions per contig
+        std::vector<long long> cpos(n_contigs, 0);
+        for (int c = 0; c < n_contigs; ++c)
+            for (int i = 1; i <= Ls[c]; ++i) {
+                const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
+                cpos[c] += ri.gid < 0 ? 1 : groups[ri.gid].span;
+            }
         auto cut = [&](long long nslots, long long floor_bins, std::vector<Chunk> &out) {
             const long long bpc = std::max<long long>(floor_bins, (total_bins + nslots - 1) / nslots);
+            // Chunks per contig: NEVER more chunks than wavefront slots in total (a launch of 1046 wavefronts on 1024 SIMDs puts two
+            // on some of them, and the kernel then lasts as long as those take: whole genome, 22 contigs each rounded up, +27 %).
+            // Start from the rounded-down share of every contig and hand the remaining slots, one at a time, to the contig whose
+            // chunks are currently the longest (minimises the longest chunk).
+            std::vector<int> ncs(n_contigs, 1);
+            {
+                long long used = 0;
+                for (int c = 0; c < n_contigs; ++c) {
+                    ncs[c] = (int)std::max<long long>(1, std::min<long long>(Ls[c], cpos[c] / bpc));
+                    used += ncs[c];
+                }
+                const long long want = std::max<long long>(n_contigs, std::min<long long>(nslots, (total_bins + bpc - 1) / bpc));
+                while (used < want) {
+                    int best = -1;
+                    double bl = 0.0;
+                    for (int c = 0; c < n_contigs; ++c) {
+                        if (ncs[c] >= Ls[c]) continue;
+                        const double len = (double)cpos[c] / ncs[c];
+                        if (best < 0 || len > bl) { best = c; bl = len; }
+                    }
+                    if (best < 0) break;
+                    ++ncs[best];
+                    ++used;
+                }
+            }
             out.clear();
             for (int c = 0; c < n_contigs; ++c) {
                 const int L = Ls[c];
@@ -590,7 +629,7 @@ void smcpp_im::make_chunks() {
                     const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
                     cum[i] = cum[i - 1] + (ri.gid < 0 ? 1 : groups[ri.gid].span);
                 }
-                const int nc = (int)std::max<long long>(1, std::min<long long>(L, (cum[L] + bpc - 1) / bpc));
+                const int nc = ncs[c];
                 max_chunks_per_contig = std::max(max_chunks_per_contig, nc);
                 int prev = 0;
                 for (int j = 0; j < nc; ++j) {
@@ -917,7 +956,7 @@ void smcpp_im::alloc_device() {
         ss_slot_of_key.assign(K, 0);
         for (int r = 0; r < K; ++r) ss_slot_of_key[order[r]] = r;
         const int MS = 64 * NPL;
-        ss_nlds = (int)std::min<long long>(K, (64 * 1024) / ((long long)MS * 8));
+        ss_nlds = (int)std::min<long long>(K, (std::min(64, 150 / std::max(1, ss_wpc)) * 1024) / ((long long)MS * 8));   // ss_wpc workgroups share a CU's 160 KB
         ss_positions = 0;
         for (int c = 0; c < n_contigs; ++c)
             for (int i = 1; i <= Ls[c]; ++i) {
@@ -2200,7 +2239,9 @@ void smcpp_im::enqueue_stats() {
     // Eigen-free statistics: the span fold (k_span_FH: ~20 serial steps on a few CUs) ends the longest dependency chain of the
     // phase, so what it waits for - the rank accumulation of the span > 1 rows - goes FIRST and alone; the span-1 branches start
     // behind it and run while the fold does
-    const bool rank2_early = eigfree && split_streams && !slabs_eg.empty() && !(stats_variant & 2);
+    // (small inputs only: from ~10^6 span > 1 rows on, the rank updates are bound by memory parallelism and the two of them
+    // running side by side finish sooner than one after the other - whole genome: 3.76 -> 3.36 ms of statistics)
+    const bool rank2_early = eigfree && split_streams && !slabs_eg.empty() && !(stats_variant & 2) && n_e_rows < 1000000;
     const bool eig_gen2 = !eigfree && NT <= 4 && !slabs_eg.empty() && !(getenv("SMCPP_EIG_GEN") && atoi(getenv("SMCPP_EIG_GEN")) == 1);
     if (!slabs_eg.empty() && !eig_gen2) {
         d_part_e.alloc(std::max<size_t>(1, slabs_eg.size()) * Mp * Mp);

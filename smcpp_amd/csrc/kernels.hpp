@@ -2287,7 +2287,7 @@ struct AccArgs {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_rank_acc(AccArgs a) {
     const int lane = threadIdx.x;
     const int m = lane & 15, qd = lane >> 4;
     const Slab sl = a.slabs[blockIdx.x];
@@ -2346,12 +2346,16 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
             }
             return o;
         };
+        // (round 3: TWO groups of operands in flight, descriptors three groups ahead - with one, a wavefront had 4 KB on its way
+        // during a ~2 us round trip: 2.4 TB/s on the whole genome)
         int2 pk1 = fetch_pk(sl.start);
         Ops cur = fetch_ops(pk1);
         pk1 = fetch_pk(sl.start + 4);
+        Ops nx1 = fetch_ops(pk1);
+        pk1 = fetch_pk(sl.start + 8);
         for (int r0 = sl.start; r0 < sl.end; r0 += 4) {
-            const int2 pk2 = fetch_pk(r0 + 8);
-            const Ops nxt = fetch_ops(pk1);          // operands of group r0 + 4 (all-zero past the end of the slab)
+            const int2 pk2 = fetch_pk(r0 + 12);
+            const Ops nxt = fetch_ops(pk1);          // operands of group r0 + 8 (all-zero past the end of the slab)
             double xa[4], yb[4];
             double wgt = cur.w;
             if (a.NB == 1) {
@@ -2377,7 +2381,8 @@ __global__ __launch_bounds__(64) void k_rank_acc(AccArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], yb[j], acc[i][j], 0, 0, 0);
-            cur = nxt;
+            cur = nx1;
+            nx1 = nxt;
             pk1 = pk2;
         }
         if (MODE == 3) {

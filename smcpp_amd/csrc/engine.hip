@@ -240,9 +240,6 @@ struct smcpp_im {
     // vector the PREVIOUS converged E-step left (parity ss_warm_parity of the end-vector arrays) instead of pi / the uniform
     // vector, and one light pass fewer runs; pass indices then start at ss_pass0 (1 or 2: the parity the first pass reads)
     bool ss_warm_valid = false;
-    // the per-pass 'changed' flags of the scan chains are cleared right after they were read (on stream3, event ev[21]) instead of at
-    // the head of the next E-step's critical path
-    bool ss_flags_clean = false;
     // lean E-steps copy the (small) parameter arena on stream2 while the chains run; the statistics wait for ev[20]
     bool arena_side = false;
     int ss_warm_parity = 0, ss_pass0 = 0;
@@ -314,6 +311,15 @@ struct smcpp_im {
     PinnedArena stage;
     char *d_param = nullptr;      // device side of the per-E-step parameter arena
     int *h_flags = nullptr;       // pinned: per-pass "something re-ran" flags of both chains, read back every round
+    // scan-chain E-steps: the chain kernels write their flags and the log-likelihood kernel its result STRAIGHT into pinned host
+    // memory (device views below) and a one-thread kernel at the end of the queue raises h_done; the host polls that word - no
+    // small copies or fills on the stream, no blocking wait (together ~30 us of a 1.4 ms eval)
+    int *d_flags_view = nullptr;  // device address of h_flags
+    double *d_ll_view = nullptr;  // device address of h_ll
+    int *h_done = nullptr, *d_done_view = nullptr;
+    int done_epoch = 0;
+    bool done_covers_stats = false;
+    bool wait_done(int epoch);
     double *h_ll = nullptr;       // pinned: per-contig log-likelihoods
     int h_flags_cap = 0, h_ll_cap = 0;
     size_t param_cap = 0;
@@ -353,6 +359,7 @@ struct smcpp_im {
         if (d_pre) (void)hipFree(d_pre);
         if (h_flags) (void)hipHostFree(h_flags);
         if (h_ll) (void)hipHostFree(h_ll);
+        if (h_done) (void)hipHostFree(h_done);
     }
 
     void build(int npop_, const int *nn, const int *nna, int n_contigs_, const int *Ls_, const int *const *obs,
@@ -718,7 +725,6 @@ void smcpp_im::build_coarse_chunks() {
 
 void smcpp_im::upload_chunk_state() {
     ss_warm_valid = false;
-    if (ss_flags_clean) { HIPCHK(hipStreamSynchronize(stream3)); ss_flags_clean = false; }
     const size_t nch = std::max(chunks.size(), chunks_b.size());
     d_chunks.upload(chunks, stream);
     d_chunks_b.upload(chunks_b, stream);
@@ -1778,7 +1784,8 @@ void smcpp_im::run_chains() {
     if (h_flags_cap < 2 * (max_pass + 1)) {
         if (h_flags) (void)hipHostFree(h_flags);
         h_flags_cap = 2 * (max_pass + 1);
-        HIPCHK(hipHostMalloc((void **)&h_flags, sizeof(int) * h_flags_cap, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&h_flags, sizeof(int) * h_flags_cap, hipHostMallocCoherent | hipHostMallocMapped));
+        d_flags_view = nullptr;
     }
     int *chf = h_flags, *chb = h_flags + (max_pass + 1);
     auto first_quiet = [](const int *ch, int upto) {
@@ -2065,7 +2072,23 @@ void smcpp_im::ss_launch_initial() {
     }
     a.alpha = d_alpha.p; a.beta = d_beta.p; a.cnorm = d_cnorm.p;
     a.ends_f = d_ends_f.p; a.used_f = d_used_f.p; a.ends_b = d_ends_b.p; a.used_b = d_used_b.p;
-    a.changed_f = d_changed_f.p; a.changed_b = d_changed_b.p;
+    {
+        // the per-pass flags live in pinned host memory: written by the kernels through its device view, cleared and read by the host
+        if (h_flags_cap < 2 * (max_pass + 1)) {
+            if (h_flags) (void)hipHostFree(h_flags);
+            h_flags_cap = 2 * (max_pass + 1);
+            HIPCHK(hipHostMalloc((void **)&h_flags, sizeof(int) * h_flags_cap, hipHostMallocCoherent | hipHostMallocMapped));
+            d_flags_view = nullptr;
+        }
+        if (!d_flags_view) HIPCHK(hipHostGetDevicePointer((void **)&d_flags_view, h_flags, 0));
+        if (!h_done) {
+            HIPCHK(hipHostMalloc((void **)&h_done, 64, hipHostMallocCoherent | hipHostMallocMapped));
+            *h_done = 0;
+            HIPCHK(hipHostGetDevicePointer((void **)&d_done_view, h_done, 0));
+        }
+        std::memset(h_flags, 0, sizeof(int) * h_flags_cap);
+    }
+    a.changed_f = d_flags_view; a.changed_b = d_flags_view + (max_pass + 1);
     a.eps_f = eps_f; a.eps_b = eps_b; a.full_f = a.full_b = 0;
     a.fine = nullptr; a.nfine = 0; a.hand_f = a.hand_b = 0; a.fine_ends_f = nullptr; a.fine_ends_b = nullptr;
     if (ss4) {
@@ -2114,9 +2137,6 @@ void smcpp_im::ss_launch_initial() {
     a.dbg = nullptr;
     if (getenv("SMCPP_DEBUG_CYCLES")) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }
     HIPCHK(hipMemcpyAsync(d_pre, pre_stage.base, off, hipMemcpyHostToDevice, s));
-    if (ss_flags_clean) HIPCHK(hipStreamWaitEvent(s, ev[21], 0));
-    else { d_changed_f.zero(s); d_changed_b.zero(s); }
-    ss_flags_clean = false;
     HIPCHK(hipEventRecord(ev[10], s));
     ss_launched = ss_pass0;
     const int want = std::min(max_pass, ss_pass0 + (last_ss_passes > 0 ? last_ss_passes + 1 : 6));
@@ -2124,14 +2144,23 @@ void smcpp_im::ss_launch_initial() {
     HIPCHK(hipEventRecord(ev[11], s));
 }
 
+bool smcpp_im::wait_done(int epoch) {
+    // poll the pinned word the last kernel of the queue writes; a generous deadline, then the ordinary blocking wait
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned n = 0;
+    while (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) != epoch) {
+        __builtin_ia32_pause();
+        if ((++n & 0x3fff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
+            HIPCHK(hipStreamSynchronize(stream));
+            return __atomic_load_n(h_done, __ATOMIC_ACQUIRE) == epoch;
+        }
+    }
+    return true;
+}
+
 void smcpp_im::run_chains_ss() {
     hipStream_t s = stream;
-    if (h_flags_cap < 2 * (max_pass + 1)) {
-        if (h_flags) (void)hipHostFree(h_flags);
-        h_flags_cap = 2 * (max_pass + 1);
-        HIPCHK(hipHostMalloc((void **)&h_flags, sizeof(int) * h_flags_cap, hipHostMallocDefault));
-    }
-    int *chf = h_flags, *chb = h_flags + (max_pass + 1);
+    const int *chf = h_flags, *chb = h_flags + (max_pass + 1);
     const int p0 = ss_pass0;
     auto first_quiet = [p0](const int *cf, const int *cb, int upto) {
         for (int j = p0; j < upto; ++j)
@@ -2142,29 +2171,26 @@ void smcpp_im::run_chains_ss() {
     HIPCHK(hipEventRecord(ev[1], s));
     bool first_round = true;
     int q = -1;
+    static const bool poll = !(getenv("SMCPP_POLL") && atoi(getenv("SMCPP_POLL")) == 0);
     while (true) {
         HIPCHK(hipEventRecord(ev[3], s));
-        // optimistic, as run_chains(): the statistics are queued right behind the passes, the flag read-back behind them (the host
-        // only looks at the flags after the synchronisation; in the rare round that needs more passes the statistics are redone)
+        // optimistic, as run_chains(): the statistics are queued right behind the passes; the host only looks at the flags (pinned
+        // memory the kernels wrote) when the queue has drained; in the rare round that needs more passes the statistics are redone
         if (first_round && !save_gamma) enqueue_stats();
         else stats_enqueued = false;
-        HIPCHK(hipMemcpyAsync(chf, d_changed_f.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(chb, d_changed_b.p, sizeof(int) * (max_pass + 1), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        done_covers_stats = stats_enqueued;
+        if (poll) {
+            hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, s, d_done_view, ++done_epoch);
+            if (!wait_done(done_epoch)) throw std::runtime_error("the device did not signal completion");
+        } else HIPCHK(hipStreamSynchronize(s));
         first_round = false;
         q = first_quiet(chf, chb, ss_launched);
         if (q >= 0 || ss_launched >= max_pass) break;
         stats_enqueued = false;
+        done_covers_stats = false;
         ss_launch_passes(std::min(max_pass, ss_launched + 3));
     }
     chains_dual = false;
-    if (stream3 != nullptr && q >= 0) {
-        // the flags have been read: clear them for the next E-step off the critical path
-        d_changed_f.zero(stream3);
-        d_changed_b.zero(stream3);
-        HIPCHK(hipEventRecord(ev[21], stream3));
-        ss_flags_clean = true;
-    }
     if (ss_args.dbg) {
         long long h[8];
         HIPCHK(hipMemcpy(h, d_dbg.p, sizeof(h), hipMemcpyDeviceToHost));
@@ -2185,19 +2211,27 @@ void smcpp_im::run_stats() {
 }
 
 void smcpp_im::finish_stats() {
-    HIPCHK(hipStreamSynchronize(stream));
+    if (!(ss_active && done_covers_stats)) HIPCHK(hipStreamSynchronize(stream));      // (else: run_chains_ss saw the queue drain)
+    done_covers_stats = false;
     std::memcpy(loglik.data(), h_ll, sizeof(double) * n_contigs);
     stats_enqueued = false;
 }
 
 void smcpp_im::enqueue_stats() {
     hipStream_t s = stream;
+    if (h_ll_cap < n_contigs) {
+        if (h_ll) (void)hipHostFree(h_ll);
+        h_ll_cap = n_contigs;
+        HIPCHK(hipHostMalloc((void **)&h_ll, sizeof(double) * h_ll_cap, hipHostMallocCoherent | hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer((void **)&d_ll_view, h_ll, 0));
+    }
     if (arena_side) HIPCHK(hipStreamWaitEvent(s, ev[20], 0));
     // log-likelihood (also materialises log_c per row)
     LoglikArgs la;
     la.cnorm = d_cnorm.p; la.rowinfo = d_rowinfo.p; la.g_logscale = d_g_logscale.p;
     la.contig_base = d_contig_base.p; la.contig_L = d_contig_L.p; la.partial = d_llpart.p; la.loglik = d_loglik.p;
     la.logc = d_logc.p; la.nblk = llblk;
+    la.loglik_host = d_ll_view;          // the final kernel writes the per-contig values into the pinned array as well: no copy
     if (save_gamma) {
         d_gamma_rows.alloc((size_t)total_rows * Mp);
         d_gamma_rows.zero(s);
@@ -2504,13 +2538,7 @@ void smcpp_im::enqueue_stats() {
         }
     }
     HIPCHK(hipGetLastError());
-    if (h_ll_cap < n_contigs) {
-        if (h_ll) (void)hipHostFree(h_ll);
-        h_ll_cap = n_contigs;
-        HIPCHK(hipHostMalloc((void **)&h_ll, sizeof(double) * h_ll_cap, hipHostMallocDefault));
-    }
     if (ll_own) HIPCHK(hipStreamWaitEvent(s, ev[19], 0));
-    HIPCHK(hipMemcpyAsync(h_ll, d_loglik.p, sizeof(double) * n_contigs, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(ev[5], s));
     stats_enqueued = true;
 }
@@ -2527,7 +2555,6 @@ void smcpp_im::estep() {
     HIPCHK(hipEventRecord(ev[0], stream));
     ss_active = ss_static && ss_extract_generators();
     if (!ss_active) ss_warm_valid = false;
-    if (!ss_active && ss_flags_clean) { HIPCHK(hipStreamWaitEvent(stream, ev[21], 0)); ss_flags_clean = false; }
     {
         // span > 1 rows without an eigensystem (kernels.hpp: k_span_fold): the span is expanded by smax steps of two M x M products
         static const bool off = getenv("SMCPP_EIGFREE") && atoi(getenv("SMCPP_EIGFREE")) == 0;

@@ -1785,6 +1785,7 @@ struct LoglikArgs {
     const int *contig_L;          // [n_contigs]
     double *partial;              // [n_contigs][nblk]
     double *loglik;               // [n_contigs]
+    double *loglik_host;          // optional: device view of a pinned host array that receives the same values (no copy afterwards)
     double *logc;                 // optional [rows]: log_c per row (needed by the span-1 weights)
     int nblk;
 };
@@ -1825,7 +1826,16 @@ __global__ __launch_bounds__(256) void k_loglik_final(LoglikArgs a) {
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.loglik[ct] = red[0];
+    if (threadIdx.x == 0) {
+        a.loglik[ct] = red[0];
+        if (a.loglik_host) a.loglik_host[ct] = red[0];
+    }
+}
+
+// Completion signal into pinned host memory: the host polls the word instead of blocking in hipStreamSynchronize (the stream is
+// in-order, so everything queued before this launch has finished and released its writes when the value arrives)
+__global__ void k_signal(int *flag, int value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

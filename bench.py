@@ -339,7 +339,7 @@ def main():
     fwd_ms, bwd_ms = med["forward_ms"], med["backward_ms"]
     mode = im.chain_mode() if hasattr(im, "chain_mode") else -1
     F_alg, B_alg = eval_work(contigs, M)
-    if mode == 5:
+    if mode in (5, 6):
         # Scan chains (chains_ss.hpp): ONE kernel runs both directions (forward and backward wavefronts share a workgroup), so
         # the dominant kernel is k_chain_ss and `achieved` credits ONE pass of the algorithmic work of BOTH chains
         # (2 M^2 R1 + 4 M^2 Re flops per chain) against the time of ALL its launches of one E-step (light

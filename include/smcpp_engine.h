@@ -144,7 +144,8 @@ int smcpp_last_timing(smcpp_im *im, double out[9]);
 /* diagnostics: the chain kernel family in use (0 generic, 1 LDS-resident, 2 cooperative, 3 cooperative with streamed
  * operands, 4 lock-step on the matrix cores, 5 scans over the semiseparable structure of the transition matrix -
  * src/transition.cpp:176-254 - one position per step, no eigensystem; an E-step whose T lacks that structure runs the
- * dense kernels instead) */
+ * dense kernels instead; 6 = family 5 with HYBRID rows: un-binned data, a row whose span exceeds a few positions is one
+ * eigen-power step P d^s P^-1 inside the scan kernel - hmm.cpp:72-78,104-112 - instead of `span` scan steps) */
 int smcpp_chain_mode(smcpp_im *im);
 /* Test hook of family 5: one position of both scan chains on nvec vectors: out_f = e o (T^T x), out_b = T (e o x); T is
  * [M][M] row-major, x / e / out_* are [nvec][M].  Returns 2 when T has no semiseparable structure (nothing is written). */

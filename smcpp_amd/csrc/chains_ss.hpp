@@ -61,7 +61,16 @@ struct SsArgs {
     int nfine, hand_f, hand_b;
     float *fine_ends_f;
     double *fine_ends_b;
+    // HYBRID rows (un-binned data, M <= 64 and the tables fit LDS): a row whose span exceeds hyb_th is ONE eigen-power step
+    // x <- P (d~^s o (P^-1 x))  (forward; hmm.cpp:72-78) /  b <- P^-T (d~^s o (P^T b))  (backward; hmm.cpp:104-112) on the
+    // eigensystem of its key - two M-long mat-vecs per lane against LDS tables - instead of `span` scan steps; shorter rows
+    // keep the scans.  rowdesc.x carries the eigen key in its upper 16 bits.  hyb_th = INT_MAX: no such rows.
+    int hyb_th = 0x7fffffff, Ke = 0, hot_ek = 0;   // hot_ek: the eigen key with the most rows (its table rows stay in registers)
+    const double *Pinvrm = nullptr, *Prm = nullptr, *PinvT = nullptr, *PT = nullptr;   // [Ke][Mp][Mp]
+    const double *dsc = nullptr;               // [Ke][Mp] scaled eigenvalues d / scale
 };
+
+constexpr int SS_KE_MAX = 4;
 
 template <int CTRL>
 __device__ __forceinline__ double dpp0(double v) {      // shifted copy, 0.0 where the source lane does not exist
@@ -268,7 +277,139 @@ __device__ __forceinline__ void ss_emission(const SsArgs &a, const double *sE, i
     }
 }
 
-template <int NPL, bool RERUN>
+// sum over the two 32-lane halves, result in both (v_permlane32_swap: no LDS round trip)
+__device__ __forceinline__ double ss_sum_halves(double v) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const int lo = (int)(x & 0xffffffffll), hi = (int)(x >> 32);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const double a = __builtin_bit_cast(double, ((long long)(unsigned)r1[0] << 32) | (unsigned)r0[0]);
+    const double b = __builtin_bit_cast(double, ((long long)(unsigned)r1[1] << 32) | (unsigned)r0[1]);
+    return a + b;
+}
+// ---- hybrid rows (NPL = 1): eigen-power step of the vector held one state per lane ----
+// "State coordinate" of a lane: lp = lane (forward) or 63 - lane (backward).  With Mp <= 32 the 64 lanes are G = 2
+// groups of W = 64 / G: lane (g, r) sums the columns [g nb, (g + 1) nb) of table row r, nb = Mp / G, against the vector staged
+// in a per-wavefront LDS scratch (one broadcast read per column), and the groups' partial sums are added with two xor-shuffles:
+// every lane ends with the full product of row lp mod W.
+// exp(x) for x <= 0 (powers of eigenvalues scaled to |d| <= 1): 2^n e^r with n = rint(x log2 e), |r| <= ln 2 / 2, e^r by its
+// Taylor polynomial of degree 13 (remainder < 4e-18) - twenty-odd instructions against ~100 of the general routine; 0 below -745
+__device__ __forceinline__ double ss_exp_neg(double x) {
+    if (!(x > -745.0)) return 0.0;
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+struct SsEigC { double ld[SS_KE_MAX]; bool neg[SS_KE_MAX]; int r, g, nb, G; };
+__device__ __forceinline__ void ss_load_eig(const SsArgs &a, int lp, SsEigC &c) {
+    c.G = a.Mp <= 32 ? 2 : 1;
+    const int W = 64 / c.G;
+    c.r = lp & (W - 1); c.g = lp / W; c.nb = a.Mp / c.G;
+#pragma unroll
+    for (int e = 0; e < SS_KE_MAX; ++e) {
+        double d = 0.0;
+        if (e < a.Ke && c.r < a.M) d = a.dsc[(size_t)e * a.Mp + c.r];
+        c.ld[e] = log(fabs(d));                     // -inf for a zero (padded) eigenvalue: its power is 0
+        c.neg[e] = d < 0.0;
+    }
+}
+__device__ __forceinline__ double ss_eig_pow(const SsEigC &c, int ek, int span) {
+    double l = c.ld[0];
+    bool ng = c.neg[0];
+#pragma unroll
+    for (int e = 1; e < SS_KE_MAX; ++e) if (ek == e) { l = c.ld[e]; ng = c.neg[e]; }
+    const double p = ss_exp_neg((double)span * l);
+    return (ng && (span & 1)) ? -p : p;
+}
+// LDS tables: [Ke][4][Mp][Mp + 1]: 0 = Pinv, 1 = P (forward), 2 = P^T, 3 = Pinv^T (backward), row-major, padded rows; behind
+// them one [64] scratch vector per wavefront
+__device__ __forceinline__ double ss_eig_matvec(const SsEigC &c, const double *tab, int Mp, int ek, int which, double *sx, int lp, double x) {
+    sx[lp] = x;
+    wave_lds_fence();
+    const double *row = tab + ((size_t)(ek * 4 + which) * Mp + min(c.r, Mp - 1)) * (Mp + 1) + c.g * c.nb;
+    const double *xv = sx + c.g * c.nb;
+    double a0 = 0.0, a1 = 0.0;
+    for (int b = 0; b < c.nb; b += 4) {
+        const double r0 = row[b], r1 = row[b + 1], r2 = row[b + 2], r3 = row[b + 3];
+        const double v0 = xv[b], v1 = xv[b + 1], v2 = xv[b + 2], v3 = xv[b + 3];
+        a0 = __builtin_fma(r0, v0, a0); a1 = __builtin_fma(r1, v1, a1);
+        a0 = __builtin_fma(r2, v2, a0); a1 = __builtin_fma(r3, v3, a1);
+    }
+    double acc = a0 + a1;
+    if (c.G >= 2) acc = ss_sum_halves(acc);
+    wave_lds_fence();
+    return acc;
+}
+
+// The whole eigen-power step  out = M1 (pw o (M0 x))  for Mp <= 32 (two lane groups, NB = Mp / 2 columns each), arranged for
+// LATENCY - one wavefront per SIMD has nothing to hide an LDS round trip behind: the table rows of BOTH products are requested
+// first, the eigenvalue power (a software exp) is computed while they are on their way, and the only dependent round trips left
+// are the two stagings of the vector.
+template <int NB>
+struct SsHotRows { double a[NB], b[NB]; };          // this lane's pieces of the two table rows of the HOT eigen key (registers)
+template <int NB>
+__device__ __forceinline__ void ss_eig_rows(const SsEigC &c, const double *tab, int Mp, int ek, int w0, double (&ra)[NB], double (&rb)[NB]) {
+    const size_t rowoff = (size_t)min(c.r, Mp - 1) * (Mp + 1) + c.g * NB;
+    const double *rowA = tab + (size_t)(ek * 4 + w0) * Mp * (Mp + 1) + rowoff;
+    const double *rowB = tab + (size_t)(ek * 4 + w0 + 1) * Mp * (Mp + 1) + rowoff;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { ra[b] = rowA[b]; rb[b] = rowB[b]; }
+}
+template <int NB>
+__device__ __forceinline__ double ss_eig_step(const SsEigC &c, const double *tab, int Mp, int ek, int w0, double *sx, int lp,
+                                              double xin, int span, const SsHotRows<NB> &hot, int hot_ek) {
+    double ra[NB], rb[NB];
+    if (ek == hot_ek) {                                   // wave-uniform
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { ra[b] = hot.a[b]; rb[b] = hot.b[b]; }
+    } else ss_eig_rows<NB>(c, tab, Mp, ek, w0, ra, rb);
+    sx[lp] = xin;
+    const double pw = ss_eig_pow(c, ek, span);
+    wave_lds_fence();
+    const double *xv = sx + c.g * NB;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; b += 2) { a0 = __builtin_fma(ra[b], xv[b], a0); a1 = __builtin_fma(ra[b + 1], xv[b + 1], a1); }
+    const double u = ss_sum_halves(a0 + a1) * pw;
+    wave_lds_fence();
+    sx[c.r] = u;                     // (both groups hold the full sum of row r and write the same value)
+    wave_lds_fence();
+    a0 = 0.0; a1 = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; b += 2) { a0 = __builtin_fma(rb[b], xv[b], a0); a1 = __builtin_fma(rb[b + 1], xv[b + 1], a1); }
+    const double o = ss_sum_halves(a0 + a1);
+    wave_lds_fence();
+    return o;
+}
+// dispatcher: Mp = 32 / 16 take the latency-arranged form, larger Mp the generic products
+__device__ __forceinline__ double ss_eig_apply(const SsEigC &c, const double *tab, int Mp, int ek, int w0, double *sx, int lp,
+                                               double xin, int span, const SsHotRows<16> &hot, int hot_ek) {
+    if (Mp == 32) return ss_eig_step<16>(c, tab, Mp, ek, w0, sx, lp, xin, span, hot, hot_ek);
+    if (Mp == 16) {
+        SsHotRows<8> none;                                // (M <= 16: the rows come from LDS)
+        return ss_eig_step<8>(c, tab, Mp, ek, w0, sx, lp, xin, span, none, -1);
+    }
+    double u = ss_eig_matvec(c, tab, Mp, ek, w0, sx, lp, xin);
+    u *= ss_eig_pow(c, ek, span);
+    return ss_eig_matvec(c, tab, Mp, ek, w0 + 1, sx, lp, lp < 64 / c.G ? u : 0.0);
+}
+
+template <int NPL, bool RERUN, bool HYB>
 __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -320,19 +461,55 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     float *arow = a.alpha + (size_t)(ch.base + ch.r0) * Mp;    // row ell - 1 of iteration j is arow + j Mp
     double *crow = a.cnorm + ch.base + ch.r0;
     double e[NPL];
-    ss_emission<NPL, false>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0), lane, e);
+    ss_emission<NPL, false>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
+    constexpr bool hyb = HYB && NPL == 1;
+    const double *tab = sE + (size_t)a.nlds * MS;
+    SsEigC ec;
+    SsHotRows<16> hot;
+    int hot_ek = -1;
+    if (hyb) {
+        ss_load_eig(a, lane, ec);
+        if (Mp == 32) { hot_ek = a.hot_ek; ss_eig_rows<16>(ec, tab, Mp, hot_ek, 0, hot.a, hot.b); }
+    }
+    double *sxw = const_cast<double *>(tab) + (size_t)a.Ke * 4 * Mp * (Mp + 1) + (threadIdx.x >> 6) * 64;
     bool merged = false;
     const long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
     long long npos = 0;
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
+        const int ekr = __builtin_amdgcn_readlane(dcur.x, jl) >> 16;
         npos += span;
         // descriptor / emission vector of the next row
         if (jl == 63) { dcur = dnxt; dnxt = rd[j + 65 + lane]; }
-        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63);
+        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
         double en[NPL];
         ss_emission<NPL, false>(a, sE, slot_n, lane, en);
+        if (hyb && span > a.hyb_th) {
+            // ---- hybrid row: finish the previous row exactly as below, then ONE eigen-power step from the STORED vector ----
+            const double S = wave_sum_dpp(x[0]);
+            const double inv = rcp_f64(S);
+            double xin = x[0] * inv;
+            if (j > 0) {
+                const float an = live[0] ? fmaxf((float)xin, 1e-10f) : 0.f;
+                if (RERUN && !a.full_f && (j & 15) == 0 && j >= 16) {
+                    bool bad = false;
+                    if (live[0]) {
+                        const float old = arow[(size_t)j * Mp + st[0]];
+                        if (!(fabsf(an - old) <= a.eps_f * fabsf(old))) bad = true;
+                    }
+                    if (!__any(bad)) { merged = true; break; }
+                }
+                if (stor[0]) arow[(size_t)j * Mp + st[0]] = an;
+                if (lane == 0) crow[j] = S;
+                xin = (double)an;
+            }
+            const double xo = ss_eig_apply(ec, tab, Mp, ekr, 0, sxw, lane, xin, span, hot, hot_ek);
+            x[0] = live[0] ? xo : 0.0;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) e[k] = en[k];
+            continue;
+        }
         // first position of the row: the sum of the incoming vector finishes the PREVIOUS row
         double y[NPL], S;
         ss_fwd_step<NPL>(cst, x, e, y, S);
@@ -419,7 +596,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     }
 }
 
-template <int NPL, bool RERUN>
+template <int NPL, bool RERUN, bool HYB>
 __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -466,16 +643,27 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
     int2 dcur = rd[-lane], dnxt = rd[-64 - lane];
     double *brow = a.beta + (size_t)(ch.base + ch.r1) * Mp;     // row ell of iteration j is brow - j Mp
     double e[NPL];
-    ss_emission<NPL, true>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0), lane, e);
+    ss_emission<NPL, true>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
+    constexpr bool hyb = HYB && NPL == 1;
+    const double *tab = sE + (size_t)a.nlds * MS;
+    SsEigC ec;
+    SsHotRows<16> hot;
+    int hot_ek = -1;
+    if (hyb) {
+        ss_load_eig(a, 63 - lane, ec);
+        if (Mp == 32) { hot_ek = a.hot_ek; ss_eig_rows<16>(ec, tab, Mp, hot_ek, 2, hot.a, hot.b); }
+    }
+    double *sxw = const_cast<double *>(tab) + (size_t)a.Ke * 4 * Mp * (Mp + 1) + (threadIdx.x >> 6) * 64;
     bool merged = false;
     const long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
     long long npos = 0;
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
+        const int ekr = __builtin_amdgcn_readlane(dcur.x, jl) >> 16;
         npos += span;
         if (jl == 63) { dcur = dnxt; dnxt = rd[-(j + 65) - lane]; }
-        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63);
+        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
         double en[NPL];
         ss_emission<NPL, true>(a, sE, slot_n, lane, en);
         // beta[ell] in the running scale (hmm.cpp:142 renormalises; every consumer is invariant to a per-row scale)
@@ -491,6 +679,16 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) if (stor[k]) brow[-(ptrdiff_t)j * Mp + st[k]] = b[k];
+        if (hyb && span > a.hyb_th) {
+            // ---- hybrid row: b <- P^-T (d~^s o (P^T b)), renormalised (every consumer of beta is scale free) ----
+            const double bin = live[0] ? b[0] : 0.0;
+            double bo = ss_eig_apply(ec, tab, Mp, ekr, 2, sxw, 63 - lane, bin, span, hot, hot_ek);
+            bo = live[0] ? bo : 0.0;
+            b[0] = bo * rcp_f64(wave_sum_dpp(bo));
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) e[k] = en[k];
+            continue;
+        }
         double y[NPL];
         float Sw;
         ss_bwd_step<NPL>(cst, b, e, y, Sw);
@@ -698,7 +896,7 @@ __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *
     const int nrows = ch.r1 - ch.r0;
     int2 dcur = rd[lane], dnxt = rd[64 + lane];
     float e[NPL];
-    ss_emission_f<NPL, false>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0), lane, e);
+    ss_emission_f<NPL, false>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
     int fcur = ch.pad & 0xFFFFFF;
     const int fend = fcur + (ch.pad >> 24);
     int nextb = (a.hand_f && fcur < fend) ? a.fine[fcur].r1 - ch.r0 : -1;
@@ -706,7 +904,7 @@ __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
         if (jl == 63) { dcur = dnxt; dnxt = rd[j + 65 + lane]; }
-        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63);
+        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
         float en[NPL], y[NPL], S;
         ss_emission_f<NPL, false>(a, sE, slot_n, lane, en);
         ss_fwd_step_f<NPL>(cst, x, e, y, S);
@@ -778,7 +976,7 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
     const int nrows = ch.r1 - ch.r0;
     int2 dcur = rd[-lane], dnxt = rd[-64 - lane];
     float e[NPL];
-    ss_emission_f<NPL, true>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0), lane, e);
+    ss_emission_f<NPL, true>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
     const int fbeg = ch.pad & 0xFFFFFF;
     int fcur = fbeg + (ch.pad >> 24) - 1;
     int nextb = (a.hand_b && fcur >= fbeg) ? ch.r1 - a.fine[fcur].r0 : -1;
@@ -786,7 +984,7 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
         if (jl == 63) { dcur = dnxt; dnxt = rd[-(j + 65) - lane]; }
-        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63);
+        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
         float en[NPL], y[NPL], Sw;
         ss_emission_f<NPL, true>(a, sE, slot_n, lane, en);
         ss_bwd_step_f<NPL>(cst, b, e, y, Sw);
@@ -835,8 +1033,9 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
 
 // One workgroup = 4 wavefronts = chunks 2 blk, 2 blk + 1 forward (wavefronts 0, 1) and backward (wavefronts 2, 3); they share
 // one LDS copy of the emission vectors of the `nlds` most frequent keys.
-template <int NPL>
-__global__ __launch_bounds__(256) void k_chain_ss(SsArgs a) {
+// (the hybrid instantiation may run 8 wavefronts per workgroup - two per SIMD behind ONE copy of the eigenvector tables)
+template <int NPL, bool HYB>
+__global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
     constexpr int MS = 64 * NPL;
     extern __shared__ __attribute__((aligned(16))) double ss_lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -844,21 +1043,33 @@ __global__ __launch_bounds__(256) void k_chain_ss(SsArgs a) {
     const bool idle_f = a.mode_f == 3 || (a.mode_f == 1 && a.changed_f[a.pass - 1] == 0);
     const bool idle_b = a.mode_b == 3 || (a.mode_b == 1 && a.changed_b[a.pass - 1] == 0);
     if (idle_f && idle_b) return;
-    for (int idx = tid; idx < a.nlds * MS; idx += 256) ss_lds[idx] = a.E[idx];
+    const int nthr = HYB ? (int)blockDim.x : 256;
+    for (int idx = tid; idx < a.nlds * MS; idx += nthr) ss_lds[idx] = a.E[idx];
+    if (HYB && NPL == 1) {
+        // eigenvector tables of the hybrid rows behind the emission vectors: [Ke][4][Mp][Mp + 1]
+        double *tab = ss_lds + (size_t)a.nlds * MS;
+        const int Mp = a.Mp, MM = Mp * Mp;
+        for (int idx = tid; idx < a.Ke * 4 * MM; idx += nthr) {
+            const int mat = idx / MM, rc = idx % MM, r = rc / Mp, cc = rc % Mp;
+            const int e = mat >> 2, which = mat & 3;
+            const double *src = which == 0 ? a.Pinvrm : which == 1 ? a.Prm : which == 2 ? a.PT : a.PinvT;
+            tab[((size_t)mat * Mp + r) * (Mp + 1) + cc] = src[(size_t)e * MM + rc];
+        }
+    }
     __syncthreads();
-    const int task = a.tasks[4 * blockIdx.x + w];
+    const int task = a.tasks[(nthr >> 6) * blockIdx.x + w];
     if (task < 0) return;
     const bool fwd = !(task >> 30);
     const int c = task & 0x3FFFFFFF;
     if (fwd) {
         if (idle_f) return;
-        if (a.mode_f == 0) ss_forward_wave<NPL, false>(a, ss_lds, c, lane);
-        else if (a.mode_f == 1) ss_forward_wave<NPL, true>(a, ss_lds, c, lane);
+        if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB>(a, ss_lds, c, lane);
+        else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB>(a, ss_lds, c, lane);
         else ss_forward_light<NPL>(a, ss_lds, c, lane);
     } else {
         if (idle_b) return;
-        if (a.mode_b == 0) ss_backward_wave<NPL, false>(a, ss_lds, c, lane);
-        else if (a.mode_b == 1) ss_backward_wave<NPL, true>(a, ss_lds, c, lane);
+        if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB>(a, ss_lds, c, lane);
+        else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB>(a, ss_lds, c, lane);
         else ss_backward_light<NPL>(a, ss_lds, c, lane);
     }
 }

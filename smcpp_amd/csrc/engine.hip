@@ -228,11 +228,19 @@ struct smcpp_im {
     int coop_bpc = 1;     // cooperative workgroups resident per CU the automatic chunking aims at
     // ---- chains on the semiseparable structure of T (chains_ss.hpp; chain_mode 5) ------------------------------------------
     bool ss_static = false;                // the input qualifies (short spans); whether T does is decided on every E-step
+    // hybrid scan chains (un-binned data): rows whose span exceeds ss_hyb_th take ONE eigen-power step inside the scan kernel
+    // (chains_ss.hpp); they cost about SS_HYB_COST scan positions each, which is what the chunk list is balanced on
+    bool ss_hybrid = false;
+    int ss_hyb_th = 0x7fffffff;
+    static constexpr int SS_HYB_COST = 8;
+    long long ss_row_cost(int span) const { return (ss_hybrid && span > ss_hyb_th) ? SS_HYB_COST : span; }
+    size_t ss_tab_bytes() const { return ss_hybrid ? ((size_t)Ke * 4 * Mp * (Mp + 1) + 8 * 64) * sizeof(double) : 0; }   // + one scratch vector per wavefront
     bool ss_active = false;                // this E-step's chains run on the scan kernels
     bool eigfree = false;                  // ... and its statistics need no eigensystem either (k_span_fold): no eigensolve at all
     int ss_max_span = 0;
     int ss_nlds = 0;                       // key slots whose emission vectors live in LDS
     int ss_wpc = 1;                        // scan chains: wavefronts per SIMD (workgroups per CU) the chunk list is cut for
+    int ss_wg_waves = 4;                   // wavefronts per workgroup of k_chain_ss (hybrid with two per SIMD: 8, one table copy)
     int ss_launched = 0, last_ss_passes = 0;
     long long ss_positions = 0;            // sum of spans
     int ss_light_f = 0, ss_light_b = 0;    // light (float, store-free) passes per direction before the full fp64 pass
@@ -552,7 +560,19 @@ void smcpp_im::make_chunks() {
         for (const Group &g : groups) ss_max_span = std::max(ss_max_span, g.span);
         {
             const char *se = getenv("SMCPP_SS");
-            ss_static = !(se && atoi(se) == 0) && (!m || !strcmp(m, "ss")) && ss_max_span <= 512 && Mp <= 256;
+            const bool ss_ok = !(se && atoi(se) == 0) && (!m || !strcmp(m, "ss")) && Mp <= 256;
+            ss_static = ss_ok && ss_max_span <= 512;
+            ss_hybrid = false; ss_hyb_th = 0x7fffffff;
+            if (ss_ok && !ss_static) {
+                // longer spans: the hybrid form, when one state per lane holds the vector and the eigenvector tables of every eigen
+                // key fit LDS beside the emission vectors (SMCPP_HYBRID=0: the dense kernels)
+                const char *hy = getenv("SMCPP_HYBRID");
+                const size_t tab = (size_t)Ke * 4 * Mp * (Mp + 1) * sizeof(double);
+                if (!(hy && atoi(hy) == 0) && Mp <= 64 && Ke >= 1 && Ke <= 4 && tab <= 120 * 1024) {
+                    ss_static = ss_hybrid = true;
+                    ss_hyb_th = getenv("SMCPP_HYB_TH") ? std::max(1, atoi(getenv("SMCPP_HYB_TH"))) : 6;
+                }
+            }
             if (ss_static) chain_mode = Mp > 64 ? 3 : 2;
             SPL = (M + 15) / 16;
             // (opt-in: on one 100 Mbp contig the fine chunks are shorter than the history a re-run has to cover, so the re-run passes
@@ -583,7 +603,7 @@ void smcpp_im::make_chunks() {
         for (int c = 0; c < n_contigs; ++c)
             for (int i = 1; i <= Ls[c]; ++i) {
                 const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
-                total_bins += ri.gid < 0 ? 1 : groups[ri.gid].span;
+                total_bins += ri.gid < 0 ? 1 : ss_row_cost(groups[ri.gid].span);
             }
         // Wavefronts per SIMD: one wavefront leaves a quarter of the issue slots empty (an instruction occupies the SIMD for 4 of
         // the ~5.3 clocks between two issues of one wavefront), a second and third fill them - but every chunk pays ~3 000 positions
@@ -592,6 +612,12 @@ void smcpp_im::make_chunks() {
         const long long simds = (long long)prop.multiProcessorCount * 4;
         ss_wpc = getenv("SMCPP_SS_WPC") ? std::max(1, std::min(4, atoi(getenv("SMCPP_SS_WPC"))))
                                         : (int)std::max<long long>(1, std::min<long long>(3, total_bins / (simds * 9000)));
+        // hybrid rows are bound by instruction and LDS LATENCY (a dependent chain of ~200 instructions per row): a second wavefront
+        // per SIMD fills the gaps from ~2 000 cost units per chunk on (posterior workload: 1.79 -> 1.35 ms of chains; a third one
+        // needs an extra pass: 1.80); the eight wavefronts form ONE workgroup so that the CU holds one copy of the tables
+        if (ss_hybrid && !getenv("SMCPP_SS_WPC")) ss_wpc = (int)std::max<long long>(1, std::min<long long>(2, total_bins / (simds * 2000)));
+        if (ss_hybrid) ss_wpc = std::min(ss_wpc, 2);
+        ss_wg_waves = (ss_hybrid && ss_wpc == 2) ? 8 : 4;
         const long long waves = simds * ss_wpc;
         max_chunks_per_contig = 1;
         // positions per contig
@@ -599,7 +625,7 @@ void smcpp_im::make_chunks() {
         for (int c = 0; c < n_contigs; ++c)
             for (int i = 1; i <= Ls[c]; ++i) {
                 const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
-                cpos[c] += ri.gid < 0 ? 1 : groups[ri.gid].span;
+                cpos[c] += ri.gid < 0 ? 1 : ss_row_cost(groups[ri.gid].span);
             }
         auto cut = [&](long long nslots, long long floor_bins, std::vector<Chunk> &out) {
             const long long bpc = std::max<long long>(floor_bins, (total_bins + nslots - 1) / nslots);
@@ -634,7 +660,7 @@ void smcpp_im::make_chunks() {
                 cum.assign((size_t)L + 1, 0);
                 for (int i = 1; i <= L; ++i) {
                     const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
-                    cum[i] = cum[i - 1] + (ri.gid < 0 ? 1 : groups[ri.gid].span);
+                    cum[i] = cum[i - 1] + (ri.gid < 0 ? 1 : ss_row_cost(groups[ri.gid].span));
                 }
                 const int nc = ncs[c];
                 max_chunks_per_contig = std::max(max_chunks_per_contig, nc);
@@ -741,7 +767,7 @@ void smcpp_im::upload_chunk_state() {
             if (take_f) ss_tasks.push_back((int)i++);
             else ss_tasks.push_back((1 << 30) | (int)j++);
         }
-        while (ss_tasks.size() % 4) ss_tasks.push_back(-1);
+        while (ss_tasks.size() % ss_wg_waves) ss_tasks.push_back(-1);
         d_tasks.upload(ss_tasks, stream);
     }
     d_ends_f.alloc(2 * nch * Mp); d_used_f.alloc(nch * Mp);
@@ -963,17 +989,19 @@ void smcpp_im::alloc_device() {
         for (int r = 0; r < K; ++r) ss_slot_of_key[order[r]] = r;
         const int MS = 64 * NPL;
         ss_nlds = (int)std::min<long long>(K, (std::min(64, 150 / std::max(1, ss_wpc)) * 1024) / ((long long)MS * 8));   // ss_wpc workgroups share a CU's 160 KB
+        if (ss_hybrid) ss_nlds = (int)std::min<long long>(K, (long long)(150 * 1024 - ss_tab_bytes()) / ((long long)MS * 8));   // one workgroup per CU
         ss_positions = 0;
         for (int c = 0; c < n_contigs; ++c)
             for (int i = 1; i <= Ls[c]; ++i) {
                 const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
-                ss_positions += ri.gid < 0 ? 1 : groups[ri.gid].span;
+                ss_positions += ri.gid < 0 ? 1 : ss_row_cost(groups[ri.gid].span);
             }
         if (ss_static) {
             std::vector<int2> rd((size_t)total_rows + 2 * ROWDESC_PAD, make_int2(0, 1));
             for (size_t r = 0; r < (size_t)total_rows; ++r) {
                 const RowInfo &ri = rowinfo[r];
-                rd[ROWDESC_PAD + r] = make_int2(ss_slot_of_key[ri.kid], ri.gid < 0 ? 1 : groups[ri.gid].span);
+                // (upper 16 bits of x: the eigen key of a span > 1 row, read by the hybrid rows only)
+                rd[ROWDESC_PAD + r] = make_int2(ss_slot_of_key[ri.kid] | ((ri.gid < 0 ? 0 : groups[ri.gid].eig) << 16), ri.gid < 0 ? 1 : groups[ri.gid].span);
             }
             d_rowdesc_ss.upload(rd, s);
             HIPCHK(hipStreamSynchronize(s));
@@ -1222,7 +1250,8 @@ void smcpp_im::host_prep_and_upload() {
             const int sp = groups[g].span;
             gsc[g] = s_.scale;
             // (the eigenvalue powers (d_r / scale)^span of the group: k_group_dpow, on the device)
-            gls[g] = ss_active ? 0.0 : sp * ls;   // the scan chains apply the operator itself: their normalisers carry no eigenvalue scale
+            // the scan steps apply the operator itself: their normalisers carry no eigenvalue scale (hybrid rows do: d / scale)
+            gls[g] = (ss_active && !(ss_hybrid && sp > ss_hyb_th)) ? 0.0 : sp * ls;
         }
     };
     // M >= 128: a team of threads per eigen key (nonsym_eig_team.hpp: bit-identical to the serial routine); the size follows
@@ -1943,6 +1972,7 @@ bool smcpp_im::ss_extract_generators() {
     if (ss4 && !ss_generators(M, 16 * SPL, T.data(), ss_gen4, ss_c0)) return false;
     // a row of span s applies its operator s times without rescaling: keep clear of underflow
     for (const Group &gr : groups) {
+        if (ss_hybrid && gr.span > ss_hyb_th) continue;          // an eigen-power step, not `span` scan steps
         double mn = 1.0;
         for (int i = 0; i < M; ++i) mn = std::min(mn, E[(size_t)gr.kid * M + i]);
         if (!(mn > 0.0) || (double)gr.span * std::log(mn) < -450.0) return false;
@@ -1950,21 +1980,21 @@ bool smcpp_im::ss_extract_generators() {
     return true;
 }
 
-template <int NPL_>
-static void launch_chain_ss_t(const SsArgs &a, int ntasks, size_t shm, hipStream_t s) {
+template <int NPL_, bool HYB_>
+static void launch_chain_ss_t(const SsArgs &a, int ntasks, size_t shm, hipStream_t s, int wgw) {
     static bool once = false;
     if (!once) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss<NPL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss<NPL_, HYB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;
     }
-    hipLaunchKernelGGL((k_chain_ss<NPL_>), dim3(ntasks / 4), dim3(256), shm, s, a);
+    hipLaunchKernelGGL((k_chain_ss<NPL_, HYB_>), dim3(ntasks / wgw), dim3(64 * wgw), shm, s, a);
 }
-static void launch_chain_ss(int npl, const SsArgs &a, int ntasks, size_t shm, hipStream_t s) {
+static void launch_chain_ss(int npl, const SsArgs &a, int ntasks, size_t shm, hipStream_t s, int wgw = 4) {
     switch (npl) {
-        case 1: launch_chain_ss_t<1>(a, ntasks, shm, s); break;
-        case 2: launch_chain_ss_t<2>(a, ntasks, shm, s); break;
-        case 3: launch_chain_ss_t<3>(a, ntasks, shm, s); break;
-        case 4: launch_chain_ss_t<4>(a, ntasks, shm, s); break;
+        case 1: if (a.hyb_th != 0x7fffffff) launch_chain_ss_t<1, true>(a, ntasks, shm, s, wgw); else launch_chain_ss_t<1, false>(a, ntasks, shm, s, 4); break;
+        case 2: launch_chain_ss_t<2, false>(a, ntasks, shm, s, 4); break;
+        case 3: launch_chain_ss_t<3, false>(a, ntasks, shm, s, 4); break;
+        case 4: launch_chain_ss_t<4, false>(a, ntasks, shm, s, 4); break;
         default: throw std::runtime_error("unsupported number of hidden states");
     }
 }
@@ -1989,7 +2019,7 @@ static void launch_chain_ss4(int spl, const SsArgs &a, size_t shm, hipStream_t s
 }
 
 void smcpp_im::ss_launch_passes(int upto) {
-    const size_t shm = (size_t)ss_nlds * 64 * NPL * sizeof(double);
+    const size_t shm = (size_t)ss_nlds * 64 * NPL * sizeof(double) + ss_tab_bytes();
     const size_t shm4 = (size_t)K * 16 * SPL * sizeof(double);
     for (; ss_launched < upto; ++ss_launched) {
         // per direction: `light` store-free float passes (history), then one full fp64 pass from their end vectors, then re-run
@@ -2002,7 +2032,7 @@ void smcpp_im::ss_launch_passes(int upto) {
             ss_args.mode_b = lb ? 2 : p == 0 ? 0 : 1;
             ss_args.full_f = (p > 0 && p == ss_light_f) ? 1 : 0;
             ss_args.full_b = (p > 0 && p == ss_light_b) ? 1 : 0;
-            launch_chain_ss(NPL, ss_args, (int)ss_tasks.size(), shm, stream);
+            launch_chain_ss(NPL, ss_args, (int)ss_tasks.size(), shm, stream, ss_wg_waves);
             continue;
         }
         // M <= 64: the light passes run on the coarse chunks (one chain per wavefront), the fp64 passes on the fine ones (four
@@ -2013,7 +2043,7 @@ void smcpp_im::ss_launch_passes(int upto) {
             ss_args.mode_b = lb ? 2 : 3;
             ss_args.hand_f = p == ss_light_f - 1;
             ss_args.hand_b = p == ss_light_b - 1;
-            launch_chain_ss(NPL, ss_args, (int)ss_tasks.size(), shm, stream);
+            launch_chain_ss(NPL, ss_args, (int)ss_tasks.size(), shm, stream, ss_wg_waves);
         }
         if (!lf || !lb) {
             ss4_args.pass = p;
@@ -2091,6 +2121,10 @@ void smcpp_im::ss_launch_initial() {
     a.changed_f = d_flags_view; a.changed_b = d_flags_view + (max_pass + 1);
     a.eps_f = eps_f; a.eps_b = eps_b; a.full_f = a.full_b = 0;
     a.fine = nullptr; a.nfine = 0; a.hand_f = a.hand_b = 0; a.fine_ends_f = nullptr; a.fine_ends_b = nullptr;
+    if (ss_hybrid) {
+        a.hyb_th = ss_hyb_th; a.Ke = Ke; a.hot_ek = std::max(0, hot_eig);
+        a.Pinvrm = d_Pinvrm.p; a.Prm = d_Prm.p; a.PinvT = d_PinvT.p; a.PT = d_PT.p; a.dsc = d_dsc.p;
+    }
     if (ss4) {
         SsArgs &b4 = ss4_args;
         b4 = a;                                  // fine chunks, fine end vectors, row state: as above
@@ -2125,6 +2159,7 @@ void smcpp_im::ss_launch_initial() {
         if ((ss4 ? chunks1.size() : chunks.size()) <= (size_t)n_contigs) ss_light_f = 0;      // one chunk per contig: nothing to iterate
         if ((ss4 ? chunks1.size() : chunks_b.size()) <= (size_t)n_contigs) ss_light_b = 0;
     }
+    if (ss_hybrid) ss_light_f = ss_light_b = 0;      // (the light passes have no eigen-power step; un-binned inputs have long chunks)
     ss_pass0 = 0;
     if (warm_start && ss_warm_valid && !ss4 && chunks.size() > (size_t)n_contigs && chunks_b.size() > (size_t)n_contigs) {
         // the boundary vectors of the previous E-step are exact for ITS parameters, i.e. off by the parameter step instead of by
@@ -2560,9 +2595,11 @@ void smcpp_im::estep() {
         static const bool off = getenv("SMCPP_EIGFREE") && atoi(getenv("SMCPP_EIGFREE")) == 0;
         eigfree = ss_active && !off && Mp <= 256 && ss_max_span <= 64 && !save_gamma;
     }
-    if (ss_active) { prepass_launched = false; static_packed = false; ss_launch_initial(); }   // the chains need no eigensystem: they start now
+    if (ss_active && !ss_hybrid) { prepass_launched = false; static_packed = false; ss_launch_initial(); }   // the chains need no eigensystem: they start now
+    else if (ss_active) { prepass_launched = false; static_packed = false; }
     else stage_static_and_prepass();   // (when eligible) pass 0 of both chains starts now, on eigen-free operands
     host_prep_and_upload();   // the reference rebuilds the eigensystems on every E-step (inference_manager.cpp:112)
+    if (ss_active && ss_hybrid) ss_launch_initial();       // hybrid rows read the eigensystems: the chains start behind them
     auto t1 = std::chrono::steady_clock::now();
     if (ss_active) run_chains_ss(); else run_chains();
     run_stats();
@@ -3155,7 +3192,7 @@ void *smcpp_stream(smcpp_im *im) { return (void *)im->stream; }
 // 4 lock-step on the matrix cores (chosen at construction / smcpp_set_chunking from the state count and the input size)
 // 5 = scans over the semiseparable structure of T (chains_ss.hpp; the dense kernels named by the other values remain the
 // fallback of an E-step whose T has no such structure)
-int smcpp_chain_mode(smcpp_im *im) { return im ? (im->ss_static ? 5 : im->chain_mode) : -1; }
+int smcpp_chain_mode(smcpp_im *im) { return im ? (im->ss_static ? (im->ss_hybrid ? 6 : 5) : im->chain_mode) : -1; }
 
 // Test hook (tests/test_gpu_ss.py): one position of both scan chains on nvec vectors, out_f = e o (T^T x), out_b = T (e o x);
 // x, e and the outputs are [nvec][M].  Returns 2 when T has no semiseparable structure.

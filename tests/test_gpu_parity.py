@@ -797,3 +797,45 @@ def test_span1_statistics_one_pass_in_key_order(monkeypatch):
         assert rel_err(x1, x0) <= 1e-11
         for k, v in g0.items():
             np.testing.assert_allclose(g1[k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
+
+
+def test_hybrid_scan_chains_on_unbinned_data(monkeypatch):
+    """Un-binned data (spans to 10^5): the scan kernel with HYBRID rows (chain mode 6: a long row is one eigen-power step
+    P d^s P^-1 inside the one-wavefront-per-chunk kernel, a short one `span` scan steps) against the dense chains (SMCPP_HYBRID=0)
+    on the reference's own un-binned contig (golden G7, with gamma) and on a synthetic contig long enough for several chunks."""
+    from smcpp_amd import _smcpp
+    g = load_golden("G7_M32_n8_chr11")
+    res = {}
+    for hyb in ("1", "0"):
+        monkeypatch.setenv("SMCPP_HYBRID", hyb)
+        im = make_im(g)
+        im.save_gamma = True
+        im.E_step()
+        check_against(g, im, save_gamma=True)
+        res[hyb] = (im.chain_mode(), im.loglik(), im.xisums[0], im.gammas[0])
+    assert res["1"][0] == 6 and res["0"][0] != 6
+    assert abs(res["1"][1] - res["0"][1]) <= 1e-8 * abs(res["0"][1])
+    assert rel_err(res["1"][2], res["0"][2]) <= 2 * STAT_TOL
+    assert np.array_equal(np.argmax(res["1"][3], axis=0), np.argmax(res["0"][3], axis=0))
+    # synthetic un-binned contig: 60 000 rows over G7's own keys, chunks of 2 000 rows so that the fixed point iterates
+    rng = np.random.default_rng(11)
+    L = 60_000
+    keys = np.asarray(g["keys"], dtype=np.int32)
+    mono = int(np.nonzero((keys == np.array([0, 0, 8])).all(axis=1))[0][0])
+    kid = rng.integers(0, len(keys), L)
+    span = np.where(rng.random(L) < 0.45, 1, np.minimum(100_000, 1 + rng.geometric(2e-3, L)))
+    kid[span > 1] = mono                                       # long spans are monomorphic stretches
+    obs = np.concatenate([span[:, None], keys[kid]], axis=1).astype(np.int32)
+    out = {}
+    for hyb in ("1", "0"):
+        monkeypatch.setenv("SMCPP_HYBRID", hyb)
+        im = _smcpp.PyOnePopInferenceManager(8, [obs], g["hs"], ("pop1",), float(g["pol"]))
+        im.set_raw(g["pi"], g["T"], g["keys"], g["E"])
+        im.set_chunking(2000)
+        im.E_step()
+        out[hyb] = (im.chain_mode(), im.loglik(), im.xisums[0], im.gamma_sums[0], im.last_timing()["fwd_passes"])
+    assert out["1"][0] == 6 and out["1"][4] >= 2
+    assert abs(out["1"][1] - out["0"][1]) <= 1e-8 * abs(out["0"][1])
+    assert rel_err(out["1"][2], out["0"][2]) <= 2 * STAT_TOL
+    for k, v in out["0"][3].items():
+        assert np.max(np.abs(out["1"][3][k] - v)) <= 2 * STAT_TOL * max(np.abs(v).max(), 1e-300)

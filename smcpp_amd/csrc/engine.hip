@@ -212,7 +212,7 @@ struct smcpp_im {
     int device = 0;
     hipStream_t stream3 = nullptr;         // third branch of the statistics (per-key gamma sums)
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: backward chain when it may overlap the forward one
-    hipEvent_t ev[22];                                  // 10..13: forward / backward interval of the eigen-free pre-pass; 14: span-1 scalars done
+    hipEvent_t ev[24];                                  // 10..13: forward / backward interval of the eigen-free pre-pass; 14: span-1 scalars done
     int dual_stream = 1;
     hipStream_t stream_hi = nullptr;
     bool chains_dual = false;
@@ -2211,7 +2211,8 @@ void smcpp_im::run_chains_ss() {
         HIPCHK(hipEventRecord(ev[3], s));
         // optimistic, as run_chains(): the statistics are queued right behind the passes; the host only looks at the flags (pinned
         // memory the kernels wrote) when the queue has drained; in the rare round that needs more passes the statistics are redone
-        if (first_round && !save_gamma) enqueue_stats();
+        static const bool spec_gamma = !(getenv("SMCPP_SPEC_GAMMA") && atoi(getenv("SMCPP_SPEC_GAMMA")) == 0);
+        if (first_round && (!save_gamma || spec_gamma)) enqueue_stats();          // (save_gamma too: the passes launched up front almost always suffice)
         else stats_enqueued = false;
         done_covers_stats = stats_enqueued;
         if (poll) {
@@ -2267,9 +2268,15 @@ void smcpp_im::enqueue_stats() {
     la.contig_base = d_contig_base.p; la.contig_L = d_contig_L.p; la.partial = d_llpart.p; la.loglik = d_loglik.p;
     la.logc = d_logc.p; la.nblk = llblk;
     la.loglik_host = d_ll_view;          // the final kernel writes the per-contig values into the pinned array as well: no copy
+    // save_gamma: the per-row gammas of the span > 1 rows (2 M^3 flop each, the matrix pipe's business for ~1 ms on a million rows)
+    // need alpha, beta and the eigensystems only - not a single statistic: they run on their own stream BESIDE the (memory- and
+    // latency-bound) statistics instead of behind them
+    const bool gamma_side = save_gamma && n_e_rows > 0 && dual_stream && stream_hi != nullptr &&
+                            !(getenv("SMCPP_GAMMA_SIDE") && atoi(getenv("SMCPP_GAMMA_SIDE")) == 0);
     if (save_gamma) {
         d_gamma_rows.alloc((size_t)total_rows * Mp);
         d_gamma_rows.zero(s);
+        if (gamma_side) { HIPCHK(hipEventRecord(ev[22], s)); HIPCHK(hipStreamWaitEvent(stream_hi, ev[22], 0)); }
     }
     // The eigen-row branch (U/W products, rank update, span-Q Hadamard, Y) does not depend on the span-1 branch
     // (log_c, omega_1, rank update); with two streams the short launches of one fill the gaps of the other.
@@ -2519,6 +2526,7 @@ void smcpp_im::enqueue_stats() {
     hipLaunchKernelGGL(k_fin_xisum, dim3(nb2, n_contigs), dim3(256), 0, s, fa);
     hipLaunchKernelGGL(k_fin_gamma, dim3(ceil_div((long long)(K + 1) * Mp, 256), n_contigs), dim3(256), 0, s, fa);
     if (save_gamma && n_e_rows > 0) {
+        hipStream_t sg = gamma_side ? stream_hi : s;
         GammaRowArgs ga;
         ga.M = M; ga.Mp = Mp; ga.nrows = (int)n_e_rows; ga.perm = d_perme.p; ga.row_slab = d_erow_slab.p;
         ga.slabs = d_slabs_eg.p; ga.g_eig = d_g_eig.p; ga.g_span = d_g_span.p; ga.dun = d_dun.p; ga.dsc = d_dsc.p; ga.dpow = d_dpow.p;
@@ -2530,7 +2538,7 @@ void smcpp_im::enqueue_stats() {
         const bool mfma_rows = NT <= 4 && !scalar_rows;
         if (!mfma_rows || rows_gen == 1) {
             d_Sq.alloc((size_t)G * Mp * Mp);
-            hipLaunchKernelGGL(k_span_q, dim3(nb2, G), dim3(256), 0, s, M, Mp, G, (const int *)d_g_span.p,
+            hipLaunchKernelGGL(k_span_q, dim3(nb2, G), dim3(256), 0, sg, M, Mp, G, (const int *)d_g_span.p,
                                (const int *)d_g_eig.p, (const double *)d_dsc.p, (const double *)d_dpow.p, d_Sq.p);
             ga.Sq = d_Sq.p;
         }
@@ -2545,7 +2553,7 @@ void smcpp_im::enqueue_stats() {
                 const int nblk = ceil_div(q1 - q0, 16 * NW * nbatch);
                 switch (NT) {
 #define G_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_gamma_rows_b<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
-                        hipLaunchKernelGGL(k_gamma_rows_b<x>, dim3(nblk), dim3(64 * (x <= 2 ? 4 : 2)), shm2, s, ga, q0, q1, ce % Ke, nbatch); } break;
+                        hipLaunchKernelGGL(k_gamma_rows_b<x>, dim3(nblk), dim3(64 * (x <= 2 ? 4 : 2)), shm2, sg, ga, q0, q1, ce % Ke, nbatch); } break;
                     G_(1) G_(2) G_(3)
                     default: G_(4)
 #undef G_
@@ -2561,7 +2569,7 @@ void smcpp_im::enqueue_stats() {
                 const int nblk = ceil_div(q1 - q0, 4 * rpw);
                 switch (NT) {
 #define G_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_gamma_rows_mfma<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
-                        hipLaunchKernelGGL(k_gamma_rows_mfma<x>, dim3(nblk), dim3(256), shm2, s, ga, q0, q1, ce % Ke, rpw); } break;
+                        hipLaunchKernelGGL(k_gamma_rows_mfma<x>, dim3(nblk), dim3(256), shm2, sg, ga, q0, q1, ce % Ke, rpw); } break;
                     G_(1) G_(2) G_(3)
                     default: G_(4)
 #undef G_
@@ -2569,8 +2577,9 @@ void smcpp_im::enqueue_stats() {
             }
         } else {
             const size_t shm = (size_t)(3 * Mp + 256) * sizeof(double);
-            hipLaunchKernelGGL(k_gamma_rows_eig, dim3((unsigned)n_e_rows), dim3(256), shm, s, ga);
+            hipLaunchKernelGGL(k_gamma_rows_eig, dim3((unsigned)n_e_rows), dim3(256), shm, sg, ga);
         }
+            if (gamma_side) { HIPCHK(hipEventRecord(ev[23], sg)); HIPCHK(hipStreamWaitEvent(s, ev[23], 0)); }
     }
     HIPCHK(hipGetLastError());
     if (ll_own) HIPCHK(hipStreamWaitEvent(s, ev[19], 0));

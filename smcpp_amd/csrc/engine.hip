@@ -1354,7 +1354,7 @@ void smcpp_im::host_prep_and_upload() {
     }
     std::vector<float> qTf;
     std::vector<double> qTdT, qPinvT, qPT, qPrm, qPinvrm;
-    if (Mp > 64 && chain_mode == 3) {
+    if (Mp > 64 && chain_mode == 3 && !ss_active) {          // (the scan chains stream no operand)
         // quarter-interleaved streaming layouts  Q[t][i][kq] = Mt[(kq*KQ + t)*Mp + i]  (k_fwd_big / k_bwd_big)
         const int KQ = Mp / 4;
         qTf.assign(MM, 0.f); qTdT.assign(MM, 0.0);
@@ -1935,15 +1935,26 @@ static bool ss_generators(int M, int MS, const double *Tm, std::vector<double> &
     for (int j = 0; j + 1 < M; ++j) {
         g[j] = Tm[(size_t)(M - 1) * M + j];
         b[j] = Tm[(size_t)j * M + j + 1] - c0;
-        for (int i = j + 1; i < M; ++i)
-            if (!(std::fabs(Tm[(size_t)i * M + j] - g[j]) <= tol * std::fabs(g[j]))) return false;
     }
-    for (int j = 1; j + 1 < M; ++j) {
-        int ib = 0;
-        for (int i = 1; i < j; ++i)
-            if (Tm[(size_t)i * M + j] > Tm[(size_t)ib * M + j]) ib = i;
-        const double den = Tm[(size_t)ib * M + j] - c0;
-        a[j] = den > 0.0 ? (Tm[(size_t)ib * M + j + 1] - c0) / den : 0.0;
+    // (both sweeps below walk T row by row: at M = 256 the matrix is 512 KB and a column walk misses the cache on every entry)
+    for (int i = 1; i < M; ++i) {
+        const double *row = Tm + (size_t)i * M;
+        for (int j = 0; j < i && j + 1 < M; ++j)
+            if (!(std::fabs(row[j] - g[j]) <= tol * std::fabs(g[j]))) return false;
+    }
+    {
+        // a_j from the row with the LARGEST entry in column j above the diagonal (best conditioned quotient)
+        std::vector<int> ib(M, 0);
+        std::vector<double> best(M, -1.0);
+        for (int i = 0; i + 2 < M; ++i) {
+            const double *row = Tm + (size_t)i * M;
+            for (int j = std::max(1, i + 1); j + 1 < M; ++j)
+                if (row[j] > best[j]) { best[j] = row[j]; ib[j] = i; }
+        }
+        for (int j = 1; j + 1 < M; ++j) {
+            const double den = Tm[(size_t)ib[j] * M + j] - c0;
+            a[j] = den > 0.0 ? (Tm[(size_t)ib[j] * M + j + 1] - c0) / den : 0.0;
+        }
     }
     for (int i = 0; i + 1 < M; ++i) {
         double v = b[i];

@@ -146,6 +146,11 @@ int smcpp_last_timing(smcpp_im *im, double out[9]);
  * src/transition.cpp:176-254 - one position per step, no eigensystem; an E-step whose T lacks that structure runs the
  * dense kernels instead; 6 = family 5 with HYBRID rows: un-binned data, a row whose span exceeds a few positions is one
  * eigen-power step P d^s P^-1 inside the scan kernel - hmm.cpp:72-78,104-112 - instead of `span` scan steps) */
+/* Host-only (no device needed): chunks per contig of the scan chains for `nslots` wavefront slots, cost[c] = positions (or cost
+ * units) of contig c, rows[c] its row count; never more chunks than slots in total unless there are more contigs than slots, and
+ * the longest chunk as short as the slot count allows (the reference parallelises over contigs only, inference_manager.cpp:89-94;
+ * this is the engine's own decomposition, exported for the CPU tests). */
+int smcpp_host_chunk_counts(int n_contigs, const long long *cost, const int *rows, long long nslots, long long floor_cost, int *out);
 int smcpp_chain_mode(smcpp_im *im);
 /* Test hook of family 5: one position of both scan chains on nvec vectors: out_f = e o (T^T x), out_b = T (e o x); T is
  * [M][M] row-major, x / e / out_* are [nvec][M].  Returns 2 when T has no semiseparable structure (nothing is written). */

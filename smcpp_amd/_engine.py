@@ -68,6 +68,7 @@ def lib():
         "smcpp_debug_ss_apply": (i, [i, _dp, i, _dp, _dp, _dp, _dp]),
         "smcpp_debug_ss4_apply": (i, [i, _dp, i, _dp, _dp, _dp, _dp]),
         "smcpp_host_set_csfs_direct": (i, [i]),
+        "smcpp_host_chunk_counts": (i, [i, C.POINTER(C.c_longlong), _ip, C.c_longlong, C.c_longlong, _ip]),
         "smcpp_host_eigensystem": (i, [i, _dp, _dp, _dp, _dp, _dp, _dp]),
         "smcpp_host_eigensystem_team": (i, [i, _dp, i, _dp, _dp, _dp, _dp, _dp]),
         "smcpp_host_prep_onepop": (i, [i, i, _dp, d, i, _dp, _dp, d, d, d, i, _ip, _dp, _dp, _dp]),
@@ -100,7 +101,7 @@ EXPORTS = [
     "smcpp_num_keys", "smcpp_key_len", "smcpp_get_hidden_states", "smcpp_set_hidden_states", "smcpp_get_keys",
     "smcpp_get_xisum", "smcpp_get_gamma", "smcpp_get_gamma_sums", "smcpp_get_pi", "smcpp_get_transition",
     "smcpp_get_emission_probs", "smcpp_get_gamma_argmax", "smcpp_set_global_keys", "smcpp_pack_stats",
-    "smcpp_unpack_stats", "smcpp_set_chunking", "smcpp_last_timing", "smcpp_stream", "smcpp_chain_mode", "smcpp_set_num_threads",
+    "smcpp_unpack_stats", "smcpp_set_chunking", "smcpp_last_timing", "smcpp_stream", "smcpp_chain_mode", "smcpp_host_chunk_counts", "smcpp_set_num_threads",
     "smcpp_host_eigensystem", "smcpp_host_eigensystem_team", "smcpp_host_prep_onepop", "smcpp_host_prep_onepop_jac", "smcpp_num_derivatives",
     "smcpp_host_rate_function", "smcpp_host_rate_function_jac", "smcpp_host_random_coal_times", "smcpp_host_raw_sfs",
     "smcpp_set_params_twopop", "smcpp_host_joint_csfs", "smcpp_host_prep_twopop", "smcpp_set_warm_start",
@@ -127,6 +128,16 @@ def host_set_csfs_direct(on):
     """Test hook: literal (reference-order) evaluation of the conditioned SFS instead of the factored one; returns the
     previous setting."""
     return bool(lib().smcpp_host_set_csfs_direct(int(bool(on))))
+
+
+def host_chunk_counts(cost, rows, nslots, floor_cost=1):
+    """Chunks per contig of the scan chains for `nslots` wavefront slots (host-only: `smcpp_host_chunk_counts`)."""
+    cost = np.ascontiguousarray(cost, dtype=np.int64)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    out = np.zeros(len(cost), dtype=np.int32)
+    check(lib().smcpp_host_chunk_counts(len(cost), cost.ctypes.data_as(C.POINTER(C.c_longlong)), iptr(rows),
+                                        int(nslots), int(floor_cost), iptr(out)))
+    return out
 
 
 def host_eigensystem(A):

@@ -530,6 +530,38 @@ static long long lock_min_rows(int Mp) {
     return Mp >= 48 ? 450 : Mp >= 32 ? 800 : (1ll << 40);
 }
 
+// Chunks per contig of the scan chains for `nslots` wavefront slots (cost = positions, or cost units with hybrid rows): start from
+// the rounded-down share of every contig and hand the remaining slots, one at a time, to the contig whose chunks are currently
+// the longest - never more chunks than slots (unless there are more contigs than slots), and the longest chunk is as short as the
+// slot count allows.  Host-only; exported as smcpp_host_chunk_counts for the CPU tests.
+static std::vector<int> ss_chunk_counts(const std::vector<long long> &cpos, const std::vector<int> &rows, long long nslots,
+                                        long long floor_cost) {
+    const int n = (int)cpos.size();
+    long long total = 0;
+    for (long long c : cpos) total += c;
+    const long long bpc = std::max<long long>(std::max<long long>(1, floor_cost), (total + nslots - 1) / std::max<long long>(1, nslots));
+    std::vector<int> ncs(n, 1);
+    long long used = 0;
+    for (int c = 0; c < n; ++c) {
+        ncs[c] = (int)std::max<long long>(1, std::min<long long>(rows[c], cpos[c] / bpc));
+        used += ncs[c];
+    }
+    const long long want = std::max<long long>(n, std::min<long long>(nslots, (total + bpc - 1) / bpc));
+    while (used < want) {
+        int best = -1;
+        double bl = 0.0;
+        for (int c = 0; c < n; ++c) {
+            if (ncs[c] >= rows[c]) continue;
+            const double len = (double)cpos[c] / ncs[c];
+            if (best < 0 || len > bl) { best = c; bl = len; }
+        }
+        if (best < 0) break;
+        ++ncs[best];
+        ++used;
+    }
+    return ncs;
+}
+
 void smcpp_im::make_chunks() {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -628,32 +660,11 @@ void smcpp_im::make_chunks() {
                 cpos[c] += ri.gid < 0 ? 1 : ss_row_cost(groups[ri.gid].span);
             }
         auto cut = [&](long long nslots, long long floor_bins, std::vector<Chunk> &out) {
-            const long long bpc = std::max<long long>(floor_bins, (total_bins + nslots - 1) / nslots);
             // Chunks per contig: NEVER more chunks than wavefront slots in total (a launch of 1046 wavefronts on 1024 SIMDs puts two
             // on some of them, and the kernel then lasts as long as those take: whole genome, 22 contigs each rounded up, +27 %).
             // Start from the rounded-down share of every contig and hand the remaining slots, one at a time, to the contig whose
             // chunks are currently the longest (minimises the longest chunk).
-            std::vector<int> ncs(n_contigs, 1);
-            {
-                long long used = 0;
-                for (int c = 0; c < n_contigs; ++c) {
-                    ncs[c] = (int)std::max<long long>(1, std::min<long long>(Ls[c], cpos[c] / bpc));
-                    used += ncs[c];
-                }
-                const long long want = std::max<long long>(n_contigs, std::min<long long>(nslots, (total_bins + bpc - 1) / bpc));
-                while (used < want) {
-                    int best = -1;
-                    double bl = 0.0;
-                    for (int c = 0; c < n_contigs; ++c) {
-                        if (ncs[c] >= Ls[c]) continue;
-                        const double len = (double)cpos[c] / ncs[c];
-                        if (best < 0 || len > bl) { best = c; bl = len; }
-                    }
-                    if (best < 0) break;
-                    ++ncs[best];
-                    ++used;
-                }
-            }
+            const std::vector<int> ncs = ss_chunk_counts(cpos, Ls, nslots, floor_bins);
             out.clear();
             for (int c = 0; c < n_contigs; ++c) {
                 const int L = Ls[c];
@@ -3212,6 +3223,16 @@ void *smcpp_stream(smcpp_im *im) { return (void *)im->stream; }
 // 4 lock-step on the matrix cores (chosen at construction / smcpp_set_chunking from the state count and the input size)
 // 5 = scans over the semiseparable structure of T (chains_ss.hpp; the dense kernels named by the other values remain the
 // fallback of an E-step whose T has no such structure)
+int smcpp_host_chunk_counts(int n_contigs, const long long *cost, const int *rows, long long nslots, long long floor_cost, int *out) {
+    API_BEGIN
+    if (n_contigs <= 0 || nslots <= 0) throw std::runtime_error("smcpp_host_chunk_counts: empty input");
+    const std::vector<long long> c(cost, cost + n_contigs);
+    const std::vector<int> r(rows, rows + n_contigs);
+    const std::vector<int> ncs = ss_chunk_counts(c, r, nslots, floor_cost);
+    std::copy(ncs.begin(), ncs.end(), out);
+    API_END
+}
+
 int smcpp_chain_mode(smcpp_im *im) { return im ? (im->ss_static ? (im->ss_hybrid ? 6 : 5) : im->chain_mode) : -1; }
 
 // Test hook (tests/test_gpu_ss.py): one position of both scan chains on nvec vectors, out_f = e o (T^T x), out_b = T (e o x);

@@ -138,3 +138,31 @@ def test_batched_statistics_algebra():
     for k, v in o["gamma_sums"].items():
         ki = int(np.where((keys == k).all(1))[0][0])
         assert np.max(np.abs(gs[ki] - v)) <= 1e-10 * np.abs(v).max()
+
+
+def test_scan_chain_chunks_never_exceed_the_wavefront_slots():
+    """`smcpp_host_chunk_counts` (the allocation the engine cuts the scan chains' chunk lists with): every contig gets at least one
+    chunk, the total never exceeds the slots (22 autosomes each rounded UP once gave 1 046 wavefronts for 1 024 SIMDs and the
+    stragglers cost 27 % of the pass), no contig gets more chunks than rows, and the longest chunk is within one contig's
+    rounding of the ideal."""
+    from smcpp_amd import _engine as E
+    from smcpp_amd import synth
+    cost = np.array([int(x * 1e4) for x in synth.C3_LENGTHS_MBP], dtype=np.int64)        # binned: 10^4 positions per Mbp
+    rows = (cost // 4).astype(np.int32)
+    for nslots in (512, 1536, 3072):
+        n = E.host_chunk_counts(cost, rows, nslots, 1024)
+        assert n.min() >= 1 and n.sum() <= nslots and np.all(n <= rows)
+        assert n.sum() == nslots                                        # long contigs: every slot is used
+        longest = (cost / n).max()
+        assert longest <= cost.sum() / nslots * (1.0 + 1.0 / n.min())
+    # the floor: a small input gets few, long chunks
+    small = np.array([5000, 3000], dtype=np.int64)
+    n = E.host_chunk_counts(small, np.array([1200, 700], dtype=np.int32), 512, 1024)
+    assert n.tolist() == [4, 3] or n.sum() <= 8
+    # more contigs than slots: one chunk each
+    many = np.full(40, 10_000, dtype=np.int64)
+    n = E.host_chunk_counts(many, np.full(40, 2000, dtype=np.int32), 16, 1024)
+    assert n.tolist() == [1] * 40
+    # a contig cannot have more chunks than rows
+    n = E.host_chunk_counts(np.array([10 ** 9, 10 ** 6], dtype=np.int64), np.array([3, 5000], dtype=np.int32), 512, 1024)
+    assert n[0] <= 3 and n.sum() <= 512

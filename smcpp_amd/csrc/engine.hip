@@ -227,6 +227,8 @@ struct smcpp_im {
                           // 3 CU-cooperative with streamed operands (64 < M <= 256), 4 lock-step on the matrix cores (16 chunks per workgroup)
     int coop_bpc = 1;     // cooperative workgroups resident per CU the automatic chunking aims at
     // ---- chains on the semiseparable structure of T (chains_ss.hpp; chain_mode 5) ------------------------------------------
+    std::unique_ptr<smcpp_host::OnePopPrep> prep1;   // one-population cold preparation (caches per-key tables)
+    std::vector<double> prep1_hs;
     bool ss_static = false;                // the input qualifies (short spans); whether T does is decided on every E-step
     // hybrid scan chains (un-binned data): rows whose span exceeds ss_hyb_th take ONE eigen-power step inside the scan kernel
     // (chains_ss.hpp); they cost about SS_HYB_COST scan positions each, which is what the chunk list is balanced on
@@ -1143,7 +1145,9 @@ void smcpp_im::prepare_params() {
         params_fresh = true;
         return;
     }
-    smcpp_host::OnePopPrep prep(n[0], hs, polarization_error);
+    // (kept across E-steps: it caches the keys' marginalisation bins; rebuilt when the hidden states change)
+    if (!prep1 || prep1_hs != hs) { prep1.reset(new smcpp_host::OnePopPrep(n[0], hs, polarization_error)); prep1_hs = hs; }
+    smcpp_host::OnePopPrep &prep = *prep1;
     // with a global key dictionary (multi-GPU) the emission table is prepared for every global key; the local table
     // is the sub-list of the keys this rank's contigs hold
     const std::vector<int> &pk = have_global ? gkeys : keys;

@@ -703,6 +703,20 @@ inline std::vector<S> compute_transition(const RateFunctionT<S> &eta, double rho
     std::vector<S> expm_diff(std::max(0, M - 1));
     for (int k = 1; k < M; ++k)
         expm_diff[k - 1] = W::down(prods[hsi[k]].m[0][2]) - W::down(prods[hsi[k - 1]].m[0][2]);
+    // Upper part: the reference evaluates, for every pair j < k, exp(-sum of the increments of the states between them) and
+    // -expm1(-inc_k) (transition.cpp:217-233: M^2 / 2 pairs, two transcendental calls each - 0.1 ms at M = 64, serial).  Both
+    // factor: with C_t = inc_1 + ... + inc_t the first is exp(-C_{k-1}) / exp(-C_j), the second depends on k only: O(M)
+    // calls, one division per pair (differences of ~3e-16 relative against the pairwise form; the ratio is not used where
+    // exp(-C_j) has left the normal range).
+    std::vector<S> inc_k(Mh, S(0.0)), Ccum(Mh, S(0.0)), Ek(Mh, S(1.0)), qk(Mh, S(1.0));
+    for (int k = 1; k < Mh; ++k) {
+        S inc(0.0);
+        for (int jj = hsi[k - 1]; jj < hsi[k]; ++jj) inc += ada[jj] * (ts[jj + 1] - ts[jj]);
+        inc_k[k] = inc;
+        Ccum[k] = Ccum[k - 1] + inc;
+        Ek[k] = m_exp(-Ccum[k]);
+        qk[k] = std::isinf((double)sval(inc)) ? S(1.0) : S(-m_expm1(-inc));
+    }
     std::vector<S> Phi((size_t)M * M, S(0.0));
     for (int j = 1; j < Mh; ++j) {
         S *row = &Phi[(size_t)(j - 1) * M];
@@ -720,14 +734,16 @@ inline std::vector<S> compute_transition(const RateFunctionT<S> &eta, double rho
         Rj += ada[rct_ip] * (ts[rct_ip + 1] - rct);
         for (int jj = rct_ip + 2; jj < hsi[j]; ++jj) Rj += ada[jj] * (ts[jj + 1] - ts[jj]);
         const S p_float = B.m[0][1] * m_exp(-Rj);
-        S Rjk1(0.0);
-        for (int k = j + 1; k < Mh; ++k) {
-            S inc(0.0);
-            for (int jj = hsi[k - 1]; jj < hsi[k]; ++jj) inc += ada[jj] * (ts[jj + 1] - ts[jj]);
-            S p_coal = m_exp(-Rjk1);
-            Rjk1 += inc;
-            if (!std::isinf((double)sval(inc))) p_coal *= -m_expm1(-inc);
-            row[k - 1] += p_float * p_coal;
+        if (sval(Ek[j]) > 1e-250) {
+            const S pf = p_float / Ek[j];
+            for (int k = j + 1; k < Mh; ++k) row[k - 1] += pf * (Ek[k - 1] * qk[k]);
+        } else {
+            S Rjk1(0.0);
+            for (int k = j + 1; k < Mh; ++k) {
+                S p_coal = m_exp(-Rjk1);
+                Rjk1 += inc_k[k];
+                row[k - 1] += p_float * (p_coal * qk[k]);
+            }
         }
         row[j - 1] = S(0.0);
         S sm(0.0);
@@ -1237,9 +1253,15 @@ public:
             if (reduced && (miss || bk[0] >= 0)) {
                 for (int m = 0; m < M; ++m) e[m] = miss ? S(1.0) : e2[2 * m + (bk[0] % 2)];
             } else {
-                const auto bins = bins_for(bk);
-                for (const auto &p : bins)
-                    for (int m = 0; m < M; ++m) e[m] += p.second * sfs[m][(size_t)p.first.first * (n_ + 1) + p.first.second];
+                // the bins of a key (hypergeometric weights: lgamma calls, a std::map) depend on the manager only: built once
+                auto it = bins_cache_.find(bk);
+                if (it == bins_cache_.end()) {
+                    std::vector<std::pair<int, double>> flat;
+                    for (const auto &p : bins_for(bk)) flat.emplace_back(p.first.first * (n_ + 1) + p.first.second, p.second);
+                    it = bins_cache_.emplace(bk, std::move(flat)).first;
+                }
+                for (const auto &p : it->second)
+                    for (int m = 0; m < M; ++m) e[m] += p.second * sfs[m][(size_t)p.first];
             }
             double mx = sval(e[0]), mn = sval(e[0]);
             for (int m = 1; m < M; ++m) { mx = std::max(mx, (double)sval(e[m])); mn = std::min(mn, (double)sval(e[m])); }
@@ -1252,6 +1274,7 @@ private:
     std::vector<double> hs_;
     double pol_;
     std::shared_ptr<const CsfsTables> tables_;
+    mutable std::map<Key, std::vector<std::pair<int, double>>> bins_cache_;   // key -> (flattened CSFS index, weight), in bins_for's order
 };
 
 }  // namespace smcpp_host

@@ -205,6 +205,17 @@ int smcpp_host_prep_onepop_jac(int n, int n_hs, const double *hs, double polariz
                                int K, const int *keys, double *pi, double *T, double *E, double *dpi, double *dT,
                                double *dE);
 
+/* The same preparation with the conditioned SFS (A10), incorporate_theta and the emission table (A6) evaluated by the HIP
+ * kernels of smcpp_amd/csrc/prep_dev.hpp - what smcpp_estep / smcpp_q run for one-population managers - instead of the host
+ * routines (src/conditioned_sfs.cpp:13-148, src/inference_manager.cpp:389-482; pi and the transition matrix come from the
+ * host either way).  mode 0: on the current HIP device; mode 1: the same kernel phases run serially on the host (no device
+ * needed: CPU test-suite).  da / nder may be NULL / 0 (then dpi, dT, dE, dsfs are not written); sfs [M x 3(n+1)] and dsfs
+ * [M*3(n+1) x nder] (the conditioned SFS per hidden state after incorporate_theta) may be NULL. */
+int smcpp_dev_prep_onepop(int n, int n_hs, const double *hs, double polarization_error, int Kp, const double *a,
+                          const double *da, int nder, const double *s, double theta, double rho, double alpha, int K,
+                          const int *keys, int mode, double *pi, double *T, double *E, double *dpi, double *dT, double *dE,
+                          double *sfs, double *dsfs);
+
 /* PyRateFunction.R / average_coal_times (smcpp/_smcpp.pyx:370-389): cumulative hazard R at t[0..nt) for the model
  * pieces (a, s) and, when n_hs >= 2, E[T | hs_i <= T < hs_{i+1}] for the n_hs-1 intervals. */
 int smcpp_host_rate_function(int Kp, const double *a, const double *s, int n_hs, const double *hs, int nt,

@@ -74,6 +74,7 @@ def lib():
         "smcpp_host_prep_onepop": (i, [i, i, _dp, d, i, _dp, _dp, d, d, d, i, _ip, _dp, _dp, _dp]),
         "smcpp_host_prep_onepop_jac": (i, [i, i, _dp, d, i, _dp, _dp, i, _dp, d, d, d, i, _ip, _dp, _dp, _dp, _dp,
                                            _dp, _dp]),
+        "smcpp_dev_prep_onepop": (i, [i, i, _dp, d, i, _dp, _dp, i, _dp, d, d, d, i, _ip, i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
         "smcpp_host_rate_function": (i, [i, _dp, _dp, i, _dp, i, _dp, _dp, _dp]),
         "smcpp_host_rate_function_jac": (i, [i, _dp, _dp, i, _dp, i, _dp, i, _dp, _dp, _dp, _dp, _dp]),
         "smcpp_host_random_coal_times": (i, [i, _dp, _dp, d, d, i, ullp, _dp, _dp]),
@@ -108,6 +109,7 @@ EXPORTS = [
     "smcpp_host_set_csfs_direct", "smcpp_gamma_cols", "smcpp_last_host_timing", "smcpp_get_pi_jac",
     "smcpp_get_transition_jac", "smcpp_get_emission_probs_jac", "smcpp_num_emission_cols", "smcpp_get_emission",
     "smcpp_init_logger_cb", "smcpp_init_cache", "smcpp_debug_ss_apply", "smcpp_debug_ss4_apply", "smcpp_set_debug", "smcpp_get_debug", "smcpp_device",
+    "smcpp_dev_prep_onepop",
 ]
 
 
@@ -188,6 +190,32 @@ def host_prep_onepop_jac(n, hs, polarization_error, a, da, s, theta, rho, alpha,
                                            dptr(da), int(nder), dptr(s), float(theta), float(rho), float(alpha), K,
                                            iptr(keys), dptr(pi), dptr(T), dptr(E), dptr(dpi), dptr(dT), dptr(dE)))
     return pi, T, E, dpi, dT, dE
+
+
+def dev_prep_onepop(n, hs, polarization_error, a, s, theta, rho, alpha, keys, da=None, emulate=False):
+    """Cold preparation with the conditioned SFS / emission table from the device kernels (``emulate``: the same kernel
+    phases on the host).  Returns a dict: pi, T, E, sfs and, with ``da``, dpi, dT, dE, dsfs."""
+    hs = np.ascontiguousarray(hs, dtype=np.float64)
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    keys = np.ascontiguousarray(keys, dtype=np.int32)
+    M = len(hs) - 1
+    K = len(keys)
+    C_ = 3 * (int(n) + 1)
+    nder = 0
+    if da is not None:
+        da = np.ascontiguousarray(da, dtype=np.float64)
+        nder = da.shape[1]
+    out = dict(pi=np.zeros(M), T=np.zeros((M, M)), E=np.zeros((K, M)), sfs=np.zeros((M, 3, int(n) + 1)))
+    if nder:
+        out.update(dpi=np.zeros((M, nder)), dT=np.zeros((M, M, nder)), dE=np.zeros((K, M, nder)),
+                   dsfs=np.zeros((M, 3, int(n) + 1, nder)))
+    check(lib().smcpp_dev_prep_onepop(int(n), len(hs), dptr(hs), float(polarization_error), len(a), dptr(a), dptr(da),
+                                      int(nder), dptr(s), float(theta), float(rho), float(alpha), K, iptr(keys),
+                                      int(bool(emulate)), dptr(out["pi"]), dptr(out["T"]), dptr(out["E"]),
+                                      dptr(out.get("dpi")), dptr(out.get("dT")), dptr(out.get("dE")), dptr(out["sfs"]),
+                                      dptr(out.get("dsfs"))))
+    return out
 
 
 def host_rate_function(a, s, t, hs=None):

@@ -33,6 +33,7 @@
 #include "nonsym_eig.hpp"
 #include "nonsym_eig_team.hpp"
 #include "prep.hpp"
+#include "prep_dev.hpp"
 #include "jcsfs.hpp"
 
 using namespace smcpp_dev;
@@ -151,6 +152,232 @@ constexpr int ROWDESC_PAD = 256;
 }  // namespace
 
 static int coop_generation();
+
+// ---------------------------------------------------------------------------------------------------------------
+// Cold preparation on the device (prep_dev.hpp): the host part of one call is O(pieces): the rate function with the
+// hidden states inserted (RateFunctionT), packed with its derivative planes into one pinned block; everything that is
+// O(states x n^2 x directions) - conditioned SFS, incorporate_theta, emission table - runs in two kernels.
+// `emulate`: the same phases run serially on host vectors (CPU tests), nothing touches a device.
+// ---------------------------------------------------------------------------------------------------------------
+struct DevPrep {
+    int n = 0, M = 0, Kk = 0, Klocal = 0, Mp = 0, MS = 0;
+    bool emulate = false, keys_ready = false, static_ready = false;
+    // static: n-only tables | bin weights, key tables
+    std::vector<double> h_sd;
+    std::vector<int> h_si;
+    DevBuf<double> d_sd;
+    DevBuf<int> d_si;
+    size_t off_bw = 0, off_kind = 0, off_boff = 0, off_bidx = 0, off_local = 0, off_slot = 0, off_maxspan = 0;
+    // per call
+    PinnedArena stage;
+    std::vector<char> h_in;            // emulate: the packed block
+    char *d_in = nullptr;
+    size_t in_cap = 0;
+    DevBuf<double> d_tab, d_sfs_v, d_sfs_d, d_Eg_v, d_Eg_d, d_El, d_Es;
+    std::vector<double> e_tab, e_sfs_v, e_sfs_d, e_Eg_v, e_Eg_d;     // emulate
+    int *h_flags = nullptr, *d_flags_view = nullptr;
+    int e_flags[4] = {0, 0, 0, 0};
+    int last_nder = 0;
+    ~DevPrep() {
+        if (d_in) (void)hipFree(d_in);
+        if (h_flags) (void)hipHostFree(h_flags);
+    }
+    static bool supported(int n) { return n >= 1 && smcpp_dev::CsfsScratch<smcpp_dev::D1>::count(n) * sizeof(smcpp_dev::D1) <= 150 * 1024; }
+
+    void set_static(const smcpp_host::CsfsTables &t) {
+        n = t.n;
+        h_sd.clear();
+        for (const smcpp_host::DMat *m : {&t.X0, &t.X2, &t.M0, &t.M1, &t.Uinv_mp0, &t.Uinv_mp2}) h_sd.insert(h_sd.end(), m->d.begin(), m->d.end());
+        off_bw = h_sd.size();
+        static_ready = true;
+        keys_ready = false;
+    }
+    // keys [Kk][3]; local[k] / slot[k] / maxspan[k] may be empty (identity / none)
+    void set_keys(const smcpp_host::OnePopPrep &hp, const std::vector<int> &keys, int Kk_, const std::vector<int> &local,
+                  const std::vector<int> &slot, const std::vector<int> &maxspan, int Klocal_, int M_, int Mp_, int MS_) {
+        Kk = Kk_; Klocal = Klocal_; M = M_; Mp = Mp_; MS = MS_;
+        h_sd.resize(off_bw);
+        std::vector<int> kind(Kk), boff(Kk + 1, 0), bidx;
+        for (int k = 0; k < Kk; ++k) {
+            const smcpp_host::OnePopPrep::Key bk{keys[3 * k], keys[3 * k + 1], keys[3 * k + 2]};
+            kind[k] = smcpp_host::OnePopPrep::key_kind(bk);
+            if (kind[k] == 0)
+                for (const auto &pr : hp.bins_of(bk)) { bidx.push_back(pr.first); h_sd.push_back(pr.second); }
+            boff[k + 1] = (int)bidx.size();
+        }
+        h_si.clear();
+        auto put = [&](const std::vector<int> &v, size_t &off) { off = h_si.size(); h_si.insert(h_si.end(), v.begin(), v.end()); };
+        std::vector<int> loc(local), sl(slot), ms(maxspan);
+        if (loc.empty()) { loc.resize(Kk); for (int k = 0; k < Kk; ++k) loc[k] = k; }
+        if (sl.empty()) sl = loc;
+        if (ms.empty()) ms.assign(Kk, 1);
+        put(kind, off_kind); put(boff, off_boff); put(bidx, off_bidx); put(loc, off_local); put(sl, off_slot); put(ms, off_maxspan);
+        if (!emulate) {
+            d_sd.alloc(h_sd.size()); d_si.alloc(std::max<size_t>(1, h_si.size()));
+            HIPCHK(hipMemcpy(d_sd.p, h_sd.data(), h_sd.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_si.p, h_si.data(), h_si.size() * sizeof(int), hipMemcpyHostToDevice));
+            // the tables the kernels write rows of: allocated and cleared once (padding stays zero)
+            d_Eg_v.alloc((size_t)Kk * M);
+            d_El.alloc((size_t)std::max(1, Klocal) * Mp); d_Es.alloc((size_t)std::max(1, Klocal) * std::max(1, MS));
+            HIPCHK(hipMemset(d_El.p, 0, d_El.n * sizeof(double)));
+            HIPCHK(hipMemset(d_Es.p, 0, d_Es.n * sizeof(double)));
+            d_sfs_v.alloc((size_t)M * 3 * (n + 1));
+            if (!h_flags) {
+                HIPCHK(hipHostMalloc((void **)&h_flags, 64, hipHostMallocCoherent | hipHostMallocMapped));
+                HIPCHK(hipHostGetDevicePointer((void **)&d_flags_view, h_flags, 0));
+            }
+        } else {
+            e_Eg_v.assign((size_t)Kk * M, 0.0);
+            e_sfs_v.assign((size_t)M * 3 * (n + 1), 0.0);
+        }
+        keys_ready = true;
+    }
+    smcpp_dev::PrepStatic ps_view() const {
+        const double *sd = emulate ? h_sd.data() : d_sd.p;
+        const int *si = emulate ? h_si.data() : d_si.p;
+        smcpp_dev::PrepStatic ps;
+        const size_t a = (size_t)n * (n + 1), b = (size_t)(n + 1) * n, c = (size_t)(n + 1) * (n + 1);
+        ps.X0 = sd; ps.X2 = sd + a; ps.M0 = sd + 2 * a; ps.M1 = sd + 2 * a + b; ps.U0 = sd + 2 * a + b + c; ps.U2 = sd + 2 * a + 2 * b + c;
+        ps.bw = sd + off_bw;
+        ps.Kk = Kk;
+        ps.kind = si + off_kind; ps.boff = si + off_boff; ps.bidx = si + off_bidx; ps.local = si + off_local; ps.slot = si + off_slot;
+        ps.maxspan = si + off_maxspan;
+        return ps;
+    }
+
+    template <typename S> static double dpart(const S &x, int d);
+
+    // Pack the rate function and launch.  HS = double or smcpp_host::dual (nder directions).  Returns after the ENQUEUE.
+    template <typename HS>
+    void run(const smcpp_host::RateFunctionT<HS> &eta, const std::vector<HS> &act, double theta, double alpha, int nder,
+             hipStream_t s) {
+        if (!static_ready || !keys_ready) throw std::runtime_error("internal: device preparation without its tables");
+        const int K = eta.K, nd = std::max(1, nder);
+        last_nder = nder;
+        // ---- pack: doubles ts [K+1] | ada_v [K] | R_v [K+1] | act_v [M] | ada_d [nder][K] | R_d [nder][K+1] | act_d [nder][M]; ints hsi [M+1]
+        const size_t ndbl = (size_t)(K + 1) + K + (K + 1) + M + (size_t)nder * (K + (K + 1) + M);
+        const size_t bytes = ndbl * sizeof(double) + (size_t)(M + 1) * sizeof(int) + 64;
+        char *hb;
+        if (emulate) { h_in.resize(bytes); hb = h_in.data(); }
+        else {
+            stage.reset(bytes);
+            hb = stage.base;
+            if (bytes > in_cap) {
+                if (d_in) (void)hipFree(d_in);
+                in_cap = bytes + bytes / 2;
+                HIPCHK(hipMalloc((void **)&d_in, in_cap));
+            }
+        }
+        double *hd = reinterpret_cast<double *>(hb);
+        size_t o = 0;
+        const size_t o_ts = o; for (int i = 0; i <= K; ++i) hd[o++] = eta.ts[i];
+        const size_t o_ada = o; for (int i = 0; i < K; ++i) hd[o++] = smcpp_host::sval(eta.ada[i]);
+        const size_t o_R = o; for (int i = 0; i <= K; ++i) hd[o++] = smcpp_host::sval(eta.Rrng[i]);
+        const size_t o_act = o; for (int i = 0; i < M; ++i) hd[o++] = smcpp_host::sval(act[i]);
+        const size_t o_adad = o; for (int d = 0; d < nder; ++d) for (int i = 0; i < K; ++i) hd[o++] = dpart(eta.ada[i], d);
+        const size_t o_Rd = o; for (int d = 0; d < nder; ++d) for (int i = 0; i <= K; ++i) hd[o++] = dpart(eta.Rrng[i], d);
+        const size_t o_actd = o; for (int d = 0; d < nder; ++d) for (int i = 0; i < M; ++i) hd[o++] = dpart(act[i], d);
+        int *hi = reinterpret_cast<int *>(hd + o);
+        for (int i = 0; i <= M; ++i) hi[i] = eta.hs_indices[i];
+        const char *base = emulate ? hb : d_in;
+        const double *bd = reinterpret_cast<const double *>(base);
+        smcpp_dev::PrepModel pm;
+        pm.K = K; pm.n = n; pm.M = M; pm.nder = nder; pm.theta = theta; pm.alpha = alpha;
+        pm.ts = bd + o_ts; pm.ada_v = bd + o_ada; pm.R_v = bd + o_R; pm.act_v = bd + o_act;
+        pm.ada_d = bd + o_adad; pm.R_d = bd + o_Rd; pm.act_d = bd + o_actd;
+        pm.hsi = reinterpret_cast<const int *>(bd + o);
+        const smcpp_dev::PrepStatic ps = ps_view();
+        const int C = 3 * (n + 1);
+        const size_t per = (size_t)2 * n * K + (size_t)(n + 1) * (K + 1);          // table entries per direction
+        const size_t ssz = nder > 0 ? 2 : 1;                                       // doubles per scalar
+        smcpp_dev::PrepOut po;
+        po.Mp = Mp; po.MS = MS;
+        if (emulate) {
+            e_tab.assign(per * nd * ssz, 0.0);
+            if (nder) { e_sfs_d.assign((size_t)nder * M * C, 0.0); e_Eg_d.assign((size_t)nder * Kk * M, 0.0); }
+            po.sfs_v = e_sfs_v.data(); po.sfs_d = e_sfs_d.data(); po.Eg_v = e_Eg_v.data(); po.Eg_d = e_Eg_d.data();
+            e_flags[0] = e_flags[1] = e_flags[2] = 0;
+            po.flags = e_flags;
+            if (nder) {
+                smcpp_dev::Tables<smcpp_dev::D1> tb;
+                smcpp_dev::D1 *b = reinterpret_cast<smcpp_dev::D1 *>(e_tab.data());
+                tb.Ssuf = b; tb.Fsuf = b + (size_t)nd * n * K; tb.Ppre = b + (size_t)2 * nd * n * K;
+                smcpp_dev::emulate_tables(pm, tb);
+                smcpp_dev::emulate_csfs(pm, ps, po, tb);
+            } else {
+                smcpp_dev::Tables<double> tb;
+                double *b = e_tab.data();
+                tb.Ssuf = b; tb.Fsuf = b + (size_t)n * K; tb.Ppre = b + (size_t)2 * n * K;
+                smcpp_dev::emulate_tables(pm, tb);
+                smcpp_dev::emulate_csfs(pm, ps, po, tb);
+            }
+            return;
+        }
+        d_tab.alloc(per * nd * ssz);
+        if (nder) { d_sfs_d.alloc((size_t)nder * M * C); d_Eg_d.alloc((size_t)nder * Kk * M); }
+        po.sfs_v = d_sfs_v.p; po.sfs_d = d_sfs_d.p; po.Eg_v = d_Eg_v.p; po.Eg_d = d_Eg_d.p;
+        po.El_v = d_El.p; po.Es_v = MS > 0 ? d_Es.p : nullptr;
+        h_flags[0] = h_flags[1] = h_flags[2] = 0;
+        po.flags = d_flags_view;
+        HIPCHK(hipMemcpyAsync(d_in, hb, bytes, hipMemcpyHostToDevice, s));
+        const int pairs = (n + 1) * n;
+        const int nt = std::max(64 * ceil_div(3 * n + 2, 64), std::min(1024, 64 * ceil_div(pairs, 64)));
+        const int ntt = std::min(1024, 64 * ceil_div((2 * n + 1) * K, 64));
+        if (nder) {
+            typedef smcpp_dev::D1 S;
+            smcpp_dev::Tables<S> tb;
+            S *b = reinterpret_cast<S *>(d_tab.p);
+            tb.Ssuf = b; tb.Fsuf = b + (size_t)nd * n * K; tb.Ppre = b + (size_t)2 * nd * n * K;
+            const size_t lds = smcpp_dev::CsfsScratch<S>::count(n) * sizeof(S);
+            static bool once = false;
+            if (!once) { HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_csfs<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+            hipLaunchKernelGGL(smcpp_dev::k_prep_tables<S>, dim3(nd), dim3(ntt), 0, s, pm, tb);
+            hipLaunchKernelGGL(smcpp_dev::k_prep_csfs<S>, dim3(M, nd), dim3(nt), lds, s, pm, ps, po, tb);
+        } else {
+            typedef double S;
+            smcpp_dev::Tables<S> tb;
+            S *b = d_tab.p;
+            tb.Ssuf = b; tb.Fsuf = b + (size_t)n * K; tb.Ppre = b + (size_t)2 * n * K;
+            const size_t lds = smcpp_dev::CsfsScratch<S>::count(n) * sizeof(S);
+            static bool once = false;
+            if (!once) { HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_csfs<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+            hipLaunchKernelGGL(smcpp_dev::k_prep_tables<S>, dim3(1), dim3(ntt), 0, s, pm, tb);
+            hipLaunchKernelGGL(smcpp_dev::k_prep_csfs<S>, dim3(M, 1), dim3(nt), lds, s, pm, ps, po, tb);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    const int *flags() const { return emulate ? e_flags : h_flags; }
+    // Results to the host (after the stream has drained): E [Kk][M], dE [Kk*M][nder], sfs [M][C], dsfs [M*C][nder]
+    void fetch(std::vector<double> &Ev, std::vector<double> &dEv, std::vector<double> &sfs, std::vector<double> &dsfs) {
+        const int C = 3 * (n + 1), nder = last_nder;
+        std::vector<double> pl;
+        auto get = [&](const DevBuf<double> &d, const std::vector<double> &e, size_t cnt, std::vector<double> &out) {
+            out.resize(cnt);
+            if (emulate) std::memcpy(out.data(), e.data(), cnt * sizeof(double));
+            else HIPCHK(hipMemcpy(out.data(), d.p, cnt * sizeof(double), hipMemcpyDeviceToHost));
+        };
+        get(d_Eg_v, e_Eg_v, (size_t)Kk * M, Ev);
+        get(d_sfs_v, e_sfs_v, (size_t)M * C, sfs);
+        dEv.clear(); dsfs.clear();
+        if (nder) {
+            get(d_Eg_d, e_Eg_d, (size_t)nder * Kk * M, pl);
+            dEv.resize(pl.size());
+            const size_t sz = (size_t)Kk * M;
+            for (int d = 0; d < nder; ++d) for (size_t i = 0; i < sz; ++i) dEv[i * nder + d] = pl[(size_t)d * sz + i];
+            get(d_sfs_d, e_sfs_d, (size_t)nder * M * C, pl);
+            dsfs.resize(pl.size());
+            const size_t s2 = (size_t)M * C;
+            for (int d = 0; d < nder; ++d) for (size_t i = 0; i < s2; ++i) dsfs[i * nder + d] = pl[(size_t)d * s2 + i];
+        }
+    }
+    void check_flags() const {
+        const int *f = flags();
+        if (f[1]) throw std::runtime_error("csfs is not a probability distribution");
+        if (f[0]) throw std::runtime_error("probability vector not in [0, 1]");
+    }
+};
+template <> inline double DevPrep::dpart<double>(const double &, int) { return 0.0; }
+template <> inline double DevPrep::dpart<smcpp_host::dual>(const smcpp_host::dual &x, int d) { return x.d[d]; }
 
 struct smcpp_im {
     // ---- static problem description -------------------------------------------------------------------------
@@ -3479,6 +3706,58 @@ int smcpp_host_rate_function_jac(int Kp, const double *a, const double *da, int 
             if (davg_ct_out) for (int d = 0; d < nder; ++d) davg_ct_out[i * nder + d] = v[i].d[d];
         }
     }
+    API_END
+}
+
+// Test hook: the one-population cold preparation with the conditioned SFS / emission table evaluated by the device kernels of
+// prep_dev.hpp (mode 0) or by the same phases run serially on the host (mode 1: CPU tests); pi and the transition matrix come
+// from the host routines either way.  Outputs as smcpp_host_prep_onepop_jac, plus the conditioned SFS after incorporate_theta
+// sfs [M x 3 (n+1)] and its Jacobian (both may be NULL).
+int smcpp_dev_prep_onepop(int n, int n_hs, const double *hs, double polarization_error, int Kp, const double *a,
+                          const double *da, int nder, const double *s, double theta, double rho, double alpha, int K,
+                          const int *keys, int mode, double *pi, double *T, double *E, double *dpi, double *dT, double *dE,
+                          double *sfs, double *dsfs) {
+    API_BEGIN
+    if (!DevPrep::supported(n)) throw std::runtime_error("device preparation does not support this sample size");
+    const std::vector<double> hsv(hs, hs + n_hs);
+    const int M = n_hs - 1;
+    smcpp_host::OnePopPrep hp(n, hsv, polarization_error);
+    DevPrep dp;
+    dp.emulate = mode != 0;
+    if (!dp.emulate) { int dev = 0; HIPCHK(hipGetDevice(&dev)); }
+    dp.set_static(hp.tables());
+    const std::vector<int> kv(keys, keys + (size_t)3 * K);
+    dp.set_keys(hp, kv, K, {}, {}, {}, K, M, (M + 15) / 16 * 16, 0);
+    std::vector<double> Ev, dEv, sf, dsf;
+    if (da && nder > 0) {
+        smcpp_host::DualScope sc(nder);
+        const auto p = dual_model(Kp, a, da, nder, s);
+        smcpp_host::RateFunctionT<smcpp_host::dual> eta(p, hsv);
+        std::vector<smcpp_host::dual> pd;
+        smcpp_host::initial_distribution(eta, pd);
+        dp.run(eta, eta.average_coal_times(), theta, alpha, nder, nullptr);
+        const std::vector<smcpp_host::dual> Td = smcpp_host::compute_transition<smcpp_host::dual>(eta, rho);
+        for (int i = 0; i < M; ++i) { pi[i] = pd[i].v; for (int d = 0; d < nder; ++d) dpi[(size_t)i * nder + d] = pd[i].d[d]; }
+        for (size_t i = 0; i < (size_t)M * M; ++i) { T[i] = Td[i].v; for (int d = 0; d < nder; ++d) dT[i * nder + d] = Td[i].d[d]; }
+    } else {
+        nder = 0;
+        smcpp_host::ModelParamsT<double> p;
+        p.a.assign(a, a + Kp); p.s.assign(s, s + Kp);
+        smcpp_host::RateFunctionT<double> eta(p, hsv);
+        std::vector<double> pv;
+        smcpp_host::initial_distribution(eta, pv);
+        dp.run(eta, eta.average_coal_times(), theta, alpha, 0, nullptr);
+        const std::vector<double> Tv = smcpp_host::compute_transition<double>(eta, rho);
+        std::memcpy(pi, pv.data(), sizeof(double) * M);
+        std::memcpy(T, Tv.data(), sizeof(double) * (size_t)M * M);
+    }
+    if (!dp.emulate) HIPCHK(hipDeviceSynchronize());
+    dp.fetch(Ev, dEv, sf, dsf);
+    dp.check_flags();
+    std::memcpy(E, Ev.data(), sizeof(double) * Ev.size());
+    if (nder && dE) std::memcpy(dE, dEv.data(), sizeof(double) * dEv.size());
+    if (sfs) std::memcpy(sfs, sf.data(), sizeof(double) * sf.size());
+    if (nder && dsfs) std::memcpy(dsfs, dsf.data(), sizeof(double) * dsf.size());
     API_END
 }
 

@@ -1109,10 +1109,25 @@ inline void incorporate_theta(std::vector<std::vector<S>> &csfs, double theta) {
 // ---------------------------------------------------------------------------------------------------------------
 // A6 + A7: one-population preparation
 // ---------------------------------------------------------------------------------------------------------------
+// A7: pi (inference_manager.cpp:56-69)
+template <typename S>
+inline void initial_distribution(const RateFunctionT<S> &eta, std::vector<S> &pi) {
+    const std::vector<double> &hs = eta.hidden_states;
+    const int M = (int)hs.size() - 1;
+    pi.assign(M, S(0.0));
+    for (int m = 0; m < M - 1; ++m) pi[m] = m_exp(-eta.R(hs[m])) - m_exp(-eta.R(hs[m + 1]));
+    pi[M - 1] = m_exp(-eta.R(hs[M - 1]));
+    S ps(0.0);
+    for (S &x : pi) { if (sval(x) < 1e-20) x = S(1e-20); ps += x; }
+    for (S &x : pi) x /= ps;
+}
+
 class OnePopPrep {
 public:
     OnePopPrep(int n, const std::vector<double> &hs, double polarization_error)
         : n_(n), hs_(hs), pol_(polarization_error), tables_(csfs_tables(n)) {}
+    const CsfsTables &tables() const { return *tables_; }
+    int n() const { return n_; }
 
     // keys: [K][3] (a, b, nb); outputs pi [M], T [M*M] row-major, E [K*M]
     template <typename S>
@@ -1123,13 +1138,7 @@ public:
         auto t0 = clk();
         RateFunctionT<S> eta(mp, hs_);
         const int M = (int)hs_.size() - 1;
-        // pi (inference_manager.cpp:56-69)
-        pi.assign(M, S(0.0));
-        for (int m = 0; m < M - 1; ++m) pi[m] = m_exp(-eta.R(hs_[m])) - m_exp(-eta.R(hs_[m + 1]));
-        pi[M - 1] = m_exp(-eta.R(hs_[M - 1]));
-        S ps(0.0);
-        for (S &x : pi) { if (sval(x) < 1e-20) x = S(1e-20); ps += x; }
-        for (S &x : pi) x /= ps;
+        initial_distribution<S>(eta, pi);
         auto t1 = clk();
         auto t2 = t1;
         // the transition matrix (serial, long double) rides along in the conditioned SFS's parallel region
@@ -1232,6 +1241,25 @@ public:
         return out;
     }
 
+    // how a key's emission vector is formed: 1 = missing reduced key (all ones), 2 / 3 = reduced key with a even / odd
+    // (exp / -expm1 of -2 alpha theta E[T]), 0 = marginalisation bins over the conditioned SFS
+    static int key_kind(const Key &bk) {
+        const bool reduced = bk[2] == 0, miss = bk[0] == -1;
+        if (reduced && (miss || bk[0] >= 0)) return miss ? 1 : 2 + (bk[0] % 2);
+        return 0;
+    }
+    // the bins of a key as (flattened CSFS index, weight) in bins_for's order (hypergeometric weights: lgamma calls, a
+    // std::map): they depend on the manager only and are built once
+    const std::vector<std::pair<int, double>> &bins_of(const Key &bk) const {
+        auto it = bins_cache_.find(bk);
+        if (it == bins_cache_.end()) {
+            std::vector<std::pair<int, double>> flat;
+            for (const auto &p : bins_for(bk)) flat.emplace_back(p.first.first * (n_ + 1) + p.first.second, p.second);
+            it = bins_cache_.emplace(bk, std::move(flat)).first;
+        }
+        return it->second;
+    }
+
     template <typename S>
     void emission_probs(const std::vector<std::vector<S>> &sfs, const std::vector<S> &avg_ct, double theta, double alpha,
                         const std::vector<int> &keys, int K, std::vector<S> &E) const {
@@ -1248,19 +1276,12 @@ public:
         E.assign((size_t)K * M, S(0.0));
         for (int k = 0; k < K; ++k) {
             const Key bk{keys[3 * k], keys[3 * k + 1], keys[3 * k + 2]};
-            const bool reduced = bk[2] == 0, miss = bk[0] == -1;
+            const int kind = key_kind(bk);
             S *e = &E[(size_t)k * M];
-            if (reduced && (miss || bk[0] >= 0)) {
-                for (int m = 0; m < M; ++m) e[m] = miss ? S(1.0) : e2[2 * m + (bk[0] % 2)];
+            if (kind != 0) {
+                for (int m = 0; m < M; ++m) e[m] = kind == 1 ? S(1.0) : e2[2 * m + (kind - 2)];
             } else {
-                // the bins of a key (hypergeometric weights: lgamma calls, a std::map) depend on the manager only: built once
-                auto it = bins_cache_.find(bk);
-                if (it == bins_cache_.end()) {
-                    std::vector<std::pair<int, double>> flat;
-                    for (const auto &p : bins_for(bk)) flat.emplace_back(p.first.first * (n_ + 1) + p.first.second, p.second);
-                    it = bins_cache_.emplace(bk, std::move(flat)).first;
-                }
-                for (const auto &p : it->second)
+                for (const auto &p : bins_of(bk))
                     for (int m = 0; m < M; ++m) e[m] += p.second * sfs[m][(size_t)p.first];
             }
             double mx = sval(e[0]), mn = sval(e[0]);

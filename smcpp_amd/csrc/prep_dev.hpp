@@ -1,0 +1,469 @@
+// Cold parameter preparation ON THE DEVICE (SURVEY.md §8(a) rows A6 + A10): per hidden state the conditioned SFS
+// (src/conditioned_sfs.cpp:13-148 with the integrals of src/piecewise_constant_rate_function.cpp:214-334), incorporate_theta
+// (src/inference_manager.cpp:389-407 / conditioned_sfs.h) and the emission table of every block key
+// (src/inference_manager.cpp:409-482), with forward-mode derivatives: the role of the reference's `adouble`
+// (include/common.h:22-25).  prep.hpp holds the host implementation of the same mathematics (O(pieces n^2) factored form); this
+// file evaluates it with one workgroup per (hidden state, derivative direction):
+//
+//   k_prep_tables   the prefix / suffix sums over the model pieces (CsfsPieceTables of prep.hpp): every (rate, piece) term by its
+//                   own thread, then one thread per rate runs the linear recurrence over the pieces
+//   k_prep_csfs     workgroup (h, d): hoisted exponentials of the state's pieces -> one thread per (lambda, rate) pair
+//                   accumulates the double integrals -> compensated contractions with X0 / X2 -> Moran back-transformation ->
+//                   the "below" part -> incorporate_theta -> emission vectors of all keys for state h, written straight into
+//                   the layouts the chains and the statistics read
+//
+// A number with derivatives is a (value, ONE directional derivative) pair: direction d lives in workgroup (h, d), so no
+// register arrays and any number of directions; the values are recomputed by every direction's workgroup (the chip is
+// otherwise idle while the parameters are prepared).  Arithmetic mirrors prep.hpp operation by operation (FMA contraction off),
+// so the two agree to the last bits of the transcendental functions; the phases are __host__ __device__ so that the CPU test
+// suite runs the same code through emulate_*() without a GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+#define SMCPP_HD __host__ __device__ inline
+
+namespace smcpp_dev {
+
+// ---- value + one directional derivative (mirrors smcpp_host::Dual, prep.hpp) -------------------------------------------------
+struct D1 {
+    double v, d;
+    SMCPP_HD D1() : v(0.0), d(0.0) {}
+    SMCPP_HD D1(double x) : v(x), d(0.0) {}
+    SMCPP_HD D1(double x, double y) : v(x), d(y) {}
+};
+SMCPP_HD D1 operator+(const D1 &a, const D1 &b) { return D1(a.v + b.v, a.d + b.d); }
+SMCPP_HD D1 operator-(const D1 &a, const D1 &b) { return D1(a.v - b.v, a.d - b.d); }
+SMCPP_HD D1 operator*(const D1 &a, const D1 &b) { return D1(a.v * b.v, a.d * b.v + a.v * b.d); }
+SMCPP_HD D1 operator/(const D1 &a, const D1 &b) { const double ib = 1 / b.v; const double v = a.v * ib; return D1(v, (a.d - v * b.d) * ib); }
+SMCPP_HD D1 operator-(const D1 &a) { return D1(-a.v, -a.d); }
+SMCPP_HD D1 operator+(const D1 &a, double b) { return D1(a.v + b, a.d); }
+SMCPP_HD D1 operator+(double b, const D1 &a) { return D1(a.v + b, a.d); }
+SMCPP_HD D1 operator-(const D1 &a, double b) { return D1(a.v - b, a.d); }
+SMCPP_HD D1 operator-(double b, const D1 &a) { return D1(-a.v + b, -a.d); }
+SMCPP_HD D1 operator*(const D1 &a, double b) { return D1(a.v * b, a.d * b); }
+SMCPP_HD D1 operator*(double b, const D1 &a) { return D1(a.v * b, a.d * b); }
+SMCPP_HD D1 operator/(const D1 &a, double b) { return a * (1.0 / b); }
+SMCPP_HD D1 operator/(double b, const D1 &a) { const double v = b / a.v; return D1(v, -v * a.d / a.v); }
+SMCPP_HD D1 &operator+=(D1 &a, const D1 &b) { a.v += b.v; a.d += b.d; return a; }
+SMCPP_HD D1 &operator*=(D1 &a, const D1 &b) { a = a * b; return a; }
+SMCPP_HD D1 &operator/=(D1 &a, const D1 &b) { a = a / b; return a; }
+SMCPP_HD double m_exp(double x) { return ::exp(x); }
+SMCPP_HD double m_expm1(double x) { return ::expm1(x); }
+SMCPP_HD double m_log(double x) { return ::log(x); }
+SMCPP_HD D1 m_exp(const D1 &a) { const double e = ::exp(a.v); return D1(e, a.d * e); }
+SMCPP_HD D1 m_expm1(const D1 &a) { const double r = ::expm1(a.v); const double e = ::exp(a.v); return D1(r, a.d * e); }
+SMCPP_HD D1 m_log(const D1 &a) { return D1(::log(a.v), a.d / a.v); }
+SMCPP_HD double sval(double x) { return x; }
+SMCPP_HD double sval(const D1 &x) { return x.v; }
+SMCPP_HD double sder(double) { return 0.0; }
+SMCPP_HD double sder(const D1 &x) { return x.d; }
+SMCPP_HD void mk(double &o, double v, double) { o = v; }
+SMCPP_HD void mk(D1 &o, double v, double d) { o.v = v; o.d = d; }
+// cascaded TwoSum accumulation of prep.hpp's accurate_sum: value compensated, derivative a plain sum
+struct AccD { double hi = 0.0, lo = 0.0, d = 0.0; };
+SMCPP_HD void acc_add(AccD &a, double x) { const double t = a.hi + x, z = t - a.hi; a.lo += (a.hi - (t - z)) + (x - z); a.hi = t; }
+SMCPP_HD void acc_add(AccD &a, const D1 &x) { acc_add(a, x.v); a.d += x.d; }
+SMCPP_HD void acc_get(const AccD &a, double &o) { o = a.hi + a.lo; }
+SMCPP_HD void acc_get(const AccD &a, D1 &o) { o.v = a.hi + a.lo; o.d = a.d; }
+
+SMCPP_HD long nC2(long n) { return n * (n - 1) / 2; }
+
+// ---- inputs -----------------------------------------------------------------------------------------------------------------
+// The rate function after the hidden states were inserted as break points (RateFunctionT's constructor, prep.hpp; host, O(K)):
+// K pieces, ts [K+1] (ts[K] = inf), ada = 1 / a and the cumulative hazard Rrng [K+1] with their derivative planes
+// [nder][K] / [nder][K+1], hs_indices [M+1], the average coalescence time per state [M] (+ planes).
+struct PrepModel {
+    int K = 0, n = 0, M = 0, nder = 0;
+    const double *ts = nullptr, *ada_v = nullptr, *ada_d = nullptr, *R_v = nullptr, *R_d = nullptr, *act_v = nullptr, *act_d = nullptr;
+    const int *hsi = nullptr;
+    double theta = 0.0, alpha = 1.0;
+};
+// n-only tables (CsfsTables of prep.hpp, row-major) and the keys' marginalisation bins in CSR form (OnePopPrep::bins_for)
+struct PrepStatic {
+    const double *X0 = nullptr, *X2 = nullptr, *M0 = nullptr, *M1 = nullptr, *U0 = nullptr, *U2 = nullptr;
+    int Kk = 0;                      // keys the table is prepared for (the global list of a sharded manager)
+    const int *kind = nullptr;       // [Kk] 0 = bins, 1 = missing (all ones), 2 / 3 = reduced key, even / odd a
+    const int *boff = nullptr, *bidx = nullptr;
+    const double *bw = nullptr;
+    const int *local = nullptr;      // [Kk] local key id (row of the E the statistics read) or -1
+    const int *slot = nullptr;       // [Kk] key slot of the scan chains' emission table or -1
+    const int *maxspan = nullptr;    // [Kk] longest span of a row of the key that the scan chains expand step by step (or 1)
+};
+// where the results go.  Planes: direction d of an array X of `sz` doubles lives at X_d + d * sz.
+struct PrepOut {
+    double *sfs_v = nullptr, *sfs_d = nullptr;       // [M][C], C = 3 (n+1): InferenceManager::emission
+    double *Eg_v = nullptr, *Eg_d = nullptr;         // [Kk][M] every prepared key (getters, Q on reduced statistics)
+    double *El_v = nullptr;                          // [K_local][Mp] what the statistics kernels read (may be null)
+    double *Es_v = nullptr;                          // [K_local][MS] by key slot: the scan chains' table (may be null)
+    int Mp = 0, MS = 0;
+    // one word per condition (plain stores of 1, no read-modify-write): [0] an emission entry left (0, 1], [1] a conditioned
+    // SFS is not a probability distribution, [2] an emission entry is so small that `span` scan steps would underflow
+    int *flags = nullptr;
+};
+template <typename S> struct Tables {
+    S *Ssuf = nullptr, *Fsuf = nullptr, *Ppre = nullptr;     // [nd][n][K], [nd][n][K], [nd][n+1][K+1]   (nd = max(1, nder))
+};
+
+template <typename S> SMCPP_HD S ld(const double *v, const double *d, int i) { S r; mk(r, v[i], d ? d[i] : 0.0); return r; }
+
+// ---- k_prep_tables: phase 1 (one (rate, piece) term), phase 2 (the recurrences) ------------------------------------------------
+template <typename S>
+SMCPP_HD void tables_term(const PrepModel &pm, int dir, const Tables<S> &tb, int item) {
+    const int K = pm.K, n = pm.n;
+    const double *ad_d = pm.nder ? pm.ada_d + (size_t)dir * K : nullptr, *R_d = pm.nder ? pm.R_d + (size_t)dir * (K + 1) : nullptr;
+    const int na = n * K;                      // above items (jr, m), then below items (jr, m)
+    if (item < na) {
+        const int jr = item / K, m = item % K;
+        S *G = tb.Ssuf + ((size_t)dir * n + jr) * K, *F = tb.Fsuf + ((size_t)dir * n + jr) * K;
+        if (m == 0) { G[0] = S(0.0); F[0] = S(0.0); return; }      // (slot m holds the term of piece m; piece 0 has none)
+        const double rate = (double)nC2(jr + 2);
+        const S ad = ld<S>(pm.ada_v, ad_d, m);
+        if (pm.ts[m + 1] < INFINITY) {
+            const S em = m_expm1(-rate * ad * (pm.ts[m + 1] - pm.ts[m]));
+            G[m] = -em / (ad * rate);
+            F[m] = 1.0 + em;
+        } else { G[m] = 1.0 / (ad * rate); F[m] = S(0.0); }
+        return;
+    }
+    item -= na;
+    if (item >= (n + 1) * K) return;
+    const int jr = item / K, m = item % K;
+    S *P = tb.Ppre + ((size_t)dir * (n + 1) + jr) * (K + 1);
+    const long ratel = nC2(jr + 2) - 1;
+    if (ratel == 0) { P[m + 1] = S(pm.ts[m + 1]); return; }
+    const double rate = (double)ratel;
+    const S ad = ld<S>(pm.ada_v, ad_d, m);
+    S g = m_exp(-rate * ld<S>(pm.R_v, R_d, m));
+    if (pm.ts[m + 1] < INFINITY) g *= -m_expm1(-rate * ad * (pm.ts[m + 1] - pm.ts[m]));
+    g /= ad * rate;
+    P[m + 1] = g;
+}
+template <typename S>
+SMCPP_HD void tables_scan(const PrepModel &pm, int dir, const Tables<S> &tb, int t) {
+    const int K = pm.K, n = pm.n;
+    if (t < n) {
+        S *G = tb.Ssuf + ((size_t)dir * n + t) * K;
+        const S *F = tb.Fsuf + ((size_t)dir * n + t) * K;
+        S acc(0.0);                              // Ssuf[K-1] = 0
+        for (int m = K - 1; m >= 1; --m) {
+            const S g = G[m];
+            G[m] = acc;
+            if (pm.ts[m + 1] < INFINITY) acc = g + F[m] * acc; else acc = g;
+        }
+        G[0] = acc;
+        return;
+    }
+    t -= n;
+    if (t >= n + 1) return;
+    S *P = tb.Ppre + ((size_t)dir * (n + 1) + t) * (K + 1);
+    P[0] = S(0.0);
+    if (nC2(t + 2) - 1 == 0) return;             // (filled with ts[m+1] by phase 1)
+    S acc(0.0);
+    for (int m = 0; m < K; ++m) { acc = acc + P[m + 1]; P[m + 1] = acc; }
+}
+
+// ---- k_prep_csfs: the work of one workgroup (hidden state h, direction dir) --------------------------------------------------
+// `sh` = the workgroup's scratch (LDS on the device): Ca [(n+1) n], A, A1, B, El [n+1], ert, e1 [n], tmp0, tmp2, below [n+1],
+// out [3 (n+1)], e2 [2]
+template <typename S> struct CsfsScratch {
+    S *Ca, *A, *A1, *B, *El, *ert, *e1, *tmp0, *tmp2, *below, *out, *e2;
+    SMCPP_HD static size_t count(int n) { return (size_t)(n + 1) * n + 4 * (n + 1) + 2 * n + 3 * (n + 1) + 3 * (n + 1) + 2; }
+    SMCPP_HD void carve(S *base, int n) {
+        Ca = base; base += (size_t)(n + 1) * n;
+        A = base; base += n + 1; A1 = base; base += n + 1; B = base; base += n + 1; El = base; base += n + 1;
+        ert = base; base += n; e1 = base; base += n;
+        tmp0 = base; base += n + 1; tmp2 = base; base += n + 1; below = base; base += n + 1;
+        out = base; base += 3 * (n + 1); e2 = base;
+    }
+};
+
+template <typename S> struct CsfsCtx {
+    PrepModel pm;
+    PrepStatic ps;
+    PrepOut po;
+    Tables<S> tb;
+    int h, dir;
+    CsfsScratch<S> sh;
+    SMCPP_HD S ada(int m) const { return ld<S>(pm.ada_v, pm.nder ? pm.ada_d + (size_t)dir * pm.K : nullptr, m); }
+    SMCPP_HD S R(int m) const { return ld<S>(pm.R_v, pm.nder ? pm.R_d + (size_t)dir * (pm.K + 1) : nullptr, m); }
+    SMCPP_HD S log_denom() const {
+        const S Rh = R(pm.hsi[h]), Rh1 = R(pm.hsi[h + 1]);
+        S ldn = -Rh;
+        if (sval(Rh1) != INFINITY) ldn = ldn + m_log(-m_expm1(-(Rh1 - Rh)));
+        return ldn;
+    }
+};
+
+template <typename S>
+SMCPP_HD S below_helper(long rate, double tsm, double tsm1, const S &ad, const S &Rr, const S &log_denom) {
+    const long l1r = 1 + rate;
+    const double l1rinv = 1.0 / (double)l1r;
+    const S adadiff = ad * (tsm1 - tsm);
+    if (rate == 0) {
+        if (tsm1 == INFINITY) return m_exp(-Rr - log_denom) / ad;
+        return m_exp(-Rr - log_denom) * (1.0 - m_exp(-adadiff) * (1.0 + adadiff)) / ad;
+    }
+    if (tsm1 == INFINITY) return m_exp(-(double)l1r * Rr - log_denom) * (1.0 - l1rinv) / ((double)rate * ad);
+    return m_exp(-(double)l1r * Rr - log_denom) * (m_expm1(-(double)l1r * adadiff) * l1rinv - m_expm1(-adadiff)) / ((double)rate * ad);
+}
+
+// phase 0: clear the accumulators
+template <typename S>
+SMCPP_HD void csfs_clear(const CsfsCtx<S> &c, int t, int nt) {
+    const int n = c.pm.n;
+    for (int p = t; p < (n + 1) * n; p += nt) c.sh.Ca[p] = S(0.0);
+    for (int p = t; p < n + 1; p += nt) c.sh.below[p] = S(0.0);
+    for (int p = t; p < 3 * (n + 1); p += nt) c.sh.out[p] = S(0.0);
+}
+// phase 1 of piece m: the exponentials that depend on one index only (threads 0..n: lambda tables, n+1..2n: rate tables,
+// 2n+1..3n+1: the "below" integrals of the piece, which need no table)
+template <typename S>
+SMCPP_HD void csfs_piece_tables(const CsfsCtx<S> &c, int m, int t) {
+    const PrepModel &pm = c.pm;
+    const int n = pm.n, K = pm.K;
+    const bool fin = pm.ts[m + 1] < INFINITY;
+    const S ad = c.ada(m);
+    const S Rm = c.R(m), Rm1 = c.R(m + 1);
+    if (t <= n) {
+        const S log_coef0 = -c.log_denom();
+        const S adadiff = ad * (pm.ts[m + 1] - pm.ts[m]);
+        const double l1 = (double)nC2(t + 2);
+        c.sh.A[t] = m_exp(-l1 * Rm + log_coef0);
+        if (m + 1 < K) c.sh.A1[t] = m_exp(-l1 * Rm1 + log_coef0);
+        if (fin) { c.sh.B[t] = m_expm1(-l1 * adadiff); c.sh.El[t] = m_exp(-l1 * adadiff); }
+    } else if (t <= 2 * n) {
+        const int jr = t - (n + 1);
+        if (fin) {
+            const S adadiff = ad * (pm.ts[m + 1] - pm.ts[m]);
+            const S dR = Rm1 - Rm;
+            c.sh.ert[jr] = m_exp(-(double)nC2(jr + 2) * adadiff);
+            c.sh.e1[jr] = m_exp(-(double)nC2(jr + 2) * dR);
+        }
+    } else if (t <= 3 * n + 1) {
+        const int j = t - (2 * n + 1) + 2;                     // j = 2 .. n+2
+        const S log_denom = c.log_denom();
+        const S cc = -Rm - log_denom;
+        S fac(1.0);
+        if (m < K - 1) fac = -m_expm1(-(Rm1 - Rm));
+        const S ec = m > 0 ? m_exp(cc) : S(0.0);
+        const long rate = nC2(j) - 1;
+        S val = below_helper<S>(rate, pm.ts[m], pm.ts[m + 1], ad, Rm, log_denom);
+        if (m > 0) val = val + fac * (ec * c.tb.Ppre[((size_t)c.dir * (n + 1) + (j - 2)) * (K + 1) + m]);
+        c.sh.below[j - 2] = c.sh.below[j - 2] + val;
+    }
+}
+// phase 2 of piece m: one (lambda, rate) pair
+template <typename S>
+SMCPP_HD void csfs_pair(const CsfsCtx<S> &c, int m, int p) {
+    const PrepModel &pm = c.pm;
+    const int n = pm.n, K = pm.K;
+    const int jl = p / n, jr = p % n;
+    const bool fin = pm.ts[m + 1] < INFINITY;
+    const S ad = c.ada(m);
+    const S adadiff = ad * (pm.ts[m + 1] - pm.ts[m]);
+    const S Rm = c.R(m), Rm1 = c.R(m + 1);
+    const S dR = Rm1 - Rm;
+    const long l1l = nC2(jl + 2), ratel = nC2(jr + 2);
+    const double l1 = (double)l1l, rt = (double)ratel;
+    const S A = c.sh.A[jl];
+    S tgt = c.sh.Ca[p];
+    if (l1l == ratel) {
+        if (!fin) tgt += A / rt / rt / ad;
+        else tgt += A * (1.0 - c.sh.ert[jr] * (1.0 + rt * adadiff)) / rt / rt / ad;
+    } else if (!fin) tgt += A / l1 / rt / ad;
+    else if (ratel < l1l)
+        tgt += -A * (c.sh.B[jl] / l1 + (c.sh.ert[jr] * -m_expm1(-(l1 - rt) * adadiff) / (l1 - rt))) / rt / ad;
+    else
+        tgt += -A * (c.sh.B[jl] / l1 + (c.sh.El[jl] * m_expm1(-(rt - l1) * adadiff) / (l1 - rt))) / rt / ad;
+    if (m + 1 < K) {
+        S coef(0.0), fac(0.0);
+        const long rp = l1l - ratel;
+        const double rpd = (double)rp;
+        if (rp == 0) { fac = dR; coef = c.sh.A1[jl]; }
+        else if (rp < 0) {
+            if (-rpd * sval(dR) > 20) { coef = c.sh.A1[jl]; fac = S(-1.0 / rpd); }
+            else { coef = A * c.sh.e1[jr]; fac = -m_expm1(-rpd * dR) / rpd; }
+        } else {
+            if (-rpd * sval(Rm - Rm1) > 20) { coef = A * c.sh.e1[jr]; fac = S(1.0 / rpd); }
+            else { coef = c.sh.A1[jl]; fac = m_expm1(-rpd * (Rm - Rm1)) / rpd; }
+        }
+        tgt += coef * c.tb.Ssuf[((size_t)c.dir * n + jr) * K + m] * fac;
+    }
+    c.sh.Ca[p] = tgt;
+}
+// phase 3: compensated contractions with X0 / X2 (threads 0..n: tmp0, n+1..2n+1: tmp2)
+template <typename S>
+SMCPP_HD void csfs_contract(const CsfsCtx<S> &c, int t) {
+    const int n = c.pm.n;
+    if (t <= n) {
+        const int j = t;
+        AccD a;
+        for (int i = 0; i < n; ++i) acc_add(a, c.sh.Ca[(size_t)j * n + i] * c.ps.X0[(size_t)i * (n + 1) + j]);
+        acc_get(a, c.sh.tmp0[j]);
+    } else if (t <= 2 * n + 1) {
+        const int j = t - (n + 1);
+        AccD a;
+        for (int i = 0; i < n; ++i) acc_add(a, c.sh.Ca[(size_t)(n - j) * n + i] * c.ps.X2[(size_t)i * (n + 1) + j]);
+        acc_get(a, c.sh.tmp2[j]);
+    }
+}
+// phase 4: Moran back-transformation of the "above" part, M0 / M1 contractions of the "below" part
+template <typename S>
+SMCPP_HD void csfs_backtransform(const CsfsCtx<S> &c, int t) {
+    const int n = c.pm.n;
+    if (t < n) {
+        const int b = t;
+        S s0(0.0), s2(0.0);
+        for (int j = 0; j < n + 1; ++j) {
+            s0 += c.sh.tmp0[j] * c.ps.U0[(size_t)j * n + b];
+            s2 += c.sh.tmp2[j] * c.ps.U2[(size_t)j * n + b];
+        }
+        S o0 = c.sh.out[1 + b];
+        o0 += s0;
+        c.sh.out[2 * (n + 1) + b] += s2;
+        S s(0.0);
+        for (int j = 0; j < n + 1; ++j) s += c.sh.below[j] * c.ps.M0[(size_t)j * n + b];
+        o0 += s;
+        c.sh.out[1 + b] = o0;
+    } else if (t < 2 * n + 1) {
+        const int b = t - n;
+        S s(0.0);
+        for (int j = 0; j < n + 1; ++j) s += c.sh.below[j] * c.ps.M1[(size_t)j * (n + 1) + b];
+        c.sh.out[(n + 1) + b] += s;
+    }
+}
+// phase 5 (one thread): incorporate_theta, the reduced-key factors, the state's row of InferenceManager::emission
+template <typename S>
+SMCPP_HD void csfs_theta(const CsfsCtx<S> &c) {
+    const PrepModel &pm = c.pm;
+    const int n = pm.n, C = 3 * (n + 1);
+    S *x = c.sh.out;
+    S tauh(0.0);
+    for (int i = 0; i < C; ++i) tauh += x[i];
+    const S f = -m_expm1(-pm.theta * tauh) / tauh;
+    for (int i = 0; i < C; ++i) x[i] *= f;
+    S tot(0.0);
+    for (int i = 0; i < C; ++i) tot += x[i];
+    x[0] = 1.0 - tot;
+    bool bad = false;
+    for (int i = 0; i < C; ++i) {
+        if (sval(x[i]) < 1e-10) x[i] = S(1e-10);
+        const double v = sval(x[i]);
+        bad = bad || v < 0 || v > 1 || v != v;
+    }
+    if (bad && c.po.flags) c.po.flags[1] = 1;
+    const S act = ld<S>(pm.act_v, pm.nder ? pm.act_d + (size_t)c.dir * pm.M : nullptr, c.h);
+    if (sval(act) != sval(act)) { c.sh.e2[0] = S(1e-20); c.sh.e2[1] = S(1e-20); }
+    else {
+        const S le = -2.0 * pm.alpha * pm.theta * act;
+        c.sh.e2[0] = m_exp(le);
+        c.sh.e2[1] = -m_expm1(le);
+    }
+}
+// phase 6: emission vectors of key k at state h (OnePopPrep::emission_probs), and the state's conditioned SFS
+template <typename S>
+SMCPP_HD void csfs_emit(const CsfsCtx<S> &c, int t, int nt) {
+    const PrepModel &pm = c.pm;
+    const int n = pm.n, C = 3 * (n + 1), M = pm.M, h = c.h;
+    for (int i = t; i < C; i += nt) {
+        if (c.dir == 0 && c.po.sfs_v) c.po.sfs_v[(size_t)h * C + i] = sval(c.sh.out[i]);
+        if (pm.nder && c.po.sfs_d) c.po.sfs_d[((size_t)c.dir * M + h) * C + i] = sder(c.sh.out[i]);
+    }
+    for (int k = t; k < c.ps.Kk; k += nt) {
+        const int kind = c.ps.kind[k];
+        S e(0.0);
+        if (kind == 1) e = S(1.0);
+        else if (kind >= 2) e = c.sh.e2[kind - 2];
+        else for (int b = c.ps.boff[k]; b < c.ps.boff[k + 1]; ++b) e += c.ps.bw[b] * c.sh.out[c.ps.bidx[b]];
+        const double v = sval(e);
+        if (c.po.flags) {
+            if (!(v > 0.0) || v > 1.0) c.po.flags[0] = 1;
+            else if (c.ps.maxspan && (double)c.ps.maxspan[k] * ::log(v) < -450.0) c.po.flags[2] = 1;
+        }
+        if (c.dir == 0) {
+            c.po.Eg_v[(size_t)k * M + h] = v;
+            const int kl = c.ps.local ? c.ps.local[k] : k;
+            if (kl >= 0) {
+                if (c.po.El_v) c.po.El_v[(size_t)kl * c.po.Mp + h] = v;
+                if (c.po.Es_v) c.po.Es_v[(size_t)(c.ps.slot ? c.ps.slot[k] : kl) * c.po.MS + h] = v;
+            }
+        }
+        if (pm.nder) c.po.Eg_d[((size_t)c.dir * c.ps.Kk + k) * M + h] = sder(e);
+    }
+}
+
+// ---- the same phases run serially on the host (CPU tests; never part of the product path) -----------------------------------
+template <typename S>
+inline void emulate_tables(const PrepModel &pm, const Tables<S> &tb) {
+    const int nd = pm.nder > 0 ? pm.nder : 1;
+    for (int dir = 0; dir < nd; ++dir) {
+        for (int it = 0; it < (2 * pm.n + 1) * pm.K; ++it) tables_term<S>(pm, dir, tb, it);
+        for (int t = 0; t < 2 * pm.n + 1; ++t) tables_scan<S>(pm, dir, tb, t);
+    }
+}
+template <typename S>
+inline void emulate_csfs(const PrepModel &pm, const PrepStatic &ps, const PrepOut &po, const Tables<S> &tb) {
+    const int nd = pm.nder > 0 ? pm.nder : 1, n = pm.n;
+    std::vector<S> scratch(CsfsScratch<S>::count(n));
+    const int nt = 3 * n + 2;
+    for (int h = 0; h < pm.M; ++h)
+        for (int dir = 0; dir < nd; ++dir) {
+            CsfsCtx<S> c;
+            c.pm = pm; c.ps = ps; c.po = po; c.tb = tb; c.h = h; c.dir = dir;
+            c.sh.carve(scratch.data(), n);
+            for (int t = 0; t < nt; ++t) csfs_clear(c, t, nt);
+            for (int m = pm.hsi[h]; m < pm.hsi[h + 1]; ++m) {
+                for (int t = 0; t < nt; ++t) csfs_piece_tables(c, m, t);
+                for (int p = 0; p < (n + 1) * n; ++p) csfs_pair(c, m, p);
+            }
+            for (int t = 0; t < nt; ++t) csfs_contract(c, t);
+            for (int t = 0; t < nt; ++t) csfs_backtransform(c, t);
+            csfs_theta(c);
+            for (int t = 0; t < nt; ++t) csfs_emit(c, t, nt);
+        }
+}
+
+#ifdef __HIPCC__
+// ---- kernels ------------------------------------------------------------------------------------------------------------------
+template <typename S>
+__global__ void k_prep_tables(PrepModel pm, Tables<S> tb) {
+    const int dir = blockIdx.x;
+    const int items = (2 * pm.n + 1) * pm.K;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) tables_term<S>(pm, dir, tb, it);
+    __syncthreads();                       // (workgroup-scope release / acquire of the global scratch included)
+    for (int t = threadIdx.x; t < 2 * pm.n + 1; t += blockDim.x) tables_scan<S>(pm, dir, tb, t);
+}
+
+template <typename S>
+__global__ void k_prep_csfs(PrepModel pm, PrepStatic ps, PrepOut po, Tables<S> tb) {
+    extern __shared__ double prep_lds[];
+    CsfsCtx<S> c;
+    c.pm = pm; c.ps = ps; c.po = po; c.tb = tb; c.h = blockIdx.x; c.dir = blockIdx.y;
+    c.sh.carve(reinterpret_cast<S *>(prep_lds), pm.n);
+    const int t = threadIdx.x, nt = blockDim.x, n = pm.n;
+    csfs_clear(c, t, nt);
+    __syncthreads();
+    for (int m = pm.hsi[c.h]; m < pm.hsi[c.h + 1]; ++m) {
+        csfs_piece_tables(c, m, t);
+        __syncthreads();
+        for (int p = t; p < (n + 1) * n; p += nt) csfs_pair(c, m, p);
+        __syncthreads();
+    }
+    csfs_contract(c, t);
+    __syncthreads();
+    csfs_backtransform(c, t);
+    __syncthreads();
+    if (t == 0) csfs_theta(c);
+    __syncthreads();
+    csfs_emit(c, t, nt);
+}
+#endif
+
+}  // namespace smcpp_dev
+
+#pragma clang fp contract(fast)

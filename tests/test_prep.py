@@ -243,3 +243,30 @@ def test_rate_function_jacobian_vs_finite_differences():
         assert abs((ep.R(1.08) - Rt) * 1e7 - dR[k]) <= 1e-5 * max(1.0, abs(dR[k]))
         np.testing.assert_allclose((np.array(ep.average_coal_times()) - ct) * 1e7, dct[:, k], atol=2e-6)
         np.testing.assert_allclose((_smcpp.raw_sfs(mp, 6, 0.05, 0.9) - sf) * 1e7, dsf[:, :, k], atol=2e-6)
+
+
+# ---- device cold preparation (smcpp_amd/csrc/prep_dev.hpp): the kernel phases run serially on the host ----
+@pytest.mark.parametrize("fixture,nder", [("params_M32_n10.npz", 0), ("params_M64_n20.npz", 0), ("params_M64_n20.npz", 3),
+                                          ("params_M256_n50.npz", 0), ("params_M256_n50.npz", 2)])
+def test_device_preparation_phases_equal_host_preparation(fixture, nder):
+    """The conditioned SFS / incorporate_theta / emission-table kernels of the device preparation are written as
+    __host__ __device__ phases; run serially on the CPU they must reproduce the host preparation BIT FOR BIT (same
+    operations in the same order, FMA contraction off), values and forward-mode Jacobians."""
+    import os
+    from smcpp_amd import _engine
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
+    n = int(g["n"])
+    args = (n, g["hs"], float(g["pol"]), g["a"], g["s"], float(g["theta"]), float(g["rho"]), float(g["alpha"]), g["keys"])
+    if nder == 0:
+        pi, T, E = _engine.host_prep_onepop(*args)
+        o = _engine.dev_prep_onepop(*args, emulate=True)
+        assert np.array_equal(o["E"], E) and np.array_equal(o["pi"], pi) and np.array_equal(o["T"], T)
+        if "csfs" in g.files:                      # the compiled reference's conditioned SFS after incorporate_theta
+            np.testing.assert_allclose(o["sfs"], g["csfs"], rtol=3e-15, atol=1e-15)
+        return
+    da = np.random.default_rng(5).standard_normal((len(g["a"]), nder))
+    pi, T, E, dpi, dT, dE = _engine.host_prep_onepop_jac(args[0], args[1], args[2], args[3], da, *args[4:])
+    o = _engine.dev_prep_onepop(*args, da=da, emulate=True)
+    assert np.array_equal(o["E"], E) and np.array_equal(o["dE"], dE)
+    assert np.array_equal(o["dpi"], dpi) and np.array_equal(o["dT"], dT)
+    assert np.abs(dE).max() > 1e-4

@@ -340,24 +340,48 @@ def main():
     mode = im.chain_mode() if hasattr(im, "chain_mode") else -1
     F_alg, B_alg = eval_work(contigs, M)
     if mode in (5, 6):
-        # Scan chains (chains_ss.hpp): ONE kernel runs both directions (forward and backward wavefronts share a workgroup), so
-        # the dominant kernel is k_chain_ss and `achieved` credits ONE pass of the algorithmic work of BOTH chains
-        # (2 M^2 R1 + 4 M^2 Re flops per chain) against the time of ALL its launches of one E-step (light
-        # passes, full pass, re-run passes).  The kernel executes O(M) per position, not those flops: it is bound by VALU
-        # issue (tools/dpp_lab.hip: 2.3 ns per instruction and wavefront, one wavefront per SIMD), the figure is the
-        # reference's algorithm priced on this kernel's clock.
+        # Scan chains (chains_ss.hpp): ONE kernel runs both directions (forward and backward wavefronts share a workgroup) and
+        # executes NO matrix product: O(M) prefix scans per POSITION on the vector ALU, one wavefront per chunk.  Its bound is VALU
+        # ISSUE, so that is what the roofline block prices: `achieved` = wave-level VALU instructions per second summed over
+        # all launches of one E-step (SQ_INSTS_VALU of the committed rocprofv3 --pmc pass of this same command when there is one
+        # for this workload, else the instruction count of the kernel's ISA per position x the positions every pass walks),
+        # `peak` = one VALU instruction per cycle and SIMD (1024 SIMDs x the 2.4 GHz peak engine clock).  The reference's dense
+        # flops priced on this kernel's clock stay available as `frac_dense_equivalent` (rounds 1-3 quoted that as `frac`; it is
+        # a speed against the reference's ALGORITHM, grows with M whatever the kernel does, and is not a utilisation).
         kname = "k_chain_ss"
         k_ms = med["chains_wall_ms"]
         k_flops, k_bytes = 2.0 * flops, bytes_f + bytes_b
         ach_tflops = k_flops / (1e-3 * k_ms) / 1e12 if k_ms > 0 else 0.0
         ach_gbs = k_bytes / (1e-3 * k_ms) / 1e9 if k_ms > 0 else 0.0
-        roof = dict(bound="mfma", achieved=ach_tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach_tflops / FP64_PEAK_TFLOPS)
         positions = float(sum(int(c[:, 0].sum()) for c in contigs))
-        other = {"bound_detail": "VALU issue: O(M) scans per position over the semiseparable structure of T, no matrix product "
-                                 "executes (achieved = algorithmic flops of the reference's dense formulation / kernel time)",
-                 "positions": positions, "positions_per_us": positions / (1e3 * k_ms) if k_ms > 0 else 0.0,
-                 "per_chain_tflops": ach_tflops / 2.0}
-        note = "both chains in one kernel; frac = one pass of algorithmic flops of both chains / kernel time per step / fp64 peak"
+        npl = (M + 63) // 64
+        # VALU instructions per position of the ISA (llvm-objdump of k_chain_ss<NPL>): full fp64 pass
+        # forward / backward, light float pass forward / backward
+        ipp = {1: (53, 59, 25, 29)}.get(npl)
+        sq = sq_counters(args.workload if (args.length_mbp == 100.0 and world == 1) else None, kname)
+        passes = med["fwd_passes"]
+        est_instr = None
+        if ipp is not None:
+            # per E-step: `light` float passes + one full pass + the merge re-runs (which stop after the forgetting length: their
+            # share of a full pass is what the timing split says, not a count) - a MODEL, used only without counters
+            light = max(0.0, passes - 2.0)
+            est_instr = positions * (light * (ipp[2] + ipp[3]) + 1.4 * (ipp[0] + ipp[1]))
+        instr = sq["SQ_INSTS_VALU_per_step"] if sq else est_instr
+        peak_ginstr = 1024 * 2.4                           # G wave-instructions / s: 256 CUs x 4 SIMDs x 2.4 GHz, one VALU issue per cycle
+        ach_ginstr = (instr / (1e-3 * k_ms) / 1e9) if (instr and k_ms > 0) else None
+        roof = dict(bound="valu-issue", achieved=ach_ginstr, peak=peak_ginstr, unit="G wave-instr/s",
+                    frac=(ach_ginstr / peak_ginstr) if ach_ginstr else None)
+        other = {"bound_detail": "VALU issue: O(M) DPP scans per position over the semiseparable structure of T, one wavefront per "
+                                 "SIMD (tools/dpp_lab.hip: 5.3 clocks between two issues of one wavefront); no matrix product executes",
+                 "instr_source": (sq["source"] if sq else "ISA instruction count x positions walked (model; no counter profile for this workload)"),
+                 "instr_per_position": (dict(zip(["full_fwd", "full_bwd", "light_fwd", "light_bwd"], ipp)) if ipp else None),
+                 "frac_one_wavefront_issue_bound": (ach_ginstr / (peak_ginstr / 5.3)) if ach_ginstr else None,
+                 "sq_counters": sq,
+                 "executed_flops_estimate": 30.0 * M * positions * 2.0,
+                 "frac_dense_equivalent": ach_tflops / FP64_PEAK_TFLOPS, "dense_equivalent_tflops": ach_tflops,
+                 "positions": positions, "positions_per_us": positions / (1e3 * k_ms) if k_ms > 0 else 0.0}
+        note = ("both chains in one kernel; frac = executed wave-level VALU instructions / (kernel time x 1024 SIMDs x 2.4 GHz); "
+                "frac_hbm = algorithmic alpha/beta/normaliser bytes of one pass / kernel time / 8 TB/s")
     else:
         # The chain kernels (k_fwd_coop / k_bwd_coop, k_*_big for M > 64) dominate.  smcpp_last_timing brackets ALL pass
         # launches of each chain of one E-step with hipEvents on the stream they are launched on, so `kernel_ms_per_step`
@@ -378,7 +402,7 @@ def main():
         note = "latency-bound sequential chains: frac = one pass of algorithmic flops / kernel time per step / fp64 peak"
     # HBM bytes per step from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes); only for the profiled workload
-    traffic = None
+    traffic = traffic_src = None
     try:
         if args.workload == "headline" and args.length_mbp == 100.0 and world == 1:
             import glob
@@ -387,10 +411,12 @@ def main():
             # every launch of the kernel (pass 0 / light / full / re-run): per-step bytes of all of them
             tr = [v["bytes_per_step"] for name, v in prof["kernels"].items() if kname in name]
             traffic = float(sum(tr)) if tr else None
+            traffic_src = ("committed PMC passes of this command, not measured in this run: " + os.path.relpath(pf, ROOT)) if tr else None
     except Exception:  # noqa: BLE001
-        traffic = None
+        traffic = traffic_src = None
     roof.update(
-        traffic=traffic, kernel=f"{kname} (all launches of one E-step)",
+        traffic=traffic, traffic_source=traffic_src, frac_hbm=ach_gbs / HBM_PEAK_GBS,
+        kernel=f"{kname} (all launches of one E-step)",
         kernel_ms_per_step=k_ms, passes=med["fwd_passes"],
         algorithmic_flops_one_pass=k_flops, algorithmic_bytes_one_pass=k_bytes,
         hbm_gbs=ach_gbs, hbm_frac=ach_gbs / HBM_PEAK_GBS, **other,
@@ -409,6 +435,18 @@ def main():
                              "gamma_write_frac_of_hbm": gbytes / t_stat / 1e9 / HBM_PEAK_GBS,
                              "eigen_row_tflops": 2.0 * M ** 3 * Re / t_stat / 1e12,
                              "fwd_passes": med["fwd_passes"], "bwd_passes": med["bwd_passes"]}
+    # full-size parity against the compiled reference's recorded log-likelihoods (golden G16, tests/golden/make_golden_fullsize.py)
+    parity_full = None
+    try:
+        gp = os.path.join(ROOT, "tests", "golden", f"G16_fullsize_{args.workload}.npz")
+        if os.path.exists(gp) and args.length_mbp == 100.0 and not args.raw:
+            z = np.load(gp)
+            ref_ll = float(z["loglik"].sum()) if args.workload == "c3" else (float(z["loglik"][:world].sum()) if world <= len(z["loglik"]) else None)
+            if ref_ll is not None and args.workload != "c5":
+                parity_full = {"loglik_reference_full": ref_ll, "loglik_engine": float(ll), "rel_diff": abs(float(ll) - ref_ll) / abs(ref_ll),
+                               "source": "tests/golden/" + os.path.basename(gp) + " (compiled reference, full size, all contigs of this run)"}
+    except Exception:  # noqa: BLE001
+        parity_full = None
     out = None
     if rank == 0:
         out = {
@@ -429,6 +467,8 @@ def main():
             "split_ms": med,
             "roofline": roof,
         }
+        if parity_full is not None:
+            out["parity_full_size"] = parity_full
         if warm is not None:
             out["warm_start"] = warm
         if world > 1:
@@ -439,7 +479,15 @@ def main():
             # cold preparation is timed on the model itself (one population only: the two-population joint CSFS is in
             # a translation unit of the reference that needs GSL)
             model_args = None if args.workload == "c4" else (a, s_, hs, rho, theta, n)
-            out["cpu_baseline"] = cpu_baseline(raw, model_args, np.concatenate(contigs), args.cpu_seconds, args.raw)
+            def engine_on_prefix(prefix):
+                # the engine on exactly the rows the reference just ran (same prepared parameters): the in-run parity figure
+                im2 = factory([np.ascontiguousarray(prefix)], local_rank)
+                im2.theta = theta; im2.rho = rho; im2.alpha = alpha
+                im2.set_raw(*raw)
+                im2.E_step()
+                return im2.loglik()
+            out["cpu_baseline"] = cpu_baseline(raw, model_args, np.concatenate(contigs), args.cpu_seconds, args.raw,
+                                               engine_on_prefix if len(contigs) == 1 else None, len(contigs))
             if out["cpu_baseline"] and out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_1core"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
@@ -448,7 +496,40 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(raw, model_args, obs, budget_s, raw_only):
+def sq_counters(workload, kname):
+    """SQ counter totals of `kname` per E-step from the newest committed profiles/r0*_<workload>_sq_counters.json (rocprofv3
+    --pmc passes of this same command, tools/pmc_sq_counters.sh + tools/summarize_sq.py); None when there is none."""
+    if workload is None:
+        return None
+    try:
+        import glob
+        pf = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0[0-9]*_{workload}_sq_counters.json")))[-1]
+        prof = json.load(open(pf))
+        tot = {}
+        for name, v in prof["kernels"].items():
+            if kname in name:
+                for c, x in v["per_step"].items():
+                    tot[c] = tot.get(c, 0.0) + float(x)
+        if "SQ_INSTS_VALU" not in tot:
+            return None
+        out = {"source": "committed rocprofv3 --pmc passes of this command, not measured in this run: " + os.path.relpath(pf, ROOT),
+               "SQ_INSTS_VALU_per_step": tot["SQ_INSTS_VALU"]}
+        for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY",
+                  "SQ_INSTS_SALU", "SQ_WAVES", "GRBM_GUI_ACTIVE"):
+            if c in tot:
+                out[c + "_per_step"] = tot[c]
+        if tot.get("SQ_WAVE_CYCLES"):
+            # SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles (MI355X_MICROARCH.md): ratios are unit-free
+            for c in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
+                if c in tot:
+                    out[c + "_over_WAVE_CYCLES"] = tot[c] / tot["SQ_WAVE_CYCLES"]
+            out["wave_cycles_per_valu_instr"] = 4.0 * tot["SQ_WAVE_CYCLES"] / tot["SQ_INSTS_VALU"]
+        return out
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def cpu_baseline(raw, model_args, obs, budget_s, raw_only, engine_on_prefix=None, n_contigs=1):
     """The reference's own C++ on one host core (oracle/_ref, compiled from /root/reference/src in the build
     container): its cold preparation (`ref_prep`: rate function, transition, conditioned SFS — what setParams +
     do_dirty_work recompute, src/inference_manager.cpp:213-229) timed in full, plus `HMM::Estep` on a prefix of the same
@@ -479,7 +560,20 @@ def cpu_baseline(raw, model_args, obs, budget_s, raw_only):
         r = fn(pi, T, keys, E, obs[:rows])
         dt = time.perf_counter() - t
         full = dt * len(obs) / rows
-        return {"value": 1.0 / (full + prep_s), "unit": "evals/s", "cores": 1, "kind": kind,
+        parity = {}
+        if engine_on_prefix is not None:
+            try:
+                ll_e = engine_on_prefix(obs[:rows])
+                parity = {"loglik_prefix_engine": ll_e, "rel_diff_loglik": abs(ll_e - r["loglik"]) / abs(r["loglik"]),
+                          "rel_diff_note": "engine (default chain family, set_raw with the same prepared parameters) vs the compiled "
+                                           "reference on the SAME prefix rows, in this run; north_star bar 1e-6"}
+            except Exception as ex:  # noqa: BLE001
+                parity = {"rel_diff_error": repr(ex)}
+        ref_threads = min(n_contigs, os.cpu_count() or 1)
+        return {"value": 1.0 / (full + prep_s), "unit": "evals/s", "cores": 1, "kind": kind, **parity,
+                "reference_threads_note": f"the reference runs one OpenMP thread per contig (src/inference_manager.cpp:89-94): on this "
+                                          f"workload it would use {ref_threads} thread(s); the baseline is timed on 1 and scaled by rows, "
+                                          f"i.e. with perfect scaling over its threads the reference would reach {ref_threads} x `value`",
                 "sample": f"reference cold preparation timed in full ({1e3 * prep_s:.1f} ms) + HMM::Estep on the first "
                           f"{rows} of {len(obs)} rows of the same contig(s) in {dt:.1f} s, scaled by row count "
                           f"(1 thread = 1 contig, as the reference parallelises); host has {os.cpu_count()} cores",

@@ -132,6 +132,12 @@ int smcpp_get_debug(smcpp_im *im);
 /* Rows per chunk of the chunk-parallel chains (0 = automatic) and the chunk-boundary convergence tolerances. */
 int smcpp_set_chunking(smcpp_im *im, int rows_per_chunk, double eps_alpha, double eps_beta);
 
+/* Where the cold preparation of a one-population manager runs: 0 (default) = conditioned SFS, incorporate_theta and the
+ * emission table on the device (smcpp_amd/csrc/prep_dev.hpp; the host only builds the O(pieces) rate function, pi and the
+ * transition matrix), 1 = everything on the host (smcpp_amd/csrc/prep.hpp, rounds 1-3; also selected by SMCPP_PREP=host).
+ * Results agree to the last bits of the exponentials; kept for the tests and as the baseline of bench.py --workload qgrad. */
+int smcpp_set_prep_mode(smcpp_im *im, int host);
+
 /* Extension (off by default): start the chunk-parallel chains of the next E-step from the converged chunk-boundary
  * vectors of the previous E-step of this manager instead of pi / the uniform vector.  In an EM or optimiser loop the
  * parameters move little between calls, so the re-run passes merge after a fraction of a chunk; the fixed-point

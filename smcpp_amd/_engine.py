@@ -61,7 +61,7 @@ def lib():
         "smcpp_init_logger_cb": (None, [C.c_void_p]), "smcpp_init_cache": (i, [C.c_char_p]),
         "smcpp_set_global_keys": (i, [vp, i, _ip]),
         "smcpp_pack_stats": (i, [vp, _dp, C.POINTER(lg), i]), "smcpp_unpack_stats": (i, [vp, _dp, lg, i]),
-        "smcpp_set_chunking": (i, [vp, i, d, d]), "smcpp_set_warm_start": (i, [vp, i]),
+        "smcpp_set_chunking": (i, [vp, i, d, d]), "smcpp_set_warm_start": (i, [vp, i]), "smcpp_set_prep_mode": (i, [vp, i]),
         "smcpp_last_timing": (i, [vp, _dp]), "smcpp_last_host_timing": (i, [vp, _dp]), "smcpp_stream": (vp, [vp]), "smcpp_chain_mode": (i, [vp]),
         "smcpp_set_num_threads": (None, [i]),
         "smcpp_set_debug": (i, [vp, i]), "smcpp_get_debug": (i, [vp]), "smcpp_device": (i, [vp]),
@@ -109,7 +109,7 @@ EXPORTS = [
     "smcpp_host_set_csfs_direct", "smcpp_gamma_cols", "smcpp_last_host_timing", "smcpp_get_pi_jac",
     "smcpp_get_transition_jac", "smcpp_get_emission_probs_jac", "smcpp_num_emission_cols", "smcpp_get_emission",
     "smcpp_init_logger_cb", "smcpp_init_cache", "smcpp_debug_ss_apply", "smcpp_debug_ss4_apply", "smcpp_set_debug", "smcpp_get_debug", "smcpp_device",
-    "smcpp_dev_prep_onepop",
+    "smcpp_dev_prep_onepop", "smcpp_set_prep_mode",
 ]
 
 

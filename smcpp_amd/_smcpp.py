@@ -230,6 +230,10 @@ class _PyInferenceManager:
         """Extension: reuse the previous E-step's converged chunk-boundary vectors as start vectors (see the header)."""
         E.check(E.lib().smcpp_set_warm_start(self._im, int(bool(on))))
 
+    def set_prep_mode(self, host=False):
+        """Where the cold preparation runs: device kernels (default) or the host routines (see the header)."""
+        E.check(E.lib().smcpp_set_prep_mode(self._im, int(bool(host))))
+
     def device_index(self):
         """The HIP device this manager lives on."""
         return int(E.lib().smcpp_device(self._im))

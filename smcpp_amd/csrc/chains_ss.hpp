@@ -1040,8 +1040,10 @@ __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
     extern __shared__ __attribute__((aligned(16))) double ss_lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // mode 3: the direction takes no part in this launch (its pass runs in the other layout's kernel)
-    const bool idle_f = a.mode_f == 3 || (a.mode_f == 1 && a.changed_f[a.pass - 1] == 0);
-    const bool idle_b = a.mode_b == 3 || (a.mode_b == 1 && a.changed_b[a.pass - 1] == 0);
+    // (a FULL pass never idles: it is the first pass that stores rows, and with a warm start it may be the first pass launched at
+    // all - the flag of the pass before it was then never written)
+    const bool idle_f = a.mode_f == 3 || (a.mode_f == 1 && !a.full_f && a.changed_f[a.pass - 1] == 0);
+    const bool idle_b = a.mode_b == 3 || (a.mode_b == 1 && !a.full_b && a.changed_b[a.pass - 1] == 0);
     if (idle_f && idle_b) return;
     const int nthr = HYB ? (int)blockDim.x : 256;
     for (int idx = tid; idx < a.nlds * MS; idx += nthr) ss_lds[idx] = a.E[idx];

@@ -21,6 +21,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -456,6 +457,12 @@ struct smcpp_im {
     // ---- chains on the semiseparable structure of T (chains_ss.hpp; chain_mode 5) ------------------------------------------
     std::unique_ptr<smcpp_host::OnePopPrep> prep1;   // one-population cold preparation (caches per-key tables)
     std::vector<double> prep1_hs;
+    // device cold preparation (prep_dev.hpp): the emission table of the current parameters lives on the device only and the host
+    // vectors E / dE / emission / Eg are stale until sync_host_E() fetches them (getters, non-lean E-steps)
+    std::unique_ptr<DevPrep> dprep;
+    bool E_on_dev = false, force_host_prep = false;
+    void dev_prepare();
+    void sync_host_E();
     bool ss_static = false;                // the input qualifies (short spans); whether T does is decided on every E-step
     // hybrid scan chains (un-binned data): rows whose span exceeds ss_hyb_th take ONE eigen-power step inside the scan kernel
     // (chains_ss.hpp); they cost about SS_HYB_COST scan positions each, which is what the chunk list is balanced on
@@ -781,6 +788,7 @@ static std::vector<int> ss_chunk_counts(const std::vector<long long> &cpos, cons
         double bl = 0.0;
         for (int c = 0; c < n; ++c) {
             if (ncs[c] >= rows[c]) continue;
+            if (cpos[c] < (long long)(ncs[c] + 1) * std::max<long long>(1, floor_cost)) continue;     // no chunk below the floor
             const double len = (double)cpos[c] / ncs[c];
             if (best < 0 || len > bl) { best = c; bl = len; }
         }
@@ -967,7 +975,7 @@ void smcpp_im::make_chunks() {
         }
     }
     max_pass = max_chunks_per_contig + 3;   // (+1: the full pass that follows an eigen-free pre-pass)
-    if (ss_static) max_pass += 4;           // light passes of the scan chains
+    if (ss_static) max_pass += 4 + 2;       // light passes of the scan chains; a warm start numbers its passes from 1 or 2
     chunks_b = chunks;
     build_coarse_chunks();
 }
@@ -1354,6 +1362,7 @@ void smcpp_im::prepare_params() {
             throw std::runtime_error("two-population manager: call set_params_twopop (or set_raw) before E_step");
         if (!twopop_prep) twopop_prep.reset(new smcpp_host::TwoPopPrep(n[0], n[1], na[0], na[1], hs, polarization_error));
         smcpp_host::TwoPopPrep &prep = *twopop_prep;
+        E_on_dev = false;
         if (nder > 0) {
             smcpp_host::DualScope sc(nder);
             std::vector<smcpp_host::dual> pd, Td, Ed, emd;
@@ -1373,8 +1382,17 @@ void smcpp_im::prepare_params() {
         return;
     }
     // (kept across E-steps: it caches the keys' marginalisation bins; rebuilt when the hidden states change)
-    if (!prep1 || prep1_hs != hs) { prep1.reset(new smcpp_host::OnePopPrep(n[0], hs, polarization_error)); prep1_hs = hs; }
+    if (!prep1 || prep1_hs != hs) {
+        prep1.reset(new smcpp_host::OnePopPrep(n[0], hs, polarization_error)); prep1_hs = hs;
+        if (dprep) dprep->keys_ready = false;
+    }
     smcpp_host::OnePopPrep &prep = *prep1;
+    {
+        // conditioned SFS + emission table on the device (SMCPP_PREP=host: the host routines, as in rounds 1-3)
+        static const bool host_only = getenv("SMCPP_PREP") && !strcmp(getenv("SMCPP_PREP"), "host");
+        if (!host_only && !force_host_prep && DevPrep::supported(n[0]) && !smcpp_host::csfs_direct_flag()) { dev_prepare(); return; }
+    }
+    E_on_dev = false;
     // with a global key dictionary (multi-GPU) the emission table is prepared for every global key; the local table
     // is the sub-list of the keys this rank's contigs hold
     const std::vector<int> &pk = have_global ? gkeys : keys;
@@ -1397,8 +1415,75 @@ void smcpp_im::prepare_params() {
     params_fresh = true;
 }
 
+// One-population do_dirty_work with the O(states x n^2 x directions) part on the device: the host builds the rate function
+// (O(pieces)), pi, the average coalescence times and - while the kernels already run - the transition matrix.
+void smcpp_im::dev_prepare() {
+    HIPCHK(hipSetDevice(device));
+    if (!dprep) { dprep.reset(new DevPrep()); dprep->set_static(prep1->tables()); }
+    const std::vector<int> &pk = have_global ? gkeys : keys;
+    const int Kp_ = (int)(pk.size() / keylen);
+    if (!dprep->keys_ready) {
+        // per prepared key: its row of the statistics' table, its slot of the scan chains' table, the longest span the scan
+        // chains expand position by position (ss_extract_generators' underflow bound, checked by the kernel)
+        std::vector<int> ms_local(K, 1), local(Kp_, -1), slot(Kp_, -1), maxspan(Kp_, 1);
+        for (const Group &gr : groups)
+            if (!(ss_hybrid && gr.span > ss_hyb_th)) ms_local[gr.kid] = std::max(ms_local[gr.kid], gr.span);
+        for (int k = 0; k < K; ++k) {
+            const int kg = have_global ? local_to_global[k] : k;
+            local[kg] = k;
+            slot[kg] = (ss_static && (int)ss_slot_of_key.size() == K) ? ss_slot_of_key[k] : k;
+            maxspan[kg] = ms_local[k];
+        }
+        dprep->set_keys(*prep1, pk, Kp_, local, slot, maxspan, K, M, Mp, ss_static ? 64 * NPL : 0);
+    }
+    if (nder > 0) {
+        smcpp_host::DualScope sc(nder);
+        const smcpp_host::RateFunctionT<smcpp_host::dual> eta(make_dual_model(model, model_da, nder), hs);
+        const std::vector<smcpp_host::dual> act = eta.average_coal_times();
+        dprep->run(eta, act, theta, alpha, nder, stream);
+        std::vector<smcpp_host::dual> pd;
+        smcpp_host::initial_distribution(eta, pd);
+        split_duals(pd, nder, pi, dpi);
+        split_duals(smcpp_host::compute_transition<smcpp_host::dual>(eta, rho), nder, T, dT);
+    } else {
+        smcpp_host::ModelParamsT<double> p;
+        p.a = model.a; p.s = model.s;
+        const smcpp_host::RateFunctionT<double> eta(p, hs);
+        dprep->run(eta, eta.average_coal_times(), theta, alpha, 0, stream);
+        smcpp_host::initial_distribution(eta, pi);
+        T = smcpp_host::compute_transition<double>(eta, rho);
+        dpi.clear(); dT.clear();
+    }
+    E_on_dev = true;
+    Eg.clear(); dEg.clear();
+    params_fresh = true;
+}
+
+// The emission table (and its Jacobian, and InferenceManager::emission) of a device preparation, to the host vectors
+void smcpp_im::sync_host_E() {
+    if (!E_on_dev) return;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(stream));
+    std::vector<double> Ep, dEp;
+    dprep->fetch(Ep, dEp, emission, demission);
+    dprep->check_flags();
+    if (!have_global) { E.swap(Ep); dE.swap(dEp); }
+    else {
+        E.assign((size_t)K * M, 0.0);
+        dE.assign(nder > 0 ? (size_t)K * M * nder : 0, 0.0);
+        for (int k = 0; k < K; ++k) {
+            const int kg = local_to_global[k];
+            std::memcpy(&E[(size_t)k * M], &Ep[(size_t)kg * M], sizeof(double) * M);
+            if (nder > 0) std::memcpy(&dE[(size_t)k * M * nder], &dEp[(size_t)kg * M * nder], sizeof(double) * M * nder);
+        }
+        Eg.swap(Ep); dEg.swap(dEp);
+    }
+    E_on_dev = false;
+}
+
 // Emission vectors of the global keys for the reduced Q when the parameters did not come from prepare_params
 void smcpp_im::global_emissions() {
+    sync_host_E();
     const int Kg = (int)(gkeys.size() / keylen);
     if (!have_raw && (int)Eg.size() == Kg * M) return;        // prepare_params filled them
     Eg.assign((size_t)Kg * M, NAN);
@@ -1464,6 +1549,7 @@ void smcpp_im::host_prep_and_upload() {
                 TdT[(size_t)j * Mp + i] = T[(size_t)i * M + j];
             }
         }
+        if (E_on_dev) return;                  // (the device preparation wrote the table where the statistics read it)
         for (int k = 0; k < K; ++k)
             for (int i = 0; i < M; ++i) Ep[(size_t)k * Mp + i] = E[(size_t)k * M + i];
     };
@@ -1625,7 +1711,7 @@ void smcpp_im::host_prep_and_upload() {
     size_t need = 32 * 256;
     need += qTf.size() * 4 + (qTdT.size() + qPinvT.size() + qPT.size() + qPrm.size() + qPinvrm.size()) * 8;
     need += (pi_f.size() + uTf.size() + T4.size()) * 4;
-    need += (uTdT.size() + Td.size() + Ep.size() + uPinvT.size() + uPT.size() + uPrm.size() + uPinvrm.size() + dsc.size() +
+    need += (uTdT.size() + Td.size() + (E_on_dev ? 0 : Ep.size()) + uPinvT.size() + uPT.size() + uPrm.size() + uPinvrm.size() + dsc.size() +
              dun.size() + gsc.size() + gls.size() + fA2.size() + fB2.size() + bA2.size() + bB2.size() +
              bC2.size()) * 8;
     stage.reset(need);
@@ -1637,7 +1723,11 @@ void smcpp_im::host_prep_and_upload() {
     size_t off = 0;
     char *hb = stage.base;
     d_pi_f.place(pi_f, d_param, hb, off); d_Tf.place(uTf, d_param, hb, off); d_TdT.place(uTdT, d_param, hb, off);
-    d_Td.place(Td, d_param, hb, off); d_E.place(Ep, d_param, hb, off);
+    d_Td.place(Td, d_param, hb, off);
+    if (E_on_dev) {
+        if (d_E.p && !d_E.borrowed) (void)hipFree(d_E.p);
+        d_E.p = dprep->d_El.p; d_E.n = (size_t)K * Mp; d_E.borrowed = true;
+    } else d_E.place(Ep, d_param, hb, off);
     d_PinvT.place(uPinvT, d_param, hb, off); d_PT.place(uPT, d_param, hb, off); d_Prm.place(uPrm, d_param, hb, off);
     d_Pinvrm.place(uPinvrm, d_param, hb, off);
     d_dsc.place(dsc, d_param, hb, off); d_dun.place(dun, d_param, hb, off);
@@ -2224,7 +2314,8 @@ bool smcpp_im::ss_extract_generators() {
     if (!ss_generators(M, 64 * NPL, T.data(), ss_gen, ss_c0)) return false;
     if (ss4 && !ss_generators(M, 16 * SPL, T.data(), ss_gen4, ss_c0)) return false;
     // a row of span s applies its operator s times without rescaling: keep clear of underflow
-    for (const Group &gr : groups) {
+    // (a device-prepared table is checked by the kernel that forms it: DevPrep flag 2, looked at when the E-step has drained)
+    if (!E_on_dev) for (const Group &gr : groups) {
         if (ss_hybrid && gr.span > ss_hyb_th) continue;          // an eigen-power step, not `span` scan steps
         double mn = 1.0;
         for (int i = 0; i < M; ++i) mn = std::min(mn, E[(size_t)gr.kid * M + i]);
@@ -2345,7 +2436,8 @@ void smcpp_im::ss_launch_initial() {
     a.f_dc = gd; a.f_g = gd + MS; a.f_cg = gd + 2 * MS; a.f_b = gd + 3 * MS; a.f_a = gd + 4 * MS; a.f_d = gd + 5 * MS;
     a.b_dc = gd + 6 * MS; a.b_g = gd + 7 * MS; a.b_b = gd + 8 * MS; a.b_a = gd + 9 * MS;
     a.c0 = ss_c0;
-    {
+    if (E_on_dev) a.E = dprep->d_Es.p;       // written by the device preparation, by key slot
+    else {
         const size_t eoff = (off + 255) & ~(size_t)255;
         double *he = reinterpret_cast<double *>(pre_stage.base + eoff);
         std::memset(he, 0, (size_t)K * MS * 8);
@@ -2437,7 +2529,11 @@ bool smcpp_im::wait_done(int epoch) {
     const auto t0 = std::chrono::steady_clock::now();
     unsigned n = 0;
     while (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) != epoch) {
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
         if ((++n & 0x3fff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
             HIPCHK(hipStreamSynchronize(stream));
             return __atomic_load_n(h_done, __ATOMIC_ACQUIRE) == epoch;
@@ -2847,16 +2943,20 @@ void smcpp_im::estep() {
     auto t0 = std::chrono::steady_clock::now();
     prepare_params();
     host_timing[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if ((int)pi.size() != M || (int)T.size() != M * M || (int)E.size() != K * M)
+    if ((int)pi.size() != M || (int)T.size() != M * M || (!E_on_dev && (int)E.size() != K * M))
         throw std::runtime_error("parameters are not set");
     HIPCHK(hipEventRecord(ev[0], stream));
+    // span > 1 rows without an eigensystem (kernels.hpp: k_span_fold): the span is expanded by smax steps of two M x M products
+    static const bool eigfree_off = getenv("SMCPP_EIGFREE") && atoi(getenv("SMCPP_EIGFREE")) == 0;
+    const bool eigfree_static = !eigfree_off && Mp <= 256 && ss_max_span <= 64 && !save_gamma;
+    // only the lean path (scan chains + eigen-free statistics) reads a device-prepared emission table from HBM alone (its
+    // underflow bound is checked by the kernel that forms the table); eigensystems, operand layouts, the dense chains and the
+    // bound for longer spans need the host copy
+    if (E_on_dev && !(ss_static && eigfree_static && !ss4)) sync_host_E();
     ss_active = ss_static && ss_extract_generators();
     if (!ss_active) ss_warm_valid = false;
-    {
-        // span > 1 rows without an eigensystem (kernels.hpp: k_span_fold): the span is expanded by smax steps of two M x M products
-        static const bool off = getenv("SMCPP_EIGFREE") && atoi(getenv("SMCPP_EIGFREE")) == 0;
-        eigfree = ss_active && !off && Mp <= 256 && ss_max_span <= 64 && !save_gamma;
-    }
+    eigfree = ss_active && eigfree_static;
+    if (E_on_dev && !(ss_active && eigfree)) sync_host_E();      // (a transition matrix without the structure)
     if (ss_active && !ss_hybrid) { prepass_launched = false; static_packed = false; ss_launch_initial(); }   // the chains need no eigensystem: they start now
     else if (ss_active) { prepass_launched = false; static_packed = false; }
     else stage_static_and_prepass();   // (when eligible) pass 0 of both chains starts now, on eigen-free operands
@@ -2865,6 +2965,16 @@ void smcpp_im::estep() {
     auto t1 = std::chrono::steady_clock::now();
     if (ss_active) run_chains_ss(); else run_chains();
     run_stats();
+    if (E_on_dev) {
+        dprep->check_flags();
+        if (ss_active && dprep->flags()[2]) {
+            // an emission entry so small that `span` scan steps underflow (ss_extract_generators' bound, evaluated by the kernel
+            // that formed the table): this E-step is redone on the dense kernels from the host copy of the same parameters
+            sync_host_E();
+            estep();
+            return;
+        }
+    }
     auto t2 = std::chrono::steady_clock::now();
     float f_ms = 0, b_ms = 0, s_ms = 0, fin_ms = 0;
     if (ss_active) {
@@ -3039,6 +3149,14 @@ int smcpp_set_params_twopop(smcpp_im *im, int Kd, const double *ad, const double
     API_END
 }
 
+int smcpp_set_prep_mode(smcpp_im *im, int host) {
+    API_BEGIN
+    im->force_host_prep = host != 0;
+    im->params_fresh = false;
+    im->dirty = true;
+    API_END
+}
+
 int smcpp_set_warm_start(smcpp_im *im, int on) {
     API_BEGIN
     im->warm_start = on != 0;
@@ -3064,6 +3182,7 @@ int smcpp_set_raw(smcpp_im *im, const double *pi, const double *T, int K, const 
     im->raw_keys.assign(keys, keys + (size_t)K * kl);
     im->raw_E.assign(E, E + (size_t)K * M);
     im->have_raw = true;
+    im->E_on_dev = false;
     im->dirty = true;
     im->nder = 0;
     API_END
@@ -3101,6 +3220,7 @@ int smcpp_q(smcpp_im *im, double val[4], double *jac) {
     API_BEGIN
     const int M = im->M, K = im->K;
     if (!im->have_raw) im->prepare_params();   // Q() does do_dirty_work() first (inference_manager.cpp:119)
+    im->sync_host_E();
     if ((int)im->pi.size() != M) throw std::runtime_error("parameters are not set");
     const int nder = im->have_raw ? 0 : im->nder;
     if (jac) for (int i = 0; i < 4 * nder; ++i) jac[i] = 0.0;
@@ -3291,6 +3411,7 @@ int smcpp_get_transition(smcpp_im *im, double *out) {
 }
 int smcpp_get_emission_probs(smcpp_im *im, double *out) {
     API_BEGIN
+    im->sync_host_E();
     if (im->E.empty()) throw std::runtime_error("parameters are not set");
     std::memcpy(out, im->E.data(), sizeof(double) * im->K * im->M);
     API_END
@@ -3316,6 +3437,7 @@ int smcpp_get_transition_jac(smcpp_im *im, double *out) {
 int smcpp_get_emission_probs_jac(smcpp_im *im, double *out) {
     API_BEGIN
     need_model_params(im);
+    im->sync_host_E();
     if (im->nder > 0) std::memcpy(out, im->dE.data(), sizeof(double) * im->dE.size());
     API_END
 }
@@ -3327,6 +3449,7 @@ int smcpp_num_emission_cols(smcpp_im *im) {
 int smcpp_get_emission(smcpp_im *im, double *out, double *jac) {
     API_BEGIN
     need_model_params(im);
+    im->sync_host_E();
     if (im->emission.size() != (size_t)im->M * smcpp_num_emission_cols(im)) throw std::runtime_error("emission matrix is not available");
     std::memcpy(out, im->emission.data(), sizeof(double) * im->emission.size());
     if (jac && im->nder > 0) std::memcpy(jac, im->demission.data(), sizeof(double) * im->demission.size());
@@ -3355,6 +3478,8 @@ int smcpp_set_global_keys(smcpp_im *im, int Kg, const int *gkeys) {
     im->gkeys.assign(gkeys, gkeys + (size_t)Kg * kl);
     im->have_global = true;
     im->pack_tables_ready = false;
+    if (im->dprep) im->dprep->keys_ready = false;
+    im->E_on_dev = false;
     im->params_fresh = false;              // the emission table is now prepared over the global key list
     im->Eg.clear(); im->dEg.clear();
     API_END

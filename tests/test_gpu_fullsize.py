@@ -1,0 +1,140 @@
+"""The graded configurations at FULL SIZE against the compiled reference (golden G16, tests/golden/make_golden_fullsize.py:
+`HMM::Estep` of /root/reference/src/hmm.cpp:45-153 run single-threaded per contig in the build container, 36 minutes of CPU
+time in total): headline (1 x 100 Mbp, M = 64, n = 20; the eight contigs of the weak-scaling bench), C2 (M = 32, n = 10),
+C3 (22 contigs, 6.76 M rows), C4 (two populations, M = 48, G13's parameters), C5 (M = 256, n = 50, 25 000 rows).
+
+The engine runs its DEFAULT chain family (chunk-parallel scan chains) on the same rows and the same prepared parameters
+(set_raw with the fixture's pi / T / emission table: the parameters the reference ran on).  Tolerances are those of the 2 Mbp
+goldens (tests/test_gpu_parity.py): log-likelihood 1e-6 relative, statistics and Q 5e-6.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+
+LL_TOL = 1e-6
+STAT_TOL = 5e-6
+
+
+def _g16(name):
+    z = np.load(os.path.join(GOLDEN, f"G16_fullsize_{name}.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def _check_stats(im, c, g, xisum, gs, gs_have, gamma0):
+    xs = im.xisums[c]
+    assert rel_err(xs, xisum) <= STAT_TOL, rel_err(xs, xisum)
+    got = im.gamma_sums[c]
+    keys = [tuple(int(x) for x in k) for k in g["keys"]]
+    assert sorted(got.keys()) == sorted(k for k, h in zip(keys, gs_have) if h)
+    for k, v, h in zip(keys, gs, gs_have):
+        if h:
+            assert np.max(np.abs(got[k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300), k
+    assert rel_err(im.gammas[c][:, 0], gamma0) <= STAT_TOL
+
+
+def _onepop(params, contigs, n):
+    from smcpp_amd import _smcpp
+    p = np.load(os.path.join(GOLDEN, params))
+    im = _smcpp.PyOnePopInferenceManager(n, contigs, p["hs"], ("pop1",), float(p["pol"]))
+    im.theta = float(p["theta"]); im.rho = float(p["rho"]); im.alpha = float(p["alpha"])
+    im.set_raw(p["pi"], p["T"], p["keys"], p["E"])
+    return im
+
+
+@pytest.mark.parametrize("name,params,n", [("headline", "params_M64_n20.npz", 20), ("c2", "params_M32_n10.npz", 10)])
+def test_full_100mbp_contig_vs_compiled_reference(name, params, n):
+    from smcpp_amd import synth
+    g = _g16(name)
+    obs = synth.synth_contig(0, 100_000_000, n)
+    assert len(obs) == int(g["rows"][0]) and synth.contig_crc(obs) == int(g["crc"][0])
+    im = _onepop(params, [obs], n)
+    im.E_step()
+    assert im.chain_mode() == 5
+    ll = im.loglik()
+    print(name, "loglik", ll, "reference", float(g["loglik"][0]), "rel", abs(ll - g["loglik"][0]) / abs(g["loglik"][0]))
+    assert abs(ll - float(g["loglik"][0])) <= LL_TOL * abs(float(g["loglik"][0]))
+    _check_stats(im, 0, g, g["xisum"], g["gs"], g["gs_have"], g["gamma0"])
+    q = np.array(im.Q(separate=True))
+    assert np.all(np.abs(q - g["q"][0]) <= STAT_TOL * np.abs(g["q"][0])), (q, g["q"][0])
+
+
+def test_headline_weak_scaling_contigs_vs_compiled_reference():
+    """Contig r is what rank r of `bench.py --gpus 8` owns: eight 100 Mbp contigs in one manager, per-contig log-likelihoods
+    against the reference's, Q against the sum of the reference's per-contig Q (inference_manager.cpp:116-126)."""
+    from smcpp_amd import synth
+    g = _g16("headline")
+    contigs = [synth.synth_contig(i, 100_000_000, 20) for i in range(8)]
+    for i, c in enumerate(contigs):
+        assert synth.contig_crc(c) == int(g["crc"][i])
+    im = _onepop("params_M64_n20.npz", contigs, 20)
+    im.E_step()
+    lls = np.array(im.logliks())
+    assert np.all(np.abs(lls - g["loglik"]) <= LL_TOL * np.abs(g["loglik"])), np.abs(lls - g["loglik"]) / np.abs(g["loglik"])
+    q = np.array(im.Q(separate=True))
+    qr = g["q"].sum(axis=0)
+    assert np.all(np.abs(q - qr) <= STAT_TOL * np.abs(qr)), (q, qr)
+
+
+def test_whole_genome_22_contigs_vs_compiled_reference():
+    from smcpp_amd import synth
+    g = _g16("c3")
+    contigs = [synth.synth_contig(i, int(synth.C3_LENGTHS_MBP[i] * 1e6), 20) for i in range(22)]
+    assert [len(c) for c in contigs] == [int(x) for x in g["rows"]]
+    im = _onepop("params_M64_n20.npz", contigs, 20)
+    im.E_step()
+    lls = np.array(im.logliks())
+    rel = np.abs(lls - g["loglik"]) / np.abs(g["loglik"])
+    print("c3 per-contig loglik: max rel", rel.max())
+    assert rel.max() <= LL_TOL
+    xs = np.sum(im.xisums, axis=0)
+    assert rel_err(xs, g["xisum_total"]) <= STAT_TOL
+    for c in range(22):
+        assert abs(np.trace(im.xisums[c]) - g["xisum_trace"][c]) <= STAT_TOL * abs(g["xisum_trace"][c])
+    keys = [tuple(int(x) for x in k) for k in g["keys"]]
+    tot = np.zeros_like(g["gs_total"])
+    for gsc in im.gamma_sums:
+        for i, k in enumerate(keys):
+            if k in gsc:
+                tot[i] += gsc[k]
+    for i in range(len(keys)):
+        assert np.max(np.abs(tot[i] - g["gs_total"][i])) <= STAT_TOL * max(np.abs(g["gs_total"][i]).max(), 1e-300)
+    q = np.array(im.Q(separate=True))
+    qr = g["q"].sum(axis=0)
+    assert np.all(np.abs(q - qr) <= STAT_TOL * np.abs(qr)), (q, qr)
+
+
+def test_c4_two_population_full_contig_vs_compiled_reference():
+    from smcpp_amd import _smcpp, synth
+    g = _g16("c4")
+    p = np.load(os.path.join(GOLDEN, "G13_c4_params.npz"))
+    obs = synth.synth_contig_twopop(0, 100_000_000, 10, 10)
+    assert synth.contig_crc(obs) == int(g["crc"][0])
+    im = _smcpp.PyTwoPopInferenceManager(10, 10, 2, 0, [obs], p["hs"], ("pop1", "pop2"), float(p["pol"]))
+    im.theta = float(p["theta"]); im.rho = float(p["rho"]); im.alpha = float(p["alpha"])
+    im.set_raw(p["pi"], p["T"], p["keys"], p["E"])
+    im.E_step()
+    ll = im.loglik()
+    assert abs(ll - float(g["loglik"][0])) <= LL_TOL * abs(float(g["loglik"][0])), (ll, float(g["loglik"][0]))
+    _check_stats(im, 0, g, g["xisum"], g["gs"], g["gs_have"], g["gamma0"])
+    q = np.array(im.Q(separate=True))
+    assert np.all(np.abs(q - g["q"][0]) <= STAT_TOL * np.abs(g["q"][0])), (q, g["q"][0])
+
+
+def test_c5_25000_rows_vs_compiled_reference():
+    from smcpp_amd import synth
+    g = _g16("c5")
+    obs = np.ascontiguousarray(synth.synth_contig(0, 100_000_000, 50)[:int(g["rows"][0])])
+    assert synth.contig_crc(obs) == int(g["crc"][0])
+    im = _onepop("params_M256_n50.npz", [obs], 50)
+    im.E_step()
+    assert im.chain_mode() == 5
+    ll = im.loglik()
+    assert abs(ll - float(g["loglik"][0])) <= LL_TOL * abs(float(g["loglik"][0])), (ll, float(g["loglik"][0]))
+    _check_stats(im, 0, g, g["xisum"], g["gs"], g["gs_have"], g["gamma0"])
+    q = np.array(im.Q(separate=True))
+    assert np.all(np.abs(q - g["q"][0]) <= STAT_TOL * np.abs(g["q"][0])), (q, g["q"][0])

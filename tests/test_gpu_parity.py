@@ -521,9 +521,13 @@ def test_many_tiny_contigs():
     assert np.isfinite(im.loglik())
 
 
-def test_warm_start_matches_cold_start():
+@pytest.mark.parametrize("rows_per_chunk", [300, 800, 1200])
+def test_warm_start_matches_cold_start(rows_per_chunk):
     """Opt-in extension: an E-step that starts its chunk-parallel chains from the previous E-step's boundary vectors
-    must give what a cold manager gives on the same (perturbed) parameters, in fewer / shorter passes."""
+    must give what a cold manager gives on the same (perturbed) parameters, in fewer / shorter passes.
+    300 rows per chunk: several light passes; 800 (3 400 positions): one forward light pass cold, so the warm start's first
+    launched forward pass is the FULL pass; 1200 (5 100 positions): no forward light pass at all (a full pass
+    must never take the idle exit on the never-written flag of the pass before it)."""
     from smcpp_amd import _smcpp, synth
     from smcpp_amd.model import PiecewiseModel
     g = load_golden("G4_M64_n20_2Mbp")
@@ -533,7 +537,7 @@ def test_warm_start_matches_cold_start():
     def manager(warm):
         im = _smcpp.PyOnePopInferenceManager(20, [obs], g["hs"], ("pop1",), float(g["pol"]))
         im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = float(g["alpha"])
-        im.set_chunking(300)                       # many chunks so that the iteration matters at this size
+        im.set_chunking(rows_per_chunk)            # many chunks so that the iteration matters at this size
         if warm:
             im.set_warm_start(True)
         return im
@@ -555,7 +559,8 @@ def test_warm_start_matches_cold_start():
         for k, v in gc.items():
             assert np.max(np.abs(gw[k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300)
         tw, tc = warm.last_timing(), cold.last_timing()
-        assert tw["fwd_passes"] <= tc["fwd_passes"] and tw["bwd_passes"] <= tc["bwd_passes"]
+        if rows_per_chunk == 300:
+            assert tw["fwd_passes"] <= tc["fwd_passes"] and tw["bwd_passes"] <= tc["bwd_passes"]
     # a JUMP in parameter space: the stale boundary vectors are then no better than pi, the iteration has to absorb it
     a2 = a0[::-1] * 2.5
     mw[:] = a2; mc[:] = a2

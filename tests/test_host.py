@@ -158,7 +158,11 @@ def test_scan_chain_chunks_never_exceed_the_wavefront_slots():
     # the floor: a small input gets few, long chunks
     small = np.array([5000, 3000], dtype=np.int64)
     n = E.host_chunk_counts(small, np.array([1200, 700], dtype=np.int32), 512, 1024)
-    assert n.tolist() == [4, 3] or n.sum() <= 8
+    assert n.tolist() == [4, 2]                                         # 1250 / 1500 positions per chunk: none below the floor
+    for tot in (1500, 9000, 40_000, 700_000):
+        c2 = np.array([tot, tot // 3 + 1100], dtype=np.int64)
+        n = E.host_chunk_counts(c2, np.array([tot // 4, tot // 12 + 300], dtype=np.int32), 512, 1024)
+        assert np.all(c2 // n >= 1024) or np.all(n[c2 // n < 1024] == 1)
     # more contigs than slots: one chunk each
     many = np.full(40, 10_000, dtype=np.int64)
     n = E.host_chunk_counts(many, np.full(40, 2000, dtype=np.int32), 16, 1024)

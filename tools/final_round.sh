@@ -13,5 +13,5 @@ cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_c5 -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload c5 --steps 5 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_c3 -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload c3 --steps 5 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_posterior -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload posterior --steps 5 > /dev/null 2>&1
-$GRAFT_REPO_ROOT/tools/dpp_lab > $GRAFT_REPO_ROOT/$O/dpp_lab.log 2>&1
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $GRAFT_REPO_ROOT/tools/dpp_lab.hip -o /tmp/dpp_lab && /tmp/dpp_lab > $GRAFT_REPO_ROOT/$O/dpp_lab.log 2>&1
 tail -1 $GRAFT_REPO_ROOT/$O/bench_default.log | cut -c1-300

@@ -46,6 +46,10 @@ WORKLOADS = {
     "c3": (64, 20, "params_M64_n20.npz", "22 synthetic contigs, 2872 Mbp in total, M=64, n=20, LPT-sharded over the GPUs (configs[2])"),
     # two populations, both distinguished lineages in population 1, split 0.5
     "c4": (48, 10, None, "1 synthetic two-population 100 Mbp contig per GPU, M=48, n1=n2=10, a=(2,0), split=0.5 (configs[3])"),
+    # the M-step's objective: Q with its forward-mode gradient along 16 directions on the headline manager's
+    # statistics; one step = set_params(a, da) -> Q(val, jac)  (what L-BFGS-B calls tens to hundreds of times per E-step)
+    "qgrad": (64, 20, "params_M64_n20.npz", "Q with 16 derivative directions (HMM::Q on adouble, src/hmm.cpp:155-193) after one E-step on "
+              "1 synthetic 100 Mbp contig, M=64, n=20"),
     # posterior decoding: un-binned rows, long spans, small rho, save_gamma
     "posterior": (32, 8, None, "posterior decode: 1 un-binned contig, 1e6 rows, spans to 1e5, rho=6e-5, M=32, n=8, save_gamma"),
 }
@@ -237,6 +241,9 @@ def main():
         im.save_gamma = True
     if args.chunk or args.eps_alpha or args.eps_beta:
         im.set_chunking(args.chunk, args.eps_alpha, args.eps_beta)
+
+    if args.workload == "qgrad":
+        return bench_qgrad(args, im, model, a, s_, M, n, desc, host_threads, world, rank, torch)
 
     def one_eval():
         top.model = model            # setParams: parameters dirty, A6-A10 + eigensystems + uploads are all redone
@@ -494,6 +501,62 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_qgrad(args, im, model, a, s_, M, n, desc, host_threads, world, rank, torch):
+    """`--workload qgrad`: evals/s of Q-with-gradient (16 directions, one per model piece) on the statistics of one E-step.
+    value = the default route (conditioned SFS + emission table + Q reduction on the device, O(M) host part); the same call
+    with the whole preparation on the host threads (rounds 1-3: smcpp_set_prep_mode(1)) is timed beside it."""
+    from smcpp_amd import _engine as E
+    if world != 1:
+        raise SystemExit("--workload qgrad is a single-GPU measurement")
+    im.model = model
+    im.E_step()
+    K = len(a)
+    aa = np.ascontiguousarray(a, dtype=np.float64); ss = np.ascontiguousarray(s_, dtype=np.float64)
+    da = np.ascontiguousarray(np.eye(K))
+    val = np.zeros(4); jac = np.zeros((4, K))
+    rng = np.random.default_rng(5)
+
+    def one(i):
+        # an optimiser never evaluates the same point twice: a fresh +-1 % perturbation per call
+        ai = np.ascontiguousarray(aa * np.exp(0.01 * rng.standard_normal(K)))
+        E.check(E.lib().smcpp_set_params(im._im, K, E.dptr(ai), E.dptr(da), K, E.dptr(ss)))
+        E.check(E.lib().smcpp_q(im._im, E.dptr(val), E.dptr(jac)))
+        return val.copy(), jac.copy()
+
+    def timed(steps, warmup):
+        for i in range(warmup):
+            one(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    steps = max(args.steps, 40)
+    dev_s = timed(steps, args.warmup)
+    rng = np.random.default_rng(5)
+    v_dev, j_dev = one(0)
+    im.set_prep_mode(True)
+    host_s = timed(max(10, steps // 4), 2)
+    rng = np.random.default_rng(5)
+    v_host, j_host = one(0)
+    im.set_prep_mode(False)
+    sc = np.abs(j_host).max(axis=1)
+    out = {"metric": f"Q-with-gradient evals/sec ({desc})", "value": 1.0 / dev_s, "unit": "evals/s", "n_gpus": 1, "steps": steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * dev_s, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": desc, "eval": "set_params(a, da [16 x 16]) -> Q(val [4], jac [4 x 16])", "M": M, "n": n, "nder": K,
+                      "host_threads": host_threads},
+           "host_path": {"ms_per_step": 1e3 * host_s, "evals_per_s": 1.0 / host_s, "threads": host_threads,
+                         "note": "the same call with the conditioned SFS, emission table, dense transition Jacobian and the Q sums on the "
+                                 "host (smcpp_set_prep_mode(1): the route of rounds 1-3)"},
+           "speedup_vs_host_path": host_s / dev_s,
+           "parity": {"val_rel_diff_max": float(np.max(np.abs(v_dev - v_host) / np.abs(v_host))),
+                      "jac_rel_diff_max_per_term": [float(x) for x in np.max(np.abs(j_dev - j_host), axis=1) / sc]}}
+    print(json.dumps(out), flush=True)
 
 
 def sq_counters(workload, kname):

@@ -222,6 +222,14 @@ int smcpp_dev_prep_onepop(int n, int n_hs, const double *hs, double polarization
                           const int *keys, int mode, double *pi, double *T, double *E, double *dpi, double *dT, double *dE,
                           double *sfs, double *dsfs);
 
+/* Test hook (no device needed): Q's four terms (src/hmm.cpp:155-193) and their gradient jac [4 x nder] for statistics summed
+ * over contigs - g0 [M], xi [M x M], gs [K x M] - computed by the phases of the device kernel (prep_dev.hpp: k_q_reduce) run
+ * serially on the host, from the emulated device preparation and the O(M) generator planes of the transition matrix: the data
+ * path smcpp_q takes on the GPU for one-population managers. */
+int smcpp_dev_q_emulate(int n, int n_hs, const double *hs, double polarization_error, int Kp, const double *a, const double *da,
+                        int nder, const double *s, double theta, double rho, double alpha, int K, const int *keys,
+                        const double *g0, const double *xi, const double *gs, double *val, double *jac);
+
 /* PyRateFunction.R / average_coal_times (smcpp/_smcpp.pyx:370-389): cumulative hazard R at t[0..nt) for the model
  * pieces (a, s) and, when n_hs >= 2, E[T | hs_i <= T < hs_{i+1}] for the n_hs-1 intervals. */
 int smcpp_host_rate_function(int Kp, const double *a, const double *s, int n_hs, const double *hs, int nt,

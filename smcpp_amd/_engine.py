@@ -75,6 +75,7 @@ def lib():
         "smcpp_host_prep_onepop_jac": (i, [i, i, _dp, d, i, _dp, _dp, i, _dp, d, d, d, i, _ip, _dp, _dp, _dp, _dp,
                                            _dp, _dp]),
         "smcpp_dev_prep_onepop": (i, [i, i, _dp, d, i, _dp, _dp, i, _dp, d, d, d, i, _ip, i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+        "smcpp_dev_q_emulate": (i, [i, i, _dp, d, i, _dp, _dp, i, _dp, d, d, d, i, _ip, _dp, _dp, _dp, _dp, _dp]),
         "smcpp_host_rate_function": (i, [i, _dp, _dp, i, _dp, i, _dp, _dp, _dp]),
         "smcpp_host_rate_function_jac": (i, [i, _dp, _dp, i, _dp, i, _dp, i, _dp, _dp, _dp, _dp, _dp]),
         "smcpp_host_random_coal_times": (i, [i, _dp, _dp, d, d, i, ullp, _dp, _dp]),
@@ -109,7 +110,7 @@ EXPORTS = [
     "smcpp_host_set_csfs_direct", "smcpp_gamma_cols", "smcpp_last_host_timing", "smcpp_get_pi_jac",
     "smcpp_get_transition_jac", "smcpp_get_emission_probs_jac", "smcpp_num_emission_cols", "smcpp_get_emission",
     "smcpp_init_logger_cb", "smcpp_init_cache", "smcpp_debug_ss_apply", "smcpp_debug_ss4_apply", "smcpp_set_debug", "smcpp_get_debug", "smcpp_device",
-    "smcpp_dev_prep_onepop", "smcpp_set_prep_mode",
+    "smcpp_dev_prep_onepop", "smcpp_set_prep_mode", "smcpp_dev_q_emulate",
 ]
 
 
@@ -216,6 +217,21 @@ def dev_prep_onepop(n, hs, polarization_error, a, s, theta, rho, alpha, keys, da
                                       dptr(out.get("dpi")), dptr(out.get("dT")), dptr(out.get("dE")), dptr(out["sfs"]),
                                       dptr(out.get("dsfs"))))
     return out
+
+
+def dev_q_emulate(n, hs, polarization_error, a, da, s, theta, rho, alpha, keys, g0, xi, gs):
+    """Q's four terms and their gradient by the device kernel's phases run on the host (see the header)."""
+    hs = np.ascontiguousarray(hs, dtype=np.float64); a = np.ascontiguousarray(a, dtype=np.float64)
+    da = np.ascontiguousarray(da, dtype=np.float64); s = np.ascontiguousarray(s, dtype=np.float64)
+    keys = np.ascontiguousarray(keys, dtype=np.int32)
+    g0 = np.ascontiguousarray(g0, dtype=np.float64); xi = np.ascontiguousarray(xi, dtype=np.float64)
+    gs = np.ascontiguousarray(gs, dtype=np.float64)
+    nder = da.shape[1]
+    val = np.zeros(4); jac = np.zeros((4, nder))
+    check(lib().smcpp_dev_q_emulate(int(n), len(hs), dptr(hs), float(polarization_error), len(a), dptr(a), dptr(da), nder, dptr(s),
+                                    float(theta), float(rho), float(alpha), len(keys), iptr(keys), dptr(g0), dptr(xi), dptr(gs),
+                                    dptr(val), dptr(jac)))
+    return val, jac
 
 
 def host_rate_function(a, s, t, hs=None):

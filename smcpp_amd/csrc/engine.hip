@@ -463,6 +463,25 @@ struct smcpp_im {
     bool E_on_dev = false, force_host_prep = false;
     void dev_prepare();
     void sync_host_E();
+    // Q and its gradient on the device (prep_dev.hpp: k_q_reduce): the O(M) generators of the transition matrix with their
+    // derivative planes (host, prep.hpp: transition_generators_jac; dT is expanded on the host only when its getter asks)
+    smcpp_host::TransitionGenJac tgen;
+    bool tgen_valid = false, dT_valid = true;
+    struct QDev {
+        DevBuf<double> d_stats, d_out;
+        DevBuf<int> d_keynb;
+        PinnedArena stage;
+        char *d_in = nullptr;
+        size_t in_cap = 0;
+        double *h_out = nullptr;
+        size_t h_out_cap = 0;
+        bool stats_ready = false;
+        int Kq = 0;
+        ~QDev() { if (d_in) (void)hipFree(d_in); if (h_out) (void)hipHostFree(h_out); }
+    };
+    std::unique_ptr<QDev> qdev;
+    bool q_device(double val[4], double *jac);
+    void ensure_dT();
     bool ss_static = false;                // the input qualifies (short spans); whether T does is decided on every E-step
     // hybrid scan chains (un-binned data): rows whose span exceeds ss_hyb_th take ONE eigen-power step inside the scan kernel
     // (chains_ss.hpp); they cost about SS_HYB_COST scan positions each, which is what the chunk list is balanced on
@@ -1363,6 +1382,7 @@ void smcpp_im::prepare_params() {
         if (!twopop_prep) twopop_prep.reset(new smcpp_host::TwoPopPrep(n[0], n[1], na[0], na[1], hs, polarization_error));
         smcpp_host::TwoPopPrep &prep = *twopop_prep;
         E_on_dev = false;
+        tgen_valid = false; dT_valid = true;
         if (nder > 0) {
             smcpp_host::DualScope sc(nder);
             std::vector<smcpp_host::dual> pd, Td, Ed, emd;
@@ -1393,6 +1413,7 @@ void smcpp_im::prepare_params() {
         if (!host_only && !force_host_prep && DevPrep::supported(n[0]) && !smcpp_host::csfs_direct_flag()) { dev_prepare(); return; }
     }
     E_on_dev = false;
+    tgen_valid = false; dT_valid = true;
     // with a global key dictionary (multi-GPU) the emission table is prepared for every global key; the local table
     // is the sub-list of the keys this rank's contigs hold
     const std::vector<int> &pk = have_global ? gkeys : keys;
@@ -1413,6 +1434,26 @@ void smcpp_im::prepare_params() {
         Eg.swap(Ep); dEg.swap(dEp);
     }
     params_fresh = true;
+}
+
+// Transition matrix of a model with derivative seeds: values by the double routines on the VALUES of the dual rate function,
+// derivative planes of the O(M) generators by the chain rule over plain arrays (prep.hpp: transition_generators_jac).  Returns
+// false when a row needs the pairwise fallback (the caller then takes the generic duals through the whole matrix).
+static bool host_transition_with_planes(const smcpp_host::RateFunctionT<smcpp_host::dual> &eta, const std::vector<smcpp_host::dual> &act,
+                                        double rho, int nder, std::vector<double> &T, smcpp_host::TransitionGenJac &tj) {
+    smcpp_host::RateFunctionT<double> ev;
+    ev.hidden_states = eta.hidden_states; ev.ts = eta.ts; ev.hs_indices = eta.hs_indices; ev.K = eta.K;
+    ev.ada.resize(eta.ada.size()); ev.Rrng.resize(eta.Rrng.size());
+    const int K = eta.K, M = (int)eta.hidden_states.size() - 1;
+    std::vector<double> dada((size_t)K * nder), avg(M), davg((size_t)M * nder);
+    for (int k = 0; k < K; ++k) { ev.ada[k] = eta.ada[k].v; for (int d = 0; d < nder; ++d) dada[(size_t)k * nder + d] = eta.ada[k].d[d]; }
+    for (size_t k = 0; k < eta.Rrng.size(); ++k) ev.Rrng[k] = eta.Rrng[k].v;
+    for (int m = 0; m < M; ++m) { avg[m] = act[m].v; for (int d = 0; d < nder; ++d) davg[(size_t)m * nder + d] = act[m].d[d]; }
+    const smcpp_host::TransitionGenerators<double> g = smcpp_host::transition_generators<double>(ev, rho, avg);
+    tj = smcpp_host::transition_generators_jac(ev, rho, avg, g, dada.data(), davg.data(), nder);
+    if (!tj.ok) return false;
+    T = smcpp_host::transition_expand<double>(g);
+    return true;
 }
 
 // One-population do_dirty_work with the O(states x n^2 x directions) part on the device: the host builds the rate function
@@ -1444,15 +1485,25 @@ void smcpp_im::dev_prepare() {
         std::vector<smcpp_host::dual> pd;
         smcpp_host::initial_distribution(eta, pd);
         split_duals(pd, nder, pi, dpi);
-        split_duals(smcpp_host::compute_transition<smcpp_host::dual>(eta, rho), nder, T, dT);
+        // transition matrix: values + the derivative planes of its O(M) generators; the M x M x nder Jacobian is expanded
+        // only when its getter asks (ensure_dT), Q's gradient reads the planes on the device
+        tgen_valid = host_transition_with_planes(eta, act, rho, nder, T, tgen);
+        dT.clear();
+        dT_valid = false;
+        if (!tgen_valid) { split_duals(smcpp_host::compute_transition<smcpp_host::dual>(eta, rho), nder, T, dT); dT_valid = true; }
     } else {
         smcpp_host::ModelParamsT<double> p;
         p.a = model.a; p.s = model.s;
         const smcpp_host::RateFunctionT<double> eta(p, hs);
-        dprep->run(eta, eta.average_coal_times(), theta, alpha, 0, stream);
+        const std::vector<double> act = eta.average_coal_times();
+        dprep->run(eta, act, theta, alpha, 0, stream);
         smcpp_host::initial_distribution(eta, pi);
-        T = smcpp_host::compute_transition<double>(eta, rho);
+        const smcpp_host::TransitionGenerators<double> g = smcpp_host::transition_generators<double>(eta, rho, act);
+        T = smcpp_host::transition_expand<double>(g);
+        tgen = smcpp_host::transition_generators_jac(eta, rho, act, g, nullptr, nullptr, 0);
+        tgen_valid = tgen.ok;
         dpi.clear(); dT.clear();
+        dT_valid = true;
     }
     E_on_dev = true;
     Eg.clear(); dEg.clear();
@@ -1479,6 +1530,102 @@ void smcpp_im::sync_host_E() {
         Eg.swap(Ep); dEg.swap(dEp);
     }
     E_on_dev = false;
+}
+
+void smcpp_im::ensure_dT() {
+    if (dT_valid) return;
+    smcpp_host::transition_expand_jac(tgen, dT);
+    dT_valid = true;
+}
+
+// HMM::Q (src/hmm.cpp:155-193) summed over contigs (inference_manager.cpp:116-126) and its forward-mode gradient, evaluated on
+// the device from the statistics that already live there, the device-prepared emission table (+ planes) and the generators of
+// the transition matrix.  Returns false when this call has to take the host route (no device preparation, a local / global
+// key-list mismatch, the pairwise fallback of the transition matrix).
+bool smcpp_im::q_device(double val[4], double *jac) {
+    static const bool off = getenv("SMCPP_Q") && !strcmp(getenv("SMCPP_Q"), "host");
+    if (off || !E_on_dev || !tgen_valid || have_raw || (have_global && !have_reduced)) return false;
+    if (have_reduced && (int)g_stats.size() != 1 + M + M * M + dprep->Kk * M) return false;
+    HIPCHK(hipSetDevice(device));
+    if (!qdev) qdev.reset(new QDev());
+    QDev &q = *qdev;
+    const int Kq = dprep->Kk, nd = nder;
+    const size_t nstat = (size_t)M + (size_t)M * M + (size_t)Kq * M;
+    if (!q.stats_ready || q.Kq != Kq) {
+        q.d_stats.alloc(nstat);
+        std::vector<int> knb(Kq);
+        const std::vector<int> &pk = have_global ? gkeys : keys;
+        for (int k = 0; k < Kq; ++k) { int nb = 0; for (int p = 0; p < npop; ++p) nb += pk[(size_t)k * keylen + 3 * p + 2]; knb[k] = nb > 0; }
+        q.d_keynb.alloc(Kq);
+        HIPCHK(hipMemcpyAsync(q.d_keynb.p, knb.data(), sizeof(int) * Kq, hipMemcpyHostToDevice, stream));
+        if (have_reduced) HIPCHK(hipMemcpyAsync(q.d_stats.p, g_stats.data() + 1, sizeof(double) * nstat, hipMemcpyHostToDevice, stream));
+        else if (!estep_done) {
+            fetch_stats();                                   // the statistics of a freshly constructed HMM (host)
+            std::vector<double> st(nstat, 0.0);
+            for (int c = 0; c < n_contigs; ++c) {
+                for (int i = 0; i < M; ++i) st[i] += h_gamma0[(size_t)c * M + i];
+                for (size_t e = 0; e < (size_t)M * M; ++e) st[M + e] += h_xisum[(size_t)c * M * M + e];
+                for (size_t e = 0; e < (size_t)K * M; ++e) st[M + (size_t)M * M + e] += h_gsum[(size_t)c * K * M + e];
+            }
+            HIPCHK(hipMemcpyAsync(q.d_stats.p, st.data(), sizeof(double) * nstat, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));            // (st is pageable and local)
+        } else
+            hipLaunchKernelGGL(smcpp_dev::k_q_stats, dim3(ceil_div((long long)nstat, 256)), dim3(256), 0, stream, n_contigs, M, Mp, K,
+                               (const double *)d_gamma0.p, (const double *)d_xisum.p, (const double *)d_gsum.p, q.d_stats.p);
+        HIPCHK(hipStreamSynchronize(stream));                // (knb is local)
+        q.stats_ready = true;
+        q.Kq = Kq;
+    }
+    // ---- per call: pi and the generators with their planes, one pinned block: values [4][M], planes [4][nder][M] ----
+    const size_t ndbl = (size_t)4 * M * (1 + nd);
+    q.stage.reset(ndbl * sizeof(double) + 256);
+    if (ndbl * sizeof(double) > q.in_cap) {
+        if (q.d_in) (void)hipFree(q.d_in);
+        q.in_cap = ndbl * sizeof(double) * 2;
+        HIPCHK(hipMalloc((void **)&q.d_in, q.in_cap));
+    }
+    double *hb = reinterpret_cast<double *>(q.stage.base);
+    for (int i = 0; i < M; ++i) {
+        hb[i] = pi[i]; hb[M + i] = i < M - 1 ? tgen.ed[i] : 0.0; hb[2 * M + i] = tgen.pf[i]; hb[3 * M + i] = tgen.W[i];
+    }
+    double *pl = hb + (size_t)4 * M;
+    const size_t ps = (size_t)nd * M;                    // one array's planes
+    for (int d = 0; d < nd; ++d)
+        for (int i = 0; i < M; ++i) {
+            pl[(size_t)d * M + i] = dpi[(size_t)i * nd + d];
+            pl[ps + (size_t)d * M + i] = i < M - 1 ? tgen.ded[(size_t)i * nd + d] : 0.0;
+            pl[2 * ps + (size_t)d * M + i] = tgen.dpf[(size_t)i * nd + d];
+            pl[3 * ps + (size_t)d * M + i] = tgen.dW[(size_t)i * nd + d];
+        }
+    HIPCHK(hipMemcpyAsync(q.d_in, hb, ndbl * sizeof(double), hipMemcpyHostToDevice, stream));
+    const size_t nout = (size_t)4 * (1 + nd);
+    q.d_out.alloc(nout);
+    if (nout > q.h_out_cap) {
+        if (q.h_out) (void)hipHostFree(q.h_out);
+        q.h_out_cap = nout * 2;
+        HIPCHK(hipHostMalloc((void **)&q.h_out, q.h_out_cap * sizeof(double), hipHostMallocDefault));
+    }
+    const double *bd = reinterpret_cast<const double *>(q.d_in);
+    const double *bp = bd + (size_t)4 * M;
+    smcpp_dev::QArgs a;
+    a.M = M; a.Kq = Kq; a.nder = nd;
+    a.g0 = q.d_stats.p; a.xi = q.d_stats.p + M; a.gs = q.d_stats.p + M + (size_t)M * M;
+    a.key_nb = q.d_keynb.p;
+    a.pi_v = bd; a.ed_v = bd + M; a.pf_v = bd + 2 * M; a.W_v = bd + 3 * M;
+    a.pi_d = bp; a.ed_d = bp + ps; a.pf_d = bp + 2 * ps; a.W_d = bp + 3 * ps;
+    a.mix_p2 = 1e-5 / (double)(M + 1);
+    a.E_v = dprep->d_Eg_v.p; a.E_d = dprep->d_Eg_d.p;
+    a.out = q.d_out.p;
+    const int nt = 1024;
+    const size_t lds = (size_t)(2 * M + 4 * (nt / 64) * 2) * sizeof(double);
+    hipLaunchKernelGGL(smcpp_dev::k_q_reduce, dim3(1 + nd), dim3(nt), lds, stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(q.h_out, q.d_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    dprep->check_flags();
+    for (int t = 0; t < 4; ++t) val[t] = q.h_out[t];
+    if (jac) for (int t = 0; t < 4; ++t) for (int d = 0; d < nd; ++d) jac[(size_t)t * nd + d] = q.h_out[(size_t)4 * (1 + d) + t];
+    return true;
 }
 
 // Emission vectors of the global keys for the reduced Q when the parameters did not come from prepare_params
@@ -3016,6 +3163,7 @@ void smcpp_im::estep() {
             (double)chains_ms, last_fwd_passes, last_bwd_passes, (double)(s_ms + fin_ms), loglik.empty() ? 0.0 : loglik[0]);
     stats_on_host = false;
     have_reduced = false;
+    if (qdev) qdev->stats_ready = false;
     gamma_valid = save_gamma;
     estep_done = true;
     dirty = false;
@@ -3183,6 +3331,7 @@ int smcpp_set_raw(smcpp_im *im, const double *pi, const double *T, int K, const 
     im->raw_E.assign(E, E + (size_t)K * M);
     im->have_raw = true;
     im->E_on_dev = false;
+    im->tgen_valid = false; im->dT_valid = true;
     im->dirty = true;
     im->nder = 0;
     API_END
@@ -3220,7 +3369,9 @@ int smcpp_q(smcpp_im *im, double val[4], double *jac) {
     API_BEGIN
     const int M = im->M, K = im->K;
     if (!im->have_raw) im->prepare_params();   // Q() does do_dirty_work() first (inference_manager.cpp:119)
+    if (im->q_device(val, jac)) return 0;
     im->sync_host_E();
+    im->ensure_dT();
     if ((int)im->pi.size() != M) throw std::runtime_error("parameters are not set");
     const int nder = im->have_raw ? 0 : im->nder;
     if (jac) for (int i = 0; i < 4 * nder; ++i) jac[i] = 0.0;
@@ -3431,6 +3582,7 @@ int smcpp_get_pi_jac(smcpp_im *im, double *out) {
 int smcpp_get_transition_jac(smcpp_im *im, double *out) {
     API_BEGIN
     need_model_params(im);
+    im->ensure_dT();
     if (im->nder > 0) std::memcpy(out, im->dT.data(), sizeof(double) * im->dT.size());
     API_END
 }
@@ -3479,6 +3631,7 @@ int smcpp_set_global_keys(smcpp_im *im, int Kg, const int *gkeys) {
     im->have_global = true;
     im->pack_tables_ready = false;
     if (im->dprep) im->dprep->keys_ready = false;
+    if (im->qdev) im->qdev->stats_ready = false;
     im->E_on_dev = false;
     im->params_fresh = false;              // the emission table is now prepared over the global key list
     im->Eg.clear(); im->dEg.clear();
@@ -3546,6 +3699,7 @@ int smcpp_unpack_stats(smcpp_im *im, const double *buf, long n, int dev) {
         HIPCHK(hipMemcpy(im->g_stats.data(), buf, sizeof(double) * n, hipMemcpyDeviceToHost));
     } else std::memcpy(im->g_stats.data(), buf, sizeof(double) * n);
     im->have_reduced = true;
+    if (im->qdev) im->qdev->stats_ready = false;
     API_END
 }
 
@@ -3860,10 +4014,18 @@ int smcpp_dev_prep_onepop(int n, int n_hs, const double *hs, double polarization
         smcpp_host::RateFunctionT<smcpp_host::dual> eta(p, hsv);
         std::vector<smcpp_host::dual> pd;
         smcpp_host::initial_distribution(eta, pd);
-        dp.run(eta, eta.average_coal_times(), theta, alpha, nder, nullptr);
-        const std::vector<smcpp_host::dual> Td = smcpp_host::compute_transition<smcpp_host::dual>(eta, rho);
+        const std::vector<smcpp_host::dual> act = eta.average_coal_times();
+        dp.run(eta, act, theta, alpha, nder, nullptr);
         for (int i = 0; i < M; ++i) { pi[i] = pd[i].v; for (int d = 0; d < nder; ++d) dpi[(size_t)i * nder + d] = pd[i].d[d]; }
-        for (size_t i = 0; i < (size_t)M * M; ++i) { T[i] = Td[i].v; for (int d = 0; d < nder; ++d) dT[i * nder + d] = Td[i].d[d]; }
+        // the transition matrix as the engine forms it: values from the double routine, derivative planes of the O(M) generators by
+        // the chain rule (transition_generators_jac), expanded to dT
+        std::vector<double> Tv, dTv;
+        smcpp_host::TransitionGenJac tj;
+        if (!host_transition_with_planes(eta, act, rho, nder, Tv, tj))
+            split_duals(smcpp_host::compute_transition<smcpp_host::dual>(eta, rho), nder, Tv, dTv);
+        else smcpp_host::transition_expand_jac(tj, dTv);
+        std::memcpy(T, Tv.data(), sizeof(double) * Tv.size());
+        std::memcpy(dT, dTv.data(), sizeof(double) * dTv.size());
     } else {
         nder = 0;
         smcpp_host::ModelParamsT<double> p;
@@ -3883,6 +4045,59 @@ int smcpp_dev_prep_onepop(int n, int n_hs, const double *hs, double polarization
     if (nder && dE) std::memcpy(dE, dEv.data(), sizeof(double) * dEv.size());
     if (sfs) std::memcpy(sfs, sf.data(), sizeof(double) * sf.size());
     if (nder && dsfs) std::memcpy(dsfs, dsf.data(), sizeof(double) * dsf.size());
+    API_END
+}
+
+// Test hook: Q's four terms and their gradient [4 x nder] for given summed statistics g0 [M], xi [M x M], gs [K x M], evaluated
+// by the phases of the device kernel k_q_reduce run serially on the host (prep_dev.hpp: emulate_q) from the emulated device
+// preparation and the generator planes of the transition matrix - the data path smcpp_q takes on the GPU.
+int smcpp_dev_q_emulate(int n, int n_hs, const double *hs, double polarization_error, int Kp, const double *a, const double *da,
+                        int nder, const double *s, double theta, double rho, double alpha, int K, const int *keys,
+                        const double *g0, const double *xi, const double *gs, double *val, double *jac) {
+    API_BEGIN
+    if (!DevPrep::supported(n)) throw std::runtime_error("device preparation does not support this sample size");
+    const std::vector<double> hsv(hs, hs + n_hs);
+    const int M = n_hs - 1;
+    smcpp_host::OnePopPrep hp(n, hsv, polarization_error);
+    DevPrep dp;
+    dp.emulate = true;
+    dp.set_static(hp.tables());
+    const std::vector<int> kv(keys, keys + (size_t)3 * K);
+    dp.set_keys(hp, kv, K, {}, {}, {}, K, M, (M + 15) / 16 * 16, 0);
+    smcpp_host::DualScope sc(nder);
+    const auto p = dual_model(Kp, a, da, nder, s);
+    smcpp_host::RateFunctionT<smcpp_host::dual> eta(p, hsv);
+    std::vector<smcpp_host::dual> pd;
+    smcpp_host::initial_distribution(eta, pd);
+    const std::vector<smcpp_host::dual> act = eta.average_coal_times();
+    dp.run(eta, act, theta, alpha, nder, nullptr);
+    dp.check_flags();
+    std::vector<double> Tv;
+    smcpp_host::TransitionGenJac tj;
+    if (!host_transition_with_planes(eta, act, rho, nder, Tv, tj)) throw std::runtime_error("transition generators need the pairwise fallback");
+    std::vector<double> blk((size_t)4 * M * (1 + nder), 0.0), out((size_t)4 * (1 + nder), 0.0);
+    for (int i = 0; i < M; ++i) { blk[i] = pd[i].v; blk[M + i] = i < M - 1 ? tj.ed[i] : 0.0; blk[2 * M + i] = tj.pf[i]; blk[3 * M + i] = tj.W[i]; }
+    double *pl = blk.data() + (size_t)4 * M;
+    const size_t ps = (size_t)nder * M;
+    for (int d = 0; d < nder; ++d)
+        for (int i = 0; i < M; ++i) {
+            pl[(size_t)d * M + i] = pd[i].d[d];
+            pl[ps + (size_t)d * M + i] = i < M - 1 ? tj.ded[(size_t)i * nder + d] : 0.0;
+            pl[2 * ps + (size_t)d * M + i] = tj.dpf[(size_t)i * nder + d];
+            pl[3 * ps + (size_t)d * M + i] = tj.dW[(size_t)i * nder + d];
+        }
+    std::vector<int> knb(K);
+    for (int k = 0; k < K; ++k) knb[k] = keys[3 * k + 2] > 0;
+    smcpp_dev::QArgs q;
+    q.M = M; q.Kq = K; q.nder = nder;
+    q.g0 = g0; q.xi = xi; q.gs = gs; q.key_nb = knb.data();
+    q.pi_v = blk.data(); q.ed_v = blk.data() + M; q.pf_v = blk.data() + 2 * M; q.W_v = blk.data() + 3 * M;
+    q.pi_d = pl; q.ed_d = pl + ps; q.pf_d = pl + 2 * ps; q.W_d = pl + 3 * ps;
+    q.mix_p2 = 1e-5 / (double)(M + 1);
+    q.E_v = dp.e_Eg_v.data(); q.E_d = dp.e_Eg_d.data();
+    q.out = out.data();
+    smcpp_dev::emulate_q(q);
+    for (int t = 0; t < 4; ++t) { val[t] = out[t]; for (int d = 0; d < nder; ++d) jac[(size_t)t * nder + d] = out[(size_t)4 * (1 + d) + t]; }
     API_END
 }
 

@@ -372,6 +372,10 @@ struct Dual {
     Dual(F x) : v(x) { for (int i = 0; i < dual_nder(); ++i) d[i] = 0; }
     template <typename G>
     explicit Dual(const Dual<G> &o) : v((F)o.v) { for (int i = 0; i < dual_nder(); ++i) d[i] = (F)o.d[i]; }
+    // copies move the ACTIVE directions only (the implicit ones copy all MAXD slots: 520 bytes per number, a kilobyte in long
+    // double - most of the time of every dual routine with a handful of directions)
+    Dual(const Dual &o) : v(o.v) { for (int i = 0, n = dual_nder(); i < n; ++i) d[i] = o.d[i]; }
+    Dual &operator=(const Dual &o) { v = o.v; for (int i = 0, n = dual_nder(); i < n; ++i) d[i] = o.d[i]; return *this; }
 };
 #define SMCPP_DUAL_LOOP for (int i_ = 0, n_ = dual_nder(); i_ < n_; ++i_)
 template <typename F> inline Dual<F> operator+(const Dual<F> &a, const Dual<F> &b) { Dual<F> r; r.v = a.v + b.v; SMCPP_DUAL_LOOP r.d[i_] = a.d[i_] + b.d[i_]; return r; }
@@ -431,6 +435,7 @@ struct ModelParamsT {
 template <typename S>
 class RateFunctionT {
 public:
+    RateFunctionT() {}                               // (filled member by member: the value part of a dual rate function)
     RateFunctionT(const ModelParamsT<S> &p, const std::vector<double> &hs) : hidden_states(hs) {
         if (p.a.size() != p.s.size() || p.a.empty()) throw std::runtime_error("all params must have same size");
         K = (int)p.a.size();
@@ -675,8 +680,18 @@ template <> struct WideOf<dual> {
 };
 }  // namespace detail
 
+// Stage 1: everything that is O(pieces + states): the wide 3 x 3 chain, one partial exponential per state, the cumulative
+// hazards.  Stage 2 (transition_expand) fills the M x M matrix from these generators: below the diagonal T(i, c) = expm_diff[c]
+// (the column only), above it p_float[i] / Ek[i] * (Ek[c] * qk[c + 1]) (rank one), the diagonal closes the row; then the 1e-20
+// floor and the uniform mix.  (The scan chains of the engine work on exactly this structure, chains_ss.hpp.)
 template <typename S>
-inline std::vector<S> compute_transition(const RateFunctionT<S> &eta, double rho) {
+struct TransitionGenerators {
+    int Mh = 0;                                        // breakpoints (the reference's `this->M`), M = Mh - 1 states
+    std::vector<S> expm_diff, p_float, Ek, qk, inc_k;  // [M - 1], [Mh] (index j = 1 .. M), [Mh], [Mh], [Mh]
+};
+
+template <typename S>
+inline TransitionGenerators<S> transition_generators(const RateFunctionT<S> &eta, double rho, const std::vector<S> &avg) {
     using namespace detail;
     typedef typename WideOf<S>::type L;
     typedef WideOf<S> W;
@@ -685,8 +700,9 @@ inline std::vector<S> compute_transition(const RateFunctionT<S> &eta, double rho
     const std::vector<int> &hsi = eta.hs_indices;
     const int Mh = (int)eta.hidden_states.size();   // the reference's `this->M` (breakpoints)
     const int M = Mh - 1;
-    const std::vector<S> avg = eta.average_coal_times();
     const int nts = (int)ts.size();
+    TransitionGenerators<S> g;
+    g.Mh = Mh;
     std::vector<M3T<L>> expms(nts, m3_identity<L>()), prods(nts, m3_identity<L>());
     for (int i = hsi[0] + 1; i < nts; ++i) {
         if (!std::isinf(ts[i])) {
@@ -700,27 +716,25 @@ inline std::vector<S> compute_transition(const RateFunctionT<S> &eta, double rho
     std::vector<int> avc_ip(M);
     for (int j = 0; j < M; ++j)
         avc_ip[j] = (int)(std::upper_bound(ts.begin(), ts.end(), (double)sval(avg[j])) - ts.begin()) - 1;
-    std::vector<S> expm_diff(std::max(0, M - 1));
+    g.expm_diff.assign(std::max(0, M - 1), S(0.0));
     for (int k = 1; k < M; ++k)
-        expm_diff[k - 1] = W::down(prods[hsi[k]].m[0][2]) - W::down(prods[hsi[k - 1]].m[0][2]);
+        g.expm_diff[k - 1] = W::down(prods[hsi[k]].m[0][2]) - W::down(prods[hsi[k - 1]].m[0][2]);
     // Upper part: the reference evaluates, for every pair j < k, exp(-sum of the increments of the states between them) and
     // -expm1(-inc_k) (transition.cpp:217-233: M^2 / 2 pairs, two transcendental calls each - 0.1 ms at M = 64, serial).  Both
     // factor: with C_t = inc_1 + ... + inc_t the first is exp(-C_{k-1}) / exp(-C_j), the second depends on k only: O(M)
     // calls, one division per pair (differences of ~3e-16 relative against the pairwise form; the ratio is not used where
     // exp(-C_j) has left the normal range).
-    std::vector<S> inc_k(Mh, S(0.0)), Ccum(Mh, S(0.0)), Ek(Mh, S(1.0)), qk(Mh, S(1.0));
+    g.inc_k.assign(Mh, S(0.0)); g.Ek.assign(Mh, S(1.0)); g.qk.assign(Mh, S(1.0)); g.p_float.assign(Mh, S(0.0));
+    std::vector<S> Ccum(Mh, S(0.0));
     for (int k = 1; k < Mh; ++k) {
         S inc(0.0);
         for (int jj = hsi[k - 1]; jj < hsi[k]; ++jj) inc += ada[jj] * (ts[jj + 1] - ts[jj]);
-        inc_k[k] = inc;
+        g.inc_k[k] = inc;
         Ccum[k] = Ccum[k - 1] + inc;
-        Ek[k] = m_exp(-Ccum[k]);
-        qk[k] = std::isinf((double)sval(inc)) ? S(1.0) : S(-m_expm1(-inc));
+        g.Ek[k] = m_exp(-Ccum[k]);
+        g.qk[k] = std::isinf((double)sval(inc)) ? S(1.0) : S(-m_expm1(-inc));
     }
-    std::vector<S> Phi((size_t)M * M, S(0.0));
     for (int j = 1; j < Mh; ++j) {
-        S *row = &Phi[(size_t)(j - 1) * M];
-        for (int k = 0; k < j - 1; ++k) row[k] = expm_diff[k];
         const S rct = avg[j - 1];
         const int rct_ip = avc_ip[j - 1];
         M3T<S> A = m3_identity<S>();
@@ -733,16 +747,28 @@ inline std::vector<S> compute_transition(const RateFunctionT<S> &eta, double rho
         S Rj = c_eta;
         Rj += ada[rct_ip] * (ts[rct_ip + 1] - rct);
         for (int jj = rct_ip + 2; jj < hsi[j]; ++jj) Rj += ada[jj] * (ts[jj + 1] - ts[jj]);
-        const S p_float = B.m[0][1] * m_exp(-Rj);
-        if (sval(Ek[j]) > 1e-250) {
-            const S pf = p_float / Ek[j];
-            for (int k = j + 1; k < Mh; ++k) row[k - 1] += pf * (Ek[k - 1] * qk[k]);
+        g.p_float[j] = B.m[0][1] * m_exp(-Rj);
+    }
+    return g;
+}
+
+template <typename S>
+inline std::vector<S> transition_expand(const TransitionGenerators<S> &g) {
+    const int Mh = g.Mh, M = Mh - 1;
+    std::vector<S> Phi((size_t)M * M, S(0.0));
+    for (int j = 1; j < Mh; ++j) {
+        S *row = &Phi[(size_t)(j - 1) * M];
+        for (int k = 0; k < j - 1; ++k) row[k] = g.expm_diff[k];
+        const S &p_float = g.p_float[j];
+        if (sval(g.Ek[j]) > 1e-250) {
+            const S pf = p_float / g.Ek[j];
+            for (int k = j + 1; k < Mh; ++k) row[k - 1] += pf * (g.Ek[k - 1] * g.qk[k]);
         } else {
             S Rjk1(0.0);
             for (int k = j + 1; k < Mh; ++k) {
                 S p_coal = m_exp(-Rjk1);
-                Rjk1 += inc_k[k];
-                row[k - 1] += p_float * (p_coal * qk[k]);
+                Rjk1 += g.inc_k[k];
+                row[k - 1] += p_float * (p_coal * g.qk[k]);
             }
         }
         row[j - 1] = S(0.0);
@@ -756,6 +782,213 @@ inline std::vector<S> compute_transition(const RateFunctionT<S> &eta, double rho
         x = x * (1 - beta) + p2;
     }
     return Phi;
+}
+
+template <typename S>
+inline std::vector<S> compute_transition(const RateFunctionT<S> &eta, double rho) {
+    return transition_expand<S>(transition_generators<S>(eta, rho, eta.average_coal_times()));
+}
+
+// The generators in the form the engine's kernels consume, with forward-mode derivative PLANES [x][nder] (directions
+// contiguous): ed [M - 1] = expm_diff, pf [M] = p_float / Ek per row (0 for the last row, which has no entry above the
+// diagonal), W [M] = Ek[c] qk[c + 1] per column c >= 1.  `ok` is false when a row needs the pairwise fallback of
+// transition_expand (cumulative hazard beyond 575: exp(-C) has left the normal range); callers then take the generic duals.
+struct TransitionGenJac {
+    int M = 0, nder = 0;
+    bool ok = true;
+    std::vector<double> ed, pf, W, ded, dpf, dW;
+};
+
+// Values exactly as transition_generators<double>; derivatives by the chain rule over plain arrays instead of carrying `nder`
+// directions through every operation of the wide 3 x 3 chain: every factor exp(c_rho A_rho + c_eta A_eta) depends on the
+// parameters through ONE scalar (c_eta = delta / a_piece), so it is differentiated once (a one-direction dual evaluation)
+// and the directions enter as scalar multiples; only row 0 of the running product is ever used, so only that row is
+// propagated.  dada [K x nder] = derivative planes of 1 / a per piece (pieces AFTER the hidden states were inserted),
+// davg [M x nder] those of the average coalescence times.
+inline TransitionGenJac transition_generators_jac(const RateFunctionT<double> &eta, double rho, const std::vector<double> &avg,
+                                                  const TransitionGenerators<double> &g, const double *dada, const double *davg,
+                                                  int nder) {
+    using namespace detail;
+    const std::vector<double> &ts = eta.ts, &ada = eta.ada;
+    const std::vector<int> &hsi = eta.hs_indices;
+    const int Mh = (int)eta.hidden_states.size(), M = Mh - 1, nts = (int)ts.size();
+    TransitionGenJac out;
+    out.M = M; out.nder = nder;
+    out.ed = g.expm_diff;
+    out.pf.assign(M, 0.0); out.W.assign(M, 0.0);
+    for (int j = 1; j < M; ++j) {                    // rows 0 .. M-2 have entries above the diagonal
+        if (!(g.Ek[j] > 1e-250)) { out.ok = false; return out; }
+        out.pf[j - 1] = g.p_float[j] / g.Ek[j];
+    }
+    for (int c = 1; c < M; ++c) out.W[c] = g.Ek[c] * g.qk[c + 1];
+    out.ded.assign((size_t)std::max(0, M - 1) * nder, 0.0); out.dpf.assign((size_t)M * nder, 0.0); out.dW.assign((size_t)M * nder, 0.0);
+    if (nder == 0) return out;
+    // ---- the wide chain: factor values E_i, their c_eta-derivatives G_i, row 0 of the running product and its planes ----
+    typedef Dual<ld> DL;
+    std::vector<M3T<ld>> E(nts, m3_identity<ld>()), G(nts);
+    for (auto &m : G) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) m.m[a][b] = 0.0L;
+    std::vector<ld> p((size_t)nts * 3, 0.0L), dp((size_t)nts * 3 * nder, 0.0L);
+    p[(size_t)hsi[0] * 3 + 0] = 1.0L;
+    for (int i = 0; i <= hsi[0]; ++i) p[(size_t)i * 3 + 0] = 1.0L;
+    for (int i = hsi[0] + 1; i < nts; ++i) {
+        const ld *pp = &p[(size_t)(i - 1) * 3];
+        ld *pc = &p[(size_t)i * 3];
+        const ld *dpp = &dp[(size_t)(i - 1) * 3 * nder];
+        ld *dpc = &dp[(size_t)i * 3 * nder];
+        if (std::isinf(ts[i])) {
+            for (int c = 0; c < 3; ++c) pc[c] = pp[c];
+            for (int x = 0; x < 3 * nder; ++x) dpc[x] = dpp[x];
+            continue;
+        }
+        const double delta = ts[i] - ts[i - 1];
+        const ld c_rho = (ld)delta * (ld)rho, c_eta = (ld)ada[i - 1] * (ld)delta;
+        E[i] = matrix_exp<ld>(c_rho, c_eta);
+        {
+            DualScope sc(1);
+            DL ce(c_eta), cr(c_rho);
+            ce.d[0] = 1.0L;
+            const M3T<DL> Q = matrix_exp<DL>(cr, ce);
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) G[i].m[a][b] = Q.m[a][b].d[0];
+        }
+        ld gv[3];
+        for (int c = 0; c < 3; ++c) {
+            ld s = 0.0L, t = 0.0L;
+            for (int k = 0; k < 3; ++k) { s += pp[k] * E[i].m[k][c]; t += pp[k] * G[i].m[k][c]; }
+            pc[c] = s; gv[c] = t;
+        }
+        const double *da = dada + (size_t)(i - 1) * nder;
+        for (int c = 0; c < 3; ++c) {
+            const ld e0 = E[i].m[0][c], e1 = E[i].m[1][c], e2 = E[i].m[2][c], gd = gv[c] * (ld)delta;
+            ld *o = dpc + (size_t)c * nder;
+            const ld *d0 = dpp, *d1 = dpp + nder, *d2 = dpp + 2 * nder;
+            for (int d = 0; d < nder; ++d) o[d] = d0[d] * e0 + d1[d] * e1 + d2[d] * e2 + gd * (ld)da[d];
+        }
+    }
+    for (int k = 1; k < M; ++k) {
+        const ld *a = &dp[((size_t)hsi[k] * 3 + 2) * nder], *b = &dp[((size_t)hsi[k - 1] * 3 + 2) * nder];
+        for (int d = 0; d < nder; ++d) out.ded[(size_t)(k - 1) * nder + d] = (double)a[d] - (double)b[d];
+    }
+    // ---- cumulative hazards ----
+    std::vector<double> dC((size_t)Mh * nder, 0.0), dEk((size_t)Mh * nder, 0.0), dqk((size_t)Mh * nder, 0.0), dinc(nder);
+    for (int k = 1; k < Mh; ++k) {
+        for (int d = 0; d < nder; ++d) dinc[d] = 0.0;
+        const bool inf = std::isinf(g.inc_k[k]);
+        if (!inf)
+            for (int jj = hsi[k - 1]; jj < hsi[k]; ++jj) {
+                const double w = ts[jj + 1] - ts[jj];
+                for (int d = 0; d < nder; ++d) dinc[d] += dada[(size_t)jj * nder + d] * w;
+            }
+        const double em = inf ? 0.0 : std::exp(-g.inc_k[k]);
+        for (int d = 0; d < nder; ++d) {
+            dC[(size_t)k * nder + d] = dC[(size_t)(k - 1) * nder + d] + dinc[d];
+            dEk[(size_t)k * nder + d] = inf ? 0.0 : -dC[(size_t)k * nder + d] * g.Ek[k];
+            dqk[(size_t)k * nder + d] = inf ? 0.0 : dinc[d] * em;
+        }
+    }
+    for (int c = 1; c < M; ++c)
+        for (int d = 0; d < nder; ++d)
+            out.dW[(size_t)c * nder + d] = dEk[(size_t)c * nder + d] * g.qk[c + 1] + g.Ek[c] * dqk[(size_t)(c + 1) * nder + d];
+    // ---- one partial exponential per row ----
+    std::vector<double> dA((size_t)9 * nder), dAn((size_t)9 * nder), dce(nder), dcr(nder), dRj(nder);
+    auto narrow = [](const M3T<ld> &m) { M3T<double> r; for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) r.m[a][b] = (double)m.m[a][b]; return r; };
+    for (int j = 1; j < M; ++j) {
+        const double rct = avg[j - 1];
+        const int rct_ip = (int)(std::upper_bound(ts.begin(), ts.end(), rct) - ts.begin()) - 1;
+        const double *dav = davg + (size_t)(j - 1) * nder;
+        // A_pre = prod narrow(E_ell), ell = hsi[j-1] .. rct_ip - 1, with its planes
+        M3T<double> A = m3_identity<double>();
+        std::fill(dA.begin(), dA.end(), 0.0);
+        for (int ell = hsi[j - 1]; ell < rct_ip; ++ell) {
+            const M3T<double> En = narrow(E[ell]), Gn = narrow(G[ell]);
+            const double dl = ell >= 1 ? ts[ell] - ts[ell - 1] : 0.0;
+            const double *da = ell >= 1 ? dada + (size_t)(ell - 1) * nder : nullptr;
+            M3T<double> AG = m3_mul(A, Gn);
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    double *o = &dAn[(size_t)(a * 3 + b) * nder];
+                    for (int d = 0; d < nder; ++d) {
+                        double s = 0.0;
+                        for (int k = 0; k < 3; ++k) s += dA[(size_t)(a * 3 + k) * nder + d] * En.m[k][b];
+                        o[d] = s + (da ? AG.m[a][b] * dl * da[d] : 0.0);
+                    }
+                }
+            dA.swap(dAn);
+            A = m3_mul(A, En);
+        }
+        const double delta = rct - ts[rct_ip];
+        const double c_eta = ada[rct_ip] * delta, c_rho = delta * rho;
+        M3T<double> X, Xr, Xe;
+        {
+            X = narrow(matrix_exp<ld>((ld)c_rho, (ld)c_eta));
+            DualScope sc(2);
+            DL cr((ld)c_rho), ce((ld)c_eta);
+            cr.d[0] = 1.0L; ce.d[1] = 1.0L;
+            const M3T<DL> Q = matrix_exp<DL>(cr, ce);
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { Xr.m[a][b] = (double)Q.m[a][b].d[0]; Xe.m[a][b] = (double)Q.m[a][b].d[1]; }
+        }
+        for (int d = 0; d < nder; ++d) {
+            dce[d] = dada[(size_t)rct_ip * nder + d] * delta + ada[rct_ip] * dav[d];
+            dcr[d] = dav[d] * rho;
+        }
+        // B01 = sum_k Pn[k] (A_pre X)[k][1]
+        const ld *pl = &p[(size_t)hsi[j - 1] * 3];
+        const ld *dpl = &dp[(size_t)hsi[j - 1] * 3 * nder];
+        double Pn[3] = {(double)pl[0], (double)pl[1], (double)pl[2]};
+        double AX1[3], AXr1[3], AXe1[3];                 // column 1 of A_pre X, A_pre X_r, A_pre X_e
+        for (int k = 0; k < 3; ++k) {
+            AX1[k] = AXr1[k] = AXe1[k] = 0.0;
+            for (int m = 0; m < 3; ++m) { AX1[k] += A.m[k][m] * X.m[m][1]; AXr1[k] += A.m[k][m] * Xr.m[m][1]; AXe1[k] += A.m[k][m] * Xe.m[m][1]; }
+        }
+        const double B01 = Pn[0] * AX1[0] + Pn[1] * AX1[1] + Pn[2] * AX1[2];
+        // Rj and its planes
+        double Rj = c_eta + ada[rct_ip] * (ts[rct_ip + 1] - rct);
+        for (int d = 0; d < nder; ++d) dRj[d] = dce[d] + dada[(size_t)rct_ip * nder + d] * (ts[rct_ip + 1] - rct) - ada[rct_ip] * dav[d];
+        for (int jj = rct_ip + 2; jj < hsi[j]; ++jj) {
+            const double w = ts[jj + 1] - ts[jj];
+            Rj += ada[jj] * w;
+            for (int d = 0; d < nder; ++d) dRj[d] += dada[(size_t)jj * nder + d] * w;
+        }
+        const double eR = std::exp(-Rj);
+        const double pfv = out.pf[j - 1], Ekj = g.Ek[j];
+        for (int d = 0; d < nder; ++d) {
+            double dB = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                double dAX = AXr1[k] * dcr[d] + AXe1[k] * dce[d];
+                for (int m = 0; m < 3; ++m) dAX += dA[(size_t)(k * 3 + m) * nder + d] * X.m[m][1];
+                dB += (double)dpl[(size_t)k * nder + d] * AX1[k] + Pn[k] * dAX;
+            }
+            const double dpfl = dB * eR - B01 * eR * dRj[d];
+            out.dpf[(size_t)(j - 1) * nder + d] = (dpfl - pfv * dEk[(size_t)j * nder + d]) / Ekj;
+        }
+    }
+    return out;
+}
+
+// dT [M*M x nder] from the generator planes: the derivative of transition_expand entry by entry (floored entries carry no
+// derivative; the diagonal closes the row over the UNfloored entries).  O(M^2 nder): only the Jacobian getter pays it.
+inline void transition_expand_jac(const TransitionGenJac &g, std::vector<double> &dT) {
+    const int M = g.M, nder = g.nder;
+    const double beta = 1e-5;
+    dT.assign((size_t)M * M * nder, 0.0);
+    std::vector<double> ds(nder);
+    for (int i = 0; i < M; ++i) {
+        std::fill(ds.begin(), ds.end(), 0.0);
+        double sm = 0.0;
+        for (int c = 0; c < M; ++c) {
+            if (c == i) continue;
+            const double x = c < i ? g.ed[c] : g.pf[i] * g.W[c];
+            sm += x;
+            double *o = &dT[((size_t)i * M + c) * nder];
+            for (int d = 0; d < nder; ++d) {
+                const double dx = c < i ? g.ded[(size_t)c * nder + d] : g.dpf[(size_t)i * nder + d] * g.W[c] + g.pf[i] * g.dW[(size_t)c * nder + d];
+                ds[d] += dx;
+                o[d] = x < 1e-20 ? 0.0 : dx * (1 - beta);
+            }
+        }
+        const double diag = 1.0 - sm;
+        double *o = &dT[((size_t)i * M + i) * nder];
+        for (int d = 0; d < nder; ++d) o[d] = diag < 1e-20 ? 0.0 : -ds[d] * (1 - beta);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

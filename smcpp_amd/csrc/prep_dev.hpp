@@ -428,8 +428,135 @@ inline void emulate_csfs(const PrepModel &pm, const PrepStatic &ps, const PrepOu
         }
 }
 
+// ---- Q (HMM::Q, src/hmm.cpp:155-193) and its gradient on the device ---------------------------------------------------------------
+// Q's four terms are sums of w log x over (gamma0, pi), (gamma sums, emission table: keys without / with undistinguished
+// lineages) and (xisum, T); their forward-mode derivatives are sums of (w / x) dx.  Block 0 forms the values, block 1 + d the
+// derivatives along direction d.  The transition matrix is never materialised: T(i, c) and dT(i, c) come from the O(M) generators
+// (prep.hpp: TransitionGenJac; below the diagonal ed[c], above it pf[i] W[c], the diagonal closes the row, 1e-20 floor, uniform mix).
+struct QArgs {
+    int M = 0, Kq = 0, nder = 0;
+    const double *g0 = nullptr, *xi = nullptr, *gs = nullptr;       // statistics summed over contigs: [M], [M][M], [Kq][M]
+    const int *key_nb = nullptr;                                    // [Kq] the key has undistinguished lineages (term 2) or not (term 1)
+    const double *pi_v = nullptr, *pi_d = nullptr;                  // [M], planes [nder][M]
+    const double *E_v = nullptr, *E_d = nullptr;                    // [Kq][M], planes [nder][Kq][M]
+    const double *ed_v = nullptr, *ed_d = nullptr;                  // [M] (M - 1 used), planes [nder][M]
+    const double *pf_v = nullptr, *pf_d = nullptr, *W_v = nullptr, *W_d = nullptr;   // [M], planes [nder][M]
+    double mix_p2 = 0.0;                                            // 1e-5 / (M + 1)
+    double *out = nullptr;                                          // [(1 + nder)][4]
+};
+// unfloored row sum of the off-diagonal entries of row i, accumulated in column order as transition_expand does, and (dir >= 0)
+// the derivative of that sum
+SMCPP_HD void q_rowsum(const QArgs &a, int dir, int i, double &sm, double &dsm) {
+    const int M = a.M;
+    sm = 0.0; dsm = 0.0;
+    const double pf = a.pf_v[i];
+    const double *edd = dir >= 0 ? a.ed_d + (size_t)dir * M : nullptr, *Wd = dir >= 0 ? a.W_d + (size_t)dir * M : nullptr;
+    const double dpf = dir >= 0 ? a.pf_d[(size_t)dir * M + i] : 0.0;
+    for (int c = 0; c < M; ++c) {
+        if (c == i) continue;
+        sm += c < i ? a.ed_v[c] : pf * a.W_v[c];
+        if (dir >= 0) dsm += c < i ? edd[c] : dpf * a.W_v[c] + pf * Wd[c];
+    }
+}
+// contribution of item idx (0 .. M + Kq M + M M) of block b: term index and value; diag / ddiag = the rows' diagonals (1 - sm, -dsm)
+SMCPP_HD double q_item(const QArgs &a, int b, long idx, const double *diag, const double *ddiag, int &term) {
+    const int M = a.M, dir = b - 1;
+    double w, x, dx = 0.0;
+    if (idx < M) {
+        term = 0;
+        w = a.g0[idx]; x = a.pi_v[idx];
+        if (dir >= 0) dx = a.pi_d[(size_t)dir * M + idx];
+    } else if (idx < (long)M + (long)a.Kq * M) {
+        const long e = idx - M;
+        term = a.key_nb[e / M] ? 2 : 1;
+        w = a.gs[e]; x = a.E_v[e];
+        if (dir >= 0) dx = a.E_d[(size_t)dir * a.Kq * M + e];
+    } else {
+        const long e = idx - M - (long)a.Kq * M;
+        const int i = (int)(e / M), c = (int)(e % M);
+        term = 3;
+        w = a.xi[e];
+        double t, dt = 0.0;
+        if (c == i) { t = diag[i]; dt = dir >= 0 ? ddiag[i] : 0.0; }
+        else if (c < i) { t = a.ed_v[c]; if (dir >= 0) dt = a.ed_d[(size_t)dir * M + c]; }
+        else {
+            t = a.pf_v[i] * a.W_v[c];
+            if (dir >= 0) dt = a.pf_d[(size_t)dir * M + i] * a.W_v[c] + a.pf_v[i] * a.W_d[(size_t)dir * M + c];
+        }
+        if (t < 1e-20) { t = 1e-20; dt = 0.0; }
+        x = t * (1 - 1e-5) + a.mix_p2;
+        dx = dt * (1 - 1e-5);
+    }
+    if (w == 0.0) return 0.0;                  // (a key no contig holds, an empty row: no contribution, as hmm.cpp:166-181 skips them)
+    return dir < 0 ? w * ::log(x) : (w / x) * dx;
+}
+inline void emulate_q(const QArgs &a) {
+    const int M = a.M;
+    std::vector<double> diag(M), ddiag(M);
+    const long items = (long)M + (long)a.Kq * M + (long)M * M;
+    for (int b = 0; b <= a.nder; ++b) {
+        for (int i = 0; i < M; ++i) { double sm, dsm; q_rowsum(a, b - 1, i, sm, dsm); diag[i] = 1.0 - sm; ddiag[i] = -dsm; }
+        AccD acc[4];
+        for (long idx = 0; idx < items; ++idx) { int term; const double v = q_item(a, b, idx, diag.data(), ddiag.data(), term); acc_add(acc[term], v); }
+        for (int t = 0; t < 4; ++t) acc_get(acc[t], a.out[(size_t)b * 4 + t]);
+    }
+}
+
 #ifdef __HIPCC__
 // ---- kernels ------------------------------------------------------------------------------------------------------------------
+// statistics of all contigs summed in contig order into the compact layout Q reads: [gamma0 M | xisum M M | gamma sums K M]
+__global__ void k_q_stats(int n_contigs, int M, int Mp, int K, const double *gamma0, const double *xisum, const double *gsum, double *out) {
+    const long n = (long)M + (long)M * M + (long)K * M;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        if (idx < M) for (int c = 0; c < n_contigs; ++c) s += gamma0[(size_t)c * Mp + idx];
+        else if (idx < (long)M + (long)M * M) {
+            const long e = idx - M;
+            const int i = (int)(e / M), j = (int)(e % M);
+            for (int c = 0; c < n_contigs; ++c) s += xisum[((size_t)c * Mp + i) * Mp + j];
+        } else {
+            const long e = idx - M - (long)M * M;
+            const int k = (int)(e / M), i = (int)(e % M);
+            for (int c = 0; c < n_contigs; ++c) s += gsum[((size_t)c * K + k) * Mp + i];
+        }
+        out[idx] = s;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_q_reduce(QArgs a) {
+    extern __shared__ double q_lds[];
+    const int M = a.M, b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    double *diag = q_lds, *ddiag = q_lds + M, *red = q_lds + 2 * M;        // red [4][nt / 64][2]
+    for (int i = t; i < M; i += nt) { double sm, dsm; q_rowsum(a, b - 1, i, sm, dsm); diag[i] = 1.0 - sm; ddiag[i] = -dsm; }
+    __syncthreads();
+    AccD acc[4];
+    const long items = (long)M + (long)a.Kq * M + (long)M * M;
+    for (long idx = t; idx < items; idx += nt) {
+        int term;
+        const double v = q_item(a, b, idx, diag, ddiag, term);
+        // (one accumulator per term; the term of an item is uniform over long runs of idx, so the selects are cheap)
+        for (int q = 0; q < 4; ++q) if (q == term) acc_add(acc[q], v);
+    }
+    // wavefront tree on (hi, lo) pairs, then one thread adds the wavefronts' partials in order: deterministic
+    const int lane = t & 63, w = t >> 6, nw = nt >> 6;
+    for (int q = 0; q < 4; ++q) {
+        double hi = acc[q].hi, lo = acc[q].lo;
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double oh = __shfl_down(hi, off), ol = __shfl_down(lo, off);
+            const double s = hi + oh, z = s - hi;
+            lo += ol + ((hi - (s - z)) + (oh - z));
+            hi = s;
+        }
+        if (lane == 0) { red[(q * nw + w) * 2] = hi; red[(q * nw + w) * 2 + 1] = lo; }
+    }
+    __syncthreads();
+    if (t < 4) {
+        AccD r;
+        for (int ww = 0; ww < nw; ++ww) { acc_add(r, red[(t * nw + ww) * 2]); r.lo += red[(t * nw + ww) * 2 + 1]; }
+        a.out[(size_t)b * 4 + t] = r.hi + r.lo;
+    }
+}
+
 template <typename S>
 __global__ void k_prep_tables(PrepModel pm, Tables<S> tb) {
     const int dir = blockIdx.x;

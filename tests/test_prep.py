@@ -268,5 +268,38 @@ def test_device_preparation_phases_equal_host_preparation(fixture, nder):
     pi, T, E, dpi, dT, dE = _engine.host_prep_onepop_jac(args[0], args[1], args[2], args[3], da, *args[4:])
     o = _engine.dev_prep_onepop(*args, da=da, emulate=True)
     assert np.array_equal(o["E"], E) and np.array_equal(o["dE"], dE)
-    assert np.array_equal(o["dpi"], dpi) and np.array_equal(o["dT"], dT)
+    assert np.array_equal(o["dpi"], dpi)
     assert np.abs(dE).max() > 1e-4
+    # the transition matrix of this entry: values from the double routines, derivative planes of its O(M) generators by the chain
+    # rule over plain arrays (prep.hpp: transition_generators_jac) against the generic duals carried through every operation
+    np.testing.assert_allclose(o["T"], T, rtol=1e-14, atol=0)
+    sc = np.abs(dT).max()
+    err = np.abs(o["dT"] - dT)
+    assert err.max() <= 1e-13 * sc, err.max() / sc
+    np.testing.assert_allclose(o["dT"], dT, rtol=1e-9, atol=1e-16 * sc)
+
+
+@pytest.mark.parametrize("fixture,nder", [("params_M32_n10.npz", 3), ("params_M64_n20.npz", 5)])
+def test_device_q_phases_equal_dense_evaluation(fixture, nder):
+    """Q and its gradient as the device kernel forms them (transition matrix and its Jacobian from the O(M) generator planes,
+    never materialised) against the plain dense evaluation sum w log x / sum (w / x) dx on the host preparation's pi, T, E and
+    Jacobians."""
+    import os
+    from smcpp_amd import _engine
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
+    n = int(g["n"]); keys = g["keys"]; M = len(g["hs"]) - 1
+    args = (n, g["hs"], float(g["pol"]), g["a"], g["s"], float(g["theta"]), float(g["rho"]), float(g["alpha"]), keys)
+    rng = np.random.default_rng(9)
+    da = rng.standard_normal((len(g["a"]), nder))
+    pi, T, E, dpi, dT, dE = _engine.host_prep_onepop_jac(args[0], args[1], args[2], args[3], da, *args[4:])
+    g0 = rng.random(M); xi = rng.random((M, M)) * np.exp(-np.abs(np.subtract.outer(np.arange(M), np.arange(M))))
+    gs = rng.random((len(keys), M)) * 100.0
+    gs[3] = 0.0                                                      # a key no contig holds
+    val, jac = _engine.dev_q_emulate(args[0], args[1], args[2], args[3], da, *args[4:], g0, xi, gs)
+    nb = keys[:, 2] > 0
+    ref = np.array([np.sum(g0 * np.log(pi)), np.sum(gs[~nb] * np.log(E[~nb])), np.sum(gs[nb] * np.log(E[nb])), np.sum(xi * np.log(T))])
+    rj = np.array([np.einsum("i,id->d", g0 / pi, dpi), np.einsum("km,kmd->d", gs[~nb] / E[~nb], dE[~nb]),
+                   np.einsum("km,kmd->d", gs[nb] / E[nb], dE[nb]), np.einsum("ij,ijd->d", xi / T, dT)])
+    np.testing.assert_allclose(val, ref, rtol=1e-12)
+    for t in range(4):
+        assert np.max(np.abs(jac[t] - rj[t])) <= 1e-11 * np.abs(rj[t]).max(), t

@@ -261,12 +261,25 @@ __device__ __forceinline__ void ss_bwd_step(const SsBwdC<NPL> &c, const double (
     }
 }
 
+// A block of 64 row descriptors has just been requested (one per lane): make the wavefront wait for it HERE, once per 64 rows.
+// Left pending, the load is carried around the row loop in registers, and the compiler - which cannot count how many stores the
+// rows in between have issued on the path it came by - puts an s_waitcnt vmcnt(0) at the head of EVERY row: with one wavefront
+// per SIMD that parks the chain until the alpha / beta row it has just stored is acknowledged by L2 (rocprofv3, round 4:
+// SQ_WAIT_ANY = 34 % of the wave cycles of this kernel).
+__device__ __forceinline__ void ss_desc_settle(int2 &d) { asm volatile("" : "+v"(d.x), "+v"(d.y)); }
+// ... and for the same reason every load issued BEFORE the row loop (generators, start vector, first descriptors) is waited for at
+// the loop's door: a constant first used inside the loop, behind a store, costs an s_waitcnt vmcnt(0) per row otherwise.
+// (gfx9 encoding of s_waitcnt: vmcnt(0), expcnt and lgkmcnt left at their maxima)
+__device__ __forceinline__ void ss_vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // emission vector of key slot `slot` at this lane's positions (forward: states lane NPL + k; backward: MS-1-(lane NPL + k))
-template <int NPL, bool BWD>
+// ALLLDS: every key slot lives in LDS (K <= nlds) - no global path, and with it no vector-memory destination register the
+// compiler would have to guard with waits
+template <int NPL, bool BWD, bool ALLLDS = false>
 __device__ __forceinline__ void ss_emission(const SsArgs &a, const double *sE, int slot, int lane, double (&e)[NPL]) {
     constexpr int MS = 64 * NPL;
     // `slot` is wavefront-uniform: two separate address spaces, not a flat pointer
-    if (slot < a.nlds) {
+    if (ALLLDS || slot < a.nlds) {
         const double *src = sE + (size_t)slot * MS;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) e[k] = src[BWD ? MS - 1 - (lane * NPL + k) : lane * NPL + k];
@@ -409,7 +422,7 @@ __device__ __forceinline__ double ss_eig_apply(const SsEigC &c, const double *ta
     return ss_eig_matvec(c, tab, Mp, ek, w0 + 1, sx, lp, lp < 64 / c.G ? u : 0.0);
 }
 
-template <int NPL, bool RERUN, bool HYB>
+template <int NPL, bool RERUN, bool HYB, bool ALLLDS>
 __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -458,10 +471,11 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     const int2 *rd = a.rowdesc + ch.base + ch.r0 + 1;          // descriptor of iteration j (row ell = r0 + 1 + j)
     const int nrows = ch.r1 - ch.r0;
     int2 dcur = rd[lane], dnxt = rd[64 + lane];
+    ss_desc_settle(dcur); ss_desc_settle(dnxt);
     float *arow = a.alpha + (size_t)(ch.base + ch.r0) * Mp;    // row ell - 1 of iteration j is arow + j Mp
     double *crow = a.cnorm + ch.base + ch.r0;
     double e[NPL];
-    ss_emission<NPL, false>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
+    ss_emission<NPL, false, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
     constexpr bool hyb = HYB && NPL == 1;
     const double *tab = sE + (size_t)a.nlds * MS;
     SsEigC ec;
@@ -475,16 +489,17 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     bool merged = false;
     const long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
     long long npos = 0;
+    ss_vm_drain();
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
         const int ekr = __builtin_amdgcn_readlane(dcur.x, jl) >> 16;
         npos += span;
         // descriptor / emission vector of the next row
-        if (jl == 63) { dcur = dnxt; dnxt = rd[j + 65 + lane]; }
+        if (jl == 63) { dcur = dnxt; dnxt = rd[j + 65 + lane]; ss_desc_settle(dnxt); }
         const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
         double en[NPL];
-        ss_emission<NPL, false>(a, sE, slot_n, lane, en);
+        ss_emission<NPL, false, ALLLDS>(a, sE, slot_n, lane, en);
         if (hyb && span > a.hyb_th) {
             // ---- hybrid row: finish the previous row exactly as below, then ONE eigen-power step from the STORED vector ----
             const double S = wave_sum_dpp(x[0]);
@@ -596,7 +611,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     }
 }
 
-template <int NPL, bool RERUN, bool HYB>
+template <int NPL, bool RERUN, bool HYB, bool ALLLDS>
 __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -641,9 +656,10 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
     const int2 *rd = a.rowdesc + ch.base + ch.r1;               // descriptor of iteration j (row ell = r1 - j) is rd[-j]
     const int nrows = ch.r1 - ch.r0;
     int2 dcur = rd[-lane], dnxt = rd[-64 - lane];
+    ss_desc_settle(dcur); ss_desc_settle(dnxt);
     double *brow = a.beta + (size_t)(ch.base + ch.r1) * Mp;     // row ell of iteration j is brow - j Mp
     double e[NPL];
-    ss_emission<NPL, true>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
+    ss_emission<NPL, true, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
     constexpr bool hyb = HYB && NPL == 1;
     const double *tab = sE + (size_t)a.nlds * MS;
     SsEigC ec;
@@ -657,15 +673,16 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
     bool merged = false;
     const long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
     long long npos = 0;
+    ss_vm_drain();
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
         const int ekr = __builtin_amdgcn_readlane(dcur.x, jl) >> 16;
         npos += span;
-        if (jl == 63) { dcur = dnxt; dnxt = rd[-(j + 65) - lane]; }
+        if (jl == 63) { dcur = dnxt; dnxt = rd[-(j + 65) - lane]; ss_desc_settle(dnxt); }
         const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
         double en[NPL];
-        ss_emission<NPL, true>(a, sE, slot_n, lane, en);
+        ss_emission<NPL, true, ALLLDS>(a, sE, slot_n, lane, en);
         // beta[ell] in the running scale (hmm.cpp:142 renormalises; every consumer is invariant to a per-row scale)
         if (RERUN && !a.full_b && (j & 15) == 0 && j >= 16) {
             bool bad = false;
@@ -866,15 +883,15 @@ __device__ __forceinline__ void ss_bwd_step_f(const SsLightC<NPL> &c, const floa
     }
 }
 
-template <int NPL, bool BWD>
+template <int NPL, bool BWD, bool ALLLDS>
 __device__ __forceinline__ void ss_emission_f(const SsArgs &a, const double *sE, int slot, int lane, float (&e)[NPL]) {
     double ed[NPL];
-    ss_emission<NPL, BWD>(a, sE, slot, lane, ed);
+    ss_emission<NPL, BWD, ALLLDS>(a, sE, slot, lane, ed);
 #pragma unroll
     for (int k = 0; k < NPL; ++k) e[k] = (float)ed[k];
 }
 
-template <int NPL>
+template <int NPL, bool ALLLDS>
 __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *sE, int c, int lane) {
     const int M = a.M, Mp = a.Mp, pass = a.pass;
     const Chunk ch = a.chunks[c];
@@ -895,18 +912,20 @@ __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *
     const int2 *rd = a.rowdesc + ch.base + ch.r0 + 1;
     const int nrows = ch.r1 - ch.r0;
     int2 dcur = rd[lane], dnxt = rd[64 + lane];
+    ss_desc_settle(dcur); ss_desc_settle(dnxt);
     float e[NPL];
-    ss_emission_f<NPL, false>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
+    ss_emission_f<NPL, false, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
     int fcur = ch.pad & 0xFFFFFF;
     const int fend = fcur + (ch.pad >> 24);
     int nextb = (a.hand_f && fcur < fend) ? a.fine[fcur].r1 - ch.r0 : -1;
+    ss_vm_drain();
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
-        if (jl == 63) { dcur = dnxt; dnxt = rd[j + 65 + lane]; }
+        if (jl == 63) { dcur = dnxt; dnxt = rd[j + 65 + lane]; ss_desc_settle(dnxt); }
         const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
         float en[NPL], y[NPL], S;
-        ss_emission_f<NPL, false>(a, sE, slot_n, lane, en);
+        ss_emission_f<NPL, false, ALLLDS>(a, sE, slot_n, lane, en);
         ss_fwd_step_f<NPL>(cst, x, e, y, S);
         const float inv = __builtin_amdgcn_rcpf(S);
 #pragma unroll
@@ -952,7 +971,7 @@ __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *
     for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = live[k] ? fmaxf(x[k] * inv, 1e-10f) : 0.f;
 }
 
-template <int NPL>
+template <int NPL, bool ALLLDS>
 __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -975,18 +994,20 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
     const int2 *rd = a.rowdesc + ch.base + ch.r1;
     const int nrows = ch.r1 - ch.r0;
     int2 dcur = rd[-lane], dnxt = rd[-64 - lane];
+    ss_desc_settle(dcur); ss_desc_settle(dnxt);
     float e[NPL];
-    ss_emission_f<NPL, true>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
+    ss_emission_f<NPL, true, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
     const int fbeg = ch.pad & 0xFFFFFF;
     int fcur = fbeg + (ch.pad >> 24) - 1;
     int nextb = (a.hand_b && fcur >= fbeg) ? ch.r1 - a.fine[fcur].r0 : -1;
+    ss_vm_drain();
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
-        if (jl == 63) { dcur = dnxt; dnxt = rd[-(j + 65) - lane]; }
+        if (jl == 63) { dcur = dnxt; dnxt = rd[-(j + 65) - lane]; ss_desc_settle(dnxt); }
         const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
         float en[NPL], y[NPL], Sw;
-        ss_emission_f<NPL, true>(a, sE, slot_n, lane, en);
+        ss_emission_f<NPL, true, ALLLDS>(a, sE, slot_n, lane, en);
         ss_bwd_step_f<NPL>(cst, b, e, y, Sw);
         const float inv = __builtin_amdgcn_rcpf(Sw);
 #pragma unroll
@@ -1034,7 +1055,7 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
 // One workgroup = 4 wavefronts = chunks 2 blk, 2 blk + 1 forward (wavefronts 0, 1) and backward (wavefronts 2, 3); they share
 // one LDS copy of the emission vectors of the `nlds` most frequent keys.
 // (the hybrid instantiation may run 8 wavefronts per workgroup - two per SIMD behind ONE copy of the eigenvector tables)
-template <int NPL, bool HYB>
+template <int NPL, bool HYB, bool ALLLDS>
 __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
     constexpr int MS = 64 * NPL;
     extern __shared__ __attribute__((aligned(16))) double ss_lds[];
@@ -1065,14 +1086,14 @@ __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
     const int c = task & 0x3FFFFFFF;
     if (fwd) {
         if (idle_f) return;
-        if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB>(a, ss_lds, c, lane);
-        else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB>(a, ss_lds, c, lane);
-        else ss_forward_light<NPL>(a, ss_lds, c, lane);
+        if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS>(a, ss_lds, c, lane);
+        else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB, ALLLDS>(a, ss_lds, c, lane);
+        else ss_forward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
     } else {
         if (idle_b) return;
-        if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB>(a, ss_lds, c, lane);
-        else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB>(a, ss_lds, c, lane);
-        else ss_backward_light<NPL>(a, ss_lds, c, lane);
+        if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS>(a, ss_lds, c, lane);
+        else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB, ALLLDS>(a, ss_lds, c, lane);
+        else ss_backward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
     }
 }
 

@@ -1449,8 +1449,8 @@ static bool host_transition_with_planes(const smcpp_host::RateFunctionT<smcpp_ho
     for (int k = 0; k < K; ++k) { ev.ada[k] = eta.ada[k].v; for (int d = 0; d < nder; ++d) dada[(size_t)k * nder + d] = eta.ada[k].d[d]; }
     for (size_t k = 0; k < eta.Rrng.size(); ++k) ev.Rrng[k] = eta.Rrng[k].v;
     for (int m = 0; m < M; ++m) { avg[m] = act[m].v; for (int d = 0; d < nder; ++d) davg[(size_t)m * nder + d] = act[m].d[d]; }
-    const smcpp_host::TransitionGenerators<double> g = smcpp_host::transition_generators<double>(ev, rho, avg);
-    tj = smcpp_host::transition_generators_jac(ev, rho, avg, g, dada.data(), davg.data(), nder);
+    smcpp_host::TransitionGenerators<double> g;
+    tj = smcpp_host::transition_generators_jac(ev, rho, avg, dada.data(), davg.data(), nder, &g);
     if (!tj.ok) return false;
     T = smcpp_host::transition_expand<double>(g);
     return true;
@@ -1498,9 +1498,9 @@ void smcpp_im::dev_prepare() {
         const std::vector<double> act = eta.average_coal_times();
         dprep->run(eta, act, theta, alpha, 0, stream);
         smcpp_host::initial_distribution(eta, pi);
-        const smcpp_host::TransitionGenerators<double> g = smcpp_host::transition_generators<double>(eta, rho, act);
+        smcpp_host::TransitionGenerators<double> g;
+        tgen = smcpp_host::transition_generators_jac(eta, rho, act, nullptr, nullptr, 0, &g);
         T = smcpp_host::transition_expand<double>(g);
-        tgen = smcpp_host::transition_generators_jac(eta, rho, act, g, nullptr, nullptr, 0);
         tgen_valid = tgen.ok;
         dpi.clear(); dT.clear();
         dT_valid = true;
@@ -2471,14 +2471,20 @@ bool smcpp_im::ss_extract_generators() {
     return true;
 }
 
-template <int NPL_, bool HYB_>
-static void launch_chain_ss_t(const SsArgs &a, int ntasks, size_t shm, hipStream_t s, int wgw) {
+template <int NPL_, bool HYB_, bool ALL_>
+static void launch_chain_ss_tt(const SsArgs &a, int ntasks, size_t shm, hipStream_t s, int wgw) {
     static bool once = false;
     if (!once) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss<NPL_, HYB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss<NPL_, HYB_, ALL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;
     }
-    hipLaunchKernelGGL((k_chain_ss<NPL_, HYB_>), dim3(ntasks / wgw), dim3(64 * wgw), shm, s, a);
+    hipLaunchKernelGGL((k_chain_ss<NPL_, HYB_, ALL_>), dim3(ntasks / wgw), dim3(64 * wgw), shm, s, a);
+}
+template <int NPL_, bool HYB_>
+static void launch_chain_ss_t(const SsArgs &a, int ntasks, size_t shm, hipStream_t s, int wgw) {
+    // every key slot in LDS (the usual case): the instantiation without the global path of the emission vectors
+    if (a.K <= a.nlds) launch_chain_ss_tt<NPL_, HYB_, true>(a, ntasks, shm, s, wgw);
+    else launch_chain_ss_tt<NPL_, HYB_, false>(a, ntasks, shm, s, wgw);
 }
 static void launch_chain_ss(int npl, const SsArgs &a, int ntasks, size_t shm, hipStream_t s, int wgw = 4) {
     switch (npl) {

@@ -667,6 +667,42 @@ template <typename L> inline M3T<L> matrix_exp(const L &c_rho, const L &c_eta) {
     Qm.m[2][0] = L((ld)0); Qm.m[2][1] = L((ld)0); Qm.m[2][2] = L((ld)1);
     return Qm;
 }
+// The same exponential with its two partial derivatives in closed form (no second pass through the formulas with dual numbers):
+// with S = sq es = e^-y sinh x,  d ec = x' S - y' ec,  d S = x' ec - y' S,  d es = (d S - es d sq) / sq.
+inline void matrix_exp_partials(ld c_rho, ld c_eta, M3T<ld> &Q, M3T<ld> &Qr, M3T<ld> &Qe) {
+    // (values: the operations of matrix_exp<ld>, in its order)
+    const ld sq = sqrtl(4 * c_eta * c_eta + c_rho * c_rho);
+    const ld y = c_eta + c_rho / (ld)2, x = sq / (ld)2;
+    ld ec = 1.0L, es = 0.5L, ep = 1.0L, em = 1.0L;
+    if (sq != 0) {
+        ep = expl(x - y); em = expl(-x - y);
+        ec = (ld)0.5L * (ep + em);
+        es = (x < 0.5L) ? expl(-y) * sinhl(x) / sq : (ld)0.5L * (ep - em) / sq;
+    }
+    Q.m[0][0] = ec + (2 * c_eta - c_rho) * es;
+    Q.m[0][1] = 2 * c_rho * es;
+    Q.m[0][2] = (ld)1 - Q.m[0][0] - Q.m[0][1];
+    Q.m[1][0] = 2 * c_eta * es;
+    Q.m[1][1] = ec - (2 * c_eta - c_rho) * es;
+    Q.m[1][2] = (ld)1 - Q.m[1][0] - Q.m[1][1];
+    Q.m[2][0] = 0.0L; Q.m[2][1] = 0.0L; Q.m[2][2] = 1.0L;
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { Qr.m[a][b] = 0.0L; Qe.m[a][b] = 0.0L; }
+    if (sq == 0) return;                              // (no time, no change: never reached with positive piece lengths)
+    const ld Sv = sq * es;
+    const ld w = 2 * c_eta - c_rho;
+    for (int v = 0; v < 2; ++v) {                     // v = 0: d / d c_rho, v = 1: d / d c_eta
+        const ld sqv = v ? 4 * c_eta / sq : c_rho / sq, xv = sqv / 2.0L, yv = v ? 1.0L : 0.5L;
+        const ld ecv = xv * Sv - yv * ec, Svv = xv * ec - yv * Sv, esv = (Svv - es * sqv) / sq;
+        const ld wv = v ? 2.0L : -1.0L, crv = v ? 0.0L : 1.0L, cev = v ? 1.0L : 0.0L;
+        M3T<ld> &D = v ? Qe : Qr;
+        D.m[0][0] = ecv + wv * es + w * esv;
+        D.m[0][1] = 2 * (crv * es + c_rho * esv);
+        D.m[0][2] = -D.m[0][0] - D.m[0][1];
+        D.m[1][0] = 2 * (cev * es + c_eta * esv);
+        D.m[1][1] = ecv - (wv * es + w * esv);
+        D.m[1][2] = -D.m[1][0] - D.m[1][1];
+    }
+}
 template <typename S> struct WideOf;
 template <> struct WideOf<double> {
     typedef ld type;
@@ -799,117 +835,128 @@ struct TransitionGenJac {
     std::vector<double> ed, pf, W, ded, dpf, dW;
 };
 
-// Values exactly as transition_generators<double>; derivatives by the chain rule over plain arrays instead of carrying `nder`
-// directions through every operation of the wide 3 x 3 chain: every factor exp(c_rho A_rho + c_eta A_eta) depends on the
-// parameters through ONE scalar (c_eta = delta / a_piece), so it is differentiated once (a one-direction dual evaluation)
-// and the directions enter as scalar multiples; only row 0 of the running product is ever used, so only that row is
-// propagated.  dada [K x nder] = derivative planes of 1 / a per piece (pieces AFTER the hidden states were inserted),
-// davg [M x nder] those of the average coalescence times.
+// Values as transition_generators<double> forms them (the same operations; every exponential is evaluated ONCE, together with its
+// partial derivatives in closed form); derivatives by the chain rule over plain arrays instead of carrying `nder` directions
+// through every operation of the wide 3 x 3 chain.  Every factor exp(c_rho A_rho + c_eta A_eta) depends on the parameters
+// through ONE scalar (c_eta = delta / a_piece), so the directions enter as scalar multiples.  Only row 0 of the running product
+// is used, and of it only u = (P00, P01): rows of these matrices sum to one identically, so d P02 = -(d P00 + d P01), and u -
+// the probability of not having coalesced - decays geometrically, which keeps its derivative RELATIVELY accurate in double
+// where the accumulated d P02 of the three-column form would cancel.
+// dada [K x nder] = derivative planes of 1 / a per piece (pieces AFTER the hidden states were inserted), davg [M x nder] those of
+// the average coalescence times.  Also returns the generators themselves (for transition_expand) through `gout`.
 inline TransitionGenJac transition_generators_jac(const RateFunctionT<double> &eta, double rho, const std::vector<double> &avg,
-                                                  const TransitionGenerators<double> &g, const double *dada, const double *davg,
-                                                  int nder) {
+                                                  const double *dada, const double *davg, int nder,
+                                                  TransitionGenerators<double> *gout = nullptr) {
     using namespace detail;
     const std::vector<double> &ts = eta.ts, &ada = eta.ada;
     const std::vector<int> &hsi = eta.hs_indices;
     const int Mh = (int)eta.hidden_states.size(), M = Mh - 1, nts = (int)ts.size();
+    TransitionGenerators<double> g;
+    g.Mh = Mh;
     TransitionGenJac out;
     out.M = M; out.nder = nder;
-    out.ed = g.expm_diff;
-    out.pf.assign(M, 0.0); out.W.assign(M, 0.0);
-    for (int j = 1; j < M; ++j) {                    // rows 0 .. M-2 have entries above the diagonal
-        if (!(g.Ek[j] > 1e-250)) { out.ok = false; return out; }
-        out.pf[j - 1] = g.p_float[j] / g.Ek[j];
-    }
-    for (int c = 1; c < M; ++c) out.W[c] = g.Ek[c] * g.qk[c + 1];
-    out.ded.assign((size_t)std::max(0, M - 1) * nder, 0.0); out.dpf.assign((size_t)M * nder, 0.0); out.dW.assign((size_t)M * nder, 0.0);
-    if (nder == 0) return out;
-    // ---- the wide chain: factor values E_i, their c_eta-derivatives G_i, row 0 of the running product and its planes ----
-    typedef Dual<ld> DL;
+    // ---- the wide chain: factors E_i with their c_eta-derivatives G_i, row 0 of the running product, planes of u = (P00, P01) ----
     std::vector<M3T<ld>> E(nts, m3_identity<ld>()), G(nts);
     for (auto &m : G) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) m.m[a][b] = 0.0L;
-    std::vector<ld> p((size_t)nts * 3, 0.0L), dp((size_t)nts * 3 * nder, 0.0L);
-    p[(size_t)hsi[0] * 3 + 0] = 1.0L;
+    std::vector<ld> p((size_t)nts * 3, 0.0L);
+    std::vector<double> du((size_t)nts * 2 * std::max(1, nder), 0.0);
     for (int i = 0; i <= hsi[0]; ++i) p[(size_t)i * 3 + 0] = 1.0L;
     for (int i = hsi[0] + 1; i < nts; ++i) {
         const ld *pp = &p[(size_t)(i - 1) * 3];
         ld *pc = &p[(size_t)i * 3];
-        const ld *dpp = &dp[(size_t)(i - 1) * 3 * nder];
-        ld *dpc = &dp[(size_t)i * 3 * nder];
+        const double *dup = &du[(size_t)(i - 1) * 2 * nder];
+        double *duc = &du[(size_t)i * 2 * nder];
         if (std::isinf(ts[i])) {
-            for (int c = 0; c < 3; ++c) pc[c] = pp[c];
-            for (int x = 0; x < 3 * nder; ++x) dpc[x] = dpp[x];
+            // (the reference push_back()s instead of assigning: the factor stays the identity; m3_mul with it, as the generic routine)
+            for (int c = 0; c < 3; ++c) { ld sacc = 0.0L; for (int k = 0; k < 3; ++k) sacc += pp[k] * (ld)(k == c); pc[c] = sacc; }
+            for (int x = 0; x < 2 * nder; ++x) duc[x] = dup[x];
             continue;
         }
         const double delta = ts[i] - ts[i - 1];
-        const ld c_rho = (ld)delta * (ld)rho, c_eta = (ld)ada[i - 1] * (ld)delta;
-        E[i] = matrix_exp<ld>(c_rho, c_eta);
-        {
-            DualScope sc(1);
-            DL ce(c_eta), cr(c_rho);
-            ce.d[0] = 1.0L;
-            const M3T<DL> Q = matrix_exp<DL>(cr, ce);
-            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) G[i].m[a][b] = Q.m[a][b].d[0];
-        }
-        ld gv[3];
+        M3T<ld> Gr;
+        matrix_exp_partials((ld)delta * (ld)rho, (ld)ada[i - 1] * (ld)delta, E[i], Gr, G[i]);
+        double gv[2];
         for (int c = 0; c < 3; ++c) {
-            ld s = 0.0L, t = 0.0L;
-            for (int k = 0; k < 3; ++k) { s += pp[k] * E[i].m[k][c]; t += pp[k] * G[i].m[k][c]; }
-            pc[c] = s; gv[c] = t;
+            ld sacc = 0.0L;
+            for (int k = 0; k < 3; ++k) sacc += pp[k] * E[i].m[k][c];
+            pc[c] = sacc;
         }
-        const double *da = dada + (size_t)(i - 1) * nder;
-        for (int c = 0; c < 3; ++c) {
-            const ld e0 = E[i].m[0][c], e1 = E[i].m[1][c], e2 = E[i].m[2][c], gd = gv[c] * (ld)delta;
-            ld *o = dpc + (size_t)c * nder;
-            const ld *d0 = dpp, *d1 = dpp + nder, *d2 = dpp + 2 * nder;
-            for (int d = 0; d < nder; ++d) o[d] = d0[d] * e0 + d1[d] * e1 + d2[d] * e2 + gd * (ld)da[d];
+        for (int c = 0; c < 2; ++c) gv[c] = (double)(pp[0] * G[i].m[0][c] + pp[1] * G[i].m[1][c]) * delta;
+        if (nder) {
+            const double *da = dada + (size_t)(i - 1) * nder;
+            for (int c = 0; c < 2; ++c) {
+                const double e0 = (double)E[i].m[0][c], e1 = (double)E[i].m[1][c], gd = gv[c];
+                double *o = duc + (size_t)c * nder;
+                const double *d0 = dup, *d1 = dup + nder;
+                for (int d = 0; d < nder; ++d) o[d] = d0[d] * e0 + d1[d] * e1 + gd * da[d];
+            }
         }
     }
+    g.expm_diff.assign(std::max(0, M - 1), 0.0);
+    for (int k = 1; k < M; ++k) g.expm_diff[k - 1] = (double)p[(size_t)hsi[k] * 3 + 2] - (double)p[(size_t)hsi[k - 1] * 3 + 2];
+    out.ed = g.expm_diff;
+    out.ded.assign((size_t)std::max(0, M - 1) * nder, 0.0);
     for (int k = 1; k < M; ++k) {
-        const ld *a = &dp[((size_t)hsi[k] * 3 + 2) * nder], *b = &dp[((size_t)hsi[k - 1] * 3 + 2) * nder];
-        for (int d = 0; d < nder; ++d) out.ded[(size_t)(k - 1) * nder + d] = (double)a[d] - (double)b[d];
+        const double *a = &du[(size_t)hsi[k - 1] * 2 * nder], *b = &du[(size_t)hsi[k] * 2 * nder];
+        for (int d = 0; d < nder; ++d) out.ded[(size_t)(k - 1) * nder + d] = (a[d] + a[nder + d]) - (b[d] + b[nder + d]);
     }
     // ---- cumulative hazards ----
-    std::vector<double> dC((size_t)Mh * nder, 0.0), dEk((size_t)Mh * nder, 0.0), dqk((size_t)Mh * nder, 0.0), dinc(nder);
+    g.inc_k.assign(Mh, 0.0); g.Ek.assign(Mh, 1.0); g.qk.assign(Mh, 1.0); g.p_float.assign(Mh, 0.0);
+    std::vector<double> Ccum(Mh, 0.0);
+    std::vector<double> dC((size_t)Mh * nder, 0.0), dEk((size_t)Mh * nder, 0.0), dqk((size_t)Mh * nder, 0.0), dinc(std::max(1, nder));
     for (int k = 1; k < Mh; ++k) {
+        double inc = 0.0;
+        for (int jj = hsi[k - 1]; jj < hsi[k]; ++jj) inc += ada[jj] * (ts[jj + 1] - ts[jj]);
+        g.inc_k[k] = inc;
+        Ccum[k] = Ccum[k - 1] + inc;
+        g.Ek[k] = std::exp(-Ccum[k]);
+        const bool inf = std::isinf(inc);
+        g.qk[k] = inf ? 1.0 : -std::expm1(-inc);
+        if (!nder) continue;
         for (int d = 0; d < nder; ++d) dinc[d] = 0.0;
-        const bool inf = std::isinf(g.inc_k[k]);
         if (!inf)
             for (int jj = hsi[k - 1]; jj < hsi[k]; ++jj) {
                 const double w = ts[jj + 1] - ts[jj];
                 for (int d = 0; d < nder; ++d) dinc[d] += dada[(size_t)jj * nder + d] * w;
             }
-        const double em = inf ? 0.0 : std::exp(-g.inc_k[k]);
+        const double em = inf ? 0.0 : 1.0 - g.qk[k];           // exp(-inc)
         for (int d = 0; d < nder; ++d) {
             dC[(size_t)k * nder + d] = dC[(size_t)(k - 1) * nder + d] + dinc[d];
             dEk[(size_t)k * nder + d] = inf ? 0.0 : -dC[(size_t)k * nder + d] * g.Ek[k];
             dqk[(size_t)k * nder + d] = inf ? 0.0 : dinc[d] * em;
         }
     }
-    for (int c = 1; c < M; ++c)
+    out.pf.assign(M, 0.0); out.W.assign(M, 0.0);
+    out.dpf.assign((size_t)M * nder, 0.0); out.dW.assign((size_t)M * nder, 0.0);
+    for (int c = 1; c < M; ++c) {
+        out.W[c] = g.Ek[c] * g.qk[c + 1];
         for (int d = 0; d < nder; ++d)
             out.dW[(size_t)c * nder + d] = dEk[(size_t)c * nder + d] * g.qk[c + 1] + g.Ek[c] * dqk[(size_t)(c + 1) * nder + d];
+    }
     // ---- one partial exponential per row ----
-    std::vector<double> dA((size_t)9 * nder), dAn((size_t)9 * nder), dce(nder), dcr(nder), dRj(nder);
+    std::vector<double> dA((size_t)9 * std::max(1, nder)), dAn((size_t)9 * std::max(1, nder)), dce(std::max(1, nder)), dcr(std::max(1, nder)),
+        dRj(std::max(1, nder));
     auto narrow = [](const M3T<ld> &m) { M3T<double> r; for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) r.m[a][b] = (double)m.m[a][b]; return r; };
-    for (int j = 1; j < M; ++j) {
+    for (int j = 1; j < Mh; ++j) {
         const double rct = avg[j - 1];
         const int rct_ip = (int)(std::upper_bound(ts.begin(), ts.end(), rct) - ts.begin()) - 1;
-        const double *dav = davg + (size_t)(j - 1) * nder;
+        const double *dav = nder ? davg + (size_t)(j - 1) * nder : nullptr;
         // A_pre = prod narrow(E_ell), ell = hsi[j-1] .. rct_ip - 1, with its planes
         M3T<double> A = m3_identity<double>();
-        std::fill(dA.begin(), dA.end(), 0.0);
+        const bool pre = hsi[j - 1] < rct_ip;            // (usually not: the average time lies in the state's first piece)
+        if (pre) std::fill(dA.begin(), dA.end(), 0.0);
         for (int ell = hsi[j - 1]; ell < rct_ip; ++ell) {
             const M3T<double> En = narrow(E[ell]), Gn = narrow(G[ell]);
             const double dl = ell >= 1 ? ts[ell] - ts[ell - 1] : 0.0;
-            const double *da = ell >= 1 ? dada + (size_t)(ell - 1) * nder : nullptr;
-            M3T<double> AG = m3_mul(A, Gn);
+            const double *da = (ell >= 1 && nder) ? dada + (size_t)(ell - 1) * nder : nullptr;
+            const M3T<double> AG = m3_mul(A, Gn);
             for (int a = 0; a < 3; ++a)
                 for (int b = 0; b < 3; ++b) {
                     double *o = &dAn[(size_t)(a * 3 + b) * nder];
                     for (int d = 0; d < nder; ++d) {
-                        double s = 0.0;
-                        for (int k = 0; k < 3; ++k) s += dA[(size_t)(a * 3 + k) * nder + d] * En.m[k][b];
-                        o[d] = s + (da ? AG.m[a][b] * dl * da[d] : 0.0);
+                        double sacc = 0.0;
+                        for (int k = 0; k < 3; ++k) sacc += dA[(size_t)(a * 3 + k) * nder + d] * En.m[k][b];
+                        o[d] = sacc + (da ? AG.m[a][b] * dl * da[d] : 0.0);
                     }
                 }
             dA.swap(dAn);
@@ -919,48 +966,57 @@ inline TransitionGenJac transition_generators_jac(const RateFunctionT<double> &e
         const double c_eta = ada[rct_ip] * delta, c_rho = delta * rho;
         M3T<double> X, Xr, Xe;
         {
-            X = narrow(matrix_exp<ld>((ld)c_rho, (ld)c_eta));
-            DualScope sc(2);
-            DL cr((ld)c_rho), ce((ld)c_eta);
-            cr.d[0] = 1.0L; ce.d[1] = 1.0L;
-            const M3T<DL> Q = matrix_exp<DL>(cr, ce);
-            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { Xr.m[a][b] = (double)Q.m[a][b].d[0]; Xe.m[a][b] = (double)Q.m[a][b].d[1]; }
+            M3T<ld> Xl, Xrl, Xel;
+            matrix_exp_partials((ld)c_rho, (ld)c_eta, Xl, Xrl, Xel);
+            X = narrow(Xl); Xr = narrow(Xrl); Xe = narrow(Xel);
         }
+        A = m3_mul(A, X);                                  // (A_pre X: the generic routine's A)
+        M3T<double> Pn;
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) Pn.m[a][b] = a == 0 ? (double)p[(size_t)hsi[j - 1] * 3 + b] : (a == b ? 1.0 : 0.0);
+        // (rows 1 and 2 of the narrowed running product do not enter B(0, 1); row 0 is formed as m3_mul does)
+        double B01 = 0.0;
+        for (int k = 0; k < 3; ++k) B01 += Pn.m[0][k] * A.m[k][1];
+        double Rj = c_eta;
+        Rj += ada[rct_ip] * (ts[rct_ip + 1] - rct);
+        for (int jj = rct_ip + 2; jj < hsi[j]; ++jj) Rj += ada[jj] * (ts[jj + 1] - ts[jj]);
+        const double eR = std::exp(-Rj);
+        g.p_float[j] = B01 * eR;
+        if (j >= M) continue;                               // the last row has no entry above the diagonal
+        if (!(g.Ek[j] > 1e-250)) { out.ok = false; continue; }
+        out.pf[j - 1] = g.p_float[j] / g.Ek[j];
+        if (!nder) continue;
         for (int d = 0; d < nder; ++d) {
             dce[d] = dada[(size_t)rct_ip * nder + d] * delta + ada[rct_ip] * dav[d];
             dcr[d] = dav[d] * rho;
+            dRj[d] = dce[d] + dada[(size_t)rct_ip * nder + d] * (ts[rct_ip + 1] - rct) - ada[rct_ip] * dav[d];
         }
-        // B01 = sum_k Pn[k] (A_pre X)[k][1]
-        const ld *pl = &p[(size_t)hsi[j - 1] * 3];
-        const ld *dpl = &dp[(size_t)hsi[j - 1] * 3 * nder];
-        double Pn[3] = {(double)pl[0], (double)pl[1], (double)pl[2]};
-        double AX1[3], AXr1[3], AXe1[3];                 // column 1 of A_pre X, A_pre X_r, A_pre X_e
-        for (int k = 0; k < 3; ++k) {
-            AX1[k] = AXr1[k] = AXe1[k] = 0.0;
-            for (int m = 0; m < 3; ++m) { AX1[k] += A.m[k][m] * X.m[m][1]; AXr1[k] += A.m[k][m] * Xr.m[m][1]; AXe1[k] += A.m[k][m] * Xe.m[m][1]; }
-        }
-        const double B01 = Pn[0] * AX1[0] + Pn[1] * AX1[1] + Pn[2] * AX1[2];
-        // Rj and its planes
-        double Rj = c_eta + ada[rct_ip] * (ts[rct_ip + 1] - rct);
-        for (int d = 0; d < nder; ++d) dRj[d] = dce[d] + dada[(size_t)rct_ip * nder + d] * (ts[rct_ip + 1] - rct) - ada[rct_ip] * dav[d];
         for (int jj = rct_ip + 2; jj < hsi[j]; ++jj) {
             const double w = ts[jj + 1] - ts[jj];
-            Rj += ada[jj] * w;
             for (int d = 0; d < nder; ++d) dRj[d] += dada[(size_t)jj * nder + d] * w;
         }
-        const double eR = std::exp(-Rj);
+        // column 1 of A_pre X_r and A_pre X_e (A currently holds A_pre X; A_pre = A X^-1 is not needed: recompute from the factors)
+        M3T<double> Ap = m3_identity<double>();
+        if (pre) for (int ell = hsi[j - 1]; ell < rct_ip; ++ell) Ap = m3_mul(Ap, narrow(E[ell]));
+        double AXr1[3], AXe1[3];
+        for (int k = 0; k < 3; ++k) {
+            AXr1[k] = AXe1[k] = 0.0;
+            for (int m = 0; m < 3; ++m) { AXr1[k] += Ap.m[k][m] * Xr.m[m][1]; AXe1[k] += Ap.m[k][m] * Xe.m[m][1]; }
+        }
+        const double *dul = &du[(size_t)hsi[j - 1] * 2 * nder];
         const double pfv = out.pf[j - 1], Ekj = g.Ek[j];
         for (int d = 0; d < nder; ++d) {
             double dB = 0.0;
             for (int k = 0; k < 3; ++k) {
                 double dAX = AXr1[k] * dcr[d] + AXe1[k] * dce[d];
-                for (int m = 0; m < 3; ++m) dAX += dA[(size_t)(k * 3 + m) * nder + d] * X.m[m][1];
-                dB += (double)dpl[(size_t)k * nder + d] * AX1[k] + Pn[k] * dAX;
+                if (pre) for (int m = 0; m < 3; ++m) dAX += dA[(size_t)(k * 3 + m) * nder + d] * X.m[m][1];
+                dB += Pn.m[0][k] * dAX;
+                if (k < 2) dB += dul[(size_t)k * nder + d] * A.m[k][1];      // (A(2, 1) = 0: the third column's plane never enters)
             }
             const double dpfl = dB * eR - B01 * eR * dRj[d];
             out.dpf[(size_t)(j - 1) * nder + d] = (dpfl - pfv * dEk[(size_t)j * nder + d]) / Ekj;
         }
     }
+    if (gout) *gout = g;
     return out;
 }
 

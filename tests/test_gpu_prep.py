@@ -56,7 +56,8 @@ def test_device_jacobians_match_host(fixture, nder):
     dd = np.abs(o["dE"] - dE)
     print(fixture, "dE: max abs", dd.max(), "scale", scale)
     assert dd.max() <= 1e-12 * scale
-    assert np.array_equal(o["dpi"], dpi) and np.array_equal(o["dT"], dT)      # host routines either way
+    assert np.array_equal(o["dpi"], dpi)                                      # host routine either way
+    assert np.max(np.abs(o["dT"] - dT)) <= 1e-13 * np.abs(dT).max()           # generator planes by the chain rule vs generic duals
 
 
 @pytest.mark.parametrize("M,n", [(1, 4), (2, 1), (5, 2), (17, 7), (48, 28)])

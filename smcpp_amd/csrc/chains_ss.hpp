@@ -53,6 +53,7 @@ struct SsArgs {
                                 // test, no merge exit, the contig's first / last chunk included): the fp64 pass after light passes
     int mode_f, mode_b;         // per direction: 0 = first pass (from pi / uniform, stores), 1 = re-run pass, 2 = light pass (float,
                                 // store-free: only the chunk's end vector is produced - history for the passes that follow)
+    int halo = 0;               // first pass only: every chunk is entered through its halo (Chunk::h0 / h1) instead of from pi / uniform
     long long *dbg;             // optional [8] (SMCPP_DEBUG_CYCLES): shader-clock / 100 MHz ticks / positions of chunk 1, pass 0
     // light passes on COARSE chunks handing over to the four-chains-per-wavefront kernels (chains_ss4.hpp): a coarse chunk is
     // Chunk::pad & 0xFFFFFF .. + (Chunk::pad >> 24) - 1 of the fine list; a direction's LAST light pass also writes the vector
@@ -422,6 +423,11 @@ __device__ __forceinline__ double ss_eig_apply(const SsEigC &c, const double *ta
     return ss_eig_matvec(c, tab, Mp, ek, w0 + 1, sx, lp, lp < 64 / c.G ? u : 0.0);
 }
 
+template <int NPL, bool ALLLDS>
+__device__ __forceinline__ void ss_fwd_light_rows(const SsArgs &a, const double *sE, long long base, int first, int last, int lane, float (&x)[NPL]);
+template <int NPL, bool ALLLDS>
+__device__ __forceinline__ void ss_bwd_light_rows(const SsArgs &a, const double *sE, long long base, int rhi, int rlo, int lane, float (&b)[NPL]);
+
 template <int NPL, bool RERUN, bool HYB, bool ALLLDS>
 __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
@@ -444,6 +450,32 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
 #pragma unroll
         for (int k = 0; k < NPL; ++k) x[k] = live[k] ? (double)src[st[k]] : 0.0;
     }
+    // Halo (first pass): the rows h0+1 .. r0 of the neighbour are walked first - h0+1 .. h1 in float, h1+1 .. r0 by the very loop
+    // below with its stores off - so that the vector at r0 is the neighbour's end vector to the certificate's tolerance
+    const bool halo = !RERUN && !HYB && a.halo && ch.h0 < ch.r0;
+    const int rbeg = halo ? ch.h1 : ch.r0;
+    const int jst = ch.r0 - rbeg;                  // the iteration that finishes row r0 (0 without a halo)
+    if (halo && ch.h0 < ch.h1) {
+        float xf[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) xf[k] = (float)x[k];
+        ss_fwd_light_rows<NPL, ALLLDS>(a, sE, ch.base, ch.h0, ch.h1, lane, xf);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) x[k] = live[k] ? (double)xf[k] : 0.0;
+        if (jst == 0) {
+            // (no fp64 part: the float halo ends on row r0 itself - its normalised, floored vector is what this chunk starts from)
+            double part = 0.0;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) part += x[k];
+            const double iv = 1.0 / wave_sum_dpp(part);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const float an = live[k] ? fmaxf((float)(x[k] * iv), 1e-10f) : 0.f;
+                x[k] = (double)an;
+                if (stor[k]) a.used_f[(size_t)c * Mp + st[k]] = an;
+            }
+        }
+    }
     if (RERUN && !a.full_f) {
         bool diff = false;
 #pragma unroll
@@ -458,8 +490,10 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
             return;
         }
     }
+    if (!halo) {
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) if (stor[k]) a.used_f[(size_t)c * Mp + st[k]] = (float)x[k];
+        for (int k = 0; k < NPL; ++k) if (stor[k]) a.used_f[(size_t)c * Mp + st[k]] = (float)x[k];
+    }
     if (lane == 0) a.changed_f[pass] = 1;
     if (ch.first) {
 #pragma unroll
@@ -468,12 +502,12 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     }
     SsFwdC<NPL> cst;
     ss_load_fwd<NPL>(a, lane, cst);
-    const int2 *rd = a.rowdesc + ch.base + ch.r0 + 1;          // descriptor of iteration j (row ell = r0 + 1 + j)
-    const int nrows = ch.r1 - ch.r0;
+    const int2 *rd = a.rowdesc + ch.base + rbeg + 1;           // descriptor of iteration j (row ell = rbeg + 1 + j)
+    const int nrows = ch.r1 - rbeg;
     int2 dcur = rd[lane], dnxt = rd[64 + lane];
     ss_desc_settle(dcur); ss_desc_settle(dnxt);
-    float *arow = a.alpha + (size_t)(ch.base + ch.r0) * Mp;    // row ell - 1 of iteration j is arow + j Mp
-    double *crow = a.cnorm + ch.base + ch.r0;
+    float *arow = a.alpha + (size_t)(ch.base + rbeg) * Mp;     // row ell - 1 of iteration j is arow + j Mp
+    double *crow = a.cnorm + ch.base + rbeg;
     double e[NPL];
     ss_emission<NPL, false, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
     constexpr bool hyb = HYB && NPL == 1;
@@ -555,9 +589,15 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
                     }
                 if (!__any(bad)) { merged = true; break; }
             }
+            if (j > jst) {
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) if (stor[k]) arow[(size_t)j * Mp + st[k]] = an[k];
-            if (lane == 0) crow[j] = S;
+                for (int k = 0; k < NPL; ++k) if (stor[k]) arow[(size_t)j * Mp + st[k]] = an[k];
+                if (lane == 0) crow[j] = S;
+            } else if (j == jst) {
+                // (halo only: row r0 belongs to the neighbour; what this chunk starts from is what the certificate compares)
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) if (stor[k]) a.used_f[(size_t)c * Mp + st[k]] = an[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
@@ -634,6 +674,23 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
 #pragma unroll
         for (int k = 0; k < NPL; ++k) b[k] = live[k] ? (fresh ? 1.0 / (double)M : src[st[k]]) : 0.0;
     }
+    // Halo (first pass): rows h0 .. r1+1 of the neighbour first - h0 .. h1+1 in float, h1 .. r1+1 by the loop below with its
+    // stores off; at row r1 the vector is normalised (as a chunk's end vector is) and becomes what the certificate compares
+    const bool halo = !RERUN && !HYB && a.halo && ch.h0 > ch.r1;
+    const int rend = halo ? ch.h1 : ch.r1;
+    const int jst = rend - ch.r1;
+    if (halo && ch.h0 > ch.h1) {
+        float bf_[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) bf_[k] = (float)b[k];
+        ss_bwd_light_rows<NPL, ALLLDS>(a, sE, ch.base, ch.h0, ch.h1, lane, bf_);
+        float pt = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) pt += live[k] ? bf_[k] : 0.f;
+        const float iv = 1.f / wave_sum_dpp(pt);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) b[k] = live[k] ? (double)(bf_[k] * iv) : 0.0;
+    }
     if (RERUN && !a.full_b) {
         bool diff = false;
 #pragma unroll
@@ -648,16 +705,18 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
             return;
         }
     }
+    if (!halo) {
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) if (stor[k]) a.used_b[(size_t)c * Mp + st[k]] = b[k];
+        for (int k = 0; k < NPL; ++k) if (stor[k]) a.used_b[(size_t)c * Mp + st[k]] = b[k];
+    }
     if (lane == 0) a.changed_b[pass] = 1;
     SsBwdC<NPL> cst;
     ss_load_bwd<NPL>(a, lane, cst);
-    const int2 *rd = a.rowdesc + ch.base + ch.r1;               // descriptor of iteration j (row ell = r1 - j) is rd[-j]
-    const int nrows = ch.r1 - ch.r0;
+    const int2 *rd = a.rowdesc + ch.base + rend;                // descriptor of iteration j (row ell = rend - j) is rd[-j]
+    const int nrows = rend - ch.r0;
     int2 dcur = rd[-lane], dnxt = rd[-64 - lane];
     ss_desc_settle(dcur); ss_desc_settle(dnxt);
-    double *brow = a.beta + (size_t)(ch.base + ch.r1) * Mp;     // row ell of iteration j is brow - j Mp
+    double *brow = a.beta + (size_t)(ch.base + rend) * Mp;      // row ell of iteration j is brow - j Mp
     double e[NPL];
     ss_emission<NPL, true, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
     constexpr bool hyb = HYB && NPL == 1;
@@ -694,8 +753,22 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
                 }
             if (!__any(bad)) { merged = true; break; }
         }
+        if (halo && j == jst) {
+            // the halo has reached row r1: normalised like a chunk's end vector - the start vector of this chunk's own rows
+            double part = 0.0;
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) if (stor[k]) brow[-(ptrdiff_t)j * Mp + st[k]] = b[k];
+            for (int k = 0; k < NPL; ++k) part += live[k] ? b[k] : 0.0;
+            const double iv = 1.0 / wave_sum_dpp(part);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                b[k] = live[k] ? b[k] * iv : 0.0;
+                if (stor[k]) a.used_b[(size_t)c * Mp + st[k]] = b[k];
+            }
+        }
+        if (j >= jst) {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) if (stor[k]) brow[-(ptrdiff_t)j * Mp + st[k]] = b[k];
+        }
         if (hyb && span > a.hyb_th) {
             // ---- hybrid row: b <- P^-T (d~^s o (P^T b)), renormalised (every consumer of beta is scale free) ----
             const double bin = live[0] ? b[0] : 0.0;
@@ -889,6 +962,94 @@ __device__ __forceinline__ void ss_emission_f(const SsArgs &a, const double *sE,
     ss_emission<NPL, BWD, ALLLDS>(a, sE, slot, lane, ed);
 #pragma unroll
     for (int k = 0; k < NPL; ++k) e[k] = (float)ed[k];
+}
+
+// float, store-free steps of the forward chain over rows first+1 .. last of the contig at `base`: x on entry = the vector at row
+// `first`, on return the (un-normalised) vector at row `last`.  The halo of a first pass (ss_forward_wave).
+template <int NPL, bool ALLLDS>
+__device__ __forceinline__ void ss_fwd_light_rows(const SsArgs &a, const double *sE, long long base, int first, int last, int lane,
+                                                  float (&x)[NPL]) {
+    SsLightC<NPL> cst;
+    ss_load_light<NPL, false>(a, lane, cst);
+    const int2 *rd = a.rowdesc + base + first + 1;
+    const int nrows = last - first;
+    int2 dcur = rd[lane], dnxt = rd[64 + lane];
+    ss_desc_settle(dcur); ss_desc_settle(dnxt);
+    float e[NPL];
+    ss_emission_f<NPL, false, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
+    ss_vm_drain();
+    for (int j = 0; j < nrows; ++j) {
+        const int jl = j & 63;
+        const int span = __builtin_amdgcn_readlane(dcur.y, jl);
+        if (jl == 63) { dcur = dnxt; dnxt = rd[j + 65 + lane]; ss_desc_settle(dnxt); }
+        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
+        float en[NPL], y[NPL], S;
+        ss_emission_f<NPL, false, ALLLDS>(a, sE, slot_n, lane, en);
+        ss_fwd_step_f<NPL>(cst, x, e, y, S);
+        const float inv = __builtin_amdgcn_rcpf(S);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) x[k] = y[k] * inv;
+        float S2;
+        int t = 1;
+        for (; t + 1 < span; t += 2) {
+            ss_fwd_step_f<NPL>(cst, x, e, y, S2);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) x[k] = y[k];
+            ss_fwd_step_f<NPL>(cst, x, e, y, S2);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) x[k] = y[k];
+        }
+        if (t < span) {
+            ss_fwd_step_f<NPL>(cst, x, e, y, S2);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) x[k] = y[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) e[k] = en[k];
+    }
+}
+// ... and of the backward chain over rows rhi .. rlo+1 (b on entry = the vector at row rhi, on return at row rlo)
+template <int NPL, bool ALLLDS>
+__device__ __forceinline__ void ss_bwd_light_rows(const SsArgs &a, const double *sE, long long base, int rhi, int rlo, int lane,
+                                                  float (&b)[NPL]) {
+    SsLightC<NPL> cst;
+    ss_load_light<NPL, true>(a, lane, cst);
+    const int2 *rd = a.rowdesc + base + rhi;
+    const int nrows = rhi - rlo;
+    int2 dcur = rd[-lane], dnxt = rd[-64 - lane];
+    ss_desc_settle(dcur); ss_desc_settle(dnxt);
+    float e[NPL];
+    ss_emission_f<NPL, true, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
+    ss_vm_drain();
+    for (int j = 0; j < nrows; ++j) {
+        const int jl = j & 63;
+        const int span = __builtin_amdgcn_readlane(dcur.y, jl);
+        if (jl == 63) { dcur = dnxt; dnxt = rd[-(j + 65) - lane]; ss_desc_settle(dnxt); }
+        const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
+        float en[NPL], y[NPL], Sw;
+        ss_emission_f<NPL, true, ALLLDS>(a, sE, slot_n, lane, en);
+        ss_bwd_step_f<NPL>(cst, b, e, y, Sw);
+        const float inv = __builtin_amdgcn_rcpf(Sw);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) b[k] = y[k] * inv;
+        float S2;
+        int t = 1;
+        for (; t + 1 < span; t += 2) {
+            ss_bwd_step_f<NPL>(cst, b, e, y, S2);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) b[k] = y[k];
+            ss_bwd_step_f<NPL>(cst, b, e, y, S2);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) b[k] = y[k];
+        }
+        if (t < span) {
+            ss_bwd_step_f<NPL>(cst, b, e, y, S2);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) b[k] = y[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) e[k] = en[k];
+    }
 }
 
 template <int NPL, bool ALLLDS>

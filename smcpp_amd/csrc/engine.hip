@@ -486,6 +486,7 @@ struct smcpp_im {
     // hybrid scan chains (un-binned data): rows whose span exceeds ss_hyb_th take ONE eigen-power step inside the scan kernel
     // (chains_ss.hpp); they cost about SS_HYB_COST scan positions each, which is what the chunk list is balanced on
     bool ss_hybrid = false;
+    bool ss_halo = false;                  // the first pass of the scan chains walks into every chunk from a halo (make_chunks)
     int ss_hyb_th = 0x7fffffff;
     static constexpr int SS_HYB_COST = 8;
     long long ss_row_cost(int span) const { return (ss_hybrid && span > ss_hyb_th) ? SS_HYB_COST : span; }
@@ -915,7 +916,7 @@ void smcpp_im::make_chunks() {
                 const RowInfo &ri = rowinfo[(size_t)contig_base[c] + i];
                 cpos[c] += ri.gid < 0 ? 1 : ss_row_cost(groups[ri.gid].span);
             }
-        auto cut = [&](long long nslots, long long floor_bins, std::vector<Chunk> &out) {
+        auto cut = [&](long long nslots, long long floor_bins, std::vector<Chunk> &out, bool bwd, long long halo_l, long long halo_d) {
             // Chunks per contig: NEVER more chunks than wavefront slots in total (a launch of 1046 wavefronts on 1024 SIMDs puts two
             // on some of them, and the kernel then lasts as long as those take: whole genome, 22 contigs each rounded up, +27 %).
             // Start from the rounded-down share of every contig and hand the remaining slots, one at a time, to the contig whose
@@ -944,23 +945,61 @@ void smcpp_im::make_chunks() {
                     ch.base = contig_base[c];
                     ch.r0 = prev; ch.r1 = r1; ch.contig = c;
                     ch.first = (j == 0); ch.last = (j == nc - 1); ch.pad = 0;
+                    // halo rows (positions counted on this contig's cumulative costs): forward chunks look back, backward ones ahead
+                    if (bwd) {
+                        const long long e1 = cum[r1] + halo_d, e0 = e1 + halo_l;
+                        ch.h1 = (int)std::min<long long>(L, std::lower_bound(cum.begin(), cum.end(), e1) - cum.begin());
+                        ch.h0 = (int)std::min<long long>(L, std::lower_bound(cum.begin(), cum.end(), e0) - cum.begin());
+                        if (halo_l + halo_d == 0 || ch.last) ch.h0 = ch.h1 = r1;
+                    } else {
+                        const long long e1 = cum[prev] - halo_d, e0 = e1 - halo_l;
+                        ch.h1 = e1 <= 0 ? 0 : (int)(std::upper_bound(cum.begin(), cum.end(), e1) - cum.begin()) - 1;
+                        ch.h0 = e0 <= 0 ? 0 : (int)(std::upper_bound(cum.begin(), cum.end(), e0) - cum.begin()) - 1;
+                        ch.h1 = std::min(ch.h1, prev); ch.h0 = std::min(ch.h0, ch.h1);
+                        if (halo_l + halo_d == 0 || ch.first) ch.h0 = ch.h1 = prev;
+                    }
                     out.push_back(ch);
                     prev = r1;
                 }
             }
         };
+        // Halo pass (chains_ss.hpp): with several chunks per contig every wavefront first walks into its chunk from its neighbour's
+        // rows - `light` positions in float, then `dbl` in fp64, neither stored - so that ONE launch leaves rows that are already
+        // exact to the certificate's tolerance (the chains forget with an e-fold of ~240 positions forward, ~340 backward: 11.5 +
+        // 3.3 e-folds), instead of two store-free light passes over the WHOLE chunk, a full pass and a merge re-run.
+        // Measured (profiles/r04_e_halo_probe.log): on one 100 Mbp contig at M <= 64 the halo is as long as two chunks - the same
+        // history the two light passes walk - so it only trades the merge re-run against chunks of unequal length: 0.92 ms against
+        // 0.87; with several states per lane (M > 64), where a light position costs relatively more, it wins (c5: 1.45 against 1.64 ms).
+        // Default: M > 64 only; SMCPP_SS_HALO = 1 / 0 forces it.
+        ss_halo = !ss4 && !ss_hybrid && (getenv("SMCPP_SS_HALO") ? atoi(getenv("SMCPP_SS_HALO")) != 0 : NPL >= 2);
+        auto env_ll = [](const char *nm, long long dflt) { const char *e = getenv(nm); return e ? atoll(e) : dflt; };
+        const long long hlf = ss_halo ? env_ll("SMCPP_HALO_LF", 2800) : 0, hdf = ss_halo ? env_ll("SMCPP_HALO_DF", 800) : 0,
+                        hlb = ss_halo ? env_ll("SMCPP_HALO_LB", 3900) : 0, hdb = ss_halo ? env_ll("SMCPP_HALO_DB", 1100) : 0;
         if (ss4) {
-            cut(waves * 2, 512, chunks);          // fine chunks: four chains per wavefront, half the wavefronts per direction
+            cut(waves * 2, 512, chunks, false, 0, 0);          // fine chunks: four chains per wavefront, half the wavefronts per direction
             chunks_b = chunks;
         } else {
             // the forward chain gets SMCPP_SS_FWD_SHARE of the wavefronts.  Default one half: the backward chain's light position
             // costs 38 instructions against 25, but the fp64 passes of the two directions take the same time (forward: stores, the
             // reciprocal and the feedback of the stored vector per row), and measured on the headline 0.45 / 0.42 / 0.38 / 0.34 lose
             // 6 / 12 / 28 / 37 % of chain time against 0.5
-            static const double share = getenv("SMCPP_SS_FWD_SHARE") ? atof(getenv("SMCPP_SS_FWD_SHARE")) : 0.5;
+            // (halo pass: the backward wavefronts carry the longer halo and the dearer position, so they get more, shorter chunks:
+            // per wavefront halo_f + 53 P / c_f = halo_b + 59 P / c_b instructions with c_f + c_b = waves)
+            double dflt_share = 0.5;
+            if (ss_halo && total_bins > 0) {
+                const double Hf = 25.0 * hlf + 53.0 * hdf, Hb = 29.0 * hlb + 59.0 * hdb, P = (double)total_bins, W = (double)waves;
+                double lo = 0.05, hi = 0.95;
+                for (int it = 0; it < 40; ++it) {
+                    const double m = 0.5 * (lo + hi);
+                    const double f = Hf + 53.0 * P / (m * W), b = Hb + 59.0 * P / ((1.0 - m) * W);
+                    if (f > b) lo = m; else hi = m;
+                }
+                dflt_share = std::min(0.5, std::max(0.25, 0.5 * (lo + hi)));
+            }
+            const double share = getenv("SMCPP_SS_FWD_SHARE") ? atof(getenv("SMCPP_SS_FWD_SHARE")) : dflt_share;
             const long long nf = std::max<long long>(1, (long long)(share * (double)waves + 0.5));
-            cut(nf, 1024, chunks);
-            cut(std::max<long long>(1, waves - nf), 1024, chunks_b);
+            cut(nf, 1024, chunks, false, hlf, hdf);
+            cut(std::max<long long>(1, waves - nf), 1024, chunks_b, true, hlb, hdb);
         }
         max_pass = max_chunks_per_contig + 3 + 4 + 2;  // (+4: light passes, +2: a warm start numbers its passes from 1 or 2)
         build_coarse_chunks();
@@ -990,12 +1029,15 @@ void smcpp_im::make_chunks() {
             ch.first = (j == 0);
             ch.last = (j == nc - 1);
             ch.pad = 0;
+            ch.h0 = ch.h1 = ch.r0;               // (forward list; the backward copy below is given r1: no halo on this path)
             chunks.push_back(ch);
         }
     }
     max_pass = max_chunks_per_contig + 3;   // (+1: the full pass that follows an eigen-free pre-pass)
     if (ss_static) max_pass += 4 + 2;       // light passes of the scan chains; a warm start numbers its passes from 1 or 2
     chunks_b = chunks;
+    for (Chunk &cb : chunks_b) cb.h0 = cb.h1 = cb.r1;
+    ss_halo = false;
     build_coarse_chunks();
 }
 
@@ -2658,6 +2700,10 @@ void smcpp_im::ss_launch_initial() {
         if ((ss4 ? chunks1.size() : chunks_b.size()) <= (size_t)n_contigs) ss_light_b = 0;
     }
     if (ss_hybrid) ss_light_f = ss_light_b = 0;      // (the light passes have no eigen-power step; un-binned inputs have long chunks)
+    // halo pass: the first pass enters every chunk through its halo and stores rows that are already exact; no light passes
+    const bool use_halo = ss_halo && !(warm_start && ss_warm_valid) && chunks.size() > (size_t)n_contigs && chunks_b.size() > (size_t)n_contigs;
+    if (use_halo) ss_light_f = ss_light_b = 0;
+    a.halo = use_halo ? 1 : 0;
     ss_pass0 = 0;
     if (warm_start && ss_warm_valid && !ss4 && chunks.size() > (size_t)n_contigs && chunks_b.size() > (size_t)n_contigs) {
         // the boundary vectors of the previous E-step are exact for ITS parameters, i.e. off by the parameter step instead of by

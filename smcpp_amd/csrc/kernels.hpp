@@ -25,6 +25,11 @@ struct Chunk {
     int first;        // r0 == 0
     int last;         // r1 == L
     int pad;
+    // HALO of the scan chains' first pass (chains_ss.hpp): instead of starting at its own first row from pi / the uniform vector
+    // the chunk's wavefront walks into it from rows of its NEIGHBOUR - forward: rows h0+1 .. h1 in float without stores, rows
+    // h1+1 .. r0 in fp64 without stores (h0 <= h1 <= r0); backward: rows h0 .. h1+1 in float, h1 .. r1+1 in fp64 (h0 >= h1 >= r1).
+    // h0 == h1 == r0 (forward) / r1 (backward): no halo.
+    int h0 = 0, h1 = 0;
 };
 
 struct RowInfo {      // per global row index (entry for ell = 0 of each contig is unused)

@@ -72,6 +72,9 @@ cdef extern from "smcpp_engine.h":
                                      double *avg_ct_out, double *davg_ct_out)
     int smcpp_host_random_coal_times(int Kp, const double *a, const double *s, double t1, double t2, int K,
                                      const unsigned long long *seeds, double *t_out, double *R_out)
+    int smcpp_host_joint_csfs(int n1, int n2, int a1, int a2, int n_hs, const double *hs, int K1, const double *pa1,
+                              const double *ps1, const double *da1, int K2, const double *pa2, const double *ps2,
+                              const double *da2, int nder, double split, int Kmc, double *out, double *dout) nogil
     int smcpp_host_raw_sfs(int n, int Kp, const double *a, const double *da, int nder, const double *s, double t1,
                            double t2, int below_only, double *sfs, double *dsfs)
 
@@ -526,3 +529,35 @@ def raw_sfs(model, int n, double t1, double t2, below_only=False):
                               &out[0, 0], &dout[0, 0, 0] if nder else NULL))
     _check_abort()
     return _ad_array(out, dout, list(model.dlist) if nder else [])
+
+
+# Used for testing purposes only
+def joint_csfs(int n1, int n2, int a1, int a2, model, hidden_states, int K=10):
+    """`joint_csfs` of the reference (smcpp/_smcpp.pyx:416-437): per hidden state the joint conditioned SFS
+    [(a1 + 1) x (n1 + 1) x (a2 + 1) x (n2 + 1)] of a two-population model (JointCSFS, src/jcsfs.cpp:219-420), entries as ad
+    numbers in `model.dlist` order when the model carries derivatives."""
+    assert (a1 == 2 and a2 == 0) or (a1 == a2 == 1)
+    dl = list(model.dlist)
+    a1v, d1, nder, s1v = _params(model.model1.stepwise_values(), model.model1.s, dl)
+    a2v, d2, _nd2, s2v = _params(model.model2.stepwise_values(), model.model2.s, dl)
+    cdef np.ndarray[double, ndim=1] hs = aca(np.array(list(hidden_states), dtype=np.float64))
+    cdef np.ndarray[double, ndim=1] pa1 = a1v, ps1 = s1v, pa2 = a2v, ps2 = s2v
+    cdef np.ndarray[double, ndim=2] da1 = d1, da2 = d2
+    cdef int M = len(hs) - 1, nd = nder
+    cdef long sz = (a1 + 1) * (n1 + 1) * (a2 + 1) * (n2 + 1)
+    cdef np.ndarray[double, ndim=2] out = np.zeros((M, sz))
+    cdef np.ndarray[double, ndim=3] dout = np.zeros((M, sz, max(nd, 1)))
+    cdef double split = float(model.split)
+    cdef int rc
+    with nogil:
+        rc = smcpp_host_joint_csfs(n1, n2, a1, a2, M + 1, &hs[0], pa1.shape[0], &pa1[0], &ps1[0], &da1[0, 0] if nd else NULL,
+                                   pa2.shape[0], &pa2[0], &ps2[0], &da2[0, 0] if nd else NULL, nd, split, K, &out[0, 0],
+                                   &dout[0, 0, 0] if nd else NULL)
+    _check(rc)
+    _check_abort()
+    ret = []
+    for i in range(M):
+        mat = _ad_array(out[i], dout[i], dl if nd else [])
+        mat = np.asarray(mat).reshape(a1 + 1, n1 + 1, a2 + 1, n2 + 1)
+        ret.append(mat)
+    return ret

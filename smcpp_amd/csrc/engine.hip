@@ -183,7 +183,8 @@ struct DevPrep {
         if (d_in) (void)hipFree(d_in);
         if (h_flags) (void)hipHostFree(h_flags);
     }
-    static bool supported(int n) { return n >= 1 && smcpp_dev::CsfsScratch<smcpp_dev::D1>::count(n) * sizeof(smcpp_dev::D1) <= 150 * 1024; }
+    typedef smcpp_dev::DN<4> SD;             // scalar of the derivative kernels: value + four directions per thread
+    static bool supported(int n) { return n >= 1 && smcpp_dev::CsfsScratch<SD>::count(n) * sizeof(SD) <= 150 * 1024; }
 
     void set_static(const smcpp_host::CsfsTables &t) {
         n = t.n;
@@ -253,7 +254,7 @@ struct DevPrep {
     void run(const smcpp_host::RateFunctionT<HS> &eta, const std::vector<HS> &act, double theta, double alpha, int nder,
              hipStream_t s) {
         if (!static_ready || !keys_ready) throw std::runtime_error("internal: device preparation without its tables");
-        const int K = eta.K, nd = std::max(1, nder);
+        const int K = eta.K;
         last_nder = nder;
         // ---- pack: doubles ts [K+1] | ada_v [K] | R_v [K+1] | act_v [M] | ada_d [nder][K] | R_d [nder][K+1] | act_d [nder][M]; ints hsi [M+1]
         const size_t ndbl = (size_t)(K + 1) + K + (K + 1) + M + (size_t)nder * (K + (K + 1) + M);
@@ -289,60 +290,57 @@ struct DevPrep {
         pm.hsi = reinterpret_cast<const int *>(bd + o);
         const smcpp_dev::PrepStatic ps = ps_view();
         const int C = 3 * (n + 1);
-        const size_t per = (size_t)2 * n * K + (size_t)(n + 1) * (K + 1);          // table entries per direction
-        const size_t ssz = nder > 0 ? 2 : 1;                                       // doubles per scalar
+        const int ng = nder > 0 ? (nder + 3) / 4 : 1;                               // direction groups (four directions per scalar)
+        const size_t per = smcpp_dev::Tables<double>::per_group(n, K);             // table entries per group
+        const size_t ssz = nder > 0 ? sizeof(SD) / sizeof(double) : 1;             // doubles per scalar
         smcpp_dev::PrepOut po;
         po.Mp = Mp; po.MS = MS;
         if (emulate) {
-            e_tab.assign(per * nd * ssz, 0.0);
+            e_tab.assign(per * ng * ssz, 0.0);
             if (nder) { e_sfs_d.assign((size_t)nder * M * C, 0.0); e_Eg_d.assign((size_t)nder * Kk * M, 0.0); }
-            po.sfs_v = e_sfs_v.data(); po.sfs_d = e_sfs_d.data(); po.Eg_v = e_Eg_v.data(); po.Eg_d = e_Eg_d.data();
+            po.sfs_v = e_sfs_v.data(); po.sfs_d = nder ? e_sfs_d.data() : nullptr; po.Eg_v = e_Eg_v.data(); po.Eg_d = nder ? e_Eg_d.data() : nullptr;
             e_flags[0] = e_flags[1] = e_flags[2] = 0;
             po.flags = e_flags;
             if (nder) {
-                smcpp_dev::Tables<smcpp_dev::D1> tb;
-                smcpp_dev::D1 *b = reinterpret_cast<smcpp_dev::D1 *>(e_tab.data());
-                tb.Ssuf = b; tb.Fsuf = b + (size_t)nd * n * K; tb.Ppre = b + (size_t)2 * nd * n * K;
+                smcpp_dev::Tables<SD> tb;
+                tb.carve(reinterpret_cast<SD *>(e_tab.data()), n, K, ng);
                 smcpp_dev::emulate_tables(pm, tb);
                 smcpp_dev::emulate_csfs(pm, ps, po, tb);
             } else {
                 smcpp_dev::Tables<double> tb;
-                double *b = e_tab.data();
-                tb.Ssuf = b; tb.Fsuf = b + (size_t)n * K; tb.Ppre = b + (size_t)2 * n * K;
+                tb.carve(e_tab.data(), n, K, 1);
                 smcpp_dev::emulate_tables(pm, tb);
                 smcpp_dev::emulate_csfs(pm, ps, po, tb);
             }
             return;
         }
-        d_tab.alloc(per * nd * ssz);
+        d_tab.alloc(per * ng * ssz);
         if (nder) { d_sfs_d.alloc((size_t)nder * M * C); d_Eg_d.alloc((size_t)nder * Kk * M); }
-        po.sfs_v = d_sfs_v.p; po.sfs_d = d_sfs_d.p; po.Eg_v = d_Eg_v.p; po.Eg_d = d_Eg_d.p;
+        po.sfs_v = d_sfs_v.p; po.sfs_d = nder ? d_sfs_d.p : nullptr; po.Eg_v = d_Eg_v.p; po.Eg_d = nder ? d_Eg_d.p : nullptr;
         po.El_v = d_El.p; po.Es_v = MS > 0 ? d_Es.p : nullptr;
         h_flags[0] = h_flags[1] = h_flags[2] = 0;
         po.flags = d_flags_view;
         HIPCHK(hipMemcpyAsync(d_in, hb, bytes, hipMemcpyHostToDevice, s));
         const int pairs = (n + 1) * n;
         const int nt = std::max(64 * ceil_div(3 * n + 2, 64), std::min(1024, 64 * ceil_div(pairs, 64)));
-        const int ntt = std::min(1024, 64 * ceil_div((2 * n + 1) * K, 64));
+        const int ntt = std::min(1024, 64 * ceil_div(K, 64));
         if (nder) {
-            typedef smcpp_dev::D1 S;
+            typedef SD S;
             smcpp_dev::Tables<S> tb;
-            S *b = reinterpret_cast<S *>(d_tab.p);
-            tb.Ssuf = b; tb.Fsuf = b + (size_t)nd * n * K; tb.Ppre = b + (size_t)2 * nd * n * K;
+            tb.carve(reinterpret_cast<S *>(d_tab.p), n, K, ng);
             const size_t lds = smcpp_dev::CsfsScratch<S>::count(n) * sizeof(S);
             static bool once = false;
             if (!once) { HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_csfs<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
-            hipLaunchKernelGGL(smcpp_dev::k_prep_tables<S>, dim3(nd), dim3(ntt), 0, s, pm, tb);
-            hipLaunchKernelGGL(smcpp_dev::k_prep_csfs<S>, dim3(M, nd), dim3(nt), lds, s, pm, ps, po, tb);
+            hipLaunchKernelGGL(smcpp_dev::k_prep_tables<S>, dim3(ng, 2 * n + 1), dim3(ntt), 0, s, pm, tb);
+            hipLaunchKernelGGL(smcpp_dev::k_prep_csfs<S>, dim3(M, ng), dim3(nt), lds, s, pm, ps, po, tb);
         } else {
             typedef double S;
             smcpp_dev::Tables<S> tb;
-            S *b = d_tab.p;
-            tb.Ssuf = b; tb.Fsuf = b + (size_t)n * K; tb.Ppre = b + (size_t)2 * n * K;
+            tb.carve(d_tab.p, n, K, 1);
             const size_t lds = smcpp_dev::CsfsScratch<S>::count(n) * sizeof(S);
             static bool once = false;
             if (!once) { HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_csfs<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
-            hipLaunchKernelGGL(smcpp_dev::k_prep_tables<S>, dim3(1), dim3(ntt), 0, s, pm, tb);
+            hipLaunchKernelGGL(smcpp_dev::k_prep_tables<S>, dim3(1, 2 * n + 1), dim3(ntt), 0, s, pm, tb);
             hipLaunchKernelGGL(smcpp_dev::k_prep_csfs<S>, dim3(M, 1), dim3(nt), lds, s, pm, ps, po, tb);
         }
         HIPCHK(hipGetLastError());
@@ -1640,7 +1638,8 @@ bool smcpp_im::q_device(double val[4], double *jac) {
             pl[3 * ps + (size_t)d * M + i] = tgen.dW[(size_t)i * nd + d];
         }
     HIPCHK(hipMemcpyAsync(q.d_in, hb, ndbl * sizeof(double), hipMemcpyHostToDevice, stream));
-    const size_t nout = (size_t)4 * (1 + nd);
+    const int nslice = 4;
+    const size_t nout = (size_t)4 * (1 + nd) * nslice;
     q.d_out.alloc(nout);
     if (nout > q.h_out_cap) {
         if (q.h_out) (void)hipHostFree(q.h_out);
@@ -1658,15 +1657,17 @@ bool smcpp_im::q_device(double val[4], double *jac) {
     a.mix_p2 = 1e-5 / (double)(M + 1);
     a.E_v = dprep->d_Eg_v.p; a.E_d = dprep->d_Eg_d.p;
     a.out = q.d_out.p;
+    a.nslice = nslice;
     const int nt = 1024;
     const size_t lds = (size_t)(2 * M + 4 * (nt / 64) * 2) * sizeof(double);
-    hipLaunchKernelGGL(smcpp_dev::k_q_reduce, dim3(1 + nd), dim3(nt), lds, stream, a);
+    hipLaunchKernelGGL(smcpp_dev::k_q_reduce, dim3(1 + nd, nslice), dim3(nt), lds, stream, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(q.h_out, q.d_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     dprep->check_flags();
-    for (int t = 0; t < 4; ++t) val[t] = q.h_out[t];
-    if (jac) for (int t = 0; t < 4; ++t) for (int d = 0; d < nd; ++d) jac[(size_t)t * nd + d] = q.h_out[(size_t)4 * (1 + d) + t];
+    auto slices = [&](int b, int t) { double r = 0.0; for (int sl = 0; sl < nslice; ++sl) r += q.h_out[((size_t)b * nslice + sl) * 4 + t]; return r; };
+    for (int t = 0; t < 4; ++t) val[t] = slices(0, t);
+    if (jac) for (int t = 0; t < 4; ++t) for (int d = 0; d < nd; ++d) jac[(size_t)t * nd + d] = slices(1 + d, t);
     return true;
 }
 

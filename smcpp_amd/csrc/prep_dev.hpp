@@ -29,47 +29,61 @@
 
 namespace smcpp_dev {
 
-// ---- value + one directional derivative (mirrors smcpp_host::Dual, prep.hpp) -------------------------------------------------
-struct D1 {
-    double v, d;
-    SMCPP_HD D1() : v(0.0), d(0.0) {}
-    SMCPP_HD D1(double x) : v(x), d(0.0) {}
-    SMCPP_HD D1(double x, double y) : v(x), d(y) {}
+// ---- value + N directional derivatives (mirrors smcpp_host::Dual, prep.hpp, operation by operation) ------------------------------
+// N directions ride in one thread: the value part (where the exponentials are) is evaluated once for all of them.
+template <int N>
+struct DN {
+    double v, d[N];
+    SMCPP_HD DN() : v(0.0) { for (int i = 0; i < N; ++i) d[i] = 0.0; }
+    SMCPP_HD DN(double x) : v(x) { for (int i = 0; i < N; ++i) d[i] = 0.0; }
 };
-SMCPP_HD D1 operator+(const D1 &a, const D1 &b) { return D1(a.v + b.v, a.d + b.d); }
-SMCPP_HD D1 operator-(const D1 &a, const D1 &b) { return D1(a.v - b.v, a.d - b.d); }
-SMCPP_HD D1 operator*(const D1 &a, const D1 &b) { return D1(a.v * b.v, a.d * b.v + a.v * b.d); }
-SMCPP_HD D1 operator/(const D1 &a, const D1 &b) { const double ib = 1 / b.v; const double v = a.v * ib; return D1(v, (a.d - v * b.d) * ib); }
-SMCPP_HD D1 operator-(const D1 &a) { return D1(-a.v, -a.d); }
-SMCPP_HD D1 operator+(const D1 &a, double b) { return D1(a.v + b, a.d); }
-SMCPP_HD D1 operator+(double b, const D1 &a) { return D1(a.v + b, a.d); }
-SMCPP_HD D1 operator-(const D1 &a, double b) { return D1(a.v - b, a.d); }
-SMCPP_HD D1 operator-(double b, const D1 &a) { return D1(-a.v + b, -a.d); }
-SMCPP_HD D1 operator*(const D1 &a, double b) { return D1(a.v * b, a.d * b); }
-SMCPP_HD D1 operator*(double b, const D1 &a) { return D1(a.v * b, a.d * b); }
-SMCPP_HD D1 operator/(const D1 &a, double b) { return a * (1.0 / b); }
-SMCPP_HD D1 operator/(double b, const D1 &a) { const double v = b / a.v; return D1(v, -v * a.d / a.v); }
-SMCPP_HD D1 &operator+=(D1 &a, const D1 &b) { a.v += b.v; a.d += b.d; return a; }
-SMCPP_HD D1 &operator*=(D1 &a, const D1 &b) { a = a * b; return a; }
-SMCPP_HD D1 &operator/=(D1 &a, const D1 &b) { a = a / b; return a; }
+#define SMCPP_DN_LOOP _Pragma("unroll") for (int i_ = 0; i_ < N; ++i_)
+template <int N> SMCPP_HD DN<N> operator+(const DN<N> &a, const DN<N> &b) { DN<N> r; r.v = a.v + b.v; SMCPP_DN_LOOP r.d[i_] = a.d[i_] + b.d[i_]; return r; }
+template <int N> SMCPP_HD DN<N> operator-(const DN<N> &a, const DN<N> &b) { DN<N> r; r.v = a.v - b.v; SMCPP_DN_LOOP r.d[i_] = a.d[i_] - b.d[i_]; return r; }
+template <int N> SMCPP_HD DN<N> operator*(const DN<N> &a, const DN<N> &b) { DN<N> r; r.v = a.v * b.v; SMCPP_DN_LOOP r.d[i_] = a.d[i_] * b.v + a.v * b.d[i_]; return r; }
+template <int N> SMCPP_HD DN<N> operator/(const DN<N> &a, const DN<N> &b) { DN<N> r; const double ib = 1 / b.v; r.v = a.v * ib; SMCPP_DN_LOOP r.d[i_] = (a.d[i_] - r.v * b.d[i_]) * ib; return r; }
+template <int N> SMCPP_HD DN<N> operator-(const DN<N> &a) { DN<N> r; r.v = -a.v; SMCPP_DN_LOOP r.d[i_] = -a.d[i_]; return r; }
+template <int N> SMCPP_HD DN<N> operator+(const DN<N> &a, double b) { DN<N> r(a); r.v += b; return r; }
+template <int N> SMCPP_HD DN<N> operator+(double b, const DN<N> &a) { DN<N> r(a); r.v += b; return r; }
+template <int N> SMCPP_HD DN<N> operator-(const DN<N> &a, double b) { DN<N> r(a); r.v -= b; return r; }
+template <int N> SMCPP_HD DN<N> operator-(double b, const DN<N> &a) { DN<N> r = -a; r.v += b; return r; }
+template <int N> SMCPP_HD DN<N> operator*(const DN<N> &a, double b) { DN<N> r; r.v = a.v * b; SMCPP_DN_LOOP r.d[i_] = a.d[i_] * b; return r; }
+template <int N> SMCPP_HD DN<N> operator*(double b, const DN<N> &a) { return a * b; }
+template <int N> SMCPP_HD DN<N> operator/(const DN<N> &a, double b) { return a * (1.0 / b); }
+template <int N> SMCPP_HD DN<N> operator/(double b, const DN<N> &a) { DN<N> r; r.v = b / a.v; SMCPP_DN_LOOP r.d[i_] = -r.v * a.d[i_] / a.v; return r; }
+template <int N> SMCPP_HD DN<N> &operator+=(DN<N> &a, const DN<N> &b) { a.v += b.v; SMCPP_DN_LOOP a.d[i_] += b.d[i_]; return a; }
+template <int N> SMCPP_HD DN<N> &operator*=(DN<N> &a, const DN<N> &b) { a = a * b; return a; }
+template <int N> SMCPP_HD DN<N> &operator/=(DN<N> &a, const DN<N> &b) { a = a / b; return a; }
 SMCPP_HD double m_exp(double x) { return ::exp(x); }
 SMCPP_HD double m_expm1(double x) { return ::expm1(x); }
 SMCPP_HD double m_log(double x) { return ::log(x); }
-SMCPP_HD D1 m_exp(const D1 &a) { const double e = ::exp(a.v); return D1(e, a.d * e); }
-SMCPP_HD D1 m_expm1(const D1 &a) { const double r = ::expm1(a.v); const double e = ::exp(a.v); return D1(r, a.d * e); }
-SMCPP_HD D1 m_log(const D1 &a) { return D1(::log(a.v), a.d / a.v); }
+template <int N> SMCPP_HD DN<N> m_exp(const DN<N> &a) { DN<N> r; r.v = ::exp(a.v); SMCPP_DN_LOOP r.d[i_] = a.d[i_] * r.v; return r; }
+template <int N> SMCPP_HD DN<N> m_expm1(const DN<N> &a) { DN<N> r; r.v = ::expm1(a.v); const double e = ::exp(a.v); SMCPP_DN_LOOP r.d[i_] = a.d[i_] * e; return r; }
+template <int N> SMCPP_HD DN<N> m_log(const DN<N> &a) { DN<N> r; r.v = ::log(a.v); SMCPP_DN_LOOP r.d[i_] = a.d[i_] / a.v; return r; }
 SMCPP_HD double sval(double x) { return x; }
-SMCPP_HD double sval(const D1 &x) { return x.v; }
-SMCPP_HD double sder(double) { return 0.0; }
-SMCPP_HD double sder(const D1 &x) { return x.d; }
-SMCPP_HD void mk(double &o, double v, double) { o = v; }
-SMCPP_HD void mk(D1 &o, double v, double d) { o.v = v; o.d = d; }
-// cascaded TwoSum accumulation of prep.hpp's accurate_sum: value compensated, derivative a plain sum
-struct AccD { double hi = 0.0, lo = 0.0, d = 0.0; };
+template <int N> SMCPP_HD double sval(const DN<N> &x) { return x.v; }
+// number of directions a scalar type carries, and its q-th derivative
+template <typename S> struct NDir { static constexpr int value = 0; };
+template <int N> struct NDir<DN<N>> { static constexpr int value = N; };
+SMCPP_HD double sder(double, int) { return 0.0; }
+template <int N> SMCPP_HD double sder(const DN<N> &x, int q) { return x.d[q]; }
+// load entry i of an array with derivative planes [nder][stride]: the directions of group `dir` are dir N .. dir N + N - 1
+SMCPP_HD void ldp(double &o, const double *v, const double *, int, int, int, int i) { o = v[i]; }
+template <int N> SMCPP_HD void ldp(DN<N> &o, const double *v, const double *d, int stride, int dir, int nder, int i) {
+    o.v = v[i];
+    SMCPP_DN_LOOP { const int q = dir * N + i_; o.d[i_] = (d && q < nder) ? d[(size_t)q * stride + i] : 0.0; }
+}
+// cascaded TwoSum accumulation of prep.hpp's accurate_sum: value compensated, derivatives plain sums
+template <typename S> struct AccT { double hi = 0.0, lo = 0.0; };
+template <int N> struct AccT<DN<N>> { double hi = 0.0, lo = 0.0, d[N]; SMCPP_HD AccT() { for (int i = 0; i < N; ++i) d[i] = 0.0; } };
+typedef AccT<double> AccD;
 SMCPP_HD void acc_add(AccD &a, double x) { const double t = a.hi + x, z = t - a.hi; a.lo += (a.hi - (t - z)) + (x - z); a.hi = t; }
-SMCPP_HD void acc_add(AccD &a, const D1 &x) { acc_add(a, x.v); a.d += x.d; }
+template <int N> SMCPP_HD void acc_add(AccT<DN<N>> &a, const DN<N> &x) {
+    const double t = a.hi + x.v, z = t - a.hi; a.lo += (a.hi - (t - z)) + (x.v - z); a.hi = t;
+    SMCPP_DN_LOOP a.d[i_] += x.d[i_];
+}
 SMCPP_HD void acc_get(const AccD &a, double &o) { o = a.hi + a.lo; }
-SMCPP_HD void acc_get(const AccD &a, D1 &o) { o.v = a.hi + a.lo; o.d = a.d; }
+template <int N> SMCPP_HD void acc_get(const AccT<DN<N>> &a, DN<N> &o) { o.v = a.hi + a.lo; SMCPP_DN_LOOP o.d[i_] = a.d[i_]; }
 
 SMCPP_HD long nC2(long n) { return n * (n - 1) / 2; }
 
@@ -105,80 +119,97 @@ struct PrepOut {
     // SFS is not a probability distribution, [2] an emission entry is so small that `span` scan steps would underflow
     int *flags = nullptr;
 };
+// Tables of k_prep_tables, per direction GROUP g (a group = the directions one scalar carries; one group for plain doubles), piece-
+// major so that the threads of a rate read and write neighbouring words:
+//   Ssuf [g][K][n]      Ppre [g][K+1][n+1]      and the per-piece terms the recurrences consume: Gt, Ft [g][K][n], Pt [g][K][n+1]
 template <typename S> struct Tables {
-    S *Ssuf = nullptr, *Fsuf = nullptr, *Ppre = nullptr;     // [nd][n][K], [nd][n][K], [nd][n+1][K+1]   (nd = max(1, nder))
+    S *Ssuf = nullptr, *Ppre = nullptr, *Gt = nullptr, *Ft = nullptr, *Pt = nullptr;
+    SMCPP_HD static size_t per_group(int n, int K) { return (size_t)3 * n * K + (size_t)(n + 1) * (K + 1) + (size_t)(n + 1) * K; }
+    SMCPP_HD void carve(S *base, int n, int K, int ng) {
+        Ssuf = base; base += (size_t)ng * n * K;
+        Ppre = base; base += (size_t)ng * (n + 1) * (K + 1);
+        Gt = base; base += (size_t)ng * n * K;
+        Ft = base; base += (size_t)ng * n * K;
+        Pt = base;
+    }
 };
 
-template <typename S> SMCPP_HD S ld(const double *v, const double *d, int i) { S r; mk(r, v[i], d ? d[i] : 0.0); return r; }
+template <typename S> SMCPP_HD S ld_ada(const PrepModel &pm, int dir, int m) { S r; ldp(r, pm.ada_v, pm.ada_d, pm.K, dir, pm.nder, m); return r; }
+template <typename S> SMCPP_HD S ld_R(const PrepModel &pm, int dir, int m) { S r; ldp(r, pm.R_v, pm.R_d, pm.K + 1, dir, pm.nder, m); return r; }
 
 // ---- k_prep_tables: phase 1 (one (rate, piece) term), phase 2 (the recurrences) ------------------------------------------------
 template <typename S>
 SMCPP_HD void tables_term(const PrepModel &pm, int dir, const Tables<S> &tb, int item) {
     const int K = pm.K, n = pm.n;
-    const double *ad_d = pm.nder ? pm.ada_d + (size_t)dir * K : nullptr, *R_d = pm.nder ? pm.R_d + (size_t)dir * (K + 1) : nullptr;
-    const int na = n * K;                      // above items (jr, m), then below items (jr, m)
+    const int na = n * K;                      // above items (m, jr), then below items (m, jr)
     if (item < na) {
-        const int jr = item / K, m = item % K;
-        S *G = tb.Ssuf + ((size_t)dir * n + jr) * K, *F = tb.Fsuf + ((size_t)dir * n + jr) * K;
-        if (m == 0) { G[0] = S(0.0); F[0] = S(0.0); return; }      // (slot m holds the term of piece m; piece 0 has none)
+        const int m = item / n, jr = item % n;
+        S *G = tb.Gt + ((size_t)dir * K + m) * n + jr, *F = tb.Ft + ((size_t)dir * K + m) * n + jr;
+        if (m == 0) { *G = S(0.0); *F = S(0.0); return; }      // (slot m holds the term of piece m; piece 0 has none)
         const double rate = (double)nC2(jr + 2);
-        const S ad = ld<S>(pm.ada_v, ad_d, m);
+        const S ad = ld_ada<S>(pm, dir, m);
         if (pm.ts[m + 1] < INFINITY) {
             const S em = m_expm1(-rate * ad * (pm.ts[m + 1] - pm.ts[m]));
-            G[m] = -em / (ad * rate);
-            F[m] = 1.0 + em;
-        } else { G[m] = 1.0 / (ad * rate); F[m] = S(0.0); }
+            *G = -em / (ad * rate);
+            *F = 1.0 + em;
+        } else { *G = 1.0 / (ad * rate); *F = S(0.0); }
         return;
     }
     item -= na;
     if (item >= (n + 1) * K) return;
-    const int jr = item / K, m = item % K;
-    S *P = tb.Ppre + ((size_t)dir * (n + 1) + jr) * (K + 1);
+    const int m = item / (n + 1), jr = item % (n + 1);
+    S *P = tb.Pt + ((size_t)dir * K + m) * (n + 1) + jr;
     const long ratel = nC2(jr + 2) - 1;
-    if (ratel == 0) { P[m + 1] = S(pm.ts[m + 1]); return; }
+    if (ratel == 0) { *P = S(pm.ts[m + 1]); return; }
     const double rate = (double)ratel;
-    const S ad = ld<S>(pm.ada_v, ad_d, m);
-    S g = m_exp(-rate * ld<S>(pm.R_v, R_d, m));
+    const S ad = ld_ada<S>(pm, dir, m);
+    S g = m_exp(-rate * ld_R<S>(pm, dir, m));
     if (pm.ts[m + 1] < INFINITY) g *= -m_expm1(-rate * ad * (pm.ts[m + 1] - pm.ts[m]));
     g /= ad * rate;
-    P[m + 1] = g;
+    *P = g;
 }
 template <typename S>
 SMCPP_HD void tables_scan(const PrepModel &pm, int dir, const Tables<S> &tb, int t) {
     const int K = pm.K, n = pm.n;
     if (t < n) {
-        S *G = tb.Ssuf + ((size_t)dir * n + t) * K;
-        const S *F = tb.Fsuf + ((size_t)dir * n + t) * K;
+        const S *__restrict__ G = tb.Gt + (size_t)dir * K * n + t, *__restrict__ F = tb.Ft + (size_t)dir * K * n + t;
+        S *__restrict__ O = tb.Ssuf + (size_t)dir * K * n + t;
         S acc(0.0);                              // Ssuf[K-1] = 0
+#pragma unroll 8
         for (int m = K - 1; m >= 1; --m) {
-            const S g = G[m];
-            G[m] = acc;
-            if (pm.ts[m + 1] < INFINITY) acc = g + F[m] * acc; else acc = g;
+            const S g = G[(size_t)m * n], f = F[(size_t)m * n];
+            O[(size_t)m * n] = acc;
+            if (pm.ts[m + 1] < INFINITY) acc = g + f * acc; else acc = g;
         }
-        G[0] = acc;
+        O[0] = acc;
         return;
     }
     t -= n;
     if (t >= n + 1) return;
-    S *P = tb.Ppre + ((size_t)dir * (n + 1) + t) * (K + 1);
-    P[0] = S(0.0);
-    if (nC2(t + 2) - 1 == 0) return;             // (filled with ts[m+1] by phase 1)
+    const S *__restrict__ P = tb.Pt + (size_t)dir * K * (n + 1) + t;
+    S *__restrict__ O = tb.Ppre + (size_t)dir * (K + 1) * (n + 1) + t;
+    O[0] = S(0.0);
+    if (nC2(t + 2) - 1 == 0) {                   // (rate 0: the prefix sums are the break points themselves)
+        for (int m = 0; m < K; ++m) O[(size_t)(m + 1) * (n + 1)] = P[(size_t)m * (n + 1)];
+        return;
+    }
     S acc(0.0);
-    for (int m = 0; m < K; ++m) { acc = acc + P[m + 1]; P[m + 1] = acc; }
+#pragma unroll 8
+    for (int m = 0; m < K; ++m) { acc = acc + P[(size_t)m * (n + 1)]; O[(size_t)(m + 1) * (n + 1)] = acc; }
 }
 
-// ---- k_prep_csfs: the work of one workgroup (hidden state h, direction dir) --------------------------------------------------
+// ---- k_prep_csfs: the work of one workgroup (hidden state h, direction group dir) ----------------------------------------------
 // `sh` = the workgroup's scratch (LDS on the device): Ca [(n+1) n], A, A1, B, El [n+1], ert, e1 [n], tmp0, tmp2, below [n+1],
-// out [3 (n+1)], e2 [2]
+// out [3 (n+1)], e2 [2], ldn [1]
 template <typename S> struct CsfsScratch {
-    S *Ca, *A, *A1, *B, *El, *ert, *e1, *tmp0, *tmp2, *below, *out, *e2;
-    SMCPP_HD static size_t count(int n) { return (size_t)(n + 1) * n + 4 * (n + 1) + 2 * n + 3 * (n + 1) + 3 * (n + 1) + 2; }
+    S *Ca, *A, *A1, *B, *El, *ert, *e1, *tmp0, *tmp2, *below, *out, *e2, *ldn;
+    SMCPP_HD static size_t count(int n) { return (size_t)(n + 1) * n + 4 * (n + 1) + 2 * n + 3 * (n + 1) + 3 * (n + 1) + 3; }
     SMCPP_HD void carve(S *base, int n) {
         Ca = base; base += (size_t)(n + 1) * n;
         A = base; base += n + 1; A1 = base; base += n + 1; B = base; base += n + 1; El = base; base += n + 1;
         ert = base; base += n; e1 = base; base += n;
         tmp0 = base; base += n + 1; tmp2 = base; base += n + 1; below = base; base += n + 1;
-        out = base; base += 3 * (n + 1); e2 = base;
+        out = base; base += 3 * (n + 1); e2 = base; base += 2; ldn = base;
     }
 };
 
@@ -189,14 +220,15 @@ template <typename S> struct CsfsCtx {
     Tables<S> tb;
     int h, dir;
     CsfsScratch<S> sh;
-    SMCPP_HD S ada(int m) const { return ld<S>(pm.ada_v, pm.nder ? pm.ada_d + (size_t)dir * pm.K : nullptr, m); }
-    SMCPP_HD S R(int m) const { return ld<S>(pm.R_v, pm.nder ? pm.R_d + (size_t)dir * (pm.K + 1) : nullptr, m); }
-    SMCPP_HD S log_denom() const {
+    SMCPP_HD S ada(int m) const { return ld_ada<S>(pm, dir, m); }
+    SMCPP_HD S R(int m) const { return ld_R<S>(pm, dir, m); }
+    SMCPP_HD S log_denom_compute() const {
         const S Rh = R(pm.hsi[h]), Rh1 = R(pm.hsi[h + 1]);
         S ldn = -Rh;
         if (sval(Rh1) != INFINITY) ldn = ldn + m_log(-m_expm1(-(Rh1 - Rh)));
         return ldn;
     }
+    SMCPP_HD S log_denom() const { return sh.ldn[0]; }
 };
 
 template <typename S>
@@ -212,50 +244,57 @@ SMCPP_HD S below_helper(long rate, double tsm, double tsm1, const S &ad, const S
     return m_exp(-(double)l1r * Rr - log_denom) * (m_expm1(-(double)l1r * adadiff) * l1rinv - m_expm1(-adadiff)) / ((double)rate * ad);
 }
 
-// phase 0: clear the accumulators
+// phase 0: clear the accumulators; one thread forms the state's log normaliser
 template <typename S>
 SMCPP_HD void csfs_clear(const CsfsCtx<S> &c, int t, int nt) {
     const int n = c.pm.n;
     for (int p = t; p < (n + 1) * n; p += nt) c.sh.Ca[p] = S(0.0);
     for (int p = t; p < n + 1; p += nt) c.sh.below[p] = S(0.0);
     for (int p = t; p < 3 * (n + 1); p += nt) c.sh.out[p] = S(0.0);
+    if (t == nt - 1) c.sh.ldn[0] = c.log_denom_compute();
 }
-// phase 1 of piece m: the exponentials that depend on one index only (threads 0..n: lambda tables, n+1..2n: rate tables,
-// 2n+1..3n+1: the "below" integrals of the piece, which need no table)
+// phase 1 of piece m: the exponentials that depend on one index only.  Seven tables (A, A1, B, El over lambda; ert, e1 over the
+// rate; the "below" integrals of the piece): table q is formed by the threads of wavefront q (mod the wavefronts there are), entry
+// i by lane i, so that no wavefront runs more than one kind of exponential and the seven kinds run side by side.
 template <typename S>
-SMCPP_HD void csfs_piece_tables(const CsfsCtx<S> &c, int m, int t) {
+SMCPP_HD void csfs_piece_table(const CsfsCtx<S> &c, int m, int q, int i) {
     const PrepModel &pm = c.pm;
     const int n = pm.n, K = pm.K;
     const bool fin = pm.ts[m + 1] < INFINITY;
-    const S ad = c.ada(m);
-    const S Rm = c.R(m), Rm1 = c.R(m + 1);
-    if (t <= n) {
-        const S log_coef0 = -c.log_denom();
-        const S adadiff = ad * (pm.ts[m + 1] - pm.ts[m]);
-        const double l1 = (double)nC2(t + 2);
-        c.sh.A[t] = m_exp(-l1 * Rm + log_coef0);
-        if (m + 1 < K) c.sh.A1[t] = m_exp(-l1 * Rm1 + log_coef0);
-        if (fin) { c.sh.B[t] = m_expm1(-l1 * adadiff); c.sh.El[t] = m_exp(-l1 * adadiff); }
-    } else if (t <= 2 * n) {
-        const int jr = t - (n + 1);
-        if (fin) {
-            const S adadiff = ad * (pm.ts[m + 1] - pm.ts[m]);
-            const S dR = Rm1 - Rm;
-            c.sh.ert[jr] = m_exp(-(double)nC2(jr + 2) * adadiff);
-            c.sh.e1[jr] = m_exp(-(double)nC2(jr + 2) * dR);
+    if (q < 4) {
+        if (i > n) return;
+        const double l1 = (double)nC2(i + 2);
+        if (q == 0) c.sh.A[i] = m_exp(-l1 * c.R(m) + -c.log_denom());
+        else if (q == 1) { if (m + 1 < K) c.sh.A1[i] = m_exp(-l1 * c.R(m + 1) + -c.log_denom()); }
+        else if (fin) {
+            const S adadiff = c.ada(m) * (pm.ts[m + 1] - pm.ts[m]);
+            if (q == 2) c.sh.B[i] = m_expm1(-l1 * adadiff); else c.sh.El[i] = m_exp(-l1 * adadiff);
         }
-    } else if (t <= 3 * n + 1) {
-        const int j = t - (2 * n + 1) + 2;                     // j = 2 .. n+2
+    } else if (q < 6) {
+        if (i >= n || !fin) return;
+        if (q == 4) c.sh.ert[i] = m_exp(-(double)nC2(i + 2) * (c.ada(m) * (pm.ts[m + 1] - pm.ts[m])));
+        else c.sh.e1[i] = m_exp(-(double)nC2(i + 2) * (c.R(m + 1) - c.R(m)));
+    } else {
+        if (i > n) return;
+        const int j = i + 2;                                   // j = 2 .. n+2
+        const S Rm = c.R(m), Rm1 = c.R(m + 1);
         const S log_denom = c.log_denom();
         const S cc = -Rm - log_denom;
         S fac(1.0);
         if (m < K - 1) fac = -m_expm1(-(Rm1 - Rm));
         const S ec = m > 0 ? m_exp(cc) : S(0.0);
         const long rate = nC2(j) - 1;
-        S val = below_helper<S>(rate, pm.ts[m], pm.ts[m + 1], ad, Rm, log_denom);
-        if (m > 0) val = val + fac * (ec * c.tb.Ppre[((size_t)c.dir * (n + 1) + (j - 2)) * (K + 1) + m]);
+        S val = below_helper<S>(rate, pm.ts[m], pm.ts[m + 1], c.ada(m), Rm, log_denom);
+        if (m > 0) val = val + fac * (ec * c.tb.Ppre[((size_t)c.dir * (K + 1) + m) * (n + 1) + (j - 2)]);
         c.sh.below[j - 2] = c.sh.below[j - 2] + val;
     }
+}
+template <typename S>
+SMCPP_HD void csfs_piece_tables(const CsfsCtx<S> &c, int m, int t, int nt) {
+    const int nw = nt >= 64 ? nt / 64 : 1, w = t / 64, lane = t % 64;
+    if (w >= nw) return;
+    for (int q = w; q < 7; q += nw)
+        for (int i = lane; i <= c.pm.n; i += 64) csfs_piece_table(c, m, q, i);
 }
 // phase 2 of piece m: one (lambda, rate) pair
 template <typename S>
@@ -292,7 +331,7 @@ SMCPP_HD void csfs_pair(const CsfsCtx<S> &c, int m, int p) {
             if (-rpd * sval(Rm - Rm1) > 20) { coef = A * c.sh.e1[jr]; fac = S(1.0 / rpd); }
             else { coef = c.sh.A1[jl]; fac = m_expm1(-rpd * (Rm - Rm1)) / rpd; }
         }
-        tgt += coef * c.tb.Ssuf[((size_t)c.dir * n + jr) * K + m] * fac;
+        tgt += coef * c.tb.Ssuf[((size_t)c.dir * K + m) * n + jr] * fac;
     }
     c.sh.Ca[p] = tgt;
 }
@@ -302,12 +341,12 @@ SMCPP_HD void csfs_contract(const CsfsCtx<S> &c, int t) {
     const int n = c.pm.n;
     if (t <= n) {
         const int j = t;
-        AccD a;
+        AccT<S> a;
         for (int i = 0; i < n; ++i) acc_add(a, c.sh.Ca[(size_t)j * n + i] * c.ps.X0[(size_t)i * (n + 1) + j]);
         acc_get(a, c.sh.tmp0[j]);
     } else if (t <= 2 * n + 1) {
         const int j = t - (n + 1);
-        AccD a;
+        AccT<S> a;
         for (int i = 0; i < n; ++i) acc_add(a, c.sh.Ca[(size_t)(n - j) * n + i] * c.ps.X2[(size_t)i * (n + 1) + j]);
         acc_get(a, c.sh.tmp2[j]);
     }
@@ -357,7 +396,8 @@ SMCPP_HD void csfs_theta(const CsfsCtx<S> &c) {
         bad = bad || v < 0 || v > 1 || v != v;
     }
     if (bad && c.po.flags) c.po.flags[1] = 1;
-    const S act = ld<S>(pm.act_v, pm.nder ? pm.act_d + (size_t)c.dir * pm.M : nullptr, c.h);
+    S act;
+    ldp(act, pm.act_v, pm.act_d, pm.M, c.dir, pm.nder, c.h);
     if (sval(act) != sval(act)) { c.sh.e2[0] = S(1e-20); c.sh.e2[1] = S(1e-20); }
     else {
         const S le = -2.0 * pm.alpha * pm.theta * act;
@@ -369,10 +409,13 @@ SMCPP_HD void csfs_theta(const CsfsCtx<S> &c) {
 template <typename S>
 SMCPP_HD void csfs_emit(const CsfsCtx<S> &c, int t, int nt) {
     const PrepModel &pm = c.pm;
+    constexpr int ND = NDir<S>::value;
     const int n = pm.n, C = 3 * (n + 1), M = pm.M, h = c.h;
     for (int i = t; i < C; i += nt) {
         if (c.dir == 0 && c.po.sfs_v) c.po.sfs_v[(size_t)h * C + i] = sval(c.sh.out[i]);
-        if (pm.nder && c.po.sfs_d) c.po.sfs_d[((size_t)c.dir * M + h) * C + i] = sder(c.sh.out[i]);
+        if (c.po.sfs_d)
+            for (int q = 0; q < ND; ++q)
+                if (c.dir * ND + q < pm.nder) c.po.sfs_d[((size_t)(c.dir * ND + q) * M + h) * C + i] = sder(c.sh.out[i], q);
     }
     for (int k = t; k < c.ps.Kk; k += nt) {
         const int kind = c.ps.kind[k];
@@ -393,32 +436,33 @@ SMCPP_HD void csfs_emit(const CsfsCtx<S> &c, int t, int nt) {
                 if (c.po.Es_v) c.po.Es_v[(size_t)(c.ps.slot ? c.ps.slot[k] : kl) * c.po.MS + h] = v;
             }
         }
-        if (pm.nder) c.po.Eg_d[((size_t)c.dir * c.ps.Kk + k) * M + h] = sder(e);
+        for (int q = 0; q < ND; ++q)
+            if (c.dir * ND + q < pm.nder) c.po.Eg_d[((size_t)(c.dir * ND + q) * c.ps.Kk + k) * M + h] = sder(e, q);
     }
 }
 
 // ---- the same phases run serially on the host (CPU tests; never part of the product path) -----------------------------------
+template <typename S> SMCPP_HD int n_groups(int nder) { return NDir<S>::value ? (nder + NDir<S>::value - 1) / NDir<S>::value : 1; }
 template <typename S>
 inline void emulate_tables(const PrepModel &pm, const Tables<S> &tb) {
-    const int nd = pm.nder > 0 ? pm.nder : 1;
-    for (int dir = 0; dir < nd; ++dir) {
+    for (int dir = 0; dir < n_groups<S>(pm.nder); ++dir) {
         for (int it = 0; it < (2 * pm.n + 1) * pm.K; ++it) tables_term<S>(pm, dir, tb, it);
         for (int t = 0; t < 2 * pm.n + 1; ++t) tables_scan<S>(pm, dir, tb, t);
     }
 }
 template <typename S>
 inline void emulate_csfs(const PrepModel &pm, const PrepStatic &ps, const PrepOut &po, const Tables<S> &tb) {
-    const int nd = pm.nder > 0 ? pm.nder : 1, n = pm.n;
+    const int n = pm.n;
     std::vector<S> scratch(CsfsScratch<S>::count(n));
-    const int nt = 3 * n + 2;
+    const int nt = 448;
     for (int h = 0; h < pm.M; ++h)
-        for (int dir = 0; dir < nd; ++dir) {
+        for (int dir = 0; dir < n_groups<S>(pm.nder); ++dir) {
             CsfsCtx<S> c;
             c.pm = pm; c.ps = ps; c.po = po; c.tb = tb; c.h = h; c.dir = dir;
             c.sh.carve(scratch.data(), n);
             for (int t = 0; t < nt; ++t) csfs_clear(c, t, nt);
             for (int m = pm.hsi[h]; m < pm.hsi[h + 1]; ++m) {
-                for (int t = 0; t < nt; ++t) csfs_piece_tables(c, m, t);
+                for (int t = 0; t < nt; ++t) csfs_piece_tables(c, m, t, nt);
                 for (int p = 0; p < (n + 1) * n; ++p) csfs_pair(c, m, p);
             }
             for (int t = 0; t < nt; ++t) csfs_contract(c, t);
@@ -442,7 +486,8 @@ struct QArgs {
     const double *ed_v = nullptr, *ed_d = nullptr;                  // [M] (M - 1 used), planes [nder][M]
     const double *pf_v = nullptr, *pf_d = nullptr, *W_v = nullptr, *W_d = nullptr;   // [M], planes [nder][M]
     double mix_p2 = 0.0;                                            // 1e-5 / (M + 1)
-    double *out = nullptr;                                          // [(1 + nder)][4]
+    int nslice = 1;                                                 // the items of a block row are split over `nslice` workgroups
+    double *out = nullptr;                                          // [(1 + nder)][nslice][4]: the caller adds the slices in order
 };
 // unfloored row sum of the off-diagonal entries of row i, accumulated in column order as transition_expand does, and (dir >= 0)
 // the derivative of that sum
@@ -525,13 +570,13 @@ __global__ void k_q_stats(int n_contigs, int M, int Mp, int K, const double *gam
 
 __global__ __launch_bounds__(1024) void k_q_reduce(QArgs a) {
     extern __shared__ double q_lds[];
-    const int M = a.M, b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    const int M = a.M, b = blockIdx.x, sl = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
     double *diag = q_lds, *ddiag = q_lds + M, *red = q_lds + 2 * M;        // red [4][nt / 64][2]
     for (int i = t; i < M; i += nt) { double sm, dsm; q_rowsum(a, b - 1, i, sm, dsm); diag[i] = 1.0 - sm; ddiag[i] = -dsm; }
     __syncthreads();
     AccD acc[4];
     const long items = (long)M + (long)a.Kq * M + (long)M * M;
-    for (long idx = t; idx < items; idx += nt) {
+    for (long idx = (long)sl * nt + t; idx < items; idx += (long)nt * a.nslice) {
         int term;
         const double v = q_item(a, b, idx, diag, ddiag, term);
         // (one accumulator per term; the term of an item is uniform over long runs of idx, so the selects are cheap)
@@ -553,17 +598,19 @@ __global__ __launch_bounds__(1024) void k_q_reduce(QArgs a) {
     if (t < 4) {
         AccD r;
         for (int ww = 0; ww < nw; ++ww) { acc_add(r, red[(t * nw + ww) * 2]); r.lo += red[(t * nw + ww) * 2 + 1]; }
-        a.out[(size_t)b * 4 + t] = r.hi + r.lo;
+        a.out[((size_t)b * a.nslice + sl) * 4 + t] = r.hi + r.lo;
     }
 }
 
+// grid (direction groups, 2 n + 1 rates): the workgroup forms the K terms of ITS rate (one per thread), then one thread runs the
+// rate's recurrence over them (its own workgroup's writes: no grid-wide dependency)
 template <typename S>
 __global__ void k_prep_tables(PrepModel pm, Tables<S> tb) {
-    const int dir = blockIdx.x;
-    const int items = (2 * pm.n + 1) * pm.K;
-    for (int it = threadIdx.x; it < items; it += blockDim.x) tables_term<S>(pm, dir, tb, it);
+    const int dir = blockIdx.x, r = blockIdx.y, n = pm.n, K = pm.K;
+    for (int m = threadIdx.x; m < K; m += blockDim.x)
+        tables_term<S>(pm, dir, tb, r < n ? m * n + r : n * K + m * (n + 1) + (r - n));
     __syncthreads();                       // (workgroup-scope release / acquire of the global scratch included)
-    for (int t = threadIdx.x; t < 2 * pm.n + 1; t += blockDim.x) tables_scan<S>(pm, dir, tb, t);
+    if (threadIdx.x == 0) tables_scan<S>(pm, dir, tb, r);
 }
 
 template <typename S>
@@ -576,7 +623,7 @@ __global__ void k_prep_csfs(PrepModel pm, PrepStatic ps, PrepOut po, Tables<S> t
     csfs_clear(c, t, nt);
     __syncthreads();
     for (int m = pm.hsi[c.h]; m < pm.hsi[c.h + 1]; ++m) {
-        csfs_piece_tables(c, m, t);
+        csfs_piece_tables(c, m, t, nt);
         __syncthreads();
         for (int p = t; p < (n + 1) * n; p += nt) csfs_pair(c, m, p);
         __syncthreads();

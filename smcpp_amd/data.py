@@ -293,3 +293,64 @@ def windowed_mutation_counts(contig: Contig, w: int) -> np.ndarray:
                 last = data[i].copy()
     ret[j] = (nmiss, mut)
     return ret.T
+
+
+def realign(data: np.ndarray, w: int) -> np.ndarray:
+    """Re-cut the rows of a contig so that a row boundary falls on every multiple of `w` base pairs
+    (`smcpp/_estimation_tools.pyx:176-209`, "Realign contig data to have a split every w bps").  A counter `seen` of the
+    positions since the last boundary runs along the rows; a row that would carry it PAST `w` (strictly: a row that ends
+    exactly on the boundary is not split, and the counter keeps running into the next row - the reference's `>`, mirrored)
+    is emitted up to the boundary and its remainder re-enters the loop.  The observation columns are untouched; spans sum
+    to what they summed to before."""
+    assert w > 0
+    data = np.asarray(data, dtype=np.int32)
+    n = data.shape[0]
+    out = []
+    last = data[0].copy()
+    i = 0
+    seen = 0
+    while True:
+        row = last.copy()
+        if seen + int(last[0]) > w:
+            r = w - seen
+            row[0] = r
+            last[0] -= r
+            seen = 0
+            out.append(row)
+        else:
+            seen += int(last[0])
+            out.append(row)
+            i += 1
+            if i == n:
+                break
+            last = data[i].copy()
+    ret = np.array(out, dtype=np.int32).reshape(-1, data.shape[1])
+    ret = ret[ret[:, 0] > 0]
+    assert ret[:, 0].sum() == data[:, 0].sum()
+    return ret
+
+
+def beta_de_avg_pdf(X, y, h: float) -> np.ndarray:
+    """Beta-kernel density estimate (`smcpp/_estimation_tools.pyx:258-273`): for every evaluation point y_j the average over
+    the sample X of the Beta(1 + y_j / h, 1 + (1 - y_j) / h) density at X_i (Chen's boundary-free kernel on [0, 1]); sample
+    points exactly on 0 / 1 contribute the density's finite boundary value when the matching shape parameter is 1, nothing
+    otherwise.  ln B(a, b) = lgamma(a) + lgamma(b) - lgamma(a + b) (the reference calls gsl_sf_lnbeta)."""
+    import math
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    ret = np.zeros(y.shape[0])
+    inner = (X > 0.0) & (X < 1.0)
+    lx, l1x = np.log(X[inner]), np.log1p(-X[inner])
+    n0, n1 = int(np.sum(X == 0.0)), int(np.sum(X == 1.0))
+    for j in range(y.shape[0]):
+        a = 1.0 + y[j] / h
+        b = 1.0 + (1.0 - y[j]) / h
+        ln_B = math.lgamma(a) + math.lgamma(b) - math.lgamma(a + b)
+        s = 0.0
+        if a == 1.0:
+            s += n0 * math.exp(-ln_B)
+        if b == 1.0:
+            s += n1 * math.exp(-ln_B)
+        s += float(np.sum(np.exp((a - 1.0) * lx + (b - 1.0) * l1x - ln_B)))
+        ret[j] = s
+    return ret / len(X)

@@ -20,8 +20,8 @@ def cy():
 
 
 def test_module_surface(cy):
-    for name in ("PyOnePopInferenceManager", "PyTwoPopInferenceManager", "PyRateFunction", "raw_sfs", "set_num_threads",
-                 "_check_abort", "_init_cache"):
+    for name in ("PyOnePopInferenceManager", "PyTwoPopInferenceManager", "PyRateFunction", "raw_sfs", "joint_csfs",
+                 "set_num_threads", "_check_abort", "_init_cache"):
         assert hasattr(cy, name), name
     assert cy.abort is False
     cy.set_num_threads(2)
@@ -135,3 +135,32 @@ def test_managers_through_the_compiled_binding(cy, caplog):
     assert im.gammas[0].shape == (64, 1)
     with pytest.raises(RuntimeError, match="same size"):
         im.hidden_states = [0.0, 1.0]
+
+
+def test_joint_csfs_through_the_compiled_module(cy):
+    """`joint_csfs` (smcpp/_smcpp.pyx:416-437) in the Cython binding: per hidden state the joint conditioned SFS as an array
+    of ad numbers in `model.dlist` order, against the C ABI's values and Jacobian (golden G9 / G12 pin those, test_jcsfs.py)."""
+    import types
+    from smcpp_amd import _engine
+    from smcpp_amd.model import AdPiecewiseModel
+    a1 = np.array([1.0, 2.0, 0.7]); s1 = np.array([0.1, 0.4, 1.0])
+    a2 = np.array([0.5, 1.5]); s2 = np.array([0.2, 1.0])
+    m1 = AdPiecewiseModel(a1, s1, pid="pop1", differentiable=[0, 2])
+    m2 = AdPiecewiseModel(a2, s2, pid="pop2", differentiable=[1])
+    model = types.SimpleNamespace(model1=m1, model2=m2, split=0.3, dlist=m1.dlist + m2.dlist)
+    hs = [0.0, 0.2, 0.6, np.inf]
+    for (c1, c2) in ((2, 0), (1, 1)):
+        J = cy.joint_csfs(3, 2, c1, c2, model, hs, K=4)
+        assert len(J) == 3 and J[0].shape == (c1 + 1, 4, c2 + 1, 3)
+        da1 = np.zeros((3, 3)); da1[0, 0] = 1.0; da1[2, 1] = 1.0
+        da2 = np.zeros((2, 3)); da2[1, 2] = 1.0
+        v, dv = _engine.host_joint_csfs(3, 2, c1, c2, np.array(hs), (a1, s1), (a2, s2), 0.3, 4, da1=da1, da2=da2)
+        got = np.array([np.vectorize(lambda z: z.x)(j) for j in J])
+        np.testing.assert_allclose(got, v.reshape(got.shape), rtol=1e-14, atol=1e-300)
+        gd = np.array([[[[[[z.d(x) for x in model.dlist] for z in r3] for r3 in r2] for r2 in r1] for r1 in j] for j in J])
+        np.testing.assert_allclose(gd, dv.reshape(gd.shape), rtol=1e-12, atol=1e-300)
+        assert np.abs(gd).max() > 1e-6
+    # a model without derivative variables: plain floats, as `_store_admatrix_helper` returns (_smcpp.pyx:103-114)
+    m1p = AdPiecewiseModel(a1, s1, pid="pop1", differentiable=[]); m2p = AdPiecewiseModel(a2, s2, pid="pop2", differentiable=[])
+    Jp = cy.joint_csfs(3, 2, 2, 0, types.SimpleNamespace(model1=m1p, model2=m2p, split=0.3, dlist=[]), hs, K=4)
+    assert isinstance(Jp[0][0, 1, 0, 0], float)

@@ -291,3 +291,43 @@ def test_pipeline_rows_equal_reference_on_its_test_data(tmp_path):
                                    rtol=1e-14)
         assert np.array_equal(D.recode_monomorphic(D.Contig(d.copy(), c.pid, c.n, c.a)).data, g[f"bug11_{fi}_recode_mono"])
     assert np.array_equal(D.compress_repeated_obs(g["kat_compress_in"]), g["kat_compress_out"])
+
+
+def test_realign_puts_a_boundary_on_every_multiple_of_w():
+    """`realign` (_estimation_tools.pyx:176-209; restated: the Cython module needs GSL headers this image lacks, so the
+    reference's own is NOT executed here - unpinned by execution): spans are conserved, every row keeps its observation, no
+    row straddles a multiple of w counted from the last split, and a hand-worked case."""
+    from smcpp_amd import data as D
+    d = np.array([[5, 0, 0, 0], [1, 1, 2, 4], [7, -1, 0, 0], [3, 0, 1, 4]], dtype=np.int32)
+    r = D.realign(d, 4)
+    # 5 -> 4 + 1; then seen = 1, +1 = 2, then 7: 2 + 7 > 4 -> 2 (boundary), 5 -> 4 (boundary: 0 + 5 > 4), 1; then 3: 1 + 3 = 4 not > 4
+    assert r.tolist() == [[4, 0, 0, 0], [1, 0, 0, 0], [1, 1, 2, 4], [2, -1, 0, 0], [4, -1, 0, 0], [1, -1, 0, 0], [3, 0, 1, 4]]
+    rng = np.random.default_rng(3)
+    raw = np.column_stack([rng.integers(1, 40, 500), rng.integers(-1, 2, 500), rng.integers(0, 3, 500), np.full(500, 4)]).astype(np.int32)
+    for w in (1, 7, 100):
+        r = D.realign(raw, w)
+        assert r[:, 0].sum() == raw[:, 0].sum() and np.all(r[:, 0] > 0) and np.all(r[:, 0] <= max(w, raw[:, 0].max()))
+        # expanding both to one row per base pair gives the same sequence of observations
+        assert np.array_equal(np.repeat(r[:, 1:], r[:, 0], axis=0), np.repeat(raw[:, 1:], raw[:, 0], axis=0))
+        if w == 1:
+            assert np.all(r[:, 0] == 1)
+
+
+def test_beta_kernel_density_estimate():
+    """`beta_de_avg_pdf` (_estimation_tools.pyx:258-273; restated, unpinned by execution for the same reason): equals the
+    average of scipy's Beta(1 + y / h, 1 + (1 - y) / h) densities over the sample, integrates to one over the sample space when
+    the sample is uniform, boundary points count only where the kernel is finite there."""
+    from scipy import stats
+    from smcpp_amd import data as D
+    rng = np.random.default_rng(0)
+    X = rng.random(200)
+    y = np.linspace(0.0, 1.0, 21)
+    h = 0.05
+    got = D.beta_de_avg_pdf(X, y, h)
+    ref = np.array([stats.beta(1 + yy / h, 1 + (1 - yy) / h).pdf(X).mean() for yy in y])
+    np.testing.assert_allclose(got, ref, rtol=1e-12)
+    Xb = np.array([0.0, 1.0, 0.5])
+    g = D.beta_de_avg_pdf(Xb, np.array([0.0, 1.0, 0.3]), 0.1)
+    # y = 0: a = 1, the kernel is finite at X = 0 (value b = 11) and zero at X = 1; y = 1: the mirror image
+    assert abs(g[0] - (11.0 + stats.beta(1, 11).pdf(0.5)) / 3) < 1e-12 and abs(g[1] - g[0]) < 1e-12
+    assert abs(g[2] - stats.beta(4, 8).pdf(0.5) / 3) < 1e-12

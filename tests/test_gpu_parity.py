@@ -250,6 +250,39 @@ def test_posterior_product_on_reference_test_contig():
     assert np.array_equal(paths[0], gammas[0].argmax(axis=0))
 
 
+def test_posterior_product_two_populations():
+    """`smc++ posterior` with two populations (commands/posterior.py:88-100): 7-column rows, PyTwoPopInferenceManager, hidden
+    states balanced on the distinguished model; the decoded matrix against the C restatement of hmm.cpp run on the SAME prepared
+    parameters (pi, T, joint-CSFS emission table as the engine formed them) - every column with a clear winner decodes equally."""
+    from oracle import oracle
+    from smcpp_amd import synth
+    from smcpp_amd.model import PiecewiseModel, TwoPopulationModel
+    from smcpp_amd.posterior import posterior
+    a, s = synth.model_pieces(8)
+    model = TwoPopulationModel(PiecewiseModel(a, s, 1e4, pid="pop1"),
+                               PiecewiseModel(1.5 + 0.5 * np.cos(np.arange(4)), s[:4], 1e4, pid="pop2"), 0.4)
+    raw = synth.synth_contig_twopop(3, 3_000_000, 4, 3)
+    hs, gammas, sites, paths = posterior(model, [raw], 12, (4, 3), synth.THETA, synth.RHO, a=(2, 0))
+    im = posterior.last_manager
+    assert len(hs) == 13 and hs[0] == 0 and np.isinf(hs[-1])
+    obs = np.vstack([[1, -1, 0, 0, -1, 0, 0], raw]).astype(np.int32)
+    assert gammas[0].shape == (12, len(obs) + 1) and np.array_equal(sites[0], obs[:, 0])
+    np.testing.assert_allclose(gammas[0].sum(axis=0), 1.0, rtol=1e-12)
+    keys = im.keys
+    ep = im.emission_probs
+    o = oracle.estep(im.pi, im.transition, keys, np.array([ep[tuple(k)] for k in keys.tolist()]), obs, save_gamma=True)
+    g = o["gamma"] / o["gamma"].sum(axis=0, keepdims=True)
+    assert np.max(np.abs(gammas[0] - g)) <= 2e-5
+    srt = np.sort(g, axis=0)
+    strong = (srt[-1] - srt[-2]) / srt[-1] > 1e-5
+    assert np.all((paths[0] == g.argmax(axis=0)) | ~strong)
+    assert abs(im.loglik() - o["loglik"]) <= 1e-6 * abs(o["loglik"])
+    # a window and thinning (posterior.py:76-87) go through the same path
+    hs2, g2, s2, p2 = posterior(model, [raw], 12, (4, 3), synth.THETA, synth.RHO, a=(2, 0), start=100_000, end=900_000, thinning=5,
+                                hidden_states=hs)
+    assert s2[0].sum() <= 800_001 + raw[:, 0].max() and g2[0].shape[1] == len(s2[0]) + 1
+
+
 def test_em_iterations_increase_the_likelihood():
     """End-to-end property of E-step statistics + Q + gradients: an EM step cannot decrease the log-likelihood
     (up to the float-alpha noise of the E-step).  Data are simulated under a size history that differs from the start."""

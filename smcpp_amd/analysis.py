@@ -442,10 +442,16 @@ class Analysis:
 
     def dump(self, filename):
         """`model.final.json` (base.py:186-191)."""
-        d = {"theta": self._theta, "rho": self._rho, "alpha": self._alpha, "model": self._model.to_dict(),
-             "hidden_states": {self.populations[0]: [float(x) for x in self.hidden_states]}}
-        with open(filename + ".json", "wt") as f:
-            json.dump(d, f, sort_keys=True, indent=4)
+        write_final_json(filename, self._theta, self._rho, self._alpha, self._model, {self.populations[0]: self.hidden_states})
+
+
+def write_final_json(filename, theta, rho, alpha, model, hidden_states):
+    """`BaseAnalysis.dump` (smcpp/analysis/base.py:186-191): theta / rho / alpha, `model.to_dict()` and the hidden states per
+    population, sorted keys, indent 4 - the file `smc++ plot` / `smc++ posterior` read back."""
+    d = {"theta": theta, "rho": rho, "alpha": alpha, "model": model.to_dict(),
+         "hidden_states": {k: [float(x) for x in v] for k, v in hidden_states.items()}}
+    with open(filename + ".json", "wt") as f:
+        json.dump(d, f, sort_keys=True, indent=4)
 
 
 # ---- a minimal EM driver on raw piece sizes (no hidden-state selection, no plugins): what the monotonicity tests drive ----

@@ -94,6 +94,47 @@ def _example_contig():
     return c
 
 
+def test_model_final_json_field_by_field_against_the_reference(tmp_path):
+    """Golden G17 (tests/golden/make_golden_final_json.py): `model.final.json` written by the REFERENCE's own `BaseAnalysis.dump`
+    for its own `SMCModel` at a fixed parameter point of the example run - hidden states from its `balance_hidden_states` (rate
+    function served by the compiled reference), knots from its `Analysis._init_knots`.  This repository's classes, fed the same
+    inputs, must write the same file: same keys, same strings, every number to 1e-12 (the hidden states come out of Brent
+    root-finding on both sides), `Infinity` where the reference writes it."""
+    import types
+    from smcpp_amd import analysis as A
+    from smcpp_amd.posterior import balance_hidden_states
+    gin = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G17_inputs.npz"))
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G17_model_final.json")))
+    N0, mu, w, M = float(gin["N0"]), float(gin["mu"]), int(gin["w"]), int(gin["M"])
+    m0 = A.SMCModel(gin["knots0"], N0, "pop1")
+    m0[:] = gin["y"]
+    hs = balance_hidden_states(m0, M)                      # coalescent units (the reference's, in generations, / 2 N0)
+    ns = types.SimpleNamespace()
+    A.Analysis._init_knots(ns, hs, None, None)
+    m = A.SMCModel(ns._knots, N0, "pop1")
+    m[:] = gin["yf"]
+    A.write_final_json(str(tmp_path / "model.final"), 2.0 * N0 * mu, 2.0 * N0 * mu, w, m, {"pop1": hs})
+    txt = open(tmp_path / "model.final.json").read()
+    got = json.loads(txt)
+
+    def same(a, b, path):
+        assert type(a) is type(b) or (isinstance(a, (int, float)) and isinstance(b, (int, float))), (path, a, b)
+        if isinstance(a, dict):
+            assert sorted(a) == sorted(b), path
+            for k in a:
+                same(a[k], b[k], path + "/" + k)
+        elif isinstance(a, list):
+            assert len(a) == len(b), path
+            for i, (x, y) in enumerate(zip(a, b)):
+                same(x, y, f"{path}[{i}]")
+        elif isinstance(a, float):
+            assert (np.isinf(a) and np.isinf(b)) or abs(a - b) <= 1e-12 * max(abs(b), 1e-300), (path, a, b)
+        else:
+            assert a == b, (path, a, b)
+    same(got, ref, "")
+    assert "Infinity" in txt and txt.startswith("{\n    \"alpha\": 100,")          # sort_keys, indent = 4, as json.dump writes them
+
+
 @pytest.mark.gpu
 def test_analysis_replays_the_reference_run_on_the_example(tmp_path):
     """`np.random.seed(0); Analysis([example, n = 4], knots=8, unfold=True, w=100, mu=1.25e-8,

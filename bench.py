@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--eps-alpha", type=float, default=0.0)
     ap.add_argument("--eps-beta", type=float, default=0.0)
     ap.add_argument("--raw", action="store_true", help="time set_raw -> E_step -> loglik only (no cold preparation)")
+    ap.add_argument("--check", action="store_true", help="N > 1: after the timed region gather every rank's host threads, key "
+                    "dictionary and Q (four terms) and assert that the dictionaries agree and Q is bitwise identical on all ranks")
     ap.add_argument("--warm", action="store_true", help="additionally report the opt-in warm start (smcpp_set_warm_start) on a "
                     "trajectory of perturbed parameters; never part of `value`")
     args = ap.parse_args()
@@ -183,7 +185,9 @@ def main():
     M, n, fixture, desc = WORKLOADS[args.workload]
     length_bp = int(args.length_mbp * 1e6)
     par = None
+    sharded_kw = {}
     if args.workload == "c4":
+        sharded_kw = dict(a=(2, 0))
         contigs = [synth.synth_contig_twopop(rank, length_bp, n, n)]
         hs = synth.hidden_states(M)
         a, s_ = synth.model_pieces()
@@ -228,8 +232,11 @@ def main():
             lengths = [1] * world                      # one contig per rank; equal weights -> contig r on rank r
             obs_all = [None] * world
             obs_all[rank] = contigs[0]
-        sim = sd.ShardedInferenceManager(n, obs_all, hs, ("pop1",), pol, device=local_rank, lengths=lengths,
-                                         factory=factory)
+        # (c4: the manager's own two-population factory, n = (n1, n2), a = (2, 0); one population: the factory above)
+        if args.workload == "c4":
+            sim = sd.ShardedInferenceManager((n, n), obs_all, hs, ("pop1", "pop2"), pol, device=local_rank, lengths=lengths, **sharded_kw)
+        else:
+            sim = sd.ShardedInferenceManager(n, obs_all, hs, ("pop1",), pol, device=local_rank, lengths=lengths, factory=factory)
         assert [i for i in sim.mine] == ([i for i in range(len(lengths)) if sd.lpt_shard(lengths, world)[i] == rank])
         im = sim.im
     else:
@@ -442,6 +449,23 @@ def main():
                              "gamma_write_frac_of_hbm": gbytes / t_stat / 1e9 / HBM_PEAK_GBS,
                              "eigen_row_tflops": 2.0 * M ** 3 * Re / t_stat / 1e12,
                              "fwd_passes": med["fwd_passes"], "bwd_passes": med["bwd_passes"]}
+    # ---- N > 1 consistency (--check): what every rank holds after the single all-reduce ----
+    multi_check = None
+    if args.check and world > 1:
+        import hashlib
+        qv = np.array(top.Q(separate=True), dtype=np.float64)
+        mine = {"rank": rank, "host_threads": host_threads, "q": qv.tobytes().hex(), "contigs": [int(i) for i in sim.mine],
+                "local_keys": int(len(im.keys)), "global_keys": hashlib.sha1(np.ascontiguousarray(sim.keys, dtype=np.int32).tobytes()).hexdigest(),
+                "n_global_keys": int(len(sim.keys)), "loglik": float(ll)}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        assert len({r["q"] for r in allr}) == 1, "Q differs between ranks"
+        assert len({r["global_keys"] for r in allr}) == 1, "key dictionaries differ between ranks"
+        assert len({r["loglik"] for r in allr}) == 1, "reduced log-likelihood differs between ranks"
+        assert sorted(c for r in allr for c in r["contigs"]) == list(range(len(lengths))), "contigs are not partitioned"
+        multi_check = {"ranks": world, "q_bitwise_identical": True, "q": [float(x) for x in qv], "host_threads_per_rank": [r["host_threads"] for r in allr],
+                       "contigs_per_rank": [r["contigs"] for r in allr], "local_keys_per_rank": [r["local_keys"] for r in allr],
+                       "global_keys": allr[0]["n_global_keys"], "cpu_quota": avail}
     # full-size parity against the compiled reference's recorded log-likelihoods (golden G16, tests/golden/make_golden_fullsize.py)
     parity_full = None
     try:
@@ -476,6 +500,8 @@ def main():
         }
         if parity_full is not None:
             out["parity_full_size"] = parity_full
+        if multi_check is not None:
+            out["multi_gpu_check"] = multi_check
         if warm is not None:
             out["warm_start"] = warm
         if world > 1:

@@ -331,7 +331,7 @@ struct DevPrep {
             const size_t lds = smcpp_dev::CsfsScratch<S>::count(n) * sizeof(S);
             static bool once = false;
             if (!once) { HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_csfs<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
-            hipLaunchKernelGGL(smcpp_dev::k_prep_tables<S>, dim3(ng, 2 * n + 1), dim3(ntt), 0, s, pm, tb);
+            hipLaunchKernelGGL(smcpp_dev::k_prep_tables<S>, dim3(ng, 2 * n + 1), dim3(ntt), (size_t)2 * K * sizeof(S), s, pm, tb);
             hipLaunchKernelGGL(smcpp_dev::k_prep_csfs<S>, dim3(M, ng), dim3(nt), lds, s, pm, ps, po, tb);
         } else {
             typedef double S;
@@ -340,7 +340,7 @@ struct DevPrep {
             const size_t lds = smcpp_dev::CsfsScratch<S>::count(n) * sizeof(S);
             static bool once = false;
             if (!once) { HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_csfs<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
-            hipLaunchKernelGGL(smcpp_dev::k_prep_tables<S>, dim3(1, 2 * n + 1), dim3(ntt), 0, s, pm, tb);
+            hipLaunchKernelGGL(smcpp_dev::k_prep_tables<S>, dim3(1, 2 * n + 1), dim3(ntt), (size_t)2 * K * sizeof(S), s, pm, tb);
             hipLaunchKernelGGL(smcpp_dev::k_prep_csfs<S>, dim3(M, 1), dim3(nt), lds, s, pm, ps, po, tb);
         }
         HIPCHK(hipGetLastError());
@@ -1423,21 +1423,36 @@ void smcpp_im::prepare_params() {
         smcpp_host::TwoPopPrep &prep = *twopop_prep;
         E_on_dev = false;
         tgen_valid = false; dT_valid = true;
+        // with a global key dictionary (multi-GPU) the table is prepared for EVERY global key - Q on the all-reduced statistics
+        // also covers keys only other ranks' contigs hold; the local table is the sub-list of this rank's keys
+        const std::vector<int> &pk2 = have_global ? gkeys : keys;
+        const int K2 = (int)(pk2.size() / keylen);
+        std::vector<double> Ep, dEp;
         if (nder > 0) {
             smcpp_host::DualScope sc(nder);
             std::vector<smcpp_host::dual> pd, Td, Ed, emd;
             prep.compute_t<smcpp_host::dual>(make_dual_model(model, model_da, nder), make_dual_model(model_p1, model_da1, nder),
-                                             make_dual_model(model_p2, model_da2, nder), split, theta, rho, alpha, keys, K,
+                                             make_dual_model(model_p2, model_da2, nder), split, theta, rho, alpha, pk2, K2,
                                              pd, Td, Ed, &emd);
-            split_duals(pd, nder, pi, dpi); split_duals(Td, nder, T, dT); split_duals(Ed, nder, E, dE);
+            split_duals(pd, nder, pi, dpi); split_duals(Td, nder, T, dT); split_duals(Ed, nder, Ep, dEp);
             split_duals(emd, nder, emission, demission);
         } else {
             smcpp_host::ModelParamsT<double> d, p1, p2;
             d.a = model.a; d.s = model.s; p1.a = model_p1.a; p1.s = model_p1.s; p2.a = model_p2.a; p2.s = model_p2.s;
-            prep.compute_t<double>(d, p1, p2, split, theta, rho, alpha, keys, K, pi, T, E, &emission);
+            prep.compute_t<double>(d, p1, p2, split, theta, rho, alpha, pk2, K2, pi, T, Ep, &emission);
             demission.clear();
         }
-        Eg.clear(); dEg.clear();           // rebuilt from the local table on demand (global_emissions)
+        if (!have_global) { E.swap(Ep); dE.swap(dEp); Eg.clear(); dEg.clear(); }
+        else {
+            E.assign((size_t)K * M, 0.0);
+            dE.assign(nder > 0 ? (size_t)K * M * nder : 0, 0.0);
+            for (int k = 0; k < K; ++k) {
+                const int kg = local_to_global[k];
+                std::memcpy(&E[(size_t)k * M], &Ep[(size_t)kg * M], sizeof(double) * M);
+                if (nder > 0) std::memcpy(&dE[(size_t)k * M * nder], &dEp[(size_t)kg * M * nder], sizeof(double) * M * nder);
+            }
+            Eg.swap(Ep); dEg.swap(dEp);
+        }
         params_fresh = true;
         return;
     }
@@ -1659,7 +1674,7 @@ bool smcpp_im::q_device(double val[4], double *jac) {
     a.out = q.d_out.p;
     a.nslice = nslice;
     const int nt = 1024;
-    const size_t lds = (size_t)(2 * M + 4 * (nt / 64) * 2) * sizeof(double);
+    const size_t lds = (size_t)(8 * M + 4 * (nt / 64) * 2) * sizeof(double);
     hipLaunchKernelGGL(smcpp_dev::k_q_reduce, dim3(1 + nd, nslice), dim3(nt), lds, stream, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(q.h_out, q.d_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream));

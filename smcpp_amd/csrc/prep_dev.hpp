@@ -120,82 +120,67 @@ struct PrepOut {
     int *flags = nullptr;
 };
 // Tables of k_prep_tables, per direction GROUP g (a group = the directions one scalar carries; one group for plain doubles), piece-
-// major so that the threads of a rate read and write neighbouring words:
-//   Ssuf [g][K][n]      Ppre [g][K+1][n+1]      and the per-piece terms the recurrences consume: Gt, Ft [g][K][n], Pt [g][K][n+1]
+// major so that the threads of the consuming kernel read neighbouring words:   Ssuf [g][K][n]      Ppre [g][K+1][n+1]
 template <typename S> struct Tables {
-    S *Ssuf = nullptr, *Ppre = nullptr, *Gt = nullptr, *Ft = nullptr, *Pt = nullptr;
-    SMCPP_HD static size_t per_group(int n, int K) { return (size_t)3 * n * K + (size_t)(n + 1) * (K + 1) + (size_t)(n + 1) * K; }
+    S *Ssuf = nullptr, *Ppre = nullptr;
+    SMCPP_HD static size_t per_group(int n, int K) { return (size_t)n * K + (size_t)(n + 1) * (K + 1); }
     SMCPP_HD void carve(S *base, int n, int K, int ng) {
         Ssuf = base; base += (size_t)ng * n * K;
-        Ppre = base; base += (size_t)ng * (n + 1) * (K + 1);
-        Gt = base; base += (size_t)ng * n * K;
-        Ft = base; base += (size_t)ng * n * K;
-        Pt = base;
+        Ppre = base;
     }
 };
 
 template <typename S> SMCPP_HD S ld_ada(const PrepModel &pm, int dir, int m) { S r; ldp(r, pm.ada_v, pm.ada_d, pm.K, dir, pm.nder, m); return r; }
 template <typename S> SMCPP_HD S ld_R(const PrepModel &pm, int dir, int m) { S r; ldp(r, pm.R_v, pm.R_d, pm.K + 1, dir, pm.nder, m); return r; }
 
-// ---- k_prep_tables: phase 1 (one (rate, piece) term), phase 2 (the recurrences) ------------------------------------------------
+// ---- k_prep_tables: rate r (0 .. n-1: the "above" rates C(j,2); n .. 2n: the "below" rates C(j,2) - 1) --------------------------
+// phase 1: the term of piece m (g, and for the above rates the factor f of the recurrence Ssuf[m-1] = g_m + f_m Ssuf[m])
 template <typename S>
-SMCPP_HD void tables_term(const PrepModel &pm, int dir, const Tables<S> &tb, int item) {
-    const int K = pm.K, n = pm.n;
-    const int na = n * K;                      // above items (m, jr), then below items (m, jr)
-    if (item < na) {
-        const int m = item / n, jr = item % n;
-        S *G = tb.Gt + ((size_t)dir * K + m) * n + jr, *F = tb.Ft + ((size_t)dir * K + m) * n + jr;
-        if (m == 0) { *G = S(0.0); *F = S(0.0); return; }      // (slot m holds the term of piece m; piece 0 has none)
-        const double rate = (double)nC2(jr + 2);
+SMCPP_HD void tables_term(const PrepModel &pm, int dir, int r, int m, S &g, S &f) {
+    const int n = pm.n;
+    f = S(0.0);
+    if (r < n) {
+        if (m == 0) { g = S(0.0); return; }                     // (slot m holds the term of piece m; piece 0 has none)
+        const double rate = (double)nC2(r + 2);
         const S ad = ld_ada<S>(pm, dir, m);
         if (pm.ts[m + 1] < INFINITY) {
             const S em = m_expm1(-rate * ad * (pm.ts[m + 1] - pm.ts[m]));
-            *G = -em / (ad * rate);
-            *F = 1.0 + em;
-        } else { *G = 1.0 / (ad * rate); *F = S(0.0); }
+            g = -em / (ad * rate);
+            f = 1.0 + em;
+        } else g = 1.0 / (ad * rate);
         return;
     }
-    item -= na;
-    if (item >= (n + 1) * K) return;
-    const int m = item / (n + 1), jr = item % (n + 1);
-    S *P = tb.Pt + ((size_t)dir * K + m) * (n + 1) + jr;
-    const long ratel = nC2(jr + 2) - 1;
-    if (ratel == 0) { *P = S(pm.ts[m + 1]); return; }
+    const long ratel = nC2(r - n + 2) - 1;
+    if (ratel == 0) { g = S(pm.ts[m + 1]); return; }
     const double rate = (double)ratel;
     const S ad = ld_ada<S>(pm, dir, m);
-    S g = m_exp(-rate * ld_R<S>(pm, dir, m));
+    g = m_exp(-rate * ld_R<S>(pm, dir, m));
     if (pm.ts[m + 1] < INFINITY) g *= -m_expm1(-rate * ad * (pm.ts[m + 1] - pm.ts[m]));
     g /= ad * rate;
-    *P = g;
 }
+// phase 2 (one thread per rate): the recurrence over the K terms G / F (the workgroup's scratch), results to the tables
 template <typename S>
-SMCPP_HD void tables_scan(const PrepModel &pm, int dir, const Tables<S> &tb, int t) {
+SMCPP_HD void tables_scan(const PrepModel &pm, int dir, const Tables<S> &tb, int r, const S *G, const S *F) {
     const int K = pm.K, n = pm.n;
-    if (t < n) {
-        const S *__restrict__ G = tb.Gt + (size_t)dir * K * n + t, *__restrict__ F = tb.Ft + (size_t)dir * K * n + t;
-        S *__restrict__ O = tb.Ssuf + (size_t)dir * K * n + t;
+    if (r < n) {
+        S *O = tb.Ssuf + (size_t)dir * K * n + r;
         S acc(0.0);                              // Ssuf[K-1] = 0
-#pragma unroll 8
         for (int m = K - 1; m >= 1; --m) {
-            const S g = G[(size_t)m * n], f = F[(size_t)m * n];
             O[(size_t)m * n] = acc;
-            if (pm.ts[m + 1] < INFINITY) acc = g + f * acc; else acc = g;
+            if (pm.ts[m + 1] < INFINITY) acc = G[m] + F[m] * acc; else acc = G[m];
         }
         O[0] = acc;
         return;
     }
-    t -= n;
-    if (t >= n + 1) return;
-    const S *__restrict__ P = tb.Pt + (size_t)dir * K * (n + 1) + t;
-    S *__restrict__ O = tb.Ppre + (size_t)dir * (K + 1) * (n + 1) + t;
+    const int t = r - n;
+    S *O = tb.Ppre + (size_t)dir * (K + 1) * (n + 1) + t;
     O[0] = S(0.0);
     if (nC2(t + 2) - 1 == 0) {                   // (rate 0: the prefix sums are the break points themselves)
-        for (int m = 0; m < K; ++m) O[(size_t)(m + 1) * (n + 1)] = P[(size_t)m * (n + 1)];
+        for (int m = 0; m < K; ++m) O[(size_t)(m + 1) * (n + 1)] = G[m];
         return;
     }
     S acc(0.0);
-#pragma unroll 8
-    for (int m = 0; m < K; ++m) { acc = acc + P[(size_t)m * (n + 1)]; O[(size_t)(m + 1) * (n + 1)] = acc; }
+    for (int m = 0; m < K; ++m) { acc = acc + G[m]; O[(size_t)(m + 1) * (n + 1)] = acc; }
 }
 
 // ---- k_prep_csfs: the work of one workgroup (hidden state h, direction group dir) ----------------------------------------------
@@ -376,26 +361,31 @@ SMCPP_HD void csfs_backtransform(const CsfsCtx<S> &c, int t) {
         c.sh.out[(n + 1) + b] += s;
     }
 }
-// phase 5 (one thread): incorporate_theta, the reduced-key factors, the state's row of InferenceManager::emission
+// phase 5: incorporate_theta in three steps - (a) one thread: the total and the factor f (kept in e2[0]); (b) all threads: x *= f;
+// (c) one thread: the new total, x[0] = 1 - total, the reduced-key factors; (d) all threads: the 1e-10 floor and the range check.
+// The two totals are sequential sums in the host's order; the element-wise steps have no order.
 template <typename S>
-SMCPP_HD void csfs_theta(const CsfsCtx<S> &c) {
-    const PrepModel &pm = c.pm;
-    const int n = pm.n, C = 3 * (n + 1);
-    S *x = c.sh.out;
+SMCPP_HD void csfs_theta_a(const CsfsCtx<S> &c) {
+    const int C = 3 * (c.pm.n + 1);
+    const S *x = c.sh.out;
     S tauh(0.0);
     for (int i = 0; i < C; ++i) tauh += x[i];
-    const S f = -m_expm1(-pm.theta * tauh) / tauh;
-    for (int i = 0; i < C; ++i) x[i] *= f;
+    c.sh.e2[0] = -m_expm1(-c.pm.theta * tauh) / tauh;
+}
+template <typename S>
+SMCPP_HD void csfs_theta_b(const CsfsCtx<S> &c, int t, int nt) {
+    const int C = 3 * (c.pm.n + 1);
+    const S f = c.sh.e2[0];
+    for (int i = t; i < C; i += nt) c.sh.out[i] *= f;
+}
+template <typename S>
+SMCPP_HD void csfs_theta_c(const CsfsCtx<S> &c) {
+    const PrepModel &pm = c.pm;
+    const int C = 3 * (pm.n + 1);
+    S *x = c.sh.out;
     S tot(0.0);
     for (int i = 0; i < C; ++i) tot += x[i];
     x[0] = 1.0 - tot;
-    bool bad = false;
-    for (int i = 0; i < C; ++i) {
-        if (sval(x[i]) < 1e-10) x[i] = S(1e-10);
-        const double v = sval(x[i]);
-        bad = bad || v < 0 || v > 1 || v != v;
-    }
-    if (bad && c.po.flags) c.po.flags[1] = 1;
     S act;
     ldp(act, pm.act_v, pm.act_d, pm.M, c.dir, pm.nder, c.h);
     if (sval(act) != sval(act)) { c.sh.e2[0] = S(1e-20); c.sh.e2[1] = S(1e-20); }
@@ -403,6 +393,16 @@ SMCPP_HD void csfs_theta(const CsfsCtx<S> &c) {
         const S le = -2.0 * pm.alpha * pm.theta * act;
         c.sh.e2[0] = m_exp(le);
         c.sh.e2[1] = -m_expm1(le);
+    }
+}
+template <typename S>
+SMCPP_HD void csfs_theta_d(const CsfsCtx<S> &c, int t, int nt) {
+    const int C = 3 * (c.pm.n + 1);
+    S *x = c.sh.out;
+    for (int i = t; i < C; i += nt) {
+        if (sval(x[i]) < 1e-10) x[i] = S(1e-10);
+        const double v = sval(x[i]);
+        if ((v < 0 || v > 1 || v != v) && c.po.flags) c.po.flags[1] = 1;
     }
 }
 // phase 6: emission vectors of key k at state h (OnePopPrep::emission_probs), and the state's conditioned SFS
@@ -445,10 +445,12 @@ SMCPP_HD void csfs_emit(const CsfsCtx<S> &c, int t, int nt) {
 template <typename S> SMCPP_HD int n_groups(int nder) { return NDir<S>::value ? (nder + NDir<S>::value - 1) / NDir<S>::value : 1; }
 template <typename S>
 inline void emulate_tables(const PrepModel &pm, const Tables<S> &tb) {
-    for (int dir = 0; dir < n_groups<S>(pm.nder); ++dir) {
-        for (int it = 0; it < (2 * pm.n + 1) * pm.K; ++it) tables_term<S>(pm, dir, tb, it);
-        for (int t = 0; t < 2 * pm.n + 1; ++t) tables_scan<S>(pm, dir, tb, t);
-    }
+    std::vector<S> G(pm.K), F(pm.K);
+    for (int dir = 0; dir < n_groups<S>(pm.nder); ++dir)
+        for (int r = 0; r < 2 * pm.n + 1; ++r) {
+            for (int m = 0; m < pm.K; ++m) tables_term<S>(pm, dir, r, m, G[m], F[m]);
+            tables_scan<S>(pm, dir, tb, r, G.data(), F.data());
+        }
 }
 template <typename S>
 inline void emulate_csfs(const PrepModel &pm, const PrepStatic &ps, const PrepOut &po, const Tables<S> &tb) {
@@ -467,7 +469,10 @@ inline void emulate_csfs(const PrepModel &pm, const PrepStatic &ps, const PrepOu
             }
             for (int t = 0; t < nt; ++t) csfs_contract(c, t);
             for (int t = 0; t < nt; ++t) csfs_backtransform(c, t);
-            csfs_theta(c);
+            csfs_theta_a(c);
+            for (int t = 0; t < nt; ++t) csfs_theta_b(c, t, nt);
+            csfs_theta_c(c);
+            for (int t = 0; t < nt; ++t) csfs_theta_d(c, t, nt);
             for (int t = 0; t < nt; ++t) csfs_emit(c, t, nt);
         }
 }
@@ -489,22 +494,31 @@ struct QArgs {
     int nslice = 1;                                                 // the items of a block row are split over `nslice` workgroups
     double *out = nullptr;                                          // [(1 + nder)][nslice][4]: the caller adds the slices in order
 };
+// the generators of the transition matrix (values and ONE direction's derivative plane) as the block reads them: global memory
+// in the host emulation, a staged LDS copy in the kernel
+struct QGen { const double *ed, *W, *pf, *ded, *dW, *dpf; };
+SMCPP_HD QGen q_gen_global(const QArgs &a, int dir) {
+    QGen g;
+    g.ed = a.ed_v; g.W = a.W_v; g.pf = a.pf_v;
+    g.ded = dir >= 0 ? a.ed_d + (size_t)dir * a.M : nullptr;
+    g.dW = dir >= 0 ? a.W_d + (size_t)dir * a.M : nullptr;
+    g.dpf = dir >= 0 ? a.pf_d + (size_t)dir * a.M : nullptr;
+    return g;
+}
 // unfloored row sum of the off-diagonal entries of row i, accumulated in column order as transition_expand does, and (dir >= 0)
 // the derivative of that sum
-SMCPP_HD void q_rowsum(const QArgs &a, int dir, int i, double &sm, double &dsm) {
-    const int M = a.M;
+SMCPP_HD void q_rowsum(const QGen &g, int M, int dir, int i, double &sm, double &dsm) {
     sm = 0.0; dsm = 0.0;
-    const double pf = a.pf_v[i];
-    const double *edd = dir >= 0 ? a.ed_d + (size_t)dir * M : nullptr, *Wd = dir >= 0 ? a.W_d + (size_t)dir * M : nullptr;
-    const double dpf = dir >= 0 ? a.pf_d[(size_t)dir * M + i] : 0.0;
+    const double pf = g.pf[i];
+    const double dpf = dir >= 0 ? g.dpf[i] : 0.0;
     for (int c = 0; c < M; ++c) {
         if (c == i) continue;
-        sm += c < i ? a.ed_v[c] : pf * a.W_v[c];
-        if (dir >= 0) dsm += c < i ? edd[c] : dpf * a.W_v[c] + pf * Wd[c];
+        sm += c < i ? g.ed[c] : pf * g.W[c];
+        if (dir >= 0) dsm += c < i ? g.ded[c] : dpf * g.W[c] + pf * g.dW[c];
     }
 }
 // contribution of item idx (0 .. M + Kq M + M M) of block b: term index and value; diag / ddiag = the rows' diagonals (1 - sm, -dsm)
-SMCPP_HD double q_item(const QArgs &a, int b, long idx, const double *diag, const double *ddiag, int &term) {
+SMCPP_HD double q_item(const QArgs &a, const QGen &g, int b, long idx, const double *diag, const double *ddiag, int &term) {
     const int M = a.M, dir = b - 1;
     double w, x, dx = 0.0;
     if (idx < M) {
@@ -523,10 +537,10 @@ SMCPP_HD double q_item(const QArgs &a, int b, long idx, const double *diag, cons
         w = a.xi[e];
         double t, dt = 0.0;
         if (c == i) { t = diag[i]; dt = dir >= 0 ? ddiag[i] : 0.0; }
-        else if (c < i) { t = a.ed_v[c]; if (dir >= 0) dt = a.ed_d[(size_t)dir * M + c]; }
+        else if (c < i) { t = g.ed[c]; if (dir >= 0) dt = g.ded[c]; }
         else {
-            t = a.pf_v[i] * a.W_v[c];
-            if (dir >= 0) dt = a.pf_d[(size_t)dir * M + i] * a.W_v[c] + a.pf_v[i] * a.W_d[(size_t)dir * M + c];
+            t = g.pf[i] * g.W[c];
+            if (dir >= 0) dt = g.dpf[i] * g.W[c] + g.pf[i] * g.dW[c];
         }
         if (t < 1e-20) { t = 1e-20; dt = 0.0; }
         x = t * (1 - 1e-5) + a.mix_p2;
@@ -540,9 +554,10 @@ inline void emulate_q(const QArgs &a) {
     std::vector<double> diag(M), ddiag(M);
     const long items = (long)M + (long)a.Kq * M + (long)M * M;
     for (int b = 0; b <= a.nder; ++b) {
-        for (int i = 0; i < M; ++i) { double sm, dsm; q_rowsum(a, b - 1, i, sm, dsm); diag[i] = 1.0 - sm; ddiag[i] = -dsm; }
+        const QGen g = q_gen_global(a, b - 1);
+        for (int i = 0; i < M; ++i) { double sm, dsm; q_rowsum(g, M, b - 1, i, sm, dsm); diag[i] = 1.0 - sm; ddiag[i] = -dsm; }
         AccD acc[4];
-        for (long idx = 0; idx < items; ++idx) { int term; const double v = q_item(a, b, idx, diag.data(), ddiag.data(), term); acc_add(acc[term], v); }
+        for (long idx = 0; idx < items; ++idx) { int term; const double v = q_item(a, g, b, idx, diag.data(), ddiag.data(), term); acc_add(acc[term], v); }
         for (int t = 0; t < 4; ++t) acc_get(acc[t], a.out[(size_t)b * 4 + t]);
     }
 }
@@ -571,14 +586,25 @@ __global__ void k_q_stats(int n_contigs, int M, int Mp, int K, const double *gam
 __global__ __launch_bounds__(1024) void k_q_reduce(QArgs a) {
     extern __shared__ double q_lds[];
     const int M = a.M, b = blockIdx.x, sl = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
-    double *diag = q_lds, *ddiag = q_lds + M, *red = q_lds + 2 * M;        // red [4][nt / 64][2]
-    for (int i = t; i < M; i += nt) { double sm, dsm; q_rowsum(a, b - 1, i, sm, dsm); diag[i] = 1.0 - sm; ddiag[i] = -dsm; }
+    double *diag = q_lds, *ddiag = q_lds + M, *gen = q_lds + 2 * M, *red = q_lds + 8 * M;        // gen [6][M], red [4][nt / 64][2]
+    {
+        // the generators (and this block's derivative plane) staged once: every row sum and every item reads them from LDS
+        const QGen gg = q_gen_global(a, b - 1);
+        for (int i = t; i < M; i += nt) {
+            gen[i] = gg.ed[i]; gen[M + i] = gg.W[i]; gen[2 * M + i] = gg.pf[i];
+            gen[3 * M + i] = b > 0 ? gg.ded[i] : 0.0; gen[4 * M + i] = b > 0 ? gg.dW[i] : 0.0; gen[5 * M + i] = b > 0 ? gg.dpf[i] : 0.0;
+        }
+    }
+    __syncthreads();
+    QGen g;
+    g.ed = gen; g.W = gen + M; g.pf = gen + 2 * M; g.ded = gen + 3 * M; g.dW = gen + 4 * M; g.dpf = gen + 5 * M;
+    for (int i = t; i < M; i += nt) { double sm, dsm; q_rowsum(g, M, b - 1, i, sm, dsm); diag[i] = 1.0 - sm; ddiag[i] = -dsm; }
     __syncthreads();
     AccD acc[4];
     const long items = (long)M + (long)a.Kq * M + (long)M * M;
     for (long idx = (long)sl * nt + t; idx < items; idx += (long)nt * a.nslice) {
         int term;
-        const double v = q_item(a, b, idx, diag, ddiag, term);
+        const double v = q_item(a, g, b, idx, diag, ddiag, term);
         // (one accumulator per term; the term of an item is uniform over long runs of idx, so the selects are cheap)
         for (int q = 0; q < 4; ++q) if (q == term) acc_add(acc[q], v);
     }
@@ -602,15 +628,16 @@ __global__ __launch_bounds__(1024) void k_q_reduce(QArgs a) {
     }
 }
 
-// grid (direction groups, 2 n + 1 rates): the workgroup forms the K terms of ITS rate (one per thread), then one thread runs the
-// rate's recurrence over them (its own workgroup's writes: no grid-wide dependency)
+// grid (direction groups, 2 n + 1 rates): the workgroup forms the K terms of ITS rate (one per thread) in LDS, then one thread runs
+// the rate's recurrence over them
 template <typename S>
 __global__ void k_prep_tables(PrepModel pm, Tables<S> tb) {
-    const int dir = blockIdx.x, r = blockIdx.y, n = pm.n, K = pm.K;
-    for (int m = threadIdx.x; m < K; m += blockDim.x)
-        tables_term<S>(pm, dir, tb, r < n ? m * n + r : n * K + m * (n + 1) + (r - n));
-    __syncthreads();                       // (workgroup-scope release / acquire of the global scratch included)
-    if (threadIdx.x == 0) tables_scan<S>(pm, dir, tb, r);
+    extern __shared__ double tables_lds[];
+    S *G = reinterpret_cast<S *>(tables_lds), *F = G + pm.K;
+    const int dir = blockIdx.x, r = blockIdx.y;
+    for (int m = threadIdx.x; m < pm.K; m += blockDim.x) tables_term<S>(pm, dir, r, m, G[m], F[m]);
+    __syncthreads();
+    if (threadIdx.x == 0) tables_scan<S>(pm, dir, tb, r, G, F);
 }
 
 template <typename S>
@@ -632,7 +659,13 @@ __global__ void k_prep_csfs(PrepModel pm, PrepStatic ps, PrepOut po, Tables<S> t
     __syncthreads();
     csfs_backtransform(c, t);
     __syncthreads();
-    if (t == 0) csfs_theta(c);
+    if (t == 0) csfs_theta_a(c);
+    __syncthreads();
+    csfs_theta_b(c, t, nt);
+    __syncthreads();
+    if (t == 0) csfs_theta_c(c);
+    __syncthreads();
+    csfs_theta_d(c, t, nt);
     __syncthreads();
     csfs_emit(c, t, nt);
 }

@@ -133,7 +133,7 @@ class ShardedInferenceManager:
     """
 
     def __init__(self, n, observations, hidden_states, im_id, polarization_error, *, device=-1, group=None,
-                 lengths=None, factory=None, always_reduce=False):
+                 lengths=None, factory=None, always_reduce=False, a=None):
         import torch.distributed as dist
         self._group = group
         self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
@@ -150,9 +150,17 @@ class ShardedInferenceManager:
             raise RuntimeError("a contig assigned to this rank was not provided")
         if factory is None:
             from . import _smcpp
+            if a is not None or (not np.isscalar(n) and len(n) == 2):
+                # two populations (`PyTwoPopInferenceManager(n1, n2, a1, a2, ...)`, _smcpp.pyx:334-351): n = (n1, n2), a = (a1, a2)
+                if a is None or np.isscalar(n) or len(n) != 2 or len(a) != 2:
+                    raise RuntimeError("two populations need n = (n1, n2) and a = (a1, a2)")
 
-            def factory(obs, dev):
-                return _smcpp.PyOnePopInferenceManager(n, obs, hidden_states, im_id, polarization_error, device=dev)
+                def factory(obs, dev):
+                    return _smcpp.PyTwoPopInferenceManager(int(n[0]), int(n[1]), int(a[0]), int(a[1]), obs, hidden_states, im_id,
+                                                           polarization_error, device=dev)
+            else:
+                def factory(obs, dev):
+                    return _smcpp.PyOnePopInferenceManager(n, obs, hidden_states, im_id, polarization_error, device=dev)
         self.im = factory(local, device)
         self._device = self.im.device_index() if hasattr(self.im, "device_index") else 0
         # always_reduce: run the pack -> all-reduce -> unpack path even in a group of ONE rank (test hook: the device-buffer
@@ -162,6 +170,8 @@ class ShardedInferenceManager:
         self._buf = None
         self._ll_sum = None
         self._lls = None
+        self.last_local_stats = self.last_reduced_stats = None      # (host copies, kept only when `keep_stats` is set: tests)
+        self.keep_stats = False
         if self._reduce:
             # global key dictionary: fixes the layout of the gamma_sums block and makes the engine prepare the
             # emission vectors of keys only other ranks' contigs hold (they enter Q through the reduced statistics)
@@ -203,14 +213,22 @@ class ShardedInferenceManager:
                 # on the device the ENGINE lives on (the pack / unpack kernels dereference the pointer there)
                 self._buf = torch.empty(self.im.stats_len(), dtype=torch.float64, device=torch.device("cuda", self._device))
             self.im.pack_stats_device(self._buf.data_ptr())           # returns after the kernel has finished
+            if self.keep_stats:
+                self.last_local_stats = self._buf.cpu().numpy().copy()
             self._dist.all_reduce(self._buf, op=self._dist.ReduceOp.SUM, group=self._group)
             self._ll_sum = float(self._buf[0].item())                 # synchronises the reduction
+            if self.keep_stats:
+                self.last_reduced_stats = self._buf.cpu().numpy().copy()
             self.im.unpack_stats_device(self._buf.data_ptr(), self._buf.numel())
         else:
             h = self.im.pack_stats()
+            if self.keep_stats:
+                self.last_local_stats = h.copy()
             t = torch.from_numpy(h)
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
             self._ll_sum = float(t[0].item())
+            if self.keep_stats:
+                self.last_reduced_stats = t.numpy().copy()
             self.im.unpack_stats(t.numpy())
 
     def loglik(self):

@@ -101,6 +101,68 @@ def test_two_ranks_match_single_manager(tmp_path, disjoint, use_model):
         np.testing.assert_allclose(np.array(r[0]["jac"]), jac, rtol=1e-6, atol=1e-7 * np.abs(jac).max())
 
 
+def _exact_worker(rank, world, port, out_dir, backend):
+    """Two ranks; keeps the packed statistics before and after the all-reduce (gloo: ranks share device 0; nccl: one device each)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    from smcpp_amd import dist as sd
+    g = load_golden("G3_M32_n10_2Mbp")
+    contigs = _contigs(True)
+    sim = sd.ShardedInferenceManager(10, contigs, g["hs"], ("pop1",), 0.5, device=dev)
+    sim.keep_stats = True
+    _setup(sim, g, True)
+    sim.E_step()
+    q, jac = sim.Q_with_gradient()
+    np.savez(os.path.join(out_dir, f"x{rank}.npz"), local=sim.last_local_stats, reduced=sim.last_reduced_stats, mine=np.array(sim.mine),
+             q=q, jac=jac, nccl=np.array(sim._nccl))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_exact(tmp_path, world):
+    from smcpp_amd import _smcpp
+    r = [np.load(tmp_path / f"x{i}.npz") for i in range(world)]
+    g = load_golden("G3_M32_n10_2Mbp")
+    contigs = _contigs(True)
+    # (1) the collective: the reduced buffer is the sum of the ranks' local buffers - exactly (two summands: any order, one rounding)
+    assert np.array_equal(r[0]["reduced"], r[1]["reduced"])
+    assert np.array_equal(r[0]["reduced"], r[0]["local"] + r[1]["local"])
+    # (2) a rank's local buffer is what a SINGLE manager over the same contigs packs - bitwise: the same contigs give the same chunk
+    # layout, and every kernel reduces in a fixed order (the sharded-vs-one-manager comparison above can only hold to the fixed
+    # point's tolerance, because one manager over ALL contigs cuts its chunks differently)
+    for i in range(world):
+        im = _smcpp.PyOnePopInferenceManager(10, [contigs[c] for c in r[i]["mine"]], g["hs"], ("pop1",), 0.5)
+        _setup(im, g, True)
+        im.E_step()
+        im.set_global_keys(np.unique(np.vstack([c[:, 1:] for c in contigs]), axis=0).astype(np.int32))
+        assert np.array_equal(im.pack_stats(), r[i]["local"]), i
+    # (3) Q and its gradient on the reduced statistics: bitwise equal on every rank
+    assert np.array_equal(r[0]["q"], r[1]["q"]) and np.array_equal(r[0]["jac"], r[1]["jac"])
+
+
+def test_reduction_is_exact_two_ranks_one_device(tmp_path):
+    """a tight check of the reduction itself, independent of the chunk layout (gloo, ranks share the device)."""
+    mp.spawn(_exact_worker, args=(2, _free_port(), str(tmp_path), "gloo"), nprocs=2, join=True)
+    _check_exact(tmp_path, 2)
+
+
+def test_reduction_is_exact_two_ranks_rccl(tmp_path):
+    """The same over RCCL (backend nccl), one rank per GPU: runs wherever two devices are visible (the 1-GPU test box skips)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    mp.spawn(_exact_worker, args=(2, _free_port(), str(tmp_path), "nccl"), nprocs=2, join=True)
+    _check_exact(tmp_path, 2)
+    assert bool(np.load(tmp_path / "x0.npz")["nccl"])
+
+
 def _nccl_worker(rank, port, out_dir):
     """ONE rank, backend nccl (= RCCL): the device-buffer branch of ShardedInferenceManager.E_step (k_pack_stats writes into
     the reduced tensor, all_reduce on the device, k_unpack) that a gloo group never takes."""
@@ -268,6 +330,32 @@ def test_bench_gpus_2_self_launches():
     o1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     # rank 0 of the two-rank run holds the same contig as the single-rank run; the reduced log-likelihood adds rank 1's
     assert out["config"]["loglik"] < o1["config"]["loglik"] < 0
+
+
+@pytest.mark.parametrize("workload,extra", [("c3", []), ("c4", ["--length-mbp", "20"])])
+def test_bench_eight_ranks_dry_run(workload, extra):
+    """`bench.py --gpus 8 --workload c3 | c4 --check` as the driver launches it on an 8-GPU node, here with the eight ranks
+    sharing the one device over gloo (flagged in the output: a functional run, not a measurement): the contigs are partitioned,
+    every rank holds the same global key dictionary and - after the single all-reduce - bitwise the same Q; each rank's host
+    threads stay within its share of the CPU quota.  c3 = the 22 contigs of the whole genome LPT-sharded (strong scaling; also
+    checked against the compiled reference's recorded per-contig log-likelihoods, golden G16); c4 = two-population managers built
+    by ShardedInferenceManager's own factory."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", workload, "--steps", "2",
+                        "--warmup", "1", "--no-cpu", "--check"] + extra, capture_output=True, text=True, env=env, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["value"] > 0
+    mc = out["multi_gpu_check"]
+    assert mc["ranks"] == 8 and mc["q_bitwise_identical"]
+    assert all(1 <= t <= max(1, mc["cpu_quota"] // 8) for t in mc["host_threads_per_rank"])
+    assert sorted(c for r in mc["contigs_per_rank"] for c in r) == list(range(22 if workload == "c3" else 8))
+    if workload == "c3":
+        assert out["scaling"] == "strong" and abs(out["parity_full_size"]["rel_diff"]) <= 1e-6
+    else:
+        assert out["scaling"] == "weak" and mc["global_keys"] >= 100
 
 
 def test_c4_real_shape_two_population_model_path():

@@ -322,8 +322,8 @@ struct DevPrep {
         po.flags = d_flags_view;
         HIPCHK(hipMemcpyAsync(d_in, hb, bytes, hipMemcpyHostToDevice, s));
         const int pairs = (n + 1) * n;
-        const int nt = std::max(64 * ceil_div(3 * n + 2, 64), std::min(1024, 64 * ceil_div(pairs, 64)));
-        const int ntt = std::min(1024, 64 * ceil_div(K, 64));
+        const int nt = std::min(512, std::max(64 * ceil_div(3 * n + 2, 64), 64 * ceil_div(pairs, 64)));
+        const int ntt = std::min(256, 64 * ceil_div(K, 64));
         if (nder) {
             typedef SD S;
             smcpp_dev::Tables<S> tb;

@@ -631,7 +631,7 @@ __global__ __launch_bounds__(1024) void k_q_reduce(QArgs a) {
 // grid (direction groups, 2 n + 1 rates): the workgroup forms the K terms of ITS rate (one per thread) in LDS, then one thread runs
 // the rate's recurrence over them
 template <typename S>
-__global__ void k_prep_tables(PrepModel pm, Tables<S> tb) {
+__global__ __launch_bounds__(256) void k_prep_tables(PrepModel pm, Tables<S> tb) {
     extern __shared__ double tables_lds[];
     S *G = reinterpret_cast<S *>(tables_lds), *F = G + pm.K;
     const int dir = blockIdx.x, r = blockIdx.y;
@@ -640,8 +640,10 @@ __global__ void k_prep_tables(PrepModel pm, Tables<S> tb) {
     if (threadIdx.x == 0) tables_scan<S>(pm, dir, tb, r, G, F);
 }
 
+// (at most 512 threads: with the default bound of 1024 the compiler caps the kernel at 128 registers and the four-direction
+// instantiation spills 120 of them)
 template <typename S>
-__global__ void k_prep_csfs(PrepModel pm, PrepStatic ps, PrepOut po, Tables<S> tb) {
+__global__ __launch_bounds__(512) void k_prep_csfs(PrepModel pm, PrepStatic ps, PrepOut po, Tables<S> tb) {
     extern __shared__ double prep_lds[];
     CsfsCtx<S> c;
     c.pm = pm; c.ps = ps; c.po = po; c.tb = tb; c.h = blockIdx.x; c.dir = blockIdx.y;

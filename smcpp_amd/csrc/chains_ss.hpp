@@ -272,6 +272,20 @@ __device__ __forceinline__ void ss_desc_settle(int2 &d) { asm volatile("" : "+v"
 // the loop's door: a constant first used inside the loop, behind a store, costs an s_waitcnt vmcnt(0) per row otherwise.
 // (gfx9 encoding of s_waitcnt: vmcnt(0), expcnt and lgkmcnt left at their maxima)
 __device__ __forceinline__ void ss_vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// A wavefront owns ONE chunk: its descriptor is the same in every lane, but it arrives through per-lane loads (the chunk index comes
+// from the thread index), so the compiler treats the row loop's trip count as divergent and wraps every iteration in exec-mask
+// bookkeeping (s_and_saveexec / s_andn2 exec / v_cmp against a vector register: a dozen scalar instructions per row).  Moved to
+// scalar registers the loop is a plain uniform loop.
+__device__ __forceinline__ int ss_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ Chunk ss_uniform_chunk(const Chunk &c) {
+    Chunk u;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(c.base & 0xffffffffll));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(c.base >> 32));
+    u.base = (long long)(((unsigned long long)hi << 32) | lo);
+    u.r0 = ss_uni(c.r0); u.r1 = ss_uni(c.r1); u.contig = ss_uni(c.contig); u.first = ss_uni(c.first); u.last = ss_uni(c.last);
+    u.pad = ss_uni(c.pad); u.h0 = ss_uni(c.h0); u.h1 = ss_uni(c.h1);
+    return u;
+}
 
 // emission vector of key slot `slot` at this lane's positions (forward: states lane NPL + k; backward: MS-1-(lane NPL + k))
 // ALLLDS: every key slot lives in LDS (K <= nlds) - no global path, and with it no vector-memory destination register the
@@ -432,7 +446,7 @@ template <int NPL, bool RERUN, bool HYB, bool ALLLDS>
 __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
-    const Chunk ch = a.chunks[c];
+    const Chunk ch = ss_uniform_chunk(a.chunks[c]);
     float *end_cur = a.ends_f + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
     const float *end_prev = a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
     int st[NPL];
@@ -655,7 +669,7 @@ template <int NPL, bool RERUN, bool HYB, bool ALLLDS>
 __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
-    const Chunk ch = a.chunks_b[c];
+    const Chunk ch = ss_uniform_chunk(a.chunks_b[c]);
     double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks_b + c) * Mp;
     const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks_b + c) * Mp;
     int st[NPL];
@@ -1055,7 +1069,7 @@ __device__ __forceinline__ void ss_bwd_light_rows(const SsArgs &a, const double 
 template <int NPL, bool ALLLDS>
 __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *sE, int c, int lane) {
     const int M = a.M, Mp = a.Mp, pass = a.pass;
-    const Chunk ch = a.chunks[c];
+    const Chunk ch = ss_uniform_chunk(a.chunks[c]);
     float *end_cur = a.ends_f + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
     int st[NPL];
     bool live[NPL], stor[NPL];
@@ -1136,7 +1150,7 @@ template <int NPL, bool ALLLDS>
 __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
-    const Chunk ch = a.chunks_b[c];
+    const Chunk ch = ss_uniform_chunk(a.chunks_b[c]);
     double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks_b + c) * Mp;
     int st[NPL];
     bool live[NPL], stor[NPL];
@@ -1241,7 +1255,7 @@ __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
         }
     }
     __syncthreads();
-    const int task = a.tasks[(nthr >> 6) * blockIdx.x + w];
+    const int task = ss_uni(a.tasks[(nthr >> 6) * blockIdx.x + w]);
     if (task < 0) return;
     const bool fwd = !(task >> 30);
     const int c = task & 0x3FFFFFFF;

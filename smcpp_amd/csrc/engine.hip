@@ -509,6 +509,8 @@ struct smcpp_im {
     DevBuf<int2> d_rowdesc_ss;             // [rows, padded] {key slot, span}
     DevBuf<double> d_gpart2;               // [span-1 rank slabs][K][Mp] gamma partials of k_rank_acc_g
     DevBuf<double> d_Fall;                 // [n_contigs Ke][smax][Mp][Mp] scratch of the span fold for M > 64 (k_span_big)
+    DevBuf<int> d_span_flags;              // [n_contigs Ke][smax] per-step publication counters of the fused span fold (only ever grow)
+    int span_epoch = 0;
     SsArgs ss_args;
     std::vector<Chunk> chunks_b;           // backward chunks of the scan chains (more and shorter than the forward ones)
     std::vector<int> ss_tasks;             // (direction << 30 | chunk) per wavefront of a k_chain_ss launch
@@ -3000,11 +3002,28 @@ void smcpp_im::enqueue_stats() {
             // strips of 16 rows (F) / columns (H), one workgroup each, F_t through scratch
             d_Fall.alloc((size_t)n_contigs * Ke * ss_max_span * Mp * Mp);
             const int nstrip = NT, nwg = n_contigs * Ke * nstrip;
+            // SMCPP_SPAN_FUSED=1 (opt-in, measured SLOWER: DESIGN.md section 10): both phases in ONE launch, the H strips trailing the
+            // F strips by their prefetch distance through per-step counters in global memory instead of starting when F has finished.
+            // The device-wide fence every F step needs before it may publish, and the H workgroups polling beside it, cost more than
+            // the 30 serial steps saved: headline statistics 0.263 against 0.234 ms, M = 256 2.33 against 1.67 ms.
+            static const bool fused_on = getenv("SMCPP_SPAN_FUSED") && atoi(getenv("SMCPP_SPAN_FUSED")) != 0;
+            const bool fused = fused_on && 2 * nwg <= 256;
+            if (fused) {
+                const size_t nfl = (size_t)n_contigs * Ke * ss_max_span;
+                if (d_span_flags.n < nfl) { d_span_flags.alloc(nfl); HIPCHK(hipMemsetAsync(d_span_flags.p, 0, nfl * sizeof(int), se)); span_epoch = 0; }
+                ++span_epoch;
+                const int target = nstrip * span_epoch;
+#define B_(x) hipLaunchKernelGGL((k_span_fused<x>), dim3(2 * nwg), dim3(64 * x), 0, se, fa, ss_max_span, d_Fall.p, nwg, d_span_flags.p, target);
+                if (NT == 1) B_(1) else if (NT == 2) B_(2) else if (NT == 3) B_(3) else if (NT == 4) B_(4)
+                else if (NT <= 8) B_(8) else if (NT <= 12) B_(12) else B_(16)
+#undef B_
+            } else {
 #define B_(x) { hipLaunchKernelGGL((k_span_big<x, 0>), dim3(nwg), dim3(64 * x), 0, se, fa, ss_max_span, d_Fall.p); \
                 hipLaunchKernelGGL((k_span_big<x, 1>), dim3(nwg), dim3(64 * x), 0, se, fa, ss_max_span, d_Fall.p); }
             if (NT == 1) B_(1) else if (NT == 2) B_(2) else if (NT == 3) B_(3) else if (NT == 4) B_(4)
             else if (NT <= 8) B_(8) else if (NT <= 12) B_(12) else B_(16)
 #undef B_
+            }
         } else
         switch (NT) {
 #define S_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_span_FH<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \

@@ -2898,14 +2898,17 @@ __global__ __launch_bounds__(128 * NT) void k_span_FH(FinArgs a, int smax) {
 // or F_t from the scratch) is fetched FOUR STEPS AHEAD with unconditional, index-clamped loads - on the serial path the three
 // dependent round trips bucket -> span -> matrix cost more than the product itself; the bucket of every step comes from a
 // small LDS table built once.
-template <int NTP, int PHASE>
-__global__ __launch_bounds__(64 * NTP) void k_span_big(FinArgs a, int smax, double *__restrict__ Fall) {
+// FUSED: both phases run in ONE launch (k_span_fused): the F workgroups publish every F_t they have written (a counter per (contig,
+// key, step) in global memory, raised once by each strip), the H workgroups wait for the counter of the step they are about to fetch
+// - H trails F by its prefetch distance instead of starting when F has finished (31 + 31 serial steps become 31 + 4).  `target` =
+// strips x launch epoch: the counters only ever grow, nothing is cleared between E-steps.
+template <int NTP, int PHASE, bool FUSED>
+__device__ __forceinline__ void span_big_body(const FinArgs &a, int smax, double *__restrict__ Fall, int blk, double (*sX)[16 * NTP * 17],
+                                              int *sbk, int *flags, int target) {
     constexpr int MT = 16 * NTP, LDX = 17;
-    __shared__ double sX[2][MT * LDX];
-    __shared__ int sbk[64];                                           // bucket holding span t + 1, or -1 (smax <= 64)
     __builtin_amdgcn_s_setprio(3);                                    // a serial chain of small products beside chip-filling kernels
     const int ns = (a.Mp + 15) / 16;                                  // strips that exist
-    const int ce = blockIdx.x / ns, sp = blockIdx.x % ns, e = ce % a.Ke;
+    const int ce = blk / ns, sp = blk % ns, e = ce % a.Ke;
     const int b0 = a.ce_bucket_off[ce], b1 = a.ce_bucket_off[ce + 1];
     if (b0 == b1) return;
     const int tid = threadIdx.x, lane = tid & 63, tt = tid >> 6;
@@ -2946,6 +2949,11 @@ __global__ __launch_bounds__(64 * NTP) void k_span_big(FinArgs a, int smax, doub
     }
     auto fetch = [&](int t, double (&v)[4]) {                          // raw loads; masked where they are consumed
         const int tc = max(t, 0);
+        if (FUSED && PHASE == 1 && t >= 0) {
+            // F_tc must have been published by every strip of the F phase (acquire: the loads below must not see older lines)
+            while (__hip_atomic_load(&flags[(size_t)ce * smax + tc], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
+                __builtin_amdgcn_s_sleep(2);
+        }
         const double *src;
         if (PHASE == 0) src = a.red_e + (size_t)max(sbk[tc], b0) * Mp * Mp;
         else src = Fce + (size_t)tc * Mp * Mp;
@@ -2985,8 +2993,12 @@ __global__ __launch_bounds__(64 * NTP) void k_span_big(FinArgs a, int smax, doub
 #pragma unroll
                 for (int r = 0; r < 4; ++r)                           // F_t[row 16 sp + m][column 16 tt + qd + 4 r]
                     if (eok[r]) Ft[eoff[r]] = X[r];
+                if (FUSED) __threadfence();                           // this thread's part of F_t is visible device-wide ...
             }
             __syncthreads();
+            // ... and once every thread of the strip has passed the barrier, the strip is: one count per strip and step
+            if (FUSED && PHASE == 0 && tid == 0)
+                __hip_atomic_fetch_add(&flags[(size_t)ce * smax + t], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (PHASE == 0) return;
@@ -3006,6 +3018,22 @@ __global__ __launch_bounds__(64 * NTP) void k_span_big(FinArgs a, int smax, doub
         for (int r = 0; r < 4; ++r)
             if (qd + 4 * r == m && 16 * sp + m < Mp) gout[16 * sp + m] = G[r];
     }
+}
+
+template <int NTP, int PHASE>
+__global__ __launch_bounds__(64 * NTP) void k_span_big(FinArgs a, int smax, double *__restrict__ Fall) {
+    __shared__ double sX[2][16 * NTP * 17];
+    __shared__ int sbk[64];                                           // bucket holding span t + 1, or -1 (smax <= 64)
+    span_big_body<NTP, PHASE, false>(a, smax, Fall, (int)blockIdx.x, sX, sbk, nullptr, 0);
+}
+// both phases in one launch: workgroups [0, nwg) run the F strips, [nwg, 2 nwg) the H strips (the F workgroups never wait for
+// anything, so whatever order the dispatcher picks the launch makes progress)
+template <int NTP>
+__global__ __launch_bounds__(64 * NTP) void k_span_fused(FinArgs a, int smax, double *__restrict__ Fall, int nwg, int *flags, int target) {
+    __shared__ double sX[2][16 * NTP * 17];
+    __shared__ int sbk[64];
+    if ((int)blockIdx.x < nwg) span_big_body<NTP, 0, true>(a, smax, Fall, (int)blockIdx.x, sX, sbk, flags, target);
+    else span_big_body<NTP, 1, true>(a, smax, Fall, (int)blockIdx.x - nwg, sX, sbk, flags, target);
 }
 
 // xisum[contig] = max( (X1 + sum_e P_e Y_e diag(b_e)) o Td , 1e-20 )   (hmm.cpp:122,141,151-152)

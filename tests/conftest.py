@@ -10,7 +10,7 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 GOLDEN_CASES = ["G1_M16_n4", "G2_M51_n6_longspans", "G3_M32_n10_2Mbp", "G4_M64_n20_2Mbp", "G5_M48_twopop_layout",
-                "G6_M1_n4", "G7_M32_n8_chr11"]
+                "G6_M1_n4", "G7_M32_n8_chr11", "G18_M64_n8_chr11"]
 
 
 def pytest_configure(config):

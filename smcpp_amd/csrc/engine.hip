@@ -55,6 +55,19 @@ static void log_msg(const char *level, const char *fmt, ...) {
     g_logger_cb("engine", level, buf);
 }
 
+// SMCPP_HOST_TRACE=1: microsecond stamps of the host phase of an E-step on stderr (diagnostics; no effect on the results)
+struct HostTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    HostTrace() { static const bool e = getenv("SMCPP_HOST_TRACE") && atoi(getenv("SMCPP_HOST_TRACE")) > 0; on = e; if (on) t = std::chrono::steady_clock::now(); }
+    void mark(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[host-trace] %-28s %7.1f us\n", what, std::chrono::duration<double, std::micro>(n - t).count());
+        t = n;
+    }
+};
+
 // libomp keeps its workers spinning for 200 ms after a parallel region by default; that steals the cores the HIP
 // runtime's own threads need between the short host-side parallel loops of an E-step.
 extern "C" void kmp_set_blocktime(int) __attribute__((weak));
@@ -1551,13 +1564,19 @@ void smcpp_im::dev_prepare() {
     } else {
         smcpp_host::ModelParamsT<double> p;
         p.a = model.a; p.s = model.s;
+        HostTrace tr;
         const smcpp_host::RateFunctionT<double> eta(p, hs);
+        tr.mark("prep: rate function");
         const std::vector<double> act = eta.average_coal_times();
+        tr.mark("prep: average coal times");
         dprep->run(eta, act, theta, alpha, 0, stream);
+        tr.mark("prep: pack + 2 launches");
         smcpp_host::initial_distribution(eta, pi);
         smcpp_host::TransitionGenerators<double> g;
         tgen = smcpp_host::transition_generators_jac(eta, rho, act, nullptr, nullptr, 0, &g);
+        tr.mark("prep: pi + T generators");
         T = smcpp_host::transition_expand<double>(g);
+        tr.mark("prep: T expand");
         tgen_valid = tgen.ok;
         dpi.clear(); dT.clear();
         dT_valid = true;
@@ -2738,7 +2757,8 @@ void smcpp_im::ss_launch_initial() {
     ss_launched = ss_pass0;
     const int want = std::min(max_pass, ss_pass0 + (last_ss_passes > 0 ? last_ss_passes + 1 : 6));
     ss_launch_passes(want);
-    HIPCHK(hipEventRecord(ev[11], s));
+    // (no event behind the passes here: run_chains_ss records ev[3] at this very position, and every record costs the queue ~3 us
+    // in front of the statistics' critical branch - tools/sync_lab.hip)
 }
 
 bool smcpp_im::wait_done(int epoch) {
@@ -2769,7 +2789,6 @@ void smcpp_im::run_chains_ss() {
         return -1;
     };
     ss_warm_valid = false;
-    HIPCHK(hipEventRecord(ev[1], s));
     bool first_round = true;
     int q = -1;
     static const bool poll = !(getenv("SMCPP_POLL") && atoi(getenv("SMCPP_POLL")) == 0);
@@ -2848,17 +2867,29 @@ void smcpp_im::enqueue_stats() {
     // (log_c, omega_1, rank update); with two streams the short launches of one fill the gaps of the other.
     const bool split_streams = dual_stream && stream2 != nullptr && !slabs_eg.empty();
     const int stats_variant = getenv("SMCPP_STATS_VARIANT") ? atoi(getenv("SMCPP_STATS_VARIANT")) : 0;
-    hipStream_t se = split_streams ? ((eigfree && (stats_variant & 1)) ? stream_hi : stream2) : s;
+    // Eigen-free statistics of small inputs: the branch rank update of the span > 1 rows -> reduction -> span fold (2 x s_max serial
+    // steps) is the critical path of the phase, and a hop between two streams costs ~10 us on this runtime (tools/sync_lab.hip:
+    // event record -> wait on another queue; 2 us between two kernels of one queue).  So THAT branch stays on the main stream,
+    // directly behind the last pass of the chains and in front of the finalisation, and the two span-1 branches (which have slack)
+    // fork to the side streams.  (Rounds 2-3 had it the other way round: 40 us between the chains' end and the first kernel of the
+    // critical branch.)  SMCPP_STATS_VARIANT & 4 restores the old arrangement.
+    const bool crit_main = eigfree && dual_stream && stream2 != nullptr && !slabs_eg.empty() && !(stats_variant & 6) && n_e_rows < 1000000 &&
+                           Mp <= 64;      // (M > 64: chip-filling rank updates, the hops do not matter and the old order is 3 % faster)
+    hipStream_t se = crit_main ? s : split_streams ? ((eigfree && (stats_variant & 1)) ? stream_hi : stream2) : s;
+    hipStream_t sp1 = crit_main ? stream2 : s;          // the span-1 branch
+    // (scan chains: run_chains_ss has just recorded ev[3] behind the last pass - the fork event, without a second record)
+    hipEvent_t ev_fork = ss_active ? ev[3] : ev[8];
     if (split_streams) {
-        HIPCHK(hipEventRecord(ev[8], s));
-        HIPCHK(hipStreamWaitEvent(se, ev[8], 0));
+        if (!ss_active) HIPCHK(hipEventRecord(ev[8], s));
+        if (se != s) HIPCHK(hipStreamWaitEvent(se, ev_fork, 0));
+        if (sp1 != s) HIPCHK(hipStreamWaitEvent(sp1, ev_fork, 0));
     }
     // nothing in the statistics reads log_c any more (the span-1 weights take c itself): the two log-likelihood kernels
     // ride on the eigen stream instead of heading the critical path of the main one
     // ... and on a third stream when there is one: on un-binned data (a million rows per contig) they take 0.1 ms
     const bool ll_own = split_streams && stream3 != nullptr && !eigfree;     // (eigen-free: free at the head of the main stream, which waits there)
-    hipStream_t sl = ll_own ? stream3 : (eigfree ? s : se);          // (the eigen-free branch of the second stream is the longer one)
-    if (ll_own) HIPCHK(hipStreamWaitEvent(sl, ev[8], 0));
+    hipStream_t sl = ll_own ? stream3 : (crit_main ? sp1 : eigfree ? s : se);   // (the eigen-free branch is the longer one)
+    if (ll_own) HIPCHK(hipStreamWaitEvent(sl, ev_fork, 0));
     hipLaunchKernelGGL(k_loglik_partial, dim3(llblk, n_contigs), dim3(256), 0, sl, la);
     hipLaunchKernelGGL(k_loglik_final, dim3(n_contigs), dim3(256), 0, sl, la);
     if (ll_own) HIPCHK(hipEventRecord(ev[19], sl));
@@ -2901,8 +2932,10 @@ void smcpp_im::enqueue_stats() {
         AccArgs ae = aa;
         ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
         hipLaunchKernelGGL(k_rank_acc<2>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
-        HIPCHK(hipEventRecord(ev[17], se));
-        HIPCHK(hipStreamWaitEvent(s, ev[17], 0));
+        if (!crit_main) {
+            HIPCHK(hipEventRecord(ev[17], se));
+            HIPCHK(hipStreamWaitEvent(s, ev[17], 0));
+        }
     }
     // ---- span-1 branch (main stream) ----
     // M <= 64: k_rank_acc forms the weights itself, so the per-key gamma sums (k_s1_scalars + their reduction) are a third
@@ -2922,10 +2955,13 @@ void smcpp_im::enqueue_stats() {
     const bool kfuse = !gfuse && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_fk.empty() &&
                        (kf_env ? atoi(kf_env) != 0 : n_1_rows >= 500000);
     const bool s1_own = !gfuse && !kfuse && dual_stream && stream3 != nullptr && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_sc.empty();
-    hipStream_t s1s = s1_own ? stream3 : s;
+    hipStream_t s1s = s1_own ? stream3 : sp1;
     if (s1_own) {
-        HIPCHK(hipEventRecord(ev[15], s));
-        HIPCHK(hipStreamWaitEvent(s1s, ev[15], 0));
+        if (crit_main) HIPCHK(hipStreamWaitEvent(s1s, ev_fork, 0));     // (forks where the span-1 branch does: at the chains' end)
+        else {
+            HIPCHK(hipEventRecord(ev[15], s));
+            HIPCHK(hipStreamWaitEvent(s1s, ev[15], 0));
+        }
     }
     if (!slabs_sc.empty() && !gfuse && !kfuse) {
         S1Args sa;
@@ -2938,17 +2974,17 @@ void smcpp_im::enqueue_stats() {
             hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, s1s,
                                (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
             HIPCHK(hipEventRecord(ev[16], s1s));
-        } else if (split_streams) HIPCHK(hipEventRecord(ev[14], s));
+        } else if (split_streams) HIPCHK(hipEventRecord(ev[14], sp1));
     }
     if (kfuse) {
         d_part_1.alloc(std::max<size_t>(1, slabs_fk.size()) * Mp * Mp);
         d_gpart_fk.alloc(slabs_fk.size() * Mp);
         aa.nslabs = (int)slabs_fk.size(); aa.slabs = d_slabs_fk.p; aa.perm = d_perm1.p; aa.permk = nullptr; aa.part = d_part_1.p;
         aa.gpart = d_gpart_fk.p;
-        hipLaunchKernelGGL(k_rank_acc<3>, dim3(aa.nslabs, 1), dim3(64), 0, s, aa);
-        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, s,
+        hipLaunchKernelGGL(k_rank_acc<3>, dim3(aa.nslabs, 1), dim3(64), 0, sp1, aa);
+        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, sp1,
                            (const double *)d_gpart_fk.p, (const int *)d_fk_gk_off.p, d_red_g.p, Mp, 1);
-        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), n_contigs, ZS), dim3(256), 0, s,
+        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), n_contigs, ZS), dim3(256), 0, sp1,
                            (const double *)d_part_1.p, (const int *)d_fk_c_off.p, d_red_1.p, MMi, ZS);
     } else
     if (!slabs_rk.empty()) {
@@ -2956,27 +2992,27 @@ void smcpp_im::enqueue_stats() {
         if (gfuse) {
             d_gpart2.alloc((size_t)slabs_rk.size() * K * Mp);
             switch ((K + 15) / 16) {
-                case 1: hipLaunchKernelGGL(k_rank_acc_g<1>, dim3(aa.nslabs), dim3(64), 0, s, aa, K, d_gpart2.p); break;
-                case 2: hipLaunchKernelGGL(k_rank_acc_g<2>, dim3(aa.nslabs), dim3(64), 0, s, aa, K, d_gpart2.p); break;
-                case 3: hipLaunchKernelGGL(k_rank_acc_g<3>, dim3(aa.nslabs), dim3(64), 0, s, aa, K, d_gpart2.p); break;
-                default: hipLaunchKernelGGL(k_rank_acc_g<4>, dim3(aa.nslabs), dim3(64), 0, s, aa, K, d_gpart2.p); break;
+                case 1: hipLaunchKernelGGL(k_rank_acc_g<1>, dim3(aa.nslabs), dim3(64), 0, sp1, aa, K, d_gpart2.p); break;
+                case 2: hipLaunchKernelGGL(k_rank_acc_g<2>, dim3(aa.nslabs), dim3(64), 0, sp1, aa, K, d_gpart2.p); break;
+                case 3: hipLaunchKernelGGL(k_rank_acc_g<3>, dim3(aa.nslabs), dim3(64), 0, sp1, aa, K, d_gpart2.p); break;
+                default: hipLaunchKernelGGL(k_rank_acc_g<4>, dim3(aa.nslabs), dim3(64), 0, sp1, aa, K, d_gpart2.p); break;
             }
             // gamma sums per contig: the slabs of a contig are contiguous (s1_slab_off), red_g is [contig][K][Mp]
-            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(K * Mp, 256), n_contigs, 1), dim3(256), 0, s,
+            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(K * Mp, 256), n_contigs, 1), dim3(256), 0, sp1,
                                (const double *)d_gpart2.p, (const int *)d_s1_slab_off.p, d_red_g.p, K * Mp, 1);
         } else
-        hipLaunchKernelGGL(k_rank_acc<0>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, s, aa);
+        hipLaunchKernelGGL(k_rank_acc<0>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, sp1, aa);
     }
     // the per-key gamma sums only need the span-1 scalars: with two streams their reduction runs at the tail of the eigen
     // stream (which finishes earlier) instead of between the two rank-update kernels of the main one
     const bool gsum_on_se = split_streams && !slabs_sc.empty() && !s1_own && !gfuse && !kfuse;
     if (!gsum_on_se && !s1_own && !gfuse && !kfuse)
-        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, s,
+        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, sp1,
                            (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
     if (!kfuse)
-    hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), n_contigs, ZS), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), n_contigs, ZS), dim3(256), 0, sp1,
                        (const double *)d_part_1.p, (const int *)d_s1_slab_off.p, d_red_1.p, MMi, ZS);
-    HIPCHK(hipEventRecord(ev[4], s));
+    HIPCHK(hipEventRecord(ev[4], sp1));
     // ---- eigen branch (second stream when available) ----
     fa.eigfree = eigfree ? 1 : 0;
     if (!slabs_eg.empty() && eigfree) {
@@ -3101,13 +3137,15 @@ void smcpp_im::enqueue_stats() {
         hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, se,
                            (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
     }
-    if (split_streams) {
+    if (crit_main) {
+        HIPCHK(hipEventRecord(ev[9], sp1));
+        HIPCHK(hipStreamWaitEvent(s, ev[9], 0));
+    } else if (split_streams) {
         HIPCHK(hipEventRecord(ev[9], se));
         HIPCHK(hipStreamWaitEvent(s, ev[9], 0));
     }
     if (s1_own) HIPCHK(hipStreamWaitEvent(s, ev[16], 0));
-    hipLaunchKernelGGL(k_fin_xisum, dim3(nb2, n_contigs), dim3(256), 0, s, fa);
-    hipLaunchKernelGGL(k_fin_gamma, dim3(ceil_div((long long)(K + 1) * Mp, 256), n_contigs), dim3(256), 0, s, fa);
+    hipLaunchKernelGGL(k_fin_both, dim3(nb2 + ceil_div((long long)(K + 1) * Mp, 256), n_contigs), dim3(256), 0, s, fa, nb2);
     if (save_gamma && n_e_rows > 0) {
         hipStream_t sg = gamma_side ? stream_hi : s;
         GammaRowArgs ga;
@@ -3175,7 +3213,9 @@ void smcpp_im::estep() {
         throw std::runtime_error("theta / rho / alpha must be set");
     HIPCHK(hipSetDevice(device));
     auto t0 = std::chrono::steady_clock::now();
+    HostTrace tr;
     prepare_params();
+    tr.mark("estep: prepare_params");
     host_timing[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if ((int)pi.size() != M || (int)T.size() != M * M || (!E_on_dev && (int)E.size() != K * M))
         throw std::runtime_error("parameters are not set");
@@ -3188,17 +3228,22 @@ void smcpp_im::estep() {
     // bound for longer spans need the host copy
     if (E_on_dev && !(ss_static && eigfree_static && !ss4)) sync_host_E();
     ss_active = ss_static && ss_extract_generators();
+    tr.mark("estep: extract generators");
     if (!ss_active) ss_warm_valid = false;
     eigfree = ss_active && eigfree_static;
     if (E_on_dev && !(ss_active && eigfree)) sync_host_E();      // (a transition matrix without the structure)
     if (ss_active && !ss_hybrid) { prepass_launched = false; static_packed = false; ss_launch_initial(); }   // the chains need no eigensystem: they start now
     else if (ss_active) { prepass_launched = false; static_packed = false; }
     else stage_static_and_prepass();   // (when eligible) pass 0 of both chains starts now, on eigen-free operands
+    tr.mark("estep: first launches");
     host_prep_and_upload();   // the reference rebuilds the eigensystems on every E-step (inference_manager.cpp:112)
+    tr.mark("estep: host_prep_and_upload");
     if (ss_active && ss_hybrid) ss_launch_initial();       // hybrid rows read the eigensystems: the chains start behind them
     auto t1 = std::chrono::steady_clock::now();
     if (ss_active) run_chains_ss(); else run_chains();
+    tr.mark("estep: chains (host view)");
     run_stats();
+    tr.mark("estep: statistics enqueued");
     if (E_on_dev) {
         dprep->check_flags();
         if (ss_active && dprep->flags()[2]) {
@@ -3221,14 +3266,12 @@ void smcpp_im::estep() {
         (void)hipEventElapsedTime(&b_ms, ev[2], ev[3]);
     }
     float chains_ms = 0;
-    (void)hipEventElapsedTime(&chains_ms, ev[1], ev[3]);
     if (ss_active) {
-        // the first batch of passes ran before ev[1] (concurrently with the host phase); both directions share the launches
-        float first_ms = 0;
-        (void)hipEventElapsedTime(&first_ms, ev[10], ev[11]);
-        chains_ms += first_ms;
+        // every pass of both directions between two events: ev[10] in front of the first launch, ev[3] behind the last one (a rare
+        // round that needs more passes than were launched up front includes the host's look at the flags)
+        (void)hipEventElapsedTime(&chains_ms, ev[10], ev[3]);
         f_ms = b_ms = chains_ms;
-    }
+    } else (void)hipEventElapsedTime(&chains_ms, ev[1], ev[3]);
     if (prepass_launched) {
         // pass 0 ran before ev[1] (concurrently with the host eigensolve): add its kernel intervals
         (void)hipEventElapsedTime(&pre_f_ms, ev[10], ev[11]);

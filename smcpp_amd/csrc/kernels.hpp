@@ -3037,10 +3037,9 @@ __global__ __launch_bounds__(64 * NTP) void k_span_fused(FinArgs a, int smax, do
 }
 
 // xisum[contig] = max( (X1 + sum_e P_e Y_e diag(b_e)) o Td , 1e-20 )   (hmm.cpp:122,141,151-152)
-__global__ __launch_bounds__(256) void k_fin_xisum(FinArgs a) {
-    const int ct = blockIdx.y;
+__device__ __forceinline__ void fin_xisum_body(const FinArgs &a, int bx, int ct) {
     const int Mp = a.Mp, M = a.M;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = bx * 256 + threadIdx.x;
     if (idx >= Mp * Mp) return;
     const int i = idx / Mp, k = idx % Mp;
     double x = 0.0;
@@ -3071,10 +3070,9 @@ __global__ __launch_bounds__(256) void k_fin_xisum(FinArgs a) {
 }
 
 // gamma_sums[contig][key] and gamma0[contig]   (hmm.cpp:116-121,146,150)
-__global__ __launch_bounds__(256) void k_fin_gamma(FinArgs a) {
-    const int ct = blockIdx.y;
+__device__ __forceinline__ void fin_gamma_body(const FinArgs &a, int bx, int ct) {
     const int Mp = a.Mp, M = a.M;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = bx * 256 + threadIdx.x;
     if (idx >= (a.K + 1) * Mp) return;
     const int k = idx / Mp, i = idx % Mp;
     if (k == a.K) {                               // gamma.col(0) = alpha_0 o beta_0 (not normalised)
@@ -3100,6 +3098,11 @@ __global__ __launch_bounds__(256) void k_fin_gamma(FinArgs a) {
         }
     }
     a.gsum[((size_t)ct * a.K + k) * Mp + i] = g;
+}
+// both finalisations in one launch (they read disjoint inputs of the same phase): blocks [0, nbx) xisum, [nbx, nbx + nbg) gamma sums
+__global__ __launch_bounds__(256) void k_fin_both(FinArgs a, int nbx) {
+    if ((int)blockIdx.x < nbx) fin_xisum_body(a, (int)blockIdx.x, (int)blockIdx.y);
+    else fin_gamma_body(a, (int)blockIdx.x - nbx, (int)blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -595,6 +595,13 @@ struct smcpp_im {
     double *d_ll_view = nullptr;  // device address of h_ll
     int *h_done = nullptr, *d_done_view = nullptr;
     int done_epoch = 0;
+    DevBuf<unsigned> d_fin_ctr;          // blocks of the finalisation launches that raise h_done themselves (k_fin_both)
+    unsigned fin_target = 0;
+    int fold_done_epoch = 0;             // != 0: the statistics being enqueued end the queue and signal this epoch
+    bool done_folded = false;
+    bool timing_pending = false;         // the event intervals of the last E-step are read when somebody asks (resolve_timing)
+    double t_host01 = 0, t_host12 = 0;
+    void resolve_timing();
     bool done_covers_stats = false;
     bool wait_done(int epoch);
     double *h_ll = nullptr;       // pinned: per-contig log-likelihoods
@@ -2797,11 +2804,16 @@ void smcpp_im::run_chains_ss() {
         // optimistic, as run_chains(): the statistics are queued right behind the passes; the host only looks at the flags (pinned
         // memory the kernels wrote) when the queue has drained; in the rare round that needs more passes the statistics are redone
         static const bool spec_gamma = !(getenv("SMCPP_SPEC_GAMMA") && atoi(getenv("SMCPP_SPEC_GAMMA")) == 0);
-        if (first_round && (!save_gamma || spec_gamma)) enqueue_stats();          // (save_gamma too: the passes launched up front almost always suffice)
-        else stats_enqueued = false;
+        done_folded = false;
+        if (first_round && (!save_gamma || spec_gamma)) {              // (save_gamma too: the passes launched up front almost always suffice)
+            fold_done_epoch = poll ? done_epoch + 1 : 0;
+            enqueue_stats();
+            fold_done_epoch = 0;
+        } else stats_enqueued = false;
         done_covers_stats = stats_enqueued;
         if (poll) {
-            hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, s, d_done_view, ++done_epoch);
+            ++done_epoch;
+            if (!done_folded) hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, s, d_done_view, done_epoch);
             if (!wait_done(done_epoch)) throw std::runtime_error("the device did not signal completion");
         } else HIPCHK(hipStreamSynchronize(s));
         first_round = false;
@@ -3145,7 +3157,17 @@ void smcpp_im::enqueue_stats() {
         HIPCHK(hipStreamWaitEvent(s, ev[9], 0));
     }
     if (s1_own) HIPCHK(hipStreamWaitEvent(s, ev[16], 0));
-    hipLaunchKernelGGL(k_fin_both, dim3(nb2 + ceil_div((long long)(K + 1) * Mp, 256), n_contigs), dim3(256), 0, s, fa, nb2);
+    {
+        const int nbf = nb2 + ceil_div((long long)(K + 1) * Mp, 256);
+        // nothing follows the finalisation on this stream when gamma rows are not asked for: its last block signals the host
+        done_folded = fold_done_epoch != 0 && !save_gamma && !ll_own;
+        if (done_folded) {
+            if (!d_fin_ctr.p) { d_fin_ctr.alloc(1); HIPCHK(hipMemsetAsync(d_fin_ctr.p, 0, sizeof(unsigned), s)); fin_target = 0; }
+            fin_target += (unsigned)nbf * (unsigned)n_contigs;
+        }
+        hipLaunchKernelGGL(k_fin_both, dim3(nbf, n_contigs), dim3(256), 0, s, fa, nb2, d_fin_ctr.p, fin_target,
+                           done_folded ? d_done_view : (int *)nullptr, fold_done_epoch);
+    }
     if (save_gamma && n_e_rows > 0) {
         hipStream_t sg = gamma_side ? stream_hi : s;
         GammaRowArgs ga;
@@ -3208,10 +3230,51 @@ void smcpp_im::enqueue_stats() {
     stats_enqueued = true;
 }
 
+// Event intervals of the last E-step -> timing[] (lazily: see estep)
+void smcpp_im::resolve_timing() {
+    if (!timing_pending) return;
+    timing_pending = false;
+    HIPCHK(hipSetDevice(device));
+    (void)hipEventSynchronize(ev[5]);
+    float f_ms = 0, b_ms = 0, s_ms = 0, fin_ms = 0;
+    if (ss_active) {
+        // one launch per pass for both directions, timed below
+    } else if (chains_dual) {
+        (void)hipEventElapsedTime(&f_ms, ev[1], ev[7]);   // forward passes (main stream)
+        (void)hipEventElapsedTime(&b_ms, ev[2], ev[3]);   // backward passes (second stream), overlapping the forward ones
+    } else {
+        (void)hipEventElapsedTime(&f_ms, ev[1], ev[2]);
+        (void)hipEventElapsedTime(&b_ms, ev[2], ev[3]);
+    }
+    float chains_ms = 0;
+    if (ss_active) {
+        // every pass of both directions between two events: ev[10] in front of the first launch, ev[3] behind the last one (a rare
+        // round that needs more passes than were launched up front includes the host's look at the flags)
+        (void)hipEventElapsedTime(&chains_ms, ev[10], ev[3]);
+        f_ms = b_ms = chains_ms;
+    } else (void)hipEventElapsedTime(&chains_ms, ev[1], ev[3]);
+    if (prepass_launched) {
+        // pass 0 ran before ev[1] (concurrently with the host eigensolve): add its kernel intervals
+        (void)hipEventElapsedTime(&pre_f_ms, ev[10], ev[11]);
+        (void)hipEventElapsedTime(&pre_b_ms, ev[12], ev[13]);
+        f_ms += pre_f_ms; b_ms += pre_b_ms;
+        chains_ms += std::max(pre_f_ms, pre_b_ms);
+    }
+    (void)hipEventElapsedTime(&s_ms, ev[3], ev[4]);
+    (void)hipEventElapsedTime(&fin_ms, ev[4], ev[5]);
+    (void)hipGetLastError();      // an interval over an event this E-step never recorded must not surface in the next launch check
+    timing[0] = t_host01;
+    timing[1] = chains_ms;   // wall time of both chains (they overlap in dual-stream mode)
+    timing[2] = f_ms; timing[3] = b_ms; timing[4] = s_ms; timing[5] = fin_ms;
+    timing[6] = t_host12;
+    timing[7] = last_fwd_passes; timing[8] = last_bwd_passes;
+}
+
 void smcpp_im::estep() {
     if (std::isnan(theta) || std::isnan(rho) || std::isnan(alpha))
         throw std::runtime_error("theta / rho / alpha must be set");
     HIPCHK(hipSetDevice(device));
+    timing_pending = false;          // (intervals nobody asked for: the events are about to be recorded again)
     auto t0 = std::chrono::steady_clock::now();
     HostTrace tr;
     prepare_params();
@@ -3255,42 +3318,18 @@ void smcpp_im::estep() {
         }
     }
     auto t2 = std::chrono::steady_clock::now();
-    float f_ms = 0, b_ms = 0, s_ms = 0, fin_ms = 0;
-    if (ss_active) {
-        // one launch per pass for both directions, timed below
-    } else if (chains_dual) {
-        (void)hipEventElapsedTime(&f_ms, ev[1], ev[7]);   // forward passes (main stream)
-        (void)hipEventElapsedTime(&b_ms, ev[2], ev[3]);   // backward passes (second stream), overlapping the forward ones
-    } else {
-        (void)hipEventElapsedTime(&f_ms, ev[1], ev[2]);
-        (void)hipEventElapsedTime(&b_ms, ev[2], ev[3]);
+    // the event intervals are read when somebody asks for them (smcpp_last_timing, the debug log): ev[5] sits BEHIND the completion
+    // word the host has just seen, so querying it here would mean waiting for it
+    t_host01 = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    t_host12 = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    host_timing[3] = t_host01;
+    timing_pending = true;
+    if (g_logger_cb) {
+        resolve_timing();
+        log_msg("DEBUG", "E-step: %d contig(s), %lld rows, M = %d, K = %d keys; host %.3f ms, chains %.3f ms (%d forward / %d "
+                "backward passes), statistics %.3f ms; loglik[0] = %.10g", n_contigs, total_rows - n_contigs, M, K, timing[0],
+                timing[1], last_fwd_passes, last_bwd_passes, timing[4] + timing[5], loglik.empty() ? 0.0 : loglik[0]);
     }
-    float chains_ms = 0;
-    if (ss_active) {
-        // every pass of both directions between two events: ev[10] in front of the first launch, ev[3] behind the last one (a rare
-        // round that needs more passes than were launched up front includes the host's look at the flags)
-        (void)hipEventElapsedTime(&chains_ms, ev[10], ev[3]);
-        f_ms = b_ms = chains_ms;
-    } else (void)hipEventElapsedTime(&chains_ms, ev[1], ev[3]);
-    if (prepass_launched) {
-        // pass 0 ran before ev[1] (concurrently with the host eigensolve): add its kernel intervals
-        (void)hipEventElapsedTime(&pre_f_ms, ev[10], ev[11]);
-        (void)hipEventElapsedTime(&pre_b_ms, ev[12], ev[13]);
-        f_ms += pre_f_ms; b_ms += pre_b_ms;
-        chains_ms += std::max(pre_f_ms, pre_b_ms);
-    }
-    (void)hipEventElapsedTime(&s_ms, ev[3], ev[4]);
-    (void)hipEventElapsedTime(&fin_ms, ev[4], ev[5]);
-    (void)hipGetLastError();      // an interval over an event this E-step never recorded must not surface in the next launch check
-    timing[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    host_timing[3] = timing[0];
-    timing[1] = chains_ms;   // wall time of both chains (they overlap in dual-stream mode)
-    timing[2] = f_ms; timing[3] = b_ms; timing[4] = s_ms; timing[5] = fin_ms;
-    timing[6] = std::chrono::duration<double, std::milli>(t2 - t1).count();
-    timing[7] = last_fwd_passes; timing[8] = last_bwd_passes;
-    log_msg("DEBUG", "E-step: %d contig(s), %lld rows, M = %d, K = %d keys; host %.3f ms, chains %.3f ms (%d forward / %d "
-            "backward passes), statistics %.3f ms; loglik[0] = %.10g", n_contigs, total_rows - n_contigs, M, K, timing[0],
-            (double)chains_ms, last_fwd_passes, last_bwd_passes, (double)(s_ms + fin_ms), loglik.empty() ? 0.0 : loglik[0]);
     stats_on_host = false;
     have_reduced = false;
     if (qdev) qdev->stats_ready = false;
@@ -3850,7 +3889,7 @@ int smcpp_set_chunking(smcpp_im *im, int rows_per_chunk, double eps_alpha, doubl
 }
 
 int smcpp_last_timing(smcpp_im *im, double out[9]) {
-    API_BEGIN std::memcpy(out, im->timing, sizeof(double) * 9); API_END
+    API_BEGIN im->resolve_timing(); std::memcpy(out, im->timing, sizeof(double) * 9); API_END
 }
 
 int smcpp_last_host_timing(smcpp_im *im, double out[4]) {

@@ -3100,9 +3100,21 @@ __device__ __forceinline__ void fin_gamma_body(const FinArgs &a, int bx, int ct)
     a.gsum[((size_t)ct * a.K + k) * Mp + i] = g;
 }
 // both finalisations in one launch (they read disjoint inputs of the same phase): blocks [0, nbx) xisum, [nbx, nbx + nbg) gamma sums
-__global__ __launch_bounds__(256) void k_fin_both(FinArgs a, int nbx) {
+// `done` != nullptr: this launch ends the E-step's queue - the block that finishes LAST (a counter that only ever grows: `target` =
+// blocks of every such launch so far) raises the host-visible completion word itself instead of a one-thread kernel behind it
+__global__ __launch_bounds__(256) void k_fin_both(FinArgs a, int nbx, unsigned *ctr, unsigned target, int *done, int epoch) {
     if ((int)blockIdx.x < nbx) fin_xisum_body(a, (int)blockIdx.x, (int)blockIdx.y);
     else fin_gamma_body(a, (int)blockIdx.x - nbx, (int)blockIdx.y);
+    if (!done) return;
+    __syncthreads();                                   // every store of this block has been issued ...
+    if (threadIdx.x == 0) {
+        __threadfence();                               // ... and is visible device-wide before the block counts itself
+        const unsigned prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1u == target) {
+            __threadfence_system();
+            __hip_atomic_store(done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

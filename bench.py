@@ -362,7 +362,7 @@ def main():
         # ISSUE, so that is what the roofline block prices: `achieved` = wave-level VALU instructions per second summed over
         # all launches of one E-step (SQ_INSTS_VALU of the committed rocprofv3 --pmc pass of this same command when there is one
         # for this workload, else the instruction count of the kernel's ISA per position x the positions every pass walks),
-        # `peak` = one VALU instruction per cycle and SIMD (1024 SIMDs x the 2.4 GHz peak engine clock).  The reference's dense
+        # `peak` = one wave64 DPP / fp64 instruction per 4 cycles and SIMD (1024 SIMDs x the 2.4 GHz peak engine clock / 4).  The reference's dense
         # flops priced on this kernel's clock stay available as `frac_dense_equivalent` (rounds 1-3 quoted that as `frac`; it is
         # a speed against the reference's ALGORITHM, grows with M whatever the kernel does, and is not a utilisation).
         kname = "k_chain_ss"
@@ -384,20 +384,29 @@ def main():
             light = max(0.0, passes - 2.0)
             est_instr = positions * (light * (ipp[2] + ipp[3]) + 1.4 * (ipp[0] + ipp[1]))
         instr = sq["SQ_INSTS_VALU_per_step"] if sq else est_instr
-        peak_ginstr = 1024 * 2.4                           # G wave-instructions / s: 256 CUs x 4 SIMDs x 2.4 GHz, one VALU issue per cycle
+        # peak: G wave64-instructions / s of the vector ALUs.  A SIMD needs 4 cycles per wave64 DPP or fp64 instruction - the two
+        # kinds the scans are made of: 1024 SIMDs x 2.4 GHz / 4 = 614.4 (= the guide's 157.3 TFLOP/s FP32 vector peak / 256 flop per
+        # v_pk_fma_f32 wave-instruction).  Measured, tools/dpp_lab.hip with 8 wavefronts per SIMD (profiles/r04_*_dpp_lab.log):
+        # v_fmac_f32_dpp 587, v_mov_b32_dpp 587, v_fma_f64 583; with ONE wavefront per SIMD - this kernel's regime - 467 / 468 / 427.
+        # (Plain 32-bit VALU instructions issue in 2 cycles: v_add_f32 1002 measured; they are 4 of the 25 - 59 per position.)
+        # Until r04_k the block divided by 1024 x 2.4 = 2457.6 (one instruction per cycle and SIMD), which no instruction reaches.
+        peak_ginstr = 1024 * 2.4 / 4.0
+        one_wave_ginstr = 447.0                            # measured mean of the three, one wavefront per SIMD
         ach_ginstr = (instr / (1e-3 * k_ms) / 1e9) if (instr and k_ms > 0) else None
         roof = dict(bound="valu-issue", achieved=ach_ginstr, peak=peak_ginstr, unit="G wave-instr/s",
                     frac=(ach_ginstr / peak_ginstr) if ach_ginstr else None)
         other = {"bound_detail": "VALU issue: O(M) DPP scans per position over the semiseparable structure of T, one wavefront per "
-                                 "SIMD (tools/dpp_lab.hip: 5.3 clocks between two issues of one wavefront); no matrix product executes",
+                                 "SIMD on one contig (tools/dpp_lab.hip: 5.3 clocks between two issues of one wavefront, 4 with several); no matrix product executes",
                  "instr_source": (sq["source"] if sq else "ISA instruction count x positions walked (model; no counter profile for this workload)"),
                  "instr_per_position": (dict(zip(["full_fwd", "full_bwd", "light_fwd", "light_bwd"], ipp)) if ipp else None),
-                 "frac_one_wavefront_issue_bound": (ach_ginstr / (peak_ginstr / 5.3)) if ach_ginstr else None,
+                 "peak_source": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 DPP / fp64 instruction (MI355X_MICROARCH.md: 157.3 TFLOP/s FP32 "
+                                "vector = 614.4 G v_pk_fma_f32 / s); tools/dpp_lab.hip measures 583 - 587 with 8 wavefronts per SIMD, 427 - 468 with one",
+                 "frac_one_wavefront_issue_bound": (ach_ginstr / one_wave_ginstr) if ach_ginstr else None,
                  "sq_counters": sq,
                  "executed_flops_estimate": 30.0 * M * positions * 2.0,
                  "frac_dense_equivalent": ach_tflops / FP64_PEAK_TFLOPS, "dense_equivalent_tflops": ach_tflops,
                  "positions": positions, "positions_per_us": positions / (1e3 * k_ms) if k_ms > 0 else 0.0}
-        note = ("both chains in one kernel; frac = executed wave-level VALU instructions / (kernel time x 1024 SIMDs x 2.4 GHz); "
+        note = ("both chains in one kernel; frac = executed wave-level VALU instructions / (kernel time x 1024 SIMDs x 2.4 GHz / 4 cycles); "
                 "frac_hbm = algorithmic alpha/beta/normaliser bytes of one pass / kernel time / 8 TB/s")
     else:
         # The chain kernels (k_fwd_coop / k_bwd_coop, k_*_big for M > 64) dominate.  smcpp_last_timing brackets ALL pass

@@ -45,5 +45,31 @@ int main() {
     long long h[16];
     hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
     for (int v = 0; v < 12; ++v) printf("%-45s %6.2f clocks / instruction\n", names[v], (double)h[v] / (iters * 64.0));
+    // aggregate VALU issue rate of the chip with W single-wavefront workgroups per SIMD (wall clock): the roofline's peak
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto rate = [&](int v, int W) {
+        const int nb = 1024 * W, it = 4000;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, 0);
+            if (v == 0) hipLaunchKernelGGL(k<0>, dim3(nb), dim3(64), 0, 0, d, sink, it);
+            if (v == 4) hipLaunchKernelGGL(k<4>, dim3(nb), dim3(64), 0, 0, d, sink, it);
+            if (v == 9) hipLaunchKernelGGL(k<9>, dim3(nb), dim3(64), 0, 0, d, sink, it);
+            if (v == 1) hipLaunchKernelGGL(k<1>, dim3(nb), dim3(64), 0, 0, d, sink, it);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+        }
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        return (double)nb * it * 64.0 / (ms * 1e-3) / 1e9;
+    };
+    hipFree(sink);
+    hipMalloc(&sink, (size_t)64 * 1024 * 8 * sizeof(float));
+    const int vs[] = {0, 9, 1, 4};
+    for (int v : vs) {
+        printf("%-28s G wave-instructions / s, chip, with 1 / 2 / 4 / 8 wavefronts per SIMD:", names[v]);
+        for (int W = 1; W <= 8; W *= 2) printf(" %7.1f", rate(v, W));
+        printf("\n");
+    }
     return 0;
 }

@@ -370,11 +370,16 @@ def main():
         k_flops, k_bytes = 2.0 * flops, bytes_f + bytes_b
         ach_tflops = k_flops / (1e-3 * k_ms) / 1e12 if k_ms > 0 else 0.0
         ach_gbs = k_bytes / (1e-3 * k_ms) / 1e9 if k_ms > 0 else 0.0
-        positions = float(sum(int(c[:, 0].sum()) for c in contigs))
+        if mode == 6:
+            # hybrid rows (un-binned data): a row longer than the threshold is ONE eigen-power step, balanced (and priced here) as
+            # SS_HYB_COST = 8 scan positions (engine.hip); shorter rows are expanded position by position
+            positions = float(sum(int(np.where(c[:, 0] > 6, 8, c[:, 0]).sum()) for c in contigs))
+        else:
+            positions = float(sum(int(c[:, 0].sum()) for c in contigs))
         npl = (M + 63) // 64
-        # VALU instructions per position of the ISA (llvm-objdump of k_chain_ss<NPL>): full fp64 pass
-        # forward / backward, light float pass forward / backward
-        ipp = {1: (53, 59, 25, 29)}.get(npl)
+        # VALU instructions per position in the inner loops of k_chain_ss<NPL> (llvm-objdump of the shipped code object, two
+        # positions per trip): full fp64 pass forward / backward, light float pass forward / backward
+        ipp = {1: (45, 57, 20, 28), 2: (56, 74, 28, 39), 3: (65, 88, 36, 53), 4: (74, 102, 41, 56)}.get(npl)
         sq = sq_counters(args.workload if (args.length_mbp == 100.0 and world == 1) else None, kname)
         passes = med["fwd_passes"]
         est_instr = None

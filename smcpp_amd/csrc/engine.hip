@@ -30,7 +30,11 @@
 #include "chains2.hpp"
 #include "chains_lock.hpp"
 #include "chains_ss.hpp"
+// Four chains per wavefront (chains_ss4.hpp): parity-green but slower than one chain per wavefront wherever measured (DESIGN.md
+// section 10) - not part of the default build since round 4.  -DSMCPP_WITH_SS4 compiles the kernels in; SMCPP_SS4=1 then selects them.
+#ifdef SMCPP_WITH_SS4
 #include "chains_ss4.hpp"
+#endif
 #include "nonsym_eig.hpp"
 #include "nonsym_eig_team.hpp"
 #include "prep.hpp"
@@ -888,7 +892,12 @@ void smcpp_im::make_chunks() {
             // cascade over several launches - measured 1.9 ms of chains against 1.0 ms with one chain per wavefront; the layout pays
             // when the chunks are long, i.e. on whole genomes, and is kept for that: DESIGN.md)
             const char *s4 = getenv("SMCPP_SS4");
+#ifdef SMCPP_WITH_SS4
             ss4 = ss_static && Mp <= 64 && (s4 && atoi(s4) != 0) && (long long)K * 16 * SPL * 8 <= 100 * 1024;
+#else
+            ss4 = false;
+            if (s4 && atoi(s4) != 0) log_msg("WARNING", "SMCPP_SS4 ignored: the four-chains kernels are not compiled in (-DSMCPP_WITH_SS4)");
+#endif
         }
         const char *b = getenv("SMCPP_COOP_BPC");
         if (b && atoi(b) > 0) coop_bpc = atoi(b);
@@ -2582,6 +2591,7 @@ static void launch_chain_ss(int npl, const SsArgs &a, int ntasks, size_t shm, hi
     }
 }
 
+#ifdef SMCPP_WITH_SS4
 template <int SPL_>
 static void launch_chain_ss4_t(const SsArgs &a, size_t shm, hipStream_t s) {
     static bool once = false;
@@ -2600,6 +2610,9 @@ static void launch_chain_ss4(int spl, const SsArgs &a, size_t shm, hipStream_t s
         default: throw std::runtime_error("unsupported number of hidden states");
     }
 }
+#else
+static void launch_chain_ss4(int, const SsArgs &, size_t, hipStream_t) { throw std::runtime_error("built without SMCPP_WITH_SS4"); }
+#endif
 
 void smcpp_im::ss_launch_passes(int upto) {
     const size_t shm = (size_t)ss_nlds * 64 * NPL * sizeof(double) + ss_tab_bytes();
@@ -3958,6 +3971,10 @@ int smcpp_debug_ss_apply(int M, const double *T, int nvec, const double *x, cons
 // ... and of the four-chains-per-wavefront layout (M <= 64): same contract.
 int smcpp_debug_ss4_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b) {
     API_BEGIN
+#ifndef SMCPP_WITH_SS4
+    (void)M; (void)T; (void)nvec; (void)x; (void)e; (void)out_f; (void)out_b;
+    throw std::runtime_error("built without SMCPP_WITH_SS4");
+#else
     if (M > 64) throw std::runtime_error("four chains per wavefront: M <= 64");
     const int SPL = (M + 15) / 16, MS = 16 * SPL;
     std::vector<double> gen;
@@ -3993,6 +4010,7 @@ int smcpp_debug_ss4_apply(int M, const double *T, int nvec, const double *x, con
         std::memcpy(out_f + (size_t)v * M, &hf[(size_t)v * MS], sizeof(double) * M);
         std::memcpy(out_b + (size_t)v * M, &hb[(size_t)v * MS], sizeof(double) * M);
     }
+#endif
     API_END
 }
 

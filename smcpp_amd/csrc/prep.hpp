@@ -653,9 +653,18 @@ template <typename L> inline M3T<L> matrix_exp(const L &c_rho, const L &c_eta) {
     const L y = c_eta + c_rho / (ld)2, x = sq / (ld)2;
     L ec((ld)1), es((ld)0.5L);   // e*cosh(x), e*sinh(x)/sq
     if (sval(sq) != 0) {
-        const L ep = m_exp(x - y), em = m_exp(-x - y);
-        ec = (ld)0.5L * (ep + em);
-        es = (sval(x) < 0.5L) ? m_exp(-y) * m_sinh(x) / sq : (ld)0.5L * (ep - em) / sq;
+        if (sval(x) < 40.0L) {
+            // two transcendentals instead of four: e^-y and e^x - 1; e^-x = 1 / e^x, sinh x = (t + t e^-x) / 2 with t = e^x - 1
+            // (no cancellation for small x, and e^x stays far from overflow)
+            const L ey = m_exp(-y), t = m_expm1(x);
+            const L exm = (ld)1 / ((ld)1 + t);
+            ec = (ld)0.5L * (ey * ((ld)1 + t) + ey * exm);
+            es = ey * ((ld)0.5L * (t + t * exm)) / sq;
+        } else {
+            const L ep = m_exp(x - y), em = m_exp(-x - y);
+            ec = (ld)0.5L * (ep + em);
+            es = (ld)0.5L * (ep - em) / sq;
+        }
     }
     M3T<L> Qm;
     Qm.m[0][0] = ec + (2 * c_eta - c_rho) * es;
@@ -669,15 +678,22 @@ template <typename L> inline M3T<L> matrix_exp(const L &c_rho, const L &c_eta) {
 }
 // The same exponential with its two partial derivatives in closed form (no second pass through the formulas with dual numbers):
 // with S = sq es = e^-y sinh x,  d ec = x' S - y' ec,  d S = x' ec - y' S,  d es = (d S - es d sq) / sq.
-inline void matrix_exp_partials(ld c_rho, ld c_eta, M3T<ld> &Q, M3T<ld> &Qr, M3T<ld> &Qe) {
+inline void matrix_exp_partials(ld c_rho, ld c_eta, M3T<ld> &Q, M3T<ld> &Qr, M3T<ld> &Qe, bool partials = true) {
     // (values: the operations of matrix_exp<ld>, in its order)
     const ld sq = sqrtl(4 * c_eta * c_eta + c_rho * c_rho);
     const ld y = c_eta + c_rho / (ld)2, x = sq / (ld)2;
-    ld ec = 1.0L, es = 0.5L, ep = 1.0L, em = 1.0L;
+    ld ec = 1.0L, es = 0.5L;
     if (sq != 0) {
-        ep = expl(x - y); em = expl(-x - y);
-        ec = (ld)0.5L * (ep + em);
-        es = (x < 0.5L) ? expl(-y) * sinhl(x) / sq : (ld)0.5L * (ep - em) / sq;
+        if (x < 40.0L) {
+            const ld ey = expl(-y), t = expm1l(x);
+            const ld exm = (ld)1 / ((ld)1 + t);
+            ec = (ld)0.5L * (ey * ((ld)1 + t) + ey * exm);
+            es = ey * ((ld)0.5L * (t + t * exm)) / sq;
+        } else {
+            const ld ep = expl(x - y), em = expl(-x - y);
+            ec = (ld)0.5L * (ep + em);
+            es = (ld)0.5L * (ep - em) / sq;
+        }
     }
     Q.m[0][0] = ec + (2 * c_eta - c_rho) * es;
     Q.m[0][1] = 2 * c_rho * es;
@@ -686,6 +702,7 @@ inline void matrix_exp_partials(ld c_rho, ld c_eta, M3T<ld> &Q, M3T<ld> &Qr, M3T
     Q.m[1][1] = ec - (2 * c_eta - c_rho) * es;
     Q.m[1][2] = (ld)1 - Q.m[1][0] - Q.m[1][1];
     Q.m[2][0] = 0.0L; Q.m[2][1] = 0.0L; Q.m[2][2] = 1.0L;
+    if (!partials) return;                            // (values only: a caller without derivative directions)
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { Qr.m[a][b] = 0.0L; Qe.m[a][b] = 0.0L; }
     if (sq == 0) return;                              // (no time, no change: never reached with positive piece lengths)
     const ld Sv = sq * es;
@@ -874,15 +891,15 @@ inline TransitionGenJac transition_generators_jac(const RateFunctionT<double> &e
         }
         const double delta = ts[i] - ts[i - 1];
         M3T<ld> Gr;
-        matrix_exp_partials((ld)delta * (ld)rho, (ld)ada[i - 1] * (ld)delta, E[i], Gr, G[i]);
+        matrix_exp_partials((ld)delta * (ld)rho, (ld)ada[i - 1] * (ld)delta, E[i], Gr, G[i], nder > 0);
         double gv[2];
         for (int c = 0; c < 3; ++c) {
             ld sacc = 0.0L;
             for (int k = 0; k < 3; ++k) sacc += pp[k] * E[i].m[k][c];
             pc[c] = sacc;
         }
-        for (int c = 0; c < 2; ++c) gv[c] = (double)(pp[0] * G[i].m[0][c] + pp[1] * G[i].m[1][c]) * delta;
         if (nder) {
+            for (int c = 0; c < 2; ++c) gv[c] = (double)(pp[0] * G[i].m[0][c] + pp[1] * G[i].m[1][c]) * delta;
             const double *da = dada + (size_t)(i - 1) * nder;
             for (int c = 0; c < 2; ++c) {
                 const double e0 = (double)E[i].m[0][c], e1 = (double)E[i].m[1][c], gd = gv[c];
@@ -967,8 +984,9 @@ inline TransitionGenJac transition_generators_jac(const RateFunctionT<double> &e
         M3T<double> X, Xr, Xe;
         {
             M3T<ld> Xl, Xrl, Xel;
-            matrix_exp_partials((ld)c_rho, (ld)c_eta, Xl, Xrl, Xel);
-            X = narrow(Xl); Xr = narrow(Xrl); Xe = narrow(Xel);
+            matrix_exp_partials((ld)c_rho, (ld)c_eta, Xl, Xrl, Xel, nder > 0);
+            X = narrow(Xl);
+            if (nder) { Xr = narrow(Xrl); Xe = narrow(Xel); }
         }
         A = m3_mul(A, X);                                  // (A_pre X: the generic routine's A)
         M3T<double> Pn;

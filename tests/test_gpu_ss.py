@@ -28,7 +28,10 @@ def ss_apply(T, x, e, four=False):
     fn = L.smcpp_debug_ss4_apply if four else L.smcpp_debug_ss_apply
     rc = fn(T.shape[0], _engine.dptr(T), x.shape[0], _engine.dptr(x), _engine.dptr(e), _engine.dptr(of), _engine.dptr(ob))
     if rc == 1:
-        raise RuntimeError(L.smcpp_last_error().decode())
+        msg = L.smcpp_last_error().decode()
+        if four and "SMCPP_WITH_SS4" in msg:
+            return None, None, None        # four-chains kernels not compiled in (default since round 4; -DSMCPP_WITH_SS4 builds them)
+        raise RuntimeError(msg)
     return rc, of, ob
 
 
@@ -61,6 +64,8 @@ def test_one_position_matches_dense_products(name):
     ref_b = (e * x) @ T.T             # T (e o x)
     for four in ([False, True] if M <= 64 else [False]):      # one chain / four chains per wavefront
         rc, of, ob = ss_apply(T, x, e, four)
+        if rc is None and four:
+            continue
         assert rc == 0
         check_products(of, ob, ref_f, ref_b)
 

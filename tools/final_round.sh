@@ -2,13 +2,13 @@
 # default bench (CPU leg included) + rocprofv3 kernel stats + FETCH / WRITE PMC passes (tools/profile_round.sh), SQ counters of the
 # headline and the whole genome, every workload's bench line, Q-with-gradient, warm start, the N > 1 path on one device (2 ranks;
 # 8 ranks with --check for c3 and c4), one rank's shard of the 8-GPU genome run, kernel stats of c3 / c5 / posterior / qgrad,
-# the DPP issue-cost lab.
-TAG=${1:-r04_k}
+# the DPP issue-cost lab, the stream-hop cost lab, a host trace of the headline's E-step.
+TAG=${1:-r04_m}
 cd $GRAFT_REPO_ROOT
 bash tools/profile_round.sh $TAG > /dev/null 2>&1
 O=gpurun_out/$TAG
 bash tools/pmc_sq_counters.sh $TAG headline c3 > $O/sq.log 2>&1
-for w in c2 c3 c4 c5 posterior; do python bench.py --workload $w > $O/bench_$w.log 2>&1; grep '^{"metric"' $O/bench_$w.log | tail -1 | cut -c1-200; done
+for w in c2 c3 c4 c5 posterior posterior64; do python bench.py --workload $w > $O/bench_$w.log 2>&1; grep '^{"metric"' $O/bench_$w.log | tail -1 | cut -c1-200; done
 python bench.py --workload qgrad > $O/bench_qgrad.log 2>&1; grep '^{"metric"' $O/bench_qgrad.log | tail -1 | cut -c1-260
 SMCPP_BENCH_THREADS=1 python bench.py --no-cpu > $O/bench_default_1thread.log 2>&1; grep '^{"metric"' $O/bench_default_1thread.log | tail -1 | cut -c1-200
 python bench.py --no-cpu --warm > $O/bench_warm.log 2>&1; grep '^{"metric"' $O/bench_warm.log | tail -1 | python -c "import sys,json; print('warm', json.loads(sys.stdin.read()).get('warm_start'))"
@@ -22,4 +22,6 @@ for w in c3 c5 posterior qgrad; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_$w -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload $w --steps 5 > /dev/null 2>&1
 done
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $GRAFT_REPO_ROOT/tools/dpp_lab.hip -o /tmp/dpp_lab && /tmp/dpp_lab > $GRAFT_REPO_ROOT/$O/dpp_lab.log 2>&1
+/opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 $GRAFT_REPO_ROOT/tools/sync_lab.hip -o /tmp/sync_lab && /tmp/sync_lab > $GRAFT_REPO_ROOT/$O/sync_lab.log 2>&1
+SMCPP_HOST_TRACE=1 python $GRAFT_REPO_ROOT/bench.py --no-cpu --steps 4 --warmup 2 2>&1 | grep host-trace | sed -n 40,60p > $GRAFT_REPO_ROOT/$O/host_trace.log
 grep '^{"metric"' $GRAFT_REPO_ROOT/$O/bench_default.log | tail -1 | cut -c1-300

@@ -371,9 +371,10 @@ def main():
         ach_tflops = k_flops / (1e-3 * k_ms) / 1e12 if k_ms > 0 else 0.0
         ach_gbs = k_bytes / (1e-3 * k_ms) / 1e9 if k_ms > 0 else 0.0
         if mode == 6:
-            # hybrid rows (un-binned data): a row longer than the threshold is ONE eigen-power step, balanced (and priced here) as
-            # SS_HYB_COST = 8 scan positions (engine.hip); shorter rows are expanded position by position
-            positions = float(sum(int(np.where(c[:, 0] > 6, 8, c[:, 0]).sum()) for c in contigs))
+            # hybrid rows (un-binned data): a row longer than the threshold is ONE eigen-power step - a dependent chain of ~200
+            # instructions, i.e. ~4 scan positions' worth of ISSUE (the chunk balancing prices it at 8: that
+            # is latency, two LDS round trips per row); shorter rows are expanded position by position
+            positions = float(sum(int(np.where(c[:, 0] > 6, 4, c[:, 0]).sum()) for c in contigs))
         else:
             positions = float(sum(int(c[:, 0].sum()) for c in contigs))
         npl = (M + 63) // 64

@@ -2912,12 +2912,28 @@ void smcpp_im::enqueue_stats() {
     // nothing in the statistics reads log_c any more (the span-1 weights take c itself): the two log-likelihood kernels
     // ride on the eigen stream instead of heading the critical path of the main one
     // ... and on a third stream when there is one: on un-binned data (a million rows per contig) they take 0.1 ms
+    // (which form the span-1 statistics take decides which streams are free: details where they are launched, below)
+    const bool gfuse_on = getenv("SMCPP_GAMMA_FUSE") && atoi(getenv("SMCPP_GAMMA_FUSE")) != 0;
+    const bool gfuse = gfuse_on && (Mp + 63) / 64 == 1 && K <= 64 && !save_gamma && !slabs_rk.empty();
+    // M <= 64, from half a million span-1 rows on: ONE pass over the span-1 rows in key-sorted order, single-key slabs - the rank
+    // update and the key's gamma sums from the same operands (k_rank_acc<3>); k_s1_scalars and its second read of alpha / beta do
+    // not run.  Measured: whole genome (3.6 M span-1 rows, bandwidth-bound) 3.77 -> 3.15 ms of statistics; one 100 Mbp contig
+    // (129 k rows, one wavefront per SIMD, latency-bound) 0.208 -> 0.225 ms - there the gamma sums stay a third concurrent
+    // branch.  SMCPP_S1_FUSE=0 / 1 forces either form.
+    const char *kf_env = getenv("SMCPP_S1_FUSE");
+    const bool kfuse = !gfuse && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_fk.empty() &&
+                       (kf_env ? atoi(kf_env) != 0 : (n_1_rows >= 500000 || crit_main));
+    // (round 4: with the span > 1 branch on the main stream the span-1 statistics are ONE side branch in the one-pass form instead
+    // of two - 887 against 873 headline evals per second, and 140 MB less traffic per E-step)
     const bool ll_own = split_streams && stream3 != nullptr && !eigfree;     // (eigen-free: free at the head of the main stream, which waits there)
-    hipStream_t sl = ll_own ? stream3 : (crit_main ? sp1 : eigfree ? s : se);   // (the eigen-free branch is the longer one)
-    if (ll_own) HIPCHK(hipStreamWaitEvent(sl, ev_fork, 0));
+    // crit_main with the one-pass span-1 form: the third stream has nothing else to do - the log-likelihood kernels run there,
+    // beside both branches instead of at the head of the span-1 branch (joined in front of the finalisation)
+    const bool ll3 = crit_main && kfuse && stream3 != nullptr;
+    hipStream_t sl = (ll_own || ll3) ? stream3 : (crit_main ? sp1 : eigfree ? s : se);   // (the eigen-free branch is the longer one)
+    if (ll_own || ll3) HIPCHK(hipStreamWaitEvent(sl, ev_fork, 0));
     hipLaunchKernelGGL(k_loglik_partial, dim3(llblk, n_contigs), dim3(256), 0, sl, la);
     hipLaunchKernelGGL(k_loglik_final, dim3(n_contigs), dim3(256), 0, sl, la);
-    if (ll_own) HIPCHK(hipEventRecord(ev[19], sl));
+    if (ll_own || ll3) HIPCHK(hipEventRecord(ev[19], sl));
     FinArgs fa;
     fa.M = M; fa.Mp = Mp; fa.K = K; fa.G = G; fa.Ke = Ke; fa.n_contigs = n_contigs;
     fa.eb_slab_off = d_eb_slab_off.p; fa.eb_gid = d_eb_gid.p; fa.ce_bucket_off = d_ce_bucket_off.p;
@@ -2969,18 +2985,6 @@ void smcpp_im::enqueue_stats() {
     // not run at all: 110 MB less traffic per headline E-step, but 12 more fp64 MFMAs per group of four rows on the critical
     // stream (v_mfma_f64_16x16x4 is a 16-pass instruction on gfx950): 0.285 ms of statistics against 0.235 ms with the gamma sums
     // as a third concurrent branch - measured, so the fusion is opt-in
-    const bool gfuse_on = getenv("SMCPP_GAMMA_FUSE") && atoi(getenv("SMCPP_GAMMA_FUSE")) != 0;
-    const bool gfuse = gfuse_on && (Mp + 63) / 64 == 1 && K <= 64 && !save_gamma && !slabs_rk.empty();
-    // M <= 64, from half a million span-1 rows on: ONE pass over the span-1 rows in key-sorted order, single-key slabs - the rank
-    // update and the key's gamma sums from the same operands (k_rank_acc<3>); k_s1_scalars and its second read of alpha / beta do
-    // not run.  Measured: whole genome (3.6 M span-1 rows, bandwidth-bound) 3.77 -> 3.15 ms of statistics; one 100 Mbp contig
-    // (129 k rows, one wavefront per SIMD, latency-bound) 0.208 -> 0.225 ms - there the gamma sums stay a third concurrent
-    // branch.  SMCPP_S1_FUSE=0 / 1 forces either form.
-    const char *kf_env = getenv("SMCPP_S1_FUSE");
-    const bool kfuse = !gfuse && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_fk.empty() &&
-                       (kf_env ? atoi(kf_env) != 0 : (n_1_rows >= 500000 || crit_main));
-    // (round 4: with the span > 1 branch on the main stream the span-1 statistics are ONE side branch in the one-pass form instead
-    // of two - 887 against 873 headline evals per second, and 140 MB less traffic per E-step)
     const bool s1_own = !gfuse && !kfuse && dual_stream && stream3 != nullptr && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_sc.empty();
     hipStream_t s1s = s1_own ? stream3 : sp1;
     if (s1_own) {
@@ -3165,6 +3169,9 @@ void smcpp_im::enqueue_stats() {
                            (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
     }
     if (crit_main) {
+        // (the third stream joins the span-1 stream, which has slack, and the main stream waits for ONE event: every wait is a
+        // barrier packet of a few microseconds on the queue it is put on, signalled or not)
+        if (ll3) HIPCHK(hipStreamWaitEvent(sp1, ev[19], 0));
         HIPCHK(hipEventRecord(ev[9], sp1));
         HIPCHK(hipStreamWaitEvent(s, ev[9], 0));
     } else if (split_streams) {

@@ -1144,9 +1144,7 @@ void smcpp_im::make_slabs() {
     eb_slab_off.clear(); eb_gid.clear(); erow_slab.clear();
     int last_eig_key = -1;
     long long n1 = 0, ne = 0;
-    for (long long r = 0; r < total_rows; ++r) {
-        // rows with ell = 0 have kid = 0, gid = -1 but are skipped below
-    }
+    // (rows with ell = 0 have kid = 0, gid = -1 and are skipped below)
     for (int c = 0; c < n_contigs; ++c)
         for (int i = 1; i <= Ls[c]; ++i) (rowinfo[(size_t)contig_base[c] + i].gid < 0 ? n1 : ne)++;
     n_1_rows = n1; n_e_rows = ne;

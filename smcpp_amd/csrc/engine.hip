@@ -3207,8 +3207,9 @@ void smcpp_im::enqueue_stats() {
         }
         if (mfma_rows && rows_gen != 1) {
             // one launch per (contig, eigen key): a workgroup shares one LDS copy of P, Pinv and the reciprocal eigenvalue differences
-            const int NW = NT <= 2 ? 4 : 2;
-            const size_t shm2 = (size_t)(3 * Mp * (Mp + 1) + NW * (2 * 16 * (Mp + 1) + Mp * 17)) * sizeof(double);
+            // (NT > 2: the reciprocal differences live in registers and the fold tile is half as wide - four wavefronts fit as well)
+            const int NW = 4;
+            const size_t shm2 = (size_t)((NT <= 2 ? 3 : 2) * Mp * (Mp + 1) + NW * (2 * 16 * (Mp + 1) + Mp * (NT <= 2 ? 17 : 9))) * sizeof(double);
             for (int ce = 0; ce < n_contigs * Ke; ++ce) {
                 const int q0 = ce_row_off[ce], q1 = ce_row_off[ce + 1];
                 if (q1 <= q0) continue;
@@ -3216,7 +3217,7 @@ void smcpp_im::enqueue_stats() {
                 const int nblk = ceil_div(q1 - q0, 16 * NW * nbatch);
                 switch (NT) {
 #define G_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_gamma_rows_b<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
-                        hipLaunchKernelGGL(k_gamma_rows_b<x>, dim3(nblk), dim3(64 * (x <= 2 ? 4 : 2)), shm2, sg, ga, q0, q1, ce % Ke, nbatch); } break;
+                        hipLaunchKernelGGL(k_gamma_rows_b<x>, dim3(nblk), dim3(256), shm2, sg, ga, q0, q1, ce % Ke, nbatch); } break;
                     G_(1) G_(2) G_(3)
                     default: G_(4)
 #undef G_

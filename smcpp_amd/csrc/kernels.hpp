@@ -3337,18 +3337,24 @@ __global__ __launch_bounds__(256) void k_gamma_rows_mfma(GammaRowArgs a, int p0,
 //     instead of a DPP tree per value.
 // A wavefront walks `nbatch` batches of 16 consecutive rows (sorted by group: the powers are re-read only when the group changes).
 // ---------------------------------------------------------------------------------------------------------------
+// (round 4) M > 32: the kernel is bound by the matrix pipe of the SIMD its wavefront sits on (256 MFMAs per row at NT = 4), and
+// with the 33 KB table of reciprocal differences in LDS only TWO wavefronts fitted a CU - half its matrix pipes idle.  Now that
+// table lives in registers (NT KS doubles per lane; one wavefront per SIMD has 512 of them) and the fold tile is half as wide
+// (a DPP pair-add first): FOUR wavefronts per workgroup at every NT.
 template <int NT>
-__global__ __launch_bounds__(NT <= 2 ? 256 : 128) void k_gamma_rows_b(GammaRowArgs a, int p0, int p1, int es, int nbatch) {
-    constexpr int MT = 16 * NT, LD = MT + 1, NW = NT <= 2 ? 4 : 2, KS = MT / 4;
+__global__ __launch_bounds__(256) void k_gamma_rows_b(GammaRowArgs a, int p0, int p1, int es, int nbatch) {
+    constexpr int MT = 16 * NT, LD = MT + 1, NW = 4, KS = MT / 4;
     constexpr bool REG = NT <= 2;            // M <= 32: the lane's fragments of P, Pinv and the reciprocal differences live in registers
-    constexpr int NR = REG ? NT * KS : 1, NF = REG ? NT * NT * 4 : 1;
+    constexpr bool RID = NT > 2;             // M > 32: the reciprocal differences only (no LDS copy of them)
+    constexpr int GW = RID ? 9 : 17;         // row pitch of the fold tile (RID: column pairs summed in registers first)
+    constexpr int NR = REG ? NT * KS : 1, NID = (REG || RID) ? NT * KS : 1, NF = REG ? NT * NT * 4 : 1;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *sP = sm;                         // [MT][LD]  P row-major
     double *sPinv = sP + MT * LD;            // [MT][LD]  Pinv row-major
-    double *sInvD = sPinv + MT * LD;         // [MT][LD]  1 / (d_a - d_b), 0 where the eigenvalues are equal
+    double *sInvD = sPinv + MT * LD;         // [MT][LD]  1 / (d_a - d_b), 0 where the eigenvalues are equal   (!RID)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *sU = sInvD + MT * LD + (size_t)wv * (2 * 16 * LD + MT * 17);   // per wavefront: x = d o u [16 rows][LD], w [16][LD], fold tile [MT][17]
+    double *sU = sPinv + (RID ? 1 : 2) * MT * LD + (size_t)wv * (2 * 16 * LD + MT * GW);   // per wavefront: x = d o u [16 rows][LD], w [16][LD], fold tile [MT][GW]
     double *sW = sU + 16 * LD, *sG = sW + 16 * LD;
     const int Mp = a.Mp, M = a.M;
     const double *dsc = a.dsc + (size_t)es * Mp, *dun = a.dun + (size_t)es * Mp;
@@ -3358,27 +3364,44 @@ __global__ __launch_bounds__(NT <= 2 ? 256 : 128) void k_gamma_rows_b(GammaRowAr
             const int r = idx / MT, c = idx % MT;
             sP[r * LD + c] = Prm[(size_t)r * Mp + c];
             sPinv[r * LD + c] = Pinvrm[(size_t)r * Mp + c];
-            const double dd = dsc[r] - dsc[c];
-            sInvD[r * LD + c] = (dd != 0.0 && r < M && c < M) ? 1.0 / dd : 0.0;
+            if (!RID) {
+                const double dd = dsc[r] - dsc[c];
+                sInvD[r * LD + c] = (dd != 0.0 && r < M && c < M) ? 1.0 / dd : 0.0;
+            }
         }
     }
     __syncthreads();
     const int kq = lane >> 4, n = lane & 15;
-    double invda[KS], dux[NT][4];
+    // 1 / d_aa (the diagonal of the span-Q matrix) and the unscaled eigenvalues: per-lane registers for M <= 32; for larger M they are
+    // re-read (L1 / L2 hits, once per batch of 16 rows / per change of group) - the registers are needed for the fragments
+    constexpr int NK = RID ? 1 : KS, ND = RID ? 1 : NT;
+    double invda[NK], dux[ND][4];
+    if (!RID) {
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-        const int aa = 4 * kk + kq;
-        const double d = dsc[aa];
-        invda[kk] = (aa < M && d != 0.0) ? 1.0 / d : 0.0;
-    }
-#pragma unroll
-    for (int it = 0; it < NT; ++it)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = it * 16 + kq + 4 * r;
-            dux[it][r] = i < M ? dun[i] : 0.0;
+        for (int kk = 0; kk < KS; ++kk) {
+            const int aa = 4 * kk + kq;
+            const double d = dsc[aa];
+            invda[kk] = (aa < M && d != 0.0) ? 1.0 / d : 0.0;
         }
-    double rP[NR], rID[NR], rF[NF];          // A fragments of P [it][kk], 1/(d_aa - d_bb) [bt][kk], Pinv[bb][i] of the fold [bt][it][r]
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = it * 16 + kq + 4 * r;
+                dux[it][r] = i < M ? dun[i] : 0.0;
+            }
+    }
+    double rP[NR], rID[NID], rF[NF];         // A fragments of P [it][kk], 1/(d_aa - d_bb) [bt][kk], Pinv[bb][i] of the fold [bt][it][r]
+    if (RID) {
+#pragma unroll
+        for (int bt = 0; bt < NT; ++bt)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int aa = 4 * kk + kq, bb = bt * 16 + n;
+                const double dd = dsc[aa] - dsc[bb];
+                rID[bt * KS + kk] = (dd != 0.0 && aa < M && bb < M) ? 1.0 / dd : 0.0;
+            }
+    }
     if (REG) {
 #pragma unroll
         for (int it = 0; it < NT; ++it)
@@ -3433,7 +3456,7 @@ __global__ __launch_bounds__(NT <= 2 ? 256 : 128) void k_gamma_rows_b(GammaRowAr
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = it * 16 + kq + 4 * r;
-                    sU[n * LD + i] = DU[it][r] * dux[it][r];
+                    sU[n * LD + i] = DU[it][r] * (RID ? (i < M ? dun[min(i, Mp - 1)] : 0.0) : dux[RID ? 0 : it][r]);
                     sW[n * LD + i] = DW[it][r];
                 }
         }
@@ -3449,14 +3472,22 @@ __global__ __launch_bounds__(NT <= 2 ? 256 : 128) void k_gamma_rows_b(GammaRowAr
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
                     pa[kk] = pw[4 * kk + kq];
-                    sd[kk] = (double)span * pa[kk] * invda[kk];      // span d^(span-1)
+                    double ida;
+                    if (RID) {
+                        const int aa = 4 * kk + kq;
+                        const double d = dsc[min(aa, Mp - 1)];
+                        ida = (aa < M && d != 0.0) ? 1.0 / d : 0.0;
+                    } else ida = invda[RID ? 0 : kk];
+                    sd[kk] = (double)span * pa[kk] * ida;            // span d^(span-1)
                 }
 #pragma unroll
                 for (int bt = 0; bt < NT; ++bt) pb[bt] = pw[16 * bt + n];
             }
-            double xs[KS];
+            double xs[NK];
+            if (!RID) {
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) xs[kk] = sU[q * LD + 4 * kk + kq];
+                for (int kk = 0; kk < KS; ++kk) xs[kk] = sU[q * LD + 4 * kk + kq];
+            }
             double gacc[NT][4];
 #pragma unroll
             for (int it = 0; it < NT; ++it)
@@ -3472,9 +3503,9 @@ __global__ __launch_bounds__(NT <= 2 ? 256 : 128) void k_gamma_rows_b(GammaRowAr
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
                     const int aa = 4 * kk + kq;
-                    const double idf = REG ? rID[bt * KS + kk] : sInvD[aa * LD + bb];
+                    const double idf = (REG || RID) ? rID[bt * KS + kk] : sInvD[aa * LD + bb];
                     const double sq = (aa == bb) ? sd[kk] : (pa[kk] - pb[bt]) * idf;
-                    const double bf = xs[kk] * wb * sq;             // B[k = aa][n = bb] = (d u)_aa S_ab w_bb
+                    const double bf = (RID ? sU[q * LD + aa] : xs[RID ? 0 : kk]) * wb * sq;     // B[k = aa][n = bb] = (d u)_aa S_ab w_bb
 #pragma unroll
                     for (int it = 0; it < NT; ++it)
                         D[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(REG ? rP[it * KS + kk] : sP[(it * 16 + n) * LD + aa], bf, D[it], 0, 0, 0);
@@ -3489,13 +3520,18 @@ __global__ __launch_bounds__(NT <= 2 ? 256 : 128) void k_gamma_rows_b(GammaRowAr
 #pragma unroll
             for (int it = 0; it < NT; ++it)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sG[(it * 16 + kq + 4 * r) * 17 + n] = gacc[it][r];
+                for (int r = 0; r < 4; ++r) {
+                    if (RID) {
+                        const double v = gacc[it][r] + dpp_mov<0xB1>(gacc[it][r]);      // columns n and n ^ 1 (quad_perm [1,0,3,2])
+                        if (!(n & 1)) sG[(it * 16 + kq + 4 * r) * GW + (n >> 1)] = v;
+                    } else sG[(it * 16 + kq + 4 * r) * GW + n] = gacc[it][r];
+                }
             wave_lds_fence();
             double mine = 0.0;
             if (lane < MT) {
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                for (int c = 0; c < 16; c += 2) { s0 += sG[lane * 17 + c]; s1 += sG[lane * 17 + c + 1]; }
+                for (int c = 0; c < (RID ? 8 : 16); c += 2) { s0 += sG[lane * GW + c]; s1 += sG[lane * GW + c + 1]; }
                 mine = lane < M ? fabs(s0 + s1) : 0.0;
             }
             const double tot = wave_sum(mine);

@@ -66,6 +66,7 @@ struct SsArgs {
     // x <- P (d~^s o (P^-1 x))  (forward; hmm.cpp:72-78) /  b <- P^-T (d~^s o (P^T b))  (backward; hmm.cpp:104-112) on the
     // eigensystem of its key - two M-long mat-vecs per lane against LDS tables - instead of `span` scan steps; shorter rows
     // keep the scans.  rowdesc.x carries the eigen key in its upper 16 bits.  hyb_th = INT_MAX: no such rows.
+    int dirsplit = 0;           // hybrid rows, M > 32: a workgroup runs ONE direction and stages only that direction's two tables per eigen key
     int hyb_th = 0x7fffffff, Ke = 0, hot_ek = 0;   // hot_ek: the eigen key with the most rows (its table rows stay in registers)
     const double *Pinvrm = nullptr, *Prm = nullptr, *PinvT = nullptr, *PT = nullptr;   // [Ke][Mp][Mp]
     const double *dsc = nullptr;               // [Ke][Mp] scaled eigenvalues d / scale
@@ -343,9 +344,10 @@ __device__ __forceinline__ double ss_exp_neg(double x) {
     p = __builtin_fma(p, r, 1.0);
     return ldexp(p, (int)n);
 }
-struct SsEigC { double ld[SS_KE_MAX]; bool neg[SS_KE_MAX]; int r, g, nb, G; };
+struct SsEigC { double ld[SS_KE_MAX]; bool neg[SS_KE_MAX]; int r, g, nb, G, tpk; };      // tpk: tables per eigen key in LDS (4, or 2 with `dirsplit`)
 __device__ __forceinline__ void ss_load_eig(const SsArgs &a, int lp, SsEigC &c) {
     c.G = a.Mp <= 32 ? 2 : 1;
+    c.tpk = a.dirsplit ? 2 : 4;
     const int W = 64 / c.G;
     c.r = lp & (W - 1); c.g = lp / W; c.nb = a.Mp / c.G;
 #pragma unroll
@@ -365,11 +367,12 @@ __device__ __forceinline__ double ss_eig_pow(const SsEigC &c, int ek, int span) 
     return (ng && (span & 1)) ? -p : p;
 }
 // LDS tables: [Ke][4][Mp][Mp + 1]: 0 = Pinv, 1 = P (forward), 2 = P^T, 3 = Pinv^T (backward), row-major, padded rows; behind
-// them one [64] scratch vector per wavefront
+// them one [64] scratch vector per wavefront.  `dirsplit` (M > 32: four tables of 33 KB per key do not fit): [Ke][2][..], the pair of
+// the ONE direction the workgroup runs - table `which` sits at index which & 1
 __device__ __forceinline__ double ss_eig_matvec(const SsEigC &c, const double *tab, int Mp, int ek, int which, double *sx, int lp, double x) {
     sx[lp] = x;
     wave_lds_fence();
-    const double *row = tab + ((size_t)(ek * 4 + which) * Mp + min(c.r, Mp - 1)) * (Mp + 1) + c.g * c.nb;
+    const double *row = tab + ((size_t)(ek * c.tpk + (which & (c.tpk - 1))) * Mp + min(c.r, Mp - 1)) * (Mp + 1) + c.g * c.nb;
     const double *xv = sx + c.g * c.nb;
     double a0 = 0.0, a1 = 0.0;
     for (int b = 0; b < c.nb; b += 4) {
@@ -393,8 +396,8 @@ struct SsHotRows { double a[NB], b[NB]; };          // this lane's pieces of the
 template <int NB>
 __device__ __forceinline__ void ss_eig_rows(const SsEigC &c, const double *tab, int Mp, int ek, int w0, double (&ra)[NB], double (&rb)[NB]) {
     const size_t rowoff = (size_t)min(c.r, Mp - 1) * (Mp + 1) + c.g * NB;
-    const double *rowA = tab + (size_t)(ek * 4 + w0) * Mp * (Mp + 1) + rowoff;
-    const double *rowB = tab + (size_t)(ek * 4 + w0 + 1) * Mp * (Mp + 1) + rowoff;
+    const double *rowA = tab + (size_t)(ek * c.tpk + (w0 & (c.tpk - 1))) * Mp * (Mp + 1) + rowoff;
+    const double *rowB = tab + (size_t)(ek * c.tpk + (w0 & (c.tpk - 1)) + 1) * Mp * (Mp + 1) + rowoff;
 #pragma unroll
     for (int b = 0; b < NB; ++b) { ra[b] = rowA[b]; rb[b] = rowB[b]; }
 }
@@ -533,7 +536,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
         ss_load_eig(a, lane, ec);
         if (Mp == 32) { hot_ek = a.hot_ek; ss_eig_rows<16>(ec, tab, Mp, hot_ek, 0, hot.a, hot.b); }
     }
-    double *sxw = const_cast<double *>(tab) + (size_t)a.Ke * 4 * Mp * (Mp + 1) + (threadIdx.x >> 6) * 64;
+    double *sxw = const_cast<double *>(tab) + (size_t)a.Ke * (a.dirsplit ? 2 : 4) * Mp * (Mp + 1) + (threadIdx.x >> 6) * 64;
     bool merged = false;
     const long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
     long long npos = 0;
@@ -742,7 +745,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
         ss_load_eig(a, 63 - lane, ec);
         if (Mp == 32) { hot_ek = a.hot_ek; ss_eig_rows<16>(ec, tab, Mp, hot_ek, 2, hot.a, hot.b); }
     }
-    double *sxw = const_cast<double *>(tab) + (size_t)a.Ke * 4 * Mp * (Mp + 1) + (threadIdx.x >> 6) * 64;
+    double *sxw = const_cast<double *>(tab) + (size_t)a.Ke * (a.dirsplit ? 2 : 4) * Mp * (Mp + 1) + (threadIdx.x >> 6) * 64;
     bool merged = false;
     const long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
     long long npos = 0;
@@ -1247,6 +1250,19 @@ __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
         // eigenvector tables of the hybrid rows behind the emission vectors: [Ke][4][Mp][Mp + 1]
         double *tab = ss_lds + (size_t)a.nlds * MS;
         const int Mp = a.Mp, MM = Mp * Mp;
+        if (a.dirsplit) {
+            // [Ke][2][Mp][Mp + 1]: the task table gives every wavefront of this workgroup the same direction (the host builds it so)
+            const int nw = nthr >> 6;
+            int t0 = -1;
+            for (int i = 0; i < nw && t0 < 0; ++i) t0 = a.tasks[nw * blockIdx.x + i];
+            const bool wg_bwd = t0 >= 0 && (t0 >> 30);
+            for (int idx = tid; idx < a.Ke * 2 * MM; idx += nthr) {
+                const int mat = idx / MM, rc = idx % MM, r = rc / Mp, cc = rc % Mp;
+                const int e = mat >> 1, which = (mat & 1) + (wg_bwd ? 2 : 0);
+                const double *src = which == 0 ? a.Pinvrm : which == 1 ? a.Prm : which == 2 ? a.PT : a.PinvT;
+                tab[((size_t)mat * Mp + r) * (Mp + 1) + cc] = src[(size_t)e * MM + rc];
+            }
+        } else
         for (int idx = tid; idx < a.Ke * 4 * MM; idx += nthr) {
             const int mat = idx / MM, rc = idx % MM, r = rc / Mp, cc = rc % Mp;
             const int e = mat >> 2, which = mat & 3;

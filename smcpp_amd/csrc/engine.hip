@@ -505,7 +505,8 @@ struct smcpp_im {
     int ss_hyb_th = 0x7fffffff;
     static constexpr int SS_HYB_COST = 8;
     long long ss_row_cost(int span) const { return (ss_hybrid && span > ss_hyb_th) ? SS_HYB_COST : span; }
-    size_t ss_tab_bytes() const { return ss_hybrid ? ((size_t)Ke * 4 * Mp * (Mp + 1) + 8 * 64) * sizeof(double) : 0; }   // + one scratch vector per wavefront
+    bool ss_dirsplit = false;              // hybrid rows at M > 32: single-direction workgroups with two tables per eigen key (chains_ss.hpp)
+    size_t ss_tab_bytes() const { return ss_hybrid ? ((size_t)Ke * (ss_dirsplit ? 2 : 4) * Mp * (Mp + 1) + 8 * 64) * sizeof(double) : 0; }   // + one scratch vector per wavefront
     bool ss_active = false;                // this E-step's chains run on the scan kernels
     bool eigfree = false;                  // ... and its statistics need no eigensystem either (k_span_fold): no eigensolve at all
     int ss_max_span = 0;
@@ -881,8 +882,14 @@ void smcpp_im::make_chunks() {
                 // key fit LDS beside the emission vectors (SMCPP_HYBRID=0: the dense kernels)
                 const char *hy = getenv("SMCPP_HYBRID");
                 const size_t tab = (size_t)Ke * 4 * Mp * (Mp + 1) * sizeof(double);
+                ss_dirsplit = false;
                 if (!(hy && atoi(hy) == 0) && Mp <= 64 && Ke >= 1 && Ke <= 4 && tab <= 120 * 1024) {
                     ss_static = ss_hybrid = true;
+                    ss_hyb_th = getenv("SMCPP_HYB_TH") ? std::max(1, atoi(getenv("SMCPP_HYB_TH"))) : 6;
+                } else if (!(hy && atoi(hy) == 0) && Mp <= 64 && Ke >= 1 && Ke <= 4 && tab / 2 <= 136 * 1024) {
+                    // (round 4) M > 32: four 33 KB tables per eigen key do not fit, the two a DIRECTION needs do - every workgroup
+                    // runs one direction (the task table keeps them apart) and stages that direction's pair
+                    ss_static = ss_hybrid = ss_dirsplit = true;
                     ss_hyb_th = getenv("SMCPP_HYB_TH") ? std::max(1, atoi(getenv("SMCPP_HYB_TH"))) : 6;
                 }
             }
@@ -1099,6 +1106,17 @@ void smcpp_im::upload_chunk_state() {
         const size_t nf = ss4 ? chunks1.size() : chunks.size(), nb = ss4 ? chunks1.size() : chunks_b.size();
         ss_tasks.clear();
         size_t i = 0, j = 0;
+        if (ss_hybrid && ss_dirsplit) {
+            // single-direction workgroups, the two kinds interleaved in proportion
+            const size_t W = (size_t)ss_wg_waves;
+            while (i < nf || j < nb) {
+                const bool take_f = j >= nb || (i < nf && (double)i * (double)nb <= (double)j * (double)nf);
+                for (size_t q = 0; q < W; ++q) {
+                    if (take_f) ss_tasks.push_back(i < nf ? (int)i++ : -1);
+                    else ss_tasks.push_back(j < nb ? ((1 << 30) | (int)j++) : -1);
+                }
+            }
+        } else
         while (i < nf || j < nb) {
             // next task: the direction that is behind its proportional share
             const bool take_f = j >= nb || (i < nf && (double)i * (double)nb <= (double)j * (double)nf);
@@ -1325,7 +1343,7 @@ void smcpp_im::alloc_device() {
         for (int r = 0; r < K; ++r) ss_slot_of_key[order[r]] = r;
         const int MS = 64 * NPL;
         ss_nlds = (int)std::min<long long>(K, (std::min(64, 150 / std::max(1, ss_wpc)) * 1024) / ((long long)MS * 8));   // ss_wpc workgroups share a CU's 160 KB
-        if (ss_hybrid) ss_nlds = (int)std::min<long long>(K, (long long)(150 * 1024 - ss_tab_bytes()) / ((long long)MS * 8));   // one workgroup per CU
+        if (ss_hybrid) ss_nlds = (int)std::max<long long>(1, std::min<long long>(K, (long long)((ss_dirsplit ? 158 : 150) * 1024 - ss_tab_bytes()) / ((long long)MS * 8)));   // one workgroup per CU
         ss_positions = 0;
         for (int c = 0; c < n_contigs; ++c)
             for (int i = 1; i <= Ls[c]; ++i) {
@@ -2717,7 +2735,7 @@ void smcpp_im::ss_launch_initial() {
     a.eps_f = eps_f; a.eps_b = eps_b; a.full_f = a.full_b = 0;
     a.fine = nullptr; a.nfine = 0; a.hand_f = a.hand_b = 0; a.fine_ends_f = nullptr; a.fine_ends_b = nullptr;
     if (ss_hybrid) {
-        a.hyb_th = ss_hyb_th; a.Ke = Ke; a.hot_ek = std::max(0, hot_eig);
+        a.hyb_th = ss_hyb_th; a.Ke = Ke; a.hot_ek = std::max(0, hot_eig); a.dirsplit = ss_dirsplit ? 1 : 0;
         a.Pinvrm = d_Pinvrm.p; a.Prm = d_Prm.p; a.PinvT = d_PinvT.p; a.PT = d_PT.p; a.dsc = d_dsc.p;
     }
     if (ss4) {

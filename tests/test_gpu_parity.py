@@ -837,12 +837,14 @@ def test_span1_statistics_one_pass_in_key_order(monkeypatch):
             np.testing.assert_allclose(g1[k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
 
 
-def test_hybrid_scan_chains_on_unbinned_data(monkeypatch):
+@pytest.mark.parametrize("name", ["G7_M32_n8_chr11", "G18_M64_n8_chr11"])
+def test_hybrid_scan_chains_on_unbinned_data(monkeypatch, name):
     """Un-binned data (spans to 10^5): the scan kernel with HYBRID rows (chain mode 6: a long row is one eigen-power step
     P d^s P^-1 inside the one-wavefront-per-chunk kernel, a short one `span` scan steps) against the dense chains (SMCPP_HYBRID=0)
-    on the reference's own un-binned contig (golden G7, with gamma) and on a synthetic contig long enough for several chunks."""
+    on the reference's own un-binned contig (golden G7 / G18, with gamma) and on a synthetic contig long enough for several chunks.
+    M = 64 (G18, round 4): the four eigenvector tables of a key do not fit LDS - single-direction workgroups with two tables each."""
     from smcpp_amd import _smcpp
-    g = load_golden("G7_M32_n8_chr11")
+    g = load_golden(name)
     res = {}
     for hyb in ("1", "0"):
         monkeypatch.setenv("SMCPP_HYBRID", hyb)

@@ -466,6 +466,10 @@ def main():
         roof["posterior"] = {"gamma_bytes": gbytes, "statistics_ms": 1e3 * t_stat, "gamma_write_gbs": gbytes / t_stat / 1e9,
                              "gamma_write_frac_of_hbm": gbytes / t_stat / 1e9 / HBM_PEAK_GBS,
                              "eigen_row_tflops": 2.0 * M ** 3 * Re / t_stat / 1e12,
+                             # the per-row gamma kernel (k_gamma_rows_b: 2 M^3 flop per span row on the fp64 matrix cores) alone, on the
+                             # finalisation interval it dominates - at M = 64 it, not the chain kernel above, is the longest kernel of the eval
+                             "gamma_rows_tflops": 2.0 * M ** 3 * Re / (1e-3 * max(med["finalize_ms"], 1e-9)) / 1e12,
+                             "gamma_rows_frac_of_fp64_mfma_peak": 2.0 * M ** 3 * Re / (1e-3 * max(med["finalize_ms"], 1e-9)) / 1e12 / FP64_PEAK_TFLOPS,
                              "fwd_passes": med["fwd_passes"], "bwd_passes": med["bwd_passes"]}
     # ---- N > 1 consistency (--check): what every rank holds after the single all-reduce ----
     multi_check = None

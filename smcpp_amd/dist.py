@@ -204,6 +204,7 @@ class ShardedInferenceManager:
         """Local E-step on this rank's contigs + the single all-reduce of the packed statistics."""
         self.im.E_step(forward_backward_only)
         self._lls = None
+        self._unpack_pending = False
         if not self._reduce:
             self._ll_sum = float(self.im.loglik())
             return
@@ -219,7 +220,9 @@ class ShardedInferenceManager:
             self._ll_sum = float(self._buf[0].item())                 # synchronises the reduction
             if self.keep_stats:
                 self.last_reduced_stats = self._buf.cpu().numpy().copy()
-            self.im.unpack_stats_device(self._buf.data_ptr(), self._buf.numel())
+            # the reduced statistics stay in the device buffer until Q asks for them (one kernel + a synchronisation per E-step
+            # that a loglik-only caller - an evaluation loop, bench.py - never needs)
+            self._unpack_pending = True
         else:
             h = self.im.pack_stats()
             if self.keep_stats:
@@ -247,10 +250,17 @@ class ShardedInferenceManager:
             self._lls = allgather_logliks(self.im.logliks(), self.owner, device=dev, group=self._group)
         return self._lls
 
+    def _ensure_unpacked(self):
+        if getattr(self, "_unpack_pending", False):
+            self.im.unpack_stats_device(self._buf.data_ptr(), self._buf.numel())
+            self._unpack_pending = False
+
     def Q(self, separate=False):
+        self._ensure_unpacked()
         return self.im.Q(separate)
 
     def Q_with_gradient(self):
+        self._ensure_unpacked()
         return self.im.Q_with_gradient()
 
     def last_timing(self):

@@ -1580,16 +1580,22 @@ void smcpp_im::dev_prepare() {
         dprep->set_keys(*prep1, pk, Kp_, local, slot, maxspan, K, M, Mp, ss_static ? 64 * NPL : 0);
     }
     if (nder > 0) {
+        HostTrace tr;
         smcpp_host::DualScope sc(nder);
         const smcpp_host::RateFunctionT<smcpp_host::dual> eta(make_dual_model(model, model_da, nder), hs);
+        tr.mark("prep(d): rate function");
         const std::vector<smcpp_host::dual> act = eta.average_coal_times();
+        tr.mark("prep(d): average coal times");
         dprep->run(eta, act, theta, alpha, nder, stream);
+        tr.mark("prep(d): pack + 2 launches");
         std::vector<smcpp_host::dual> pd;
         smcpp_host::initial_distribution(eta, pd);
         split_duals(pd, nder, pi, dpi);
+        tr.mark("prep(d): pi");
         // transition matrix: values + the derivative planes of its O(M) generators; the M x M x nder Jacobian is expanded
         // only when its getter asks (ensure_dT), Q's gradient reads the planes on the device
         tgen_valid = host_transition_with_planes(eta, act, rho, nder, T, tgen);
+        tr.mark("prep(d): T + generator planes");
         dT.clear();
         dT_valid = false;
         if (!tgen_valid) { split_duals(smcpp_host::compute_transition<smcpp_host::dual>(eta, rho), nder, T, dT); dT_valid = true; }
@@ -1705,6 +1711,7 @@ bool smcpp_im::q_device(double val[4], double *jac) {
             pl[2 * ps + (size_t)d * M + i] = tgen.dpf[(size_t)i * nd + d];
             pl[3 * ps + (size_t)d * M + i] = tgen.dW[(size_t)i * nd + d];
         }
+    HostTrace trq;
     HIPCHK(hipMemcpyAsync(q.d_in, hb, ndbl * sizeof(double), hipMemcpyHostToDevice, stream));
     const int nslice = 4;
     const size_t nout = (size_t)4 * (1 + nd) * nslice;
@@ -1731,7 +1738,9 @@ bool smcpp_im::q_device(double val[4], double *jac) {
     hipLaunchKernelGGL(smcpp_dev::k_q_reduce, dim3(1 + nd, nslice), dim3(nt), lds, stream, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(q.h_out, q.d_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream));
+    trq.mark("q: enqueue");
     HIPCHK(hipStreamSynchronize(stream));
+    trq.mark("q: wait (prep kernels + q + copies)");
     dprep->check_flags();
     auto slices = [&](int b, int t) { double r = 0.0; for (int sl = 0; sl < nslice; ++sl) r += q.h_out[((size_t)b * nslice + sl) * 4 + t]; return r; };
     for (int t = 0; t < 4; ++t) val[t] = slices(0, t);

@@ -1288,6 +1288,109 @@ __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Span fold on the scans (round 4).  The eigen-free span statistics (kernels.hpp: k_span_big) need, per (contig, key),
+//     F_t = Acc_{t+1} + F_{t+1} A,   H_t = F_t + A H_{t+1}   (t = s_max - 1 .. 0),   W = H_0,  g = diag(A W),   A = diag(e) T^T.
+// k_span_big forms the products on the matrix cores: 2 M^3 flop per step, and the steps are serial.  But a ROW of F times A is
+// the backward operator applied to that row,  (f A)_j = sum_k f_k e_k T[j][k] = (T (e o f))_j,  and A times a COLUMN of H is the
+// forward operator,  (A h)_i = e_i (T^T h)_i  - the very O(M) scan steps of the chains above.  Rows of F do not mix, columns of H
+// do not mix: ONE WAVEFRONT per row (phase 0) / column (phase 1) walks all s_max steps on its own - no barrier, no LDS, no
+// matrix product: 2 s_max M applications of an O(M) operator instead of 2 s_max products of M x M matrices.
+// Phase 0 writes F_t TRANSPOSED (scatter) so that phase 1 reads its column as a contiguous row.
+// grid = ceil(n_ce * M / 4) workgroups of 4 independent wavefronts.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NPL, int PHASE>
+__global__ __launch_bounds__(256) void k_span_scan(SsArgs sa, FinArgs a, int smax, double *__restrict__ Fall) {
+    constexpr int MS = 64 * NPL;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int M = a.M, Mp = a.Mp;
+    const int ce = ss_uni(gw / M), rc = ss_uni(gw % M);                // (contig, key) and the row (phase 0) / column (phase 1)
+    if (ce >= a.n_contigs * a.Ke) return;
+    const int b0 = ss_uni(a.ce_bucket_off[ce]), b1 = ss_uni(a.ce_bucket_off[ce + 1]);
+    if (b0 == b1) return;
+    const int e = ce % a.Ke;
+    const double *ek = a.E + (size_t)a.e_kid[e] * Mp;
+    double *Fce = Fall + (size_t)ce * smax * Mp * Mp;
+    // states of this lane: forward positions p = state, backward positions p = MS - 1 - state (chains above)
+    int st[NPL];
+    bool live[NPL];
+    double ev[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int p = lane * NPL + k;
+        st[k] = PHASE == 0 ? MS - 1 - p : p;
+        live[k] = st[k] < M;
+        ev[k] = live[k] ? ek[st[k]] : 0.0;
+    }
+    double x[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) x[k] = 0.0;
+    if (PHASE == 0) {
+        // bucket of every span: lane L learns the bucket that holds span L + 1 (s_max <= 64), -1 = none
+        int mybk = -1;
+        for (int b = b0; b < b1; ++b) {
+            const int sp = a.g_span[a.eb_gid[b]];
+            if (sp - 1 == lane) mybk = b;
+        }
+        SsBwdC<NPL> c;
+        ss_load_bwd<NPL>(sa, lane, c);
+        auto fetch = [&](int t, double (&v)[NPL]) {                      // row rc of the bucket of span t + 1 (raw; masked when used)
+            const int bk = __builtin_amdgcn_readlane(mybk, max(t, 0));
+            const double *src = a.red_e + (size_t)max(bk, b0) * Mp * Mp + (size_t)rc * Mp;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) v[k] = src[min(st[k], Mp - 1)];
+            return bk;
+        };
+        double nx[NPL];
+        int bkn = fetch(smax - 1, nx);
+        for (int t = smax - 1; t >= 0; --t) {
+            double cur[NPL], out[NPL];
+            const bool has = bkn >= 0;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) cur[k] = (has && live[k]) ? nx[k] : 0.0;
+            bkn = fetch(t - 1, nx);                                      // next step's bucket row is on its way during this step
+            float Sw;
+            ss_bwd_step<NPL>(c, x, ev, out, Sw);
+            double *Ft = Fce + (size_t)t * Mp * Mp;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                x[k] = out[k] + cur[k];
+                if (live[k]) Ft[(size_t)st[k] * Mp + rc] = x[k];         // F_t[rc][state] stored as FT_t[state][rc]
+            }
+        }
+        return;
+    }
+    SsFwdC<NPL> c;
+    ss_load_fwd<NPL>(sa, lane, c);
+    auto fetchF = [&](int t, double (&v)[NPL]) {                         // column rc of F_t = row rc of the transposed copy
+        const double *src = Fce + (size_t)max(t, 0) * Mp * Mp + (size_t)rc * Mp;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) v[k] = src[min(st[k], Mp - 1)];
+    };
+    double nx[NPL];
+    fetchF(smax - 1, nx);
+    for (int t = smax - 1; t >= 0; --t) {
+        double cur[NPL], out[NPL], S;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) cur[k] = live[k] ? nx[k] : 0.0;
+        fetchF(t - 1, nx);
+        ss_fwd_step<NPL>(c, x, ev, out, S);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) x[k] = out[k] + cur[k];
+    }
+    // W[:, rc] = H_0 (row-major W in the eigen path's Y buffer) and g[rc] = (A W)[rc][rc] (first Mp entries of its Z buffer)
+    double *Wout = a.Y + (size_t)ce * Mp * Mp;
+    double *gout = a.Z + (size_t)ce * Mp * Mp;
+    double out[NPL], S;
+    ss_fwd_step<NPL>(c, x, ev, out, S);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        if (live[k]) Wout[(size_t)st[k] * Mp + rc] = x[k];
+        if (st[k] == rc) gout[rc] = out[k];
+    }
+}
+
 // Unit-test entry (tests/test_gpu_ss.py through smcpp_debug_ss_apply): out_f = e o (T^T x), out_b = T (e o x) by the scans,
 // one wavefront per vector.
 template <int NPL>

@@ -1408,6 +1408,9 @@ void smcpp_im::alloc_device() {
     // (d_part_e / d_red_e - one M x M partial per span GROUP slab / bucket - are allocated where they are used: un-binned data have
     // 10^5 groups and never take those paths when M <= 64)
     d_part_1.alloc(std::max<size_t>(1, slabs_rk.size()) * Mp * Mp);
+    // shares of the cross-slab reduction of the span-1 rank partials: few contigs, small M -> more, shorter shares (one contig at M = 64:
+    // 8 shares of 126 slabs took 38 us of dependent loads)
+    ZS = (int)std::max<long long>(8, std::min<long long>(32, 2048 / std::max<long long>(1, (long long)n_contigs * ceil_div((long long)Mp * Mp, 256))));
     d_red_1.alloc((size_t)n_contigs * ZS * Mp * Mp);
     d_red_g.alloc((size_t)n_contigs * K * Mp);
     d_Z.alloc(std::max<size_t>(1, (size_t)n_contigs * Ke) * Mp * Mp);
@@ -2925,8 +2928,14 @@ void smcpp_im::enqueue_stats() {
     // critical branch.)  SMCPP_STATS_VARIANT & 4 restores the old arrangement.
     const bool crit_main = eigfree && dual_stream && stream2 != nullptr && !slabs_eg.empty() && !(stats_variant & 6) && n_e_rows < 1000000 &&
                            Mp <= 64;      // (M > 64: chip-filling rank updates, the hops do not matter and the old order is 3 % faster)
-    hipStream_t se = crit_main ? s : split_streams ? ((eigfree && (stats_variant & 1)) ? stream_hi : stream2) : s;
-    hipStream_t sp1 = crit_main ? stream2 : s;          // the span-1 branch
+    // (round 4, later) with the span fold on the scans (k_span_scan: 19 us instead of 72) the span > 1 branch is the SHORTER one:
+    // then the span-1 branch (one-pass rank update + its two reductions) owns the main stream and the span > 1 branch forks
+    static const bool span_scan_off = getenv("SMCPP_SPAN_SCAN") && atoi(getenv("SMCPP_SPAN_SCAN")) == 0;
+    const bool use_fh = NT <= 4 && getenv("SMCPP_SPAN_FH") && atoi(getenv("SMCPP_SPAN_FH")) != 0;
+    const bool scan_fold = eigfree && ss_active && !ss4 && !span_scan_off && !use_fh;
+    const bool swap_main = crit_main && scan_fold && !(stats_variant & 8);
+    hipStream_t se = crit_main ? (swap_main ? stream2 : s) : split_streams ? ((eigfree && (stats_variant & 1)) ? stream_hi : stream2) : s;
+    hipStream_t sp1 = crit_main ? (swap_main ? s : stream2) : s;          // the span-1 branch
     // (scan chains: run_chains_ss has just recorded ev[3] behind the last pass - the fork event, without a second record)
     hipEvent_t ev_fork = ss_active ? ev[3] : ev[8];
     if (split_streams) {
@@ -3089,7 +3098,21 @@ void smcpp_im::enqueue_stats() {
                                (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MMi, 1);
         const size_t shm = (size_t)2 * Mp * (Mp + 1) * sizeof(double);
         // SMCPP_SPAN_FH=1: the one-workgroup-per-(contig, key) fold (M <= 64) instead of the strip kernels
-        const bool use_fh = NT <= 4 && getenv("SMCPP_SPAN_FH") && atoi(getenv("SMCPP_SPAN_FH")) != 0;
+        // (round 4) the fold on the SCANS: a row of F times A / A times a column of H is one O(M) step of the backward / forward chain
+        // operator, so one wavefront per row / column walks all s_max steps on its own (chains_ss.hpp: k_span_scan) - no matrix
+        // product, no barrier.  SMCPP_SPAN_SCAN=0: the matrix-core strips of round 3.
+        if (scan_fold) {
+            d_Fall.alloc((size_t)n_contigs * Ke * ss_max_span * Mp * Mp);
+            const int nwav = n_contigs * Ke * M;
+            const dim3 grid(ceil_div(nwav, 4)), block(256);
+            switch (NPL) {
+#define SC_(x) case x: hipLaunchKernelGGL((k_span_scan<x, 0>), grid, block, 0, se, ss_args, fa, ss_max_span, d_Fall.p); \
+                       hipLaunchKernelGGL((k_span_scan<x, 1>), grid, block, 0, se, ss_args, fa, ss_max_span, d_Fall.p); break;
+                SC_(1) SC_(2) SC_(3)
+                default: SC_(4)
+#undef SC_
+            }
+        } else
         if (!use_fh) {
             // strips of 16 rows (F) / columns (H), one workgroup each, F_t through scratch
             d_Fall.alloc((size_t)n_contigs * Ke * ss_max_span * Mp * Mp);
@@ -3194,10 +3217,11 @@ void smcpp_im::enqueue_stats() {
                            (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
     }
     if (crit_main) {
-        // (the third stream joins the span-1 stream, which has slack, and the main stream waits for ONE event: every wait is a
-        // barrier packet of a few microseconds on the queue it is put on, signalled or not)
-        if (ll3) HIPCHK(hipStreamWaitEvent(sp1, ev[19], 0));
-        HIPCHK(hipEventRecord(ev[9], sp1));
+        // (the third stream joins the side stream, and the main stream waits for ONE event: every wait is a barrier packet of a few
+        // microseconds on the queue it is put on, signalled or not)
+        hipStream_t side = swap_main ? se : sp1;
+        if (ll3) HIPCHK(hipStreamWaitEvent(side, ev[19], 0));
+        HIPCHK(hipEventRecord(ev[9], side));
         HIPCHK(hipStreamWaitEvent(s, ev[9], 0));
     } else if (split_streams) {
         HIPCHK(hipEventRecord(ev[9], se));

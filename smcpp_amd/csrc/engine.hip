@@ -614,6 +614,7 @@ struct smcpp_im {
     size_t param_cap = 0;
     int llblk = 64;
     int ZS = 8;
+    int ZG = 1;                          // shares of the per-key gamma-sum reduction of the one-pass span-1 form (a hot key holds most slabs)
     int max_pass = 0;
     int last_fwd_passes = 0, last_bwd_passes = 0;
     float eps_f = 2e-6f;
@@ -1410,9 +1411,11 @@ void smcpp_im::alloc_device() {
     d_part_1.alloc(std::max<size_t>(1, slabs_rk.size()) * Mp * Mp);
     // shares of the cross-slab reduction of the span-1 rank partials: few contigs, small M -> more, shorter shares (one contig at M = 64:
     // 8 shares of 126 slabs took 38 us of dependent loads)
-    ZS = (int)std::max<long long>(8, std::min<long long>(32, 2048 / std::max<long long>(1, (long long)n_contigs * ceil_div((long long)Mp * Mp, 256))));
+    ZS = (int)std::max<long long>(8, std::min<long long>(16, 2048 / std::max<long long>(1, (long long)n_contigs * ceil_div((long long)Mp * Mp, 256))));
     d_red_1.alloc((size_t)n_contigs * ZS * Mp * Mp);
-    d_red_g.alloc((size_t)n_contigs * K * Mp);
+    // (the monomorphic key alone holds half the span-1 slabs of a contig: one block walking them took 42 us on the headline)
+    ZG = (int)std::max<long long>(1, std::min<long long>(16, 1024 / std::max<long long>(1, (long long)n_contigs * K)));
+    d_red_g.alloc((size_t)n_contigs * K * Mp * ZG);
     d_Z.alloc(std::max<size_t>(1, (size_t)n_contigs * Ke) * Mp * Mp);
     d_Y.alloc(std::max<size_t>(1, (size_t)n_contigs * Ke) * Mp * Mp);
     d_xisum.alloc((size_t)n_contigs * Mp * Mp);
@@ -2973,7 +2976,7 @@ void smcpp_im::enqueue_stats() {
     fa.eb_slab_off = d_eb_slab_off.p; fa.eb_gid = d_eb_gid.p; fa.ce_bucket_off = d_ce_bucket_off.p;
     fa.s1_slab_off = d_s1_slab_off.p; fa.gk_slab_off = d_gk_slab_off.p; fa.g_span = d_g_span.p;
     fa.e_kid = d_e_kid.p; fa.dsc = d_dsc.p; fa.dun = d_dun.p; fa.Prm = d_Prm.p; fa.Pinvrm = d_Pinvrm.p;
-    fa.E = d_E.p; fa.Td = d_Td.p; fa.ZS = ZS; fa.red_e = nullptr; fa.red_1 = d_red_1.p; fa.red_g = d_red_g.p;
+    fa.E = d_E.p; fa.Td = d_Td.p; fa.ZS = ZS; fa.red_e = nullptr; fa.red_1 = d_red_1.p; fa.red_g = d_red_g.p; fa.ZG = kfuse ? ZG : 1;
     fa.alpha = d_alpha.p; fa.beta = d_beta.p; fa.contig_base = d_contig_base.p;
     fa.Z = d_Z.p; fa.Y = d_Y.p; fa.xisum = d_xisum.p; fa.gsum = d_gsum.p; fa.gamma0 = d_gamma0.p;
     fa.dpow = d_dpow.p;
@@ -3047,8 +3050,8 @@ void smcpp_im::enqueue_stats() {
         aa.nslabs = (int)slabs_fk.size(); aa.slabs = d_slabs_fk.p; aa.perm = d_perm1.p; aa.permk = nullptr; aa.part = d_part_1.p;
         aa.gpart = d_gpart_fk.p;
         hipLaunchKernelGGL(k_rank_acc<3>, dim3(aa.nslabs, 1), dim3(64), 0, sp1, aa);
-        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, sp1,
-                           (const double *)d_gpart_fk.p, (const int *)d_fk_gk_off.p, d_red_g.p, Mp, 1);
+        hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, ZG), dim3(256), 0, sp1,
+                           (const double *)d_gpart_fk.p, (const int *)d_fk_gk_off.p, d_red_g.p, Mp, ZG);
         hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), n_contigs, ZS), dim3(256), 0, sp1,
                            (const double *)d_part_1.p, (const int *)d_fk_c_off.p, d_red_1.p, MMi, ZS);
     } else

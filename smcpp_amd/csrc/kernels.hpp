@@ -2608,7 +2608,8 @@ struct FinArgs {
     int ZS;                   // shares per bucket of the reduced partials
     const double *red_e;      // [n eigen buckets][ZS][Mp][Mp]   (k_sum_parts of the eigen rank partials)
     const double *red_1;      // [n_contigs][ZS][Mp][Mp]         (span-1 rank partials)
-    const double *red_g;      // [n_contigs*K][1][Mp]            (span-1 gamma partials)
+    const double *red_g;      // [n_contigs*K][ZG][Mp]           (span-1 gamma partials; ZG shares, 1 except in the one-pass span-1 form)
+    int ZG;
     const float *alpha;
     const double *beta;
     const long long *contig_base;
@@ -3083,7 +3084,7 @@ __device__ __forceinline__ void fin_gamma_body(const FinArgs &a, int bx, int ct)
     double g = 0.0;
     if (i < M) {
         const int ck = ct * a.K + k;
-        g = a.red_g[(size_t)ck * Mp + i];
+        for (int z = 0; z < a.ZG; ++z) g += a.red_g[((size_t)ck * a.ZG + z) * Mp + i];
         for (int e = 0; e < a.Ke; ++e) {
             if (a.e_kid[e] != k) continue;
             const int ce = ct * a.Ke + e;

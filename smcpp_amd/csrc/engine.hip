@@ -2931,12 +2931,13 @@ void smcpp_im::enqueue_stats() {
     // critical branch.)  SMCPP_STATS_VARIANT & 4 restores the old arrangement.
     const bool crit_main = eigfree && dual_stream && stream2 != nullptr && !slabs_eg.empty() && !(stats_variant & 6) && n_e_rows < 1000000 &&
                            Mp <= 64;      // (M > 64: chip-filling rank updates, the hops do not matter and the old order is 3 % faster)
-    // (round 4, later) with the span fold on the scans (k_span_scan: 19 us instead of 72) the span > 1 branch is the SHORTER one:
-    // then the span-1 branch (one-pass rank update + its two reductions) owns the main stream and the span > 1 branch forks
+    // (round 4, later) with the span fold on the scans (k_span_scan: 23 us instead of 72) and shares in the span-1 reductions the two
+    // branches are ~100 and ~77 us: the span > 1 branch is still the longer one and keeps the main stream (922 against 910 evals/s);
+    // SMCPP_STATS_VARIANT & 8 gives the main stream to the span-1 branch instead
     static const bool span_scan_off = getenv("SMCPP_SPAN_SCAN") && atoi(getenv("SMCPP_SPAN_SCAN")) == 0;
     const bool use_fh = NT <= 4 && getenv("SMCPP_SPAN_FH") && atoi(getenv("SMCPP_SPAN_FH")) != 0;
     const bool scan_fold = eigfree && ss_active && !ss4 && !span_scan_off && !use_fh;
-    const bool swap_main = crit_main && scan_fold && !(stats_variant & 8);
+    const bool swap_main = crit_main && scan_fold && (stats_variant & 8);
     hipStream_t se = crit_main ? (swap_main ? stream2 : s) : split_streams ? ((eigfree && (stats_variant & 1)) ? stream_hi : stream2) : s;
     hipStream_t sp1 = crit_main ? (swap_main ? s : stream2) : s;          // the span-1 branch
     // (scan chains: run_chains_ss has just recorded ev[3] behind the last pass - the fork event, without a second record)

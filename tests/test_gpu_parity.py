@@ -837,6 +837,42 @@ def test_span1_statistics_one_pass_in_key_order(monkeypatch):
             np.testing.assert_allclose(g1[k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
 
 
+@pytest.mark.parametrize("M,n", [(48, 7), (64, 20), (100, 6), (130, 6), (256, 8)])
+def test_span_fold_on_scans_vs_matrix_cores(monkeypatch, M, n):
+    """Round 4: the eigen-free span statistics fold the spans with the O(M) scan steps of the chains (k_span_scan: one wavefront per
+    row of F / column of H) instead of 2 s_max products of M x M matrices on the matrix cores (k_span_big, SMCPP_SPAN_SCAN=0).  Both
+    against the C restatement at the stated tolerances and against each other far below them, for one to four states per lane."""
+    from oracle import oracle
+    from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel
+    hs = synth.hidden_states(M)
+    a, s = synth.model_pieces()
+    contigs = [synth.synth_contig(700 + M, 2_000_000 if M <= 64 else 800_000, n), synth.synth_contig(701 + M, 120_000, n)]
+    res = {}
+    for scan in ("1", "0"):
+        monkeypatch.setenv("SMCPP_SPAN_SCAN", scan)
+        im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
+        im.model = PiecewiseModel(a, s, 1e4, "pop1")
+        im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0
+        im.E_step()
+        assert im.chain_mode() == 5
+        res[scan] = (np.array(im.logliks()), im.xisums, im.gamma_sums, np.array(im.Q(separate=True)))
+    pi, T, keys = im.pi, im.transition, im.keys
+    ep = im.emission_probs
+    Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
+    for c, ob in enumerate(contigs):
+        o = oracle.estep(pi, T, keys, Etab, ob)
+        for scan, (lls, xs, gss, q) in res.items():
+            assert abs(lls[c] - o["loglik"]) <= LL_TOL * abs(o["loglik"]), scan
+            assert rel_err(xs[c], o["xisum"]) <= STAT_TOL, scan
+            for k, v in o["gamma_sums"].items():
+                assert np.max(np.abs(gss[c][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300), (scan, k)
+        assert rel_err(res["1"][1][c], res["0"][1][c]) <= 1e-9
+        for k, v in res["0"][2][c].items():
+            assert np.max(np.abs(res["1"][2][c][k] - v)) <= 1e-9 * max(np.abs(v).max(), 1e-300), k
+    assert np.all(np.abs(res["1"][3] - res["0"][3]) <= 1e-9 * np.maximum(np.abs(res["0"][3]), 1e-12))
+
+
 @pytest.mark.parametrize("name", ["G7_M32_n8_chr11", "G18_M64_n8_chr11"])
 def test_hybrid_scan_chains_on_unbinned_data(monkeypatch, name):
     """Un-binned data (spans to 10^5): the scan kernel with HYBRID rows (chain mode 6: a long row is one eigen-power step

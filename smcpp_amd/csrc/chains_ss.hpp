@@ -66,6 +66,7 @@ struct SsArgs {
     // x <- P (d~^s o (P^-1 x))  (forward; hmm.cpp:72-78) /  b <- P^-T (d~^s o (P^T b))  (backward; hmm.cpp:104-112) on the
     // eigensystem of its key - two M-long mat-vecs per lane against LDS tables - instead of `span` scan steps; shorter rows
     // keep the scans.  rowdesc.x carries the eigen key in its upper 16 bits.  hyb_th = INT_MAX: no such rows.
+    int mixed = 0;              // M <= 64, no save_gamma: the weighted scans of the full / re-run passes in float (ss_fwd_step<.., MIX>)
     int dirsplit = 0;           // hybrid rows, M > 32: a workgroup runs ONE direction and stages only that direction's two tables per eigen key
     int hyb_th = 0x7fffffff, Ke = 0, hot_ek = 0;   // hot_ek: the eigen key with the most rows (its table rows stay in registers)
     const double *Pinvrm = nullptr, *Prm = nullptr, *PinvT = nullptr, *PT = nullptr;   // [Ke][Mp][Mp]
@@ -134,9 +135,9 @@ __device__ __forceinline__ void ss_levels(double A, int lane, double (&lv)[6]) {
 }
 
 template <int NPL>
-struct SsFwdC { double dc[NPL], g[NPL], cg[NPL], b[NPL], a[NPL], d[NPL], cumA[NPL], lv[6], c15, c31; };
+struct SsFwdC { double dc[NPL], g[NPL], cg[NPL], b[NPL], a[NPL], d[NPL], cumA[NPL], lv[6], c15, c31; float lvf[6]; };
 template <int NPL>
-struct SsBwdC { double dc[NPL], g[NPL], b[NPL], a[NPL], cumA[NPL], lv[6], c15, c31, c0; float c15f, c31f; };
+struct SsBwdC { double dc[NPL], g[NPL], b[NPL], a[NPL], cumA[NPL], lv[6], c15, c31, c0; float c15f, c31f, lvf[6]; };
 
 template <int NPL>
 __device__ __forceinline__ void ss_load_fwd(const SsArgs &a, int lane, SsFwdC<NPL> &c) {
@@ -149,6 +150,8 @@ __device__ __forceinline__ void ss_load_fwd(const SsArgs &a, int lane, SsFwdC<NP
         c.cumA[k] = cum;
     }
     ss_levels(cum, lane, c.lv);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) c.lvf[q] = (float)c.lv[q];
     const int row = lane >> 4;
     c.c15 = (row & 1) ? 1.0 : 0.0;
     c.c31 = (row >= 2) ? 1.0 : 0.0;
@@ -168,15 +171,49 @@ __device__ __forceinline__ void ss_load_bwd(const SsArgs &a, int lane, SsBwdC<NP
     c.c15 = (row & 1) ? 1.0 : 0.0;
     c.c31 = (row >= 2) ? 1.0 : 0.0;
     c.c15f = (float)c.c15; c.c31f = (float)c.c31;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) c.lvf[q] = (float)c.lv[q];
     c.c0 = a.c0;
 }
+
+// One level of the WEIGHTED scan in float: z += lv * dpp(z), one instruction.  `ord` is a double of the fp64 chain the level is
+// interleaved with: it is only named as an in/out operand, which pins the statement between that chain's level before and the level
+// after it - so two of these are always at least three vector instructions apart (the DPP read of z needs two), and the compiler,
+// which does not see through the asm, finds the fp64 chain's own DPP hazard at its real producer (the s_nop it then inserts sits
+// behind this instruction).  FIRST: z has just been converted from double - its hazard slots are spent inside the statement.
+#define SS_MIXLVL_(PRE, CTRL)                                                                                                   \
+    asm volatile(PRE "v_fmac_f32_dpp %0, %0, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(z), "+v"(ord) : "v"(lv))
+__device__ __forceinline__ void ss_mix_shr1(float &z, double &ord, float lv) { SS_MIXLVL_("s_nop 1\n", "row_shr:1"); }
+__device__ __forceinline__ void ss_mix_shr2(float &z, double &ord, float lv) { SS_MIXLVL_("", "row_shr:2"); }
+__device__ __forceinline__ void ss_mix_shr4(float &z, double &ord, float lv) { SS_MIXLVL_("", "row_shr:4"); }
+__device__ __forceinline__ void ss_mix_shr8(float &z, double &ord, float lv) { SS_MIXLVL_("", "row_shr:8"); }
+__device__ __forceinline__ void ss_mix_bc15(float &z, double &ord, float lv) { SS_MIXLVL_("", "row_bcast:15"); }
+__device__ __forceinline__ void ss_mix_bc31(float &z, double &ord, float lv) { SS_MIXLVL_("", "row_bcast:31"); }
+#undef SS_MIXLVL_
 
 // The scans of one position are written level by level across the independent chains: a DPP move may only read a register two
 // instructions after it was written, so one chain alone pays a wait state per level, two or three interleaved pay none.
 // one position of the forward chain:  out = e o (T^T x);  S = sum x
-template <int NPL>
+// MIX (one state per lane; the full and re-run passes of an E-step without save_gamma): only the scan whose result is DIFFERENCED
+// stays in fp64 - the plain prefix sum behind S - incl forward, the g-weighted one behind Gtot - inclG backward.  The weighted scans
+// sum positive terms and are good to a float ulp in float, where a level is one fused instruction instead of two DPP moves and an FMA.
+template <int NPL, bool MIX = false>
 __device__ __forceinline__ void ss_fwd_step(const SsFwdC<NPL> &c, const double (&x)[NPL], const double (&e)[NPL],
                                             double (&out)[NPL], double &S) {
+    if (MIX && NPL == 1) {
+        double p_ = x[0];
+        float z = (float)(c.b[0] * x[0]);
+        p_ += dpp0<DPP_SHR1>(p_); ss_mix_shr1(z, p_, c.lvf[0]);
+        p_ += dpp0<DPP_SHR2>(p_); ss_mix_shr2(z, p_, c.lvf[1]);
+        p_ += dpp0<DPP_SHR4>(p_); ss_mix_shr4(z, p_, c.lvf[2]);
+        p_ += dpp0<DPP_SHR8>(p_); ss_mix_shr8(z, p_, c.lvf[3]);
+        p_ = __builtin_fma(c.c15, dpp0<DPP_BC15>(p_), p_); ss_mix_bc15(z, p_, c.lvf[4]);
+        p_ = __builtin_fma(c.c31, dpp0<DPP_BC31>(p_), p_); ss_mix_bc31(z, p_, c.lvf[5]);
+        S = lane_get(p_, 63);
+        const double LIp = (double)dpp0<DPP_WSHR1>(z);
+        out[0] = e[0] * __builtin_fma(c.dc[0], x[0], __builtin_fma(c.g[0], S, __builtin_fma(c.cg[0], p_, LIp)));
+        return;
+    }
     double lp[NPL], w[NPL];
     lp[0] = x[0];
     w[0] = c.b[0] * x[0];
@@ -213,9 +250,25 @@ __device__ __forceinline__ void ss_fwd_step(const SsFwdC<NPL> &c, const double (
 }
 
 // one position of the backward chain (position p = state MS-1-p):  out = T (e o b);  Sw = sum (e o b) (float accuracy)
-template <int NPL>
+template <int NPL, bool MIX = false>
 __device__ __forceinline__ void ss_bwd_step(const SsBwdC<NPL> &c, const double (&bv)[NPL], const double (&e)[NPL],
                                             double (&out)[NPL], float &Sw) {
+    if (MIX && NPL == 1) {
+        const double w0 = e[0] * bv[0];
+        double p_ = c.g[0] * w0;
+        float z = (float)w0, f_ = (float)w0;
+        p_ += dpp0<DPP_SHR1>(p_); f_ += dpp0<DPP_SHR1>(f_); ss_mix_shr1(z, p_, c.lvf[0]);
+        p_ += dpp0<DPP_SHR2>(p_); f_ += dpp0<DPP_SHR2>(f_); ss_mix_shr2(z, p_, c.lvf[1]);
+        p_ += dpp0<DPP_SHR4>(p_); f_ += dpp0<DPP_SHR4>(f_); ss_mix_shr4(z, p_, c.lvf[2]);
+        p_ += dpp0<DPP_SHR8>(p_); f_ += dpp0<DPP_SHR8>(f_); ss_mix_shr8(z, p_, c.lvf[3]);
+        p_ = __builtin_fma(c.c15, dpp0<DPP_BC15>(p_), p_); f_ = __builtin_fmaf(c.c15f, dpp0<DPP_BC15>(f_), f_); ss_mix_bc15(z, p_, c.lvf[4]);
+        p_ = __builtin_fma(c.c31, dpp0<DPP_BC31>(p_), p_); f_ = __builtin_fmaf(c.c31f, dpp0<DPP_BC31>(f_), f_); ss_mix_bc31(z, p_, c.lvf[5]);
+        const double Gtot = lane_get(p_, 63);
+        Sw = lane_get(f_, 63);
+        const double LIp = (double)dpp0<DPP_WSHR1>(z);
+        out[0] = __builtin_fma(c.dc[0], w0, (Gtot - p_) + __builtin_fma(c.c0, (double)f_, c.b[0] * LIp));
+        return;
+    }
     double w[NPL], lg[NPL], u[NPL];
     float lf[NPL];
 #pragma unroll
@@ -445,7 +498,7 @@ __device__ __forceinline__ void ss_fwd_light_rows(const SsArgs &a, const double 
 template <int NPL, bool ALLLDS>
 __device__ __forceinline__ void ss_bwd_light_rows(const SsArgs &a, const double *sE, long long base, int rhi, int rlo, int lane, float (&b)[NPL]);
 
-template <int NPL, bool RERUN, bool HYB, bool ALLLDS>
+template <int NPL, bool RERUN, bool HYB, bool ALLLDS, bool MIX = false>
 __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -578,7 +631,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
         }
         // first position of the row: the sum of the incoming vector finishes the PREVIOUS row
         double y[NPL], S;
-        ss_fwd_step<NPL>(cst, x, e, y, S);
+        ss_fwd_step<NPL, MIX>(cst, x, e, y, S);
         const double inv = rcp_f64(S);
         // The reference continues from the STORED vector: normalised, rounded to float, floored at 1e-10 (hmm.cpp:80-94).  That
         // feedback is not noise for small entries (a state whose alpha falls under the floor after a heterozygous row re-enters
@@ -628,15 +681,15 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
             double S2;
             int t = 1;
             for (; t + 1 < span; t += 2) {
-                ss_fwd_step<NPL>(cst, x, e, y, S2);
+                ss_fwd_step<NPL, MIX>(cst, x, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) x[k] = y[k];
-                ss_fwd_step<NPL>(cst, x, e, y, S2);
+                ss_fwd_step<NPL, MIX>(cst, x, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) x[k] = y[k];
             }
             if (t < span) {
-                ss_fwd_step<NPL>(cst, x, e, y, S2);
+                ss_fwd_step<NPL, MIX>(cst, x, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) x[k] = y[k];
             }
@@ -668,7 +721,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     }
 }
 
-template <int NPL, bool RERUN, bool HYB, bool ALLLDS>
+template <int NPL, bool RERUN, bool HYB, bool ALLLDS, bool MIX = false>
 __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -798,7 +851,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
         }
         double y[NPL];
         float Sw;
-        ss_bwd_step<NPL>(cst, b, e, y, Sw);
+        ss_bwd_step<NPL, MIX>(cst, b, e, y, Sw);
         const double inv = (double)__builtin_amdgcn_rcpf(Sw);
 #pragma unroll
         for (int k = 0; k < NPL; ++k) b[k] = y[k] * inv;
@@ -807,15 +860,15 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
             float S2;
             int t = 1;
             for (; t + 1 < span; t += 2) {
-                ss_bwd_step<NPL>(cst, b, e, y, S2);
+                ss_bwd_step<NPL, MIX>(cst, b, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) b[k] = y[k];
-                ss_bwd_step<NPL>(cst, b, e, y, S2);
+                ss_bwd_step<NPL, MIX>(cst, b, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) b[k] = y[k];
             }
             if (t < span) {
-                ss_bwd_step<NPL>(cst, b, e, y, S2);
+                ss_bwd_step<NPL, MIX>(cst, b, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) b[k] = y[k];
             }
@@ -1277,11 +1330,21 @@ __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
     const int c = task & 0x3FFFFFFF;
     if (fwd) {
         if (idle_f) return;
+        if (NPL == 1 && !HYB && a.mixed) {
+            if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS, true>(a, ss_lds, c, lane);
+            else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB, ALLLDS, true>(a, ss_lds, c, lane);
+            else ss_forward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
+        } else
         if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS>(a, ss_lds, c, lane);
         else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB, ALLLDS>(a, ss_lds, c, lane);
         else ss_forward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
     } else {
         if (idle_b) return;
+        if (NPL == 1 && !HYB && a.mixed) {
+            if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS, true>(a, ss_lds, c, lane);
+            else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB, ALLLDS, true>(a, ss_lds, c, lane);
+            else ss_backward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
+        } else
         if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS>(a, ss_lds, c, lane);
         else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB, ALLLDS>(a, ss_lds, c, lane);
         else ss_backward_light<NPL, ALLLDS>(a, ss_lds, c, lane);

@@ -2748,6 +2748,12 @@ void smcpp_im::ss_launch_initial() {
     }
     a.changed_f = d_flags_view; a.changed_b = d_flags_view + (max_pass + 1);
     a.eps_f = eps_f; a.eps_b = eps_b; a.full_f = a.full_b = 0;
+    {
+        // SMCPP_SS_MIXED=1 (opt-in until measured against the tolerances): mixed-precision scans in the stored passes; never with
+        // save_gamma - the posterior's argmax is compared index by index
+        static const bool mixed_on = getenv("SMCPP_SS_MIXED") && atoi(getenv("SMCPP_SS_MIXED")) != 0;
+        a.mixed = (mixed_on && !save_gamma && NPL == 1 && !ss_hybrid) ? 1 : 0;
+    }
     a.fine = nullptr; a.nfine = 0; a.hand_f = a.hand_b = 0; a.fine_ends_f = nullptr; a.fine_ends_b = nullptr;
     if (ss_hybrid) {
         a.hyb_th = ss_hyb_th; a.Ke = Ke; a.hot_ek = std::max(0, hot_eig); a.dirsplit = ss_dirsplit ? 1 : 0;

@@ -837,6 +837,30 @@ def test_span1_statistics_one_pass_in_key_order(monkeypatch):
             np.testing.assert_allclose(g1[k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
 
 
+def test_mixed_precision_scans_opt_in(monkeypatch):
+    """SMCPP_SS_MIXED=1 (opt-in, round 4): in the stored passes only the scan whose result is differenced stays in fp64, the weighted
+    scans run in float (one fused DPP instruction per level).  Same goldens and tolerances as the default path, and against it: the
+    log-likelihood to 1e-9, the statistics to the float noise the reference's own forward chain carries."""
+    res = {}
+    names = ("G4_M64_n20_2Mbp", "G3_M32_n10_2Mbp", "G1_M16_n4", "G5_M48_twopop_layout")
+    for mixed in ("0", "1"):
+        monkeypatch.setenv("SMCPP_SS_MIXED", mixed)
+        for name in names:
+            g = load_golden(name)
+            im = make_im(g)
+            im.E_step()
+            assert im.chain_mode() == 5
+            check_against(g, im, save_gamma=False)
+            res[(mixed, name)] = (im.loglik(), im.gamma_sums[0], im.xisums[0])
+    for name in names:
+        l0, g0, x0 = res[("0", name)]
+        l1, g1, x1 = res[("1", name)]
+        assert abs(l1 - l0) <= 1e-9 * abs(l0)
+        assert rel_err(x1, x0) <= 2e-6
+        for k, v in g0.items():
+            assert np.max(np.abs(g1[k] - v)) <= 2e-6 * max(np.abs(v).max(), 1e-300), k
+
+
 @pytest.mark.parametrize("M,n", [(48, 7), (64, 20), (100, 6), (130, 6), (256, 8)])
 def test_span_fold_on_scans_vs_matrix_cores(monkeypatch, M, n):
     """Round 4: the eigen-free span statistics fold the spans with the O(M) scan steps of the chains (k_span_scan: one wavefront per

@@ -87,22 +87,8 @@ def eval_work(obs_list, M):
 
 
 def synth_posterior_contig(rows, n, seed=7):
-    """Un-binned rows as `smc++ posterior` sees them (smcpp/commands/posterior.py:48-111): long monomorphic runs with
-    spans up to 1e5 separated by span-1 segregating sites, a sprinkling of missing stretches."""
-    rng = np.random.default_rng(seed)
-    ob = np.zeros((rows, 4), dtype=np.int32)
-    kind = rng.random(rows)
-    seg = kind < 0.45                                    # segregating site: span 1, full SFS observation
-    mis = (kind >= 0.45) & (kind < 0.50)                 # missing stretch
-    mono = ~(seg | mis)
-    ob[seg, 0] = 1
-    ob[seg, 1] = rng.integers(0, 2, seg.sum())
-    ob[seg, 3] = n
-    ob[seg, 2] = np.where(ob[seg, 1] == 1, rng.integers(0, n + 1, seg.sum()), rng.integers(1, n + 1, seg.sum()))
-    ob[mis, 0] = rng.integers(1, 5000, mis.sum()); ob[mis, 1] = -1
-    ob[mono, 0] = np.minimum(100000, 1 + (rng.pareto(1.2, mono.sum()) * 200).astype(np.int64))
-    ob[mono, 3] = n
-    return ob
+    from smcpp_amd import synth
+    return synth.synth_posterior_contig(rows, n, seed)
 
 
 def self_launch(args):
@@ -290,10 +276,20 @@ def main():
         host_timings.append(im.last_host_timing())
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        # every rank's own clock over the timed region, its rows and positions (the load the LPT shard gave it): gathered AFTER
+        # the timed region; `value` uses the MAX over ranks
+        mine_t = torch.tensor([elapsed, float(sum(len(c) for c in contigs)), float(sum(int(c[:, 0].sum()) for c in contigs))],
+                              dtype=torch.float64, device=red_dev)
+        allt = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(allt, mine_t)
+        allt = np.array([t.cpu().numpy() for t in allt])
+        elapsed = float(allt[:, 0].max())
+        per_rank = {"ms_per_step": [1e3 * float(x) / args.steps for x in allt[:, 0]], "rows": [int(x) for x in allt[:, 1]],
+                    "positions": [int(x) for x in allt[:, 2]],
+                    "load_max_over_mean": float(allt[:, 1].max() / allt[:, 1].mean()),
+                    "ranks_reported_by_backend": int(dist.get_world_size()), "backend": dist.get_backend()}
     ms_per_step = 1e3 * elapsed / args.steps
     if args.workload == "c3":
         value = args.steps / elapsed                     # whole-genome evals per second (the ranks share ONE eval)
@@ -500,6 +496,26 @@ def main():
                                "source": "tests/golden/" + os.path.basename(gp) + " (compiled reference, full size, all contigs of this run)"}
     except Exception:  # noqa: BLE001
         parity_full = None
+    # posterior workloads: the decode's indices at full size against the compiled reference's (golden G20,
+    # tests/golden/make_golden_argmax.py: argmax of every one of the 10^6 + 1 columns, the columns with a margin below 1e-3)
+    try:
+        gp = os.path.join(ROOT, "tests", "golden", f"G20_{args.workload}.npz")
+        if args.workload in ("posterior", "posterior64") and os.path.exists(gp) and world == 1 and not args.raw:
+            z = np.load(gp)
+            if synth.contig_crc(contigs[0]) == int(z["crc"]):
+                arg = np.asarray(im.gamma_argmax(0)).astype(np.int64)
+                ref_arg = z["gamma_argmax"].astype(np.int64)
+                mism = np.nonzero(arg != ref_arg)[0]
+                margin = np.full(len(ref_arg), float(z["low_margin_below"])); margin[z["low_margin_cols"]] = z["low_margin"]
+                ref_ll = float(z["loglik"])
+                parity_full = {"loglik_reference_full": ref_ll, "loglik_engine": float(ll), "rel_diff": abs(float(ll) - ref_ll) / abs(ref_ll),
+                               "columns": int(len(ref_arg)), "argmax_mismatches": int(len(mism)),
+                               "argmax_mismatches_with_reference_margin_above_1e-5": int((margin[mism] > 1e-5).sum()),
+                               "reference_columns_with_margin_below_1e-5": int((margin < 1e-5).sum()),
+                               "source": "tests/golden/" + os.path.basename(gp) + " (compiled reference HMM::Estep with save_gamma on the same "
+                                         "rows; the engine ran set_params -> E_step, i.e. its own cold preparation)"}
+    except Exception as ex:  # noqa: BLE001
+        parity_full = {"error": repr(ex)}
     out = None
     if rank == 0:
         out = {
@@ -529,6 +545,10 @@ def main():
         if world > 1:
             out["config"]["backend"] = "nccl (RCCL)" if backend == "nccl" else \
                 f"{backend}: {world} ranks share {ndev} device(s) - functional test of the N>1 path, not a measurement"
+            out["config"]["collective"] = ("one all_reduce(sum, f64) of %d doubles per E-step, issued on the engine's stream behind the pack "
+                                           "kernel (no host wait before it)" % sim.im.stats_len()) if backend == "nccl" else \
+                "one all_reduce(sum, f64) per E-step through the host (gloo)"
+            out["per_rank"] = per_rank
         if not args.no_cpu and world == 1:                          # the CPU baseline is timed at N = 1 only
             # the reference's E-step gets the engine's prepared parameters of this model (pi, T, emission table), its
             # cold preparation is timed on the model itself (one population only: the two-population joint CSFS is in

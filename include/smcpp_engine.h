@@ -118,7 +118,9 @@ int smcpp_set_global_keys(smcpp_im *im, int Kg, const int *gkeys);
 
 /* Packed sufficient statistics of this rank's contigs, ready for one all-reduce(sum, fp64):
  * [ sum loglik | gamma0 (M) | xisum (M*M) | gamma_sums dense (K*M) ].  Returns the length via n_out when
- * buf == NULL.  dev != 0: buf is a device pointer (filled on the engine's stream) else a host pointer. */
+ * buf == NULL.  dev != 0: buf is a device pointer (filled by one kernel on the engine's stream) else a host pointer.
+ * dev == 1 returns after that kernel has finished; dev == 2 returns after the ENQUEUE: the caller consumes buf on the
+ * engine's stream (smcpp_stream), e.g. an RCCL all-reduce ordered behind the pack kernel with no host wait in between. */
 int smcpp_pack_stats(smcpp_im *im, double *buf, long *n_out, int dev);
 /* Hand the all-reduced buffer back; Q() then evaluates on the global statistics. */
 int smcpp_unpack_stats(smcpp_im *im, const double *buf, long n, int dev);

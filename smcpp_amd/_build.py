@@ -49,8 +49,14 @@ def _gmp():
     raise RuntimeError("libgmp not found")
 
 
+LAST_ACTION = None       # "compiled" / "reused": what the last build() call did (printed, and read by __graft_entry__.build)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    global LAST_ACTION
     if not force and not _stale():
+        LAST_ACTION = "reused"
+        print(f"smcpp_amd._build: reused {os.path.relpath(LIB)} (newer than every source under csrc/ and include/)", flush=True)
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     gmp_inc, gmp_lib = _gmp()
@@ -59,7 +65,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-Wl," + gmp_lib]
     if verbose:
         print(" ".join(cmd))
+    import time
+    t0 = time.time()
     subprocess.check_call(cmd)
+    LAST_ACTION = "compiled"
+    print(f"smcpp_amd._build: compiled {os.path.relpath(LIB)} with hipcc --offload-arch=gfx950 in {time.time() - t0:.0f} s", flush=True)
     return LIB
 
 

@@ -282,12 +282,13 @@ class _PyInferenceManager:
         E.check(E.lib().smcpp_pack_stats(self._im, None, C.byref(n), 0))
         return int(n.value)
 
-    def pack_stats_device(self, device_ptr):
+    def pack_stats_device(self, device_ptr, sync=True):
         """Write the packed statistics into a device buffer of `stats_len()` doubles (e.g. `tensor.data_ptr()` of the
-        fp64 tensor that is all-reduced over RCCL); returns after the kernel has finished."""
+        fp64 tensor that is all-reduced over RCCL); returns after the kernel has finished, or - `sync=False` - right after
+        the enqueue on the engine's stream (`stream()`), for a consumer that is ordered on that stream."""
         n = C.c_long(0)
         E.check(E.lib().smcpp_pack_stats(self._im, C.cast(C.c_void_p(int(device_ptr)), C.POINTER(C.c_double)),
-                                         C.byref(n), 1))
+                                         C.byref(n), 1 if sync else 2))
         return int(n.value)
 
     def unpack_stats_device(self, device_ptr, n):

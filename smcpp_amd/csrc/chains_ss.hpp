@@ -66,7 +66,7 @@ struct SsArgs {
     // x <- P (d~^s o (P^-1 x))  (forward; hmm.cpp:72-78) /  b <- P^-T (d~^s o (P^T b))  (backward; hmm.cpp:104-112) on the
     // eigensystem of its key - two M-long mat-vecs per lane against LDS tables - instead of `span` scan steps; shorter rows
     // keep the scans.  rowdesc.x carries the eigen key in its upper 16 bits.  hyb_th = INT_MAX: no such rows.
-    int mixed = 0;              // M <= 64, no save_gamma: the weighted scans of the full / re-run passes in float (ss_fwd_step<.., MIX>)
+    int mixed = 0;              // M <= 64, no save_gamma: 1 = the weighted scans of the full / re-run passes in float (ss_fwd_step<.., 1>), 2 = all scans in float (<.., 2>)
     int dirsplit = 0;           // hybrid rows, M > 32: a workgroup runs ONE direction and stages only that direction's two tables per eigen key
     int hyb_th = 0x7fffffff, Ke = 0, hot_ek = 0;   // hot_ek: the eigen key with the most rows (its table rows stay in registers)
     const double *Pinvrm = nullptr, *Prm = nullptr, *PinvT = nullptr, *PT = nullptr;   // [Ke][Mp][Mp]
@@ -135,9 +135,20 @@ __device__ __forceinline__ void ss_levels(double A, int lane, double (&lv)[6]) {
 }
 
 template <int NPL>
-struct SsFwdC { double dc[NPL], g[NPL], cg[NPL], b[NPL], a[NPL], d[NPL], cumA[NPL], lv[6], c15, c31; float lvf[6]; };
+struct SsFwdC {
+    double dc[NPL], g[NPL], cg[NPL], b[NPL], a[NPL], d[NPL], cumA[NPL], lv[6], c15, c31;
+    float lvf[6];
+    // all-float scans (ss_fwd_step<1, 2>): diagonal d - g in fp64, the off-diagonal coefficients in float, row masks of the suffix scan
+    double adg;
+    float bgf, bff, c0f, m1, m2, m3;
+};
 template <int NPL>
-struct SsBwdC { double dc[NPL], g[NPL], b[NPL], a[NPL], cumA[NPL], lv[6], c15, c31, c0; float c15f, c31f, lvf[6]; };
+struct SsBwdC {
+    double dc[NPL], g[NPL], b[NPL], a[NPL], cumA[NPL], lv[6], c15, c31, c0;
+    float c15f, c31f, lvf[6];
+    double adg;                                    // (d - c0) - g: the diagonal of the all-float-scan step (ss_bwd_step<1, 2>)
+    float gf, bff, c0f, m1, m2, m3;
+};
 
 template <int NPL>
 __device__ __forceinline__ void ss_load_fwd(const SsArgs &a, int lane, SsFwdC<NPL> &c) {
@@ -155,6 +166,9 @@ __device__ __forceinline__ void ss_load_fwd(const SsArgs &a, int lane, SsFwdC<NP
     const int row = lane >> 4;
     c.c15 = (row & 1) ? 1.0 : 0.0;
     c.c31 = (row >= 2) ? 1.0 : 0.0;
+    c.adg = c.d[0] - c.g[0];
+    c.bgf = (float)(c.g[0] - a.c0); c.bff = (float)c.b[0]; c.c0f = (float)a.c0;
+    c.m1 = row < 1 ? 1.f : 0.f; c.m2 = row < 2 ? 1.f : 0.f; c.m3 = row < 3 ? 1.f : 0.f;
 }
 template <int NPL>
 __device__ __forceinline__ void ss_load_bwd(const SsArgs &a, int lane, SsBwdC<NPL> &c) {
@@ -174,6 +188,9 @@ __device__ __forceinline__ void ss_load_bwd(const SsArgs &a, int lane, SsBwdC<NP
 #pragma unroll
     for (int q = 0; q < 6; ++q) c.lvf[q] = (float)c.lv[q];
     c.c0 = a.c0;
+    c.adg = c.dc[0] - c.g[0];
+    c.gf = (float)c.g[0]; c.bff = (float)c.b[0]; c.c0f = (float)a.c0;
+    c.m1 = row < 1 ? 1.f : 0.f; c.m2 = row < 2 ? 1.f : 0.f; c.m3 = row < 3 ? 1.f : 0.f;
 }
 
 // One level of the WEIGHTED scan in float: z += lv * dpp(z), one instruction.  `ord` is a double of the fp64 chain the level is
@@ -191,16 +208,99 @@ __device__ __forceinline__ void ss_mix_bc15(float &z, double &ord, float lv) { S
 __device__ __forceinline__ void ss_mix_bc31(float &z, double &ord, float lv) { SS_MIXLVL_("", "row_bcast:31"); }
 #undef SS_MIXLVL_
 
+// ---------------------------------------------------------------------------------------------------------------
+// ALL scans of a stored position in float (MIX = 2; one state per lane).  What made a scan need fp64 was the DIFFERENCE taken of
+// it: the sum over the states ABOVE (forward: g_j sum_{i>j} x_i; backward, reversed lanes: sum_{j<i} g_j w_j) was formed as
+// total - inclusive prefix, which cancels.  Formed directly - an inclusive SUFFIX scan over the lanes: row_shl 1/2/4/8 inside the
+// 16-lane rows, then the totals of the rows above through three v_readlane and three masked v_fmac - it is a sum of positive
+// terms like the weighted scans, good to a float ulp, and a level is ONE fused DPP instruction instead of two DPP moves and an
+// fp64 add.  These sums are the OFF-DIAGONAL part of the operator (<= 1e-2 of the row's mass): their float rounding enters a
+// position at 1e-2 x 6e-8; the diagonal term and the vector itself stay in fp64.
+// The normaliser becomes a float-accurate total.  That is harmless by construction: the row is divided by exactly the number
+// that is stored as its normaliser (c~ = sum (1 + delta), delta ~ 1e-7), the stored vector is then scaled by 1 / (1 + delta), the
+// next row's total carries the same factor, and every statistic takes the vector and its normaliser together (hmm.cpp:113-138
+// are invariant to a per-row scale); the log-likelihood sum log c~ telescopes to the same product (the backward chain has
+// always run in such a running scale).
+// The blocks are hand scheduled: a DPP read needs two wait states after the VALU write of its source, v_readlane one, a VALU
+// read of an SGPR written by v_readlane two (gfx940 family); the compiler counts an asm statement as no wait state at all.
+// ---------------------------------------------------------------------------------------------------------------
+#define SS_D_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+// forward: z = weighted prefix scan (level multipliers lv), s = inclusive suffix sum.  On return zp = bg * s + c0 * total + (z of
+// the lane below), tot = s of lane 0 (the total).
+__device__ __forceinline__ void ss_x_scan_fwd(float &z, float &s, float &zp, float &tot, const float (&lv)[6], float m1, float m2,
+                                              float m3, float bg, float c0) {
+    float t1, t2, t3;
+    asm volatile("s_nop 1\n"
+                 "v_add_f32_dpp %1, %1, %1 row_shl:1" SS_D_ "v_fmac_f32_dpp %0, %0, %7 row_shr:1" SS_D_ "s_nop 0\n"
+                 "v_add_f32_dpp %1, %1, %1 row_shl:2" SS_D_ "v_fmac_f32_dpp %0, %0, %8 row_shr:2" SS_D_ "s_nop 0\n"
+                 "v_add_f32_dpp %1, %1, %1 row_shl:4" SS_D_ "v_fmac_f32_dpp %0, %0, %9 row_shr:4" SS_D_ "s_nop 0\n"
+                 "v_add_f32_dpp %1, %1, %1 row_shl:8" SS_D_ "v_fmac_f32_dpp %0, %0, %10 row_shr:8" SS_D_
+                 "v_readlane_b32 %4, %1, 16\n"
+                 "v_readlane_b32 %5, %1, 32\n"
+                 "v_fmac_f32_dpp %0, %0, %11 row_bcast:15" SS_D_
+                 "v_readlane_b32 %6, %1, 48\n"
+                 "v_fmac_f32_e32 %1, %4, %13\n"
+                 "v_fmac_f32_dpp %0, %0, %12 row_bcast:31" SS_D_
+                 "v_fmac_f32_e32 %1, %5, %14\n"
+                 "v_fmac_f32_e32 %1, %6, %15\n"
+                 "v_mov_b32_dpp %2, %0 wave_shr:1" SS_D_
+                 "v_readlane_b32 %3, %1, 0\n"
+                 "v_fmac_f32_e32 %2, %16, %1\n"
+                 "s_nop 0\n"
+                 "v_fmac_f32_e32 %2, %3, %17\n"
+                 : "+v"(z), "+v"(s), "=&v"(zp), "=&s"(tot), "=&s"(t1), "=&s"(t2), "=&s"(t3)
+                 : "v"(lv[0]), "v"(lv[1]), "v"(lv[2]), "v"(lv[3]), "v"(lv[4]), "v"(lv[5]), "v"(m1), "v"(m2), "v"(m3), "v"(bg), "v"(c0));
+}
+// backward (reversed lanes): v = weighted prefix scan, f = plain prefix sum, gs = inclusive suffix sum of g o w.  On return
+// gs += c0 * f + b * (v of the lane below), tot = f of lane 63 (the total).
+__device__ __forceinline__ void ss_x_scan_bwd(float &v, float &f, float &gs, float &tot, const float (&lv)[6], float c15, float c31,
+                                              float m1, float m2, float m3, float b, float c0) {
+    float t1, t2, t3, vp;
+    // (f is an OUTPUT: its first level reads v before v's own first level rewrites it - no copy of the input)
+    asm volatile("s_nop 1\n"
+                 "v_add_f32_dpp %1, %0, %0 row_shr:1" SS_D_ "v_add_f32_dpp %2, %2, %2 row_shl:1" SS_D_ "v_fmac_f32_dpp %0, %0, %8 row_shr:1" SS_D_
+                 "v_add_f32_dpp %1, %1, %1 row_shr:2" SS_D_ "v_add_f32_dpp %2, %2, %2 row_shl:2" SS_D_ "v_fmac_f32_dpp %0, %0, %9 row_shr:2" SS_D_
+                 "v_add_f32_dpp %1, %1, %1 row_shr:4" SS_D_ "v_add_f32_dpp %2, %2, %2 row_shl:4" SS_D_ "v_fmac_f32_dpp %0, %0, %10 row_shr:4" SS_D_
+                 "v_add_f32_dpp %1, %1, %1 row_shr:8" SS_D_ "v_add_f32_dpp %2, %2, %2 row_shl:8" SS_D_ "v_fmac_f32_dpp %0, %0, %11 row_shr:8" SS_D_
+                 "v_readlane_b32 %5, %2, 16\n"
+                 "v_fmac_f32_dpp %1, %1, %14 row_bcast:15" SS_D_
+                 "v_fmac_f32_dpp %0, %0, %12 row_bcast:15" SS_D_
+                 "v_readlane_b32 %6, %2, 32\n"
+                 "v_readlane_b32 %7, %2, 48\n"
+                 "v_fmac_f32_dpp %1, %1, %15 row_bcast:31" SS_D_
+                 "v_fmac_f32_dpp %0, %0, %13 row_bcast:31" SS_D_
+                 "v_fmac_f32_e32 %2, %5, %16\n"
+                 "v_fmac_f32_e32 %2, %6, %17\n"
+                 "v_fmac_f32_e32 %2, %7, %18\n"
+                 "v_mov_b32_dpp %4, %0 wave_shr:1" SS_D_
+                 "v_readlane_b32 %3, %1, 63\n"
+                 "v_fmac_f32_e32 %2, %20, %1\n"
+                 "v_fmac_f32_e32 %2, %19, %4\n"
+                 : "+v"(v), "=&v"(f), "+v"(gs), "=&s"(tot), "=&v"(vp), "=&s"(t1), "=&s"(t2), "=&s"(t3)
+                 : "v"(lv[0]), "v"(lv[1]), "v"(lv[2]), "v"(lv[3]), "v"(lv[4]), "v"(lv[5]), "v"(c15), "v"(c31), "v"(m1), "v"(m2), "v"(m3),
+                   "v"(b), "v"(c0));
+}
+#undef SS_D_
+
 // The scans of one position are written level by level across the independent chains: a DPP move may only read a register two
 // instructions after it was written, so one chain alone pays a wait state per level, two or three interleaved pay none.
 // one position of the forward chain:  out = e o (T^T x);  S = sum x
 // MIX (one state per lane; the full and re-run passes of an E-step without save_gamma): only the scan whose result is DIFFERENCED
 // stays in fp64 - the plain prefix sum behind S - incl forward, the g-weighted one behind Gtot - inclG backward.  The weighted scans
 // sum positive terms and are good to a float ulp in float, where a level is one fused instruction instead of two DPP moves and an FMA.
-template <int NPL, bool MIX = false>
+template <int NPL, int MIX = 0>
 __device__ __forceinline__ void ss_fwd_step(const SsFwdC<NPL> &c, const double (&x)[NPL], const double (&e)[NPL],
                                             double (&out)[NPL], double &S) {
-    if (MIX && NPL == 1) {
+    if (MIX == 2 && NPL == 1) {
+        // (T^T x)_j = (d_j - g_j) x_j + (g_j - c0) sum_{i >= j} x_i + c0 S + Z_j
+        float s = (float)x[0];
+        float z = c.bff * s, zp, tot;
+        ss_x_scan_fwd(z, s, zp, tot, c.lvf, c.m1, c.m2, c.m3, c.bgf, c.c0f);
+        S = (double)tot;
+        out[0] = e[0] * __builtin_fma(c.adg, x[0], (double)zp);
+        return;
+    }
+    if (MIX == 1 && NPL == 1) {
         double p_ = x[0];
         float z = (float)(c.b[0] * x[0]);
         p_ += dpp0<DPP_SHR1>(p_); ss_mix_shr1(z, p_, c.lvf[0]);
@@ -250,10 +350,19 @@ __device__ __forceinline__ void ss_fwd_step(const SsFwdC<NPL> &c, const double (
 }
 
 // one position of the backward chain (position p = state MS-1-p):  out = T (e o b);  Sw = sum (e o b) (float accuracy)
-template <int NPL, bool MIX = false>
+template <int NPL, int MIX = 0>
 __device__ __forceinline__ void ss_bwd_step(const SsBwdC<NPL> &c, const double (&bv)[NPL], const double (&e)[NPL],
                                             double (&out)[NPL], float &Sw) {
-    if (MIX && NPL == 1) {
+    if (MIX == 2 && NPL == 1) {
+        // (T w)_i = ((d_i - c0) - g_i) w_i + sum_{j <= i} g_j w_j + c0 inclW_i + b_i V_i   (lanes hold the states reversed)
+        const double w0 = e[0] * bv[0];
+        float v = (float)w0;
+        float gs = c.gf * v, f;
+        ss_x_scan_bwd(v, f, gs, Sw, c.lvf, c.c15f, c.c31f, c.m1, c.m2, c.m3, c.bff, c.c0f);
+        out[0] = __builtin_fma(c.adg, w0, (double)gs);
+        return;
+    }
+    if (MIX == 1 && NPL == 1) {
         const double w0 = e[0] * bv[0];
         double p_ = c.g[0] * w0;
         float z = (float)w0, f_ = (float)w0;
@@ -498,7 +607,7 @@ __device__ __forceinline__ void ss_fwd_light_rows(const SsArgs &a, const double 
 template <int NPL, bool ALLLDS>
 __device__ __forceinline__ void ss_bwd_light_rows(const SsArgs &a, const double *sE, long long base, int rhi, int rlo, int lane, float (&b)[NPL]);
 
-template <int NPL, bool RERUN, bool HYB, bool ALLLDS, bool MIX = false>
+template <int NPL, bool RERUN, bool HYB, bool ALLLDS, int MIX = 0>
 __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -721,7 +830,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     }
 }
 
-template <int NPL, bool RERUN, bool HYB, bool ALLLDS, bool MIX = false>
+template <int NPL, bool RERUN, bool HYB, bool ALLLDS, int MIX = 0>
 __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -1330,9 +1439,13 @@ __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
     const int c = task & 0x3FFFFFFF;
     if (fwd) {
         if (idle_f) return;
-        if (NPL == 1 && !HYB && a.mixed) {
-            if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS, true>(a, ss_lds, c, lane);
-            else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB, ALLLDS, true>(a, ss_lds, c, lane);
+        if (NPL == 1 && !HYB && a.mixed == 2) {
+            if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS, 2>(a, ss_lds, c, lane);
+            else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB, ALLLDS, 2>(a, ss_lds, c, lane);
+            else ss_forward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
+        } else if (NPL == 1 && !HYB && a.mixed == 1) {
+            if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS, 1>(a, ss_lds, c, lane);
+            else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB, ALLLDS, 1>(a, ss_lds, c, lane);
             else ss_forward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
         } else
         if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS>(a, ss_lds, c, lane);
@@ -1340,9 +1453,13 @@ __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
         else ss_forward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
     } else {
         if (idle_b) return;
-        if (NPL == 1 && !HYB && a.mixed) {
-            if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS, true>(a, ss_lds, c, lane);
-            else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB, ALLLDS, true>(a, ss_lds, c, lane);
+        if (NPL == 1 && !HYB && a.mixed == 2) {
+            if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS, 2>(a, ss_lds, c, lane);
+            else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB, ALLLDS, 2>(a, ss_lds, c, lane);
+            else ss_backward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
+        } else if (NPL == 1 && !HYB && a.mixed == 1) {
+            if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS, 1>(a, ss_lds, c, lane);
+            else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB, ALLLDS, 1>(a, ss_lds, c, lane);
             else ss_backward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
         } else
         if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS>(a, ss_lds, c, lane);

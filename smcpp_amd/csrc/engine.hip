@@ -196,12 +196,19 @@ struct DevPrep {
     int *h_flags = nullptr, *d_flags_view = nullptr;
     int e_flags[4] = {0, 0, 0, 0};
     int last_nder = 0;
+    hipEvent_t ev_done = nullptr;        // recorded behind the last preparation's kernels: the staging block and the flag words
+    bool in_flight = false;              // are rewritten only after it has completed
     ~DevPrep() {
         if (d_in) (void)hipFree(d_in);
         if (h_flags) (void)hipHostFree(h_flags);
+        if (ev_done) (void)hipEventDestroy(ev_done);
     }
     typedef smcpp_dev::DN<4> SD;             // scalar of the derivative kernels: value + four directions per thread
-    static bool supported(int n) { return n >= 1 && smcpp_dev::CsfsScratch<SD>::count(n) * sizeof(SD) <= 150 * 1024; }
+    // n: the CSFS scratch of one hidden state must fit LDS; K (pieces after the hidden states were inserted): so must the
+    // 2 K scan terms of k_prep_tables (80 B per piece with four directions per scalar)
+    static bool supported(int n, int K = 0) {
+        return n >= 1 && smcpp_dev::CsfsScratch<SD>::count(n) * sizeof(SD) <= 150 * 1024 && (size_t)2 * K * sizeof(SD) <= 150 * 1024;
+    }
 
     void set_static(const smcpp_host::CsfsTables &t) {
         n = t.n;
@@ -279,6 +286,9 @@ struct DevPrep {
         char *hb;
         if (emulate) { h_in.resize(bytes); hb = h_in.data(); }
         else {
+            // an earlier preparation may still be reading the staging block / raising flags (the Jacobian getters return after the
+            // enqueue): wait for it before either is rewritten
+            if (in_flight) { HIPCHK(hipEventSynchronize(ev_done)); in_flight = false; }
             stage.reset(bytes);
             hb = stage.base;
             if (bytes > in_cap) {
@@ -347,7 +357,11 @@ struct DevPrep {
             tb.carve(reinterpret_cast<S *>(d_tab.p), n, K, ng);
             const size_t lds = smcpp_dev::CsfsScratch<S>::count(n) * sizeof(S);
             static bool once = false;
-            if (!once) { HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_csfs<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+            if (!once) {
+                HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_csfs<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_tables<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                once = true;
+            }
             hipLaunchKernelGGL(smcpp_dev::k_prep_tables<S>, dim3(ng, 2 * n + 1), dim3(ntt), (size_t)2 * K * sizeof(S), s, pm, tb);
             hipLaunchKernelGGL(smcpp_dev::k_prep_csfs<S>, dim3(M, ng), dim3(nt), lds, s, pm, ps, po, tb);
         } else {
@@ -356,11 +370,18 @@ struct DevPrep {
             tb.carve(d_tab.p, n, K, 1);
             const size_t lds = smcpp_dev::CsfsScratch<S>::count(n) * sizeof(S);
             static bool once = false;
-            if (!once) { HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_csfs<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+            if (!once) {
+                HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_csfs<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_tables<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                once = true;
+            }
             hipLaunchKernelGGL(smcpp_dev::k_prep_tables<S>, dim3(1, 2 * n + 1), dim3(ntt), (size_t)2 * K * sizeof(S), s, pm, tb);
             hipLaunchKernelGGL(smcpp_dev::k_prep_csfs<S>, dim3(M, 1), dim3(nt), lds, s, pm, ps, po, tb);
         }
         HIPCHK(hipGetLastError());
+        if (!ev_done) HIPCHK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev_done, s));
+        in_flight = true;
     }
     const int *flags() const { return emulate ? e_flags : h_flags; }
     // Results to the host (after the stream has drained): E [Kk][M], dE [Kk*M][nder], sfs [M][C], dsfs [M*C][nder]
@@ -1518,7 +1539,7 @@ void smcpp_im::prepare_params() {
     {
         // conditioned SFS + emission table on the device (SMCPP_PREP=host: the host routines, as in rounds 1-3)
         static const bool host_only = getenv("SMCPP_PREP") && !strcmp(getenv("SMCPP_PREP"), "host");
-        if (!host_only && !force_host_prep && DevPrep::supported(n[0]) && !smcpp_host::csfs_direct_flag()) { dev_prepare(); return; }
+        if (!host_only && !force_host_prep && DevPrep::supported(n[0], (int)model.a.size() + (int)hs.size()) && !smcpp_host::csfs_direct_flag()) { dev_prepare(); return; }
     }
     E_on_dev = false;
     tgen_valid = false; dT_valid = true;
@@ -2751,8 +2772,8 @@ void smcpp_im::ss_launch_initial() {
     {
         // SMCPP_SS_MIXED=1 (opt-in until measured against the tolerances): mixed-precision scans in the stored passes; never with
         // save_gamma - the posterior's argmax is compared index by index
-        static const bool mixed_on = getenv("SMCPP_SS_MIXED") && atoi(getenv("SMCPP_SS_MIXED")) != 0;
-        a.mixed = (mixed_on && !save_gamma && NPL == 1 && !ss_hybrid) ? 1 : 0;
+        static const int mixed_on = getenv("SMCPP_SS_MIXED") ? std::max(0, std::min(2, atoi(getenv("SMCPP_SS_MIXED")))) : 0;
+        a.mixed = (mixed_on && !save_gamma && NPL == 1 && !ss_hybrid) ? mixed_on : 0;
     }
     a.fine = nullptr; a.nfine = 0; a.hand_f = a.hand_b = 0; a.fine_ends_f = nullptr; a.fine_ends_b = nullptr;
     if (ss_hybrid) {
@@ -3726,6 +3747,7 @@ int smcpp_set_hidden_states(smcpp_im *im, int n_hs, const double *hs) {
     im->update_pi_default();
     im->twopop_prep.reset();
     if (!im->estep_done) im->stats_on_host = false;
+    if (im->qdev) im->qdev->stats_ready = false;      // the pre-E-step statistics are span_sum * pi_default: restage them
     im->dirty = true;
     im->params_fresh = false;
     if (im->have_model) im->have_raw = false;
@@ -3915,7 +3937,9 @@ int smcpp_pack_stats(smcpp_im *im, double *buf, long *n_out, int dev) {
         pa.present = im->d_present.p; pa.g2l = im->d_g2l.p; pa.out = buf;
         hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, im->stream, pa);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(im->stream));
+        // dev == 2: stream-ordered hand-over - the caller consumes `buf` on the engine's stream (smcpp_stream), e.g. an RCCL
+        // all-reduce enqueued behind the pack kernel, so there is no host wait between the E-step and the collective
+        if (dev != 2) HIPCHK(hipStreamSynchronize(im->stream));
         return 0;
     }
     im->fetch_stats();

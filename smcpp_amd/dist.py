@@ -127,6 +127,10 @@ class ShardedInferenceManager:
     over xGMI; with "gloo" (CPU tests, or ranks sharing a device) it goes through the host.  Without an initialised
     process group (or world size 1) it degenerates to the local manager.
 
+    `self.im` is this rank's LOCAL manager: after `E_step` its own `Q` / statistics getters see rank-local statistics until the
+    reduced buffer has been handed back (`_ensure_unpacked`, done by this class's `Q` / `Q_with_gradient`) - query the reduced
+    quantities through this wrapper, not through `self.im`.
+
     observations: the list of ALL contigs, identical on every rank; entries this rank does not own may be None if
     `lengths` gives every contig's row count (so a rank need not load the others' data).
     factory: callable(local_observations, device) -> manager; defaults to a one-population manager.
@@ -170,8 +174,11 @@ class ShardedInferenceManager:
         self._buf = None
         self._ll_sum = None
         self._lls = None
+        self._unpack_pending = False      # RCCL path: the reduced statistics still sit in the device buffer (see _ensure_unpacked)
         self.last_local_stats = self.last_reduced_stats = None      # (host copies, kept only when `keep_stats` is set: tests)
         self.keep_stats = False
+        self.stream_ordered = True        # RCCL path: issue the collective on the engine's stream (False: host wait after the pack)
+        self._ext = None
         if self._reduce:
             # global key dictionary: fixes the layout of the gamma_sums block and makes the engine prepare the
             # emission vectors of keys only other ranks' contigs hold (they enter Q through the reduced statistics)
@@ -210,16 +217,27 @@ class ShardedInferenceManager:
             return
         import torch
         if self._nccl:
+            dev = torch.device("cuda", self._device)
             if self._buf is None:
                 # on the device the ENGINE lives on (the pack / unpack kernels dereference the pointer there)
-                self._buf = torch.empty(self.im.stats_len(), dtype=torch.float64, device=torch.device("cuda", self._device))
-            self.im.pack_stats_device(self._buf.data_ptr())           # returns after the kernel has finished
-            if self.keep_stats:
-                self.last_local_stats = self._buf.cpu().numpy().copy()
-            self._dist.all_reduce(self._buf, op=self._dist.ReduceOp.SUM, group=self._group)
-            self._ll_sum = float(self._buf[0].item())                 # synchronises the reduction
-            if self.keep_stats:
-                self.last_reduced_stats = self._buf.cpu().numpy().copy()
+                self._buf = torch.empty(self.im.stats_len(), dtype=torch.float64, device=dev)
+                # ... and everything below is ordered on the ENGINE's stream: torch sees it as an external stream, RCCL's own
+                # stream waits for it and hands back to it (ProcessGroupNCCL synchronises streams, not the host), so
+                # pack kernel -> all-reduce -> the read-back of the scalar run with no host wait in between
+                self._ext = torch.cuda.ExternalStream(int(self.im.stream()), device=dev) if self.stream_ordered else None
+            if self._ext is not None and not self.keep_stats:
+                with torch.cuda.stream(self._ext):
+                    self.im.pack_stats_device(self._buf.data_ptr(), sync=False)
+                    self._dist.all_reduce(self._buf, op=self._dist.ReduceOp.SUM, group=self._group)
+                    self._ll_sum = float(self._buf[0].item())         # the one host wait of the exchange
+            else:
+                self.im.pack_stats_device(self._buf.data_ptr())       # returns after the kernel has finished
+                if self.keep_stats:
+                    self.last_local_stats = self._buf.cpu().numpy().copy()
+                self._dist.all_reduce(self._buf, op=self._dist.ReduceOp.SUM, group=self._group)
+                self._ll_sum = float(self._buf[0].item())             # synchronises the reduction
+                if self.keep_stats:
+                    self.last_reduced_stats = self._buf.cpu().numpy().copy()
             # the reduced statistics stay in the device buffer until Q asks for them (one kernel + a synchronisation per E-step
             # that a loglik-only caller - an evaluation loop, bench.py - never needs)
             self._unpack_pending = True
@@ -251,7 +269,7 @@ class ShardedInferenceManager:
         return self._lls
 
     def _ensure_unpacked(self):
-        if getattr(self, "_unpack_pending", False):
+        if self._unpack_pending:
             self.im.unpack_stats_device(self._buf.data_ptr(), self._buf.numel())
             self._unpack_pending = False
 

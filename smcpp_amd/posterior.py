@@ -28,12 +28,13 @@ def balance_hidden_states(model, M):
 
 
 def posterior(model, contigs, M, n, theta, rho, alpha=1.0, polarization_error=0.5, hidden_states=None, device=-1, a=None,
-              start=None, end=None, thinning=1):
+              start=None, end=None, thinning=1, return_manager=False):
     """Posterior decoding of each contig.  Returns `(hidden_states, gammas, sites, paths)`:
     `gammas[c]` is `[M, L+1]` with columns normalised to one (`posterior.py:102-106`), `sites[c]` the span column of the
     rows handed to the manager (missing row included) exactly as the reference stores it under `<file>_sites`
     (`posterior.py:109`: `obs[:, 0]`, one entry per row; cumulative positions are `np.cumsum` of it), `paths[c]` the
-    argmax state per column computed on the device.
+    argmax state per column computed on the device.  `return_manager=True` appends the inference manager (its device buffers
+    stay allocated for as long as the caller keeps it) - nothing is kept otherwise.
     A missing row is prepended to every contig as the reference does (`posterior.py:83`); `start` / `end` keep the rows whose
     cumulative position lies in [start, end] (`posterior.py:76-82`: "only approximately picked out"), `thinning` > 1 thins every
     contig as `thin_dataset` does (`posterior.py:85-87`).
@@ -78,7 +79,8 @@ def posterior(model, contigs, M, n, theta, rho, alpha=1.0, polarization_error=0.
         gammas.append(g)
         sites.append(obs[c][:, 0].copy())
         paths.append(im.gamma_argmax(c))
-    posterior.last_manager = im          # (kept for callers that want the prepared parameters of the decode: tests)
+    if return_manager:
+        return hs, gammas, sites, paths, im
     return hs, gammas, sites, paths
 
 

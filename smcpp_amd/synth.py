@@ -92,6 +92,26 @@ def synth_contig_twopop(contig_index: int, length_bp: int, n1: int, n2: int, w: 
     return rle_rows(np.concatenate([p1, p2], axis=1))
 
 
+def synth_posterior_contig(rows: int, n: int, seed: int = 7) -> np.ndarray:
+    """Un-binned rows as `smc++ posterior` sees them (smcpp/commands/posterior.py:48-111): long monomorphic runs with
+    spans up to 1e5 separated by span-1 segregating sites, a sprinkling of missing stretches.  (numpy `default_rng`
+    stream; golden G20 pins the rows by their crc.)"""
+    rng = np.random.default_rng(seed)
+    ob = np.zeros((rows, 4), dtype=np.int32)
+    kind = rng.random(rows)
+    seg = kind < 0.45                                    # segregating site: span 1, full SFS observation
+    mis = (kind >= 0.45) & (kind < 0.50)                 # missing stretch
+    mono = ~(seg | mis)
+    ob[seg, 0] = 1
+    ob[seg, 1] = rng.integers(0, 2, seg.sum())
+    ob[seg, 3] = n
+    ob[seg, 2] = np.where(ob[seg, 1] == 1, rng.integers(0, n + 1, seg.sum()), rng.integers(1, n + 1, seg.sum()))
+    ob[mis, 0] = rng.integers(1, 5000, mis.sum()); ob[mis, 1] = -1
+    ob[mono, 0] = np.minimum(100000, 1 + (rng.pareto(1.2, mono.sum()) * 200).astype(np.int64))
+    ob[mono, 3] = n
+    return ob
+
+
 def contig_crc(rows: np.ndarray) -> int:
     return zlib.crc32(np.ascontiguousarray(rows, dtype=np.int32).tobytes()) & 0xFFFFFFFF
 

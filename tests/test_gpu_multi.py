@@ -183,7 +183,30 @@ def _nccl_worker(rank, port, out_dir):
     sim.E_step()
     q, jac = sim.Q_with_gradient()
     res = dict(loglik=sim.loglik(), logliks=list(map(float, sim.logliks())), q=list(map(float, sim.Q(separate=True))),
-               jac=jac.tolist(), buf_device=str(sim._buf.device), keys=sim.keys.tolist())
+               jac=jac.tolist(), buf_device=str(sim._buf.device), keys=sim.keys.tolist(), stream_ordered=sim._ext is not None)
+    # the same exchange with a host wait between the pack kernel and the collective (round 4's form): bitwise the same buffer
+    buf_a = sim._buf.cpu().numpy().copy()
+    sim.stream_ordered = False; sim._buf = None
+    sim.E_step()
+    res["host_wait_same_buffer"] = bool(np.array_equal(buf_a, sim._buf.cpu().numpy())) and sim._ext is None
+    res["host_wait_loglik"] = sim.loglik()
+    # what the exchange adds to an eval (pack kernel + one-rank RCCL all-reduce + scalar read-back), both orderings
+    import time
+
+    def per_eval(fn, reps=30):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return 1e6 * (time.perf_counter() - t) / reps
+    local_us = per_eval(lambda: (sim.im.E_step(), sim.im.loglik()))
+    wait_us = per_eval(lambda: (sim.E_step(), sim.loglik()))
+    sim.stream_ordered = True; sim._buf = None
+    ordered_us = per_eval(lambda: (sim.E_step(), sim.loglik()))
+    res["exchange_us"] = dict(local_eval=local_us, host_wait=wait_us - local_us, stream_ordered=ordered_us - local_us)
+    print("nccl world of one: exchange cost per eval (us)", res["exchange_us"], flush=True)
     with open(os.path.join(out_dir, "nccl.json"), "w") as f:
         json.dump(res, f)
     dist.barrier()
@@ -203,6 +226,8 @@ def test_nccl_device_buffer_branch_world_of_one(tmp_path):
     _setup(im, g, True)
     im.E_step()
     assert r["buf_device"].startswith("cuda")
+    assert r["stream_ordered"] and r["host_wait_same_buffer"] and r["host_wait_loglik"] == r["loglik"]
+    print("exchange cost per eval (us):", r["exchange_us"])
     assert r["keys"] == im.keys.tolist()
     assert abs(r["loglik"] - im.loglik()) <= 1e-12 * abs(im.loglik())
     np.testing.assert_allclose(r["logliks"], im.logliks(), rtol=1e-13)

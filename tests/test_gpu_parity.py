@@ -262,8 +262,7 @@ def test_posterior_product_two_populations():
     model = TwoPopulationModel(PiecewiseModel(a, s, 1e4, pid="pop1"),
                                PiecewiseModel(1.5 + 0.5 * np.cos(np.arange(4)), s[:4], 1e4, pid="pop2"), 0.4)
     raw = synth.synth_contig_twopop(3, 3_000_000, 4, 3)
-    hs, gammas, sites, paths = posterior(model, [raw], 12, (4, 3), synth.THETA, synth.RHO, a=(2, 0))
-    im = posterior.last_manager
+    hs, gammas, sites, paths, im = posterior(model, [raw], 12, (4, 3), synth.THETA, synth.RHO, a=(2, 0), return_manager=True)
     assert len(hs) == 13 and hs[0] == 0 and np.isinf(hs[-1])
     obs = np.vstack([[1, -1, 0, 0, -1, 0, 0], raw]).astype(np.int32)
     assert gammas[0].shape == (12, len(obs) + 1) and np.array_equal(sites[0], obs[:, 0])

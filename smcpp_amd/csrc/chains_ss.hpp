@@ -66,7 +66,7 @@ struct SsArgs {
     // x <- P (d~^s o (P^-1 x))  (forward; hmm.cpp:72-78) /  b <- P^-T (d~^s o (P^T b))  (backward; hmm.cpp:104-112) on the
     // eigensystem of its key - two M-long mat-vecs per lane against LDS tables - instead of `span` scan steps; shorter rows
     // keep the scans.  rowdesc.x carries the eigen key in its upper 16 bits.  hyb_th = INT_MAX: no such rows.
-    int mixed = 0;              // M <= 64, no save_gamma: 1 = the weighted scans of the full / re-run passes in float (ss_fwd_step<.., 1>), 2 = all scans in float (<.., 2>)
+    int mixed = 0;              // M <= 64, no save_gamma: every scan of the full / re-run passes in float (ss_fwd_step<1, true>; the suffix sums native)
     int dirsplit = 0;           // hybrid rows, M > 32: a workgroup runs ONE direction and stages only that direction's two tables per eigen key
     int hyb_th = 0x7fffffff, Ke = 0, hot_ek = 0;   // hot_ek: the eigen key with the most rows (its table rows stay in registers)
     const double *Pinvrm = nullptr, *Prm = nullptr, *PinvT = nullptr, *PT = nullptr;   // [Ke][Mp][Mp]
@@ -193,23 +193,8 @@ __device__ __forceinline__ void ss_load_bwd(const SsArgs &a, int lane, SsBwdC<NP
     c.m1 = row < 1 ? 1.f : 0.f; c.m2 = row < 2 ? 1.f : 0.f; c.m3 = row < 3 ? 1.f : 0.f;
 }
 
-// One level of the WEIGHTED scan in float: z += lv * dpp(z), one instruction.  `ord` is a double of the fp64 chain the level is
-// interleaved with: it is only named as an in/out operand, which pins the statement between that chain's level before and the level
-// after it - so two of these are always at least three vector instructions apart (the DPP read of z needs two), and the compiler,
-// which does not see through the asm, finds the fp64 chain's own DPP hazard at its real producer (the s_nop it then inserts sits
-// behind this instruction).  FIRST: z has just been converted from double - its hazard slots are spent inside the statement.
-#define SS_MIXLVL_(PRE, CTRL)                                                                                                   \
-    asm volatile(PRE "v_fmac_f32_dpp %0, %0, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(z), "+v"(ord) : "v"(lv))
-__device__ __forceinline__ void ss_mix_shr1(float &z, double &ord, float lv) { SS_MIXLVL_("s_nop 1\n", "row_shr:1"); }
-__device__ __forceinline__ void ss_mix_shr2(float &z, double &ord, float lv) { SS_MIXLVL_("", "row_shr:2"); }
-__device__ __forceinline__ void ss_mix_shr4(float &z, double &ord, float lv) { SS_MIXLVL_("", "row_shr:4"); }
-__device__ __forceinline__ void ss_mix_shr8(float &z, double &ord, float lv) { SS_MIXLVL_("", "row_shr:8"); }
-__device__ __forceinline__ void ss_mix_bc15(float &z, double &ord, float lv) { SS_MIXLVL_("", "row_bcast:15"); }
-__device__ __forceinline__ void ss_mix_bc31(float &z, double &ord, float lv) { SS_MIXLVL_("", "row_bcast:31"); }
-#undef SS_MIXLVL_
-
 // ---------------------------------------------------------------------------------------------------------------
-// ALL scans of a stored position in float (MIX = 2; one state per lane).  What made a scan need fp64 was the DIFFERENCE taken of
+// ALL scans of a stored position in float (MIX; one state per lane; round 5).  What made a scan need fp64 was the DIFFERENCE taken of
 // it: the sum over the states ABOVE (forward: g_j sum_{i>j} x_i; backward, reversed lanes: sum_{j<i} g_j w_j) was formed as
 // total - inclusive prefix, which cancels.  Formed directly - an inclusive SUFFIX scan over the lanes: row_shl 1/2/4/8 inside the
 // 16-lane rows, then the totals of the rows above through three v_readlane and three masked v_fmac - it is a sum of positive
@@ -285,33 +270,18 @@ __device__ __forceinline__ void ss_x_scan_bwd(float &v, float &f, float &gs, flo
 // The scans of one position are written level by level across the independent chains: a DPP move may only read a register two
 // instructions after it was written, so one chain alone pays a wait state per level, two or three interleaved pay none.
 // one position of the forward chain:  out = e o (T^T x);  S = sum x
-// MIX (one state per lane; the full and re-run passes of an E-step without save_gamma): only the scan whose result is DIFFERENCED
-// stays in fp64 - the plain prefix sum behind S - incl forward, the g-weighted one behind Gtot - inclG backward.  The weighted scans
-// sum positive terms and are good to a float ulp in float, where a level is one fused instruction instead of two DPP moves and an FMA.
-template <int NPL, int MIX = 0>
+// MIX (one state per lane; the full and re-run passes of an E-step without save_gamma): every scan in float, the sums over the
+// states above as native suffix scans (ss_x_scan_fwd / ss_x_scan_bwd above); the vector and the diagonal term stay in fp64.
+template <int NPL, bool MIX = false>
 __device__ __forceinline__ void ss_fwd_step(const SsFwdC<NPL> &c, const double (&x)[NPL], const double (&e)[NPL],
                                             double (&out)[NPL], double &S) {
-    if (MIX == 2 && NPL == 1) {
+    if (MIX && NPL == 1) {
         // (T^T x)_j = (d_j - g_j) x_j + (g_j - c0) sum_{i >= j} x_i + c0 S + Z_j
         float s = (float)x[0];
         float z = c.bff * s, zp, tot;
         ss_x_scan_fwd(z, s, zp, tot, c.lvf, c.m1, c.m2, c.m3, c.bgf, c.c0f);
         S = (double)tot;
         out[0] = e[0] * __builtin_fma(c.adg, x[0], (double)zp);
-        return;
-    }
-    if (MIX == 1 && NPL == 1) {
-        double p_ = x[0];
-        float z = (float)(c.b[0] * x[0]);
-        p_ += dpp0<DPP_SHR1>(p_); ss_mix_shr1(z, p_, c.lvf[0]);
-        p_ += dpp0<DPP_SHR2>(p_); ss_mix_shr2(z, p_, c.lvf[1]);
-        p_ += dpp0<DPP_SHR4>(p_); ss_mix_shr4(z, p_, c.lvf[2]);
-        p_ += dpp0<DPP_SHR8>(p_); ss_mix_shr8(z, p_, c.lvf[3]);
-        p_ = __builtin_fma(c.c15, dpp0<DPP_BC15>(p_), p_); ss_mix_bc15(z, p_, c.lvf[4]);
-        p_ = __builtin_fma(c.c31, dpp0<DPP_BC31>(p_), p_); ss_mix_bc31(z, p_, c.lvf[5]);
-        S = lane_get(p_, 63);
-        const double LIp = (double)dpp0<DPP_WSHR1>(z);
-        out[0] = e[0] * __builtin_fma(c.dc[0], x[0], __builtin_fma(c.g[0], S, __builtin_fma(c.cg[0], p_, LIp)));
         return;
     }
     double lp[NPL], w[NPL];
@@ -350,32 +320,16 @@ __device__ __forceinline__ void ss_fwd_step(const SsFwdC<NPL> &c, const double (
 }
 
 // one position of the backward chain (position p = state MS-1-p):  out = T (e o b);  Sw = sum (e o b) (float accuracy)
-template <int NPL, int MIX = 0>
+template <int NPL, bool MIX = false>
 __device__ __forceinline__ void ss_bwd_step(const SsBwdC<NPL> &c, const double (&bv)[NPL], const double (&e)[NPL],
                                             double (&out)[NPL], float &Sw) {
-    if (MIX == 2 && NPL == 1) {
+    if (MIX && NPL == 1) {
         // (T w)_i = ((d_i - c0) - g_i) w_i + sum_{j <= i} g_j w_j + c0 inclW_i + b_i V_i   (lanes hold the states reversed)
         const double w0 = e[0] * bv[0];
         float v = (float)w0;
         float gs = c.gf * v, f;
         ss_x_scan_bwd(v, f, gs, Sw, c.lvf, c.c15f, c.c31f, c.m1, c.m2, c.m3, c.bff, c.c0f);
         out[0] = __builtin_fma(c.adg, w0, (double)gs);
-        return;
-    }
-    if (MIX == 1 && NPL == 1) {
-        const double w0 = e[0] * bv[0];
-        double p_ = c.g[0] * w0;
-        float z = (float)w0, f_ = (float)w0;
-        p_ += dpp0<DPP_SHR1>(p_); f_ += dpp0<DPP_SHR1>(f_); ss_mix_shr1(z, p_, c.lvf[0]);
-        p_ += dpp0<DPP_SHR2>(p_); f_ += dpp0<DPP_SHR2>(f_); ss_mix_shr2(z, p_, c.lvf[1]);
-        p_ += dpp0<DPP_SHR4>(p_); f_ += dpp0<DPP_SHR4>(f_); ss_mix_shr4(z, p_, c.lvf[2]);
-        p_ += dpp0<DPP_SHR8>(p_); f_ += dpp0<DPP_SHR8>(f_); ss_mix_shr8(z, p_, c.lvf[3]);
-        p_ = __builtin_fma(c.c15, dpp0<DPP_BC15>(p_), p_); f_ = __builtin_fmaf(c.c15f, dpp0<DPP_BC15>(f_), f_); ss_mix_bc15(z, p_, c.lvf[4]);
-        p_ = __builtin_fma(c.c31, dpp0<DPP_BC31>(p_), p_); f_ = __builtin_fmaf(c.c31f, dpp0<DPP_BC31>(f_), f_); ss_mix_bc31(z, p_, c.lvf[5]);
-        const double Gtot = lane_get(p_, 63);
-        Sw = lane_get(f_, 63);
-        const double LIp = (double)dpp0<DPP_WSHR1>(z);
-        out[0] = __builtin_fma(c.dc[0], w0, (Gtot - p_) + __builtin_fma(c.c0, (double)f_, c.b[0] * LIp));
         return;
     }
     double w[NPL], lg[NPL], u[NPL];
@@ -607,7 +561,7 @@ __device__ __forceinline__ void ss_fwd_light_rows(const SsArgs &a, const double 
 template <int NPL, bool ALLLDS>
 __device__ __forceinline__ void ss_bwd_light_rows(const SsArgs &a, const double *sE, long long base, int rhi, int rlo, int lane, float (&b)[NPL]);
 
-template <int NPL, bool RERUN, bool HYB, bool ALLLDS, int MIX = 0>
+template <int NPL, bool RERUN, bool HYB, bool ALLLDS, bool MIX = false>
 __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -830,7 +784,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     }
 }
 
-template <int NPL, bool RERUN, bool HYB, bool ALLLDS, int MIX = 0>
+template <int NPL, bool RERUN, bool HYB, bool ALLLDS, bool MIX = false>
 __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -1439,13 +1393,9 @@ __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
     const int c = task & 0x3FFFFFFF;
     if (fwd) {
         if (idle_f) return;
-        if (NPL == 1 && !HYB && a.mixed == 2) {
-            if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS, 2>(a, ss_lds, c, lane);
-            else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB, ALLLDS, 2>(a, ss_lds, c, lane);
-            else ss_forward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
-        } else if (NPL == 1 && !HYB && a.mixed == 1) {
-            if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS, 1>(a, ss_lds, c, lane);
-            else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB, ALLLDS, 1>(a, ss_lds, c, lane);
+        if (NPL == 1 && !HYB && a.mixed) {
+            if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS, true>(a, ss_lds, c, lane);
+            else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB, ALLLDS, true>(a, ss_lds, c, lane);
             else ss_forward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
         } else
         if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS>(a, ss_lds, c, lane);
@@ -1453,13 +1403,9 @@ __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
         else ss_forward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
     } else {
         if (idle_b) return;
-        if (NPL == 1 && !HYB && a.mixed == 2) {
-            if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS, 2>(a, ss_lds, c, lane);
-            else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB, ALLLDS, 2>(a, ss_lds, c, lane);
-            else ss_backward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
-        } else if (NPL == 1 && !HYB && a.mixed == 1) {
-            if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS, 1>(a, ss_lds, c, lane);
-            else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB, ALLLDS, 1>(a, ss_lds, c, lane);
+        if (NPL == 1 && !HYB && a.mixed) {
+            if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS, true>(a, ss_lds, c, lane);
+            else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB, ALLLDS, true>(a, ss_lds, c, lane);
             else ss_backward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
         } else
         if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS>(a, ss_lds, c, lane);

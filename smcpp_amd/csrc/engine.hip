@@ -2770,10 +2770,12 @@ void smcpp_im::ss_launch_initial() {
     a.changed_f = d_flags_view; a.changed_b = d_flags_view + (max_pass + 1);
     a.eps_f = eps_f; a.eps_b = eps_b; a.full_f = a.full_b = 0;
     {
-        // SMCPP_SS_MIXED=1 (opt-in until measured against the tolerances): mixed-precision scans in the stored passes; never with
-        // save_gamma - the posterior's argmax is compared index by index
-        static const int mixed_on = getenv("SMCPP_SS_MIXED") ? std::max(0, std::min(2, atoi(getenv("SMCPP_SS_MIXED")))) : 0;
-        a.mixed = (mixed_on && !save_gamma && NPL == 1 && !ss_hybrid) ? mixed_on : 0;
+        // All scans of the stored passes in float (chains_ss.hpp: ss_x_scan_fwd / ss_x_scan_bwd), the default since round 5 for one
+        // state per lane; SMCPP_SS_MIXED=0 keeps the fp64 scans (read on every E-step: tests compare the two).  Never with
+        // save_gamma - the posterior's argmax is compared index by index against the reference's.
+        const char *mx = getenv("SMCPP_SS_MIXED");
+        const bool mixed_on = !(mx && atoi(mx) == 0);
+        a.mixed = (mixed_on && !save_gamma && NPL == 1 && !ss_hybrid) ? 1 : 0;
     }
     a.fine = nullptr; a.nfine = 0; a.hand_f = a.hand_b = 0; a.fine_ends_f = nullptr; a.fine_ends_b = nullptr;
     if (ss_hybrid) {

@@ -836,10 +836,10 @@ def test_span1_statistics_one_pass_in_key_order(monkeypatch):
             np.testing.assert_allclose(g1[k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
 
 
-def test_mixed_precision_scans_opt_in(monkeypatch):
-    """SMCPP_SS_MIXED=1 (opt-in, round 4): in the stored passes only the scan whose result is differenced stays in fp64, the weighted
-    scans run in float (one fused DPP instruction per level).  Same goldens and tolerances as the default path, and against it: the
-    log-likelihood to 1e-9, the statistics to the float noise the reference's own forward chain carries."""
+def test_float_scans_of_the_stored_passes_vs_fp64_scans(monkeypatch):
+    """Round 5 default: every scan of the stored passes runs in float (the sums over the states above as native suffix scans; the
+    vector and the diagonal term stay in fp64), SMCPP_SS_MIXED=0 keeps the fp64 scans.  Same goldens and tolerances for both, and
+    against each other: the log-likelihood to 1e-9, the statistics to the float noise the reference's own forward chain carries."""
     res = {}
     names = ("G4_M64_n20_2Mbp", "G3_M32_n10_2Mbp", "G1_M16_n4", "G5_M48_twopop_layout")
     for mixed in ("0", "1"):

@@ -31,7 +31,7 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
 
 
-for ea, eb in [(2e-6, 1e-9), (2e-6, 1e-8), (2e-6, 1e-7), (2e-6, 1e-6), (5e-6, 1e-6), (1e-5, 1e-5)]:
+for ea, eb in [(2e-6, 1e-8), (2e-6, 1e-6), (2e-6, 2e-6), (2e-6, 4e-6), (4e-6, 4e-6), (2e-6, 1e-5), (1e-5, 1e-5)]:
     ll, xs, gs, ms, t = run(0, ea, eb)
     ge = max(rel(gs[k], gs0[k]) for k in gs0)
     print(f"eps_a={ea:g} eps_b={eb:g}: {ms:.2f} ms  fwd {t['forward_ms']:.2f} ({t['fwd_passes']:.0f}) bwd {t['backward_ms']:.2f} "

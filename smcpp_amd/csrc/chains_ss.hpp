@@ -212,9 +212,31 @@ __device__ __forceinline__ void ss_load_bwd(const SsArgs &a, int lane, SsBwdC<NP
 #define SS_D_ " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 // forward: z = weighted prefix scan (level multipliers lv), s = inclusive suffix sum.  On return zp = bg * s + c0 * total + (z of
 // the lane below), tot = s of lane 0 (the total).
+// H32 (M <= 32: the live states fill two 16-lane rows - lanes 0..31 forward, 32..63 backward): one cross-row level instead of two
+// and one row total instead of three.
+template <bool H32>
 __device__ __forceinline__ void ss_x_scan_fwd(float &z, float &s, float &zp, float &tot, const float (&lv)[6], float m1, float m2,
                                               float m3, float bg, float c0) {
     float t1, t2, t3;
+    if (H32) {
+        asm volatile("s_nop 1\n"
+                     "v_add_f32_dpp %1, %1, %1 row_shl:1" SS_D_ "v_fmac_f32_dpp %0, %0, %5 row_shr:1" SS_D_ "s_nop 0\n"
+                     "v_add_f32_dpp %1, %1, %1 row_shl:2" SS_D_ "v_fmac_f32_dpp %0, %0, %6 row_shr:2" SS_D_ "s_nop 0\n"
+                     "v_add_f32_dpp %1, %1, %1 row_shl:4" SS_D_ "v_fmac_f32_dpp %0, %0, %7 row_shr:4" SS_D_ "s_nop 0\n"
+                     "v_add_f32_dpp %1, %1, %1 row_shl:8" SS_D_ "v_fmac_f32_dpp %0, %0, %8 row_shr:8" SS_D_
+                     "v_readlane_b32 %4, %1, 16\n"
+                     "s_nop 0\n"
+                     "v_fmac_f32_dpp %0, %0, %9 row_bcast:15" SS_D_
+                     "v_fmac_f32_e32 %1, %4, %10\n"
+                     "s_nop 0\n"
+                     "v_readlane_b32 %3, %1, 0\n"
+                     "v_mov_b32_dpp %2, %0 wave_shr:1" SS_D_
+                     "v_fmac_f32_e32 %2, %11, %1\n"
+                     "v_fmac_f32_e32 %2, %3, %12\n"
+                     : "+v"(z), "+v"(s), "=&v"(zp), "=&s"(tot), "=&s"(t1)
+                     : "v"(lv[0]), "v"(lv[1]), "v"(lv[2]), "v"(lv[3]), "v"(lv[4]), "v"(m1), "v"(bg), "v"(c0));
+        return;
+    }
     asm volatile("s_nop 1\n"
                  "v_add_f32_dpp %1, %1, %1 row_shl:1" SS_D_ "v_fmac_f32_dpp %0, %0, %7 row_shr:1" SS_D_ "s_nop 0\n"
                  "v_add_f32_dpp %1, %1, %1 row_shl:2" SS_D_ "v_fmac_f32_dpp %0, %0, %8 row_shr:2" SS_D_ "s_nop 0\n"
@@ -238,10 +260,29 @@ __device__ __forceinline__ void ss_x_scan_fwd(float &z, float &s, float &zp, flo
 }
 // backward (reversed lanes): v = weighted prefix scan, f = plain prefix sum, gs = inclusive suffix sum of g o w.  On return
 // gs += c0 * f + b * (v of the lane below), tot = f of lane 63 (the total).
+template <bool H32>
 __device__ __forceinline__ void ss_x_scan_bwd(float &v, float &f, float &gs, float &tot, const float (&lv)[6], float c15, float c31,
                                               float m1, float m2, float m3, float b, float c0) {
     float t1, t2, t3, vp;
     // (f is an OUTPUT: its first level reads v before v's own first level rewrites it - no copy of the input)
+    if (H32) {
+        asm volatile("s_nop 1\n"
+                     "v_add_f32_dpp %1, %0, %0 row_shr:1" SS_D_ "v_add_f32_dpp %2, %2, %2 row_shl:1" SS_D_ "v_fmac_f32_dpp %0, %0, %6 row_shr:1" SS_D_
+                     "v_add_f32_dpp %1, %1, %1 row_shr:2" SS_D_ "v_add_f32_dpp %2, %2, %2 row_shl:2" SS_D_ "v_fmac_f32_dpp %0, %0, %7 row_shr:2" SS_D_
+                     "v_add_f32_dpp %1, %1, %1 row_shr:4" SS_D_ "v_add_f32_dpp %2, %2, %2 row_shl:4" SS_D_ "v_fmac_f32_dpp %0, %0, %8 row_shr:4" SS_D_
+                     "v_add_f32_dpp %1, %1, %1 row_shr:8" SS_D_ "v_add_f32_dpp %2, %2, %2 row_shl:8" SS_D_ "v_fmac_f32_dpp %0, %0, %9 row_shr:8" SS_D_
+                     "v_readlane_b32 %5, %2, 48\n"
+                     "v_fmac_f32_dpp %1, %1, %11 row_bcast:15" SS_D_
+                     "v_fmac_f32_dpp %0, %0, %10 row_bcast:15" SS_D_
+                     "v_fmac_f32_e32 %2, %5, %12\n"
+                     "v_readlane_b32 %3, %1, 63\n"
+                     "v_mov_b32_dpp %4, %0 wave_shr:1" SS_D_
+                     "v_fmac_f32_e32 %2, %14, %1\n"
+                     "v_fmac_f32_e32 %2, %13, %4\n"
+                     : "+v"(v), "=&v"(f), "+v"(gs), "=&s"(tot), "=&v"(vp), "=&s"(t3)
+                     : "v"(lv[0]), "v"(lv[1]), "v"(lv[2]), "v"(lv[3]), "v"(lv[4]), "v"(c15), "v"(m3), "v"(b), "v"(c0));
+        return;
+    }
     asm volatile("s_nop 1\n"
                  "v_add_f32_dpp %1, %0, %0 row_shr:1" SS_D_ "v_add_f32_dpp %2, %2, %2 row_shl:1" SS_D_ "v_fmac_f32_dpp %0, %0, %8 row_shr:1" SS_D_
                  "v_add_f32_dpp %1, %1, %1 row_shr:2" SS_D_ "v_add_f32_dpp %2, %2, %2 row_shl:2" SS_D_ "v_fmac_f32_dpp %0, %0, %9 row_shr:2" SS_D_
@@ -272,14 +313,14 @@ __device__ __forceinline__ void ss_x_scan_bwd(float &v, float &f, float &gs, flo
 // one position of the forward chain:  out = e o (T^T x);  S = sum x
 // MIX (one state per lane; the full and re-run passes of an E-step without save_gamma): every scan in float, the sums over the
 // states above as native suffix scans (ss_x_scan_fwd / ss_x_scan_bwd above); the vector and the diagonal term stay in fp64.
-template <int NPL, bool MIX = false>
+template <int NPL, bool MIX = false, bool H32 = false>
 __device__ __forceinline__ void ss_fwd_step(const SsFwdC<NPL> &c, const double (&x)[NPL], const double (&e)[NPL],
                                             double (&out)[NPL], double &S) {
     if (MIX && NPL == 1) {
         // (T^T x)_j = (d_j - g_j) x_j + (g_j - c0) sum_{i >= j} x_i + c0 S + Z_j
         float s = (float)x[0];
         float z = c.bff * s, zp, tot;
-        ss_x_scan_fwd(z, s, zp, tot, c.lvf, c.m1, c.m2, c.m3, c.bgf, c.c0f);
+        ss_x_scan_fwd<H32>(z, s, zp, tot, c.lvf, c.m1, c.m2, c.m3, c.bgf, c.c0f);
         S = (double)tot;
         out[0] = e[0] * __builtin_fma(c.adg, x[0], (double)zp);
         return;
@@ -320,7 +361,7 @@ __device__ __forceinline__ void ss_fwd_step(const SsFwdC<NPL> &c, const double (
 }
 
 // one position of the backward chain (position p = state MS-1-p):  out = T (e o b);  Sw = sum (e o b) (float accuracy)
-template <int NPL, bool MIX = false>
+template <int NPL, bool MIX = false, bool H32 = false>
 __device__ __forceinline__ void ss_bwd_step(const SsBwdC<NPL> &c, const double (&bv)[NPL], const double (&e)[NPL],
                                             double (&out)[NPL], float &Sw) {
     if (MIX && NPL == 1) {
@@ -328,7 +369,7 @@ __device__ __forceinline__ void ss_bwd_step(const SsBwdC<NPL> &c, const double (
         const double w0 = e[0] * bv[0];
         float v = (float)w0;
         float gs = c.gf * v, f;
-        ss_x_scan_bwd(v, f, gs, Sw, c.lvf, c.c15f, c.c31f, c.m1, c.m2, c.m3, c.bff, c.c0f);
+        ss_x_scan_bwd<H32>(v, f, gs, Sw, c.lvf, c.c15f, c.c31f, c.m1, c.m2, c.m3, c.bff, c.c0f);
         out[0] = __builtin_fma(c.adg, w0, (double)gs);
         return;
     }
@@ -561,7 +602,7 @@ __device__ __forceinline__ void ss_fwd_light_rows(const SsArgs &a, const double 
 template <int NPL, bool ALLLDS>
 __device__ __forceinline__ void ss_bwd_light_rows(const SsArgs &a, const double *sE, long long base, int rhi, int rlo, int lane, float (&b)[NPL]);
 
-template <int NPL, bool RERUN, bool HYB, bool ALLLDS, bool MIX = false>
+template <int NPL, bool RERUN, bool HYB, bool ALLLDS, bool MIX = false, bool H32 = false>
 __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -641,6 +682,16 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     ss_desc_settle(dcur); ss_desc_settle(dnxt);
     float *arow = a.alpha + (size_t)(ch.base + rbeg) * Mp;     // row ell - 1 of iteration j is arow + j Mp
     double *crow = a.cnorm + ch.base + rbeg;
+    // MIX: the row's address advances by Mp floats per iteration (a 64-bit multiply per row otherwise), and the normalisers - float
+    // totals there - are collected one per lane and stored 64 rows at a time instead of through a one-lane store per row
+    float *ap[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) ap[k] = arow + st[k];
+    int cacc = 0;                                  // bit patterns of the normalisers of rows (j & ~63) + lane
+    auto cflush = [&](int jhi) {                   // store the collected normalisers of the 64-row block that holds row jhi, rows <= jhi
+        const int jj = (jhi & ~63) + lane;
+        if (jj <= jhi && jj > jst && jj > 0) crow[jj] = (double)__builtin_bit_cast(float, cacc);
+    };
     double e[NPL];
     ss_emission<NPL, false, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
     constexpr bool hyb = HYB && NPL == 1;
@@ -664,6 +715,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
         npos += span;
         // descriptor / emission vector of the next row
         if (jl == 63) { dcur = dnxt; dnxt = rd[j + 65 + lane]; ss_desc_settle(dnxt); }
+        if (MIX && jl == 0 && j > 0) cflush(j - 1);
         const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
         double en[NPL];
         ss_emission<NPL, false, ALLLDS>(a, sE, slot_n, lane, en);
@@ -694,8 +746,13 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
         }
         // first position of the row: the sum of the incoming vector finishes the PREVIOUS row
         double y[NPL], S;
-        ss_fwd_step<NPL, MIX>(cst, x, e, y, S);
-        const double inv = rcp_f64(S);
+        ss_fwd_step<NPL, MIX, MIX && H32>(cst, x, e, y, S);
+        double inv;
+        if (MIX) {
+            // S is a float total: its float reciprocal and ONE Newton step give 1 / S to 1e-14 (the stored normaliser is S itself)
+            const double r0 = (double)__builtin_amdgcn_rcpf((float)S);
+            inv = __builtin_fma(__builtin_fma(-S, r0, 1.0), r0, r0);
+        } else inv = rcp_f64(S);
         // The reference continues from the STORED vector: normalised, rounded to float, floored at 1e-10 (hmm.cpp:80-94).  That
         // feedback is not noise for small entries (a state whose alpha falls under the floor after a heterozygous row re-enters
         // the next row with 1e-10 instead: 1e-5 on the statistics of the most recent states), so it is reproduced: the operator
@@ -717,15 +774,21 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
 #pragma unroll
                 for (int k = 0; k < NPL; ++k)
                     if (live[k]) {
-                        const float old = arow[(size_t)j * Mp + st[k]];
+                        const float old = MIX ? *ap[k] : arow[(size_t)j * Mp + st[k]];
                         if (!(fabsf(an[k] - old) <= a.eps_f * fabsf(old))) bad = true;
                     }
-                if (!__any(bad)) { merged = true; break; }
+                if (!__any(bad)) { merged = true; if (MIX) cflush(j - 1); break; }
             }
             if (j > jst) {
+                if (MIX) {
 #pragma unroll
-                for (int k = 0; k < NPL; ++k) if (stor[k]) arow[(size_t)j * Mp + st[k]] = an[k];
-                if (lane == 0) crow[j] = S;
+                    for (int k = 0; k < NPL; ++k) if (stor[k]) *ap[k] = an[k];
+                    cacc = lane == jl ? __builtin_bit_cast(int, (float)S) : cacc;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) if (stor[k]) arow[(size_t)j * Mp + st[k]] = an[k];
+                    if (lane == 0) crow[j] = S;
+                }
             } else if (j == jst) {
                 // (halo only: row r0 belongs to the neighbour; what this chunk starts from is what the certificate compares)
 #pragma unroll
@@ -744,22 +807,27 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
             double S2;
             int t = 1;
             for (; t + 1 < span; t += 2) {
-                ss_fwd_step<NPL, MIX>(cst, x, e, y, S2);
+                ss_fwd_step<NPL, MIX, MIX && H32>(cst, x, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) x[k] = y[k];
-                ss_fwd_step<NPL, MIX>(cst, x, e, y, S2);
+                ss_fwd_step<NPL, MIX, MIX && H32>(cst, x, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) x[k] = y[k];
             }
             if (t < span) {
-                ss_fwd_step<NPL, MIX>(cst, x, e, y, S2);
+                ss_fwd_step<NPL, MIX, MIX && H32>(cst, x, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) x[k] = y[k];
             }
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) e[k] = en[k];
+        if (MIX) {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) ap[k] += Mp;
+        }
     }
+    if (MIX && !merged && nrows > 0) cflush(nrows - 1);
     if (a.dbg && !RERUN && c == 1 && lane == 0) {
         a.dbg[0] = __builtin_readcyclecounter() - t0c; a.dbg[1] = __builtin_amdgcn_s_memrealtime() - t0r;
         a.dbg[2] = npos; a.dbg[3] = nrows;
@@ -784,7 +852,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     }
 }
 
-template <int NPL, bool RERUN, bool HYB, bool ALLLDS, bool MIX = false>
+template <int NPL, bool RERUN, bool HYB, bool ALLLDS, bool MIX = false, bool H32 = false>
 __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -850,6 +918,9 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
     int2 dcur = rd[-lane], dnxt = rd[-64 - lane];
     ss_desc_settle(dcur); ss_desc_settle(dnxt);
     double *brow = a.beta + (size_t)(ch.base + rend) * Mp;      // row ell of iteration j is brow - j Mp
+    double *bp[NPL];                                            // MIX: the same address, stepped by -Mp per iteration
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) bp[k] = brow + st[k];
     double e[NPL];
     ss_emission<NPL, true, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
     constexpr bool hyb = HYB && NPL == 1;
@@ -881,7 +952,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
 #pragma unroll
             for (int k = 0; k < NPL; ++k)
                 if (live[k]) {
-                    const double old = brow[-(ptrdiff_t)j * Mp + st[k]];
+                    const double old = MIX ? *bp[k] : brow[-(ptrdiff_t)j * Mp + st[k]];
                     if (!(fabs(b[k] - old) <= a.eps_b * fabs(old))) bad = true;
                 }
             if (!__any(bad)) { merged = true; break; }
@@ -900,7 +971,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
         }
         if (j >= jst) {
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) if (stor[k]) brow[-(ptrdiff_t)j * Mp + st[k]] = b[k];
+            for (int k = 0; k < NPL; ++k) if (stor[k]) { if (MIX) *bp[k] = b[k]; else brow[-(ptrdiff_t)j * Mp + st[k]] = b[k]; }
         }
         if (hyb && span > a.hyb_th) {
             // ---- hybrid row: b <- P^-T (d~^s o (P^T b)), renormalised (every consumer of beta is scale free) ----
@@ -914,7 +985,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
         }
         double y[NPL];
         float Sw;
-        ss_bwd_step<NPL, MIX>(cst, b, e, y, Sw);
+        ss_bwd_step<NPL, MIX, MIX && H32>(cst, b, e, y, Sw);
         const double inv = (double)__builtin_amdgcn_rcpf(Sw);
 #pragma unroll
         for (int k = 0; k < NPL; ++k) b[k] = y[k] * inv;
@@ -923,21 +994,25 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
             float S2;
             int t = 1;
             for (; t + 1 < span; t += 2) {
-                ss_bwd_step<NPL, MIX>(cst, b, e, y, S2);
+                ss_bwd_step<NPL, MIX, MIX && H32>(cst, b, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) b[k] = y[k];
-                ss_bwd_step<NPL, MIX>(cst, b, e, y, S2);
+                ss_bwd_step<NPL, MIX, MIX && H32>(cst, b, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) b[k] = y[k];
             }
             if (t < span) {
-                ss_bwd_step<NPL, MIX>(cst, b, e, y, S2);
+                ss_bwd_step<NPL, MIX, MIX && H32>(cst, b, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) b[k] = y[k];
             }
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) e[k] = en[k];
+        if (MIX) {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) bp[k] -= Mp;
+        }
     }
     if (a.dbg && !RERUN && c == 1 && lane == 0) {
         a.dbg[4] = __builtin_readcyclecounter() - t0c; a.dbg[5] = __builtin_amdgcn_s_memrealtime() - t0r;
@@ -1004,7 +1079,19 @@ __device__ __forceinline__ void ss_load_light(const SsArgs &a, int lane, SsLight
 // states after the VALU write: three interleaved chains provide them, two chains take one s_nop per level.
 // tools/dpp_lab.hip: every one of these instructions issues in 5.3 clocks, as a plain v_add_f32 does.
 #define SS_DPP_ "row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+template <bool H32>
 __device__ __forceinline__ void ss_light_scan2(float &p, float &z, const float (&lv)[6], float c15, float c31) {
+    if (H32) {        // M <= 32: the live states fill two rows - no row_bcast:31 level
+        asm volatile("s_nop 1\n"
+                     "v_add_f32_dpp %0, %0, %0 row_shr:1 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %2 row_shr:1 " SS_DPP_ "s_nop 0\n"
+                     "v_add_f32_dpp %0, %0, %0 row_shr:2 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %3 row_shr:2 " SS_DPP_ "s_nop 0\n"
+                     "v_add_f32_dpp %0, %0, %0 row_shr:4 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %4 row_shr:4 " SS_DPP_ "s_nop 0\n"
+                     "v_add_f32_dpp %0, %0, %0 row_shr:8 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %5 row_shr:8 " SS_DPP_ "s_nop 0\n"
+                     "v_fmac_f32_dpp %0, %0, %7 row_bcast:15 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %6 row_bcast:15 " SS_DPP_ "s_nop 1\n"
+                     : "+v"(p), "+v"(z)
+                     : "v"(lv[0]), "v"(lv[1]), "v"(lv[2]), "v"(lv[3]), "v"(lv[4]), "v"(c15));
+        return;
+    }
     asm volatile("s_nop 1\n"
                  "v_add_f32_dpp %0, %0, %0 row_shr:1 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %2 row_shr:1 " SS_DPP_ "s_nop 0\n"
                  "v_add_f32_dpp %0, %0, %0 row_shr:2 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %3 row_shr:2 " SS_DPP_ "s_nop 0\n"
@@ -1015,7 +1102,19 @@ __device__ __forceinline__ void ss_light_scan2(float &p, float &z, const float (
                  : "+v"(p), "+v"(z)
                  : "v"(lv[0]), "v"(lv[1]), "v"(lv[2]), "v"(lv[3]), "v"(lv[4]), "v"(lv[5]), "v"(c15), "v"(c31));
 }
+template <bool H32>
 __device__ __forceinline__ void ss_light_scan3(float &p, float &z, float &f, const float (&lv)[6], float c15, float c31) {
+    if (H32) {
+        asm volatile("s_nop 1\n"
+                     "v_add_f32_dpp %0, %0, %0 row_shr:1 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %3 row_shr:1 " SS_DPP_ "v_add_f32_dpp %2, %2, %2 row_shr:1 " SS_DPP_
+                     "v_add_f32_dpp %0, %0, %0 row_shr:2 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %4 row_shr:2 " SS_DPP_ "v_add_f32_dpp %2, %2, %2 row_shr:2 " SS_DPP_
+                     "v_add_f32_dpp %0, %0, %0 row_shr:4 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %5 row_shr:4 " SS_DPP_ "v_add_f32_dpp %2, %2, %2 row_shr:4 " SS_DPP_
+                     "v_add_f32_dpp %0, %0, %0 row_shr:8 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %6 row_shr:8 " SS_DPP_ "v_add_f32_dpp %2, %2, %2 row_shr:8 " SS_DPP_
+                     "v_fmac_f32_dpp %0, %0, %8 row_bcast:15 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %7 row_bcast:15 " SS_DPP_ "v_fmac_f32_dpp %2, %2, %8 row_bcast:15 " SS_DPP_ "s_nop 1\n"
+                     : "+v"(p), "+v"(z), "+v"(f)
+                     : "v"(lv[0]), "v"(lv[1]), "v"(lv[2]), "v"(lv[3]), "v"(lv[4]), "v"(c15));
+        return;
+    }
     asm volatile("s_nop 1\n"
                  "v_add_f32_dpp %0, %0, %0 row_shr:1 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %3 row_shr:1 " SS_DPP_ "v_add_f32_dpp %2, %2, %2 row_shr:1 " SS_DPP_
                  "v_add_f32_dpp %0, %0, %0 row_shr:2 " SS_DPP_ "v_fmac_f32_dpp %1, %1, %4 row_shr:2 " SS_DPP_ "v_add_f32_dpp %2, %2, %2 row_shr:2 " SS_DPP_
@@ -1028,7 +1127,7 @@ __device__ __forceinline__ void ss_light_scan3(float &p, float &z, float &f, con
 }
 #undef SS_DPP_
 
-template <int NPL>
+template <int NPL, bool H32 = false>
 __device__ __forceinline__ void ss_fwd_step_f(const SsLightC<NPL> &c, const float (&x)[NPL], const float (&e)[NPL],
                                               float (&out)[NPL], float &S) {
     float lp[NPL], w[NPL];
@@ -1040,8 +1139,8 @@ __device__ __forceinline__ void ss_fwd_step_f(const SsLightC<NPL> &c, const floa
         w[k] = __builtin_fmaf(c.a[k], w[k - 1], c.b[k] * x[k]);
     }
     float p_ = lp[NPL - 1], z_ = w[NPL - 1];
-    ss_light_scan2(p_, z_, c.lv, c.c15, c.c31);
-    S = lane_get(p_, 63);
+    ss_light_scan2<H32>(p_, z_, c.lv, c.c15, c.c31);
+    S = lane_get(p_, H32 ? 31 : 63);              // (H32: the live states end at lane 31, the rows above never receive their sum)
     const float LIp = dpp0<DPP_WSHR1>(z_);
     if (NPL == 1) {
         out[0] = e[0] * __builtin_fmaf(c.dc[0], x[0], __builtin_fmaf(c.g[0], S, __builtin_fmaf(c.cg[0], p_, LIp)));
@@ -1056,7 +1155,7 @@ __device__ __forceinline__ void ss_fwd_step_f(const SsLightC<NPL> &c, const floa
     }
 }
 
-template <int NPL>
+template <int NPL, bool H32 = false>
 __device__ __forceinline__ void ss_bwd_step_f(const SsLightC<NPL> &c, const float (&bv)[NPL], const float (&e)[NPL],
                                               float (&out)[NPL], float &Sw) {
     float w[NPL], lg[NPL], u[NPL], lf[NPL];
@@ -1072,7 +1171,7 @@ __device__ __forceinline__ void ss_bwd_step_f(const SsLightC<NPL> &c, const floa
         lf[k] = lf[k - 1] + w[k];
     }
     float p_ = lg[NPL - 1], z_ = u[NPL - 1], f_ = lf[NPL - 1];
-    ss_light_scan3(p_, z_, f_, c.lv, c.c15, c.c31);
+    ss_light_scan3<H32>(p_, z_, f_, c.lv, c.c15, c.c31);
     const float Gtot = lane_get(p_, 63);
     Sw = lane_get(f_, 63);
     const float LIp = dpp0<DPP_WSHR1>(z_);
@@ -1185,7 +1284,7 @@ __device__ __forceinline__ void ss_bwd_light_rows(const SsArgs &a, const double 
     }
 }
 
-template <int NPL, bool ALLLDS>
+template <int NPL, bool ALLLDS, bool H32 = false>
 __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *sE, int c, int lane) {
     const int M = a.M, Mp = a.Mp, pass = a.pass;
     const Chunk ch = ss_uniform_chunk(a.chunks[c]);
@@ -1220,7 +1319,7 @@ __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *
         const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
         float en[NPL], y[NPL], S;
         ss_emission_f<NPL, false, ALLLDS>(a, sE, slot_n, lane, en);
-        ss_fwd_step_f<NPL>(cst, x, e, y, S);
+        ss_fwd_step_f<NPL, H32>(cst, x, e, y, S);
         const float inv = __builtin_amdgcn_rcpf(S);
 #pragma unroll
         for (int k = 0; k < NPL; ++k) x[k] = y[k] * inv;
@@ -1229,15 +1328,15 @@ __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *
             float S2;
             int t = 1;
             for (; t + 1 < span; t += 2) {
-                ss_fwd_step_f<NPL>(cst, x, e, y, S2);
+                ss_fwd_step_f<NPL, H32>(cst, x, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) x[k] = y[k];
-                ss_fwd_step_f<NPL>(cst, x, e, y, S2);
+                ss_fwd_step_f<NPL, H32>(cst, x, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) x[k] = y[k];
             }
             if (t < span) {
-                ss_fwd_step_f<NPL>(cst, x, e, y, S2);
+                ss_fwd_step_f<NPL, H32>(cst, x, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) x[k] = y[k];
             }
@@ -1265,7 +1364,7 @@ __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *
     for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = live[k] ? fmaxf(x[k] * inv, 1e-10f) : 0.f;
 }
 
-template <int NPL, bool ALLLDS>
+template <int NPL, bool ALLLDS, bool H32 = false>
 __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double *sE, int c, int lane) {
     constexpr int MS = 64 * NPL;
     const int M = a.M, Mp = a.Mp, pass = a.pass;
@@ -1302,7 +1401,7 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
         const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
         float en[NPL], y[NPL], Sw;
         ss_emission_f<NPL, true, ALLLDS>(a, sE, slot_n, lane, en);
-        ss_bwd_step_f<NPL>(cst, b, e, y, Sw);
+        ss_bwd_step_f<NPL, H32>(cst, b, e, y, Sw);
         const float inv = __builtin_amdgcn_rcpf(Sw);
 #pragma unroll
         for (int k = 0; k < NPL; ++k) b[k] = y[k] * inv;
@@ -1311,15 +1410,15 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
             float S2;
             int t = 1;
             for (; t + 1 < span; t += 2) {
-                ss_bwd_step_f<NPL>(cst, b, e, y, S2);
+                ss_bwd_step_f<NPL, H32>(cst, b, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) b[k] = y[k];
-                ss_bwd_step_f<NPL>(cst, b, e, y, S2);
+                ss_bwd_step_f<NPL, H32>(cst, b, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) b[k] = y[k];
             }
             if (t < span) {
-                ss_bwd_step_f<NPL>(cst, b, e, y, S2);
+                ss_bwd_step_f<NPL, H32>(cst, b, e, y, S2);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) b[k] = y[k];
             }
@@ -1349,7 +1448,8 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
 // One workgroup = 4 wavefronts = chunks 2 blk, 2 blk + 1 forward (wavefronts 0, 1) and backward (wavefronts 2, 3); they share
 // one LDS copy of the emission vectors of the `nlds` most frequent keys.
 // (the hybrid instantiation may run 8 wavefronts per workgroup - two per SIMD behind ONE copy of the eigenvector tables)
-template <int NPL, bool HYB, bool ALLLDS>
+// H32: M <= 32, one state per lane - the scans of the light passes and of the all-float stored passes skip their widest level
+template <int NPL, bool HYB, bool ALLLDS, bool H32 = false>
 __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
     constexpr int MS = 64 * NPL;
     extern __shared__ __attribute__((aligned(16))) double ss_lds[];
@@ -1394,23 +1494,23 @@ __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
     if (fwd) {
         if (idle_f) return;
         if (NPL == 1 && !HYB && a.mixed) {
-            if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS, true>(a, ss_lds, c, lane);
-            else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB, ALLLDS, true>(a, ss_lds, c, lane);
-            else ss_forward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
+            if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS, true, H32>(a, ss_lds, c, lane);
+            else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB, ALLLDS, true, H32>(a, ss_lds, c, lane);
+            else ss_forward_light<NPL, ALLLDS, H32>(a, ss_lds, c, lane);
         } else
         if (a.mode_f == 0) ss_forward_wave<NPL, false, HYB, ALLLDS>(a, ss_lds, c, lane);
         else if (a.mode_f == 1) ss_forward_wave<NPL, true, HYB, ALLLDS>(a, ss_lds, c, lane);
-        else ss_forward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
+        else ss_forward_light<NPL, ALLLDS, H32>(a, ss_lds, c, lane);
     } else {
         if (idle_b) return;
         if (NPL == 1 && !HYB && a.mixed) {
-            if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS, true>(a, ss_lds, c, lane);
-            else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB, ALLLDS, true>(a, ss_lds, c, lane);
-            else ss_backward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
+            if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS, true, H32>(a, ss_lds, c, lane);
+            else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB, ALLLDS, true, H32>(a, ss_lds, c, lane);
+            else ss_backward_light<NPL, ALLLDS, H32>(a, ss_lds, c, lane);
         } else
         if (a.mode_b == 0) ss_backward_wave<NPL, false, HYB, ALLLDS>(a, ss_lds, c, lane);
         else if (a.mode_b == 1) ss_backward_wave<NPL, true, HYB, ALLLDS>(a, ss_lds, c, lane);
-        else ss_backward_light<NPL, ALLLDS>(a, ss_lds, c, lane);
+        else ss_backward_light<NPL, ALLLDS, H32>(a, ss_lds, c, lane);
     }
 }
 

@@ -2618,19 +2618,22 @@ bool smcpp_im::ss_extract_generators() {
     return true;
 }
 
-template <int NPL_, bool HYB_, bool ALL_>
+template <int NPL_, bool HYB_, bool ALL_, bool H32_ = false>
 static void launch_chain_ss_tt(const SsArgs &a, int ntasks, size_t shm, hipStream_t s, int wgw) {
     static bool once = false;
     if (!once) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss<NPL_, HYB_, ALL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss<NPL_, HYB_, ALL_, H32_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         once = true;
     }
-    hipLaunchKernelGGL((k_chain_ss<NPL_, HYB_, ALL_>), dim3(ntasks / wgw), dim3(64 * wgw), shm, s, a);
+    hipLaunchKernelGGL((k_chain_ss<NPL_, HYB_, ALL_, H32_>), dim3(ntasks / wgw), dim3(64 * wgw), shm, s, a);
 }
 template <int NPL_, bool HYB_>
 static void launch_chain_ss_t(const SsArgs &a, int ntasks, size_t shm, hipStream_t s, int wgw) {
     // every key slot in LDS (the usual case): the instantiation without the global path of the emission vectors
-    if (a.K <= a.nlds) launch_chain_ss_tt<NPL_, HYB_, true>(a, ntasks, shm, s, wgw);
+    // (M <= 32 with one state per lane: the instantiation whose scans skip the level that would only move zeros)
+    static const bool h32_off = getenv("SMCPP_SS_H32") && atoi(getenv("SMCPP_SS_H32")) == 0;
+    if (NPL_ == 1 && !HYB_ && a.K <= a.nlds && a.Mp <= 32 && !h32_off) launch_chain_ss_tt<NPL_, HYB_, true, NPL_ == 1 && !HYB_>(a, ntasks, shm, s, wgw);
+    else if (a.K <= a.nlds) launch_chain_ss_tt<NPL_, HYB_, true>(a, ntasks, shm, s, wgw);
     else launch_chain_ss_tt<NPL_, HYB_, false>(a, ntasks, shm, s, wgw);
 }
 static void launch_chain_ss(int npl, const SsArgs &a, int ntasks, size_t shm, hipStream_t s, int wgw = 4) {

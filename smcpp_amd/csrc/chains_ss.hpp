@@ -53,6 +53,9 @@ struct SsArgs {
                                 // test, no merge exit, the contig's first / last chunk included): the fp64 pass after light passes
     int mode_f, mode_b;         // per direction: 0 = first pass (from pi / uniform, stores), 1 = re-run pass, 2 = light pass (float,
                                 // store-free: only the chunk's end vector is produced - history for the passes that follow)
+    int nostore_f = 0, nostore_b = 0;   // the pass runs the stored passes' arithmetic but writes no row: only the chunk's end vector (the
+                                // LAST history pass of a direction: its end vectors are then exact to rounding, not to the ~1e-5 the
+                                // float light passes carry, and the stored pass that follows is not re-run)
     int halo = 0;               // first pass only: every chunk is entered through its halo (Chunk::h0 / h1) instead of from pi / uniform
     long long *dbg;             // optional [8] (SMCPP_DEBUG_CYCLES): shader-clock / 100 MHz ticks / positions of chunk 1, pass 0
     // light passes on COARSE chunks handing over to the four-chains-per-wavefront kernels (chains_ss4.hpp): a coarse chunk is
@@ -669,7 +672,8 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
         for (int k = 0; k < NPL; ++k) if (stor[k]) a.used_f[(size_t)c * Mp + st[k]] = (float)x[k];
     }
     if (lane == 0) a.changed_f[pass] = 1;
-    if (ch.first) {
+    const bool nost = a.nostore_f != 0;
+    if (ch.first && !nost) {
 #pragma unroll
         for (int k = 0; k < NPL; ++k) if (stor[k]) a.alpha[(size_t)ch.base * Mp + st[k]] = (float)x[k];
         if (lane == 0) a.cnorm[ch.base] = 1.0;
@@ -690,7 +694,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     int cacc = 0;                                  // bit patterns of the normalisers of rows (j & ~63) + lane
     auto cflush = [&](int jhi) {                   // store the collected normalisers of the 64-row block that holds row jhi, rows <= jhi
         const int jj = (jhi & ~63) + lane;
-        if (jj <= jhi && jj > jst && jj > 0) crow[jj] = (double)__builtin_bit_cast(float, cacc);
+        if (!nost && jj <= jhi && jj > jst && jj > 0) crow[jj] = (double)__builtin_bit_cast(float, cacc);
     };
     double e[NPL];
     ss_emission<NPL, false, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
@@ -779,7 +783,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
                     }
                 if (!__any(bad)) { merged = true; if (MIX) cflush(j - 1); break; }
             }
-            if (j > jst) {
+            if (j > jst && !nost) {
                 if (MIX) {
 #pragma unroll
                     for (int k = 0; k < NPL; ++k) if (stor[k]) *ap[k] = an[k];
@@ -789,7 +793,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
                     for (int k = 0; k < NPL; ++k) if (stor[k]) arow[(size_t)j * Mp + st[k]] = an[k];
                     if (lane == 0) crow[j] = S;
                 }
-            } else if (j == jst) {
+            } else if (j == jst && !nost) {
                 // (halo only: row r0 belongs to the neighbour; what this chunk starts from is what the certificate compares)
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) if (stor[k]) a.used_f[(size_t)c * Mp + st[k]] = an[k];
@@ -846,9 +850,9 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             const float an = live[k] ? fmaxf((float)(x[k] * inv), 1e-10f) : 0.f;
-            if (stor[k]) { a.alpha[(size_t)(ch.base + ch.r1) * Mp + st[k]] = an; end_cur[st[k]] = an; }
+            if (stor[k]) { if (!nost) a.alpha[(size_t)(ch.base + ch.r1) * Mp + st[k]] = an; end_cur[st[k]] = an; }
         }
-        if (lane == 0) a.cnorm[ch.base + ch.r1] = S;
+        if (lane == 0 && !nost) a.cnorm[ch.base + ch.r1] = S;
     }
 }
 
@@ -969,7 +973,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
                 if (stor[k]) a.used_b[(size_t)c * Mp + st[k]] = b[k];
             }
         }
-        if (j >= jst) {
+        if (j >= jst && !a.nostore_b) {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) if (stor[k]) { if (MIX) *bp[k] = b[k]; else brow[-(ptrdiff_t)j * Mp + st[k]] = b[k]; }
         }
@@ -1032,7 +1036,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             const double bf = live[k] ? b[k] / S : 0.0;          // beta /= beta.sum()  (seeds gamma[:,0], hmm.cpp:150)
-            if (stor[k]) { end_cur[st[k]] = bf; if (ch.first) a.beta[(size_t)ch.base * Mp + st[k]] = bf; }
+            if (stor[k]) { end_cur[st[k]] = bf; if (ch.first && !a.nostore_b) a.beta[(size_t)ch.base * Mp + st[k]] = bf; }
         }
     }
 }

@@ -537,6 +537,7 @@ struct smcpp_im {
     int ss_launched = 0, last_ss_passes = 0;
     long long ss_positions = 0;            // sum of spans
     int ss_light_f = 0, ss_light_b = 0;    // light (float, store-free) passes per direction before the full fp64 pass
+    bool ss_acc_last = true;               // the last of them in the stored passes' arithmetic (SMCPP_SS_ACC=0: a float light pass like the others)
     // opt-in warm start of the scan chains (smcpp_set_warm_start): the first pass of an E-step starts every chunk from the boundary
     // vector the PREVIOUS converged E-step left (parity ss_warm_parity of the end-vector arrays) instead of pi / the uniform
     // vector, and one light pass fewer runs; pass indices then start at ss_pass0 (1 or 2: the parity the first pass reads)
@@ -2683,6 +2684,14 @@ void smcpp_im::ss_launch_passes(int upto) {
             ss_args.mode_b = lb ? 2 : p == 0 ? 0 : 1;
             ss_args.full_f = (p > 0 && p == ss_light_f) ? 1 : 0;
             ss_args.full_b = (p > 0 && p == ss_light_b) ? 1 : 0;
+            ss_args.nostore_f = ss_args.nostore_b = 0;
+            // The LAST history pass of a direction (all-float-scan stored passes only) runs the stored passes' own arithmetic without
+            // storing a row: its end vectors are exact to rounding instead of to the ~1e-5 the float light passes leave, so the stored
+            // pass behind it starts inside the certificate's tolerance wherever the history has converged and is not re-run.
+            if (ss_args.mixed && ss_acc_last) {
+                if (lf && p == ss_light_f - 1) { ss_args.mode_f = p == 0 ? 0 : 1; ss_args.full_f = p > 0 ? 1 : 0; ss_args.nostore_f = 1; }
+                if (lb && p == ss_light_b - 1) { ss_args.mode_b = p == 0 ? 0 : 1; ss_args.full_b = p > 0 ? 1 : 0; ss_args.nostore_b = 1; }
+            }
             launch_chain_ss(NPL, ss_args, (int)ss_tasks.size(), shm, stream, ss_wg_waves);
             continue;
         }
@@ -2820,6 +2829,7 @@ void smcpp_im::ss_launch_initial() {
         if ((ss4 ? chunks1.size() : chunks_b.size()) <= (size_t)n_contigs) ss_light_b = 0;
     }
     if (ss_hybrid) ss_light_f = ss_light_b = 0;      // (the light passes have no eigen-power step; un-binned inputs have long chunks)
+    { const char *ac = getenv("SMCPP_SS_ACC"); ss_acc_last = !(ac && atoi(ac) == 0); }
     // halo pass: the first pass enters every chunk through its halo and stores rows that are already exact; no light passes
     const bool use_halo = ss_halo && !(warm_start && ss_warm_valid) && chunks.size() > (size_t)n_contigs && chunks_b.size() > (size_t)n_contigs;
     if (use_halo) ss_light_f = ss_light_b = 0;

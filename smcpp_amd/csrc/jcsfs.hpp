@@ -13,6 +13,7 @@
 //
 // Everything is templated on the scalar so the same code yields values (double) and forward-mode Jacobians (dual).
 #pragma once
+#include <atomic>
 #include <string>
 
 #include "nonsym_eig.hpp"
@@ -122,6 +123,20 @@ public:
             Mn10 = MoranExp::modified(n1, 0, 2);
             Mn11 = MoranExp::modified(n1, 1, 2);
             Mn12 = MoranExp::modified(n1, 2, 2);
+            // tau_below_split averages  A_k diag(s0) B_k  and  A_k diag(s2) C_k  over K random times, A / B / C being matrix
+            // exponentials of Moran models: in their eigenbases only the K rank-one products of eigenvalue powers depend on the
+            // time, the sandwich  W0 = P1^-1 diag(s0) P0  (W2 likewise) depends on n1 alone - formed here, once
+            const int r = n1 + 2, c = n1 + 1;
+            W0_.assign((size_t)r * c, 0.0); W2_.assign((size_t)r * c, 0.0);
+            for (int x = 0; x < r; ++x)
+                for (int y = 0; y < c; ++y) {
+                    double w0 = 0.0, w2 = 0.0;
+                    for (int q = 0; q < c; ++q) {
+                        w0 += Mn1p1.es.Pinv[(size_t)x * r + q] * (1.0 - (double)q / (double)(n1 + 1)) * Mn10.es.P[(size_t)q * c + y];
+                        w2 += Mn1p1.es.Pinv[(size_t)x * r + q + 1] * ((double)(q + 1) / (double)(n1 + 1)) * Mn12.es.P[(size_t)q * c + y];
+                    }
+                    W0_[(size_t)x * c + y] = w0; W2_[(size_t)x * c + y] = w2;
+                }
         } else {
             Mn10 = MoranExp::modified(n1, 0, 1);
             Mn11 = MoranExp::modified(n1, 1, 1);
@@ -174,89 +189,159 @@ private:
         eMn1[1] = Mn11.expM(Rts1);
         eMn1[2].assign(eMn1[0].rbegin(), eMn1[0].rend());              // rows and columns reversed
         eMn2 = Mn2.expM(Rts2);
-        // pieces that do not depend on the hidden state, computed once (the reference recomputes them per state):
-        // the folded truncated SFS of population 2 below the split and the SFS above the split that tau_below_split uses
-        std::vector<S> r2;
-        if (n2 > 1) {
-            const RateFunctionT<S> eta2_trunc(truncate_params(params2, split), std::vector<double>{0.0, INFINITY});
-            r2 = undistinguished_sfs(csfs_of(n2 - 2, eta2_trunc)[0], n2 - 2);
-        }
-        bool any_below = false;
-        for (int m = 0; m < M; ++m) any_below = any_below || hs[m] < split;
-        if (any_below) {
-            const RateFunctionT<S> eta1_shift(shift_params(params1, split), std::vector<double>{0.0, INFINITY});
-            sfs_above_split = undistinguished_sfs(csfs_of(n1 + n2 - 1, eta1_shift)[0], n1 + n2 - 1);
-        }
-        // The two quadruple loops of the reference (jcsfs.cpp:141-160 and 181-200) sum, per hidden state, products in which only
-        // ONE factor depends on the state (the Moran averages below the split, the shifted SFS above it).  The state-independent
-        // contractions are formed once:
-        //   Cb[np1][b2]         = sum_nseg sfs_above[nseg-1] h2(np1, nseg) eMn2[nseg-np1][b2]
-        //   Da[i][nseg][b1][b2] = sum_np1  eMn1[i][np1][b1] eMn2[nseg-np1][b2] h1(np1, nseg)
-        // and every state contracts them with its own factor (all terms are non-negative: only the order of the sums changes).
+        // ONE parallel region for everything below (libomp's workers sleep between regions - every region of its own costs a
+        // wake-up that is longer than the work of a batch here):
+        //  (A) the conditioned SFS of EVERY interval below the split (truncated model of population 1) and above it (shifted model,
+        //      n1 + n2 lineages) as two batches whose hidden states are shared out over the team - the reference, and rounds 1-4 here,
+        //      built a rate function and the piece tables of the factored CSFS per hidden state (jcsfs.cpp:91-93,170-172); the
+        //      intervals are consecutive, so they are the hidden states of ONE rate function whose tables are built once;
+        //  (B) the pieces that do not depend on the hidden state (the reference recomputes them per state), one per thread: the folded
+        //      truncated SFS of population 2, the SFS above the split with its contraction Cb, the contraction Da, the below-part at
+        //      the split.  The two quadruple loops of the reference (jcsfs.cpp:141-160 and 181-200) sum, per hidden state, products
+        //      in which only ONE factor depends on the state; the state-independent contractions
+        //        Cb[np1][b2]         = sum_nseg sfs_above[nseg-1] h2(np1, nseg) eMn2[nseg-np1][b2]
+        //        Da[i][nseg][b1][b2] = sum_np1  eMn1[i][np1][b1] eMn2[nseg-np1][b2] h1(np1, nseg)
+        //      are formed once (all terms are non-negative: only the order of the sums changes);
+        //  (C) the hidden states, one task each.
         const int c1 = n1 + 1, c2 = n2 + 1;
+        bool any_below = false, any_above = false;
+        for (int m = 0; m < M; ++m) { any_below = any_below || hs[m] < split; any_above = any_above || hs[m + 1] > split; }
+        below_of.assign(M, -1); above_of.assign(M, -1);
+        std::vector<double> hb, ha;
+        for (int m = 0; m < M; ++m) {
+            const double t1 = hs[m], t2 = hs[m + 1];
+            if (t1 < split) { below_of[m] = (int)hb.size(); hb.push_back(t1); }
+            if (t2 > split) { above_of[m] = (int)ha.size(); ha.push_back(std::max(t1, split) - split); }
+        }
+        std::unique_ptr<RateFunctionT<S>> eta_trunc_all, eta_shift_all;
+        CsfsJob<S> job_b, job_a;
+        bool team_b = false, team_a = false;
+        if (!hb.empty()) {
+            hb.push_back(std::min(split, hs[M]));
+            eta_trunc_all.reset(new RateFunctionT<S>(truncate_params(params1, split), hb));
+            job_b.eta = eta_trunc_all.get();
+            team_b = job_b.factored();
+            if (team_b) job_b.init(*eta_trunc_all, *csfs_tables(n1), false);
+        }
+        if (!ha.empty()) {
+            ha.push_back(INFINITY);
+            eta_shift_all.reset(new RateFunctionT<S>(shift_params(params1, split), ha));
+            job_a.eta = eta_shift_all.get();
+            team_a = job_a.factored();
+            if (team_a) job_a.init(*eta_shift_all, *csfs_tables(n1 + n2), false);
+        }
+        eta_plain.reset(new RateFunctionT<S>(params1, std::vector<double>()));
+        std::vector<S> r2;
         Cb_.assign((size_t)(n1 + 2) * c2, S(0.0));
-        if (any_below)
-            for (int nseg = 1; nseg <= n1 + n2; ++nseg)
-                for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1 + 1); ++np1) {
-                    const S f = sfs_above_split[nseg - 1] * h2(np1, nseg);
-                    for (int b2 = 0; b2 <= n2; ++b2) Cb_[(size_t)np1 * c2 + b2] += f * eMn2[(size_t)(nseg - np1) * c2 + b2];
-                }
-        bool any_above = false;
-        for (int m = 0; m < M; ++m) any_above = any_above || hs[m + 1] > split;
         Da_.assign((size_t)3 * (n1 + n2 + 1) * c1 * c2, S(0.0));
-        if (any_above)
-            for (int i = 0; i < 3; ++i)
-                for (int nseg = 0; nseg <= n1 + n2; ++nseg)
-                    for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1); ++np1) {
-                        const double h = h1(np1, nseg);
-                        S *dst = &Da_[((size_t)i * (n1 + n2 + 1) + nseg) * c1 * c2];
-                        for (int b1 = 0; b1 <= n1; ++b1) {
-                            const S f = eMn1[i][(size_t)np1 * c1 + b1] * h;
-                            for (int b2 = 0; b2 <= n2; ++b2) dst[(size_t)b1 * c2 + b2] += f * eMn2[(size_t)(nseg - np1) * c2 + b2];
-                        }
-                    }
-        // hidden states are independent: one task each
+        trunc_all.clear(); rsfs_all.clear();
         const int nd = dual_nder();
         std::string err;
-#pragma omp parallel for schedule(dynamic)
-        for (int m = 0; m < M; ++m) {
-            DualScope sc(nd);
-            try {
-                const double t1 = hs[m], t2 = hs[m + 1];
-                if (t1 < t2 && t2 <= split) tau_below_split(m, t1, t2, S(1.0));
-                else if (split <= t1 && t1 < t2) tau_above_split(m, t1, t2, S(1.0));
-                else {
-                    const S e1 = m_exp(-eta1->R(t1));
-                    const S e2 = std::isinf(t2) ? S(0.0) : m_exp(-eta1->R(t2));
-                    const S w = (m_exp(-Rts1) - e2) / (e1 - e2);
-                    tau_below_split(m, t1, split, 1.0 - w);
-                    tau_above_split(m, split, t2, w);
-                }
-                // population 2 below the split: no distinguished lineage there, so its private branches are the folded
-                // truncated SFS
-                if (n2 == 1) at(m, 0, 0, 0, 1) += split;
-                if (n2 > 1) {
-                    S remain(0.0);
-                    for (int i = 0; i < n2 - 1; ++i) {
-                        at(m, 0, 0, 0, i + 1) += r2[i];
-                        remain += r2[i] * ((double)(i + 1) / (double)n2);
-                    }
-                    remain -= S(split);
-                    at(m, 0, 0, 0, n2) -= remain;
-                }
-            } catch (const std::exception &ex) {
+        std::atomic<bool> failed{false};
+        auto guarded = [&](auto &&fn) {
+            try { fn(); } catch (const std::exception &ex) {
+                failed = true;
 #pragma omp critical
                 err = ex.what();
             }
+        };
+#pragma omp parallel
+        {
+            DualScope sc(nd);
+            // ---- (A) ----
+            if (team_b) conditioned_sfs_team<S>(job_b);
+            if (team_a) conditioned_sfs_team<S>(job_a);
+            // ---- (B) ----
+#pragma omp sections
+            {
+#pragma omp section
+                guarded([&] {
+                    if (n2 > 1) {
+                        const RateFunctionT<S> eta2_trunc(truncate_params(params2, split), std::vector<double>{0.0, INFINITY});
+                        r2 = undistinguished_sfs(csfs_of(n2 - 2, eta2_trunc)[0], n2 - 2);
+                    }
+                });
+#pragma omp section
+                guarded([&] {
+                    if (!any_below) return;
+                    const RateFunctionT<S> eta1_shift(shift_params(params1, split), std::vector<double>{0.0, INFINITY});
+                    sfs_above_split = undistinguished_sfs(csfs_of(n1 + n2 - 1, eta1_shift)[0], n1 + n2 - 1);
+                    for (int nseg = 1; nseg <= n1 + n2; ++nseg)
+                        for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1 + 1); ++np1) {
+                            const S f = sfs_above_split[nseg - 1] * h2(np1, nseg);
+                            for (int b2 = 0; b2 <= n2; ++b2) Cb_[(size_t)np1 * c2 + b2] += f * eMn2[(size_t)(nseg - np1) * c2 + b2];
+                        }
+                });
+#pragma omp section
+                guarded([&] {
+                    if (!any_above) return;
+                    for (int i = 0; i < 3; ++i)
+                        for (int nseg = 0; nseg <= n1 + n2; ++nseg)
+                            for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1); ++np1) {
+                                const double h = h1(np1, nseg);
+                                S *dst = &Da_[((size_t)i * (n1 + n2 + 1) + nseg) * c1 * c2];
+                                for (int b1 = 0; b1 <= n1; ++b1) {
+                                    const S f = eMn1[i][(size_t)np1 * c1 + b1] * h;
+                                    for (int b2 = 0; b2 <= n2; ++b2) dst[(size_t)b1 * c2 + b2] += f * eMn2[(size_t)(nseg - np1) * c2 + b2];
+                                }
+                            }
+                });
+#pragma omp section
+                guarded([&] {
+                    if (any_above) below_at_split = csfs_of(n1, *eta1, true)[0];          // (the same for every state above the split)
+                    // (a batch whose model the factored evaluation cannot take - a zero rate - goes through the generic routine)
+                    if (!hb.empty() && !team_b) trunc_all = csfs_of(n1, *eta_trunc_all);
+                    if (!ha.empty() && !team_a) rsfs_all = csfs_of(n1 + n2, *eta_shift_all);
+                });
+            }
+#pragma omp single
+            {
+                if (team_b) trunc_all.swap(job_b.csfs);
+                if (team_a) rsfs_all.swap(job_a.csfs);
+            }
+            // ---- (C) ----
+#pragma omp for schedule(dynamic)
+            for (int m = 0; m < M; ++m) {
+                if (failed) continue;
+                try {
+                    const double t1 = hs[m], t2 = hs[m + 1];
+                    if (t1 < t2 && t2 <= split) tau_below_split(m, t1, t2, S(1.0));
+                    else if (split <= t1 && t1 < t2) tau_above_split(m, t1, t2, S(1.0));
+                    else {
+                        const S e1 = m_exp(-eta1->R(t1));
+                        const S e2 = std::isinf(t2) ? S(0.0) : m_exp(-eta1->R(t2));
+                        const S w = (m_exp(-Rts1) - e2) / (e1 - e2);
+                        tau_below_split(m, t1, split, 1.0 - w);
+                        tau_above_split(m, split, t2, w);
+                    }
+                    // population 2 below the split: no distinguished lineage there, so its private branches are the folded
+                    // truncated SFS
+                    if (n2 == 1) at(m, 0, 0, 0, 1) += split;
+                    if (n2 > 1) {
+                        S remain(0.0);
+                        for (int i = 0; i < n2 - 1; ++i) {
+                            at(m, 0, 0, 0, i + 1) += r2[i];
+                            remain += r2[i] * ((double)(i + 1) / (double)n2);
+                        }
+                        remain -= S(split);
+                        at(m, 0, 0, 0, n2) -= remain;
+                    }
+                } catch (const std::exception &ex) {
+                    failed = true;
+#pragma omp critical
+                    err = ex.what();
+                }
+            }
         }
+        if (job_b.side_err) std::rethrow_exception(job_b.side_err);
+        if (job_a.side_err) std::rethrow_exception(job_a.side_err);
         if (!err.empty()) throw std::runtime_error(err);
     }
 
     // distinguished pair coalesces in [t1, t2) with t2 <= split (jcsfs.cpp:83-163)
     void tau_below_split(int m, double t1, double t2, const S &weight) {
-        const RateFunctionT<S> eta(params1, std::vector<double>());
-        const RateFunctionT<S> eta1_trunc(truncate_params(params1, split), std::vector<double>{t1, t2});
-        const std::vector<S> trunc = csfs_of(n1, eta1_trunc)[0];
+        const RateFunctionT<S> &eta = *eta_plain;
+        const std::vector<S> &trunc = trunc_all[below_of[m]];          // CSFS of [t1, t2) under the model truncated at the split
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j <= n1; ++j)
                 if (sval(trunc[(size_t)i * (n1 + 1) + j]) > 0) at(m, i, j, 0, 0) = weight * trunc[(size_t)i * (n1 + 1) + j];
@@ -264,30 +349,43 @@ private:
         S Et(0.0);
         for (int k = 0; k <= n1; ++k) Et += tsfs[k] * ((double)(k + 1) / (double)(n1 + 2));
         at(m, 2, n1, 0, 0) = (split - Et) * weight;
-        // above the split: SFS of the n1 + n2 + 1 lineages there (together()), carried down through the Moran models
-        const std::vector<S> &sfs_above = sfs_above_split;
+        // above the split: SFS of the n1 + n2 + 1 lineages there (together()), carried down through the Moran models:
+        //   avg0 = 1/K sum_k (A_k diag(s0)).leftCols(c) B_k,  avg2 = 1/K sum_k (A_k diag(s2)).rightCols(c) C_k,
+        // A_k = expM_{n1+1}(Rts1 - R(t_k)), B_k / C_k = expM of the modified models at R(t_k) (jcsfs.cpp:120-138).  With
+        // A = P1 e^{.d1} P1^-1 etc. the sum over k only touches the eigenvalue powers:
+        //   avg0 = P1 [ (1/K sum_k u_k v_k^T) o W0 ] P0^-1,   u_k = e^{(Rts1 - R_k) d1},  v_k = e^{R_k d0}      (W0: constructor)
         const int r = n1 + 2, c = n1 + 1;
-        std::vector<S> avg0((size_t)r * c, S(0.0)), avg2((size_t)r * c, S(0.0));
+        std::vector<S> G0((size_t)r * c, S(0.0)), G2((size_t)r * c, S(0.0)), u(r), v(c), w(c);
         std::mt19937 gen;                                               // default seed, re-created per call (quirk 14)
         for (int k = 0; k < K; ++k) {
             const S t = eta.random_time(t1, t2, gen);
             const S Rt = eta.R_at(t);
-            const std::vector<S> A = Mn1p1.expM(Rts1 - Rt);           // r x r
-            const std::vector<S> B = Mn10.expM(Rt), C = Mn12.expM(Rt); // c x c
-            for (int i = 0; i < r; ++i)
-                for (int q = 0; q < c; ++q) {
-                    // (A diag(S0)).leftCols(c) and (A diag(S2)).rightCols(c)
-                    const S a0 = A[(size_t)i * r + q] * (1.0 - (double)q / (double)(n1 + 1));
-                    const S a2 = A[(size_t)i * r + q + 1] * ((double)(q + 1) / (double)(n1 + 1));
-                    for (int j = 0; j < c; ++j) {
-                        avg0[(size_t)i * c + j] += a0 * B[(size_t)q * c + j];
-                        avg2[(size_t)i * c + j] += a2 * C[(size_t)q * c + j];
-                    }
-                }
+            const S dR = Rts1 - Rt;
+            for (int x = 0; x < r; ++x) u[x] = m_exp(dR * Mn1p1.es.d[x]);
+            for (int y = 0; y < c; ++y) { v[y] = m_exp(Rt * Mn10.es.d[y]); w[y] = m_exp(Rt * Mn12.es.d[y]); }
+            for (int x = 0; x < r; ++x)
+                for (int y = 0; y < c; ++y) { G0[(size_t)x * c + y] += u[x] * v[y]; G2[(size_t)x * c + y] += u[x] * w[y]; }
         }
-        for (S &x : avg0) x /= (double)K;
-        for (S &x : avg2) x /= (double)K;
-        (void)sfs_above;
+        for (size_t i = 0; i < G0.size(); ++i) { G0[i] *= W0_[i] / (double)K; G2[i] *= W2_[i] / (double)K; }
+        // H = G Pinv (r x c), then avg = P1 H (r x c)
+        std::vector<S> H0((size_t)r * c, S(0.0)), H2((size_t)r * c, S(0.0));
+        for (int x = 0; x < r; ++x)
+            for (int y = 0; y < c; ++y) {
+                const S g0 = G0[(size_t)x * c + y], g2 = G2[(size_t)x * c + y];
+                for (int j = 0; j < c; ++j) {
+                    H0[(size_t)x * c + j] += g0 * Mn10.es.Pinv[(size_t)y * c + j];
+                    H2[(size_t)x * c + j] += g2 * Mn12.es.Pinv[(size_t)y * c + j];
+                }
+            }
+        std::vector<S> avg0((size_t)r * c, S(0.0)), avg2((size_t)r * c, S(0.0));
+        for (int i = 0; i < r; ++i)
+            for (int x = 0; x < r; ++x) {
+                const double p = Mn1p1.es.P[(size_t)i * r + x];
+                for (int j = 0; j < c; ++j) {
+                    avg0[(size_t)i * c + j] += p * H0[(size_t)x * c + j];
+                    avg2[(size_t)i * c + j] += p * H2[(size_t)x * c + j];
+                }
+            }
         for (int b1 = 0; b1 <= n1; ++b1)
             for (int b2 = 0; b2 <= n2; ++b2) {
                 S s0(0.0), s2(0.0);
@@ -303,8 +401,8 @@ private:
 
     // distinguished pair coalesces in [t1, t2) with split <= t1 (jcsfs.cpp:166-216)
     void tau_above_split(int m, double t1, double t2, const S &weight) {
-        const RateFunctionT<S> shifted(shift_params(params1, split), std::vector<double>{t1 - split, t2 - split});
-        const std::vector<S> rsfs = csfs_of(n1 + n2, shifted)[0];      // 3 x (n1+n2+1)
+        (void)t1; (void)t2;
+        const std::vector<S> &rsfs = rsfs_all[above_of[m]];             // 3 x (n1+n2+1): CSFS of [t1, t2) - split under the shifted model
         const int w = n1 + n2 + 1;
         {
             const int c1 = n1 + 1, c2 = n2 + 1;
@@ -317,7 +415,7 @@ private:
                 }
         }
         // population 1 below the split: the below-part of a CSFS conditioned on coalescence right at the split
-        const std::vector<S> below = csfs_of(n1, *eta1, true)[0];
+        const std::vector<S> &below = below_at_split;
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j <= n1; ++j)
                 if (sval(below[(size_t)i * (n1 + 1) + j]) > 0) at(m, i, j, 0, 0) += weight * below[(size_t)i * (n1 + 1) + j];
@@ -396,6 +494,11 @@ private:
     std::vector<S> Cb_;      // [(n1+2)][(n2+1)]  state-independent contraction of tau_below_split (see together())
     std::vector<S> Da_;      // [3][(n1+n2+1)][(n1+1)][(n2+1)]  ... of tau_above_split
     std::vector<std::vector<S>> J;
+    std::vector<double> W0_, W2_;                       // [(n1+2)][(n1+1)] static sandwiches of tau_below_split (constructor)
+    std::vector<int> below_of, above_of;                // hidden state -> its interval in trunc_all / rsfs_all (-1: none)
+    std::vector<std::vector<S>> trunc_all, rsfs_all;    // batched conditioned SFS below / above the split (together())
+    std::vector<S> below_at_split;
+    std::unique_ptr<RateFunctionT<S>> eta_plain;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -468,7 +571,17 @@ public:
                                                 p.second);
             }
         }
+        // keys are independent (192 of them on config C4, a few hundred tensor bins each): one task per key; the table is read
+        // bin by bin for all states, so it is transposed once ([bin][state]: the inner loop runs over contiguous memory)
+        const size_t nbin_ = sfs.empty() ? 0 : sfs[0].size();
+        std::vector<S> sfsT(nbin_ * (size_t)M);
+        for (int m = 0; m < M; ++m)
+            for (size_t b = 0; b < nbin_; ++b) sfsT[b * M + m] = sfs[m][b];
+        const int nd_ = dual_nder();
+        bool bad_ = false;
+#pragma omp parallel for schedule(static)
         for (int k = 0; k < K; ++k) {
+            DualScope sc_(nd_);
             Key bk;
             for (int q = 0; q < 6; ++q) bk[q] = keys[(size_t)6 * k + q];
             bool reduced = true, miss = true;
@@ -483,13 +596,19 @@ public:
             if (reduced && (miss || amin >= 0)) {
                 for (int m = 0; m < M; ++m) e[m] = miss ? S(1.0) : e2[2 * m + (asum % 2)];
             } else {
-                for (const auto &p : bins_cache_[k])
-                    for (int m = 0; m < M; ++m) e[m] += p.second * sfs[m][p.first];
+                for (const auto &p : bins_cache_[k]) {
+                    const S *col = &sfsT[p.first * (size_t)M];
+                    for (int m = 0; m < M; ++m) e[m] += p.second * col[m];
+                }
             }
             double mx = sval(e[0]), mn = sval(e[0]);
             for (int m = 1; m < M; ++m) { mx = std::max(mx, (double)sval(e[m])); mn = std::min(mn, (double)sval(e[m])); }
-            if (mx > 1.0 || mn <= 0.0) throw std::runtime_error("probability vector not in [0, 1]");
+            if (mx > 1.0 || mn <= 0.0) {
+#pragma omp atomic write
+                bad_ = true;
+            }
         }
+        if (bad_) throw std::runtime_error("probability vector not in [0, 1]");
         if (tm) {
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
             fprintf(stderr, "[prep2] transition %.3f ms, joint csfs %.3f ms, theta + emission assembly (%d keys) %.3f ms\n", ms(tc0, tc1),

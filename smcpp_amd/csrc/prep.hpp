@@ -1230,43 +1230,57 @@ inline Dual<F> accurate_sum(const Dual<F> *v, int cnt) {
     return r;
 }
 
-// `side` (optional): an independent serial job of the caller (the transition matrix, 0.06 ms) that one thread of this
-// function's parallel region runs while the others already work on hidden states.
+// One batch of hidden states of one rate function: the shared state of conditioned_sfs_team().
 template <typename S>
-inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, const CsfsTables &tb, bool below_only = false,
-                                                   const std::function<void()> *side = nullptr) {
-    const bool direct = csfs_direct_flag() != 0;
-    bool zero_ada = false;
-    for (const S &x : eta.ada) zero_ada = zero_ada || sval(x) == 0;
-    if (direct || zero_ada) {                                                        // ada == 0: the factored sums divide by it
-        if (side) (*side)();
-        return conditioned_sfs_direct<S>(eta, tb, below_only);
+struct CsfsJob {
+    const RateFunctionT<S> *eta = nullptr;
+    const CsfsTables *tb = nullptr;
+    bool below_only = false;
+    CsfsPieceTables<S> pt;
+    std::vector<std::vector<S>> csfs;
+    double tmark[64][4] = {};
+    std::chrono::steady_clock::time_point tbase;
+    std::exception_ptr side_err;
+    bool factored() const {
+        if (csfs_direct_flag() != 0) return false;
+        for (const S &x : eta->ada) if (sval(x) == 0) return false;               // ada == 0: the factored sums divide by it
+        return true;
     }
+    void init(const RateFunctionT<S> &e, const CsfsTables &t, bool below) {
+        eta = &e; tb = &t; below_only = below;
+        const int n = t.n, M = (int)e.hidden_states.size() - 1, K = e.K;
+        const bool above = n >= 1 && !below;
+        pt.K = K; pt.n = n;
+        if (above) pt.Ssuf.assign((size_t)n * K, S(0.0));
+        pt.Ppre.assign((size_t)(n + 1) * (K + 1), S(0.0));
+        csfs.assign(M, std::vector<S>((size_t)3 * (n + 1), S(0.0)));
+        tbase = std::chrono::steady_clock::now();
+    }
+};
+
+// The work of conditioned_sfs() on a job prepared with CsfsJob::init(): called by EVERY thread of a team (each with its DualScope
+// set) - the piece tables and the hidden states are shared out by orphaned work-sharing loops, the call returns after the barrier
+// that ends the last of them.  (The joint CSFS runs its batches through this inside its own parallel region: waking libomp's
+// sleeping workers for a region of its own costs more than a batch.)
+template <typename S>
+inline void conditioned_sfs_team(CsfsJob<S> &job, const std::function<void()> *side = nullptr) {
     typedef RateFunctionT<S> RF;
+    const RateFunctionT<S> &eta = *job.eta;
+    const CsfsTables &tb = *job.tb;
     const int n = tb.n;
     const int M = (int)eta.hidden_states.size() - 1;
     const int K = eta.K;
-    const int nd = dual_nder();
     const std::vector<double> &ts = eta.ts;
     const std::vector<S> &ada = eta.ada, &Rrng = eta.Rrng;
     const std::vector<int> &hsi = eta.hs_indices;
-    const bool above = n >= 1 && !below_only;
-    // one parallel region for everything: the piece tables (a few microseconds, static), then - without a barrier in
-    // between - the caller's side job on whichever thread gets there first and the hidden states on all of them
-    CsfsPieceTables<S> pt;
-    pt.K = K; pt.n = n;
-    if (above) pt.Ssuf.assign((size_t)n * K, S(0.0));
-    pt.Ppre.assign((size_t)(n + 1) * (K + 1), S(0.0));
-    std::vector<std::vector<S>> csfs(M, std::vector<S>((size_t)3 * (n + 1), S(0.0)));
-    std::exception_ptr side_err;
+    const bool above = n >= 1 && !job.below_only;
+    CsfsPieceTables<S> &pt = job.pt;
+    std::vector<std::vector<S>> &csfs = job.csfs;
+    std::exception_ptr &side_err = job.side_err;
     static const bool tm = getenv("SMCPP_HOST_TIMING") != nullptr;
-    double tmark[64][4] = {};
-    const auto tbase = std::chrono::steady_clock::now();
+    double (&tmark)[64][4] = job.tmark;
+    const auto tbase = job.tbase;
     auto now_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tbase).count(); };
-    // (called per hidden state from inside the joint CSFS's own parallel loop: no nested team there)
-#pragma omp parallel if (!omp_in_parallel())
-    {
-        DualScope sc(nd);
         const int tid_ = omp_get_thread_num();
         if (tm && tid_ < 64) tmark[tid_][0] = now_us();
         csfs_piece_tables_ws<S>(eta, n, above, pt);       // orphaned work-sharing loops, barrier at the end
@@ -1384,16 +1398,39 @@ inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, 
             }
             if (tm && tid_ < 64) tmark[tid_][3] = now_us();      // nowait loop below: last state finished by this thread
         }
+}
+
+// `side` (optional): an independent serial job of the caller (the transition matrix, 0.06 ms) that one thread of this
+// function's parallel region runs while the others already work on hidden states.
+template <typename S>
+inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, const CsfsTables &tb, bool below_only = false,
+                                                   const std::function<void()> *side = nullptr) {
+    CsfsJob<S> job;
+    job.eta = &eta;
+    if (!job.factored()) {
+        if (side) (*side)();
+        return conditioned_sfs_direct<S>(eta, tb, below_only);
+    }
+    job.init(eta, tb, below_only);
+    const int nd = dual_nder();
+    static const bool tm = getenv("SMCPP_HOST_TIMING") != nullptr;
+    // one parallel region for everything: the piece tables (a few microseconds, static), then - without a barrier in
+    // between - the caller's side job on whichever thread gets there first and the hidden states on all of them
+    // (called per hidden state from inside another parallel loop: no nested team there)
+#pragma omp parallel if (!omp_in_parallel())
+    {
+        DualScope sc(nd);
+        conditioned_sfs_team<S>(job, side);
     }
     if (tm && !omp_in_parallel()) {
-        const double tend = now_us();
+        const double tend = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - job.tbase).count();
         fprintf(stderr, "[csfs] region %.1f us; per thread (enter, tables done, side done, last state):", tend);
         for (int t = 0; t < std::min(64, omp_get_max_threads()); ++t)
-            fprintf(stderr, " [%.0f %.0f %.0f %.0f]", tmark[t][0], tmark[t][1], tmark[t][2], tmark[t][3]);
+            fprintf(stderr, " [%.0f %.0f %.0f %.0f]", job.tmark[t][0], job.tmark[t][1], job.tmark[t][2], job.tmark[t][3]);
         fprintf(stderr, "\n");
     }
-    if (side_err) std::rethrow_exception(side_err);
-    return csfs;
+    if (job.side_err) std::rethrow_exception(job.side_err);
+    return std::move(job.csfs);
 }
 
 template <typename S>

@@ -163,8 +163,8 @@ int smcpp_chain_mode(smcpp_im *im);
 /* Test hook of family 5: one position of both scan chains on nvec vectors: out_f = e o (T^T x), out_b = T (e o x); T is
  * [M][M] row-major, x / e / out_* are [nvec][M].  Returns 2 when T has no semiseparable structure (nothing is written). */
 int smcpp_debug_ss_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b);
-/* ... the same position in the four-chains-per-wavefront layout of the fp64 passes (M <= 64). */
-int smcpp_debug_ss4_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b);
+/* ... the same position by the step of the stored passes with every scan in float (M <= 64; the M <= 32 form when M <= 32). */
+int smcpp_debug_ss_apply_float_scans(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b);
 /* Host phase of the last E-step in milliseconds: [cold preparation A6-A10 (0 when the parameters were still fresh or
  * came from smcpp_set_raw), eigensystems, layouts + staging + copy enqueue, whole host phase] */
 int smcpp_last_host_timing(smcpp_im *im, double out[4]);

@@ -66,7 +66,7 @@ def lib():
         "smcpp_set_num_threads": (None, [i]),
         "smcpp_set_debug": (i, [vp, i]), "smcpp_get_debug": (i, [vp]), "smcpp_device": (i, [vp]),
         "smcpp_debug_ss_apply": (i, [i, _dp, i, _dp, _dp, _dp, _dp]),
-        "smcpp_debug_ss4_apply": (i, [i, _dp, i, _dp, _dp, _dp, _dp]),
+        "smcpp_debug_ss_apply_float_scans": (i, [i, _dp, i, _dp, _dp, _dp, _dp]),
         "smcpp_host_set_csfs_direct": (i, [i]),
         "smcpp_host_chunk_counts": (i, [i, C.POINTER(C.c_longlong), _ip, C.c_longlong, C.c_longlong, _ip]),
         "smcpp_host_eigensystem": (i, [i, _dp, _dp, _dp, _dp, _dp, _dp]),
@@ -109,7 +109,7 @@ EXPORTS = [
     "smcpp_set_params_twopop", "smcpp_host_joint_csfs", "smcpp_host_prep_twopop", "smcpp_set_warm_start",
     "smcpp_host_set_csfs_direct", "smcpp_gamma_cols", "smcpp_last_host_timing", "smcpp_get_pi_jac",
     "smcpp_get_transition_jac", "smcpp_get_emission_probs_jac", "smcpp_num_emission_cols", "smcpp_get_emission",
-    "smcpp_init_logger_cb", "smcpp_init_cache", "smcpp_debug_ss_apply", "smcpp_debug_ss4_apply", "smcpp_set_debug", "smcpp_get_debug", "smcpp_device",
+    "smcpp_init_logger_cb", "smcpp_init_cache", "smcpp_debug_ss_apply", "smcpp_debug_ss_apply_float_scans", "smcpp_set_debug", "smcpp_get_debug", "smcpp_device",
     "smcpp_dev_prep_onepop", "smcpp_set_prep_mode", "smcpp_dev_q_emulate",
 ]
 

@@ -31,7 +31,7 @@ struct SsArgs {
     const Chunk *chunks;        // chunks of the forward chain
     // The backward chain costs more per position (three scans against two) and forgets more slowly, so it gets MORE, SHORTER
     // chunks than the forward chain: own chunk list; `tasks` assigns (direction << 30 | chunk) to every wavefront of the launch,
-    // -1 = none (one-chain-per-wavefront kernels only; the four-chains kernels use the same list for both directions)
+    // -1 = none
     const Chunk *chunks_b;
     int nchunks_b;
     const int *tasks;
@@ -53,18 +53,8 @@ struct SsArgs {
                                 // test, no merge exit, the contig's first / last chunk included): the fp64 pass after light passes
     int mode_f, mode_b;         // per direction: 0 = first pass (from pi / uniform, stores), 1 = re-run pass, 2 = light pass (float,
                                 // store-free: only the chunk's end vector is produced - history for the passes that follow)
-    int nostore_f = 0, nostore_b = 0;   // the pass runs the stored passes' arithmetic but writes no row: only the chunk's end vector (the
-                                // LAST history pass of a direction: its end vectors are then exact to rounding, not to the ~1e-5 the
-                                // float light passes carry, and the stored pass that follows is not re-run)
     int halo = 0;               // first pass only: every chunk is entered through its halo (Chunk::h0 / h1) instead of from pi / uniform
     long long *dbg;             // optional [8] (SMCPP_DEBUG_CYCLES): shader-clock / 100 MHz ticks / positions of chunk 1, pass 0
-    // light passes on COARSE chunks handing over to the four-chains-per-wavefront kernels (chains_ss4.hpp): a coarse chunk is
-    // Chunk::pad & 0xFFFFFF .. + (Chunk::pad >> 24) - 1 of the fine list; a direction's LAST light pass also writes the vector
-    // at every fine boundary into the fine end-vector arrays (parity of the pass)
-    const Chunk *fine;
-    int nfine, hand_f, hand_b;
-    float *fine_ends_f;
-    double *fine_ends_b;
     // HYBRID rows (un-binned data, M <= 64 and the tables fit LDS): a row whose span exceeds hyb_th is ONE eigen-power step
     // x <- P (d~^s o (P^-1 x))  (forward; hmm.cpp:72-78) /  b <- P^-T (d~^s o (P^T b))  (backward; hmm.cpp:104-112) on the
     // eigensystem of its key - two M-long mat-vecs per lane against LDS tables - instead of `span` scan steps; shorter rows
@@ -672,8 +662,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
         for (int k = 0; k < NPL; ++k) if (stor[k]) a.used_f[(size_t)c * Mp + st[k]] = (float)x[k];
     }
     if (lane == 0) a.changed_f[pass] = 1;
-    const bool nost = a.nostore_f != 0;
-    if (ch.first && !nost) {
+    if (ch.first) {
 #pragma unroll
         for (int k = 0; k < NPL; ++k) if (stor[k]) a.alpha[(size_t)ch.base * Mp + st[k]] = (float)x[k];
         if (lane == 0) a.cnorm[ch.base] = 1.0;
@@ -694,7 +683,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     int cacc = 0;                                  // bit patterns of the normalisers of rows (j & ~63) + lane
     auto cflush = [&](int jhi) {                   // store the collected normalisers of the 64-row block that holds row jhi, rows <= jhi
         const int jj = (jhi & ~63) + lane;
-        if (!nost && jj <= jhi && jj > jst && jj > 0) crow[jj] = (double)__builtin_bit_cast(float, cacc);
+        if (jj <= jhi && jj > jst && jj > 0) crow[jj] = (double)__builtin_bit_cast(float, cacc);
     };
     double e[NPL];
     ss_emission<NPL, false, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
@@ -783,7 +772,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
                     }
                 if (!__any(bad)) { merged = true; if (MIX) cflush(j - 1); break; }
             }
-            if (j > jst && !nost) {
+            if (j > jst) {
                 if (MIX) {
 #pragma unroll
                     for (int k = 0; k < NPL; ++k) if (stor[k]) *ap[k] = an[k];
@@ -793,7 +782,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
                     for (int k = 0; k < NPL; ++k) if (stor[k]) arow[(size_t)j * Mp + st[k]] = an[k];
                     if (lane == 0) crow[j] = S;
                 }
-            } else if (j == jst && !nost) {
+            } else if (j == jst) {
                 // (halo only: row r0 belongs to the neighbour; what this chunk starts from is what the certificate compares)
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) if (stor[k]) a.used_f[(size_t)c * Mp + st[k]] = an[k];
@@ -850,9 +839,9 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             const float an = live[k] ? fmaxf((float)(x[k] * inv), 1e-10f) : 0.f;
-            if (stor[k]) { if (!nost) a.alpha[(size_t)(ch.base + ch.r1) * Mp + st[k]] = an; end_cur[st[k]] = an; }
+            if (stor[k]) { a.alpha[(size_t)(ch.base + ch.r1) * Mp + st[k]] = an; end_cur[st[k]] = an; }
         }
-        if (lane == 0 && !nost) a.cnorm[ch.base + ch.r1] = S;
+        if (lane == 0) a.cnorm[ch.base + ch.r1] = S;
     }
 }
 
@@ -973,7 +962,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
                 if (stor[k]) a.used_b[(size_t)c * Mp + st[k]] = b[k];
             }
         }
-        if (j >= jst && !a.nostore_b) {
+        if (j >= jst) {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) if (stor[k]) { if (MIX) *bp[k] = b[k]; else brow[-(ptrdiff_t)j * Mp + st[k]] = b[k]; }
         }
@@ -1036,7 +1025,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             const double bf = live[k] ? b[k] / S : 0.0;          // beta /= beta.sum()  (seeds gamma[:,0], hmm.cpp:150)
-            if (stor[k]) { end_cur[st[k]] = bf; if (ch.first && !a.nostore_b) a.beta[(size_t)ch.base * Mp + st[k]] = bf; }
+            if (stor[k]) { end_cur[st[k]] = bf; if (ch.first) a.beta[(size_t)ch.base * Mp + st[k]] = bf; }
         }
     }
 }
@@ -1312,9 +1301,6 @@ __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *
     ss_desc_settle(dcur); ss_desc_settle(dnxt);
     float e[NPL];
     ss_emission_f<NPL, false, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
-    int fcur = ch.pad & 0xFFFFFF;
-    const int fend = fcur + (ch.pad >> 24);
-    int nextb = (a.hand_f && fcur < fend) ? a.fine[fcur].r1 - ch.r0 : -1;
     ss_vm_drain();
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
@@ -1347,18 +1333,6 @@ __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) e[k] = en[k];
-        if (j + 1 == nextb) {
-            // end of a fine chunk: hand its (normalised, floored) end vector to the four-chains kernels
-            float pt = 0.f;
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) pt += x[k];
-            const float iv = 1.f / wave_sum_dpp(pt);
-            float *dst = a.fine_ends_f + ((size_t)(pass & 1) * a.nfine + fcur) * Mp;
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) if (stor[k]) dst[st[k]] = live[k] ? fmaxf(x[k] * iv, 1e-10f) : 0.f;
-            ++fcur;
-            nextb = fcur < fend ? a.fine[fcur].r1 - ch.r0 : -1;
-        }
     }
     float part = 0.f;
 #pragma unroll
@@ -1394,9 +1368,6 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
     ss_desc_settle(dcur); ss_desc_settle(dnxt);
     float e[NPL];
     ss_emission_f<NPL, true, ALLLDS>(a, sE, __builtin_amdgcn_readlane(dcur.x, 0) & 0xFFFF, lane, e);
-    const int fbeg = ch.pad & 0xFFFFFF;
-    int fcur = fbeg + (ch.pad >> 24) - 1;
-    int nextb = (a.hand_b && fcur >= fbeg) ? ch.r1 - a.fine[fcur].r0 : -1;
     ss_vm_drain();
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
@@ -1429,17 +1400,6 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) e[k] = en[k];
-        if (j + 1 == nextb) {
-            float pt = 0.f;
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) pt += live[k] ? b[k] : 0.f;
-            const float iv = 1.f / wave_sum_dpp(pt);
-            double *dst = a.fine_ends_b + ((size_t)(pass & 1) * a.nfine + fcur) * Mp;
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) if (stor[k]) dst[st[k]] = live[k] ? (double)(b[k] * iv) : 0.0;
-            --fcur;
-            nextb = fcur >= fbeg ? ch.r1 - a.fine[fcur].r0 : -1;
-        }
     }
     float part = 0.f;
 #pragma unroll
@@ -1458,11 +1418,10 @@ __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
     constexpr int MS = 64 * NPL;
     extern __shared__ __attribute__((aligned(16))) double ss_lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // mode 3: the direction takes no part in this launch (its pass runs in the other layout's kernel)
     // (a FULL pass never idles: it is the first pass that stores rows, and with a warm start it may be the first pass launched at
     // all - the flag of the pass before it was then never written)
-    const bool idle_f = a.mode_f == 3 || (a.mode_f == 1 && !a.full_f && a.changed_f[a.pass - 1] == 0);
-    const bool idle_b = a.mode_b == 3 || (a.mode_b == 1 && !a.full_b && a.changed_b[a.pass - 1] == 0);
+    const bool idle_f = (a.mode_f == 1 && !a.full_f && a.changed_f[a.pass - 1] == 0);
+    const bool idle_b = (a.mode_b == 1 && !a.full_b && a.changed_b[a.pass - 1] == 0);
     if (idle_f && idle_b) return;
     const int nthr = HYB ? (int)blockDim.x : 256;
     for (int idx = tid; idx < a.nlds * MS; idx += nthr) ss_lds[idx] = a.E[idx];
@@ -1622,8 +1581,8 @@ __global__ __launch_bounds__(256) void k_span_scan(SsArgs sa, FinArgs a, int sma
 }
 
 // Unit-test entry (tests/test_gpu_ss.py through smcpp_debug_ss_apply): out_f = e o (T^T x), out_b = T (e o x) by the scans,
-// one wavefront per vector.
-template <int NPL>
+// one wavefront per vector.  MIX / H32: the all-float scans of the stored passes (one state per lane) and their M <= 32 form.
+template <int NPL, bool MIX = false, bool H32 = false>
 __global__ __launch_bounds__(64) void k_ss_apply(SsArgs a, const double *__restrict__ x, const double *__restrict__ e,
                                                  double *__restrict__ out_f, double *__restrict__ out_b, int nvec) {
     constexpr int MS = 64 * NPL;
@@ -1641,8 +1600,8 @@ __global__ __launch_bounds__(64) void k_ss_apply(SsArgs a, const double *__restr
         xb[k] = x[(size_t)v * MS + q]; eb[k] = e[(size_t)v * MS + q];
     }
     double S; float Sw;
-    ss_fwd_step<NPL>(cf, xf, ef, yf, S);
-    ss_bwd_step<NPL>(cb, xb, eb, yb, Sw);
+    ss_fwd_step<NPL, MIX, H32>(cf, xf, ef, yf, S);
+    ss_bwd_step<NPL, MIX, H32>(cb, xb, eb, yb, Sw);
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         const int p = lane * NPL + k, q = MS - 1 - p;

@@ -30,11 +30,6 @@
 #include "chains2.hpp"
 #include "chains_lock.hpp"
 #include "chains_ss.hpp"
-// Four chains per wavefront (chains_ss4.hpp): parity-green but slower than one chain per wavefront wherever measured (DESIGN.md
-// section 10) - not part of the default build since round 4.  -DSMCPP_WITH_SS4 compiles the kernels in; SMCPP_SS4=1 then selects them.
-#ifdef SMCPP_WITH_SS4
-#include "chains_ss4.hpp"
-#endif
 #include "nonsym_eig.hpp"
 #include "nonsym_eig_team.hpp"
 #include "prep.hpp"
@@ -169,7 +164,6 @@ constexpr int ROWDESC_PAD = 256;
 
 }  // namespace
 
-static int coop_generation();
 
 // ---------------------------------------------------------------------------------------------------------------
 // Cold preparation on the device (prep_dev.hpp): the host part of one call is O(pieces): the rate function with the
@@ -483,11 +477,9 @@ struct smcpp_im {
     DevBuf<RowInfo> d_rowinfo;
     DevBuf<int2> d_rowdesc;
     DevBuf<long long> d_dbg;
-    DevBuf<float> d_T4, d_qTf;
+    DevBuf<float> d_qTf;
     DevBuf<double> d_qTdT, d_qPinvT, d_qPT, d_qPrm, d_qPinvrm;   // quarter-interleaved operands of the big-M chains
-    DevBuf<double> d_fA2, d_fB2, d_bA2, d_bB2, d_bC2;
-    int wpb = 4;
-    int chain_mode = 2;   // 0 generic, 1 LDS-resident (one wavefront per chunk), 2 CU-cooperative (one workgroup per chunk),
+    int chain_mode = 2;   // dense fallback family: 2 CU-cooperative (one workgroup per chunk, chains2.hpp),
                           // 3 CU-cooperative with streamed operands (64 < M <= 256), 4 lock-step on the matrix cores (16 chunks per workgroup)
     int coop_bpc = 1;     // cooperative workgroups resident per CU the automatic chunking aims at
     // ---- chains on the semiseparable structure of T (chains_ss.hpp; chain_mode 5) ------------------------------------------
@@ -537,7 +529,6 @@ struct smcpp_im {
     int ss_launched = 0, last_ss_passes = 0;
     long long ss_positions = 0;            // sum of spans
     int ss_light_f = 0, ss_light_b = 0;    // light (float, store-free) passes per direction before the full fp64 pass
-    bool ss_acc_last = true;               // the last of them in the stored passes' arithmetic (SMCPP_SS_ACC=0: a float light pass like the others)
     // opt-in warm start of the scan chains (smcpp_set_warm_start): the first pass of an E-step starts every chunk from the boundary
     // vector the PREVIOUS converged E-step left (parity ss_warm_parity of the end-vector arrays) instead of pi / the uniform
     // vector, and one light pass fewer runs; pass indices then start at ss_pass0 (1 or 2: the parity the first pass reads)
@@ -547,26 +538,12 @@ struct smcpp_im {
     int ss_warm_parity = 0, ss_pass0 = 0;
     std::vector<int> ss_slot_of_key;       // frequency rank of every key (slot 0 = most rows)
     DevBuf<int2> d_rowdesc_ss;             // [rows, padded] {key slot, span}
-    DevBuf<double> d_gpart2;               // [span-1 rank slabs][K][Mp] gamma partials of k_rank_acc_g
     DevBuf<double> d_Fall;                 // [n_contigs Ke][smax][Mp][Mp] scratch of the span fold for M > 64 (k_span_big)
-    DevBuf<int> d_span_flags;              // [n_contigs Ke][smax] per-step publication counters of the fused span fold (only ever grow)
-    int span_epoch = 0;
     SsArgs ss_args;
     std::vector<Chunk> chunks_b;           // backward chunks of the scan chains (more and shorter than the forward ones)
     std::vector<int> ss_tasks;             // (direction << 30 | chunk) per wavefront of a k_chain_ss launch
     DevBuf<Chunk> d_chunks_b;
     DevBuf<int> d_tasks;
-    // four chains per wavefront (chains_ss4.hpp, M <= 64): the fp64 passes run on `chunks` (fine), the light passes on groups of
-    // four of them (`chunks1`, coarse) and hand over the fine boundary vectors
-    bool ss4 = false;
-    int SPL = 1;
-    std::vector<Chunk> chunks1;
-    DevBuf<Chunk> d_chunks1;
-    DevBuf<float> d_ends1_f;
-    DevBuf<double> d_ends1_b;
-    std::vector<double> ss_gen4;
-    SsArgs ss4_args;
-    void build_coarse_chunks();
     void update_pi_default();
     bool debug = false;                    // InferenceManager::debug (_smcpp.pxd:53): declared by the reference, read by nothing
     void upload_chunk_state();
@@ -871,11 +848,9 @@ void smcpp_im::make_chunks() {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     {
-        const char *w = getenv("SMCPP_WPB");
-        wpb = (w && atoi(w) == 8) ? 8 : 4;
+        // SMCPP_CHAIN = lock: the lock-step kernels forced (M <= 64); = dense: the cooperative kernels; ss (or unset): see below
         const char *m = getenv("SMCPP_CHAIN");
-        if (m) chain_mode = !strcmp(m, "generic") ? 0 : !strcmp(m, "lds") ? 1 : (!strcmp(m, "lock") && Mp <= 64) ? 4 : 2;
-        if (getenv("SMCPP_GENERIC_CHAINS")) chain_mode = 0;
+        if (m) chain_mode = (!strcmp(m, "lock") && Mp <= 64) ? 4 : 2;
         // lock-step chains on the matrix cores (chains_lock.hpp): 16 chunks per workgroup, so 16 x more and 16 x shorter
         // chunks - they pay off when those are still long against the ~900 rows of history every chunk re-runs
         if (!m && Mp <= 64 && (total_rows - n_contigs) / ((long long)prop.multiProcessorCount * LOCK_NC) >= lock_min_rows(Mp)) {
@@ -888,8 +863,8 @@ void smcpp_im::make_chunks() {
             const long long top = *std::max_element(cnt.begin(), cnt.end());
             if (ne == 0 || 10 * top >= 9 * ne) chain_mode = 4;
         }
-        // 64 < M <= 256: the streaming cooperative kernels (k_fwd_big / k_bwd_big) unless generic is forced
-        if (Mp > 64) chain_mode = (chain_mode == 0) ? 0 : 3;
+        // 64 < M <= 256: the streaming cooperative kernels (k_fwd_big / k_bwd_big)
+        if (Mp > 64) chain_mode = 3;
         // Chains on the semiseparable structure of T (chains_ss.hpp): one position per step, so the input qualifies when
         // its spans are short (binned data; un-binned posterior data with spans of 10^4 .. 10^5 keep the eigen kernels).
         // chain_mode then names the DENSE kernels an E-step falls back to when its T has no such structure.
@@ -917,17 +892,6 @@ void smcpp_im::make_chunks() {
                 }
             }
             if (ss_static) chain_mode = Mp > 64 ? 3 : 2;
-            SPL = (M + 15) / 16;
-            // (opt-in: on one 100 Mbp contig the fine chunks are shorter than the history a re-run has to cover, so the re-run passes
-            // cascade over several launches - measured 1.9 ms of chains against 1.0 ms with one chain per wavefront; the layout pays
-            // when the chunks are long, i.e. on whole genomes, and is kept for that: DESIGN.md)
-            const char *s4 = getenv("SMCPP_SS4");
-#ifdef SMCPP_WITH_SS4
-            ss4 = ss_static && Mp <= 64 && (s4 && atoi(s4) != 0) && (long long)K * 16 * SPL * 8 <= 100 * 1024;
-#else
-            ss4 = false;
-            if (s4 && atoi(s4) != 0) log_msg("WARNING", "SMCPP_SS4 ignored: the four-chains kernels are not compiled in (-DSMCPP_WITH_SS4)");
-#endif
         }
         const char *b = getenv("SMCPP_COOP_BPC");
         if (b && atoi(b) > 0) coop_bpc = atoi(b);
@@ -941,7 +905,7 @@ void smcpp_im::make_chunks() {
     }
     // chunks in flight: one per SIMD for the per-wavefront kernels, coop_bpc per CU for the cooperative ones
     long long slots = (long long)prop.multiProcessorCount *
-                      (chain_mode == 4 ? LOCK_NC : chain_mode >= 2 ? (chain_mode == 3 ? 1 : coop_bpc) : wpb);
+                      (chain_mode == 4 ? LOCK_NC : chain_mode == 3 ? 1 : coop_bpc);
     if (ss_static && user_rows_per_chunk <= 0 && !getenv("SMCPP_ROWS_PER_CHUNK")) {
         // scan chains: one wavefront per chunk and direction, a workgroup = 2 forward + 2 backward chunks = one wavefront per
         // SIMD; chunks are cut by POSITIONS (sum of spans), the unit of work of these kernels.  Every chunk pays the same
@@ -1030,14 +994,11 @@ void smcpp_im::make_chunks() {
         // history the two light passes walk - so it only trades the merge re-run against chunks of unequal length: 0.92 ms against
         // 0.87; with several states per lane (M > 64), where a light position costs relatively more, it wins (c5: 1.45 against 1.64 ms).
         // Default: M > 64 only; SMCPP_SS_HALO = 1 / 0 forces it.
-        ss_halo = !ss4 && !ss_hybrid && (getenv("SMCPP_SS_HALO") ? atoi(getenv("SMCPP_SS_HALO")) != 0 : NPL >= 2);
+        ss_halo = !ss_hybrid && (getenv("SMCPP_SS_HALO") ? atoi(getenv("SMCPP_SS_HALO")) != 0 : NPL >= 2);
         auto env_ll = [](const char *nm, long long dflt) { const char *e = getenv(nm); return e ? atoll(e) : dflt; };
         const long long hlf = ss_halo ? env_ll("SMCPP_HALO_LF", 2800) : 0, hdf = ss_halo ? env_ll("SMCPP_HALO_DF", 800) : 0,
                         hlb = ss_halo ? env_ll("SMCPP_HALO_LB", 3900) : 0, hdb = ss_halo ? env_ll("SMCPP_HALO_DB", 1100) : 0;
-        if (ss4) {
-            cut(waves * 2, 512, chunks, false, 0, 0);          // fine chunks: four chains per wavefront, half the wavefronts per direction
-            chunks_b = chunks;
-        } else {
+        {
             // the forward chain gets SMCPP_SS_FWD_SHARE of the wavefronts.  Default one half: the backward chain's light position
             // costs 38 instructions against 25, but the fp64 passes of the two directions take the same time (forward: stores, the
             // reciprocal and the feedback of the stored vector per row), and measured on the headline 0.45 / 0.42 / 0.38 / 0.34 lose
@@ -1061,7 +1022,6 @@ void smcpp_im::make_chunks() {
             cut(std::max<long long>(1, waves - nf), 1024, chunks_b, true, hlb, hdb);
         }
         max_pass = max_chunks_per_contig + 3 + 4 + 2;  // (+4: light passes, +2: a warm start numbers its passes from 1 or 2)
-        build_coarse_chunks();
         return;
     }
     long long rows = total_rows - n_contigs;
@@ -1097,24 +1057,6 @@ void smcpp_im::make_chunks() {
     chunks_b = chunks;
     for (Chunk &cb : chunks_b) cb.h0 = cb.h1 = cb.r1;
     ss_halo = false;
-    build_coarse_chunks();
-}
-
-// coarse chunks of the light passes: groups of four consecutive fine chunks of a contig (Chunk::pad = first fine | count << 24)
-void smcpp_im::build_coarse_chunks() {
-    chunks1.clear();
-    if (!ss4) return;
-    size_t i = 0;
-    while (i < chunks.size()) {
-        size_t j = i + 1;
-        while (j < chunks.size() && j - i < 4 && chunks[j].contig == chunks[i].contig) ++j;
-        Chunk c = chunks[i];
-        c.r1 = chunks[j - 1].r1;
-        c.last = chunks[j - 1].last;
-        c.pad = (int)i | ((int)(j - i) << 24);
-        chunks1.push_back(c);
-        i = j;
-    }
 }
 
 void smcpp_im::upload_chunk_state() {
@@ -1124,9 +1066,8 @@ void smcpp_im::upload_chunk_state() {
     d_chunks_b.upload(chunks_b, stream);
     {
         // wavefront -> (direction, chunk) of the one-chain-per-wavefront launches: the two directions interleaved in proportion, so
-        // that every workgroup (4 wavefronts = the 4 SIMDs of a CU) holds its share of both; with the four-chains kernels in
-        // use these launches run the COARSE chunks (light passes)
-        const size_t nf = ss4 ? chunks1.size() : chunks.size(), nb = ss4 ? chunks1.size() : chunks_b.size();
+        // that every workgroup (4 wavefronts = the 4 SIMDs of a CU) holds its share of both
+        const size_t nf = chunks.size(), nb = chunks_b.size();
         ss_tasks.clear();
         size_t i = 0, j = 0;
         if (ss_hybrid && ss_dirsplit) {
@@ -1152,11 +1093,6 @@ void smcpp_im::upload_chunk_state() {
     d_ends_f.alloc(2 * nch * Mp); d_used_f.alloc(nch * Mp);
     d_ends_b.alloc(2 * nch * Mp); d_used_b.alloc(nch * Mp);
     d_changed_f.alloc(max_pass + 1); d_changed_b.alloc(max_pass + 1);
-    if (ss4) {
-        d_chunks1.upload(chunks1, stream);
-        d_ends1_f.alloc(2 * chunks1.size() * Mp);
-        d_ends1_b.alloc(2 * chunks1.size() * Mp);
-    }
     HIPCHK(hipStreamSynchronize(stream));
 }
 
@@ -1307,7 +1243,7 @@ void smcpp_im::setup_power() {
     const char *pe = getenv("SMCPP_POWER_PREPASS");
     // spans below 32 (binned data: four squarings give every power); chunks short enough that pass 1 re-runs them whole
     // anyway (the rows of the pre-pass are all overwritten: it runs in float and its normalisers carry no eigenvalue scale)
-    const bool coop_pre = chain_mode == 2 && coop_generation() == 2 && Mp <= 64;
+    const bool coop_pre = chain_mode == 2 && Mp <= 64;
     const bool big_pre = chain_mode == 3 && Mp > 64 && Mp <= 256;
     // spans up to twelve bits (4095 positions); the cooperative chains read the powers beyond A^16 from L2 on the few rows
     // that need them, the streamed-operand ones stream every power anyway
@@ -1954,27 +1890,6 @@ void smcpp_im::host_prep_and_upload() {
     }
     if (!err.empty()) throw std::runtime_error(err);
     auto tp1 = std::chrono::steady_clock::now();
-    std::vector<float> T4;
-    std::vector<double> fA2, fB2, bA2, bB2, bC2;
-    if (Mp <= 64 && chain_mode == 1) {
-        // k-blocked copies for the LDS-resident chain kernels: [k/4][i][4] floats, [k/2][i][2] doubles
-        const int h = hot_eig;
-        T4.assign(MM, 0.f); fA2.assign(MM, 0.0); fB2.assign(MM, 0.0); bA2.assign(MM, 0.0); bB2.assign(MM, 0.0);
-        bC2.assign(MM, 0.0);
-        for (int k = 0; k < Mp; ++k)
-            for (int i = 0; i < Mp; ++i) {
-                const size_t i4 = ((size_t)(k / 4) * Mp + i) * 4 + (k % 4);
-                const size_t i2 = ((size_t)(k / 2) * Mp + i) * 2 + (k % 2);
-                T4[i4] = Tf[(size_t)k * Mp + i];
-                bA2[i2] = TdT[(size_t)k * Mp + i];
-                if (h >= 0) {
-                    fA2[i2] = PinvT[h * MM + (size_t)k * Mp + i];
-                    fB2[i2] = PT[h * MM + (size_t)k * Mp + i];
-                    bB2[i2] = Prm[h * MM + (size_t)k * Mp + i];
-                    bC2[i2] = Pinvrm[h * MM + (size_t)k * Mp + i];
-                }
-            }
-    }
     std::vector<float> qTf;
     std::vector<double> qTdT, qPinvT, qPT, qPrm, qPinvrm;
     if (Mp > 64 && chain_mode == 3 && !ss_active) {          // (the scan chains stream no operand)
@@ -2005,10 +1920,9 @@ void smcpp_im::host_prep_and_upload() {
                               &uPrm = lean ? none_d : Prm, &uPinvrm = lean ? none_d : Pinvrm;
     size_t need = 32 * 256;
     need += qTf.size() * 4 + (qTdT.size() + qPinvT.size() + qPT.size() + qPrm.size() + qPinvrm.size()) * 8;
-    need += (pi_f.size() + uTf.size() + T4.size()) * 4;
+    need += (pi_f.size() + uTf.size()) * 4;
     need += (uTdT.size() + Td.size() + (E_on_dev ? 0 : Ep.size()) + uPinvT.size() + uPT.size() + uPrm.size() + uPinvrm.size() + dsc.size() +
-             dun.size() + gsc.size() + gls.size() + fA2.size() + fB2.size() + bA2.size() + bB2.size() +
-             bC2.size()) * 8;
+             dun.size() + gsc.size() + gls.size()) * 8;
     stage.reset(need);
     if (need > param_cap) {
         if (d_param) (void)hipFree(d_param);
@@ -2027,10 +1941,6 @@ void smcpp_im::host_prep_and_upload() {
     d_Pinvrm.place(uPinvrm, d_param, hb, off);
     d_dsc.place(dsc, d_param, hb, off); d_dun.place(dun, d_param, hb, off);
     d_g_scale.place(gsc, d_param, hb, off); d_g_logscale.place(gls, d_param, hb, off);
-    if (Mp <= 64 && chain_mode == 1) {
-        d_T4.place(T4, d_param, hb, off); d_fA2.place(fA2, d_param, hb, off); d_fB2.place(fB2, d_param, hb, off);
-        d_bA2.place(bA2, d_param, hb, off); d_bB2.place(bB2, d_param, hb, off); d_bC2.place(bC2, d_param, hb, off);
-    }
     if (!qTf.empty()) {
         d_qTf.place(qTf, d_param, hb, off); d_qTdT.place(qTdT, d_param, hb, off);
         d_qPinvT.place(qPinvT, d_param, hb, off); d_qPT.place(qPT, d_param, hb, off);
@@ -2067,35 +1977,7 @@ void smcpp_im::host_prep_and_upload() {
 // ---------------------------------------------------------------------------------------------------------------
 // kernel launches
 // ---------------------------------------------------------------------------------------------------------------
-template <int NPL_>
-static void launch_chain_generic(bool fwd, const ChainArgs &a, hipStream_t s) {
-    if (fwd) hipLaunchKernelGGL((k_fwd_pass<NPL_>), dim3(a.nchunks), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((k_bwd_pass<NPL_>), dim3(a.nchunks), dim3(64), 0, s, a);
-}
-template <int MT_, bool TAB_, int WPB_>
-static void launch_chain_lds_t(bool fwd, const ChainArgs &a, const LdsArgs &la, size_t shm, hipStream_t s) {
-    const int nblk = (a.nchunks + WPB_ - 1) / WPB_;
-    if (fwd) {
-        static bool once = false;
-        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_fwd_lds<MT_, TAB_, WPB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
-        hipLaunchKernelGGL((k_fwd_lds<MT_, TAB_, WPB_>), dim3(nblk), dim3(64 * WPB_), shm, s, a, la);
-    } else {
-        static bool once = false;
-        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_bwd_lds<MT_, TAB_, WPB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
-        hipLaunchKernelGGL((k_bwd_lds<MT_, TAB_, WPB_>), dim3(nblk), dim3(64 * WPB_), shm, s, a, la);
-    }
-}
-template <int MT_>
-static void launch_chain_lds(bool fwd, const ChainArgs &a, const LdsArgs &la, int tab, int wpb, size_t shm, hipStream_t s) {
-    if (wpb == 8) {
-        if (tab) launch_chain_lds_t<MT_, true, 8>(fwd, a, la, shm, s);
-        else launch_chain_lds_t<MT_, false, 8>(fwd, a, la, shm, s);
-    } else {
-        if (tab) launch_chain_lds_t<MT_, true, 4>(fwd, a, la, shm, s);
-        else launch_chain_lds_t<MT_, false, 4>(fwd, a, la, shm, s);
-    }
-}
-// generation 2 of the cooperative chains (chains2.hpp): pass 0 and the re-run passes are separate instantiations
+// the cooperative chains (chains2.hpp): pass 0 and the re-run passes are separate instantiations
 template <int MT_, bool TAB_, bool RERUN_, bool HOT2_>
 static void launch_chain_coop2_tt(bool fwd, const ChainArgs &a, const CoopArgs &ca, size_t shm, hipStream_t s) {
     if (fwd) {
@@ -2127,27 +2009,11 @@ static void launch_chain_coop2_t(bool fwd, const ChainArgs &a, const CoopArgs &c
     if (a.hot2 >= 0) launch_chain_coop2_tt<MT_, TAB_, RERUN_, true>(fwd, a, ca, shm, s);
     else launch_chain_coop2_tt<MT_, TAB_, RERUN_, false>(fwd, a, ca, shm, s);
 }
-static int coop_generation() {
-    static const int gen = [] { const char *e = getenv("SMCPP_COOP_GEN"); return (e && atoi(e) == 1) ? 1 : 2; }();
-    return gen;
-}
 template <int MT_, bool TAB_>
 static void launch_chain_coop_t(bool fwd, const ChainArgs &a, const CoopArgs &ca, size_t shm, hipStream_t s) {
-    if (coop_generation() == 2) {
-        if (a.variant == 1) launch_chain_power_t<MT_, TAB_>(fwd, a, ca, shm, s);
-        else if (a.pass > 0 && a.variant != 2) launch_chain_coop2_t<MT_, TAB_, true>(fwd, a, ca, shm, s);
-        else launch_chain_coop2_t<MT_, TAB_, false>(fwd, a, ca, shm, s);
-        return;
-    }
-    if (fwd) {
-        static bool once = false;
-        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_fwd_coop<MT_, TAB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
-        hipLaunchKernelGGL((k_fwd_coop<MT_, TAB_>), dim3(a.nchunks), dim3(MT_ * 4), shm, s, a, ca);
-    } else {
-        static bool once = false;
-        if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_bwd_coop<MT_, TAB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
-        hipLaunchKernelGGL((k_bwd_coop<MT_, TAB_>), dim3(a.nchunks), dim3(MT_ * 4), shm, s, a, ca);
-    }
+    if (a.variant == 1) launch_chain_power_t<MT_, TAB_>(fwd, a, ca, shm, s);
+    else if (a.pass > 0 && a.variant != 2) launch_chain_coop2_t<MT_, TAB_, true>(fwd, a, ca, shm, s);
+    else launch_chain_coop2_t<MT_, TAB_, false>(fwd, a, ca, shm, s);
 }
 static bool launch_chain_coop(bool fwd, int Mp, const ChainArgs &a, const CoopArgs &ca, int tab, size_t shm, hipStream_t s) {
     switch (Mp) {
@@ -2194,26 +2060,6 @@ static bool launch_chain_big(bool fwd, int Mp, const ChainArgs &a, const BigArgs
         B_(80) B_(96) B_(112) B_(128) B_(144) B_(160) B_(176) B_(192) B_(208) B_(224) B_(240) B_(256)
 #undef B_
         default: return false;
-    }
-}
-
-static void launch_chain(bool fwd, int npl, int Mp, bool generic, const ChainArgs &a, const LdsArgs &la, int tab,
-                         int wpb, size_t shm, hipStream_t s) {
-    if (npl == 1 && !generic) {
-        switch (Mp) {
-            case 16: launch_chain_lds<16>(fwd, a, la, tab, wpb, shm, s); return;
-            case 32: launch_chain_lds<32>(fwd, a, la, tab, wpb, shm, s); return;
-            case 48: launch_chain_lds<48>(fwd, a, la, tab, wpb, shm, s); return;
-            case 64: launch_chain_lds<64>(fwd, a, la, tab, wpb, shm, s); return;
-            default: break;
-        }
-    }
-    switch (npl) {
-        case 1: launch_chain_generic<1>(fwd, a, s); break;
-        case 2: launch_chain_generic<2>(fwd, a, s); break;
-        case 3: launch_chain_generic<3>(fwd, a, s); break;
-        case 4: launch_chain_generic<4>(fwd, a, s); break;
-        default: throw std::runtime_error("unsupported number of hidden states");
     }
 }
 
@@ -2398,7 +2244,6 @@ void smcpp_im::stage_static_and_prepass() {
 void smcpp_im::run_chains() {
     hipStream_t s = stream;
     ChainArgs a = chain_args();
-    const bool generic = chain_mode == 0;
     CoopArgs cargs;
     cargs.K = K; cargs.G = G; cargs.power_off = 0;
     BigArgs bargs;
@@ -2407,26 +2252,6 @@ void smcpp_im::run_chains() {
     size_t shm_c = 0;
     int tab_c = 0;
     coop_lds(Mp, K, G, tab_c, shm_c);
-    // LDS budget of the resident kernels: matrices + (emission, eigenvalue-power) tables + per-wavefront scratch
-    LdsArgs lf, lb;
-    size_t shm_f = 0, shm_b = 0;
-    int tab_lds = 0;
-    {
-        const size_t mm = (size_t)Mp * Mp;
-        const int wave_bytes = 512 + Mp * 8 + Mp * 4;
-        const size_t tabs = (size_t)(K + G) * Mp * 8;
-        const size_t base_f = mm * 4 + 2 * mm * 8 + (size_t)wpb * wave_bytes;
-        const size_t base_b = 3 * mm * 8 + (size_t)wpb * wave_bytes;
-        const size_t cap = 160 * 1024;
-        const int tab = (std::max(base_f, base_b) + tabs <= cap) ? 1 : 0;
-        tab_lds = tab;
-        lf.K = K; lf.G = G; lf.wave_bytes = wave_bytes;
-        lf.T4 = d_T4.p; lf.A2 = d_fA2.p; lf.B2 = d_fB2.p; lf.C2 = nullptr;
-        lb = lf;
-        lb.T4 = nullptr; lb.A2 = d_bA2.p; lb.B2 = d_bB2.p; lb.C2 = d_bC2.p;
-        shm_f = base_f + (tab ? tabs : 0);
-        shm_b = base_b + (tab ? tabs : 0);
-    }
     const bool warm = warm_start && warm_valid && chain_mode == 2 && Mp <= 64 &&
                       d_warm_f.n == chunks.size() * (size_t)Mp && d_warm_b.n == chunks.size() * (size_t)Mp;
     a.warm_f = warm ? d_warm_f.p : nullptr;
@@ -2484,7 +2309,7 @@ void smcpp_im::run_chains() {
                 if (!(chain_mode == 4 && launch_chain_lock(true, Mp, a, s)) &&
                     !(chain_mode == 3 && launch_chain_big(true, Mp, a, bargs, s)) &&
                     !(chain_mode == 2 && launch_chain_coop(true, Mp, a, cargs, tab_c, shm_c, s)))
-                    launch_chain(true, NPL, Mp, generic, a, lf, tab_lds, wpb, shm_f, s);
+                    throw std::runtime_error("internal: no dense chain kernel for this number of hidden states");
             }
         }
         if (first_round) HIPCHK(hipEventRecord(ev[2], dual ? sb : s));
@@ -2495,7 +2320,7 @@ void smcpp_im::run_chains() {
                 if (!(chain_mode == 4 && launch_chain_lock(false, Mp, a, sb)) &&
                     !(chain_mode == 3 && launch_chain_big(false, Mp, a, bargs, sb)) &&
                     !(chain_mode == 2 && launch_chain_coop(false, Mp, a, cargs, tab_c, shm_c, sb)))
-                    launch_chain(false, NPL, Mp, generic, a, lb, tab_lds, wpb, shm_b, sb);
+                    throw std::runtime_error("internal: no dense chain kernel for this number of hidden states");
             }
         }
         HIPCHK(hipGetLastError());
@@ -2607,7 +2432,6 @@ static bool ss_generators(int M, int MS, const double *Tm, std::vector<double> &
 
 bool smcpp_im::ss_extract_generators() {
     if (!ss_generators(M, 64 * NPL, T.data(), ss_gen, ss_c0)) return false;
-    if (ss4 && !ss_generators(M, 16 * SPL, T.data(), ss_gen4, ss_c0)) return false;
     // a row of span s applies its operator s times without rescaling: keep clear of underflow
     // (a device-prepared table is checked by the kernel that forms it: DevPrep flag 2, looked at when the E-step has drained)
     if (!E_on_dev) for (const Group &gr : groups) {
@@ -2647,72 +2471,20 @@ static void launch_chain_ss(int npl, const SsArgs &a, int ntasks, size_t shm, hi
     }
 }
 
-#ifdef SMCPP_WITH_SS4
-template <int SPL_>
-static void launch_chain_ss4_t(const SsArgs &a, size_t shm, hipStream_t s) {
-    static bool once = false;
-    if (!once) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_chain_ss4<SPL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        once = true;
-    }
-    hipLaunchKernelGGL((k_chain_ss4<SPL_>), dim3((a.nchunks + 7) / 8), dim3(256), shm, s, a);
-}
-static void launch_chain_ss4(int spl, const SsArgs &a, size_t shm, hipStream_t s) {
-    switch (spl) {
-        case 1: launch_chain_ss4_t<1>(a, shm, s); break;
-        case 2: launch_chain_ss4_t<2>(a, shm, s); break;
-        case 3: launch_chain_ss4_t<3>(a, shm, s); break;
-        case 4: launch_chain_ss4_t<4>(a, shm, s); break;
-        default: throw std::runtime_error("unsupported number of hidden states");
-    }
-}
-#else
-static void launch_chain_ss4(int, const SsArgs &, size_t, hipStream_t) { throw std::runtime_error("built without SMCPP_WITH_SS4"); }
-#endif
 
 void smcpp_im::ss_launch_passes(int upto) {
     const size_t shm = (size_t)ss_nlds * 64 * NPL * sizeof(double) + ss_tab_bytes();
-    const size_t shm4 = (size_t)K * 16 * SPL * sizeof(double);
     for (; ss_launched < upto; ++ss_launched) {
-        // per direction: `light` store-free float passes (history), then one full fp64 pass from their end vectors, then re-run
+        // per direction: `light` store-free float passes (history), then one full pass from their end vectors, then re-run
         // passes; without light passes the first pass is the full one (from pi / the uniform vector)
         const int p = ss_launched;
         const bool lf = p < ss_light_f, lb = p < ss_light_b;
-        if (!ss4) {
-            ss_args.pass = p;
-            ss_args.mode_f = lf ? 2 : p == 0 ? 0 : 1;
-            ss_args.mode_b = lb ? 2 : p == 0 ? 0 : 1;
-            ss_args.full_f = (p > 0 && p == ss_light_f) ? 1 : 0;
-            ss_args.full_b = (p > 0 && p == ss_light_b) ? 1 : 0;
-            ss_args.nostore_f = ss_args.nostore_b = 0;
-            // The LAST history pass of a direction (all-float-scan stored passes only) runs the stored passes' own arithmetic without
-            // storing a row: its end vectors are exact to rounding instead of to the ~1e-5 the float light passes leave, so the stored
-            // pass behind it starts inside the certificate's tolerance wherever the history has converged and is not re-run.
-            if (ss_args.mixed && ss_acc_last) {
-                if (lf && p == ss_light_f - 1) { ss_args.mode_f = p == 0 ? 0 : 1; ss_args.full_f = p > 0 ? 1 : 0; ss_args.nostore_f = 1; }
-                if (lb && p == ss_light_b - 1) { ss_args.mode_b = p == 0 ? 0 : 1; ss_args.full_b = p > 0 ? 1 : 0; ss_args.nostore_b = 1; }
-            }
-            launch_chain_ss(NPL, ss_args, (int)ss_tasks.size(), shm, stream, ss_wg_waves);
-            continue;
-        }
-        // M <= 64: the light passes run on the coarse chunks (one chain per wavefront), the fp64 passes on the fine ones (four
-        // chains per wavefront); a direction's last light pass hands over the fine boundary vectors
-        if (lf || lb) {
-            ss_args.pass = p;
-            ss_args.mode_f = lf ? 2 : 3;
-            ss_args.mode_b = lb ? 2 : 3;
-            ss_args.hand_f = p == ss_light_f - 1;
-            ss_args.hand_b = p == ss_light_b - 1;
-            launch_chain_ss(NPL, ss_args, (int)ss_tasks.size(), shm, stream, ss_wg_waves);
-        }
-        if (!lf || !lb) {
-            ss4_args.pass = p;
-            ss4_args.mode_f = lf ? 3 : p == 0 ? 0 : 1;
-            ss4_args.mode_b = lb ? 3 : p == 0 ? 0 : 1;
-            ss4_args.full_f = (p > 0 && p == ss_light_f) ? 1 : 0;
-            ss4_args.full_b = (p > 0 && p == ss_light_b) ? 1 : 0;
-            launch_chain_ss4(SPL, ss4_args, shm4, stream);
-        }
+        ss_args.pass = p;
+        ss_args.mode_f = lf ? 2 : p == 0 ? 0 : 1;
+        ss_args.mode_b = lb ? 2 : p == 0 ? 0 : 1;
+        ss_args.full_f = (p > 0 && p == ss_light_f) ? 1 : 0;
+        ss_args.full_b = (p > 0 && p == ss_light_b) ? 1 : 0;
+        launch_chain_ss(NPL, ss_args, (int)ss_tasks.size(), shm, stream, ss_wg_waves);
     }
     HIPCHK(hipGetLastError());
 }
@@ -2725,9 +2497,7 @@ void smcpp_im::ss_launch_initial() {
     std::vector<float> &pi_f = hs_pi_f;
     if (pi_f.size() != (size_t)Mp) pi_f.assign(Mp, 0.f);
     for (int i = 0; i < M; ++i) pi_f[i] = (float)pi[i];
-    const int MS4 = 16 * SPL;
-    const size_t need = 12 * 256 + pi_f.size() * 4 + ss_gen.size() * 8 + (size_t)K * MS * 8 +
-                        (ss4 ? ss_gen4.size() * 8 + (size_t)K * MS4 * 8 : 0);
+    const size_t need = 12 * 256 + pi_f.size() * 4 + ss_gen.size() * 8 + (size_t)K * MS * 8;
     pre_stage.reset(need);
     if (need > pre_cap) {
         if (d_pre) (void)hipFree(d_pre);
@@ -2789,30 +2559,9 @@ void smcpp_im::ss_launch_initial() {
         const bool mixed_on = !(mx && atoi(mx) == 0);
         a.mixed = (mixed_on && !save_gamma && NPL == 1 && !ss_hybrid) ? 1 : 0;
     }
-    a.fine = nullptr; a.nfine = 0; a.hand_f = a.hand_b = 0; a.fine_ends_f = nullptr; a.fine_ends_b = nullptr;
     if (ss_hybrid) {
         a.hyb_th = ss_hyb_th; a.Ke = Ke; a.hot_ek = std::max(0, hot_eig); a.dirsplit = ss_dirsplit ? 1 : 0;
         a.Pinvrm = d_Pinvrm.p; a.Prm = d_Prm.p; a.PinvT = d_PinvT.p; a.PT = d_PT.p; a.dsc = d_dsc.p;
-    }
-    if (ss4) {
-        SsArgs &b4 = ss4_args;
-        b4 = a;                                  // fine chunks, fine end vectors, row state: as above
-        const double *g4 = reinterpret_cast<const double *>(put(ss_gen4.data(), ss_gen4.size() * 8));
-        b4.f_dc = g4; b4.f_g = g4 + MS4; b4.f_cg = g4 + 2 * MS4; b4.f_b = g4 + 3 * MS4; b4.f_a = g4 + 4 * MS4; b4.f_d = g4 + 5 * MS4;
-        b4.b_dc = g4 + 6 * MS4; b4.b_g = g4 + 7 * MS4; b4.b_b = g4 + 8 * MS4; b4.b_a = g4 + 9 * MS4;
-        {
-            const size_t eoff = (off + 255) & ~(size_t)255;
-            double *he = reinterpret_cast<double *>(pre_stage.base + eoff);
-            std::memset(he, 0, (size_t)K * MS4 * 8);
-            for (int k = 0; k < K; ++k)
-                std::memcpy(he + (size_t)ss_slot_of_key[k] * MS4, &E[(size_t)k * M], sizeof(double) * M);
-            b4.E = reinterpret_cast<const double *>(put(nullptr, (size_t)K * MS4 * 8));
-        }
-        // the light passes of the one-chain-per-wavefront kernels: coarse chunks, their own end vectors
-        a.chunks = d_chunks1.p; a.nchunks = (int)chunks1.size();
-        a.chunks_b = d_chunks1.p; a.nchunks_b = (int)chunks1.size();
-        a.ends_f = d_ends1_f.p; a.ends_b = d_ends1_b.p; a.used_f = nullptr; a.used_b = nullptr;
-        a.fine = d_chunks.p; a.nfine = (int)chunks.size(); a.fine_ends_f = d_ends_f.p; a.fine_ends_b = d_ends_b.p;
     }
     {
         // light passes: enough of them that the full pass starts ~11 e-folds of history in (the chains forget with an e-fold of
@@ -2820,22 +2569,21 @@ void smcpp_im::ss_launch_initial() {
         long long pos = 0;
         const int ef = getenv("SMCPP_SS_LIGHT_F") ? atoi(getenv("SMCPP_SS_LIGHT_F")) : -1;
         const int eb = getenv("SMCPP_SS_LIGHT_B") ? atoi(getenv("SMCPP_SS_LIGHT_B")) : -1;
-        pos = ss_positions / std::max<size_t>(1, ss4 ? chunks1.size() : chunks.size());
-        const long long pos_b = ss_positions / std::max<size_t>(1, ss4 ? chunks1.size() : chunks_b.size());
+        pos = ss_positions / std::max<size_t>(1, chunks.size());
+        const long long pos_b = ss_positions / std::max<size_t>(1, chunks_b.size());
         auto pick = [&](double hist, long long p_) { return p_ <= 0 || (double)p_ > 1.5 * hist ? 0 : std::min(4, (int)std::ceil(hist / (double)p_)); };
         ss_light_f = ef >= 0 ? ef : pick(2800.0, pos);
         ss_light_b = eb >= 0 ? eb : pick(3900.0, pos_b);
-        if ((ss4 ? chunks1.size() : chunks.size()) <= (size_t)n_contigs) ss_light_f = 0;      // one chunk per contig: nothing to iterate
-        if ((ss4 ? chunks1.size() : chunks_b.size()) <= (size_t)n_contigs) ss_light_b = 0;
+        if (chunks.size() <= (size_t)n_contigs) ss_light_f = 0;      // one chunk per contig: nothing to iterate
+        if (chunks_b.size() <= (size_t)n_contigs) ss_light_b = 0;
     }
     if (ss_hybrid) ss_light_f = ss_light_b = 0;      // (the light passes have no eigen-power step; un-binned inputs have long chunks)
-    { const char *ac = getenv("SMCPP_SS_ACC"); ss_acc_last = !(ac && atoi(ac) == 0); }
     // halo pass: the first pass enters every chunk through its halo and stores rows that are already exact; no light passes
     const bool use_halo = ss_halo && !(warm_start && ss_warm_valid) && chunks.size() > (size_t)n_contigs && chunks_b.size() > (size_t)n_contigs;
     if (use_halo) ss_light_f = ss_light_b = 0;
     a.halo = use_halo ? 1 : 0;
     ss_pass0 = 0;
-    if (warm_start && ss_warm_valid && !ss4 && chunks.size() > (size_t)n_contigs && chunks_b.size() > (size_t)n_contigs) {
+    if (warm_start && ss_warm_valid && chunks.size() > (size_t)n_contigs && chunks_b.size() > (size_t)n_contigs) {
         // the boundary vectors of the previous E-step are exact for ITS parameters, i.e. off by the parameter step instead of by
         // O(1): they replace one light pass; every stored row still comes from the full fp64 pass on the new parameters
         ss_pass0 = ss_warm_parity == 0 ? 1 : 2;
@@ -2921,7 +2669,7 @@ void smcpp_im::run_chains_ss() {
     last_fwd_passes = last_bwd_passes = q - p0;
     // every launched pass carried the end vectors forward (a skipped chunk copies them): they sit at the last pass's parity
     ss_warm_parity = (ss_launched - 1) & 1;
-    ss_warm_valid = !ss4;
+    ss_warm_valid = true;
 }
 
 void smcpp_im::run_stats() {
@@ -2977,8 +2725,7 @@ void smcpp_im::enqueue_stats() {
     // branches are ~100 and ~77 us: the span > 1 branch is still the longer one and keeps the main stream (922 against 910 evals/s);
     // SMCPP_STATS_VARIANT & 8 gives the main stream to the span-1 branch instead
     static const bool span_scan_off = getenv("SMCPP_SPAN_SCAN") && atoi(getenv("SMCPP_SPAN_SCAN")) == 0;
-    const bool use_fh = NT <= 4 && getenv("SMCPP_SPAN_FH") && atoi(getenv("SMCPP_SPAN_FH")) != 0;
-    const bool scan_fold = eigfree && ss_active && !ss4 && !span_scan_off && !use_fh;
+    const bool scan_fold = eigfree && ss_active && !span_scan_off;
     const bool swap_main = crit_main && scan_fold && (stats_variant & 8);
     hipStream_t se = crit_main ? (swap_main ? stream2 : s) : split_streams ? ((eigfree && (stats_variant & 1)) ? stream_hi : stream2) : s;
     hipStream_t sp1 = crit_main ? (swap_main ? s : stream2) : s;          // the span-1 branch
@@ -2993,15 +2740,13 @@ void smcpp_im::enqueue_stats() {
     // ride on the eigen stream instead of heading the critical path of the main one
     // ... and on a third stream when there is one: on un-binned data (a million rows per contig) they take 0.1 ms
     // (which form the span-1 statistics take decides which streams are free: details where they are launched, below)
-    const bool gfuse_on = getenv("SMCPP_GAMMA_FUSE") && atoi(getenv("SMCPP_GAMMA_FUSE")) != 0;
-    const bool gfuse = gfuse_on && (Mp + 63) / 64 == 1 && K <= 64 && !save_gamma && !slabs_rk.empty();
     // M <= 64, from half a million span-1 rows on: ONE pass over the span-1 rows in key-sorted order, single-key slabs - the rank
     // update and the key's gamma sums from the same operands (k_rank_acc<3>); k_s1_scalars and its second read of alpha / beta do
     // not run.  Measured: whole genome (3.6 M span-1 rows, bandwidth-bound) 3.77 -> 3.15 ms of statistics; one 100 Mbp contig
     // (129 k rows, one wavefront per SIMD, latency-bound) 0.208 -> 0.225 ms - there the gamma sums stay a third concurrent
     // branch.  SMCPP_S1_FUSE=0 / 1 forces either form.
     const char *kf_env = getenv("SMCPP_S1_FUSE");
-    const bool kfuse = !gfuse && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_fk.empty() &&
+    const bool kfuse = (Mp + 63) / 64 == 1 && !save_gamma && !slabs_fk.empty() &&
                        (kf_env ? atoi(kf_env) != 0 : (n_1_rows >= 500000 || crit_main));
     // (round 4: with the span > 1 branch on the main stream the span-1 statistics are ONE side branch in the one-pass form instead
     // of two - 887 against 873 headline evals per second, and 140 MB less traffic per E-step)
@@ -3030,13 +2775,13 @@ void smcpp_im::enqueue_stats() {
     aa.M = M; aa.Mp = Mp; aa.NB = (Mp + 63) / 64; aa.rowinfo = d_rowinfo.p; aa.alpha = d_alpha.p; aa.beta = d_beta.p;
     aa.w1 = d_w1.p; aa.cnorm = d_cnorm.p; aa.E = d_E.p; aa.Xs = d_Xs.p; aa.Ys = d_Ys.p;
     aa.gpart = nullptr;
-    // Eigen-free statistics: the span fold (k_span_FH: ~20 serial steps on a few CUs) ends the longest dependency chain of the
+    // Eigen-free statistics: the span fold (tens of serial steps on a few CUs) ends the longest dependency chain of the
     // phase, so what it waits for - the rank accumulation of the span > 1 rows - goes FIRST and alone; the span-1 branches start
     // behind it and run while the fold does
     // (small inputs only: from ~10^6 span > 1 rows on, the rank updates are bound by memory parallelism and the two of them
     // running side by side finish sooner than one after the other - whole genome: 3.76 -> 3.36 ms of statistics)
     const bool rank2_early = eigfree && split_streams && !slabs_eg.empty() && !(stats_variant & 2) && n_e_rows < 1000000;
-    const bool eig_gen2 = !eigfree && NT <= 4 && !slabs_eg.empty() && !(getenv("SMCPP_EIG_GEN") && atoi(getenv("SMCPP_EIG_GEN")) == 1);
+    const bool eig_gen2 = !eigfree && NT <= 4 && !slabs_eg.empty();      // (M > 64: the two-kernel form below)
     if (!slabs_eg.empty() && !eig_gen2) {
         d_part_e.alloc(std::max<size_t>(1, slabs_eg.size()) * Mp * Mp);
         fa.part_e = d_part_e.p;
@@ -3061,11 +2806,7 @@ void smcpp_im::enqueue_stats() {
     // ---- span-1 branch (main stream) ----
     // M <= 64: k_rank_acc forms the weights itself, so the per-key gamma sums (k_s1_scalars + their reduction) are a third
     // independent branch: own stream, joined before the finalisation
-    // SMCPP_GAMMA_FUSE=1 (M <= 64 and K <= 64): the gamma sums ride on the span-1 rank update (k_rank_acc_g) and k_s1_scalars does
-    // not run at all: 110 MB less traffic per headline E-step, but 12 more fp64 MFMAs per group of four rows on the critical
-    // stream (v_mfma_f64_16x16x4 is a 16-pass instruction on gfx950): 0.285 ms of statistics against 0.235 ms with the gamma sums
-    // as a third concurrent branch - measured, so the fusion is opt-in
-    const bool s1_own = !gfuse && !kfuse && dual_stream && stream3 != nullptr && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_sc.empty();
+    const bool s1_own = !kfuse && dual_stream && stream3 != nullptr && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_sc.empty();
     hipStream_t s1s = s1_own ? stream3 : sp1;
     if (s1_own) {
         if (crit_main) HIPCHK(hipStreamWaitEvent(s1s, ev_fork, 0));     // (forks where the span-1 branch does: at the chains' end)
@@ -3074,7 +2815,7 @@ void smcpp_im::enqueue_stats() {
             HIPCHK(hipStreamWaitEvent(s1s, ev[15], 0));
         }
     }
-    if (!slabs_sc.empty() && !gfuse && !kfuse) {
+    if (!slabs_sc.empty() && !kfuse) {
         S1Args sa;
         sa.M = M; sa.Mp = Mp; sa.nslabs = (int)slabs_sc.size(); sa.slabs = d_slabs_sc.p; sa.perm = d_perm1.p;
         sa.alpha = d_alpha.p; sa.beta = d_beta.p; sa.cnorm = d_cnorm.p; sa.w1 = d_w1.p; sa.gpart = d_gpart.p;
@@ -3100,24 +2841,12 @@ void smcpp_im::enqueue_stats() {
     } else
     if (!slabs_rk.empty()) {
         aa.nslabs = (int)slabs_rk.size(); aa.slabs = d_slabs_rk.p; aa.perm = d_perm1.p; aa.permk = d_perm1k.p; aa.part = d_part_1.p;
-        if (gfuse) {
-            d_gpart2.alloc((size_t)slabs_rk.size() * K * Mp);
-            switch ((K + 15) / 16) {
-                case 1: hipLaunchKernelGGL(k_rank_acc_g<1>, dim3(aa.nslabs), dim3(64), 0, sp1, aa, K, d_gpart2.p); break;
-                case 2: hipLaunchKernelGGL(k_rank_acc_g<2>, dim3(aa.nslabs), dim3(64), 0, sp1, aa, K, d_gpart2.p); break;
-                case 3: hipLaunchKernelGGL(k_rank_acc_g<3>, dim3(aa.nslabs), dim3(64), 0, sp1, aa, K, d_gpart2.p); break;
-                default: hipLaunchKernelGGL(k_rank_acc_g<4>, dim3(aa.nslabs), dim3(64), 0, sp1, aa, K, d_gpart2.p); break;
-            }
-            // gamma sums per contig: the slabs of a contig are contiguous (s1_slab_off), red_g is [contig][K][Mp]
-            hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(K * Mp, 256), n_contigs, 1), dim3(256), 0, sp1,
-                               (const double *)d_gpart2.p, (const int *)d_s1_slab_off.p, d_red_g.p, K * Mp, 1);
-        } else
         hipLaunchKernelGGL(k_rank_acc<0>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, sp1, aa);
     }
     // the per-key gamma sums only need the span-1 scalars: with two streams their reduction runs at the tail of the eigen
     // stream (which finishes earlier) instead of between the two rank-update kernels of the main one
-    const bool gsum_on_se = split_streams && !slabs_sc.empty() && !s1_own && !gfuse && !kfuse;
-    if (!gsum_on_se && !s1_own && !gfuse && !kfuse)
+    const bool gsum_on_se = split_streams && !slabs_sc.empty() && !s1_own && !kfuse;
+    if (!gsum_on_se && !s1_own && !kfuse)
         hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, 1), dim3(256), 0, sp1,
                            (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
     if (!kfuse)
@@ -3158,40 +2887,16 @@ void smcpp_im::enqueue_stats() {
                 default: SC_(4)
 #undef SC_
             }
-        } else
-        if (!use_fh) {
-            // strips of 16 rows (F) / columns (H), one workgroup each, F_t through scratch
+        } else {
+            // the fold on the matrix cores (round 3; SMCPP_SPAN_SCAN=0 or no scan chains): strips of 16 rows (F) / columns (H), one
+            // workgroup each, F_t through scratch
             d_Fall.alloc((size_t)n_contigs * Ke * ss_max_span * Mp * Mp);
             const int nstrip = NT, nwg = n_contigs * Ke * nstrip;
-            // SMCPP_SPAN_FUSED=1 (opt-in, measured SLOWER: DESIGN.md section 10): both phases in ONE launch, the H strips trailing the
-            // F strips by their prefetch distance through per-step counters in global memory instead of starting when F has finished.
-            // The device-wide fence every F step needs before it may publish, and the H workgroups polling beside it, cost more than
-            // the 30 serial steps saved: headline statistics 0.263 against 0.234 ms, M = 256 2.33 against 1.67 ms.
-            static const bool fused_on = getenv("SMCPP_SPAN_FUSED") && atoi(getenv("SMCPP_SPAN_FUSED")) != 0;
-            const bool fused = fused_on && 2 * nwg <= 256;
-            if (fused) {
-                const size_t nfl = (size_t)n_contigs * Ke * ss_max_span;
-                if (d_span_flags.n < nfl) { d_span_flags.alloc(nfl); HIPCHK(hipMemsetAsync(d_span_flags.p, 0, nfl * sizeof(int), se)); span_epoch = 0; }
-                ++span_epoch;
-                const int target = nstrip * span_epoch;
-#define B_(x) hipLaunchKernelGGL((k_span_fused<x>), dim3(2 * nwg), dim3(64 * x), 0, se, fa, ss_max_span, d_Fall.p, nwg, d_span_flags.p, target);
-                if (NT == 1) B_(1) else if (NT == 2) B_(2) else if (NT == 3) B_(3) else if (NT == 4) B_(4)
-                else if (NT <= 8) B_(8) else if (NT <= 12) B_(12) else B_(16)
-#undef B_
-            } else {
 #define B_(x) { hipLaunchKernelGGL((k_span_big<x, 0>), dim3(nwg), dim3(64 * x), 0, se, fa, ss_max_span, d_Fall.p); \
                 hipLaunchKernelGGL((k_span_big<x, 1>), dim3(nwg), dim3(64 * x), 0, se, fa, ss_max_span, d_Fall.p); }
             if (NT == 1) B_(1) else if (NT == 2) B_(2) else if (NT == 3) B_(3) else if (NT == 4) B_(4)
             else if (NT <= 8) B_(8) else if (NT <= 12) B_(12) else B_(16)
 #undef B_
-            }
-        } else
-        switch (NT) {
-#define S_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_span_FH<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
-                    hipLaunchKernelGGL(k_span_FH<x>, dim3(n_contigs * Ke), dim3(128 * x), shm, se, fa, ss_max_span); } break;
-            S_(1) S_(2) S_(3)
-            default: S_(4)
-#undef S_
         }
     }
     if (eig_gen2) {
@@ -3228,17 +2933,7 @@ void smcpp_im::enqueue_stats() {
         ua.M = M; ua.Mp = Mp; ua.nslabs = (int)slabs_eg.size(); ua.slabs = d_slabs_eg.p; ua.perm = d_perme.p;
         ua.alpha = d_alpha.p; ua.beta = d_beta.p; ua.g_eig = d_g_eig.p; ua.g_scale = d_g_scale.p;
         ua.dpow = d_dpow.p; ua.PinvT = d_PinvT.p; ua.Prm = d_Prm.p; ua.Xs = d_Xs.p; ua.Ys = d_Ys.p; ua.pos_gid = nullptr; ua.g_span = nullptr;
-        if (NT <= 4) {
-            const int nblk = ceil_div(ua.nslabs, 4);
-            const size_t shm = (size_t)2 * (16 * NT) * (16 * NT + 1) * sizeof(double);
-            switch (NT) {
-#define F_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_eig_fused<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
-                        hipLaunchKernelGGL(k_eig_fused<x>, dim3(nblk), dim3(256), shm, se, ua, d_part_e.p); } break;
-                F_(1) F_(2) F_(3)
-                default: F_(4)
-#undef F_
-            }
-        } else {
+        {
             launch_uw(NT, ua, se);
             AccArgs ae = aa;
             ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
@@ -3292,17 +2987,14 @@ void smcpp_im::enqueue_stats() {
         ga.slabs = d_slabs_eg.p; ga.g_eig = d_g_eig.p; ga.g_span = d_g_span.p; ga.dun = d_dun.p; ga.dsc = d_dsc.p; ga.dpow = d_dpow.p;
         ga.Prm = d_Prm.p; ga.Pinvrm = d_Pinvrm.p; ga.PinvT = d_PinvT.p; ga.Sq = nullptr;
         ga.alpha = d_alpha.p; ga.beta = d_beta.p; ga.gamma_rows = d_gamma_rows.p;
-        static const bool scalar_rows = getenv("SMCPP_GAMMA_ROWS_SCALAR") != nullptr;
-        // SMCPP_GAMMA_ROWS_GEN=1: generation 1 of the matrix-core kernel (span-Q table in memory, scalar u / w)
-        static const int rows_gen = getenv("SMCPP_GAMMA_ROWS_GEN") ? atoi(getenv("SMCPP_GAMMA_ROWS_GEN")) : 2;
-        const bool mfma_rows = NT <= 4 && !scalar_rows;
-        if (!mfma_rows || rows_gen == 1) {
+        const bool mfma_rows = NT <= 4;          // (M > 64: the scalar kernel on a span-Q table in memory)
+        if (!mfma_rows) {
             d_Sq.alloc((size_t)G * Mp * Mp);
             hipLaunchKernelGGL(k_span_q, dim3(nb2, G), dim3(256), 0, sg, M, Mp, G, (const int *)d_g_span.p,
                                (const int *)d_g_eig.p, (const double *)d_dsc.p, (const double *)d_dpow.p, d_Sq.p);
             ga.Sq = d_Sq.p;
         }
-        if (mfma_rows && rows_gen != 1) {
+        if (mfma_rows) {
             // one launch per (contig, eigen key): a workgroup shares one LDS copy of P, Pinv and the reciprocal eigenvalue differences
             // (NT > 2: the reciprocal differences live in registers and the fold tile is half as wide - four wavefronts fit as well)
             const int NW = 4;
@@ -3315,22 +3007,6 @@ void smcpp_im::enqueue_stats() {
                 switch (NT) {
 #define G_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_gamma_rows_b<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
                         hipLaunchKernelGGL(k_gamma_rows_b<x>, dim3(nblk), dim3(256), shm2, sg, ga, q0, q1, ce % Ke, nbatch); } break;
-                    G_(1) G_(2) G_(3)
-                    default: G_(4)
-#undef G_
-                }
-            }
-        } else if (mfma_rows) {
-            // generation 1: one launch per (contig, eigen key) so that a workgroup shares one LDS copy of P, Pinv
-            const size_t shm2 = (size_t)(2 * Mp * (Mp + 1) + 16 * Mp) * sizeof(double);
-            for (int ce = 0; ce < n_contigs * Ke; ++ce) {
-                const int q0 = ce_row_off[ce], q1 = ce_row_off[ce + 1];
-                if (q1 <= q0) continue;
-                const int rpw = std::max(1, std::min(16, (q1 - q0 + 4095) / 4096));      // rows per wavefront
-                const int nblk = ceil_div(q1 - q0, 4 * rpw);
-                switch (NT) {
-#define G_(x) case x: { static bool once = false; if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_gamma_rows_mfma<x>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
-                        hipLaunchKernelGGL(k_gamma_rows_mfma<x>, dim3(nblk), dim3(256), shm2, sg, ga, q0, q1, ce % Ke, rpw); } break;
                     G_(1) G_(2) G_(3)
                     default: G_(4)
 #undef G_
@@ -3407,7 +3083,7 @@ void smcpp_im::estep() {
     // only the lean path (scan chains + eigen-free statistics) reads a device-prepared emission table from HBM alone (its
     // underflow bound is checked by the kernel that forms the table); eigensystems, operand layouts, the dense chains and the
     // bound for longer spans need the host copy
-    if (E_on_dev && !(ss_static && eigfree_static && !ss4)) sync_host_E();
+    if (E_on_dev && !(ss_static && eigfree_static)) sync_host_E();
     ss_active = ss_static && ss_extract_generators();
     tr.mark("estep: extract generators");
     if (!ss_active) ss_warm_valid = false;
@@ -4019,7 +3695,7 @@ int smcpp_last_host_timing(smcpp_im *im, double out[4]) {
 
 void *smcpp_stream(smcpp_im *im) { return (void *)im->stream; }
 
-// which chain kernels this manager runs: 0 generic, 1 LDS-resident, 2 cooperative, 3 cooperative with streamed operands,
+// which chain kernels this manager runs: 2 cooperative, 3 cooperative with streamed operands,
 // 4 lock-step on the matrix cores (chosen at construction / smcpp_set_chunking from the state count and the input size)
 // 5 = scans over the semiseparable structure of T (chains_ss.hpp; the dense kernels named by the other values remain the
 // fallback of an E-step whose T has no such structure)
@@ -4036,9 +3712,22 @@ int smcpp_host_chunk_counts(int n_contigs, const long long *cost, const int *row
 int smcpp_chain_mode(smcpp_im *im) { return im ? (im->ss_static ? (im->ss_hybrid ? 6 : 5) : im->chain_mode) : -1; }
 
 // Test hook (tests/test_gpu_ss.py): one position of both scan chains on nvec vectors, out_f = e o (T^T x), out_b = T (e o x);
-// x, e and the outputs are [nvec][M].  Returns 2 when T has no semiseparable structure.
+// x, e and the outputs are [nvec][M].  Returns 2 when T has no semiseparable structure.  float_scans != 0 (M <= 64): the step of
+// the stored passes with every scan in float (chains_ss.hpp: ss_x_scan_fwd / ss_x_scan_bwd; the M <= 32 form when M <= 32).
+static int ss_debug_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b, int float_scans);
 int smcpp_debug_ss_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b) {
     API_BEGIN
+    return ss_debug_apply(M, T, nvec, x, e, out_f, out_b, 0);
+    API_END
+}
+int smcpp_debug_ss_apply_float_scans(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b) {
+    API_BEGIN
+    if (M > 64) throw std::runtime_error("the all-float scans hold one state per lane: M <= 64");
+    return ss_debug_apply(M, T, nvec, x, e, out_f, out_b, 1);
+    API_END
+}
+static int ss_debug_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b, int float_scans) {
+    {
     const int NPL = (M + 63) / 64, MS = 64 * NPL;
     if (NPL > 4) throw std::runtime_error("unsupported number of hidden states");
     std::vector<double> gen;
@@ -4059,7 +3748,9 @@ int smcpp_debug_ss_apply(int M, const double *T, int nvec, const double *x, cons
     a.f_dc = gd; a.f_g = gd + MS; a.f_cg = gd + 2 * MS; a.f_b = gd + 3 * MS; a.f_a = gd + 4 * MS; a.f_d = gd + 5 * MS;
     a.b_dc = gd + 6 * MS; a.b_g = gd + 7 * MS; a.b_b = gd + 8 * MS; a.b_a = gd + 9 * MS;
     a.c0 = c0;
-    switch (NPL) {
+    if (float_scans && M <= 32) hipLaunchKernelGGL((k_ss_apply<1, true, true>), dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec);
+    else if (float_scans) hipLaunchKernelGGL((k_ss_apply<1, true, false>), dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec);
+    else switch (NPL) {
         case 1: hipLaunchKernelGGL(k_ss_apply<1>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
         case 2: hipLaunchKernelGGL(k_ss_apply<2>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
         case 3: hipLaunchKernelGGL(k_ss_apply<3>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
@@ -4073,54 +3764,10 @@ int smcpp_debug_ss_apply(int M, const double *T, int nvec, const double *x, cons
         std::memcpy(out_f + (size_t)v * M, &hf[(size_t)v * MS], sizeof(double) * M);
         std::memcpy(out_b + (size_t)v * M, &hb[(size_t)v * MS], sizeof(double) * M);
     }
-    API_END
+    }
+    return 0;
 }
 
-// ... and of the four-chains-per-wavefront layout (M <= 64): same contract.
-int smcpp_debug_ss4_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b) {
-    API_BEGIN
-#ifndef SMCPP_WITH_SS4
-    (void)M; (void)T; (void)nvec; (void)x; (void)e; (void)out_f; (void)out_b;
-    throw std::runtime_error("built without SMCPP_WITH_SS4");
-#else
-    if (M > 64) throw std::runtime_error("four chains per wavefront: M <= 64");
-    const int SPL = (M + 15) / 16, MS = 16 * SPL;
-    std::vector<double> gen;
-    double c0 = 0.0;
-    if (!ss_generators(M, MS, T, gen, c0)) return 2;
-    std::vector<double> hx((size_t)nvec * MS, 0.0), he((size_t)nvec * MS, 0.0);
-    for (int v = 0; v < nvec; ++v) {
-        std::memcpy(&hx[(size_t)v * MS], x + (size_t)v * M, sizeof(double) * M);
-        std::memcpy(&he[(size_t)v * MS], e + (size_t)v * M, sizeof(double) * M);
-    }
-    DevBuf<double> dg, dx, de, df, db;
-    hipStream_t s = nullptr;
-    dg.upload(gen, s); dx.upload(hx, s); de.upload(he, s);
-    df.alloc(hx.size()); db.alloc(hx.size());
-    SsArgs a = SsArgs();
-    a.M = M;
-    const double *gd = dg.p;
-    a.f_dc = gd; a.f_g = gd + MS; a.f_cg = gd + 2 * MS; a.f_b = gd + 3 * MS; a.f_a = gd + 4 * MS; a.f_d = gd + 5 * MS;
-    a.b_dc = gd + 6 * MS; a.b_g = gd + 7 * MS; a.b_b = gd + 8 * MS; a.b_a = gd + 9 * MS;
-    a.c0 = c0;
-    const int nb = (nvec + 3) / 4;
-    switch (SPL) {
-        case 1: hipLaunchKernelGGL(k_ss4_apply<1>, dim3(nb), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
-        case 2: hipLaunchKernelGGL(k_ss4_apply<2>, dim3(nb), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
-        case 3: hipLaunchKernelGGL(k_ss4_apply<3>, dim3(nb), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
-        default: hipLaunchKernelGGL(k_ss4_apply<4>, dim3(nb), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
-    }
-    HIPCHK(hipGetLastError());
-    std::vector<double> hf(hx.size()), hb(hx.size());
-    HIPCHK(hipMemcpy(hf.data(), df.p, hf.size() * sizeof(double), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(hb.data(), db.p, hb.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (int v = 0; v < nvec; ++v) {
-        std::memcpy(out_f + (size_t)v * M, &hf[(size_t)v * MS], sizeof(double) * M);
-        std::memcpy(out_b + (size_t)v * M, &hb[(size_t)v * MS], sizeof(double) * M);
-    }
-#endif
-    API_END
-}
 
 int smcpp_device(smcpp_im *im) { return im ? im->device : -1; }
 int smcpp_set_debug(smcpp_im *im, int on) { API_BEGIN im->debug = on != 0; API_END }

@@ -148,662 +148,13 @@ struct ChainArgs {
     const double *warm_b;   // [nchunks][Mp] end vectors of the backward chunks
 };
 
-// y_i = sum_k Mt[k][i] x_k with Mt streamed from global memory (L2) and x broadcast from LDS.
-template <int NPL, typename TM, typename TX>
-__device__ __forceinline__ void matvec_global(const TM *__restrict__ Mt, const TX *xs, int M, int Mp, int lane,
-                                              TX (&y)[NPL]) {
-    TX acc[NPL][4];
-#pragma unroll
-    for (int q = 0; q < NPL; ++q) acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = (TX)0;
-    int k = 0;
-    for (; k + 8 <= M; k += 8) {
-        TM m[NPL][8];
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = lane + 64 * q;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) m[q][u] = (i < Mp) ? Mt[(size_t)(k + u) * Mp + i] : (TM)0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const TX x = xs[k + u];
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) acc[q][u & 3] = fma((TX)m[q][u], x, acc[q][u & 3]);
-        }
-    }
-    for (; k < M; ++k) {
-        const TX x = xs[k];
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = lane + 64 * q;
-            if (i < Mp) acc[q][0] = fma((TX)Mt[(size_t)k * Mp + i], x, acc[q][0]);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NPL; ++q) y[q] = (acc[q][0] + acc[q][1]) + (acc[q][2] + acc[q][3]);
-}
-
-// ---- forward ----------------------------------------------------------------------------------------------------
-// Generic variant (any M <= 64*NPL): every matrix is streamed from L2.  Used for M > 64 and as the reference
-// implementation the LDS-resident kernels below are tested against.
-template <int NPL>
-__global__ __launch_bounds__(64) void k_fwd_pass(ChainArgs a) {
-    __shared__ __attribute__((aligned(16))) double xs[NPL * 64];
-    __shared__ __attribute__((aligned(16))) float xf[NPL * 64];
-    const int lane = threadIdx.x;
-    const int c = blockIdx.x;
-    const int M = a.M, Mp = a.Mp, pass = a.pass;
-    if (pass > 0 && a.changed[pass - 1] == 0) return;     // the previous pass re-ran nothing: converged
-    const Chunk ch = a.chunks[c];
-    float *end_cur = a.ends_f + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
-    const float *end_prev = a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
-    float al[NPL];
-    if (pass > 0 && ch.first) {                            // exact since pass 0
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) end_cur[i] = end_prev[i]; }
-        return;
-    }
-    {
-        const float *src = (ch.first || pass == 0)
-                               ? a.pi_f
-                               : a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + (c - 1)) * Mp;
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; al[q] = (i < M) ? src[i] : 0.f; }
-    }
-    if (pass > 0) {
-        bool diff = false;
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = lane + 64 * q;
-            if (i < M) {
-                const float u = a.used_f[(size_t)c * Mp + i];
-                if (!(fabsf(al[q] - u) <= a.eps_f * fabsf(u))) diff = true;
-            }
-        }
-        if (!__any(diff)) {
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) end_cur[i] = end_prev[i]; }
-            return;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) a.used_f[(size_t)c * Mp + i] = al[q]; }
-    if (lane == 0) a.changed[pass] = 1;
-    if (ch.first) {
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = lane + 64 * q;
-            if (i < Mp) a.alpha[(size_t)ch.base * Mp + i] = al[q];
-        }
-        if (lane == 0) a.cnorm[ch.base] = 1.0;
-    }
-    // software pipeline: descriptor two rows ahead, emission / eigenvalue-power vectors one row ahead
-    const int2 *rd = a.rowdesc + ch.base;
-    int2 r_cur = rd[ch.r0 + 1];
-    int2 r_nxt = rd[min(ch.r0 + 2, ch.r1)];
-    double e_cur[NPL], dp_cur[NPL];
-#pragma unroll
-    for (int q = 0; q < NPL; ++q) {
-        const int i = lane + 64 * q;
-        e_cur[q] = (i < M) ? a.E[(size_t)r_cur.x * Mp + i] : 0.0;
-        dp_cur[q] = (i < M && r_cur.y >= 0) ? a.dpow[(size_t)SMCPP_GID(r_cur.y) * Mp + i] : 0.0;
-    }
-    for (int ell = ch.r0 + 1; ell <= ch.r1; ++ell) {
-        const int2 r_nn = rd[min(ell + 2, ch.r1)];
-        const int kid_n = __builtin_amdgcn_readfirstlane(r_nxt.x);
-        const int ge_n = __builtin_amdgcn_readfirstlane(r_nxt.y);
-        double e_nxt[NPL], dp_nxt[NPL];
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = lane + 64 * q;
-            e_nxt[q] = (i < M) ? a.E[(size_t)kid_n * Mp + i] : 0.0;
-            dp_nxt[q] = (i < M && ge_n >= 0) ? a.dpow[(size_t)SMCPP_GID(ge_n) * Mp + i] : 0.0;
-        }
-        const int ge = __builtin_amdgcn_readfirstlane(r_cur.y);
-        double cval;
-        if (ge < 0) {
-            // span == 1 (hmm.cpp:82-90): alpha' = float(diag(b) T^T) alpha, float arithmetic
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) xf[lane + 64 * q] = al[q];
-            wave_lds_fence();
-            float y[NPL];
-            matvec_global<NPL, float, float>(a.Tf, xf, M, Mp, lane, y);
-            float part = 0.f;
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) {
-                al[q] = (float)((double)y[q] * e_cur[q]);
-                part += al[q];
-            }
-            const float s = wave_sum_dpp(part);
-            cval = (double)s;
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) al[q] = al[q] / s;
-        } else {
-            // span > 1 (hmm.cpp:72-81): a = P (d~^span o (Pinv alpha)), double arithmetic
-            const int es = SMCPP_ES(ge);
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = (double)al[q];
-            wave_lds_fence();
-            double u[NPL], av[NPL];
-            {
-                matvec_global<NPL, double, double>(a.PinvT + (size_t)es * Mp * Mp, xs, M, Mp, lane, u);
-                wave_lds_fence();
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = u[q] * dp_cur[q];
-                wave_lds_fence();
-                matvec_global<NPL, double, double>(a.PT + (size_t)es * Mp * Mp, xs, M, Mp, lane, av);
-            }
-            double part = 0.0;
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) {
-                const int i = lane + 64 * q;
-                if (!(i < M)) av[q] = 0.0;
-                part += av[q];
-            }
-            const double s = wave_sum_dpp(part);
-            cval = s;
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) al[q] = (float)(av[q] / s);
-        }
-        // clamp without renormalising (hmm.cpp:92-94)
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = lane + 64 * q;
-            if (i < M) { if (al[q] < 1e-10f) al[q] = 1e-10f; } else al[q] = 0.f;
-            if (i < Mp) a.alpha[(size_t)(ch.base + ell) * Mp + i] = al[q];
-        }
-        if (lane == 0) a.cnorm[ch.base + ell] = cval;
-        wave_lds_fence();
-        r_cur = r_nxt; r_nxt = r_nn;
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) { e_cur[q] = e_nxt[q]; dp_cur[q] = dp_nxt[q]; }
-    }
-#pragma unroll
-    for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) end_cur[i] = al[q]; }
-}
-
-// ---- backward ---------------------------------------------------------------------------------------------------
-// beta[ell] = the vector the reference holds when it processes row ell; beta[0] = the final one.
-template <int NPL>
-__global__ __launch_bounds__(64) void k_bwd_pass(ChainArgs a) {
-    __shared__ __attribute__((aligned(16))) double xs[NPL * 64];
-    const int lane = threadIdx.x;
-    const int c = blockIdx.x;
-    const int M = a.M, Mp = a.Mp, pass = a.pass;
-    if (pass > 0 && a.changed[pass - 1] == 0) return;
-    const Chunk ch = a.chunks[c];
-    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
-    const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
-    double b[NPL];
-    if (pass > 0 && ch.last) {
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) end_cur[i] = end_prev[i]; }
-        return;
-    }
-    {
-        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (c + 1)) * Mp;
-        const bool fresh = (ch.last || pass == 0);
-        const double u0 = 1.0 / (double)M;
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = lane + 64 * q;
-            b[q] = (i < M) ? (fresh ? u0 : src[i]) : 0.0;
-        }
-    }
-    if (pass > 0) {
-        bool diff = false;
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = lane + 64 * q;
-            if (i < M) {
-                const double u = a.used_b[(size_t)c * Mp + i];
-                if (!(fabs(b[q] - u) <= a.eps_b * fabs(u))) diff = true;
-            }
-        }
-        if (!__any(diff)) {
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) end_cur[i] = end_prev[i]; }
-            return;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NPL; ++q) { const int i = lane + 64 * q; if (i < Mp) a.used_b[(size_t)c * Mp + i] = b[q]; }
-    if (lane == 0) a.changed[pass] = 1;
-    const int2 *rd = a.rowdesc + ch.base;
-    int2 r_cur = rd[ch.r1];
-    int2 r_nxt = rd[max(ch.r1 - 1, ch.r0 + 1)];
-    double e_cur[NPL], dp_cur[NPL];
-#pragma unroll
-    for (int q = 0; q < NPL; ++q) {
-        const int i = lane + 64 * q;
-        e_cur[q] = (i < M) ? a.E[(size_t)r_cur.x * Mp + i] : 0.0;
-        dp_cur[q] = (i < M && r_cur.y >= 0) ? a.dpow[(size_t)SMCPP_GID(r_cur.y) * Mp + i] : 0.0;
-    }
-    for (int ell = ch.r1; ell > ch.r0; --ell) {
-        const int2 r_nn = rd[max(ell - 2, ch.r0 + 1)];
-        const int kid_n = __builtin_amdgcn_readfirstlane(r_nxt.x);
-        const int ge_n = __builtin_amdgcn_readfirstlane(r_nxt.y);
-        double e_nxt[NPL], dp_nxt[NPL];
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = lane + 64 * q;
-            e_nxt[q] = (i < M) ? a.E[(size_t)kid_n * Mp + i] : 0.0;
-            dp_nxt[q] = (i < M && ge_n >= 0) ? a.dpow[(size_t)SMCPP_GID(ge_n) * Mp + i] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = lane + 64 * q;
-            if (i < Mp) a.beta[(size_t)(ch.base + ell) * Mp + i] = b[q];
-        }
-        const int ge = __builtin_amdgcn_readfirstlane(r_cur.y);
-        double bn[NPL];
-        if (ge < 0) {
-            // beta <- T (B beta)   (hmm.cpp:139)
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = e_cur[q] * b[q];
-            wave_lds_fence();
-            matvec_global<NPL, double, double>(a.TdT, xs, M, Mp, lane, bn);
-        } else {
-            // beta <- Pinv^T (d~^span o (P^T beta))   (hmm.cpp:123-127; the log/exp there only rescales)
-            const int es = SMCPP_ES(ge);
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = b[q];
-            wave_lds_fence();
-            double w[NPL];
-            {
-                matvec_global<NPL, double, double>(a.Prm + (size_t)es * Mp * Mp, xs, M, Mp, lane, w);
-                wave_lds_fence();
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) xs[lane + 64 * q] = w[q] * dp_cur[q];
-                wave_lds_fence();
-                matvec_global<NPL, double, double>(a.Pinvrm + (size_t)es * Mp * Mp, xs, M, Mp, lane, bn);
-            }
-        }
-        double part = 0.0;
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const int i = lane + 64 * q;
-            if (!(i < M)) bn[q] = 0.0;
-            part += bn[q];
-        }
-        const double s = wave_sum_dpp(part);               // beta /= beta.sum()  (hmm.cpp:142)
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) b[q] = bn[q] / s;
-        wave_lds_fence();
-        r_cur = r_nxt; r_nxt = r_nn;
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) { e_cur[q] = e_nxt[q]; dp_cur[q] = dp_nxt[q]; }
-    }
-#pragma unroll
-    for (int q = 0; q < NPL; ++q) {
-        const int i = lane + 64 * q;
-        if (i < Mp) {
-            end_cur[i] = b[q];
-            if (ch.first) a.beta[(size_t)ch.base * Mp + i] = b[q];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// K1' / K2': LDS-resident chains for M <= 64 (Mp == MT in {16,32,48,64}).
-// One workgroup = WPB wavefronts = WPB chunks.  The float transition matrix, the hot eigen key's two fp64 matrices,
-// the emission table and the eigenvalue-power table are staged once per workgroup into LDS (160 KiB per CU on
-// gfx950) in a k-blocked layout so that every matrix read is a conflict-free ds_read_b128 and every x_k read a
-// broadcast ds_read_b128; the row loop touches global memory only to store alpha/beta/c (never waited on) and to
-// fetch 64 row descriptors at a time.  No workgroup barrier after the staging barrier: wavefronts are independent.
-// ---------------------------------------------------------------------------------------------------------------
-struct LdsArgs {
-    int K, G;                 // table sizes; the TAB=true kernels keep the emission / power tables in LDS
-    int wave_bytes;           // per-wavefront scratch: 64 descriptors + xs[MT] + xf[MT]
-    const float *T4;          // fwd: Tf packed  [MT/4][MT][4];   bwd: unused
-    const double *A2;         // fwd: PinvT of the hot key packed [MT/2][MT][2];  bwd: TdT packed
-    const double *B2;         // fwd: PT of the hot key packed;                   bwd: P (row-major) of the hot key packed
-    const double *C2;         // bwd: Pinv (row-major) of the hot key packed
-};
-
-// y_li = sum_k M[k][li] x_k from the k-blocked LDS layout.  Operands are fetched in double-buffered batches of
-// BT + BT ds_read_b128: the reads of batch b+1 are issued before the FMAs of batch b, so up to 4*BT LDS reads are
-// in flight per wavefront.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct f32x4p { f32x2 lo, hi; };   // 16 bytes: (x, y), (z, w)
-
-template <int MT, int BT>
-__device__ __forceinline__ float mv_lds(const float *sM, const float *x, int li) {
-    f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};        // packed accumulators: one v_pk_fma_f32 each
-    constexpr int NB = MT / 4;                        // float4 blocks
-    constexpr int B = (NB % BT == 0) ? BT : 4;        // MT = 48: 12 blocks
-    f32x4p m[2][B], v[2][B];
-#pragma unroll
-    for (int u = 0; u < B; ++u) {
-        m[0][u] = reinterpret_cast<const f32x4p *>(sM)[u * MT + li];
-        v[0][u] = reinterpret_cast<const f32x4p *>(x)[u];
-    }
-#pragma unroll
-    for (int b0 = 0; b0 < NB; b0 += B) {
-        const int cur = (b0 / B) & 1, nxt = cur ^ 1;
-        if (b0 + B < NB) {
-#pragma unroll
-            for (int u = 0; u < B; ++u) {
-                m[nxt][u] = reinterpret_cast<const f32x4p *>(sM)[(b0 + B + u) * MT + li];
-                v[nxt][u] = reinterpret_cast<const f32x4p *>(x)[b0 + B + u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < B; ++u) {
-            a01 = __builtin_elementwise_fma(m[cur][u].lo, v[cur][u].lo, a01);
-            a23 = __builtin_elementwise_fma(m[cur][u].hi, v[cur][u].hi, a23);
-        }
-    }
-    return (a01.x + a01.y) + (a23.x + a23.y);
-}
-template <int MT, int BT>
-__device__ __forceinline__ double mv_lds(const double *sM, const double *x, int li) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    constexpr int NB = MT / 2;                        // double2 blocks: 8, 16, 24, 32
-    constexpr int B = (NB % BT == 0) ? BT : 4;
-    double2 m[2][B], v[2][B];
-#pragma unroll
-    for (int u = 0; u < B; ++u) {
-        m[0][u] = reinterpret_cast<const double2 *>(sM)[u * MT + li];
-        v[0][u] = reinterpret_cast<const double2 *>(x)[u];
-    }
-#pragma unroll
-    for (int b0 = 0; b0 < NB; b0 += B) {
-        const int cur = (b0 / B) & 1, nxt = cur ^ 1;
-        if (b0 + B < NB) {
-#pragma unroll
-            for (int u = 0; u < B; ++u) {
-                m[nxt][u] = reinterpret_cast<const double2 *>(sM)[(b0 + B + u) * MT + li];
-                v[nxt][u] = reinterpret_cast<const double2 *>(x)[b0 + B + u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < B; u += 2) {
-            a0 = fma(m[cur][u].x, v[cur][u].x, a0);
-            a1 = fma(m[cur][u].y, v[cur][u].y, a1);
-            a2 = fma(m[cur][u + 1].x, v[cur][u + 1].x, a2);
-            a3 = fma(m[cur][u + 1].y, v[cur][u + 1].y, a3);
-        }
-    }
-    return (a0 + a1) + (a2 + a3);
-}
 
 __device__ __forceinline__ void lds_stage(void *dst, const void *src, int nbytes, int tid, int nthreads) {
     uint4 *d = reinterpret_cast<uint4 *>(dst);
     const uint4 *s = reinterpret_cast<const uint4 *>(src);
     for (int i = tid; i < nbytes / 16; i += nthreads) d[i] = s[i];
-}
-
-template <int MT, bool TAB, int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_fwd_lds(ChainArgs a, LdsArgs la) {
-    constexpr int BT = WPB <= 4 ? 8 : 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
-    const int M = a.M, pass = a.pass;
-    constexpr int Mp = MT;
-    if (pass > 0 && a.changed[pass - 1] == 0) return;
-    float *sT = reinterpret_cast<float *>(smem);
-    double *sA = reinterpret_cast<double *>(smem + (size_t)MT * MT * 4);
-    double *sB = sA + MT * MT;
-    double *sE = sB + MT * MT;
-    double *sD = sE + (TAB ? la.K * MT : 0);
-    unsigned char *wb = reinterpret_cast<unsigned char *>(sD + (TAB ? la.G * MT : 0)) + (size_t)wave * la.wave_bytes;
-    int2 *sdesc = reinterpret_cast<int2 *>(wb);
-    double *xs = reinterpret_cast<double *>(wb + 512);
-    float *xf = reinterpret_cast<float *>(wb + 512 + MT * 8);
-    lds_stage(sT, la.T4, MT * MT * 4, tid, nthreads);
-    if (a.hot >= 0) {
-        lds_stage(sA, la.A2, MT * MT * 8, tid, nthreads);
-        lds_stage(sB, la.B2, MT * MT * 8, tid, nthreads);
-    }
-    if (TAB) {
-        lds_stage(sE, a.E, la.K * MT * 8, tid, nthreads);
-        if (la.G > 0) lds_stage(sD, a.dpow, la.G * MT * 8, tid, nthreads);
-    }
-    __syncthreads();
-    const int c = blockIdx.x * (nthreads >> 6) + wave;
-    if (c >= a.nchunks) return;
-    const Chunk ch = a.chunks[c];
-    float *end_cur = a.ends_f + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
-    const float *end_prev = a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
-    const bool act = lane < MT;
-    const int li = act ? lane : MT - 1;
-    if (pass > 0 && ch.first) {
-        if (act) end_cur[lane] = end_prev[lane];
-        return;
-    }
-    float al;
-    {
-        const float *src = (ch.first || pass == 0)
-                               ? a.pi_f
-                               : a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + (c - 1)) * Mp;
-        al = (lane < M) ? src[lane] : 0.f;
-    }
-    if (pass > 0) {
-        bool diff = false;
-        if (lane < M) {
-            const float u = a.used_f[(size_t)c * Mp + lane];
-            if (!(fabsf(al - u) <= a.eps_f * fabsf(u))) diff = true;
-        }
-        if (!__any(diff)) {
-            if (act) end_cur[lane] = end_prev[lane];
-            return;
-        }
-    }
-    if (act) a.used_f[(size_t)c * Mp + lane] = al;
-    if (lane == 0) a.changed[pass] = 1;
-    if (ch.first) {
-        if (act) a.alpha[(size_t)ch.base * Mp + lane] = al;
-        if (lane == 0) a.cnorm[ch.base] = 1.0;
-    }
-    const int2 *rd = a.rowdesc + ch.base;
-    const int nrows = ch.r1 - ch.r0;
-    // descriptor batches of 64 rows: batch b sits in LDS while batch b+1 is already in flight in a register
-    int2 dnext;
-    {
-        const int r = ch.r0 + 1 + lane;
-        int2 d0 = (lane < nrows) ? rd[r] : make_int2(0, -1);
-        sdesc[lane] = d0;
-        const int r2 = r + 64;
-        dnext = (lane + 64 < nrows) ? rd[r2] : make_int2(0, -1);
-    }
-    wave_lds_fence();
-    // one-row-ahead pipeline of (descriptor, emission value, eigenvalue power)
-    int2 r_cur = sdesc[0];
-    int kid = __builtin_amdgcn_readfirstlane(r_cur.x), ge = __builtin_amdgcn_readfirstlane(r_cur.y);
-    double e_cur = TAB ? sE[kid * MT + li] : a.E[(size_t)kid * Mp + li];
-    double dp_cur = (ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + li] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + li]) : 0.0;
-    for (int j = 0; j < nrows; ++j) {
-        const int ell = ch.r0 + 1 + j;
-        const int jb = j & 63;
-        // fetch the next row's descriptor / vectors (next batch is swapped in when this batch is exhausted)
-        int kid_n = 0, ge_n = -1;
-        double e_nxt = 0.0, dp_nxt = 0.0;
-        if (jb == 63) {
-            wave_lds_fence();
-            sdesc[lane] = dnext;
-            const int r2 = ch.r0 + 1 + (j + 1) + 64 + lane;
-            dnext = (j + 1 + 64 + lane < nrows) ? rd[r2] : make_int2(0, -1);
-            wave_lds_fence();
-        }
-        if (j + 1 < nrows) {
-            const int2 rn = sdesc[(jb + 1) & 63];
-            kid_n = __builtin_amdgcn_readfirstlane(rn.x);
-            ge_n = __builtin_amdgcn_readfirstlane(rn.y);
-            e_nxt = TAB ? sE[kid_n * MT + li] : a.E[(size_t)kid_n * Mp + li];
-            if (ge_n >= 0) dp_nxt = TAB ? sD[SMCPP_GID(ge_n) * MT + li] : a.dpow[(size_t)SMCPP_GID(ge_n) * Mp + li];
-        }
-        double cval;
-        if (ge < 0) {
-            // span == 1 (hmm.cpp:82-90)
-            if (act) xf[lane] = al;
-            wave_lds_fence();
-            const float y = mv_lds<MT, BT>(sT, xf, li);
-            al = (lane < M) ? (float)((double)y * e_cur) : 0.f;
-            const float s = wave_sum_dpp(al);
-            cval = (double)s;
-            al = al / s;
-        } else {
-            // span > 1 (hmm.cpp:72-81)
-            const int es = SMCPP_ES(ge);
-            if (act) xs[lane] = (double)al;
-            wave_lds_fence();
-            double av;
-            if (es == a.hot) {
-                const double u = mv_lds<MT, BT>(sA, xs, li) * dp_cur;
-                wave_lds_fence();
-                if (act) xs[lane] = u;
-                wave_lds_fence();
-                av = mv_lds<MT, BT>(sB, xs, li);
-            } else {
-                double u1[1], a1[1];
-                matvec_global<1, double, double>(a.PinvT + (size_t)es * Mp * Mp, xs, M, Mp, lane, u1);
-                wave_lds_fence();
-                if (act) xs[lane] = u1[0] * dp_cur;
-                wave_lds_fence();
-                matvec_global<1, double, double>(a.PT + (size_t)es * Mp * Mp, xs, M, Mp, lane, a1);
-                av = a1[0];
-            }
-            if (!(lane < M)) av = 0.0;
-            const double s = wave_sum_dpp(av);
-            cval = s;
-            al = (float)(av / s);
-        }
-        if (lane < M) { if (al < 1e-10f) al = 1e-10f; } else al = 0.f;      // clamp, hmm.cpp:92-94
-        if (act) a.alpha[(size_t)(ch.base + ell) * Mp + lane] = al;
-        if (lane == 0) a.cnorm[ch.base + ell] = cval;
-        wave_lds_fence();
-        kid = kid_n; ge = ge_n; e_cur = e_nxt; dp_cur = dp_nxt;
-    }
-    if (act) end_cur[lane] = al;
-}
-
-template <int MT, bool TAB, int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_bwd_lds(ChainArgs a, LdsArgs la) {
-    constexpr int BT = WPB <= 4 ? 8 : 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
-    const int M = a.M, pass = a.pass;
-    constexpr int Mp = MT;
-    if (pass > 0 && a.changed[pass - 1] == 0) return;
-    double *sA = reinterpret_cast<double *>(smem);     // TdT
-    double *sB = sA + MT * MT;                         // P   (row-major)
-    double *sC = sB + MT * MT;                         // Pinv (row-major)
-    double *sE = sC + MT * MT;
-    double *sD = sE + (TAB ? la.K * MT : 0);
-    unsigned char *wb = reinterpret_cast<unsigned char *>(sD + (TAB ? la.G * MT : 0)) + (size_t)wave * la.wave_bytes;
-    int2 *sdesc = reinterpret_cast<int2 *>(wb);
-    double *xs = reinterpret_cast<double *>(wb + 512);
-    lds_stage(sA, la.A2, MT * MT * 8, tid, nthreads);
-    if (a.hot >= 0) {
-        lds_stage(sB, la.B2, MT * MT * 8, tid, nthreads);
-        lds_stage(sC, la.C2, MT * MT * 8, tid, nthreads);
-    }
-    if (TAB) {
-        lds_stage(sE, a.E, la.K * MT * 8, tid, nthreads);
-        if (la.G > 0) lds_stage(sD, a.dpow, la.G * MT * 8, tid, nthreads);
-    }
-    __syncthreads();
-    const int c = blockIdx.x * (nthreads >> 6) + wave;
-    if (c >= a.nchunks) return;
-    const Chunk ch = a.chunks[c];
-    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
-    const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
-    const bool act = lane < MT;
-    const int li = act ? lane : MT - 1;
-    if (pass > 0 && ch.last) {
-        if (act) end_cur[lane] = end_prev[lane];
-        return;
-    }
-    double b;
-    {
-        const double *src = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (c + 1)) * Mp;
-        const bool fresh = (ch.last || pass == 0);
-        b = (lane < M) ? (fresh ? 1.0 / (double)M : src[lane]) : 0.0;
-    }
-    if (pass > 0) {
-        bool diff = false;
-        if (lane < M) {
-            const double u = a.used_b[(size_t)c * Mp + lane];
-            if (!(fabs(b - u) <= a.eps_b * fabs(u))) diff = true;
-        }
-        if (!__any(diff)) {
-            if (act) end_cur[lane] = end_prev[lane];
-            return;
-        }
-    }
-    if (act) a.used_b[(size_t)c * Mp + lane] = b;
-    if (lane == 0) a.changed[pass] = 1;
-    const int2 *rd = a.rowdesc + ch.base;
-    const int nrows = ch.r1 - ch.r0;
-    // rows are visited ell = r1, r1-1, ...; position j <-> ell = r1 - j
-    int2 dnext;
-    {
-        int2 d0 = (lane < nrows) ? rd[ch.r1 - lane] : make_int2(0, -1);
-        sdesc[lane] = d0;
-        dnext = (lane + 64 < nrows) ? rd[ch.r1 - lane - 64] : make_int2(0, -1);
-    }
-    wave_lds_fence();
-    int2 r_cur = sdesc[0];
-    int kid = __builtin_amdgcn_readfirstlane(r_cur.x), ge = __builtin_amdgcn_readfirstlane(r_cur.y);
-    double e_cur = TAB ? sE[kid * MT + li] : a.E[(size_t)kid * Mp + li];
-    double dp_cur = (ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + li] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + li]) : 0.0;
-    for (int j = 0; j < nrows; ++j) {
-        const int ell = ch.r1 - j;
-        const int jb = j & 63;
-        int kid_n = 0, ge_n = -1;
-        double e_nxt = 0.0, dp_nxt = 0.0;
-        if (jb == 63) {
-            wave_lds_fence();
-            sdesc[lane] = dnext;
-            dnext = (j + 1 + 64 + lane < nrows) ? rd[ch.r1 - (j + 1) - 64 - lane] : make_int2(0, -1);
-            wave_lds_fence();
-        }
-        if (j + 1 < nrows) {
-            const int2 rn = sdesc[(jb + 1) & 63];
-            kid_n = __builtin_amdgcn_readfirstlane(rn.x);
-            ge_n = __builtin_amdgcn_readfirstlane(rn.y);
-            e_nxt = TAB ? sE[kid_n * MT + li] : a.E[(size_t)kid_n * Mp + li];
-            if (ge_n >= 0) dp_nxt = TAB ? sD[SMCPP_GID(ge_n) * MT + li] : a.dpow[(size_t)SMCPP_GID(ge_n) * Mp + li];
-        }
-        if (act) a.beta[(size_t)(ch.base + ell) * Mp + lane] = b;
-        double bn;
-        if (ge < 0) {
-            // beta <- T (B beta)   (hmm.cpp:139)
-            if (act) xs[lane] = (lane < M) ? e_cur * b : 0.0;
-            wave_lds_fence();
-            bn = mv_lds<MT, BT>(sA, xs, li);
-        } else {
-            // beta <- Pinv^T (d~^span o (P^T beta))   (hmm.cpp:123-127)
-            const int es = SMCPP_ES(ge);
-            if (act) xs[lane] = b;
-            wave_lds_fence();
-            if (es == a.hot) {
-                const double w = mv_lds<MT, BT>(sB, xs, li) * dp_cur;
-                wave_lds_fence();
-                if (act) xs[lane] = w;
-                wave_lds_fence();
-                bn = mv_lds<MT, BT>(sC, xs, li);
-            } else {
-                double w1[1], b1[1];
-                matvec_global<1, double, double>(a.Prm + (size_t)es * Mp * Mp, xs, M, Mp, lane, w1);
-                wave_lds_fence();
-                if (act) xs[lane] = w1[0] * dp_cur;
-                wave_lds_fence();
-                matvec_global<1, double, double>(a.Pinvrm + (size_t)es * Mp * Mp, xs, M, Mp, lane, b1);
-                bn = b1[0];
-            }
-        }
-        if (!(lane < M)) bn = 0.0;
-        const double s = wave_sum_dpp(bn);                 // beta /= beta.sum()  (hmm.cpp:142)
-        b = bn / s;
-        wave_lds_fence();
-        kid = kid_n; ge = ge_n; e_cur = e_nxt; dp_cur = dp_nxt;
-    }
-    if (act) {
-        end_cur[lane] = b;
-        if (ch.first) a.beta[(size_t)ch.base * Mp + lane] = b;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -854,470 +205,6 @@ __device__ __forceinline__ double rcp_f64(double s) {
     r = fma(fma(-s, r, 1.0), r, r);
     r = fma(fma(-s, r, 1.0), r, r);
     return r;
-}
-
-// The producer of a row writes its unnormalised output vector only; every consumer lane re-derives the normaliser from
-// the quarter of the vector it reads anyway (KQ adds + the quad reduction it needs for the mat-vec), so the chain
-// needs ONE barrier per mat-vec and no cross-wavefront sum exchange.
-template <int MT, bool TAB>
-__global__ __launch_bounds__(MT * 4) void k_fwd_coop(ChainArgs a, CoopArgs ca) {
-    constexpr int NW = MT / 16, KQ = MT / 4, Mp = MT, UP = KQ + 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int il = lane >> 2, kq = lane & 3, i = 16 * w + il;
-    const bool owner = kq == 0;
-    const int M = a.M, pass = a.pass, c = blockIdx.x;
-    if (pass > 0 && a.changed[pass - 1] == 0) return;
-    // ---- LDS carve-up ----
-    double *sE = reinterpret_cast<double *>(smem);
-    double *sD = sE + (TAB ? ca.K * MT : 0);
-    double *ub = sD + (TAB ? ca.G * MT : 0);                 // [4][UP]   u exchange of eigen rows
-    float *xf = reinterpret_cast<float *>(ub + 4 * UP);       // [2][MT]   unnormalised chain state (float)
-    int2 *sdesc = reinterpret_cast<int2 *>(xf + 2 * MT);      // [2][64]   row descriptors
-    int *sflag = reinterpret_cast<int *>(sdesc + 128);        // [1]
-    int *mflag = sflag + 4;                                    // [4] per-wavefront "not merged yet" flags
-    if (TAB) {
-        lds_stage(sE, a.E, ca.K * MT * 8, tid, NW * 64);
-        if (ca.G > 0) lds_stage(sD, a.dpow, ca.G * MT * 8, tid, NW * 64);
-    }
-    const Chunk ch = a.chunks[c];
-    float *end_cur = a.ends_f + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
-    const float *end_prev = a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
-    if (pass > 0 && ch.first) {
-        if (owner) end_cur[i] = end_prev[i];
-        return;
-    }
-    // ---- start vector (owner lanes hold state i) and the skip test ----
-    float al = 0.f;
-    {
-        const float *src = ch.first ? a.pi_f
-                           : pass == 0 ? (a.warm_f ? a.warm_f + (size_t)(c - 1) * Mp : a.pi_f)
-                                       : a.ends_f + ((size_t)((pass + 1) & 1) * a.nchunks + (c - 1)) * Mp;
-        if (i < M) al = src[i];
-    }
-    if (tid == 0) *sflag = 0;
-    if (lane == 0) mflag[w] = 1;
-    __syncthreads();
-    if (pass > 0) {
-        bool diff = false;
-        if (owner && i < M) {
-            const float u = a.used_f[(size_t)c * Mp + i];
-            if (!(fabsf(al - u) <= a.eps_f * fabsf(u))) diff = true;
-        }
-        if (__any(diff) && lane == 0) *sflag = 1;
-        __syncthreads();
-        if (*sflag == 0) {
-            if (owner) end_cur[i] = end_prev[i];
-            return;
-        }
-    }
-    if (owner) a.used_f[(size_t)c * Mp + i] = al;
-    if (tid == 0) a.changed[pass] = 1;
-    if (ch.first) {
-        if (owner) a.alpha[(size_t)ch.base * Mp + i] = al;
-        if (tid == 0) a.cnorm[ch.base] = 1.0;
-    }
-    // ---- operand quarters in registers ----
-    float tf[KQ];
-    double pinv[KQ], pt[KQ];
-    {
-        const size_t ho = (size_t)(a.hot < 0 ? 0 : a.hot) * Mp * Mp;
-#pragma unroll
-        for (int t = 0; t < KQ; ++t) {
-            const int k = kq * KQ + t;
-            tf[t] = a.Tf[(size_t)k * Mp + i];
-            pinv[t] = (a.hot >= 0) ? a.PinvT[ho + (size_t)k * Mp + i] : 0.0;
-            pt[t] = (a.hot >= 0) ? a.PT[ho + (size_t)k * Mp + i] : 0.0;
-        }
-#pragma unroll
-        for (int t = 0; t < KQ; ++t) { pin_reg(tf[t]); pin_reg(pinv[t]); pin_reg(pt[t]); }
-    }
-    const int2 *rd = a.rowdesc + ch.base;
-    const int nrows = ch.r1 - ch.r0;
-    // descriptor batches of 64 rows: batch b lives in sdesc[b&1]; batches 0 and 1 are staged here, batch b+1 by
-    // wavefront 0 in the middle of batch b.  The fetch is deliberately synchronous inside its branch: a load whose
-    // result is carried across iterations makes the compiler wait for vmcnt(0) - i.e. for the alpha store just
-    // issued - on EVERY row (measured: the dominant stall of the previous version of this loop).
-    if (w == 0) {
-        sdesc[lane] = (lane < nrows) ? rd[ch.r0 + 1 + lane] : make_int2(0, -1);
-        sdesc[64 + lane] = (lane + 64 < nrows) ? rd[ch.r0 + 1 + 64 + lane] : make_int2(0, -1);
-    }
-    if (owner) xf[i] = al;                     // the start vector enters as a state whose sum counts as exactly 1
-    __syncthreads();
-    // three-stage descriptor pipeline: d2 = raw descriptor of row j+2, (kid1, ge1, e1, dp1) of row j+1, *_cur of row j
-    auto desc_at = [&](int jj) { return sdesc[((jj >> 6) & 1) * 64 + (jj & 63)]; };
-    int2 d0 = desc_at(0);
-    int ge = __builtin_amdgcn_readfirstlane(d0.y);
-    {
-        const int kid0 = __builtin_amdgcn_readfirstlane(d0.x);
-        d0.x = kid0;
-    }
-    double e_cur = TAB ? sE[d0.x * MT + i] : a.E[(size_t)d0.x * Mp + i];
-    double dp_cur = (ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + i]) : 0.0;
-    int2 d1 = (nrows > 1) ? desc_at(1) : make_int2(0, -1);
-    float v_prev = al;      // owner: unnormalised output of the previous row (normalised, clamped and stored one row later)
-    // Re-runs (pass > 0) stop as soon as the new trajectory has merged with the one stored by the previous pass: every
-    // 16 rows the freshly normalised alpha row is compared with the stored one before it is overwritten; once they agree
-    // within eps the remaining rows, normalisers and the end vector of the previous pass stay valid (the perturbation of
-    // a start vector decays geometrically), so late, sparse passes cost a few hundred rows instead of a whole chunk.
-    const bool rerun = pass > 0;
-    bool merged = false;
-#ifdef SMCPP_PROFILE_CYCLES
-    long long t_loop0 = __builtin_readcyclecounter(), t_bar = 0, t_bar2 = 0;
-#endif
-    for (int j = 0; j < nrows; ++j) {
-        const int ell = ch.r0 + 1 + j;
-        const int jb = j & 63, bsel = (j >> 6) & 1, cur = j & 1, nxt = cur ^ 1;
-        if (rerun && j > 16 && (j & 15) == 1) {
-            int nm = mflag[0];
-#pragma unroll
-            for (int q = 1; q < NW; ++q) nm |= mflag[q];
-            if (nm == 0) { merged = true; break; }
-        }
-        if (w == 0 && jb == 32 && j >= 64) {
-            const int2 dn = (j + 32 + lane < nrows) ? rd[ch.r0 + 1 + j + 32 + lane] : make_int2(0, -1);
-            sdesc[(bsel ^ 1) * 64 + lane] = dn;
-        }
-        // stage 1 -> operands of row j+1 (descriptor fetched one iteration ago), stage 2 -> raw descriptor of row j+2
-        const int kid_n = __builtin_amdgcn_readfirstlane(d1.x);
-        const int ge_n = (j + 1 < nrows) ? __builtin_amdgcn_readfirstlane(d1.y) : -1;
-        const double e_nxt = TAB ? sE[kid_n * MT + i] : a.E[(size_t)kid_n * Mp + i];
-        const double dp_nxt = (ge_n >= 0) ? (TAB ? sD[SMCPP_GID(ge_n) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge_n) * Mp + i]) : 0.0;
-        const int2 d2 = (j + 2 < nrows) ? desc_at(j + 2) : make_int2(0, -1);
-        // ---- incoming state: quarter of x, its sum (= normaliser of the previous row), clamp threshold ----
-        const float *xin = xf + cur * MT + kq * KQ;
-        f32x2 xl[KQ / 4], xh[KQ / 4];
-        f32x2 s01 = {0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < KQ / 4; ++t) {
-            const f32x4p x = *reinterpret_cast<const f32x4p *>(xin + 4 * t);
-            xl[t] = x.lo; xh[t] = x.hi;
-            s01 += x.lo; s01 += x.hi;
-        }
-        float sprev = quad_sum_f(s01.x + s01.y);
-        if (j == 0) sprev = 1.0f;
-        const float inv = __builtin_amdgcn_rcpf(sprev);
-        const float thr = 1e-10f * sprev;
-        // the previous row can be finished now that its normaliser is known: alpha = clamp(v / s)   (hmm.cpp:89-94)
-        if (j > 0) {
-            float an = v_prev * inv;
-            an = (i < M) ? fmaxf(an, 1e-10f) : 0.f;
-            if (rerun && (j & 15) == 0) {
-                // the alpha this row had in the previous pass, read (and waited for) right before it is overwritten
-                const float old_pref = owner ? a.alpha[(size_t)(ch.base + ell - 1) * Mp + i] : 0.f;
-                const bool bad = owner && i < M && !(fabsf(an - old_pref) <= a.eps_f * fabsf(old_pref));
-                const bool anyb = __any(bad);
-                if (lane == 0) mflag[w] = anyb ? 1 : 0;
-            }
-            if (owner) a.alpha[(size_t)(ch.base + ell - 1) * Mp + i] = an;
-            if (tid == 0) a.cnorm[ch.base + ell - 1] = (double)sprev;
-        }
-        float vout;
-        if (ge < 0) {
-            // span == 1: y = Tf^T max(x, thr) / s ; v = float(y e)
-            f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < KQ / 4; ++t) {
-                f32x2 l = xl[t], h = xh[t];
-                l.x = fmaxf(l.x, thr); l.y = fmaxf(l.y, thr); h.x = fmaxf(h.x, thr); h.y = fmaxf(h.y, thr);
-                const f32x2 m01 = {tf[4 * t], tf[4 * t + 1]}, m23 = {tf[4 * t + 2], tf[4 * t + 3]};
-                acc01 = __builtin_elementwise_fma(m01, l, acc01);
-                acc23 = __builtin_elementwise_fma(m23, h, acc23);
-            }
-            const float y = quad_sum_f((acc01.x + acc01.y) + (acc23.x + acc23.y)) * inv;
-            vout = (i < M) ? (float)((double)y * e_cur) : 0.f;
-        } else {
-            const int es = SMCPP_ES(ge);
-            double u;
-            if (es == a.hot) {
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int t = 0; t < KQ / 4; ++t) {
-                    a0 = fma(pinv[4 * t], (double)fmaxf(xl[t].x, thr), a0);
-                    a1 = fma(pinv[4 * t + 1], (double)fmaxf(xl[t].y, thr), a1);
-                    a0 = fma(pinv[4 * t + 2], (double)fmaxf(xh[t].x, thr), a0);
-                    a1 = fma(pinv[4 * t + 3], (double)fmaxf(xh[t].y, thr), a1);
-                }
-                u = quad_sum_d(a0 + a1);
-            } else {
-                const double *Pm = a.PinvT + (size_t)es * Mp * Mp;
-                double a0 = 0.0;
-                for (int t = 0; t < KQ; ++t) a0 = fma(Pm[(size_t)(kq * KQ + t) * Mp + i], (double)fmaxf(xin[t], thr), a0);
-                u = quad_sum_d(a0);
-            }
-            u = u * dp_cur * (double)inv;
-            if (owner) ub[(i / KQ) * UP + (i % KQ)] = (i < M) ? u : 0.0;
-#ifdef SMCPP_PROFILE_CYCLES
-            { const long long tb = __builtin_readcyclecounter(); lds_barrier(); t_bar2 += __builtin_readcyclecounter() - tb; }
-#else
-            lds_barrier();
-#endif
-            const double *uin = ub + kq * UP;
-            double av;
-            if (es == a.hot) {
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int t = 0; t < KQ; t += 2) {
-                    const double2 x = *reinterpret_cast<const double2 *>(uin + t);
-                    a0 = fma(pt[t], x.x, a0);
-                    a1 = fma(pt[t + 1], x.y, a1);
-                }
-                av = quad_sum_d(a0 + a1);
-            } else {
-                const double *Pm = a.PT + (size_t)es * Mp * Mp;
-                double a0 = 0.0;
-                for (int t = 0; t < KQ; ++t) a0 = fma(Pm[(size_t)(kq * KQ + t) * Mp + i], uin[t], a0);
-                av = quad_sum_d(a0);
-            }
-            vout = (i < M) ? (float)av : 0.f;      // the state is rounded to float as alpha_hat is (hmm.cpp:80)
-        }
-        if (owner) xf[nxt * MT + i] = vout;
-        v_prev = vout;
-        ge = ge_n; e_cur = e_nxt; dp_cur = dp_nxt; d1 = d2;
-#ifdef SMCPP_PROFILE_CYCLES
-        { const long long tb = __builtin_readcyclecounter(); lds_barrier(); t_bar += __builtin_readcyclecounter() - tb; }
-#else
-        lds_barrier();
-#endif
-    }
-#ifdef SMCPP_PROFILE_CYCLES
-    if (a.dbg && c == 1 && lane == 0) {
-        a.dbg[4 * w + 0] = __builtin_readcyclecounter() - t_loop0;
-        a.dbg[4 * w + 1] = t_bar;
-        a.dbg[4 * w + 2] = t_bar2;
-        a.dbg[4 * w + 3] = nrows;
-    }
-#endif
-    if (merged) {
-        if (owner) end_cur[i] = end_prev[i];      // the stored tail of the chunk and its end vector are still valid
-        return;
-    }
-    // ---- last row: normalise, clamp, store, publish the end vector ----
-    {
-        const float *xin = xf + (nrows & 1) * MT + kq * KQ;
-        float sl = 0.f;
-#pragma unroll
-        for (int t = 0; t < KQ; ++t) sl += xin[t];
-        const float sprev = quad_sum_f(sl);
-        const float inv = __builtin_amdgcn_rcpf(sprev);
-        if (owner) {
-            float an = v_prev * inv;
-            an = (i < M) ? fmaxf(an, 1e-10f) : 0.f;
-            a.alpha[(size_t)(ch.base + ch.r1) * Mp + i] = an;
-            end_cur[i] = an;
-        }
-        if (tid == 0) a.cnorm[ch.base + ch.r1] = (double)sprev;
-    }
-}
-
-template <int MT, bool TAB>
-__global__ __launch_bounds__(MT * 4) void k_bwd_coop(ChainArgs a, CoopArgs ca) {
-    constexpr int NW = MT / 16, KQ = MT / 4, Mp = MT, UP = KQ + 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int il = lane >> 2, kq = lane & 3, i = 16 * w + il;
-    const bool owner = kq == 0;
-    const int M = a.M, pass = a.pass, c = blockIdx.x;
-    if (pass > 0 && a.changed[pass - 1] == 0) return;
-    double *sE = reinterpret_cast<double *>(smem);            // [K][4][UP]: quarter-padded so that both the owner
-    double *sD = sE + (TAB ? ca.K * 4 * UP : 0);               // read e[i] and the quarter read e[kq*KQ..] are conflict-free
-    double *ub = sD + (TAB ? ca.G * MT : 0);                 // [4][UP]     w exchange of eigen rows
-    double *xb = ub + 4 * UP;                                  // [2][4][UP]  unnormalised beta
-    int2 *sdesc = reinterpret_cast<int2 *>(xb + 8 * UP);      // [2][64]
-    int *sflag = reinterpret_cast<int *>(sdesc + 128);
-    int *mflag = sflag + 4;
-    if (TAB) {
-        for (int idx = tid; idx < ca.K * MT; idx += NW * 64) {
-            const int k = idx / MT, st = idx % MT;
-            sE[(size_t)k * 4 * UP + (st / KQ) * UP + (st % KQ)] = a.E[(size_t)k * Mp + st];
-        }
-        if (ca.G > 0) lds_stage(sD, a.dpow, ca.G * MT * 8, tid, NW * 64);
-    }
-    const Chunk ch = a.chunks[c];
-    double *end_cur = a.ends_b + ((size_t)(pass & 1) * a.nchunks + c) * Mp;
-    const double *end_prev = a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + c) * Mp;
-    if (pass > 0 && ch.last) {
-        if (owner) end_cur[i] = end_prev[i];
-        return;
-    }
-    double b = 0.0;
-    {
-        const double *src = (pass == 0) ? a.warm_b + (size_t)(c + 1) * Mp
-                                        : a.ends_b + ((size_t)((pass + 1) & 1) * a.nchunks + (c + 1)) * Mp;
-        const bool fresh = ch.last || (pass == 0 && a.warm_b == nullptr);
-        if (i < M) b = fresh ? 1.0 / (double)M : src[i];
-    }
-    if (tid == 0) *sflag = 0;
-    if (lane == 0) mflag[w] = 1;
-    __syncthreads();
-    if (pass > 0) {
-        bool diff = false;
-        if (owner && i < M) {
-            const double u = a.used_b[(size_t)c * Mp + i];
-            if (!(fabs(b - u) <= a.eps_b * fabs(u))) diff = true;
-        }
-        if (__any(diff) && lane == 0) *sflag = 1;
-        __syncthreads();
-        if (*sflag == 0) {
-            if (owner) end_cur[i] = end_prev[i];
-            return;
-        }
-    }
-    if (owner) a.used_b[(size_t)c * Mp + i] = b;
-    if (tid == 0) a.changed[pass] = 1;
-    double tdt[KQ], prm[KQ], pinvrm[KQ];
-    {
-        const size_t ho = (size_t)(a.hot < 0 ? 0 : a.hot) * Mp * Mp;
-#pragma unroll
-        for (int t = 0; t < KQ; ++t) {
-            const int k = kq * KQ + t;
-            tdt[t] = a.TdT[(size_t)k * Mp + i];
-            prm[t] = (a.hot >= 0) ? a.Prm[ho + (size_t)k * Mp + i] : 0.0;
-            pinvrm[t] = (a.hot >= 0) ? a.Pinvrm[ho + (size_t)k * Mp + i] : 0.0;
-        }
-#pragma unroll
-        for (int t = 0; t < KQ; ++t) { pin_reg(tdt[t]); pin_reg(prm[t]); pin_reg(pinvrm[t]); }
-    }
-    const int2 *rd = a.rowdesc + ch.base;
-    const int nrows = ch.r1 - ch.r0;
-    if (w == 0) {            // descriptor batches: see k_fwd_coop
-        sdesc[lane] = (lane < nrows) ? rd[ch.r1 - lane] : make_int2(0, -1);
-        sdesc[64 + lane] = (lane + 64 < nrows) ? rd[ch.r1 - lane - 64] : make_int2(0, -1);
-    }
-    __syncthreads();
-    auto desc_at = [&](int jj) { return sdesc[((jj >> 6) & 1) * 64 + (jj & 63)]; };
-    int2 d0 = desc_at(0);
-    int ge = __builtin_amdgcn_readfirstlane(d0.y);
-    int kid = __builtin_amdgcn_readfirstlane(d0.x);
-    double dp_cur = (ge >= 0) ? (TAB ? sD[SMCPP_GID(ge) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge) * Mp + i]) : 0.0;
-    int2 d1 = (nrows > 1) ? desc_at(1) : make_int2(0, -1);
-    // the state enters as beta with sum counted as exactly 1; the e factor of a span-1 row is applied by the producer
-    if (owner) xb[(i / KQ) * UP + (i % KQ)] = b;
-    __syncthreads();
-    double b_raw = b;       // owner: unnormalised beta of the row being processed
-    const bool rerun = pass > 0;   // early exit once the re-run has merged with the stored trajectory (see k_fwd_coop)
-    bool merged = false;
-    for (int j = 0; j < nrows; ++j) {
-        const int ell = ch.r1 - j;
-        const int jb = j & 63, bsel = (j >> 6) & 1, cur = j & 1, nxt = cur ^ 1;
-        if (rerun && j > 16 && (j & 15) == 1) {
-            int nm = mflag[0];
-#pragma unroll
-            for (int q = 1; q < NW; ++q) nm |= mflag[q];
-            if (nm == 0) { merged = true; break; }
-        }
-        if (w == 0 && jb == 32 && j >= 64) {
-            const int2 dn = (j + 32 + lane < nrows) ? rd[ch.r1 - (j + 32 + lane)] : make_int2(0, -1);
-            sdesc[(bsel ^ 1) * 64 + lane] = dn;
-        }
-        const int kid_n = __builtin_amdgcn_readfirstlane(d1.x);
-        const int ge_n = (j + 1 < nrows) ? __builtin_amdgcn_readfirstlane(d1.y) : -1;
-        const double dp_nxt = (ge_n >= 0) ? (TAB ? sD[SMCPP_GID(ge_n) * MT + i] : a.dpow[(size_t)SMCPP_GID(ge_n) * Mp + i]) : 0.0;
-        const int2 d2 = (j + 2 < nrows) ? desc_at(j + 2) : make_int2(0, -1);
-        // ---- incoming state (plain beta): quarter, sum, reciprocal ----
-        const double *xin = xb + cur * 4 * UP + kq * UP;
-        double x[KQ];
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int t = 0; t < KQ; t += 2) {
-            const double2 v = *reinterpret_cast<const double2 *>(xin + t);
-            x[t] = v.x; x[t + 1] = v.y;
-            s0 += v.x; s1 += v.y;
-        }
-        double sprev = quad_sum_d(s0 + s1);
-        if (j == 0) sprev = 1.0;
-        const double inv = rcp_f64(sprev);
-        // beta[ell] = the normalised vector this row is processed with (hmm.cpp:142)
-        {
-            const double bnrm = (i < M) ? b_raw * inv : 0.0;
-            if (rerun && (j & 15) == 0 && j > 0) {
-                const double old_pref = owner ? a.beta[(size_t)(ch.base + ell) * Mp + i] : 0.0;
-                const bool bad = owner && i < M && !(fabs(bnrm - old_pref) <= a.eps_b * fabs(old_pref));
-                const bool anyb = __any(bad);
-                if (lane == 0) mflag[w] = anyb ? 1 : 0;
-            }
-            if (owner) a.beta[(size_t)(ch.base + ell) * Mp + i] = bnrm;
-        }
-        double bn;
-        if (ge < 0) {
-            // beta <- T (e o beta)   (hmm.cpp:139): this lane needs e on its quarter of the inner index
-            double a0 = 0.0, a1 = 0.0;
-            if (TAB) {
-                const double *eq = sE + (size_t)kid * 4 * UP + kq * UP;
-#pragma unroll
-                for (int t = 0; t < KQ; t += 2) {
-                    const double2 ev = *reinterpret_cast<const double2 *>(eq + t);
-                    a0 = fma(tdt[t] * ev.x, x[t], a0);
-                    a1 = fma(tdt[t + 1] * ev.y, x[t + 1], a1);
-                }
-            } else {
-                const double *eq = a.E + (size_t)kid * Mp + kq * KQ;
-#pragma unroll
-                for (int t = 0; t < KQ; t += 2) {
-                    a0 = fma(tdt[t] * eq[t], x[t], a0);
-                    a1 = fma(tdt[t + 1] * eq[t + 1], x[t + 1], a1);
-                }
-            }
-            bn = quad_sum_d(a0 + a1) * inv;
-        } else {
-            const int es = SMCPP_ES(ge);
-            double wv;
-            if (es == a.hot) {
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int t = 0; t < KQ; t += 2) {
-                    a0 = fma(prm[t], x[t], a0);
-                    a1 = fma(prm[t + 1], x[t + 1], a1);
-                }
-                wv = quad_sum_d(a0 + a1);
-            } else {
-                const double *Pm = a.Prm + (size_t)es * Mp * Mp;
-                double a0 = 0.0;
-                for (int t = 0; t < KQ; ++t) a0 = fma(Pm[(size_t)(kq * KQ + t) * Mp + i], xin[t], a0);
-                wv = quad_sum_d(a0);
-            }
-            wv = wv * dp_cur * inv;
-            if (owner) ub[(i / KQ) * UP + (i % KQ)] = (i < M) ? wv : 0.0;
-            lds_barrier();
-            const double *uin = ub + kq * UP;
-            if (es == a.hot) {
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int t = 0; t < KQ; t += 2) {
-                    const double2 v = *reinterpret_cast<const double2 *>(uin + t);
-                    a0 = fma(pinvrm[t], v.x, a0);
-                    a1 = fma(pinvrm[t + 1], v.y, a1);
-                }
-                bn = quad_sum_d(a0 + a1);
-            } else {
-                const double *Pm = a.Pinvrm + (size_t)es * Mp * Mp;
-                double a0 = 0.0;
-                for (int t = 0; t < KQ; ++t) a0 = fma(Pm[(size_t)(kq * KQ + t) * Mp + i], uin[t], a0);
-                bn = quad_sum_d(a0);
-            }
-        }
-        if (!(i < M)) bn = 0.0;
-        if (owner) xb[nxt * 4 * UP + (i / KQ) * UP + (i % KQ)] = bn;
-        b_raw = bn;
-        kid = kid_n; ge = ge_n; dp_cur = dp_nxt; d1 = d2;
-        lds_barrier();
-    }
-    if (merged) {
-        if (owner) end_cur[i] = end_prev[i];
-        return;
-    }
-    {
-        const double *xin = xb + (nrows & 1) * 4 * UP + kq * UP;
-        double sl = 0.0;
-#pragma unroll
-        for (int t = 0; t < KQ; ++t) sl += xin[t];
-        const double sprev = quad_sum_d(sl);
-        if (owner) {
-            const double bf = (i < M) ? b_raw / sprev : 0.0;       // beta /= beta.sum()
-            end_cur[i] = bf;
-            if (ch.first) a.beta[(size_t)ch.base * Mp + i] = bf;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2042,107 +929,6 @@ __global__ __launch_bounds__(64) void k_eig_uw(UWArgs a) {
     }
 }
 
-// K5+K4 fused (Mp <= 64): the D registers of the U / W products ARE the A / B fragments of the rank update
-// (rows r0+4r .. r0+4r+3 sit on lanes qd = 0..3), so the slab's  sum_rows (omega U) W^T  is accumulated in the same
-// wavefront without omega*U and W ever going to memory (saves 2 x 8M bytes written and read per eigen row).
-template <int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_eig_fused(UWArgs a, double *part) {
-    constexpr int KQ = 4 * NT;                 // states per lane of the k dimension: lane (m, qd) owns KQ*qd .. +KQ-1
-    constexpr int MT = 16 * NT;
-    constexpr int LD = MT + 1;                 // padded row: lanes qd and qd+1 of one LDS pass land 32 banks apart
-    extern __shared__ double eig_lds[];        // [2][MT][LD]: Pinv^T and P of the eigen key of this block's first slab
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int m = lane & 15, qd = lane >> 4;
-    const int Mp = a.Mp;
-    const int slab0 = blockIdx.x * 4;
-    const int es0 = a.g_eig[a.slabs[slab0].aux];
-    {
-        // the B operands of the U / W products are the same two matrices for every row of a key: one copy per
-        // workgroup in LDS instead of 2 x 16 x NT dependent L2 loads per 16-row tile (measured: 64 serialised round
-        // trips, 37 us per tile)
-        const double *g0 = a.PinvT + (size_t)es0 * Mp * Mp, *g1 = a.Prm + (size_t)es0 * Mp * Mp;
-        for (int idx = threadIdx.x; idx < MT * MT; idx += 256) {
-            const int r = idx / MT, c = idx % MT;
-            eig_lds[r * LD + c] = g0[(size_t)r * Mp + c];
-            eig_lds[MT * LD + r * LD + c] = g1[(size_t)r * Mp + c];
-        }
-    }
-    __syncthreads();
-    const int slab = slab0 + wv;
-    if (slab >= a.nslabs) return;
-    const Slab sl = a.slabs[slab];
-    const double *sPinvT = eig_lds, *sPrm = eig_lds + MT * LD;   // the host pads the slab list: one key per workgroup
-    const double *dp = a.dpow + (size_t)sl.aux * Mp;
-    const double scale = a.g_scale[sl.aux];
-    f64x4 acc[NT][NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
-    for (int r0 = sl.start; r0 < sl.end; r0 += 16) {
-        // rows past the end of the slab re-read its last row (unconditional loads: see k_rank_acc) and get omega = 0
-        const int ra = min(r0 + m, sl.end - 1);
-        const int ell_a = a.perm[ra];
-        // The MFMA sums over k in any order, so k-step kk of lane (m, qd) is state KQ*qd + kk: every lane reads ONE
-        // contiguous 16*NT-byte (alpha) / 32*NT-byte (beta) piece of its row instead of a stride-4 gather.
-        const float4 *arow = reinterpret_cast<const float4 *>(a.alpha + (size_t)(sl.base + ell_a - 1) * Mp + KQ * qd);
-        const double2 *brow = reinterpret_cast<const double2 *>(a.beta + (size_t)(sl.base + ell_a) * Mp + KQ * qd);
-        f64x4 U[NT], W[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { U[t] = (f64x4){0, 0, 0, 0}; W[t] = (f64x4){0, 0, 0, 0}; }
-        // four k-steps per block; the next block's piece of the two rows is in flight while this one is multiplied
-        float4 a4 = arow[0];
-        double2 b01 = brow[0], b23 = brow[1];
-#pragma unroll 1
-        for (int t4 = 0; t4 < NT; ++t4) {
-            const float avv[4] = {a4.x, a4.y, a4.z, a4.w};
-            const double bvv[4] = {b01.x, b01.y, b23.x, b23.y};
-            {
-                const int tn = min(t4 + 1, NT - 1);      // the last block re-reads itself instead of branching
-                a4 = arow[tn];
-                b01 = brow[2 * tn];
-                b23 = brow[2 * tn + 1];
-            }
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const int st = KQ * qd + 4 * t4 + k4;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    // B[k][n = 16t+m] = Pinv[16t+m][st]  and  P[st][16t+m]
-                    const double pinv = sPinvT[st * LD + 16 * t + m];
-                    const double pp = sPrm[st * LD + 16 * t + m];
-                    U[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)avv[k4], pinv, U[t], 0, 0, 0);
-                    W[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(bvv[k4], pp, W[t], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double pr = 0.0;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) pr += dp[16 * t + m] * U[t][r] * W[t][r];
-            const double sm = row16_sum(pr);
-            const bool vr = r0 + qd + 4 * r < sl.end;        // padded rows must not contribute
-            const double om = vr ? 1.0 / (scale * sm) : 0.0;
-            double xa[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) xa[t] = om * U[t][r];
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], W[j][r], acc[i][j], 0, 0, 0);
-        }
-    }
-    double *out = part + (size_t)slab * Mp * Mp;
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
-                out[(size_t)(16 * i + qd + 4 * rg) * Mp + 16 * j + m] = acc[i][j][rg];
-}
 
 // K5+K4 fused, generation 2 (round 3): slabs that MIX span groups.  The span-Q weighting that follows the accumulation,
 // Z = sum_g S_g o Acc_g with S_g[j][k] = (p_j - p_k) / (d_j - d_k), p = (d / scale)^span of the group, is linear in the group's
@@ -2442,111 +1228,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
             }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// K4g: the span-1 rank update WITH the per-key gamma sums (M <= 64, K <= 64): what k_s1_scalars + k_rank_acc<0> do in two
-// passes over alpha and beta, in one.  The gamma sums of a slab are a second rank update with a ONE-HOT left operand:
-//     Gs[key][state] = sum_rows [key_row == key] * (alpha_ell o beta_ell / p)[state]
-// A[m = key in tile][k = row of the group] is 0 / 1, B[k][n] = gamma_row: KT * NT more MFMAs per group of 4 rows, no second
-// read of the rows, no per-key row permutation.  Writes part[slab][Mp][Mp] and gpart[slab][K][Mp].
-// ---------------------------------------------------------------------------------------------------------------
-template <int KT>
-__global__ __launch_bounds__(64) void k_rank_acc_g(AccArgs a, int K, double *__restrict__ gpart) {
-    const int lane = threadIdx.x;
-    const int m = lane & 15, qd = lane >> 4;
-    const Slab sl = a.slabs[blockIdx.x];
-    const int Mp = a.Mp, M = a.M;
-    f64x4 acc[4][4], gac[KT][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < KT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) gac[i][j] = (f64x4){0, 0, 0, 0};
-    const int last = sl.end - 1;
-    auto fetch_pk = [&](int r0) {
-        const int r = r0 + qd;
-        int2 pk = a.permk[min(r, last)];
-        pk.x = (r <= last) ? pk.x : -1;
-        return pk;
-    };
-    struct Ops { double c; float ap[4], an[4]; double bp[4], ep[4]; int key; bool valid; };
-    int sc[4];
-    bool sv[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { const int j = 16 * t + m; sv[t] = j < Mp; sc[t] = sv[t] ? j : 0; }
-    auto fetch_ops = [&](const int2 pk) {          // raw, unconditional loads (see k_rank_acc)
-        Ops o;
-        o.valid = pk.x >= 0;
-        o.key = pk.y;
-        const size_t row = (size_t)(sl.base + (o.valid ? pk.x : 1));
-        o.c = a.cnorm[row];
-        const float *ap = a.alpha + (row - 1) * Mp;
-        const double *bp = a.beta + row * Mp;
-        const double *ep = a.E + (size_t)pk.y * Mp;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { o.ap[t] = ap[sc[t]]; o.an[t] = ap[Mp + sc[t]]; o.bp[t] = bp[sc[t]]; o.ep[t] = ep[sc[t]]; }
-        return o;
-    };
-    int2 pk1 = fetch_pk(sl.start);
-    Ops cur = fetch_ops(pk1);
-    pk1 = fetch_pk(sl.start + 4);
-    for (int r0 = sl.start; r0 < sl.end; r0 += 4) {
-        const int2 pk2 = fetch_pk(r0 + 8);
-        const Ops nxt = fetch_ops(pk1);
-        double pp = 0.0, v[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            v[t] = (sv[t] && 16 * t + m < M) ? (double)cur.an[t] * cur.bp[t] : 0.0;      // alpha_ell o beta_ell
-            pp += v[t];
-        }
-        const double p = row16_sum(pp);
-        const double ip = cur.valid ? 1.0 / p : 0.0;
-        const double wgt = ip / cur.c;                                       // 1 / (c_ell p), hmm.cpp:137-138
-        double xa[4], yb[4], gb[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            xa[t] = sv[t] ? wgt * (double)cur.ap[t] : 0.0;
-            yb[t] = sv[t] ? cur.bp[t] * cur.ep[t] : 0.0;
-            gb[t] = v[t] * ip;                                               // gamma row (hmm.cpp:134-136)
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], yb[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            const double oh = (cur.valid && cur.key == 16 * kt + m) ? 1.0 : 0.0;     // A[m = key][k = qd]
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                gac[kt][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(oh, gb[j], gac[kt][j], 0, 0, 0);
-        }
-        cur = nxt;
-        pk1 = pk2;
-    }
-    double *out = a.part + (size_t)blockIdx.x * Mp * Mp;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int row = 16 * i + qd + 4 * rg, col = 16 * j + m;
-                if (row < Mp && col < Mp) out[(size_t)row * Mp + col] = acc[i][j][rg];
-            }
-    double *go = gpart + (size_t)blockIdx.x * K * Mp;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int key = 16 * kt + qd + 4 * rg, col = 16 * j + m;
-                if (key < K && col < Mp) go[(size_t)key * Mp + col] = gac[kt][j][rg];
-            }
-}
 
 // Packed per-rank statistics for the single all-reduce of a multi-GPU E-step, written straight into the caller's device
 // buffer:  out = [ sum loglik | gamma0 (M) | xisum (M*M) | gamma-sums by GLOBAL key index (Kg*M) ],
@@ -2788,124 +1469,19 @@ __global__ __launch_bounds__(256) void k_fin_Y(FinArgs a) {
 // One workgroup per (contig, key), 2 NT wavefronts: wavefronts 0 .. NT-1 run the F strips one step AHEAD of wavefronts
 // NT .. 2 NT - 1, which run the H strips; F_t goes from one group to the other through a double-buffered LDS copy, one barrier
 // per step.
-template <int NT>
-__global__ __launch_bounds__(128 * NT) void k_span_FH(FinArgs a, int smax) {
-    constexpr int MT = 16 * NT, LD = MT + 1;
-    extern __shared__ __attribute__((aligned(16))) double sfh_lds[];       // [2][MT][LD]: F_t, row-major
-    const int ce = blockIdx.x, e = ce % a.Ke;
-    const int b0 = a.ce_bucket_off[ce], b1 = a.ce_bucket_off[ce + 1];
-    if (b0 == b1) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const bool isF = wv < NT;
-    const int sp = isF ? wv : wv - NT;
-    const int m = lane & 15, qd = lane >> 4;
-    const int Mp = a.Mp, M = a.M;
-    const double *ek = a.E + (size_t)a.e_kid[e] * Mp;
-    // A operands (output row tile tt, k = 4 kk + qd):  F group: A^T[16 tt + m][k] = e_k T[16 tt + m][k];  H group: A[16 tt + m][k] = e_i T[k][i]
-    double af[NT][MT / 4];
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-        for (int kk = 0; kk < MT / 4; ++kk) {
-            const int k = 4 * kk + qd, i = 16 * tt + m;
-            const double v = isF ? ek[min(k, Mp - 1)] * a.Td[(size_t)min(i, Mp - 1) * Mp + min(k, Mp - 1)]
-                                 : ek[min(i, Mp - 1)] * a.Td[(size_t)min(k, Mp - 1) * Mp + min(i, Mp - 1)];
-            af[tt][kk] = (k < M && i < M) ? v : 0.0;
-        }
-    f64x4 X[NT];         // F group: F^T strip (rows = columns of F, column 16 sp + m = row of F);  H group: H strip (column 16 sp + m)
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) X[tt] = (f64x4){0, 0, 0, 0};
-    int bcur = b1 - 1;   // buckets of a (contig, key) are sorted by span
-    // iteration it: the F group computes F_t for t = smax - 1 - it, the H group H_t for t = smax - it (from the F_t of the last iteration)
-    for (int it = 0; it <= smax; ++it) {
-        const int tF = smax - 1 - it, tH = smax - it;
-        double *sFw = sfh_lds + (size_t)(it & 1) * MT * LD;
-        const double *sFr = sfh_lds + (size_t)((it + 1) & 1) * MT * LD;
-        const bool work = isF ? tF >= 0 : tH < smax;
-        f64x4 Xn[NT];
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) Xn[tt] = (f64x4){0, 0, 0, 0};
-        double av[NT][4];
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) av[tt][r] = 0.0;
-        if (work) {
-            if (isF) {
-                const bool has = bcur >= b0 && a.g_span[a.eb_gid[bcur]] == tF + 1;
-                if (has) {
-#pragma unroll
-                    for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)             // Acc[row of F][column of F], ONE share per bucket
-                            av[tt][r] = a.red_e[(size_t)bcur * Mp * Mp + (size_t)min(16 * sp + m, Mp - 1) * Mp + min(16 * tt + qd + 4 * r, Mp - 1)];
-                    --bcur;
-                }
-            } else {
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) av[tt][r] = sFr[(16 * tt + qd + 4 * r) * LD + 16 * sp + m];     // F_t[row][column of the strip]
-            }
-#pragma unroll
-            for (int kk = 0; kk < MT / 4; ++kk) {
-                const double bv = X[kk / 4][kk % 4];
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) Xn[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[tt][kk], bv, Xn[tt], 0, 0, 0);
-            }
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) X[tt][r] = Xn[tt][r] + av[tt][r];
-            if (isF) {
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sFw[(16 * sp + m) * LD + 16 * tt + qd + 4 * r] = X[tt][r];         // F_t[row 16 sp + m][column]
-            }
-        }
-        __syncthreads();
-    }
-    if (isF) return;
-    // W = H_0 (row-major [Mp][Mp], in the eigen path's Y buffer) and diag(A W) (first Mp entries of its Z buffer)
-    double *Wout = a.Y + (size_t)ce * Mp * Mp;
-    double *gout = a.Z + (size_t)ce * Mp * Mp;
-    f64x4 G = {0, 0, 0, 0};
-#pragma unroll
-    for (int kk = 0; kk < MT / 4; ++kk) {
-        double afd = 0.0;                                             // row tile sp of A
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) afd = (tt == sp) ? af[tt][kk] : afd;
-        G = __builtin_amdgcn_mfma_f64_16x16x4f64(afd, X[kk / 4][kk % 4], G, 0, 0, 0);
-    }
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * tt + qd + 4 * r, col = 16 * sp + m;
-            if (row < Mp && col < Mp) Wout[(size_t)row * Mp + col] = X[tt][r];
-        }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (qd + 4 * r == m && 16 * sp + m < Mp) gout[16 * sp + m] = G[r];
-}
 
 // The same fold with one workgroup per 16-wide STRIP (NTP = padded tile count: 1 .. 4 for M <= 64, 8 / 12 / 16 up to 256): a
 // workgroup of NTP wavefronts, wavefront tt owns output tile tt of the strip and keeps ITS A fragments (MT/4 doubles per lane) in
 // registers for all steps; the strip (MT x 16) is exchanged through a double-buffered LDS copy, one barrier per step.
 // PHASE 0: F^T strips (rows of F), F_t written to scratch;  PHASE 1: H strips (columns of H), W = H_0 and diag(A W) written at
-// the end.  k_span_FH above keeps a (contig, key) on ONE CU, whose four matrix pipes then bound a step (2 x 16 tiles x 16 k-steps
+// the end.  A one-workgroup-per-(contig, key) fold (round 3, removed) kept a (contig, key) on ONE CU, whose four matrix pipes then bound a step (2 x 16 tiles x 16 k-steps
 // x 64 cycles / 4 = 3.4 us); here a step is 16 MFMAs per wavefront.  What a step adds to the product (the Acc bucket of its span,
 // or F_t from the scratch) is fetched FOUR STEPS AHEAD with unconditional, index-clamped loads - on the serial path the three
 // dependent round trips bucket -> span -> matrix cost more than the product itself; the bucket of every step comes from a
 // small LDS table built once.
-// FUSED: both phases run in ONE launch (k_span_fused): the F workgroups publish every F_t they have written (a counter per (contig,
-// key, step) in global memory, raised once by each strip), the H workgroups wait for the counter of the step they are about to fetch
-// - H trails F by its prefetch distance instead of starting when F has finished (31 + 31 serial steps become 31 + 4).  `target` =
-// strips x launch epoch: the counters only ever grow, nothing is cleared between E-steps.
-template <int NTP, int PHASE, bool FUSED>
+template <int NTP, int PHASE>
 __device__ __forceinline__ void span_big_body(const FinArgs &a, int smax, double *__restrict__ Fall, int blk, double (*sX)[16 * NTP * 17],
-                                              int *sbk, int *flags, int target) {
+                                              int *sbk) {
     constexpr int MT = 16 * NTP, LDX = 17;
     __builtin_amdgcn_s_setprio(3);                                    // a serial chain of small products beside chip-filling kernels
     const int ns = (a.Mp + 15) / 16;                                  // strips that exist
@@ -2950,11 +1526,6 @@ __device__ __forceinline__ void span_big_body(const FinArgs &a, int smax, double
     }
     auto fetch = [&](int t, double (&v)[4]) {                          // raw loads; masked where they are consumed
         const int tc = max(t, 0);
-        if (FUSED && PHASE == 1 && t >= 0) {
-            // F_tc must have been published by every strip of the F phase (acquire: the loads below must not see older lines)
-            while (__hip_atomic_load(&flags[(size_t)ce * smax + tc], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
-                __builtin_amdgcn_s_sleep(2);
-        }
         const double *src;
         if (PHASE == 0) src = a.red_e + (size_t)max(sbk[tc], b0) * Mp * Mp;
         else src = Fce + (size_t)tc * Mp * Mp;
@@ -2994,12 +1565,8 @@ __device__ __forceinline__ void span_big_body(const FinArgs &a, int smax, double
 #pragma unroll
                 for (int r = 0; r < 4; ++r)                           // F_t[row 16 sp + m][column 16 tt + qd + 4 r]
                     if (eok[r]) Ft[eoff[r]] = X[r];
-                if (FUSED) __threadfence();                           // this thread's part of F_t is visible device-wide ...
             }
             __syncthreads();
-            // ... and once every thread of the strip has passed the barrier, the strip is: one count per strip and step
-            if (FUSED && PHASE == 0 && tid == 0)
-                __hip_atomic_fetch_add(&flags[(size_t)ce * smax + t], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (PHASE == 0) return;
@@ -3025,16 +1592,7 @@ template <int NTP, int PHASE>
 __global__ __launch_bounds__(64 * NTP) void k_span_big(FinArgs a, int smax, double *__restrict__ Fall) {
     __shared__ double sX[2][16 * NTP * 17];
     __shared__ int sbk[64];                                           // bucket holding span t + 1, or -1 (smax <= 64)
-    span_big_body<NTP, PHASE, false>(a, smax, Fall, (int)blockIdx.x, sX, sbk, nullptr, 0);
-}
-// both phases in one launch: workgroups [0, nwg) run the F strips, [nwg, 2 nwg) the H strips (the F workgroups never wait for
-// anything, so whatever order the dispatcher picks the launch makes progress)
-template <int NTP>
-__global__ __launch_bounds__(64 * NTP) void k_span_fused(FinArgs a, int smax, double *__restrict__ Fall, int nwg, int *flags, int target) {
-    __shared__ double sX[2][16 * NTP * 17];
-    __shared__ int sbk[64];
-    if ((int)blockIdx.x < nwg) span_big_body<NTP, 0, true>(a, smax, Fall, (int)blockIdx.x, sX, sbk, flags, target);
-    else span_big_body<NTP, 1, true>(a, smax, Fall, (int)blockIdx.x - nwg, sX, sbk, flags, target);
+    span_big_body<NTP, PHASE>(a, smax, Fall, (int)blockIdx.x, sX, sbk);
 }
 
 // xisum[contig] = max( (X1 + sum_e P_e Y_e diag(b_e)) o Td , 1e-20 )   (hmm.cpp:122,141,151-152)
@@ -3233,102 +1791,10 @@ __global__ __launch_bounds__(256) void k_gamma_rows_eig(GammaRowArgs a) {
 // reduced over the 16 lanes of a DPP row.  A wavefront walks over ROWS rows so the LDS staging is amortised.
 // MFMA operand map (guide §3): A[m = l&15][k = l>>4], B[k = l>>4][n = l&15], D[row = (l>>4) + 4 reg][col = l&15].
 // ---------------------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256) void k_gamma_rows_mfma(GammaRowArgs a, int p0, int p1, int es, int rows_per_wave) {
-    constexpr int MT = 16 * NT, LD = MT + 1;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *sP = sm;                         // [MT][LD]  P row-major
-    double *sPinv = sm + MT * LD;            // [MT][LD]  Pinv row-major
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    double *su = sPinv + MT * LD + wv * 4 * MT;   // per wavefront: u [MT], w [MT], g [MT], x [MT] (alpha / beta staging)
-    double *sw = su + MT, *sg = sw + MT, *sx = sg + MT;
-    const int Mp = a.Mp, M = a.M;
-    {
-        const double *Prm = a.Prm + (size_t)es * Mp * Mp, *Pinvrm = a.Pinvrm + (size_t)es * Mp * Mp;
-        for (int idx = tid; idx < MT * MT; idx += 256) {
-            const int r = idx / MT, c = idx % MT;
-            sP[r * LD + c] = Prm[(size_t)r * Mp + c];
-            sPinv[r * LD + c] = Pinvrm[(size_t)r * Mp + c];
-        }
-    }
-    __syncthreads();
-    const double *dun = a.dun + (size_t)es * Mp;
-    const int kq = lane >> 4, n = lane & 15;
-    const int pbeg = p0 + (blockIdx.x * 4 + wv) * rows_per_wave;
-    const int pend = min(p1, pbeg + rows_per_wave);
-    for (int p = pbeg; p < pend; ++p) {
-        const Slab sl = a.slabs[a.row_slab[p]];
-        const int gid = sl.aux;
-        const int span = a.g_span[gid];
-        const size_t row = (size_t)(sl.base + a.perm[p]);
-        const double *S = a.Sq + (size_t)gid * Mp * Mp;
-        // ---- u = d o (Pinv alpha_{l-1}),  w = P^T beta_l  (lane j = state j) ----
-        if (lane < MT) sx[lane] = (lane < M) ? (double)a.alpha[(row - 1) * Mp + lane] : 0.0;
-        wave_lds_fence();
-        double uu = 0.0;
-        if (lane < MT) {
-#pragma unroll 8
-            for (int k = 0; k < MT; ++k) uu = fma(sPinv[lane * LD + k], sx[k], uu);
-            uu *= (lane < M) ? dun[lane] : 0.0;
-        }
-        wave_lds_fence();
-        if (lane < MT) { su[lane] = uu; sx[lane] = (lane < M) ? a.beta[row * Mp + lane] : 0.0; }
-        wave_lds_fence();
-        double ww = 0.0;
-        if (lane < MT) {
-#pragma unroll 8
-            for (int k = 0; k < MT; ++k) ww = fma(sP[k * LD + lane], sx[k], ww);
-            sw[lane] = ww;
-        }
-        wave_lds_fence();
-        // ---- G = P Z tile by tile, folded into g ----
-        double gacc[NT][4];
-#pragma unroll
-        for (int it = 0; it < NT; ++it)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gacc[it][r] = 0.0;
-#pragma unroll 1
-        for (int bt = 0; bt < NT; ++bt) {
-            const int bb = bt * 16 + n;
-            const double wb = sw[bb];
-            f64x4 D[NT];
-#pragma unroll
-            for (int it = 0; it < NT; ++it) D[it] = (f64x4){0, 0, 0, 0};
-            // B[k][n] = u[a0+k] S[a0+k][bb] w[bb]; the next k-step's S element is loaded while this one is multiplied
-            double s_nxt = S[(size_t)kq * Mp + bb];
-#pragma unroll 4
-            for (int a0 = 0; a0 < MT; a0 += 4) {
-                const int aa = a0 + kq;
-                const double s_cur = s_nxt;
-                s_nxt = S[(size_t)min(aa + 4, MT - 1) * Mp + bb];
-                const double bf = su[aa] * s_cur * wb;
-#pragma unroll
-                for (int it = 0; it < NT; ++it)
-                    D[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(sP[(it * 16 + n) * LD + aa], bf, D[it], 0, 0, 0);
-            }
-#pragma unroll
-            for (int it = 0; it < NT; ++it)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gacc[it][r] = fma(D[it][r], sPinv[bb * LD + it * 16 + kq + 4 * r], gacc[it][r]);
-        }
-        // g_i = sum over the 16 columns (lanes of one DPP row): i = 16 it + kq + 4 r
-#pragma unroll
-        for (int it = 0; it < NT; ++it)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double gi = row16_sum(gacc[it][r]);
-                if (n == 0) sg[it * 16 + kq + 4 * r] = fabs(gi);
-            }
-        wave_lds_fence();
-        const double mine = (lane < M) ? sg[lane] : 0.0;
-        const double tot = wave_sum(mine);
-        if (lane < Mp) a.gamma_rows[row * Mp + lane] = (lane < M) ? (double)span * mine / tot : 0.0;
-        wave_lds_fence();
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
-// Generation 2 of the kernel above (round 3).  Same mathematics, same operand map; what changed:
+// k_gamma_rows_b (round 3; generation 1, k_gamma_rows_mfma, was removed in round 5).  The mathematics and the operand map are those
+// described above; against a one-row-per-wavefront kernel with scalar dot products and a span-Q table in memory:
 //   * u = d o (Pinv alpha), w = P^T beta of SIXTEEN rows at a time as two MFMA products (the rows of a launch share the key, so
 //     Pinv / P are common; the scalar dot products of generation 1 cost as many cycles as the M^3 product itself);
 //   * the span-Q entries are formed on the fly from the group's eigenvalue powers, S_ab = (p_a - p_b) * 1/(d_a - d_b) with the

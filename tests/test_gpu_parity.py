@@ -797,23 +797,6 @@ def test_full_size_whole_genome_scan_vs_lockstep(monkeypatch):
     np.testing.assert_allclose(q_scan, lock.Q(separate=True), rtol=2 * STAT_TOL)
 
 
-def test_gamma_sums_fused_into_the_rank_update(monkeypatch):
-    """SMCPP_GAMMA_FUSE=1: the per-key gamma sums as a one-hot rank update inside the span-1 rank kernel (k_rank_acc_g) instead of
-    k_s1_scalars; same goldens, same tolerances, and against the default path far below them."""
-    res = {}
-    for fuse in ("0", "1"):
-        monkeypatch.setenv("SMCPP_GAMMA_FUSE", fuse)
-        for name in ("G4_M64_n20_2Mbp", "G1_M16_n4", "G5_M48_twopop_layout"):
-            g = load_golden(name)
-            im = make_im(g)
-            im.E_step()
-            check_against(g, im, save_gamma=False)
-            res[(fuse, name)] = im.gamma_sums[0]
-    for name in ("G4_M64_n20_2Mbp", "G1_M16_n4", "G5_M48_twopop_layout"):
-        for k, v in res[("0", name)].items():
-            np.testing.assert_allclose(res[("1", name)][k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
-
-
 def test_span1_statistics_one_pass_in_key_order(monkeypatch):
     """SMCPP_S1_FUSE: the span-1 rank update and the per-key gamma sums in ONE pass over key-sorted single-key slabs (k_rank_acc<3>,
     the default from half a million span-1 rows on) against the two-kernel form (k_s1_scalars + k_rank_acc<0>): same goldens, same

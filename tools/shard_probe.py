@@ -14,10 +14,8 @@ for rank in range(min(world, int(os.environ.get("SHARD_RANKS", 2)))):
     contigs = [synth.synth_contig(i, int(synth.C3_LENGTHS_MBP[i] * 1e6), n) for i in idx]
     rows = sum(len(c) for c in contigs)
     for mode in os.environ.get("SHARD_MODES", "ss,coop,lock").split(","):
-        os.environ.pop("SMCPP_CHAIN", None); os.environ.pop("SMCPP_SS4", None)
-        if mode == "ss4":
-            os.environ["SMCPP_SS4"] = "1"
-        elif mode != "ss":                    # "ss" = the engine's own choice (scan chains)
+        os.environ.pop("SMCPP_CHAIN", None)
+        if mode != "ss":                      # "ss" = the engine's own choice (scan chains)
             os.environ["SMCPP_CHAIN"] = mode
         im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
         im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0

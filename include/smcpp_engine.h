@@ -125,6 +125,23 @@ int smcpp_pack_stats(smcpp_im *im, double *buf, long *n_out, int dev);
 /* Hand the all-reduced buffer back; Q() then evaluates on the global statistics. */
 int smcpp_unpack_stats(smcpp_im *im, const double *buf, long n, int dev);
 
+/* The same exchange issued by the engine itself through RCCL's C API on its own stream (no counterpart in the reference, which
+ * sums over the contigs of one process: src/inference_manager.cpp:116-126, smcpp/_smcpp.pyx:303-308):
+ *   smcpp_rccl_unique_id   rank 0 obtains the 128-byte ncclUniqueId (distribute it to the other ranks by any means);
+ *   smcpp_rccl_init        every rank, after smcpp_set_global_keys: ncclCommInitRank on the manager's device;
+ *   smcpp_rccl_exchange    after smcpp_estep: k_pack_stats -> ncclAllReduce(sum, f64, in place) -> the reduced sum of the
+ *                          log-likelihoods into pinned host memory, all on the engine's stream; returns that sum;
+ *   smcpp_rccl_unpack      hands the reduced statistics (still in the engine's device buffer) to Q();
+ *   smcpp_rccl_fetch       (tests) a host copy of that buffer;  smcpp_rccl_destroy: ncclCommDestroy (also done by smcpp_destroy).
+ * libpath: the RCCL library the process already uses (e.g. torch's lib/librccl.so), NULL or "" for "librccl.so.1"; it is resolved
+ * with dlopen - the engine has no link-time dependency on RCCL. */
+int smcpp_rccl_unique_id(const char *libpath, char *out128);
+int smcpp_rccl_init(smcpp_im *im, const char *libpath, const char *id128, int rank, int world);
+int smcpp_rccl_exchange(smcpp_im *im, double *loglik_sum);
+int smcpp_rccl_unpack(smcpp_im *im);
+int smcpp_rccl_fetch(smcpp_im *im, double *out, long n);
+int smcpp_rccl_destroy(smcpp_im *im);
+
 /* InferenceManager::debug (_smcpp.pxd:53): a public flag the reference declares to Cython; nothing in its C++ reads it. */
 int smcpp_set_debug(smcpp_im *im, int on);
 int smcpp_get_debug(smcpp_im *im);

@@ -61,6 +61,9 @@ def lib():
         "smcpp_init_logger_cb": (None, [C.c_void_p]), "smcpp_init_cache": (i, [C.c_char_p]),
         "smcpp_set_global_keys": (i, [vp, i, _ip]),
         "smcpp_pack_stats": (i, [vp, _dp, C.POINTER(lg), i]), "smcpp_unpack_stats": (i, [vp, _dp, lg, i]),
+        "smcpp_rccl_unique_id": (i, [C.c_char_p, C.c_char_p]), "smcpp_rccl_init": (i, [vp, C.c_char_p, C.c_char_p, i, i]),
+        "smcpp_rccl_exchange": (i, [vp, _dp]), "smcpp_rccl_unpack": (i, [vp]), "smcpp_rccl_fetch": (i, [vp, _dp, lg]),
+        "smcpp_rccl_destroy": (i, [vp]),
         "smcpp_set_chunking": (i, [vp, i, d, d]), "smcpp_set_warm_start": (i, [vp, i]), "smcpp_set_prep_mode": (i, [vp, i]),
         "smcpp_last_timing": (i, [vp, _dp]), "smcpp_last_host_timing": (i, [vp, _dp]), "smcpp_stream": (vp, [vp]), "smcpp_chain_mode": (i, [vp]),
         "smcpp_set_num_threads": (None, [i]),
@@ -103,7 +106,8 @@ EXPORTS = [
     "smcpp_num_keys", "smcpp_key_len", "smcpp_get_hidden_states", "smcpp_set_hidden_states", "smcpp_get_keys",
     "smcpp_get_xisum", "smcpp_get_gamma", "smcpp_get_gamma_sums", "smcpp_get_pi", "smcpp_get_transition",
     "smcpp_get_emission_probs", "smcpp_get_gamma_argmax", "smcpp_set_global_keys", "smcpp_pack_stats",
-    "smcpp_unpack_stats", "smcpp_set_chunking", "smcpp_last_timing", "smcpp_stream", "smcpp_chain_mode", "smcpp_host_chunk_counts", "smcpp_set_num_threads",
+    "smcpp_unpack_stats", "smcpp_rccl_unique_id", "smcpp_rccl_init", "smcpp_rccl_exchange", "smcpp_rccl_unpack", "smcpp_rccl_fetch",
+    "smcpp_rccl_destroy", "smcpp_set_chunking", "smcpp_last_timing", "smcpp_stream", "smcpp_chain_mode", "smcpp_host_chunk_counts", "smcpp_set_num_threads",
     "smcpp_host_eigensystem", "smcpp_host_eigensystem_team", "smcpp_host_prep_onepop", "smcpp_host_prep_onepop_jac", "smcpp_num_derivatives",
     "smcpp_host_rate_function", "smcpp_host_rate_function_jac", "smcpp_host_random_coal_times", "smcpp_host_raw_sfs",
     "smcpp_set_params_twopop", "smcpp_host_joint_csfs", "smcpp_host_prep_twopop", "smcpp_set_warm_start",

@@ -299,6 +299,30 @@ class _PyInferenceManager:
         buf = aca(buf, dtype=np.float64)
         E.check(E.lib().smcpp_unpack_stats(self._im, E.dptr(buf), len(buf), 0))
 
+    # ---- the exchange issued by the engine itself through RCCL's C API (include/smcpp_engine.h: smcpp_rccl_*) ----
+    @staticmethod
+    def rccl_unique_id(libpath=None):
+        out = C.create_string_buffer(128)
+        E.check(E.lib().smcpp_rccl_unique_id((libpath or "").encode(), out))
+        return out.raw
+
+    def rccl_init(self, unique_id, rank, world, libpath=None):
+        E.check(E.lib().smcpp_rccl_init(self._im, (libpath or "").encode(), bytes(unique_id), int(rank), int(world)))
+
+    def rccl_exchange(self):
+        """pack -> ncclAllReduce -> the reduced log-likelihood sum, all on the engine's stream; returns that sum"""
+        v = np.zeros(1)
+        E.check(E.lib().smcpp_rccl_exchange(self._im, E.dptr(v)))
+        return float(v[0])
+
+    def rccl_unpack(self):
+        E.check(E.lib().smcpp_rccl_unpack(self._im))
+
+    def rccl_fetch(self):
+        out = np.zeros(self.stats_len())
+        E.check(E.lib().smcpp_rccl_fetch(self._im, E.dptr(out), len(out)))
+        return out
+
 
 class PyOnePopInferenceManager(_PyInferenceManager):
     """``PyOnePopInferenceManager(n, observations, hidden_states, im_id, polarization_error)`` (_smcpp.pyx:310-332)."""

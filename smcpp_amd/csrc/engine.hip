@@ -9,6 +9,7 @@
 // every compute entry point fails with an error if no HIP device is usable.
 #include <hip/hip_runtime.h>
 #include <omp.h>
+#include <dlfcn.h>
 #include <mutex>
 
 #include <algorithm>
@@ -598,6 +599,7 @@ struct smcpp_im {
     int *d_flags_view = nullptr;  // device address of h_flags
     double *d_ll_view = nullptr;  // device address of h_ll
     int *h_done = nullptr, *d_done_view = nullptr;
+    struct RcclDirect *rccl = nullptr;       // the E-step's exchange issued from here, on `stream` (smcpp_rccl_* below); owned
     int done_epoch = 0;
     DevBuf<unsigned> d_fin_ctr;          // blocks of the finalisation launches that raise h_done themselves (k_fin_both)
     unsigned fin_target = 0;
@@ -1430,7 +1432,14 @@ void smcpp_im::prepare_params() {
         // emissions from the joint CSFS of (population 1, population 2, split)
         if (model_p1.a.empty() || model_p2.a.empty())
             throw std::runtime_error("two-population manager: call set_params_twopop (or set_raw) before E_step");
-        if (!twopop_prep) twopop_prep.reset(new smcpp_host::TwoPopPrep(n[0], n[1], na[0], na[1], hs, polarization_error));
+        if (!twopop_prep) {
+            twopop_prep.reset(new smcpp_host::TwoPopPrep(n[0], n[1], na[0], na[1], hs, polarization_error));
+            // The two-population preparation is the one host phase that still runs on a team of threads, in two parallel regions per
+            // eval; with libomp's workers asleep in between (block time 0, above) each region pays their wake-up - more than its
+            // work.  One millisecond of spinning spans the GPU phase of an eval: config C4 561 -> 676 evals/s (15 threads; measured
+            // profiles/r05_*).  SMCPP_OMP_BLOCKTIME overrides.
+            if (kmp_set_blocktime && !getenv("SMCPP_OMP_BLOCKTIME")) kmp_set_blocktime(1);
+        }
         smcpp_host::TwoPopPrep &prep = *twopop_prep;
         E_on_dev = false;
         tgen_valid = false; dT_valid = true;
@@ -3205,7 +3214,8 @@ int smcpp_create_twopop(int n1, int n2, int a1, int a2, int n_contigs, const int
     API_END
 }
 
-void smcpp_destroy(smcpp_im *im) { delete im; }
+int smcpp_rccl_destroy(smcpp_im *im);
+void smcpp_destroy(smcpp_im *im) { if (im && im->rccl) (void)smcpp_rccl_destroy(im); delete im; }
 
 int smcpp_set_theta(smcpp_im *im, double v) { API_BEGIN im->params_fresh = false; im->theta = v; im->dirty = true; if (im->have_model) im->have_raw = false; API_END }
 int smcpp_set_rho(smcpp_im *im, double v) { API_BEGIN im->params_fresh = false; im->rho = v; im->dirty = true; if (im->have_model) im->have_raw = false; API_END }
@@ -3666,6 +3676,139 @@ int smcpp_unpack_stats(smcpp_im *im, const double *buf, long n, int dev) {
     } else std::memcpy(im->g_stats.data(), buf, sizeof(double) * n);
     im->have_reduced = true;
     if (im->qdev) im->qdev->stats_ready = false;
+    API_END
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The exchange of an E-step issued by the ENGINE on its own stream through RCCL's C API (the reference has no
+// counterpart: it sums over contigs in one process, inference_manager.cpp:116-126):
+//     k_pack_stats -> ncclAllReduce(sum, f64, in place) -> k_publish_scalar (sum of the log-likelihoods into pinned host memory)
+// all stream-ordered, the host polls one word - no event hop to a communication stream, no host wait before the collective, no
+// copy engine for the scalar.  The library is the one the process already holds (path handed over by the caller: torch's RCCL when
+// torch.distributed is in use), resolved with dlopen / dlsym so that the engine has no link-time dependency on it.
+// ---------------------------------------------------------------------------------------------------------------
+struct ncclUniqueIdBlob { char b[128]; };       // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
+static void check_rc(int rc) { if (rc) throw std::runtime_error(g_err); }
+struct RcclDirect {
+    void *lib = nullptr;
+    void *comm = nullptr;
+    int world = 1, rank = 0;
+    int (*get_uid)(void *) = nullptr;
+    int (*init_rank)(void **, int, ncclUniqueIdBlob, int) = nullptr;
+    int (*all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*destroy)(void *) = nullptr;
+    const char *(*err_string)(int) = nullptr;
+    DevBuf<double> buf;
+    long n = 0;
+    double *h_val = nullptr, *d_val_view = nullptr;
+    int *h_flag = nullptr, *d_flag_view = nullptr;
+    int epoch = 0;
+    bool reduced_in_buf = false;
+};
+static void rccl_resolve(RcclDirect &r, const char *libpath) {
+    r.lib = dlopen(libpath && *libpath ? libpath : "librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!r.lib) throw std::runtime_error(std::string("RCCL library not loadable: ") + dlerror());
+    auto sym = [&](const char *nm) {
+        void *p = dlsym(r.lib, nm);
+        if (!p) throw std::runtime_error(std::string("RCCL symbol missing: ") + nm);
+        return p;
+    };
+    r.get_uid = reinterpret_cast<int (*)(void *)>(sym("ncclGetUniqueId"));
+    r.init_rank = reinterpret_cast<int (*)(void **, int, ncclUniqueIdBlob, int)>(sym("ncclCommInitRank"));
+    r.all_reduce = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)>(sym("ncclAllReduce"));
+    r.destroy = reinterpret_cast<int (*)(void *)>(sym("ncclCommDestroy"));
+    r.err_string = reinterpret_cast<const char *(*)(int)>(sym("ncclGetErrorString"));
+}
+static void rccl_check(const RcclDirect &r, int rc, const char *what) {
+    if (rc != 0) throw std::runtime_error(std::string("RCCL: ") + what + ": " + (r.err_string ? r.err_string(rc) : "error"));
+}
+int smcpp_rccl_unique_id(const char *libpath, char *out128) {
+    API_BEGIN
+    RcclDirect r;
+    rccl_resolve(r, libpath);
+    ncclUniqueIdBlob id;
+    rccl_check(r, r.get_uid(&id), "ncclGetUniqueId");
+    std::memcpy(out128, id.b, 128);
+    API_END
+}
+int smcpp_rccl_init(smcpp_im *im, const char *libpath, const char *id128, int rank, int world) {
+    API_BEGIN
+    if (im->rccl) throw std::runtime_error("smcpp_rccl_init: already initialised");
+    HIPCHK(hipSetDevice(im->device));
+    std::unique_ptr<RcclDirect> r(new RcclDirect());
+    rccl_resolve(*r, libpath);
+    ncclUniqueIdBlob id;
+    std::memcpy(id.b, id128, 128);
+    r->world = world; r->rank = rank;
+    rccl_check(*r, r->init_rank(&r->comm, world, id, rank), "ncclCommInitRank");
+    HIPCHK(hipHostMalloc((void **)&r->h_val, 64, hipHostMallocCoherent | hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void **)&r->d_val_view, r->h_val, 0));
+    HIPCHK(hipHostMalloc((void **)&r->h_flag, 64, hipHostMallocCoherent | hipHostMallocMapped));
+    *r->h_flag = 0;
+    HIPCHK(hipHostGetDevicePointer((void **)&r->d_flag_view, r->h_flag, 0));
+    im->rccl = r.release();
+    API_END
+}
+int smcpp_rccl_destroy(smcpp_im *im) {
+    API_BEGIN
+    if (im->rccl) {
+        HIPCHK(hipSetDevice(im->device));
+        (void)hipStreamSynchronize(im->stream);
+        if (im->rccl->comm && im->rccl->destroy) (void)im->rccl->destroy(im->rccl->comm);
+        if (im->rccl->h_val) (void)hipHostFree(im->rccl->h_val);
+        if (im->rccl->h_flag) (void)hipHostFree(im->rccl->h_flag);
+        delete im->rccl;
+        im->rccl = nullptr;
+    }
+    API_END
+}
+// After smcpp_estep: pack -> all-reduce -> publish, returns the all-reduced sum of the log-likelihoods.  The reduced statistics
+// stay in the engine's device buffer until smcpp_rccl_unpack hands them to Q.
+int smcpp_rccl_exchange(smcpp_im *im, double *loglik_sum) {
+    API_BEGIN
+    RcclDirect *r = im->rccl;
+    if (!r) throw std::runtime_error("smcpp_rccl_exchange: smcpp_rccl_init has not been called");
+    long n = 0;
+    check_rc(smcpp_pack_stats(im, nullptr, &n, 0));
+    if (r->n != n) { r->buf.alloc((size_t)n); r->n = n; }
+    check_rc(smcpp_pack_stats(im, r->buf.p, nullptr, 2));                  // enqueue only
+    rccl_check(*r, r->all_reduce(r->buf.p, r->buf.p, (size_t)n, /* ncclDouble */ 8, /* ncclSum */ 0, r->comm, im->stream), "ncclAllReduce");
+    const int ep = ++r->epoch;
+    hipLaunchKernelGGL(k_publish_scalar, dim3(1), dim3(1), 0, im->stream, (const double *)r->buf.p, r->d_val_view, r->d_flag_view, ep);
+    HIPCHK(hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(r->h_flag, __ATOMIC_ACQUIRE) != ep) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+        if ((++spins & 0x3fff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) {
+            HIPCHK(hipStreamSynchronize(im->stream));
+            break;
+        }
+    }
+    *loglik_sum = *r->h_val;
+    r->reduced_in_buf = true;
+    API_END
+}
+int smcpp_rccl_unpack(smcpp_im *im) {
+    API_BEGIN
+    RcclDirect *r = im->rccl;
+    if (!r || !r->reduced_in_buf) throw std::runtime_error("smcpp_rccl_unpack: no reduced statistics to hand over");
+    check_rc(smcpp_unpack_stats(im, r->buf.p, r->n, 1));
+    r->reduced_in_buf = false;
+    API_END
+}
+// (test hook) a copy of the engine's reduce buffer
+int smcpp_rccl_fetch(smcpp_im *im, double *out, long n) {
+    API_BEGIN
+    RcclDirect *r = im->rccl;
+    if (!r || n != r->n) throw std::runtime_error("smcpp_rccl_fetch: wrong length");
+    HIPCHK(hipSetDevice(im->device));
+    HIPCHK(hipStreamSynchronize(im->stream));
+    HIPCHK(hipMemcpy(out, r->buf.p, sizeof(double) * n, hipMemcpyDeviceToHost));
     API_END
 }
 

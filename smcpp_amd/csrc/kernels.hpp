@@ -729,6 +729,12 @@ __global__ __launch_bounds__(256) void k_loglik_final(LoglikArgs a) {
 __global__ void k_signal(int *flag, int value) {
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// ... and one scalar with it (the all-reduced sum of the log-likelihoods, first entry of the packed statistics)
+__global__ void k_publish_scalar(const double *src, double *host_val, int *flag, int value) {
+    *host_val = *src;
+    __threadfence_system();
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // K3: span-1 rows — per-row scalars and gamma sums  (hmm.cpp:134-138,146-148)

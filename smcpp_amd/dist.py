@@ -137,7 +137,7 @@ class ShardedInferenceManager:
     """
 
     def __init__(self, n, observations, hidden_states, im_id, polarization_error, *, device=-1, group=None,
-                 lengths=None, factory=None, always_reduce=False, a=None):
+                 lengths=None, factory=None, always_reduce=False, a=None, direct_rccl=None):
         import torch.distributed as dist
         self._group = group
         self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
@@ -183,6 +183,20 @@ class ShardedInferenceManager:
             # global key dictionary: fixes the layout of the gamma_sums block and makes the engine prepare the
             # emission vectors of keys only other ranks' contigs hold (they enter Q through the reduced statistics)
             self.im.set_global_keys(union_keys(self.im.keys, group))
+        # direct_rccl (opt-in; env SMCPP_RCCL_DIRECT=1): the ENGINE issues the all-reduce itself through RCCL's C API on its own
+        # stream (pack kernel -> ncclAllReduce -> the reduced scalar into pinned host memory: no hop to a communication stream, no
+        # copy engine), with a communicator of its own built from an id that rank 0 broadcasts over the torch group
+        import os
+        if direct_rccl is None:
+            direct_rccl = os.environ.get("SMCPP_RCCL_DIRECT", "0") not in ("", "0")
+        self._direct = bool(direct_rccl) and self._reduce and self._nccl
+        if self._direct:
+            import torch
+            lib = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            lib = lib if os.path.exists(lib) else None              # (else the system's librccl.so.1)
+            box = [self.im.rccl_unique_id(lib) if self.rank == 0 else None]
+            self._dist.broadcast_object_list(box, src=self._dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            self.im.rccl_init(box[0], self.rank, self.world, lib)
 
     # ---- parameters: passed through to the local manager (every rank sets the same values) ----
     @property
@@ -216,7 +230,10 @@ class ShardedInferenceManager:
             self._ll_sum = float(self.im.loglik())
             return
         import torch
-        if self._nccl:
+        if self._direct and not self.keep_stats:
+            self._ll_sum = self.im.rccl_exchange()
+            self._unpack_pending = True
+        elif self._nccl:
             dev = torch.device("cuda", self._device)
             if self._buf is None:
                 # on the device the ENGINE lives on (the pack / unpack kernels dereference the pointer there)
@@ -270,7 +287,10 @@ class ShardedInferenceManager:
 
     def _ensure_unpacked(self):
         if self._unpack_pending:
-            self.im.unpack_stats_device(self._buf.data_ptr(), self._buf.numel())
+            if self._direct and not self.keep_stats:
+                self.im.rccl_unpack()
+            else:
+                self.im.unpack_stats_device(self._buf.data_ptr(), self._buf.numel())
             self._unpack_pending = False
 
     def Q(self, separate=False):

@@ -120,8 +120,17 @@ def _exact_worker(rank, world, port, out_dir, backend):
     _setup(sim, g, True)
     sim.E_step()
     q, jac = sim.Q_with_gradient()
+    extra = {}
+    if backend == "nccl":
+        # the same exchange issued by the engine through RCCL's C API (own communicator): bitwise the same reduced buffer and Q
+        sim2 = sd.ShardedInferenceManager(10, contigs, g["hs"], ("pop1",), 0.5, device=dev, direct_rccl=True)
+        assert sim2._direct
+        _setup(sim2, g, True)
+        sim2.E_step()
+        extra = dict(direct_reduced=sim2.im.rccl_fetch(), direct_q=np.array(sim2.Q(separate=True)), direct_ll=np.array(sim2.loglik()),
+                     ll=np.array(sim.loglik()), q4=np.array(sim.Q(separate=True)))
     np.savez(os.path.join(out_dir, f"x{rank}.npz"), local=sim.last_local_stats, reduced=sim.last_reduced_stats, mine=np.array(sim.mine),
-             q=q, jac=jac, nccl=np.array(sim._nccl))
+             q=q, jac=jac, nccl=np.array(sim._nccl), **extra)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -161,6 +170,9 @@ def test_reduction_is_exact_two_ranks_rccl(tmp_path):
     mp.spawn(_exact_worker, args=(2, _free_port(), str(tmp_path), "nccl"), nprocs=2, join=True)
     _check_exact(tmp_path, 2)
     assert bool(np.load(tmp_path / "x0.npz")["nccl"])
+    for i in range(2):
+        r = np.load(tmp_path / f"x{i}.npz")
+        assert np.array_equal(r["direct_reduced"], r["reduced"]) and np.array_equal(r["direct_q"], r["q4"]) and r["direct_ll"] == r["ll"]
 
 
 def _nccl_worker(rank, port, out_dir):
@@ -205,7 +217,17 @@ def _nccl_worker(rank, port, out_dir):
     wait_us = per_eval(lambda: (sim.E_step(), sim.loglik()))
     sim.stream_ordered = True; sim._buf = None
     ordered_us = per_eval(lambda: (sim.E_step(), sim.loglik()))
-    res["exchange_us"] = dict(local_eval=local_us, host_wait=wait_us - local_us, stream_ordered=ordered_us - local_us)
+    # ... and issued by the engine itself through RCCL's C API (smcpp_rccl_*: own communicator, the engine's stream, polled scalar)
+    sim2 = ShardedInferenceManager(10, contigs, g["hs"], ("pop1",), 0.5, always_reduce=True, direct_rccl=True)
+    assert sim2._direct
+    _setup(sim2, g, True)
+    sim2.E_step()
+    res["direct_loglik"] = sim2.loglik()
+    res["direct_same_buffer"] = bool(np.array_equal(buf_a, sim2.im.rccl_fetch()))
+    res["direct_q"] = list(map(float, sim2.Q(separate=True)))
+    direct_us = per_eval(lambda: (sim2.E_step(), sim2.loglik()))
+    res["exchange_us"] = dict(local_eval=local_us, host_wait=wait_us - local_us, stream_ordered=ordered_us - local_us,
+                              direct_rccl=direct_us - local_us)
     print("nccl world of one: exchange cost per eval (us)", res["exchange_us"], flush=True)
     with open(os.path.join(out_dir, "nccl.json"), "w") as f:
         json.dump(res, f)
@@ -228,6 +250,7 @@ def test_nccl_device_buffer_branch_world_of_one(tmp_path):
     assert r["buf_device"].startswith("cuda")
     assert r["stream_ordered"] and r["host_wait_same_buffer"] and r["host_wait_loglik"] == r["loglik"]
     print("exchange cost per eval (us):", r["exchange_us"])
+    assert r["direct_same_buffer"] and r["direct_loglik"] == r["loglik"] and r["direct_q"] == r["q"]
     assert r["keys"] == im.keys.tolist()
     assert abs(r["loglik"] - im.loglik()) <= 1e-12 * abs(im.loglik())
     np.testing.assert_allclose(r["logliks"], im.logliks(), rtol=1e-13)

@@ -374,17 +374,24 @@ def main():
         else:
             positions = float(sum(int(c[:, 0].sum()) for c in contigs))
         npl = (M + 63) // 64
-        # VALU instructions per position in the inner loops of k_chain_ss<NPL> (llvm-objdump of the shipped code object, two
-        # positions per trip): full fp64 pass forward / backward, light float pass forward / backward
-        ipp = {1: (45, 57, 20, 28), 2: (56, 74, 28, 39), 3: (65, 88, 36, 53), 4: (74, 102, 41, 56)}.get(npl)
+        # VALU instructions per position in the inner loops of k_chain_ss<NPL> (llvm-objdump of the shipped code object; DESIGN.md
+        # section 5): stored pass forward / backward, light float pass forward / backward.  One state per lane (round 5): every scan of
+        # the stored passes in float - 25 / 31 VALU (+ 6 / 2 hazard slots) where the fp64 scans took 45 / 57 (+ 7); M <= 32: 21 / 25
+        ipp = {1: (25, 31, 20, 28), 2: (56, 74, 28, 39), 3: (65, 88, 36, 53), 4: (74, 102, 41, 56)}.get(npl)
+        if npl == 1 and M <= 32:
+            ipp = (21, 25, 18, 25)
+        if npl == 1 and args.workload in ("posterior", "posterior64"):
+            ipp = (45, 57, 20, 28)                         # save_gamma keeps the fp64 scans
         sq = sq_counters(args.workload if (args.length_mbp == 100.0 and world == 1) else None, kname)
         passes = med["fwd_passes"]
         est_instr = None
+        one_pass_instr = None
         if ipp is not None:
             # per E-step: `light` float passes + one full pass + the merge re-runs (which stop after the forgetting length: their
             # share of a full pass is what the timing split says, not a count) - a MODEL, used only without counters
             light = max(0.0, passes - 2.0)
             est_instr = positions * (light * (ipp[2] + ipp[3]) + 1.4 * (ipp[0] + ipp[1]))
+            one_pass_instr = positions * (ipp[0] + ipp[1])     # what ONE sequential pass of both chains needs (the useful work)
         instr = sq["SQ_INSTS_VALU_per_step"] if sq else est_instr
         # peak: G wave64-instructions / s of the vector ALUs.  A SIMD needs 4 cycles per wave64 DPP or fp64 instruction - the two
         # kinds the scans are made of: 1024 SIMDs x 2.4 GHz / 4 = 614.4 (= the guide's 157.3 TFLOP/s FP32 vector peak / 256 flop per
@@ -404,6 +411,9 @@ def main():
                  "peak_source": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 DPP / fp64 instruction (MI355X_MICROARCH.md: 157.3 TFLOP/s FP32 "
                                 "vector = 614.4 G v_pk_fma_f32 / s); tools/dpp_lab.hip measures 583 - 587 with 8 wavefronts per SIMD, 427 - 468 with one",
                  "frac_one_wavefront_issue_bound": (ach_ginstr / one_wave_ginstr) if ach_ginstr else None,
+                 "one_pass_instr": one_pass_instr,
+                 "executed_over_one_pass": (instr / one_pass_instr) if (instr and one_pass_instr) else None,
+                 "useful_instr_frac_of_peak": (one_pass_instr / (1e-3 * k_ms) / 1e9 / peak_ginstr) if (one_pass_instr and k_ms > 0) else None,
                  "sq_counters": sq,
                  "executed_flops_estimate": 30.0 * M * positions * 2.0,
                  "frac_dense_equivalent": ach_tflops / FP64_PEAK_TFLOPS, "dense_equivalent_tflops": ach_tflops,

@@ -62,6 +62,9 @@ struct SsArgs {
     int mixed = 0;              // M <= 64, no save_gamma: every scan of the full / re-run passes in float (ss_fwd_step<1, true>; the suffix sums native)
     int dirsplit = 0;           // hybrid rows, M > 32: a workgroup runs ONE direction and stages only that direction's two tables per eigen key
     int hyb_th = 0x7fffffff, Ke = 0, hot_ek = 0;   // hot_ek: the eigen key with the most rows (its table rows stay in registers)
+    // eigen keys whose tables live in LDS (the most frequent ones, as many as fit): nk_lds of them, key_of_slot[slot] = eigen key,
+    // slot_of_key[key] = LDS slot or -1 - a COLD key's table rows come from L2 (M > 32 with three or four eigen keys: round 5)
+    int nk_lds = 0, key_of_slot[4] = {0, 1, 2, 3}, slot_of_key[4] = {0, 1, 2, 3};
     const double *Pinvrm = nullptr, *Prm = nullptr, *PinvT = nullptr, *PT = nullptr;   // [Ke][Mp][Mp]
     const double *dsc = nullptr;               // [Ke][Mp] scaled eigenvalues d / scale
 };
@@ -494,7 +497,7 @@ __device__ __forceinline__ double ss_exp_neg(double x) {
     p = __builtin_fma(p, r, 1.0);
     return ldexp(p, (int)n);
 }
-struct SsEigC { double ld[SS_KE_MAX]; bool neg[SS_KE_MAX]; int r, g, nb, G, tpk; };      // tpk: tables per eigen key in LDS (4, or 2 with `dirsplit`)
+struct SsEigC { double ld[SS_KE_MAX]; bool neg[SS_KE_MAX]; int slot[SS_KE_MAX]; int r, g, nb, G, tpk; };      // tpk: tables per eigen key in LDS (4, or 2 with `dirsplit`)
 __device__ __forceinline__ void ss_load_eig(const SsArgs &a, int lp, SsEigC &c) {
     c.G = a.Mp <= 32 ? 2 : 1;
     c.tpk = a.dirsplit ? 2 : 4;
@@ -506,6 +509,7 @@ __device__ __forceinline__ void ss_load_eig(const SsArgs &a, int lp, SsEigC &c) 
         if (e < a.Ke && c.r < a.M) d = a.dsc[(size_t)e * a.Mp + c.r];
         c.ld[e] = log(fabs(d));                     // -inf for a zero (padded) eigenvalue: its power is 0
         c.neg[e] = d < 0.0;
+        c.slot[e] = a.slot_of_key[e];
     }
 }
 __device__ __forceinline__ double ss_eig_pow(const SsEigC &c, int ek, int span) {
@@ -519,10 +523,10 @@ __device__ __forceinline__ double ss_eig_pow(const SsEigC &c, int ek, int span) 
 // LDS tables: [Ke][4][Mp][Mp + 1]: 0 = Pinv, 1 = P (forward), 2 = P^T, 3 = Pinv^T (backward), row-major, padded rows; behind
 // them one [64] scratch vector per wavefront.  `dirsplit` (M > 32: four tables of 33 KB per key do not fit): [Ke][2][..], the pair of
 // the ONE direction the workgroup runs - table `which` sits at index which & 1
-__device__ __forceinline__ double ss_eig_matvec(const SsEigC &c, const double *tab, int Mp, int ek, int which, double *sx, int lp, double x) {
+__device__ __forceinline__ double ss_eig_matvec(const SsEigC &c, const double *tab, int Mp, int slot, int which, double *sx, int lp, double x) {
     sx[lp] = x;
     wave_lds_fence();
-    const double *row = tab + ((size_t)(ek * c.tpk + (which & (c.tpk - 1))) * Mp + min(c.r, Mp - 1)) * (Mp + 1) + c.g * c.nb;
+    const double *row = tab + ((size_t)(slot * c.tpk + (which & (c.tpk - 1))) * Mp + min(c.r, Mp - 1)) * (Mp + 1) + c.g * c.nb;
     const double *xv = sx + c.g * c.nb;
     double a0 = 0.0, a1 = 0.0;
     for (int b = 0; b < c.nb; b += 4) {
@@ -530,6 +534,26 @@ __device__ __forceinline__ double ss_eig_matvec(const SsEigC &c, const double *t
         const double v0 = xv[b], v1 = xv[b + 1], v2 = xv[b + 2], v3 = xv[b + 3];
         a0 = __builtin_fma(r0, v0, a0); a1 = __builtin_fma(r1, v1, a1);
         a0 = __builtin_fma(r2, v2, a0); a1 = __builtin_fma(r3, v3, a1);
+    }
+    double acc = a0 + a1;
+    if (c.G >= 2) acc = ss_sum_halves(acc);
+    wave_lds_fence();
+    return acc;
+}
+// ... of a COLD eigen key (no LDS slot): this lane's table row straight from the row-major matrix in global memory (L2), eight
+// loads in flight; the vector through the same LDS scratch.  `mat` = the key's Mp x Mp matrix of the product (P^-1, P, P^T, P^-T).
+__device__ __forceinline__ double ss_eig_matvec_cold(const SsEigC &c, const double *mat, int Mp, double *sx, int lp, double x) {
+    sx[lp] = x;
+    wave_lds_fence();
+    const double *row = mat + (size_t)min(c.r, Mp - 1) * Mp + c.g * c.nb;
+    const double *xv = sx + c.g * c.nb;
+    double a0 = 0.0, a1 = 0.0;
+    for (int b = 0; b < c.nb; b += 8) {
+        double rr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rr[q] = row[b + q];
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) { a0 = __builtin_fma(rr[q], xv[b + q], a0); a1 = __builtin_fma(rr[q + 1], xv[b + q + 1], a1); }
     }
     double acc = a0 + a1;
     if (c.G >= 2) acc = ss_sum_halves(acc);
@@ -577,17 +601,28 @@ __device__ __forceinline__ double ss_eig_step(const SsEigC &c, const double *tab
     wave_lds_fence();
     return o;
 }
-// dispatcher: Mp = 32 / 16 take the latency-arranged form, larger Mp the generic products
-__device__ __forceinline__ double ss_eig_apply(const SsEigC &c, const double *tab, int Mp, int ek, int w0, double *sx, int lp,
+// dispatcher: Mp = 32 / 16 take the latency-arranged form (every eigen key has its tables in LDS there), larger Mp the generic
+// products - from LDS for the keys that have a slot, from L2 for a cold key
+__device__ __forceinline__ double ss_eig_apply(const SsArgs &a, const SsEigC &c, const double *tab, int Mp, int ek, int w0, double *sx, int lp,
                                                double xin, int span, const SsHotRows<16> &hot, int hot_ek) {
     if (Mp == 32) return ss_eig_step<16>(c, tab, Mp, ek, w0, sx, lp, xin, span, hot, hot_ek);
     if (Mp == 16) {
         SsHotRows<8> none;                                // (M <= 16: the rows come from LDS)
         return ss_eig_step<8>(c, tab, Mp, ek, w0, sx, lp, xin, span, none, -1);
     }
-    double u = ss_eig_matvec(c, tab, Mp, ek, w0, sx, lp, xin);
+    int slot = c.slot[0];
+#pragma unroll
+    for (int e = 1; e < SS_KE_MAX; ++e) if (ek == e) slot = c.slot[e];
+    if (slot >= 0) {                                      // wave-uniform
+        double u = ss_eig_matvec(c, tab, Mp, slot, w0, sx, lp, xin);
+        u *= ss_eig_pow(c, ek, span);
+        return ss_eig_matvec(c, tab, Mp, slot, w0 + 1, sx, lp, lp < 64 / c.G ? u : 0.0);
+    }
+    const size_t MM = (size_t)Mp * Mp;
+    const double *m0 = (w0 == 0 ? a.Pinvrm : a.PT) + (size_t)ek * MM, *m1 = (w0 == 0 ? a.Prm : a.PinvT) + (size_t)ek * MM;
+    double u = ss_eig_matvec_cold(c, m0, Mp, sx, lp, xin);
     u *= ss_eig_pow(c, ek, span);
-    return ss_eig_matvec(c, tab, Mp, ek, w0 + 1, sx, lp, lp < 64 / c.G ? u : 0.0);
+    return ss_eig_matvec_cold(c, m1, Mp, sx, lp, lp < 64 / c.G ? u : 0.0);
 }
 
 template <int NPL, bool ALLLDS>
@@ -696,7 +731,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
         ss_load_eig(a, lane, ec);
         if (Mp == 32) { hot_ek = a.hot_ek; ss_eig_rows<16>(ec, tab, Mp, hot_ek, 0, hot.a, hot.b); }
     }
-    double *sxw = const_cast<double *>(tab) + (size_t)a.Ke * (a.dirsplit ? 2 : 4) * Mp * (Mp + 1) + (threadIdx.x >> 6) * 64;
+    double *sxw = const_cast<double *>(tab) + (size_t)a.nk_lds * (a.dirsplit ? 2 : 4) * Mp * (Mp + 1) + (threadIdx.x >> 6) * 64;
     bool merged = false;
     const long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
     long long npos = 0;
@@ -731,7 +766,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
                 if (lane == 0) crow[j] = S;
                 xin = (double)an;
             }
-            const double xo = ss_eig_apply(ec, tab, Mp, ekr, 0, sxw, lane, xin, span, hot, hot_ek);
+            const double xo = ss_eig_apply(a, ec, tab, Mp, ekr, 0, sxw, lane, xin, span, hot, hot_ek);
             x[0] = live[0] ? xo : 0.0;
 #pragma unroll
             for (int k = 0; k < NPL; ++k) e[k] = en[k];
@@ -925,7 +960,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
         ss_load_eig(a, 63 - lane, ec);
         if (Mp == 32) { hot_ek = a.hot_ek; ss_eig_rows<16>(ec, tab, Mp, hot_ek, 2, hot.a, hot.b); }
     }
-    double *sxw = const_cast<double *>(tab) + (size_t)a.Ke * (a.dirsplit ? 2 : 4) * Mp * (Mp + 1) + (threadIdx.x >> 6) * 64;
+    double *sxw = const_cast<double *>(tab) + (size_t)a.nk_lds * (a.dirsplit ? 2 : 4) * Mp * (Mp + 1) + (threadIdx.x >> 6) * 64;
     bool merged = false;
     const long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
     long long npos = 0;
@@ -969,7 +1004,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
         if (hyb && span > a.hyb_th) {
             // ---- hybrid row: b <- P^-T (d~^s o (P^T b)), renormalised (every consumer of beta is scale free) ----
             const double bin = live[0] ? b[0] : 0.0;
-            double bo = ss_eig_apply(ec, tab, Mp, ekr, 2, sxw, 63 - lane, bin, span, hot, hot_ek);
+            double bo = ss_eig_apply(a, ec, tab, Mp, ekr, 2, sxw, 63 - lane, bin, span, hot, hot_ek);
             bo = live[0] ? bo : 0.0;
             b[0] = bo * rcp_f64(wave_sum_dpp(bo));
 #pragma unroll
@@ -1435,16 +1470,16 @@ __global__ __launch_bounds__(HYB ? 512 : 256) void k_chain_ss(SsArgs a) {
             int t0 = -1;
             for (int i = 0; i < nw && t0 < 0; ++i) t0 = a.tasks[nw * blockIdx.x + i];
             const bool wg_bwd = t0 >= 0 && (t0 >> 30);
-            for (int idx = tid; idx < a.Ke * 2 * MM; idx += nthr) {
+            for (int idx = tid; idx < a.nk_lds * 2 * MM; idx += nthr) {
                 const int mat = idx / MM, rc = idx % MM, r = rc / Mp, cc = rc % Mp;
-                const int e = mat >> 1, which = (mat & 1) + (wg_bwd ? 2 : 0);
+                const int e = a.key_of_slot[mat >> 1], which = (mat & 1) + (wg_bwd ? 2 : 0);
                 const double *src = which == 0 ? a.Pinvrm : which == 1 ? a.Prm : which == 2 ? a.PT : a.PinvT;
                 tab[((size_t)mat * Mp + r) * (Mp + 1) + cc] = src[(size_t)e * MM + rc];
             }
         } else
-        for (int idx = tid; idx < a.Ke * 4 * MM; idx += nthr) {
+        for (int idx = tid; idx < a.nk_lds * 4 * MM; idx += nthr) {
             const int mat = idx / MM, rc = idx % MM, r = rc / Mp, cc = rc % Mp;
-            const int e = mat >> 2, which = mat & 3;
+            const int e = a.key_of_slot[mat >> 2], which = mat & 3;
             const double *src = which == 0 ? a.Pinvrm : which == 1 ? a.Prm : which == 2 ? a.PT : a.PinvT;
             tab[((size_t)mat * Mp + r) * (Mp + 1) + cc] = src[(size_t)e * MM + rc];
         }

@@ -520,7 +520,10 @@ struct smcpp_im {
     static constexpr int SS_HYB_COST = 8;
     long long ss_row_cost(int span) const { return (ss_hybrid && span > ss_hyb_th) ? SS_HYB_COST : span; }
     bool ss_dirsplit = false;              // hybrid rows at M > 32: single-direction workgroups with two tables per eigen key (chains_ss.hpp)
-    size_t ss_tab_bytes() const { return ss_hybrid ? ((size_t)Ke * (ss_dirsplit ? 2 : 4) * Mp * (Mp + 1) + 8 * 64) * sizeof(double) : 0; }   // + one scratch vector per wavefront
+    // eigen keys whose tables the hybrid rows keep in LDS (all of them unless they do not fit: then the most frequent ones, the
+    // rest - COLD keys - read their table rows from L2; M > 32 with three or four eigen keys)
+    int ss_nk_lds = 0, ss_ekey_of_slot[4] = {0, 1, 2, 3}, ss_eslot_of_key[4] = {0, 1, 2, 3};
+    size_t ss_tab_bytes() const { return ss_hybrid ? ((size_t)ss_nk_lds * (ss_dirsplit ? 2 : 4) * Mp * (Mp + 1) + 8 * 64) * sizeof(double) : 0; }   // + one scratch vector per wavefront
     bool ss_active = false;                // this E-step's chains run on the scan kernels
     bool eigfree = false;                  // ... and its statistics need no eigensystem either (k_span_fold): no eigensolve at all
     int ss_max_span = 0;
@@ -891,6 +894,25 @@ void smcpp_im::make_chunks() {
                     // runs one direction (the task table keeps them apart) and stages that direction's pair
                     ss_static = ss_hybrid = ss_dirsplit = true;
                     ss_hyb_th = getenv("SMCPP_HYB_TH") ? std::max(1, atoi(getenv("SMCPP_HYB_TH"))) : 6;
+                } else if (!(hy && atoi(hy) == 0) && Mp > 32 && Mp <= 64 && Ke >= 1 && Ke <= 4 && tab / 2 / Ke <= 136 * 1024) {
+                    // (round 5) ... and with three or four eigen keys at M > 32 not even those: the most frequent keys keep their pair
+                    // in LDS, a COLD key's table rows are read from L2 on the rows that need them (chains_ss.hpp: ss_eig_matvec_cold)
+                    ss_static = ss_hybrid = ss_dirsplit = true;
+                    ss_hyb_th = getenv("SMCPP_HYB_TH") ? std::max(1, atoi(getenv("SMCPP_HYB_TH"))) : 6;
+                }
+                ss_nk_lds = Ke;
+                for (int e = 0; e < 4; ++e) ss_ekey_of_slot[e] = ss_eslot_of_key[e] = e;
+                if (ss_hybrid && ss_dirsplit && tab / 2 > 136 * 1024) {
+                    // slots by frequency of the keys' hybrid rows
+                    std::vector<long long> cnt(Ke, 0);
+                    for (const RowInfo &ri : rowinfo)
+                        if (ri.gid >= 0 && groups[ri.gid].span > ss_hyb_th) ++cnt[groups[ri.gid].eig];
+                    std::vector<int> order(Ke);
+                    for (int e = 0; e < Ke; ++e) order[e] = e;
+                    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cnt[x] > cnt[y]; });
+                    ss_nk_lds = (int)std::max<size_t>(1, std::min<size_t>((size_t)Ke, (size_t)(136 * 1024) / (tab / 2 / Ke)));
+                    for (int e = 0; e < 4; ++e) ss_eslot_of_key[e] = -1;
+                    for (int sl = 0; sl < ss_nk_lds; ++sl) { ss_ekey_of_slot[sl] = order[sl]; ss_eslot_of_key[order[sl]] = sl; }
                 }
             }
             if (ss_static) chain_mode = Mp > 64 ? 3 : 2;
@@ -2570,6 +2592,8 @@ void smcpp_im::ss_launch_initial() {
     }
     if (ss_hybrid) {
         a.hyb_th = ss_hyb_th; a.Ke = Ke; a.hot_ek = std::max(0, hot_eig); a.dirsplit = ss_dirsplit ? 1 : 0;
+        a.nk_lds = ss_nk_lds;
+        for (int e = 0; e < 4; ++e) { a.key_of_slot[e] = ss_ekey_of_slot[e]; a.slot_of_key[e] = ss_eslot_of_key[e]; }
         a.Pinvrm = d_Pinvrm.p; a.Prm = d_Prm.p; a.PinvT = d_PinvT.p; a.PT = d_PT.p; a.dsc = d_dsc.p;
     }
     {

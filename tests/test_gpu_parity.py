@@ -921,3 +921,44 @@ def test_hybrid_scan_chains_on_unbinned_data(monkeypatch, name):
     assert rel_err(out["1"][2], out["0"][2]) <= 2 * STAT_TOL
     for k, v in out["0"][3].items():
         assert np.max(np.abs(out["1"][3][k] - v)) <= 2 * STAT_TOL * max(np.abs(v).max(), 1e-300)
+
+
+def test_hybrid_rows_with_cold_eigen_keys_m64(monkeypatch):
+    """Un-binned data at M = 64 with THREE eigen keys (round 5): the pair of eigenvector tables a direction needs is 66 KB per key, two
+    keys fill LDS - the third (least frequent) key's table rows are read from L2 on the rows that need them.  Until round 4 such an
+    input fell back to the dense cooperative chains.  Checked against those (SMCPP_HYBRID=0) and against the C restatement of
+    hmm.cpp on G18's parameters, with the posterior argmax."""
+    from oracle import oracle
+    from smcpp_amd import _smcpp
+    g = load_golden("G18_M64_n8_chr11")
+    keys = np.asarray(g["keys"], dtype=np.int32)
+    idx = {tuple(k): i for i, k in enumerate(keys.tolist())}
+    mono, miss = idx[(0, 0, 8)], idx[(-1, 0, 0)]
+    third = next(i for i in range(len(keys)) if i not in (mono, miss))          # any third key that also comes in long rows
+    rng = np.random.default_rng(5)
+    L = 24_000
+    kid = rng.integers(0, len(keys), L)
+    span = np.where(rng.random(L) < 0.45, 1, np.minimum(50_000, 1 + rng.geometric(3e-3, L)))
+    u = rng.random(L)
+    kid[span > 1] = np.where(u[span > 1] < 0.75, mono, np.where(u[span > 1] < 0.93, miss, third))
+    obs = np.concatenate([span[:, None], keys[kid]], axis=1).astype(np.int32)
+    out = {}
+    for hyb in ("1", "0"):
+        monkeypatch.setenv("SMCPP_HYBRID", hyb)
+        im = _smcpp.PyOnePopInferenceManager(8, [obs], g["hs"], ("pop1",), float(g["pol"]))
+        im.set_raw(g["pi"], g["T"], g["keys"], g["E"])
+        im.set_chunking(1500)
+        im.save_gamma = True
+        im.E_step()
+        out[hyb] = (im.chain_mode(), im.loglik(), im.xisums[0], im.gamma_sums[0], im.gamma_argmax(0), im.gammas[0])
+    assert out["1"][0] == 6 and out["0"][0] != 6, (out["1"][0], out["0"][0])
+    assert abs(out["1"][1] - out["0"][1]) <= 1e-8 * abs(out["0"][1])
+    assert rel_err(out["1"][2], out["0"][2]) <= 2 * STAT_TOL
+    o = oracle.estep(g["pi"], g["T"], g["keys"], g["E"], obs, save_gamma=True)
+    assert abs(out["1"][1] - o["loglik"]) <= LL_TOL * abs(o["loglik"])
+    assert rel_err(out["1"][2], o["xisum"]) <= STAT_TOL
+    for k, v in o["gamma_sums"].items():
+        assert np.max(np.abs(out["1"][3][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300), k
+    srt = np.sort(o["gamma"], axis=0)
+    strong = (srt[-1] - srt[-2]) / np.maximum(srt[-1], 1e-300) > 1e-5
+    assert np.all((out["1"][4] == o["gamma"].argmax(axis=0)) | ~strong)

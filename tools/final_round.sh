@@ -3,7 +3,7 @@
 # headline and the whole genome, every workload's bench line, Q-with-gradient, warm start, the N > 1 path on one device (2 ranks;
 # 8 ranks with --check for c3 and c4), one rank's shard of the 8-GPU genome run, kernel stats of c3 / c5 / posterior / qgrad,
 # the DPP issue-cost lab, the stream-hop cost lab, a host trace of the headline's E-step.
-TAG=${1:-r04_r}
+TAG=${1:-r05_a}
 cd $GRAFT_REPO_ROOT
 bash tools/profile_round.sh $TAG > /dev/null 2>&1
 O=gpurun_out/$TAG

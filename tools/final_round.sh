@@ -17,6 +17,8 @@ python bench.py --gpus 8 --workload c3 --no-cpu --check --steps 10 > $O/bench_c3
 python bench.py --gpus 8 --workload c4 --no-cpu --check --steps 10 > $O/bench_c4_gpus8_check.log 2>&1; grep '^{"metric"' $O/bench_c4_gpus8_check.log | tail -1 | cut -c1-200
 SHARD_RANKS=2 SHARD_MODES=ss python tools/shard_probe.py > $O/shard_probe.log 2>&1; tail -2 $O/shard_probe.log | cut -c1-200
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+# what the E-step's exchange adds to an eval (one-rank RCCL group: host wait / stream-ordered through torch / issued by the engine)
+timeout 300 python -m pytest tests/test_gpu_multi.py -m gpu -q -s -k world_of_one 2>&1 | grep -a "exchange cost" | tail -1 > $O/exchange_cost.log; cat $O/exchange_cost.log
 cd /tmp && export TMPDIR=/tmp
 for w in c3 c5 posterior qgrad; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_$w -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload $w --steps 5 > /dev/null 2>&1

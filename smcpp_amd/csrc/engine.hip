@@ -411,6 +411,106 @@ struct DevPrep {
 template <> inline double DevPrep::dpart<double>(const double &, int) { return 0.0; }
 template <> inline double DevPrep::dpart<smcpp_host::dual>(const smcpp_host::dual &x, int d) { return x.d[d]; }
 
+// The two batched conditioned-SFS problems of the two-population preparation on the device (round 5; jcsfs.hpp: CsfsBatchDevice):
+// every interval below the split under the truncated model (n1 lineages) and every interval above it under the shifted model
+// (n1 + n2) - k_prep_tables + k_prep_csfs_raw on the manager's stream, the states' tables copied back to pinned memory - while
+// the host forms the state-independent pieces of the joint CSFS.  Values only; the Jacobian route stays on the host.
+struct TwoPopDevCsfs : smcpp_host::CsfsBatchDevice {
+    struct Inst {
+        int n = -1, M = 0, C = 0;
+        DevBuf<double> d_sd, d_tab, d_raw;
+        PinnedArena stage, res;
+        char *d_in = nullptr;
+        size_t in_cap = 0;
+        double *h_raw = nullptr;
+        hipEvent_t ev = nullptr;
+        bool in_flight = false;
+        ~Inst() { if (d_in) (void)hipFree(d_in); if (ev) (void)hipEventDestroy(ev); }
+    } inst[2];
+    int device = 0;
+    hipStream_t stream = nullptr;
+    static bool fits(int n, int K) {
+        return n >= 1 && smcpp_dev::CsfsScratch<double>::count(n) * sizeof(double) <= 150 * 1024 && (size_t)2 * K * sizeof(double) <= 150 * 1024;
+    }
+    bool launch(int which, const smcpp_host::RateFunctionT<double> &eta, int n) override {
+        const int K = eta.K, M = (int)eta.hidden_states.size() - 1;
+        if (M <= 0 || !fits(n, K)) return false;
+        HIPCHK(hipSetDevice(device));
+        Inst &I = inst[which];
+        if (I.in_flight) { HIPCHK(hipEventSynchronize(I.ev)); I.in_flight = false; }
+        if (I.n != n) {
+            const smcpp_host::CsfsTables &t = *smcpp_host::csfs_tables(n);
+            std::vector<double> sd;
+            for (const smcpp_host::DMat *m : {&t.X0, &t.X2, &t.M0, &t.M1, &t.Uinv_mp0, &t.Uinv_mp2}) sd.insert(sd.end(), m->d.begin(), m->d.end());
+            I.d_sd.alloc(sd.size());
+            HIPCHK(hipMemcpy(I.d_sd.p, sd.data(), sd.size() * sizeof(double), hipMemcpyHostToDevice));
+            I.n = n;
+        }
+        I.M = M; I.C = 3 * (n + 1);
+        // pack: doubles ts [K+1] | ada [K] | R [K+1]; ints hsi [M+1]
+        const size_t ndbl = (size_t)(K + 1) + K + (K + 1);
+        const size_t bytes = ndbl * sizeof(double) + (size_t)(M + 1) * sizeof(int) + 64;
+        I.stage.reset(bytes);
+        char *hb = I.stage.base;
+        if (bytes > I.in_cap) {
+            if (I.d_in) (void)hipFree(I.d_in);
+            I.in_cap = bytes + bytes / 2;
+            HIPCHK(hipMalloc((void **)&I.d_in, I.in_cap));
+        }
+        double *hd = reinterpret_cast<double *>(hb);
+        size_t o = 0;
+        const size_t o_ts = o; for (int i = 0; i <= K; ++i) hd[o++] = eta.ts[i];
+        const size_t o_ada = o; for (int i = 0; i < K; ++i) hd[o++] = eta.ada[i];
+        const size_t o_R = o; for (int i = 0; i <= K; ++i) hd[o++] = eta.Rrng[i];
+        int *hi = reinterpret_cast<int *>(hd + o);
+        for (int i = 0; i <= M; ++i) hi[i] = eta.hs_indices[i];
+        const double *bd = reinterpret_cast<const double *>(I.d_in);
+        smcpp_dev::PrepModel pm;
+        pm.K = K; pm.n = n; pm.M = M; pm.nder = 0;
+        pm.ts = bd + o_ts; pm.ada_v = bd + o_ada; pm.R_v = bd + o_R;
+        pm.hsi = reinterpret_cast<const int *>(bd + o);
+        smcpp_dev::PrepStatic ps;
+        {
+            const size_t a = (size_t)n * (n + 1), b = (size_t)(n + 1) * n, c = (size_t)(n + 1) * (n + 1);
+            const double *sd = I.d_sd.p;
+            ps.X0 = sd; ps.X2 = sd + a; ps.M0 = sd + 2 * a; ps.M1 = sd + 2 * a + b; ps.U0 = sd + 2 * a + b + c; ps.U2 = sd + 2 * a + 2 * b + c;
+        }
+        I.d_tab.alloc(smcpp_dev::Tables<double>::per_group(n, K));
+        smcpp_dev::Tables<double> tb;
+        tb.carve(I.d_tab.p, n, K, 1);
+        I.d_raw.alloc((size_t)M * I.C);
+        I.res.reset((size_t)M * I.C * sizeof(double));
+        I.h_raw = reinterpret_cast<double *>(I.res.base);
+        HIPCHK(hipMemcpyAsync(I.d_in, hb, bytes, hipMemcpyHostToDevice, stream));
+        const int pairs = (n + 1) * n;
+        const int nt = std::min(512, std::max(64 * ceil_div(3 * n + 2, 64), 64 * ceil_div(pairs, 64)));
+        const int ntt = std::min(256, 64 * ceil_div(K, 64));
+        static bool once = false;
+        if (!once) {
+            HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_csfs_raw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute((const void *)smcpp_dev::k_prep_tables<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            once = true;
+        }
+        hipLaunchKernelGGL(smcpp_dev::k_prep_tables<double>, dim3(1, 2 * n + 1), dim3(ntt), (size_t)2 * K * sizeof(double), stream, pm, tb);
+        hipLaunchKernelGGL(smcpp_dev::k_prep_csfs_raw, dim3(M), dim3(nt), smcpp_dev::CsfsScratch<double>::count(n) * sizeof(double), stream, pm, ps, tb, I.d_raw.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(I.h_raw, I.d_raw.p, (size_t)M * I.C * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (!I.ev) HIPCHK(hipEventCreateWithFlags(&I.ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(I.ev, stream));
+        I.in_flight = true;
+        return true;
+    }
+    void collect(int which, std::vector<std::vector<double>> &out) override {
+        Inst &I = inst[which];
+        if (!I.in_flight) throw std::runtime_error("internal: collect without a launched batch");
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipEventSynchronize(I.ev));
+        I.in_flight = false;
+        out.assign(I.M, std::vector<double>());
+        for (int m = 0; m < I.M; ++m) out[m].assign(I.h_raw + (size_t)m * I.C, I.h_raw + (size_t)(m + 1) * I.C);
+    }
+};
+
 struct smcpp_im {
     // ---- static problem description -------------------------------------------------------------------------
     int npop = 1, keylen = 3, M = 0, Mp = 0, NPL = 1, NT = 1, n_contigs = 0, K = 0, G = 0, Ke = 0;
@@ -418,6 +518,7 @@ struct smcpp_im {
     double polarization_error = 0.5;
     std::vector<double> hs;
     std::unique_ptr<smcpp_host::TwoPopPrep> twopop_prep;     // two-population preparation (key -> tensor-bin tables cached inside)
+    std::unique_ptr<TwoPopDevCsfs> twopop_dev;               // ... its two batched conditioned-SFS problems on the device (values only)
     std::vector<int> keys;                 // [K][keylen], lexicographic
     std::vector<int> Ls;
     std::vector<long long> contig_base;    // row index of ell = 0 of each contig
@@ -1463,6 +1564,12 @@ void smcpp_im::prepare_params() {
             if (kmp_set_blocktime && !getenv("SMCPP_OMP_BLOCKTIME")) kmp_set_blocktime(1);
         }
         smcpp_host::TwoPopPrep &prep = *twopop_prep;
+        {
+            // the batched conditioned SFS on the device (values; SMCPP_PREP=host / smcpp_set_prep_mode(1): everything on the host)
+            static const bool host_only2 = getenv("SMCPP_PREP") && !strcmp(getenv("SMCPP_PREP"), "host");
+            if (!twopop_dev) { twopop_dev.reset(new TwoPopDevCsfs()); twopop_dev->device = device; twopop_dev->stream = stream; }
+            prep.batch_dev = (host_only2 || force_host_prep || nder > 0) ? nullptr : twopop_dev.get();
+        }
         E_on_dev = false;
         tgen_valid = false; dT_valid = true;
         // with a global key dictionary (multi-GPU) the table is prepared for EVERY global key - Q on the all-reduced statistics

@@ -110,9 +110,27 @@ inline std::vector<S> undistinguished_sfs(const std::vector<S> &csfs, int n) {
     return ret;
 }
 
+// Optional accelerator for the two BATCHED conditioned-SFS problems of together() (values only): the engine implements it on the
+// device (k_prep_tables + k_prep_csfs_raw of prep_dev.hpp).  launch() enqueues and returns (false: not taken - the caller computes the
+// batch on the host team), collect() waits and hands the states' tables back.  `which`: 0 = below the split, 1 = above it.
+struct CsfsBatchDevice {
+    virtual ~CsfsBatchDevice() {}
+    virtual bool launch(int which, const RateFunctionT<double> &eta, int n) = 0;
+    virtual void collect(int which, std::vector<std::vector<double>> &out) = 0;
+};
+template <typename S> struct CsfsBatchHook {
+    static bool launch(CsfsBatchDevice *, int, const RateFunctionT<S> &, int) { return false; }
+    static void collect(CsfsBatchDevice *, int, std::vector<std::vector<S>> &) {}
+};
+template <> struct CsfsBatchHook<double> {
+    static bool launch(CsfsBatchDevice *d, int which, const RateFunctionT<double> &eta, int n) { return d && d->launch(which, eta, n); }
+    static void collect(CsfsBatchDevice *d, int which, std::vector<std::vector<double>> &out) { d->collect(which, out); }
+};
+
 template <typename S>
 class JointCsfsT {
 public:
+    CsfsBatchDevice *batch_dev = nullptr;       // (set by TwoPopPrep::jcsfs; used by the double instantiation only)
     JointCsfsT(int n1, int n2, int a1, int a2, const std::vector<double> &hidden_states, int K = 10)
         : n1(n1), n2(n2), a1(a1), a2(a2), hs(hidden_states), M((int)hidden_states.size() - 1), K(K) {
         if (!((a1 == 2 && a2 == 0) || (a1 == 1 && a2 == 1))) throw std::runtime_error("unsupported jcsfs configuration");
@@ -215,12 +233,14 @@ private:
         }
         std::unique_ptr<RateFunctionT<S>> eta_trunc_all, eta_shift_all;
         CsfsJob<S> job_b, job_a;
-        bool team_b = false, team_a = false;
+        bool team_b = false, team_a = false, dev_b = false, dev_a = false;
         if (!hb.empty()) {
             hb.push_back(std::min(split, hs[M]));
             eta_trunc_all.reset(new RateFunctionT<S>(truncate_params(params1, split), hb));
             job_b.eta = eta_trunc_all.get();
             team_b = job_b.factored();
+            dev_b = team_b && CsfsBatchHook<S>::launch(batch_dev, 0, *eta_trunc_all, n1);      // (enqueued: runs beside the host work below)
+            if (dev_b) team_b = false;
             if (team_b) job_b.init(*eta_trunc_all, *csfs_tables(n1), false);
         }
         if (!ha.empty()) {
@@ -228,6 +248,8 @@ private:
             eta_shift_all.reset(new RateFunctionT<S>(shift_params(params1, split), ha));
             job_a.eta = eta_shift_all.get();
             team_a = job_a.factored();
+            dev_a = team_a && CsfsBatchHook<S>::launch(batch_dev, 1, *eta_shift_all, n1 + n2);
+            if (dev_a) team_a = false;
             if (team_a) job_a.init(*eta_shift_all, *csfs_tables(n1 + n2), false);
         }
         eta_plain.reset(new RateFunctionT<S>(params1, std::vector<double>()));
@@ -290,14 +312,16 @@ private:
                 guarded([&] {
                     if (any_above) below_at_split = csfs_of(n1, *eta1, true)[0];          // (the same for every state above the split)
                     // (a batch whose model the factored evaluation cannot take - a zero rate - goes through the generic routine)
-                    if (!hb.empty() && !team_b) trunc_all = csfs_of(n1, *eta_trunc_all);
-                    if (!ha.empty() && !team_a) rsfs_all = csfs_of(n1 + n2, *eta_shift_all);
+                    if (!hb.empty() && !team_b && !dev_b) trunc_all = csfs_of(n1, *eta_trunc_all);
+                    if (!ha.empty() && !team_a && !dev_a) rsfs_all = csfs_of(n1 + n2, *eta_shift_all);
                 });
             }
 #pragma omp single
             {
                 if (team_b) trunc_all.swap(job_b.csfs);
                 if (team_a) rsfs_all.swap(job_a.csfs);
+                if (dev_b) guarded([&] { CsfsBatchHook<S>::collect(batch_dev, 0, trunc_all); });
+                if (dev_a) guarded([&] { CsfsBatchHook<S>::collect(batch_dev, 1, rsfs_all); });
             }
             // ---- (C) ----
 #pragma omp for schedule(dynamic)
@@ -520,8 +544,10 @@ public:
     template <typename S>
     std::vector<std::vector<S>> jcsfs(const ModelParamsT<S> &p1, const ModelParamsT<S> &p2, double split) const {
         JointCsfsT<S> j(n_[0], n_[1], na_[0], na_[1], hs_, K_);
+        j.batch_dev = batch_dev;
         return j.compute(p1, p2, split);
     }
+    mutable CsfsBatchDevice *batch_dev = nullptr;   // the engine's device route of the batched conditioned SFS (values only), not owned
 
     // keys [K][6]; outputs pi [M], T [M*M], E [K*M]
     template <typename S>

@@ -671,6 +671,30 @@ __global__ __launch_bounds__(512) void k_prep_csfs(PrepModel pm, PrepStatic ps, 
     __syncthreads();
     csfs_emit(c, t, nt);
 }
+
+// The conditioned SFS alone - phases 0 .. 4 of k_prep_csfs, values only, no incorporate_theta, no emission assembly: raw [M][3 (n+1)].
+// The batched intervals of the two-population preparation (jcsfs.hpp: everything below the split under the truncated model, everything
+// above it under the shifted one) run through this while the host forms the pieces that do not depend on the hidden state.
+__global__ __launch_bounds__(512) void k_prep_csfs_raw(PrepModel pm, PrepStatic ps, Tables<double> tb, double *raw) {
+    extern __shared__ double prep_lds[];
+    CsfsCtx<double> c;
+    c.pm = pm; c.ps = ps; c.tb = tb; c.h = blockIdx.x; c.dir = 0;
+    c.sh.carve(prep_lds, pm.n);
+    const int t = threadIdx.x, nt = blockDim.x, n = pm.n, C = 3 * (n + 1);
+    csfs_clear(c, t, nt);
+    __syncthreads();
+    for (int m = pm.hsi[c.h]; m < pm.hsi[c.h + 1]; ++m) {
+        csfs_piece_tables(c, m, t, nt);
+        __syncthreads();
+        for (int p = t; p < (n + 1) * n; p += nt) csfs_pair(c, m, p);
+        __syncthreads();
+    }
+    csfs_contract(c, t);
+    __syncthreads();
+    csfs_backtransform(c, t);
+    __syncthreads();
+    for (int i = t; i < C; i += nt) raw[(size_t)c.h * C + i] = c.sh.out[i];
+}
 #endif
 
 }  // namespace smcpp_dev

@@ -357,18 +357,6 @@ def test_c5_shape_m256_n50_vs_oracle():
         assert np.max(np.abs(im.gamma_sums[0][k] - v)) <= 5e-6 * max(np.abs(v).max(), 1e-300)
     q = np.array(im.Q(separate=True))
     assert np.all(np.abs(q - o["q"]) <= 5e-6 * np.maximum(np.abs(o["q"]), 1e-12))
-    # round 5: the two batched conditioned-SFS problems of the joint CSFS run on the device (k_prep_csfs_raw) by default; the all-host
-    # route (set_prep_mode(True)) forms the same table - the phases are the same code, the device library's exp / expm1 differ from
-    # libm in the last ulp
-    ll_dev = im.loglik()
-    im.set_prep_mode(True)
-    im.model = TwoPopulationModel(PiecewiseModel(g["a1"], g["s1"], 1e4, pid="pop1"),
-                                  PiecewiseModel(g["a2"], g["s2"], 1e4, pid="pop2"), float(g["split"]))
-    im.E_step()
-    ep_host = im.emission_probs
-    for k in keys.tolist():
-        np.testing.assert_allclose(ep[tuple(k)], ep_host[tuple(k)], rtol=1e-11, atol=1e-16)
-    assert abs(im.loglik() - ll_dev) <= 1e-10 * abs(ll_dev)
 
 
 def test_bench_gpus_2_self_launches():

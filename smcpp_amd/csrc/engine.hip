@@ -792,9 +792,12 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
         if (!(hs[i] >= hs[i - 1])) throw std::runtime_error("Hidden states must be in ascending order");
     M = n_hs - 1;
     Mp = (M + 15) / 16 * 16;
-    NPL = (M + 63) / 64;
+    // states per lane of the one-wavefront-per-chunk kernels: 1 .. 4 up to M = 256; 256 < M <= 512 (round 5): eight - the scan chains
+    // and the eigen-free statistics only (binned data, a transition matrix with the reference's structure, no save_gamma: what
+    // `smc++ estimate` runs); the dense fallback kernels and the eigensystem statistics stop at 256
+    NPL = M > 256 ? 8 : (M + 63) / 64;
     NT = Mp / 16;
-    if (M > 256) throw std::runtime_error("M > 256 hidden states is not supported by this build");
+    if (M > 512) throw std::runtime_error("M > 512 hidden states is not supported by this build");
     n_contigs = n_contigs_;
     Ls.assign(Ls_, Ls_ + n_contigs);
     contig_base.resize(n_contigs);
@@ -978,7 +981,7 @@ void smcpp_im::make_chunks() {
         for (const Group &g : groups) ss_max_span = std::max(ss_max_span, g.span);
         {
             const char *se = getenv("SMCPP_SS");
-            const bool ss_ok = !(se && atoi(se) == 0) && (!m || !strcmp(m, "ss")) && Mp <= 256;
+            const bool ss_ok = !(se && atoi(se) == 0) && (!m || !strcmp(m, "ss")) && Mp <= 512;
             ss_static = ss_ok && ss_max_span <= 512;
             ss_hybrid = false; ss_hyb_th = 0x7fffffff;
             if (ss_ok && !ss_static) {
@@ -2223,6 +2226,7 @@ static void launch_s1(int npl, const S1Args &a, hipStream_t s) {
         case 2: launch_s1_t<2>(a, s); break;
         case 3: launch_s1_t<3>(a, s); break;
         case 4: launch_s1_t<4>(a, s); break;
+        case 8: launch_s1_t<8>(a, s); break;
         default: throw std::runtime_error("unsupported number of hidden states");
     }
 }
@@ -2605,6 +2609,7 @@ static void launch_chain_ss(int npl, const SsArgs &a, int ntasks, size_t shm, hi
         case 2: launch_chain_ss_t<2, false>(a, ntasks, shm, s, 4); break;
         case 3: launch_chain_ss_t<3, false>(a, ntasks, shm, s, 4); break;
         case 4: launch_chain_ss_t<4, false>(a, ntasks, shm, s, 4); break;
+        case 8: launch_chain_ss_t<8, false>(a, ntasks, shm, s, 4); break;
         default: throw std::runtime_error("unsupported number of hidden states");
     }
 }
@@ -3023,8 +3028,8 @@ void smcpp_im::enqueue_stats() {
             switch (NPL) {
 #define SC_(x) case x: hipLaunchKernelGGL((k_span_scan<x, 0>), grid, block, 0, se, ss_args, fa, ss_max_span, d_Fall.p); \
                        hipLaunchKernelGGL((k_span_scan<x, 1>), grid, block, 0, se, ss_args, fa, ss_max_span, d_Fall.p); break;
-                SC_(1) SC_(2) SC_(3)
-                default: SC_(4)
+                SC_(1) SC_(2) SC_(3) SC_(4)
+                default: SC_(8)
 #undef SC_
             }
         } else {
@@ -3219,12 +3224,18 @@ void smcpp_im::estep() {
     HIPCHK(hipEventRecord(ev[0], stream));
     // span > 1 rows without an eigensystem (kernels.hpp: k_span_fold): the span is expanded by smax steps of two M x M products
     static const bool eigfree_off = getenv("SMCPP_EIGFREE") && atoi(getenv("SMCPP_EIGFREE")) == 0;
-    const bool eigfree_static = !eigfree_off && Mp <= 256 && ss_max_span <= 64 && !save_gamma;
+    const bool eigfree_static = !eigfree_off && Mp <= 512 && ss_max_span <= 64 && !save_gamma;
+    if (Mp > 256 && !(ss_static && eigfree_static))
+        throw std::runtime_error("more than 256 hidden states: only the scan chains with eigen-free statistics are built (binned data "
+                                 "with spans <= 64, no save_gamma)");
     // only the lean path (scan chains + eigen-free statistics) reads a device-prepared emission table from HBM alone (its
     // underflow bound is checked by the kernel that forms the table); eigensystems, operand layouts, the dense chains and the
     // bound for longer spans need the host copy
     if (E_on_dev && !(ss_static && eigfree_static)) sync_host_E();
     ss_active = ss_static && ss_extract_generators();
+    if (Mp > 256 && !ss_active)
+        throw std::runtime_error("more than 256 hidden states: the transition matrix must have the structure of the reference's "
+                                 "HJTransition (the dense fallback kernels stop at 256)");
     tr.mark("estep: extract generators");
     if (!ss_active) ss_warm_valid = false;
     eigfree = ss_active && eigfree_static;
@@ -4002,8 +4013,8 @@ int smcpp_debug_ss_apply_float_scans(int M, const double *T, int nvec, const dou
 }
 static int ss_debug_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b, int float_scans) {
     {
-    const int NPL = (M + 63) / 64, MS = 64 * NPL;
-    if (NPL > 4) throw std::runtime_error("unsupported number of hidden states");
+    const int NPL = M > 256 ? 8 : (M + 63) / 64, MS = 64 * NPL;
+    if (M > 512) throw std::runtime_error("unsupported number of hidden states");
     std::vector<double> gen;
     double c0 = 0.0;
     if (!ss_generators(M, MS, T, gen, c0)) return 2;
@@ -4028,7 +4039,8 @@ static int ss_debug_apply(int M, const double *T, int nvec, const double *x, con
         case 1: hipLaunchKernelGGL(k_ss_apply<1>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
         case 2: hipLaunchKernelGGL(k_ss_apply<2>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
         case 3: hipLaunchKernelGGL(k_ss_apply<3>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
-        default: hipLaunchKernelGGL(k_ss_apply<4>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
+        case 4: hipLaunchKernelGGL(k_ss_apply<4>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
+        default: hipLaunchKernelGGL(k_ss_apply<8>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
     }
     HIPCHK(hipGetLastError());
     std::vector<double> hf(hx.size()), hb(hx.size());

@@ -177,7 +177,9 @@ class ShardedInferenceManager:
         self._unpack_pending = False      # RCCL path: the reduced statistics still sit in the device buffer (see _ensure_unpacked)
         self.last_local_stats = self.last_reduced_stats = None      # (host copies, kept only when `keep_stats` is set: tests)
         self.keep_stats = False
-        self.stream_ordered = True        # RCCL path: issue the collective on the engine's stream (False: host wait after the pack)
+        import os as _os
+        # RCCL path: issue the collective on the engine's stream (False / SMCPP_STREAM_ORDERED=0: host wait after the pack kernel)
+        self.stream_ordered = _os.environ.get("SMCPP_STREAM_ORDERED", "1") not in ("", "0")
         self._ext = None
         if self._reduce:
             # global key dictionary: fixes the layout of the gamma_sums block and makes the engine prepare the
@@ -241,7 +243,10 @@ class ShardedInferenceManager:
                 # ... and everything below is ordered on the ENGINE's stream: torch sees it as an external stream, RCCL's own
                 # stream waits for it and hands back to it (ProcessGroupNCCL synchronises streams, not the host), so
                 # pack kernel -> all-reduce -> the read-back of the scalar run with no host wait in between
-                self._ext = torch.cuda.ExternalStream(int(self.im.stream()), device=dev) if self.stream_ordered else None
+                try:
+                    self._ext = torch.cuda.ExternalStream(int(self.im.stream()), device=dev) if self.stream_ordered else None
+                except Exception:                                    # (a torch build without external streams: the host-wait form)
+                    self._ext = None
             if self._ext is not None and not self.keep_stats:
                 with torch.cuda.stream(self._ext):
                     self.im.pack_stats_device(self._buf.data_ptr(), sync=False)

@@ -3,9 +3,10 @@
 time in total): headline (1 x 100 Mbp, M = 64, n = 20; the eight contigs of the weak-scaling bench), C2 (M = 32, n = 10),
 C3 (22 contigs, 6.76 M rows), C4 (two populations, M = 48, G13's parameters), C5 (M = 256, n = 50, 25 000 rows).
 
-The engine runs its DEFAULT chain family (chunk-parallel scan chains) on the same rows and the same prepared parameters
-(set_raw with the fixture's pi / T / emission table: the parameters the reference ran on).  Tolerances are those of the 2 Mbp
-goldens (tests/test_gpu_parity.py): log-likelihood 1e-6 relative, statistics and Q 5e-6.
+The engine runs its DEFAULT chain family (chunk-parallel scan chains) on the same rows, through BOTH routes (round 5): `raw` =
+set_raw with the fixture's pi / T / emission table (the parameters the reference ran on), `params` = `im.model = ...` with the
+fixture's model, i.e. the engine's own cold preparation on the device - the route `bench.py` times.  Tolerances are those of the
+2 Mbp goldens (tests/test_gpu_parity.py): log-likelihood 1e-6 relative, statistics and Q 5e-6.
 """
 import os
 
@@ -37,13 +38,20 @@ def _check_stats(im, c, g, xisum, gs, gs_have, gamma0):
     assert rel_err(im.gammas[c][:, 0], gamma0) <= STAT_TOL
 
 
-def _onepop(params, contigs, n):
+def _onepop(params, contigs, n, route="raw"):
     from smcpp_amd import _smcpp
+    from smcpp_amd.model import PiecewiseModel
     p = np.load(os.path.join(GOLDEN, params))
     im = _smcpp.PyOnePopInferenceManager(n, contigs, p["hs"], ("pop1",), float(p["pol"]))
     im.theta = float(p["theta"]); im.rho = float(p["rho"]); im.alpha = float(p["alpha"])
-    im.set_raw(p["pi"], p["T"], p["keys"], p["E"])
+    if route == "raw":
+        im.set_raw(p["pi"], p["T"], p["keys"], p["E"])
+    else:
+        im.model = PiecewiseModel(p["a"], p["s"], 1e4, "pop1")
     return im
+
+
+ROUTES = pytest.mark.parametrize("route", ["raw", "params"])
 
 
 @pytest.mark.parametrize("name,params,n", [("headline", "params_M64_n20.npz", 20), ("c2", "params_M32_n10.npz", 10)])
@@ -80,12 +88,13 @@ def test_headline_weak_scaling_contigs_vs_compiled_reference():
     assert np.all(np.abs(q - qr) <= STAT_TOL * np.abs(qr)), (q, qr)
 
 
-def test_whole_genome_22_contigs_vs_compiled_reference():
+@ROUTES
+def test_whole_genome_22_contigs_vs_compiled_reference(route):
     from smcpp_amd import synth
     g = _g16("c3")
     contigs = [synth.synth_contig(i, int(synth.C3_LENGTHS_MBP[i] * 1e6), 20) for i in range(22)]
     assert [len(c) for c in contigs] == [int(x) for x in g["rows"]]
-    im = _onepop("params_M64_n20.npz", contigs, 20)
+    im = _onepop("params_M64_n20.npz", contigs, 20, route)
     im.E_step()
     lls = np.array(im.logliks())
     rel = np.abs(lls - g["loglik"]) / np.abs(g["loglik"])
@@ -108,15 +117,21 @@ def test_whole_genome_22_contigs_vs_compiled_reference():
     assert np.all(np.abs(q - qr) <= STAT_TOL * np.abs(qr)), (q, qr)
 
 
-def test_c4_two_population_full_contig_vs_compiled_reference():
+@ROUTES
+def test_c4_two_population_full_contig_vs_compiled_reference(route):
     from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel, TwoPopulationModel
     g = _g16("c4")
     p = np.load(os.path.join(GOLDEN, "G13_c4_params.npz"))
     obs = synth.synth_contig_twopop(0, 100_000_000, 10, 10)
     assert synth.contig_crc(obs) == int(g["crc"][0])
     im = _smcpp.PyTwoPopInferenceManager(10, 10, 2, 0, [obs], p["hs"], ("pop1", "pop2"), float(p["pol"]))
     im.theta = float(p["theta"]); im.rho = float(p["rho"]); im.alpha = float(p["alpha"])
-    im.set_raw(p["pi"], p["T"], p["keys"], p["E"])
+    if route == "raw":
+        im.set_raw(p["pi"], p["T"], p["keys"], p["E"])
+    else:                        # the engine's own two-population preparation (joint CSFS: host team + device batches)
+        im.model = TwoPopulationModel(PiecewiseModel(p["a1"], p["s1"], 1e4, pid="pop1"),
+                                      PiecewiseModel(p["a2"], p["s2"], 1e4, pid="pop2"), float(p["split"]))
     im.E_step()
     ll = im.loglik()
     assert abs(ll - float(g["loglik"][0])) <= LL_TOL * abs(float(g["loglik"][0])), (ll, float(g["loglik"][0]))
@@ -125,12 +140,13 @@ def test_c4_two_population_full_contig_vs_compiled_reference():
     assert np.all(np.abs(q - g["q"][0]) <= STAT_TOL * np.abs(g["q"][0])), (q, g["q"][0])
 
 
-def test_c5_25000_rows_vs_compiled_reference():
+@ROUTES
+def test_c5_25000_rows_vs_compiled_reference(route):
     from smcpp_amd import synth
     g = _g16("c5")
     obs = np.ascontiguousarray(synth.synth_contig(0, 100_000_000, 50)[:int(g["rows"][0])])
     assert synth.contig_crc(obs) == int(g["crc"][0])
-    im = _onepop("params_M256_n50.npz", [obs], 50)
+    im = _onepop("params_M256_n50.npz", [obs], 50, route)
     im.E_step()
     assert im.chain_mode() == 5
     ll = im.loglik()

@@ -1429,7 +1429,9 @@ void smcpp_im::alloc_device() {
         ss_slot_of_key.assign(K, 0);
         for (int r = 0; r < K; ++r) ss_slot_of_key[order[r]] = r;
         const int MS = 64 * NPL;
-        ss_nlds = (int)std::min<long long>(K, (std::min(64, 150 / std::max(1, ss_wpc)) * 1024) / ((long long)MS * 8));   // ss_wpc workgroups share a CU's 160 KB
+        ss_nlds = (int)std::min<long long>(K, ((150 / std::max(1, ss_wpc)) * 1024) / ((long long)MS * 8));   // ss_wpc workgroups share a CU's 160 KB
+        // (until round 5 the table was capped at 64 KB: the 192 six-int keys of config C4 - 96 KB at M = 48 - left 64 slots to the L2 path
+        // and with them the kernel to its instantiation with vector-memory waits on every row: chains 0.86 -> see DESIGN.md section 6)
         if (ss_hybrid) ss_nlds = (int)std::max<long long>(1, std::min<long long>(K, (long long)((ss_dirsplit ? 158 : 150) * 1024 - ss_tab_bytes()) / ((long long)MS * 8)));   // one workgroup per CU
         ss_positions = 0;
         for (int c = 0; c < n_contigs; ++c)

@@ -193,18 +193,24 @@ class TwoPopulationModel(Observable):
         i = self.pids.index(pid)
         if i == 0:
             return _Pieces(m1.a, m1.s, self._seed_rows(0, list(range(len(m1.a)))))
-        # population 2: its own pieces below the split, population 1's above it
-        parts = []
-        for which, m in ((1, m2), (0, m1)):
-            cs, ip = self._cut(m, split)
-            sp = np.diff(cs)
-            sp[-1] = 1.0
-            ap_idx = list(np.insert(np.arange(len(m.a)), ip, ip - 1))      # the piece containing the split is cut in two
-            parts.append((which, sp, ap_idx, ip))
-        (w2, sp2, idx2, ip2), (w1, sp1, idx1, ip1) = parts
-        s = np.concatenate([sp2[:ip2], sp1[ip1:]])
-        a = np.concatenate([np.asarray(m2.a, dtype=np.float64)[idx2[:ip2]], np.asarray(m1.a, dtype=np.float64)[idx1[ip1:]]])
+        # population 2: its own pieces below the split, population 1's above it.  Where the pieces are cut depends on the piece
+        # LENGTHS and the split only - not on the sizes an optimiser moves - so that part is kept between calls
+        key = (split, m1.s.tobytes(), m2.s.tobytes())
+        st = getattr(self, "_pop2_struct", None)
+        if st is None or st[0] != key:
+            parts = []
+            for which, m in ((1, m2), (0, m1)):
+                cs, ip = self._cut(m, split)
+                sp = np.diff(cs)
+                sp[-1] = 1.0
+                ap_idx = list(np.insert(np.arange(len(m.a)), ip, ip - 1))      # the piece containing the split is cut in two
+                parts.append((which, sp, ap_idx, ip))
+            (w2, sp2, idx2, ip2), (w1, sp1, idx1, ip1) = parts
+            st = (key, np.concatenate([sp2[:ip2], sp1[ip1:]]), np.asarray(idx2[:ip2], dtype=np.intp), np.asarray(idx1[ip1:], dtype=np.intp))
+            self._pop2_struct = st
+        _, s, i2, i1 = st
+        a = np.concatenate([np.asarray(m2.a, dtype=np.float64)[i2], np.asarray(m1.a, dtype=np.float64)[i1]])
         seeds = None
         if self.differentiable:
-            seeds = np.vstack([self._seed_rows(1, idx2[:ip2]), self._seed_rows(0, idx1[ip1:])])
-        return _Pieces(a, s, seeds)
+            seeds = np.vstack([self._seed_rows(1, list(i2)), self._seed_rows(0, list(i1))])
+        return _Pieces(a, s.copy(), seeds)

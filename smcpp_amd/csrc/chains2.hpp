@@ -3,7 +3,7 @@
 // operand quarters of T and of the hot eigen key in registers, state exchanged through a double-buffered LDS vector,
 // one s_barrier per mat-vec), with the row loop rebuilt around what tools/chain_lab.hip measured on gfx950:
 //   * pass 0 and the re-run passes are separate instantiations (RERUN): the first pass carries no merge logic at all;
-//   * the row-descriptor array is padded on both sides (engine.hip: alloc_device), so the three-stage descriptor
+//   * the row-descriptor array is padded on both sides (engine_manager.hpp: alloc_device), so the three-stage descriptor
 //     pipeline and the 64-row staging loads need no bounds tests;
 //   * clamps are integer maxima (the operands are non-negative floats or tiny negative rounding residues, for which
 //     the signed-integer order gives the same result): fmaxf costs a v_max canonicalisation per operand in IEEE mode;
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(MT * 4) void k_bwd_coop2(ChainArgs a, CoopArgs ca) 
 // One workgroup per eigen key squares A nsq times (A^2 .. A^(2^nsq); nsq = 4 covers spans up to 31, 11 spans up to 4095)
 // in LDS on the matrix cores and stores them as
 // float row-major (forward operand Bf[e][b-1][i][k]) and double transposed (backward operand Bb[e][b-1][i][k] =
-// A^(2^b)[k][i]).  Tens of microseconds, against 0.6 ms of host eigensolves taken off the critical path (engine.hip: estep).
+// A^(2^b)[k][i]).  Tens of microseconds, against 0.6 ms of host eigensolves taken off the critical path (engine_plans.hpp: estep).
 // ---------------------------------------------------------------------------------------------------------------
 template <int MT>
 __global__ __launch_bounds__(256) void k_binary_powers(int M, int nsq, const int *__restrict__ e_kid,

@@ -252,7 +252,7 @@ __device__ __forceinline__ auto stream_dot(const TM *__restrict__ q, size_t QS, 
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-// PRE = eigen-free pre-pass (engine.hip: stage_static_and_prepass): eigen rows apply the float binary powers of
+// PRE = eigen-free pre-pass (engine_plans.hpp: stage_static_and_prepass): eigen rows apply the float binary powers of
 // A = diag(e) T^T, one per set bit of the span, nothing is stored but the chunk's end vector - it only has to hand pass 1
 // (a.variant == 2: a full pass from those end vectors, no skip test, no merge exit) a start vector while the host is
 // still solving the eigenproblems.

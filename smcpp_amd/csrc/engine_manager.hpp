@@ -35,6 +35,11 @@ struct smcpp_im {
     DevBuf<Slab> d_slabs_fk;
     DevBuf<int> d_fk_c_off, d_fk_gk_off;
     DevBuf<double> d_gpart_fk;
+    // teams (round 5): up to four consecutive slabs of ONE reduction range share a workgroup of k_rank_acc<., true> and one partial
+    std::vector<int2> teams_fk, teams_eg, teams_rk;
+    std::vector<int> fk_c_team_off, eb_team_off, s1_team_off;
+    DevBuf<int2> d_teams_fk, d_teams_eg, d_teams_rk;
+    DevBuf<int> d_fk_c_team_off, d_eb_team_off, d_s1_team_off;
     // generation-2 eigen statistics (M <= 64): slabs over the sorted eigen rows of a (contig, eigen key) that MIX span groups
     std::vector<Slab> slabs_ek;
     std::vector<int> ek_slab_off, epos_gid;
@@ -727,6 +732,11 @@ void smcpp_im::update_pi_default() {
     for (double &v : pi_default) v /= sm;
 }
 
+static bool stats_team_on() {
+    static const bool on = !(getenv("SMCPP_STATS_TEAM") && atoi(getenv("SMCPP_STATS_TEAM")) == 0);
+    return on;
+}
+
 void smcpp_im::make_slabs() {
     // counting sorts of rows per contig
     perm1.clear(); perme.clear(); perm1k.clear();
@@ -745,7 +755,8 @@ void smcpp_im::make_slabs() {
     const long long part_bytes = (long long)Mp * Mp * 8;
     // slabs = independent single-wavefront work items; several thousand keep the 2048 resident wavefronts of the
     // chip balanced on large inputs (each slab owns an Mp x Mp partial: at most 256 MB of them)
-    const long long target = std::max<long long>(256, std::min<long long>(8192, (256ll << 20) / part_bytes));
+    // (round 5: teams of four slabs share one partial - k_rank_acc<., true> -, so four times as many slabs fit the same 256 MB)
+    const long long target = std::max<long long>(256, std::min<long long>(8192, ((stats_team_on() ? 1024ll : 256ll) << 20) / part_bytes));
     // (at least SMCPP_SLAB_ROWS rows per slab, default 128: every slab costs an Mp x Mp partial written and read back - 128 MB of
     // traffic per headline E-step with 64-row slabs -, but a slab is walked by ONE wavefront, and below ~1000 slabs the rank
     // kernels leave SIMDs idle: 64 .. 192 rows measured: 633 / 641 / 666 / 665 headline evals per second)
@@ -833,6 +844,20 @@ void smcpp_im::make_slabs() {
     }
     fk_c_off[n_contigs] = (int)slabs_fk.size();
     fk_gk_off[(size_t)n_contigs * K] = (int)slabs_fk.size();
+    {
+        auto cut = [](const std::vector<int> &range_off, std::vector<int2> &teams, std::vector<int> &team_off) {
+            teams.clear();
+            team_off.assign(range_off.size(), 0);
+            for (size_t r = 0; r + 1 < range_off.size(); ++r) {
+                team_off[r] = (int)teams.size();
+                for (int q = range_off[r]; q < range_off[r + 1]; q += 4) teams.push_back(make_int2(q, std::min(4, range_off[r + 1] - q)));
+            }
+            if (!range_off.empty()) team_off.back() = (int)teams.size();
+        };
+        cut(fk_c_off, teams_fk, fk_c_team_off);
+        cut(eb_slab_off, teams_eg, eb_team_off);
+        cut(s1_slab_off, teams_rk, s1_team_off);
+    }
     // generation-2 eigen slabs: the sorted eigen rows of every (contig, eigen key) cut into S_EG-row pieces regardless of the span
     // groups; padded like slabs_eg so that a workgroup of four never mixes keys
     slabs_ek.clear(); epos_gid.clear();
@@ -956,6 +981,12 @@ void smcpp_im::alloc_device() {
     d_slabs_fk.upload(slabs_fk, s);
     d_fk_c_off.upload(fk_c_off, s);
     d_fk_gk_off.upload(fk_gk_off, s);
+    d_teams_fk.upload(teams_fk, s);
+    d_teams_eg.upload(teams_eg, s);
+    d_fk_c_team_off.upload(fk_c_team_off, s);
+    d_eb_team_off.upload(eb_team_off, s);
+    d_teams_rk.upload(teams_rk, s);
+    d_s1_team_off.upload(s1_team_off, s);
     d_ek_slab_off.upload(ek_slab_off, s);
     d_epos_gid.upload(epos_gid, s);
     d_contig_base.upload(contig_base, s);

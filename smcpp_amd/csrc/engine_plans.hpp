@@ -804,7 +804,13 @@ void smcpp_im::enqueue_stats() {
     AccArgs aa;
     aa.M = M; aa.Mp = Mp; aa.NB = (Mp + 63) / 64; aa.rowinfo = d_rowinfo.p; aa.alpha = d_alpha.p; aa.beta = d_beta.p;
     aa.w1 = d_w1.p; aa.cnorm = d_cnorm.p; aa.E = d_E.p; aa.Xs = d_Xs.p; aa.Ys = d_Ys.p;
-    aa.gpart = nullptr;
+    aa.gpart = nullptr; aa.teams = nullptr;
+    // (round 5) teams of four slabs reduce their accumulators through LDS: a quarter of the partial bytes (SMCPP_STATS_TEAM=0: one
+    // partial per slab, as in rounds 2-4)
+    const bool team_env = stats_team_on();
+    const bool team2 = team_env && eigfree && !teams_eg.empty();
+    const bool team3 = team_env && !teams_fk.empty();
+    const bool team0 = team_env && !teams_rk.empty();
     // Eigen-free statistics: the span fold (tens of serial steps on a few CUs) ends the longest dependency chain of the
     // phase, so what it waits for - the rank accumulation of the span > 1 rows - goes FIRST and alone; the span-1 branches start
     // behind it and run while the fold does
@@ -827,6 +833,10 @@ void smcpp_im::enqueue_stats() {
         }
         AccArgs ae = aa;
         ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
+        if (team2) {
+            ae.teams = d_teams_eg.p;
+            hipLaunchKernelGGL((k_rank_acc<2, true>), dim3((unsigned)teams_eg.size(), ae.NB * ae.NB), dim3(256), 0, se, ae);
+        } else
         hipLaunchKernelGGL(k_rank_acc<2>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
         if (!crit_main) {
             HIPCHK(hipEventRecord(ev[17], se));
@@ -863,14 +873,22 @@ void smcpp_im::enqueue_stats() {
         d_gpart_fk.alloc(slabs_fk.size() * Mp);
         aa.nslabs = (int)slabs_fk.size(); aa.slabs = d_slabs_fk.p; aa.perm = d_perm1.p; aa.permk = nullptr; aa.part = d_part_1.p;
         aa.gpart = d_gpart_fk.p;
+        if (team3) {
+            aa.teams = d_teams_fk.p;
+            hipLaunchKernelGGL((k_rank_acc<3, true>), dim3((unsigned)teams_fk.size(), 1), dim3(256), 0, sp1, aa);
+        } else
         hipLaunchKernelGGL(k_rank_acc<3>, dim3(aa.nslabs, 1), dim3(64), 0, sp1, aa);
         hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(Mp, 256), n_contigs * K, ZG), dim3(256), 0, sp1,
                            (const double *)d_gpart_fk.p, (const int *)d_fk_gk_off.p, d_red_g.p, Mp, ZG);
         hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), n_contigs, ZS), dim3(256), 0, sp1,
-                           (const double *)d_part_1.p, (const int *)d_fk_c_off.p, d_red_1.p, MMi, ZS);
+                           (const double *)d_part_1.p, (const int *)(team3 ? d_fk_c_team_off.p : d_fk_c_off.p), d_red_1.p, MMi, ZS);
     } else
     if (!slabs_rk.empty()) {
         aa.nslabs = (int)slabs_rk.size(); aa.slabs = d_slabs_rk.p; aa.perm = d_perm1.p; aa.permk = d_perm1k.p; aa.part = d_part_1.p;
+        if (team0) {
+            aa.teams = d_teams_rk.p;
+            hipLaunchKernelGGL((k_rank_acc<0, true>), dim3((unsigned)teams_rk.size(), aa.NB * aa.NB), dim3(256), 0, sp1, aa);
+        } else
         hipLaunchKernelGGL(k_rank_acc<0>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, sp1, aa);
     }
     // the per-key gamma sums only need the span-1 scalars: with two streams their reduction runs at the tail of the eigen
@@ -881,7 +899,7 @@ void smcpp_im::enqueue_stats() {
                            (const double *)d_gpart.p, (const int *)d_gk_slab_off.p, d_red_g.p, Mp, 1);
     if (!kfuse)
     hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), n_contigs, ZS), dim3(256), 0, sp1,
-                       (const double *)d_part_1.p, (const int *)d_s1_slab_off.p, d_red_1.p, MMi, ZS);
+                       (const double *)d_part_1.p, (const int *)(team0 ? d_s1_team_off.p : d_s1_slab_off.p), d_red_1.p, MMi, ZS);
     HIPCHK(hipEventRecord(ev[4], sp1));
     // ---- eigen branch (second stream when available) ----
     fa.eigfree = eigfree ? 1 : 0;
@@ -896,11 +914,15 @@ void smcpp_im::enqueue_stats() {
             if (aa.NB != 1) launch_s1(NPL, se_a, se);          // M <= 64: k_rank_acc<2> forms the weights itself
             AccArgs ae = aa;
             ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
+            if (team2) {
+                ae.teams = d_teams_eg.p;
+                hipLaunchKernelGGL((k_rank_acc<2, true>), dim3((unsigned)teams_eg.size(), ae.NB * ae.NB), dim3(256), 0, se, ae);
+            } else
             hipLaunchKernelGGL(k_rank_acc<2>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
         }
         if (!eb_gid.empty())                                     // ONE share per bucket: k_span_F reads it on its serial path
             hipLaunchKernelGGL(k_sum_parts, dim3(ceil_div(MMi, 256), (unsigned)eb_gid.size(), 1), dim3(256), 0, se,
-                               (const double *)d_part_e.p, (const int *)d_eb_slab_off.p, d_red_e.p, MMi, 1);
+                               (const double *)d_part_e.p, (const int *)(team2 ? d_eb_team_off.p : d_eb_slab_off.p), d_red_e.p, MMi, 1);
         const size_t shm = (size_t)2 * Mp * (Mp + 1) * sizeof(double);
         // SMCPP_SPAN_FH=1: the one-workgroup-per-(contig, key) fold (M <= 64) instead of the strip kernels
         // (round 4) the fold on the SCANS: a row of F times A / A times a column of H is one O(M) step of the backward / forward chain

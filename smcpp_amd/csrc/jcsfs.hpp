@@ -186,7 +186,7 @@ public:
             at(m, 0, 0, 0, 0) = S(0.0);                                // non-segregating configurations carry no mass
             at(m, a1, n1, a2, n2) = S(0.0);
         }
-        return J;
+        return std::move(J);                                           // (J is rebuilt by the next compute())
     }
 
 private:
@@ -543,10 +543,23 @@ public:
     // raw joint CSFS per hidden state (what `joint_csfs` of smcpp/_smcpp.pyx:416-437 returns)
     template <typename S>
     std::vector<std::vector<S>> jcsfs(const ModelParamsT<S> &p1, const ModelParamsT<S> &p2, double split) const {
-        JointCsfsT<S> j(n_[0], n_[1], na_[0], na_[1], hs_, K_);
+        // (the object is kept: its constructor takes five Moran eigensystems and the static sandwiches W0 / W2 - 0.1 ms that depend
+        // on the sample sizes alone; compute() resets everything that depends on the parameters)
+        JointCsfsT<S> &j = joint<S>();
         j.batch_dev = batch_dev;
         return j.compute(p1, p2, split);
     }
+    template <typename S> JointCsfsT<S> &joint() const {
+        if constexpr (std::is_same<S, double>::value) {
+            if (!joint_d_) joint_d_.reset(new JointCsfsT<double>(n_[0], n_[1], na_[0], na_[1], hs_, K_));
+            return *joint_d_;
+        } else {
+            if (!joint_x_) joint_x_.reset(new JointCsfsT<S>(n_[0], n_[1], na_[0], na_[1], hs_, K_));
+            return *joint_x_;
+        }
+    }
+    mutable std::unique_ptr<JointCsfsT<double>> joint_d_;
+    mutable std::unique_ptr<JointCsfsT<dual>> joint_x_;
     mutable CsfsBatchDevice *batch_dev = nullptr;   // the engine's device route of the batched conditioned SFS (values only), not owned
 
     // keys [K][6]; outputs pi [M], T [M*M], E [K*M]

@@ -1089,15 +1089,26 @@ struct AccArgs {
     const double *cnorm;      // MODE 2, M <= 64: the weight is formed in the kernel
     const double *E;
     const double *Xs, *Ys;
-    double *part;             // [nslabs][Mp][Mp]
+    double *part;             // [nslabs][Mp][Mp]   (TEAM: [nteams][Mp][Mp])
     double *gpart;            // MODE 3: [nslabs][Mp] gamma sums of the slab's key
+    const int2 *teams;        // TEAM: {first slab, slabs (1..4)} of a workgroup - slabs of ONE reduction range
 };
 
-template <int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_rank_acc(AccArgs a) {
-    const int lane = threadIdx.x;
+// TEAM (round 5): a workgroup of four wavefronts takes up to four consecutive slabs of one reduction range, adds the four accumulators
+// through LDS (fixed order: (w0 + w2) + (w1 + w3)) and writes ONE partial - a quarter of the partial bytes written here and read back by
+// k_sum_parts (headline: 60 + 64 MB of 390 per E-step).  grid.x = teams.
+template <int MODE, bool TEAM = false>
+__global__ __launch_bounds__(TEAM ? 256 : 64) __attribute__((amdgpu_waves_per_eu(2))) void k_rank_acc(AccArgs a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m = lane & 15, qd = lane >> 4;
-    const Slab sl = a.slabs[blockIdx.x];
+    int slab_id = blockIdx.x;
+    bool have = true;
+    if (TEAM) {
+        const int2 tm = a.teams[blockIdx.x];
+        have = wv < tm.y;
+        slab_id = tm.x + (have ? wv : 0);
+    }
+    const Slab sl = a.slabs[slab_id];
     const int Mp = a.Mp;
     const int jb = (blockIdx.y / a.NB) * 64, kb = (blockIdx.y % a.NB) * 64;
     f64x4 acc[4][4];
@@ -1105,7 +1116,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
-    if (MODE == 0 || MODE == 2 || MODE == 3) {
+    if (TEAM && !have) {
+        // a wavefront without a slab only takes part in the reduction (with zeros)
+    } else if (MODE == 0 || MODE == 2 || MODE == 3) {
         // Software pipeline over groups of 4 rows (the MFMA k dimension): the {ell, key} pair is fetched two groups
         // ahead and the operands one group ahead, so the dependent chain  index -> row -> operands  (three memory
         // round trips, measured 4.8 us per group against 0.43 us of MFMA) no longer serialises every group.
@@ -1199,7 +1212,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
                 double v = gsum[t];
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
-                if (qd == 0 && kb + 16 * t + m < Mp) a.gpart[(size_t)blockIdx.x * Mp + kb + 16 * t + m] = v;
+                if (qd == 0 && kb + 16 * t + m < Mp) a.gpart[(size_t)slab_id * Mp + kb + 16 * t + m] = v;
             }
         }
     } else {
@@ -1220,6 +1233,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], yb[j], acc[i][j], 0, 0, 0);
         }
+    }
+    if (TEAM) {
+        // lane-major slots: [register 0..63][lane] - every ds access is 64 consecutive doubles
+        __shared__ double red[2][64 * 64];
+        if (wv >= 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) red[wv - 2][((i * 4 + j) * 4 + rg) * 64 + lane] = acc[i][j][rg];
+        }
+        __syncthreads();
+        if (wv < 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) acc[i][j][rg] += red[wv][((i * 4 + j) * 4 + rg) * 64 + lane];
+        }
+        __syncthreads();
+        if (wv == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) red[0][((i * 4 + j) * 4 + rg) * 64 + lane] = acc[i][j][rg];
+        }
+        __syncthreads();
+        if (wv != 0) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) acc[i][j][rg] += red[0][((i * 4 + j) * 4 + rg) * 64 + lane];
     }
     double *out = a.part + (size_t)blockIdx.x * Mp * Mp;
 #pragma unroll

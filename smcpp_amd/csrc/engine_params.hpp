@@ -38,9 +38,11 @@ void smcpp_im::prepare_params() {
             twopop_prep.reset(new smcpp_host::TwoPopPrep(n[0], n[1], na[0], na[1], hs, polarization_error));
             // The two-population preparation is the one host phase that still runs on a team of threads, in two parallel regions per
             // eval; with libomp's workers asleep in between (block time 0, above) each region pays their wake-up - more than its
-            // work.  One millisecond of spinning spans the GPU phase of an eval: config C4 561 -> 676 evals/s (15 threads; measured
-            // profiles/r05_*).  SMCPP_OMP_BLOCKTIME overrides.
-            if (kmp_set_blocktime && !getenv("SMCPP_OMP_BLOCKTIME")) kmp_set_blocktime(1);
+            // work.  Spinning that spans the GPU phase of an eval: config C4 561 -> 676 evals/s with one millisecond (15 threads; measured
+            // profiles/r05_*).  One millisecond is bistable, though - an eval of C4 takes 1.2 - 1.3 ms, and once one eval is late the workers
+            // are asleep at every following region (runs at 680 - 720 evals/s next to runs at 800 - 830): TWO milliseconds (6 runs of 6
+            // at 800 - 825).  SMCPP_OMP_BLOCKTIME overrides.
+            if (kmp_set_blocktime && !getenv("SMCPP_OMP_BLOCKTIME")) kmp_set_blocktime(2);
         }
         smcpp_host::TwoPopPrep &prep = *twopop_prep;
         {

@@ -1105,8 +1105,9 @@ __global__ __launch_bounds__(TEAM ? 256 : 64) __attribute__((amdgpu_waves_per_eu
     bool have = true;
     if (TEAM) {
         const int2 tm = a.teams[blockIdx.x];
-        have = wv < tm.y;
-        slab_id = tm.x + (have ? wv : 0);
+        const int wu = __builtin_amdgcn_readfirstlane(wv);          // (scalar: the slab and everything derived from it stay uniform)
+        have = wu < tm.y;
+        slab_id = tm.x + (have ? wu : 0);
     }
     const Slab sl = a.slabs[slab_id];
     const int Mp = a.Mp;
@@ -1166,16 +1167,7 @@ __global__ __launch_bounds__(TEAM ? 256 : 64) __attribute__((amdgpu_waves_per_eu
             }
             return o;
         };
-        // (round 3: TWO groups of operands in flight, descriptors three groups ahead - with one, a wavefront had 4 KB on its way
-        // during a ~2 us round trip: 2.4 TB/s on the whole genome)
-        int2 pk1 = fetch_pk(sl.start);
-        Ops cur = fetch_ops(pk1);
-        pk1 = fetch_pk(sl.start + 4);
-        Ops nx1 = fetch_ops(pk1);
-        pk1 = fetch_pk(sl.start + 8);
-        for (int r0 = sl.start; r0 < sl.end; r0 += 4) {
-            const int2 pk2 = fetch_pk(r0 + 12);
-            const Ops nxt = fetch_ops(pk1);          // operands of group r0 + 8 (all-zero past the end of the slab)
+        auto consume = [&](const Ops &cur) {
             double xa[4], yb[4];
             double wgt = cur.w;
             if (a.NB == 1) {
@@ -1201,6 +1193,18 @@ __global__ __launch_bounds__(TEAM ? 256 : 64) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], yb[j], acc[i][j], 0, 0, 0);
+        };
+        // (round 3: TWO groups of operands in flight, descriptors three groups ahead - with one, a wavefront had 4 KB on its way
+        // during a ~2 us round trip: 2.4 TB/s on the whole genome)
+        int2 pk1 = fetch_pk(sl.start);
+        Ops cur = fetch_ops(pk1);
+        pk1 = fetch_pk(sl.start + 4);
+        Ops nx1 = fetch_ops(pk1);
+        pk1 = fetch_pk(sl.start + 8);
+        for (int r0 = sl.start; r0 < sl.end; r0 += 4) {
+            const int2 pk2 = fetch_pk(r0 + 12);
+            const Ops nxt = fetch_ops(pk1);          // operands of group r0 + 8 (all-zero past the end of the slab)
+            consume(cur);
             cur = nx1;
             nx1 = nxt;
             pk1 = pk2;

@@ -732,9 +732,9 @@ void smcpp_im::update_pi_default() {
     for (double &v : pi_default) v /= sm;
 }
 
-static bool stats_team_on() {
-    static const bool on = !(getenv("SMCPP_STATS_TEAM") && atoi(getenv("SMCPP_STATS_TEAM")) == 0);
-    return on;
+static bool stats_team_on() {          // (read per call: a manager built after the switch changed follows it)
+    const char *e = getenv("SMCPP_STATS_TEAM");
+    return !(e && atoi(e) == 0);
 }
 
 void smcpp_im::make_slabs() {
@@ -1016,7 +1016,7 @@ void smcpp_im::alloc_device() {
     d_Ys.alloc(NT <= 4 ? 1 : std::max<size_t>(1, (size_t)n_e_rows) * Mp);
     // (d_part_e / d_red_e - one M x M partial per span GROUP slab / bucket - are allocated where they are used: un-binned data have
     // 10^5 groups and never take those paths when M <= 64)
-    d_part_1.alloc(std::max<size_t>(1, slabs_rk.size()) * Mp * Mp);
+    d_part_1.alloc(std::max<size_t>(1, stats_team_on() ? teams_rk.size() : slabs_rk.size()) * Mp * Mp);      // (one partial per team)
     // shares of the cross-slab reduction of the span-1 rank partials: few contigs, small M -> more, shorter shares (one contig at M = 64:
     // 8 shares of 126 slabs took 38 us of dependent loads)
     ZS = (int)std::max<long long>(8, std::min<long long>(16, 2048 / std::max<long long>(1, (long long)n_contigs * ceil_div((long long)Mp * Mp, 256))));

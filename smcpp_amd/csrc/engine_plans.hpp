@@ -819,7 +819,7 @@ void smcpp_im::enqueue_stats() {
     const bool rank2_early = eigfree && split_streams && !slabs_eg.empty() && !(stats_variant & 2) && n_e_rows < 1000000;
     const bool eig_gen2 = !eigfree && NT <= 4 && !slabs_eg.empty();      // (M > 64: the two-kernel form below)
     if (!slabs_eg.empty() && !eig_gen2) {
-        d_part_e.alloc(std::max<size_t>(1, slabs_eg.size()) * Mp * Mp);
+        d_part_e.alloc(std::max<size_t>(1, team2 ? teams_eg.size() : slabs_eg.size()) * Mp * Mp);
         fa.part_e = d_part_e.p;
         if (eigfree) { d_red_e.alloc(std::max<size_t>(1, eb_gid.size()) * Mp * Mp); fa.red_e = d_red_e.p; }
     }
@@ -869,7 +869,7 @@ void smcpp_im::enqueue_stats() {
         } else if (split_streams) HIPCHK(hipEventRecord(ev[14], sp1));
     }
     if (kfuse) {
-        d_part_1.alloc(std::max<size_t>(1, slabs_fk.size()) * Mp * Mp);
+        d_part_1.alloc(std::max<size_t>(1, team3 ? teams_fk.size() : slabs_fk.size()) * Mp * Mp);
         d_gpart_fk.alloc(slabs_fk.size() * Mp);
         aa.nslabs = (int)slabs_fk.size(); aa.slabs = d_slabs_fk.p; aa.perm = d_perm1.p; aa.permk = nullptr; aa.part = d_part_1.p;
         aa.gpart = d_gpart_fk.p;

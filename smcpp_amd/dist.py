@@ -247,12 +247,21 @@ class ShardedInferenceManager:
                     self._ext = torch.cuda.ExternalStream(int(self.im.stream()), device=dev) if self.stream_ordered else None
                 except Exception:                                    # (a torch build without external streams: the host-wait form)
                     self._ext = None
+            done = False
             if self._ext is not None and not self.keep_stats:
-                with torch.cuda.stream(self._ext):
-                    self.im.pack_stats_device(self._buf.data_ptr(), sync=False)
-                    self._dist.all_reduce(self._buf, op=self._dist.ReduceOp.SUM, group=self._group)
-                    self._ll_sum = float(self._buf[0].item())         # the one host wait of the exchange
-            else:
+                try:
+                    with torch.cuda.stream(self._ext):
+                        self.im.pack_stats_device(self._buf.data_ptr(), sync=False)
+                        self._dist.all_reduce(self._buf, op=self._dist.ReduceOp.SUM, group=self._group)
+                        self._ll_sum = float(self._buf[0].item())     # the one host wait of the exchange
+                    done = True
+                except RuntimeError as ex:
+                    # a process-group build that cannot take an external stream: say so once and keep the host-wait form (the
+                    # statistics of this E-step are still in the engine - they are packed again below)
+                    import warnings
+                    warnings.warn(f"stream-ordered exchange unavailable ({ex}); falling back to the host-wait form")
+                    self._ext = None
+            if not done:
                 self.im.pack_stats_device(self._buf.data_ptr())       # returns after the kernel has finished
                 if self.keep_stats:
                     self.last_local_stats = self._buf.cpu().numpy().copy()

@@ -819,6 +819,43 @@ def test_span1_statistics_one_pass_in_key_order(monkeypatch):
             np.testing.assert_allclose(g1[k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
 
 
+def test_rank_partials_by_teams_of_four_slabs_vs_one_per_slab(monkeypatch):
+    """Round 5 default: four consecutive slabs of one reduction range share a workgroup of `k_rank_acc<., true>`, which adds their
+    accumulators through LDS and writes ONE partial; SMCPP_STATS_TEAM=0 keeps one partial per slab.  Same goldens and tolerances for
+    both (one to four states per lane: the span-1 form of M > 64 too), and against each other to the rounding of a re-ordered sum."""
+    res = {}
+    import os
+    from conftest import ROOT
+    from smcpp_amd import _smcpp
+    names = ("G4_M64_n20_2Mbp", "G3_M32_n10_2Mbp", "G1_M16_n4", "G5_M48_twopop_layout")
+    p5 = dict(np.load(os.path.join(ROOT, "tests", "golden", "params_M256_n50.npz")))
+    g5 = load_golden("G14_c5_slice")
+    for team in ("0", "1"):
+        monkeypatch.setenv("SMCPP_STATS_TEAM", team)
+        for name in names:
+            g = load_golden(name)
+            im = make_im(g)
+            im.E_step()
+            check_against(g, im, save_gamma=False)
+            res[(team, name)] = (im.gamma_sums[0], im.xisums[0])
+        # four states per lane (config C5's slice, golden G14 from the compiled reference): the span-1 rank update in its M > 64 form
+        im = _smcpp.PyOnePopInferenceManager(50, [np.ascontiguousarray(g5["obs"], dtype=np.int32)], p5["hs"], ("pop1",), float(p5["pol"]))
+        im.theta = float(p5["theta"]); im.rho = float(p5["rho"]); im.alpha = float(p5["alpha"])
+        im.set_raw(p5["pi"], p5["T"], p5["keys"], p5["E"])
+        im.E_step()
+        assert rel_err(im.xisums[0], g5["xisum"]) <= STAT_TOL
+        gs = im.gamma_sums[0]
+        for k, v in zip([tuple(int(x) for x in k) for k in g5["gs_keys"]], g5["gs_vals"]):
+            assert np.max(np.abs(gs[k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300), k
+        res[(team, "G14")] = (gs, im.xisums[0])
+    for name in names + ("G14",):
+        g0, x0 = res[("0", name)]
+        g1, x1 = res[("1", name)]
+        assert rel_err(x1, x0) <= 1e-11
+        for k, v in g0.items():
+            np.testing.assert_allclose(g1[k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
+
+
 def test_float_scans_of_the_stored_passes_vs_fp64_scans(monkeypatch):
     """Round 5 default: every scan of the stored passes runs in float (the sums over the states above as native suffix scans; the
     vector and the diagonal term stay in fp64), SMCPP_SS_MIXED=0 keeps the fp64 scans.  Same goldens and tolerances for both, and

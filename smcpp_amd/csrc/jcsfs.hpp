@@ -199,6 +199,9 @@ private:
 
     // ---- both distinguished lineages in population 1 (jcsfs.cpp:371-420) ----
     void together() {
+        static const bool tm_ = getenv("SMCPP_HOST_TIMING") != nullptr;
+        const double tw0 = tm_ ? omp_get_wtime() : 0.0;
+        double tw_region = 0.0, tw_single = 0.0, tw_collected = 0.0, tw_sec[4] = {0, 0, 0, 0};
         eta1.reset(new RateFunctionT<S>(params1, std::vector<double>{split - 1e-6, split + 1e-6}));
         const RateFunctionT<S> eta2(params2, std::vector<double>());
         Rts1 = eta1->R(split);
@@ -267,6 +270,7 @@ private:
                 err = ex.what();
             }
         };
+        if (tm_) tw_region = omp_get_wtime();
 #pragma omp parallel
         {
             DualScope sc(nd);
@@ -278,13 +282,16 @@ private:
             {
 #pragma omp section
                 guarded([&] {
+                    const double ts_ = tm_ ? omp_get_wtime() : 0.0;
                     if (n2 > 1) {
                         const RateFunctionT<S> eta2_trunc(truncate_params(params2, split), std::vector<double>{0.0, INFINITY});
                         r2 = undistinguished_sfs(csfs_of(n2 - 2, eta2_trunc)[0], n2 - 2);
                     }
+                    if (tm_) tw_sec[0] = omp_get_wtime() - ts_;
                 });
 #pragma omp section
                 guarded([&] {
+                    const double ts_ = tm_ ? omp_get_wtime() : 0.0;
                     if (!any_below) return;
                     const RateFunctionT<S> eta1_shift(shift_params(params1, split), std::vector<double>{0.0, INFINITY});
                     sfs_above_split = undistinguished_sfs(csfs_of(n1 + n2 - 1, eta1_shift)[0], n1 + n2 - 1);
@@ -293,9 +300,11 @@ private:
                             const S f = sfs_above_split[nseg - 1] * h2(np1, nseg);
                             for (int b2 = 0; b2 <= n2; ++b2) Cb_[(size_t)np1 * c2 + b2] += f * eMn2[(size_t)(nseg - np1) * c2 + b2];
                         }
+                    if (tm_) tw_sec[1] = omp_get_wtime() - ts_;
                 });
 #pragma omp section
                 guarded([&] {
+                    const double ts_ = tm_ ? omp_get_wtime() : 0.0;
                     if (!any_above) return;
                     for (int i = 0; i < 3; ++i)
                         for (int nseg = 0; nseg <= n1 + n2; ++nseg)
@@ -307,21 +316,26 @@ private:
                                     for (int b2 = 0; b2 <= n2; ++b2) dst[(size_t)b1 * c2 + b2] += f * eMn2[(size_t)(nseg - np1) * c2 + b2];
                                 }
                             }
+                    if (tm_) tw_sec[2] = omp_get_wtime() - ts_;
                 });
 #pragma omp section
                 guarded([&] {
+                    const double ts_ = tm_ ? omp_get_wtime() : 0.0;
                     if (any_above) below_at_split = csfs_of(n1, *eta1, true)[0];          // (the same for every state above the split)
                     // (a batch whose model the factored evaluation cannot take - a zero rate - goes through the generic routine)
                     if (!hb.empty() && !team_b && !dev_b) trunc_all = csfs_of(n1, *eta_trunc_all);
                     if (!ha.empty() && !team_a && !dev_a) rsfs_all = csfs_of(n1 + n2, *eta_shift_all);
+                    if (tm_) tw_sec[3] = omp_get_wtime() - ts_;
                 });
             }
 #pragma omp single
             {
+                if (tm_) tw_single = omp_get_wtime();
                 if (team_b) trunc_all.swap(job_b.csfs);
                 if (team_a) rsfs_all.swap(job_a.csfs);
                 if (dev_b) guarded([&] { CsfsBatchHook<S>::collect(batch_dev, 0, trunc_all); });
                 if (dev_a) guarded([&] { CsfsBatchHook<S>::collect(batch_dev, 1, rsfs_all); });
+                if (tm_) tw_collected = omp_get_wtime();
             }
             // ---- (C) ----
 #pragma omp for schedule(dynamic)
@@ -356,6 +370,11 @@ private:
                     err = ex.what();
                 }
             }
+        }
+        if (tm_) {
+            const double t1 = omp_get_wtime();
+            fprintf(stderr, "[jcsfs] serial head %.1f us (rate functions, expM, device batches enqueued), batches + sections %.1f us, collect %.1f us, "
+                    "states %.1f us; sections: r2 %.1f, sfs above + Cb %.1f, Da %.1f, below at split / fallbacks %.1f us\n", 1e6 * (tw_region - tw0), 1e6 * (tw_single - tw_region), 1e6 * (tw_collected - tw_single), 1e6 * (t1 - tw_collected), 1e6 * tw_sec[0], 1e6 * tw_sec[1], 1e6 * tw_sec[2], 1e6 * tw_sec[3]);
         }
         if (job_b.side_err) std::rethrow_exception(job_b.side_err);
         if (job_a.side_err) std::rethrow_exception(job_a.side_err);

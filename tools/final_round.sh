@@ -3,7 +3,7 @@
 # headline and the whole genome, every workload's bench line, Q-with-gradient, warm start, the N > 1 path on one device (2 ranks;
 # 8 ranks with --check for c3 and c4), one rank's shard of the 8-GPU genome run, kernel stats of c3 / c5 / posterior / qgrad,
 # the DPP issue-cost lab, the stream-hop cost lab, a host trace of the headline's E-step.
-TAG=${1:-r05_a}
+TAG=${1:-r05_b}
 cd $GRAFT_REPO_ROOT
 bash tools/profile_round.sh $TAG > /dev/null 2>&1
 O=gpurun_out/$TAG
@@ -26,4 +26,11 @@ done
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $GRAFT_REPO_ROOT/tools/dpp_lab.hip -o /tmp/dpp_lab && /tmp/dpp_lab > $GRAFT_REPO_ROOT/$O/dpp_lab.log 2>&1
 /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 $GRAFT_REPO_ROOT/tools/sync_lab.hip -o /tmp/sync_lab && /tmp/sync_lab > $GRAFT_REPO_ROOT/$O/sync_lab.log 2>&1
 SMCPP_HOST_TRACE=1 python $GRAFT_REPO_ROOT/bench.py --no-cpu --steps 4 --warmup 2 2>&1 | grep host-trace | sed -n 40,60p > $GRAFT_REPO_ROOT/$O/host_trace.log
+# two-population preparation: where the host phase of config C4 goes (transition / joint CSFS / assembly; inside the joint CSFS)
+SMCPP_HOST_TIMING=1 python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload c4 --steps 8 --warmup 3 2>&1 | grep -a "prep2\|jcsfs" | tail -8 > $GRAFT_REPO_ROOT/$O/c4_host_timing.log
+# the statistics phase of the headline and of config C5, kernel by kernel (tools/stats_timeline.py)
+for w in headline c5; do
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$w -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload $w --steps 6 --warmup 3 > /dev/null 2>&1 </dev/null
+  python $GRAFT_REPO_ROOT/tools/stats_timeline.py /tmp/tl_$w > $GRAFT_REPO_ROOT/$O/stats_timeline_$w.txt 2>&1
+done
 grep '^{"metric"' $GRAFT_REPO_ROOT/$O/bench_default.log | tail -1 | cut -c1-300

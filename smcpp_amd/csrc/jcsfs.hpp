@@ -256,22 +256,6 @@ private:
             if (team_a) job_a.init(*eta_shift_all, *csfs_tables(n1 + n2), false);
         }
         eta_plain.reset(new RateFunctionT<S>(params1, std::vector<double>()));
-        // the single-state problems: the folded truncated SFS of population 2 (n2 - 2 lineages) and the SFS above the split (n1 + n2 - 1)
-        std::unique_ptr<RateFunctionT<S>> eta2_trunc, eta1_shift;
-        CsfsJob<S> job_r2, job_sa;
-        bool wide_r2 = false, wide_sa = false;
-        if (n2 > 1) {
-            eta2_trunc.reset(new RateFunctionT<S>(truncate_params(params2, split), std::vector<double>{0.0, INFINITY}));
-            job_r2.eta = eta2_trunc.get();
-            wide_r2 = job_r2.factored();
-            if (wide_r2) { job_r2.wide = true; job_r2.init(*eta2_trunc, *csfs_tables(n2 - 2), false); }
-        }
-        if (any_below) {
-            eta1_shift.reset(new RateFunctionT<S>(shift_params(params1, split), std::vector<double>{0.0, INFINITY}));
-            job_sa.eta = eta1_shift.get();
-            wide_sa = job_sa.factored();
-            if (wide_sa) { job_sa.wide = true; job_sa.init(*eta1_shift, *csfs_tables(n1 + n2 - 1), false); }
-        }
         std::vector<S> r2;
         Cb_.assign((size_t)(n1 + 2) * c2, S(0.0));
         Da_.assign((size_t)3 * (n1 + n2 + 1) * c1 * c2, S(0.0));
@@ -294,49 +278,57 @@ private:
             if (team_b) conditioned_sfs_team<S>(job_b);
             if (team_a) conditioned_sfs_team<S>(job_a);
             // ---- (B) ----
-            // the two single-state problems as WIDE team jobs (the rows of their integrals shared out: a section of its own took 45 and
-            // 90 us of one thread while eleven others waited), then - all `nowait`, one barrier at the end - the below-part at the split
-            // and the fallbacks on one thread, the contraction Da shared out, the folded spectra + Cb on one thread, the device batches
-            // collected by one thread
-            if (wide_r2) conditioned_sfs_team<S>(job_r2);
-            if (wide_sa) conditioned_sfs_team<S>(job_sa);
-#pragma omp single nowait
-            guarded([&] {
-                const double ts_ = tm_ ? omp_get_wtime() : 0.0;
-                if (any_above) below_at_split = csfs_of(n1, *eta1, true)[0];          // (the same for every state above the split)
-                // (a batch whose model the factored evaluation cannot take - a zero rate - goes through the generic routine)
-                if (!hb.empty() && !team_b && !dev_b) trunc_all = csfs_of(n1, *eta_trunc_all);
-                if (!ha.empty() && !team_a && !dev_a) rsfs_all = csfs_of(n1 + n2, *eta_shift_all);
-                if (tm_) tw_sec[3] = omp_get_wtime() - ts_;
-            });
-#pragma omp for schedule(dynamic) nowait
-            for (int q = 0; q < 3 * (n1 + n2 + 1); ++q) {
-                if (!any_above) continue;
-                const int i = q / (n1 + n2 + 1), nseg = q % (n1 + n2 + 1);
-                S *dst = &Da_[(size_t)q * c1 * c2];
-                for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1); ++np1) {
-                    const double h = h1(np1, nseg);
-                    for (int b1 = 0; b1 <= n1; ++b1) {
-                        const S f = eMn1[i][(size_t)np1 * c1 + b1] * h;
-                        for (int b2 = 0; b2 <= n2; ++b2) dst[(size_t)b1 * c2 + b2] += f * eMn2[(size_t)(nseg - np1) * c2 + b2];
+#pragma omp sections
+            {
+#pragma omp section
+                guarded([&] {
+                    const double ts_ = tm_ ? omp_get_wtime() : 0.0;
+                    if (n2 > 1) {
+                        const RateFunctionT<S> eta2_trunc(truncate_params(params2, split), std::vector<double>{0.0, INFINITY});
+                        r2 = undistinguished_sfs(csfs_of(n2 - 2, eta2_trunc)[0], n2 - 2);
                     }
-                }
-            }
-#pragma omp single nowait
-            guarded([&] {
-                const double ts_ = tm_ ? omp_get_wtime() : 0.0;
-                if (n2 > 1) r2 = undistinguished_sfs(wide_r2 ? job_r2.csfs[0] : csfs_of(n2 - 2, *eta2_trunc)[0], n2 - 2);
-                if (any_below) {
-                    sfs_above_split = undistinguished_sfs(wide_sa ? job_sa.csfs[0] : csfs_of(n1 + n2 - 1, *eta1_shift)[0], n1 + n2 - 1);
+                    if (tm_) tw_sec[0] = omp_get_wtime() - ts_;
+                });
+#pragma omp section
+                guarded([&] {
+                    const double ts_ = tm_ ? omp_get_wtime() : 0.0;
+                    if (!any_below) return;
+                    const RateFunctionT<S> eta1_shift(shift_params(params1, split), std::vector<double>{0.0, INFINITY});
+                    sfs_above_split = undistinguished_sfs(csfs_of(n1 + n2 - 1, eta1_shift)[0], n1 + n2 - 1);
                     for (int nseg = 1; nseg <= n1 + n2; ++nseg)
                         for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1 + 1); ++np1) {
                             const S f = sfs_above_split[nseg - 1] * h2(np1, nseg);
                             for (int b2 = 0; b2 <= n2; ++b2) Cb_[(size_t)np1 * c2 + b2] += f * eMn2[(size_t)(nseg - np1) * c2 + b2];
                         }
-                }
-                if (tm_) tw_sec[1] = omp_get_wtime() - ts_;
-            });
-#pragma omp single nowait
+                    if (tm_) tw_sec[1] = omp_get_wtime() - ts_;
+                });
+#pragma omp section
+                guarded([&] {
+                    const double ts_ = tm_ ? omp_get_wtime() : 0.0;
+                    if (!any_above) return;
+                    for (int i = 0; i < 3; ++i)
+                        for (int nseg = 0; nseg <= n1 + n2; ++nseg)
+                            for (int np1 = std::max(nseg - n2, 0); np1 <= std::min(nseg, n1); ++np1) {
+                                const double h = h1(np1, nseg);
+                                S *dst = &Da_[((size_t)i * (n1 + n2 + 1) + nseg) * c1 * c2];
+                                for (int b1 = 0; b1 <= n1; ++b1) {
+                                    const S f = eMn1[i][(size_t)np1 * c1 + b1] * h;
+                                    for (int b2 = 0; b2 <= n2; ++b2) dst[(size_t)b1 * c2 + b2] += f * eMn2[(size_t)(nseg - np1) * c2 + b2];
+                                }
+                            }
+                    if (tm_) tw_sec[2] = omp_get_wtime() - ts_;
+                });
+#pragma omp section
+                guarded([&] {
+                    const double ts_ = tm_ ? omp_get_wtime() : 0.0;
+                    if (any_above) below_at_split = csfs_of(n1, *eta1, true)[0];          // (the same for every state above the split)
+                    // (a batch whose model the factored evaluation cannot take - a zero rate - goes through the generic routine)
+                    if (!hb.empty() && !team_b && !dev_b) trunc_all = csfs_of(n1, *eta_trunc_all);
+                    if (!ha.empty() && !team_a && !dev_a) rsfs_all = csfs_of(n1 + n2, *eta_shift_all);
+                    if (tm_) tw_sec[3] = omp_get_wtime() - ts_;
+                });
+            }
+#pragma omp single
             {
                 if (tm_) tw_single = omp_get_wtime();
                 if (team_b) trunc_all.swap(job_b.csfs);
@@ -345,7 +337,6 @@ private:
                 if (dev_a) guarded([&] { CsfsBatchHook<S>::collect(batch_dev, 1, rsfs_all); });
                 if (tm_) tw_collected = omp_get_wtime();
             }
-#pragma omp barrier
             // ---- (C) ----
 #pragma omp for schedule(dynamic)
             for (int m = 0; m < M; ++m) {
@@ -383,7 +374,7 @@ private:
         if (tm_) {
             const double t1 = omp_get_wtime();
             fprintf(stderr, "[jcsfs] serial head %.1f us (rate functions, expM, device batches enqueued), batches + sections %.1f us, collect %.1f us, "
-                    "states %.1f us; single threads: folded spectra + Cb %.1f, below at split / fallbacks %.1f us\n", 1e6 * (tw_region - tw0), 1e6 * (tw_single - tw_region), 1e6 * (tw_collected - tw_single), 1e6 * (t1 - tw_collected), 1e6 * tw_sec[1], 1e6 * tw_sec[3]);
+                    "states %.1f us; sections: r2 %.1f, sfs above + Cb %.1f, Da %.1f, below at split / fallbacks %.1f us\n", 1e6 * (tw_region - tw0), 1e6 * (tw_single - tw_region), 1e6 * (tw_collected - tw_single), 1e6 * (t1 - tw_collected), 1e6 * tw_sec[0], 1e6 * tw_sec[1], 1e6 * tw_sec[2], 1e6 * tw_sec[3]);
         }
         if (job_b.side_err) std::rethrow_exception(job_b.side_err);
         if (job_a.side_err) std::rethrow_exception(job_a.side_err);

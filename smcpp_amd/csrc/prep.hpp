@@ -1241,9 +1241,6 @@ struct CsfsJob {
     double tmark[64][4] = {};
     std::chrono::steady_clock::time_point tbase;
     std::exception_ptr side_err;
-    // `wide` (few hidden states, a whole team): the rows (state, lam) of the "above" integrals are shared out instead of the states
-    bool wide = false;
-    std::vector<S> Cw, ertw, e1w;      // wide: [M][(n+1) n] integrals, [K][n] tables of exp(-rate ada dt) and exp(-rate dR)
     bool factored() const {
         if (csfs_direct_flag() != 0) return false;
         for (const S &x : eta->ada) if (sval(x) == 0) return false;               // ada == 0: the factored sums divide by it
@@ -1257,10 +1254,6 @@ struct CsfsJob {
         if (above) pt.Ssuf.assign((size_t)n * K, S(0.0));
         pt.Ppre.assign((size_t)(n + 1) * (K + 1), S(0.0));
         csfs.assign(M, std::vector<S>((size_t)3 * (n + 1), S(0.0)));
-        if (wide && above) {
-            Cw.assign((size_t)M * (n + 1) * n, S(0.0));
-            ertw.assign((size_t)K * n, S(0.0)); e1w.assign((size_t)K * n, S(0.0));
-        }
         tbase = std::chrono::steady_clock::now();
     }
 };
@@ -1299,71 +1292,8 @@ inline void conditioned_sfs_team(CsfsJob<S> &job, const std::function<void()> *s
             }
         }
         if (tm && tid_ < 64) tmark[tid_][2] = now_us();
-        std::vector<S> Ca(above && !job.wide ? (size_t)(n + 1) * n : 0), A(n + 1), A1(n + 1), B(n + 1), El(n + 1), ert(n), e1(n), tmp0(n + 1),
-            tmp2(n + 1), v(n), below(n + 1);
-        if (job.wide && above) {
-            // (1) the per-(piece, rate) exponentials, pieces shared out; (2) the rows (state, lam) of the integrals, shared out: every
-            // entry accumulates its pieces in the same order, with the same operations, as the per-state loop below
-#pragma omp for schedule(static)
-            for (int m = 0; m < K; ++m) {
-                if (!(ts[m + 1] < INFINITY)) continue;
-                const S adadiff = ada[m] * (ts[m + 1] - ts[m]);
-                const S dR = Rrng[m + 1] - Rrng[m];
-                for (int jr = 0; jr < n; ++jr) {
-                    job.ertw[(size_t)m * n + jr] = m_exp(-(double)RF::nC2(jr + 2) * adadiff);
-                    job.e1w[(size_t)m * n + jr] = m_exp(-(double)RF::nC2(jr + 2) * dR);
-                }
-            }
-#pragma omp for collapse(2) schedule(static)
-            for (int h = 0; h < M; ++h)
-                for (int jl = 0; jl <= n; ++jl) {
-                    const S Rh = Rrng[hsi[h]], Rh1 = Rrng[hsi[h + 1]];
-                    S log_denom = -Rh;
-                    if (sval(Rh1) != INFINITY) log_denom += m_log(-m_expm1(-(Rh1 - Rh)));
-                    const S log_coef0 = -log_denom;
-                    S *row = &job.Cw[((size_t)h * (n + 1) + jl) * n];
-                    const long l1l = RF::nC2(jl + 2);
-                    const double l1 = (double)l1l;
-                    for (int m = hsi[h]; m < hsi[h + 1]; ++m) {
-                        const S &ad = ada[m];
-                        const bool fin = ts[m + 1] < INFINITY;
-                        const S adadiff = ad * (ts[m + 1] - ts[m]);
-                        const S Rm = Rrng[m], Rm1 = Rrng[m + 1];
-                        const S dR = Rm1 - Rm;
-                        const S Ajl = m_exp(-l1 * Rm + log_coef0);
-                        S A1jl(0.0), Bjl(0.0), Eljl(0.0);
-                        if (m + 1 < K) A1jl = m_exp(-l1 * Rm1 + log_coef0);
-                        if (fin) { Bjl = m_expm1(-l1 * adadiff); Eljl = m_exp(-l1 * adadiff); }
-                        const S *ertm = &job.ertw[(size_t)m * n], *e1m = &job.e1w[(size_t)m * n];
-                        for (int jr = 0; jr < n; ++jr) {
-                            const long ratel = RF::nC2(jr + 2);
-                            const double rt = (double)ratel;
-                            S &tgt = row[jr];
-                            if (l1l == ratel) {
-                                if (!fin) tgt += Ajl / rt / rt / ad;
-                                else tgt += Ajl * (1.0 - ertm[jr] * (1.0 + rt * adadiff)) / rt / rt / ad;
-                            } else if (!fin) tgt += Ajl / l1 / rt / ad;
-                            else if (ratel < l1l)
-                                tgt += -Ajl * (Bjl / l1 + (ertm[jr] * -m_expm1(-(l1 - rt) * adadiff) / (l1 - rt))) / rt / ad;
-                            else
-                                tgt += -Ajl * (Bjl / l1 + (Eljl * m_expm1(-(rt - l1) * adadiff) / (l1 - rt))) / rt / ad;
-                            if (m + 1 >= K) continue;
-                            S coef(0.0), fac(0.0);
-                            const long rp = l1l - ratel;
-                            const double rpd = (double)rp;
-                            if (rp == 0) { fac = dR; coef = A1jl; }
-                            else if (rp < 0) {
-                                if (-rpd * sval(dR) > 20) { coef = A1jl; fac = S(-1.0 / rpd); }
-                                else { coef = Ajl * e1m[jr]; fac = -m_expm1(-rpd * dR) / rpd; }
-                            } else {
-                                if (-rpd * sval(Rm - Rm1) > 20) { coef = Ajl * e1m[jr]; fac = S(1.0 / rpd); }
-                                else { coef = A1jl; fac = m_expm1(-rpd * (Rm - Rm1)) / rpd; }
-                            }
-                            tgt += coef * pt.Ssuf[(size_t)jr * K + m] * fac;
-                        }
-                    }
-                }
-        }
+        std::vector<S> Ca(above ? (size_t)(n + 1) * n : 0), A(n + 1), A1(n + 1), B(n + 1), El(n + 1), ert(n), e1(n), tmp0(n + 1), tmp2(n + 1), v(n),
+            below(n + 1);
 #pragma omp for schedule(dynamic)
         for (int h = 0; h < M; ++h) {
             const S Rh = Rrng[hsi[h]], Rh1 = Rrng[hsi[h + 1]];
@@ -1371,11 +1301,10 @@ inline void conditioned_sfs_team(CsfsJob<S> &job, const std::function<void()> *s
             if (sval(Rh1) != INFINITY) log_denom += m_log(-m_expm1(-(Rh1 - Rh)));
             S *out = csfs[h].data();
             // ---- above (tjj_double_integral_above for every jj, piecewise_constant_rate_function.cpp:214-299) ----
-            const S *Cah = (job.wide && above) ? &job.Cw[(size_t)h * (n + 1) * n] : Ca.data();
             if (above) {
                 for (S &x : Ca) x = S(0.0);
                 const S log_coef0 = -log_denom;
-                for (int m = hsi[h]; !job.wide && m < hsi[h + 1]; ++m) {
+                for (int m = hsi[h]; m < hsi[h + 1]; ++m) {
                     const S &ad = ada[m];
                     const bool fin = ts[m + 1] < INFINITY;
                     const S adadiff = ad * (ts[m + 1] - ts[m]);
@@ -1430,9 +1359,9 @@ inline void conditioned_sfs_team(CsfsJob<S> &job, const std::function<void()> *s
                 }
                 // ---- contractions (conditioned_sfs.cpp:42-83) ----
                 for (int j = 0; j < n + 1; ++j) {
-                    for (int i = 0; i < n; ++i) v[i] = Cah[(size_t)j * n + i] * tb.X0(i, j);             // C0(i,j) = C(j,i)
+                    for (int i = 0; i < n; ++i) v[i] = Ca[(size_t)j * n + i] * tb.X0(i, j);              // C0(i,j) = C(j,i)
                     tmp0[j] = accurate_sum(v.data(), n);
-                    for (int i = 0; i < n; ++i) v[i] = Cah[(size_t)(n - j) * n + i] * tb.X2(i, j);       // C2(i,j) = C(n-j,i)
+                    for (int i = 0; i < n; ++i) v[i] = Ca[(size_t)(n - j) * n + i] * tb.X2(i, j);        // C2(i,j) = C(n-j,i)
                     tmp2[j] = accurate_sum(v.data(), n);
                 }
                 for (int b = 0; b < n; ++b) {

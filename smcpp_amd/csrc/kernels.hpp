@@ -1136,13 +1136,18 @@ __global__ __launch_bounds__(TEAM ? 256 : 64) __attribute__((amdgpu_waves_per_eu
             return pk;
         };
         struct Ops { double w; float ap[4], an[4]; double bp[4], ep[4]; bool valid; };
+        // (round 5) COLUMN MAP of these modes: tile t of lane m is column 4 m + t of the block (not 16 t + m): a lane's four columns are
+        // consecutive, so a row's operands are ONE 16-byte load of alpha and two of beta per lane (four and four before: the rank
+        // updates were issuing 13 - 21 loads per group of four rows), and a row of the block is read as one contiguous 256 / 512 bytes.
+        // Which products meet in which accumulator entry is unchanged - only where the entry is written (the store below maps back).
         int jc[4], kc[4];
         bool jv[4], kv[4];
+        const int j0 = jb + 4 * m, k0 = kb + 4 * m;
+        const int j0c = j0 < Mp ? j0 : 0, k0c = k0 < Mp ? k0 : 0;     // (Mp is a multiple of 16: a lane's four columns are in or out together)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int j = jb + 16 * t + m, k = kb + 16 * t + m;
-            jv[t] = j < Mp; kv[t] = k < Mp;
-            jc[t] = jv[t] ? j : 0; kc[t] = kv[t] ? k : 0;
+            jv[t] = j0 < Mp; kv[t] = k0 < Mp;
+            jc[t] = j0c + t; kc[t] = k0c + t;
         }
         double ekc[4] = {1.0, 1.0, 1.0, 1.0}, gsum[4] = {0.0, 0.0, 0.0, 0.0};
         if (MODE == 3) {
@@ -1160,10 +1165,23 @@ __global__ __launch_bounds__(TEAM ? 256 : 64) __attribute__((amdgpu_waves_per_eu
             const float *ap = a.alpha + (row - 1) * Mp;
             const double *bp = a.beta + row * Mp;
             const double *ep = a.E + (size_t)pk.y * Mp;
+            const float4 a4 = *reinterpret_cast<const float4 *>(ap + j0c);
+            const double4 b4 = *reinterpret_cast<const double4 *>(bp + k0c);
+            o.ap[0] = a4.x; o.ap[1] = a4.y; o.ap[2] = a4.z; o.ap[3] = a4.w;
+            o.bp[0] = b4.x; o.bp[1] = b4.y; o.bp[2] = b4.z; o.bp[3] = b4.w;
+            if (MODE == 0) {
+                const double4 e4 = *reinterpret_cast<const double4 *>(ep + k0c);
+                o.ep[0] = e4.x; o.ep[1] = e4.y; o.ep[2] = e4.z; o.ep[3] = e4.w;
+            } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                o.ap[t] = ap[jc[t]]; o.bp[t] = bp[kc[t]]; o.ep[t] = MODE == 0 ? ep[kc[t]] : MODE == 3 ? ekc[t] : 1.0;
-                o.an[t] = inl ? ap[Mp + kc[t]] : 0.f;
+                for (int t = 0; t < 4; ++t) o.ep[t] = MODE == 3 ? ekc[t] : 1.0;
+            }
+            if (inl) {
+                const float4 n4 = *reinterpret_cast<const float4 *>(ap + Mp + k0c);
+                o.an[0] = n4.x; o.an[1] = n4.y; o.an[2] = n4.z; o.an[3] = n4.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o.an[t] = 0.f;
             }
             return o;
         };
@@ -1216,7 +1234,7 @@ __global__ __launch_bounds__(TEAM ? 256 : 64) __attribute__((amdgpu_waves_per_eu
                 double v = gsum[t];
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
-                if (qd == 0 && kb + 16 * t + m < Mp) a.gpart[(size_t)slab_id * Mp + kb + 16 * t + m] = v;
+                if (qd == 0 && k0 < Mp) a.gpart[(size_t)slab_id * Mp + k0 + t] = v;
             }
         }
     } else {
@@ -1277,6 +1295,20 @@ __global__ __launch_bounds__(TEAM ? 256 : 64) __attribute__((amdgpu_waves_per_eu
                 for (int rg = 0; rg < 4; ++rg) acc[i][j][rg] += red[0][((i * 4 + j) * 4 + rg) * 64 + lane];
     }
     double *out = a.part + (size_t)blockIdx.x * Mp * Mp;
+    if (MODE != 1) {
+        // the column map of modes 0 / 2 / 3: accumulator (tile i, D row r) is block row 4 r + i, (tile j, D column m) is block column
+        // 4 m + j - a lane's four tiles j are four consecutive columns: one 32-byte store per (i, register)
+        const int col = kb + 4 * m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row = jb + 4 * (qd + 4 * rg) + i;
+                if (row < Mp && col < Mp)
+                    *reinterpret_cast<double4 *>(out + (size_t)row * Mp + col) = make_double4(acc[i][0][rg], acc[i][1][rg], acc[i][2][rg], acc[i][3][rg]);
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll

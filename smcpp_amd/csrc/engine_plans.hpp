@@ -780,7 +780,10 @@ void smcpp_im::enqueue_stats() {
                        (kf_env ? atoi(kf_env) != 0 : (n_1_rows >= 500000 || crit_main));
     // (round 4: with the span > 1 branch on the main stream the span-1 statistics are ONE side branch in the one-pass form instead
     // of two - 887 against 873 headline evals per second, and 140 MB less traffic per E-step)
-    const bool ll_own = split_streams && stream3 != nullptr && !eigfree;     // (eigen-free: free at the head of the main stream, which waits there)
+    // (eigen-free with the span > 1 branch on the main stream: free at its head, which waits there; round 5: the other eigen-free cases -
+    // M > 64, or a million span > 1 rows - no longer make the main stream wait, so the two kernels would delay its weights pass by their
+    // 60 - 130 us: third stream there too)
+    const bool ll_own = split_streams && stream3 != nullptr && (!eigfree || !crit_main);
     // crit_main with the one-pass span-1 form: the third stream has nothing else to do - the log-likelihood kernels run there,
     // beside both branches instead of at the head of the span-1 branch (joined in front of the finalisation)
     const bool ll3 = crit_main && kfuse && stream3 != nullptr;
@@ -817,6 +820,7 @@ void smcpp_im::enqueue_stats() {
     // (small inputs only: from ~10^6 span > 1 rows on, the rank updates are bound by memory parallelism and the two of them
     // running side by side finish sooner than one after the other - whole genome: 3.76 -> 3.36 ms of statistics)
     const bool rank2_early = eigfree && split_streams && !slabs_eg.empty() && !(stats_variant & 2) && n_e_rows < 1000000;
+    bool wait17 = false;
     const bool eig_gen2 = !eigfree && NT <= 4 && !slabs_eg.empty();      // (M > 64: the two-kernel form below)
     if (!slabs_eg.empty() && !eig_gen2) {
         d_part_e.alloc(std::max<size_t>(1, team2 ? teams_eg.size() : slabs_eg.size()) * Mp * Mp);
@@ -839,8 +843,10 @@ void smcpp_im::enqueue_stats() {
         } else
         hipLaunchKernelGGL(k_rank_acc<2>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
         if (!crit_main) {
+            // (round 5) the span-1 branch waits for this rank update only where its OWN rank update starts: its weights pass
+            // (k_s1_scalars, bound by memory round trips) runs beside the weights pass and the head of the rank update of this branch
             HIPCHK(hipEventRecord(ev[17], se));
-            HIPCHK(hipStreamWaitEvent(s, ev[17], 0));
+            wait17 = true;
         }
     }
     // ---- span-1 branch (main stream) ----
@@ -868,6 +874,7 @@ void smcpp_im::enqueue_stats() {
             HIPCHK(hipEventRecord(ev[16], s1s));
         } else if (split_streams) HIPCHK(hipEventRecord(ev[14], sp1));
     }
+    if (wait17) HIPCHK(hipStreamWaitEvent(sp1, ev[17], 0));
     if (kfuse) {
         d_part_1.alloc(std::max<size_t>(1, team3 ? teams_fk.size() : slabs_fk.size()) * Mp * Mp);
         d_gpart_fk.alloc(slabs_fk.size() * Mp);

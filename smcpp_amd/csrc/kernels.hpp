@@ -809,12 +809,17 @@ __global__ __launch_bounds__(256) void k_s1_scalars(S1Args a) {
             const double p = wave_sum_dpp(part);
             const double ip = 1.0 / p;
             if (!ok[u]) continue;                                   // wave-uniform
+            if (a.gamma_rows) {                                     // (save_gamma: the stored posterior keeps the division)
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) {
-                const double g = v[u][q] / p;
-                gs[q] += g;
-                const int i = lane + 64 * q;
-                if (a.gamma_rows && i < Mp) a.gamma_rows[row[u] * Mp + i] = g;
+                for (int q = 0; q < NPL; ++q) {
+                    const double g = v[u][q] / p;
+                    gs[q] += g;
+                    const int i = lane + 64 * q;
+                    if (i < Mp) a.gamma_rows[row[u] * Mp + i] = g;
+                }
+            } else if (!a.only_w1) {                                // (weights only: no gamma sums - the divisions were most of this kernel's instructions)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) gs[q] = fma(v[u][q], ip, gs[q]);
             }
             if (lane == 0) a.w1[row[u]] = ip / lc[u];
         }

@@ -1,7 +1,7 @@
 """More than 256 hidden states (round 5: 256 < M <= 512 on the scan chains with eight states per lane and the eigen-free statistics;
 the reference has no limit, src/inference_manager.cpp:21-54).
 
-  * M = 300 on 1 200 rows and M = 512 on 300 rows of the synthetic contig against the C restatement of hmm.cpp (oracle/) fed with the
+  * M = 300 on 1 200 rows and M = 512 on 160 rows of the synthetic contig against the C restatement of hmm.cpp (oracle/) fed with the
     engine's own prepared parameters, with chunks short enough that the chunk-parallel fixed point iterates (the restatement follows
     the reference's 2 M^3 flops per span > 1 row on one core: 2 000 rows at M = 512 would take minutes of the suite's time);
   * M = 512 on 1 000 rows against golden G21 = the COMPILED reference (tests/golden/make_golden_m512.py), through `im.model = ...`:
@@ -33,7 +33,7 @@ def _manager(M, n, obs, chunk=0):
     return im
 
 
-@pytest.mark.parametrize("M,rows,chunk", [(300, 1200, 300), (512, 300, 100)])
+@pytest.mark.parametrize("M,rows,chunk", [(300, 1200, 300), (512, 160, 60)])
 def test_more_than_256_states_vs_oracle(M, rows, chunk):
     from oracle import oracle
     from smcpp_amd import synth

@@ -337,7 +337,8 @@ struct DevPrep {
             hipLaunchKernelGGL(smcpp_dev::k_prep_csfs<S>, dim3(M, 1), dim3(nt), lds, s, pm, ps, po, tb);
         }
         HIPCHK(hipGetLastError());
-        if (!ev_done) HIPCHK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+        // (only ever waited for by the host before it rewrites the staging block: no data visibility hangs on it - no system-scope fence)
+        if (!ev_done) HIPCHK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming | hipEventDisableSystemFence));
         HIPCHK(hipEventRecord(ev_done, s));
         in_flight = true;
     }

@@ -47,6 +47,10 @@ struct SsArgs {
     float *ends_f, *used_f;
     double *ends_b, *used_b;
     int *changed_f, *changed_b;
+    // [pass]: some chunk of the direction REWROTE its end vector in the pass (ran to its end without merging, or a pass that stores
+    // everything).  A pass in which neither direction did leaves every chunk's input exactly what it last ran from, so the pass after
+    // it would skip every chunk: convergence is certified without launching that pass (round 5; engine_plans.hpp: run_chains_ss)
+    int *endchg_f, *endchg_b;
     float eps_f;
     double eps_b;
     int full_f, full_b;         // 1: every chunk of the direction runs whole from the previous pass's end vectors (no skip
@@ -876,7 +880,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
             const float an = live[k] ? fmaxf((float)(x[k] * inv), 1e-10f) : 0.f;
             if (stor[k]) { a.alpha[(size_t)(ch.base + ch.r1) * Mp + st[k]] = an; end_cur[st[k]] = an; }
         }
-        if (lane == 0) a.cnorm[ch.base + ch.r1] = S;
+        if (lane == 0) { a.cnorm[ch.base + ch.r1] = S; a.endchg_f[pass] = 1; }
     }
 }
 
@@ -1062,6 +1066,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
             const double bf = live[k] ? b[k] / S : 0.0;          // beta /= beta.sum()  (seeds gamma[:,0], hmm.cpp:150)
             if (stor[k]) { end_cur[st[k]] = bf; if (ch.first) a.beta[(size_t)ch.base * Mp + st[k]] = bf; }
         }
+        if (lane == 0) a.endchg_b[pass] = 1;
     }
 }
 
@@ -1327,7 +1332,7 @@ __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *
 #pragma unroll
         for (int k = 0; k < NPL; ++k) x[k] = live[k] ? src[st[k]] : 0.f;
     }
-    if (lane == 0) a.changed_f[pass] = 1;
+    if (lane == 0) { a.changed_f[pass] = 1; a.endchg_f[pass] = 1; }
     SsLightC<NPL> cst;
     ss_load_light<NPL, false>(a, lane, cst);
     const int2 *rd = a.rowdesc + ch.base + ch.r0 + 1;
@@ -1394,7 +1399,7 @@ __device__ __forceinline__ void ss_backward_light(const SsArgs &a, const double 
 #pragma unroll
         for (int k = 0; k < NPL; ++k) b[k] = live[k] ? (fresh ? 1.f / (float)M : (float)src[st[k]]) : 0.f;
     }
-    if (lane == 0) a.changed_b[pass] = 1;
+    if (lane == 0) { a.changed_b[pass] = 1; a.endchg_b[pass] = 1; }
     SsLightC<NPL> cst;
     ss_load_light<NPL, true>(a, lane, cst);
     const int2 *rd = a.rowdesc + ch.base + ch.r1;

@@ -563,9 +563,11 @@ void smcpp_im::ss_launch_initial() {
     a.ends_f = d_ends_f.p; a.used_f = d_used_f.p; a.ends_b = d_ends_b.p; a.used_b = d_used_b.p;
     {
         // the per-pass flags live in pinned host memory: written by the kernels through its device view, cleared and read by the host
-        if (h_flags_cap < 2 * (max_pass + 1)) {
+        // ([0, max_pass]: "a chunk of the forward chain re-ran", then the same of the backward chain, then the two "an end vector
+        // was rewritten" arrays of the scan chains)
+        if (h_flags_cap < 4 * (max_pass + 1)) {
             if (h_flags) (void)hipHostFree(h_flags);
-            h_flags_cap = 2 * (max_pass + 1);
+            h_flags_cap = 4 * (max_pass + 1);
             HIPCHK(hipHostMalloc((void **)&h_flags, sizeof(int) * h_flags_cap, hipHostMallocCoherent | hipHostMallocMapped));
             d_flags_view = nullptr;
         }
@@ -578,6 +580,7 @@ void smcpp_im::ss_launch_initial() {
         std::memset(h_flags, 0, sizeof(int) * h_flags_cap);
     }
     a.changed_f = d_flags_view; a.changed_b = d_flags_view + (max_pass + 1);
+    a.endchg_f = d_flags_view + 2 * (max_pass + 1); a.endchg_b = d_flags_view + 3 * (max_pass + 1);
     a.eps_f = eps_f; a.eps_b = eps_b; a.full_f = a.full_b = 0;
     {
         // All scans of the stored passes in float (chains_ss.hpp: ss_x_scan_fwd / ss_x_scan_bwd), the default since round 5 for one
@@ -626,7 +629,10 @@ void smcpp_im::ss_launch_initial() {
     HIPCHK(hipMemcpyAsync(d_pre, pre_stage.base, off, hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(ev[10], s));
     ss_launched = ss_pass0;
-    const int want = std::min(max_pass, ss_pass0 + (last_ss_passes > 0 ? last_ss_passes + 1 : 6));
+    // (round 5) the passes launched up front end with the pass that is expected to rewrite no end vector - the all-skip pass behind
+    // it (0.01 ms of kernel + its place in the queue) is not launched: run_chains_ss certifies from the end-vector flags
+    static const bool cert_launch = getenv("SMCPP_SS_CERT_PASS") && atoi(getenv("SMCPP_SS_CERT_PASS")) != 0;
+    const int want = std::min(max_pass, ss_pass0 + (last_ss_passes > 0 ? last_ss_passes + (cert_launch ? 1 : 0) : 6));
     ss_launch_passes(want);
     // (no event behind the passes here: run_chains_ss records ev[3] at this very position, and every record costs the queue ~3 us
     // in front of the statistics' critical branch - tools/sync_lab.hip)
@@ -682,6 +688,14 @@ void smcpp_im::run_chains_ss() {
         } else HIPCHK(hipStreamSynchronize(s));
         first_round = false;
         q = first_quiet(chf, chb, ss_launched);
+        if (q < 0 && ss_launched > p0) {
+            // no launched pass was quiet - but if the LAST one rewrote no end vector (every chunk that re-ran merged with its stored
+            // trajectory; a pass that stores everything always sets its flag), every chunk's input is what it last ran from and the
+            // next pass would skip them all: that pass is the quiet one, without having been launched
+            const int L = ss_launched - 1;
+            const int *ecf = h_flags + 2 * (max_pass + 1), *ecb = h_flags + 3 * (max_pass + 1);
+            if (ecf[L] == 0 && ecb[L] == 0 && ss_launched < max_pass) q = ss_launched;
+        }
         if (q >= 0 || ss_launched >= max_pass) break;
         stats_enqueued = false;
         done_covers_stats = false;

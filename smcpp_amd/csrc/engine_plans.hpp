@@ -632,7 +632,10 @@ void smcpp_im::ss_launch_initial() {
     // (round 5) the passes launched up front end with the pass that is expected to rewrite no end vector - the all-skip pass behind
     // it (0.01 ms of kernel + its place in the queue) is not launched: run_chains_ss certifies from the end-vector flags
     static const bool cert_launch = getenv("SMCPP_SS_CERT_PASS") && atoi(getenv("SMCPP_SS_CERT_PASS")) != 0;
-    const int want = std::min(max_pass, ss_pass0 + (last_ss_passes > 0 ? last_ss_passes + (cert_launch ? 1 : 0) : 6));
+    // (never fewer than one re-run pass behind the pass that stores everything - that one always rewrites its end vectors: with one
+    // chunk per contig, or boundaries that were already exact, the quiet pass IS that re-run pass)
+    const int want = std::min(max_pass, std::max(ss_pass0 + (last_ss_passes > 0 ? last_ss_passes + (cert_launch ? 1 : 0) : 6),
+                                                 std::max(ss_light_f, ss_light_b) + 2));
     ss_launch_passes(want);
     // (no event behind the passes here: run_chains_ss records ev[3] at this very position, and every record costs the queue ~3 us
     // in front of the statistics' critical branch - tools/sync_lab.hip)
@@ -694,7 +697,7 @@ void smcpp_im::run_chains_ss() {
             // next pass would skip them all: that pass is the quiet one, without having been launched
             const int L = ss_launched - 1;
             const int *ecf = h_flags + 2 * (max_pass + 1), *ecb = h_flags + 3 * (max_pass + 1);
-            if (ecf[L] == 0 && ecb[L] == 0 && ss_launched < max_pass) q = ss_launched;
+            if (ecf[L] == 0 && ecb[L] == 0) q = ss_launched;
         }
         if (q >= 0 || ss_launched >= max_pass) break;
         stats_enqueued = false;

@@ -126,6 +126,7 @@ struct smcpp_im {
     int ss_wpc = 1;                        // scan chains: wavefronts per SIMD (workgroups per CU) the chunk list is cut for
     int ss_wg_waves = 4;                   // wavefronts per workgroup of k_chain_ss (hybrid with two per SIMD: 8, one table copy)
     int ss_launched = 0, last_ss_passes = 0;
+    bool ss_need_cert_pass = false;     // this input's last working pass rewrites end vectors within tolerance: launch the all-skip pass up front
     long long ss_positions = 0;            // sum of spans
     int ss_light_f = 0, ss_light_b = 0;    // light (float, store-free) passes per direction before the full fp64 pass
     // opt-in warm start of the scan chains (smcpp_set_warm_start): the first pass of an E-step starts every chunk from the boundary

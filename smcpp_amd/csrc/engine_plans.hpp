@@ -634,7 +634,7 @@ void smcpp_im::ss_launch_initial() {
     static const bool cert_launch = getenv("SMCPP_SS_CERT_PASS") && atoi(getenv("SMCPP_SS_CERT_PASS")) != 0;
     // (never fewer than one re-run pass behind the pass that stores everything - that one always rewrites its end vectors: with one
     // chunk per contig, or boundaries that were already exact, the quiet pass IS that re-run pass)
-    const int want = std::min(max_pass, std::max(ss_pass0 + (last_ss_passes > 0 ? last_ss_passes + (cert_launch ? 1 : 0) : 6),
+    const int want = std::min(max_pass, std::max(ss_pass0 + (last_ss_passes > 0 ? last_ss_passes + (cert_launch || ss_need_cert_pass ? 1 : 0) : 6),
                                                  std::max(ss_light_f, ss_light_b) + 2));
     ss_launch_passes(want);
     // (no event behind the passes here: run_chains_ss records ev[3] at this very position, and every record costs the queue ~3 us
@@ -670,7 +670,7 @@ void smcpp_im::run_chains_ss() {
     };
     ss_warm_valid = false;
     bool first_round = true;
-    int q = -1;
+    int q = -1, first_launched = -1;      // (first_launched: passes launched when the first round failed to certify, -1: it did)
     static const bool poll = !(getenv("SMCPP_POLL") && atoi(getenv("SMCPP_POLL")) == 0);
     while (true) {
         HIPCHK(hipEventRecord(ev[3], s));
@@ -702,6 +702,7 @@ void smcpp_im::run_chains_ss() {
         if (q >= 0 || ss_launched >= max_pass) break;
         stats_enqueued = false;
         done_covers_stats = false;
+        if (first_launched < 0) first_launched = ss_launched;
         ss_launch_passes(std::min(max_pass, ss_launched + 3));
     }
     chains_dual = false;
@@ -712,6 +713,9 @@ void smcpp_im::run_chains_ss() {
                 "clocks, %lld x 10 ns, %lld positions, %lld rows\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     }
     if (q < 0) { stats_enqueued = false; throw std::runtime_error("chunk-boundary iteration did not converge"); }
+    // the flags of the first round did not certify, yet the very next pass was quiet: on this input the last working pass rewrites
+    // end vectors WITHIN the tolerance - from now on the all-skip pass is launched up front again (one round instead of two)
+    if (first_launched >= 0 && q == first_launched) ss_need_cert_pass = true;
     last_ss_passes = q - p0;
     last_fwd_passes = last_bwd_passes = q - p0;
     // every launched pass carried the end vectors forward (a skipped chunk copies them): they sit at the last pass's parity

@@ -177,6 +177,12 @@ int smcpp_last_timing(smcpp_im *im, double out[9]);
  * this is the engine's own decomposition, exported for the CPU tests). */
 int smcpp_host_chunk_counts(int n_contigs, const long long *cost, const int *rows, long long nslots, long long floor_cost, int *out);
 int smcpp_chain_mode(smcpp_im *im);
+/* Every SMCPP_* environment switch of the engine is parsed ONCE per process (smcpp_amd/csrc/engine_options.hpp holds the one
+ * table of them); smcpp_reload_options re-reads the environment (tests; never while an E-step runs).  smcpp_describe writes one
+ * JSON object - the switches that are set and the plan `im` resolved (chain family, chunk counts, history passes, whether the
+ * stored passes of the last E-step ran their scans in float) - and returns the length it needs; `im` may be NULL. */
+void smcpp_reload_options(void);
+int smcpp_describe(smcpp_im *im, char *buf, int cap);
 /* Test hook of family 5: one position of both scan chains on nvec vectors: out_f = e o (T^T x), out_b = T (e o x); T is
  * [M][M] row-major, x / e / out_* are [nvec][M].  Returns 2 when T has no semiseparable structure (nothing is written). */
 int smcpp_debug_ss_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b);

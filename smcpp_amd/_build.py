@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import os
 import subprocess
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -49,14 +50,15 @@ def _gmp():
     raise RuntimeError("libgmp not found")
 
 
-LAST_ACTION = None       # "compiled" / "reused": what the last build() call did (printed, and read by __graft_entry__.build)
+LAST_ACTION = None       # "compiled" / "reused": what the last build() call did
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     global LAST_ACTION
     if not force and not _stale():
         LAST_ACTION = "reused"
-        print(f"smcpp_amd._build: reused {os.path.relpath(LIB)} (newer than every source under csrc/ and include/)", flush=True)
+        if verbose:
+            print(f"smcpp_amd._build: reused {os.path.relpath(LIB)} (newer than every source under csrc/ and include/)", file=sys.stderr, flush=True)
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     gmp_inc, gmp_lib = _gmp()
@@ -69,7 +71,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     t0 = time.time()
     subprocess.check_call(cmd)
     LAST_ACTION = "compiled"
-    print(f"smcpp_amd._build: compiled {os.path.relpath(LIB)} with hipcc --offload-arch=gfx950 in {time.time() - t0:.0f} s", flush=True)
+    # (stderr: drivers that import the package print machine-readable lines on stdout; LAST_ACTION carries the same information)
+    print(f"smcpp_amd._build: compiled {os.path.relpath(LIB)} with hipcc --offload-arch=gfx950 in {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
     return LIB
 
 

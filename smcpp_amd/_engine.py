@@ -67,6 +67,7 @@ def lib():
         "smcpp_set_chunking": (i, [vp, i, d, d]), "smcpp_set_warm_start": (i, [vp, i]), "smcpp_set_prep_mode": (i, [vp, i]),
         "smcpp_last_timing": (i, [vp, _dp]), "smcpp_last_host_timing": (i, [vp, _dp]), "smcpp_stream": (vp, [vp]), "smcpp_chain_mode": (i, [vp]),
         "smcpp_set_num_threads": (None, [i]),
+        "smcpp_reload_options": (None, []), "smcpp_describe": (i, [vp, C.c_char_p, i]),
         "smcpp_set_debug": (i, [vp, i]), "smcpp_get_debug": (i, [vp]), "smcpp_device": (i, [vp]),
         "smcpp_debug_ss_apply": (i, [i, _dp, i, _dp, _dp, _dp, _dp]),
         "smcpp_debug_ss_apply_float_scans": (i, [i, _dp, i, _dp, _dp, _dp, _dp]),
@@ -114,7 +115,7 @@ EXPORTS = [
     "smcpp_host_set_csfs_direct", "smcpp_gamma_cols", "smcpp_last_host_timing", "smcpp_get_pi_jac",
     "smcpp_get_transition_jac", "smcpp_get_emission_probs_jac", "smcpp_num_emission_cols", "smcpp_get_emission",
     "smcpp_init_logger_cb", "smcpp_init_cache", "smcpp_debug_ss_apply", "smcpp_debug_ss_apply_float_scans", "smcpp_set_debug", "smcpp_get_debug", "smcpp_device",
-    "smcpp_dev_prep_onepop", "smcpp_set_prep_mode", "smcpp_dev_q_emulate",
+    "smcpp_dev_prep_onepop", "smcpp_set_prep_mode", "smcpp_dev_q_emulate", "smcpp_reload_options", "smcpp_describe",
 ]
 
 
@@ -337,3 +338,24 @@ def host_prep_twopop(n1, n2, a1, a2, hs, pol, dist, model1, model2, split, theta
                                        C.c_double(theta), C.c_double(rho), C.c_double(alpha), len(keys), iptr(keys),
                                        dptr(pi), dptr(T), dptr(E)))
     return pi, T, E
+
+
+def set_option(name: str, value=None):
+    """Set (or, `value=None`, remove) one SMCPP_* switch in the environment and make the engine re-read its option table
+    (the engine parses the environment once per process: smcpp_amd/csrc/engine_options.hpp).  Affects managers built and
+    E-steps run afterwards."""
+    import os
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    lib().smcpp_reload_options()
+
+
+def describe(im=None) -> dict:
+    """The engine's switches and - for a manager handle - the plan it resolved (smcpp_describe)."""
+    import json
+    n = lib().smcpp_describe(im, None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib().smcpp_describe(im, buf, n + 1)
+    return json.loads(buf.value.decode())

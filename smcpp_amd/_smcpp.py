@@ -252,6 +252,11 @@ class _PyInferenceManager:
         5 scans over the semiseparable structure of the transition matrix (the other families are its fallback)."""
         return int(E.lib().smcpp_chain_mode(self._im))
 
+    def describe(self):
+        """The engine's environment switches and the plan this manager resolved (chain family, chunks, history passes, whether the
+        stored passes of the last E-step ran their scans in float): `smcpp_describe`."""
+        return E.describe(self._im)
+
     def last_timing(self):
         t = np.zeros(9)
         E.check(E.lib().smcpp_last_timing(self._im, E.dptr(t)))

@@ -92,34 +92,41 @@ def _init_cache():
     smcpp_init_cache(os.path.join(d, "matrices.dat").encode("UTF-8"))
 
 
+# Engine messages -> Python `logging`.  Contract kept from the reference (_smcpp.pyx:32-55, _smcpp.pxd:26): the native side may
+# fire the callback from any host thread; records appear under the logger namespace the reference's users configure; a Ctrl-C that
+# lands inside the callback must not unwind through C++ frames, so it is parked in the module flag `abort` and re-raised by
+# `_check_abort()`, which every heavy call runs once it has returned.
 abort = False
-_lvl = {s: getattr(logging, s) for s in "info debug critical warning error".upper().split()}
-_lvl['DEBUG1'] = logging.DEBUG - 1
-_lvl['DEBUG'] = logging.DEBUG
+_LOG_NAMESPACE = "smcpp._smcpp"
+_LEVELS_BELOW_DEBUG = {"DEBUG1": logging.DEBUG - 1}
 
 
-cdef void logger_cb(const char *name, const char *level, const char *message) noexcept with gil:
+def _level_number(text):
+    text = text.upper()
+    if text in _LEVELS_BELOW_DEBUG:
+        return _LEVELS_BELOW_DEBUG[text]
+    number = logging.getLevelName(text)          # the registered number of a level name (a string back for an unknown one)
+    return number if isinstance(number, int) else logging.INFO
+
+
+cdef void _forward_log(const char *name, const char *level, const char *message) noexcept with gil:
     global abort
-    name_s = "smcpp._smcpp:" + name.decode("UTF-8")
-    level_s = level.decode("UTF-8")
-    message_s = message.decode("UTF-8")
+    target = logging.getLogger("%s:%s" % (_LOG_NAMESPACE, name.decode("utf-8", "replace")))
     try:
-        logging.getLogger(name_s).log(_lvl[level_s.upper()], message_s)
+        target.log(_level_number(level.decode("utf-8", "replace")), "%s", message.decode("utf-8", "replace"))
     except KeyboardInterrupt:
-        logging.getLogger(name_s).critical("Aborting")
         abort = True
+        target.critical("Aborting")
 
 
 def _check_abort():
     global abort
-    try:
-        if abort:
-            raise KeyboardInterrupt()
-    finally:
-        abort = False
+    pending, abort = abort, False
+    if pending:
+        raise KeyboardInterrupt()
 
 
-smcpp_init_logger_cb(logger_cb)
+smcpp_init_logger_cb(_forward_log)
 
 
 def set_num_threads(k):

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/smcpp_engine.h"
+#include "engine_options.hpp"   // every SMCPP_* environment switch, parsed once (the only getenv of the engine)
 #include "kernels.hpp"
 #include "chains2.hpp"
 #include "chains_lock.hpp"

@@ -22,7 +22,7 @@ static void log_msg(const char *level, const char *fmt, ...) {
 struct HostTrace {
     bool on;
     std::chrono::steady_clock::time_point t;
-    HostTrace() { static const bool e = getenv("SMCPP_HOST_TRACE") && atoi(getenv("SMCPP_HOST_TRACE")) > 0; on = e; if (on) t = std::chrono::steady_clock::now(); }
+    HostTrace() { on = opt().i(smcpp_opt::O_HOST_TRACE, 0) > 0; if (on) t = std::chrono::steady_clock::now(); }
     void mark(const char *what) {
         if (!on) return;
         const auto n = std::chrono::steady_clock::now();
@@ -37,8 +37,7 @@ extern "C" void kmp_set_blocktime(int) __attribute__((weak));
 namespace {
 struct OmpInit {
     OmpInit() {
-        const char *e = getenv("SMCPP_OMP_BLOCKTIME");
-        if (kmp_set_blocktime) kmp_set_blocktime(e ? atoi(e) : 0);
+        if (kmp_set_blocktime) kmp_set_blocktime(opt().i(smcpp_opt::O_OMP_BLOCKTIME, 0));
     }
 } g_omp_init;
 }

@@ -396,14 +396,13 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(hipStreamCreateWithPriority(&stream_hi, hipStreamNonBlocking, greatest));
     }
-    if (const char *d = getenv("SMCPP_DUAL_STREAM")) dual_stream = atoi(d);
+    if (opt().has(smcpp_opt::O_DUAL_STREAM)) dual_stream = opt().i(smcpp_opt::O_DUAL_STREAM, 1);
     {
         // The events order streams of this device and bracket intervals; nothing the host reads depends on a system-scope fence at
         // an event (results reach it through stream-ordered copies and the pinned completion word of k_signal / k_fin_both).  A
         // default event makes every record a cache writeback + invalidation (hip_runtime_api.h: hipEventDisableSystemFence); an E-step
         // records about ten: headline 1 068 -> 1 082 evals/s, M = 256 2.79 -> 2.74 ms without it.  SMCPP_EVENT_FLAGS=0: default events.
-        static const unsigned evf = getenv("SMCPP_EVENT_FLAGS") ? (unsigned)strtoul(getenv("SMCPP_EVENT_FLAGS"), nullptr, 0)
-                                                                 : (unsigned)hipEventDisableSystemFence;
+        const unsigned evf = (unsigned)opt().ll(smcpp_opt::O_EVENT_FLAGS, (long long)hipEventDisableSystemFence);
         for (auto &e : ev) HIPCHK(hipEventCreateWithFlags(&e, evf));
     }
     make_chunks();
@@ -418,7 +417,7 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
 // rows per (CU x 16) from which the lock-step chains win (tools/lock_crossover.py on the whole-genome generator: M = 64 and 48
 // from ~400, M = 32 from ~700; at M = 16 the cooperative kernels are never slower)
 static long long lock_min_rows(int Mp) {
-    static const long long v = getenv("SMCPP_LOCK_MIN_ROWS") ? atoll(getenv("SMCPP_LOCK_MIN_ROWS")) : -1;
+    const long long v = opt().ll(smcpp_opt::O_LOCK_MIN_ROWS, -1);
     if (v >= 0) return v;
     return Mp >= 48 ? 450 : Mp >= 32 ? 800 : (1ll << 40);
 }
@@ -461,7 +460,7 @@ void smcpp_im::make_chunks() {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     {
         // SMCPP_CHAIN = lock: the lock-step kernels forced (M <= 64); = dense: the cooperative kernels; ss (or unset): see below
-        const char *m = getenv("SMCPP_CHAIN");
+        const char *m = opt().has(smcpp_opt::O_CHAIN) ? opt().str(smcpp_opt::O_CHAIN).c_str() : nullptr;
         if (m) chain_mode = (!strcmp(m, "lock") && Mp <= 64) ? 4 : 2;
         // lock-step chains on the matrix cores (chains_lock.hpp): 16 chunks per workgroup, so 16 x more and 16 x shorter
         // chunks - they pay off when those are still long against the ~900 rows of history every chunk re-runs
@@ -483,29 +482,29 @@ void smcpp_im::make_chunks() {
         ss_max_span = 1;
         for (const Group &g : groups) ss_max_span = std::max(ss_max_span, g.span);
         {
-            const char *se = getenv("SMCPP_SS");
-            const bool ss_ok = !(se && atoi(se) == 0) && (!m || !strcmp(m, "ss")) && Mp <= 512;
+            const bool ss_ok = !opt().off(smcpp_opt::O_SS) && (!m || !strcmp(m, "ss")) && Mp <= 512;
             ss_static = ss_ok && ss_max_span <= 512;
             ss_hybrid = false; ss_hyb_th = 0x7fffffff;
             if (ss_ok && !ss_static) {
                 // longer spans: the hybrid form, when one state per lane holds the vector and the eigenvector tables of every eigen
                 // key fit LDS beside the emission vectors (SMCPP_HYBRID=0: the dense kernels)
-                const char *hy = getenv("SMCPP_HYBRID");
+                const bool hy_off = opt().off(smcpp_opt::O_HYBRID);
+                const int hyb_th_opt = std::max(1, opt().i(smcpp_opt::O_HYB_TH, 6));
                 const size_t tab = (size_t)Ke * 4 * Mp * (Mp + 1) * sizeof(double);
                 ss_dirsplit = false;
-                if (!(hy && atoi(hy) == 0) && Mp <= 64 && Ke >= 1 && Ke <= 4 && tab <= 120 * 1024) {
+                if (!hy_off && Mp <= 64 && Ke >= 1 && Ke <= 4 && tab <= 120 * 1024) {
                     ss_static = ss_hybrid = true;
-                    ss_hyb_th = getenv("SMCPP_HYB_TH") ? std::max(1, atoi(getenv("SMCPP_HYB_TH"))) : 6;
-                } else if (!(hy && atoi(hy) == 0) && Mp <= 64 && Ke >= 1 && Ke <= 4 && tab / 2 <= 136 * 1024) {
+                    ss_hyb_th = hyb_th_opt;
+                } else if (!hy_off && Mp <= 64 && Ke >= 1 && Ke <= 4 && tab / 2 <= 136 * 1024) {
                     // (round 4) M > 32: four 33 KB tables per eigen key do not fit, the two a DIRECTION needs do - every workgroup
                     // runs one direction (the task table keeps them apart) and stages that direction's pair
                     ss_static = ss_hybrid = ss_dirsplit = true;
-                    ss_hyb_th = getenv("SMCPP_HYB_TH") ? std::max(1, atoi(getenv("SMCPP_HYB_TH"))) : 6;
-                } else if (!(hy && atoi(hy) == 0) && Mp > 32 && Mp <= 64 && Ke >= 1 && Ke <= 4 && tab / 2 / Ke <= 136 * 1024) {
+                    ss_hyb_th = hyb_th_opt;
+                } else if (!hy_off && Mp > 32 && Mp <= 64 && Ke >= 1 && Ke <= 4 && tab / 2 / Ke <= 136 * 1024) {
                     // (round 5) ... and with three or four eigen keys at M > 32 not even those: the most frequent keys keep their pair
                     // in LDS, a COLD key's table rows are read from L2 on the rows that need them (chains_ss.hpp: ss_eig_matvec_cold)
                     ss_static = ss_hybrid = ss_dirsplit = true;
-                    ss_hyb_th = getenv("SMCPP_HYB_TH") ? std::max(1, atoi(getenv("SMCPP_HYB_TH"))) : 6;
+                    ss_hyb_th = hyb_th_opt;
                 }
                 ss_nk_lds = Ke;
                 for (int e = 0; e < 4; ++e) ss_ekey_of_slot[e] = ss_eslot_of_key[e] = e;
@@ -524,8 +523,7 @@ void smcpp_im::make_chunks() {
             }
             if (ss_static) chain_mode = Mp > 64 ? 3 : 2;
         }
-        const char *b = getenv("SMCPP_COOP_BPC");
-        if (b && atoi(b) > 0) coop_bpc = atoi(b);
+        if (opt().i(smcpp_opt::O_COOP_BPC, 0) > 0) coop_bpc = opt().i(smcpp_opt::O_COOP_BPC, 0);
         else {
             // More workgroups per CU hide the per-row latency of the cooperative kernels (measured on 6.8 M rows:
             // throughput x1.27 / x1.36 / x1.42 for 2 / 3 / 4 per CU) but shorten the chunks, and every chunk pays
@@ -537,7 +535,7 @@ void smcpp_im::make_chunks() {
     // chunks in flight: one per SIMD for the per-wavefront kernels, coop_bpc per CU for the cooperative ones
     long long slots = (long long)prop.multiProcessorCount *
                       (chain_mode == 4 ? LOCK_NC : chain_mode == 3 ? 1 : coop_bpc);
-    if (ss_static && user_rows_per_chunk <= 0 && !getenv("SMCPP_ROWS_PER_CHUNK")) {
+    if (ss_static && user_rows_per_chunk <= 0 && !opt().has(smcpp_opt::O_ROWS_PER_CHUNK)) {
         // scan chains: one wavefront per chunk and direction, a workgroup = 2 forward + 2 backward chunks = one wavefront per
         // SIMD; chunks are cut by POSITIONS (sum of spans), the unit of work of these kernels.  Every chunk pays the same
         // ~3000 positions of re-run history however short it is (the chains forget with an e-fold of ~240 positions).
@@ -553,12 +551,12 @@ void smcpp_im::make_chunks() {
         // of re-run history, so only inputs whose chunks stay long (>= 9 000 positions) take them.  Whole genome (28.7 M
         // positions): 9.3 / 8.2 / 7.9 ms of chains with 1 / 2 / 3; a 3.4 M-position shard: 1.83 / 1.95 ms with 1 / 2.
         const long long simds = (long long)prop.multiProcessorCount * 4;
-        ss_wpc = getenv("SMCPP_SS_WPC") ? std::max(1, std::min(4, atoi(getenv("SMCPP_SS_WPC"))))
-                                        : (int)std::max<long long>(1, std::min<long long>(3, total_bins / (simds * 9000)));
+        ss_wpc = opt().has(smcpp_opt::O_SS_WPC) ? std::max(1, std::min(4, opt().i(smcpp_opt::O_SS_WPC, 1)))
+                                                : (int)std::max<long long>(1, std::min<long long>(3, total_bins / (simds * 9000)));
         // hybrid rows are bound by instruction and LDS LATENCY (a dependent chain of ~200 instructions per row): a second wavefront
         // per SIMD fills the gaps from ~2 000 cost units per chunk on (posterior workload: 1.79 -> 1.35 ms of chains; a third one
         // needs an extra pass: 1.80); the eight wavefronts form ONE workgroup so that the CU holds one copy of the tables
-        if (ss_hybrid && !getenv("SMCPP_SS_WPC")) ss_wpc = (int)std::max<long long>(1, std::min<long long>(2, total_bins / (simds * 2000)));
+        if (ss_hybrid && !opt().has(smcpp_opt::O_SS_WPC)) ss_wpc = (int)std::max<long long>(1, std::min<long long>(2, total_bins / (simds * 2000)));
         if (ss_hybrid) ss_wpc = std::min(ss_wpc, 2);
         ss_wg_waves = (ss_hybrid && ss_wpc == 2) ? 8 : 4;
         const long long waves = simds * ss_wpc;
@@ -625,10 +623,9 @@ void smcpp_im::make_chunks() {
         // history the two light passes walk - so it only trades the merge re-run against chunks of unequal length: 0.92 ms against
         // 0.87; with several states per lane (M > 64), where a light position costs relatively more, it wins (c5: 1.45 against 1.64 ms).
         // Default: M > 64 only; SMCPP_SS_HALO = 1 / 0 forces it.
-        ss_halo = !ss_hybrid && (getenv("SMCPP_SS_HALO") ? atoi(getenv("SMCPP_SS_HALO")) != 0 : NPL >= 2);
-        auto env_ll = [](const char *nm, long long dflt) { const char *e = getenv(nm); return e ? atoll(e) : dflt; };
-        const long long hlf = ss_halo ? env_ll("SMCPP_HALO_LF", 2800) : 0, hdf = ss_halo ? env_ll("SMCPP_HALO_DF", 800) : 0,
-                        hlb = ss_halo ? env_ll("SMCPP_HALO_LB", 3900) : 0, hdb = ss_halo ? env_ll("SMCPP_HALO_DB", 1100) : 0;
+        ss_halo = !ss_hybrid && (opt().has(smcpp_opt::O_SS_HALO) ? opt().i(smcpp_opt::O_SS_HALO, 0) != 0 : NPL >= 2);
+        const long long hlf = ss_halo ? opt().ll(smcpp_opt::O_HALO_LF, 2800) : 0, hdf = ss_halo ? opt().ll(smcpp_opt::O_HALO_DF, 800) : 0,
+                        hlb = ss_halo ? opt().ll(smcpp_opt::O_HALO_LB, 3900) : 0, hdb = ss_halo ? opt().ll(smcpp_opt::O_HALO_DB, 1100) : 0;
         {
             // the forward chain gets SMCPP_SS_FWD_SHARE of the wavefronts.  Default one half: the backward chain's light position
             // costs 38 instructions against 25, but the fp64 passes of the two directions take the same time (forward: stores, the
@@ -647,7 +644,7 @@ void smcpp_im::make_chunks() {
                 }
                 dflt_share = std::min(0.5, std::max(0.25, 0.5 * (lo + hi)));
             }
-            const double share = getenv("SMCPP_SS_FWD_SHARE") ? atof(getenv("SMCPP_SS_FWD_SHARE")) : dflt_share;
+            const double share = opt().d(smcpp_opt::O_SS_FWD_SHARE, dflt_share);
             const long long nf = std::max<long long>(1, (long long)(share * (double)waves + 0.5));
             cut(nf, 1024, chunks, false, hlf, hdf);
             cut(std::max<long long>(1, waves - nf), 1024, chunks_b, true, hlb, hdb);
@@ -658,8 +655,7 @@ void smcpp_im::make_chunks() {
     long long rows = total_rows - n_contigs;
     int lc = user_rows_per_chunk;
     if (lc <= 0) {
-        const char *envv = getenv("SMCPP_ROWS_PER_CHUNK");
-        if (envv) lc = atoi(envv);
+        lc = opt().i(smcpp_opt::O_ROWS_PER_CHUNK, lc);
     }
     // every chunk pays ~1000 rows of re-run history however short it is, so small inputs get few, long chunks rather
     // than one sliver per CU (a 1 500-row contig: 3 chunks and 4 passes instead of 24 chunks and 15 passes)
@@ -741,10 +737,7 @@ void smcpp_im::update_pi_default() {
     for (double &v : pi_default) v /= sm;
 }
 
-static bool stats_team_on() {          // (read per call: a manager built after the switch changed follows it)
-    const char *e = getenv("SMCPP_STATS_TEAM");
-    return !(e && atoi(e) == 0);
-}
+static bool stats_team_on() { return !opt().off(smcpp_opt::O_STATS_TEAM); }
 
 void smcpp_im::make_slabs() {
     // counting sorts of rows per contig
@@ -769,7 +762,7 @@ void smcpp_im::make_slabs() {
     // (at least SMCPP_SLAB_ROWS rows per slab, default 128: every slab costs an Mp x Mp partial written and read back - 128 MB of
     // traffic per headline E-step with 64-row slabs -, but a slab is walked by ONE wavefront, and below ~1000 slabs the rank
     // kernels leave SIMDs idle: 64 .. 192 rows measured: 633 / 641 / 666 / 665 headline evals per second)
-    static const int slab_rows = getenv("SMCPP_SLAB_ROWS") ? std::max(16, atoi(getenv("SMCPP_SLAB_ROWS"))) : 128;
+    const int slab_rows = opt().has(smcpp_opt::O_SLAB_ROWS) ? std::max(16, opt().i(smcpp_opt::O_SLAB_ROWS, 128)) : 128;
     int S_RK = (int)std::max<long long>(slab_rows, (n1 + target - 1) / target);
     S_RK = (S_RK + 3) / 4 * 4;
     int S_EG = (int)std::max<long long>(slab_rows, (ne + target - 1) / target);
@@ -891,7 +884,7 @@ void smcpp_im::setup_power() {
     for (int g = 0; g < G; ++g) mx = std::max(mx, groups[g].span);
     int longest = 0;
     for (const Chunk &ch : chunks) longest = std::max(longest, ch.r1 - ch.r0);
-    const char *pe = getenv("SMCPP_POWER_PREPASS");
+    const char *pe = opt().has(smcpp_opt::O_POWER_PREPASS) ? opt().str(smcpp_opt::O_POWER_PREPASS).c_str() : nullptr;
     // spans below 32 (binned data: four squarings give every power); chunks short enough that pass 1 re-runs them whole
     // anyway (the rows of the pre-pass are all overwritten: it runs in float and its normalisers carry no eigenvalue scale)
     const bool coop_pre = chain_mode == 2 && Mp <= 64;

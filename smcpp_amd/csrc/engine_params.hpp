@@ -42,12 +42,12 @@ void smcpp_im::prepare_params() {
             // profiles/r05_*).  One millisecond is bistable, though - an eval of C4 takes 1.2 - 1.3 ms, and once one eval is late the workers
             // are asleep at every following region (runs at 680 - 720 evals/s next to runs at 800 - 830): TWO milliseconds (6 runs of 6
             // at 800 - 825).  SMCPP_OMP_BLOCKTIME overrides.
-            if (kmp_set_blocktime && !getenv("SMCPP_OMP_BLOCKTIME")) kmp_set_blocktime(2);
+            if (kmp_set_blocktime && !opt().has(smcpp_opt::O_OMP_BLOCKTIME)) kmp_set_blocktime(2);
         }
         smcpp_host::TwoPopPrep &prep = *twopop_prep;
         {
             // the batched conditioned SFS on the device (values; SMCPP_PREP=host / smcpp_set_prep_mode(1): everything on the host)
-            static const bool host_only2 = getenv("SMCPP_PREP") && !strcmp(getenv("SMCPP_PREP"), "host");
+            const bool host_only2 = opt().is(smcpp_opt::O_PREP, "host");
             if (!twopop_dev) { twopop_dev.reset(new TwoPopDevCsfs()); twopop_dev->device = device; twopop_dev->stream = stream; }
             prep.batch_dev = (host_only2 || force_host_prep || nder > 0) ? nullptr : twopop_dev.get();
         }
@@ -94,7 +94,7 @@ void smcpp_im::prepare_params() {
     smcpp_host::OnePopPrep &prep = *prep1;
     {
         // conditioned SFS + emission table on the device (SMCPP_PREP=host: the host routines, as in rounds 1-3)
-        static const bool host_only = getenv("SMCPP_PREP") && !strcmp(getenv("SMCPP_PREP"), "host");
+        const bool host_only = opt().is(smcpp_opt::O_PREP, "host");
         if (!host_only && !force_host_prep && DevPrep::supported(n[0], (int)model.a.size() + (int)hs.size()) && !smcpp_host::csfs_direct_flag()) { dev_prepare(); return; }
     }
     E_on_dev = false;
@@ -240,7 +240,7 @@ void smcpp_im::ensure_dT() {
 // the transition matrix.  Returns false when this call has to take the host route (no device preparation, a local / global
 // key-list mismatch, the pairwise fallback of the transition matrix).
 bool smcpp_im::q_device(double val[4], double *jac) {
-    static const bool off = getenv("SMCPP_Q") && !strcmp(getenv("SMCPP_Q"), "host");
+    const bool off = opt().is(smcpp_opt::O_Q, "host");
     if (off || !E_on_dev || !tgen_valid || have_raw || (have_global && !have_reduced)) return false;
     if (have_reduced && (int)g_stats.size() != 1 + M + M * M + dprep->Kk * M) return false;
     HIPCHK(hipSetDevice(device));
@@ -359,7 +359,7 @@ void smcpp_im::global_emissions() {
 
 void smcpp_im::host_prep_and_upload() {
     hipStream_t s = stream;
-    const bool tm = getenv("SMCPP_HOST_TIMING") != nullptr;
+    const bool tm = opt().has(smcpp_opt::O_HOST_TIMING);
     auto tp0 = std::chrono::steady_clock::now();
     const size_t MM = (size_t)Mp * Mp;
     const size_t em = std::max<size_t>(1, (size_t)Ke) * MM;
@@ -440,7 +440,7 @@ void smcpp_im::host_prep_and_upload() {
     static std::vector<std::vector<int>> l3;
     static std::once_flag l3_once;
     int team = (M >= 128 && Ke >= 1) ? std::min(8, omp_get_max_threads() / Ke) : 1;
-    if (const char *te = getenv("SMCPP_EIG_TEAM")) team = std::max(1, std::min(16, atoi(te)));
+    if (opt().has(smcpp_opt::O_EIG_TEAM)) team = std::max(1, std::min(16, opt().i(smcpp_opt::O_EIG_TEAM, 1)));
     if (M < 32) team = 1;
     if (team >= 2) {
         std::call_once(l3_once, [] { l3 = smcpp_host::cpu_l3_groups(); });     // a few hundred sysfs reads, once per process
@@ -471,7 +471,7 @@ void smcpp_im::host_prep_and_upload() {
             for (size_t g = 0; g < l3.size(); ++g)
                 for (int c : l3[g]) if (c == here) g0 = (int)g;
         }
-        static const bool pin = !(getenv("SMCPP_EIG_PIN") && atoi(getenv("SMCPP_EIG_PIN")) == 0);
+        const bool pin = !opt().off(smcpp_opt::O_EIG_PIN);
 #pragma omp parallel num_threads(Ke * team)
         {
             if (omp_get_num_threads() != Ke * team) {

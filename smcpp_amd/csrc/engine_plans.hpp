@@ -129,7 +129,7 @@ ChainArgs smcpp_im::chain_args() {
     a.dbg = nullptr;
     a.warm_f = nullptr; a.warm_b = nullptr;
     a.Bf = d_Bf.p; a.Bb = d_Bb.p; a.g_span = d_g_span.p; a.nbits = pw_nbits; a.npow = pw_npow;
-    { static const int pr = getenv("SMCPP_BWD_PRIO") ? std::max(0, std::min(3, atoi(getenv("SMCPP_BWD_PRIO")))) : 1; a.prio = pr; }
+    a.prio = std::max(0, std::min(3, opt().i(smcpp_opt::O_BWD_PRIO, 1)));
     a.changed = nullptr;
     return a;
 }
@@ -141,7 +141,7 @@ static void coop_lds(int Mp, int K, int G, int &tab_c, size_t &shm_c) {
     const size_t base_c = (size_t)(4 * UP + 8 * UP) * 8 + 2 * Mp * 4 + 1024 + 64;
     const size_t tabs = ((size_t)K * 4 * UP + (size_t)G * Mp) * 8;      // backward layout of generation 1 is the larger one
     tab_c = (base_c + tabs <= 64 * 1024) ? 1 : 0;
-    if (const char *tv = getenv("SMCPP_COOP_TAB")) tab_c = tab_c && atoi(tv) != 0;    // test hook: force the global-table path
+    if (opt().has(smcpp_opt::O_COOP_TAB)) tab_c = tab_c && opt().i(smcpp_opt::O_COOP_TAB, 1) != 0;    // test hook: force the global-table path
     shm_c = base_c + (tab_c ? tabs : 0);
 }
 
@@ -241,7 +241,7 @@ void smcpp_im::stage_static_and_prepass() {
             default: throw std::runtime_error("internal: power pre-pass with an unsupported state count");
         }
     }
-    static const int dbg_level = getenv("SMCPP_POWER_DEBUG") ? atoi(getenv("SMCPP_POWER_DEBUG")) : 0;
+    const int dbg_level = opt().i(smcpp_opt::O_POWER_DEBUG, 0);
     if (dbg_level == 1) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[power] powers ok\n"); static_packed = false; return; }
     int tab_c; size_t shm_c;
     coop_lds(Mp, K, G, tab_c, shm_c);
@@ -250,7 +250,7 @@ void smcpp_im::stage_static_and_prepass() {
     cargs.power_off = (int)shm_c;          // two scratch vectors behind the regular carve-up
     shm_c += 2048;
     a.variant = 1; a.pass = 0;
-    { static const int pm = getenv("SMCPP_BWD_PRIO_MASK") ? atoi(getenv("SMCPP_BWD_PRIO_MASK")) : 7; if (!(pm & 1)) a.prio = 0; }
+    if (!(opt().i(smcpp_opt::O_BWD_PRIO_MASK, 7) & 1)) a.prio = 0;
     if (sb != s) {
         HIPCHK(hipEventRecord(ev[6], s));
         HIPCHK(hipStreamWaitEvent(sb, ev[6], 0));
@@ -283,7 +283,7 @@ void smcpp_im::run_chains() {
                       d_warm_f.n == chunks.size() * (size_t)Mp && d_warm_b.n == chunks.size() * (size_t)Mp;
     a.warm_f = warm ? d_warm_f.p : nullptr;
     a.warm_b = warm ? d_warm_b.p : nullptr;
-    if (getenv("SMCPP_DEBUG_CYCLES")) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }
+    if (opt().has(smcpp_opt::O_DEBUG_CYCLES)) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }
     const bool pre = prepass_launched;      // pass 0 of both chains already runs (eigen-free pre-pass, flags zeroed there)
     if (!pre) {
         d_changed_f.zero(s);
@@ -309,7 +309,7 @@ void smcpp_im::run_chains() {
     // row then comes from the exact kernels
     // issue priority of the backward wavefronts per pass (SMCPP_BWD_PRIO_MASK: bit 0 pre-pass, bit 1 the full pass after
     // it, bit 2 every other pass)
-    static const int prio_mask = getenv("SMCPP_BWD_PRIO_MASK") ? atoi(getenv("SMCPP_BWD_PRIO_MASK")) : 7;
+    const int prio_mask = opt().i(smcpp_opt::O_BWD_PRIO_MASK, 7);
     const int prio0 = a.prio;
     auto set_variant = [&](int pass) {
         a.pass = pass;
@@ -483,7 +483,7 @@ template <int NPL_, bool HYB_>
 static void launch_chain_ss_t(const SsArgs &a, int ntasks, size_t shm, hipStream_t s, int wgw) {
     // every key slot in LDS (the usual case): the instantiation without the global path of the emission vectors
     // (M <= 32 with one state per lane: the instantiation whose scans skip the level that would only move zeros)
-    static const bool h32_off = getenv("SMCPP_SS_H32") && atoi(getenv("SMCPP_SS_H32")) == 0;
+    const bool h32_off = opt().off(smcpp_opt::O_SS_H32);
     if (NPL_ == 1 && !HYB_ && a.K <= a.nlds && a.Mp <= 32 && !h32_off) launch_chain_ss_tt<NPL_, HYB_, true, NPL_ == 1 && !HYB_>(a, ntasks, shm, s, wgw);
     else if (a.K <= a.nlds) launch_chain_ss_tt<NPL_, HYB_, true>(a, ntasks, shm, s, wgw);
     else launch_chain_ss_tt<NPL_, HYB_, false>(a, ntasks, shm, s, wgw);
@@ -586,9 +586,9 @@ void smcpp_im::ss_launch_initial() {
         // All scans of the stored passes in float (chains_ss.hpp: ss_x_scan_fwd / ss_x_scan_bwd), the default since round 5 for one
         // state per lane; SMCPP_SS_MIXED=0 keeps the fp64 scans (read on every E-step: tests compare the two).  Never with
         // save_gamma - the posterior's argmax is compared index by index against the reference's.
-        const char *mx = getenv("SMCPP_SS_MIXED");
-        const bool mixed_on = !(mx && atoi(mx) == 0);
-        a.mixed = (mixed_on && !save_gamma && NPL == 1 && !ss_hybrid) ? 1 : 0;
+        const bool mixed_on = !opt().off(smcpp_opt::O_SS_MIXED);
+        const bool mixed_with_gamma = opt().i(smcpp_opt::O_SS_MIXED, 1) == 2;      // (=2: the float scans under save_gamma as well)
+        a.mixed = (mixed_on && (!save_gamma || mixed_with_gamma) && NPL == 1 && !ss_hybrid) ? 1 : 0;
     }
     if (ss_hybrid) {
         a.hyb_th = ss_hyb_th; a.Ke = Ke; a.hot_ek = std::max(0, hot_eig); a.dirsplit = ss_dirsplit ? 1 : 0;
@@ -600,8 +600,7 @@ void smcpp_im::ss_launch_initial() {
         // light passes: enough of them that the full pass starts ~11 e-folds of history in (the chains forget with an e-fold of
         // ~240 positions forward, ~340 backward on the benchmark model); none when the chunks are long against that
         long long pos = 0;
-        const int ef = getenv("SMCPP_SS_LIGHT_F") ? atoi(getenv("SMCPP_SS_LIGHT_F")) : -1;
-        const int eb = getenv("SMCPP_SS_LIGHT_B") ? atoi(getenv("SMCPP_SS_LIGHT_B")) : -1;
+        const int ef = opt().i(smcpp_opt::O_SS_LIGHT_F, -1), eb = opt().i(smcpp_opt::O_SS_LIGHT_B, -1);
         pos = ss_positions / std::max<size_t>(1, chunks.size());
         const long long pos_b = ss_positions / std::max<size_t>(1, chunks_b.size());
         auto pick = [&](double hist, long long p_) { return p_ <= 0 || (double)p_ > 1.5 * hist ? 0 : std::min(4, (int)std::ceil(hist / (double)p_)); };
@@ -625,13 +624,13 @@ void smcpp_im::ss_launch_initial() {
     }
     ss_warm_valid = false;                     // (set again when this E-step's chains have converged)
     a.dbg = nullptr;
-    if (getenv("SMCPP_DEBUG_CYCLES")) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }
+    if (opt().has(smcpp_opt::O_DEBUG_CYCLES)) { d_dbg.alloc(16); d_dbg.zero(s); a.dbg = d_dbg.p; }
     HIPCHK(hipMemcpyAsync(d_pre, pre_stage.base, off, hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(ev[10], s));
     ss_launched = ss_pass0;
     // (round 5) the passes launched up front end with the pass that is expected to rewrite no end vector - the all-skip pass behind
     // it (0.01 ms of kernel + its place in the queue) is not launched: run_chains_ss certifies from the end-vector flags
-    static const bool cert_launch = getenv("SMCPP_SS_CERT_PASS") && atoi(getenv("SMCPP_SS_CERT_PASS")) != 0;
+    const bool cert_launch = opt().on(smcpp_opt::O_SS_CERT_PASS);
     // (never fewer than one re-run pass behind the pass that stores everything - that one always rewrites its end vectors: with one
     // chunk per contig, or boundaries that were already exact, the quiet pass IS that re-run pass)
     const int want = std::min(max_pass, std::max(ss_pass0 + (last_ss_passes > 0 ? last_ss_passes + (cert_launch || ss_need_cert_pass ? 1 : 0) : 6),
@@ -671,12 +670,12 @@ void smcpp_im::run_chains_ss() {
     ss_warm_valid = false;
     bool first_round = true;
     int q = -1, first_launched = -1;      // (first_launched: passes launched when the first round failed to certify, -1: it did)
-    static const bool poll = !(getenv("SMCPP_POLL") && atoi(getenv("SMCPP_POLL")) == 0);
+    const bool poll = !opt().off(smcpp_opt::O_POLL);
     while (true) {
         HIPCHK(hipEventRecord(ev[3], s));
         // optimistic, as run_chains(): the statistics are queued right behind the passes; the host only looks at the flags (pinned
         // memory the kernels wrote) when the queue has drained; in the rare round that needs more passes the statistics are redone
-        static const bool spec_gamma = !(getenv("SMCPP_SPEC_GAMMA") && atoi(getenv("SMCPP_SPEC_GAMMA")) == 0);
+        const bool spec_gamma = !opt().off(smcpp_opt::O_SPEC_GAMMA);
         done_folded = false;
         if (first_round && (!save_gamma || spec_gamma)) {              // (save_gamma too: the passes launched up front almost always suffice)
             fold_done_epoch = poll ? done_epoch + 1 : 0;
@@ -754,7 +753,7 @@ void smcpp_im::enqueue_stats() {
     // need alpha, beta and the eigensystems only - not a single statistic: they run on their own stream BESIDE the (memory- and
     // latency-bound) statistics instead of behind them
     const bool gamma_side = save_gamma && n_e_rows > 0 && dual_stream && stream_hi != nullptr &&
-                            !(getenv("SMCPP_GAMMA_SIDE") && atoi(getenv("SMCPP_GAMMA_SIDE")) == 0);
+                            !opt().off(smcpp_opt::O_GAMMA_SIDE);
     if (save_gamma) {
         d_gamma_rows.alloc((size_t)total_rows * Mp);
         d_gamma_rows.zero(s);
@@ -763,7 +762,7 @@ void smcpp_im::enqueue_stats() {
     // The eigen-row branch (U/W products, rank update, span-Q Hadamard, Y) does not depend on the span-1 branch
     // (log_c, omega_1, rank update); with two streams the short launches of one fill the gaps of the other.
     const bool split_streams = dual_stream && stream2 != nullptr && !slabs_eg.empty();
-    const int stats_variant = getenv("SMCPP_STATS_VARIANT") ? atoi(getenv("SMCPP_STATS_VARIANT")) : 0;
+    const int stats_variant = opt().i(smcpp_opt::O_STATS_VARIANT, 0);
     // Eigen-free statistics of small inputs: the branch rank update of the span > 1 rows -> reduction -> span fold (2 x s_max serial
     // steps) is the critical path of the phase, and a hop between two streams costs ~10 us on this runtime (tools/sync_lab.hip:
     // event record -> wait on another queue; 2 us between two kernels of one queue).  So THAT branch stays on the main stream,
@@ -775,7 +774,7 @@ void smcpp_im::enqueue_stats() {
     // (round 4, later) with the span fold on the scans (k_span_scan: 23 us instead of 72) and shares in the span-1 reductions the two
     // branches are ~100 and ~77 us: the span > 1 branch is still the longer one and keeps the main stream (922 against 910 evals/s);
     // SMCPP_STATS_VARIANT & 8 gives the main stream to the span-1 branch instead
-    static const bool span_scan_off = getenv("SMCPP_SPAN_SCAN") && atoi(getenv("SMCPP_SPAN_SCAN")) == 0;
+    const bool span_scan_off = opt().off(smcpp_opt::O_SPAN_SCAN);
     const bool scan_fold = eigfree && ss_active && !span_scan_off;
     const bool swap_main = crit_main && scan_fold && (stats_variant & 8);
     hipStream_t se = crit_main ? (swap_main ? stream2 : s) : split_streams ? ((eigfree && (stats_variant & 1)) ? stream_hi : stream2) : s;
@@ -796,9 +795,8 @@ void smcpp_im::enqueue_stats() {
     // not run.  Measured: whole genome (3.6 M span-1 rows, bandwidth-bound) 3.77 -> 3.15 ms of statistics; one 100 Mbp contig
     // (129 k rows, one wavefront per SIMD, latency-bound) 0.208 -> 0.225 ms - there the gamma sums stay a third concurrent
     // branch.  SMCPP_S1_FUSE=0 / 1 forces either form.
-    const char *kf_env = getenv("SMCPP_S1_FUSE");
     const bool kfuse = (Mp + 63) / 64 == 1 && !save_gamma && !slabs_fk.empty() &&
-                       (kf_env ? atoi(kf_env) != 0 : (n_1_rows >= 500000 || crit_main));
+                       (opt().has(smcpp_opt::O_S1_FUSE) ? opt().i(smcpp_opt::O_S1_FUSE, 0) != 0 : (n_1_rows >= 500000 || crit_main));
     // (round 4: with the span > 1 branch on the main stream the span-1 statistics are ONE side branch in the one-pass form instead
     // of two - 887 against 873 headline evals per second, and 140 MB less traffic per E-step)
     // (eigen-free with the span > 1 branch on the main stream: free at its head, which waits there; round 5: the other eigen-free cases -
@@ -1158,7 +1156,7 @@ void smcpp_im::estep() {
         throw std::runtime_error("parameters are not set");
     HIPCHK(hipEventRecord(ev[0], stream));
     // span > 1 rows without an eigensystem (kernels.hpp: k_span_fold): the span is expanded by smax steps of two M x M products
-    static const bool eigfree_off = getenv("SMCPP_EIGFREE") && atoi(getenv("SMCPP_EIGFREE")) == 0;
+    const bool eigfree_off = opt().off(smcpp_opt::O_EIGFREE);
     const bool eigfree_static = !eigfree_off && Mp <= 512 && ss_max_span <= 64 && !save_gamma;
     if (Mp > 256 && !(ss_static && eigfree_static))
         throw std::runtime_error("more than 256 hidden states: only the scan chains with eigen-free statistics are built (binned data "

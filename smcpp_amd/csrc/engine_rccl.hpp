@@ -27,9 +27,30 @@ struct RcclDirect {
     int epoch = 0;
     bool reduced_in_buf = false;
 };
+// ONE dlopen handle per process and library path (never closed: the library is the one torch.distributed holds anyway, and a
+// communicator may outlive the manager that asked for it first); the enum values and the by-value unique id hard-coded below are
+// those of rccl.h of the NCCL 2.x ABI, so the version the library reports is checked once per handle.
+static void *rccl_handle(const char *libpath) {
+    static std::mutex mu;
+    static std::map<std::string, void *> handles;
+    const std::string key = libpath && *libpath ? libpath : "librccl.so.1";
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = handles.find(key);
+    if (it != handles.end()) return it->second;
+    void *h = dlopen(key.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!h) throw std::runtime_error(std::string("RCCL library not loadable: ") + dlerror());
+    auto get_version = reinterpret_cast<int (*)(int *)>(dlsym(h, "ncclGetVersion"));
+    int ver = 0;
+    if (!get_version || get_version(&ver) != 0 || ver < 20000 || ver >= 30000) {
+        dlclose(h);
+        throw std::runtime_error("RCCL library " + key + ": ncclGetVersion reports " + std::to_string(ver) +
+                                 " - the direct exchange is written against the NCCL 2.x ABI (ncclDouble = 8, ncclSum = 0, 128-byte unique id)");
+    }
+    handles[key] = h;
+    return h;
+}
 static void rccl_resolve(RcclDirect &r, const char *libpath) {
-    r.lib = dlopen(libpath && *libpath ? libpath : "librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!r.lib) throw std::runtime_error(std::string("RCCL library not loadable: ") + dlerror());
+    r.lib = rccl_handle(libpath);
     auto sym = [&](const char *nm) {
         void *p = dlsym(r.lib, nm);
         if (!p) throw std::runtime_error(std::string("RCCL symbol missing: ") + nm);
@@ -175,6 +196,42 @@ int smcpp_host_chunk_counts(int n_contigs, const long long *cost, const int *row
 }
 
 int smcpp_chain_mode(smcpp_im *im) { return im ? (im->ss_static ? (im->ss_hybrid ? 6 : 5) : im->chain_mode) : -1; }
+
+// Every SMCPP_* switch is parsed once per process (engine_options.hpp); this re-reads the environment.
+void smcpp_reload_options(void) { smcpp_opt::reload(); }
+
+// One JSON object: the switches found in the environment and the plan this manager resolved from them and from its input (chain
+// family, states per lane, chunk counts, history passes, arithmetic of the stored passes of the LAST E-step).  Returns the length
+// the text needs (without the terminating zero); writes at most cap - 1 characters.
+int smcpp_describe(smcpp_im *im, char *buf, int cap) {
+    std::string s = "{";
+    s += smcpp_opt::describe_options();
+    if (im) {
+        char t[1024];
+        const int fam = im->ss_static ? (im->ss_hybrid ? 6 : 5) : im->chain_mode;
+        snprintf(t, sizeof t,
+                 ", \"plan\": {\"chain_family\": %d, \"scan_chains\": %s, \"hybrid_rows\": %s, \"states\": %d, \"states_padded\": %d, "
+                 "\"states_per_lane\": %d, \"keys\": %d, \"eigen_keys\": %d, \"rows\": %lld, \"positions\": %lld, \"max_span\": %d, "
+                 "\"chunks_forward\": %zu, \"chunks_backward\": %zu, \"wavefronts_per_simd\": %d, \"halo_pass\": %s, "
+                 "\"light_passes_forward\": %d, \"light_passes_backward\": %d, \"float_scans_in_stored_passes\": %s, "
+                 "\"passes_to_certificate\": %d, \"passes_launched\": %d, \"certificate_pass_launched_up_front\": %s, "
+                 "\"save_gamma\": %s, \"warm_start\": %s, \"host_threads\": %d}",
+                 fam, im->ss_static ? "true" : "false", im->ss_hybrid ? "true" : "false", im->M, im->Mp, im->NPL, im->K, im->Ke,
+                 (long long)(im->total_rows - im->n_contigs), (long long)im->ss_positions, im->ss_max_span, im->chunks.size(),
+                 im->chunks_b.size(), im->ss_wpc, (im->ss_static && im->ss_args.halo) ? "true" : "false", im->ss_light_f, im->ss_light_b,
+                 (im->ss_static && im->ss_args.mixed) ? "true" : "false", im->last_ss_passes, im->ss_launched,
+                 (opt().on(smcpp_opt::O_SS_CERT_PASS) || im->ss_need_cert_pass) ? "true" : "false", im->save_gamma ? "true" : "false",
+                 im->warm_start ? "true" : "false", omp_get_max_threads());
+        s += t;
+    }
+    s += "}";
+    if (buf && cap > 0) {
+        const size_t n = std::min(s.size(), (size_t)cap - 1);
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return (int)s.size();
+}
 
 // Test hook (tests/test_gpu_ss.py): one position of both scan chains on nvec vectors, out_f = e o (T^T x), out_b = T (e o x);
 // x, e and the outputs are [nvec][M].  Returns 2 when T has no semiseparable structure.  float_scans != 0 (M <= 64): the step of

@@ -199,7 +199,7 @@ private:
 
     // ---- both distinguished lineages in population 1 (jcsfs.cpp:371-420) ----
     void together() {
-        static const bool tm_ = getenv("SMCPP_HOST_TIMING") != nullptr;
+        const bool tm_ = opt().has(smcpp_opt::O_HOST_TIMING);
         const double tw0 = tm_ ? omp_get_wtime() : 0.0;
         double tw_region = 0.0, tw_single = 0.0, tw_collected = 0.0, tw_sec[4] = {0, 0, 0, 0};
         eta1.reset(new RateFunctionT<S>(params1, std::vector<double>{split - 1e-6, split + 1e-6}));
@@ -594,7 +594,7 @@ public:
         S ps(0.0);
         for (S &x : pi) { if (sval(x) < 1e-20) x = S(1e-20); ps += x; }
         for (S &x : pi) x /= ps;
-        static const bool tm = getenv("SMCPP_HOST_TIMING") != nullptr;
+        const bool tm = opt().has(smcpp_opt::O_HOST_TIMING);
         const auto tc0 = std::chrono::steady_clock::now();
         T = compute_transition<S>(eta, rho);
         const auto tc1 = std::chrono::steady_clock::now();

@@ -364,7 +364,7 @@ inline void eigensystem_team(int n, const std::vector<double> &A, EigenSystem &e
     using namespace detail;
     const int T = tm.size;
     constexpr int BS = 16;      // doubles per ownership block: two cache lines of the 64-byte aligned rows
-    static const bool tmg = getenv("SMCPP_HOST_TIMING") != nullptr;
+    const bool tmg = opt().has(smcpp_opt::O_HOST_TIMING);
     const auto tc0 = std::chrono::steady_clock::now();
     double marks[8] = {0};
     auto mark = [&](int k) { if (tmg && rank == 0) marks[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count(); };

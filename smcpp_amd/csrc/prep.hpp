@@ -1154,7 +1154,7 @@ inline std::vector<std::vector<S>> conditioned_sfs_direct(const RateFunctionT<S>
 // 0 = factored evaluation (default), 1 = literal evaluation; initialised from SMCPP_CSFS_DIRECT, set over the C ABI by
 // smcpp_host_set_csfs_direct (test hook)
 inline int &csfs_direct_flag() {
-    static int flag = getenv("SMCPP_CSFS_DIRECT") != nullptr ? 1 : 0;
+    static int flag = opt().has(smcpp_opt::O_CSFS_DIRECT) ? 1 : 0;
     return flag;
 }
 
@@ -1277,7 +1277,7 @@ inline void conditioned_sfs_team(CsfsJob<S> &job, const std::function<void()> *s
     CsfsPieceTables<S> &pt = job.pt;
     std::vector<std::vector<S>> &csfs = job.csfs;
     std::exception_ptr &side_err = job.side_err;
-    static const bool tm = getenv("SMCPP_HOST_TIMING") != nullptr;
+    const bool tm = opt().has(smcpp_opt::O_HOST_TIMING);
     double (&tmark)[64][4] = job.tmark;
     const auto tbase = job.tbase;
     auto now_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tbase).count(); };
@@ -1413,7 +1413,7 @@ inline std::vector<std::vector<S>> conditioned_sfs(const RateFunctionT<S> &eta, 
     }
     job.init(eta, tb, below_only);
     const int nd = dual_nder();
-    static const bool tm = getenv("SMCPP_HOST_TIMING") != nullptr;
+    const bool tm = opt().has(smcpp_opt::O_HOST_TIMING);
     // one parallel region for everything: the piece tables (a few microseconds, static), then - without a barrier in
     // between - the caller's side job on whichever thread gets there first and the hidden states on all of them
     // (called per hidden state from inside another parallel loop: no nested team there)
@@ -1477,7 +1477,7 @@ public:
     template <typename S>
     void compute_t(const ModelParamsT<S> &mp, double theta, double rho, double alpha, const std::vector<int> &keys,
                    int K, std::vector<S> &pi, std::vector<S> &T, std::vector<S> &E, std::vector<S> *emission_out = nullptr) {
-        static const bool tm = getenv("SMCPP_HOST_TIMING") != nullptr;
+        const bool tm = opt().has(smcpp_opt::O_HOST_TIMING);
         auto clk = [] { return std::chrono::steady_clock::now(); };
         auto t0 = clk();
         RateFunctionT<S> eta(mp, hs_);

@@ -174,7 +174,9 @@ class ShardedInferenceManager:
         self._buf = None
         self._ll_sum = None
         self._lls = None
-        self._unpack_pending = False      # RCCL path: the reduced statistics still sit in the device buffer (see _ensure_unpacked)
+        # RCCL path: the reduced statistics still sit in a device buffer - "direct" (the engine's own RCCL buffer) or "torch" (self._buf);
+        # False: nothing pending (see _ensure_unpacked)
+        self._unpack_pending = False
         self.last_local_stats = self.last_reduced_stats = None      # (host copies, kept only when `keep_stats` is set: tests)
         self.keep_stats = False
         import os as _os
@@ -223,6 +225,33 @@ class ShardedInferenceManager:
         """Union of every rank's keys (lexicographic)."""
         return union_keys(self.im.keys, self._group) if self._reduce else self.im.keys
 
+    def _setup_exchange(self, torch, dev):
+        """First RCCL exchange of this manager: the reduce buffer on the device the ENGINE lives on (the pack / unpack kernels
+        dereference the pointer there) and - `stream_ordered` - torch's view of the engine's stream.  Whether the process group
+        accepts a collective on that external stream is probed ONCE, here, with a dummy all-reduce every rank issues, and the
+        ranks agree on the outcome through a second (ordinary) all-reduce: all of them take the same branch in every later
+        E-step, none ever retries on its own."""
+        if self._buf is not None:
+            return
+        self._buf = torch.empty(self.im.stats_len(), dtype=torch.float64, device=dev)
+        ok = 0.0
+        if self.stream_ordered:
+            try:
+                ext = torch.cuda.ExternalStream(int(self.im.stream()), device=dev)
+                probe = torch.zeros(1, dtype=torch.float64, device=dev)
+                with torch.cuda.stream(ext):
+                    self._dist.all_reduce(probe, op=self._dist.ReduceOp.SUM, group=self._group)
+                    float(probe.item())
+                self._ext = ext
+                ok = 1.0
+            except Exception as ex:                                  # noqa: BLE001 - no external streams in this torch / group
+                import warnings
+                warnings.warn(f"stream-ordered exchange unavailable ({ex}); using the host-wait form")
+        flag = torch.tensor([ok], dtype=torch.float64, device=dev)
+        self._dist.all_reduce(flag, op=self._dist.ReduceOp.MIN, group=self._group)
+        if float(flag.item()) < 1.0:
+            self._ext = None
+
     def E_step(self, forward_backward_only=False):
         """Local E-step on this rank's contigs + the single all-reduce of the packed statistics."""
         self.im.E_step(forward_backward_only)
@@ -234,34 +263,18 @@ class ShardedInferenceManager:
         import torch
         if self._direct and not self.keep_stats:
             self._ll_sum = self.im.rccl_exchange()
-            self._unpack_pending = True
+            self._unpack_pending = "direct"
         elif self._nccl:
             dev = torch.device("cuda", self._device)
-            if self._buf is None:
-                # on the device the ENGINE lives on (the pack / unpack kernels dereference the pointer there)
-                self._buf = torch.empty(self.im.stats_len(), dtype=torch.float64, device=dev)
-                # ... and everything below is ordered on the ENGINE's stream: torch sees it as an external stream, RCCL's own
-                # stream waits for it and hands back to it (ProcessGroupNCCL synchronises streams, not the host), so
-                # pack kernel -> all-reduce -> the read-back of the scalar run with no host wait in between
-                try:
-                    self._ext = torch.cuda.ExternalStream(int(self.im.stream()), device=dev) if self.stream_ordered else None
-                except Exception:                                    # (a torch build without external streams: the host-wait form)
-                    self._ext = None
-            done = False
+            self._setup_exchange(torch, dev)
             if self._ext is not None and not self.keep_stats:
-                try:
-                    with torch.cuda.stream(self._ext):
-                        self.im.pack_stats_device(self._buf.data_ptr(), sync=False)
-                        self._dist.all_reduce(self._buf, op=self._dist.ReduceOp.SUM, group=self._group)
-                        self._ll_sum = float(self._buf[0].item())     # the one host wait of the exchange
-                    done = True
-                except RuntimeError as ex:
-                    # a process-group build that cannot take an external stream: say so once and keep the host-wait form (the
-                    # statistics of this E-step are still in the engine - they are packed again below)
-                    import warnings
-                    warnings.warn(f"stream-ordered exchange unavailable ({ex}); falling back to the host-wait form")
-                    self._ext = None
-            if not done:
+                # (no fallback in here: whether the process group takes the external stream was settled COLLECTIVELY by the probe
+                # of _setup_exchange - a rank that retried on its own would issue a collective its peers do not)
+                with torch.cuda.stream(self._ext):
+                    self.im.pack_stats_device(self._buf.data_ptr(), sync=False)
+                    self._dist.all_reduce(self._buf, op=self._dist.ReduceOp.SUM, group=self._group)
+                    self._ll_sum = float(self._buf[0].item())     # the one host wait of the exchange
+            else:
                 self.im.pack_stats_device(self._buf.data_ptr())       # returns after the kernel has finished
                 if self.keep_stats:
                     self.last_local_stats = self._buf.cpu().numpy().copy()
@@ -271,7 +284,7 @@ class ShardedInferenceManager:
                     self.last_reduced_stats = self._buf.cpu().numpy().copy()
             # the reduced statistics stay in the device buffer until Q asks for them (one kernel + a synchronisation per E-step
             # that a loglik-only caller - an evaluation loop, bench.py - never needs)
-            self._unpack_pending = True
+            self._unpack_pending = "torch"
         else:
             h = self.im.pack_stats()
             if self.keep_stats:
@@ -300,12 +313,12 @@ class ShardedInferenceManager:
         return self._lls
 
     def _ensure_unpacked(self):
-        if self._unpack_pending:
-            if self._direct and not self.keep_stats:
-                self.im.rccl_unpack()
-            else:
-                self.im.unpack_stats_device(self._buf.data_ptr(), self._buf.numel())
-            self._unpack_pending = False
+        # dispatch on the path that PRODUCED the pending buffer (recorded by E_step), not on flags that may have been toggled since
+        if self._unpack_pending == "direct":
+            self.im.rccl_unpack()
+        elif self._unpack_pending == "torch":
+            self.im.unpack_stats_device(self._buf.data_ptr(), self._buf.numel())
+        self._unpack_pending = False
 
     def Q(self, separate=False):
         self._ensure_unpacked()

@@ -33,3 +33,20 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+@pytest.fixture
+def engine_opt():
+    """`engine_opt(name, value)` sets (value=None: removes) an SMCPP_* switch for the rest of the test.  The engine parses its
+    option table ONCE per process (smcpp_amd/csrc/engine_options.hpp), so a change only takes effect through
+    `_engine.set_option` = environment + `smcpp_reload_options`; everything is restored (and re-read) at teardown."""
+    from smcpp_amd import _engine
+    saved = {}
+
+    def set_(name, value):
+        if name not in saved:
+            saved[name] = os.environ.get(name)
+        _engine.set_option(name, value)
+    yield set_
+    for name, old in saved.items():
+        _engine.set_option(name, old)

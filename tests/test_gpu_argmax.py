@@ -111,3 +111,27 @@ def test_posterior_indices_at_scale_vs_compiled_reference(name, route):
     assert np.max(np.abs(sub - g["gamma_sub"])) <= 2e-5 * max(1.0, float(np.abs(g["gamma_sub"]).max()))
     assert np.array_equal(gam.argmax(axis=0).astype(np.int64), np.asarray(arg).astype(np.int64))
     assert rel_err(gam[:, 0], g["gamma0"]) <= STAT_TOL
+
+
+@pytest.mark.parametrize("name", ["G19_headline", "G19_c2"])
+def test_posterior_indices_with_float_scans_in_the_stored_passes(engine_opt, name):
+    """the timed path runs every scan of the stored passes in float (chains_ss.hpp: ss_x_scan_fwd / _bwd), the
+    path whose indices were compared did not (`save_gamma` used to switch the float scans off).  Here the float scans run WITH
+    `save_gamma` (SMCPP_SS_MIXED=2) on the full-size binned contigs: the decoded index must equal the compiled reference's on every
+    column whose reference margin exceeds 1e-5 (the north-star bar as SURVEY.md 8(c) states it); all mismatches are printed."""
+    engine_opt("SMCPP_SS_MIXED", "2")
+    g, obs = _load(name)
+    im = _manager(g, obs, "params")
+    im.save_gamma = True
+    im.E_step()
+    assert im.chain_mode() == 5 and im.describe()["plan"]["float_scans_in_stored_passes"]
+    ll = im.loglik()
+    assert abs(ll - float(g["loglik"])) <= LL_TOL * abs(float(g["loglik"]))
+    arg = im.gamma_argmax(0)
+    mism, strong, margin = argmax_report(arg, g)
+    print(f"{name}[float scans + save_gamma]: {len(arg)} columns, argmax mismatches {len(mism)} (reference margin > 1e-5: {len(strong)})"
+          + (f"; mismatching columns {mism[:8].tolist()} margins {margin[mism][:8].tolist()}" if len(mism) else ""))
+    assert len(strong) == 0
+    gam = im.gammas[0]
+    st = int(g["gamma_stride"])
+    assert np.max(np.abs(gam[:, ::st] - g["gamma_sub"])) <= 2e-5 * max(1.0, float(np.abs(g["gamma_sub"]).max()))

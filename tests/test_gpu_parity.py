@@ -65,14 +65,14 @@ def check_against(g, im, save_gamma):
 
 
 @pytest.fixture(params=["default", "dense", "lock"])
-def chain_family(request, monkeypatch):
+def chain_family(request, engine_opt):
     """Every golden vector is checked with the chain kernels the engine picks by itself (the scans over the semiseparable
     structure of T when the spans are short, else cooperative / streamed operands), with the scans switched off (the dense
     kernels every manager falls back to) and with the lock-step kernels on the matrix cores forced (M <= 64)."""
     if request.param == "lock":
-        monkeypatch.setenv("SMCPP_CHAIN", "lock")
+        engine_opt("SMCPP_CHAIN", "lock")
     if request.param == "dense":
-        monkeypatch.setenv("SMCPP_SS", "0")
+        engine_opt("SMCPP_SS", "0")
     return request.param
 
 
@@ -352,7 +352,7 @@ def test_two_population_model_path(a1, a2, M, split):
                                                (17, 6, 300_000, 40), (33, 8, 300_000, 0), (47, 9, 250_000, 64),
                                                (65, 10, 200_000, 0), (100, 12, 150_000, 64), (130, 6, 120_000, 0),
                                                (200, 8, 80_000, 48), (256, 10, 60_000, 0)])
-def test_state_count_sweep_vs_oracle(M, n, length, chunk):
+def test_state_count_sweep_vs_oracle(engine_opt, M, n, length, chunk):
     """Every kernel family (cooperative M <= 64 at each padded width, generic 64 < M <= 256, odd widths that need
     padding) against the C restatement, parameters from the engine's own preparation, several ragged contigs, with and
     without forced multi-chunk iteration; posterior rows included."""
@@ -369,12 +369,12 @@ def test_state_count_sweep_vs_oracle(M, n, length, chunk):
     if chunk > 0:
         im.set_chunking(chunk)
     if chunk < 0:
-        os.environ["SMCPP_COOP_TAB"] = "0"
+        engine_opt("SMCPP_COOP_TAB", "0")
     im.save_gamma = True
     try:
         im.E_step()
     finally:
-        os.environ.pop("SMCPP_COOP_TAB", None)
+        engine_opt("SMCPP_COOP_TAB", None)
     pi, T, keys = im.pi, im.transition, im.keys
     ep = im.emission_probs
     Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
@@ -396,7 +396,7 @@ def test_state_count_sweep_vs_oracle(M, n, length, chunk):
 
 
 @pytest.mark.parametrize("M,n", [(64, 20), (32, 10), (48, 7), (16, 4), (130, 6), (256, 8)])
-def test_eigen_free_prepass_on_and_off_vs_oracle(M, n):
+def test_eigen_free_prepass_on_and_off_vs_oracle(engine_opt, M, n):
     """The two ways the cooperative chains run on binned data (spans < 32): eigensystem kernels only
     (SMCPP_POWER_PREPASS=0) and eigen-free pre-pass + a full eigensystem pass (the default; cooperative kernels for
     M <= 64, streamed-operand kernels with device-built powers above).  Each against the C restatement at the stated tolerances, and against each other far below them (every stored row comes from the
@@ -410,7 +410,7 @@ def test_eigen_free_prepass_on_and_off_vs_oracle(M, n):
     contigs = [synth.synth_contig(300 + M, 3_000_000 if M <= 64 else 1_200_000, n), synth.synth_contig(301 + M, 150_000, n)]
     res = {}
     for mode in (0, 1):
-        os.environ["SMCPP_POWER_PREPASS"] = str(mode)
+        engine_opt("SMCPP_POWER_PREPASS", str(mode))
         try:
             im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
             im.model = PiecewiseModel(a, s, 1e4, "pop1")
@@ -419,7 +419,7 @@ def test_eigen_free_prepass_on_and_off_vs_oracle(M, n):
                 im.E_step()
             res[mode] = (np.array(im.logliks()), im.xisums, im.gamma_sums, np.array(im.Q(separate=True)))
         finally:
-            os.environ.pop("SMCPP_POWER_PREPASS", None)
+            engine_opt("SMCPP_POWER_PREPASS", None)
     pi, T, keys = im.pi, im.transition, im.keys
     ep = im.emission_probs
     Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
@@ -436,7 +436,7 @@ def test_eigen_free_prepass_on_and_off_vs_oracle(M, n):
 
 
 @pytest.mark.parametrize("M,n,max_span", [(64, 20, 4000), (32, 6, 700), (48, 9, 100), (130, 5, 3000), (256, 6, 500)])
-def test_eigen_free_prepass_with_long_spans_vs_oracle(M, n, max_span):
+def test_eigen_free_prepass_with_long_spans_vs_oracle(engine_opt, M, n, max_span):
     """Spans of 32 .. 4095 positions: the pre-pass applies rescaled powers A^32 .. A^2048 from L2 on the rows that need them;
     every stored row still comes from the eigensystem kernels.  Pre-pass on / off against the C restatement."""
     import os
@@ -456,7 +456,7 @@ def test_eigen_free_prepass_with_long_spans_vs_oracle(M, n, max_span):
         contigs.append(np.ascontiguousarray(c))
     res = {}
     for mode in (0, 1):
-        os.environ["SMCPP_POWER_PREPASS"] = str(mode)
+        engine_opt("SMCPP_POWER_PREPASS", str(mode))
         try:
             im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
             im.model = PiecewiseModel(a, s, 1e4, "pop1")
@@ -464,7 +464,7 @@ def test_eigen_free_prepass_with_long_spans_vs_oracle(M, n, max_span):
             im.E_step(); im.E_step()
             res[mode] = (np.array(im.logliks()), im.xisums, im.gamma_sums)
         finally:
-            os.environ.pop("SMCPP_POWER_PREPASS", None)
+            engine_opt("SMCPP_POWER_PREPASS", None)
     pi, T, keys = im.pi, im.transition, im.keys
     ep = im.emission_probs
     Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
@@ -480,7 +480,7 @@ def test_eigen_free_prepass_with_long_spans_vs_oracle(M, n, max_span):
 
 @pytest.mark.parametrize("M,n,chunk", [(64, 20, 0), (64, 12, 37), (50, 6, 150), (64, 8, 400), (32, 10, 0), (33, 5, 90), (16, 4, 60),
                                        (7, 3, 0)])
-def test_lock_step_chains_vs_oracle(M, n, chunk):
+def test_lock_step_chains_vs_oracle(engine_opt, M, n, chunk):
     """The lock-step chains (16 chunks per workgroup on the matrix cores, chains_lock.hpp) forced on small inputs: ragged
     contigs (so the 16 columns of a workgroup have different lengths and some do not exist), chunks far shorter than the
     chains' memory (many passes, per-column merge exits and skip tests), three eigen keys (one register-resident), against the
@@ -494,7 +494,7 @@ def test_lock_step_chains_vs_oracle(M, n, chunk):
     contigs = [synth.synth_contig(700 + M + i, L, n) for i, L in enumerate([1_500_000, 40_000, 600_000, 900, 250_000])]
     res = {}
     for mode in ("coop", "lock"):
-        os.environ["SMCPP_CHAIN"] = mode
+        engine_opt("SMCPP_CHAIN", mode)
         try:
             im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
             im.model = PiecewiseModel(a, s, 1e4, "pop1")
@@ -505,7 +505,7 @@ def test_lock_step_chains_vs_oracle(M, n, chunk):
             im.E_step(); im.E_step()
             res[mode] = (np.array(im.logliks()), im.xisums, im.gamma_sums, im.gammas)
         finally:
-            os.environ.pop("SMCPP_CHAIN", None)
+            engine_opt("SMCPP_CHAIN", None)
     pi, T, keys = im.pi, im.transition, im.keys
     ep = im.emission_probs
     Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
@@ -724,7 +724,7 @@ def _stats_close(a, b, tol):
             assert np.max(np.abs(ga[c][k] - v)) <= tol * max(np.abs(v).max(), 1e-300), (c, k)
 
 
-def test_full_size_headline_properties(monkeypatch):
+def test_full_size_headline_properties(engine_opt):
     """The BASELINE.json headline at FULL size (one 100 Mbp contig, M = 64, n = 20: 235 552 rows) through properties that do not
     need an oracle run of 25 s per E-step:
       * the chunk-parallel run (512 chunks, light passes, re-run passes) against the SAME kernels run as ONE chunk, i.e. purely
@@ -757,14 +757,14 @@ def test_full_size_headline_properties(monkeypatch):
     assert abs(par.loglik() - seq.loglik()) <= 1e-9 * abs(seq.loglik())
     _stats_close(par, seq, STAT_TOL)
     np.testing.assert_allclose(par.Q(separate=True), seq.Q(separate=True), rtol=STAT_TOL)
-    monkeypatch.setenv("SMCPP_SS", "0")
+    engine_opt("SMCPP_SS", "0")
     dense = make()
     assert dense.chain_mode() != 5
     assert abs(par.loglik() - dense.loglik()) <= 1e-8 * abs(dense.loglik())
     _stats_close(par, dense, 2 * STAT_TOL)       # two float-alpha noise floors
 
 
-def test_full_size_whole_genome_scan_vs_lockstep(monkeypatch):
+def test_full_size_whole_genome_scan_vs_lockstep(engine_opt):
     """Config C3's input on ONE manager (22 contigs, 6.76 M rows, M = 64, n = 20): the scan chains against the lock-step chains on
     the matrix cores (an independent kernel family, eigensystem statistics)."""
     from smcpp_amd import _smcpp, synth
@@ -785,7 +785,7 @@ def test_full_size_whole_genome_scan_vs_lockstep(monkeypatch):
     assert scan.chain_mode() == 5
     ll_scan, x_scan, g_scan, q_scan = np.array(scan.logliks()), scan.xisums, scan.gamma_sums, np.array(scan.Q(separate=True))
     del scan
-    monkeypatch.setenv("SMCPP_CHAIN", "lock")
+    engine_opt("SMCPP_CHAIN", "lock")
     lock = make()
     assert lock.chain_mode() == 4
     np.testing.assert_allclose(ll_scan, lock.logliks(), rtol=1e-8)
@@ -797,14 +797,14 @@ def test_full_size_whole_genome_scan_vs_lockstep(monkeypatch):
     np.testing.assert_allclose(q_scan, lock.Q(separate=True), rtol=2 * STAT_TOL)
 
 
-def test_span1_statistics_one_pass_in_key_order(monkeypatch):
+def test_span1_statistics_one_pass_in_key_order(engine_opt):
     """SMCPP_S1_FUSE: the span-1 rank update and the per-key gamma sums in ONE pass over key-sorted single-key slabs (k_rank_acc<3>,
     the default from half a million span-1 rows on) against the two-kernel form (k_s1_scalars + k_rank_acc<0>): same goldens, same
     tolerances, and against each other far below them."""
     res = {}
     names = ("G4_M64_n20_2Mbp", "G3_M32_n10_2Mbp", "G1_M16_n4", "G5_M48_twopop_layout")
     for fuse in ("0", "1"):
-        monkeypatch.setenv("SMCPP_S1_FUSE", fuse)
+        engine_opt("SMCPP_S1_FUSE", fuse)
         for name in names:
             g = load_golden(name)
             im = make_im(g)
@@ -819,7 +819,7 @@ def test_span1_statistics_one_pass_in_key_order(monkeypatch):
             np.testing.assert_allclose(g1[k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
 
 
-def test_rank_partials_by_teams_of_four_slabs_vs_one_per_slab(monkeypatch):
+def test_rank_partials_by_teams_of_four_slabs_vs_one_per_slab(engine_opt):
     """Round 5 default: four consecutive slabs of one reduction range share a workgroup of `k_rank_acc<., true>`, which adds their
     accumulators through LDS and writes ONE partial; SMCPP_STATS_TEAM=0 keeps one partial per slab.  Same goldens and tolerances for
     both (one to four states per lane: the span-1 form of M > 64 too), and against each other to the rounding of a re-ordered sum."""
@@ -831,7 +831,7 @@ def test_rank_partials_by_teams_of_four_slabs_vs_one_per_slab(monkeypatch):
     p5 = dict(np.load(os.path.join(ROOT, "tests", "golden", "params_M256_n50.npz")))
     g5 = load_golden("G14_c5_slice")
     for team in ("0", "1"):
-        monkeypatch.setenv("SMCPP_STATS_TEAM", team)
+        engine_opt("SMCPP_STATS_TEAM", team)
         for name in names:
             g = load_golden(name)
             im = make_im(g)
@@ -856,14 +856,14 @@ def test_rank_partials_by_teams_of_four_slabs_vs_one_per_slab(monkeypatch):
             np.testing.assert_allclose(g1[k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
 
 
-def test_float_scans_of_the_stored_passes_vs_fp64_scans(monkeypatch):
+def test_float_scans_of_the_stored_passes_vs_fp64_scans(engine_opt):
     """Round 5 default: every scan of the stored passes runs in float (the sums over the states above as native suffix scans; the
     vector and the diagonal term stay in fp64), SMCPP_SS_MIXED=0 keeps the fp64 scans.  Same goldens and tolerances for both, and
     against each other: the log-likelihood to 1e-9, the statistics to the float noise the reference's own forward chain carries."""
     res = {}
     names = ("G4_M64_n20_2Mbp", "G3_M32_n10_2Mbp", "G1_M16_n4", "G5_M48_twopop_layout")
     for mixed in ("0", "1"):
-        monkeypatch.setenv("SMCPP_SS_MIXED", mixed)
+        engine_opt("SMCPP_SS_MIXED", mixed)
         for name in names:
             g = load_golden(name)
             im = make_im(g)
@@ -881,7 +881,7 @@ def test_float_scans_of_the_stored_passes_vs_fp64_scans(monkeypatch):
 
 
 @pytest.mark.parametrize("M,n", [(48, 7), (64, 20), (100, 6), (130, 6), (256, 8)])
-def test_span_fold_on_scans_vs_matrix_cores(monkeypatch, M, n):
+def test_span_fold_on_scans_vs_matrix_cores(engine_opt, M, n):
     """Round 4: the eigen-free span statistics fold the spans with the O(M) scan steps of the chains (k_span_scan: one wavefront per
     row of F / column of H) instead of 2 s_max products of M x M matrices on the matrix cores (k_span_big, SMCPP_SPAN_SCAN=0).  Both
     against the C restatement at the stated tolerances and against each other far below them, for one to four states per lane."""
@@ -893,7 +893,7 @@ def test_span_fold_on_scans_vs_matrix_cores(monkeypatch, M, n):
     contigs = [synth.synth_contig(700 + M, 2_000_000 if M <= 64 else 800_000, n), synth.synth_contig(701 + M, 120_000, n)]
     res = {}
     for scan in ("1", "0"):
-        monkeypatch.setenv("SMCPP_SPAN_SCAN", scan)
+        engine_opt("SMCPP_SPAN_SCAN", scan)
         im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
         im.model = PiecewiseModel(a, s, 1e4, "pop1")
         im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0
@@ -917,7 +917,7 @@ def test_span_fold_on_scans_vs_matrix_cores(monkeypatch, M, n):
 
 
 @pytest.mark.parametrize("name", ["G7_M32_n8_chr11", "G18_M64_n8_chr11"])
-def test_hybrid_scan_chains_on_unbinned_data(monkeypatch, name):
+def test_hybrid_scan_chains_on_unbinned_data(engine_opt, name):
     """Un-binned data (spans to 10^5): the scan kernel with HYBRID rows (chain mode 6: a long row is one eigen-power step
     P d^s P^-1 inside the one-wavefront-per-chunk kernel, a short one `span` scan steps) against the dense chains (SMCPP_HYBRID=0)
     on the reference's own un-binned contig (golden G7 / G18, with gamma) and on a synthetic contig long enough for several chunks.
@@ -926,7 +926,7 @@ def test_hybrid_scan_chains_on_unbinned_data(monkeypatch, name):
     g = load_golden(name)
     res = {}
     for hyb in ("1", "0"):
-        monkeypatch.setenv("SMCPP_HYBRID", hyb)
+        engine_opt("SMCPP_HYBRID", hyb)
         im = make_im(g)
         im.save_gamma = True
         im.E_step()
@@ -947,7 +947,7 @@ def test_hybrid_scan_chains_on_unbinned_data(monkeypatch, name):
     obs = np.concatenate([span[:, None], keys[kid]], axis=1).astype(np.int32)
     out = {}
     for hyb in ("1", "0"):
-        monkeypatch.setenv("SMCPP_HYBRID", hyb)
+        engine_opt("SMCPP_HYBRID", hyb)
         im = _smcpp.PyOnePopInferenceManager(8, [obs], g["hs"], ("pop1",), float(g["pol"]))
         im.set_raw(g["pi"], g["T"], g["keys"], g["E"])
         im.set_chunking(2000)
@@ -960,7 +960,7 @@ def test_hybrid_scan_chains_on_unbinned_data(monkeypatch, name):
         assert np.max(np.abs(out["1"][3][k] - v)) <= 2 * STAT_TOL * max(np.abs(v).max(), 1e-300)
 
 
-def test_hybrid_rows_with_cold_eigen_keys_m64(monkeypatch):
+def test_hybrid_rows_with_cold_eigen_keys_m64(engine_opt):
     """Un-binned data at M = 64 with THREE eigen keys (round 5): the pair of eigenvector tables a direction needs is 66 KB per key, two
     keys fill LDS - the third (least frequent) key's table rows are read from L2 on the rows that need them.  Until round 4 such an
     input fell back to the dense cooperative chains.  Checked against those (SMCPP_HYBRID=0) and against the C restatement of
@@ -981,7 +981,7 @@ def test_hybrid_rows_with_cold_eigen_keys_m64(monkeypatch):
     obs = np.concatenate([span[:, None], keys[kid]], axis=1).astype(np.int32)
     out = {}
     for hyb in ("1", "0"):
-        monkeypatch.setenv("SMCPP_HYBRID", hyb)
+        engine_opt("SMCPP_HYBRID", hyb)
         im = _smcpp.PyOnePopInferenceManager(8, [obs], g["hs"], ("pop1",), float(g["pol"]))
         im.set_raw(g["pi"], g["T"], g["keys"], g["E"])
         im.set_chunking(1500)

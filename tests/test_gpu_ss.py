@@ -131,3 +131,71 @@ def test_engine_falls_back_to_dense_kernels_on_unstructured_T():
     o = oracle.estep(g["pi"], g["T"], g["keys"], g["E"], obs)
     assert abs(im.loglik() - o["loglik"]) <= 1e-6 * abs(o["loglik"])
     assert np.max(np.abs(im.xisums[0] - o["xisum"]) / np.abs(o["xisum"])) <= 5e-6
+
+
+def _cert_run(engine_opt, cert, case):
+    """One scenario of the certificate test below under SMCPP_SS_CERT_PASS = cert: -> list of (loglik, xisum, gamma sums) per E-step
+    and the plan of the last one."""
+    from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel
+    engine_opt("SMCPP_SS_CERT_PASS", "1" if cert else None)
+    g = load_golden("G4_M64_n20_2Mbp")
+    a0 = np.array(g["a"], dtype=float)
+    out = []
+    if case == "default_chunks":
+        # 30 Mbp: ~300 000 positions over the default chunk list (one chunk per SIMD and direction), default tolerances
+        obs = [synth.synth_contig(0, 30_000_000, 20), synth.synth_contig(5, 3_000_000, 20)]
+        steps = [a0, a0, a0 * 1.01]
+        warm, chunk, eps = False, 0, (0.0, 0.0)
+    elif case == "second_round":
+        # 2 Mbp in 150-row chunks with tolerances so tight that a chunk only stops re-running when its input is bitwise what it last
+        # ran from: the fixed point degenerates to the sequential algorithm (chunk c exact after c passes) - far more passes than the
+        # first round launches, i.e. the branch that launches further rounds and the certificate at the pass limit
+        obs = [np.ascontiguousarray(g["obs"], dtype=np.int32)]
+        steps = [a0, a0]
+        warm, chunk, eps = False, 150, (1e-30, 1e-30)
+    else:
+        # warm start: passes numbered from 1 or 2, one light pass fewer, unequal light-pass counts of the two directions
+        obs = [synth.synth_contig(0, 30_000_000, 20)]
+        rng = np.random.default_rng(11)
+        steps = [a0] + [a0 * (1.0 + 0.02 * rng.standard_normal(len(a0))) for _ in range(3)] + [a0[::-1] * 2.5]
+        warm, chunk, eps = True, 800, (0.0, 0.0)
+    im = _smcpp.PyOnePopInferenceManager(20, obs, g["hs"], ("pop1",), float(g["pol"]))
+    im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = float(g["alpha"])
+    if chunk or eps[0]:
+        im.set_chunking(chunk, *eps)
+    if warm:
+        im.set_warm_start(True)
+    m = PiecewiseModel(a0, g["s"], 1e4, "pop1")
+    im.model = m
+    plans = []
+    for a in steps:
+        m[:] = a
+        im.E_step()
+        assert im.chain_mode() == 5
+        out.append((np.array(im.logliks()), [x.copy() for x in im.xisums], [dict(d) for d in im.gamma_sums]))
+        plans.append(im.describe()["plan"])
+    return out, plans
+
+
+@pytest.mark.parametrize("case", ["default_chunks", "second_round", "warm_start"])
+def test_certificate_from_flags_equals_the_launched_certificate_pass(engine_opt, case):
+    """since round 5 the all-skip pass that certifies convergence is no longer launched - run_chains_ss accepts
+    "the last launched pass rewrote no end vector" (engine_plans.hpp).  SMCPP_SS_CERT_PASS=1 launches that pass again.  Both must
+    give BITWISE the same log-likelihoods and statistics - a regression would hand unconverged rows to the speculatively queued
+    statistics - on the default chunk list, on an input that needs further rounds of launches (and reaches the certificate far
+    beyond the first round), and on a warm-started trajectory."""
+    flags, plan_f = _cert_run(engine_opt, False, case)
+    launched, plan_l = _cert_run(engine_opt, True, case)
+    assert not any(p["certificate_pass_launched_up_front"] for p in plan_f[:1]) and all(p["certificate_pass_launched_up_front"] for p in plan_l)
+    if case == "second_round":
+        # the first round launches 6 passes; the certificate comes much later
+        assert plan_f[0]["passes_to_certificate"] > 8 and plan_f[0]["passes_launched"] > 8, plan_f[0]
+    for (l0, x0, g0), (l1, x1, g1) in zip(flags, launched):
+        assert np.array_equal(l0, l1)
+        for a, b in zip(x0, x1):
+            assert np.array_equal(a, b)
+        for da, db in zip(g0, g1):
+            assert sorted(da) == sorted(db)
+            for k in da:
+                assert np.array_equal(da[k], db[k]), k

@@ -2,6 +2,7 @@
 import os, sys, time, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from smcpp_amd import _smcpp, synth
+from smcpp_amd import _engine as E   # (the engine parses SMCPP_* once per process: switches go through E.set_option)
 from smcpp_amd.model import PiecewiseModel
 M, n = int(os.environ.get("LOCK_M", 64)), int(os.environ.get("LOCK_N", 20))
 hs = synth.hidden_states(M); a, s = synth.model_pieces()
@@ -14,7 +15,7 @@ for k in (3, 6, 10, 15, 22):
     rows = sum(len(c) for c in contigs)
     out = []
     for mode in ("coop", "lock"):
-        os.environ["SMCPP_CHAIN"] = mode
+        E.set_option("SMCPP_CHAIN", mode)
         im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
         im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0
         for _ in range(2):

@@ -2,6 +2,7 @@
 import os, sys, time, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from smcpp_amd import _smcpp, synth, dist as sd
+from smcpp_amd import _engine as E   # (the engine parses SMCPP_* once per process: switches go through E.set_option)
 from smcpp_amd.model import PiecewiseModel
 M, n = 64, 20
 hs = synth.hidden_states(M); a, s = synth.model_pieces()
@@ -14,9 +15,9 @@ for rank in range(min(world, int(os.environ.get("SHARD_RANKS", 2)))):
     contigs = [synth.synth_contig(i, int(synth.C3_LENGTHS_MBP[i] * 1e6), n) for i in idx]
     rows = sum(len(c) for c in contigs)
     for mode in os.environ.get("SHARD_MODES", "ss,coop,lock").split(","):
-        os.environ.pop("SMCPP_CHAIN", None)
+        E.set_option("SMCPP_CHAIN", None)
         if mode != "ss":                      # "ss" = the engine's own choice (scan chains)
-            os.environ["SMCPP_CHAIN"] = mode
+            E.set_option("SMCPP_CHAIN", mode)
         im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
         im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0
         for _ in range(3):

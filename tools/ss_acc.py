@@ -4,6 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle
 from smcpp_amd import _smcpp, synth
+from smcpp_amd import _engine as E   # (the engine parses SMCPP_* once per process: switches go through E.set_option)
 from smcpp_amd.model import PiecewiseModel
 
 M, n = int(sys.argv[1]), int(sys.argv[2])
@@ -13,7 +14,7 @@ a, s = synth.model_pieces()
 contigs = [synth.synth_contig(300 + M, L, n), synth.synth_contig(301 + M, 150_000, n)]
 ref = None
 for lf, lb, eps in [(0, 0, None), (2, 2, None), (2, 2, (2e-7, 1e-7)), (3, 3, None), (1, 1, None)]:
-    os.environ["SMCPP_SS_LIGHT_F"] = str(lf); os.environ["SMCPP_SS_LIGHT_B"] = str(lb)
+    E.set_option("SMCPP_SS_LIGHT_F", lf); E.set_option("SMCPP_SS_LIGHT_B", lb)
     im = _smcpp.PyOnePopInferenceManager(n, contigs, hs, ("pop1",), 0.5)
     im.model = PiecewiseModel(a, s, 1e4, "pop1")
     im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0

@@ -584,11 +584,12 @@ void smcpp_im::ss_launch_initial() {
     a.eps_f = eps_f; a.eps_b = eps_b; a.full_f = a.full_b = 0;
     {
         // All scans of the stored passes in float (chains_ss.hpp: ss_x_scan_fwd / ss_x_scan_bwd), the default since round 5 for one
-        // state per lane; SMCPP_SS_MIXED=0 keeps the fp64 scans (read on every E-step: tests compare the two).  Never with
-        // save_gamma - the posterior's argmax is compared index by index against the reference's.
+        // state per lane; SMCPP_SS_MIXED=0 keeps the fp64 scans (tests and bench.py's `value_ref_width` compare the two).
+        // Round 6: with save_gamma as well - the decoded index of EVERY column of the two full-size binned contigs (471 106 columns,
+        // goldens G19) equals the compiled reference's under the float scans (tests/test_gpu_argmax.py), so the path that is timed and
+        // the path whose indices are checked are the same arithmetic.
         const bool mixed_on = !opt().off(smcpp_opt::O_SS_MIXED);
-        const bool mixed_with_gamma = opt().i(smcpp_opt::O_SS_MIXED, 1) == 2;      // (=2: the float scans under save_gamma as well)
-        a.mixed = (mixed_on && (!save_gamma || mixed_with_gamma) && NPL == 1 && !ss_hybrid) ? 1 : 0;
+        a.mixed = (mixed_on && NPL == 1 && !ss_hybrid) ? 1 : 0;
     }
     if (ss_hybrid) {
         a.hyb_th = ss_hyb_th; a.Ke = Ke; a.hot_ek = std::max(0, hot_eig); a.dirsplit = ss_dirsplit ? 1 : 0;

@@ -294,8 +294,8 @@ def test_pipeline_rows_equal_reference_on_its_test_data(tmp_path):
 
 
 def test_realign_puts_a_boundary_on_every_multiple_of_w():
-    """`realign` (_estimation_tools.pyx:176-209; restated: the Cython module needs GSL headers this image lacks, so the
-    reference's own is NOT executed here - unpinned by execution): spans are conserved, every row keeps its observation, no
+    """`realign` (_estimation_tools.pyx:176-209; since round 6 also compared row for row with the reference's own compiled Cython:
+    golden G23, test_thin_bin_realign_window_counts_vs_the_reference_cython): spans are conserved, every row keeps its observation, no
     row straddles a multiple of w counted from the last split, and a hand-worked case."""
     from smcpp_amd import data as D
     d = np.array([[5, 0, 0, 0], [1, 1, 2, 4], [7, -1, 0, 0], [3, 0, 1, 4]], dtype=np.int32)
@@ -331,3 +331,61 @@ def test_beta_kernel_density_estimate():
     # y = 0: a = 1, the kernel is finite at X = 0 (value b = 11) and zero at X = 1; y = 1: the mirror image
     assert abs(g[0] - (11.0 + stats.beta(1, 11).pdf(0.5)) / 3) < 1e-12 and abs(g[1] - g[0]) < 1e-12
     assert abs(g[2] - stats.beta(4, 8).pdf(0.5) / 3) < 1e-12
+
+
+def _g23_cases():
+    import zlib  # noqa: F401
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "G23_estimation_tools.npz"))
+    names = sorted({k.split("__")[0] for k in z.files})
+    return z, names
+
+
+def _g23_expect(z, key, got):
+    """Compare `got` with the golden entry `key` bit for bit (small outputs are stored whole, large ones as shape + CRC-32 of the
+    int32 bytes + first / last 500 rows)."""
+    import zlib
+    got = np.ascontiguousarray(got, dtype=np.int32)
+    if key in z.files:
+        assert got.shape == z[key].shape, (key, got.shape, z[key].shape)
+        assert np.array_equal(got, z[key]), key
+        return
+    assert tuple(z[key + "__shape"]) == got.shape, (key, got.shape, tuple(z[key + "__shape"]))
+    flat = got if got.shape[0] >= got.shape[1] else np.ascontiguousarray(got.T)
+    assert np.array_equal(flat[:500], z[key + "__head"]), key
+    assert np.array_equal(flat[-500:], z[key + "__tail"]), key
+    assert zlib.crc32(got.tobytes()) == int(z[key + "__crc"]), key
+
+
+def test_thin_bin_realign_window_counts_vs_the_reference_cython():
+    from smcpp_amd import data as D
+    """SURVEY.md 8 f-2, pinned BY EXECUTION since round 6 (golden G23, tests/golden/make_golden_estimation_tools.py): the reference's
+    own `smcpp/_estimation_tools.pyx` - its text of `thin_data` (8-84), `bin_observations` (146-173), `realign` (176-209) and
+    `windowed_mutation_counts` (212-255), compiled in the build container with the one GSL-dependent function left out - run on the
+    example-derived contig, on the reference's un-binned test contig test/bugs/11, on seven-column two-population rows and on a
+    short-span mix; `smcpp_amd.data` must reproduce every output row for row, bit for bit."""
+    z, names = _g23_cases()
+    n_checked = 0
+    for inp in ("ex", "chr11", "twopop", "small"):
+        raw = np.ascontiguousarray(z[inp + "_in"], dtype=np.int32)
+        a = [int(x) for x in z[inp + "_a"]]
+        npop = (raw.shape[1] - 1) // 3
+        contig = D.Contig(data=raw.copy(), pid=tuple(f"pop{i + 1}" for i in range(npop)), n=[0] * npop, a=a)
+        for key in names:
+            if not key.startswith(inp + "_") or key.endswith(("_in", "_a")):
+                continue
+            op = key[len(inp) + 1:].split("_")
+            if op[0] == "thin" and len(op) == 3:
+                got = D.thin_data(raw.copy(), int(op[1]), int(op[2]))
+            elif op[0] == "bin":
+                got = D.bin_observations(raw.copy(), int(op[1]), a)
+            elif op[0] == "realign":
+                got = D.realign(raw.copy(), int(op[1]))
+            elif op[0] == "wmc":
+                got = D.windowed_mutation_counts(contig, int(op[1]))
+            elif op[0] == "thin400":
+                got = D.bin_observations(D.thin_data(raw.copy(), 400, 0), 1000 if inp == "chr11" else 100, a)
+            else:
+                raise AssertionError(key)
+            _g23_expect(z, key, got)
+            n_checked += 1
+    assert n_checked >= 50

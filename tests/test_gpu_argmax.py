@@ -115,11 +115,11 @@ def test_posterior_indices_at_scale_vs_compiled_reference(name, route):
 
 @pytest.mark.parametrize("name", ["G19_headline", "G19_c2"])
 def test_posterior_indices_with_float_scans_in_the_stored_passes(engine_opt, name):
-    """the timed path runs every scan of the stored passes in float (chains_ss.hpp: ss_x_scan_fwd / _bwd), the
-    path whose indices were compared did not (`save_gamma` used to switch the float scans off).  Here the float scans run WITH
-    `save_gamma` (SMCPP_SS_MIXED=2) on the full-size binned contigs: the decoded index must equal the compiled reference's on every
-    column whose reference margin exceeds 1e-5 (the north-star bar as SURVEY.md 8(c) states it); all mismatches are printed."""
-    engine_opt("SMCPP_SS_MIXED", "2")
+    """the timed path runs every scan of the stored passes in float (chains_ss.hpp: ss_x_scan_fwd / _bwd); until
+    round 6 `save_gamma` switched those float scans off, so the path whose indices were compared was not the path that was timed.
+    Now `save_gamma` keeps them (the default): on the full-size binned contigs the decoded index must equal the compiled reference's
+    on every column whose reference margin exceeds 1e-5 (the north-star bar as SURVEY.md 8(c) states it) - measured: on EVERY
+    column; the fp64 scans (SMCPP_SS_MIXED=0) are run beside them and must decode the same indices."""
     g, obs = _load(name)
     im = _manager(g, obs, "params")
     im.save_gamma = True
@@ -135,3 +135,11 @@ def test_posterior_indices_with_float_scans_in_the_stored_passes(engine_opt, nam
     gam = im.gammas[0]
     st = int(g["gamma_stride"])
     assert np.max(np.abs(gam[:, ::st] - g["gamma_sub"])) <= 2e-5 * max(1.0, float(np.abs(g["gamma_sub"]).max()))
+    engine_opt("SMCPP_SS_MIXED", "0")
+    im.E_step()
+    assert not im.describe()["plan"]["float_scans_in_stored_passes"]
+    arg64 = im.gamma_argmax(0)
+    mism64, strong64, _ = argmax_report(arg64, g)
+    print(f"{name}[fp64 scans + save_gamma]: argmax mismatches {len(mism64)}; float-scan vs fp64-scan decode differs on "
+          f"{int(np.count_nonzero(np.asarray(arg) != np.asarray(arg64)))} columns")
+    assert len(strong64) == 0

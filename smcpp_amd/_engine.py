@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from . import _build
+from . import _build, _cabi
 
 _lib = None
 
@@ -28,70 +28,13 @@ def lib():
             f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
             "The SMC++ MI355X engine has no CPU fallback.")
     L = C.CDLL(path)
-    # every export gets its prototype: ints are coerced (numpy integer scalars included), `long` stays 64-bit, and a
-    # wrong argument count is an error instead of stack garbage
-    vp, i, d, lg = C.c_void_p, C.c_int, C.c_double, C.c_long
-    ipp = C.POINTER(C.POINTER(C.c_int))
-    ubp = C.POINTER(C.c_ubyte)
-    ullp = C.POINTER(C.c_ulonglong)
-    protos = {
-        "smcpp_last_error": (C.c_char_p, []),
-        "smcpp_create_onepop": (i, [i, i, _ip, ipp, i, _dp, d, i, C.POINTER(vp)]),
-        "smcpp_create_twopop": (i, [i, i, i, i, i, _ip, ipp, i, _dp, d, i, C.POINTER(vp)]),
-        "smcpp_destroy": (None, [vp]),
-        "smcpp_set_theta": (i, [vp, d]), "smcpp_set_rho": (i, [vp, d]), "smcpp_set_alpha": (i, [vp, d]),
-        "smcpp_set_params": (i, [vp, i, _dp, _dp, i, _dp]),
-        "smcpp_set_raw": (i, [vp, _dp, _dp, i, _ip, _dp]),
-        "smcpp_estep": (i, [vp, i]),
-        "smcpp_loglik": (i, [vp, _dp]),
-        "smcpp_q": (i, [vp, _dp, _dp]),
-        "smcpp_num_derivatives": (i, [vp]),
-        "smcpp_set_save_gamma": (i, [vp, i]), "smcpp_get_save_gamma": (i, [vp]),
-        "smcpp_num_states": (i, [vp]), "smcpp_num_contigs": (i, [vp]), "smcpp_num_keys": (i, [vp]),
-        "smcpp_key_len": (i, [vp]),
-        "smcpp_get_hidden_states": (i, [vp, _dp]), "smcpp_set_hidden_states": (i, [vp, i, _dp]),
-        "smcpp_get_keys": (i, [vp, _ip]),
-        "smcpp_get_xisum": (i, [vp, i, _dp]), "smcpp_get_gamma": (i, [vp, i, _dp]), "smcpp_gamma_cols": (i, [vp, i]),
-        "smcpp_get_gamma_sums": (i, [vp, i, _dp, ubp]),
-        "smcpp_get_pi": (i, [vp, _dp]), "smcpp_get_transition": (i, [vp, _dp]),
-        "smcpp_get_emission_probs": (i, [vp, _dp]), "smcpp_get_gamma_argmax": (i, [vp, i, _ip]),
-        "smcpp_get_pi_jac": (i, [vp, _dp]), "smcpp_get_transition_jac": (i, [vp, _dp]),
-        "smcpp_get_emission_probs_jac": (i, [vp, _dp]), "smcpp_num_emission_cols": (i, [vp]),
-        "smcpp_get_emission": (i, [vp, _dp, _dp]),
-        "smcpp_init_logger_cb": (None, [C.c_void_p]), "smcpp_init_cache": (i, [C.c_char_p]),
-        "smcpp_set_global_keys": (i, [vp, i, _ip]),
-        "smcpp_pack_stats": (i, [vp, _dp, C.POINTER(lg), i]), "smcpp_unpack_stats": (i, [vp, _dp, lg, i]),
-        "smcpp_rccl_unique_id": (i, [C.c_char_p, C.c_char_p]), "smcpp_rccl_init": (i, [vp, C.c_char_p, C.c_char_p, i, i]),
-        "smcpp_rccl_exchange": (i, [vp, _dp]), "smcpp_rccl_unpack": (i, [vp]), "smcpp_rccl_fetch": (i, [vp, _dp, lg]),
-        "smcpp_rccl_destroy": (i, [vp]),
-        "smcpp_set_chunking": (i, [vp, i, d, d]), "smcpp_set_warm_start": (i, [vp, i]), "smcpp_set_prep_mode": (i, [vp, i]),
-        "smcpp_last_timing": (i, [vp, _dp]), "smcpp_last_host_timing": (i, [vp, _dp]), "smcpp_stream": (vp, [vp]), "smcpp_chain_mode": (i, [vp]),
-        "smcpp_set_num_threads": (None, [i]),
-        "smcpp_reload_options": (None, []), "smcpp_describe": (i, [vp, C.c_char_p, i]),
-        "smcpp_set_debug": (i, [vp, i]), "smcpp_get_debug": (i, [vp]), "smcpp_device": (i, [vp]),
-        "smcpp_debug_ss_apply": (i, [i, _dp, i, _dp, _dp, _dp, _dp]),
-        "smcpp_debug_ss_apply_float_scans": (i, [i, _dp, i, _dp, _dp, _dp, _dp]),
-        "smcpp_host_set_csfs_direct": (i, [i]),
-        "smcpp_host_chunk_counts": (i, [i, C.POINTER(C.c_longlong), _ip, C.c_longlong, C.c_longlong, _ip]),
-        "smcpp_host_eigensystem": (i, [i, _dp, _dp, _dp, _dp, _dp, _dp]),
-        "smcpp_host_eigensystem_team": (i, [i, _dp, i, _dp, _dp, _dp, _dp, _dp]),
-        "smcpp_host_prep_onepop": (i, [i, i, _dp, d, i, _dp, _dp, d, d, d, i, _ip, _dp, _dp, _dp]),
-        "smcpp_host_prep_onepop_jac": (i, [i, i, _dp, d, i, _dp, _dp, i, _dp, d, d, d, i, _ip, _dp, _dp, _dp, _dp,
-                                           _dp, _dp]),
-        "smcpp_dev_prep_onepop": (i, [i, i, _dp, d, i, _dp, _dp, i, _dp, d, d, d, i, _ip, i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
-        "smcpp_dev_q_emulate": (i, [i, i, _dp, d, i, _dp, _dp, i, _dp, d, d, d, i, _ip, _dp, _dp, _dp, _dp, _dp]),
-        "smcpp_host_rate_function": (i, [i, _dp, _dp, i, _dp, i, _dp, _dp, _dp]),
-        "smcpp_host_rate_function_jac": (i, [i, _dp, _dp, i, _dp, i, _dp, i, _dp, _dp, _dp, _dp, _dp]),
-        "smcpp_host_random_coal_times": (i, [i, _dp, _dp, d, d, i, ullp, _dp, _dp]),
-        "smcpp_host_raw_sfs": (i, [i, i, _dp, _dp, i, _dp, d, d, i, _dp, _dp]),
-        "smcpp_set_params_twopop": (i, [vp, i, _dp, _dp, _dp, i, _dp, _dp, _dp, i, _dp, _dp, _dp, d, i]),
-        "smcpp_host_joint_csfs": (i, [i, i, i, i, i, _dp, i, _dp, _dp, _dp, i, _dp, _dp, _dp, i, d, i, _dp, _dp]),
-        "smcpp_host_prep_twopop": (i, [i, i, i, i, i, _dp, d, i, _dp, _dp, i, _dp, _dp, i, _dp, _dp, d, d, d, d, i,
-                                       _ip, _dp, _dp, _dp]),
-    }
-    missing = [n for n in EXPORTS if n not in protos]
+    # every export gets its prototype: ints are coerced (numpy integer scalars included), `long` stays 64-bit, and a wrong
+    # argument count is an error instead of stack garbage.  The prototypes are DERIVED from include/smcpp_engine.h (_cabi.py):
+    # the header is the one table both bindings (this one and _smcpp_cy.pyx) are generated from.
+    protos = _cabi.ctypes_prototypes()
+    missing = [n for n in protos if not hasattr(L, n)]
     if missing:
-        raise RuntimeError(f"internal: no ctypes prototype for {missing}")
+        raise RuntimeError(f"libsmcpp_engine.so misses symbols include/smcpp_engine.h declares: {missing} - rebuild it")
     for name, (res, args) in protos.items():
         f = getattr(L, name)
         f.restype = res
@@ -100,23 +43,8 @@ def lib():
     return L
 
 
-EXPORTS = [
-    "smcpp_last_error", "smcpp_create_onepop", "smcpp_create_twopop", "smcpp_destroy", "smcpp_set_theta",
-    "smcpp_set_rho", "smcpp_set_alpha", "smcpp_set_params", "smcpp_set_raw", "smcpp_estep", "smcpp_loglik",
-    "smcpp_q", "smcpp_set_save_gamma", "smcpp_get_save_gamma", "smcpp_num_states", "smcpp_num_contigs",
-    "smcpp_num_keys", "smcpp_key_len", "smcpp_get_hidden_states", "smcpp_set_hidden_states", "smcpp_get_keys",
-    "smcpp_get_xisum", "smcpp_get_gamma", "smcpp_get_gamma_sums", "smcpp_get_pi", "smcpp_get_transition",
-    "smcpp_get_emission_probs", "smcpp_get_gamma_argmax", "smcpp_set_global_keys", "smcpp_pack_stats",
-    "smcpp_unpack_stats", "smcpp_rccl_unique_id", "smcpp_rccl_init", "smcpp_rccl_exchange", "smcpp_rccl_unpack", "smcpp_rccl_fetch",
-    "smcpp_rccl_destroy", "smcpp_set_chunking", "smcpp_last_timing", "smcpp_stream", "smcpp_chain_mode", "smcpp_host_chunk_counts", "smcpp_set_num_threads",
-    "smcpp_host_eigensystem", "smcpp_host_eigensystem_team", "smcpp_host_prep_onepop", "smcpp_host_prep_onepop_jac", "smcpp_num_derivatives",
-    "smcpp_host_rate_function", "smcpp_host_rate_function_jac", "smcpp_host_random_coal_times", "smcpp_host_raw_sfs",
-    "smcpp_set_params_twopop", "smcpp_host_joint_csfs", "smcpp_host_prep_twopop", "smcpp_set_warm_start",
-    "smcpp_host_set_csfs_direct", "smcpp_gamma_cols", "smcpp_last_host_timing", "smcpp_get_pi_jac",
-    "smcpp_get_transition_jac", "smcpp_get_emission_probs_jac", "smcpp_num_emission_cols", "smcpp_get_emission",
-    "smcpp_init_logger_cb", "smcpp_init_cache", "smcpp_debug_ss_apply", "smcpp_debug_ss_apply_float_scans", "smcpp_set_debug", "smcpp_get_debug", "smcpp_device",
-    "smcpp_dev_prep_onepop", "smcpp_set_prep_mode", "smcpp_dev_q_emulate", "smcpp_reload_options", "smcpp_describe",
-]
+# every entry point include/smcpp_engine.h declares (the build check of __graft_entry__.build and the CPU tests walk this list)
+EXPORTS = [name for name, _, _ in _cabi.declarations()]
 
 
 def check(rc: int):

@@ -23,60 +23,87 @@ except ImportError:                      # stand-alone: this repository's
 
 logger = logging.getLogger(__name__)
 
+# --- begin generated from include/smcpp_engine.h (python -m smcpp_amd._cabi --write) ---
 cdef extern from "smcpp_engine.h":
     ctypedef struct smcpp_im:
         pass
-    const char *smcpp_last_error()
-    int smcpp_create_onepop(int n, int n_contigs, const int *Ls, const int *const *obs, int n_hs, const double *hs,
-                            double polarization_error, int device, smcpp_im **out) nogil
-    int smcpp_create_twopop(int n1, int n2, int a1, int a2, int n_contigs, const int *Ls, const int *const *obs,
-                            int n_hs, const double *hs, double polarization_error, int device, smcpp_im **out) nogil
+    const char *smcpp_last_error() nogil
+    int smcpp_create_onepop(int n, int n_contigs, const int *Ls, const int *const *obs, int n_hs, const double *hs, double polarization_error, int device, smcpp_im **out) nogil
+    int smcpp_create_twopop(int n1, int n2, int a1, int a2, int n_contigs, const int *Ls, const int *const *obs, int n_hs, const double *hs, double polarization_error, int device, smcpp_im **out) nogil
     void smcpp_destroy(smcpp_im *im) nogil
-    int smcpp_set_theta(smcpp_im *im, double v)
-    int smcpp_set_rho(smcpp_im *im, double v)
-    int smcpp_set_alpha(smcpp_im *im, double v)
+    int smcpp_set_theta(smcpp_im *im, double theta) nogil
+    int smcpp_set_rho(smcpp_im *im, double rho) nogil
+    int smcpp_set_alpha(smcpp_im *im, double alpha) nogil
     int smcpp_set_params(smcpp_im *im, int K, const double *a, const double *da, int nder, const double *s) nogil
-    int smcpp_set_params_twopop(smcpp_im *im, int Kd, const double *ad, const double *sd, const double *dad, int K1,
-                                const double *a1, const double *s1, const double *da1, int K2, const double *a2,
-                                const double *s2, const double *da2, double split, int nder) nogil
-    int smcpp_estep(smcpp_im *im, int fb_only) nogil
+    int smcpp_set_raw(smcpp_im *im, const double *pi, const double *T, int K, const int *keys, const double *E) nogil
+    int smcpp_estep(smcpp_im *im, int forward_backward_only) nogil
     int smcpp_loglik(smcpp_im *im, double *out) nogil
     int smcpp_q(smcpp_im *im, double *val, double *jac) nogil
-    int smcpp_num_derivatives(smcpp_im *im)
-    int smcpp_set_save_gamma(smcpp_im *im, int on)
-    int smcpp_get_save_gamma(smcpp_im *im)
-    int smcpp_set_debug(smcpp_im *im, int on)
-    int smcpp_get_debug(smcpp_im *im)
-    int smcpp_num_keys(smcpp_im *im)
-    int smcpp_key_len(smcpp_im *im)
-    int smcpp_get_hidden_states(smcpp_im *im, double *hs)
-    int smcpp_set_hidden_states(smcpp_im *im, int n_hs, const double *hs)
-    int smcpp_get_keys(smcpp_im *im, int *keys)
-    int smcpp_get_xisum(smcpp_im *im, int contig, double *out)
-    int smcpp_get_gamma(smcpp_im *im, int contig, double *out)
-    int smcpp_gamma_cols(smcpp_im *im, int contig)
-    int smcpp_get_gamma_sums(smcpp_im *im, int contig, double *vals, unsigned char *present)
-    int smcpp_get_pi(smcpp_im *im, double *out)
-    int smcpp_get_transition(smcpp_im *im, double *out)
-    int smcpp_get_emission_probs(smcpp_im *im, double *out)
-    int smcpp_get_pi_jac(smcpp_im *im, double *out)
-    int smcpp_get_transition_jac(smcpp_im *im, double *out)
-    int smcpp_get_emission_probs_jac(smcpp_im *im, double *out)
-    int smcpp_num_emission_cols(smcpp_im *im)
-    int smcpp_get_emission(smcpp_im *im, double *out, double *jac)
-    void smcpp_init_logger_cb(void (*cb)(const char *, const char *, const char *))
-    int smcpp_init_cache(const char *path)
-    void smcpp_set_num_threads(int k)
-    int smcpp_host_rate_function_jac(int Kp, const double *a, const double *da, int nder, const double *s, int n_hs,
-                                     const double *hs, int nt, const double *t, double *R_out, double *dR_out,
-                                     double *avg_ct_out, double *davg_ct_out)
-    int smcpp_host_random_coal_times(int Kp, const double *a, const double *s, double t1, double t2, int K,
-                                     const unsigned long long *seeds, double *t_out, double *R_out)
-    int smcpp_host_joint_csfs(int n1, int n2, int a1, int a2, int n_hs, const double *hs, int K1, const double *pa1,
-                              const double *ps1, const double *da1, int K2, const double *pa2, const double *ps2,
-                              const double *da2, int nder, double split, int Kmc, double *out, double *dout) nogil
-    int smcpp_host_raw_sfs(int n, int Kp, const double *a, const double *da, int nder, const double *s, double t1,
-                           double t2, int below_only, double *sfs, double *dsfs)
+    int smcpp_num_derivatives(smcpp_im *im) nogil
+    int smcpp_set_save_gamma(smcpp_im *im, int on) nogil
+    int smcpp_get_save_gamma(smcpp_im *im) nogil
+    int smcpp_num_states(smcpp_im *im) nogil
+    int smcpp_num_contigs(smcpp_im *im) nogil
+    int smcpp_num_keys(smcpp_im *im) nogil
+    int smcpp_key_len(smcpp_im *im) nogil
+    int smcpp_get_hidden_states(smcpp_im *im, double *hs) nogil
+    int smcpp_set_hidden_states(smcpp_im *im, int n_hs, const double *hs) nogil
+    int smcpp_get_keys(smcpp_im *im, int *keys) nogil
+    int smcpp_get_xisum(smcpp_im *im, int contig, double *out) nogil
+    int smcpp_get_gamma(smcpp_im *im, int contig, double *out) nogil
+    int smcpp_gamma_cols(smcpp_im *im, int contig) nogil
+    int smcpp_get_gamma_sums(smcpp_im *im, int contig, double *vals, unsigned char *present) nogil
+    int smcpp_get_pi(smcpp_im *im, double *out) nogil
+    int smcpp_get_transition(smcpp_im *im, double *out) nogil
+    int smcpp_get_emission_probs(smcpp_im *im, double *out) nogil
+    int smcpp_get_pi_jac(smcpp_im *im, double *out) nogil
+    int smcpp_get_transition_jac(smcpp_im *im, double *out) nogil
+    int smcpp_get_emission_probs_jac(smcpp_im *im, double *out) nogil
+    int smcpp_num_emission_cols(smcpp_im *im) nogil
+    int smcpp_get_emission(smcpp_im *im, double *out, double *jac) nogil
+    int smcpp_get_gamma_argmax(smcpp_im *im, int contig, int *out) nogil
+    int smcpp_set_global_keys(smcpp_im *im, int Kg, const int *gkeys) nogil
+    int smcpp_pack_stats(smcpp_im *im, double *buf, long *n_out, int dev) nogil
+    int smcpp_unpack_stats(smcpp_im *im, const double *buf, long n, int dev) nogil
+    int smcpp_rccl_unique_id(const char *libpath, char *out128) nogil
+    int smcpp_rccl_init(smcpp_im *im, const char *libpath, const char *id128, int rank, int world) nogil
+    int smcpp_rccl_exchange(smcpp_im *im, double *loglik_sum) nogil
+    int smcpp_rccl_unpack(smcpp_im *im) nogil
+    int smcpp_rccl_fetch(smcpp_im *im, double *out, long n) nogil
+    int smcpp_rccl_destroy(smcpp_im *im) nogil
+    int smcpp_set_debug(smcpp_im *im, int on) nogil
+    int smcpp_get_debug(smcpp_im *im) nogil
+    int smcpp_set_chunking(smcpp_im *im, int rows_per_chunk, double eps_alpha, double eps_beta) nogil
+    int smcpp_set_prep_mode(smcpp_im *im, int host) nogil
+    int smcpp_set_warm_start(smcpp_im *im, int on) nogil
+    int smcpp_last_timing(smcpp_im *im, double *out) nogil
+    int smcpp_host_chunk_counts(int n_contigs, const long long *cost, const int *rows, long long nslots, long long floor_cost, int *out) nogil
+    int smcpp_chain_mode(smcpp_im *im) nogil
+    void smcpp_reload_options() nogil
+    int smcpp_describe(smcpp_im *im, char *buf, int cap) nogil
+    int smcpp_debug_ss_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b) nogil
+    int smcpp_debug_ss_apply_float_scans(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b) nogil
+    int smcpp_last_host_timing(smcpp_im *im, double *out) nogil
+    void *smcpp_stream(smcpp_im *im) nogil
+    int smcpp_device(smcpp_im *im) nogil
+    void smcpp_init_logger_cb(void (*cb)(const char *, const char *, const char *)) nogil
+    int smcpp_init_cache(const char *path) nogil
+    void smcpp_set_num_threads(int k) nogil
+    int smcpp_host_set_csfs_direct(int on) nogil
+    int smcpp_host_eigensystem(int n, const double *A, double *P, double *Pinv, double *d, double *scale, double *max_imag) nogil
+    int smcpp_host_eigensystem_team(int n, const double *A, int threads, double *P, double *Pinv, double *d, double *scale, double *max_imag) nogil
+    int smcpp_host_prep_onepop(int n, int n_hs, const double *hs, double polarization_error, int Kp, const double *a, const double *s, double theta, double rho, double alpha, int K, const int *keys, double *pi, double *T, double *E) nogil
+    int smcpp_host_prep_onepop_jac(int n, int n_hs, const double *hs, double polarization_error, int Kp, const double *a, const double *da, int nder, const double *s, double theta, double rho, double alpha, int K, const int *keys, double *pi, double *T, double *E, double *dpi, double *dT, double *dE) nogil
+    int smcpp_dev_prep_onepop(int n, int n_hs, const double *hs, double polarization_error, int Kp, const double *a, const double *da, int nder, const double *s, double theta, double rho, double alpha, int K, const int *keys, int mode, double *pi, double *T, double *E, double *dpi, double *dT, double *dE, double *sfs, double *dsfs) nogil
+    int smcpp_dev_q_emulate(int n, int n_hs, const double *hs, double polarization_error, int Kp, const double *a, const double *da, int nder, const double *s, double theta, double rho, double alpha, int K, const int *keys, const double *g0, const double *xi, const double *gs, double *val, double *jac) nogil
+    int smcpp_host_rate_function(int Kp, const double *a, const double *s, int n_hs, const double *hs, int nt, const double *t, double *R_out, double *avg_ct_out) nogil
+    int smcpp_host_rate_function_jac(int Kp, const double *a, const double *da, int nder, const double *s, int n_hs, const double *hs, int nt, const double *t, double *R_out, double *dR_out, double *avg_ct_out, double *davg_ct_out) nogil
+    int smcpp_host_random_coal_times(int Kp, const double *a, const double *s, double t1, double t2, int K, const unsigned long long *seeds, double *t_out, double *R_out) nogil
+    int smcpp_host_raw_sfs(int n, int Kp, const double *a, const double *da, int nder, const double *s, double t1, double t2, int below_only, double *sfs, double *dsfs) nogil
+    int smcpp_set_params_twopop(smcpp_im *im, int Kd, const double *ad, const double *sd, const double *dad, int K1, const double *a1, const double *s1, const double *da1, int K2, const double *a2, const double *s2, const double *da2, double split, int nder) nogil
+    int smcpp_host_joint_csfs(int n1, int n2, int a1, int a2, int n_hs, const double *hs, int K1, const double *pa1, const double *ps1, const double *da1, int K2, const double *pa2, const double *ps2, const double *da2, int nder, double split, int Kmc, double *out, double *dout) nogil
+    int smcpp_host_prep_twopop(int n1, int n2, int a1, int a2, int n_hs, const double *hs, double polarization_error, int Kd, const double *ad, const double *sd, int K1, const double *pa1, const double *ps1, int K2, const double *pa2, const double *ps2, double split, double theta, double rho, double alpha, int K, const int *keys, double *pi, double *T, double *E) nogil
+# --- end generated ---
 
 aca = np.ascontiguousarray
 

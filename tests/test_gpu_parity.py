@@ -836,7 +836,13 @@ def test_rank_partials_by_teams_of_four_slabs_vs_one_per_slab(engine_opt):
             g = load_golden(name)
             im = make_im(g)
             im.E_step()
-            check_against(g, im, save_gamma=False)
+            try:
+                check_against(g, im, save_gamma=False)
+            except AssertionError:
+                print("DEBUG", name, team, im.describe(), im.last_timing(), im.logliks())
+                im.E_step(); print("DEBUG second E-step", im.logliks(), im.describe()["plan"])
+                im2 = make_im(g); im2.E_step(); print("DEBUG second manager", im2.logliks(), im2.describe()["plan"])
+                raise
             res[(team, name)] = (im.gamma_sums[0], im.xisums[0])
         # four states per lane (config C5's slice, golden G14 from the compiled reference): the span-1 rank update in its M > 64 form
         im = _smcpp.PyOnePopInferenceManager(50, [np.ascontiguousarray(g5["obs"], dtype=np.int32)], p5["hs"], ("pop1",), float(p5["pol"]))
@@ -910,10 +916,13 @@ def test_span_fold_on_scans_vs_matrix_cores(engine_opt, M, n):
             assert rel_err(xs[c], o["xisum"]) <= STAT_TOL, scan
             for k, v in o["gamma_sums"].items():
                 assert np.max(np.abs(gss[c][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300), (scan, k)
-        assert rel_err(res["1"][1][c], res["0"][1][c]) <= 1e-9
+        # (round 6: until the engine's switches were parsed through one table with an explicit reload, SMCPP_SPAN_SCAN was latched at
+        # its first read and both legs of this test ran the same fold; measured now that they differ: the largest PER-ENTRY relative
+        # difference of the xi sums is 1.1e-9 .. 1.5e-9 - entries of 1e-10 summed in two different orders - against 5e-6 to the oracle)
+        assert rel_err(res["1"][1][c], res["0"][1][c]) <= 1e-8
         for k, v in res["0"][2][c].items():
-            assert np.max(np.abs(res["1"][2][c][k] - v)) <= 1e-9 * max(np.abs(v).max(), 1e-300), k
-    assert np.all(np.abs(res["1"][3] - res["0"][3]) <= 1e-9 * np.maximum(np.abs(res["0"][3]), 1e-12))
+            assert np.max(np.abs(res["1"][2][c][k] - v)) <= 1e-8 * max(np.abs(v).max(), 1e-300), k
+    assert np.all(np.abs(res["1"][3] - res["0"][3]) <= 1e-8 * np.maximum(np.abs(res["0"][3]), 1e-12))
 
 
 @pytest.mark.parametrize("name", ["G7_M32_n8_chr11", "G18_M64_n8_chr11"])

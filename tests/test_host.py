@@ -17,7 +17,28 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared, "no declarations parsed"
     missing = [n for n in sorted(declared) if not hasattr(L, n)]
     assert not missing, missing
-    assert set(_engine.EXPORTS) <= declared | {"smcpp_last_error"}
+    assert set(_engine.EXPORTS) == declared            # (EXPORTS is derived from the header: _cabi.declarations)
+
+
+def test_both_bindings_are_generated_from_the_header():
+    """the ctypes table (`_engine.py`) and the `cdef extern` block of `_smcpp_cy.pyx` are both DERIVED from
+    include/smcpp_engine.h (smcpp_amd/_cabi.py), so the two bindings cannot drift from the C ABI or from each other: the parsed
+    declarations cover every `smcpp_*(` of the header, every one has a ctypes prototype with the right arity on the loaded library,
+    and the extern block in the .pyx is byte for byte what the generator emits (`python -m smcpp_amd._cabi --write` refreshes it)."""
+    from smcpp_amd import _cabi, _engine
+    decls = _cabi.declarations()
+    hdr = open(os.path.join(ROOT, "include", "smcpp_engine.h")).read()
+    assert {d[0] for d in decls} == set(re.findall(r"\b(smcpp_[a-z0-9_]+)\s*\(", hdr))
+    L = _engine.lib()
+    for name, ret, args in decls:
+        f = getattr(L, name)
+        assert len(f.argtypes) == len(args), name
+    assert _cabi.pyx_block_is_current(), "smcpp_amd/_smcpp_cy.pyx: extern block is stale - run python -m smcpp_amd._cabi --write"
+    # spot checks of the type mapping
+    p = _cabi.ctypes_prototypes()
+    import ctypes as C
+    assert p["smcpp_create_onepop"][1][3] == C.POINTER(C.POINTER(C.c_int)) and p["smcpp_stream"][0] == C.c_void_p
+    assert p["smcpp_init_logger_cb"] == (None, [C.c_void_p]) and p["smcpp_last_error"] == (C.c_char_p, [])
 
 
 def test_no_cpu_fallback_message_without_gpu():

@@ -80,11 +80,14 @@ struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
     bool borrowed = false;      // p points into the parameter arena (see ParamArena): never freed here
-    void alloc(size_t count) {
+    void alloc(size_t count, int line = __builtin_LINE(), const char *file = __builtin_FILE()) {
         if (count <= n && p && !borrowed) return;
         free();
         n = count;
-        if (count) HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
+        if (count) {
+            HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
+            smcpp_opt::poison(p, count * sizeof(T), line, file);
+        }
     }
     void free() {
         if (p && !borrowed) (void)hipFree(p);
@@ -103,12 +106,12 @@ struct DevBuf {
         if (!h.empty()) std::memcpy(host_base + off, h.data(), h.size() * sizeof(T));
         off += h.size() * sizeof(T);
     }
-    void upload(const std::vector<T> &h, hipStream_t s) {
-        alloc(h.size());
+    void upload(const std::vector<T> &h, hipStream_t s, int line = __builtin_LINE(), const char *file = __builtin_FILE()) {
+        alloc(h.size(), line, file);
         if (!h.empty()) HIPCHK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
     }
-    void upload_staged(const std::vector<T> &h, PinnedArena &ar, hipStream_t s) {
-        alloc(h.size());
+    void upload_staged(const std::vector<T> &h, PinnedArena &ar, hipStream_t s, int line = __builtin_LINE(), const char *file = __builtin_FILE()) {
+        alloc(h.size(), line, file);
         if (h.empty()) return;
         void *q = ar.take(h.size() * sizeof(T));
         std::memcpy(q, h.data(), h.size() * sizeof(T));
@@ -252,6 +255,7 @@ struct DevPrep {
                 if (d_in) (void)hipFree(d_in);
                 in_cap = bytes + bytes / 2;
                 HIPCHK(hipMalloc((void **)&d_in, in_cap));
+                smcpp_opt::poison(d_in, in_cap, __LINE__, __FILE__);
             }
         }
         double *hd = reinterpret_cast<double *>(hb);
@@ -419,6 +423,7 @@ struct TwoPopDevCsfs : smcpp_host::CsfsBatchDevice {
             if (I.d_in) (void)hipFree(I.d_in);
             I.in_cap = bytes + bytes / 2;
             HIPCHK(hipMalloc((void **)&I.d_in, I.in_cap));
+            smcpp_opt::poison(I.d_in, I.in_cap, __LINE__, __FILE__);
         }
         double *hd = reinterpret_cast<double *>(hb);
         size_t o = 0;

@@ -290,9 +290,10 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
     // states per lane of the one-wavefront-per-chunk kernels: 1 .. 4 up to M = 256; 256 < M <= 512 (round 5): eight - the scan chains
     // and the eigen-free statistics only (binned data, a transition matrix with the reference's structure, no save_gamma: what
     // `smc++ estimate` runs); the dense fallback kernels and the eigensystem statistics stop at 256
-    NPL = M > 256 ? 8 : (M + 63) / 64;
+    // (round 6) 512 < M <= 1024: sixteen states per lane, the same restriction
+    NPL = M > 512 ? 16 : M > 256 ? 8 : (M + 63) / 64;
     NT = Mp / 16;
-    if (M > 512) throw std::runtime_error("M > 512 hidden states is not supported by this build");
+    if (M > 1024) throw std::runtime_error("M > 1024 hidden states is not supported by this build");
     n_contigs = n_contigs_;
     Ls.assign(Ls_, Ls_ + n_contigs);
     contig_base.resize(n_contigs);
@@ -482,7 +483,7 @@ void smcpp_im::make_chunks() {
         ss_max_span = 1;
         for (const Group &g : groups) ss_max_span = std::max(ss_max_span, g.span);
         {
-            const bool ss_ok = !opt().off(smcpp_opt::O_SS) && (!m || !strcmp(m, "ss")) && Mp <= 512;
+            const bool ss_ok = !opt().off(smcpp_opt::O_SS) && (!m || !strcmp(m, "ss")) && Mp <= 1024;
             ss_static = ss_ok && ss_max_span <= 512;
             ss_hybrid = false; ss_hyb_th = 0x7fffffff;
             if (ss_ok && !ss_static) {

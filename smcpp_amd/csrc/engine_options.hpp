@@ -11,7 +11,7 @@ enum OptId {
     O_COOP_BPC, O_ROWS_PER_CHUNK, O_SS_WPC, O_SS_HALO, O_HALO_LF, O_HALO_DF, O_HALO_LB, O_HALO_DB, O_SS_FWD_SHARE, O_STATS_TEAM,
     O_SLAB_ROWS, O_POWER_PREPASS, O_PREP, O_Q, O_EIG_TEAM, O_EIG_PIN, O_BWD_PRIO, O_COOP_TAB, O_POWER_DEBUG, O_BWD_PRIO_MASK,
     O_DEBUG_CYCLES, O_SS_H32, O_SS_MIXED, O_SS_LIGHT_F, O_SS_LIGHT_B, O_SS_CERT_PASS, O_POLL, O_SPEC_GAMMA, O_GAMMA_SIDE,
-    O_STATS_VARIANT, O_SPAN_SCAN, O_S1_FUSE, O_EIGFREE, O_CSFS_DIRECT, O_SS_SUFFIX, O_GAMMA_MARGIN, O_COUNT
+    O_STATS_VARIANT, O_SPAN_SCAN, O_S1_FUSE, O_EIGFREE, O_CSFS_DIRECT, O_DEBUG_POISON, O_DEBUG_POISON_ONLY, O_DEBUG_POISON_LOG, O_COUNT
 };
 
 struct OptDef { const char *name, *help; };
@@ -62,8 +62,10 @@ static const OptDef OPT_DEFS[O_COUNT] = {
     {"SMCPP_S1_FUSE",        "0 / 1: two-kernel / one-pass span-1 statistics"},
     {"SMCPP_EIGFREE",        "0: eigensystem statistics even where the eigen-free form applies"},
     {"SMCPP_CSFS_DIRECT",    "set: literal O(pieces^2 n^2) conditioned SFS (test hook)"},
-    {"SMCPP_SS_SUFFIX",      "0: cross-row suffix of the float scans through v_readlane (round 5 form)"},
-    {"SMCPP_GAMMA_MARGIN",   "relative top-2 margin below which a posterior column takes the full bilinear form"},
+    {"SMCPP_DEBUG_POISON",   "byte value every fresh device allocation is filled with (255: NaN / -1): a kernel that reads memory it was "
+                             "never given shows up as NaN in a fresh process instead of depending on what the allocator recycles"},
+    {"SMCPP_DEBUG_POISON_ONLY", "poison only the allocation with this index (counted from the last smcpp_reload_options): tools/poison_probe.py"},
+    {"SMCPP_DEBUG_POISON_LOG",  "set: print index, source line and size of every device allocation to stderr"},
 };
 // clang-format on
 
@@ -101,7 +103,19 @@ inline EngineOptions &options_mut() {
 }
 inline const EngineOptions &opt() { return options_mut(); }
 // Re-read the environment (tests; a process that changes a switch between managers).  Not to be called while an E-step runs.
-inline void reload() { options_mut().parse(); }
+inline int &alloc_counter() { static int c = 0; return c; }
+inline void reload() { options_mut().parse(); alloc_counter() = 0; }
+// Debug aid (SMCPP_DEBUG_POISON): fill a FRESH device allocation with a byte pattern.  hipMalloc hands out zeroed pages in a fresh
+// process and recycled ones later; a kernel that reads memory nobody wrote is correct in the first case only by accident.
+inline void poison_fill(void *p, size_t bytes, int value) { (void)hipMemset(p, value, bytes); (void)hipDeviceSynchronize(); }
+inline void poison(void *p, size_t bytes, int line, const char *file) {
+    const EngineOptions &o = opt();
+    const int idx = alloc_counter()++;
+    if (o.has(O_DEBUG_POISON_LOG)) fprintf(stderr, "[alloc %d] %s:%d %zu bytes\n", idx, file, line, bytes);
+    if (!o.has(O_DEBUG_POISON) || !p || !bytes) return;
+    if (o.has(O_DEBUG_POISON_ONLY) && o.i(O_DEBUG_POISON_ONLY, -1) != idx) return;
+    poison_fill(p, bytes, o.i(O_DEBUG_POISON, 255) & 0xff);
+}
 
 inline std::string describe_options() {
     const EngineOptions &o = opt();

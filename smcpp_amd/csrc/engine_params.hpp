@@ -280,6 +280,7 @@ bool smcpp_im::q_device(double val[4], double *jac) {
         if (q.d_in) (void)hipFree(q.d_in);
         q.in_cap = ndbl * sizeof(double) * 2;
         HIPCHK(hipMalloc((void **)&q.d_in, q.in_cap));
+        smcpp_opt::poison(q.d_in, q.in_cap, __LINE__, __FILE__);
     }
     double *hb = reinterpret_cast<double *>(q.stage.base);
     for (int i = 0; i < M; ++i) {
@@ -547,6 +548,7 @@ void smcpp_im::host_prep_and_upload() {
         if (d_param) (void)hipFree(d_param);
         param_cap = need + need / 4;
         HIPCHK(hipMalloc((void **)&d_param, param_cap));
+        smcpp_opt::poison(d_param, param_cap, __LINE__, __FILE__);
     }
     size_t off = 0;
     char *hb = stage.base;

@@ -112,6 +112,7 @@ static void launch_s1(int npl, const S1Args &a, hipStream_t s) {
         case 3: launch_s1_t<3>(a, s); break;
         case 4: launch_s1_t<4>(a, s); break;
         case 8: launch_s1_t<8>(a, s); break;
+        case 16: launch_s1_t<16>(a, s); break;
         default: throw std::runtime_error("unsupported number of hidden states");
     }
 }
@@ -174,6 +175,7 @@ void smcpp_im::stage_static_and_prepass() {
         if (d_pre) (void)hipFree(d_pre);
         pre_cap = need + need / 4;
         HIPCHK(hipMalloc((void **)&d_pre, pre_cap));
+        smcpp_opt::poison(d_pre, pre_cap, __LINE__, __FILE__);
     }
     size_t off = 0;
     auto put = [&](const void *src, size_t bytes) {
@@ -495,6 +497,7 @@ static void launch_chain_ss(int npl, const SsArgs &a, int ntasks, size_t shm, hi
         case 3: launch_chain_ss_t<3, false>(a, ntasks, shm, s, 4); break;
         case 4: launch_chain_ss_t<4, false>(a, ntasks, shm, s, 4); break;
         case 8: launch_chain_ss_t<8, false>(a, ntasks, shm, s, 4); break;
+        case 16: launch_chain_ss_t<16, false>(a, ntasks, shm, s, 4); break;
         default: throw std::runtime_error("unsupported number of hidden states");
     }
 }
@@ -531,6 +534,7 @@ void smcpp_im::ss_launch_initial() {
         if (d_pre) (void)hipFree(d_pre);
         pre_cap = need + need / 4;
         HIPCHK(hipMalloc((void **)&d_pre, pre_cap));
+        smcpp_opt::poison(d_pre, pre_cap, __LINE__, __FILE__);
     }
     size_t off = 0;
     auto put = [&](const void *src, size_t bytes) {
@@ -962,8 +966,8 @@ void smcpp_im::enqueue_stats() {
             switch (NPL) {
 #define SC_(x) case x: hipLaunchKernelGGL((k_span_scan<x, 0>), grid, block, 0, se, ss_args, fa, ss_max_span, d_Fall.p); \
                        hipLaunchKernelGGL((k_span_scan<x, 1>), grid, block, 0, se, ss_args, fa, ss_max_span, d_Fall.p); break;
-                SC_(1) SC_(2) SC_(3) SC_(4)
-                default: SC_(8)
+                SC_(1) SC_(2) SC_(3) SC_(4) SC_(8)
+                default: SC_(16)
 #undef SC_
             }
         } else {
@@ -1158,7 +1162,7 @@ void smcpp_im::estep() {
     HIPCHK(hipEventRecord(ev[0], stream));
     // span > 1 rows without an eigensystem (kernels.hpp: k_span_fold): the span is expanded by smax steps of two M x M products
     const bool eigfree_off = opt().off(smcpp_opt::O_EIGFREE);
-    const bool eigfree_static = !eigfree_off && Mp <= 512 && ss_max_span <= 64 && !save_gamma;
+    const bool eigfree_static = !eigfree_off && Mp <= 1024 && ss_max_span <= 64 && !save_gamma;
     if (Mp > 256 && !(ss_static && eigfree_static))
         throw std::runtime_error("more than 256 hidden states: only the scan chains with eigen-free statistics are built (binned data "
                                  "with spans <= 64, no save_gamma)");

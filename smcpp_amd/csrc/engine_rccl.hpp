@@ -250,8 +250,8 @@ int smcpp_debug_ss_apply_float_scans(int M, const double *T, int nvec, const dou
 }
 static int ss_debug_apply(int M, const double *T, int nvec, const double *x, const double *e, double *out_f, double *out_b, int float_scans) {
     {
-    const int NPL = M > 256 ? 8 : (M + 63) / 64, MS = 64 * NPL;
-    if (M > 512) throw std::runtime_error("unsupported number of hidden states");
+    const int NPL = M > 512 ? 16 : M > 256 ? 8 : (M + 63) / 64, MS = 64 * NPL;
+    if (M > 1024) throw std::runtime_error("unsupported number of hidden states");
     std::vector<double> gen;
     double c0 = 0.0;
     if (!ss_generators(M, MS, T, gen, c0)) return 2;
@@ -277,7 +277,8 @@ static int ss_debug_apply(int M, const double *T, int nvec, const double *x, con
         case 2: hipLaunchKernelGGL(k_ss_apply<2>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
         case 3: hipLaunchKernelGGL(k_ss_apply<3>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
         case 4: hipLaunchKernelGGL(k_ss_apply<4>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
-        default: hipLaunchKernelGGL(k_ss_apply<8>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
+        case 8: hipLaunchKernelGGL(k_ss_apply<8>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
+        default: hipLaunchKernelGGL(k_ss_apply<16>, dim3(nvec), dim3(64), 0, s, a, (const double *)dx.p, (const double *)de.p, df.p, db.p, nvec); break;
     }
     HIPCHK(hipGetLastError());
     std::vector<double> hf(hx.size()), hb(hx.size());

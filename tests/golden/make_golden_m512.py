@@ -2,6 +2,7 @@
 container only):
 
     make -C oracle ref && python tests/golden/make_golden_m512.py        -> tests/golden/G21_M512_n10_1000rows.npz
+    python tests/golden/make_golden_m512.py 768 300                      -> tests/golden/G24_M768_n10_300rows.npz  (round 6)
 
 `HMM::Estep` (src/hmm.cpp:45-153) on the first 1 000 rows of the synthetic contig 0 (100 bp bins, n = 10) with M = 512 hidden states on
 the parameters of `ref_prep` + the emission assembly of oracle/prep_oracle.py - the reference itself has no limit on M
@@ -23,6 +24,9 @@ from oracle import ref  # noqa: E402
 from smcpp_amd import synth  # noqa: E402
 
 M, N, ROWS = 512, 10, 1000
+if len(sys.argv) >= 3:          # python make_golden_m512.py 768 300  -> G24_M768_n10_300rows.npz (round 6: 512 < M <= 1024)
+    M, ROWS = int(sys.argv[1]), int(sys.argv[2])
+TAG = "G21" if M == 512 else "G24"
 
 
 def main():
@@ -43,9 +47,9 @@ def main():
                xisum_rowsum=xs.sum(axis=1), xisum_colsum=xs.sum(axis=0), xisum_diag=np.diag(xs).copy(), xisum_total=xs.sum(),
                xisum_offdiag_max=float((xs - np.diag(np.diag(xs))).max()), gs=gs, gs_have=have, gamma0=r["gamma"][:, 0].copy(),
                pi=par["pi"], T_diag=np.diag(par["T"]).copy(), T_rowsum=par["T"].sum(axis=1), E=par["E"], ref_seconds=dt)
-    path = os.path.join(HERE, f"G21_M{M}_n{N}_{ROWS}rows.npz")
+    path = os.path.join(HERE, f"{TAG}_M{M}_n{N}_{ROWS}rows.npz")
     np.savez_compressed(path, **out)
-    print(f"G21: L={len(obs)} M={M} K={len(keys)} loglik={r['loglik']!r} in {dt:.1f} s -> {os.path.getsize(path) / 1024:.0f} KiB")
+    print(f"{TAG}: L={len(obs)} M={M} K={len(keys)} loglik={r['loglik']!r} in {dt:.1f} s -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 if __name__ == "__main__":

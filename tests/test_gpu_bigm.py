@@ -1,11 +1,12 @@
 """More than 256 hidden states (round 5: 256 < M <= 512 on the scan chains with eight states per lane and the eigen-free statistics;
-the reference has no limit, src/inference_manager.cpp:21-54).
+round 6: 512 < M <= 1024 with sixteen; the reference has no limit, src/inference_manager.cpp:21-54).
 
   * M = 300 on 1 200 rows and M = 512 on 160 rows of the synthetic contig against the C restatement of hmm.cpp (oracle/) fed with the
     engine's own prepared parameters, with chunks short enough that the chunk-parallel fixed point iterates (the restatement follows
     the reference's 2 M^3 flops per span > 1 row on one core: 2 000 rows at M = 512 would take minutes of the suite's time);
-  * M = 512 on 1 000 rows against golden G21 = the COMPILED reference (tests/golden/make_golden_m512.py), through `im.model = ...`:
-    the engine's own cold preparation on the device;
+  * M = 512 on 1 000 rows against golden G21 and M = 768 on 300 rows against golden G24 = the COMPILED reference
+    (tests/golden/make_golden_m512.py), through `im.model = ...`: the engine's own cold preparation on the device;
+  * M = 768 (70 rows) and M = 1024 (40 rows) against the C restatement;
   * what is not built beyond 256 fails loudly: save_gamma, a transition matrix without the reference's structure.
 """
 import os
@@ -19,6 +20,15 @@ pytestmark = pytest.mark.gpu
 
 LL_TOL = 1e-6
 STAT_TOL = 5e-6
+# 512 < M <= 1024 (round 6, sixteen states per lane): the per-entry tolerance of the statistics is 1e-5 there, observed 7.2e-6 on the
+# xi sums at M = 768 / 1024 against both the C restatement and the compiled reference.  The scan chains reproduce the reference's
+# feedback of the STORED float alpha through the diagonal of the operator only (chains_ss.hpp); the remainder is the float rounding
+# times the off-diagonal mass of T, which grows as the hidden states get narrower.  The log-likelihood bar (1e-6) is unchanged.
+STAT_TOL_WIDE = 1e-5
+
+
+def _stat_tol(M):
+    return STAT_TOL if M <= 512 else STAT_TOL_WIDE
 
 
 def _manager(M, n, obs, chunk=0):
@@ -33,7 +43,7 @@ def _manager(M, n, obs, chunk=0):
     return im
 
 
-@pytest.mark.parametrize("M,rows,chunk", [(300, 1200, 300), (512, 160, 60)])
+@pytest.mark.parametrize("M,rows,chunk", [(300, 1200, 300), (512, 160, 60), (768, 70, 30), (1024, 40, 18)])
 def test_more_than_256_states_vs_oracle(M, rows, chunk):
     from oracle import oracle
     from smcpp_amd import synth
@@ -48,23 +58,27 @@ def test_more_than_256_states_vs_oracle(M, rows, chunk):
     o = oracle.estep(im.pi, im.transition, keys, Etab, obs)
     ll = im.loglik()
     assert abs(ll - o["loglik"]) <= LL_TOL * abs(o["loglik"]), (ll, o["loglik"])
-    assert rel_err(im.xisums[0], o["xisum"]) <= STAT_TOL
+    tol = _stat_tol(M)
+    print(f"M = {M}: loglik rel {abs(ll - o['loglik']) / abs(o['loglik']):.2e}, xisum rel {rel_err(im.xisums[0], o['xisum']):.2e}, "
+          f"states per lane {im.describe()['plan']['states_per_lane']}")
+    assert rel_err(im.xisums[0], o["xisum"]) <= tol
     for k, v in o["gamma_sums"].items():
-        assert np.max(np.abs(im.gamma_sums[0][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300), k
-    assert rel_err(im.gammas[0][:, 0], o["gamma"][:, 0]) <= STAT_TOL
+        assert np.max(np.abs(im.gamma_sums[0][k] - v)) <= tol * max(np.abs(v).max(), 1e-300), k
+    assert rel_err(im.gammas[0][:, 0], o["gamma"][:, 0]) <= tol
     q = np.array(im.Q(separate=True))
-    assert np.all(np.abs(q - o["q"]) <= STAT_TOL * np.maximum(np.abs(o["q"]), 1e-12)), (q, o["q"])
+    assert np.all(np.abs(q - o["q"]) <= tol * np.maximum(np.abs(o["q"]), 1e-12)), (q, o["q"])
     # one chunk = the sequential algorithm: the same numbers
     im1 = _manager(M, n, obs, chunk=10 ** 6)
     im1.E_step()
     assert abs(im1.loglik() - ll) <= 1e-9 * abs(ll)
-    assert rel_err(im1.xisums[0], im.xisums[0]) <= STAT_TOL
+    assert rel_err(im1.xisums[0], im.xisums[0]) <= tol
 
 
-def test_m512_vs_compiled_reference():
+@pytest.mark.parametrize("fixture,chunk", [("G21_M512_n10_1000rows", 250), ("G24_M768_n10_300rows", 100)])
+def test_m512_and_m768_vs_compiled_reference(fixture, chunk):
     from smcpp_amd import _smcpp, synth
     from smcpp_amd.model import PiecewiseModel
-    z = np.load(os.path.join(GOLDEN, "G21_M512_n10_1000rows.npz"))
+    z = np.load(os.path.join(GOLDEN, fixture + ".npz"))
     g = {k: z[k] for k in z.files}
     n, rows = int(g["n"]), int(g["rows"])
     obs = np.ascontiguousarray(synth.synth_contig(0, 100_000_000, n)[:rows], dtype=np.int32)
@@ -72,10 +86,10 @@ def test_m512_vs_compiled_reference():
     im = _smcpp.PyOnePopInferenceManager(n, [obs], g["hs"], ("pop1",), float(g["pol"]))
     im.model = PiecewiseModel(g["a"], g["s"], 1e4, "pop1")
     im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = float(g["alpha"])
-    im.set_chunking(250)
+    im.set_chunking(chunk)
     im.E_step()
-    assert im.chain_mode() == 5
-    # the engine's own preparation against the reference's at M = 512
+    assert im.chain_mode() == 5 and im.describe()["plan"]["states_per_lane"] == (8 if im.M <= 512 else 16)
+    # the engine's own preparation against the reference's at M = 512 / 768
     np.testing.assert_allclose(im.pi, g["pi"], rtol=1e-12)
     T = im.transition
     np.testing.assert_allclose(np.diag(T), g["T_diag"], rtol=1e-10)
@@ -86,18 +100,19 @@ def test_m512_vs_compiled_reference():
         np.testing.assert_allclose(ep[tuple(k)], ref_E[tuple(k)], rtol=1e-9, atol=1e-16)
     ll = im.loglik()
     assert abs(ll - float(g["loglik"])) <= LL_TOL * abs(float(g["loglik"])), (ll, float(g["loglik"]))
+    tol = _stat_tol(im.M)
     xs = im.xisums[0]
     for got, want in ((xs.sum(axis=1), g["xisum_rowsum"]), (xs.sum(axis=0), g["xisum_colsum"]), (np.diag(xs), g["xisum_diag"])):
-        assert np.max(np.abs(got - want)) <= STAT_TOL * np.abs(want).max()
-    assert abs(xs.sum() - float(g["xisum_total"])) <= STAT_TOL * abs(float(g["xisum_total"]))
+        assert np.max(np.abs(got - want)) <= tol * np.abs(want).max()
+    assert abs(xs.sum() - float(g["xisum_total"])) <= tol * abs(float(g["xisum_total"]))
     keys = [tuple(int(x) for x in k) for k in g["keys"]]
     got = im.gamma_sums[0]
     for k, v, h in zip(keys, g["gs"], g["gs_have"]):
         if h:
-            assert np.max(np.abs(got[k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300), k
-    assert rel_err(im.gammas[0][:, 0], g["gamma0"]) <= STAT_TOL
+            assert np.max(np.abs(got[k] - v)) <= tol * max(np.abs(v).max(), 1e-300), k
+    assert rel_err(im.gammas[0][:, 0], g["gamma0"]) <= tol
     q = np.array(im.Q(separate=True))
-    assert np.all(np.abs(q - g["q"]) <= STAT_TOL * np.maximum(np.abs(g["q"]), 1e-12)), (q, g["q"])
+    assert np.all(np.abs(q - g["q"]) <= tol * np.maximum(np.abs(g["q"]), 1e-12)), (q, g["q"])
 
 
 def test_beyond_256_states_unbuilt_paths_fail_loudly():
@@ -117,5 +132,5 @@ def test_beyond_256_states_unbuilt_paths_fail_loudly():
     im.set_raw(im.pi, T, keys, np.array([ep[tuple(k)] for k in keys.tolist()]))
     with pytest.raises(RuntimeError, match="256"):
         im.E_step()
-    with pytest.raises(RuntimeError):
-        _manager(600, n, obs)
+    with pytest.raises(RuntimeError, match="1024"):
+        _manager(1100, n, obs)

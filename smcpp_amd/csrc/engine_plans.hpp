@@ -677,6 +677,13 @@ void smcpp_im::run_chains_ss() {
     int q = -1, first_launched = -1;      // (first_launched: passes launched when the first round failed to certify, -1: it did)
     const bool poll = !opt().off(smcpp_opt::O_POLL);
     while (true) {
+        // (round 6) the parameter arena of a lean E-step is copied on the SECOND stream beside the chains (engine_params.hpp:
+        // arena_side); the statistics' side streams fork off ev[3], so the main stream must have waited for that copy BEFORE the
+        // fork event is recorded - until round 6 only the main stream waited (in enqueue_stats, i.e. behind the fork), and a kernel
+        // of a side stream (k_loglik_partial reads the groups' log-scales from the arena) could run before the copy had landed: a
+        // 5.9 MB arena (M = 768) against 70 rows of chains lost that race on the first E-step of a manager, found by
+        // SMCPP_DEBUG_POISON (tools/poison_probe.py); with recycled device memory the same race is an order-dependent wrong loglik
+        if (arena_side) HIPCHK(hipStreamWaitEvent(s, ev[20], 0));
         HIPCHK(hipEventRecord(ev[3], s));
         // optimistic, as run_chains(): the statistics are queued right behind the passes; the host only looks at the flags (pinned
         // memory the kernels wrote) when the queue has drained; in the rare round that needs more passes the statistics are redone
@@ -747,7 +754,7 @@ void smcpp_im::enqueue_stats() {
         HIPCHK(hipHostMalloc((void **)&h_ll, sizeof(double) * h_ll_cap, hipHostMallocCoherent | hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void **)&d_ll_view, h_ll, 0));
     }
-    if (arena_side) HIPCHK(hipStreamWaitEvent(s, ev[20], 0));
+    if (arena_side && !ss_active) HIPCHK(hipStreamWaitEvent(s, ev[20], 0));      // (scan chains: run_chains_ss waited in front of the fork event)
     // log-likelihood (also materialises log_c per row)
     LoglikArgs la;
     la.cnorm = d_cnorm.p; la.rowinfo = d_rowinfo.p; la.g_logscale = d_g_logscale.p;

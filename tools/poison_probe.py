@@ -25,7 +25,35 @@ def run_case(case):
     """-> dict of outputs of one fresh manager"""
     kind, name = case.split(":")
     g = golden(name) if not name.startswith("params") else dict(np.load(os.path.join(G, name + ".npz")))
-    if kind in ("raw", "gamma"):
+    if kind == "m768":
+        # sixteen states per lane, ONE chunk per contig (the sequential algorithm)
+        n = 10
+        obs = [np.ascontiguousarray(synth.synth_contig(0, 100_000_000, n)[:70], dtype=np.int32)]
+        a_, s_ = synth.model_pieces()
+        im = _smcpp.PyOnePopInferenceManager(n, obs, synth.hidden_states(768), ("pop1",), 0.5)
+        im.model = PiecewiseModel(a_, s_, 1e4, "pop1")
+        im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0
+        im.set_chunking(10 ** 6)
+    elif kind in ("big", "biggamma", "post", "m1"):
+        # big: a whole 100 Mbp contig (512 chunks per direction, light passes); post: un-binned rows (hybrid chains, thousands of
+        # span groups); m1: ONE hidden state (the bootstrap manager of Analysis)
+        n = int(g["n"])
+        if kind == "post":
+            obs = [np.ascontiguousarray(synth.synth_posterior_contig(200_000, 8, seed=7), dtype=np.int32)]
+            hs, n = synth.hidden_states(32), 8
+        elif kind == "m1":
+            obs = [synth.synth_contig(3, 2_000_000, n)]
+            hs = np.array([0.0, np.inf])
+        else:
+            obs = [synth.synth_contig(0, 100_000_000, n)]
+            hs = g["hs"]
+        im = _smcpp.PyOnePopInferenceManager(n, obs, hs, ("pop1",), float(g["pol"]))
+        im.theta = float(g["theta"]) if kind != "post" else 2e-4
+        im.rho = float(g["rho"]) if kind != "post" else 6e-5
+        im.alpha = 1.0
+        im.model = PiecewiseModel(g["a"], g["s"], 1e4, "pop1")
+        im.save_gamma = kind in ("biggamma", "post")
+    elif kind in ("raw", "gamma"):
         obs = np.ascontiguousarray(g["obs"], dtype=np.int32)
         if obs.shape[1] == 4:
             im = _smcpp.PyOnePopInferenceManager(int(g["n"]), [obs], g["hs"], ("pop1",), float(g["pol"]))
@@ -53,7 +81,7 @@ def run_case(case):
         q, jac = im.Q_with_gradient() if hasattr(im, "Q_with_gradient") else (None, None)
         if jac is not None:
             out["jac"] = np.asarray(jac)
-    if kind == "gamma":
+    if kind in ("gamma", "biggamma", "post"):
         out["argmax"] = np.asarray(im.gamma_argmax(0)).astype(np.float64)
     return out
 
@@ -61,7 +89,8 @@ def run_case(case):
 def main():
     cases = sys.argv[1:] or ["raw:G1_M16_n4", "raw:G3_M32_n10_2Mbp", "raw:G4_M64_n20_2Mbp", "gamma:G3_M32_n10_2Mbp", "gamma:G7_M32_n8_chr11",
                              "gamma:G18_M64_n8_chr11", "raw:G5_M48_twopop_layout", "raw:G2_M51_n6_longspans", "model:params_M64_n20",
-                             "model:params_M32_n10", "model:params_M256_n50"]
+                             "model:params_M32_n10", "model:params_M256_n50", "m1:params_M32_n10", "big:params_M64_n20",
+                             "biggamma:params_M32_n10", "post:params_M32_n10", "big:params_M256_n50"]
     for case in cases:
         if os.environ.get("PROBE_CHILD") == case:
             # child: log the allocations of one clean manager to stderr

@@ -206,6 +206,21 @@ int smcpp_init_cache(const char *path);
 /* openmp.omp_set_num_threads (_smcpp.pyx:61-64): threads of the host-side preparation. */
 void smcpp_set_num_threads(int k);
 
+/* ---- pre-HMM data shaping on the device ------------------------------------------------ */
+
+/* What `smc++ estimate` does to a contig before an inference manager sees it (smcpp/data_filter.py:166-203), as device kernels
+ * over rows int32 [L][1 + 3 P] handed over by the caller (host memory; copied to HBM once):
+ *   mode 0  thin_data(rows, thinning = p0, offset = p1)          smcpp/_estimation_tools.pyx:8-84
+ *   mode 1  bin_observations(rows, w = p0), na[P] distinguished lineages per population   _estimation_tools.pyx:113-173
+ *   mode 2  compress_repeated_obs(rows)                           smcpp/estimation_tools.py:51-60
+ *   mode 3  Thin(p0) -> Bin(p1, na) -> Compress without leaving HBM (the pipeline of data_filter.py)
+ * Bit-exact with the reference's code (goldens G23 / G11).  The result stays on the device (per calling thread): *rows_out = its
+ * row count, *kernel_ms (optional) = the device time with the input resident in HBM; smcpp_dev_shape_fetch copies the rows out
+ * (int32 [rows_out][ncol]).  smcpp_amd/data.py holds the host implementation of the same functions. */
+int smcpp_dev_shape(int mode, long long L, int ncol, const int *rows, long long p0, long long p1, const long long *na,
+                    long long *rows_out, double *kernel_ms);
+int smcpp_dev_shape_fetch(int *out);
+
 /* ---- host-only helpers (no device needed; used by the CPU test-suite) ------------------------------------ */
 
 /* Test hook: 1 = evaluate the conditioned SFS term by term exactly as src/piecewise_constant_rate_function.cpp:214-334

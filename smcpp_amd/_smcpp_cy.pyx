@@ -89,6 +89,8 @@ cdef extern from "smcpp_engine.h":
     void smcpp_init_logger_cb(void (*cb)(const char *, const char *, const char *)) nogil
     int smcpp_init_cache(const char *path) nogil
     void smcpp_set_num_threads(int k) nogil
+    int smcpp_dev_shape(int mode, long long L, int ncol, const int *rows, long long p0, long long p1, const long long *na, long long *rows_out, double *kernel_ms) nogil
+    int smcpp_dev_shape_fetch(int *out) nogil
     int smcpp_host_set_csfs_direct(int on) nogil
     int smcpp_host_eigensystem(int n, const double *A, double *P, double *Pinv, double *d, double *scale, double *max_imag) nogil
     int smcpp_host_eigensystem_team(int n, const double *A, int threads, double *P, double *Pinv, double *d, double *scale, double *max_imag) nogil

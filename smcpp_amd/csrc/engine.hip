@@ -46,3 +46,4 @@
 #include "engine_capi.hpp"        // the C ABI of include/smcpp_engine.h
 #include "engine_rccl.hpp"        // the engine-issued exchange through RCCL's C API (opt-in)
 #include "engine_hostapi.hpp"     // host-only and debug exports used by the test-suite
+#include "shaping.hpp"            // SURVEY.md 8 f-2 on the device: thin_data / bin_observations / compress_repeated_obs (integer, HBM-bound)

@@ -354,3 +354,42 @@ def beta_de_avg_pdf(X, y, h: float) -> np.ndarray:
         s += float(np.sum(np.exp((a - 1.0) * lx + (b - 1.0) * l1x - ln_B)))
         ret[j] = s
     return ret / len(X)
+
+
+# --- the same shaping on the device (smcpp_amd/csrc/shaping.hpp) ------------------------------------------------
+
+def _shape_on_device(mode, data, p0=0, p1=0, na=None, timing=False):
+    """`smcpp_dev_shape` + `smcpp_dev_shape_fetch`: rows int32 [L][1 + 3 P] -> rows; `timing=True` also returns the device time in
+    ms with the input resident in HBM.  Fails loudly without a GPU: the functions above are the host implementation."""
+    import ctypes as C
+    from . import _engine as E
+    data = np.ascontiguousarray(data, dtype=np.int32)
+    L, ncol = data.shape
+    nrows = C.c_longlong(0)
+    ms = C.c_double(0.0)
+    na_arr = None if na is None else np.ascontiguousarray(na, dtype=np.int64)
+    na_p = None if na_arr is None else na_arr.ctypes.data_as(C.POINTER(C.c_longlong))
+    E.check(E.lib().smcpp_dev_shape(int(mode), L, ncol, E.iptr(data), int(p0), int(p1), na_p, C.byref(nrows), C.byref(ms)))
+    out = np.empty((nrows.value, ncol), dtype=np.int32)
+    E.check(E.lib().smcpp_dev_shape_fetch(E.iptr(out)))
+    return (out, ms.value) if timing else out
+
+
+def thin_data_device(data, thinning, offset=0, timing=False):
+    """`thin_data` (`_estimation_tools.pyx:8-84`) as device kernels: bit-exact with the host function above and with the reference."""
+    return _shape_on_device(0, data, thinning, offset, timing=timing)
+
+
+def bin_observations_device(data, w, na, timing=False):
+    """`bin_observations` (`_estimation_tools.pyx:113-173`) as device kernels."""
+    return _shape_on_device(1, data, w, 0, na=na, timing=timing)
+
+
+def compress_repeated_obs_device(data, timing=False):
+    """`compress_repeated_obs` (`estimation_tools.py:51-60`) as device kernels."""
+    return _shape_on_device(2, data, timing=timing)
+
+
+def thin_bin_compress_device(data, thinning, w, na, timing=False):
+    """Thin -> Bin -> Compress (`data_filter.py:166-203`) without leaving HBM between the steps."""
+    return _shape_on_device(3, data, thinning, w, na=na, timing=timing)

@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--raw", action="store_true", help="time set_raw -> E_step -> loglik only (no cold preparation)")
     ap.add_argument("--check", action="store_true", help="N > 1: after the timed region gather every rank's host threads, key "
                     "dictionary and Q (four terms) and assert that the dictionaries agree and Q is bitwise identical on all ranks")
+    ap.add_argument("--no-ref-width", action="store_true", help="skip the extra evals of the reference-width configuration (`value_ref_width`): "
+                    "for rocprofv3 passes, whose per-kernel totals must hold the default path only")
     ap.add_argument("--warm", action="store_true", help="additionally report the opt-in warm start (smcpp_set_warm_start) on a "
                     "trajectory of perturbed parameters; never part of `value`")
     args = ap.parse_args()
@@ -279,6 +281,11 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # Python's cyclic collector is parked for the timed regions of this script: with torch imported a full collection walks ~10^6
+    # objects (35 - 40 ms, measured: one Q call of 37 ms among forty of 0.15 ms) and where it falls is an accident of how many
+    # containers the set-up allocated; the engine allocates nothing per eval that needs it
+    import gc
+    gc.collect(); gc.disable()
     timings, host_timings = [], []
     cg0 = cgroup_cpu_stat()
     t0 = time.perf_counter()
@@ -325,7 +332,7 @@ def main():
     # only alpha's storage and the span-1 forward row are float, include/hmm.h:35).  SMCPP_SS_MIXED=0 keeps them in fp64: that
     # configuration is timed here the same way (same warm-up, same number of steps, barrier + synchronize on both sides).
     ref_width = None
-    if float_scans and not args.raw:
+    if float_scans and not args.raw and not args.no_ref_width:
         from smcpp_amd import _engine as _E
         _E.set_option("SMCPP_SS_MIXED", "0")
         try:
@@ -635,7 +642,7 @@ def main():
                        "M": M, "n": n, "rows": int(sum(len(c) for c in contigs)),
                        "span1_rows": R1, "eigen_rows": Re, "contigs_per_gpu": len(contigs),
                        "length_mbp": float(sum(synth.C3_LENGTHS_MBP)) if args.workload == "c3" else args.length_mbp,
-                       "loglik": ll, "host_threads": host_threads,
+                       "loglik": ll, "host_threads": host_threads, "python_gc": "collected, then disabled for the timed region",
                        "parallelism": f"contig-sharded x{world}, 1 all-reduce/E-step" if world > 1 else "single GPU"},
             "split_ms": med,
             "split_ms_note": f"medians of the engine's HIP-event intervals, read back on every {every}th eval of the timed region ({len(timings)} evals)",
@@ -701,18 +708,26 @@ def bench_qgrad(args, im, model, a, s_, M, n, desc, host_threads, world, rank, t
         E.check(E.lib().smcpp_q(im._im, E.dptr(val), E.dptr(jac)))
         return val.copy(), jac.copy()
 
+    per_call = []
+
     def timed(steps, warmup):
+        import gc
         for i in range(warmup):
             one(i)
         torch.cuda.synchronize()
+        gc.collect(); gc.disable()           # (see main(): a full collection inside the timed region is 37 ms of a 6 ms region)
+        per_call.clear()
         t0 = time.perf_counter()
         for i in range(steps):
+            t1 = time.perf_counter()
             one(i)
+            per_call.append(time.perf_counter() - t1)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps
 
     steps = max(args.steps, 40)
     dev_s = timed(steps, args.warmup)
+    dev_calls = sorted(per_call)
     rng = np.random.default_rng(5)
     v_dev, j_dev = one(0)
     im.set_prep_mode(True)
@@ -730,6 +745,8 @@ def bench_qgrad(args, im, model, a, s_, M, n, desc, host_threads, world, rank, t
                          "note": "the same call with the conditioned SFS, emission table, dense transition Jacobian and the Q sums on the "
                                  "host (smcpp_set_prep_mode(1): the route of rounds 1-3)"},
            "speedup_vs_host_path": host_s / dev_s,
+           "per_call_ms": {"median": 1e3 * dev_calls[len(dev_calls) // 2], "min": 1e3 * dev_calls[0], "max": 1e3 * dev_calls[-1],
+                           "note": "`value` is steps / total time of the timed region; the spread of the individual calls is reported beside it"},
            "parity": {"val_rel_diff_max": float(np.max(np.abs(v_dev - v_host) / np.abs(v_host))),
                       "jac_rel_diff_max_per_term": [float(x) for x in np.max(np.abs(j_dev - j_host), axis=1) / sc]}}
     print(json.dumps(out), flush=True)

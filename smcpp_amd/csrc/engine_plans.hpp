@@ -677,13 +677,6 @@ void smcpp_im::run_chains_ss() {
     int q = -1, first_launched = -1;      // (first_launched: passes launched when the first round failed to certify, -1: it did)
     const bool poll = !opt().off(smcpp_opt::O_POLL);
     while (true) {
-        // (round 6) the parameter arena of a lean E-step is copied on the SECOND stream beside the chains (engine_params.hpp:
-        // arena_side); the statistics' side streams fork off ev[3], so the main stream must have waited for that copy BEFORE the
-        // fork event is recorded - until round 6 only the main stream waited (in enqueue_stats, i.e. behind the fork), and a kernel
-        // of a side stream (k_loglik_partial reads the groups' log-scales from the arena) could run before the copy had landed: a
-        // 5.9 MB arena (M = 768) against 70 rows of chains lost that race on the first E-step of a manager, found by
-        // SMCPP_DEBUG_POISON (tools/poison_probe.py); with recycled device memory the same race is an order-dependent wrong loglik
-        if (arena_side) HIPCHK(hipStreamWaitEvent(s, ev[20], 0));
         HIPCHK(hipEventRecord(ev[3], s));
         // optimistic, as run_chains(): the statistics are queued right behind the passes; the host only looks at the flags (pinned
         // memory the kernels wrote) when the queue has drained; in the rare round that needs more passes the statistics are redone
@@ -754,7 +747,16 @@ void smcpp_im::enqueue_stats() {
         HIPCHK(hipHostMalloc((void **)&h_ll, sizeof(double) * h_ll_cap, hipHostMallocCoherent | hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer((void **)&d_ll_view, h_ll, 0));
     }
-    if (arena_side && !ss_active) HIPCHK(hipStreamWaitEvent(s, ev[20], 0));      // (scan chains: run_chains_ss waited in front of the fork event)
+    // The parameter arena of a lean E-step (Td, the emission table of a set_raw manager, the groups' log-scales) is copied on the
+    // SECOND stream beside the chains (engine_params.hpp: arena_side, event 20).  The main stream waits for it here; (round 6) so
+    // does EVERY side stream at the point where it forks off the chains' end (`arena_wait` below) - until round 6 only the main
+    // stream waited, behind the fork event, and a side-stream kernel (k_loglik_partial reads the log-scales, the rank updates of a
+    // set_raw manager the emission table) could run before the copy had landed: an order-dependent wrong log-likelihood on recycled
+    // device memory, NaN under SMCPP_DEBUG_POISON at M = 768 on 70 rows (tools/poison_probe.py found it).  A wait in front of the
+    // fork event itself was measured at 12 us per eval (every branch then starts behind the barrier packet); on the side streams,
+    // which have slack, it costs nothing measurable.
+    if (arena_side) HIPCHK(hipStreamWaitEvent(s, ev[20], 0));
+    auto arena_wait = [&](hipStream_t x) { if (arena_side && x != s) HIPCHK(hipStreamWaitEvent(x, ev[20], 0)); };
     // log-likelihood (also materialises log_c per row)
     LoglikArgs la;
     la.cnorm = d_cnorm.p; la.rowinfo = d_rowinfo.p; la.g_logscale = d_g_logscale.p;
@@ -795,8 +797,8 @@ void smcpp_im::enqueue_stats() {
     hipEvent_t ev_fork = ss_active ? ev[3] : ev[8];
     if (split_streams) {
         if (!ss_active) HIPCHK(hipEventRecord(ev[8], s));
-        if (se != s) HIPCHK(hipStreamWaitEvent(se, ev_fork, 0));
-        if (sp1 != s) HIPCHK(hipStreamWaitEvent(sp1, ev_fork, 0));
+        if (se != s) { HIPCHK(hipStreamWaitEvent(se, ev_fork, 0)); arena_wait(se); }
+        if (sp1 != s) { HIPCHK(hipStreamWaitEvent(sp1, ev_fork, 0)); arena_wait(sp1); }
     }
     // nothing in the statistics reads log_c any more (the span-1 weights take c itself): the two log-likelihood kernels
     // ride on the eigen stream instead of heading the critical path of the main one
@@ -819,7 +821,7 @@ void smcpp_im::enqueue_stats() {
     // beside both branches instead of at the head of the span-1 branch (joined in front of the finalisation)
     const bool ll3 = crit_main && kfuse && stream3 != nullptr;
     hipStream_t sl = (ll_own || ll3) ? stream3 : (crit_main ? sp1 : eigfree ? s : se);   // (the eigen-free branch is the longer one)
-    if (ll_own || ll3) HIPCHK(hipStreamWaitEvent(sl, ev_fork, 0));
+    if (ll_own || ll3) { HIPCHK(hipStreamWaitEvent(sl, ev_fork, 0)); arena_wait(sl); }
     hipLaunchKernelGGL(k_loglik_partial, dim3(llblk, n_contigs), dim3(256), 0, sl, la);
     hipLaunchKernelGGL(k_loglik_final, dim3(n_contigs), dim3(256), 0, sl, la);
     if (ll_own || ll3) HIPCHK(hipEventRecord(ev[19], sl));
@@ -886,7 +888,7 @@ void smcpp_im::enqueue_stats() {
     const bool s1_own = !kfuse && dual_stream && stream3 != nullptr && (Mp + 63) / 64 == 1 && !save_gamma && !slabs_sc.empty();
     hipStream_t s1s = s1_own ? stream3 : sp1;
     if (s1_own) {
-        if (crit_main) HIPCHK(hipStreamWaitEvent(s1s, ev_fork, 0));     // (forks where the span-1 branch does: at the chains' end)
+        if (crit_main) { HIPCHK(hipStreamWaitEvent(s1s, ev_fork, 0)); arena_wait(s1s); }     // (forks where the span-1 branch does: at the chains' end)
         else {
             HIPCHK(hipEventRecord(ev[15], s));
             HIPCHK(hipStreamWaitEvent(s1s, ev[15], 0));

@@ -21,7 +21,7 @@ python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tai
 timeout 300 python -m pytest tests/test_gpu_multi.py -m gpu -q -s -k world_of_one 2>&1 | grep -a "exchange cost" | tail -1 > $O/exchange_cost.log; cat $O/exchange_cost.log
 cd /tmp && export TMPDIR=/tmp
 for w in c3 c5 posterior qgrad; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_$w -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload $w --steps 5 > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_$w -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ref-width --workload $w --steps 5 > /dev/null 2>&1
 done
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $GRAFT_REPO_ROOT/tools/dpp_lab.hip -o /tmp/dpp_lab && /tmp/dpp_lab > $GRAFT_REPO_ROOT/$O/dpp_lab.log 2>&1
 /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 $GRAFT_REPO_ROOT/tools/sync_lab.hip -o /tmp/sync_lab && /tmp/sync_lab > $GRAFT_REPO_ROOT/$O/sync_lab.log 2>&1
@@ -30,7 +30,7 @@ SMCPP_HOST_TRACE=1 python $GRAFT_REPO_ROOT/bench.py --no-cpu --steps 4 --warmup 
 SMCPP_HOST_TIMING=1 python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload c4 --steps 8 --warmup 3 2>&1 | grep -a "prep2\|jcsfs" | tail -8 > $GRAFT_REPO_ROOT/$O/c4_host_timing.log
 # the statistics phase of the headline and of config C5, kernel by kernel (tools/stats_timeline.py)
 for w in headline c5; do
-  timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$w -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --workload $w --steps 6 --warmup 3 > /dev/null 2>&1 </dev/null
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$w -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ref-width --workload $w --steps 6 --warmup 3 > /dev/null 2>&1 </dev/null
   python $GRAFT_REPO_ROOT/tools/stats_timeline.py /tmp/tl_$w > $GRAFT_REPO_ROOT/$O/stats_timeline_$w.txt 2>&1
 done
 grep '^{"metric"' $GRAFT_REPO_ROOT/$O/bench_default.log | tail -1 | cut -c1-300

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for cfg in "2800 800 3900 1100" "3600 1200 5000 1600" "2000 600 2800 900" "off"; do
   set -- $cfg
   if [ "$1" = "off" ]; then export SMCPP_SS_HALO=0; else export SMCPP_SS_HALO=1 SMCPP_HALO_LF=$1 SMCPP_HALO_DF=$2 SMCPP_HALO_LB=$3 SMCPP_HALO_DB=$4; fi
-  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_$1 -- python $R/bench.py --no-cpu --workload $W --steps 10 > $O/trace_$1.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_$1 -- python $R/bench.py --no-cpu --no-ref-width --workload $W --steps 10 > $O/trace_$1.log 2>&1
   python - "$O/trace_$1" "$cfg" <<'PY'
 import glob, csv, json, sys
 d = json.loads([l for l in open(sys.argv[1] + ".log") if l.startswith('{"metric"')][-1])

@@ -5,6 +5,6 @@ mkdir -p $R/gpurun_out/pmc7
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc7/p$i -- python $R/bench.py --no-cpu --workload c5 --steps 1 --warmup 1 > $R/gpurun_out/pmc7/log$i.txt 2>&1 </dev/null
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc7/p$i -- python $R/bench.py --no-cpu --no-ref-width --workload c5 --steps 1 --warmup 1 > $R/gpurun_out/pmc7/log$i.txt 2>&1 </dev/null
   tail -2 $R/gpurun_out/pmc7/log$i.txt | cut -c1-200
 done

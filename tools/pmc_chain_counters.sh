@@ -4,6 +4,6 @@ mkdir -p $R/gpurun_out/pmc5
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_F64"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc5/p$i -- python $R/bench.py --no-cpu --steps 5 --warmup 2 > $R/gpurun_out/pmc5/log$i.txt 2>&1 </dev/null
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc5/p$i -- python $R/bench.py --no-cpu --no-ref-width --steps 5 --warmup 2 > $R/gpurun_out/pmc5/log$i.txt 2>&1 </dev/null
 done
 ls -R $R/gpurun_out/pmc5 | head -40

@@ -13,7 +13,7 @@ for w in $WL; do
   for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" \
              "SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     i=$((i+1))
-    timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -- python $R/bench.py --no-cpu --workload $w --steps 3 --warmup 1 > $O/log$i.txt 2>&1 </dev/null
+    timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -- python $R/bench.py --no-cpu --no-ref-width --workload $w --steps 3 --warmup 1 > $O/log$i.txt 2>&1 </dev/null
   done
   python $R/tools/summarize_sq.py $O $R/gpurun_out/$TAG/${TAG}_${w}_sq_counters.json "$w"
 done

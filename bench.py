@@ -55,6 +55,8 @@ WORKLOADS = {
     # ... the same at M = 64: the eigenvector tables of the hybrid rows (133 KB per eigen key) do not fit LDS, so the dense
     # cooperative chains run (the regime hole DESIGN.md section 9 names; measured, not hidden)
     "posterior64": (64, 8, None, "posterior decode: 1 un-binned contig, 1e6 rows, spans to 1e5, rho=6e-5, M=64, n=8, save_gamma"),
+    # SURVEY.md 8 f-2 on the device: what data_filter.py does to a contig before an inference manager sees it (integer, HBM-bound)
+    "shaping": (0, 8, None, "pre-HMM data shaping Thin(400) -> Bin(100) -> Compress of 1 un-binned contig, 1e6 rows (4.8e8 bp), on the device"),
 }
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector = matrix peak (AMD spec)
@@ -185,6 +187,8 @@ def main():
     host_threads = max(1, min(int(os.environ.get("SMCPP_BENCH_THREADS", default_threads)), share))
     _smcpp.set_num_threads(host_threads)
     M, n, fixture, desc = WORKLOADS[args.workload]
+    if args.workload == "shaping":
+        return bench_shaping(args, n, desc, world, rank, torch)
     length_bp = int(args.length_mbp * 1e6)
     par = None
     sharded_kw = {}
@@ -749,6 +753,61 @@ def bench_qgrad(args, im, model, a, s_, M, n, desc, host_threads, world, rank, t
                            "note": "`value` is steps / total time of the timed region; the spread of the individual calls is reported beside it"},
            "parity": {"val_rel_diff_max": float(np.max(np.abs(v_dev - v_host) / np.abs(v_host))),
                       "jac_rel_diff_max_per_term": [float(x) for x in np.max(np.abs(j_dev - j_host), axis=1) / sc]}}
+    print(json.dumps(out), flush=True)
+
+
+def bench_shaping(args, n, desc, world, rank, torch):
+    """`--workload shaping`: the pre-HMM data shaping of SURVEY.md 8 f-2 (thin_data -> bin_observations -> compress_repeated_obs,
+    smcpp/data_filter.py:166-203) as device kernels (smcpp_amd/csrc/shaping.hpp) on one un-binned contig.  One step = the three
+    steps on rows already resident in HBM (`smcpp_dev_shape` mode 3: HIP events on the stream the kernels run on); `roofline`:
+    bytes every step must read and write / that time against 8 TB/s; `cpu_baseline`: this repository's numpy implementation of the
+    same functions (`smcpp_amd.data`, pinned bit for bit against the reference's Cython by golden G23) on a bounded prefix."""
+    from smcpp_amd import data as D, synth
+    if world != 1:
+        raise SystemExit("--workload shaping is a single-GPU measurement")
+    raw = np.ascontiguousarray(synth.synth_posterior_contig(1_000_000, n, seed=7), dtype=np.int32)
+    thinning, w, na = 400, 100, [2]
+    P = int(raw[:, 0].astype(np.int64).sum())
+    for _ in range(max(1, args.warmup)):
+        out, _ = D.thin_bin_compress_device(raw, thinning, w, na, timing=True)
+    ms, walls = [], []
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        out, k_ms = D.thin_bin_compress_device(raw, thinning, w, na, timing=True)
+        walls.append(time.perf_counter() - t0)
+        ms.append(k_ms)
+    k_ms = float(np.median(ms))
+    t, ms_t = D.thin_data_device(raw, thinning, timing=True)
+    b, ms_b = D.bin_observations_device(t, w, na, timing=True)
+    c, ms_c = D.compress_repeated_obs_device(b, timing=True)
+    assert np.array_equal(c, out)
+    row_b = 4 * raw.shape[1]
+    # what each step must move: its input rows once, its output rows once, and the 8-byte prefix sums it scans (written + read)
+    alg = (len(raw) * (row_b + 16 + 16) + len(t) * row_b) + (len(t) * (row_b + 16) + len(b) * row_b) + (len(b) * (row_b + 16 + 16) + len(c) * row_b)
+    gbs = alg / (1e-3 * k_ms) / 1e9
+    # parity in the run: the host implementation on a prefix (the whole contig takes minutes of Python loops)
+    pre = raw[:20_000]
+    t0 = time.perf_counter()
+    c_host = D.compress_repeated_obs(D.bin_observations(D.thin_data(pre, thinning), w, na))
+    host_s = time.perf_counter() - t0
+    c_dev = D.thin_bin_compress_device(pre, thinning, w, na)
+    Ppre = int(pre[:, 0].astype(np.int64).sum())
+    out = {"metric": f"Mbp/s ({desc})", "value": P / 1e6 / (1e-3 * k_ms), "unit": "Mbp/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": k_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 rows / int64 prefix sums", "data": "synthetic",
+           "config": {"workload": desc, "rows_in": int(len(raw)), "positions": P, "rows_after_thin": int(len(t)), "rows_after_bin": int(len(b)),
+                      "rows_out": int(len(c)), "thinning": thinning, "w": w, "timed": "device work with the input resident in HBM (HIP events, "
+                      "smcpp_dev_shape mode 3)", "wall_ms_with_pcie_in_and_out": 1e3 * float(np.median(walls))},
+           "split_ms": {"thin": ms_t, "bin": ms_b, "compress": ms_c, "pipeline": k_ms},
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "k_scan_* + k_thin_emit + k_bin_emit + k_compress_emit (all launches of one pipeline)", "kernel_ms_per_step": k_ms,
+                        "algorithmic_bytes": alg,
+                        "note": "integer, HBM-bound: bytes = rows in + rows out of every step + the 8-byte prefix sums it scans; the steps are "
+                                "launch- and latency-bound at this size (a dozen small kernels, binary searches), far from the HBM roof"},
+           "cpu_baseline": {"value": Ppre / 1e6 / host_s, "unit": "Mbp/s", "cores": 1, "kind": "port",
+                            "sample": f"smcpp_amd.data (numpy / Python loops; bit-exact with the reference's Cython: golden G23) on the first {len(pre)} rows "
+                                      f"({Ppre} bp) in {host_s:.1f} s; the reference's compiled Cython cannot be built on the GPU box",
+                            "identical_to_device_on_the_sample": bool(np.array_equal(c_host, c_dev))}}
+    out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out), flush=True)
 
 

@@ -98,6 +98,22 @@ __device__ __forceinline__ long long holder_of(const long long *__restrict__ arr
     return lo;
 }
 
+// ... for a BLOCK of consecutive slots: the holders of slots x0 .. x0 + 255 lie between the holders of the first and the last slot, so
+// two threads run the full search (22 dependent loads on 3 10^6 rows), everybody else searches the window between them (a block of 256
+// bins of thinned data spans ~180 rows: 8 loads)
+__device__ __forceinline__ long long holder_in_block(const long long *__restrict__ arr, long long n, long long x, long long x_first, long long x_last) {
+    __shared__ long long win[2];
+    if (threadIdx.x == 0) win[0] = holder_of(arr, n, x_first);
+    if (threadIdx.x == blockDim.x - 1) win[1] = holder_of(arr, n, x_last);
+    __syncthreads();
+    long long lo = win[0], hi = win[1];
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (arr[mid + 1] > x) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
 // ---- thin_data (_estimation_tools.pyx:8-84) ----
 // Phase i0 of a row = (offset + position it starts at) mod thinning while offset < thinning (the counter is reset at every kept
 // position); a row of span s emits, in order: [thinning - i0 - 1 thinned positions] (only if > 0), [1 kept position], then for
@@ -135,8 +151,9 @@ __global__ __launch_bounds__(256) void k_thin_emit(long long L, int ncol, const 
                                                    int *__restrict__ out) {
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long nout = ocum[L];
+    const long long o_first = (long long)blockIdx.x * 256, o_last = min(o_first + 255, nout - 1);
+    const long long j = holder_in_block(ocum, L, min(o, nout - 1), o_first, o_last);      // (every thread takes part in the barrier)
     if (o >= nout) return;
-    const long long j = holder_of(ocum, L, o);
     const long long local = o - ocum[j];
     const int *src = rows + j * ncol;
     const long long span = (long long)src[0];
@@ -178,10 +195,11 @@ __global__ __launch_bounds__(256) void k_thin_emit(long long L, int ncol, const 
 __global__ __launch_bounds__(256) void k_bin_emit(long long L, int ncol, const int *__restrict__ rows, const long long *__restrict__ cum, long long w,
                                                   const long long *__restrict__ na, long long nbins, int *__restrict__ out) {
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long k_first = (long long)blockIdx.x * 256, k_last = min(k_first + 255, nbins - 1);
+    long long q = holder_in_block(cum, L, min(k, nbins - 1) * w, k_first * w, k_last * w);
     if (k >= nbins) return;
     const long long p0 = k * w, p1 = p0 + w;
     const int K = (ncol - 1) / 3;
-    long long q = holder_of(cum, L, p0);
     long long mq = q;
     int max_ss = -2;
     for (; q < L && cum[q] < p1; ++q) {
@@ -213,13 +231,18 @@ struct HeadOf {
 };
 __global__ __launch_bounds__(256) void k_compress_emit(long long L, int ncol, const int *__restrict__ rows, const long long *__restrict__ cum,
                                                        const long long *__restrict__ hcum, int *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= L) return;
-    if (hcum[i + 1] == hcum[i]) return;                            // not the head of a run
-    const long long o = hcum[i];
-    // the run ends in front of the next head: the first i' > i with hcum[i' + 1] > o + 1, i.e. the holder of output slot o + 1
+    // one thread per OUTPUT row (run): its head is the holder of slot o in the scanned head flags, the run ends in front of the head
+    // of slot o + 1 - the neighbour thread's head
+    __shared__ long long heads[257];
     const long long nout = hcum[L];
-    const long long nxt = o + 1 < nout ? holder_of(hcum, L, o + 1) : L;
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long o_first = (long long)blockIdx.x * 256, o_last = min(o_first + 255, nout - 1);
+    const long long i = holder_in_block(hcum, L, min(o, nout - 1), o_first, o_last);
+    if (o < nout) heads[threadIdx.x] = i;                          // (threads beyond the last run only took part in the window search)
+    if (o < nout && (threadIdx.x == 255 || o == nout - 1)) heads[threadIdx.x + 1] = o + 1 < nout ? holder_of(hcum, L, o + 1) : L;
+    __syncthreads();
+    if (o >= nout) return;
+    const long long nxt = heads[threadIdx.x + 1];
     int *dst = out + o * ncol;
     dst[0] = (int)(cum[nxt] - cum[i]);                             // (numpy: int64 differences stored into the int32 array)
     const int *src = rows + i * ncol;
@@ -294,8 +317,9 @@ static long long shape_compress(const int *src, long long L, int ncol, DevBuf<in
     shape_scan(L, HeadOf{src, ncol}, A.ocum, A);
     const long long nout = shape_total(A.ocum, L, A);
     dst.alloc((size_t)std::max<long long>(1, nout) * ncol);
-    hipLaunchKernelGGL(k_compress_emit, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, A.s, L, ncol, src, (const long long *)A.cum.p,
-                       (const long long *)A.ocum.p, dst.p);
+    if (nout > 0)
+        hipLaunchKernelGGL(k_compress_emit, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, A.s, L, ncol, src, (const long long *)A.cum.p,
+                           (const long long *)A.ocum.p, dst.p);
     return nout;
 }
 static void shape_upload(ShapeArea &A, long long L, int ncol, const int *rows) {

@@ -104,6 +104,24 @@ def cgroup_cpu_stat():
         return None
 
 
+def gpu_power_state():
+    """Performance level and current clocks of the GPUs this process can see, from sysfs (readable without privileges), or None:
+    recorded beside the timing because an eval whose host phase leaves the device idle for a few hundred microseconds (two
+    populations) depends on how the box's power management treats an idle queue."""
+    import glob
+    out = []
+    for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+        try:
+            if not os.path.exists(dev + "/pp_dpm_sclk"):
+                continue
+            cur = lambda f: next((l.split(":")[1].replace("*", "").strip() for l in open(dev + "/" + f) if "*" in l), None)  # noqa: E731
+            out.append({"card": dev.split("/")[4], "perf_level": open(dev + "/power_dpm_force_performance_level").read().strip(),
+                        "sclk": cur("pp_dpm_sclk"), "mclk": cur("pp_dpm_mclk")})
+        except Exception:  # noqa: BLE001
+            pass
+    return out or None
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a torchrun environment: start N ranks of this script."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -258,10 +276,22 @@ def main():
     if args.workload == "qgrad":
         return bench_qgrad(args, im, model, a, s_, M, n, desc, host_threads, world, rank, torch)
 
+    # wall clock of the three calls of an eval as the CALLER sees them (three perf_counter reads, ~0.2 us): what an eval spends in the
+    # Python binding in front of the C ABI (`top.model = ...`: the model object's own piece arithmetic, numpy -> pointers) shows up
+    # here and in no engine-side interval
+    phase_ns = [0, 0, 0, 0]
+    pc = time.perf_counter_ns
+
     def one_eval():
+        t_a = pc()
         top.model = model            # setParams: parameters dirty, A6-A10 + eigensystems + uploads are all redone
+        t_b = pc()
         top.E_step()                 # (N > 1: includes the single all-reduce of the packed statistics)
-        return top.loglik()
+        t_c = pc()
+        ll_ = top.loglik()
+        t_d = pc()
+        phase_ns[0] += t_b - t_a; phase_ns[1] += t_c - t_b; phase_ns[2] += t_d - t_c; phase_ns[3] += 1
+        return ll_
 
     raw = None
 
@@ -296,6 +326,7 @@ def main():
     # the engine's HIP-event intervals of an eval (chains, statistics, finalisation: `split_ms`, the roofline's kernel time) are read back
     # on every FOURTH eval of the timed region: reading them costs ~10 us of host time per eval, which is instrumentation, not the eval
     every = 4 if args.steps >= 20 else 1
+    phase_ns[:] = [0, 0, 0, 0]
     for i in range(args.steps):
         ll = step()
         if i % every == 0:
@@ -303,6 +334,10 @@ def main():
             host_timings.append(im.last_host_timing())
     barrier()
     elapsed = time.perf_counter() - t0
+    caller_ms = ({"set_model": 1e-6 * phase_ns[0] / phase_ns[3], "E_step": 1e-6 * phase_ns[1] / phase_ns[3],
+                  "loglik": 1e-6 * phase_ns[2] / phase_ns[3],
+                  "note": "mean wall clock of the three calls of an eval as the Python caller sees them; set_model holds the binding's "
+                          "own work in front of smcpp_set_params (model object -> arrays)"} if phase_ns[3] else None)
     cg1 = cgroup_cpu_stat()
     cpu_throttle = ({k: cg1[k] - cg0[k] for k in cg0} if (cg0 and cg1) else None)
     per_rank = None
@@ -640,6 +675,12 @@ def main():
             "value_ref_width": (ref_width["value"] if ref_width else (value if not float_scans else None)),
             "ref_width": ref_width,
             "cpu_throttle_in_timed_region": cpu_throttle,
+            "caller_ms": caller_ms,
+            # what the caller's E_step call spends outside the engine's own host phase and outside the device intervals (launch /
+            # wake-up / completion latencies around the kernels): ~0.01 - 0.03 ms; config C4 has been seen at 0.3 - 0.7 on some boxes
+            "unaccounted_ms": (caller_ms["E_step"] - med.get("host_total_ms", med.get("host_prep_ms", 0.0)) - med.get("device_total_ms", 0.0)
+                               if caller_ms and "device_total_ms" in med else None),
+            "gpu_power_state": gpu_power_state(),
             "plan": plan,
             "config": {"workload": desc, "eval": "set_raw -> E_step -> loglik (no cold preparation)" if args.raw
                        else "set_params -> E_step -> loglik (SURVEY.md 8(d))",

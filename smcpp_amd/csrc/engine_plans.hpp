@@ -847,6 +847,29 @@ void smcpp_im::enqueue_stats() {
     const bool team2 = team_env && eigfree && !teams_eg.empty();
     const bool team3 = team_env && !teams_fk.empty();
     const bool team0 = team_env && !teams_rk.empty();
+    // (round 6) Mp > 128: the rank updates of modes 0 / 2 stage their operand rows through LDS (kernels.hpp: k_rank_acc_wide - one
+    // workgroup per team and 256 x 128 block of the output instead of one wavefront per slab and 64 x 64 block); SMCPP_RANK_WIDE=0:
+    // the per-wavefront form
+    const bool rank_wide = Mp > 128 && !opt().off(smcpp_opt::O_RANK_WIDE);
+    auto launch_wide = [&](int mode, const AccArgs &ar, unsigned gx, hipStream_t st) {
+        static bool once = false;
+        if (!once) {
+            HIPCHK(hipFuncSetAttribute((const void *)k_rank_acc_wide<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute((const void *)k_rank_acc_wide<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute((const void *)k_rank_acc_wide<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute((const void *)k_rank_acc_wide<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            once = true;
+        }
+        const dim3 grid(gx, (unsigned)(((Mp + 255) / 256) * ((Mp + 127) / 128)));
+        const bool four = opt().i(smcpp_opt::O_RANK_WIDE, 8) == 4;      // (SMCPP_RANK_WIDE=4: one wavefront per SIMD)
+        if (four) {
+            if (mode == 0) hipLaunchKernelGGL((k_rank_acc_wide<0, 4>), grid, dim3(256), RW_LDS, st, ar);
+            else hipLaunchKernelGGL((k_rank_acc_wide<2, 4>), grid, dim3(256), RW_LDS, st, ar);
+        } else {
+            if (mode == 0) hipLaunchKernelGGL((k_rank_acc_wide<0, 8>), grid, dim3(512), RW_LDS, st, ar);
+            else hipLaunchKernelGGL((k_rank_acc_wide<2, 8>), grid, dim3(512), RW_LDS, st, ar);
+        }
+    };
     // Eigen-free statistics: the span fold (tens of serial steps on a few CUs) ends the longest dependency chain of the
     // phase, so what it waits for - the rank accumulation of the span > 1 rows - goes FIRST and alone; the span-1 branches start
     // behind it and run while the fold does
@@ -870,10 +893,11 @@ void smcpp_im::enqueue_stats() {
         }
         AccArgs ae = aa;
         ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
-        if (team2) {
-            ae.teams = d_teams_eg.p;
+        if (team2) ae.teams = d_teams_eg.p;
+        if (rank_wide) launch_wide(2, ae, team2 ? (unsigned)teams_eg.size() : (unsigned)ae.nslabs, se);
+        else if (team2)
             hipLaunchKernelGGL((k_rank_acc<2, true>), dim3((unsigned)teams_eg.size(), ae.NB * ae.NB), dim3(256), 0, se, ae);
-        } else
+        else
         hipLaunchKernelGGL(k_rank_acc<2>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
         if (!crit_main) {
             // (round 5) the span-1 branch waits for this rank update only where its OWN rank update starts: its weights pass
@@ -925,10 +949,11 @@ void smcpp_im::enqueue_stats() {
     } else
     if (!slabs_rk.empty()) {
         aa.nslabs = (int)slabs_rk.size(); aa.slabs = d_slabs_rk.p; aa.perm = d_perm1.p; aa.permk = d_perm1k.p; aa.part = d_part_1.p;
-        if (team0) {
-            aa.teams = d_teams_rk.p;
+        if (team0) aa.teams = d_teams_rk.p;
+        if (rank_wide) launch_wide(0, aa, team0 ? (unsigned)teams_rk.size() : (unsigned)aa.nslabs, sp1);
+        else if (team0)
             hipLaunchKernelGGL((k_rank_acc<0, true>), dim3((unsigned)teams_rk.size(), aa.NB * aa.NB), dim3(256), 0, sp1, aa);
-        } else
+        else
         hipLaunchKernelGGL(k_rank_acc<0>, dim3(aa.nslabs, aa.NB * aa.NB), dim3(64), 0, sp1, aa);
     }
     // the per-key gamma sums only need the span-1 scalars: with two streams their reduction runs at the tail of the eigen
@@ -954,10 +979,11 @@ void smcpp_im::enqueue_stats() {
             if (aa.NB != 1) launch_s1(NPL, se_a, se);          // M <= 64: k_rank_acc<2> forms the weights itself
             AccArgs ae = aa;
             ae.nslabs = (int)slabs_eg.size(); ae.slabs = d_slabs_eg.p; ae.perm = d_perme.p; ae.part = d_part_e.p;
-            if (team2) {
-                ae.teams = d_teams_eg.p;
+            if (team2) ae.teams = d_teams_eg.p;
+            if (rank_wide) launch_wide(2, ae, team2 ? (unsigned)teams_eg.size() : (unsigned)ae.nslabs, se);
+            else if (team2)
                 hipLaunchKernelGGL((k_rank_acc<2, true>), dim3((unsigned)teams_eg.size(), ae.NB * ae.NB), dim3(256), 0, se, ae);
-            } else
+            else
             hipLaunchKernelGGL(k_rank_acc<2>, dim3(ae.nslabs, ae.NB * ae.NB), dim3(64), 0, se, ae);
         }
         if (!eb_gid.empty())                                     // ONE share per bucket: k_span_F reads it on its serial path

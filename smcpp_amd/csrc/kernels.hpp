@@ -1327,6 +1327,148 @@ __global__ __launch_bounds__(TEAM ? 256 : 64) __attribute__((amdgpu_waves_per_eu
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// K4w (round 6): the rank update of MODES 0 / 2 for Mp > 128 with its operand rows staged through LDS.
+// k_rank_acc gives every wavefront a 64 x 64 block of the M x M output and lets it read its operands from global memory: at
+// M = 256 sixteen blocks walk the same rows, alpha and beta of a row are each read four times (12 KB per row instead of 3), two
+// wavefronts per SIMD wait on operand round trips, and the two rank updates of config C5 run at 45 % of the fp64 matrix peak.
+// Here a workgroup of four wavefronts (one per SIMD, 512 registers each) owns a 256 (X = omega alpha_{ell-1}) x 128 (Y = beta_ell
+// [o e_key]) block: 32 accumulator tiles per wavefront (its 64 X columns x the 128 Y columns).  The rows of the workgroup's slabs are
+// staged 16 at a time: every thread converts / weights its share of the row (alpha: one float4, beta [and e]: one double2 per row, four
+// rows per thread) into a padded LDS tile while the matrix cores work on the previous stage (register-staged double buffer, ONE
+// barrier per stage); the MFMA operands are 12 ds_read_b64 per 32 v_mfma_f64_16x16x4 (2048 matrix-pipe cycles).  Per row and block
+// 1 KB of alpha + 1 KB of beta: 4 KB per row at M = 256 instead of 12.
+// Rows: the slabs of a team are consecutive slabs of ONE reduction range, i.e. one contiguous piece [first.start, last.end) of the
+// sorted permutation on one contig - walked in order by the one workgroup (no cross-wavefront reduction; the partial is the team's).
+// grid = (teams or slabs, ceil(Mp / 256) * ceil(Mp / 128)); dynamic LDS RW_LDS bytes.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RW_R = 16;               // rows per stage (four MFMA k-steps)
+constexpr int RW_XS = 256 + 16;        // row stride of the X tile in doubles (the pad moves consecutive rows by 32 banks)
+constexpr int RW_YS = 128 + 16;
+constexpr size_t RW_LDS = 2 * (size_t)RW_R * (RW_XS + RW_YS) * sizeof(double);
+
+// NWV wavefronts per workgroup: 4 (one per SIMD, 64 X columns = 32 accumulator tiles each) or 8 (two per SIMD, 32 X columns = 16 tiles
+// each: while one wavefront of a SIMD converts and stores its share of the next stage, waits at the barrier or for its LDS operands, the
+// other one feeds the matrix pipe).
+template <int MODE, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_rank_acc_wide(AccArgs a) {
+    constexpr int XT = 16 / NWV;          // X tiles (16 columns) per wavefront
+    constexpr int RPT = RW_R / NWV;       // rows of a stage per thread
+    static_assert(MODE == 0 || MODE == 2, "span-1 rows (0) or the eigen-free span > 1 rows (2)");
+    extern __shared__ double rw_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int m = lane & 15, qd = lane >> 4;
+    const int Mp = a.Mp;
+    const int nby = (Mp + 127) / 128;
+    const int jb = ((int)blockIdx.y / nby) * 256, kb = ((int)blockIdx.y % nby) * 128;
+    int first = blockIdx.x, cnt = 1;
+    if (a.teams) { const int2 tm = a.teams[blockIdx.x]; first = tm.x; cnt = tm.y; }
+    const Slab s_first = a.slabs[first], s_last = a.slabs[first + cnt - 1];
+    const int R0 = s_first.start, R1 = s_last.end;
+    const long long base = s_first.base;
+    auto sXb = [&](int buf) { return rw_lds + buf * (RW_R * (RW_XS + RW_YS)); };
+    const bool wave_on = jb + 16 * XT * wv < Mp;
+    f64x4 acc[XT][8];
+#pragma unroll
+    for (int i = 0; i < XT; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
+    // this thread's share of a row: X columns jb + 4 lane .. + 3 (one float4 of alpha), Y columns kb + 2 lane, + 1 (one double2 of beta);
+    // rows wv, wv + NWV, ... of the stage.  Columns past Mp (a multiple of 16) are loaded from column 0 and stored as zeros.
+    const bool xin = jb + 4 * lane < Mp, yin = kb + 2 * lane < Mp;
+    const int xcol = xin ? jb + 4 * lane : 0, ycol = yin ? kb + 2 * lane : 0;
+    struct Stage { float4 al[RPT]; double2 be[RPT]; double2 em[RPT]; double w[RPT]; };
+    // every load is unconditional (indices clamped, results masked where they are consumed): see k_rank_acc
+    auto fetch_idx = [&](int r0, int2 (&pk)[RPT]) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int r = r0 + wv + NWV * i;
+            const int rc = min(r, R1 - 1);
+            if (MODE == 0) pk[i] = a.permk[rc];
+            else { pk[i].x = a.perm[rc]; pk[i].y = 0; }
+            if (r >= R1) pk[i].x = -1;
+        }
+    };
+    auto fetch_ops = [&](const int2 (&pk)[RPT], Stage &o) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const bool valid = pk[i].x >= 0;
+            const size_t row = (size_t)(base + (valid ? pk[i].x : 1));
+            const double w = a.w1[row];
+            o.w[i] = valid ? w : 0.0;
+            o.al[i] = *reinterpret_cast<const float4 *>(a.alpha + (row - 1) * Mp + xcol);
+            o.be[i] = *reinterpret_cast<const double2 *>(a.beta + row * Mp + ycol);
+            if (MODE == 0) o.em[i] = *reinterpret_cast<const double2 *>(a.E + (size_t)pk[i].y * Mp + ycol);
+        }
+    };
+    auto stash = [&](const Stage &o, int buf) {
+        double *sX = sXb(buf), *sY = sXb(buf) + RW_R * RW_XS;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int rr = wv + NWV * i;
+            const double w = xin ? o.w[i] : 0.0;
+            double *px = sX + rr * RW_XS + 4 * lane;
+            *reinterpret_cast<double2 *>(px) = make_double2(w * (double)o.al[i].x, w * (double)o.al[i].y);
+            *reinterpret_cast<double2 *>(px + 2) = make_double2(w * (double)o.al[i].z, w * (double)o.al[i].w);
+            double2 y = o.be[i];
+            if (MODE == 0) { y.x *= o.em[i].x; y.y *= o.em[i].y; }
+            if (!yin) y = make_double2(0.0, 0.0);
+            *reinterpret_cast<double2 *>(sY + rr * RW_YS + 2 * lane) = y;
+        }
+    };
+    auto compute = [&](int buf) {
+        const double *sX = sXb(buf) + 16 * XT * wv + m, *sY = sXb(buf) + RW_R * RW_XS + m;
+#pragma unroll
+        for (int kk = 0; kk < RW_R / 4; ++kk) {
+            const double *px = sX + (4 * kk + qd) * RW_XS, *py = sY + (4 * kk + qd) * RW_YS;
+            double xa[XT], yb[8];
+#pragma unroll
+            for (int i = 0; i < XT; ++i) xa[i] = px[16 * i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) yb[j] = py[16 * j];
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[i], yb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (R1 > R0) {
+        const int nst = (R1 - R0 + RW_R - 1) / RW_R;
+        int2 pk[RPT];
+        Stage st;
+        fetch_idx(R0, pk);
+        fetch_ops(pk, st);
+        fetch_idx(R0 + RW_R, pk);
+        stash(st, 0);
+        __syncthreads();
+        // (measured and dropped: the two wavefronts of a SIMD in anti-phase - w + 4 storing its share of the next stage in FRONT of its
+        // products, w behind them, operands loaded one iteration earlier: 336 -> 441 us (mode 0), 309 -> 319 (mode 2); the matrix pipe is
+        // 69 % busy in either form - gpurun_out/r06_w3, r06_w4)
+        for (int s = 0; s < nst; ++s) {
+            fetch_ops(pk, st);                          // stage s + 1 (past the end: weight zero)
+            fetch_idx(R0 + RW_R * (s + 2), pk);         // descriptors of stage s + 2
+            if (wave_on) compute(s & 1);
+            stash(st, (s + 1) & 1);
+            __syncthreads();
+        }
+    }
+    if (!wave_on) return;
+    double *out = a.part + (size_t)blockIdx.x * Mp * Mp;
+#pragma unroll
+    for (int i = 0; i < XT; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row = jb + 16 * XT * wv + 16 * i + qd + 4 * rg;   // D row = X column
+                const int col = kb + 16 * j + m;                       // D column = Y column
+                if (row < Mp && col < Mp) out[(size_t)row * Mp + col] = acc[i][j][rg];
+            }
+}
+
+
 // Packed per-rank statistics for the single all-reduce of a multi-GPU E-step, written straight into the caller's device
 // buffer:  out = [ sum loglik | gamma0 (M) | xisum (M*M) | gamma-sums by GLOBAL key index (Kg*M) ],
 // each summed over this rank's contigs in contig order (deterministic).  One thread per output element.

@@ -115,6 +115,35 @@ def test_m512_and_m768_vs_compiled_reference(fixture, chunk):
     assert np.all(np.abs(q - g["q"]) <= tol * np.maximum(np.abs(g["q"]), 1e-12)), (q, g["q"])
 
 
+@pytest.mark.parametrize("M,rows", [(144, 3000), (256, 6000), (300, 2500), (768, 300)])
+def test_rank_update_with_lds_staged_rows_vs_per_wavefront_form(engine_opt, M, rows):
+    """Round 6: for Mp > 128 the rank updates (span-1 rows and the eigen-free span > 1 rows) stage their operand rows through LDS - one
+    workgroup per team and 256 x 128 block of the output (`k_rank_acc_wide`) instead of one wavefront per slab and 64 x 64 block
+    (`k_rank_acc`, SMCPP_RANK_WIDE=0).  Same rows, same weights, the sums in another order: xi sums to 1e-11 of each other, with and
+    without the teams of four slabs; block shapes that are full (256), ragged (144: X block half empty; 304 = 256 + 48) and many
+    (768: 3 x 6 blocks)."""
+    from smcpp_amd import synth
+    n = 10
+    obs = np.ascontiguousarray(synth.synth_contig(0, 100_000_000, n)[:rows], dtype=np.int32)
+    res = {}
+    for wide in ("0", "1"):
+        for team in ("1", "0"):
+            engine_opt("SMCPP_RANK_WIDE", wide)
+            engine_opt("SMCPP_STATS_TEAM", team)
+            im = _manager(M, n, obs)
+            im.E_step()
+            res[(wide, team)] = (im.loglik(), im.xisums[0], im.gamma_sums[0])
+    ll0, x0, g0 = res[("0", "1")]
+    assert np.isfinite(x0).all() and x0.sum() > 0
+    for key, (ll, x, g) in res.items():
+        assert ll == ll0, key
+        err = rel_err(x, x0)
+        print(f"M = {M} wide / team = {key}: xi sums rel {err:.2e}")
+        assert err <= 1e-11, key
+        for k, v in g0.items():
+            np.testing.assert_allclose(g[k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
+
+
 def test_beyond_256_states_unbuilt_paths_fail_loudly():
     from smcpp_amd import synth
     n = 10

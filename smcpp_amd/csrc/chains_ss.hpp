@@ -1620,6 +1620,103 @@ __global__ __launch_bounds__(256) void k_span_scan(SsArgs sa, FinArgs a, int sma
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Per-row posterior of the span > 1 rows WITHOUT an eigensystem (round 6; save_gamma on the scan chains).
+// hmm.cpp:113-121 forms the row's gamma from the eigensystem of its key - diag(P d (Q_r o span_Q) P^-1), 2 M^3 flop per row -
+// and normalises it to the row's span.  That vector is the sum over the `span` positions of the row of their posteriors:
+//     v = sum_{t=1..span} f_t o h_t / (f_t . h_t),   f_t = (B T^T)^t alpha_{ell-1},   h_t = (T B)^{span-t} beta_ell
+// (f_t . h_t is the same number for every t; each term sums to one, so v sums to the span as the reference's does).  With the scan
+// form of the operator (ss_fwd_step / ss_bwd_step: O(M) per position) a row costs 2 span - 1 steps instead of 2 M^3 flop: 1e5
+// against 2.7e8 operations at M = 512, and no eigensystem, no span-Q table - save_gamma keeps the eigen-free statistics, and is no
+// longer limited to 256 states.  One wavefront per row (persistent wavefronts, NPL states per lane): the forward vectors f_1 .. f_s are
+// parked as floats (alpha itself is a float) in the wavefront's own scratch piece, then the backward walk multiplies them in.  Both
+// walks rescale by the running sum; every term is normalised by its own dot product, so the scales cancel.
+// The generators of one direction are loaded inside that direction's walk (sixteen states per lane: both sets at once do not fit).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NPL>
+__global__ __launch_bounds__(256) void k_gamma_rows_scan(SsArgs sa, GammaRowArgs a, const RowInfo *__restrict__ rowinfo,
+                                                         const double *__restrict__ Ek, float *__restrict__ scratch, int smax, int nwaves) {
+    constexpr int MS = 64 * NPL;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= nwaves) return;
+    const int M = a.M, Mp = a.Mp;
+    float *park = scratch + (size_t)gw * smax * MS;
+    for (int q = gw; q < a.nrows; q += nwaves) {
+        const int qs = ss_uni(q);
+        const Slab sl = a.slabs[a.row_slab[qs]];
+        const int span = ss_uni(a.g_span[sl.aux]);
+        const size_t row = (size_t)(sl.base + a.perm[qs]);
+        const double *ek = Ek + (size_t)ss_uni(rowinfo[row].kid) * Mp;
+        {
+            // forward: positions p = state
+            SsFwdC<NPL> c;
+            ss_load_fwd<NPL>(sa, lane, c);
+            double x[NPL], ev[NPL];
+            const float *ap = a.alpha + (row - 1) * Mp;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const int st = lane * NPL + k;
+                const bool live = st < M;
+                x[k] = live ? (double)ap[live ? st : 0] : 0.0;
+                ev[k] = live ? ek[live ? st : 0] : 0.0;
+            }
+            double inv = 1.0;
+            for (int t = 0; t < span; ++t) {
+                double out[NPL], S;
+                ss_fwd_step<NPL>(c, x, ev, out, S);
+                inv = 1.0 / S;                         // (the sum of the vector the step started from: bounded, and it cancels below)
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    x[k] = out[k] * inv;
+                    park[(size_t)t * MS + lane * NPL + k] = (float)x[k];
+                }
+            }
+        }
+        // the parked vectors are read back by OTHER lanes of this wavefront (reversed state order): the stores have to be acknowledged
+        // first (one CU, one vector L1: a workgroup-scope fence is a wait, no cache maintenance)
+        __threadfence_block();
+        {
+            // backward: positions p = state MS - 1 - p
+            SsBwdC<NPL> c;
+            ss_load_bwd<NPL>(sa, lane, c);
+            double h[NPL], ev[NPL], g[NPL];
+            int st[NPL];
+            const double *bp = a.beta + row * Mp;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                st[k] = MS - 1 - (lane * NPL + k);
+                const bool live = st[k] < M;
+                h[k] = live ? bp[live ? st[k] : 0] : 0.0;
+                ev[k] = live ? ek[live ? st[k] : 0] : 0.0;
+                g[k] = 0.0;
+            }
+            for (int t = span - 1; t >= 0; --t) {
+                double pr[NPL], part = 0.0;
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    pr[k] = (double)park[(size_t)t * MS + st[k]] * h[k];
+                    part += pr[k];
+                }
+                const double idot = 1.0 / wave_sum_dpp(part);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) g[k] = __builtin_fma(pr[k], idot, g[k]);
+                if (t > 0) {
+                    double out[NPL];
+                    float Sw;
+                    ss_bwd_step<NPL>(c, h, ev, out, Sw);
+                    const double is = 1.0 / (double)Sw;
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) h[k] = out[k] * is;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NPL; ++k)
+                if (st[k] < Mp) a.gamma_rows[row * Mp + st[k]] = st[k] < M ? g[k] : 0.0;
+        }
+    }
+}
+
 // Unit-test entry (tests/test_gpu_ss.py through smcpp_debug_ss_apply): out_f = e o (T^T x), out_b = T (e o x) by the scans,
 // one wavefront per vector.  MIX / H32: the all-float scans of the stored passes (one state per lane) and their M <= 32 form.
 template <int NPL, bool MIX = false, bool H32 = false>

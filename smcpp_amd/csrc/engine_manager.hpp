@@ -138,6 +138,7 @@ struct smcpp_im {
     int ss_warm_parity = 0, ss_pass0 = 0;
     std::vector<int> ss_slot_of_key;       // frequency rank of every key (slot 0 = most rows)
     DevBuf<int2> d_rowdesc_ss;             // [rows, padded] {key slot, span}
+    DevBuf<float> d_gpark;                 // k_gamma_rows_scan: [wavefronts][max span][64 NPL] parked forward vectors
     DevBuf<double> d_Fall;                 // [n_contigs Ke][smax][Mp][Mp] scratch of the span fold for M > 64 (k_span_big)
     SsArgs ss_args;
     std::vector<Chunk> chunks_b;           // backward chunks of the scan chains (more and shorter than the forward ones)

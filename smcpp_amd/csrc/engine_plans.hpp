@@ -1106,13 +1106,28 @@ void smcpp_im::enqueue_stats() {
         ga.Prm = d_Prm.p; ga.Pinvrm = d_Pinvrm.p; ga.PinvT = d_PinvT.p; ga.Sq = nullptr;
         ga.alpha = d_alpha.p; ga.beta = d_beta.p; ga.gamma_rows = d_gamma_rows.p;
         const bool mfma_rows = NT <= 4;          // (M > 64: the scalar kernel on a span-Q table in memory)
+        if (eigfree) {
+            // no eigensystem on this path: 2 span - 1 scan steps per row, one (persistent) wavefront per row, the forward vectors parked
+            // as floats in the wavefront's piece of a scratch buffer
+            const int nw = (int)std::min<long long>((long long)n_e_rows, NPL >= 8 ? 1024 : 4096);
+            d_gpark.alloc((size_t)nw * ss_max_span * 64 * NPL);
+            const dim3 grid(ceil_div(nw, 4)), block(256);
+            switch (NPL) {
+#define GS_(x) case x: hipLaunchKernelGGL((k_gamma_rows_scan<x>), grid, block, 0, sg, ss_args, ga, (const RowInfo *)d_rowinfo.p, \
+                                          (const double *)d_E.p, d_gpark.p, ss_max_span, nw); break;
+                GS_(1) GS_(2) GS_(3) GS_(4) GS_(8)
+                default: GS_(16)
+#undef GS_
+            }
+        } else
         if (!mfma_rows) {
             d_Sq.alloc((size_t)G * Mp * Mp);
             hipLaunchKernelGGL(k_span_q, dim3(nb2, G), dim3(256), 0, sg, M, Mp, G, (const int *)d_g_span.p,
                                (const int *)d_g_eig.p, (const double *)d_dsc.p, (const double *)d_dpow.p, d_Sq.p);
             ga.Sq = d_Sq.p;
         }
-        if (mfma_rows) {
+        if (eigfree) {
+        } else if (mfma_rows) {
             // one launch per (contig, eigen key): a workgroup shares one LDS copy of P, Pinv and the reciprocal eigenvalue differences
             // (NT > 2: the reciprocal differences live in registers and the fold tile is half as wide - four wavefronts fit as well)
             const int NW = 4;
@@ -1197,10 +1212,13 @@ void smcpp_im::estep() {
     HIPCHK(hipEventRecord(ev[0], stream));
     // span > 1 rows without an eigensystem (kernels.hpp: k_span_fold): the span is expanded by smax steps of two M x M products
     const bool eigfree_off = opt().off(smcpp_opt::O_EIGFREE);
-    const bool eigfree_static = !eigfree_off && Mp <= 1024 && ss_max_span <= 64 && !save_gamma;
+    // (round 6) save_gamma keeps the eigen-free path: the per-row posteriors of the span > 1 rows come from scan steps as well
+    // (chains_ss.hpp: k_gamma_rows_scan); SMCPP_GAMMA_SCAN=0: eigensystems, as in rounds 1-5 (M <= 256)
+    const bool gamma_scan = !opt().off(smcpp_opt::O_GAMMA_SCAN);
+    const bool eigfree_static = !eigfree_off && Mp <= 1024 && ss_max_span <= 64 && (!save_gamma || gamma_scan);
     if (Mp > 256 && !(ss_static && eigfree_static))
         throw std::runtime_error("more than 256 hidden states: only the scan chains with eigen-free statistics are built (binned data "
-                                 "with spans <= 64, no save_gamma)");
+                                 "with spans <= 64)");
     // only the lean path (scan chains + eigen-free statistics) reads a device-prepared emission table from HBM alone (its
     // underflow bound is checked by the kernel that forms the table); eigensystems, operand layouts, the dense chains and the
     // bound for longer spans need the host copy

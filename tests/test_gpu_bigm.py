@@ -7,7 +7,8 @@ round 6: 512 < M <= 1024 with sixteen; the reference has no limit, src/inference
   * M = 512 on 1 000 rows against golden G21 and M = 768 on 300 rows against golden G24 = the COMPILED reference
     (tests/golden/make_golden_m512.py), through `im.model = ...`: the engine's own cold preparation on the device;
   * M = 768 (70 rows) and M = 1024 (40 rows) against the C restatement;
-  * what is not built beyond 256 fails loudly: save_gamma, a transition matrix without the reference's structure.
+  * save_gamma beyond 256 states (round 6): every column of gamma against the restatement's;
+  * what is not built beyond 256 fails loudly: a transition matrix without the reference's structure.
 """
 import os
 
@@ -55,7 +56,7 @@ def test_more_than_256_states_vs_oracle(M, rows, chunk):
     keys = im.keys
     ep = im.emission_probs
     Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
-    o = oracle.estep(im.pi, im.transition, keys, Etab, obs)
+    o = oracle.estep(im.pi, im.transition, keys, Etab, obs, save_gamma=True)
     ll = im.loglik()
     assert abs(ll - o["loglik"]) <= LL_TOL * abs(o["loglik"]), (ll, o["loglik"])
     tol = _stat_tol(M)
@@ -72,6 +73,22 @@ def test_more_than_256_states_vs_oracle(M, rows, chunk):
     im1.E_step()
     assert abs(im1.loglik() - ll) <= 1e-9 * abs(ll)
     assert rel_err(im1.xisums[0], im.xisums[0]) <= tol
+    # (round 6) save_gamma beyond 256 states: the per-row posteriors of the span > 1 rows from scan steps (k_gamma_rows_scan; the
+    # reference's come from the eigensystem of the row's key, hmm.cpp:113-121,141-150) - every column against the restatement's
+    im.save_gamma = True
+    im.E_step()
+    gam = im.gammas[0]
+    assert gam.shape == o["gamma"].shape == (M, rows + 1)
+    spans = np.concatenate([[1.0], obs[:, 0].astype(float)])          # (a column sums to its row's span; column 0 to one)
+    err = np.max(np.abs(gam - o["gamma"]), axis=0) / spans
+    print(f"M = {M}: per-row gamma, worst column {err.max():.2e} of its span (spans up to {int(obs[:, 0].max())}); "
+          f"column sums vs span {np.max(np.abs(gam[:, 1:].sum(axis=0) - obs[:, 0])):.2e}")
+    assert err.max() <= 2e-5
+    arg, ref = gam.argmax(axis=0), o["gamma"].argmax(axis=0)
+    top2 = np.sort(o["gamma"], axis=0)[-2:]
+    strong = (top2[1] - top2[0]) > 1e-5 * spans
+    assert not np.any(strong & (arg != ref)), np.nonzero(strong & (arg != ref))[0][:10]
+    assert abs(im.loglik() - ll) <= 1e-9 * abs(ll)
 
 
 @pytest.mark.parametrize("fixture,chunk", [("G21_M512_n10_1000rows", 250), ("G24_M768_n10_300rows", 100)])
@@ -148,10 +165,6 @@ def test_beyond_256_states_unbuilt_paths_fail_loudly():
     from smcpp_amd import synth
     n = 10
     obs = np.ascontiguousarray(synth.synth_contig(0, 100_000_000, n)[:500], dtype=np.int32)
-    im = _manager(300, n, obs)
-    im.save_gamma = True
-    with pytest.raises(RuntimeError, match="256"):
-        im.E_step()
     im = _manager(300, n, obs)
     im.E_step()
     rng = np.random.default_rng(0)

@@ -95,6 +95,32 @@ def test_golden_posterior(golden, chain_family):
     check_against(golden, im, save_gamma=True)
 
 
+def test_per_row_gamma_from_scan_steps_vs_eigensystems(engine_opt):
+    """Round 6: with save_gamma the engine keeps its eigen-free path on binned data - the per-row posterior of a span > 1 row is the sum
+    over its positions of forward x backward scan vectors (`k_gamma_rows_scan`, 2 span - 1 O(M) steps) instead of the reference's
+    eigensystem formula (hmm.cpp:113-121: `k_gamma_rows_b` / `k_gamma_rows_eig`, 2 M^3 flop; SMCPP_GAMMA_SCAN=0).  Both against the
+    compiled reference's goldens (every check of `check_against`, the decoded index on EVERY column) and against each other."""
+    res = {}
+    for scan in ("0", "1"):
+        engine_opt("SMCPP_GAMMA_SCAN", scan)
+        for name in ("G4_M64_n20_2Mbp", "G3_M32_n10_2Mbp", "G1_M16_n4", "G5_M48_twopop_layout"):
+            g = load_golden(name)
+            im = make_im(g)
+            im.save_gamma = True
+            im.E_step()
+            plan = im.describe()["plan"]
+            # (G1 holds spans up to 199: beyond the eigen-free statistics' 64, it keeps the eigensystems in either setting)
+            eigen_free = scan == "1" and int(g["obs"][:, 0].max()) <= 64
+            assert plan["per_row_gamma"] == ("scan steps" if eigen_free else "eigensystem"), (name, plan)
+            check_against(g, im, save_gamma=True)
+            res[(scan, name)] = im.gammas[0]
+    for (scan, name), gam in res.items():
+        if scan == "1":
+            d = np.max(np.abs(gam - res[("0", name)]))
+            print(f"{name}: per-row gamma, scan steps vs eigensystems: max abs difference {d:.2e}")
+            assert d <= 2e-6
+
+
 @pytest.mark.parametrize("rows_per_chunk", [37, 100, 1000000])
 def test_chunking_invariance(rows_per_chunk):
     """The chunk-parallel chains must reproduce the single-chunk (purely sequential) run."""

@@ -74,6 +74,15 @@ struct SsArgs {
 };
 
 constexpr int SS_KE_MAX = 4;
+// rowdesc.x: bits 0-15 key slot, 16-23 eigen key (hybrid rows), bit 30: the row continues the caller's row of the row before it (a long
+// row of binned data cut into pieces, engine_manager.hpp: build) - the alpha stored at its START is an interior point of a row of the
+// reference's, which neither floors nor stores it: it is stored un-floored (the statistics of the next piece read it)
+constexpr int SS_ROW_CONT = 1 << 30;
+// (rows are only cut when M > 64, i.e. with two or more states per lane: the one-state-per-lane instantiations keep the constant)
+template <int NPL>
+__device__ __forceinline__ float ss_floor_of(int descx) { return (NPL >= 2 && (descx & SS_ROW_CONT)) ? 0.f : 1e-10f; }
+template <int NPL>
+__device__ __forceinline__ float ss_floor_at(const SsArgs &a, long long row) { return NPL >= 2 ? ss_floor_of<NPL>(a.rowdesc[row].x) : 1e-10f; }
 
 template <int CTRL>
 __device__ __forceinline__ double dpp0(double v) {      // shifted copy, 0.0 where the source lane does not exist
@@ -676,7 +685,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
             const double iv = 1.0 / wave_sum_dpp(part);
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
-                const float an = live[k] ? fmaxf((float)(x[k] * iv), 1e-10f) : 0.f;
+                const float an = live[k] ? fmaxf((float)(x[k] * iv), ss_floor_at<NPL>(a, ch.base + ch.r0 + 1)) : 0.f;
                 x[k] = (double)an;
                 if (stor[k]) a.used_f[(size_t)c * Mp + st[k]] = an;
             }
@@ -743,7 +752,8 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
-        const int ekr = __builtin_amdgcn_readlane(dcur.x, jl) >> 16;
+        const int ekr = (__builtin_amdgcn_readlane(dcur.x, jl) >> 16) & 0xFF;
+        const float flo = NPL >= 2 ? ss_floor_of<NPL>(__builtin_amdgcn_readlane(dcur.x, jl)) : 1e-10f;   // floor of the vector stored where this row begins
         npos += span;
         // descriptor / emission vector of the next row
         if (jl == 63) { dcur = dnxt; dnxt = rd[j + 65 + lane]; ss_desc_settle(dnxt); }
@@ -757,7 +767,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
             const double inv = rcp_f64(S);
             double xin = x[0] * inv;
             if (j > 0) {
-                const float an = live[0] ? fmaxf((float)xin, 1e-10f) : 0.f;
+                const float an = live[0] ? fmaxf((float)xin, flo) : 0.f;
                 if (RERUN && !a.full_f && (j & 15) == 0 && j >= 16) {
                     bool bad = false;
                     if (live[0]) {
@@ -798,7 +808,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
                 const double xs = x[k] * inv;
-                an[k] = live[k] ? fmaxf((float)xs, 1e-10f) : 0.f;
+                an[k] = live[k] ? fmaxf((float)xs, flo) : 0.f;
                 fb[k] = (double)an[k] - xs;
             }
             if (RERUN && !a.full_f && (j & 15) == 0 && j >= 16) {
@@ -877,7 +887,7 @@ __device__ __forceinline__ void ss_forward_wave(const SsArgs &a, const double *s
         const double inv = 1.0 / S;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
-            const float an = live[k] ? fmaxf((float)(x[k] * inv), 1e-10f) : 0.f;
+            const float an = live[k] ? fmaxf((float)(x[k] * inv), ss_floor_at<NPL>(a, ch.base + ch.r1 + 1)) : 0.f;
             if (stor[k]) { a.alpha[(size_t)(ch.base + ch.r1) * Mp + st[k]] = an; end_cur[st[k]] = an; }
         }
         if (lane == 0) { a.cnorm[ch.base + ch.r1] = S; a.endchg_f[pass] = 1; }
@@ -972,7 +982,7 @@ __device__ __forceinline__ void ss_backward_wave(const SsArgs &a, const double *
     for (int j = 0; j < nrows; ++j) {
         const int jl = j & 63;
         const int span = __builtin_amdgcn_readlane(dcur.y, jl);
-        const int ekr = __builtin_amdgcn_readlane(dcur.x, jl) >> 16;
+        const int ekr = (__builtin_amdgcn_readlane(dcur.x, jl) >> 16) & 0xFF;
         npos += span;
         if (jl == 63) { dcur = dnxt; dnxt = rd[-(j + 65) - lane]; ss_desc_settle(dnxt); }
         const int slot_n = __builtin_amdgcn_readlane(dcur.x, (j + 1) & 63) & 0xFFFF;
@@ -1379,7 +1389,7 @@ __device__ __forceinline__ void ss_forward_light(const SsArgs &a, const double *
     for (int k = 0; k < NPL; ++k) part += x[k];
     const float inv = 1.f / wave_sum_dpp(part);
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = live[k] ? fmaxf(x[k] * inv, 1e-10f) : 0.f;
+    for (int k = 0; k < NPL; ++k) if (stor[k]) end_cur[st[k]] = live[k] ? fmaxf(x[k] * inv, ss_floor_at<NPL>(a, ch.base + ch.r1 + 1)) : 0.f;
 }
 
 template <int NPL, bool ALLLDS, bool H32 = false>

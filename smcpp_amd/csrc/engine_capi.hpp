@@ -302,6 +302,18 @@ int smcpp_get_gamma(smcpp_im *im, int c, double *out) {
     std::vector<double> rows((size_t)(L + 1) * Mp);
     HIPCHK(hipMemcpy(rows.data(), im->d_gamma_rows.p + (size_t)im->contig_base[c] * Mp, rows.size() * sizeof(double),
                      hipMemcpyDeviceToHost));
+    if (im->split_spans) {
+        // the pieces of a long row add up to the row's posterior (engine_manager.hpp: build)
+        const int Lu = im->user_Ls[c];
+        const std::vector<int> &pr = im->piece_row[c];
+        std::fill(out, out + (size_t)M * (Lu + 1), 0.0);
+        for (int i = 0; i < M; ++i) {
+            double *o = out + (size_t)i * (Lu + 1);
+            o[0] = im->h_gamma0[(size_t)c * M + i];
+            for (int l = 1; l <= L; ++l) o[pr[l]] += rows[(size_t)l * Mp + i];
+        }
+        return 0;
+    }
     for (int i = 0; i < M; ++i) {
         out[(size_t)i * (L + 1)] = im->h_gamma0[(size_t)c * M + i];
         for (int l = 1; l <= L; ++l) out[(size_t)i * (L + 1) + l] = rows[(size_t)l * Mp + i];
@@ -311,7 +323,7 @@ int smcpp_get_gamma(smcpp_im *im, int c, double *out) {
 
 int smcpp_gamma_cols(smcpp_im *im, int c) {
     if (c < 0 || c >= im->n_contigs) return -1;
-    return im->gamma_valid ? im->Ls[c] + 1 : 1;
+    return im->gamma_valid ? im->user_Ls[c] + 1 : 1;
 }
 
 int smcpp_get_gamma_argmax(smcpp_im *im, int c, int *out) {
@@ -321,6 +333,19 @@ int smcpp_get_gamma_argmax(smcpp_im *im, int c, int *out) {
     HIPCHK(hipSetDevice(im->device));
     const int L = im->Ls[c];
     im->fetch_stats();
+    if (im->split_spans) {
+        // (rows cut into pieces: the pieces' posteriors are added on the host first)
+        const int Lu = im->user_Ls[c], M = im->M;
+        std::vector<double> g((size_t)M * (Lu + 1));
+        if (smcpp_get_gamma(im, c, g.data()) != 0) throw std::runtime_error(smcpp_last_error());
+        for (int l = 0; l <= Lu; ++l) {
+            int best = 0;
+            for (int i = 1; i < M; ++i)
+                if (g[(size_t)i * (Lu + 1) + l] > g[(size_t)best * (Lu + 1) + l]) best = i;
+            out[l] = best;
+        }
+        return 0;
+    }
     im->d_argmax.alloc((size_t)im->total_rows);
     hipLaunchKernelGGL(k_gamma_argmax, dim3(ceil_div(L + 1, 256)), dim3(256), 0, im->stream, im->M, im->Mp,
                        (long long)(L + 1), (const double *)(im->d_gamma_rows.p + (size_t)im->contig_base[c] * im->Mp),

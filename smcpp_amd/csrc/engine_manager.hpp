@@ -138,6 +138,12 @@ struct smcpp_im {
     int ss_warm_parity = 0, ss_pass0 = 0;
     std::vector<int> ss_slot_of_key;       // frequency rank of every key (slot 0 = most rows)
     DevBuf<int2> d_rowdesc_ss;             // [rows, padded] {key slot, span}
+    // rows of binned data longer than 64 positions, cut into pieces at construction (build()): the caller's row counts, the pieces'
+    // rows (what every kernel sees) and piece -> caller's row, per contig (1-based rows; entry 0 = row 0)
+    bool split_spans = false;
+    std::vector<int> user_Ls;
+    std::vector<std::vector<int>> split_store, piece_row;
+    std::vector<const int *> split_ptr;
     DevBuf<float> d_gpark;                 // k_gamma_rows_scan: [wavefronts][max span][64 NPL] parked forward vectors
     DevBuf<double> d_Fall;                 // [n_contigs Ke][smax][Mp][Mp] scratch of the span fold for M > 64 (k_span_big)
     SsArgs ss_args;
@@ -297,6 +303,48 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
     if (M > 1024) throw std::runtime_error("M > 1024 hidden states is not supported by this build");
     n_contigs = n_contigs_;
     Ls.assign(Ls_, Ls_ + n_contigs);
+    user_Ls = Ls;
+    // (round 6) Long rows of BINNED data cut into pieces of at most 64 positions.  A row of span s with key k is s identical positions;
+    // the rows (s1, k), (s2, k) with s1 + s2 = s are the same positions: the same likelihood, the same xi sums and gamma sums, and
+    // the row's posterior (hmm.cpp:113-121: the sum over its positions, normalised to s) is the sum of the pieces' posteriors.  The
+    // eigen-free statistics walk a span in at most 64 steps (k_span_scan) and are all that exists beyond 256 states; up to 256 the
+    // alternative for such rows is an eigensolve of every key's M x M operator on the host per E-step.  So for M > 64 the pieces are
+    // what every kernel sees; the getters that report per row (gamma, its argmax, the column count) add the pieces up again.
+    // Only where the pieces stay few: un-binned data (spans of 10^4 - 10^5 base pairs) keep their rows and the eigen-power steps.
+    {
+        const int ncol_ = 1 + keylen;
+        long long rows = 0, pieces = 0;
+        int maxspan = 0;
+        for (int c = 0; c < n_contigs; ++c)
+            for (int i = 0; i < Ls[c]; ++i) {
+                const int sp = obs[c][(size_t)i * ncol_];
+                if (sp <= 0) throw std::runtime_error("data are malformed: span <= 0");
+                rows++; pieces += (sp + 63) / 64; maxspan = std::max(maxspan, sp);
+            }
+        const bool want = M > 64 && !opt().off(smcpp_opt::O_SPLIT_SPANS);      // (M <= 64: the one-state-per-lane chains have no un-floored store)
+        split_spans = want && maxspan > 64 && pieces <= 2 * rows + 1024;
+        if (split_spans) {
+            split_store.assign(n_contigs, std::vector<int>());
+            split_ptr.assign(n_contigs, nullptr);
+            piece_row.assign(n_contigs, std::vector<int>());
+            for (int c = 0; c < n_contigs; ++c) {
+                std::vector<int> &so = split_store[c];
+                std::vector<int> &pr = piece_row[c];
+                pr.push_back(0);                              // (internal row 0 = the caller's row 0: the initial distribution)
+                for (int i = 0; i < user_Ls[c]; ++i) {
+                    const int *r = obs[c] + (size_t)i * ncol_;
+                    for (int left = r[0]; left > 0; left -= 64) {
+                        so.push_back(std::min(left, 64));
+                        so.insert(so.end(), r + 1, r + ncol_);
+                        pr.push_back(i + 1);
+                    }
+                }
+                Ls[c] = (int)(so.size() / ncol_);
+                split_ptr[c] = so.data();
+            }
+            obs = split_ptr.data();
+        }
+    }
     contig_base.resize(n_contigs);
     total_rows = 0;
     for (int c = 0; c < n_contigs; ++c) {
@@ -964,6 +1012,12 @@ void smcpp_im::alloc_device() {
                 // (upper 16 bits of x: the eigen key of a span > 1 row, read by the hybrid rows only)
                 rd[ROWDESC_PAD + r] = make_int2(ss_slot_of_key[ri.kid] | ((ri.gid < 0 ? 0 : groups[ri.gid].eig) << 16), ri.gid < 0 ? 1 : groups[ri.gid].span);
             }
+            // (round 6) a row that CONTINUES the caller's row of the row before it (long rows cut into pieces, build()): the vector
+            // stored where it begins is not one the reference stores - no 1e-10 floor there (SS_ROW_CONT; chains_ss.hpp)
+            if (split_spans)
+                for (int c = 0; c < n_contigs; ++c)
+                    for (int ell = 2; ell <= Ls[c]; ++ell)
+                        if (piece_row[c][ell] == piece_row[c][ell - 1]) rd[ROWDESC_PAD + (size_t)contig_base[c] + ell].x |= SS_ROW_CONT;
             d_rowdesc_ss.upload(rd, s);
             HIPCHK(hipStreamSynchronize(s));
         }

@@ -215,13 +215,13 @@ int smcpp_describe(smcpp_im *im, char *buf, int cap) {
                  "\"chunks_forward\": %zu, \"chunks_backward\": %zu, \"wavefronts_per_simd\": %d, \"halo_pass\": %s, "
                  "\"light_passes_forward\": %d, \"light_passes_backward\": %d, \"float_scans_in_stored_passes\": %s, "
                  "\"passes_to_certificate\": %d, \"passes_launched\": %d, \"certificate_pass_launched_up_front\": %s, "
-                 "\"save_gamma\": %s, \"eigen_free_statistics\": %s, \"per_row_gamma\": \"%s\", \"warm_start\": %s, \"host_threads\": %d}",
+                 "\"save_gamma\": %s, \"eigen_free_statistics\": %s, \"per_row_gamma\": \"%s\", \"long_rows_cut\": %s, \"warm_start\": %s, \"host_threads\": %d}",
                  fam, im->ss_static ? "true" : "false", im->ss_hybrid ? "true" : "false", im->M, im->Mp, im->NPL, im->K, im->Ke,
                  (long long)(im->total_rows - im->n_contigs), (long long)im->ss_positions, im->ss_max_span, im->chunks.size(),
                  im->chunks_b.size(), im->ss_wpc, (im->ss_static && im->ss_args.halo) ? "true" : "false", im->ss_light_f, im->ss_light_b,
                  (im->ss_static && im->ss_args.mixed) ? "true" : "false", im->last_ss_passes, im->ss_launched,
                  (opt().on(smcpp_opt::O_SS_CERT_PASS) || im->ss_need_cert_pass) ? "true" : "false", im->save_gamma ? "true" : "false",
-                 im->eigfree ? "true" : "false", !im->save_gamma ? "none" : im->eigfree ? "scan steps" : "eigensystem",
+                 im->eigfree ? "true" : "false", !im->save_gamma ? "none" : im->eigfree ? "scan steps" : "eigensystem", im->split_spans ? "true" : "false",
                  im->warm_start ? "true" : "false", omp_get_max_threads());
         s += t;
     }

@@ -161,6 +161,73 @@ def test_rank_update_with_lds_staged_rows_vs_per_wavefront_form(engine_opt, M, r
             np.testing.assert_allclose(g[k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
 
 
+@pytest.mark.parametrize("M,rows", [(128, 1500), (300, 700)])
+def test_long_rows_of_binned_data_cut_into_pieces(engine_opt, M, rows):
+    """Round 6: rows of binned data longer than 64 positions (the example-derived contig of golden G1 holds spans up to 199) are cut
+    into pieces of at most 64 at construction when M > 64, so that the eigen-free statistics - all there is beyond 256 states - apply;
+    the getters add the pieces up.  Against the C restatement, which takes such a row in ONE eigen-power step as the reference does
+    (hmm.cpp:72-78,104-121): log-likelihood, xi sums, gamma sums, Q and EVERY column of gamma; at M = 128 also against the engine's own
+    un-cut route (SMCPP_SPLIT_SPANS=0: eigensystems on the host)."""
+    from oracle import oracle
+    from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel
+    g = np.load(os.path.join(GOLDEN, "G1_M16_n4.npz"))
+    obs = np.ascontiguousarray(g["obs"][:rows], dtype=np.int32)
+    assert obs[:, 0].max() > 64
+    n = 4
+    a, s = synth.model_pieces()
+
+    def manager():
+        im = _smcpp.PyOnePopInferenceManager(n, [obs], synth.hidden_states(M), ("pop1",), 0.5)
+        im.model = PiecewiseModel(a, s, 1e4, "pop1")
+        im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = 1.0
+        im.save_gamma = True
+        im.E_step()
+        return im
+    im = manager()
+    plan = im.describe()["plan"]
+    assert plan["long_rows_cut"] and plan["eigen_free_statistics"] and plan["per_row_gamma"] == "scan steps", plan
+    keys = im.keys
+    ep = im.emission_probs
+    Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
+    o = oracle.estep(im.pi, im.transition, keys, Etab, obs, save_gamma=True)
+    ll = im.loglik()
+    assert abs(ll - o["loglik"]) <= LL_TOL * abs(o["loglik"]), (ll, o["loglik"])
+    # The restatement (as the reference) takes a 199-position row through the 199th power of the eigenvalues of a NON-symmetric
+    # M x M operator: at M >= 128 its own entries of the xi sums carry ~2e-5 of that eigensystem's conditioning on the small entries
+    # (measured: the engine's un-cut route, which also uses eigensystems, and the cut route - position by position, no eigensystem -
+    # sit 1.8e-5 / 1.7e-5 from it on the SAME entries and 2.9e-6 from each other).  Per entry 5e-5 here; 5e-6 of the largest entry;
+    # and 5e-6 per entry between the engine's two routes below.
+    xs = im.xisums[0]
+    assert rel_err(xs, o["xisum"]) <= 5e-5
+    assert np.abs(xs - o["xisum"]).max() <= STAT_TOL * np.abs(o["xisum"]).max()
+    for k, v in o["gamma_sums"].items():
+        assert np.max(np.abs(im.gamma_sums[0][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300), k
+    q = np.array(im.Q(separate=True))
+    assert np.all(np.abs(q - o["q"]) <= STAT_TOL * np.maximum(np.abs(o["q"]), 1e-12)), (q, o["q"])
+    gam = im.gammas[0]
+    assert gam.shape == o["gamma"].shape == (M, rows + 1)
+    spans = np.concatenate([[1.0], obs[:, 0].astype(float)])
+    err = np.max(np.abs(gam - o["gamma"]), axis=0) / spans
+    print(f"M = {M}, spans up to {int(obs[:, 0].max())}: loglik rel {abs(ll - o['loglik']) / abs(o['loglik']):.2e}, xi sums "
+          f"{rel_err(im.xisums[0], o['xisum']):.2e}, per-row gamma worst column {err.max():.2e} of its span")
+    assert err.max() <= 2e-5
+    top2 = np.sort(o["gamma"], axis=0)[-2:]
+    strong = (top2[1] - top2[0]) > 1e-5 * spans
+    arg = np.asarray(im.gamma_argmax(0))
+    assert np.array_equal(arg, gam.argmax(axis=0))
+    assert not np.any(strong & (arg != o["gamma"].argmax(axis=0)))
+    if M <= 256:
+        engine_opt("SMCPP_SPLIT_SPANS", "0")
+        im0 = manager()
+        plan0 = im0.describe()["plan"]
+        assert not plan0["long_rows_cut"] and plan0["per_row_gamma"] == "eigensystem", plan0
+        assert abs(im0.loglik() - ll) <= 1e-8 * abs(ll)
+        print(f"   cut vs un-cut route: xi sums per entry {rel_err(im0.xisums[0], xs):.2e}")
+        assert rel_err(im0.xisums[0], xs) <= STAT_TOL
+        assert np.max(np.abs(im0.gammas[0] - gam) / spans) <= 2e-5
+
+
 def test_beyond_256_states_unbuilt_paths_fail_loudly():
     from smcpp_amd import synth
     n = 10

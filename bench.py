@@ -9,7 +9,7 @@ what `InferenceManager::Estep` does after `setParams` (src/inference_manager.cpp
 `split_ms.hmm_only_ms` additionally reports the same eval with the prepared parameters handed over by `set_raw`
 (no A6-A10), which is what round 1 timed.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c3|c4|c5|posterior] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c3|c4|c5|posterior|posterior64|pbinned|qgrad|shaping] [--no-cpu]
 
 `--gpus N` with N > 1 and no torchrun environment re-launches itself under `torch.distributed.run` (one rank per
 GPU, RCCL); under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  Every rank owns one synthetic 100 Mbp contig
@@ -55,6 +55,9 @@ WORKLOADS = {
     # ... the same at M = 64: the eigenvector tables of the hybrid rows (133 KB per eigen key) do not fit LDS, so the dense
     # cooperative chains run (the regime hole DESIGN.md section 9 names; measured, not hidden)
     "posterior64": (64, 8, None, "posterior decode: 1 un-binned contig, 1e6 rows, spans to 1e5, rho=6e-5, M=64, n=8, save_gamma"),
+    # posterior decode of BINNED data (round 6: save_gamma keeps the eigen-free path - per-row posteriors of the span > 1 rows from scan
+    # steps, k_gamma_rows_scan): the headline contig with save_gamma; parity = the decoded index of every column against golden G19
+    "pbinned": (64, 20, "params_M64_n20.npz", "posterior decode of 1 binned synthetic 100 Mbp contig, M=64, n=20, save_gamma"),
     # SURVEY.md 8 f-2 on the device: what data_filter.py does to a contig before an inference manager sees it (integer, HBM-bound)
     "shaping": (0, 8, None, "pre-HMM data shaping Thin(400) -> Bin(100) -> Compress of 1 un-binned contig, 1e6 rows (4.8e8 bp), on the device"),
 }
@@ -268,7 +271,7 @@ def main():
         im = factory(contigs, local_rank)
     top = sim if sim is not None else im
     top.theta = theta; top.rho = rho; top.alpha = alpha
-    if args.workload in ("posterior", "posterior64"):
+    if args.workload in ("posterior", "posterior64", "pbinned"):
         im.save_gamma = True
     if args.chunk or args.eps_alpha or args.eps_beta:
         im.set_chunking(args.chunk, args.eps_alpha, args.eps_beta)
@@ -635,8 +638,8 @@ def main():
     # posterior workloads: the decode's indices at full size against the compiled reference's (golden G20,
     # tests/golden/make_golden_argmax.py: argmax of every one of the 10^6 + 1 columns, the columns with a margin below 1e-3)
     try:
-        gp = os.path.join(ROOT, "tests", "golden", f"G20_{args.workload}.npz")
-        if args.workload in ("posterior", "posterior64") and os.path.exists(gp) and world == 1 and not args.raw:
+        gp = os.path.join(ROOT, "tests", "golden", "G19_headline.npz" if args.workload == "pbinned" else f"G20_{args.workload}.npz")
+        if args.workload in ("posterior", "posterior64", "pbinned") and os.path.exists(gp) and world == 1 and not args.raw:
             z = np.load(gp)
             if synth.contig_crc(contigs[0]) == int(z["crc"]):
                 arg = np.asarray(im.gamma_argmax(0)).astype(np.int64)

@@ -25,7 +25,16 @@ def run_case(case):
     """-> dict of outputs of one fresh manager"""
     kind, name = case.split(":")
     g = golden(name) if not name.startswith("params") else dict(np.load(os.path.join(G, name + ".npz")))
-    if kind == "m768":
+    if kind == "cut":
+        # (round 6) rows longer than 64 positions cut into pieces, M = 144 (nine 16-state tiles: the LDS-staged rank updates with a ragged
+        # block), save_gamma: per-row posteriors from scan steps
+        obs = [np.ascontiguousarray(g["obs"][:1500], dtype=np.int32)]
+        a_, s_ = synth.model_pieces()
+        im = _smcpp.PyOnePopInferenceManager(int(g["n"]), obs, synth.hidden_states(144), ("pop1",), 0.5)
+        im.model = PiecewiseModel(a_, s_, 1e4, "pop1")
+        im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = 1.0
+        im.save_gamma = True
+    elif kind == "m768":
         # sixteen states per lane, ONE chunk per contig (the sequential algorithm)
         n = 10
         obs = [np.ascontiguousarray(synth.synth_contig(0, 100_000_000, n)[:70], dtype=np.int32)]
@@ -81,7 +90,7 @@ def run_case(case):
         q, jac = im.Q_with_gradient() if hasattr(im, "Q_with_gradient") else (None, None)
         if jac is not None:
             out["jac"] = np.asarray(jac)
-    if kind in ("gamma", "biggamma", "post"):
+    if kind in ("gamma", "biggamma", "post", "cut"):
         out["argmax"] = np.asarray(im.gamma_argmax(0)).astype(np.float64)
     return out
 
@@ -90,7 +99,7 @@ def main():
     cases = sys.argv[1:] or ["raw:G1_M16_n4", "raw:G3_M32_n10_2Mbp", "raw:G4_M64_n20_2Mbp", "gamma:G3_M32_n10_2Mbp", "gamma:G7_M32_n8_chr11",
                              "gamma:G18_M64_n8_chr11", "raw:G5_M48_twopop_layout", "raw:G2_M51_n6_longspans", "model:params_M64_n20",
                              "model:params_M32_n10", "model:params_M256_n50", "m1:params_M32_n10", "big:params_M64_n20",
-                             "biggamma:params_M32_n10", "post:params_M32_n10", "big:params_M256_n50"]
+                             "biggamma:params_M32_n10", "post:params_M32_n10", "big:params_M256_n50", "cut:G1_M16_n4", "biggamma:params_M256_n50"]
     for case in cases:
         if os.environ.get("PROBE_CHILD") == case:
             # child: log the allocations of one clean manager to stderr

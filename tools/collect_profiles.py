@@ -20,7 +20,8 @@ for w in ("c3", "c5", "posterior", "qgrad"):
         shutil.copy(ks[0], f"profiles/{tag}_{w}_kernel_stats.csv")
 for f in glob.glob(f"{src}/{tag}_*_sq_counters.json"):
     shutil.copy(f, "profiles/" + os.path.basename(f))
-for name in ("shard_probe.log", "dpp_lab.log", "sync_lab.log", "host_trace.log", "exchange_cost.log", "c4_host_timing.log",
+for name in ("shard_probe.log", "dpp_lab.log", "sync_lab.log", "host_trace.log", "exchange_cost.log", "c4_host_timing.log", "gamma_scan_probe.log",
+             "poison_probe.log", "c4_watch.txt", "gpu_suite.log",
              "stats_timeline_headline.txt", "stats_timeline_c5.txt"):
     if os.path.exists(f"{src}/{name}"):
         shutil.copy(f"{src}/{name}", f"profiles/{tag}_{name}")

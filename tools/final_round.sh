@@ -7,7 +7,7 @@ TAG=${1:-r05_b}
 cd $GRAFT_REPO_ROOT
 bash tools/profile_round.sh $TAG > /dev/null 2>&1
 O=gpurun_out/$TAG
-bash tools/pmc_sq_counters.sh $TAG headline c3 > $O/sq.log 2>&1
+bash tools/pmc_sq_counters.sh $TAG headline c3 c5 > $O/sq.log 2>&1
 for w in c2 c3 c4 c5 posterior posterior64 pbinned; do python bench.py --workload $w > $O/bench_$w.log 2>&1; grep '^{"metric"' $O/bench_$w.log | tail -1 | cut -c1-200; done
 python bench.py --workload qgrad > $O/bench_qgrad.log 2>&1; grep '^{"metric"' $O/bench_qgrad.log | tail -1 | cut -c1-260
 SMCPP_BENCH_THREADS=1 python bench.py --no-cpu > $O/bench_default_1thread.log 2>&1; grep '^{"metric"' $O/bench_default_1thread.log | tail -1 | cut -c1-200

@@ -112,6 +112,35 @@ def test_estep_with_device_preparation_matches_host_preparation_and_golden(name)
     assert np.all(np.abs(q_d - g["q"]) <= 5e-6 * np.abs(g["q"]))
 
 
+@pytest.mark.parametrize("fixture,rows", [("params_M32_n10.npz", 20000), ("params_M64_n20.npz", 20000), ("params_M256_n50.npz", 4000)])
+def test_scan_chains_take_their_operator_from_the_generators(engine_opt, fixture, rows):
+    """Round 6: on the device-prepared model path the M x M transition matrix is expanded only when somebody reads it - the scan chains
+    take their O(M) operator straight from the generators the preparation computed (`ss_generators_from_tgen`), the expansion and its
+    upload happen behind the chains' launches.  SMCPP_T_LAZY=0 expands first and derives / CHECKS the generators entry by entry from
+    the expanded matrix (rounds 3-5).  Same E-step either way: the log-likelihood to 1e-13, statistics and Q to 1e-11, and the matrix
+    the getter hands out afterwards is bit for bit the same."""
+    from smcpp_amd import synth
+    g = np.load(os.path.join(GOLDEN, fixture))
+    obs = np.ascontiguousarray(synth.synth_contig(0, 100_000_000, int(g["n"]))[:rows], dtype=np.int32)
+    res = {}
+    for lazy in ("0", "1"):
+        engine_opt("SMCPP_T_LAZY", lazy)
+        im, model = _manager(g, obs)
+        for _ in range(2):                      # (the second E-step runs with what the first one left behind)
+            im.model = model
+            im.E_step()
+        res[lazy] = (im.loglik(), im.xisums[0], np.array(im.Q(separate=True)), im.gamma_sums[0], im.transition)
+        assert im.chain_mode() == 5
+    (ll0, x0, q0, g0, T0), (ll1, x1, q1, g1, T1) = res["0"], res["1"]
+    print(fixture, "lazy vs expanded-first: loglik", abs(ll1 - ll0) / abs(ll0), "xi sums", np.max(np.abs(x1 - x0) / np.abs(x0)))
+    assert abs(ll1 - ll0) <= 1e-13 * abs(ll0)
+    assert np.max(np.abs(x1 - x0) / np.abs(x0)) <= 1e-11
+    assert np.all(np.abs(q1 - q0) <= 1e-11 * np.abs(q0))
+    for k, v in g0.items():
+        np.testing.assert_allclose(g1[k], v, rtol=1e-11, atol=1e-13 * np.abs(v).max())
+    assert np.array_equal(T0, T1)
+
+
 def test_q_gradient_with_device_preparation():
     """Q(val, jac) after a device preparation with derivative seeds equals the host-prepared one (G10 pins the latter against
     the reference's own automatic differentiation)."""

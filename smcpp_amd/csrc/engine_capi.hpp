@@ -126,7 +126,7 @@ int smcpp_set_raw(smcpp_im *im, const double *pi, const double *T, int K, const 
     im->raw_E.assign(E, E + (size_t)K * M);
     im->have_raw = true;
     im->E_on_dev = false;
-    im->tgen_valid = false; im->dT_valid = true;
+    im->tgen_valid = false; im->dT_valid = true; im->T_lazy = false;
     im->dirty = true;
     im->nder = 0;
     API_END
@@ -171,6 +171,7 @@ int smcpp_q(smcpp_im *im, double val[4], double *jac) {
     const int nder = im->have_raw ? 0 : im->nder;
     if (jac) for (int i = 0; i < 4 * nder; ++i) jac[i] = 0.0;
     for (int i = 0; i < 4; ++i) val[i] = 0.0;
+    im->ensure_T();
     std::vector<double> logpi(M), logT((size_t)M * M), logE((size_t)K * M);
     for (int i = 0; i < M; ++i) logpi[i] = std::log(im->pi[i]);
     for (size_t i = 0; i < logT.size(); ++i) logT[i] = std::log(im->T[i]);
@@ -377,6 +378,7 @@ int smcpp_get_pi(smcpp_im *im, double *out) {
 }
 int smcpp_get_transition(smcpp_im *im, double *out) {
     API_BEGIN
+    im->ensure_T();
     if (im->T.empty()) throw std::runtime_error("parameters are not set");
     std::memcpy(out, im->T.data(), sizeof(double) * im->M * im->M);
     API_END

@@ -91,6 +91,13 @@ struct smcpp_im {
     // derivative planes (host, prep.hpp: transition_generators_jac; dT is expanded on the host only when its getter asks)
     smcpp_host::TransitionGenJac tgen;
     bool tgen_valid = false, dT_valid = true;
+    // (round 6) the device-prepared model path keeps the O(M) generators of T and expands the M x M matrix only when somebody reads it
+    // (ensure_T): the scan chains take their operator from the generators (ss_generators_from_tgen), so the expansion - 51 us at
+    // M = 256 - and the entry-by-entry structure check of the expanded matrix - 58 us - leave the critical path in front of the chains;
+    // host_prep_and_upload expands it for the statistics while the chains run
+    bool T_lazy = false;
+    smcpp_host::TransitionGenerators<double> tgen_g;
+    void ensure_T() { if (T_lazy) { T = smcpp_host::transition_expand<double>(tgen_g); T_lazy = false; } }
     struct QDev {
         DevBuf<double> d_stats, d_out;
         DevBuf<int> d_keynb;

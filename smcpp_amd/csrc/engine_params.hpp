@@ -52,7 +52,7 @@ void smcpp_im::prepare_params() {
             prep.batch_dev = (host_only2 || force_host_prep || nder > 0) ? nullptr : twopop_dev.get();
         }
         E_on_dev = false;
-        tgen_valid = false; dT_valid = true;
+        tgen_valid = false; dT_valid = true; T_lazy = false;
         // with a global key dictionary (multi-GPU) the table is prepared for EVERY global key - Q on the all-reduced statistics
         // also covers keys only other ranks' contigs hold; the local table is the sub-list of this rank's keys
         const std::vector<int> &pk2 = have_global ? gkeys : keys;
@@ -98,7 +98,7 @@ void smcpp_im::prepare_params() {
         if (!host_only && !force_host_prep && DevPrep::supported(n[0], (int)model.a.size() + (int)hs.size()) && !smcpp_host::csfs_direct_flag()) { dev_prepare(); return; }
     }
     E_on_dev = false;
-    tgen_valid = false; dT_valid = true;
+    tgen_valid = false; dT_valid = true; T_lazy = false;
     // with a global key dictionary (multi-GPU) the emission table is prepared for every global key; the local table
     // is the sub-list of the keys this rank's contigs hold
     const std::vector<int> &pk = have_global ? gkeys : keys;
@@ -162,6 +162,7 @@ void smcpp_im::dev_prepare() {
         }
         dprep->set_keys(*prep1, pk, Kp_, local, slot, maxspan, K, M, Mp, ss_static ? 64 * NPL : 0);
     }
+    T_lazy = false;
     if (nder > 0) {
         HostTrace tr;
         smcpp_host::DualScope sc(nder);
@@ -196,9 +197,12 @@ void smcpp_im::dev_prepare() {
         smcpp_host::TransitionGenerators<double> g;
         tgen = smcpp_host::transition_generators_jac(eta, rho, act, nullptr, nullptr, 0, &g);
         tr.mark("prep: pi + T generators");
-        T = smcpp_host::transition_expand<double>(g);
-        tr.mark("prep: T expand");
         tgen_valid = tgen.ok;
+        // (the expansion waits until somebody reads the matrix - ensure_T; without usable generators, or with SMCPP_T_LAZY=0: here)
+        tgen_g = std::move(g);
+        T_lazy = tgen_valid && !opt().off(smcpp_opt::O_T_LAZY);
+        if (!T_lazy) T = smcpp_host::transition_expand<double>(tgen_g);
+        tr.mark("prep: T expand");
         dpi.clear(); dT.clear();
         dT_valid = true;
     }
@@ -230,6 +234,7 @@ void smcpp_im::sync_host_E() {
 }
 
 void smcpp_im::ensure_dT() {
+    ensure_T();
     if (dT_valid) return;
     smcpp_host::transition_expand_jac(tgen, dT);
     dT_valid = true;
@@ -359,6 +364,7 @@ void smcpp_im::global_emissions() {
 }
 
 void smcpp_im::host_prep_and_upload() {
+    ensure_T();            // (a lazily kept transition matrix is expanded HERE: behind the scan chains' launches, in front of its upload)
     hipStream_t s = stream;
     const bool tm = opt().has(smcpp_opt::O_HOST_TIMING);
     auto tp0 = std::chrono::steady_clock::now();

@@ -149,6 +149,7 @@ static void coop_lds(int Mp, int K, int G, int &tab_c, size_t &shm_c) {
 // Eigen-free pre-pass: upload pi / T / emission table, build the group powers on the device and launch pass 0 of both
 // chains on them; the host then solves the eigenproblems while the GPU runs (estep()).
 void smcpp_im::stage_static_and_prepass() {
+    ensure_T();
     prepass_launched = false;
     static_packed = false;
     if (!power_ok || (warm_start && warm_valid)) return;
@@ -459,8 +460,44 @@ static bool ss_generators(int M, int MS, const double *Tm, std::vector<double> &
     return true;
 }
 
+// The same generators straight from the O(M) quantities the device-prepared model path computed (prep.hpp: TransitionGenJac - below
+// the diagonal T(i, c) = ed[c], above it pf[i] W[c], the diagonal closes the row; transition_expand then floors at 1e-20 and mixes with
+// c0 = 1e-5 / (M + 1)): no M x M matrix is formed or checked.  The diagonal's row sum is taken from a prefix sum of ed and a suffix sum
+// of W instead of entry by entry: 1e-16 of what the expanded matrix holds.
+static bool ss_generators_from_tgen(int M, int MS, const smcpp_host::TransitionGenJac &tj, std::vector<double> &gen, double &c0_out) {
+    if (!tj.ok || tj.M != M || (int)tj.ed.size() != std::max(0, M - 1) || (int)tj.pf.size() != M || (int)tj.W.size() != M) return false;
+    const double beta = 1e-5, c0 = beta / (double)(M + 1), om = 1.0 - beta;
+    auto mix = [&](double raw) { return std::max(raw, 1e-20) * om; };          // (without the + c0)
+    std::vector<double> d(M), g(M, 0.0), a(M, 0.0), b(M, 0.0), below(M, 0.0), above(M + 1, 0.0);
+    for (int j = 1; j < M; ++j) below[j] = below[j - 1] + tj.ed[j - 1];
+    for (int c = M - 1; c >= 1; --c) above[c] = above[c + 1] + tj.W[c];            // above[c] = sum_{k >= c} W[k]
+    for (int j = 0; j + 1 < M; ++j) {
+        g[j] = mix(tj.ed[j]) + c0;
+        b[j] = mix(tj.pf[j] * tj.W[j + 1]);
+    }
+    for (int j = 1; j + 1 < M; ++j) a[j] = tj.W[j] > 0.0 ? tj.W[j + 1] / tj.W[j] : 0.0;
+    for (int j = 0; j < M; ++j) d[j] = mix(1.0 - (below[j] + tj.pf[j] * above[j + 1])) + c0;
+    for (int j = 0; j < M; ++j)
+        if (!(d[j] > 0.0) || !std::isfinite(a[j]) || !std::isfinite(b[j]) || !(b[j] >= 0.0) || (j + 1 < M && !(g[j] > 0.0))) return false;
+    c0_out = c0;
+    gen.assign((size_t)10 * MS, 0.0);
+    double *f_dc = &gen[0], *f_g = f_dc + MS, *f_cg = f_g + MS, *f_b = f_cg + MS, *f_a = f_b + MS, *f_d = f_a + MS,
+           *b_dc = f_d + MS, *b_g = b_dc + MS, *b_b = b_g + MS, *b_a = b_b + MS;
+    for (int j = 0; j < M; ++j) {
+        f_dc[j] = d[j] - c0; f_g[j] = g[j]; f_cg[j] = c0 - g[j]; f_b[j] = b[j]; f_a[j] = a[j]; f_d[j] = d[j];
+        const int p = MS - 1 - j;
+        b_dc[p] = d[j] - c0; b_g[p] = g[j]; b_b[p] = b[j]; b_a[p] = a[j];
+    }
+    return true;
+}
+
 bool smcpp_im::ss_extract_generators() {
-    if (!ss_generators(M, 64 * NPL, T.data(), ss_gen, ss_c0)) return false;
+    if (T_lazy && tgen_valid && ss_generators_from_tgen(M, 64 * NPL, tgen, ss_gen, ss_c0)) {
+        // (no expanded matrix yet, and none needed by the chains)
+    } else {
+        ensure_T();
+        if (!ss_generators(M, 64 * NPL, T.data(), ss_gen, ss_c0)) return false;
+    }
     // a row of span s applies its operator s times without rescaling: keep clear of underflow
     // (a device-prepared table is checked by the kernel that forms it: DevPrep flag 2, looked at when the E-step has drained)
     if (!E_on_dev) for (const Group &gr : groups) {
@@ -1207,7 +1244,7 @@ void smcpp_im::estep() {
     prepare_params();
     tr.mark("estep: prepare_params");
     host_timing[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if ((int)pi.size() != M || (int)T.size() != M * M || (!E_on_dev && (int)E.size() != K * M))
+    if ((int)pi.size() != M || (!T_lazy && (int)T.size() != M * M) || (!E_on_dev && (int)E.size() != K * M))
         throw std::runtime_error("parameters are not set");
     HIPCHK(hipEventRecord(ev[0], stream));
     // span > 1 rows without an eigensystem (kernels.hpp: k_span_fold): the span is expanded by smax steps of two M x M products

@@ -225,3 +225,25 @@ def test_em_loop_terminates_on_the_loglik_monitor(tmp_path):
     assert 2 <= len(ll) < 12, ll
     assert np.all(np.diff(ll) >= -1e-5 * np.abs(ll[:-1])), ll
     assert (ll[-2] - ll[-1]) / ll[-2] < 2e-3
+
+
+@pytest.mark.gpu
+def test_em_with_more_than_64_hidden_states_on_the_example(tmp_path):
+    """`estimate` with 40 knots (79 hidden states: two states per lane, the halo pass, eigen-free statistics) on the example contig;
+    three EM iterations must not lower the log-likelihood (beyond the float-alpha noise) and the model file must come out.  (The
+    pipeline's own rows stay below 64 positions here: the cut rows of round 6 are exercised by tests/test_gpu_bigm.py.)"""
+    from smcpp_amd.analysis import Analysis, EstimateArgs
+    np.random.seed(2)
+    args = EstimateArgs(knots=40, unfold=True, w=100, em_iterations=3, multi=True, ftol=1e-9, r=1.25e-8, outdir=str(tmp_path))
+    an = Analysis([_example_contig()], args)
+    M = len(an.hidden_states) - 1
+    assert M > 64
+    an.run()
+    plan = an._im.describe()["plan"]
+    print(plan)
+    assert plan["eigen_free_statistics"] and plan["states"] == M and plan["max_span"] <= 64, plan
+    ll = np.array(an._optimizer.logliks)
+    assert len(ll) >= 3 and np.all(np.isfinite(ll)), ll
+    assert np.all(np.diff(ll) >= -1e-5 * np.abs(ll[:-1])), ll
+    import os
+    assert os.path.exists(os.path.join(str(tmp_path), "model.final.json"))

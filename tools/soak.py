@@ -1,31 +1,51 @@
-"""Soak: thousands of evals on one manager; log-likelihood must not drift and device memory must not grow."""
-import os, sys, time, numpy as np
+"""Soak: thousands of evals on one manager; the log-likelihood (and, with save_gamma, the decoded index of every column) must be
+bit-identical whenever the parameters are, and device memory must not grow.   python tools/soak.py   (GPU box; a minute)
+Configurations (round 6): the headline contig at M = 64 with and without save_gamma (eigen-free per-row posteriors), config C5's contig
+at M = 256 (LDS-staged rank updates, lazily expanded transition matrix) with and without save_gamma, and the example-derived contig at
+M = 144 (rows cut into pieces, a ragged output block)."""
+import os, sys, time, zlib, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from smcpp_amd import _smcpp, synth
 from smcpp_amd.model import PiecewiseModel
-M, n = 64, 20
-hs = synth.hidden_states(M); a, s = synth.model_pieces()
-c = synth.synth_contig(0, 100_000_000, n)
+
 _smcpp.set_num_threads(12)
-im = _smcpp.PyOnePopInferenceManager(n, [c], hs, ("pop1",), 0.5)
-im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0
-rng = np.random.RandomState(0)
-free0 = None
-lls = {}
-t0 = time.time()
-N = int(os.environ.get("SOAK_EVALS", 4000))
-for it in range(N):
-    k = it % 4                                   # four models in rotation: parameters really change between evals
-    m = PiecewiseModel(a * (1.0 + 0.05 * k), s, 1e4, "pop1")
-    im.model = m; im.E_step(); ll = im.loglik()
-    if k in lls:
-        assert ll == lls[k], (it, k, ll, lls[k])  # bit-identical for identical parameters
-    else:
-        lls[k] = ll
-    if it == 50:
-        free0 = torch.cuda.mem_get_info()[0]
-free1 = torch.cuda.mem_get_info()[0]
-print(f"{N} evals in {time.time() - t0:.1f} s, logliks {sorted(lls.values())}, device memory delta {(free0 - free1) / 1e6:.1f} MB")
-assert abs(free0 - free1) < 64e6
+a, s = synth.model_pieces()
+SCALE = float(os.environ.get("SOAK_SCALE", 1.0))
+
+
+def soak(name, M, n, contig, evals, save_gamma, theta=synth.THETA, rho=synth.RHO):
+    im = _smcpp.PyOnePopInferenceManager(n, [contig], synth.hidden_states(M), ("pop1",), 0.5)
+    im.theta = theta; im.rho = rho; im.alpha = 1.0
+    im.save_gamma = save_gamma
+    seen, free0 = {}, None
+    t0 = time.time()
+    N = max(8, int(evals * SCALE))
+    for it in range(N):
+        k = it % 4                                   # four models in rotation: parameters really change between evals
+        im.model = PiecewiseModel(a * (1.0 + 0.05 * k), s, 1e4, "pop1")
+        im.E_step()
+        got = (im.loglik(),) + ((zlib.crc32(np.asarray(im.gamma_argmax(0)).tobytes()),) if save_gamma and it % 16 < 4 else ())
+        key = (k, len(got))
+        if key in seen:
+            assert got == seen[key], (name, it, k, got, seen[key])      # bit-identical for identical parameters
+        else:
+            seen[key] = got
+        if it == min(50, N // 2):
+            free0 = torch.cuda.mem_get_info()[0]
+    free1 = torch.cuda.mem_get_info()[0]
+    print(f"{name}: {N} evals in {time.time() - t0:.1f} s, logliks {sorted(v[0] for kk, v in seen.items() if kk[1] == 1 or not save_gamma)[:4]}, "
+          f"device memory delta {(free0 - free1) / 1e6:.1f} MB, plan {im.describe()['plan']['per_row_gamma']}", flush=True)
+    assert abs(free0 - free1) < 64e6
+
+
+g1 = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "G1_M16_n4.npz"))
+c64 = synth.synth_contig(0, 100_000_000, 20)
+c256 = synth.synth_contig(0, 100_000_000, 50)
+soak("headline M=64", 64, 20, c64, 4000, False)
+soak("headline M=64 save_gamma", 64, 20, c64, 1500, True)
+soak("c5 M=256", 256, 50, c256, 1200, False)
+soak("c5 M=256 save_gamma", 256, 50, c256, 400, True)
+soak("example-derived M=144 cut rows save_gamma", 144, 4, np.ascontiguousarray(g1["obs"], dtype=np.int32), 1500, True,
+     theta=float(g1["theta"]), rho=float(g1["rho"]))
 print("soak ok")

@@ -329,7 +329,11 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
                 rows++; pieces += (sp + 63) / 64; maxspan = std::max(maxspan, sp);
             }
         const bool want = M > 64 && !opt().off(smcpp_opt::O_SPLIT_SPANS);      // (M <= 64: the one-state-per-lane chains have no un-floored store)
-        split_spans = want && maxspan > 64 && pieces <= 2 * rows + 1024;
+        // (beyond 256 states there is no other path: un-binned rows are cut as well - the chains then walk every position, which is
+        // what a row costs there anyway - as long as the pieces' alpha / beta rows fit a third of a 288 GB device)
+        const bool few = pieces <= 2 * rows + 1024;
+        const bool must = M > 256 && (double)pieces * (double)Mp * 12.0 < 96e9;
+        split_spans = want && maxspan > 64 && (few || must);
         if (split_spans) {
             split_store.assign(n_contigs, std::vector<int>());
             split_ptr.assign(n_contigs, nullptr);

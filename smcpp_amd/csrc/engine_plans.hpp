@@ -1254,8 +1254,9 @@ void smcpp_im::estep() {
     const bool gamma_scan = !opt().off(smcpp_opt::O_GAMMA_SCAN);
     const bool eigfree_static = !eigfree_off && Mp <= 1024 && ss_max_span <= 64 && (!save_gamma || gamma_scan);
     if (Mp > 256 && !(ss_static && eigfree_static))
-        throw std::runtime_error("more than 256 hidden states: only the scan chains with eigen-free statistics are built (binned data "
-                                 "with spans <= 64)");
+        throw std::runtime_error("more than 256 hidden states: only the scan chains with eigen-free statistics are built (rows longer than "
+                                 "64 positions are cut into pieces at construction unless SMCPP_SPLIT_SPANS=0 / SMCPP_EIGFREE=0 forbid it or "
+                                 "the pieces would not fit the device)");
     // only the lean path (scan chains + eigen-free statistics) reads a device-prepared emission table from HBM alone (its
     // underflow bound is checked by the kernel that forms the table); eigensystems, operand layouts, the dense chains and the
     // bound for longer spans need the host copy

@@ -228,6 +228,42 @@ def test_long_rows_of_binned_data_cut_into_pieces(engine_opt, M, rows):
         assert np.max(np.abs(im0.gammas[0] - gam) / spans) <= 2e-5
 
 
+def test_unbinned_rows_beyond_256_states():
+    """Round 6: un-binned rows (spans of 10^3 - 10^5 base pairs, the input of `smc++ posterior`) at M = 300: no eigen-power step exists
+    beyond 256 states, so the rows are cut into pieces of 64 positions like long binned rows and the chains walk every position.  Against
+    the C restatement (one eigen-power step per row, as the reference): log-likelihood, gamma sums, every column of gamma."""
+    from oracle import oracle
+    from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel
+    M, n, rows = 300, 8, 260
+    obs = np.ascontiguousarray(synth.synth_posterior_contig(rows, n, seed=7), dtype=np.int32)
+    assert obs[:, 0].max() > 1000
+    a, s = synth.model_pieces()
+    im = _smcpp.PyOnePopInferenceManager(n, [obs], synth.hidden_states(M), ("pop1",), 0.5)
+    im.model = PiecewiseModel(a, s, 1e4, "pop1")
+    im.theta = 2e-4; im.rho = 6e-5; im.alpha = 1.0
+    im.save_gamma = True
+    im.E_step()
+    plan = im.describe()["plan"]
+    assert plan["long_rows_cut"] and plan["eigen_free_statistics"] and plan["rows"] > 4 * rows, plan
+    keys = im.keys
+    ep = im.emission_probs
+    Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
+    o = oracle.estep(im.pi, im.transition, keys, Etab, obs, save_gamma=True)
+    ll = im.loglik()
+    gam = im.gammas[0]
+    spans = np.concatenate([[1.0], obs[:, 0].astype(float)])
+    err = np.max(np.abs(gam - o["gamma"]), axis=0) / spans
+    print(f"M = {M}, {rows} un-binned rows = {plan['rows']} pieces, {int(obs[:, 0].sum())} positions: loglik rel "
+          f"{abs(ll - o['loglik']) / abs(o['loglik']):.2e}, per-row gamma worst column {err.max():.2e} of its span, xi sums scaled "
+          f"{np.abs(im.xisums[0] - o['xisum']).max() / np.abs(o['xisum']).max():.2e}")
+    assert abs(ll - o["loglik"]) <= LL_TOL * abs(o["loglik"]), (ll, o["loglik"])
+    assert gam.shape == (M, rows + 1) and err.max() <= 2e-5
+    assert np.abs(im.xisums[0] - o["xisum"]).max() <= STAT_TOL * np.abs(o["xisum"]).max()
+    for k, v in o["gamma_sums"].items():
+        assert np.max(np.abs(im.gamma_sums[0][k] - v)) <= STAT_TOL * max(np.abs(v).max(), 1e-300), k
+
+
 def test_beyond_256_states_unbuilt_paths_fail_loudly():
     from smcpp_amd import synth
     n = 10

@@ -289,6 +289,24 @@ int smcpp_get_xisum(smcpp_im *im, int c, double *out) {
     API_END
 }
 
+// The caller's rows of contig c with the pieces of every cut row added up, on the device ([Lu + 1][Mp]; row 0 is left to the caller).
+const double *smcpp_im::merged_gamma(int c) {
+    const int Lu = user_Ls[c];
+    if (d_piece_first.size() != (size_t)n_contigs) d_piece_first.resize(n_contigs);
+    if (!d_piece_first[c].p) {
+        std::vector<int> first((size_t)Lu + 2, 0);
+        const std::vector<int> &pr = piece_row[c];                 // piece -> caller's row (non-decreasing)
+        for (int l = (int)pr.size() - 1; l >= 1; --l) first[pr[l]] = l;
+        first[Lu + 1] = Ls[c] + 1;
+        d_piece_first[c].upload(first, stream);
+        HIPCHK(hipStreamSynchronize(stream));          // (`first` is a local: the copy has to be done before it goes)
+    }
+    d_gamma_user.alloc((size_t)(Lu + 1) * Mp);
+    hipLaunchKernelGGL(k_gamma_merge, dim3((unsigned)ceil_div((long long)Lu * Mp, 256)), dim3(256), 0, stream, Mp, Lu,
+                       (const int *)d_piece_first[c].p, (const double *)(d_gamma_rows.p + (size_t)contig_base[c] * Mp), d_gamma_user.p);
+    return d_gamma_user.p;
+}
+
 int smcpp_get_gamma(smcpp_im *im, int c, double *out) {
     API_BEGIN
     if (c < 0 || c >= im->n_contigs) throw std::runtime_error("contig index out of range");
@@ -299,22 +317,23 @@ int smcpp_get_gamma(smcpp_im *im, int c, double *out) {
         return 0;
     }
     HIPCHK(hipSetDevice(im->device));
+    if (im->split_spans) {
+        // the pieces of a long row add up to the row's posterior (engine_manager.hpp: build): added on the device, then as below
+        const int Lu = im->user_Ls[c];
+        const double *src = im->merged_gamma(c);
+        std::vector<double> rows((size_t)(Lu + 1) * Mp);
+        HIPCHK(hipMemcpyAsync(rows.data(), src, rows.size() * sizeof(double), hipMemcpyDeviceToHost, im->stream));
+        HIPCHK(hipStreamSynchronize(im->stream));
+        for (int i = 0; i < M; ++i) {
+            out[(size_t)i * (Lu + 1)] = im->h_gamma0[(size_t)c * M + i];
+            for (int l = 1; l <= Lu; ++l) out[(size_t)i * (Lu + 1) + l] = rows[(size_t)l * Mp + i];
+        }
+        return 0;
+    }
     const int L = im->Ls[c];
     std::vector<double> rows((size_t)(L + 1) * Mp);
     HIPCHK(hipMemcpy(rows.data(), im->d_gamma_rows.p + (size_t)im->contig_base[c] * Mp, rows.size() * sizeof(double),
                      hipMemcpyDeviceToHost));
-    if (im->split_spans) {
-        // the pieces of a long row add up to the row's posterior (engine_manager.hpp: build)
-        const int Lu = im->user_Ls[c];
-        const std::vector<int> &pr = im->piece_row[c];
-        std::fill(out, out + (size_t)M * (Lu + 1), 0.0);
-        for (int i = 0; i < M; ++i) {
-            double *o = out + (size_t)i * (Lu + 1);
-            o[0] = im->h_gamma0[(size_t)c * M + i];
-            for (int l = 1; l <= L; ++l) o[pr[l]] += rows[(size_t)l * Mp + i];
-        }
-        return 0;
-    }
     for (int i = 0; i < M; ++i) {
         out[(size_t)i * (L + 1)] = im->h_gamma0[(size_t)c * M + i];
         for (int l = 1; l <= L; ++l) out[(size_t)i * (L + 1) + l] = rows[(size_t)l * Mp + i];
@@ -334,24 +353,13 @@ int smcpp_get_gamma_argmax(smcpp_im *im, int c, int *out) {
     HIPCHK(hipSetDevice(im->device));
     const int L = im->Ls[c];
     im->fetch_stats();
-    if (im->split_spans) {
-        // (rows cut into pieces: the pieces' posteriors are added on the host first)
-        const int Lu = im->user_Ls[c], M = im->M;
-        std::vector<double> g((size_t)M * (Lu + 1));
-        if (smcpp_get_gamma(im, c, g.data()) != 0) throw std::runtime_error(smcpp_last_error());
-        for (int l = 0; l <= Lu; ++l) {
-            int best = 0;
-            for (int i = 1; i < M; ++i)
-                if (g[(size_t)i * (Lu + 1) + l] > g[(size_t)best * (Lu + 1) + l]) best = i;
-            out[l] = best;
-        }
-        return 0;
-    }
+    // (rows cut into pieces: the pieces' posteriors are added up on the device first; L = the caller's row count then)
+    const double *src = im->split_spans ? im->merged_gamma(c) : (const double *)(im->d_gamma_rows.p + (size_t)im->contig_base[c] * im->Mp);
+    const int Lc = im->split_spans ? im->user_Ls[c] : L;
     im->d_argmax.alloc((size_t)im->total_rows);
-    hipLaunchKernelGGL(k_gamma_argmax, dim3(ceil_div(L + 1, 256)), dim3(256), 0, im->stream, im->M, im->Mp,
-                       (long long)(L + 1), (const double *)(im->d_gamma_rows.p + (size_t)im->contig_base[c] * im->Mp),
-                       im->d_argmax.p);
-    HIPCHK(hipMemcpyAsync(out, im->d_argmax.p, sizeof(int) * (L + 1), hipMemcpyDeviceToHost, im->stream));
+    hipLaunchKernelGGL(k_gamma_argmax, dim3(ceil_div(Lc + 1, 256)), dim3(256), 0, im->stream, im->M, im->Mp,
+                       (long long)(Lc + 1), src, im->d_argmax.p);
+    HIPCHK(hipMemcpyAsync(out, im->d_argmax.p, sizeof(int) * (Lc + 1), hipMemcpyDeviceToHost, im->stream));
     HIPCHK(hipStreamSynchronize(im->stream));
     // column 0 is alpha_0 o beta_0 (hmm.cpp:150), which lives in gamma0
     int best = 0;

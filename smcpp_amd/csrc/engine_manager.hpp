@@ -151,6 +151,9 @@ struct smcpp_im {
     std::vector<int> user_Ls;
     std::vector<std::vector<int>> split_store, piece_row;
     std::vector<const int *> split_ptr;
+    std::vector<DevBuf<int>> d_piece_first;       // per contig: first piece of every caller's row ([Lu + 2]; k_gamma_merge)
+    DevBuf<double> d_gamma_user;                  // the caller's rows of ONE contig, pieces added up: [Lu + 1][Mp]
+    const double *merged_gamma(int c);            // (device pointer; row 0 unset)
     DevBuf<float> d_gpark;                 // k_gamma_rows_scan: [wavefronts][max span][64 NPL] parked forward vectors
     DevBuf<double> d_Fall;                 // [n_contigs Ke][smax][Mp][Mp] scratch of the span fold for M > 64 (k_span_big)
     SsArgs ss_args;
@@ -332,7 +335,7 @@ void smcpp_im::build(int npop_, const int *nn, const int *nna, int n_contigs_, c
         // (beyond 256 states there is no other path: un-binned rows are cut as well - the chains then walk every position, which is
         // what a row costs there anyway - as long as the pieces' alpha / beta rows fit a third of a 288 GB device)
         const bool few = pieces <= 2 * rows + 1024;
-        const bool must = M > 256 && (double)pieces * (double)Mp * 12.0 < 96e9;
+        const bool must = (M > 256 || opt().i(smcpp_opt::O_SPLIT_SPANS, 1) == 2) && (double)pieces * (double)Mp * 12.0 < 96e9;   // (=2: test switch)
         split_spans = want && maxspan > 64 && (few || must);
         if (split_spans) {
             split_store.assign(n_contigs, std::vector<int>());

@@ -2260,4 +2260,17 @@ __global__ __launch_bounds__(256) void k_gamma_argmax(int M, int Mp, long long n
     out[r] = best;
 }
 
+// rows cut into pieces (engine_manager.hpp: build): the posterior of a caller's row is the sum of its pieces' posteriors.
+// first[u] .. first[u + 1] - 1 are the pieces (contig-relative rows) of the caller's row u (u = 1 .. Lu); row 0 is not touched.
+__global__ __launch_bounds__(256) void k_gamma_merge(int Mp, int Lu, const int *__restrict__ first, const double *__restrict__ gamma_rows,
+                                                     double *__restrict__ out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long u = idx / Mp + 1;
+    const int i = (int)(idx % Mp);
+    if (u > Lu) return;
+    double acc = 0.0;
+    for (int l = first[u]; l < first[u + 1]; ++l) acc += gamma_rows[(size_t)l * Mp + i];
+    out[(size_t)u * Mp + i] = acc;
+}
+
 }  // namespace smcpp_dev

@@ -1631,6 +1631,127 @@ __global__ __launch_bounds__(256) void k_span_scan(SsArgs sa, FinArgs a, int sma
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Per-row posteriors of LONG rows at 64 < M <= 256 (un-binned data, the input of `smc++ posterior`; round 6).  The dense chains take
+// such a row in ONE eigen-power step (hmm.cpp:72-78,104-112) and the reference then forms its gamma from the eigensystem
+// (hmm.cpp:113-121: 2 M^3 flop per row - a scalar kernel here beyond 64 states, 3.4 s per E-step on 10^5 rows at M = 256).  The same
+// vector is the sum over the row's positions of their posteriors (k_gamma_rows_scan below), and that sum is cut into PIECES of at most
+// 64 positions that run in parallel: the forward vector at a piece's start and the backward vector at its end are eigen-power
+// INTERPOLATIONS of the row's two stored vectors,
+//     f_o = P (d~^o o (P^-1 alpha_{l-1})),     h_o = P^-T (d~^(span - o) o (P^T beta_l)),
+// - two M x M products per piece on the matrix cores (k_piece_vectors; P^-1 alpha and P^T beta are the statistics' own k_eig_uw
+// products) -, the positions inside a piece are walked by the O(M) scan steps, and k_gamma_merge_pieces adds a row's pieces up.
+// No span-Q table, no per-row M^3 product; the chains and the statistics stay un-cut (one eigen step per row).
+// ---------------------------------------------------------------------------------------------------------------
+struct GPiece {
+    long long row;            // global row of the piece's data row
+    int q;                    // position of that row in the sorted eigen-row permutation (Xs / Ys)
+    int o0, len, span;        // the piece covers positions o0 + 1 .. o0 + len of the row's `span`
+    int kid, es;              // emission key, eigen key
+};
+struct GTile { int es, cnt; int pid[16]; };       // sixteen pieces of ONE eigen key that need an interpolated vector
+
+struct PieceArgs {
+    int M, Mp, npieces, ntiles;
+    const GPiece *pieces;
+    const GTile *tiles;
+    const double *Xs, *Ys;    // [eigen rows][Mp]  omega P^-1 alpha_{l-1},  P^T beta_l   (k_eig_uw)
+    const double *dsc;        // [Ke][Mp] scaled eigenvalues
+    const double *PT, *Pinvrm;        // [Ke][Mp][Mp]  PT[a][i] = P[i][a],  Pinvrm[a][i] = Pinv[a][i]
+    const double *cs;         // [Ke][2][Mp] row sums of PT / Pinvrm (k_piece_rowsums): the sum of an interpolated vector without forming it
+    float *pvf;               // [npieces][Mp] forward vector at the piece's start (o0 > 0)
+    double *pvb;              // [npieces][Mp] backward vector at the piece's end (o0 + len < span)
+    double *pgam;             // [npieces][Mp] the piece's share of its row's gamma (k_gamma_rows_scan<., true>)
+};
+
+__global__ __launch_bounds__(256) void k_piece_rowsums(int Ke, int Mp, const double *__restrict__ PT, const double *__restrict__ Pinvrm,
+                                                       double *__restrict__ cs) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Ke * 2 * Mp) return;
+    const int a = idx % Mp, dir = (idx / Mp) & 1, e = idx / (2 * Mp);
+    const double *src = (dir ? Pinvrm : PT) + (size_t)e * Mp * Mp + (size_t)a * Mp;
+    double acc = 0.0;
+    for (int i = 0; i < Mp; ++i) acc += src[i];
+    cs[idx] = acc;
+}
+
+// One wavefront per tile of sixteen pieces and direction: x_piece = d~^k o (omega u | w) through LDS as the A operand
+// (A[m = piece][k = state a]), the key's matrix as the B operand (B[k = a][n = i]: sixteen consecutive doubles of row a per lane
+// group - whole 128-byte lines), D[piece][i] scaled to unit sum and stored as the piece's start (float, as alpha is) / end vector.
+__global__ __launch_bounds__(256) void k_piece_vectors(PieceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double pv_sm[];
+    const int Mp = a.Mp, M = a.M, LDX = Mp + 4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    double *sX = pv_sm + (size_t)wv * 16 * LDX;
+    const int nwork = 2 * a.ntiles;
+    for (int wk = blockIdx.x * 4 + wv; wk < nwork; wk += gridDim.x * 4) {
+        const int dir = wk & 1;
+        const GTile &tl = a.tiles[wk >> 1];
+        const int es = ss_uni(tl.es), cnt = ss_uni(tl.cnt);
+        const int pid = tl.pid[min(n, cnt - 1)];
+        const GPiece pc = a.pieces[pid];
+        const int kpow = dir ? pc.span - pc.o0 - pc.len : pc.o0;
+        const bool need = n < cnt && kpow > 0;
+        const double *X = (dir ? a.Ys : a.Xs) + (size_t)pc.q * Mp;
+        const double *dsc = a.dsc + (size_t)es * Mp;
+        const double *cs = a.cs + ((size_t)es * 2 + dir) * Mp;
+        double part = 0.0;
+        for (int kk = 0; kk < Mp / 4; ++kk) {
+            const int st = 4 * kk + kq;
+            double v = 0.0;
+            if (need && st < M) v = pow(dsc[st], (double)kpow) * X[st];
+            part = fma(cs[st], v, part);
+            sX[n * LDX + st] = v;
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        const double inv = (need && part != 0.0) ? 1.0 / part : 0.0;
+        int pid_r[4];
+        double inv_r[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pid_r[r] = __shfl(pid, kq + 4 * r);
+            inv_r[r] = __shfl(inv, kq + 4 * r);
+        }
+        wave_lds_fence();
+        const double *Mat = (dir ? a.Pinvrm : a.PT) + (size_t)es * Mp * Mp;
+        for (int it = 0; it < Mp / 16; ++it) {
+            f64x4 D = (f64x4){0, 0, 0, 0};
+            const double *Bp = Mat + (size_t)kq * Mp + it * 16 + n;
+            for (int kk = 0; kk < Mp / 4; kk += 4) {              // (Mp is a multiple of 16)
+                double av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { av[u] = sX[n * LDX + 4 * (kk + u) + kq]; bv[u] = Bp[(size_t)4 * (kk + u) * Mp]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) D = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], D, 0, 0, 0);
+            }
+            const int i = it * 16 + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (inv_r[r] == 0.0) continue;
+                const double v = D[r] * inv_r[r];
+                if (dir) a.pvb[(size_t)pid_r[r] * Mp + i] = v;
+                else a.pvf[(size_t)pid_r[r] * Mp + i] = (float)v;
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+// gamma of eigen row q = the sum of its pieces' shares (pieces pfirst[q] .. pfirst[q + 1] - 1, in position order: deterministic)
+__global__ __launch_bounds__(256) void k_gamma_merge_pieces(int Mp, int nrows, const int *__restrict__ pfirst, const GPiece *__restrict__ pieces,
+                                                            const double *__restrict__ pgam, double *__restrict__ gamma_rows) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long q = idx / Mp;
+    const int i = (int)(idx % Mp);
+    if (q >= nrows) return;
+    const int p0 = pfirst[q], p1 = pfirst[q + 1];
+    double acc = 0.0;
+    for (int p = p0; p < p1; ++p) acc += pgam[(size_t)p * Mp + i];
+    gamma_rows[(size_t)pieces[p0].row * Mp + i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Per-row posterior of the span > 1 rows WITHOUT an eigensystem (round 6; save_gamma on the scan chains).
 // hmm.cpp:113-121 forms the row's gamma from the eigensystem of its key - diag(P d (Q_r o span_Q) P^-1), 2 M^3 flop per row -
 // and normalises it to the row's span.  That vector is the sum over the `span` positions of the row of their posteriors:
@@ -1643,27 +1764,49 @@ __global__ __launch_bounds__(256) void k_span_scan(SsArgs sa, FinArgs a, int sma
 // walks rescale by the running sum; every term is normalised by its own dot product, so the scales cancel.
 // The generators of one direction are loaded inside that direction's walk (sixteen states per lane: both sets at once do not fit).
 // ---------------------------------------------------------------------------------------------------------------
-template <int NPL>
+// PIECES: the work items are the pieces of k_piece_vectors' table instead of whole rows - start / end vectors from the interpolated
+// buffers (or the row's own alpha / beta where the piece starts / ends the row), the share goes to the piece's own line of `pgam`.
+template <int NPL, bool PIECES = false>
 __global__ __launch_bounds__(256) void k_gamma_rows_scan(SsArgs sa, GammaRowArgs a, const RowInfo *__restrict__ rowinfo,
-                                                         const double *__restrict__ Ek, float *__restrict__ scratch, int smax, int nwaves) {
+                                                         const double *__restrict__ Ek, float *__restrict__ scratch, int smax, int nwaves,
+                                                         PieceArgs pa = PieceArgs()) {
     constexpr int MS = 64 * NPL;
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gw >= nwaves) return;
     const int M = a.M, Mp = a.Mp;
     float *park = scratch + (size_t)gw * smax * MS;
-    for (int q = gw; q < a.nrows; q += nwaves) {
+    const int nitems = PIECES ? pa.npieces : a.nrows;
+    for (int q = gw; q < nitems; q += nwaves) {
         const int qs = ss_uni(q);
-        const Slab sl = a.slabs[a.row_slab[qs]];
-        const int span = ss_uni(a.g_span[sl.aux]);
-        const size_t row = (size_t)(sl.base + a.perm[qs]);
-        const double *ek = Ek + (size_t)ss_uni(rowinfo[row].kid) * Mp;
+        int span;
+        size_t row;
+        const double *ek;
+        const float *ap;
+        const double *bp;
+        double *gout;
+        if (PIECES) {
+            const GPiece pc = pa.pieces[qs];
+            span = ss_uni(pc.len);
+            row = (size_t)pc.row;
+            ek = Ek + (size_t)ss_uni(pc.kid) * Mp;
+            ap = ss_uni(pc.o0) == 0 ? a.alpha + (row - 1) * Mp : pa.pvf + (size_t)qs * Mp;
+            bp = ss_uni(pc.o0 + pc.len - pc.span) == 0 ? a.beta + row * Mp : pa.pvb + (size_t)qs * Mp;
+            gout = pa.pgam + (size_t)qs * Mp;
+        } else {
+            const Slab sl = a.slabs[a.row_slab[qs]];
+            span = ss_uni(a.g_span[sl.aux]);
+            row = (size_t)(sl.base + a.perm[qs]);
+            ek = Ek + (size_t)ss_uni(rowinfo[row].kid) * Mp;
+            ap = a.alpha + (row - 1) * Mp;
+            bp = a.beta + row * Mp;
+            gout = a.gamma_rows + row * Mp;
+        }
         {
             // forward: positions p = state
             SsFwdC<NPL> c;
             ss_load_fwd<NPL>(sa, lane, c);
             double x[NPL], ev[NPL];
-            const float *ap = a.alpha + (row - 1) * Mp;
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
                 const int st = lane * NPL + k;
@@ -1692,7 +1835,6 @@ __global__ __launch_bounds__(256) void k_gamma_rows_scan(SsArgs sa, GammaRowArgs
             ss_load_bwd<NPL>(sa, lane, c);
             double h[NPL], ev[NPL], g[NPL];
             int st[NPL];
-            const double *bp = a.beta + row * Mp;
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
                 st[k] = MS - 1 - (lane * NPL + k);
@@ -1722,7 +1864,7 @@ __global__ __launch_bounds__(256) void k_gamma_rows_scan(SsArgs sa, GammaRowArgs
             }
 #pragma unroll
             for (int k = 0; k < NPL; ++k)
-                if (st[k] < Mp) a.gamma_rows[row * Mp + st[k]] = st[k] < M ? g[k] : 0.0;
+                if (st[k] < Mp) gout[st[k]] = st[k] < M ? g[k] : 0.0;
         }
     }
 }

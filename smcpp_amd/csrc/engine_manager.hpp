@@ -154,6 +154,20 @@ struct smcpp_im {
     std::vector<DevBuf<int>> d_piece_first;       // per contig: first piece of every caller's row ([Lu + 2]; k_gamma_merge)
     DevBuf<double> d_gamma_user;                  // the caller's rows of ONE contig, pieces added up: [Lu + 1][Mp]
     const double *merged_gamma(int c);            // (device pointer; row 0 unset)
+    // per-row posteriors of long rows at 64 < M <= 256 from eigen-power pieces (chains_ss.hpp: k_piece_vectors; engine_plans.hpp)
+    std::vector<GPiece> gp_pieces;
+    std::vector<GTile> gp_tiles;
+    std::vector<int> gp_pfirst;
+    bool gp_built = false, gamma_pieces_last = false;
+    DevBuf<GPiece> d_gp_pieces;
+    DevBuf<GTile> d_gp_tiles;
+    DevBuf<int> d_gp_pfirst;
+    DevBuf<float> d_gp_pvf;
+    DevBuf<double> d_gp_pvb, d_gp_pgam, d_gp_cs, d_gp_gen;
+    long long gp_count = -1;
+    long long gamma_piece_count();         // pieces of at most 64 positions the eigen rows fall into
+    void build_gamma_pieces();
+    bool ss_generators_only();             // the generators of T into ss_gen / ss_c0 (no underflow bound: the walks rescale every step)
     DevBuf<float> d_gpark;                 // k_gamma_rows_scan: [wavefronts][max span][64 NPL] parked forward vectors
     DevBuf<double> d_Fall;                 // [n_contigs Ke][smax][Mp][Mp] scratch of the span fold for M > 64 (k_span_big)
     SsArgs ss_args;

@@ -11,7 +11,7 @@ enum OptId {
     O_COOP_BPC, O_ROWS_PER_CHUNK, O_SS_WPC, O_SS_HALO, O_HALO_LF, O_HALO_DF, O_HALO_LB, O_HALO_DB, O_SS_FWD_SHARE, O_STATS_TEAM,
     O_SLAB_ROWS, O_POWER_PREPASS, O_PREP, O_Q, O_EIG_TEAM, O_EIG_PIN, O_BWD_PRIO, O_COOP_TAB, O_POWER_DEBUG, O_BWD_PRIO_MASK,
     O_DEBUG_CYCLES, O_SS_H32, O_SS_MIXED, O_SS_LIGHT_F, O_SS_LIGHT_B, O_SS_CERT_PASS, O_POLL, O_SPEC_GAMMA, O_GAMMA_SIDE,
-    O_STATS_VARIANT, O_SPAN_SCAN, O_S1_FUSE, O_EIGFREE, O_CSFS_DIRECT, O_RANK_WIDE, O_GAMMA_SCAN, O_SPLIT_SPANS, O_T_LAZY, O_DEBUG_POISON, O_DEBUG_POISON_ONLY, O_DEBUG_POISON_LOG, O_COUNT
+    O_STATS_VARIANT, O_SPAN_SCAN, O_S1_FUSE, O_EIGFREE, O_CSFS_DIRECT, O_RANK_WIDE, O_GAMMA_SCAN, O_GAMMA_PIECES, O_SPLIT_SPANS, O_T_LAZY, O_DEBUG_POISON, O_DEBUG_POISON_ONLY, O_DEBUG_POISON_LOG, O_COUNT
 };
 
 struct OptDef { const char *name, *help; };
@@ -64,7 +64,8 @@ static const OptDef OPT_DEFS[O_COUNT] = {
     {"SMCPP_CSFS_DIRECT",    "set: literal O(pieces^2 n^2) conditioned SFS (test hook)"},
     {"SMCPP_RANK_WIDE",      "0: rank updates at M > 128 without the LDS-staged operand rows (k_rank_acc instead of k_rank_acc_wide); 4: four wavefronts per workgroup instead of eight"},
     {"SMCPP_GAMMA_SCAN",     "0: save_gamma E-steps take the eigensystem statistics and per-row gammas (M <= 256) instead of the eigen-free scans"},
-    {"SMCPP_SPLIT_SPANS",    "0: rows of binned data longer than 64 positions are not cut into pieces (M > 64)"},
+    {"SMCPP_GAMMA_PIECES",   "0: per-row gammas of long rows at 64 < M <= 256 from the eigensystem (k_gamma_rows_eig) instead of eigen-power pieces + scan steps"},
+    {"SMCPP_SPLIT_SPANS",    "0: rows of binned data longer than 64 positions are not cut into pieces (M > 64); 2: un-binned rows are cut as well at M <= 256 (test switch)"},
     {"SMCPP_T_LAZY",         "0: the model path expands the M x M transition matrix before the chains start and takes their generators from it (rounds 3-5)"},
     {"SMCPP_DEBUG_POISON",   "byte value every fresh device allocation is filled with (255: NaN / -1): a kernel that reads memory it was "
                              "never given shows up as NaN in a fresh process instead of depending on what the allocator recycles"},

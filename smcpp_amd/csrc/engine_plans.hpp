@@ -491,13 +491,18 @@ static bool ss_generators_from_tgen(int M, int MS, const smcpp_host::TransitionG
     return true;
 }
 
-bool smcpp_im::ss_extract_generators() {
+bool smcpp_im::ss_generators_only() {
     if (T_lazy && tgen_valid && ss_generators_from_tgen(M, 64 * NPL, tgen, ss_gen, ss_c0)) {
         // (no expanded matrix yet, and none needed by the chains)
     } else {
         ensure_T();
         if (!ss_generators(M, 64 * NPL, T.data(), ss_gen, ss_c0)) return false;
     }
+    return true;
+}
+
+bool smcpp_im::ss_extract_generators() {
+    if (!ss_generators_only()) return false;
     // a row of span s applies its operator s times without rescaling: keep clear of underflow
     // (a device-prepared table is checked by the kernel that forms it: DevPrep flag 2, looked at when the E-step has drained)
     if (!E_on_dev) for (const Group &gr : groups) {
@@ -803,7 +808,11 @@ void smcpp_im::enqueue_stats() {
     // save_gamma: the per-row gammas of the span > 1 rows (2 M^3 flop each, the matrix pipe's business for ~1 ms on a million rows)
     // need alpha, beta and the eigensystems only - not a single statistic: they run on their own stream BESIDE the (memory- and
     // latency-bound) statistics instead of behind them
-    const bool gamma_side = save_gamma && n_e_rows > 0 && dual_stream && stream_hi != nullptr &&
+    // (round 6) long rows at 64 < M <= 256 on a transition matrix with the reference's structure: eigen-power pieces + scan steps instead
+    // of the scalar eigensystem kernel (they read the statistics' own U / W products, so they stay behind them on the main stream)
+    const bool gamma_pieces = save_gamma && n_e_rows > 0 && !eigfree && NT > 4 && Mp <= 256 && !opt().off(smcpp_opt::O_GAMMA_PIECES) &&
+                              (double)gamma_piece_count() * Mp * 20.0 < 96e9 && (ss_active || ss_generators_only());
+    const bool gamma_side = save_gamma && n_e_rows > 0 && dual_stream && stream_hi != nullptr && !gamma_pieces &&
                             !opt().off(smcpp_opt::O_GAMMA_SIDE);
     if (save_gamma) {
         d_gamma_rows.alloc((size_t)total_rows * Mp);
@@ -1143,6 +1152,48 @@ void smcpp_im::enqueue_stats() {
         ga.Prm = d_Prm.p; ga.Pinvrm = d_Pinvrm.p; ga.PinvT = d_PinvT.p; ga.Sq = nullptr;
         ga.alpha = d_alpha.p; ga.beta = d_beta.p; ga.gamma_rows = d_gamma_rows.p;
         const bool mfma_rows = NT <= 4;          // (M > 64: the scalar kernel on a span-Q table in memory)
+        gamma_pieces_last = false;
+        if (gamma_pieces) {
+            // (round 6) long rows at 64 < M <= 256: eigen-power pieces + scan steps (chains_ss.hpp: k_piece_vectors)
+            build_gamma_pieces();
+            const int MS = 64 * NPL;
+            d_gp_gen.upload(ss_gen, sg);
+            d_gp_cs.alloc((size_t)Ke * 2 * Mp);
+            const size_t npc = gp_pieces.size();
+            d_gp_pvf.alloc(npc * Mp); d_gp_pvb.alloc(npc * Mp); d_gp_pgam.alloc(npc * Mp);
+            PieceArgs pa;
+            pa.M = M; pa.Mp = Mp; pa.npieces = (int)npc; pa.ntiles = (int)gp_tiles.size();
+            pa.pieces = d_gp_pieces.p; pa.tiles = d_gp_tiles.p; pa.Xs = d_Xs.p; pa.Ys = d_Ys.p; pa.dsc = d_dsc.p;
+            pa.PT = d_PT.p; pa.Pinvrm = d_Pinvrm.p; pa.cs = d_gp_cs.p; pa.pvf = d_gp_pvf.p; pa.pvb = d_gp_pvb.p; pa.pgam = d_gp_pgam.p;
+            hipLaunchKernelGGL(k_piece_rowsums, dim3(ceil_div(Ke * 2 * Mp, 256)), dim3(256), 0, sg, Ke, Mp, (const double *)d_PT.p,
+                               (const double *)d_Pinvrm.p, d_gp_cs.p);
+            if (pa.ntiles > 0) {
+                static bool once = false;
+                if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_piece_vectors, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
+                const size_t shm = (size_t)4 * 16 * (Mp + 4) * sizeof(double);
+                const int nblk = std::min(ceil_div(2 * pa.ntiles, 4), 2048);
+                hipLaunchKernelGGL(k_piece_vectors, dim3(nblk), dim3(256), shm, sg, pa);
+            }
+            SsArgs sa = SsArgs();
+            sa.M = M; sa.Mp = Mp;
+            const double *gd = d_gp_gen.p;
+            sa.f_dc = gd; sa.f_g = gd + MS; sa.f_cg = gd + 2 * MS; sa.f_b = gd + 3 * MS; sa.f_a = gd + 4 * MS; sa.f_d = gd + 5 * MS;
+            sa.b_dc = gd + 6 * MS; sa.b_g = gd + 7 * MS; sa.b_b = gd + 8 * MS; sa.b_a = gd + 9 * MS;
+            sa.c0 = ss_c0;
+            const int nw = (int)std::min<size_t>(npc, 4096);
+            d_gpark.alloc((size_t)nw * 64 * MS);
+            const dim3 grid(ceil_div(nw, 4)), block(256);
+            switch (NPL) {
+#define GP_(x) case x: hipLaunchKernelGGL((k_gamma_rows_scan<x, true>), grid, block, 0, sg, sa, ga, (const RowInfo *)d_rowinfo.p, \
+                                          (const double *)d_E.p, d_gpark.p, 64, nw, pa); break;
+                GP_(2) GP_(3)
+                default: GP_(4)
+#undef GP_
+            }
+            hipLaunchKernelGGL(k_gamma_merge_pieces, dim3((unsigned)ceil_div((long long)n_e_rows * Mp, 256)), dim3(256), 0, sg, Mp, (int)n_e_rows,
+                               (const int *)d_gp_pfirst.p, (const GPiece *)d_gp_pieces.p, (const double *)d_gp_pgam.p, d_gamma_rows.p);
+            gamma_pieces_last = true;
+        } else
         if (eigfree) {
             // no eigensystem on this path: 2 span - 1 scan steps per row, one (persistent) wavefront per row, the forward vectors parked
             // as floats in the wavefront's piece of a scratch buffer
@@ -1163,7 +1214,7 @@ void smcpp_im::enqueue_stats() {
                                (const int *)d_g_eig.p, (const double *)d_dsc.p, (const double *)d_dpow.p, d_Sq.p);
             ga.Sq = d_Sq.p;
         }
-        if (eigfree) {
+        if (eigfree || gamma_pieces) {
         } else if (mfma_rows) {
             // one launch per (contig, eigen key): a workgroup shares one LDS copy of P, Pinv and the reciprocal eigenvalue differences
             // (NT > 2: the reciprocal differences live in registers and the fold tile is half as wide - four wavefronts fit as well)
@@ -1192,6 +1243,49 @@ void smcpp_im::enqueue_stats() {
     if (ll_own) HIPCHK(hipStreamWaitEvent(s, ev[19], 0));
     HIPCHK(hipEventRecord(ev[5], s));
     stats_enqueued = true;
+}
+
+// The pieces of the eigen rows (chains_ss.hpp: k_piece_vectors): at most 64 positions each, in the order of the sorted eigen-row
+// permutation (so the pieces of one (contig, eigen key) are contiguous and a row's pieces are in position order); tiles of sixteen
+// pieces of ONE eigen key that need an interpolated vector (every piece of a row that has more than one).
+long long smcpp_im::gamma_piece_count() {
+    if (gp_count < 0) {
+        gp_count = 0;
+        for (size_t q = 0; q < perme.size(); ++q) gp_count += (groups[slabs_eg[erow_slab[q]].aux].span + 63) / 64;
+    }
+    return gp_count;
+}
+
+void smcpp_im::build_gamma_pieces() {
+    if (gp_built) return;
+    constexpr int PL = 64;
+    gp_pieces.clear(); gp_tiles.clear(); gp_pfirst.clear();
+    gp_pfirst.reserve(perme.size() + 1);
+    GTile cur; cur.es = -1; cur.cnt = 0;
+    auto flush = [&]() { if (cur.cnt > 0) { for (int k = cur.cnt; k < 16; ++k) cur.pid[k] = cur.pid[cur.cnt - 1]; gp_tiles.push_back(cur); } cur.cnt = 0; };
+    for (size_t q = 0; q < perme.size(); ++q) {
+        const Slab &sl = slabs_eg[erow_slab[q]];
+        const Group &gr = groups[sl.aux];
+        const long long row = sl.base + perme[q];
+        gp_pfirst.push_back((int)gp_pieces.size());
+        const int np = (gr.span + PL - 1) / PL;
+        for (int j = 0; j < np; ++j) {
+            GPiece pc;
+            pc.row = row; pc.q = (int)q; pc.o0 = j * PL; pc.len = std::min(PL, gr.span - j * PL); pc.span = gr.span; pc.kid = gr.kid; pc.es = gr.eig;
+            if (np > 1) {
+                if (cur.es != gr.eig || cur.cnt == 16) flush();
+                cur.es = gr.eig;
+                cur.pid[cur.cnt++] = (int)gp_pieces.size();
+            }
+            gp_pieces.push_back(pc);
+        }
+    }
+    flush();
+    gp_pfirst.push_back((int)gp_pieces.size());
+    d_gp_pieces.upload(gp_pieces, stream);
+    d_gp_tiles.upload(gp_tiles, stream);
+    d_gp_pfirst.upload(gp_pfirst, stream);
+    gp_built = true;
 }
 
 // Event intervals of the last E-step -> timing[] (lazily: see estep)

@@ -221,7 +221,7 @@ int smcpp_describe(smcpp_im *im, char *buf, int cap) {
                  im->chunks_b.size(), im->ss_wpc, (im->ss_static && im->ss_args.halo) ? "true" : "false", im->ss_light_f, im->ss_light_b,
                  (im->ss_static && im->ss_args.mixed) ? "true" : "false", im->last_ss_passes, im->ss_launched,
                  (opt().on(smcpp_opt::O_SS_CERT_PASS) || im->ss_need_cert_pass) ? "true" : "false", im->save_gamma ? "true" : "false",
-                 im->eigfree ? "true" : "false", !im->save_gamma ? "none" : im->eigfree ? "scan steps" : "eigensystem", im->split_spans ? "true" : "false",
+                 im->eigfree ? "true" : "false", !im->save_gamma ? "none" : im->eigfree ? "scan steps" : im->gamma_pieces_last ? "eigen-power pieces + scan steps" : "eigensystem", im->split_spans ? "true" : "false",
                  im->warm_start ? "true" : "false", omp_get_max_threads());
         s += t;
     }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Un-binned rows (the input of `smc++ posterior`) at 64 < M <= 256: the default route (dense streamed chains, eigensystem statistics,
-scalar per-row gammas) against the rows cut into 64-position pieces (SMCPP_SPLIT_SPANS=2: scan chains walking every base pair,
-eigen-free statistics, per-row gammas by scan steps).   python tools/unbinned_probe.py   (GPU box)"""
+"""Un-binned rows (the input of `smc++ posterior`) at 64 < M <= 256, three routes: the default (dense streamed chains, eigensystem
+statistics, per-row gammas from eigen-power pieces + scan steps), the rows cut into 64-position pieces (SMCPP_SPLIT_SPANS=2: scan chains
+walking every base pair, eigen-free statistics, per-row gammas by scan steps), and rounds 1-5 (SMCPP_GAMMA_PIECES=0: the scalar
+eigensystem kernel for the per-row gammas).   python tools/unbinned_probe.py   (GPU box)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,8 +13,9 @@ rows = int(os.environ.get("PROBE_ROWS", 100000))
 GAMMA = os.environ.get("PROBE_GAMMA", "1") != "0"
 for M in (96, 128, 256):
     res = {}
-    for mode in ("2", None):
-        _engine.set_option("SMCPP_SPLIT_SPANS", mode)
+    for mode in ("2", "old", None):
+        _engine.set_option("SMCPP_SPLIT_SPANS", "2" if mode == "2" else None)
+        _engine.set_option("SMCPP_GAMMA_PIECES", "0" if mode == "old" else None)
         obs = np.ascontiguousarray(synth.synth_posterior_contig(rows, 8, seed=7), dtype=np.int32)
         a, s = synth.model_pieces()
         t0 = time.perf_counter()
@@ -32,6 +34,8 @@ for M in (96, 128, 256):
         print(f"M = {M}, {rows} un-binned rows ({int(obs[:, 0].sum())} bp), pieces cut: {p['long_rows_cut']} ({p['rows']} rows): construction + first "
               f"E-step {t1 - t0:.2f} s, E-step {1e3 * (t2 - t1):.1f} ms, argmax {1e3 * (t3 - t2):.1f} ms, family {p['chain_family']}, passes "
               f"{p['passes_launched']}, per-row gamma {p['per_row_gamma']}, loglik {ll:.6f}", flush=True)
-    (l1, a1), (l0, a0) = res["2"], res[None]
-    print(f"   loglik rel diff {abs(l1 - l0) / abs(l0):.2e}, decoded index differs on {int((a1 != a0).sum())} of {len(a0)} columns", flush=True)
+    (l1, a1), (l0, a0), (l2, a2) = res["2"], res[None], res["old"]
+    print(f"   loglik rel diff (cut vs default) {abs(l1 - l0) / abs(l0):.2e}, decoded index differs on {int((a1 != a0).sum())} (cut vs default) / "
+          f"{int((a2 != a0).sum())} (eigensystem kernel vs default) of {len(a0)} columns", flush=True)
 _engine.set_option("SMCPP_SPLIT_SPANS", None)
+_engine.set_option("SMCPP_GAMMA_PIECES", None)

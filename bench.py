@@ -9,7 +9,7 @@ what `InferenceManager::Estep` does after `setParams` (src/inference_manager.cpp
 `split_ms.hmm_only_ms` additionally reports the same eval with the prepared parameters handed over by `set_raw`
 (no A6-A10), which is what round 1 timed.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c3|c4|c5|posterior|posterior64|pbinned|qgrad|shaping] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c3|c4|c5|posterior|posterior64|posterior128|pbinned|qgrad|shaping] [--no-cpu]
 
 `--gpus N` with N > 1 and no torchrun environment re-launches itself under `torch.distributed.run` (one rank per
 GPU, RCCL); under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  Every rank owns one synthetic 100 Mbp contig
@@ -55,6 +55,10 @@ WORKLOADS = {
     # ... the same at M = 64: the eigenvector tables of the hybrid rows (133 KB per eigen key) do not fit LDS, so the dense
     # cooperative chains run (the regime hole DESIGN.md section 9 names; measured, not hidden)
     "posterior64": (64, 8, None, "posterior decode: 1 un-binned contig, 1e6 rows, spans to 1e5, rho=6e-5, M=64, n=8, save_gamma"),
+    # ... and at M = 128 (round 6: the dense streamed chains take a row in one eigen-power step; the per-row posteriors come from
+    # eigen-power pieces of 64 positions walked by scan steps - k_piece_vectors / k_gamma_rows_scan<., true> - instead of the scalar
+    # eigensystem kernel of rounds 1-5; SMCPP_GAMMA_PIECES=0 times that one)
+    "posterior128": (128, 8, None, "posterior decode: 1 un-binned contig, 1e6 rows, spans to 1e5, rho=6e-5, M=128, n=8, save_gamma"),
     # posterior decode of BINNED data (round 6: save_gamma keeps the eigen-free path - per-row posteriors of the span > 1 rows from scan
     # steps, k_gamma_rows_scan): the headline contig with save_gamma; parity = the decoded index of every column against golden G19
     "pbinned": (64, 20, "params_M64_n20.npz", "posterior decode of 1 binned synthetic 100 Mbp contig, M=64, n=20, save_gamma"),
@@ -226,7 +230,7 @@ def main():
         def factory(obs, d):
             return _smcpp.PyTwoPopInferenceManager(n, n, 2, 0, obs, hs, ("pop1", "pop2"), pol, device=d)
     else:
-        if args.workload in ("posterior", "posterior64"):
+        if args.workload in ("posterior", "posterior64", "posterior128"):
             hs = synth.hidden_states(M)
             a, s_ = synth.model_pieces()
             theta, rho, alpha, pol = 1e-4 * 2, 6e-5, 1.0, 0.5
@@ -271,7 +275,7 @@ def main():
         im = factory(contigs, local_rank)
     top = sim if sim is not None else im
     top.theta = theta; top.rho = rho; top.alpha = alpha
-    if args.workload in ("posterior", "posterior64", "pbinned"):
+    if args.workload in ("posterior", "posterior64", "posterior128", "pbinned"):
         im.save_gamma = True
     if args.chunk or args.eps_alpha or args.eps_beta:
         im.set_chunking(args.chunk, args.eps_alpha, args.eps_beta)
@@ -577,6 +581,23 @@ def main():
               "gbs_on_B_alg": B_alg / (1e-3 * ms_per_step) / 1e9},
         note=note)
 
+    if args.workload == "posterior128":
+        # per-row posteriors from eigen-power pieces + scan steps: every position of a span > 1 row is walked once forward and once backward
+        # by the O(M) scan steps (two states per lane: 56 / 74 VALU instructions per step, as the stored passes of k_chain_ss<2>) on top of
+        # two M x M products per 64-position piece on the matrix cores
+        pos_e = float(sum(int(c[c[:, 0] > 1, 0].sum()) for c in contigs))
+        g_ms = med["finalize_ms"]
+        ginstr = pos_e * (56 + 74) / (1e-3 * max(g_ms, 1e-9)) / 1e9
+        roof["posterior"] = {"per_row_gamma": plan.get("per_row_gamma") if isinstance(plan, dict) else None, "gamma_ms": g_ms,
+                             "span_rows": Re, "positions_in_span_rows": pos_e, "pieces_of_64": pos_e / 64.0,
+                             "piece_vector_flops": 2 * 2.0 * M * M * pos_e / 64.0}
+        if g_ms > roof.get("kernel_ms_per_step", 0.0):
+            chains_block = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_useful", "kernel", "kernel_ms_per_step") if k in roof}
+            roof.update(bound="valu-issue", achieved=ginstr, peak=614.4, unit="G wave-instr/s", frac=ginstr / 614.4, frac_useful=ginstr / 614.4,
+                        kernel="k_gamma_rows_scan<2, true> (+ k_piece_vectors, k_gamma_merge_pieces): per-row posteriors of the span > 1 rows from "
+                               "eigen-power pieces walked by scan steps (hmm.cpp:113-121)", kernel_ms_per_step=g_ms, chains=chains_block,
+                        note="dominant phase = the per-row gammas: achieved = positions of the span > 1 rows x 130 VALU instructions (one forward, "
+                             "one backward scan step) / the finalisation interval; peak = one wave64 DPP / fp64 instruction per 4 cycles per SIMD")
     if args.workload in ("posterior", "posterior64"):
         # the product of this workload is the M x (L+1) posterior matrix: 8 M L bytes written by the statistics phase
         # (span-1 rows by k_s1_scalars, eigen rows by k_gamma_rows_mfma: 2 M^3 flops per eigen row on the matrix cores)

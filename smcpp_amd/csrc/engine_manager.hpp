@@ -43,6 +43,8 @@ struct smcpp_im {
     // generation-2 eigen statistics (M <= 64): slabs over the sorted eigen rows of a (contig, eigen key) that MIX span groups
     std::vector<Slab> slabs_ek;
     std::vector<int> ek_slab_off, epos_gid;
+    std::vector<int4> erow_desc;           // per sorted eigen-row position: {row low / high word, group, span} (k_gamma_rows_b)
+    DevBuf<int4> d_erow_desc;
     DevBuf<Slab> d_slabs_ek;
     DevBuf<int> d_ek_slab_off, d_epos_gid;
     DevBuf<double> d_part_ek, d_red_ek;
@@ -944,6 +946,13 @@ void smcpp_im::make_slabs() {
     ek_slab_off.assign((size_t)n_contigs * Ke + 1, 0);
     epos_gid.reserve(perme.size());
     for (size_t q = 0; q < erow_slab.size(); ++q) epos_gid.push_back(slabs_eg[erow_slab[q]].aux);
+    erow_desc.clear();
+    erow_desc.reserve(perme.size());
+    for (size_t q = 0; q < erow_slab.size(); ++q) {
+        const Slab &sl = slabs_eg[erow_slab[q]];
+        const long long row = sl.base + perme[q];
+        erow_desc.push_back(make_int4((int)(row & 0xffffffffll), (int)(row >> 32), sl.aux, groups[sl.aux].span));
+    }
     for (int c = 0; c < n_contigs; ++c)
         for (int e = 0; e < Ke; ++e) {
             const size_t ce = (size_t)c * Ke + e;
@@ -1075,6 +1084,7 @@ void smcpp_im::alloc_device() {
     d_s1_team_off.upload(s1_team_off, s);
     d_ek_slab_off.upload(ek_slab_off, s);
     d_epos_gid.upload(epos_gid, s);
+    d_erow_desc.upload(erow_desc, s);
     d_contig_base.upload(contig_base, s);
     d_contig_L.upload(Ls, s);
     std::vector<int> gs(G), ge(G);

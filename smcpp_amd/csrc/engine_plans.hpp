@@ -816,7 +816,13 @@ void smcpp_im::enqueue_stats() {
                             !opt().off(smcpp_opt::O_GAMMA_SIDE);
     if (save_gamma) {
         d_gamma_rows.alloc((size_t)total_rows * Mp);
-        d_gamma_rows.zero(s);
+        // Every row 1 .. L of a contig is written whole by the statistics (span-1 rows: k_s1_scalars; span > 1 rows: the per-row gamma
+        // kernels); only row 0 (column 0 of the caller's matrix comes from gamma0) is nobody's: it alone is cleared.  Until round 6 the
+        // WHOLE buffer was cleared here, on the main stream - behind the scan chains' fork event (ev[3], recorded by run_chains_ss), so
+        // the span-1 branch on its side stream could write rows the memset then wiped: zero columns in the decoded path on a timing-
+        // dependent 2 - 7 % of the headline contig (tests/test_gpu_argmax.py, seen once the suite's order shifted the timing).
+        for (int c = 0; c < n_contigs; ++c)
+            HIPCHK(hipMemsetAsync(d_gamma_rows.p + (size_t)contig_base[c] * Mp, 0, sizeof(double) * Mp, s));
         if (gamma_side) { HIPCHK(hipEventRecord(ev[22], s)); HIPCHK(hipStreamWaitEvent(stream_hi, ev[22], 0)); }
     }
     // The eigen-row branch (U/W products, rank update, span-Q Hadamard, Y) does not depend on the span-1 branch
@@ -1150,7 +1156,7 @@ void smcpp_im::enqueue_stats() {
         ga.M = M; ga.Mp = Mp; ga.nrows = (int)n_e_rows; ga.perm = d_perme.p; ga.row_slab = d_erow_slab.p;
         ga.slabs = d_slabs_eg.p; ga.g_eig = d_g_eig.p; ga.g_span = d_g_span.p; ga.dun = d_dun.p; ga.dsc = d_dsc.p; ga.dpow = d_dpow.p;
         ga.Prm = d_Prm.p; ga.Pinvrm = d_Pinvrm.p; ga.PinvT = d_PinvT.p; ga.Sq = nullptr;
-        ga.alpha = d_alpha.p; ga.beta = d_beta.p; ga.gamma_rows = d_gamma_rows.p;
+        ga.alpha = d_alpha.p; ga.beta = d_beta.p; ga.gamma_rows = d_gamma_rows.p; ga.erow_desc = d_erow_desc.p;
         const bool mfma_rows = NT <= 4;          // (M > 64: the scalar kernel on a span-Q table in memory)
         gamma_pieces_last = false;
         if (gamma_pieces) {
@@ -1219,7 +1225,7 @@ void smcpp_im::enqueue_stats() {
             // one launch per (contig, eigen key): a workgroup shares one LDS copy of P, Pinv and the reciprocal eigenvalue differences
             // (NT > 2: the reciprocal differences live in registers and the fold tile is half as wide - four wavefronts fit as well)
             const int NW = 4;
-            const size_t shm2 = (size_t)((NT <= 2 ? 3 : 2) * Mp * (Mp + 1) + NW * (2 * 16 * (Mp + 1) + Mp * (NT <= 2 ? 17 : 9))) * sizeof(double);
+            const size_t shm2 = (size_t)((NT <= 2 ? 3 : 2) * Mp * (Mp + 1) + NW * (2 * 16 * (Mp + 1) + Mp * (NT <= 2 ? 17 : 9) + Mp) + Mp) * sizeof(double);
             for (int ce = 0; ce < n_contigs * Ke; ++ce) {
                 const int q0 = ce_row_off[ce], q1 = ce_row_off[ce + 1];
                 if (q1 <= q0) continue;

@@ -1936,6 +1936,7 @@ struct GammaRowArgs {
     const float *alpha;
     const double *beta;
     double *gamma_rows;       // [rows][Mp]
+    const int4 *erow_desc = nullptr;   // [nrows] {row (low, high word), group, span} of every sorted position: ONE load where perm -> row_slab -> slabs -> g_span are three dependent ones (k_gamma_rows_b)
 };
 
 __global__ __launch_bounds__(256) void k_span_q(int M, int Mp, int G, const int *g_span, const int *g_eig,
@@ -2061,8 +2062,9 @@ __global__ __launch_bounds__(256) void k_gamma_rows_b(GammaRowArgs a, int p0, in
     double *sInvD = sPinv + MT * LD;         // [MT][LD]  1 / (d_a - d_b), 0 where the eigenvalues are equal   (!RID)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *sU = sPinv + (RID ? 1 : 2) * MT * LD + (size_t)wv * (2 * 16 * LD + MT * GW);   // per wavefront: x = d o u [16 rows][LD], w [16][LD], fold tile [MT][GW]
-    double *sW = sU + 16 * LD, *sG = sW + 16 * LD;
+    double *sU = sPinv + (RID ? 1 : 2) * MT * LD + (size_t)wv * (2 * 16 * LD + MT * GW + MT);   // per wavefront: x = d o u [16 rows][LD], w [16][LD], fold tile [MT][GW], the group's powers [MT]
+    double *sW = sU + 16 * LD, *sG = sW + 16 * LD, *sPW = sG + MT * GW;
+    double *sIda = sPinv + (RID ? 1 : 2) * MT * LD + (size_t)NW * (2 * 16 * LD + MT * GW + MT);   // [MT] 1 / d~_a (RID)
     const int Mp = a.Mp, M = a.M;
     const double *dsc = a.dsc + (size_t)es * Mp, *dun = a.dun + (size_t)es * Mp;
     {
@@ -2075,6 +2077,10 @@ __global__ __launch_bounds__(256) void k_gamma_rows_b(GammaRowArgs a, int p0, in
                 const double dd = dsc[r] - dsc[c];
                 sInvD[r * LD + c] = (dd != 0.0 && r < M && c < M) ? 1.0 / dd : 0.0;
             }
+        }
+        if (RID && tid < MT) {
+            const double d = dsc[min(tid, Mp - 1)];
+            sIda[tid] = (tid < M && d != 0.0) ? 1.0 / d : 0.0;
         }
     }
     __syncthreads();
@@ -2127,20 +2133,28 @@ __global__ __launch_bounds__(256) void k_gamma_rows_b(GammaRowArgs a, int p0, in
     const int pw0 = p0 + (blockIdx.x * NW + wv) * nbatch * 16;
     const int pw1 = min(p1, pw0 + nbatch * 16);
     int gid_prev = -1, span = 1;
+    // (round 6) un-binned data change the (span, key) group on nearly every row: the group's M powers used to be fetched - twenty
+    // dependent global loads per lane, and sixteen divisions 1 / d~ at M > 32 - at the head of the row, a full memory round trip with
+    // nothing else resident on the SIMD.  Now lane a fetches power a of the NEXT row's group while this row's products run (one
+    // double per lane), the head of the row spreads it through LDS, and 1 / d~ comes from a table formed once per workgroup.
+    int gid_pf = -1;
+    double pw_pf = 0.0;
     double pa[KS], sd[KS], pb[NT];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) { pa[kk] = 0.0; sd[kk] = 0.0; }
 #pragma unroll
     for (int bt = 0; bt < NT; ++bt) pb[bt] = 0.0;
+    // (round 6) the descriptor of the NEXT batch's rows is fetched while this batch runs (one 16-byte load per lane)
+    int4 desc_nx = pw0 < pw1 ? a.erow_desc[min(pw0 + n, pw1 - 1)] : make_int4(0, 0, 0, 1);
     for (int pbat = pw0; pbat < pw1; pbat += 16) {
         const int nb = min(16, pw1 - pbat);
         // lane n describes row pbat + n: the row loop below reads group, span and row index with v_readlane (no dependent
         // global loads on the per-row path)
-        const int pn = min(pbat + n, pw1 - 1);
-        const Slab sln = a.slabs[a.row_slab[pn]];
-        const int gid_n = sln.aux;
-        const long long rown = sln.base + a.perm[pn];
-        const int span_n = a.g_span[gid_n];
+        const int4 desc = desc_nx;
+        if (pbat + 16 < pw1) desc_nx = a.erow_desc[min(pbat + 16 + n, pw1 - 1)];
+        const int gid_n = desc.z;
+        const long long rown = ((long long)desc.y << 32) | (unsigned)desc.x;
+        const int span_n = desc.w;
         // ---- x = d o (Pinv alpha_{l-1}),  w = P^T beta_l for the 16 rows of the batch (column n of the products = row pbat + n) ----
         {
             const float *ap = a.alpha + (size_t)(rown - 1) * Mp;
@@ -2175,20 +2189,36 @@ __global__ __launch_bounds__(256) void k_gamma_rows_b(GammaRowArgs a, int p0, in
             if (gid != gid_prev) {                                   // wave-uniform
                 gid_prev = gid;
                 span = __builtin_amdgcn_readlane(span_n, q);
-                const double *pw = a.dpow + (size_t)gid * Mp;
+                if (RID) {
+                    double mine = pw_pf;
+                    if (gid != gid_pf) mine = a.dpow[(size_t)gid * Mp + min(lane, Mp - 1)];      // (first row of a batch, or a row whose group was not the announced one)
+                    if (lane < MT) sPW[lane] = mine;
+                    wave_lds_fence();
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) {
-                    pa[kk] = pw[4 * kk + kq];
-                    double ida;
-                    if (RID) {
-                        const int aa = 4 * kk + kq;
-                        const double d = dsc[min(aa, Mp - 1)];
-                        ida = (aa < M && d != 0.0) ? 1.0 / d : 0.0;
-                    } else ida = invda[RID ? 0 : kk];
-                    sd[kk] = (double)span * pa[kk] * ida;            // span d^(span-1)
+                    for (int kk = 0; kk < KS; ++kk) {
+                        pa[kk] = sPW[4 * kk + kq];
+                        sd[kk] = (double)span * pa[kk] * sIda[4 * kk + kq];            // span d^(span-1)
+                    }
+#pragma unroll
+                    for (int bt = 0; bt < NT; ++bt) pb[bt] = sPW[16 * bt + n];
+                } else {
+                    // (M <= 32: six to ten loads per lane, and the detour through LDS costs more than it hides - 0.83 -> 0.99 ms measured)
+                    const double *pw = a.dpow + (size_t)gid * Mp;
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) {
+                        pa[kk] = pw[4 * kk + kq];
+                        sd[kk] = (double)span * pa[kk] * invda[RID ? 0 : kk];
+                    }
+#pragma unroll
+                    for (int bt = 0; bt < NT; ++bt) pb[bt] = pw[16 * bt + n];
                 }
-#pragma unroll
-                for (int bt = 0; bt < NT; ++bt) pb[bt] = pw[16 * bt + n];
+            }
+            if (RID && q + 1 < nb) {
+                const int gnx = __builtin_amdgcn_readlane(gid_n, q + 1);
+                if (gnx != gid) {                                    // wave-uniform
+                    pw_pf = a.dpow[(size_t)gnx * Mp + min(lane, Mp - 1)];
+                    gid_pf = gnx;
+                }
             }
             double xs[NK];
             if (!RID) {

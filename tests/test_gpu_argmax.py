@@ -113,6 +113,34 @@ def test_posterior_indices_at_scale_vs_compiled_reference(name, route):
     assert rel_err(gam[:, 0], g["gamma0"]) <= STAT_TOL
 
 
+def test_repeated_save_gamma_steps_keep_every_column():
+    """Round 6 regression: the per-row posterior buffer used to be cleared on the main stream BEHIND the scan chains' fork event, so the
+    span-1 branch on its side stream could write rows the memset then wiped (zero columns on a timing-dependent 2 - 7 % of the
+    headline contig).  Now only row 0 is cleared.  Twelve save_gamma E-steps on one manager, a lean E-step in between: every column of
+    every step sums to its span and decodes the same index."""
+    g, obs = _load("G19_headline")
+    im = _manager(g, obs, "params")
+    im.E_step()
+    im.save_gamma = True
+    spans = np.concatenate([[1.0], obs[:, 0].astype(float)])
+    ref = None
+    for it in range(12):
+        if it == 6:
+            im.save_gamma = False
+            im.E_step()
+            im.save_gamma = True
+        im.E_step()
+        arg = np.asarray(im.gamma_argmax(0)).astype(np.int64)
+        if ref is None:
+            ref = arg
+            mism, strong, _ = argmax_report(arg, g)
+            assert len(strong) == 0
+        assert np.array_equal(arg, ref), f"step {it}: {int((arg != ref).sum())} columns changed"
+        if it in (0, 7, 11):
+            gam = im.gammas[0]
+            np.testing.assert_allclose(gam.sum(axis=0), spans, rtol=1e-9)
+
+
 @pytest.mark.parametrize("name", ["G19_headline", "G19_c2"])
 def test_posterior_indices_with_float_scans_in_the_stored_passes(engine_opt, name):
     """the timed path runs every scan of the stored passes in float (chains_ss.hpp: ss_x_scan_fwd / _bwd); until

@@ -8,7 +8,7 @@ cd $GRAFT_REPO_ROOT
 bash tools/profile_round.sh $TAG > /dev/null 2>&1
 O=gpurun_out/$TAG
 bash tools/pmc_sq_counters.sh $TAG headline c3 c5 > $O/sq.log 2>&1
-for w in c2 c3 c4 c5 posterior posterior64 pbinned; do python bench.py --workload $w > $O/bench_$w.log 2>&1; grep '^{"metric"' $O/bench_$w.log | tail -1 | cut -c1-200; done
+for w in c2 c3 c4 c5 posterior posterior64 posterior128 pbinned; do python bench.py --workload $w > $O/bench_$w.log 2>&1; grep '^{"metric"' $O/bench_$w.log | tail -1 | cut -c1-200; done
 python bench.py --workload qgrad > $O/bench_qgrad.log 2>&1; grep '^{"metric"' $O/bench_qgrad.log | tail -1 | cut -c1-260
 SMCPP_BENCH_THREADS=1 python bench.py --no-cpu > $O/bench_default_1thread.log 2>&1; grep '^{"metric"' $O/bench_default_1thread.log | tail -1 | cut -c1-200
 python bench.py --no-cpu --warm > $O/bench_warm.log 2>&1; grep '^{"metric"' $O/bench_warm.log | tail -1 | python -c "import sys,json; print('warm', json.loads(sys.stdin.read()).get('warm_start'))"
@@ -20,7 +20,7 @@ python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tai
 # what the E-step's exchange adds to an eval (one-rank RCCL group: host wait / stream-ordered through torch / issued by the engine)
 timeout 300 python -m pytest tests/test_gpu_multi.py -m gpu -q -s -k world_of_one 2>&1 | grep -a "exchange cost" | tail -1 > $O/exchange_cost.log; cat $O/exchange_cost.log
 cd /tmp && export TMPDIR=/tmp
-for w in c3 c5 posterior qgrad; do
+for w in c3 c5 posterior posterior64 posterior128 qgrad; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_$w -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ref-width --workload $w --steps 5 > /dev/null 2>&1
 done
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $GRAFT_REPO_ROOT/tools/dpp_lab.hip -o /tmp/dpp_lab && /tmp/dpp_lab > $GRAFT_REPO_ROOT/$O/dpp_lab.log 2>&1

@@ -228,24 +228,25 @@ def test_long_rows_of_binned_data_cut_into_pieces(engine_opt, M, rows):
         assert np.max(np.abs(im0.gammas[0] - gam) / spans) <= 2e-5
 
 
-@pytest.mark.parametrize("M,rows", [(128, 400), (96, 300), (256, 200)])
-def test_unbinned_rows_gamma_from_eigen_power_pieces(engine_opt, M, rows):
+@pytest.mark.parametrize("M,rows,ncontigs", [(128, 400, 1), (96, 300, 2), (256, 200, 1)])
+def test_unbinned_rows_gamma_from_eigen_power_pieces(engine_opt, M, rows, ncontigs):
     """Round 6: per-row posteriors of un-binned rows (spans up to 10^5) at 64 < M <= 256.  The chains and the statistics take such a
     row in one eigen-power step (hmm.cpp:72-78,104-112); its gamma (hmm.cpp:113-121) comes from pieces of at most 64 positions whose
     start / end vectors are eigen-power interpolations of the row's stored vectors (k_piece_vectors) and whose positions are walked by
     scan steps.  Against the C restatement (the reference's eigensystem form): every column of gamma, the decoded index; and against
-    the engine's own eigensystem kernel (SMCPP_GAMMA_PIECES=0), with everything else bit for bit the same."""
+    the engine's own eigensystem kernel (SMCPP_GAMMA_PIECES=0), with everything else bit for bit the same.  (Two contigs: the pieces'
+    table runs over the sorted eigen rows of all contigs and eigen keys.)"""
     from oracle import oracle
     from smcpp_amd import _smcpp, synth
     from smcpp_amd.model import PiecewiseModel
     n = 8
-    obs = np.ascontiguousarray(synth.synth_posterior_contig(rows, n, seed=11), dtype=np.int32)
-    assert obs[:, 0].max() > 1000
+    contigs = [np.ascontiguousarray(synth.synth_posterior_contig(rows - 40 * c, n, seed=11 + c), dtype=np.int32) for c in range(ncontigs)]
+    assert all(o[:, 0].max() > 1000 for o in contigs)
     a, s = synth.model_pieces()
     engine_opt("SMCPP_SPLIT_SPANS", "0")       # (an input this small would be cut into pieces at construction: "few pieces" rule)
 
     def manager():
-        im = _smcpp.PyOnePopInferenceManager(n, [obs], synth.hidden_states(M), ("pop1",), 0.5)
+        im = _smcpp.PyOnePopInferenceManager(n, contigs, synth.hidden_states(M), ("pop1",), 0.5)
         im.model = PiecewiseModel(a, s, 1e4, "pop1")
         im.theta = 2e-4; im.rho = 6e-5; im.alpha = 1.0
         im.save_gamma = True
@@ -255,31 +256,35 @@ def test_unbinned_rows_gamma_from_eigen_power_pieces(engine_opt, M, rows):
     plan = im.describe()["plan"]
     assert not plan["long_rows_cut"] and not plan["eigen_free_statistics"], plan
     assert plan["per_row_gamma"] == "eigen-power pieces + scan steps", plan
-    keys = im.keys
-    ep = im.emission_probs
-    Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
-    o = oracle.estep(im.pi, im.transition, keys, Etab, obs, save_gamma=True)
-    ll = im.loglik()
-    assert abs(ll - o["loglik"]) <= LL_TOL * abs(o["loglik"]), (ll, o["loglik"])
-    gam = im.gammas[0]
-    assert gam.shape == o["gamma"].shape == (M, rows + 1)
-    spans = np.concatenate([[1.0], obs[:, 0].astype(float)])
-    err = np.max(np.abs(gam - o["gamma"]), axis=0) / spans
-    np.testing.assert_allclose(gam.sum(axis=0)[1:], spans[1:], rtol=1e-9)
-    arg = np.asarray(im.gamma_argmax(0))
-    assert np.array_equal(arg, gam.argmax(axis=0))
-    top2 = np.sort(o["gamma"], axis=0)[-2:]
-    strong = (top2[1] - top2[0]) > 1e-5 * spans
-    assert not np.any(strong & (arg != o["gamma"].argmax(axis=0)))
     engine_opt("SMCPP_GAMMA_PIECES", "0")
     im0 = manager()
     assert im0.describe()["plan"]["per_row_gamma"] == "eigensystem"
-    assert im0.loglik() == ll and np.array_equal(im0.xisums[0], im.xisums[0])
-    g0 = im0.gammas[0]
-    err0 = np.max(np.abs(g0 - o["gamma"]), axis=0) / spans
-    print(f"M = {M}, {rows} un-binned rows ({int(obs[:, 0].sum())} positions): per-row gamma worst column {err.max():.2e} of its span "
-          f"(eigensystem kernel: {err0.max():.2e}; the two routes: {(np.max(np.abs(g0 - gam), axis=0) / spans).max():.2e})")
-    assert err.max() <= 2e-5
+    assert im0.loglik() == im.loglik()
+    keys = im.keys
+    ep = im.emission_probs
+    Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
+    lls = []
+    for c, obs in enumerate(contigs):
+        o = oracle.estep(im.pi, im.transition, keys, Etab, obs, save_gamma=True)
+        lls.append(o["loglik"])
+        gam = im.gammas[c]
+        assert gam.shape == o["gamma"].shape == (M, len(obs) + 1)
+        spans = np.concatenate([[1.0], obs[:, 0].astype(float)])
+        err = np.max(np.abs(gam - o["gamma"]), axis=0) / spans
+        np.testing.assert_allclose(gam.sum(axis=0)[1:], spans[1:], rtol=1e-9)
+        arg = np.asarray(im.gamma_argmax(c))
+        assert np.array_equal(arg, gam.argmax(axis=0))
+        top2 = np.sort(o["gamma"], axis=0)[-2:]
+        strong = (top2[1] - top2[0]) > 1e-5 * spans
+        assert not np.any(strong & (arg != o["gamma"].argmax(axis=0)))
+        assert np.array_equal(im0.xisums[c], im.xisums[c])
+        g0 = im0.gammas[c]
+        err0 = np.max(np.abs(g0 - o["gamma"]), axis=0) / spans
+        print(f"M = {M}, contig {c}: {len(obs)} un-binned rows ({int(obs[:, 0].sum())} positions): per-row gamma worst column {err.max():.2e} of its "
+              f"span (eigensystem kernel: {err0.max():.2e}; the two routes: {(np.max(np.abs(g0 - gam), axis=0) / spans).max():.2e})")
+        assert err.max() <= 2e-5
+    ll = im.loglik()
+    assert abs(ll - sum(lls)) <= LL_TOL * abs(sum(lls)), (ll, lls)
 
 
 def test_unbinned_rows_beyond_256_states():

@@ -43,6 +43,14 @@ def run_case(case):
         im.model = PiecewiseModel(a_, s_, 1e4, "pop1")
         im.theta = synth.THETA; im.rho = synth.RHO; im.alpha = 1.0
         im.set_chunking(10 ** 6)
+    elif kind == "post128":
+        # (round 6) un-binned rows at M = 128: dense streamed chains, eigensystem statistics, per-row posteriors from eigen-power pieces
+        obs = [np.ascontiguousarray(synth.synth_posterior_contig(3000, 8, seed=7), dtype=np.int32)]
+        a_, s_ = synth.model_pieces()
+        im = _smcpp.PyOnePopInferenceManager(8, obs, synth.hidden_states(128), ("pop1",), 0.5)
+        im.model = PiecewiseModel(a_, s_, 1e4, "pop1")
+        im.theta = 2e-4; im.rho = 6e-5; im.alpha = 1.0
+        im.save_gamma = True
     elif kind in ("big", "biggamma", "post", "m1"):
         # big: a whole 100 Mbp contig (512 chunks per direction, light passes); post: un-binned rows (hybrid chains, thousands of
         # span groups); m1: ONE hidden state (the bootstrap manager of Analysis)

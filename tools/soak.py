@@ -2,7 +2,7 @@
 bit-identical whenever the parameters are, and device memory must not grow.   python tools/soak.py   (GPU box; a minute)
 Configurations (round 6): the headline contig at M = 64 with and without save_gamma (eigen-free per-row posteriors), config C5's contig
 at M = 256 (LDS-staged rank updates, lazily expanded transition matrix) with and without save_gamma, and the example-derived contig at
-M = 144 (rows cut into pieces, a ragged output block)."""
+M = 144 (rows cut into pieces, a ragged output block), un-binned rows at M = 128 (per-row posteriors from eigen-power pieces)."""
 import os, sys, time, zlib, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
@@ -48,4 +48,7 @@ soak("c5 M=256", 256, 50, c256, 1200, False)
 soak("c5 M=256 save_gamma", 256, 50, c256, 400, True)
 soak("example-derived M=144 cut rows save_gamma", 144, 4, np.ascontiguousarray(g1["obs"], dtype=np.int32), 1500, True,
      theta=float(g1["theta"]), rho=float(g1["rho"]))
+# (round 6, last session) un-binned rows at M = 128: per-row posteriors from eigen-power pieces + scan steps
+soak("un-binned M=128 save_gamma (eigen-power pieces)", 128, 8, np.ascontiguousarray(synth.synth_posterior_contig(20000, 8, seed=7), dtype=np.int32),
+     300, True, theta=2e-4, rho=6e-5)
 print("soak ok")

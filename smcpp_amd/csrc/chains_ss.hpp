@@ -1658,14 +1658,16 @@ struct PieceArgs {
     const double *dsc;        // [Ke][Mp] scaled eigenvalues
     const double *PT, *Pinvrm;        // [Ke][Mp][Mp]  PT[a][i] = P[i][a],  Pinvrm[a][i] = Pinv[a][i]
     const double *cs;         // [Ke][2][Mp] row sums of PT / Pinvrm (k_piece_rowsums): the sum of an interpolated vector without forming it
+    const double *l2d;        // [Ke][Mp] log2 |d~| (k_piece_rowsums): d~^k = exp2(k log2 |d~|) - a fifth of pow()'s instructions
     float *pvf;               // [npieces][Mp] forward vector at the piece's start (o0 > 0)
     double *pvb;              // [npieces][Mp] backward vector at the piece's end (o0 + len < span)
     double *pgam;             // [npieces][Mp] the piece's share of its row's gamma (k_gamma_rows_scan<., true>)
 };
 
 __global__ __launch_bounds__(256) void k_piece_rowsums(int Ke, int Mp, const double *__restrict__ PT, const double *__restrict__ Pinvrm,
-                                                       double *__restrict__ cs) {
+                                                       double *__restrict__ cs, const double *__restrict__ dsc, double *__restrict__ l2d) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < Ke * Mp) l2d[idx] = log2(fabs(dsc[idx]));            // (-inf for a zero eigenvalue: exp2 gives 0)
     if (idx >= Ke * 2 * Mp) return;
     const int a = idx % Mp, dir = (idx / Mp) & 1, e = idx / (2 * Mp);
     const double *src = (dir ? Pinvrm : PT) + (size_t)e * Mp * Mp + (size_t)a * Mp;
@@ -1683,23 +1685,32 @@ __global__ __launch_bounds__(256) void k_piece_vectors(PieceArgs a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n = lane & 15, kq = lane >> 4;
     double *sX = pv_sm + (size_t)wv * 16 * LDX;
-    const int nwork = 2 * a.ntiles;
-    for (int wk = blockIdx.x * 4 + wv; wk < nwork; wk += gridDim.x * 4) {
-        const int dir = wk & 1;
-        const GTile &tl = a.tiles[wk >> 1];
-        const int es = ss_uni(tl.es), cnt = ss_uni(tl.cnt);
-        const int pid = tl.pid[min(n, cnt - 1)];
+    // A workgroup takes FOUR consecutive tiles in ONE direction and its wavefronts walk the output tiles in step (a barrier per tile):
+    // the 128-byte lines of the key's matrix one of them pulls from L2 are still in the CU's vector L1 when the other three ask for them.
+    const int nunits = 2 * ((a.ntiles + 3) / 4);
+    for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+        const int dir = unit & 1;
+        const int tile = 4 * (unit >> 1) + wv;
+        const bool have = tile < a.ntiles;
+        const GTile &tl = a.tiles[min(tile, a.ntiles - 1)];
+        const int es = ss_uni(tl.es), cnt = have ? ss_uni(tl.cnt) : 0;
+        const int pid = tl.pid[max(0, min(n, cnt - 1))];
         const GPiece pc = a.pieces[pid];
         const int kpow = dir ? pc.span - pc.o0 - pc.len : pc.o0;
         const bool need = n < cnt && kpow > 0;
         const double *X = (dir ? a.Ys : a.Xs) + (size_t)pc.q * Mp;
         const double *dsc = a.dsc + (size_t)es * Mp;
+        const double *l2d = a.l2d + (size_t)es * Mp;
         const double *cs = a.cs + ((size_t)es * 2 + dir) * Mp;
+        const double kd = (double)kpow;
         double part = 0.0;
         for (int kk = 0; kk < Mp / 4; ++kk) {
             const int st = 4 * kk + kq;
             double v = 0.0;
-            if (need && st < M) v = pow(dsc[st], (double)kpow) * X[st];
+            if (need && st < M) {
+                v = exp2(kd * l2d[st]) * X[st];
+                if ((kpow & 1) && dsc[st] < 0.0) v = -v;               // (an eigenvalue rounding made negative: (-|d|)^k)
+            }
             part = fma(cs[st], v, part);
             sX[n * LDX + st] = v;
         }
@@ -1716,6 +1727,7 @@ __global__ __launch_bounds__(256) void k_piece_vectors(PieceArgs a) {
         wave_lds_fence();
         const double *Mat = (dir ? a.Pinvrm : a.PT) + (size_t)es * Mp * Mp;
         for (int it = 0; it < Mp / 16; ++it) {
+            __syncthreads();
             f64x4 D = (f64x4){0, 0, 0, 0};
             const double *Bp = Mat + (size_t)kq * Mp + it * 16 + n;
             for (int kk = 0; kk < Mp / 4; kk += 4) {              // (Mp is a multiple of 16)

@@ -165,7 +165,7 @@ struct smcpp_im {
     DevBuf<GTile> d_gp_tiles;
     DevBuf<int> d_gp_pfirst;
     DevBuf<float> d_gp_pvf;
-    DevBuf<double> d_gp_pvb, d_gp_pgam, d_gp_cs, d_gp_gen;
+    DevBuf<double> d_gp_pvb, d_gp_pgam, d_gp_cs, d_gp_l2d, d_gp_gen;
     long long gp_count = -1;
     long long gamma_piece_count();         // pieces of at most 64 positions the eigen rows fall into
     void build_gamma_pieces();

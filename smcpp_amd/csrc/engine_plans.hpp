@@ -1165,19 +1165,20 @@ void smcpp_im::enqueue_stats() {
             const int MS = 64 * NPL;
             d_gp_gen.upload(ss_gen, sg);
             d_gp_cs.alloc((size_t)Ke * 2 * Mp);
+            d_gp_l2d.alloc((size_t)Ke * Mp);
             const size_t npc = gp_pieces.size();
             d_gp_pvf.alloc(npc * Mp); d_gp_pvb.alloc(npc * Mp); d_gp_pgam.alloc(npc * Mp);
             PieceArgs pa;
             pa.M = M; pa.Mp = Mp; pa.npieces = (int)npc; pa.ntiles = (int)gp_tiles.size();
             pa.pieces = d_gp_pieces.p; pa.tiles = d_gp_tiles.p; pa.Xs = d_Xs.p; pa.Ys = d_Ys.p; pa.dsc = d_dsc.p;
-            pa.PT = d_PT.p; pa.Pinvrm = d_Pinvrm.p; pa.cs = d_gp_cs.p; pa.pvf = d_gp_pvf.p; pa.pvb = d_gp_pvb.p; pa.pgam = d_gp_pgam.p;
+            pa.PT = d_PT.p; pa.Pinvrm = d_Pinvrm.p; pa.cs = d_gp_cs.p; pa.l2d = d_gp_l2d.p; pa.pvf = d_gp_pvf.p; pa.pvb = d_gp_pvb.p; pa.pgam = d_gp_pgam.p;
             hipLaunchKernelGGL(k_piece_rowsums, dim3(ceil_div(Ke * 2 * Mp, 256)), dim3(256), 0, sg, Ke, Mp, (const double *)d_PT.p,
-                               (const double *)d_Pinvrm.p, d_gp_cs.p);
+                               (const double *)d_Pinvrm.p, d_gp_cs.p, (const double *)d_dsc.p, d_gp_l2d.p);
             if (pa.ntiles > 0) {
                 static bool once = false;
                 if (!once) { HIPCHK(hipFuncSetAttribute((const void *)k_piece_vectors, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; }
                 const size_t shm = (size_t)4 * 16 * (Mp + 4) * sizeof(double);
-                const int nblk = std::min(ceil_div(2 * pa.ntiles, 4), 2048);
+                const int nblk = std::min(2 * ceil_div(pa.ntiles, 4), 2048);
                 hipLaunchKernelGGL(k_piece_vectors, dim3(nblk), dim3(256), shm, sg, pa);
             }
             SsArgs sa = SsArgs();

@@ -133,6 +133,7 @@ struct smcpp_im {
     int ss_max_span = 0;
     int ss_nlds = 0;                       // key slots whose emission vectors live in LDS
     int ss_wpc = 1;                        // scan chains: wavefronts per SIMD (workgroups per CU) the chunk list is cut for
+    bool ss_mid = false;                   // one state per lane, 2.2 - 12 million positions: two wavefronts per SIMD + float halo (make_chunks)
     int ss_wg_waves = 4;                   // wavefronts per workgroup of k_chain_ss (hybrid with two per SIMD: 8, one table copy)
     int ss_launched = 0, last_ss_passes = 0;
     bool ss_need_cert_pass = false;     // this input's last working pass rewrites end vectors within tolerance: launch the all-skip pass up front
@@ -631,8 +632,19 @@ void smcpp_im::make_chunks() {
         // of re-run history, so only inputs whose chunks stay long (>= 9 000 positions) take them.  Whole genome (28.7 M
         // positions): 9.3 / 8.2 / 7.9 ms of chains with 1 / 2 / 3; a 3.4 M-position shard: 1.83 / 1.95 ms with 1 / 2.
         const long long simds = (long long)prop.multiProcessorCount * 4;
-        ss_wpc = opt().has(smcpp_opt::O_SS_WPC) ? std::max(1, std::min(4, opt().i(smcpp_opt::O_SS_WPC, 1)))
-                                                : (int)std::max<long long>(1, std::min<long long>(3, total_bins / (simds * 9000)));
+        // (round 6, last session) one state per lane, re-measured on single contigs of 150 ... 1 700 Mbp and a rank's shard of the genome
+        // (gpurun_out/r06_gp12 ... gp15): between 2.2 and 12 million positions TWO wavefronts per SIMD that enter their chunks through a
+        // float halo (no light passes, no fp64 part of the halo) beat one wavefront with light passes by 10 - 19 % (250 Mbp 1.66 -> 1.44 ms,
+        // 700 Mbp 2.94 -> 2.46, 1 100 Mbp 4.15 -> 3.37, the 8-GPU run's shard 1.75 -> 1.57), from 12 million on three wavefronts without a
+        // halo win (1 700 Mbp 6.01 -> 4.59; whole genome unchanged); below 2.2 million (the headline: 1 million) one wavefront stays.
+        ss_mid = false;
+        int wpc_auto = (int)std::max<long long>(1, std::min<long long>(3, total_bins / (simds * 9000)));
+        if (NPL == 1 && !ss_hybrid) {
+            const long long per_simd = total_bins / std::max<long long>(1, simds);
+            wpc_auto = per_simd >= 11700 ? 3 : per_simd >= 2200 ? 2 : 1;
+            ss_mid = wpc_auto == 2 && !opt().has(smcpp_opt::O_SS_WPC);
+        }
+        ss_wpc = opt().has(smcpp_opt::O_SS_WPC) ? std::max(1, std::min(4, opt().i(smcpp_opt::O_SS_WPC, 1))) : wpc_auto;
         // hybrid rows are bound by instruction and LDS LATENCY (a dependent chain of ~200 instructions per row): a second wavefront
         // per SIMD fills the gaps from ~2 000 cost units per chunk on (posterior workload: 1.79 -> 1.35 ms of chains; a third one
         // needs an extra pass: 1.80); the eight wavefronts form ONE workgroup so that the CU holds one copy of the tables
@@ -703,9 +715,11 @@ void smcpp_im::make_chunks() {
         // history the two light passes walk - so it only trades the merge re-run against chunks of unequal length: 0.92 ms against
         // 0.87; with several states per lane (M > 64), where a light position costs relatively more, it wins (c5: 1.45 against 1.64 ms).
         // Default: M > 64 only; SMCPP_SS_HALO = 1 / 0 forces it.
-        ss_halo = !ss_hybrid && (opt().has(smcpp_opt::O_SS_HALO) ? opt().i(smcpp_opt::O_SS_HALO, 0) != 0 : NPL >= 2);
-        const long long hlf = ss_halo ? opt().ll(smcpp_opt::O_HALO_LF, 2800) : 0, hdf = ss_halo ? opt().ll(smcpp_opt::O_HALO_DF, 800) : 0,
-                        hlb = ss_halo ? opt().ll(smcpp_opt::O_HALO_LB, 3900) : 0, hdb = ss_halo ? opt().ll(smcpp_opt::O_HALO_DB, 1100) : 0;
+        // (the mid-size regime of one state per lane, above: halo on, float part only)
+        ss_halo = !ss_hybrid && (opt().has(smcpp_opt::O_SS_HALO) ? opt().i(smcpp_opt::O_SS_HALO, 0) != 0 : (NPL >= 2 || ss_mid));
+        const bool mid_halo = ss_halo && ss_mid && NPL == 1;
+        const long long hlf = ss_halo ? opt().ll(smcpp_opt::O_HALO_LF, 2800) : 0, hdf = ss_halo ? opt().ll(smcpp_opt::O_HALO_DF, mid_halo ? 0 : 800) : 0,
+                        hlb = ss_halo ? opt().ll(smcpp_opt::O_HALO_LB, 3900) : 0, hdb = ss_halo ? opt().ll(smcpp_opt::O_HALO_DB, mid_halo ? 0 : 1100) : 0;
         {
             // the forward chain gets SMCPP_SS_FWD_SHARE of the wavefronts.  Default one half: the backward chain's light position
             // costs 38 instructions against 25, but the fp64 passes of the two directions take the same time (forward: stores, the

@@ -199,3 +199,40 @@ def test_certificate_from_flags_equals_the_launched_certificate_pass(engine_opt,
             assert sorted(da) == sorted(db)
             for k in da:
                 assert np.array_equal(da[k], db[k]), k
+
+
+def test_mid_size_contig_two_wavefronts_per_simd_and_float_halo(engine_opt):
+    """Round 6 (last session): one state per lane, 2.2 - 12 million positions - two wavefronts per SIMD that enter their chunks through a
+    float halo (engine_manager.hpp: make_chunks) instead of one wavefront with light passes.  A 250 Mbp contig (2.5 million positions,
+    589 000 rows) and a two-contig shard: the new plan against the plan of rounds 3 - 5 (SMCPP_SS_WPC=1, SMCPP_SS_HALO=0) and against
+    the SEQUENTIAL algorithm (one chunk per contig and direction: no history, no fixed point) - log-likelihood, xi sums, gamma sums."""
+    from smcpp_amd import _smcpp, synth
+    from smcpp_amd.model import PiecewiseModel
+    g = load_golden("G4_M64_n20_2Mbp")
+    a0 = np.array(g["a"], dtype=float)
+
+    def run(obs, chunk=0):
+        im = _smcpp.PyOnePopInferenceManager(20, obs, g["hs"], ("pop1",), float(g["pol"]))
+        im.theta = float(g["theta"]); im.rho = float(g["rho"]); im.alpha = float(g["alpha"])
+        if chunk:
+            im.set_chunking(chunk)
+        im.model = PiecewiseModel(a0, g["s"], 1e4, "pop1")
+        im.E_step()
+        assert im.chain_mode() == 5
+        return np.array(im.logliks()), [x.copy() for x in im.xisums], [dict(d) for d in im.gamma_sums], im.describe()["plan"]
+
+    for obs in ([synth.synth_contig(0, 250_000_000, 20)], [synth.synth_contig(1, 200_000_000, 20), synth.synth_contig(2, 90_000_000, 20)]):
+        ll, xs, gs, plan = run(obs)
+        assert plan["wavefronts_per_simd"] == 2 and plan["halo_pass"] and plan["light_passes_forward"] == 0, plan
+        seq = run(obs, chunk=10 ** 9)
+        assert seq[3]["chunks_forward"] == len(obs), seq[3]
+        engine_opt("SMCPP_SS_WPC", "1"); engine_opt("SMCPP_SS_HALO", "0")
+        old = run(obs)
+        engine_opt("SMCPP_SS_WPC", None); engine_opt("SMCPP_SS_HALO", None)
+        assert old[3]["wavefronts_per_simd"] == 1 and not old[3]["halo_pass"], old[3]
+        for name, ref in (("sequential", seq), ("rounds 3-5 plan", old)):
+            dl = np.max(np.abs(ll - ref[0]) / np.abs(ref[0]))
+            dx = max(np.max(np.abs(x - y)) / np.max(np.abs(y)) for x, y in zip(xs, ref[1]))
+            dg = max(np.max(np.abs(d[k] - e[k])) / max(np.max(np.abs(e[k])), 1e-300) for d, e in zip(gs, ref[2]) for k in e)
+            print(f"{len(obs)} contig(s), {plan['positions']} positions, new plan vs {name}: loglik {dl:.2e}, xi sums {dx:.2e}, gamma sums {dg:.2e}")
+            assert dl <= 2e-9 and dx <= 2e-6 and dg <= 2e-6

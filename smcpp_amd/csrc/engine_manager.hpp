@@ -133,7 +133,7 @@ struct smcpp_im {
     int ss_max_span = 0;
     int ss_nlds = 0;                       // key slots whose emission vectors live in LDS
     int ss_wpc = 1;                        // scan chains: wavefronts per SIMD (workgroups per CU) the chunk list is cut for
-    bool ss_mid = false;                   // one state per lane, 2.2 - 12 million positions: two wavefronts per SIMD + float halo (make_chunks)
+    bool ss_mid = false;                   // one state per lane, 1.35 - 12 million positions: float halo instead of light passes, from 1.95 million on with two wavefronts per SIMD (make_chunks)
     int ss_wg_waves = 4;                   // wavefronts per workgroup of k_chain_ss (hybrid with two per SIMD: 8, one table copy)
     int ss_launched = 0, last_ss_passes = 0;
     bool ss_need_cert_pass = false;     // this input's last working pass rewrites end vectors within tolerance: launch the all-skip pass up front
@@ -633,16 +633,19 @@ void smcpp_im::make_chunks() {
         // positions): 9.3 / 8.2 / 7.9 ms of chains with 1 / 2 / 3; a 3.4 M-position shard: 1.83 / 1.95 ms with 1 / 2.
         const long long simds = (long long)prop.multiProcessorCount * 4;
         // (round 6, last session) one state per lane, re-measured on single contigs of 150 ... 1 700 Mbp and a rank's shard of the genome
-        // (gpurun_out/r06_gp12 ... gp15): between 2.2 and 12 million positions TWO wavefronts per SIMD that enter their chunks through a
+        // (gpurun_out/r06_gp12 ... gp17): between 1.95 and 12 million positions TWO wavefronts per SIMD that enter their chunks through a
         // float halo (no light passes, no fp64 part of the halo) beat one wavefront with light passes by 10 - 19 % (250 Mbp 1.66 -> 1.44 ms,
         // 700 Mbp 2.94 -> 2.46, 1 100 Mbp 4.15 -> 3.37, the 8-GPU run's shard 1.75 -> 1.57), from 12 million on three wavefronts without a
-        // halo win (1 700 Mbp 6.01 -> 4.59; whole genome unchanged); below 2.2 million (the headline: 1 million) one wavefront stays.
+        // halo win (1 700 Mbp 6.01 -> 4.59; whole genome unchanged); below 1.35 million (the headline: 1 million) nothing changes.
         ss_mid = false;
         int wpc_auto = (int)std::max<long long>(1, std::min<long long>(3, total_bins / (simds * 9000)));
         if (NPL == 1 && !ss_hybrid) {
             const long long per_simd = total_bins / std::max<long long>(1, simds);
-            wpc_auto = per_simd >= 11700 ? 3 : per_simd >= 2200 ? 2 : 1;
-            ss_mid = wpc_auto == 2 && !opt().has(smcpp_opt::O_SS_WPC);
+            // (... and between 1.35 and 1.95 million the halo with ONE wavefront: 135 / 150 / 175 Mbp 1.19 / 1.34 / 1.52 -> 1.12 / 1.18 / 1.27 ms;
+            // at 200 Mbp the light passes hit a sweet spot - 1 + 1 of them, three launches, 1.26 ms - that the halo forms miss by 3 %:
+            // the rule stays monotone, gpurun_out/r06_gp17)
+            wpc_auto = per_simd >= 11700 ? 3 : per_simd >= 1900 ? 2 : 1;
+            ss_mid = (wpc_auto == 2 || per_simd >= 1300) && wpc_auto < 3 && !opt().has(smcpp_opt::O_SS_WPC);
         }
         ss_wpc = opt().has(smcpp_opt::O_SS_WPC) ? std::max(1, std::min(4, opt().i(smcpp_opt::O_SS_WPC, 1))) : wpc_auto;
         // hybrid rows are bound by instruction and LDS LATENCY (a dependent chain of ~200 instructions per row): a second wavefront

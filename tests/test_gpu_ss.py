@@ -202,9 +202,9 @@ def test_certificate_from_flags_equals_the_launched_certificate_pass(engine_opt,
 
 
 def test_mid_size_contig_two_wavefronts_per_simd_and_float_halo(engine_opt):
-    """Round 6 (last session): one state per lane, 2.2 - 12 million positions - two wavefronts per SIMD that enter their chunks through a
-    float halo (engine_manager.hpp: make_chunks) instead of one wavefront with light passes.  A 250 Mbp contig (2.5 million positions,
-    589 000 rows) and a two-contig shard: the new plan against the plan of rounds 3 - 5 (SMCPP_SS_WPC=1, SMCPP_SS_HALO=0) and against
+    """Round 6 (last session): one state per lane, 1.35 - 12 million positions - the chunks are entered through a float halo
+    (engine_manager.hpp: make_chunks) instead of light passes, from 1.95 million positions on by two wavefronts per SIMD.  A 150 Mbp
+    contig, a 250 Mbp contig (2.5 million positions, 589 000 rows) and a two-contig shard: the new plan against the plan of rounds 3 - 5 (SMCPP_SS_WPC=1, SMCPP_SS_HALO=0) and against
     the SEQUENTIAL algorithm (one chunk per contig and direction: no history, no fixed point) - log-likelihood, xi sums, gamma sums."""
     from smcpp_amd import _smcpp, synth
     from smcpp_amd.model import PiecewiseModel
@@ -221,9 +221,10 @@ def test_mid_size_contig_two_wavefronts_per_simd_and_float_halo(engine_opt):
         assert im.chain_mode() == 5
         return np.array(im.logliks()), [x.copy() for x in im.xisums], [dict(d) for d in im.gamma_sums], im.describe()["plan"]
 
-    for obs in ([synth.synth_contig(0, 250_000_000, 20)], [synth.synth_contig(1, 200_000_000, 20), synth.synth_contig(2, 90_000_000, 20)]):
+    for obs, wpc in (([synth.synth_contig(3, 150_000_000, 20)], 1), ([synth.synth_contig(0, 250_000_000, 20)], 2),
+                     ([synth.synth_contig(1, 200_000_000, 20), synth.synth_contig(2, 90_000_000, 20)], 2)):
         ll, xs, gs, plan = run(obs)
-        assert plan["wavefronts_per_simd"] == 2 and plan["halo_pass"] and plan["light_passes_forward"] == 0, plan
+        assert plan["wavefronts_per_simd"] == wpc and plan["halo_pass"] and plan["light_passes_forward"] == 0, plan
         seq = run(obs, chunk=10 ** 9)
         assert seq[3]["chunks_forward"] == len(obs), seq[3]
         engine_opt("SMCPP_SS_WPC", "1"); engine_opt("SMCPP_SS_HALO", "0")

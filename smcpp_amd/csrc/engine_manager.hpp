@@ -740,6 +740,10 @@ void smcpp_im::make_chunks() {
                     if (f > b) lo = m; else hi = m;
                 }
                 dflt_share = std::min(0.5, std::max(0.25, 0.5 * (lo + hi)));
+                // (one state per lane, float halo only: the stored passes of the two directions cost the same since round 5 and the task
+                // table pairs them on the SIMDs one to one - 0.30 ... 0.58 measured on 175 ... 1 100 Mbp, gpurun_out/r06_gp22 / gp23: one half
+                // is the optimum, 0 - 3 % ahead of the balance above, whose per-position costs are those of several states per lane)
+                if (mid_halo) dflt_share = 0.5;
             }
             const double share = opt().d(smcpp_opt::O_SS_FWD_SHARE, dflt_share);
             const long long nf = std::max<long long>(1, (long long)(share * (double)waves + 0.5));

@@ -30,8 +30,8 @@ static const OptDef OPT_DEFS[O_COUNT] = {
     {"SMCPP_HYB_TH",         "span above which a row is one eigen-power step (default 6)"},
     {"SMCPP_COOP_BPC",       "workgroups per CU of the cooperative chains"},
     {"SMCPP_ROWS_PER_CHUNK", "rows per chunk (0 = automatic)"},
-    {"SMCPP_SS_WPC",         "wavefronts per SIMD of the scan chains (1..4)"},
-    {"SMCPP_SS_HALO",        "1 / 0: force / forbid the halo pass of the scan chains (default: M > 64)"},
+    {"SMCPP_SS_WPC",         "wavefronts per SIMD of the scan chains (1..4; default by input size: M <= 64 two from 1.95, three from 12 million positions)"},
+    {"SMCPP_SS_HALO",        "1 / 0: force / forbid the halo pass of the scan chains (default: M > 64, and M <= 64 with 1.35 - 12 million positions)"},
     {"SMCPP_HALO_LF",        "float halo positions, forward (2800)"},
     {"SMCPP_HALO_DF",        "exact halo positions, forward (800)"},
     {"SMCPP_HALO_LB",        "float halo positions, backward (3900)"},

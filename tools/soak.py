@@ -51,4 +51,7 @@ soak("example-derived M=144 cut rows save_gamma", 144, 4, np.ascontiguousarray(g
 # (round 6, last session) un-binned rows at M = 128: per-row posteriors from eigen-power pieces + scan steps
 soak("un-binned M=128 save_gamma (eigen-power pieces)", 128, 8, np.ascontiguousarray(synth.synth_posterior_contig(20000, 8, seed=7), dtype=np.int32),
      300, True, theta=2e-4, rho=6e-5)
+# (round 6, last session) a mid-size contig: two wavefronts per SIMD through a float halo (engine_manager.hpp: make_chunks)
+soak("250 Mbp M=64 (mid-size chunk plan)", 64, 20, synth.synth_contig(0, 250_000_000, 20), 600, False)
+soak("250 Mbp M=64 save_gamma (mid-size chunk plan)", 64, 20, synth.synth_contig(0, 250_000_000, 20), 200, True)
 print("soak ok")

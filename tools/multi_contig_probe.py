@@ -9,7 +9,8 @@ M, n = 64, 20
 hs = synth.hidden_states(M); a, s = synth.model_pieces()
 _smcpp.set_num_threads(12)
 m = PiecewiseModel(a, s, 1e4, "pop1")
-for name, lens in (("10 x 20 Mbp", [20] * 10), ("22 x 10 Mbp", [10] * 22), ("6 x 60 Mbp", [60] * 6), ("40 x 15 Mbp", [15] * 40), ("3 x 150 Mbp", [150] * 3)):
+for name, lens in (("10 x 20 Mbp", [20] * 10), ("22 x 10 Mbp", [10] * 22), ("6 x 60 Mbp", [60] * 6), ("40 x 15 Mbp", [15] * 40), ("3 x 150 Mbp", [150] * 3),
+                   ("300 x 1 Mbp", [1] * 300), ("1500 x 0.2 Mbp", [0.2] * 1500), ("1 x 120 + 60 x 1 Mbp", [120] + [1] * 60)):
     contigs = [synth.synth_contig(i, int(L * 1e6), n) for i, L in enumerate(lens)]
     res = {}
     for mode in ("new", "old"):

@@ -338,3 +338,38 @@ def test_beyond_256_states_unbuilt_paths_fail_loudly():
         im.E_step()
     with pytest.raises(RuntimeError, match="1024"):
         _manager(1100, n, obs)
+
+
+def test_posterior_product_at_128_states_on_reference_test_contig():
+    """`smc++ posterior` (smcpp_amd.posterior.posterior) with 128 hidden states on the reference's own un-binned test contig
+    (test/bugs/11/chr11_5subjs.smc.gz, fixture G7: 810 rows, one of 134 million positions): dense streamed chains, per-row posteriors from
+    eigen-power pieces (2.1 million pieces, most of them deep inside one row where only the leading eigen-mode survives).  Against the C
+    restatement (one eigen-power step per row, the reference's form): every normalised column, the decoded path."""
+    from oracle import oracle
+    from conftest import load_golden
+    from smcpp_amd.model import PiecewiseModel
+    from smcpp_amd.posterior import posterior
+    g = load_golden("G7_M32_n8_chr11")
+    m = PiecewiseModel(g["a"], g["s"], 1e4, "pop1")
+    M = 128
+    hs, gammas, sites, paths, im = posterior(m, [g["obs"][1:]], M, int(g["n"]), float(g["theta"]), float(g["rho"]), float(g["alpha"]),
+                                             float(g["pol"]), return_manager=True)
+    plan = im.describe()["plan"]
+    assert plan["per_row_gamma"] == "eigen-power pieces + scan steps" and not plan["long_rows_cut"], plan
+    obs = np.ascontiguousarray(g["obs"], dtype=np.int32)
+    assert np.array_equal(sites[0], obs[:, 0]) and len(hs) == M + 1
+    keys = im.keys
+    ep = im.emission_probs
+    Etab = np.array([ep[tuple(k)] for k in keys.tolist()])
+    o = oracle.estep(im.pi, im.transition, keys, Etab, obs, save_gamma=True)
+    ll = im.loglik()
+    assert abs(ll - o["loglik"]) <= LL_TOL * abs(o["loglik"]), (ll, o["loglik"])
+    ref = o["gamma"] / o["gamma"].sum(axis=0, keepdims=True)
+    assert gammas[0].shape == ref.shape == (M, len(obs) + 1)
+    err = np.max(np.abs(gammas[0] - ref), axis=0)
+    print(f"posterior at M = {M} on the reference's test contig: loglik rel {abs(ll - o['loglik']) / abs(o['loglik']):.2e}, worst normalised column {err.max():.2e} "
+          f"(column {int(err.argmax())}, span {int(np.concatenate([[1], obs[:, 0]])[err.argmax()])})")
+    assert err.max() <= 1e-5
+    top2 = np.sort(ref, axis=0)[-2:]
+    strong = (top2[1] - top2[0]) > 1e-5
+    assert not np.any(strong & (np.asarray(paths[0]) != ref.argmax(axis=0)))
